@@ -1,0 +1,285 @@
+#!/usr/bin/env python3
+"""Generate the committed golden vectors under tests/golden/.
+
+Runs ONLY in the build container: it imports the reference's own Python from
+/root/reference (with empty stand-ins for the third-party packages that are not
+installed: mmcv, cv2, skimage, pycocotools, and for the reference's compiled
+CUDA ops) and records inputs + the reference's outputs as small .npz files.
+Nothing from the reference travels: the fixtures hold numbers only.
+
+Vectors written (each is {inputs..., expected...}):
+  nms3d.npz        mmdet/core/evaluation/coco_utils.py:245-282 nms_3d_python
+                   (the reference's only CPU NMS3D; true 3D IoU, keep iff iou <= thr)
+  iou3d.npz        mmdet/core/bbox/geometry.py:49-60 bbox_overlaps (6-col branch)
+                   + the known answers of bbox_overlaps_test :81-101
+  codec.npz        mmdet/core/bbox/transforms.py:34-65,105-160,220-239
+  anchors.npz      mmdet/core/anchor/anchor_generator_3d.py:6-92
+  roi_levels.npz   mmdet/models/roi_extractors/single_level.py:58-82
+  backbone_fpn.npz mmdet/models/backbones/resnet3d.py + necks/fpn3d.py forward/backward
+                   with a closed-form weight fill (tests/golden/weightfill.py)
+
+usage: python tests/golden/make_golden.py   (from the repo root)
+"""
+import ast
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = '/root/reference'
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from weightfill import fill_module_closed_form, cotangent_like, volume_like  # noqa: E402
+
+
+def _pkg(name, path):
+    m = types.ModuleType(name)
+    m.__path__ = [path]
+    sys.modules[name] = m
+    return m
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def import_reference():
+    import torch.nn as nn
+
+    def constant_init(module, val, bias=0):
+        nn.init.constant_(module.weight, val)
+        if hasattr(module, 'bias') and module.bias is not None:
+            nn.init.constant_(module.bias, bias)
+
+    def kaiming_init(module, mode='fan_out', nonlinearity='relu', bias=0, distribution='normal'):
+        if distribution == 'uniform':
+            nn.init.kaiming_uniform_(module.weight, mode=mode, nonlinearity=nonlinearity)
+        else:
+            nn.init.kaiming_normal_(module.weight, mode=mode, nonlinearity=nonlinearity)
+        if hasattr(module, 'bias') and module.bias is not None:
+            nn.init.constant_(module.bias, bias)
+
+    def xavier_init(module, gain=1, bias=0, distribution='normal'):
+        if distribution == 'uniform':
+            nn.init.xavier_uniform_(module.weight, gain=gain)
+        else:
+            nn.init.xavier_normal_(module.weight, gain=gain)
+        if hasattr(module, 'bias') and module.bias is not None:
+            nn.init.constant_(module.bias, bias)
+
+    def normal_init(module, mean=0, std=1, bias=0):
+        nn.init.normal_(module.weight, mean, std)
+        if hasattr(module, 'bias') and module.bias is not None:
+            nn.init.constant_(module.bias, bias)
+
+    _pkg('mmdet', f'{REF}/mmdet')
+    _pkg('mmdet.models', f'{REF}/mmdet/models')
+    for sub in ('backbones', 'necks', 'roi_extractors'):
+        _pkg(f'mmdet.models.{sub}', f'{REF}/mmdet/models/{sub}')
+    _stub('mmcv')
+    _stub('mmcv.runner', load_checkpoint=None)
+    _stub('mmcv.cnn', constant_init=constant_init, kaiming_init=kaiming_init,
+          xavier_init=xavier_init, normal_init=normal_init)
+    _stub('mmdet.ops', DeformConv=None, ModulatedDeformConv=None, nms=None)
+    for n in ('cv2', 'skimage', 'skimage.transform', 'pycocotools', 'pycocotools.mask'):
+        _stub(n)
+    _pkg('mmdet.core', f'{REF}/mmdet/core')
+    _pkg('mmdet.core.bbox', f'{REF}/mmdet/core/bbox')
+    _pkg('mmdet.core.anchor', f'{REF}/mmdet/core/anchor')
+    ref = types.SimpleNamespace()
+    ref.tr = importlib.import_module('mmdet.core.bbox.transforms')
+    ref.geo = importlib.import_module('mmdet.core.bbox.geometry')
+    ref.ag = importlib.import_module('mmdet.core.anchor.anchor_generator_3d')
+    ref.ResNet3D = importlib.import_module('mmdet.models.backbones.resnet3d').ResNet3D
+    ref.FPN3D = importlib.import_module('mmdet.models.necks.fpn3d').FPN3D
+    ref.SingleRoIExtractor = importlib.import_module('mmdet.models.roi_extractors.single_level').SingleRoIExtractor
+    # coco_utils imports pycocotools/tqdm/mmcv at module level: pull the one function out by AST
+    src = open(f'{REF}/mmdet/core/evaluation/coco_utils.py').read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == 'nms_3d_python'][0]
+    ns = {'np': np}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), 'coco_utils.nms_3d_python', 'exec'), ns)
+    ref.nms_3d_python = ns['nms_3d_python']
+    return ref
+
+
+# ----------------------------------------------------------------------------------------------
+def rand_boxes(rng, n, vol=(512, 512, 80), size_xy=(6, 60), size_z=(3, 20), cluster=0):
+    """[n,6] fp32 boxes x1,y1,x2,y2,z1,z2 (inclusive).  cluster>0: boxes jittered around
+    `cluster` centres so that many pairs overlap above typical thresholds."""
+    W, H, D = vol
+    if cluster:
+        cid = rng.integers(0, cluster, n)
+        ctr = rng.uniform([20, 20, 5], [W - 20, H - 20, D - 5], size=(cluster, 3))
+        csz = np.concatenate([rng.uniform(*size_xy, size=(cluster, 2)), rng.uniform(*size_z, size=(cluster, 1))], 1)
+        ctr = ctr[cid] + rng.normal(0, 0.08, size=(n, 3)) * csz[cid]
+        sz3 = csz[cid] * (1.0 + rng.normal(0, 0.08, size=(n, 3)))
+        sxy, sz = sz3[:, :2], sz3[:, 2:]
+    else:
+        ctr = rng.uniform([0, 0, 0], [W, H, D], size=(n, 3))
+        sxy = rng.uniform(*size_xy, size=(n, 2))
+        sz = rng.uniform(*size_z, size=(n, 1))
+    half = np.concatenate([sxy, sz], 1) / 2
+    lo, hi = ctr - half, ctr + half
+    b = np.stack([lo[:, 0], lo[:, 1], hi[:, 0], hi[:, 1], lo[:, 2], hi[:, 2]], 1)
+    return b.astype(np.float32)
+
+
+def iou_matrix_f64(b):
+    b = b.astype(np.float64)
+    x1, y1, x2, y2, z1, z2 = [b[:, i] for i in range(6)]
+    w = np.clip(np.minimum(x2[:, None], x2) - np.maximum(x1[:, None], x1) + 1, 0, None)
+    h = np.clip(np.minimum(y2[:, None], y2) - np.maximum(y1[:, None], y1) + 1, 0, None)
+    d = np.clip(np.minimum(z2[:, None], z2) - np.maximum(z1[:, None], z1) + 1, 0, None)
+    inter = w * h * d
+    a = (x2 - x1 + 1) * (y2 - y1 + 1) * (z2 - z1 + 1)
+    return inter / (a[:, None] + a - inter)
+
+
+def make_nms(ref, out):
+    rng = np.random.default_rng(20260101)
+    cases = {}
+    specs = [(1, 0.7, 0), (2, 0.5, 1), (7, 0.3, 2), (63, 0.7, 6), (64, 0.7, 6), (65, 0.5, 6),
+             (128, 0.7, 10), (200, 0.1, 20), (333, 0.5, 25), (500, 0.7, 30), (1000, 0.7, 60),
+             (2000, 0.7, 150), (2000, 0.5, 0), (4000, 0.5, 300)]
+    for k, (n, thr, cl) in enumerate(specs):
+        for attempt in range(100):
+            boxes = rand_boxes(rng, n, cluster=cl)
+            scores = rng.permutation(n).astype(np.float32) / np.float32(n) + np.float32(0.5 / n)  # distinct
+            iou = iou_matrix_f64(boxes)
+            if np.abs(iou - thr).min() > 1e-5:   # no pair within fp32 noise of the threshold
+                break
+        else:
+            raise RuntimeError('could not draw a threshold-safe case')
+        dets = np.concatenate([boxes, scores[:, None]], 1).astype(np.float32)
+        kept = ref.nms_3d_python(np.arange(n), dets, thr)      # reference call; fp32 numpy arithmetic
+        keep = np.sort(np.asarray(kept, dtype=np.int64))         # nms_kernel.cu:253-256 returns ascending indices
+        cases[f'dets_{k}'] = dets
+        cases[f'thr_{k}'] = np.float32(thr)
+        cases[f'keep_{k}'] = keep
+        print(f'  nms case {k}: n={n} thr={thr} kept={len(keep)}')
+    cases['num_cases'] = np.int64(len(specs))
+    np.savez_compressed(out, **cases)
+
+
+def make_iou(ref, out):
+    rng = np.random.default_rng(7)
+    a = rand_boxes(rng, 37, cluster=5)
+    b = rand_boxes(rng, 53, cluster=5)
+    iou = ref.geo.bbox_overlaps(torch.from_numpy(a), torch.from_numpy(b)).numpy()
+    ka1 = np.array([[2, 3, 4, 6, 3, 4], [39, 63, 203, 112, 4, 5], [49, 75, 203, 125, 4, 5], [31, 69, 201, 125, 4, 5]], np.float32)
+    ka2 = np.array([[2, 3, 4, 6, 3, 4], [54, 66, 198, 114, 4, 5], [42, 78, 186, 126, 4, 5], [18, 63, 235, 135, 4, 5]], np.float32)
+    ref.geo.bbox_overlaps_test()   # the reference's own known-answer test must pass here
+    ka = np.array([ref.geo.bbox_overlaps(torch.from_numpy(ka1[i:i + 1]), torch.from_numpy(ka2[i:i + 1]))[0, 0].item()
+                   for i in range(4)], np.float64)
+    assert [round(v, 4) for v in ka] == [1.0, 0.798, 0.7899, 0.6125]
+    np.savez_compressed(out, a=a, b=b, iou=iou.astype(np.float32), ka1=ka1, ka2=ka2, ka=ka.astype(np.float32),
+                        ka_rounded=np.array([1.0, 0.798, 0.7899, 0.6125]))
+
+
+def make_codec(ref, out):
+    rng = np.random.default_rng(11)
+    n = 257
+    rois = rand_boxes(rng, n)
+    deltas = rng.normal(0, 0.6, size=(n, 6)).astype(np.float32)
+    deltas[:5] *= 20  # exercise the +-4.135 clamp on dw,dh,dz,dd
+    means = [0., 0., 0., 0., 0., 0.]
+    stds = [0.1, 0.1, 0.2, 0.2, 0.1, 0.1]
+    max_shape = (512, 512, 3, 80)
+    dec_rpn = ref.tr.delta2bbox3D(torch.from_numpy(rois), torch.from_numpy(deltas), [0.] * 6, [1.] * 6, max_shape).numpy()
+    dec_rcnn = ref.tr.delta2bbox3D(torch.from_numpy(rois), torch.from_numpy(deltas), means, stds, max_shape).numpy()
+    dec_noclip = ref.tr.delta2bbox3D(torch.from_numpy(rois), torch.from_numpy(deltas), means, stds, None).numpy()
+    deltas12 = rng.normal(0, 0.5, size=(n, 12)).astype(np.float32)   # 2 classes x 6 (reg_class_agnostic=False)
+    dec12 = ref.tr.delta2bbox3D(torch.from_numpy(rois), torch.from_numpy(deltas12), means, stds, max_shape).numpy()
+    gt = rand_boxes(rng, n)
+    enc = ref.tr.bbox2delta3d(torch.from_numpy(rois), torch.from_numpy(gt), means, stds).numpy()
+    roi_list = [torch.from_numpy(rois[:100]), torch.from_numpy(rois[100:100]), torch.from_numpy(rois[100:])]
+    r7 = ref.tr.bbox2roi3D(roi_list).numpy()
+    np.savez_compressed(out, rois=rois, deltas=deltas, deltas12=deltas12, gt=gt, means=np.array(means, np.float32),
+                        stds=np.array(stds, np.float32), max_shape=np.array(max_shape), dec_rpn=dec_rpn,
+                        dec_rcnn=dec_rcnn, dec_noclip=dec_noclip, dec12=dec12, enc=enc, rois7=r7,
+                        split=np.array([100, 0, n - 100]))
+
+
+def make_anchors(ref, out):
+    d = {}
+    # configs/3d-multi-resolution-rcnn.py:20-24 (rpn_head) and :32-36 (rpn_head_2)
+    strides, dstrides = [4, 8, 16, 32, 64], [2, 4, 8, 16, 32]
+    for tag, scale in (('s2', 2), ('s3', 3)):
+        for lv, (s, ds) in enumerate(zip(strides, dstrides)):
+            g = ref.ag.AnchorGenerator3D(s, [scale], [scale], [1.0], ds)
+            d[f'base_{tag}_{lv}'] = g.base_anchors.numpy()
+    g = ref.ag.AnchorGenerator3D(4, [2], [2], [1.0], 2)
+    assert g.base_anchors.tolist() == [[-2, -2, 5, 5, -1, 2]]
+    fs = (3, 5, 4)   # (feat_z, feat_h, feat_w)
+    d['grid_fs'] = np.array(fs)
+    d['grid'] = g.grid_anchors(fs, 4, 2, device='cpu').numpy()
+    d['valid'] = g.valid_flags(fs, (2, 4, 3), device='cpu').numpy()
+    d['valid_size'] = np.array((2, 4, 3))
+    np.savez_compressed(out, **d)
+
+
+def make_roi_levels(ref, out):
+    rng = np.random.default_rng(5)
+    n = 400
+    boxes = rand_boxes(rng, n, size_xy=(2, 300), size_z=(1, 60))
+    rois = np.concatenate([np.zeros((n, 1), np.float32), boxes], 1)
+    ext = ref.SingleRoIExtractor.__new__(ref.SingleRoIExtractor)
+    ext.finest_scale = 56
+    lv = ref.SingleRoIExtractor.map_roi_levels(ext, torch.from_numpy(rois), 4).numpy()
+    np.savez_compressed(out, rois=rois, levels=lv.astype(np.int64), finest_scale=np.int64(56), num_levels=np.int64(4))
+
+
+def make_backbone(ref, out):
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    bb = ref.ResNet3D(depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=-1, style='pytorch')
+    fpn = ref.FPN3D(in_channels=[64, 128, 256, 512], out_channels=64, num_outs=5)
+    fill_module_closed_form(bb, 1)
+    fill_module_closed_form(fpn, 2)
+    bb.train()      # norm_eval=True keeps BN in eval mode (resnet3d.py:480-486)
+    fpn.train()
+    d = {}
+    for tag, shape in (('a', (1, 3, 8, 32, 32)), ('b', (1, 3, 16, 64, 64))):
+        x = volume_like(shape)
+        bb.zero_grad(); fpn.zero_grad()
+        c = bb(x)
+        p = fpn(c)
+        loss = sum((o * cotangent_like(o.shape, i)).sum() for i, o in enumerate(p))
+        loss.backward()
+        for i, o in enumerate(c):
+            d[f'{tag}_c{i}'] = o.detach().numpy()
+        for i, o in enumerate(p):
+            d[f'{tag}_p{i}'] = o.detach().numpy()
+        names, norms = [], []
+        for pref, m in (('backbone.', bb), ('neck.', fpn)):
+            for k, v in m.named_parameters():
+                names.append(pref + k)
+                norms.append(float(v.grad.double().norm()))
+        d[f'{tag}_grad_names'] = np.array(names)
+        d[f'{tag}_grad_norms'] = np.array(norms)
+        for k in ('conv1.weight', 'bn3d1.weight', 'bn3d1.bias', 'layer1.0.conv2.weight', 'layer1.0.bn3d3.weight',
+                  'layer2.0.downsample.0.weight', 'layer4.2.conv3.weight', 'layer3.1.bn3d2.bias'):
+            d[f'{tag}_g_backbone.{k}'] = dict(bb.named_parameters())[k].grad.numpy().copy()
+        for k in ('lateral_convs.0.conv.weight', 'lateral_convs.3.conv.bias', 'fpn_convs.0.conv.weight', 'fpn_convs.2.conv.bias'):
+            d[f'{tag}_g_neck.{k}'] = dict(fpn.named_parameters())[k].grad.numpy().copy()
+        d[f'{tag}_loss'] = np.float64(loss.item())
+        print(f'  backbone case {tag}: shape={shape} loss={loss.item():.6f}')
+    np.savez_compressed(out, **d)
+
+
+if __name__ == '__main__':
+    ref = import_reference()
+    which = sys.argv[1:] or ['nms', 'iou', 'codec', 'anchors', 'roi_levels', 'backbone']
+    if 'nms' in which: make_nms(ref, f'{HERE}/nms3d.npz')
+    if 'iou' in which: make_iou(ref, f'{HERE}/iou3d.npz')
+    if 'codec' in which: make_codec(ref, f'{HERE}/codec.npz')
+    if 'anchors' in which: make_anchors(ref, f'{HERE}/anchors.npz')
+    if 'roi_levels' in which: make_roi_levels(ref, f'{HERE}/roi_levels.npz')
+    if 'backbone' in which: make_backbone(ref, f'{HERE}/backbone_fpn.npz')
+    print('golden vectors written to', HERE)
