@@ -1,0 +1,127 @@
+"""ctypes binding of libmr3d_hip.so (C ABI: include/mr3d.h).
+
+The product path has NO fallback: if the library is missing or a call fails, an exception is
+raised.  PyTorch is used for device memory and streams only.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_PKG, 'libmr3d_hip.so')
+_CSRC = os.path.join(_PKG, 'csrc')
+_lib = None
+
+OK = 0
+LAYOUT_NCDHW = 0
+LAYOUT_NDHWC = 1
+ROIALIGN_BUG_COMPAT = 1
+
+
+class Mr3dError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile every HIP source for gfx950 into libmr3d_hip.so (hipcc cross-compiles without a GPU)."""
+    cmd = ['make', '-C', _CSRC, '-j', str(min(8, os.cpu_count() or 1))]
+    subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            raise Mr3dError(
+                f'{_SO} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                f'(or `make -C {_CSRC}`). There is no CPU fallback for the HIP hot path.')
+        L = ctypes.CDLL(_SO)
+        L.mr3d_version.restype = ctypes.c_char_p
+        L.mr3d_status_string.restype = ctypes.c_char_p
+        L.mr3d_status_string.argtypes = [ctypes.c_int]
+        L.mr3d_nms3d_workspace_bytes.restype = ctypes.c_size_t
+        L.mr3d_nms3d_workspace_bytes.argtypes = [ctypes.c_int]
+        _lib = L
+    return _lib
+
+
+def check(status, what):
+    if status != OK:
+        raise Mr3dError(f'{what}: {lib().mr3d_status_string(int(status)).decode()} (status {status})')
+
+
+def stream_ptr(device=None):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def feature_layout(t):
+    """NCDHW-contiguous or channels_last_3d; anything else is an error (the reference demands
+    contiguous inputs: mmdet/ops/roi_align/src/roi_align_cuda.cpp:34-39)."""
+    if t.is_contiguous():
+        return LAYOUT_NCDHW
+    if t.dim() == 5 and t.is_contiguous(memory_format=torch.channels_last_3d):
+        return LAYOUT_NDHWC
+    raise RuntimeError('features must be contiguous (NCDHW) or channels_last_3d')
+
+
+# --------------------------------------------------------------------------------------------
+def nms3d(dets, iou_threshold):
+    """dets: [n,7] fp32 device tensor (any row stride) -> int64 tensor of kept ORIGINAL indices, ascending.
+    (nms_cuda.nms_3d, mmdet/ops/nms/src/nms_cuda.cpp:16-21)"""
+    if not dets.is_cuda:
+        raise RuntimeError('dets must be a CUDAtensor ')          # CHECK_CUDA, nms_cuda.cpp:4
+    if dets.dim() != 2 or dets.size(1) != 7:
+        raise RuntimeError('nms_3d expects dets of shape [n, 7]')
+    if dets.dtype != torch.float32:
+        raise RuntimeError('nms_3d expects float32 dets')         # nms_kernel.cu:197,207
+    n = dets.size(0)
+    if n == 0:
+        return torch.empty((0,), dtype=torch.long, device=dets.device)
+    if dets.stride(1) != 1:
+        dets = dets.contiguous()
+    L = lib()
+    with torch.cuda.device(dets.device):
+        ws_bytes = int(L.mr3d_nms3d_workspace_bytes(n))
+        ws = torch.empty((ws_bytes + 256,), dtype=torch.uint8, device=dets.device)
+        off = (-ws.data_ptr()) % 256
+        keep = torch.empty((n,), dtype=torch.long, device=dets.device)
+        num = torch.empty((1,), dtype=torch.int32, device=dets.device)
+        st = L.mr3d_nms3d(ptr(dets), ctypes.c_int(n), ctypes.c_int(dets.stride(0)), ctypes.c_float(iou_threshold),
+                          ptr(keep), ptr(num), ctypes.c_void_p(ws.data_ptr() + off), ctypes.c_size_t(ws_bytes),
+                          stream_ptr(dets.device))
+        check(st, 'mr3d_nms3d')
+        k = int(num.item())      # the only host sync: 4 bytes (the reference copies the whole bit-matrix)
+    return keep[:k]
+
+
+def roi_align3d_forward(features, rois, out_d, out_h, out_w, spatial_scale, spatial_scale_depth, sample_num, output):
+    layout = feature_layout(features)
+    N, C, D, H, W = features.shape
+    with torch.cuda.device(features.device):
+        st = lib().mr3d_roi_align3d_forward(
+            ptr(features), ptr(rois), ctypes.c_int(rois.size(0)), ctypes.c_int(N), ctypes.c_int(C), ctypes.c_int(D),
+            ctypes.c_int(H), ctypes.c_int(W), ctypes.c_int(out_d), ctypes.c_int(out_h), ctypes.c_int(out_w),
+            ctypes.c_float(spatial_scale), ctypes.c_float(spatial_scale_depth), ctypes.c_int(sample_num),
+            ctypes.c_int(layout), ptr(output), stream_ptr(features.device))
+    check(st, 'mr3d_roi_align3d_forward')
+
+
+def roi_align3d_backward(top_grad, rois, out_d, out_h, out_w, spatial_scale, spatial_scale_depth, sample_num,
+                         bottom_grad, bug_compat=True):
+    layout = feature_layout(bottom_grad)
+    N, C, D, H, W = bottom_grad.shape
+    with torch.cuda.device(bottom_grad.device):
+        st = lib().mr3d_roi_align3d_backward(
+            ptr(top_grad), ptr(rois), ctypes.c_int(rois.size(0)), ctypes.c_int(N), ctypes.c_int(C), ctypes.c_int(D),
+            ctypes.c_int(H), ctypes.c_int(W), ctypes.c_int(out_d), ctypes.c_int(out_h), ctypes.c_int(out_w),
+            ctypes.c_float(spatial_scale), ctypes.c_float(spatial_scale_depth), ctypes.c_int(sample_num),
+            ctypes.c_int(layout), ctypes.c_int(ROIALIGN_BUG_COMPAT if bug_compat else 0), ptr(bottom_grad),
+            stream_ptr(bottom_grad.device))
+    check(st, 'mr3d_roi_align3d_backward')

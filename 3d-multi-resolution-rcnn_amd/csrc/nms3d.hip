@@ -1,0 +1,259 @@
+// NMS3D for gfx950: score sort, 64x64 IoU bit-matrix, greedy sweep and index
+// compaction, all on the device (no D2H mask copy, no host loop).
+//
+// Semantics follow the reference's nms_cuda_3d (mmdet/ops/nms/src/nms_kernel.cu:196-257):
+//   sort by score descending (:199-201) -> bit (i,j) = IoU3D(i,j) > thr, strict (:122)
+//   -> greedy sweep in sorted order (:237-249) -> original indices, ascending (:253-256).
+// The IoU arithmetic is devIoU3d's fp32 op order (:23-33) and must stay bit-exact:
+// this file is compiled with -ffp-contract=off and IEEE fp32 division.
+//
+// A CDNA wavefront is 64 lanes, so one wave owns one 64-bit row word of the bit-matrix
+// and lane == bit position; the sweep resolves one 64-box block at a time with scalar
+// (SGPR) bit tricks and v_readlane instead of a 64k-iteration host loop.
+#include "mr3d_common.h"
+
+namespace {
+
+constexpr int kSortLdsMax = 4096;   // boxes sorted inside one workgroup's LDS (32 KiB of keys)
+constexpr int kSortThreads = 1024;
+
+// (score desc, index asc) as one ascending u64 key
+__device__ __forceinline__ uint64_t make_key(float s, int idx) {
+  uint32_t u = __float_as_uint(s);
+  if (u == 0x80000000u) u = 0u;                       // -0.0 compares equal to +0.0
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);     // order-preserving float -> uint
+  u = ~u;                                             // descending score
+  return ((uint64_t)u << 32) | (uint32_t)idx;
+}
+
+// sorted box record: {x1,y1,x2,y2} {z1,z2,volume,0}.  volume = (x2-x1+1)*(y2-y1+1)*(z2-z1+1)
+// evaluated exactly like Sa/Sb in devIoU3d, so hoisting it out of the pair loop is bit-neutral.
+__device__ __forceinline__ void store_box(const float *dets, int stride, int src, float4 *boxes, int dst) {
+  const float *p = dets + (size_t)src * stride;
+  float x1 = p[0], y1 = p[1], x2 = p[2], y2 = p[3], z1 = p[4], z2 = p[5];
+  float vol = (x2 - x1 + 1) * (y2 - y1 + 1) * (z2 - z1 + 1);
+  boxes[2 * dst] = make_float4(x1, y1, x2, y2);
+  boxes[2 * dst + 1] = make_float4(z1, z2, vol, 0.f);
+}
+
+// ---- sort, n <= kSortLdsMax: one workgroup, bitonic network in LDS -------------------
+__global__ __launch_bounds__(kSortThreads) void nms3d_sort_lds_kernel(const float *__restrict__ dets, int n, int stride,
+                                                                     int np2, int *__restrict__ order,
+                                                                     float4 *__restrict__ boxes) {
+  __shared__ uint64_t keys[kSortLdsMax];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < np2; i += kSortThreads)
+    keys[i] = (i < n) ? make_key(dets[(size_t)i * stride + 6], i) : ~0ull;
+  __syncthreads();
+  for (int k = 2; k <= np2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < np2; i += kSortThreads) {
+        int p = i ^ j;
+        if (p > i) {
+          uint64_t a = keys[i], b = keys[p];
+          bool up = (i & k) == 0;
+          if ((a > b) == up) { keys[i] = b; keys[p] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < n; i += kSortThreads) {
+    int src = (int)(uint32_t)keys[i];
+    order[i] = src;
+    store_box(dets, stride, src, boxes, i);
+  }
+}
+
+// ---- sort, n > kSortLdsMax: bitonic network over global memory (rare path) -----------
+__global__ void nms3d_keys_init_kernel(const float *__restrict__ dets, int n, int stride, int np2,
+                                       uint64_t *__restrict__ keys) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < np2) keys[i] = (i < n) ? make_key(dets[(size_t)i * stride + 6], i) : ~0ull;
+}
+
+__global__ void nms3d_bitonic_step_kernel(uint64_t *__restrict__ keys, int np2, int j, int k) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= np2) return;
+  int p = i ^ j;
+  if (p > i) {
+    uint64_t a = keys[i], b = keys[p];
+    bool up = (i & k) == 0;
+    if ((a > b) == up) { keys[i] = b; keys[p] = a; }
+  }
+}
+
+__global__ void nms3d_gather_kernel(const float *__restrict__ dets, int n, int stride,
+                                    const uint64_t *__restrict__ keys, int *__restrict__ order,
+                                    float4 *__restrict__ boxes) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int src = (int)(uint32_t)keys[i];
+  order[i] = src;
+  store_box(dets, stride, src, boxes, i);
+}
+
+// ---- 64x64 suppression words; one wave per (row block, col block), upper triangle only ---
+// (the reference also fills the blocks below the diagonal, nms_kernel.cu:86, but its sweep
+//  never reads them: `for (j = nblock; ...)`, :244)
+__global__ __launch_bounds__(MR3D_WAVE) void nms3d_mask_kernel(const float4 *__restrict__ boxes, int n, int cb,
+                                                              float thr, uint64_t *__restrict__ mask) {
+  const int c = blockIdx.x, r = blockIdx.y;
+  if (c < r) return;
+  __shared__ float4 cbx[2 * MR3D_WAVE];
+  const int lane = threadIdx.x;
+  const int cidx = c * 64 + lane;
+  if (cidx < n) {
+    cbx[2 * lane] = boxes[2 * cidx];
+    cbx[2 * lane + 1] = boxes[2 * cidx + 1];
+  }
+  __syncthreads();
+  const int ridx = r * 64 + lane;
+  if (ridx >= n) return;
+  const float4 a0 = boxes[2 * ridx], a1 = boxes[2 * ridx + 1];
+  const int csz = min(n - c * 64, 64);
+  const int start = (r == c) ? lane + 1 : 0;
+  uint64_t t = 0;
+  for (int i = 0; i < csz; ++i) {
+    const float4 b0 = cbx[2 * i], b1 = cbx[2 * i + 1];
+    float left = fmaxf(a0.x, b0.x), right = fminf(a0.z, b0.z);
+    float top = fmaxf(a0.y, b0.y), bottom = fminf(a0.w, b0.w);
+    float front = fmaxf(a1.x, b1.x), back = fminf(a1.y, b1.y);
+    float width = fmaxf(right - left + 1, 0.f), height = fmaxf(bottom - top + 1, 0.f);
+    float depth = fmaxf(back - front + 1, 0.f);
+    float interS = width * height * depth;
+    float iou = interS / (a1.z + b1.z - interS);
+    if (i >= start && iou > thr) t |= 1ull << i;
+  }
+  mask[(size_t)ridx * cb + c] = t;
+}
+
+// ---- greedy sweep + compaction: one workgroup ---------------------------------------------
+// LDS: remv[cb] (suppressed bits per sorted block), flags[cb] (kept bits in ORIGINAL index space).
+constexpr int kSweepThreads = 256;
+constexpr int kRowsPerItem = 8;     // mask rows OR-ed by one thread per work item
+
+__global__ __launch_bounds__(kSweepThreads) void nms3d_sweep_kernel(const uint64_t *__restrict__ mask,
+                                                                   const int *__restrict__ order, int n, int cb,
+                                                                   int64_t *__restrict__ keep_out,
+                                                                   int32_t *__restrict__ num_keep) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t sm[];
+  uint64_t *remv = sm;
+  uint64_t *flags = sm + cb;
+  uint64_t *bcast = sm + 2 * cb;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < 2 * cb + 1; i += kSweepThreads) sm[i] = 0;
+  __syncthreads();
+
+  for (int b = 0; b < cb; ++b) {
+    if (wave == 0) {
+      const int row = b * 64 + lane;
+      const uint64_t diag = (row < n) ? mask[(size_t)row * cb + b] : 0ull;
+      const int rows = min(64, n - b * 64);
+      const uint64_t valid = (rows == 64) ? ~0ull : ((1ull << rows) - 1ull);
+      uint64_t avail = mr3d_uniform64(~remv[b] & valid);   // wave-uniform: lives in SGPRs
+      uint64_t kept = 0;
+      while (avail) {
+        const int t = __builtin_ctzll(avail);
+        kept |= 1ull << t;
+        avail &= ~mr3d_readlane64(diag, t);
+        avail &= ~(1ull << t);
+      }
+      if (lane == 0) *bcast = kept;
+      if ((kept >> lane) & 1ull) {
+        const int oi = order[row];
+        atomicOr((unsigned int *)flags + (oi >> 5), 1u << (oi & 31));
+      }
+    }
+    __syncthreads();
+    const uint64_t kept = *bcast;
+    // remv[w] |= OR_{t in kept} mask[b*64+t][w] for every later block w.
+    // work item = (word w, group of kRowsPerItem rows); loads are unconditional (a dropped row
+    // re-reads row 0 of the block, an L1 hit) so the compiler can keep all of them in flight.
+    const int later = cb - (b + 1);
+    const int items = later * (64 / kRowsPerItem);
+    for (int it = tid; it < items; it += kSweepThreads) {
+      const int w = b + 1 + it % later;
+      const int g = it / later;
+      uint64_t acc = 0;
+#pragma unroll
+      for (int q = 0; q < kRowsPerItem; ++q) {
+        const int t = g * kRowsPerItem + q;
+        const bool on = (kept >> t) & 1ull;           // kept bits only exist for rows < n
+        const uint64_t v = mask[(size_t)(b * 64 + (on ? t : 0)) * cb + w];
+        acc |= on ? v : 0ull;
+      }
+      if (acc) atomicOr((unsigned long long *)&remv[w], (unsigned long long)acc);
+    }
+    __syncthreads();
+  }
+
+  if (wave == 0) {
+    int base = 0;
+    for (int w = 0; w < cb; ++w) {
+      const uint64_t f = flags[w];
+      if ((f >> lane) & 1ull) keep_out[base + __popcll(f & ((1ull << lane) - 1ull))] = (int64_t)w * 64 + lane;
+      base += __popcll(f);
+    }
+    if (lane == 0) *num_keep = base;
+  }
+}
+
+struct NmsWorkspace {
+  uint64_t *keys;
+  int *order;
+  float4 *boxes;
+  uint64_t *mask;
+  size_t total;
+};
+
+NmsWorkspace carve(void *ws, int n) {
+  const int np2 = mr3d_next_pow2(n);
+  const size_t cb = (size_t)(n + 63) / 64;
+  size_t off = 0;
+  NmsWorkspace w;
+  char *base = (char *)ws;
+  w.keys = (uint64_t *)(base + off);  off += mr3d_align_up(n > kSortLdsMax ? sizeof(uint64_t) * np2 : 0, 256);
+  w.order = (int *)(base + off);      off += mr3d_align_up(sizeof(int) * (size_t)n, 256);
+  w.boxes = (float4 *)(base + off);   off += mr3d_align_up(sizeof(float) * 8 * (size_t)n, 256);
+  w.mask = (uint64_t *)(base + off);  off += mr3d_align_up(sizeof(uint64_t) * (size_t)n * cb, 256);
+  w.total = off;
+  return w;
+}
+
+}  // namespace
+
+extern "C" size_t mr3d_nms3d_workspace_bytes(int n) {
+  if (n <= 0) return 256;
+  return carve(nullptr, n).total;
+}
+
+extern "C" int mr3d_nms3d(const float *dets, int n, int row_stride, float iou_threshold, int64_t *keep_out,
+                          int32_t *num_keep_out, void *workspace, size_t workspace_bytes, mr3d_stream_t stream_) {
+  hipStream_t stream = mr3d_stream(stream_);
+  if (n < 0 || !num_keep_out) return MR3D_ERR_INVALID_ARG;
+  if (n == 0) {
+    return hipMemsetAsync(num_keep_out, 0, sizeof(int32_t), stream) == hipSuccess ? MR3D_OK : MR3D_ERR_LAUNCH;
+  }
+  if (!dets || !keep_out || row_stride < 7) return MR3D_ERR_INVALID_ARG;
+  if (!workspace || workspace_bytes < mr3d_nms3d_workspace_bytes(n) || ((uintptr_t)workspace & 255))
+    return MR3D_ERR_WORKSPACE;
+  const int cb = (n + 63) / 64;
+  const size_t sweep_lds = sizeof(uint64_t) * (2 * (size_t)cb + 1);
+  if (sweep_lds > 64 * 1024) return MR3D_ERR_UNSUPPORTED;   // n > ~262k boxes
+  NmsWorkspace w = carve(workspace, n);
+  const int np2 = mr3d_next_pow2(n);
+
+  if (n <= kSortLdsMax) {
+    nms3d_sort_lds_kernel<<<1, kSortThreads, 0, stream>>>(dets, n, row_stride, np2, w.order, w.boxes);
+  } else {
+    const int th = 256, bl = (np2 + th - 1) / th;
+    nms3d_keys_init_kernel<<<bl, th, 0, stream>>>(dets, n, row_stride, np2, w.keys);
+    for (int k = 2; k <= np2; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) nms3d_bitonic_step_kernel<<<bl, th, 0, stream>>>(w.keys, np2, j, k);
+    nms3d_gather_kernel<<<(n + th - 1) / th, th, 0, stream>>>(dets, n, row_stride, w.keys, w.order, w.boxes);
+  }
+  nms3d_mask_kernel<<<dim3(cb, cb), MR3D_WAVE, 0, stream>>>(w.boxes, n, cb, iou_threshold, w.mask);
+  nms3d_sweep_kernel<<<1, kSweepThreads, sweep_lds, stream>>>(w.mask, w.order, n, cb, keep_out, num_keep_out);
+  return mr3d_launch_status();
+}

@@ -1,0 +1,378 @@
+// RoIAlign3D forward / backward for gfx950.
+//
+// Arithmetic follows the reference kernels (mmdet/ops/roi_align/src/roi_align_kernel.cu):
+//   roi geometry :232-259, sample coordinates :271-281, trilinear taps :64-149 / :383-442,
+//   mean over samples :288, backward scatter g_k = top*w_k/count :596-619,
+//   backward's top_grad index bug :554-555 (kept behind MR3D_ROIALIGN_BUG_COMPAT).
+//
+// Two kernel families:
+//   *_generic : one lane per output element, arbitrary feature strides -- the reference's
+//               decomposition; used for NCDHW features and for sample_num == 0.
+//   *_cl      : channels-last (NDHWC) features.  A wave owns one output bin and its 64 lanes
+//               are 64 consecutive channels, so each trilinear tap is ONE coalesced 256-B read
+//               (forward) or ONE 256-B contiguous fp32 atomic (backward: the full-rate atomic
+//               shape on MI355X).  Per-axis tap tables (index/weight per sample, shared by all
+//               channels and all bins of the RoI) are built once per workgroup in LDS; the
+//               [bin][channel] tile is transposed through LDS so the [R,C,PD,PH,PW] output /
+//               top_grad side is accessed in 256-B runs as well.
+#include "mr3d_common.h"
+
+namespace {
+
+struct RoiGeom {
+  int b;
+  float sw, sh, sd;   // roi_start_{w,h,d}
+  float bw, bh, bd;   // bin sizes
+  int nw, nh, nd;     // samples per bin
+};
+
+__device__ __forceinline__ RoiGeom roi_geom(const float *__restrict__ roi, float scale, float scale_d, int sample_num,
+                                            int PD, int PH, int PW) {
+  RoiGeom g;
+  g.b = (int)roi[0];
+  g.sw = roi[1] * scale;
+  g.sh = roi[2] * scale;
+  const float ew = (roi[3] + 1) * scale;
+  const float eh = (roi[4] + 1) * scale;
+  g.sd = roi[5] * scale_d;
+  const float ed = (roi[6] + 1) * scale_d;
+  const float rw = fmaxf(ew - g.sw, 0.f);
+  const float rh = fmaxf(eh - g.sh, 0.f);
+  const float rd = fmaxf(ed - g.sd, 0.f);
+  g.bd = rd / PD;
+  g.bh = rh / PH;
+  g.bw = rw / PW;
+  g.nd = (sample_num > 0) ? sample_num : (int)ceilf(rd / PD);
+  g.nh = (sample_num > 0) ? sample_num : (int)ceilf(rh / PH);
+  g.nw = (sample_num > 0) ? sample_num : (int)ceilf(rw / PW);
+  return g;
+}
+
+// one axis of bilinear_interpolate_3d (:69-103,:105-110): returns false when the coordinate is
+// outside (-1, dim) (the whole sample then contributes 0 / scatters nothing).
+struct AxisTap {
+  int lo, hi;
+  float l, h;   // weight of hi, weight of lo
+};
+
+__device__ __forceinline__ bool axis_tap(float v, int dim, AxisTap &t) {
+  if (v < -1.0f || v > (float)dim) return false;
+  if (v <= 0) v = 0;
+  int lo = (int)v;
+  if (lo >= dim - 1) {
+    t.hi = t.lo = dim - 1;
+    v = (float)t.lo;
+  } else {
+    t.lo = lo;
+    t.hi = lo + 1;
+  }
+  t.l = v - (float)t.lo;
+  t.h = 1.f - t.l;
+  return true;
+}
+
+__device__ __forceinline__ float sample_coord(float start, int p, float bin, int i, int ns) {
+  return start + p * bin + (float)(i + .5f) * bin / (float)ns;
+}
+
+// ------------------------------------------------------------------------------------------
+// generic: lane per output element, feature strides (sN,sC,sD,sH,sW) in elements
+// ------------------------------------------------------------------------------------------
+struct Strides { long long n, c, d, h, w; };
+
+__global__ __launch_bounds__(256) void roi_align3d_fwd_generic(long long total, const float *__restrict__ feat,
+                                                               const float *__restrict__ rois, float scale, float scale_d,
+                                                               int sample_num, int C, int D, int H, int W, int PD, int PH,
+                                                               int PW, Strides st, float *__restrict__ out) {
+  for (long long index = (long long)blockIdx.x * blockDim.x + threadIdx.x; index < total;
+       index += (long long)blockDim.x * gridDim.x) {
+    const int pw = (int)(index % PW);
+    const int ph = (int)((index / PW) % PH);
+    const int pd = (int)((index / PW / PH) % PD);
+    const int c = (int)((index / PW / PH / PD) % C);
+    const int n = (int)(index / PW / PH / PD / C);
+    const RoiGeom g = roi_geom(rois + (size_t)n * 7, scale, scale_d, sample_num, PD, PH, PW);
+    const float *src = feat + g.b * st.n + c * st.c;
+    float acc = 0.f;
+    for (int iz = 0; iz < g.nd; ++iz) {
+      AxisTap tz;
+      const bool vz = axis_tap(sample_coord(g.sd, pd, g.bd, iz, g.nd), D, tz);
+      for (int iy = 0; iy < g.nh; ++iy) {
+        AxisTap ty;
+        const bool vy = axis_tap(sample_coord(g.sh, ph, g.bh, iy, g.nh), H, ty);
+        for (int ix = 0; ix < g.nw; ++ix) {
+          AxisTap tx;
+          const bool vx = axis_tap(sample_coord(g.sw, pw, g.bw, ix, g.nw), W, tx);
+          if (!(vz && vy && vx)) continue;
+          const float *zl = src + tz.lo * st.d, *zh = src + tz.hi * st.d;
+          const long long yl = ty.lo * st.h, yh = ty.hi * st.h, xl = tx.lo * st.w, xh = tx.hi * st.w;
+          const float v1 = zl[yl + xl], v2 = zl[yl + xh], v3 = zl[yh + xl], v4 = zl[yh + xh];
+          const float v5 = zh[yl + xl], v6 = zh[yl + xh], v7 = zh[yh + xl], v8 = zh[yh + xh];
+          const float w1 = tx.h * ty.h * tz.h, w5 = tx.h * ty.h * tz.l;
+          const float w2 = tx.l * ty.h * tz.h, w6 = tx.l * ty.h * tz.l;
+          const float w3 = tx.h * ty.l * tz.h, w7 = tx.h * ty.l * tz.l;
+          const float w4 = tx.l * ty.l * tz.h, w8 = tx.l * ty.l * tz.l;
+          acc += (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4 + w5 * v5 + w6 * v6 + w7 * v7 + w8 * v8);
+        }
+      }
+    }
+    acc /= (float)(g.nd * g.nh * g.nw);
+    out[index] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void roi_align3d_bwd_generic(long long total, const float *__restrict__ top,
+                                                               const float *__restrict__ rois, float scale, float scale_d,
+                                                               int sample_num, int C, int D, int H, int W, int PD, int PH,
+                                                               int PW, Strides st, int bug_compat,
+                                                               float *__restrict__ bottom) {
+  for (long long index = (long long)blockIdx.x * blockDim.x + threadIdx.x; index < total;
+       index += (long long)blockDim.x * gridDim.x) {
+    const int pw = (int)(index % PW);
+    const int ph = (int)((index / PW) % PH);
+    const int pd = (int)((index / PW / PH) % PD);
+    const int c = (int)((index / PW / PH / PD) % C);
+    const int n = (int)(index / PW / PH / PD / C);
+    const RoiGeom g = roi_geom(rois + (size_t)n * 7, scale, scale_d, sample_num, PD, PH, PW);
+    float *dst = bottom + g.b * st.n + c * st.c;
+    const long long off = (long long)(n * C + c) * PD * PH * PW + (bug_compat ? pd * PD * PW : pd * PH * PW) + ph * PW + pw;
+    const float tg = top[off];
+    const float count = (float)(g.nd * g.nh * g.nw);
+    for (int iz = 0; iz < g.nd; ++iz) {
+      AxisTap tz;
+      const bool vz = axis_tap(sample_coord(g.sd, pd, g.bd, iz, g.nd), D, tz);
+      for (int iy = 0; iy < g.nh; ++iy) {
+        AxisTap ty;
+        const bool vy = axis_tap(sample_coord(g.sh, ph, g.bh, iy, g.nh), H, ty);
+        for (int ix = 0; ix < g.nw; ++ix) {
+          AxisTap tx;
+          const bool vx = axis_tap(sample_coord(g.sw, pw, g.bw, ix, g.nw), W, tx);
+          if (!(vz && vy && vx)) continue;
+          float *zl = dst + tz.lo * st.d, *zh = dst + tz.hi * st.d;
+          const long long yl = ty.lo * st.h, yh = ty.hi * st.h, xl = tx.lo * st.w, xh = tx.hi * st.w;
+          atomicAdd(zl + yl + xl, tg * (tx.h * ty.h * tz.h) / count);
+          atomicAdd(zl + yl + xh, tg * (tx.l * ty.h * tz.h) / count);
+          atomicAdd(zl + yh + xl, tg * (tx.h * ty.l * tz.h) / count);
+          atomicAdd(zl + yh + xh, tg * (tx.l * ty.l * tz.h) / count);
+          atomicAdd(zh + yl + xl, tg * (tx.h * ty.h * tz.l) / count);
+          atomicAdd(zh + yl + xh, tg * (tx.l * ty.h * tz.l) / count);
+          atomicAdd(zh + yh + xl, tg * (tx.h * ty.l * tz.l) / count);
+          atomicAdd(zh + yh + xh, tg * (tx.l * ty.l * tz.l) / count);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// channels-last fast path
+// ------------------------------------------------------------------------------------------
+constexpr int kClThreads = 256;          // 4 waves
+constexpr int kClBins = 64;              // bins per workgroup (one LDS tile)
+constexpr int kAxisCap = 256;            // table entries per axis (P * sample_num)
+
+// table entry: lo/hi are ELEMENT offsets along the axis (index * stride), valid folded into weights:
+// an out-of-range sample gets l = h = 0 and offsets 0, so it adds exactly 0 like the reference's `return 0`.
+struct __attribute__((aligned(16))) TabEntry {
+  int lo, hi;
+  float l, h;
+};
+
+__device__ __forceinline__ void build_axis_table(TabEntry *tab, float start, float bin, int P, int ns, int dim,
+                                                 int stride, int tid) {
+  for (int e = tid; e < P * ns; e += kClThreads) {
+    const int p = e / ns, i = e - p * ns;
+    AxisTap t;
+    TabEntry te;
+    if (axis_tap(sample_coord(start, p, bin, i, ns), dim, t)) {
+      te.lo = t.lo * stride; te.hi = t.hi * stride; te.l = t.l; te.h = t.h;
+    } else {
+      te.lo = 0; te.hi = 0; te.l = 0.f; te.h = 0.f;
+    }
+    tab[e] = te;
+  }
+}
+
+template <bool kBackward>
+__global__ __launch_bounds__(kClThreads) void roi_align3d_cl(const float *__restrict__ feat_or_top_src,
+                                                            float *__restrict__ out_or_bottom,
+                                                            const float *__restrict__ rois, float scale, float scale_d,
+                                                            int ns, int C, int D, int H, int W, int PD, int PH, int PW,
+                                                            int bug_compat) {
+  __shared__ TabEntry tabx[kAxisCap], taby[kAxisCap], tabz[kAxisCap];
+  __shared__ float tile[kClBins][MR3D_WAVE + 1];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = blockIdx.x;
+  const int B = PD * PH * PW;
+  const int bin0 = blockIdx.y * kClBins;
+  const int nb = min(kClBins, B - bin0);
+  const RoiGeom g = roi_geom(rois + (size_t)r * 7, scale, scale_d, ns, PD, PH, PW);
+  // element strides of the NDHWC tensor
+  const int sW = C, sH = W * C;
+  const long long sD = (long long)H * W * C;
+  build_axis_table(tabx, g.sw, g.bw, PW, ns, W, sW, tid);
+  build_axis_table(taby, g.sh, g.bh, PH, ns, H, sH, tid);
+  build_axis_table(tabz, g.sd, g.bd, PD, ns, D, 1, tid);   // z offsets can exceed int: keep the index, scale below
+  __syncthreads();
+  const float count = (float)(ns * ns * ns);
+  const long long base_n = (long long)g.b * D * sD;
+
+  for (int cg = 0; cg < C; cg += MR3D_WAVE) {
+    const int c = cg + lane;
+    const bool cok = c < C;
+    if (kBackward) {
+      // stage top_grad[r, cg..cg+63, bin0..bin0+nb) as tile[bin][channel]
+      const float *top = feat_or_top_src;
+      for (int cc = wave; cc < MR3D_WAVE; cc += kClThreads / MR3D_WAVE) {
+        const int ch = cg + cc;
+        if (ch < C && lane < nb) {
+          const int bin = bin0 + lane;
+          const int pw = bin % PW, ph = (bin / PW) % PH, pd = bin / (PW * PH);
+          const int off = (bug_compat ? pd * PD * PW : pd * PH * PW) + ph * PW + pw;
+          tile[lane][cc] = top[((size_t)r * C + ch) * B + off];
+        }
+      }
+      __syncthreads();
+    }
+    for (int bi = wave; bi < nb; bi += kClThreads / MR3D_WAVE) {
+      const int bin = bin0 + bi;
+      const int pw = bin % PW, ph = (bin / PW) % PH, pd = bin / (PW * PH);
+      float acc = 0.f;
+      const float tg = kBackward ? tile[bi][lane] : 0.f;
+      for (int iz = 0; iz < ns; ++iz) {
+        const TabEntry tz = tabz[pd * ns + iz];
+        const long long zl = base_n + tz.lo * sD, zh = base_n + tz.hi * sD;
+        for (int iy = 0; iy < ns; ++iy) {
+          const TabEntry ty = taby[ph * ns + iy];
+          for (int ix = 0; ix < ns; ++ix) {
+            const TabEntry tx = tabx[pw * ns + ix];
+            // an out-of-range sample has l = h = 0 on that axis: it adds 0 / scatters nothing (:69-71, :600)
+            if ((tx.l + tx.h) * (ty.l + ty.h) * (tz.l + tz.h) == 0.f) continue;
+            const float w1 = tx.h * ty.h * tz.h, w5 = tx.h * ty.h * tz.l;
+            const float w2 = tx.l * ty.h * tz.h, w6 = tx.l * ty.h * tz.l;
+            const float w3 = tx.h * ty.l * tz.h, w7 = tx.h * ty.l * tz.l;
+            const float w4 = tx.l * ty.l * tz.h, w8 = tx.l * ty.l * tz.l;
+            const long long o1 = zl + ty.lo + tx.lo + c, o2 = zl + ty.lo + tx.hi + c;
+            const long long o3 = zl + ty.hi + tx.lo + c, o4 = zl + ty.hi + tx.hi + c;
+            const long long o5 = zh + ty.lo + tx.lo + c, o6 = zh + ty.lo + tx.hi + c;
+            const long long o7 = zh + ty.hi + tx.lo + c, o8 = zh + ty.hi + tx.hi + c;
+            if (!kBackward) {
+              const float *f = feat_or_top_src;
+              if (cok) {
+                const float v1 = f[o1], v2 = f[o2], v3 = f[o3], v4 = f[o4];
+                const float v5 = f[o5], v6 = f[o6], v7 = f[o7], v8 = f[o8];
+                acc += (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4 + w5 * v5 + w6 * v6 + w7 * v7 + w8 * v8);
+              }
+            } else {
+              float *bt = out_or_bottom;
+              if (cok) {
+                atomicAdd(bt + o1, tg * w1 / count);
+                atomicAdd(bt + o2, tg * w2 / count);
+                atomicAdd(bt + o3, tg * w3 / count);
+                atomicAdd(bt + o4, tg * w4 / count);
+                atomicAdd(bt + o5, tg * w5 / count);
+                atomicAdd(bt + o6, tg * w6 / count);
+                atomicAdd(bt + o7, tg * w7 / count);
+                atomicAdd(bt + o8, tg * w8 / count);
+              }
+            }
+          }
+        }
+      }
+      if (!kBackward) tile[bi][lane] = acc / count;
+    }
+    __syncthreads();
+    if (!kBackward) {
+      // tile[bin][channel] -> out[r, channel, bin]: 256-B runs of consecutive bins per channel
+      for (int cc = wave; cc < MR3D_WAVE; cc += kClThreads / MR3D_WAVE) {
+        const int ch = cg + cc;
+        if (ch < C && lane < nb) out_or_bottom[((size_t)r * C + ch) * B + bin0 + lane] = tile[lane][cc];
+      }
+      __syncthreads();
+    }
+  }
+}
+
+int check_common(const void *a, const void *b, const void *c, int num_rois, int batch, int C, int D, int H, int W, int PD,
+                 int PH, int PW, int sample_num, int layout) {
+  if (num_rois < 0 || batch <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || PD <= 0 || PH <= 0 || PW <= 0 ||
+      sample_num < 0)
+    return MR3D_ERR_INVALID_ARG;
+  if (layout != MR3D_LAYOUT_NCDHW && layout != MR3D_LAYOUT_NDHWC) return MR3D_ERR_INVALID_ARG;
+  if (num_rois > 0 && (!a || !b || !c)) return MR3D_ERR_INVALID_ARG;
+  return MR3D_OK;
+}
+
+Strides strides_for(int layout, int C, int D, int H, int W) {
+  Strides s;
+  if (layout == MR3D_LAYOUT_NCDHW) {
+    s.w = 1; s.h = W; s.d = (long long)H * W; s.c = (long long)D * H * W; s.n = (long long)C * D * H * W;
+  } else {
+    s.c = 1; s.w = C; s.h = (long long)W * C; s.d = (long long)H * W * C; s.n = (long long)D * H * W * C;
+  }
+  return s;
+}
+
+bool use_cl(int layout, int sample_num, int PD, int PH, int PW) {
+  return layout == MR3D_LAYOUT_NDHWC && sample_num > 0 && PD * sample_num <= kAxisCap && PH * sample_num <= kAxisCap &&
+         PW * sample_num <= kAxisCap;
+}
+
+}  // namespace
+
+extern "C" int mr3d_roi_align3d_forward(const float *features, const float *rois, int num_rois, int batch, int channels,
+                                        int depth, int height, int width, int pooled_depth, int pooled_height,
+                                        int pooled_width, float spatial_scale, float spatial_scale_depth, int sample_num,
+                                        int layout, float *output, mr3d_stream_t stream_) {
+  int st = check_common(features, rois, output, num_rois, batch, channels, depth, height, width, pooled_depth,
+                        pooled_height, pooled_width, sample_num, layout);
+  if (st != MR3D_OK) return st;
+  if (num_rois == 0) return MR3D_OK;
+  hipStream_t stream = mr3d_stream(stream_);
+  const int B = pooled_depth * pooled_height * pooled_width;
+  if (use_cl(layout, sample_num, pooled_depth, pooled_height, pooled_width)) {
+    dim3 grid(num_rois, (B + kClBins - 1) / kClBins);
+    roi_align3d_cl<false><<<grid, kClThreads, 0, stream>>>(features, output, rois, spatial_scale, spatial_scale_depth,
+                                                          sample_num, channels, depth, height, width, pooled_depth,
+                                                          pooled_height, pooled_width, 0);
+  } else {
+    const long long total = (long long)num_rois * channels * B;
+    const long long blocks = (total + 255) / 256;
+    const int grid = (int)(blocks < 65536 ? blocks : 65536);
+    roi_align3d_fwd_generic<<<grid, 256, 0, stream>>>(total, features, rois, spatial_scale, spatial_scale_depth,
+                                                      sample_num, channels, depth, height, width, pooled_depth,
+                                                      pooled_height, pooled_width,
+                                                      strides_for(layout, channels, depth, height, width), output);
+  }
+  return mr3d_launch_status();
+}
+
+extern "C" int mr3d_roi_align3d_backward(const float *top_grad, const float *rois, int num_rois, int batch, int channels,
+                                         int depth, int height, int width, int pooled_depth, int pooled_height,
+                                         int pooled_width, float spatial_scale, float spatial_scale_depth, int sample_num,
+                                         int layout, int flags, float *bottom_grad, mr3d_stream_t stream_) {
+  int st = check_common(top_grad, rois, bottom_grad, num_rois, batch, channels, depth, height, width, pooled_depth,
+                        pooled_height, pooled_width, sample_num, layout);
+  if (st != MR3D_OK) return st;
+  if (num_rois == 0) return MR3D_OK;
+  hipStream_t stream = mr3d_stream(stream_);
+  const int bug = (flags & MR3D_ROIALIGN_BUG_COMPAT) ? 1 : 0;
+  const int B = pooled_depth * pooled_height * pooled_width;
+  if (use_cl(layout, sample_num, pooled_depth, pooled_height, pooled_width)) {
+    dim3 grid(num_rois, (B + kClBins - 1) / kClBins);
+    roi_align3d_cl<true><<<grid, kClThreads, 0, stream>>>(top_grad, bottom_grad, rois, spatial_scale,
+                                                         spatial_scale_depth, sample_num, channels, depth, height, width,
+                                                         pooled_depth, pooled_height, pooled_width, bug);
+  } else {
+    const long long total = (long long)num_rois * channels * B;
+    const long long blocks = (total + 255) / 256;
+    const int grid = (int)(blocks < 65536 ? blocks : 65536);
+    roi_align3d_bwd_generic<<<grid, 256, 0, stream>>>(total, top_grad, rois, spatial_scale, spatial_scale_depth,
+                                                      sample_num, channels, depth, height, width, pooled_depth,
+                                                      pooled_height, pooled_width,
+                                                      strides_for(layout, channels, depth, height, width), bug,
+                                                      bottom_grad);
+  }
+  return mr3d_launch_status();
+}

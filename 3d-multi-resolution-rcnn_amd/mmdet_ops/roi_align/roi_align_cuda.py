@@ -1,0 +1,49 @@
+"""Stand-in for the reference's compiled `roi_align_cuda` extension module
+(mmdet/ops/roi_align/src/roi_align_cuda.cpp:152-157: forward, forward3d, backward, backward3d).
+Same positional signatures; outputs are written in place; returns 1 like the reference."""
+import torch
+
+from ... import _hip
+
+
+def _check(t, name):
+    # CHECK_INPUT = CHECK_CUDA + CHECK_CONTIGUOUS (roi_align_cuda.cpp:34-39) -> RuntimeError
+    if not t.is_cuda:
+        raise RuntimeError(f'{name} must be a CUDAtensor ')
+    if t.dtype != torch.float32:
+        raise RuntimeError(f'{name} must be float32 (half/double are not built for gfx950 yet)')
+
+
+def forward3d(features, rois, pooled_depth, pooled_height, pooled_width, spatial_scale, spatial_scale_depth,
+              sample_num, output):
+    _check(features, 'features'); _check(rois, 'rois'); _check(output, 'output')
+    if not (rois.is_contiguous() and output.is_contiguous()):
+        raise RuntimeError('rois/output must be contiguous ')
+    if rois.dim() != 2 or rois.size(1) != 7:
+        # the reference prints "wrong roi size" and returns 0, which its Python caller ignores
+        # (roi_align_cuda.cpp:80-83); raising is strictly safer
+        raise RuntimeError('wrong roi size: rois must be [num_rois, 7]')
+    _hip.roi_align3d_forward(features, rois, int(pooled_depth), int(pooled_height), int(pooled_width),
+                             float(spatial_scale), float(spatial_scale_depth), int(sample_num), output)
+    return 1
+
+
+def backward3d(top_grad, rois, pooled_depth, pooled_height, pooled_width, spatial_scale, spatial_scale_depth,
+               sample_num, bottom_grad, bug_compat=True):
+    _check(top_grad, 'top_grad'); _check(rois, 'rois'); _check(bottom_grad, 'bottom_grad')
+    if not (rois.is_contiguous() and top_grad.is_contiguous()):
+        raise RuntimeError('rois/top_grad must be contiguous ')
+    if rois.dim() != 2 or rois.size(1) != 7:
+        raise RuntimeError('wrong roi size: rois must be [num_rois, 7]')
+    _hip.roi_align3d_backward(top_grad, rois, int(pooled_depth), int(pooled_height), int(pooled_width),
+                              float(spatial_scale), float(spatial_scale_depth), int(sample_num), bottom_grad,
+                              bug_compat=bug_compat)
+    return 1
+
+
+def forward(*args, **kwargs):
+    raise NotImplementedError('2D roi_align_cuda.forward is outside the 3D hot path')
+
+
+def backward(*args, **kwargs):
+    raise NotImplementedError('2D roi_align_cuda.backward is outside the 3D hot path')

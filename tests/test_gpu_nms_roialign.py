@@ -1,0 +1,178 @@
+"""GPU parity tests (run on the MI355X box with `-m gpu`): the HIP path, called through the
+C ABI, against the oracle and the committed golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import binding as orc
+import ref_impls as ri
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    import mr3d_amd
+    assert torch.cuda.is_available()
+    assert mr3d_amd._hip.lib().mr3d_device_ok() == 1
+    return torch.device('cuda:0')
+
+
+# ------------------------------------------------------------------ NMS3D: bit-exact indices
+def test_nms3d_golden(dev, golden_dir):
+    from mr3d_amd.mmdet_ops import nms
+    g = np.load(f'{golden_dir}/nms3d.npz')
+    for k in range(int(g['num_cases'])):
+        dets = torch.from_numpy(g[f'dets_{k}']).to(dev)
+        kept, inds = nms(dets, float(g[f'thr_{k}']))
+        assert inds.dtype == torch.long and inds.device == dets.device
+        np.testing.assert_array_equal(inds.cpu().numpy(), g[f'keep_{k}'], err_msg=f'case {k}')
+        np.testing.assert_array_equal(kept.cpu().numpy(), g[f'dets_{k}'][g[f'keep_{k}']])
+
+
+@pytest.mark.parametrize('n', [1, 2, 63, 64, 65, 127, 128, 129, 777, 2000, 4096, 4097, 6000])
+def test_nms3d_vs_oracle_random(dev, n):
+    from mr3d_amd.mmdet_ops.nms import nms_cuda
+    rng = np.random.default_rng(n)
+    nc = max(1, n // 6)
+    ctr = rng.uniform([10, 10, 4], [500, 500, 76], size=(nc, 3))[rng.integers(0, nc, n)] + rng.normal(0, 1.5, (n, 3))
+    half = rng.uniform([3, 3, 1.5], [14, 14, 6], size=(nc, 3))[rng.integers(0, nc, n)] * rng.uniform(0.8, 1.2, (n, 3))
+    boxes = np.stack([ctr[:, 0] - half[:, 0], ctr[:, 1] - half[:, 1], ctr[:, 0] + half[:, 0], ctr[:, 1] + half[:, 1],
+                      ctr[:, 2] - half[:, 2], ctr[:, 2] + half[:, 2]], 1)
+    scores = rng.uniform(0, 1, n)
+    dets = np.concatenate([boxes, scores[:, None]], 1).astype(np.float32)
+    for thr in (0.3, 0.7):
+        inds = nms_cuda.nms_3d(torch.from_numpy(dets).to(dev), thr)
+        np.testing.assert_array_equal(inds.cpu().numpy(), orc.nms3d(dets, thr))
+
+
+def test_nms3d_ties_duplicates_and_strided_input(dev):
+    from mr3d_amd.mmdet_ops.nms import nms_cuda
+    rng = np.random.default_rng(5)
+    base = rng.uniform(0, 100, size=(40, 3))
+    boxes = np.concatenate([base, base + rng.uniform(5, 20, size=(40, 3))], 1)[:, [0, 1, 3, 4, 2, 5]]
+    dets = np.concatenate([np.tile(boxes, (5, 1)), np.zeros((200, 1))], 1).astype(np.float32)
+    dets[:, 6] = np.repeat([0.5, 0.25, 0.5, 0.75, 0.5], 40)          # many equal scores, exact duplicates
+    exp = orc.nms3d(dets, 0.5)
+    got = nms_cuda.nms_3d(torch.from_numpy(dets).to(dev), 0.5)
+    np.testing.assert_array_equal(got.cpu().numpy(), exp)
+    wide = torch.zeros((200, 11), device=dev)
+    wide[:, 2:9] = torch.from_numpy(dets).to(dev)
+    got2 = nms_cuda.nms_3d(wide[:, 2:9], 0.5)                         # row stride 11, not contiguous
+    np.testing.assert_array_equal(got2.cpu().numpy(), exp)
+
+
+def test_nms3d_empty_and_strict_threshold(dev):
+    from mr3d_amd.mmdet_ops import nms
+    kept, inds = nms(torch.zeros((0, 7), device=dev), 0.5)
+    assert inds.numel() == 0 and inds.dtype == torch.long
+    a = torch.tensor([[0, 0, 3, 3, 0, 0, 0.9], [0, 0, 3, 1, 0, 0, 0.8]], device=dev)   # IoU == 0.5 exactly
+    assert nms(a, 0.5)[1].tolist() == [0, 1]
+    assert nms(a, 0.4999)[1].tolist() == [0]
+    # numpy in -> numpy out with device_id (nms_wrapper.py:29-31,50-51)
+    k, i = nms(a.cpu().numpy(), 0.4999, device_id=0)
+    assert isinstance(i, np.ndarray) and i.tolist() == [0] and k.shape == (1, 7)
+
+
+def test_nms3d_all_suppressed_and_none_suppressed_full_size(dev):
+    """size-independent properties at the benchmark size (N = 2000)."""
+    from mr3d_amd.mmdet_ops.nms import nms_cuda
+    n = 2000
+    one = np.array([[10, 10, 50, 50, 4, 20, 0]], np.float32)
+    dets = np.tile(one, (n, 1)); dets[:, 6] = np.linspace(0.1, 0.9, n)
+    got = nms_cuda.nms_3d(torch.from_numpy(dets).to(dev), 0.7)
+    assert got.tolist() == [n - 1]                                      # only the best survives
+    g = np.arange(n, dtype=np.float32)
+    far = np.stack([g * 100, g * 0, g * 100 + 10, g * 0 + 10, g * 0, g * 0 + 4, np.linspace(0.9, 0.1, n)], 1).astype(np.float32)
+    got = nms_cuda.nms_3d(torch.from_numpy(far).to(dev), 0.7)
+    assert got.tolist() == list(range(n))                               # disjoint boxes: all kept, ascending
+    # idempotence: NMS of the kept set keeps everything
+    rng = np.random.default_rng(1)
+    d = np.concatenate([rng.uniform(0, 60, (n, 3)), rng.uniform(0, 1, (n, 4))], 1).astype(np.float32)
+    d = np.stack([d[:, 0], d[:, 1], d[:, 0] + 20 * d[:, 3] + 4, d[:, 1] + 20 * d[:, 4] + 4, d[:, 2], d[:, 2] + 8 * d[:, 5] + 2, d[:, 6]], 1)
+    t = torch.from_numpy(d.astype(np.float32)).to(dev)
+    k1 = nms_cuda.nms_3d(t, 0.5)
+    k2 = nms_cuda.nms_3d(t[k1], 0.5)
+    assert k2.tolist() == list(range(k1.numel()))
+    np.testing.assert_array_equal(k1.cpu().numpy(), orc.nms3d(d.astype(np.float32), 0.5))
+
+
+# ------------------------------------------------------------------ RoIAlign3D: <= 1e-4 rel
+RTOL, ATOL = 1e-4, 1e-5      # north-star tolerance for floating point (BASELINE.json)
+
+
+def _feat(rng, shape, fmt, dev):
+    f = torch.from_numpy(rng.normal(size=shape).astype(np.float32)).to(dev)
+    return f.contiguous(memory_format=fmt)
+
+
+@pytest.mark.parametrize('fmt', [torch.contiguous_format, torch.channels_last_3d])
+@pytest.mark.parametrize('C,P,sample_num', [(64, (3, 7, 7), 2), (64, (10, 14, 14), 2), (5, (2, 3, 4), 0),
+                                            (70, (3, 7, 7), 1), (16, (1, 1, 1), 3)])
+def test_roi_align3d_forward_backward_vs_oracle(dev, fmt, C, P, sample_num):
+    from mr3d_amd.mmdet_ops import RoIAlign3D
+    rng = np.random.default_rng(C * 100 + P[0])
+    N, D, H, W = 2, 10, 24, 20
+    feat = _feat(rng, (N, C, D, H, W), fmt, dev)
+    rois = ri.rand_rois(rng, 33, N, (W * 4, H * 4, D * 2), max_xy=90, max_z=20)
+    rois[0, 1:] = [-20, -20, 30, 30, -6, 8]
+    rois[1, 1:] = [70, 80, 200, 200, 15, 60]
+    rois[2, 1:] = [10, 10, 10, 10, 3, 3]
+    rois[3, 1:] = [30, 30, 20, 20, 5, 2]          # malformed: end < start -> extent clamped (:241-243)
+    fnp = feat.cpu().numpy()                       # logical NCDHW view
+    for bug in (True, False):
+        layer = RoIAlign3D(P[1], P[0], 0.25, 0.5, sample_num=sample_num, bug_compat=bug)
+        assert P[1] == P[2]
+        f = feat.clone().requires_grad_(True)
+        out = layer(f, torch.from_numpy(rois).to(dev))
+        exp = orc.roi_align3d_forward(fnp, rois, *P, 0.25, 0.5, sample_num)
+        if sample_num == 0:
+            ok = np.isfinite(exp)                  # zero-extent roi with adaptive sampling is 0/0 = NaN (Appendix A.1)
+            assert np.array_equal(np.isfinite(out.detach().cpu().numpy()), ok)
+        else:
+            ok = np.ones_like(exp, bool)
+        np.testing.assert_allclose(out.detach().cpu().numpy()[ok], exp[ok], rtol=RTOL, atol=ATOL)
+        top = rng.normal(size=exp.shape).astype(np.float32)
+        out.backward(torch.from_numpy(top).to(dev))
+        expb = orc.roi_align3d_backward(top, rois, fnp.shape, 0.25, 0.5, sample_num, bug_compat=bug)
+        assert f.grad.is_contiguous(memory_format=fmt)
+        np.testing.assert_allclose(f.grad.cpu().numpy(), expb, rtol=RTOL, atol=5e-5)
+
+
+def test_roi_align3d_benchmark_shapes_properties(dev):
+    """Full BASELINE sizes (512 rois x 64 ch x (3,7,7) on a P2-sized map): properties that need no oracle run:
+    a constant feature map pools to the same constant wherever all taps are in range, and the
+    two layouts agree with each other."""
+    from mr3d_amd.mmdet_ops import RoIAlign3D
+    rng = np.random.default_rng(2)
+    N, C, D, H, W = 1, 64, 40, 128, 128
+    rois = ri.rand_rois(rng, 512, N, (512, 512, 80))
+    r = torch.from_numpy(rois).to(dev)
+    layer = RoIAlign3D(7, 3, 0.25, 0.5, sample_num=2)
+    const = torch.full((N, C, D, H, W), 1.5, device=dev)
+    np.testing.assert_allclose(layer(const, r).cpu().numpy(), 1.5, rtol=1e-6)
+    f = torch.randn((N, C, D, H, W), device=dev)
+    a = layer(f, r)
+    b = layer(f.contiguous(memory_format=torch.channels_last_3d), r)
+    np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=RTOL, atol=ATOL)
+    # linearity in the features
+    f2 = torch.randn_like(f)
+    c = layer(2 * f + f2, r)
+    np.testing.assert_allclose(c.cpu().numpy(), (2 * a + layer(f2, r)).cpu().numpy(), rtol=1e-4, atol=1e-4)
+    # sampled check against the oracle on a subset of rois
+    sub = rois[:16]
+    exp = orc.roi_align3d_forward(f.cpu().numpy(), sub, 3, 7, 7, 0.25, 0.5, 2)
+    np.testing.assert_allclose(a[:16].cpu().numpy(), exp, rtol=RTOL, atol=ATOL)
+
+
+def test_roi_align3d_error_conventions(dev):
+    from mr3d_amd.mmdet_ops.roi_align import roi_align_cuda
+    f = torch.zeros((1, 4, 4, 8, 8), device=dev)
+    out = torch.zeros((2, 4, 3, 7, 7), device=dev)
+    with pytest.raises(RuntimeError):
+        roi_align_cuda.forward3d(f, torch.zeros((2, 5), device=dev), 3, 7, 7, 0.25, 0.5, 2, out)    # wrong roi size
+    with pytest.raises(RuntimeError):
+        roi_align_cuda.forward3d(f.cpu(), torch.zeros((2, 7), device=dev), 3, 7, 7, 0.25, 0.5, 2, out)
+    with pytest.raises(RuntimeError):
+        roi_align_cuda.forward3d(f.permute(0, 1, 3, 2, 4), torch.zeros((2, 7), device=dev), 3, 7, 7, 0.25, 0.5, 2, out)
+    assert roi_align_cuda.forward3d(f, torch.zeros((0, 7), device=dev), 3, 7, 7, 0.25, 0.5, 2, out[:0]) == 1
