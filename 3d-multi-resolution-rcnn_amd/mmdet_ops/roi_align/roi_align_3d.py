@@ -55,7 +55,7 @@ class RoIAlignFunction3D(Function):
         grad_input = None
         if ctx.needs_input_grad[0]:
             fmt = torch.channels_last_3d if ctx.channels_last else torch.contiguous_format
-            grad_input = torch.zeros(ctx.feature_size, dtype=rois.dtype, device=rois.device, memory_format=fmt)
+            grad_input = torch.empty(ctx.feature_size, dtype=rois.dtype, device=rois.device, memory_format=fmt).zero_()
             out_d, out_h, out_w = grad_output.shape[2:]
             roi_align_cuda.backward3d(grad_output.contiguous(), rois, out_d, out_h, out_w, ctx.spatial_scale,
                                       ctx.spatial_scale_depth, ctx.sample_num, grad_input, bug_compat=ctx.bug_compat)

@@ -121,8 +121,8 @@ def test_roi_align3d_forward_backward_vs_oracle(dev, fmt, C, P, sample_num):
     rois[3, 1:] = [30, 30, 20, 20, 5, 2]          # malformed: end < start -> extent clamped (:241-243)
     fnp = feat.cpu().numpy()                       # logical NCDHW view
     for bug in (True, False):
-        layer = RoIAlign3D(P[1], P[0], 0.25, 0.5, sample_num=sample_num, bug_compat=bug)
-        assert P[1] == P[2]
+        out_size = P[1] if P[1] == P[2] else (P[1], P[2])
+        layer = RoIAlign3D(out_size, P[0], 0.25, 0.5, sample_num=sample_num, bug_compat=bug)
         f = feat.clone().requires_grad_(True)
         out = layer(f, torch.from_numpy(rois).to(dev))
         exp = orc.roi_align3d_forward(fnp, rois, *P, 0.25, 0.5, sample_num)
@@ -136,7 +136,9 @@ def test_roi_align3d_forward_backward_vs_oracle(dev, fmt, C, P, sample_num):
         out.backward(torch.from_numpy(top).to(dev))
         expb = orc.roi_align3d_backward(top, rois, fnp.shape, 0.25, 0.5, sample_num, bug_compat=bug)
         assert f.grad.is_contiguous(memory_format=fmt)
-        np.testing.assert_allclose(f.grad.cpu().numpy(), expb, rtol=RTOL, atol=5e-5)
+        # a voxel gradient is a sum of many +- atomics (order differs from the serial oracle): tolerance is
+        # 1e-4 relative to the gradient's scale, not to each (possibly cancelling) element
+        np.testing.assert_allclose(f.grad.cpu().numpy(), expb, rtol=RTOL, atol=RTOL * np.abs(expb).max())
 
 
 def test_roi_align3d_benchmark_shapes_properties(dev):
