@@ -125,3 +125,55 @@ def roi_align3d_backward(top_grad, rois, out_d, out_h, out_w, spatial_scale, spa
             ctypes.c_int(layout), ctypes.c_int(ROIALIGN_BUG_COMPAT if bug_compat else 0), ptr(bottom_grad),
             stream_ptr(bottom_grad.device))
     check(st, 'mr3d_roi_align3d_backward')
+
+
+# --------------------------------------------------------------------------------------------
+class Conv3dDesc(ctypes.Structure):
+    """mr3d_conv3d_desc (include/mr3d.h)"""
+    _fields_ = [(n, ctypes.c_void_p) for n in ('x', 'w', 'y', 'shift', 'add1', 'add2', 'up', 'mask')] + \
+               [(n, ctypes.c_int) for n in ('n', 'd', 'h', 'w_in', 'cin', 'cout', 'kd', 'kh', 'kw', 'sd', 'sh', 'sw',
+                                            'pd', 'ph', 'pw', 'up_d', 'up_h', 'up_w', 'relu')]
+
+
+def _opt(t):
+    return None if t is None else t.data_ptr()
+
+
+def pack_conv_weight(w):
+    """torch Conv3d weight [Cout, Cin, kd, kh, kw] -> [kd*kh*kw, Cin, Cout] contiguous (the layout the kernels read)."""
+    co, ci = w.shape[:2]
+    return w.reshape(co, ci, -1).permute(2, 1, 0).contiguous()
+
+
+def conv3d_out_shape(x_shape, cout, k, stride, pad):
+    n, d, h, w, _ = x_shape
+    return (n, (d + 2 * pad[0] - k[0]) // stride[0] + 1, (h + 2 * pad[1] - k[1]) // stride[1] + 1,
+            (w + 2 * pad[2] - k[2]) // stride[2] + 1, cout)
+
+
+def conv3d_forward(x, w_packed, k, stride, pad, shift=None, add1=None, add2=None, up=None, mask=None, relu=False,
+                   out=None):
+    """x: [N,D,H,W,Cin] contiguous (NDHWC); w_packed: [taps,Cin,Cout]; returns y [N,Do,Ho,Wo,Cout]."""
+    assert x.is_cuda and x.is_contiguous() and x.dtype == torch.float32 and x.dim() == 5
+    assert w_packed.is_contiguous() and w_packed.dim() == 3 and w_packed.size(1) == x.size(4)
+    cout = w_packed.size(2)
+    oshape = conv3d_out_shape(x.shape, cout, k, stride, pad)
+    y = out if out is not None else torch.empty(oshape, dtype=torch.float32, device=x.device)
+    assert tuple(y.shape) == tuple(oshape) and y.is_contiguous()
+    for t in (add1, add2, mask):
+        assert t is None or (tuple(t.shape) == tuple(oshape) and t.is_contiguous())
+    d = Conv3dDesc()
+    d.x, d.w, d.y = x.data_ptr(), w_packed.data_ptr(), y.data_ptr()
+    d.shift, d.add1, d.add2, d.up, d.mask = _opt(shift), _opt(add1), _opt(add2), _opt(up), _opt(mask)
+    d.n, d.d, d.h, d.w_in, d.cin, d.cout = x.size(0), x.size(1), x.size(2), x.size(3), x.size(4), cout
+    d.kd, d.kh, d.kw = k
+    d.sd, d.sh, d.sw = stride
+    d.pd, d.ph, d.pw = pad
+    if up is not None:
+        assert up.is_contiguous() and up.size(4) == cout and up.size(0) == x.size(0)
+        d.up_d, d.up_h, d.up_w = up.size(1), up.size(2), up.size(3)
+    d.relu = int(bool(relu))
+    with torch.cuda.device(x.device):
+        st = lib().mr3d_conv3d_forward(ctypes.byref(d), stream_ptr(x.device))
+    check(st, 'mr3d_conv3d_forward')
+    return y

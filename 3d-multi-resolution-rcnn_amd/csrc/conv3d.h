@@ -1,0 +1,33 @@
+// Argument blocks shared by the conv3d kernels (conv3d_fwd.hip, conv3d_wgrad.hip) and the
+// plan executor.  All activations are NDHWC fp32 (channels-last); weights are packed
+// [tap][Cin][Cout] (tap = (kd*KH + kh)*KW + kw, Cout innermost).
+#pragma once
+#include "mr3d_common.h"
+
+struct Conv3dFwdArgs {
+  const float *x;       // [N, D, H, W, Cin]
+  const float *w;       // [KD*KH*KW][Cin][Cout]
+  float *y;             // [N, Do, Ho, Wo, Cout]
+  const float *shift;   // [Cout] added to every output position (bias / folded BN shift), may be null
+  const float *add1;    // same shape as y, added before the activation, may be null
+  const float *add2;    // idem
+  const float *up;      // [N, Du, Hu, Wu, Cout]: nearest-upsampled to y's grid and added, may be null
+  const float *mask;    // same shape as y: y = mask > 0 ? y : 0 (ReLU backward), may be null
+  int N, D, H, W, Cin;
+  int Do, Ho, Wo, Cout;
+  int pd, ph, pw;
+  int Du, Hu, Wu;
+  int relu;
+};
+
+struct Conv3dWgradArgs {
+  const float *x;       // [N, D, H, W, Cin]   forward input
+  const float *dy;      // [N, Do, Ho, Wo, Cout] upstream gradient (already ReLU-masked)
+  float *dw;            // [KD*KH*KW][Cin][Cout], PRE-ZEROED; partial sums are added atomically
+  int N, D, H, W, Cin;
+  int Do, Ho, Wo, Cout;
+  int pd, ph, pw;
+};
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;

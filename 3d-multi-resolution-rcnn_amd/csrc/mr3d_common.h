@@ -10,6 +10,7 @@
 
 static inline hipStream_t mr3d_stream(mr3d_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// hipGetLastError() also clears the sticky error, so a failed call does not poison the next one
 static inline int mr3d_launch_status() {
   return hipGetLastError() == hipSuccess ? MR3D_OK : MR3D_ERR_LAUNCH;
 }

@@ -91,6 +91,28 @@ int mr3d_roi_align3d_backward(const float *top_grad, const float *rois, int num_
                               float spatial_scale, float spatial_scale_depth, int sample_num,
                               int layout, int flags, float *bottom_grad, mr3d_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * conv3d forward (+ fused epilogue) -- replaces the torch.nn.Conv3d / cuDNN calls on the reference's
+ * backbone-neck path and the elementwise ops that follow them:
+ *   mmdet/models/backbones/resnet3d.py:126,139,173,251,398 (Conv3d), :198-226 (norm, ReLU, residual add);
+ *   mmdet/models/utils/conv_module3d.py:34; mmdet/models/necks/fpn3d.py:99-108 (lateral + nearest-upsample add).
+ * Layout: activations NDHWC fp32 (channels_last_3d), weights packed [kd*kh*kw][Cin][Cout].
+ * y = act( conv(x, w) + shift[co] + add1 + add2 + nearest_up(up) ), act = ReLU if relu; then, if mask,
+ * y = mask > 0 ? y : 0  (the ReLU backward of a data-gradient call: dgrad = conv with flipped,
+ * transposed weights).  Output size: floor((in + 2*pad - k)/stride) + 1 per axis.
+ * Supported here: cubic kernels 1 / 3 (stride 1 or 2, Cin % 16 == 0) and 7 (stride (1,2,2), Cin == 4,
+ * i.e. the 3-channel stem zero-padded to 4); Cout % 16 == 0.  Anything else: MR3D_ERR_UNSUPPORTED.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  const float *x; const float *w; float *y;
+  const float *shift; const float *add1; const float *add2; const float *up; const float *mask;
+  int n, d, h, w_in, cin, cout;
+  int kd, kh, kw, sd, sh, sw, pd, ph, pw;
+  int up_d, up_h, up_w;
+  int relu;
+} mr3d_conv3d_desc;
+int mr3d_conv3d_forward(const mr3d_conv3d_desc *desc, mr3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

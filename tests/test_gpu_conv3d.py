@@ -1,0 +1,94 @@
+"""GPU parity tests of the MFMA implicit-GEMM conv3d kernels against torch's CPU fp32 conv
+(the arithmetic the reference delegates to torch.nn.Conv3d)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4     # north-star tolerance for conv floating point
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+def _cl(x):      # NCDHW cpu tensor -> NDHWC device tensor
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def _check(got_ndhwc, ref_ncdhw, what):
+    got = got_ndhwc.permute(0, 4, 1, 2, 3).cpu()
+    scale = ref_ncdhw.abs().max().item()
+    err = (got - ref_ncdhw).abs().max().item()
+    assert err <= RTOL * scale, f'{what}: max err {err:.3e} vs scale {scale:.3e}'
+
+
+CASES = [
+    # (Cin, Cout, k, stride, pad, (D,H,W))
+    (16, 16, 1, (1, 1, 1), 0, (5, 9, 11)),
+    (16, 64, 1, (1, 1, 1), 0, (4, 8, 8)),
+    (64, 16, 1, (1, 1, 1), 0, (6, 10, 7)),
+    (64, 32, 1, (1, 1, 1), 0, (4, 9, 8)),
+    (32, 128, 1, (1, 1, 1), 0, (3, 8, 9)),
+    (128, 64, 1, (1, 1, 1), 0, (3, 5, 8)),
+    (512, 128, 1, (1, 1, 1), 0, (2, 4, 5)),
+    (64, 128, 1, (2, 2, 2), 0, (6, 10, 12)),
+    (16, 16, 3, (1, 1, 1), 1, (6, 10, 12)),
+    (32, 32, 3, (1, 1, 1), 1, (5, 9, 9)),
+    (64, 64, 3, (1, 1, 1), 1, (8, 16, 17)),
+    (128, 128, 3, (1, 1, 1), 1, (3, 6, 8)),
+    (32, 32, 3, (2, 2, 2), 1, (8, 16, 14)),
+    (64, 64, 3, (2, 2, 2), 1, (7, 11, 9)),
+    (4, 16, 7, (1, 2, 2), 3, (6, 20, 24)),
+]
+
+
+@pytest.mark.parametrize('cin,cout,k,stride,pad,dhw', CASES)
+def test_conv3d_forward_plain(dev, cin, cout, k, stride, pad, dhw):
+    from mr3d_amd import _hip
+    g = torch.Generator().manual_seed(cin * 1000 + cout + k)
+    x = torch.randn((2, cin) + dhw, generator=g)
+    w = torch.randn((cout, cin, k, k, k), generator=g) / np.sqrt(cin * k ** 3)
+    ref = F.conv3d(x, w, None, stride, pad)
+    y = _hip.conv3d_forward(_cl(x).to(dev), _hip.pack_conv_weight(w).to(dev), (k,) * 3, stride, (pad,) * 3)
+    assert tuple(y.shape) == (2,) + tuple(ref.shape[2:]) + (cout,)
+    _check(y, ref, 'plain')
+
+
+def test_conv3d_forward_fused_epilogue(dev):
+    from mr3d_amd import _hip
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn((1, 64, 6, 10, 12), generator=g)
+    w = torch.randn((64, 64, 3, 3, 3), generator=g) / np.sqrt(64 * 27)
+    shift = torch.randn(64, generator=g)
+    add1 = torch.randn((1, 64, 6, 10, 12), generator=g)
+    add2 = torch.randn((1, 64, 6, 10, 12), generator=g)
+    up = torch.randn((1, 64, 3, 5, 6), generator=g)
+    mask = torch.randn((1, 64, 6, 10, 12), generator=g)
+    conv = F.conv3d(x, w, shift, 1, 1)
+    ref = torch.relu(conv + add1 + add2 + F.interpolate(up, size=(6, 10, 12), mode='nearest'))
+    y = _hip.conv3d_forward(_cl(x).to(dev), _hip.pack_conv_weight(w).to(dev), (3, 3, 3), (1, 1, 1), (1, 1, 1),
+                            shift=shift.to(dev), add1=_cl(add1).to(dev), add2=_cl(add2).to(dev), up=_cl(up).to(dev),
+                            relu=True)
+    _check(y, ref, 'fused relu')
+    ref2 = (conv + add1) * (mask > 0)
+    y2 = _hip.conv3d_forward(_cl(x).to(dev), _hip.pack_conv_weight(w).to(dev), (3, 3, 3), (1, 1, 1), (1, 1, 1),
+                             shift=shift.to(dev), add1=_cl(add1).to(dev), mask=_cl(mask).to(dev))
+    _check(y2, ref2, 'fused mask')
+    # odd upsample ratio (5 -> 3 style sizes as F.interpolate(size=...) sees them in FPN3D)
+    up3 = torch.randn((1, 64, 2, 3, 5), generator=g)
+    ref3 = conv + F.interpolate(up3, size=(6, 10, 12), mode='nearest')
+    y3 = _hip.conv3d_forward(_cl(x).to(dev), _hip.pack_conv_weight(w).to(dev), (3, 3, 3), (1, 1, 1), (1, 1, 1),
+                             shift=shift.to(dev), up=_cl(up3).to(dev))
+    _check(y3, ref3, 'fused upsample odd')
+
+
+def test_conv3d_unsupported_is_loud(dev):
+    from mr3d_amd import _hip
+    x = torch.zeros((1, 2, 4, 4, 12), device=dev)      # Cin = 12
+    w = torch.zeros((1, 12, 16), device=dev)
+    with pytest.raises(_hip.Mr3dError):
+        _hip.conv3d_forward(x, w, (1, 1, 1), (1, 1, 1), (0, 0, 0))
