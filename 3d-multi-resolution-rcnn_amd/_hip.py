@@ -177,3 +177,28 @@ def conv3d_forward(x, w_packed, k, stride, pad, shift=None, add1=None, add2=None
         st = lib().mr3d_conv3d_forward(ctypes.byref(d), stream_ptr(x.device))
     check(st, 'mr3d_conv3d_forward')
     return y
+
+
+class Conv3dWgradDesc(ctypes.Structure):
+    """mr3d_conv3d_wgrad_desc (include/mr3d.h)"""
+    _fields_ = [(n, ctypes.c_void_p) for n in ('x', 'dy', 'dw')] + \
+               [(n, ctypes.c_int) for n in ('n', 'd', 'h', 'w_in', 'cin', 'cout', 'kd', 'kh', 'kw', 'sd', 'sh', 'sw',
+                                            'pd', 'ph', 'pw')]
+
+
+def conv3d_wgrad(x, dy, dw_packed, k, stride, pad):
+    """dw_packed [taps,Cin,Cout] += wgrad(x [N,D,H,W,Cin], dy [N,Do,Ho,Wo,Cout]); dw must be pre-zeroed."""
+    assert x.is_cuda and x.is_contiguous() and dy.is_contiguous() and dw_packed.is_contiguous()
+    cout = dw_packed.size(2)
+    assert tuple(dy.shape) == tuple(conv3d_out_shape(x.shape, cout, k, stride, pad))
+    assert dw_packed.size(0) == k[0] * k[1] * k[2] and dw_packed.size(1) == x.size(4)
+    d = Conv3dWgradDesc()
+    d.x, d.dy, d.dw = x.data_ptr(), dy.data_ptr(), dw_packed.data_ptr()
+    d.n, d.d, d.h, d.w_in, d.cin, d.cout = x.size(0), x.size(1), x.size(2), x.size(3), x.size(4), cout
+    d.kd, d.kh, d.kw = k
+    d.sd, d.sh, d.sw = stride
+    d.pd, d.ph, d.pw = pad
+    with torch.cuda.device(x.device):
+        st = lib().mr3d_conv3d_wgrad(ctypes.byref(d), stream_ptr(x.device))
+    check(st, 'mr3d_conv3d_wgrad')
+    return dw_packed

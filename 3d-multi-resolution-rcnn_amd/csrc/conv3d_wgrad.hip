@@ -1,0 +1,233 @@
+// conv3d weight gradient on the fp32 matrix cores of gfx950.
+//
+//   dw[tap][ci][co] = sum over (n, output position p) of x[n, p*stride + tap - pad][ci] * dy[n, p][co]
+//
+// the wgrad half of the autograd backward of torch.nn.Conv3d at the reference's call sites
+// (mmdet/models/backbones/resnet3d.py:126,139,173,251,398; utils/conv_module3d.py:34).
+//
+// GEMM view per tap: M = Cin (a chunk of CC channels), N = Cout, K = output positions -- the long
+// dimension, so every workgroup walks many 256-position tiles and keeps its accumulators in
+// registers the whole time; one fp32 atomic pass at the end adds them into dw (few workgroups, so
+// atomic bytes are tiny next to the MFMA work).
+//   * per tile the x halo block [halo position][CC] and the dy tile [position][NB] are staged in LDS
+//     (the same halo block serves all taps: a tap is a constant LDS offset);
+//   * v_mfma_f32_16x16x4_f32: A[i = ci][k = 4 consecutive positions], B[k][j = co];
+//   * the 4 waves split the TAPS (each wave owns every 4th tap with its own accumulators and streams
+//     all 256 positions); a pointwise conv (1 tap) splits the POSITIONS across waves instead;
+//   * the 7x7x7 stem (Cin = 3 padded to 4) merges (kw, ci) into the GEMM row: with channels innermost
+//     and no row padding, row i = kw*4 + ci of tap group (kd, kh) is simply halo_float[base + i],
+//     so a 28(32)-row M dimension exists even though Cin is 4.
+#include "conv3d.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+template <int KD_, int KH_, int KW_, int SD_, int SH_, int SW_, int CC_, int NB_, bool MERGEW_, int TD_ = 4>
+struct WgCfg {
+  static constexpr int KD = KD_, KH = KH_, KW = KW_, SD = SD_, SH = SH_, SW = SW_, CC = CC_, NB = NB_;
+  static constexpr bool MERGEW = MERGEW_;
+  static constexpr int TD = TD_, TH = 8, TW = 8, M = TD * 64;
+  static constexpr bool PW1 = (KD == 1 && KH == 1 && KW == 1);
+  static constexpr int LSD = PW1 ? 1 : SD, LSH = PW1 ? 1 : SH, LSW = PW1 ? 1 : SW;
+  static constexpr int GSD = PW1 ? SD : 1, GSH = PW1 ? SH : 1, GSW = PW1 ? SW : 1;
+  static constexpr int HD = (TD - 1) * LSD + KD, HH = (TH - 1) * LSH + KH, HW = (TW - 1) * LSW + KW;
+  static constexpr int HP = HD * HH * HW;
+  static constexpr int ROW = MERGEW ? CC : CC + 1;
+  static constexpr int DROW = NB + 1;
+  static constexpr int XF = HP * ROW + (MERGEW ? 32 : 0);   // merged rows of the last halo position read past it
+  static constexpr int LDS_BYTES = (XF + M * DROW) * 4;
+  static constexpr int MROWS = MERGEW ? 32 : CC;
+  static constexpr int MT = MROWS / 16, NT = NB / 16;
+  static constexpr int TAPG = MERGEW ? KD * KH : KD * KH * KW;   // accumulator groups
+  static constexpr int TPW = PW1 ? 1 : (TAPG + 3) / 4;           // tap groups per wave
+  static_assert(!MERGEW || CC == 4, "kw-merge needs 4 channels, unpadded rows");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+template <class C>
+__global__ __launch_bounds__(kThreads) void conv3d_wgrad_kernel(Conv3dWgradArgs p, int tiles_d, int tiles_h, int tiles_w) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *xh = lds;
+  float *dyt = lds + C::XF;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  const int c0 = blockIdx.y * C::CC;
+  const int n0 = blockIdx.z * C::NB;
+  const int num_tiles = p.N * tiles_d * tiles_h * tiles_w;
+
+  f32x4 acc[C::TPW][C::MT][C::NT];
+#pragma unroll
+  for (int t = 0; t < C::TPW; ++t)
+    for (int mt = 0; mt < C::MT; ++mt)
+      for (int nt = 0; nt < C::NT; ++nt) acc[t][mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // LDS offset of each of this wave's tap groups (wave-uniform)
+  int tapoff[C::TPW];
+#pragma unroll
+  for (int t = 0; t < C::TPW; ++t) {
+    int g = t * 4 + wave;
+    if (g >= C::TAPG) g = C::TAPG - 1;          // surplus slot: recomputes the last group, result dropped
+    if (C::MERGEW) {
+      const int kd = g / C::KH, kh = g % C::KH;
+      tapoff[t] = ((kd * C::HH + kh) * C::HW) * C::ROW;
+    } else {
+      const int kw = g % C::KW, kh = (g / C::KW) % C::KH, kd = g / (C::KW * C::KH);
+      tapoff[t] = ((kd * C::HH + kh) * C::HW + kw) * C::ROW;
+    }
+  }
+
+  for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
+    int b = tile;
+    const int tw_i = b % tiles_w; b /= tiles_w;
+    const int th_i = b % tiles_h; b /= tiles_h;
+    const int td_i = b % tiles_d; b /= tiles_d;
+    const int n = b;
+    const int od0 = td_i * C::TD, oh0 = th_i * C::TH, ow0 = tw_i * C::TW;
+    const int id0 = od0 * C::SD - p.pd, ih0 = oh0 * C::SH - p.ph, iw0 = ow0 * C::SW - p.pw;
+    __syncthreads();
+    // ---- stage x halo block (CC channels)
+    constexpr int Q = C::CC / 4;
+    for (int it = tid; it < C::HP * Q; it += kThreads) {
+      const int pos = it / Q, q = it - pos * Q;
+      const int hw = pos % C::HW, hh = (pos / C::HW) % C::HH, hd = pos / (C::HW * C::HH);
+      const int id = id0 + hd * C::GSD, ih = ih0 + hh * C::GSH, iw = iw0 + hw * C::GSW;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
+        v = *reinterpret_cast<const float4 *>(p.x + ((((size_t)n * p.D + id) * p.H + ih) * p.W + iw) * p.Cin + c0 + q * 4);
+      float *d = xh + pos * C::ROW + q * 4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    if (C::MERGEW)
+      for (int it = tid; it < 32; it += kThreads) xh[C::HP * C::ROW + it] = 0.f;
+    // ---- stage dy tile [256][NB] (zeros outside the output volume)
+    constexpr int QN = C::NB / 4;
+    for (int it = tid; it < C::M * QN; it += kThreads) {
+      const int m = it / QN, q = it - m * QN;
+      const int tw = m % C::TW, th = (m / C::TW) % C::TH, td = m / (C::TW * C::TH);
+      const int od = od0 + td, oh = oh0 + th, ow = ow0 + tw;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (od < p.Do && oh < p.Ho && ow < p.Wo)
+        v = *reinterpret_cast<const float4 *>(p.dy + ((((size_t)n * p.Do + od) * p.Ho + oh) * p.Wo + ow) * p.Cout + n0 + q * 4);
+      float *d = dyt + m * C::DROW + q * 4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+
+    // ---- K loop: 4 positions per MFMA
+    constexpr int KSTEPS = C::M / 4;
+    constexpr int KPW = C::PW1 ? KSTEPS / 4 : KSTEPS;       // pointwise: waves split the positions
+    const int kk0 = C::PW1 ? wave * KPW : 0;
+#pragma unroll 2
+    for (int kq = 0; kq < KPW; ++kq) {
+      const int m = (kk0 + kq) * 4 + lk;
+      const int tw = m % C::TW, th = (m / C::TW) % C::TH, td = m / (C::TW * C::TH);
+      const int hp = (((td * C::LSD) * C::HH + th * C::LSH) * C::HW + tw * C::LSW) * C::ROW + li;
+      float bf[C::NT];
+#pragma unroll
+      for (int nt = 0; nt < C::NT; ++nt) bf[nt] = dyt[m * C::DROW + nt * 16 + li];
+#pragma unroll
+      for (int t = 0; t < C::TPW; ++t) {
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt) {
+          const float a = xh[hp + tapoff[t] + mt * 16];
+#pragma unroll
+          for (int nt = 0; nt < C::NT; ++nt)
+            acc[t][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf[nt], acc[t][mt][nt], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- add the partial sums into dw[tap][ci][co]
+#pragma unroll
+  for (int t = 0; t < C::TPW; ++t) {
+    const int g = t * 4 + wave;
+    if (!C::PW1 && g >= C::TAPG) continue;
+#pragma unroll
+    for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = mt * 16 + lk * 4 + r;
+          const int co = n0 + nt * 16 + li;
+          size_t idx;
+          if (C::MERGEW) {
+            const int kw = row >> 2, ci = row & 3;
+            if (kw >= C::KW) continue;
+            idx = ((size_t)(g * C::KW + kw) * p.Cin + ci) * p.Cout + co;
+          } else {
+            idx = ((size_t)(C::PW1 ? 0 : g) * p.Cin + c0 + row) * p.Cout + co;
+          }
+          atomicAdd(p.dw + idx, acc[t][mt][nt][r]);
+        }
+  }
+}
+
+template <class C>
+int launch_wgrad(const Conv3dWgradArgs &a, hipStream_t stream) {
+  const int tiles_d = (a.Do + C::TD - 1) / C::TD, tiles_h = (a.Ho + C::TH - 1) / C::TH, tiles_w = (a.Wo + C::TW - 1) / C::TW;
+  const int num_tiles = a.N * tiles_d * tiles_h * tiles_w;
+  static bool attr_done = false;
+  if (!attr_done && C::LDS_BYTES > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3d_wgrad_kernel<C>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess) {
+      (void)hipGetLastError();
+      return MR3D_ERR_LAUNCH;
+    }
+    attr_done = true;
+  }
+  const int chunks = a.Cin / C::CC, ntiles = a.Cout / C::NB;
+  int gx = 512 / (chunks * ntiles);      // ~2 workgroups per CU in total
+  if (gx < 1) gx = 1;
+  if (gx > num_tiles) gx = num_tiles;
+  dim3 grid((unsigned)gx, (unsigned)chunks, (unsigned)ntiles);
+  conv3d_wgrad_kernel<C><<<grid, kThreads, C::LDS_BYTES, stream>>>(a, tiles_d, tiles_h, tiles_w);
+  return mr3d_launch_status();
+}
+
+template <int K, int SD, int SH, int SW, int CC, int TD = 4>
+int dispatch_wg(const Conv3dWgradArgs &a, int nb, hipStream_t stream) {
+  switch (nb) {
+    case 16: return launch_wgrad<WgCfg<K, K, K, SD, SH, SW, CC, 16, false, TD>>(a, stream);
+    case 32: return launch_wgrad<WgCfg<K, K, K, SD, SH, SW, CC, 32, false, TD>>(a, stream);
+    case 64: return launch_wgrad<WgCfg<K, K, K, SD, SH, SW, CC, 64, false, TD>>(a, stream);
+  }
+  return MR3D_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" int mr3d_conv3d_wgrad(const mr3d_conv3d_wgrad_desc *d, mr3d_stream_t stream_) {
+  if (!d || !d->x || !d->dy || !d->dw) return MR3D_ERR_INVALID_ARG;
+  if (d->kd != d->kh || d->kh != d->kw) return MR3D_ERR_UNSUPPORTED;
+  Conv3dWgradArgs a;
+  a.x = d->x; a.dy = d->dy; a.dw = d->dw;
+  a.N = d->n; a.D = d->d; a.H = d->h; a.W = d->w_in; a.Cin = d->cin; a.Cout = d->cout;
+  a.pd = d->pd; a.ph = d->ph; a.pw = d->pw;
+  a.Do = (d->d + 2 * d->pd - d->kd) / d->sd + 1;
+  a.Ho = (d->h + 2 * d->ph - d->kh) / d->sh + 1;
+  a.Wo = (d->w_in + 2 * d->pw - d->kw) / d->sw + 1;
+  if (a.N <= 0 || a.Do <= 0 || a.Ho <= 0 || a.Wo <= 0) return MR3D_ERR_INVALID_ARG;
+  const int nb = a.Cout % 64 == 0 ? 64 : (a.Cout % 32 == 0 ? 32 : (a.Cout % 16 == 0 ? 16 : 0));
+  if (!nb) return MR3D_ERR_UNSUPPORTED;
+  hipStream_t stream = mr3d_stream(stream_);
+  const int k = d->kd, s = d->sd * 100 + d->sh * 10 + d->sw;
+  if (k == 1 && s == 111) {
+    if (a.Cin % 64 == 0) return dispatch_wg<1, 1, 1, 1, 64>(a, nb, stream);
+    if (a.Cin % 32 == 0) return dispatch_wg<1, 1, 1, 1, 32>(a, nb, stream);
+    if (a.Cin % 16 == 0) return dispatch_wg<1, 1, 1, 1, 16>(a, nb, stream);
+  } else if (k == 1 && s == 222) {
+    if (a.Cin % 64 == 0) return dispatch_wg<1, 2, 2, 2, 64>(a, nb, stream);
+    if (a.Cin % 16 == 0) return dispatch_wg<1, 2, 2, 2, 16>(a, nb, stream);
+  } else if (k == 3 && s == 111) {
+    if (a.Cin % 16 == 0) return dispatch_wg<3, 1, 1, 1, 16>(a, nb, stream);
+  } else if (k == 3 && s == 222) {
+    if (a.Cin % 16 == 0) return dispatch_wg<3, 2, 2, 2, 16, 1>(a, nb, stream);   // 3x17x17 halo: one output plane per tile
+  } else if (k == 7 && s == 122) {
+    if (a.Cin == 4 && nb == 16) return launch_wgrad<WgCfg<7, 7, 7, 1, 2, 2, 4, 16, true>>(a, stream);
+  }
+  return MR3D_ERR_UNSUPPORTED;
+}

@@ -113,6 +113,21 @@ typedef struct {
 } mr3d_conv3d_desc;
 int mr3d_conv3d_forward(const mr3d_conv3d_desc *desc, mr3d_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * conv3d weight gradient -- the wgrad half of autograd's backward of the torch.nn.Conv3d calls above
+ * (reference: loss.backward() in mmdet/core/utils/dist_utils.py:52-53 reaching the Conv3d modules).
+ *   dw[tap][ci][co] += sum_{n,p} x[n, p*stride + tap - pad][ci] * dy[n, p][co]
+ * x, dy NDHWC fp32; dw packed [kd*kh*kw][Cin][Cout], PRE-ZEROED by the caller (partial sums of the
+ * workgroups are added with fp32 atomics: last-bit nondeterministic like any atomic reduction).
+ * Same kernel-size / stride / channel support as mr3d_conv3d_forward.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  const float *x; const float *dy; float *dw;
+  int n, d, h, w_in, cin, cout;
+  int kd, kh, kw, sd, sh, sw, pd, ph, pw;
+} mr3d_conv3d_wgrad_desc;
+int mr3d_conv3d_wgrad(const mr3d_conv3d_wgrad_desc *desc, mr3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

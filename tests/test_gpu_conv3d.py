@@ -92,3 +92,20 @@ def test_conv3d_unsupported_is_loud(dev):
     w = torch.zeros((1, 12, 16), device=dev)
     with pytest.raises(_hip.Mr3dError):
         _hip.conv3d_forward(x, w, (1, 1, 1), (1, 1, 1), (0, 0, 0))
+
+
+@pytest.mark.parametrize('cin,cout,k,stride,pad,dhw', CASES)
+def test_conv3d_wgrad(dev, cin, cout, k, stride, pad, dhw):
+    from mr3d_amd import _hip
+    g = torch.Generator().manual_seed(cin * 1000 + cout + k + 7)
+    x = torch.randn((2, cin) + dhw, generator=g)
+    w = torch.zeros((cout, cin, k, k, k), requires_grad=True)
+    y = F.conv3d(x, w, None, stride, pad)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    ref = _hip.pack_conv_weight(w.grad)                     # [taps, Cin, Cout]
+    dw = torch.zeros(ref.shape, device=dev)
+    _hip.conv3d_wgrad(_cl(x).to(dev), _cl(dy).to(dev), dw, (k,) * 3, stride, (pad,) * 3)
+    err = (dw.cpu() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= RTOL * scale, f'wgrad max err {err:.3e} vs scale {scale:.3e}'
