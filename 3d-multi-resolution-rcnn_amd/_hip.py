@@ -132,7 +132,8 @@ class Conv3dDesc(ctypes.Structure):
     """mr3d_conv3d_desc (include/mr3d.h)"""
     _fields_ = [(n, ctypes.c_void_p) for n in ('x', 'w', 'y', 'shift', 'add1', 'add2', 'up', 'mask')] + \
                [(n, ctypes.c_int) for n in ('n', 'd', 'h', 'w_in', 'cin', 'cout', 'kd', 'kh', 'kw', 'sd', 'sh', 'sw',
-                                            'pd', 'ph', 'pw', 'up_d', 'up_h', 'up_w', 'relu')]
+                                            'pd', 'ph', 'pw', 'up_d', 'up_h', 'up_w', 'relu',
+                                            'ys_d', 'ys_h', 'ys_w', 'y_d', 'y_h', 'y_w')]
 
 
 def _opt(t):
@@ -152,16 +153,18 @@ def conv3d_out_shape(x_shape, cout, k, stride, pad):
 
 
 def conv3d_forward(x, w_packed, k, stride, pad, shift=None, add1=None, add2=None, up=None, mask=None, relu=False,
-                   out=None):
+                   out=None, out_stride=None):
     """x: [N,D,H,W,Cin] contiguous (NDHWC); w_packed: [taps,Cin,Cout]; returns y [N,Do,Ho,Wo,Cout]."""
     assert x.is_cuda and x.is_contiguous() and x.dtype == torch.float32 and x.dim() == 5
     assert w_packed.is_contiguous() and w_packed.dim() == 3 and w_packed.size(1) == x.size(4)
     cout = w_packed.size(2)
     oshape = conv3d_out_shape(x.shape, cout, k, stride, pad)
     y = out if out is not None else torch.empty(oshape, dtype=torch.float32, device=x.device)
-    assert tuple(y.shape) == tuple(oshape) and y.is_contiguous()
+    if out_stride is None:
+        assert tuple(y.shape) == tuple(oshape)
+    assert y.is_contiguous()
     for t in (add1, add2, mask):
-        assert t is None or (tuple(t.shape) == tuple(oshape) and t.is_contiguous())
+        assert t is None or (tuple(t.shape) == tuple(y.shape) and t.is_contiguous())
     d = Conv3dDesc()
     d.x, d.w, d.y = x.data_ptr(), w_packed.data_ptr(), y.data_ptr()
     d.shift, d.add1, d.add2, d.up, d.mask = _opt(shift), _opt(add1), _opt(add2), _opt(up), _opt(mask)
@@ -173,6 +176,9 @@ def conv3d_forward(x, w_packed, k, stride, pad, shift=None, add1=None, add2=None
         assert up.is_contiguous() and up.size(4) == cout and up.size(0) == x.size(0)
         d.up_d, d.up_h, d.up_w = up.size(1), up.size(2), up.size(3)
     d.relu = int(bool(relu))
+    if out_stride is not None:
+        d.ys_d, d.ys_h, d.ys_w = out_stride
+        d.y_d, d.y_h, d.y_w = y.size(1), y.size(2), y.size(3)
     with torch.cuda.device(x.device):
         st = lib().mr3d_conv3d_forward(ctypes.byref(d), stream_ptr(x.device))
     check(st, 'mr3d_conv3d_forward')
@@ -181,19 +187,19 @@ def conv3d_forward(x, w_packed, k, stride, pad, shift=None, add1=None, add2=None
 
 class Conv3dWgradDesc(ctypes.Structure):
     """mr3d_conv3d_wgrad_desc (include/mr3d.h)"""
-    _fields_ = [(n, ctypes.c_void_p) for n in ('x', 'dy', 'dw')] + \
+    _fields_ = [(n, ctypes.c_void_p) for n in ('x', 'dy', 'dw', 'dbias')] + \
                [(n, ctypes.c_int) for n in ('n', 'd', 'h', 'w_in', 'cin', 'cout', 'kd', 'kh', 'kw', 'sd', 'sh', 'sw',
                                             'pd', 'ph', 'pw')]
 
 
-def conv3d_wgrad(x, dy, dw_packed, k, stride, pad):
+def conv3d_wgrad(x, dy, dw_packed, k, stride, pad, dbias=None):
     """dw_packed [taps,Cin,Cout] += wgrad(x [N,D,H,W,Cin], dy [N,Do,Ho,Wo,Cout]); dw must be pre-zeroed."""
     assert x.is_cuda and x.is_contiguous() and dy.is_contiguous() and dw_packed.is_contiguous()
     cout = dw_packed.size(2)
     assert tuple(dy.shape) == tuple(conv3d_out_shape(x.shape, cout, k, stride, pad))
     assert dw_packed.size(0) == k[0] * k[1] * k[2] and dw_packed.size(1) == x.size(4)
     d = Conv3dWgradDesc()
-    d.x, d.dy, d.dw = x.data_ptr(), dy.data_ptr(), dw_packed.data_ptr()
+    d.x, d.dy, d.dw, d.dbias = x.data_ptr(), dy.data_ptr(), dw_packed.data_ptr(), _opt(dbias)
     d.n, d.d, d.h, d.w_in, d.cin, d.cout = x.size(0), x.size(1), x.size(2), x.size(3), x.size(4), cout
     d.kd, d.kh, d.kw = k
     d.sd, d.sh, d.sw = stride
@@ -202,3 +208,53 @@ def conv3d_wgrad(x, dy, dw_packed, k, stride, pad):
         st = lib().mr3d_conv3d_wgrad(ctypes.byref(d), stream_ptr(x.device))
     check(st, 'mr3d_conv3d_wgrad')
     return dw_packed
+
+
+# --------------------------------------------------------------------------------------------
+# plan records (mr3d_op / mr3d_layer_desc in include/mr3d.h)
+OP_CONV_FWD, OP_CONV_WGRAD, OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_ZERO_STUFF2, OP_UPSAMPLE_ADJ = 1, 2, 3, 4, 5, 6
+OP_SUBSAMPLE_FWD, OP_SUBSAMPLE_BWD, OP_VOLUME_PACK, OP_MEMSET0, OP_AXPY, OP_PREP_WEIGHTS, OP_FINISH_GRADS = 7, 8, 9, 10, 11, 12, 13
+
+
+class Op(ctypes.Structure):
+    _fields_ = [('kind', ctypes.c_int32), ('i', ctypes.c_int32 * 27), ('f', ctypes.c_float * 4), ('p', ctypes.c_void_p * 8)]
+
+
+class LayerDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_longlong) for n in ('w_off', 'gamma_off', 'beta_off', 'mean_off', 'var_off', 'bias_off',
+                                                 'wf_off', 'wb_off', 'shift_off', 'scale_off', 'dwraw_off', 'dbias_off')] + \
+               [('co', ctypes.c_int), ('ci', ctypes.c_int), ('ci_pad', ctypes.c_int), ('taps', ctypes.c_int),
+                ('eps', ctypes.c_float), ('reserved', ctypes.c_int)]
+
+
+def make_op(kind, ptrs=(), ints=(), alpha=0.0):
+    o = Op()
+    o.kind = kind
+    for k, v in enumerate(ptrs):
+        o.p[k] = None if v is None else (v.data_ptr() if hasattr(v, 'data_ptr') else int(v))
+    for k, v in enumerate(ints):
+        o.i[k] = int(v)
+    o.f[0] = float(alpha)
+    return o
+
+
+def split64(v):
+    v = int(v)
+    lo, hi = v & 0xFFFFFFFF, (v >> 32) & 0xFFFFFFFF
+    return (lo - (1 << 32) if lo >= (1 << 31) else lo), (hi - (1 << 32) if hi >= (1 << 31) else hi)
+
+
+class Plan:
+    """A list of mr3d_op records executed by one mr3d_plan_run call on the current stream."""
+
+    def __init__(self, ops):
+        self.n = len(ops)
+        self.array = (Op * self.n)(*ops)
+        self._failed = ctypes.c_int(-1)
+
+    def run(self, device=None):
+        st = lib().mr3d_plan_run(self.array, ctypes.c_int(self.n), ctypes.byref(self._failed), stream_ptr(device))
+        if st != OK:
+            k = self._failed.value
+            raise Mr3dError(f'mr3d_plan_run: op #{k} (kind {self.array[k].kind}) failed: '
+                            f'{lib().mr3d_status_string(int(st)).decode()}')

@@ -1,0 +1,357 @@
+// HBM-bound helper kernels of the backbone/neck path (all activations NDHWC fp32, C % 4 == 0,
+// 16-byte vector accesses along C):
+//   maxpool 3x3x3 / stride 2 / pad 1 forward + backward   (resnet3d.py:409 nn.MaxPool3d, :471)
+//   zero-stuffing for stride-2 data gradients, nearest-upsample adjoint (fpn3d.py:106-108 backward),
+//   stride-2 subsample forward/backward (fpn3d.py:121-123: F.max_pool3d(x, 1, stride=2)),
+//   NCDHW(3 ch) -> NDHWC(4 ch) volume repack for the stem,
+//   table-driven weight preparation (BN-eval folding + repack) and gradient finishing.
+#include "mr3d_common.h"
+
+namespace {
+
+constexpr int kT = 256;
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+
+// ---------------------------------------------------------------- maxpool k3 s2 p1
+// scan order (kd, kh, kw); the FIRST maximum wins (torch: `val > maxval`), its tap id is stored.
+__global__ __launch_bounds__(kT) void maxpool_fwd_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                        uint32_t *__restrict__ idx, int N, int D, int H, int W, int C,
+                                                        int Do, int Ho, int Wo) {
+  const int C4 = C / 4;
+  const long long total = (long long)N * Do * Ho * Wo * C4;
+  for (long long t = (long long)blockIdx.x * kT + threadIdx.x; t < total; t += (long long)gridDim.x * kT) {
+    const int c4 = (int)(t % C4);
+    long long r = t / C4;
+    const int ow = (int)(r % Wo); r /= Wo;
+    const int oh = (int)(r % Ho); r /= Ho;
+    const int od = (int)(r % Do);
+    const int n = (int)(r / Do);
+    float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    uint32_t bi0 = 0, bi1 = 0, bi2 = 0, bi3 = 0;
+    for (int kd = 0; kd < 3; ++kd) {
+      const int id = od * 2 - 1 + kd;
+      if ((unsigned)id >= (unsigned)D) continue;
+      for (int kh = 0; kh < 3; ++kh) {
+        const int ih = oh * 2 - 1 + kh;
+        if ((unsigned)ih >= (unsigned)H) continue;
+        for (int kw = 0; kw < 3; ++kw) {
+          const int iw = ow * 2 - 1 + kw;
+          if ((unsigned)iw >= (unsigned)W) continue;
+          const float4 v = ld4(x + ((((size_t)n * D + id) * H + ih) * W + iw) * C + c4 * 4);
+          const uint32_t tap = (kd * 3 + kh) * 3 + kw;
+          if (v.x > best.x) { best.x = v.x; bi0 = tap; }
+          if (v.y > best.y) { best.y = v.y; bi1 = tap; }
+          if (v.z > best.z) { best.z = v.z; bi2 = tap; }
+          if (v.w > best.w) { best.w = v.w; bi3 = tap; }
+        }
+      }
+    }
+    st4(y + (size_t)t * 4, best);
+    idx[t] = bi0 | (bi1 << 8) | (bi2 << 16) | (bi3 << 24);
+  }
+}
+
+// dx[i] = relu'(xact[i]) * sum over the (<= 8) windows o that cover i and whose argmax is i, of dy[o]
+__global__ __launch_bounds__(kT) void maxpool_bwd_kernel(const float *__restrict__ dy, const uint32_t *__restrict__ idx,
+                                                        const float *__restrict__ xact, float *__restrict__ dx, int N,
+                                                        int D, int H, int W, int C, int Do, int Ho, int Wo) {
+  const int C4 = C / 4;
+  const long long total = (long long)N * D * H * W * C4;
+  for (long long t = (long long)blockIdx.x * kT + threadIdx.x; t < total; t += (long long)gridDim.x * kT) {
+    const int c4 = (int)(t % C4);
+    long long r = t / C4;
+    const int iw = (int)(r % W); r /= W;
+    const int ih = (int)(r % H); r /= H;
+    const int id = (int)(r % D);
+    const int n = (int)(r / D);
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    // windows along one axis: i = 2o - 1 + k, k in {0,1,2}  ->  o in {(i+1)/2 (k = i+1-2o)} and, for odd i, (i-1)/2
+    for (int od = (id + 1) / 2; od >= (id + 1) / 2 - ((id & 1) ? 1 : 0); --od) {
+      if ((unsigned)od >= (unsigned)Do) continue;
+      const int kd = id + 1 - 2 * od;
+      for (int oh = (ih + 1) / 2; oh >= (ih + 1) / 2 - ((ih & 1) ? 1 : 0); --oh) {
+        if ((unsigned)oh >= (unsigned)Ho) continue;
+        const int kh = ih + 1 - 2 * oh;
+        for (int ow = (iw + 1) / 2; ow >= (iw + 1) / 2 - ((iw & 1) ? 1 : 0); --ow) {
+          if ((unsigned)ow >= (unsigned)Wo) continue;
+          const int kw = iw + 1 - 2 * ow;
+          const uint32_t tap = (kd * 3 + kh) * 3 + kw;
+          const size_t o = ((((size_t)n * Do + od) * Ho + oh) * Wo + ow) * C4 + c4;
+          const uint32_t ix = idx[o];
+          const float4 v = ld4(dy + o * 4);
+          if ((ix & 255u) == tap) g.x += v.x;
+          if (((ix >> 8) & 255u) == tap) g.y += v.y;
+          if (((ix >> 16) & 255u) == tap) g.z += v.z;
+          if ((ix >> 24) == tap) g.w += v.w;
+        }
+      }
+    }
+    if (xact) {
+      const float4 a = ld4(xact + (size_t)t * 4);
+      g.x = a.x > 0.f ? g.x : 0.f; g.y = a.y > 0.f ? g.y : 0.f; g.z = a.z > 0.f ? g.z : 0.f; g.w = a.w > 0.f ? g.w : 0.f;
+    }
+    st4(dx + (size_t)t * 4, g);
+  }
+}
+
+// ---------------------------------------------------------------- zero-stuffing: dst[2o] = src[o], else 0
+__global__ __launch_bounds__(kT) void zero_stuff_kernel(const float *__restrict__ src, float *__restrict__ dst, int N, int Do,
+                                                       int Ho, int Wo, int D, int H, int W, int C) {
+  const int C4 = C / 4;
+  const long long total = (long long)N * D * H * W * C4;
+  for (long long t = (long long)blockIdx.x * kT + threadIdx.x; t < total; t += (long long)gridDim.x * kT) {
+    const int c4 = (int)(t % C4);
+    long long r = t / C4;
+    const int iw = (int)(r % W); r /= W;
+    const int ih = (int)(r % H); r /= H;
+    const int id = (int)(r % D);
+    const int n = (int)(r / D);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!((id | ih | iw) & 1) && id / 2 < Do && ih / 2 < Ho && iw / 2 < Wo)
+      v = ld4(src + ((((size_t)n * Do + id / 2) * Ho + ih / 2) * Wo + iw / 2) * C + c4 * 4);
+    st4(dst + (size_t)t * 4, v);
+  }
+}
+
+// ---------------------------------------------------------------- nearest-upsample adjoint
+__device__ __forceinline__ int nearest_src(int dst, int in, int out) {
+  int s = (int)floorf((float)dst * ((float)in / (float)out));
+  return s < in - 1 ? s : in - 1;
+}
+// [lo, hi) = fine indices whose nearest source is u (nearest_src is monotone in dst)
+__device__ __forceinline__ void child_range(int u, int in, int out, int &lo, int &hi) {
+  int f = (int)(((long long)u * out) / in);
+  if (f > out - 1) f = out - 1;
+  while (f > 0 && nearest_src(f - 1, in, out) >= u) --f;
+  while (f < out && nearest_src(f, in, out) < u) ++f;
+  lo = f;
+  while (f < out && nearest_src(f, in, out) == u) ++f;
+  hi = f;
+}
+
+__global__ __launch_bounds__(kT) void upsample_adjoint_add_kernel(const float *__restrict__ gf, float *__restrict__ gc, int N,
+                                                                 int Df, int Hf, int Wf, int Dc, int Hc, int Wc, int C) {
+  const int C4 = C / 4;
+  const long long total = (long long)N * Dc * Hc * Wc * C4;
+  for (long long t = (long long)blockIdx.x * kT + threadIdx.x; t < total; t += (long long)gridDim.x * kT) {
+    const int c4 = (int)(t % C4);
+    long long r = t / C4;
+    const int uw = (int)(r % Wc); r /= Wc;
+    const int uh = (int)(r % Hc); r /= Hc;
+    const int ud = (int)(r % Dc);
+    const int n = (int)(r / Dc);
+    int d0, d1, h0, h1, w0, w1;
+    child_range(ud, Dc, Df, d0, d1);
+    child_range(uh, Hc, Hf, h0, h1);
+    child_range(uw, Wc, Wf, w0, w1);
+    float4 g = ld4(gc + (size_t)t * 4);
+    for (int d = d0; d < d1; ++d)
+      for (int h = h0; h < h1; ++h)
+        for (int w = w0; w < w1; ++w) {
+          const float4 v = ld4(gf + ((((size_t)n * Df + d) * Hf + h) * Wf + w) * C + c4 * 4);
+          g.x += v.x; g.y += v.y; g.z += v.z; g.w += v.w;
+        }
+    st4(gc + (size_t)t * 4, g);
+  }
+}
+
+// ---------------------------------------------------------------- stride-2 subsample (max_pool3d k=1 s=2)
+template <bool kBackward>
+__global__ __launch_bounds__(kT) void subsample2_kernel(const float *__restrict__ src, float *__restrict__ dst, int N, int D,
+                                                       int H, int W, int C, int Do, int Ho, int Wo) {
+  // forward: dst[o] = src[2o] (dst is the coarse grid); backward: dst[2o] += src[o] (dst is the fine grid)
+  const int C4 = C / 4;
+  const long long total = (long long)N * Do * Ho * Wo * C4;
+  for (long long t = (long long)blockIdx.x * kT + threadIdx.x; t < total; t += (long long)gridDim.x * kT) {
+    const int c4 = (int)(t % C4);
+    long long r = t / C4;
+    const int ow = (int)(r % Wo); r /= Wo;
+    const int oh = (int)(r % Ho); r /= Ho;
+    const int od = (int)(r % Do);
+    const int n = (int)(r / Do);
+    const size_t fine = ((((size_t)n * D + od * 2) * H + oh * 2) * W + ow * 2) * C + c4 * 4;
+    if (!kBackward) {
+      st4(dst + (size_t)t * 4, ld4(src + fine));
+    } else {
+      float4 a = ld4(dst + fine);
+      const float4 v = ld4(src + (size_t)t * 4);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+      st4(dst + fine, a);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- volume repack [N,3,D,H,W] -> [N,D,H,W,4]
+__global__ __launch_bounds__(kT) void ncdhw3_to_ndhwc4_kernel(const float *__restrict__ src, float *__restrict__ dst, int N,
+                                                             long long vox) {
+  const long long total = (long long)N * vox;
+  for (long long t = (long long)blockIdx.x * kT + threadIdx.x; t < total; t += (long long)gridDim.x * kT) {
+    const long long n = t / vox, v = t - n * vox;
+    const float *s = src + n * 3 * vox + v;
+    st4(dst + (size_t)t * 4, make_float4(s[0], s[vox], s[2 * vox], 0.f));
+  }
+}
+
+__global__ __launch_bounds__(kT) void axpy_kernel(float *__restrict__ dst, const float *__restrict__ src, float alpha,
+                                                 long long n4) {
+  for (long long t = (long long)blockIdx.x * kT + threadIdx.x; t < n4; t += (long long)gridDim.x * kT) {
+    float4 a = ld4(dst + t * 4);
+    const float4 b = ld4(src + t * 4);
+    a.x += alpha * b.x; a.y += alpha * b.y; a.z += alpha * b.z; a.w += alpha * b.w;
+    st4(dst + t * 4, a);
+  }
+}
+
+// ---------------------------------------------------------------- table-driven weight prep / grad finish
+__device__ __forceinline__ float layer_scale(const mr3d_layer_desc &L, const float *params, int co) {
+  if (L.gamma_off < 0) return 1.f;
+  return params[L.gamma_off + co] * (1.f / sqrtf(params[L.var_off + co] + L.eps));   // BN eval: gamma * invstd
+}
+
+// packed fwd weights wf[tap][ci_pad][co] = s[co] * W[co][ci][tap]; dgrad weights wb[taps-1-tap][co][ci_pad] = same;
+// shift[co] = beta - mean*s (BN) or bias or 0; scale[co] = s.
+__global__ __launch_bounds__(kT) void prep_weights_kernel(const mr3d_layer_desc *__restrict__ table,
+                                                         const float *__restrict__ params, float *__restrict__ packed) {
+  const mr3d_layer_desc L = table[blockIdx.y];
+  const int total = L.taps * L.ci_pad * L.co;
+  for (int e = blockIdx.x * kT + threadIdx.x; e < total; e += gridDim.x * kT) {
+    const int co = e % L.co, ci = (e / L.co) % L.ci_pad, tap = e / (L.co * L.ci_pad);
+    float v = 0.f;
+    if (ci < L.ci) v = layer_scale(L, params, co) * params[L.w_off + ((long long)co * L.ci + ci) * L.taps + tap];
+    packed[L.wf_off + e] = v;
+    if (L.wb_off >= 0) packed[L.wb_off + ((long long)(L.taps - 1 - tap) * L.co + co) * L.ci_pad + ci] = v;
+  }
+  if (blockIdx.x == 0)
+    for (int co = threadIdx.x; co < L.co; co += kT) {
+      const float s = layer_scale(L, params, co);
+      float sh = 0.f;
+      if (L.gamma_off >= 0) sh = params[L.beta_off + co] - params[L.mean_off + co] * s;
+      else if (L.bias_off >= 0) sh = params[L.bias_off + co];
+      packed[L.shift_off + co] = sh;
+      packed[L.scale_off + co] = s;
+    }
+}
+
+// grads[w] += s[co] * dwraw[tap][ci][co]   (dwraw = gradient w.r.t. the FOLDED weights)
+__global__ __launch_bounds__(kT) void finish_wgrads_kernel(const mr3d_layer_desc *__restrict__ table,
+                                                          const float *__restrict__ params,
+                                                          const float *__restrict__ scratch, float *__restrict__ grads) {
+  const mr3d_layer_desc L = table[blockIdx.y];
+  const int total = L.co * L.ci * L.taps;
+  for (int e = blockIdx.x * kT + threadIdx.x; e < total; e += gridDim.x * kT) {
+    const int tap = e % L.taps, ci = (e / L.taps) % L.ci, co = e / (L.taps * L.ci);
+    grads[L.w_off + e] += layer_scale(L, params, co) * scratch[L.dwraw_off + ((long long)tap * L.ci_pad + ci) * L.co + co];
+  }
+}
+
+// per output channel c (one wave each):  dot = sum_k W[c][k] * dwraw[k][c]  ( = sum_p dy*z )
+//   BN:   dgamma += invstd*(dot - mean*sumdy),  dbeta += sumdy        conv bias: dbias += sumdy
+__global__ __launch_bounds__(kT) void finish_affine_kernel(const mr3d_layer_desc *__restrict__ table,
+                                                          const float *__restrict__ params,
+                                                          const float *__restrict__ scratch, float *__restrict__ grads) {
+  const mr3d_layer_desc L = table[blockIdx.y];
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * (kT / 64) + (threadIdx.x >> 6);
+  if (c >= L.co) return;
+  const float sumdy = scratch[L.dbias_off + c];
+  if (L.gamma_off < 0) {
+    if (L.bias_off >= 0 && lane == 0) grads[L.bias_off + c] += sumdy;
+    return;
+  }
+  float dot = 0.f;
+  const int K = L.ci * L.taps;
+  for (int k = lane; k < K; k += 64) {
+    const int tap = k % L.taps, ci = k / L.taps;
+    dot += params[L.w_off + (long long)c * K + k] * scratch[L.dwraw_off + ((long long)tap * L.ci_pad + ci) * L.co + c];
+  }
+  for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+  if (lane == 0) {
+    const float invstd = 1.f / sqrtf(params[L.var_off + c] + L.eps);
+    grads[L.gamma_off + c] += invstd * (dot - params[L.mean_off + c] * sumdy);
+    grads[L.beta_off + c] += sumdy;
+  }
+}
+
+inline int grid_for(long long total) {
+  long long b = (total + kT - 1) / kT;
+  return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+}  // namespace
+
+extern "C" int mr3d_maxpool3d_forward(const float *x, float *y, uint32_t *argmax, int n, int d, int h, int w, int c,
+                                      mr3d_stream_t s) {
+  if (!x || !y || !argmax || c % 4) return MR3D_ERR_INVALID_ARG;
+  const int Do = (d - 1) / 2 + 1, Ho = (h - 1) / 2 + 1, Wo = (w - 1) / 2 + 1;
+  maxpool_fwd_kernel<<<grid_for((long long)n * Do * Ho * Wo * c / 4), kT, 0, mr3d_stream(s)>>>(x, y, argmax, n, d, h, w, c, Do,
+                                                                                          Ho, Wo);
+  return mr3d_launch_status();
+}
+
+extern "C" int mr3d_maxpool3d_backward(const float *dy, const uint32_t *argmax, const float *relu_of, float *dx, int n, int d,
+                                       int h, int w, int c, mr3d_stream_t s) {
+  if (!dy || !dx || !argmax || c % 4) return MR3D_ERR_INVALID_ARG;
+  const int Do = (d - 1) / 2 + 1, Ho = (h - 1) / 2 + 1, Wo = (w - 1) / 2 + 1;
+  maxpool_bwd_kernel<<<grid_for((long long)n * d * h * w * c / 4), kT, 0, mr3d_stream(s)>>>(dy, argmax, relu_of, dx, n, d, h, w,
+                                                                                         c, Do, Ho, Wo);
+  return mr3d_launch_status();
+}
+
+extern "C" int mr3d_zero_stuff2(const float *src, float *dst, int n, int do_, int ho, int wo, int d, int h, int w, int c,
+                                mr3d_stream_t s) {
+  if (!src || !dst || c % 4) return MR3D_ERR_INVALID_ARG;
+  zero_stuff_kernel<<<grid_for((long long)n * d * h * w * c / 4), kT, 0, mr3d_stream(s)>>>(src, dst, n, do_, ho, wo, d, h, w, c);
+  return mr3d_launch_status();
+}
+
+extern "C" int mr3d_upsample_nearest_adjoint_add(const float *grad_fine, float *grad_coarse, int n, int df, int hf, int wf,
+                                                 int dc, int hc, int wc, int c, mr3d_stream_t s) {
+  if (!grad_fine || !grad_coarse || c % 4) return MR3D_ERR_INVALID_ARG;
+  upsample_adjoint_add_kernel<<<grid_for((long long)n * dc * hc * wc * c / 4), kT, 0, mr3d_stream(s)>>>(grad_fine, grad_coarse, n,
+                                                                                                     df, hf, wf, dc, hc, wc, c);
+  return mr3d_launch_status();
+}
+
+extern "C" int mr3d_subsample2_forward(const float *x, float *y, int n, int d, int h, int w, int c, mr3d_stream_t s) {
+  if (!x || !y || c % 4) return MR3D_ERR_INVALID_ARG;
+  const int Do = (d - 1) / 2 + 1, Ho = (h - 1) / 2 + 1, Wo = (w - 1) / 2 + 1;
+  subsample2_kernel<false><<<grid_for((long long)n * Do * Ho * Wo * c / 4), kT, 0, mr3d_stream(s)>>>(x, y, n, d, h, w, c, Do, Ho, Wo);
+  return mr3d_launch_status();
+}
+
+extern "C" int mr3d_subsample2_backward_add(const float *dy, float *dx, int n, int d, int h, int w, int c, mr3d_stream_t s) {
+  if (!dy || !dx || c % 4) return MR3D_ERR_INVALID_ARG;
+  const int Do = (d - 1) / 2 + 1, Ho = (h - 1) / 2 + 1, Wo = (w - 1) / 2 + 1;
+  subsample2_kernel<true><<<grid_for((long long)n * Do * Ho * Wo * c / 4), kT, 0, mr3d_stream(s)>>>(dy, dx, n, d, h, w, c, Do, Ho, Wo);
+  return mr3d_launch_status();
+}
+
+extern "C" int mr3d_volume_to_ndhwc4(const float *ncdhw3, float *ndhwc4, int n, int d, int h, int w, mr3d_stream_t s) {
+  if (!ncdhw3 || !ndhwc4) return MR3D_ERR_INVALID_ARG;
+  const long long vox = (long long)d * h * w;
+  ncdhw3_to_ndhwc4_kernel<<<grid_for((long long)n * vox), kT, 0, mr3d_stream(s)>>>(ncdhw3, ndhwc4, n, vox);
+  return mr3d_launch_status();
+}
+
+extern "C" int mr3d_axpy(float *dst, const float *src, float alpha, long long count, mr3d_stream_t s) {
+  if (!dst || !src || count % 4) return MR3D_ERR_INVALID_ARG;
+  axpy_kernel<<<grid_for(count / 4), kT, 0, mr3d_stream(s)>>>(dst, src, alpha, count / 4);
+  return mr3d_launch_status();
+}
+
+extern "C" int mr3d_prepare_weights(const mr3d_layer_desc *table, int num_layers, const float *params, float *packed,
+                                    mr3d_stream_t s) {
+  if (!table || !params || !packed || num_layers <= 0) return MR3D_ERR_INVALID_ARG;
+  prep_weights_kernel<<<dim3(64, num_layers), kT, 0, mr3d_stream(s)>>>(table, params, packed);
+  return mr3d_launch_status();
+}
+
+extern "C" int mr3d_finish_grads(const mr3d_layer_desc *table, int num_layers, int max_cout, const float *params,
+                                 const float *scratch, float *grads, mr3d_stream_t s) {
+  if (!table || !params || !scratch || !grads || num_layers <= 0 || max_cout <= 0) return MR3D_ERR_INVALID_ARG;
+  finish_wgrads_kernel<<<dim3(64, num_layers), kT, 0, mr3d_stream(s)>>>(table, params, scratch, grads);
+  finish_affine_kernel<<<dim3((max_cout + 3) / 4, num_layers), kT, 0, mr3d_stream(s)>>>(table, params, scratch, grads);
+  return mr3d_launch_status();
+}

@@ -18,12 +18,16 @@ struct Conv3dFwdArgs {
   int pd, ph, pw;
   int Du, Hu, Wu;
   int relu;
+  // y is a [N, yD, yH, yW, Cout] buffer; output (od,oh,ow) lands at (od*ysd, oh*ysh, ow*ysw): lets a
+  // coarse-grid result be scattered onto the even positions of a pre-zeroed fine grid (stride-2 dgrad)
+  int ysd, ysh, ysw, yD, yH, yW;
 };
 
 struct Conv3dWgradArgs {
   const float *x;       // [N, D, H, W, Cin]   forward input
   const float *dy;      // [N, Do, Ho, Wo, Cout] upstream gradient (already ReLU-masked)
   float *dw;            // [KD*KH*KW][Cin][Cout], PRE-ZEROED; partial sums are added atomically
+  float *dbias;         // [Cout] += sum over positions of dy (bias / BN-beta gradient), PRE-ZEROED, may be null
   int N, D, H, W, Cin;
   int Do, Ho, Wo, Cout;
   int pd, ph, pw;

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(kThreads) void conv3d_fwd_kernel(Conv3dFwdArgs p, i
       const int tw = m % C::TW, th = (m / C::TW) % C::TH, td = m / (C::TW * C::TH);
       const int od = od0 + td, oh = oh0 + th, ow = ow0 + tw;
       if (od < p.Do && oh < p.Ho && ow < p.Wo) {
-        const size_t idx = ((((size_t)n * p.Do + od) * p.Ho + oh) * p.Wo + ow) * p.Cout + co;
+        const size_t idx = ((((size_t)n * p.yD + od * p.ysd) * p.yH + oh * p.ysh) * p.yW + ow * p.ysw) * p.Cout + co;
         float v = acc[mt][r] + sh;
         if (p.add1) v += p.add1[idx];
         if (p.add2) v += p.add2[idx];
@@ -215,6 +215,9 @@ extern "C" int mr3d_conv3d_forward(const mr3d_conv3d_desc *d, mr3d_stream_t stre
   a.Wo = (d->w_in + 2 * d->pw - d->kw) / d->sw + 1;
   a.Du = d->up_d; a.Hu = d->up_h; a.Wu = d->up_w;
   a.relu = d->relu;
+  a.ysd = d->ys_d > 0 ? d->ys_d : 1; a.ysh = d->ys_h > 0 ? d->ys_h : 1; a.ysw = d->ys_w > 0 ? d->ys_w : 1;
+  a.yD = d->y_d > 0 ? d->y_d : a.Do; a.yH = d->y_h > 0 ? d->y_h : a.Ho; a.yW = d->y_w > 0 ? d->y_w : a.Wo;
+  if ((a.Do - 1) * a.ysd >= a.yD || (a.Ho - 1) * a.ysh >= a.yH || (a.Wo - 1) * a.ysw >= a.yW) return MR3D_ERR_INVALID_ARG;
   if (a.N <= 0 || a.Do <= 0 || a.Ho <= 0 || a.Wo <= 0) return MR3D_ERR_INVALID_ARG;
   if (a.up && (a.Du <= 0 || a.Hu <= 0 || a.Wu <= 0)) return MR3D_ERR_INVALID_ARG;
   const int nb = pick_nb(a.Cout);

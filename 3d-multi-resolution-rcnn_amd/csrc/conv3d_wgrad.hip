@@ -63,6 +63,7 @@ __global__ __launch_bounds__(kThreads) void conv3d_wgrad_kernel(Conv3dWgradArgs 
     for (int mt = 0; mt < C::MT; ++mt)
       for (int nt = 0; nt < C::NT; ++nt) acc[t][mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  float bsum = 0.f;   // this thread's share of sum_p dy[p][co] (only the first Cin chunk reduces it)
   // LDS offset of each of this wave's tap groups (wave-uniform)
   int tapoff[C::TPW];
 #pragma unroll
@@ -115,6 +116,10 @@ __global__ __launch_bounds__(kThreads) void conv3d_wgrad_kernel(Conv3dWgradArgs 
     }
     __syncthreads();
 
+    if (p.dbias && blockIdx.y == 0) {
+      const int co = tid % C::NB;
+      for (int m = tid / C::NB; m < C::M; m += kThreads / C::NB) bsum += dyt[m * C::DROW + co];
+    }
     // ---- K loop: 4 positions per MFMA
     constexpr int KSTEPS = C::M / 4;
     constexpr int KPW = C::PW1 ? KSTEPS / 4 : KSTEPS;       // pointwise: waves split the positions
@@ -140,6 +145,7 @@ __global__ __launch_bounds__(kThreads) void conv3d_wgrad_kernel(Conv3dWgradArgs 
     }
   }
 
+  if (p.dbias && blockIdx.y == 0) atomicAdd(p.dbias + n0 + tid % C::NB, bsum);
   // ---- add the partial sums into dw[tap][ci][co]
 #pragma unroll
   for (int t = 0; t < C::TPW; ++t) {
@@ -204,7 +210,7 @@ extern "C" int mr3d_conv3d_wgrad(const mr3d_conv3d_wgrad_desc *d, mr3d_stream_t 
   if (!d || !d->x || !d->dy || !d->dw) return MR3D_ERR_INVALID_ARG;
   if (d->kd != d->kh || d->kh != d->kw) return MR3D_ERR_UNSUPPORTED;
   Conv3dWgradArgs a;
-  a.x = d->x; a.dy = d->dy; a.dw = d->dw;
+  a.x = d->x; a.dy = d->dy; a.dw = d->dw; a.dbias = d->dbias;
   a.N = d->n; a.D = d->d; a.H = d->h; a.W = d->w_in; a.Cin = d->cin; a.Cout = d->cout;
   a.pd = d->pd; a.ph = d->ph; a.pw = d->pw;
   a.Do = (d->d + 2 * d->pd - d->kd) / d->sd + 1;

@@ -1,0 +1,439 @@
+"""ResNet3D-50 + FPN3D feature extractor (`extract_feat`) on the MI355X conv engine.
+
+Mirrors the reference's `TwoStageDetector3D2Scales.extract_feat` (mmdet/models/detectors/
+two_stage_3d_2scales.py:123-127) = `ResNet3D.forward` (mmdet/models/backbones/resnet3d.py:467-478,
+Bottleneck :198-233, stem :397-409, make_res_layer :238-285) followed by `FPN3D.forward`
+(mmdet/models/necks/fpn3d.py:95-134), with the reference's parameter names
+(`backbone.conv1.weight`, `backbone.layer1.0.bn3d1.running_var`, `neck.lateral_convs.0.conv.bias`, ...)
+so that a reference checkpoint's state_dict loads unchanged.
+
+MI355X design (not a module-by-module translation):
+  * every tensor is NDHWC fp32; the volume comes in as the reference's [N,3,D,H,W] and the pyramid goes
+    out as [N,64,D,H,W] tensors with channels_last_3d strides (zero-copy views);
+  * all parameters and BN buffers live in ONE flat arena, all gradients in a mirror arena (the buffer the
+    data-parallel all-reduce runs on); BatchNorm3d runs in eval mode during training (norm_eval=True,
+    resnet3d.py:330,480-486) so it is folded into the conv weights + a per-channel shift by one
+    table-driven kernel per step; gamma/beta gradients are recovered from the wgrad results;
+  * forward and backward are pre-built *plans* (lists of kernel records) replayed by one native call each;
+    conv + BN + ReLU (+ residual add / + nearest-upsample add) is one MFMA implicit-GEMM kernel, and every
+    data-gradient kernel applies the ReLU mask of the layer it feeds in its epilogue.
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _hip
+
+_ALIGN = 64     # floats; keeps every sub-buffer 256-byte aligned
+
+
+class _Holder(nn.Module):
+    """empty container used to reproduce the reference's module tree (for state_dict key names)"""
+
+
+def _attach(root, dotted, tensor, is_param):
+    parts = dotted.split('.')
+    m = root
+    for p in parts[:-1]:
+        if not hasattr(m, p):
+            m.add_module(p, _Holder())
+        m = getattr(m, p)
+    if is_param:
+        m.register_parameter(parts[-1], tensor)
+    else:
+        m.register_buffer(parts[-1], tensor)
+
+
+class _ConvSpec:
+    def __init__(self, name, cin, cout, k, stride, pad, bn=None, bias=False, need_dgrad=True):
+        self.name, self.cin, self.cout, self.k, self.stride, self.pad = name, cin, cout, k, stride, pad
+        self.bn, self.bias, self.need_dgrad = bn, bias, need_dgrad
+        self.cin_pad = 4 if cin == 3 else cin
+        self.taps = k ** 3
+        self.index = -1
+
+
+class ExtractFeat3D(nn.Module):
+    STAGE_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
+
+    def __init__(self, depth=50, fpn_out_channels=64, num_outs=5, zero_init_residual=True, device='cuda'):
+        super().__init__()
+        if depth not in self.STAGE_BLOCKS:
+            raise KeyError(f'invalid depth {depth} for the bottleneck ResNet3D engine')
+        assert num_outs == 5, 'the shipped config uses 4 pyramid levels + 1 max-pooled level (configs/...py:11-15)'
+        self.depth = depth
+        self.device = torch.device(device)
+        self.fpn_out = fpn_out_channels
+        self.zero_init_residual = zero_init_residual
+        self.eps = 1e-5                                    # norm.py:50 cfg_.setdefault('eps', 1e-5)
+        self._build_specs()
+        self._build_arena()
+        self._plans = {}
+        self.init_weights()
+
+    # ------------------------------------------------------------------ structure
+    def _build_specs(self):
+        S = []
+        add = S.append
+        add(_ConvSpec('backbone.conv1', 3, 16, 7, (1, 2, 2), 3, bn='backbone.bn3d1', need_dgrad=False))
+        self.blocks = []          # (stage, block, stride, has_downsample, inplanes, planes)
+        inplanes = 16
+        for si, nb in enumerate(self.STAGE_BLOCKS[self.depth]):
+            planes = 16 * 2 ** si
+            for bi in range(nb):
+                stride = 2 if (bi == 0 and si > 0) else 1
+                pre = f'backbone.layer{si + 1}.{bi}'
+                ds = bi == 0 and (stride != 1 or inplanes != planes * 4)
+                blk = dict(stage=si, block=bi, stride=stride, ds=ds, inplanes=inplanes, planes=planes, pre=pre)
+                blk['conv1'] = _ConvSpec(pre + '.conv1', inplanes, planes, 1, (1, 1, 1), 0, bn=pre + '.bn3d1')
+                blk['conv2'] = _ConvSpec(pre + '.conv2', planes, planes, 3, (stride,) * 3, 1, bn=pre + '.bn3d2')
+                blk['conv3'] = _ConvSpec(pre + '.conv3', planes, planes * 4, 1, (1, 1, 1), 0, bn=pre + '.bn3d3')
+                for key in ('conv1', 'conv2', 'conv3'):
+                    add(blk[key])
+                if ds:
+                    blk['dsconv'] = _ConvSpec(pre + '.downsample.0', inplanes, planes * 4, 1, (stride,) * 3, 0,
+                                              bn=pre + '.downsample.1')
+                    add(blk['dsconv'])
+                self.blocks.append(blk)
+                inplanes = planes * 4
+        self.stage_out_channels = [16 * 2 ** i * 4 for i in range(4)]
+        self.lateral, self.fpnconv = [], []
+        for i, c in enumerate(self.stage_out_channels):
+            self.lateral.append(_ConvSpec(f'neck.lateral_convs.{i}.conv', c, self.fpn_out, 1, (1, 1, 1), 0, bias=True))
+            self.fpnconv.append(_ConvSpec(f'neck.fpn_convs.{i}.conv', self.fpn_out, self.fpn_out, 3, (1, 1, 1), 1, bias=True))
+            add(self.lateral[-1]); add(self.fpnconv[-1])
+        for k, s in enumerate(S):
+            s.index = k
+        self.specs = S
+
+    def _build_arena(self):
+        entries = []            # (name, shape, is_param)
+        for s in self.specs:
+            entries.append((s.name + '.weight', (s.cout, s.cin, s.k, s.k, s.k), True))
+            if s.bias:
+                entries.append((s.name + '.bias', (s.cout,), True))
+            if s.bn:
+                entries.append((s.bn + '.weight', (s.cout,), True))
+                entries.append((s.bn + '.bias', (s.cout,), True))
+                entries.append((s.bn + '.running_mean', (s.cout,), False))
+                entries.append((s.bn + '.running_var', (s.cout,), False))
+        off, self.offsets = 0, {}
+        for name, shape, _ in entries:
+            self.offsets[name] = off
+            off += -(-int(np.prod(shape)) // _ALIGN) * _ALIGN
+        self.arena_size = off
+        arena = torch.zeros(off, dtype=torch.float32, device=self.device)
+        grads = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.register_buffer('_arena', arena, persistent=False)
+        self.register_buffer('_grad_arena', grads, persistent=False)
+        for name, shape, is_param in entries:
+            o, n = self.offsets[name], int(np.prod(shape))
+            view = arena[o:o + n].view(shape)
+            if is_param:
+                p = nn.Parameter(view)
+                p.grad = grads[o:o + n].view(shape)
+                _attach(self, name, p, True)
+            else:
+                _attach(self, name, view, False)
+        for s in self.specs:
+            if s.bn:
+                _attach(self, s.bn + '.num_batches_tracked', torch.zeros((), dtype=torch.long, device=self.device), False)
+        # packed-weight arena and wgrad scratch arena + the layer table
+        poff = soff = 0
+        table = (_hip.LayerDesc * len(self.specs))()
+        for s in self.specs:
+            L = table[s.index]
+            nw = s.taps * s.cin_pad * s.cout
+            L.w_off = self.offsets[s.name + '.weight']
+            L.bias_off = self.offsets[s.name + '.bias'] if s.bias else -1
+            if s.bn:
+                L.gamma_off, L.beta_off = self.offsets[s.bn + '.weight'], self.offsets[s.bn + '.bias']
+                L.mean_off, L.var_off = self.offsets[s.bn + '.running_mean'], self.offsets[s.bn + '.running_var']
+            else:
+                L.gamma_off = L.beta_off = L.mean_off = L.var_off = -1
+            al = lambda v: -(-v // _ALIGN) * _ALIGN
+            L.wf_off = poff; poff += al(nw)
+            if s.need_dgrad:
+                L.wb_off = poff; poff += al(nw)
+            else:
+                L.wb_off = -1
+            L.shift_off = poff; poff += al(s.cout)
+            L.scale_off = poff; poff += al(s.cout)
+            L.dwraw_off = soff; soff += al(nw)
+            L.dbias_off = soff; soff += al(s.cout)
+            L.co, L.ci, L.ci_pad, L.taps, L.eps = s.cout, s.cin, s.cin_pad, s.taps, self.eps
+        self._table_host = table
+        raw = np.frombuffer(bytes(table), dtype=np.uint8).copy()
+        self.register_buffer('_table', torch.from_numpy(raw).to(self.device), persistent=False)
+        self.register_buffer('_packed', torch.zeros(poff, dtype=torch.float32, device=self.device), persistent=False)
+        self.register_buffer('_scratch', torch.zeros(soff, dtype=torch.float32, device=self.device), persistent=False)
+        self.max_cout = max(s.cout for s in self.specs)
+
+    # ------------------------------------------------------------------ parameters
+    def init_weights(self, pretrained=None):
+        """resnet3d.py:440-465 (kaiming-normal fan_out convs, BN = 1/0, zero-init of every block's bn3d3) and
+        fpn3d.py:90-93 (xavier-uniform convs, zero bias)."""
+        if isinstance(pretrained, str):
+            sd = torch.load(pretrained, map_location='cpu')
+            sd = sd.get('state_dict', sd.get('model_state_dict', sd))
+            sd = {(k[7:] if k.startswith('module.') else k): v for k, v in sd.items()}      # resnet3d.py:431-436
+            self.load_state_dict(sd, strict=False)
+            return
+        with torch.no_grad():
+            for s in self.specs:
+                w = self.get_parameter(s.name + '.weight')
+                if s.name.startswith('backbone.'):
+                    nn.init.kaiming_normal_(w, mode='fan_out', nonlinearity='relu')
+                else:
+                    nn.init.xavier_uniform_(w)
+                    self.get_parameter(s.name + '.bias').zero_()
+                if s.bn:
+                    self.get_parameter(s.bn + '.weight').fill_(1.0)
+                    self.get_parameter(s.bn + '.bias').zero_()
+                    self.get_buffer(s.bn + '.running_mean').zero_()
+                    self.get_buffer(s.bn + '.running_var').fill_(1.0)
+            if self.zero_init_residual:
+                for b in self.blocks:
+                    self.get_parameter(b['conv3'].bn + '.weight').zero_()
+
+    @property
+    def flat_params(self):
+        return self._arena
+
+    @property
+    def flat_grads(self):
+        return self._grad_arena
+
+    def zero_grad(self, set_to_none=False):
+        self._grad_arena.zero_()
+
+    # ------------------------------------------------------------------ plan construction
+    def _w(self, spec, kind):
+        off = getattr(self._table_host[spec.index], kind + '_off')
+        assert off >= 0
+        return self._packed.data_ptr() + 4 * off
+
+    def _s(self, spec, kind):
+        return self._scratch.data_ptr() + 4 * getattr(self._table_host[spec.index], kind + '_off')
+
+    @staticmethod
+    def _conv_ints(x_shape, cin, cout, k, stride, pad, up=None, relu=0, ys=None, ydims=None):
+        n, d, h, w, _ = x_shape
+        ints = [n, d, h, w, cin, cout, k, k, k, stride[0], stride[1], stride[2], pad, pad, pad]
+        ints += list(up) if up is not None else [0, 0, 0]
+        ints += [int(relu)]
+        ints += list(ys) if ys is not None else [0, 0, 0]
+        ints += list(ydims) if ydims is not None else [0, 0, 0]
+        return ints
+
+    def _conv_fwd(self, x, spec, y, add1=None, add2=None, up=None, relu=False):
+        ints = self._conv_ints(x.shape, spec.cin_pad, spec.cout, spec.k, spec.stride, spec.pad,
+                               up=None if up is None else up.shape[1:4], relu=relu)
+        return _hip.make_op(_hip.OP_CONV_FWD, [x, self._w(spec, 'wf'), y, self._w(spec, 'shift'), add1, add2, up, None], ints)
+
+    def _conv_dgrad(self, dy, spec, dx, add1=None, add2=None, mask=None, scatter=False):
+        """dx = conv_transpose(dy) as a stride-1 conv with flipped/transposed folded weights.  `dy` must already
+        be on dx's grid (dense, or zero-stuffed for a strided 3x3x3); scatter=True instead writes a pointwise
+        stride-2 result onto the even positions of the pre-zeroed dx."""
+        k, pad = spec.k, spec.k - 1 - spec.pad
+        if scatter:
+            ints = self._conv_ints(dy.shape, spec.cout, spec.cin_pad, k, (1, 1, 1), pad, ys=spec.stride, ydims=dx.shape[1:4])
+        else:
+            ints = self._conv_ints(dy.shape, spec.cout, spec.cin_pad, k, (1, 1, 1), pad)
+        return _hip.make_op(_hip.OP_CONV_FWD, [dy, self._w(spec, 'wb'), dx, None, add1, add2, None, mask], ints)
+
+    def _conv_wgrad(self, x, dy, spec):
+        n, d, h, w, _ = x.shape
+        ints = [n, d, h, w, spec.cin_pad, spec.cout, spec.k, spec.k, spec.k, *spec.stride, spec.pad, spec.pad, spec.pad]
+        return _hip.make_op(_hip.OP_CONV_WGRAD, [x, dy, self._s(spec, 'dwraw'), self._s(spec, 'dbias')], ints)
+
+    def _new(self, shape, dtype=torch.float32):
+        t = torch.empty(tuple(shape), dtype=dtype, device=self.device)
+        self._building.append(t)      # plans hold raw pointers: every buffer must outlive them
+        return t
+
+    def _out_shape(self, x_shape, spec):
+        return _hip.conv3d_out_shape(x_shape, spec.cout, (spec.k,) * 3, spec.stride, (spec.pad,) * 3)
+
+    def _build_plan(self, in_shape):
+        N, C, D, H, W = in_shape
+        assert C == 3, 'the detector asserts 3 input channels (two_stage_3d_2scales.py:148)'
+        P = type('PlanState', (), {})()
+        self._building = P.buffers = []
+        fwd, bwd = [], []
+        nL = len(self.specs)
+        prep = _hip.make_op(_hip.OP_PREP_WEIGHTS, [self._table, self._arena, self._packed], [nL])
+        fwd.append(prep)
+        # ---------------- forward
+        P.x_in = self._new((N, 3, D, H, W))
+        P.x4 = self._new((N, D, H, W, 4))
+        fwd.append(_hip.make_op(_hip.OP_VOLUME_PACK, [P.x_in, P.x4], [N, D, H, W]))
+        stem = self.specs[0]
+        P.stem_out = self._new(self._out_shape(P.x4.shape, stem))
+        fwd.append(self._conv_fwd(P.x4, stem, P.stem_out, relu=True))
+        _, sd, sh, sw, _ = P.stem_out.shape
+        pshape = (N, (sd - 1) // 2 + 1, (sh - 1) // 2 + 1, (sw - 1) // 2 + 1, 16)
+        P.pool_out = self._new(pshape)
+        P.pool_idx = self._new(pshape[:4] + (4,), torch.int32)
+        fwd.append(_hip.make_op(_hip.OP_MAXPOOL_FWD, [P.stem_out, P.pool_out, P.pool_idx], [N, sd, sh, sw, 16]))
+        x = P.pool_out
+        P.blk = []
+        stage_outs = []
+        for b in self.blocks:
+            st = dict(x=x)
+            st['a1'] = self._new(self._out_shape(x.shape, b['conv1']))
+            fwd.append(self._conv_fwd(x, b['conv1'], st['a1'], relu=True))
+            st['a2'] = self._new(self._out_shape(st['a1'].shape, b['conv2']))
+            fwd.append(self._conv_fwd(st['a1'], b['conv2'], st['a2'], relu=True))
+            oshape = self._out_shape(st['a2'].shape, b['conv3'])
+            if b['ds']:
+                st['idn'] = self._new(oshape)
+                fwd.append(self._conv_fwd(x, b['dsconv'], st['idn']))
+                idn = st['idn']
+            else:
+                idn = x
+            st['out'] = self._new(oshape)
+            fwd.append(self._conv_fwd(st['a2'], b['conv3'], st['out'], add1=idn, relu=True))
+            P.blk.append(st)
+            x = st['out']
+            last_of_stage = b['block'] == self.STAGE_BLOCKS[self.depth][b['stage']] - 1
+            if last_of_stage:
+                stage_outs.append(x)
+        P.C = stage_outs
+        P.lat = [None] * 4
+        for i in (3, 2, 1, 0):
+            P.lat[i] = self._new(self._out_shape(P.C[i].shape, self.lateral[i]))
+            fwd.append(self._conv_fwd(P.C[i], self.lateral[i], P.lat[i], up=P.lat[i + 1] if i < 3 else None))
+        P.outs = []
+        for i in range(4):
+            o = self._new(self._out_shape(P.lat[i].shape, self.fpnconv[i]))
+            fwd.append(self._conv_fwd(P.lat[i], self.fpnconv[i], o))
+            P.outs.append(o)
+        _, d5, h5, w5, _ = P.outs[3].shape
+        p6 = self._new((N, (d5 - 1) // 2 + 1, (h5 - 1) // 2 + 1, (w5 - 1) // 2 + 1, self.fpn_out))
+        fwd.append(_hip.make_op(_hip.OP_SUBSAMPLE_FWD, [P.outs[3], p6], [N, d5, h5, w5, self.fpn_out]))
+        P.outs.append(p6)
+
+        # ---------------- backward
+        P.gouts = [self._new(o.shape) for o in P.outs]
+        bwd.append(_hip.make_op(_hip.OP_MEMSET0, [self._scratch], _hip.split64(self._scratch.numel() * 4)))
+        bwd.append(_hip.make_op(_hip.OP_SUBSAMPLE_BWD, [P.gouts[4], P.gouts[3]], [N, d5, h5, w5, self.fpn_out]))
+        glat = [self._new(l.shape) for l in P.lat]
+        gC_lat = [self._new(c.shape) for c in P.C]
+        for i in range(4):
+            bwd.append(self._conv_wgrad(P.lat[i], P.gouts[i], self.fpnconv[i]))
+            bwd.append(self._conv_dgrad(P.gouts[i], self.fpnconv[i], glat[i]))
+            if i > 0:
+                nf, df, hf, wf, c = glat[i - 1].shape
+                bwd.append(_hip.make_op(_hip.OP_UPSAMPLE_ADJ, [glat[i - 1], glat[i]],
+                                        [N, df, hf, wf, glat[i].shape[1], glat[i].shape[2], glat[i].shape[3], c]))
+            bwd.append(self._conv_wgrad(P.C[i], glat[i], self.lateral[i]))
+            # the gradient of the LAST stage output only comes through its lateral conv: apply its ReLU mask here
+            bwd.append(self._conv_dgrad(glat[i], self.lateral[i], gC_lat[i], mask=P.C[3] if i == 3 else None))
+        g = gC_lat[3]                     # grad w.r.t. the current block's output, ReLU-masked
+        for bi in range(len(self.blocks) - 1, -1, -1):
+            b, st = self.blocks[bi], P.blk[bi]
+            x = st['x']
+            bwd.append(self._conv_wgrad(st['a2'], g, b['conv3']))
+            g_a2 = self._new(st['a2'].shape)
+            bwd.append(self._conv_dgrad(g, b['conv3'], g_a2, mask=st['a2']))
+            bwd.append(self._conv_wgrad(st['a1'], g_a2, b['conv2']))
+            g_a1 = self._new(st['a1'].shape)
+            if b['stride'] == 1:
+                bwd.append(self._conv_dgrad(g_a2, b['conv2'], g_a1, mask=st['a1']))
+            else:
+                stuffed = self._new(st['a1'].shape[:4] + (b['planes'],))
+                n_, do_, ho_, wo_, c_ = g_a2.shape
+                bwd.append(_hip.make_op(_hip.OP_ZERO_STUFF2, [g_a2, stuffed],
+                                        [n_, do_, ho_, wo_, stuffed.shape[1], stuffed.shape[2], stuffed.shape[3], c_]))
+                bwd.append(self._conv_dgrad(stuffed, b['conv2'], g_a1, mask=st['a1']))
+            bwd.append(self._conv_wgrad(x, g_a1, b['conv1']))
+            first_of_stage = b['block'] == 0
+            lat_part = gC_lat[b['stage'] - 1] if (first_of_stage and b['stage'] > 0) else None
+            mask = x if bi > 0 else None          # x of the very first block is the max-pool output (no ReLU after it)
+            gx = self._new(x.shape)
+            if b['ds']:
+                bwd.append(self._conv_wgrad(x, g, b['dsconv']))
+                t = self._new(x.shape)
+                if b['stride'] == 1:
+                    bwd.append(self._conv_dgrad(g, b['dsconv'], t))
+                else:
+                    bwd.append(_hip.make_op(_hip.OP_MEMSET0, [t], _hip.split64(t.numel() * 4)))
+                    bwd.append(self._conv_dgrad(g, b['dsconv'], t, scatter=True))
+                bwd.append(self._conv_dgrad(g_a1, b['conv1'], gx, add1=t, add2=lat_part, mask=mask))
+            else:
+                assert lat_part is None
+                bwd.append(self._conv_dgrad(g_a1, b['conv1'], gx, add1=g, mask=mask))
+            g = gx
+        g_stem = self._new(P.stem_out.shape)
+        bwd.append(_hip.make_op(_hip.OP_MAXPOOL_BWD, [g, P.pool_idx, P.stem_out, g_stem], [N, sd, sh, sw, 16]))
+        bwd.append(self._conv_wgrad(P.x4, g_stem, stem))
+        bwd.append(_hip.make_op(_hip.OP_FINISH_GRADS, [self._table, self._arena, self._scratch, self._grad_arena],
+                                [nL, self.max_cout]))
+        P.fwd_ops, P.bwd_ops = fwd, bwd
+        P.fwd, P.bwd = _hip.Plan(fwd), _hip.Plan(bwd)
+        self._building = None
+        return P
+
+    def _plan_for(self, shape):
+        key = tuple(shape)
+        if key not in self._plans:
+            self._plans[key] = self._build_plan(key)
+        return self._plans[key]
+
+    # ------------------------------------------------------------------ execution
+    def forward_features(self, img):
+        """img: [N,3,D,H,W] fp32 on the engine's device -> (P2..P6) as [N,64,d,h,w] channels_last_3d views."""
+        if not img.is_cuda:
+            raise NotImplementedError('ExtractFeat3D runs on the MI355X only (no CPU fallback)')
+        P = self._plan_for(img.shape)
+        P.x_in.copy_(img)
+        with torch.cuda.device(self.device):
+            P.fwd.run(self.device)
+        self._last = P
+        return tuple(o.permute(0, 4, 1, 2, 3) for o in P.outs)
+
+    def backward_features(self, grads):
+        """grads: gradients w.r.t. the 5 pyramid outputs (any memory format; None = zero).  Accumulates parameter
+        gradients into the flat gradient arena (== every parameter's .grad)."""
+        P = self._last
+        for gbuf, g in zip(P.gouts, grads):
+            if g is None:
+                gbuf.zero_()
+            else:
+                gbuf.copy_(g.permute(0, 2, 3, 4, 1))
+        with torch.cuda.device(self.device):
+            P.bwd.run(self.device)
+
+    def forward(self, img):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return _ExtractFeatFn.apply(self, img, self._autograd_anchor())
+        return self.forward_features(img)
+
+    def _autograd_anchor(self):
+        if not hasattr(self, '_anchor'):
+            self._anchor = torch.zeros((), device=self.device, requires_grad=True)
+        return self._anchor
+
+    def train(self, mode=True):
+        # BatchNorm3d stays in eval mode either way (norm_eval=True, resnet3d.py:480-486)
+        return super().train(mode)
+
+
+class _ExtractFeatFn(torch.autograd.Function):
+    """autograd bridge: the engine writes parameter gradients straight into the flat gradient arena
+    (p.grad of every parameter is a view of it), so backward returns no tensor gradients."""
+
+    @staticmethod
+    def forward(ctx, engine, img, anchor):
+        ctx.engine = engine
+        outs = engine.forward_features(img)
+        return tuple(o.clone(memory_format=torch.preserve_format) for o in outs)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *grads):
+        ctx.engine.backward_features(grads)
+        return None, None, None

@@ -110,6 +110,9 @@ typedef struct {
   int kd, kh, kw, sd, sh, sw, pd, ph, pw;
   int up_d, up_h, up_w;
   int relu;
+  /* optional output scatter: y is a [n, y_d, y_h, y_w, cout] buffer and output (od,oh,ow) is written at
+   * (od*ys_d, oh*ys_h, ow*ys_w) (0 = dense: ys = 1, y dims = output dims); add1/add2/mask index like y */
+  int ys_d, ys_h, ys_w, y_d, y_h, y_w;
 } mr3d_conv3d_desc;
 int mr3d_conv3d_forward(const mr3d_conv3d_desc *desc, mr3d_stream_t stream);
 
@@ -123,10 +126,93 @@ int mr3d_conv3d_forward(const mr3d_conv3d_desc *desc, mr3d_stream_t stream);
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
   const float *x; const float *dy; float *dw;
+  float *dbias;   /* [cout] += sum_p dy[p][co] (bias / BN-beta gradient); pre-zeroed; may be NULL */
   int n, d, h, w_in, cin, cout;
   int kd, kh, kw, sd, sh, sw, pd, ph, pw;
 } mr3d_conv3d_wgrad_desc;
 int mr3d_conv3d_wgrad(const mr3d_conv3d_wgrad_desc *desc, mr3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * HBM-bound helpers of the backbone / neck path (activations NDHWC fp32, channels % 4 == 0).
+ *   maxpool3d: nn.MaxPool3d(kernel 3, stride 2, padding 1) (mmdet/models/backbones/resnet3d.py:409,471);
+ *     forward stores the argmax tap (4 x u8 per 4 channels; first maximum in (kd,kh,kw) scan order, as
+ *     torch); backward gathers dy through it and, if relu_of != NULL, zeroes positions where relu_of <= 0
+ *     (the stem ReLU that precedes the pool).  Output size floor((in-1)/2)+1 per axis.
+ *   zero_stuff2: dst[2o] = src[o], 0 elsewhere (stride-2 data gradient as a stride-1 conv).
+ *   upsample_nearest_adjoint_add: grad_coarse[u] += sum of grad_fine[f] over f with nearest_src(f) == u
+ *     (backward of F.interpolate(mode='nearest') in mmdet/models/necks/fpn3d.py:106-108).
+ *   subsample2: y[o] = x[2o] (F.max_pool3d(x, 1, stride=2), fpn3d.py:121-123) and its adjoint (+=).
+ *   volume_to_ndhwc4: [N,3,D,H,W] -> [N,D,H,W,4] (4th channel 0) for the stem kernel.
+ *   axpy: dst += alpha * src (count % 4 == 0).
+ * ---------------------------------------------------------------------------------------------- */
+int mr3d_maxpool3d_forward(const float *x, float *y, uint32_t *argmax, int n, int d, int h, int w, int c, mr3d_stream_t s);
+int mr3d_maxpool3d_backward(const float *dy, const uint32_t *argmax, const float *relu_of, float *dx,
+                            int n, int d, int h, int w, int c, mr3d_stream_t s);
+int mr3d_zero_stuff2(const float *src, float *dst, int n, int do_, int ho, int wo, int d, int h, int w, int c, mr3d_stream_t s);
+int mr3d_upsample_nearest_adjoint_add(const float *grad_fine, float *grad_coarse, int n, int df, int hf, int wf,
+                                      int dc, int hc, int wc, int c, mr3d_stream_t s);
+int mr3d_subsample2_forward(const float *x, float *y, int n, int d, int h, int w, int c, mr3d_stream_t s);
+int mr3d_subsample2_backward_add(const float *dy, float *dx, int n, int d, int h, int w, int c, mr3d_stream_t s);
+int mr3d_volume_to_ndhwc4(const float *ncdhw3, float *ndhwc4, int n, int d, int h, int w, mr3d_stream_t s);
+int mr3d_axpy(float *dst, const float *src, float alpha, long long count, mr3d_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * Table-driven parameter handling for conv (+ eval-mode BatchNorm3d or bias) layers.  All parameters and
+ * BN buffers live in ONE flat fp32 arena (`params`), gradients in a mirror arena with identical offsets
+ * (`grads`: the buffer the data-parallel all-reduce runs on, mmdet/core/utils/dist_utils.py:9-41).
+ *   prepare_weights: folds BN-eval (norm_eval=True, resnet3d.py:330,480-486) into the conv:
+ *       s = gamma / sqrt(running_var + eps);  packed wf[tap][ci_pad][co] = s[co] * W[co][ci][tap];
+ *       dgrad weights wb[taps-1-tap][co][ci_pad] = same value; shift = beta - running_mean*s | bias | 0.
+ *   finish_grads: from dwraw (= mr3d_conv3d_wgrad output w.r.t. the FOLDED weights) and sumdy (dbias):
+ *       grads[W] += s[co]*dwraw;  dgamma += invstd*(sum_k W[c,k]*dwraw[k,c] - mean*sumdy);  dbeta += sumdy;
+ *       conv bias: dbias += sumdy.   (BN gamma/beta keep receiving gradients: normalize frozen=False, :329.)
+ * Offsets are in floats; -1 = absent.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  long long w_off, gamma_off, beta_off, mean_off, var_off, bias_off;   /* into params / grads          */
+  long long wf_off, wb_off, shift_off, scale_off;                      /* into the packed-weight arena */
+  long long dwraw_off, dbias_off;                                      /* into the scratch arena       */
+  int co, ci, ci_pad, taps;
+  float eps;
+  int reserved;
+} mr3d_layer_desc;
+int mr3d_prepare_weights(const mr3d_layer_desc *table, int num_layers, const float *params, float *packed, mr3d_stream_t s);
+int mr3d_finish_grads(const mr3d_layer_desc *table, int num_layers, int max_cout, const float *params,
+                      const float *scratch, float *grads, mr3d_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * Plan executor: runs a pre-built list of the operations above with ONE call (the host-side loop of
+ * ~500 launches per training step stays in native code; the call only enqueues, so it can be captured
+ * in a hipGraph).  Replaces the Python module-by-module dispatch of ResNet3D.forward / FPN3D.forward
+ * (resnet3d.py:467-478, fpn3d.py:95-134) and of autograd's backward over them.
+ * Field use per kind (unused = 0):
+ *   CONV_FWD      p = {x,w,y,shift,add1,add2,up,mask}   i = the 25 ints of mr3d_conv3d_desc in order
+ *   CONV_WGRAD    p = {x,dy,dw,dbias}                   i = the 15 ints of mr3d_conv3d_wgrad_desc
+ *   MAXPOOL_FWD   p = {x,y,argmax}                      i = {n,d,h,w,c}
+ *   MAXPOOL_BWD   p = {dy,argmax,relu_of,dx}            i = {n,d,h,w,c}
+ *   ZERO_STUFF2   p = {src,dst}                         i = {n,do,ho,wo,d,h,w,c}
+ *   UPSAMPLE_ADJ  p = {grad_fine,grad_coarse}           i = {n,df,hf,wf,dc,hc,wc,c}
+ *   SUBSAMPLE_FWD p = {x,y}   SUBSAMPLE_BWD p = {dy,dx} i = {n,d,h,w,c}
+ *   VOLUME_PACK   p = {ncdhw3,ndhwc4}                   i = {n,d,h,w}
+ *   MEMSET0       p = {dst}                             i = {bytes_lo, bytes_hi}
+ *   AXPY          p = {dst,src}  f[0] = alpha           i = {count_lo, count_hi}
+ *   PREP_WEIGHTS  p = {table,params,packed}             i = {num_layers}
+ *   FINISH_GRADS  p = {table,params,scratch,grads}      i = {num_layers,max_cout}
+ * Returns the first non-OK status; *failed_index (host int, may be NULL) receives the op index.
+ * ---------------------------------------------------------------------------------------------- */
+typedef enum {
+  MR3D_OP_CONV_FWD = 1, MR3D_OP_CONV_WGRAD = 2, MR3D_OP_MAXPOOL_FWD = 3, MR3D_OP_MAXPOOL_BWD = 4,
+  MR3D_OP_ZERO_STUFF2 = 5, MR3D_OP_UPSAMPLE_ADJ = 6, MR3D_OP_SUBSAMPLE_FWD = 7, MR3D_OP_SUBSAMPLE_BWD = 8,
+  MR3D_OP_VOLUME_PACK = 9, MR3D_OP_MEMSET0 = 10, MR3D_OP_AXPY = 11, MR3D_OP_PREP_WEIGHTS = 12,
+  MR3D_OP_FINISH_GRADS = 13
+} mr3d_op_kind;
+typedef struct {
+  int32_t kind;
+  int32_t i[27];
+  float f[4];
+  void *p[8];
+} mr3d_op;
+int mr3d_plan_run(const mr3d_op *ops_host, int num_ops, int *failed_index_host, mr3d_stream_t stream);
 
 #ifdef __cplusplus
 }

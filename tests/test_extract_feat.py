@@ -1,0 +1,119 @@
+"""ExtractFeat3D (ResNet3D-50 + FPN3D on the HIP conv engine): CPU structural tests + GPU parity against
+the reference-generated golden vectors and a plain-PyTorch fp32 restatement."""
+import numpy as np
+import pytest
+import torch
+
+from weightfill import closed_form_array, volume_like, cotangent_like
+from torch_ref_model import RefExtractFeat
+
+RTOL = 1e-4
+
+
+def _fill_like_golden(named):
+    """same closed-form fill as tests/golden/make_golden.py: backbone names (salt 1) / neck names (salt 2),
+    keyed WITHOUT the detector-level prefix"""
+    with torch.no_grad():
+        for name, t in named:
+            if name.endswith('num_batches_tracked') or '.' not in name:     # skip the engine's private flat arenas
+                continue
+            pref, rest = name.split('.', 1)
+            salt = {'backbone': 1, 'neck': 2}[pref]
+            t.copy_(torch.from_numpy(closed_form_array(rest, tuple(t.shape), salt)).to(t.device))
+
+
+def test_torch_restatement_matches_reference_golden(golden_dir):
+    """pins tests/torch_ref_model.py to the real reference modules (outputs + gradients)"""
+    g = np.load(f'{golden_dir}/backbone_fpn.npz')
+    m = RefExtractFeat()
+    _fill_like_golden(list(m.named_parameters()) + list(m.named_buffers()))
+    x = volume_like((1, 3, 8, 32, 32))
+    outs = m(x)
+    loss = sum((o * cotangent_like(o.shape, i)).sum() for i, o in enumerate(outs))
+    loss.backward()
+    for i, o in enumerate(outs):
+        np.testing.assert_allclose(o.detach().numpy(), g[f'a_p{i}'], rtol=1e-4, atol=1e-4 * np.abs(g[f'a_p{i}']).max())
+    norms = dict(zip(g['a_grad_names'].tolist(), g['a_grad_norms'].tolist()))
+    for k, p in m.named_parameters():
+        assert abs(p.grad.double().norm().item() - norms[k]) <= 1e-3 * max(norms[k], 1e-6), k
+
+
+@pytest.mark.gpu
+def test_engine_state_dict_and_arena():
+    from mr3d_amd.detector import ExtractFeat3D
+    eng = ExtractFeat3D()
+    ref = RefExtractFeat()
+    assert set(eng.state_dict().keys()) == set(ref.state_dict().keys())
+    assert len(eng.state_dict()) == 318 + 16                    # 318 backbone entries + 16 FPN
+    assert sum(p.numel() for p in eng.parameters()) == 2909744 + 504320
+    for p in eng.parameters():                                   # every .grad is a view of the flat gradient arena
+        assert p.grad.data_ptr() >= eng.flat_grads.data_ptr()
+    # zero-init of the last norm of every block (resnet3d.py:458-461)
+    assert float(eng.get_parameter('backbone.layer3.2.bn3d3.weight').detach().abs().sum()) == 0.0
+    eng.load_state_dict(ref.state_dict())                        # a reference-shaped checkpoint loads in place
+    np.testing.assert_array_equal(eng.get_parameter('backbone.conv1.weight').detach().cpu().numpy(),
+                                  ref.backbone.conv1.weight.detach().numpy())
+
+
+def _rel_err(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('tag,shape', [('a', (1, 3, 8, 32, 32)), ('b', (1, 3, 16, 64, 64))])
+def test_engine_matches_reference_golden(golden_dir, tag, shape):
+    from mr3d_amd.detector import ExtractFeat3D
+    g = np.load(f'{golden_dir}/backbone_fpn.npz')
+    eng = ExtractFeat3D()
+    _fill_like_golden(list(eng.named_parameters()) + list(eng.named_buffers()))
+    x = volume_like(shape).cuda()
+    outs = eng.forward_features(x)
+    for i, o in enumerate(outs):
+        assert o.shape == g[f'{tag}_p{i}'].shape
+        assert _rel_err(o.cpu().numpy(), g[f'{tag}_p{i}']) <= RTOL, f'P{i + 2}'
+    eng.zero_grad()
+    eng.backward_features([cotangent_like(o.shape, i).cuda() for i, o in enumerate(outs)])
+    norms = dict(zip(g[f'{tag}_grad_names'].tolist(), g[f'{tag}_grad_norms'].tolist()))
+    for k, p in eng.named_parameters():
+        got = p.grad.double().norm().item()
+        assert abs(got - norms[k]) <= 2e-4 * max(norms[k], 1e-6) + 1e-7, (k, got, norms[k])
+    for key in g.files:
+        if key.startswith(f'{tag}_g_'):
+            name = key[len(f'{tag}_g_'):]
+            assert _rel_err(eng.get_parameter(name).grad.cpu().numpy(), g[key]) <= 3e-4, name
+
+
+@pytest.mark.gpu
+def test_engine_vs_torch_restatement_random_weights_batch2():
+    """random (not closed-form) weights, batch 2, odd sizes; autograd bridge; gradient accumulation"""
+    from mr3d_amd.detector import ExtractFeat3D
+    torch.manual_seed(3)
+    ref = RefExtractFeat()
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if p.dim() == 1:
+                p.copy_(torch.rand_like(p) * 0.5 + 0.5 if n.endswith('weight') else torch.randn_like(p) * 0.1)
+        for n, b in ref.named_buffers():
+            if n.endswith('running_mean'):
+                b.copy_(torch.randn_like(b) * 0.1)
+            elif n.endswith('running_var'):
+                b.copy_(torch.rand_like(b) + 0.5)
+    eng = ExtractFeat3D()
+    eng.load_state_dict(ref.state_dict())
+    x = torch.randn(2, 3, 10, 40, 36)
+    outs_ref = ref(x)
+    cots = [torch.randn_like(o) for o in outs_ref]
+    sum((o * c).sum() for o, c in zip(outs_ref, cots)).backward()
+    eng.zero_grad()
+    outs = eng(x.cuda())                                        # through torch.autograd
+    for o, r in zip(outs, outs_ref):
+        assert _rel_err(o.detach().cpu().numpy(), r.detach().numpy()) <= RTOL
+    sum((o * c.cuda()).sum() for o, c in zip(outs, cots)).backward()
+    for (k, p), (k2, q) in zip(sorted(eng.named_parameters()), sorted(ref.named_parameters())):
+        assert k == k2
+        assert _rel_err(p.grad.cpu().numpy(), q.grad.numpy()) <= 3e-4, k
+    # a second backward accumulates (autograd semantics of .grad)
+    g1 = eng.flat_grads.clone()
+    outs = eng(x.cuda())
+    sum((o * c.cuda()).sum() for o, c in zip(outs, cots)).backward()
+    assert _rel_err(eng.flat_grads.cpu().numpy(), 2 * g1.cpu().numpy()) <= 1e-5
