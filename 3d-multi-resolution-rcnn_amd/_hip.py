@@ -252,9 +252,54 @@ class Plan:
         self.array = (Op * self.n)(*ops)
         self._failed = ctypes.c_int(-1)
 
-    def run(self, device=None):
-        st = lib().mr3d_plan_run(self.array, ctypes.c_int(self.n), ctypes.byref(self._failed), stream_ptr(device))
+    def _run_range(self, lo, hi, device):
+        if hi <= lo:
+            return
+        base = ctypes.cast(ctypes.byref(self.array, lo * ctypes.sizeof(Op)), ctypes.POINTER(Op))
+        st = lib().mr3d_plan_run(base, ctypes.c_int(hi - lo), ctypes.byref(self._failed), stream_ptr(device))
         if st != OK:
-            k = self._failed.value
+            k = lo + self._failed.value
             raise Mr3dError(f'mr3d_plan_run: op #{k} (kind {self.array[k].kind}) failed: '
                             f'{lib().mr3d_status_string(int(st)).decode()}')
+
+    def run(self, device=None, marks=None):
+        """Enqueue every op on torch's current stream.  marks: optional sorted op indices to bracket with
+        torch.cuda.Event pairs (same stream as the kernels); returns {index: (start_event, end_event)}."""
+        if not marks:
+            self._run_range(0, self.n, device)
+            return {}
+        ev, pos = {}, 0
+        for k in marks:
+            self._run_range(pos, k, device)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            self._run_range(k, k + 1, device)
+            e.record()
+            ev[k] = (s, e)
+            pos = k + 1
+        self._run_range(pos, self.n, device)
+        return ev
+
+
+def op_kernel_key(op):
+    """identity of the device kernel an op launches (template instance for the conv kernels) + its
+    algorithmic FLOPs (2*MAC over the REAL channels; the 3-channel stem is stored padded to 4)"""
+    i = op.i
+    if op.kind in (OP_CONV_FWD, OP_CONV_WGRAD):
+        n, d, h, w, cin, cout, k = i[0], i[1], i[2], i[3], i[4], i[5], i[6]
+        sd, sh, sw, pd = i[9], i[10], i[11], i[12]
+        do, ho, wo = (d + 2 * pd - k) // sd + 1, (h + 2 * pd - k) // sh + 1, (w + 2 * pd - k) // sw + 1
+        nb = 64 if cout % 64 == 0 else (32 if cout % 32 == 0 else 16)
+        if k == 1:
+            cc = 64 if cin % 64 == 0 else (32 if cin % 32 == 0 else 16)
+        else:
+            cc = 4 if cin == 4 else (8 if (k == 3 and sd == 2 and op.kind == OP_CONV_FWD) else 16)
+        real_cin = 3 if (cin == 4 and k == 7) else cin
+        flops = 2.0 * n * do * ho * wo * cout * real_cin * k ** 3
+        name = 'conv3d_fwd' if op.kind == OP_CONV_FWD else 'conv3d_wgrad'
+        return f'{name}<k{k},s{sd}{sh}{sw},cc{cc},nb{nb}>', flops
+    names = {OP_MAXPOOL_FWD: 'maxpool_fwd', OP_MAXPOOL_BWD: 'maxpool_bwd', OP_ZERO_STUFF2: 'zero_stuff', OP_UPSAMPLE_ADJ:
+             'upsample_adjoint_add', OP_SUBSAMPLE_FWD: 'subsample2_fwd', OP_SUBSAMPLE_BWD: 'subsample2_bwd', OP_VOLUME_PACK:
+             'ncdhw3_to_ndhwc4', OP_MEMSET0: 'memset', OP_AXPY: 'axpy', OP_PREP_WEIGHTS: 'prep_weights', OP_FINISH_GRADS:
+             'finish_grads'}
+    return names.get(op.kind, f'op{op.kind}'), 0.0

@@ -1,0 +1,152 @@
+"""Data-parallel gradient exchange (the only collective on the reference's hot path).
+
+Mirror of mmdet/core/utils/dist_utils.py:9-57 (`allreduce_grads`, `_allreduce_coalesced`,
+`DistOptimizerHook.after_train_iter`) and of the one-time parameter broadcast that mmcv's
+MMDistributedDataParallel performs at wrap time (mmdet/apis/train.py:92).
+
+MI355X-first: gradients already live in ONE persistent flat fp32 arena (ExtractFeat3D.flat_grads and
+FlatArena below), so the reference's per-iteration flatten + copy-back (`_flatten_dense_tensors`,
+`tensor.copy_(synced)`, dist_utils.py:22-28) disappears: one in-place SUM all-reduce over RCCL/xGMI on the
+arena, then one in-place 1/world scale.  Semantics kept: SUM then divide (not pre-divide), issued after
+backward and before gradient clipping (dist_utils.py:51-57).  Works on any torch.distributed backend
+("nccl" = RCCL on ROCm; "gloo" for the CPU tests).
+"""
+from collections import OrderedDict
+
+import torch
+import torch.distributed as dist
+
+
+def allreduce_flat_grads(flat, world_size=None, group=None):
+    """in-place mean of a flat gradient buffer over the data-parallel group"""
+    if world_size is None:
+        world_size = dist.get_world_size(group)
+    if world_size == 1:
+        return flat
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat.div_(world_size)
+    return flat
+
+
+def broadcast_params(flat, src=0, group=None):
+    """identical initial weights on every rank (what MMDistributedDataParallel.__init__ does with its
+    coalesced state_dict broadcast, mmdet/apis/train.py:92)"""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(flat, src=src, group=group)
+    return flat
+
+
+class FlatArena:
+    """Re-homes the parameters (and their .grad) of arbitrary nn.Modules into two persistent flat fp32
+    buffers, so that heads written in plain PyTorch join the same single all-reduce as the conv engine."""
+
+    def __init__(self, params):
+        params = [p for p in params if p.requires_grad]
+        assert params, 'no trainable parameters'
+        dev = params[0].device
+        n = sum(p.numel() for p in params)
+        self.flat_params = torch.empty(n, dtype=torch.float32, device=dev)
+        self.flat_grads = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        with torch.no_grad():
+            for p in params:
+                k = p.numel()
+                self.flat_params[off:off + k].copy_(p.detach().reshape(-1))
+                p.data = self.flat_params[off:off + k].view(p.shape)
+                p.grad = self.flat_grads[off:off + k].view(p.shape)
+                off += k
+        self.params = params
+
+    def zero_grad(self):
+        self.flat_grads.zero_()
+
+
+def _allreduce_coalesced(tensors, world_size, bucket_size_mb=-1, group=None):
+    """reference-compatible path for gradients that are NOT in a flat arena (dist_utils.py:9-28): bucket by
+    tensor type (or by size when bucket_size_mb > 0), flatten, SUM all-reduce, divide, copy back."""
+    if bucket_size_mb > 0:
+        limit, buckets, cur, size = bucket_size_mb * 1024 * 1024, [], [], 0
+        for t in tensors:
+            nbytes = t.numel() * t.element_size()
+            if cur and (size + nbytes > limit or t.type() != cur[0].type()):
+                buckets.append(cur); cur, size = [], 0
+            cur.append(t); size += nbytes
+        if cur:
+            buckets.append(cur)
+    else:
+        by_type = OrderedDict()
+        for t in tensors:
+            by_type.setdefault(t.type(), []).append(t)
+        buckets = list(by_type.values())
+    for bucket in buckets:
+        flat = torch.cat([t.reshape(-1) for t in bucket])
+        dist.all_reduce(flat, group=group)
+        flat.div_(world_size)
+        off = 0
+        for t in bucket:
+            t.copy_(flat[off:off + t.numel()].view_as(t))
+            off += t.numel()
+
+
+def _arena_of(grads):
+    """if every gradient is a view into one contiguous storage range return that range as a flat tensor"""
+    if not grads:
+        return None
+    base = grads[0].untyped_storage().data_ptr()
+    if any(g.untyped_storage().data_ptr() != base or g.dtype != torch.float32 or not g.is_contiguous() for g in grads):
+        return None
+    lo = min(g.storage_offset() for g in grads)
+    hi = max(g.storage_offset() + g.numel() for g in grads)
+    flat = torch.empty(0, dtype=torch.float32, device=grads[0].device)
+    flat.set_(grads[0].untyped_storage(), lo, (hi - lo,))
+    return flat
+
+
+def allreduce_grads(model, coalesce=True, bucket_size_mb=-1, group=None):
+    """same call signature and result as the reference (dist_utils.py:31-41): every rank ends with the mean
+    gradient.  Gradients that already share one flat arena are reduced in place with a single collective."""
+    grads = [p.grad.data for p in model.parameters() if p.requires_grad and p.grad is not None]
+    world_size = dist.get_world_size(group)
+    if coalesce:
+        flat = _arena_of(grads) if bucket_size_mb <= 0 else None
+        if flat is not None:
+            allreduce_flat_grads(flat, world_size, group)      # padding between views is reduced too: harmless zeros
+        else:
+            _allreduce_coalesced(grads, world_size, bucket_size_mb, group)
+    else:
+        for t in grads:
+            dist.all_reduce(t.div_(world_size), group=group)   # dist_utils.py:40-41
+
+
+def clip_grad_norm_flat(flat_grads_list, max_norm, norm_type=2):
+    """L2 clip over one or more flat gradient arenas (grad_clip=dict(max_norm=35, norm_type=2),
+    configs/3d-multi-resolution-rcnn.py:236) without a host sync"""
+    assert norm_type == 2
+    total = torch.sqrt(sum((g * g).sum() for g in flat_grads_list))
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    for g in flat_grads_list:
+        g.mul_(coef)
+    return total
+
+
+class DistOptimizerStep:
+    """`DistOptimizerHook.after_train_iter` (dist_utils.py:44-57) as a callable:
+    zero_grad -> loss.backward() -> allreduce_grads -> clip -> optimizer.step()."""
+
+    def __init__(self, model, optimizer, grad_clip=None, coalesce=True, bucket_size_mb=-1):
+        self.model, self.optimizer, self.grad_clip = model, optimizer, grad_clip
+        self.coalesce, self.bucket_size_mb = coalesce, bucket_size_mb
+
+    def __call__(self, loss):
+        self.optimizer.zero_grad()
+        for m in self.model.modules():
+            if hasattr(m, 'flat_grads') and m is not self.model:
+                m.zero_grad()
+        if hasattr(self.model, 'flat_grads'):
+            self.model.zero_grad()
+        loss.backward()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            allreduce_grads(self.model, self.coalesce, self.bucket_size_mb)
+        if self.grad_clip is not None:
+            torch.nn.utils.clip_grad_norm_([p for p in self.model.parameters() if p.requires_grad], **self.grad_clip)
+        self.optimizer.step()

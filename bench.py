@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training iterations/sec of the ResNet3D-50 + FPN3D forward+backward hot path on
+synthetic 1x3x80x512x512 fp32 volumes (BASELINE.json configs[1]), one volume per GPU (data parallel,
+weak scaling).  For N > 1 every step ends with the reference's gradient exchange: one SUM all-reduce of the
+flat fp32 gradient arena over RCCL followed by 1/world (mmdet/core/utils/dist_utils.py:9-41).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line (rank 0).  `roofline` is measured live: HIP events (torch.cuda.Event on the stream the
+kernels are launched on) bracket every launch of the dominant kernel inside the timed steps.
+`cpu_baseline` times the oracle's plain-PyTorch CPU restatement of the same graph on the host cores
+(rank 0, N == 1 only, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+# algorithmic FLOPs of one forward+backward of backbone+FPN on a 1x3x80x512x512 volume
+FLOP_FWD_BWD_512 = 1124.38e9
+PEAK_FP32_MATRIX = 157.3e12          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32 peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--vol', type=int, nargs=3, default=[80, 512, 512], metavar=('D', 'H', 'W'),
+                    help='volume size (default = the configuration the metric is quoted on)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the cpu_baseline sample')
+    ap.add_argument('--per-kernel', action='store_true', help='also print a per-kernel time table to stderr')
+    return ap.parse_args()
+
+
+def cpu_baseline(seconds):
+    """oracle/torch_ref_model.py (pinned to the reference by tests/golden/backbone_fpn.npz) forward+backward on the
+    host cores, on the reference's own CPU-runnable case (configs[0]: 1x3x32x128x128), scaled to 512x512x80
+    volumes by the algorithmic FLOP ratio 432.34/10.81 = 40.0."""
+    from oracle.torch_ref_model import RefExtractFeat
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    m = RefExtractFeat()
+    x = torch.randn(1, 3, 32, 128, 128)
+
+    def it():
+        m.zero_grad()
+        outs = m(x)
+        sum(o.sum() for o in outs).backward()
+
+    for _ in range(2):
+        it()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        it()
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 200:
+            break
+    per_small = el / n
+    scale = 432.34 / 10.81
+    return {'value': 1.0 / (per_small * scale), 'unit': 'iters/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'{n} fwd+bwd iterations of the PyTorch-CPU (oneDNN) restatement on 1x3x32x128x128 '
+                      f'({per_small * 1e3:.1f} ms each), scaled x{scale:.1f} by algorithmic FLOPs to 512x512x80'}
+
+
+def ops_microbench(dev):
+    """second half of BASELINE.json's metric: RoIAlign3D + NMS3D microseconds per volume (SURVEY.md section 8d inputs)"""
+    import numpy as np
+    from mr3d_amd.mmdet_ops import RoIAlign3D
+    from mr3d_amd.mmdet_ops.nms import nms_cuda
+    g = torch.Generator(device='cpu').manual_seed(0)
+    out = {}
+
+    def timed(fn, iters=20):
+        fn(); torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(iters):
+            fn()
+        e.record(); torch.cuda.synchronize()
+        return s.elapsed_time(e) * 1e3 / iters
+
+    # NMS3D: 5 pyramid levels x 2 pathways per volume; per level N in {2000,2000,2000,1280,192}, thr 0.7
+    tot = 0.0
+    for lvl, (n, stride, zs) in enumerate(zip((2000, 2000, 2000, 1280, 192), (4, 8, 16, 32, 64), (2, 4, 8, 16, 32))):
+        size = torch.tensor([stride * 2.0, stride * 2.0, zs * 2.0])
+        ctr = torch.rand(n, 3, generator=g) * torch.tensor([512.0, 512.0, 80.0])
+        ctr = ctr + torch.randn(n, 3, generator=g) * 0.25 * size
+        half = size * (1 + 0.25 * torch.randn(n, 3, generator=g)).abs() / 2
+        boxes = torch.stack([ctr[:, 0] - half[:, 0], ctr[:, 1] - half[:, 1], ctr[:, 0] + half[:, 0], ctr[:, 1] + half[:, 1],
+                             ctr[:, 2] - half[:, 2], ctr[:, 2] + half[:, 2]], 1)
+        dets = torch.cat([boxes, torch.rand(n, 1, generator=g)], 1).to(dev)
+        tot += timed(lambda: nms_cuda.nms_3d(dets, 0.7))
+    out['nms3d_us_per_vol'] = 2 * tot
+    # RoIAlign3D: 512 rois x 64 ch x (3,7,7) and 128 rois x (10,14,14) on a channels-last P2 map, forward+backward
+    feat = torch.randn(1, 64, 40, 128, 128, device=dev).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
+    rng = np.random.default_rng(0)
+
+    def rois(n):
+        s = np.exp(rng.uniform(np.log([4, 4, 2]), np.log([128, 128, 40]), (n, 3)))
+        c = rng.uniform([0, 0, 0], [512, 512, 80], (n, 3))
+        lo, hi = np.clip(c - s / 2, 0, [511, 511, 79]), np.clip(c + s / 2, 0, [511, 511, 79])
+        return torch.tensor(np.stack([np.zeros(n), lo[:, 0], lo[:, 1], hi[:, 0], hi[:, 1], lo[:, 2], hi[:, 2]], 1),
+                            dtype=torch.float32, device=dev)
+
+    for tag, n, osz, od in (('bbox', 512, 7, 3), ('mask', 128, 14, 10)):
+        layer, r = RoIAlign3D(osz, od, 0.25, 0.5, sample_num=2), rois(n)
+        out[f'roialign3d_{tag}_fwd_us'] = timed(lambda: layer(feat.detach(), r))
+        top = torch.randn(n, 64, od, osz, osz, device=dev)
+
+        def fb():
+            feat.grad = None
+            layer(feat, r).backward(top)
+        out[f'roialign3d_{tag}_fwd_bwd_us'] = timed(fb, iters=5)
+    return out
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get('RANK', 0))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the HIP hot path has no CPU fallback')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)          # backend "nccl" is RCCL on ROCm
+
+    import mr3d_amd
+    from mr3d_amd import _hip
+    from mr3d_amd.detector import ExtractFeat3D
+    from mr3d_amd.dist_utils import allreduce_flat_grads, broadcast_params
+
+    torch.manual_seed(1234 + rank)
+    D, H, W = a.vol
+    eng = ExtractFeat3D(device=dev)
+    if world > 1:
+        broadcast_params(eng.flat_params)                       # identical initial weights on all ranks (mmcv DDP init)
+    x = torch.randn(1, 3, D, H, W, device=dev)
+    outs = eng.forward_features(x)
+    cots = [torch.randn(o.shape, device=dev).contiguous(memory_format=torch.channels_last_3d) for o in outs]
+    plan = eng._plan_for(x.shape)
+    scale = (D * H * W) / (80.0 * 512 * 512)
+
+    def step(marks_f=None, marks_b=None):
+        eng.zero_grad()
+        plan.x_in.copy_(x)
+        ev = plan.fwd.run(dev, marks_f)
+        for gbuf, g in zip(plan.gouts, cots):
+            gbuf.copy_(g.permute(0, 2, 3, 4, 1))
+        evb = plan.bwd.run(dev, marks_b)
+        if world > 1:
+            allreduce_flat_grads(eng.flat_grads, world)
+        return ev, evb
+
+    # ---- warmup; the last warmup step is bracketed op by op to find the dominant kernel
+    for _ in range(max(a.warmup - 1, 0)):
+        step()
+    ev, evb = step(list(range(plan.fwd.n)), list(range(plan.bwd.n)))
+    torch.cuda.synchronize()
+    groups = {}
+    for which, events, p in (('f', ev, plan.fwd), ('b', evb, plan.bwd)):
+        for k, (s, e) in events.items():
+            key, flops = _hip.op_kernel_key(p.array[k])
+            gk = groups.setdefault(key, {'ms': 0.0, 'flops': 0.0, 'ops': [], 'n': 0})
+            gk['ms'] += s.elapsed_time(e); gk['flops'] += flops; gk['n'] += 1; gk['ops'].append((which, k))
+    dom = max(groups, key=lambda k: groups[k]['ms'])
+    if a.per_kernel and rank == 0:
+        tot = sum(v['ms'] for v in groups.values())
+        for k, v in sorted(groups.items(), key=lambda kv: -kv[1]['ms']):
+            tf = v['flops'] / v['ms'] / 1e9 if v['ms'] > 0 else 0
+            print(f'{k:40s} n={v["n"]:3d} {v["ms"]:8.3f} ms {100 * v["ms"] / tot:5.1f}%  {tf:7.2f} TFLOP/s', file=sys.stderr)
+        print(f'sum of per-op times {tot:.3f} ms', file=sys.stderr)
+    marks_f = sorted(k for w_, k in groups[dom]['ops'] if w_ == 'f')
+    marks_b = sorted(k for w_, k in groups[dom]['ops'] if w_ == 'b')
+
+    # ---- timed region: exactly K steps between barrier + synchronize on both sides
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dom_events = []
+    for _ in range(a.steps):
+        e1, e2 = step(marks_f, marks_b)
+        dom_events.append((e1, e2))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    if rank == 0:
+        dom_ms = sum(s.elapsed_time(e) for e1, e2 in dom_events for (s, e) in list(e1.values()) + list(e2.values()))
+        launches = a.steps * groups[dom]['n']
+        ach = groups[dom]['flops'] * a.steps / (dom_ms * 1e-3)
+        ms_per_step = el * 1e3 / a.steps
+        res = {
+            'metric': 'train iters/sec on 512x512x80 vols (ResNet3D-50+FPN3D forward+backward, fp32)',
+            'value': world * a.steps / el, 'unit': 'iters/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'data': 'synthetic',
+            'config': {'workload': f'BASELINE configs[1]: 1x3x{D}x{H}x{W} fp32 volume per GPU, ResNet3D-50 + FPN3D '
+                                   'forward+backward (eval-mode BN, random-init weights)' +
+                                   ('' if world == 1 else ' + flat-gradient all-reduce over RCCL'),
+                       'global_batch': world, 'parallelism': f'dp{world}'},
+            'roofline': {'bound': 'mfma', 'kernel': dom, 'achieved': ach / 1e12, 'peak': PEAK_FP32_MATRIX / 1e12,
+                         'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_MATRIX, 'traffic': None,
+                         'avg_launch_ms': dom_ms / launches, 'launches_per_step': groups[dom]['n'],
+                         'whole_step_frac': FLOP_FWD_BWD_512 * scale / (ms_per_step * 1e-3) / PEAK_FP32_MATRIX},
+        }
+        if world == 1:
+            try:
+                res['aux'] = {k: round(v, 1) for k, v in ops_microbench(dev).items()}
+            except Exception as exc:  # the headline number must still print
+                res['aux'] = {'error': repr(exc)}
+            if not a.no_cpu_baseline:
+                res['cpu_baseline'] = cpu_baseline(a.cpu_seconds)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,4 +1,6 @@
-"""Plain-PyTorch fp32 restatement of the reference's ResNet3D-50 + FPN3D graph (test infrastructure).
+"""Plain-PyTorch fp32 restatement of the reference's ResNet3D-50 + FPN3D graph.
+
+TEST INFRASTRUCTURE (part of the oracle): imported only by tests/ and by bench.py's cpu_baseline leg.
 
 Follows mmdet/models/backbones/resnet3d.py:89-235,238-285,289-478 and mmdet/models/necks/fpn3d.py:10-134
 with the same parameter names, so the closed-form weight fill (tests/golden/weightfill.py) gives the same

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from weightfill import closed_form_array, volume_like, cotangent_like
-from torch_ref_model import RefExtractFeat
+from oracle.torch_ref_model import RefExtractFeat
 
 RTOL = 1e-4
 
