@@ -48,7 +48,19 @@ def cpu_baseline(seconds):
     host cores, on the reference's own CPU-runnable case (configs[0]: 1x3x32x128x128), scaled to 512x512x80
     volumes by the algorithmic FLOP ratio 432.34/10.81 = 40.0."""
     from oracle.torch_ref_model import RefExtractFeat
-    cores = os.cpu_count() or 1
+    # threads = the CPUs this process may really use: affinity mask, clipped by the cgroup CPU quota (the GPU box
+    # shows 256 CPUs but grants 16: 256 oneDNN threads took 85 s per iteration there, 16 take 66 ms)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            avail = max(1, min(avail, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    cores = max(1, min(avail, 32))
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     m = RefExtractFeat()
@@ -59,8 +71,7 @@ def cpu_baseline(seconds):
         outs = m(x)
         sum(o.sum() for o in outs).backward()
 
-    for _ in range(2):
-        it()
+    it()                                   # warm-up (oneDNN primitive creation)
     n, t0 = 0, time.perf_counter()
     while True:
         it()
@@ -71,6 +82,7 @@ def cpu_baseline(seconds):
     per_small = el / n
     scale = 432.34 / 10.81
     return {'value': 1.0 / (per_small * scale), 'unit': 'iters/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'host_cpus': avail,
             'sample': f'{n} fwd+bwd iterations of the PyTorch-CPU (oneDNN) restatement on 1x3x32x128x128 '
                       f'({per_small * 1e3:.1f} ms each), scaled x{scale:.1f} by algorithmic FLOPs to 512x512x80'}
 
