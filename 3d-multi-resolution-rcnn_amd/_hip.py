@@ -214,6 +214,7 @@ def conv3d_wgrad(x, dy, dw_packed, k, stride, pad, dbias=None):
 # plan records (mr3d_op / mr3d_layer_desc in include/mr3d.h)
 OP_CONV_FWD, OP_CONV_WGRAD, OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_ZERO_STUFF2, OP_UPSAMPLE_ADJ = 1, 2, 3, 4, 5, 6
 OP_SUBSAMPLE_FWD, OP_SUBSAMPLE_BWD, OP_VOLUME_PACK, OP_MEMSET0, OP_AXPY, OP_PREP_WEIGHTS, OP_FINISH_GRADS = 7, 8, 9, 10, 11, 12, 13
+OP_STEM_FWD, OP_STEM_WGRAD = 14, 15
 
 
 class Op(ctypes.Structure):
@@ -298,8 +299,34 @@ def op_kernel_key(op):
         flops = 2.0 * n * do * ho * wo * cout * real_cin * k ** 3
         name = 'conv3d_fwd' if op.kind == OP_CONV_FWD else 'conv3d_wgrad'
         return f'{name}<k{k},s{sd}{sh}{sw},cc{cc},nb{nb}>', flops
+    if op.kind in (OP_STEM_FWD, OP_STEM_WGRAD):
+        n, d, h, w = i[0], i[1], i[2], i[3]
+        flops = 2.0 * n * d * ((h - 1) // 2 + 1) * ((w - 1) // 2 + 1) * 16 * 3 * 343
+        return ('stem_fwd' if op.kind == OP_STEM_FWD else 'stem_wgrad'), flops
     names = {OP_MAXPOOL_FWD: 'maxpool_fwd', OP_MAXPOOL_BWD: 'maxpool_bwd', OP_ZERO_STUFF2: 'zero_stuff', OP_UPSAMPLE_ADJ:
              'upsample_adjoint_add', OP_SUBSAMPLE_FWD: 'subsample2_fwd', OP_SUBSAMPLE_BWD: 'subsample2_bwd', OP_VOLUME_PACK:
              'ncdhw3_to_ndhwc4', OP_MEMSET0: 'memset', OP_AXPY: 'axpy', OP_PREP_WEIGHTS: 'prep_weights', OP_FINISH_GRADS:
              'finish_grads'}
     return names.get(op.kind, f'op{op.kind}'), 0.0
+
+
+def stem_conv_forward(x_ncdhw, w_packed, shift=None, relu=False):
+    """x [N,3,D,H,W] planar fp32, w_packed [343,4,16] -> y [N,D,Ho,Wo,16] (mr3d_stem_conv_forward)"""
+    assert x_ncdhw.is_cuda and x_ncdhw.is_contiguous() and x_ncdhw.size(1) == 3 and tuple(w_packed.shape) == (343, 4, 16)
+    n, _, d, h, w = x_ncdhw.shape
+    y = torch.empty((n, d, (h - 1) // 2 + 1, (w - 1) // 2 + 1, 16), dtype=torch.float32, device=x_ncdhw.device)
+    with torch.cuda.device(x_ncdhw.device):
+        st = lib().mr3d_stem_conv_forward(ptr(x_ncdhw), ptr(w_packed), ctypes.c_void_p(_opt(shift)), ptr(y), n, d, h, w,
+                                          int(bool(relu)), stream_ptr(x_ncdhw.device))
+    check(st, 'mr3d_stem_conv_forward')
+    return y
+
+
+def stem_conv_wgrad(x_ncdhw, dy, dw_packed, dbias=None):
+    n, _, d, h, w = x_ncdhw.shape
+    assert dy.is_contiguous() and tuple(dw_packed.shape) == (343, 4, 16)
+    with torch.cuda.device(x_ncdhw.device):
+        st = lib().mr3d_stem_conv_wgrad(ptr(x_ncdhw), ptr(dy), ptr(dw_packed), ctypes.c_void_p(_opt(dbias)), n, d, h, w,
+                                        stream_ptr(x_ncdhw.device))
+    check(st, 'mr3d_stem_conv_wgrad')
+    return dw_packed

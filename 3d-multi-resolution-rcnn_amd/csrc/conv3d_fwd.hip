@@ -225,6 +225,10 @@ extern "C" int mr3d_conv3d_forward(const mr3d_conv3d_desc *d, mr3d_stream_t stre
   hipStream_t stream = mr3d_stream(stream_);
   const int k = d->kd, s = d->sd * 100 + d->sh * 10 + d->sw;
   if (k == 1 && s == 111) {
+    if (a.pd == 0 && a.ph == 0 && a.pw == 0) {
+      const int st = mr3d_pointwise_fwd_try(a, stream);
+      if (st != MR3D_ERR_UNSUPPORTED) return st;
+    }
     if (a.Cin % 64 == 0) return dispatch_nb<1, 1, 1, 1, 64>(a, nb, stream);
     if (a.Cin % 32 == 0) return dispatch_nb<1, 1, 1, 1, 32>(a, nb, stream);
     if (a.Cin % 16 == 0) return dispatch_nb<1, 1, 1, 1, 16>(a, nb, stream);

@@ -51,6 +51,11 @@ int run_one(const mr3d_op &o, mr3d_stream_t s) {
     case MR3D_OP_FINISH_GRADS:
       return mr3d_finish_grads((const mr3d_layer_desc *)p[0], i[0], i[1], (const float *)p[1], (const float *)p[2],
                                (float *)p[3], s);
+    case MR3D_OP_STEM_FWD:
+      return mr3d_stem_conv_forward((const float *)p[0], (const float *)p[1], (const float *)p[2], (float *)p[3], i[0], i[1], i[2],
+                                    i[3], i[4], s);
+    case MR3D_OP_STEM_WGRAD:
+      return mr3d_stem_conv_wgrad((const float *)p[0], (const float *)p[1], (float *)p[2], (float *)p[3], i[0], i[1], i[2], i[3], s);
   }
   return MR3D_ERR_INVALID_ARG;
 }

@@ -1,0 +1,431 @@
+// Pointwise (1x1x1, stride 1) convolution forward / data gradient and weight gradient for the
+// HBM-bound layers of the backbone (large position counts, Cin*Cout small): bottleneck conv1 / conv3 /
+// downsample of resnet3d.py:126,173,251 and the FPN laterals fpn3d.py:48-55.
+//
+// These layers move 3-25 FLOP per byte: they live on the HBM roofline, not the MFMA one.  Design for
+// bytes in flight, not for the matrix pipe:
+//   * every WAVE is an independent streaming engine: it owns a private LDS slab, walks its own sequence of
+//     row tiles (ROWS consecutive positions x all Cin channels -- contiguous in NDHWC memory, so the tile is
+//     one fully coalesced run of 16-B-per-lane loads) and never meets a workgroup barrier;
+//   * software pipeline per wave: the global loads of tile t+1 are issued into registers before the MFMAs
+//     of tile t start, and land in LDS after them -> up to 16 KiB per wave / 128 KiB per CU in flight;
+//   * the weight fragments of the whole layer stay in VGPRs for the kernel's lifetime when Cin*Cout <= 4096
+//     (all 655k-position layers), otherwise in LDS, loaded once per (persistent) workgroup;
+//   * fp32 MFMA (32x32x2, or 16x16x4 when Cout = 16) does the arithmetic -- far below its peak by design;
+//   * epilogue fused exactly like conv3d_fwd.hip (shift, two residual adds, nearest-upsample add, ReLU, mask).
+// wgrad: dW[ci][co] = sum_p x[p][ci]*dy[p][co]: both operands stream; per wave both tiles are staged in its
+// LDS slab, the [Cin x Cout] accumulators stay in registers across all tiles, one atomic pass at the end;
+// sum_p dy[p][co] (bias / BN-beta gradient) is reduced in the same pass.
+#include "conv3d.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int kWavesPerWG = 4;
+
+__device__ __forceinline__ int pw_nearest_src(int dst, int in, int out) {
+  int s = (int)floorf((float)dst * ((float)in / (float)out));
+  return s < in - 1 ? s : in - 1;
+}
+
+template <int CI_, int CO_>
+struct PwCfg {
+  static constexpr int CI = CI_, CO = CO_;
+  static constexpr bool k16 = (CO == 16);
+  static constexpr int TM = k16 ? 16 : 32;
+  static constexpr int KSTEP = k16 ? 4 : 2;
+  static constexpr int KK = CI / KSTEP;
+  static constexpr int NT = CO / TM;
+  static constexpr bool BREG = (KK * NT <= 64);            // weights resident in VGPRs
+  static constexpr int ROWS = (CI <= 64 && CO <= 64) ? 64 : 32;   // rows per wave tile (register budget)
+  static constexpr int MT = ROWS / TM;
+  static constexpr int RS = CI + 4;                        // LDS row stride (floats), keeps 16-B alignment
+  static constexpr int OS = CO + 4;                        // LDS row stride of the output tile
+  static constexpr int SLAB = ROWS * (RS > OS ? RS : OS);  // floats per wave: x tile, later reused for the y tile
+  static constexpr int NOUT = ROWS * CO / 4 / 64;          // float4 per lane of the output tile
+  static constexpr int WLDS = BREG ? 0 : CI * CO;          // floats of weights in LDS
+  static constexpr int LDS_BYTES = (WLDS + kWavesPerWG * SLAB) * 4;
+  static constexpr int NLOAD = ROWS * CI / 4 / 64;         // float4 loads per lane per tile
+  static constexpr int ACC = k16 ? 4 : 16;
+  static_assert(ROWS * CI % 256 == 0 && ROWS * CO % 256 == 0, "tiles must be whole numbers of wave-wide float4 accesses");
+};
+
+template <class C>
+__global__ __launch_bounds__(256) void pointwise_fwd_kernel(Conv3dFwdArgs p, long long rows_total) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float *slab = lds + C::WLDS + wave * C::SLAB;
+  const int li = lane % C::TM, lk = lane / C::TM;
+  using acc_t = typename std::conditional<C::k16, f32x4, f32x16>::type;
+
+  // ---- weights: registers (whole layer) or LDS
+  float breg[C::BREG ? C::KK : 1][C::BREG ? C::NT : 1];
+  if constexpr (C::BREG) {
+#pragma unroll
+    for (int kk = 0; kk < C::KK; ++kk)
+#pragma unroll
+      for (int nt = 0; nt < C::NT; ++nt) breg[kk][nt] = p.w[(size_t)(kk * C::KSTEP + lk) * C::CO + nt * C::TM + li];
+  } else {
+    for (int e = tid; e < C::CI * C::CO / 4; e += 256)
+      *reinterpret_cast<float4 *>(lds + e * 4) = *reinterpret_cast<const float4 *>(p.w + (size_t)e * 4);
+    __syncthreads();
+  }
+
+  const long long ntiles = (rows_total + C::ROWS - 1) / C::ROWS;
+  const long long wstride = (long long)gridDim.x * kWavesPerWG;
+  long long tile = (long long)blockIdx.x * kWavesPerWG + wave;
+
+  float4 pre[C::NLOAD];
+  auto issue_loads = [&](long long t) {
+    const long long f0 = t * (C::ROWS * C::CI / 4);               // float4 index of the tile start
+    const long long fmax = rows_total * (C::CI / 4);
+#pragma unroll
+    for (int q = 0; q < C::NLOAD; ++q) {
+      const long long f = f0 + q * 64 + lane;
+      pre[q] = (f < fmax) ? reinterpret_cast<const float4 *>(p.x)[f] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  if (tile < ntiles) issue_loads(tile);
+
+  for (; tile < ntiles; tile += wstride) {
+    // ---- registers -> this wave's LDS slab (row-padded)
+#pragma unroll
+    for (int q = 0; q < C::NLOAD; ++q) {
+      const int f = q * 64 + lane;
+      const int row = f / (C::CI / 4), c4 = f % (C::CI / 4);
+      *reinterpret_cast<float4 *>(slab + row * C::RS + c4 * 4) = pre[q];
+    }
+    if (tile + wstride < ntiles) issue_loads(tile + wstride);       // in flight during the MFMAs below
+
+    acc_t acc[C::MT][C::NT];
+#pragma unroll
+    for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < C::ACC; ++r) acc[mt][nt][r] = 0.f;
+
+#pragma unroll
+    for (int kk = 0; kk < C::KK; ++kk) {
+      float a[C::MT], b[C::NT];
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt) a[mt] = slab[(mt * C::TM + li) * C::RS + kk * C::KSTEP + lk];
+#pragma unroll
+      for (int nt = 0; nt < C::NT; ++nt) {
+        if constexpr (C::BREG) b[nt] = breg[kk][nt];
+        else b[nt] = lds[(kk * C::KSTEP + lk) * C::CO + nt * C::TM + li];
+      }
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < C::NT; ++nt) {
+          if constexpr (C::k16)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+          else
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue.  Each optional term is one wave-uniform branch around a fully unrolled batch of
+    // loads (so the loads of a term are all in flight together), never a per-element branch.
+    const long long row0 = tile * C::ROWS;
+    if (row0 + C::ROWS <= rows_total) {
+      // (1) accumulators -> this wave's LDS slab as a [ROWS][CO] tile (the x tile is dead by now), then
+      // (2) walk the tile in memory order, 16 B per lane: residual / mask loads and the store are all
+      //     fully coalesced 1-KiB wave accesses instead of 4-B-per-lane column accesses.
+#pragma unroll
+      for (int nt = 0; nt < C::NT; ++nt) {
+        const float sh = p.shift ? p.shift[nt * C::TM + li] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < C::ACC; ++r) {
+            const int row = mt * C::TM + (C::k16 ? (lk * 4 + r) : ((r & 3) + 8 * (r >> 2) + 4 * lk));
+            slab[row * C::OS + nt * C::TM + li] = acc[mt][nt][r] + sh;
+          }
+      }
+      const size_t t4 = (size_t)row0 * (C::CO / 4);           // float4 index of the tile in y / add / mask
+      float4 v[C::NOUT];
+#pragma unroll
+      for (int q = 0; q < C::NOUT; ++q) {
+        const int f = q * 64 + lane;
+        v[q] = *reinterpret_cast<const float4 *>(slab + (f / (C::CO / 4)) * C::OS + (f % (C::CO / 4)) * 4);
+      }
+      if (p.add1) {
+        const float4 *a4 = reinterpret_cast<const float4 *>(p.add1) + t4;
+#pragma unroll
+        for (int q = 0; q < C::NOUT; ++q) {
+          const float4 a = a4[q * 64 + lane];
+          v[q].x += a.x; v[q].y += a.y; v[q].z += a.z; v[q].w += a.w;
+        }
+      }
+      if (p.add2) {
+        const float4 *a4 = reinterpret_cast<const float4 *>(p.add2) + t4;
+#pragma unroll
+        for (int q = 0; q < C::NOUT; ++q) {
+          const float4 a = a4[q * 64 + lane];
+          v[q].x += a.x; v[q].y += a.y; v[q].z += a.z; v[q].w += a.w;
+        }
+      }
+      if (p.up) {
+#pragma unroll
+        for (int q = 0; q < C::NOUT; ++q) {
+          const int f = q * 64 + lane;
+          unsigned pq = (unsigned)(row0 + f / (C::CO / 4));      // positions fit 32 bits (checked by the launcher)
+          const unsigned ow = pq % (unsigned)p.Wo; pq /= (unsigned)p.Wo;
+          const unsigned oh = pq % (unsigned)p.Ho; pq /= (unsigned)p.Ho;
+          const unsigned od = pq % (unsigned)p.Do;
+          const unsigned n = pq / (unsigned)p.Do;
+          const int ud = pw_nearest_src((int)od, p.Du, p.Do), uh = pw_nearest_src((int)oh, p.Hu, p.Ho),
+                    uw = pw_nearest_src((int)ow, p.Wu, p.Wo);
+          const float4 a = *reinterpret_cast<const float4 *>(
+              p.up + ((((size_t)n * p.Du + ud) * p.Hu + uh) * p.Wu + uw) * C::CO + (f % (C::CO / 4)) * 4);
+          v[q].x += a.x; v[q].y += a.y; v[q].z += a.z; v[q].w += a.w;
+        }
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int q = 0; q < C::NOUT; ++q) {
+          v[q].x = fmaxf(v[q].x, 0.f); v[q].y = fmaxf(v[q].y, 0.f); v[q].z = fmaxf(v[q].z, 0.f); v[q].w = fmaxf(v[q].w, 0.f);
+        }
+      }
+      if (p.mask) {
+        const float4 *m4 = reinterpret_cast<const float4 *>(p.mask) + t4;
+#pragma unroll
+        for (int q = 0; q < C::NOUT; ++q) {
+          const float4 m = m4[q * 64 + lane];
+          v[q].x = m.x > 0.f ? v[q].x : 0.f; v[q].y = m.y > 0.f ? v[q].y : 0.f;
+          v[q].z = m.z > 0.f ? v[q].z : 0.f; v[q].w = m.w > 0.f ? v[q].w : 0.f;
+        }
+      }
+      float4 *y4 = reinterpret_cast<float4 *>(p.y) + t4;
+#pragma unroll
+      for (int q = 0; q < C::NOUT; ++q) y4[q * 64 + lane] = v[q];
+    } else {
+      // ragged last tile: per-element predicates (at most one tile per launch)
+      for (int nt = 0; nt < C::NT; ++nt) {
+        const int co = nt * C::TM + li;
+        const float sh = p.shift ? p.shift[co] : 0.f;
+        for (int mt = 0; mt < C::MT; ++mt)
+          for (int r = 0; r < C::ACC; ++r) {
+            const int row = C::k16 ? (lk * 4 + r) : ((r & 3) + 8 * (r >> 2) + 4 * lk);
+            const long long pos = row0 + mt * C::TM + row;
+            if (pos >= rows_total) continue;
+            const size_t idx = (size_t)pos * C::CO + co;
+            float v = acc[mt][nt][r] + sh;
+            if (p.add1) v += p.add1[idx];
+            if (p.add2) v += p.add2[idx];
+            if (p.up) {
+              unsigned q = (unsigned)pos;
+              const unsigned ow = q % (unsigned)p.Wo; q /= (unsigned)p.Wo;
+              const unsigned oh = q % (unsigned)p.Ho; q /= (unsigned)p.Ho;
+              const unsigned od = q % (unsigned)p.Do;
+              const unsigned n = q / (unsigned)p.Do;
+              const int ud = pw_nearest_src((int)od, p.Du, p.Do), uh = pw_nearest_src((int)oh, p.Hu, p.Ho),
+                        uw = pw_nearest_src((int)ow, p.Wu, p.Wo);
+              v += p.up[((((size_t)n * p.Du + ud) * p.Hu + uh) * p.Wu + uw) * C::CO + co];
+            }
+            if (p.relu) v = fmaxf(v, 0.f);
+            if (p.mask) v = p.mask[idx] > 0.f ? v : 0.f;
+            p.y[idx] = v;
+          }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ wgrad
+template <int CI_, int CO_>
+struct PwWgCfg {
+  static constexpr int CI = CI_, CO = CO_;
+  static constexpr int MT = CI / 16, NT = CO / 16;        // 16x16x4 tiles of the [CI x CO] result
+  static constexpr int ROWS = 32;                         // positions per wave tile (8 MFMA k-steps)
+  static constexpr int XS = CI + 4, YS = CO + 4;          // LDS row strides
+  static constexpr int SLAB = ROWS * (XS + YS);
+  static constexpr int LDS_BYTES = kWavesPerWG * SLAB * 4;
+  static constexpr int NLX = ROWS * CI / 4 / 64, NLY = ROWS * CO / 4 / 64;
+  static_assert(MT * NT <= 16, "accumulators: [CI x CO] <= 4096 per wave");
+  static_assert((ROWS * CI) % 256 == 0 && (ROWS * CO) % 256 == 0, "whole wave-wide float4 loads");
+};
+
+template <class C>
+__global__ __launch_bounds__(256) void pointwise_wgrad_kernel(Conv3dWgradArgs p, long long rows_total) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float *xs = lds + wave * C::SLAB;
+  float *ys = xs + C::ROWS * C::XS;
+  const int li = lane & 15, lk = lane >> 4;
+
+  f32x4 acc[C::MT][C::NT];
+#pragma unroll
+  for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < C::NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum[C::NT];
+#pragma unroll
+  for (int nt = 0; nt < C::NT; ++nt) bsum[nt] = 0.f;
+
+  const long long ntiles = (rows_total + C::ROWS - 1) / C::ROWS;
+  const long long wstride = (long long)gridDim.x * kWavesPerWG;
+  long long tile = (long long)blockIdx.x * kWavesPerWG + wave;
+  float4 px[C::NLX], py[C::NLY];
+  auto issue_loads = [&](long long t) {
+    const long long fx0 = t * (C::ROWS * C::CI / 4), fxmax = rows_total * (C::CI / 4);
+    const long long fy0 = t * (C::ROWS * C::CO / 4), fymax = rows_total * (C::CO / 4);
+#pragma unroll
+    for (int q = 0; q < C::NLX; ++q) {
+      const long long f = fx0 + q * 64 + lane;
+      px[q] = (f < fxmax) ? reinterpret_cast<const float4 *>(p.x)[f] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < C::NLY; ++q) {
+      const long long f = fy0 + q * 64 + lane;
+      py[q] = (f < fymax) ? reinterpret_cast<const float4 *>(p.dy)[f] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  if (tile < ntiles) issue_loads(tile);
+
+  for (; tile < ntiles; tile += wstride) {
+#pragma unroll
+    for (int q = 0; q < C::NLX; ++q) {
+      const int f = q * 64 + lane;
+      *reinterpret_cast<float4 *>(xs + (f / (C::CI / 4)) * C::XS + (f % (C::CI / 4)) * 4) = px[q];
+    }
+#pragma unroll
+    for (int q = 0; q < C::NLY; ++q) {
+      const int f = q * 64 + lane;
+      *reinterpret_cast<float4 *>(ys + (f / (C::CO / 4)) * C::YS + (f % (C::CO / 4)) * 4) = py[q];
+    }
+    if (tile + wstride < ntiles) issue_loads(tile + wstride);
+#pragma unroll
+    for (int ks = 0; ks < C::ROWS / 4; ++ks) {
+      const int row = ks * 4 + lk;                      // A[i = ci][k = position], B[k = position][j = co]
+      float a[C::MT], b[C::NT];
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt) a[mt] = xs[row * C::XS + mt * 16 + li];
+#pragma unroll
+      for (int nt = 0; nt < C::NT; ++nt) { b[nt] = ys[row * C::YS + nt * 16 + li]; bsum[nt] += b[nt]; }
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < C::NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[nt], acc[mt][nt], 0, 0, 0);
+    }
+  }
+
+  // ---- one atomic pass: dw[ci][co] and dbias[co]
+#pragma unroll
+  for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        atomicAdd(p.dw + (size_t)(mt * 16 + lk * 4 + r) * C::CO + nt * 16 + li, acc[mt][nt][r]);
+  if (p.dbias) {
+#pragma unroll
+    for (int nt = 0; nt < C::NT; ++nt) {
+      float s = bsum[nt];
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      if (lk == 0) atomicAdd(p.dbias + nt * 16 + li, s);
+    }
+  }
+}
+
+int num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+template <class C, class K>
+int set_lds_attr(K kernel) {
+  static bool done = false;
+  if (!done && C::LDS_BYTES > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            C::LDS_BYTES) != hipSuccess) {
+      (void)hipGetLastError();
+      return MR3D_ERR_LAUNCH;
+    }
+    done = true;
+  }
+  return MR3D_OK;
+}
+
+template <int CI, int CO>
+int launch_pw_fwd(const Conv3dFwdArgs &a, hipStream_t stream) {
+  using C = PwCfg<CI, CO>;
+  if (set_lds_attr<C>(pointwise_fwd_kernel<C>) != MR3D_OK) return MR3D_ERR_LAUNCH;
+  const long long rows = (long long)a.N * a.Do * a.Ho * a.Wo;
+  const long long ntiles = (rows + C::ROWS - 1) / C::ROWS;
+  const int wg_per_cu = (160 * 1024) / C::LDS_BYTES > 2 ? 2 : ((160 * 1024) / C::LDS_BYTES < 1 ? 1 : (160 * 1024) / C::LDS_BYTES);
+  long long grid = (long long)num_cus() * wg_per_cu;
+  const long long need = (ntiles + kWavesPerWG - 1) / kWavesPerWG;
+  if (grid > need) grid = need;
+  pointwise_fwd_kernel<C><<<(unsigned)grid, 256, C::LDS_BYTES, stream>>>(a, rows);
+  return mr3d_launch_status();
+}
+
+template <int CI, int CO>
+int launch_pw_wgrad(const Conv3dWgradArgs &a, hipStream_t stream) {
+  using C = PwWgCfg<CI, CO>;
+  if (set_lds_attr<C>(pointwise_wgrad_kernel<C>) != MR3D_OK) return MR3D_ERR_LAUNCH;
+  const long long rows = (long long)a.N * a.Do * a.Ho * a.Wo;
+  const long long ntiles = (rows + C::ROWS - 1) / C::ROWS;
+  const int wg_per_cu = (160 * 1024) / C::LDS_BYTES > 2 ? 2 : ((160 * 1024) / C::LDS_BYTES < 1 ? 1 : (160 * 1024) / C::LDS_BYTES);
+  long long grid = (long long)num_cus() * wg_per_cu;
+  const long long need = (ntiles + kWavesPerWG * 4 - 1) / (kWavesPerWG * 4);   // >= 4 tiles per wave before the atomics
+  if (grid > need) grid = need;
+  if (grid < 1) grid = 1;
+  pointwise_wgrad_kernel<C><<<(unsigned)grid, 256, C::LDS_BYTES, stream>>>(a, rows);
+  return mr3d_launch_status();
+}
+
+}  // namespace
+
+// Returns MR3D_ERR_UNSUPPORTED when the shape is not one of the streaming instances: the caller then uses
+// the generic halo-tile kernels of conv3d_fwd.hip / conv3d_wgrad.hip.
+int mr3d_pointwise_fwd_try(const Conv3dFwdArgs &a, hipStream_t stream) {
+  if (a.ysd != 1 || a.ysh != 1 || a.ysw != 1 || a.yD != a.Do || a.yH != a.Ho || a.yW != a.Wo) return MR3D_ERR_UNSUPPORTED;
+  if (a.D != a.Do || a.H != a.Ho || a.W != a.Wo) return MR3D_ERR_UNSUPPORTED;      // stride 1, no padding
+  const long long rows = (long long)a.N * a.Do * a.Ho * a.Wo;
+  if (rows < 32768 || rows > 0x7fffffffLL) return MR3D_ERR_UNSUPPORTED;             // small maps: not HBM-bound
+  const int key = a.Cin * 1000 + a.Cout;
+  switch (key) {
+    case 16016: return launch_pw_fwd<16, 16>(a, stream);
+    case 16064: return launch_pw_fwd<16, 64>(a, stream);
+    case 64016: return launch_pw_fwd<64, 16>(a, stream);
+    case 64032: return launch_pw_fwd<64, 32>(a, stream);
+    case 32064: return launch_pw_fwd<32, 64>(a, stream);
+    case 64064: return launch_pw_fwd<64, 64>(a, stream);
+    case 32128: return launch_pw_fwd<32, 128>(a, stream);
+    case 128032: return launch_pw_fwd<128, 32>(a, stream);
+    case 64128: return launch_pw_fwd<64, 128>(a, stream);
+    case 128064: return launch_pw_fwd<128, 64>(a, stream);
+  }
+  return MR3D_ERR_UNSUPPORTED;
+}
+
+int mr3d_pointwise_wgrad_try(const Conv3dWgradArgs &a, hipStream_t stream) {
+  if (a.D != a.Do || a.H != a.Ho || a.W != a.Wo) return MR3D_ERR_UNSUPPORTED;
+  const long long rows = (long long)a.N * a.Do * a.Ho * a.Wo;
+  if (rows < 32768) return MR3D_ERR_UNSUPPORTED;
+  const int key = a.Cin * 1000 + a.Cout;
+  switch (key) {
+    case 16016: return launch_pw_wgrad<16, 16>(a, stream);
+    case 16064: return launch_pw_wgrad<16, 64>(a, stream);
+    case 64016: return launch_pw_wgrad<64, 16>(a, stream);
+    case 64032: return launch_pw_wgrad<64, 32>(a, stream);
+    case 64064: return launch_pw_wgrad<64, 64>(a, stream);
+    case 32128: return launch_pw_wgrad<32, 128>(a, stream);
+    case 128032: return launch_pw_wgrad<128, 32>(a, stream);
+  }
+  return MR3D_ERR_UNSUPPORTED;
+}

@@ -1,0 +1,289 @@
+// The ResNet3D stem: Conv3d(3, 16, kernel 7, stride (1,2,2), padding 3) (+ folded BN + ReLU), forward and
+// weight gradient (mmdet/models/backbones/resnet3d.py:397-409,467-469).  40 % of the backbone's forward
+// FLOPs sit in this one layer, and it is the worst shape for a generic implicit GEMM (Cin = 3, Cout = 16),
+// so it gets its own kernels that read the volume in the reference's own planar NCDHW layout.
+//
+// GEMM mapping (v_mfma_f32_16x16x4_f32):
+//   forward  D[i = 16 consecutive output x][j = 16 Cout] += A[i][k] * B[k][j],  K = (ci, kd, kh, kw)
+//     kw is padded 7 -> 8 and split as kw = 2*k + s (k = MFMA k index 0..3, s = step 0/1), so the A
+//     operands of BOTH steps of a (ci,kd,kh) row are one aligned ds_read_b64 per lane:
+//        A_s[i][k] = slab[plane d+kd][row 2h+kh][2*x_i + 2*k + s]
+//     consecutive lanes read consecutive 8-byte words: conflict-free without padding tricks.
+//   wgrad    D[i = Cout][j = (kh pair, kw)] += A[i][k = 4 output x] * B[k][j]:
+//        A = dy[pos][co] (LDS tile), B = slab[d+kd][2h + kh0 + (j>>3)][2*x_k + (j&7)]
+//     the 3x7x4 (ci, kd, kh-pair) accumulator tiles are split over the 8 waves and live in registers
+//     across a persistent loop over tiles; one atomic pass at the end.
+// One input channel of the halo block ((TD+6) x (2*TH+5) x 72 floats) is resident in LDS at a time.
+#include "conv3d.h"
+
+namespace {
+
+constexpr int kStemThreads = 512;      // 8 waves: 2 per SIMD
+constexpr int SW_ROW = 72;             // LDS row stride in floats (69 used; multiple of 8 keeps b64 alignment)
+
+// ------------------------------------------------------------------------------------------------ forward
+struct StemFwdArgs {
+  const float *x;      // [N,3,D,H,W] planar
+  const float *wf;     // packed [tap = (kd*7+kh)*7+kw][4][16] (generic packing, BN scale folded, ci 3 = 0)
+  const float *shift;  // [16]
+  float *y;            // [N, D, Ho, Wo, 16]
+  int N, D, H, W, Ho, Wo;
+  int relu;
+};
+
+template <int TD, int TH, int TW>
+struct StemGeo {
+  static constexpr int PD = TD + 6, PH = 2 * (TH - 1) + 7, PW = 2 * (TW - 1) + 7;
+  static constexpr int SLAB = PD * PH * SW_ROW;          // floats of one input channel
+  static_assert(PW <= SW_ROW, "row stride");
+};
+
+template <int TD, int TH, int TW, class G>
+__device__ __forceinline__ void stem_stage_channel(float *slab, const float *__restrict__ xc, int D, int H, int W, int d0,
+                                                   int h0, int w0, int tid) {
+  // xc: base of one (n, ci) plane set; halo origin in input coords: (d0-3, 2*h0-3, 2*w0-3)
+  for (int e = tid; e < G::PD * G::PH * SW_ROW; e += kStemThreads) {
+    const int c = e % SW_ROW, r = (e / SW_ROW) % G::PH, pl = e / (SW_ROW * G::PH);
+    const int id = d0 - 3 + pl, ih = 2 * h0 - 3 + r, iw = 2 * w0 - 3 + c;
+    float v = 0.f;
+    if (c < G::PW && (unsigned)id < (unsigned)D && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+      v = xc[((size_t)id * H + ih) * W + iw];
+    slab[e] = v;
+  }
+}
+
+__global__ __launch_bounds__(kStemThreads) void stem_fwd_kernel(StemFwdArgs p, int tiles_d, int tiles_h, int tiles_w) {
+  constexpr int TD = 8, TH = 8, TW = 32;
+  using G = StemGeo<TD, TH, TW>;
+  extern __shared__ __attribute__((aligned(16))) float slab[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // = output depth inside the tile
+  const int li = lane & 15, lk = lane >> 4;
+  int b = blockIdx.x;
+  const int tw_i = b % tiles_w; b /= tiles_w;
+  const int th_i = b % tiles_h; b /= tiles_h;
+  const int td_i = b % tiles_d; b /= tiles_d;
+  const int n = b;
+  const int d0 = td_i * TD, h0 = th_i * TH, w0 = tw_i * TW;
+
+  f32x4 acc[TH][2];
+#pragma unroll
+  for (int th = 0; th < TH; ++th)
+    for (int wb = 0; wb < 2; ++wb) acc[th][wb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // lane's 8-byte word inside a row: x = wb*16 + li, word index = x + lk  (floats 2x + 2lk, 2x + 2lk + 1)
+  const int lane_off = 2 * li + 2 * lk;
+  const size_t vox = (size_t)p.D * p.H * p.W;
+
+  for (int ci = 0; ci < 3; ++ci) {
+    __syncthreads();
+    stem_stage_channel<TD, TH, TW, G>(slab, p.x + ((size_t)n * 3 + ci) * vox, p.D, p.H, p.W, d0, h0, w0, tid);
+    __syncthreads();
+    // B for (kd, kh): step s uses kw = 2*lk + s; element wf[((kd*7+kh)*7 + kw)*64 + ci*16 + co]
+    auto load_b = [&](int kd, int kh, float &b0, float &b1) {
+      const float *wrow = p.wf + (size_t)((kd * 7 + kh) * 7) * 64 + ci * 16 + li;
+      b0 = wrow[(2 * lk) * 64];
+      b1 = (2 * lk + 1 < 7) ? wrow[(2 * lk + 1) * 64] : 0.f;
+    };
+    float bc0, bc1, bn0 = 0.f, bn1 = 0.f;
+    load_b(0, 0, bc0, bc1);
+    for (int kd = 0; kd < 7; ++kd) {
+#pragma unroll
+      for (int kh = 0; kh < 7; ++kh) {
+        const int nkh = (kh == 6) ? 0 : kh + 1, nkd = (kh == 6) ? kd + 1 : kd;
+        if (nkd < 7) load_b(nkd, nkh, bn0, bn1);
+        const float *rowbase = slab + ((wave + kd) * G::PH + kh) * SW_ROW + lane_off;
+#pragma unroll
+        for (int th = 0; th < TH; ++th) {
+#pragma unroll
+          for (int wb = 0; wb < 2; ++wb) {
+            const float2 a = *reinterpret_cast<const float2 *>(rowbase + (2 * th) * SW_ROW + wb * 32);
+            acc[th][wb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bc0, acc[th][wb], 0, 0, 0);
+            acc[th][wb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bc1, acc[th][wb], 0, 0, 0);
+          }
+        }
+        bc0 = bn0; bc1 = bn1;
+      }
+    }
+  }
+
+  // epilogue: + shift, ReLU, NDHWC store (lane: co = li, rows x = wb*16 + lk*4 + r)
+  const int od = d0 + wave;
+  if (od >= p.D) return;
+  const float sh = p.shift ? p.shift[li] : 0.f;
+#pragma unroll
+  for (int th = 0; th < TH; ++th) {
+    const int oh = h0 + th;
+    if (oh >= p.Ho) continue;
+#pragma unroll
+    for (int wb = 0; wb < 2; ++wb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ow = w0 + wb * 16 + lk * 4 + r;
+        if (ow < p.Wo) {
+          float v = acc[th][wb][r] + sh;
+          if (p.relu) v = fmaxf(v, 0.f);
+          p.y[((((size_t)n * p.D + od) * p.Ho + oh) * p.Wo + ow) * 16 + li] = v;
+        }
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ wgrad
+struct StemWgradArgs {
+  const float *x;      // [N,3,D,H,W] planar
+  const float *dy;     // [N, D, Ho, Wo, 16]
+  float *dw;           // packed [343][4][16], pre-zeroed (ci 3 stays 0)
+  float *dbias;        // [16] or null
+  int N, D, H, W, Ho, Wo;
+};
+
+__global__ __launch_bounds__(kStemThreads) void stem_wgrad_kernel(StemWgradArgs p, int tiles_d, int tiles_h, int tiles_w) {
+  constexpr int TD = 4, TH = 8, TW = 32;
+  using G = StemGeo<TD, TH, TW>;
+  constexpr int M = TD * TH * TW;          // 1024 positions per tile
+  constexpr int DYROW = 17;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *slab = lds;
+  float *dyt = lds + G::SLAB;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  const size_t vox = (size_t)p.D * p.H * p.W;
+  const int num_tiles = p.N * tiles_d * tiles_h * tiles_w;
+
+  // accumulator tiles: g = q*8 + wave (q = 0..3), g in [0,28): kd = g / 4, kh-pair hp = g % 4 (rows kh = 2hp, 2hp+1)
+  f32x4 acc[3][4];
+#pragma unroll
+  for (int ci = 0; ci < 3; ++ci)
+    for (int q = 0; q < 4; ++q) acc[ci][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int goff[4];
+  bool gok[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int g = q * 8 + wave;
+    gok[q] = g < 28;
+    const int gg = gok[q] ? g : 27;
+    const int kd = gg >> 2, hp = gg & 3;
+    // B[k][j]: row kh = 2hp + (j>>3), col kw = j&7 ; lane j = li
+    goff[q] = (kd * G::PH + 2 * hp + (li >> 3)) * SW_ROW + (li & 7);
+  }
+  float bsum = 0.f;
+
+  for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
+    int b = tile;
+    const int tw_i = b % tiles_w; b /= tiles_w;
+    const int th_i = b % tiles_h; b /= tiles_h;
+    const int td_i = b % tiles_d; b /= tiles_d;
+    const int n = b;
+    const int d0 = td_i * TD, h0 = th_i * TH, w0 = tw_i * TW;
+    __syncthreads();
+    // dy tile [m][16] (m = (td*TH + th)*TW + tw), zeros outside
+    for (int it = tid; it < M * 4; it += kStemThreads) {
+      const int m = it >> 2, q4 = it & 3;
+      const int tw = m % TW, th = (m / TW) % TH, td = m / (TW * TH);
+      const int od = d0 + td, oh = h0 + th, ow = w0 + tw;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (od < p.D && oh < p.Ho && ow < p.Wo)
+        v = *reinterpret_cast<const float4 *>(p.dy + ((((size_t)n * p.D + od) * p.Ho + oh) * p.Wo + ow) * 16 + q4 * 4);
+      float *d = dyt + m * DYROW + q4 * 4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    for (int ci = 0; ci < 3; ++ci) {
+      if (ci) __syncthreads();
+      stem_stage_channel<TD, TH, TW, G>(slab, p.x + ((size_t)n * 3 + ci) * vox, p.D, p.H, p.W, d0, h0, w0, tid);
+      __syncthreads();
+#pragma unroll 2
+      for (int ks = 0; ks < M / 4; ++ks) {
+        const int m = ks * 4 + lk;                                  // this lane's position (k index)
+        const int tw = m % TW, th = (m / TW) % TH, td = m / (TW * TH);
+        const float a = dyt[m * DYROW + li];                        // A[i = co][k]
+        if (ci == 0 && wave == 0) bsum += a;
+        const int pos = (td * G::PH + 2 * th) * SW_ROW + 2 * tw;    // halo origin of that position
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float bv = slab[pos + goff[q]];
+          if (ci == 0) acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[0][q], 0, 0, 0);
+          else if (ci == 1) acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[1][q], 0, 0, 0);
+          else acc[2][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[2][q], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // D[i = co][j]: lane holds col j = li, rows co = lk*4 + r
+#pragma unroll
+  for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (!gok[q]) continue;
+      const int g = q * 8 + wave;
+      const int kd = g >> 2, kh = 2 * (g & 3) + (li >> 3), kw = li & 7;
+      if (kh < 7 && kw < 7) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          atomicAdd(p.dw + ((size_t)((kd * 7 + kh) * 7 + kw) * 4 + ci) * 16 + lk * 4 + r, acc[ci][q][r]);
+      }
+    }
+  if (p.dbias && wave == 0) {
+    float s = bsum;
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    if (lk == 0) atomicAdd(p.dbias + li, s);
+  }
+}
+
+}  // namespace
+
+extern "C" int mr3d_stem_conv_forward(const float *x_ncdhw, const float *w_packed, const float *shift, float *y, int n, int d,
+                                      int h, int w, int relu, mr3d_stream_t stream_) {
+  if (!x_ncdhw || !w_packed || !y || n <= 0 || d <= 0 || h <= 0 || w <= 0) return MR3D_ERR_INVALID_ARG;
+  StemFwdArgs a;
+  a.x = x_ncdhw; a.wf = w_packed; a.shift = shift; a.y = y;
+  a.N = n; a.D = d; a.H = h; a.W = w;
+  a.Ho = (h + 6 - 7) / 2 + 1; a.Wo = (w + 6 - 7) / 2 + 1;
+  a.relu = relu;
+  using G = StemGeo<8, 8, 32>;
+  constexpr int lds_bytes = G::SLAB * 4;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(stem_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            lds_bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      return MR3D_ERR_LAUNCH;
+    }
+    attr = true;
+  }
+  const int td = (d + 7) / 8, th = (a.Ho + 7) / 8, tw = (a.Wo + 31) / 32;
+  stem_fwd_kernel<<<(unsigned)(n * td * th * tw), kStemThreads, lds_bytes, mr3d_stream(stream_)>>>(a, td, th, tw);
+  return mr3d_launch_status();
+}
+
+extern "C" int mr3d_stem_conv_wgrad(const float *x_ncdhw, const float *dy, float *dw_packed, float *dbias, int n, int d, int h,
+                                    int w, mr3d_stream_t stream_) {
+  if (!x_ncdhw || !dy || !dw_packed || n <= 0 || d <= 0 || h <= 0 || w <= 0) return MR3D_ERR_INVALID_ARG;
+  StemWgradArgs a;
+  a.x = x_ncdhw; a.dy = dy; a.dw = dw_packed; a.dbias = dbias;
+  a.N = n; a.D = d; a.H = h; a.W = w;
+  a.Ho = (h + 6 - 7) / 2 + 1; a.Wo = (w + 6 - 7) / 2 + 1;
+  using G = StemGeo<4, 8, 32>;
+  constexpr int lds_bytes = (G::SLAB + 4 * 8 * 32 * 17) * 4;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(stem_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            lds_bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      return MR3D_ERR_LAUNCH;
+    }
+    attr = true;
+  }
+  const int td = (d + 3) / 4, th = (a.Ho + 7) / 8, tw = (a.Wo + 31) / 32;
+  int tiles = n * td * th * tw;
+  int dev = 0, cus = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+    cus = prop.multiProcessorCount;
+  const int grid = tiles < cus ? tiles : cus;
+  stem_wgrad_kernel<<<(unsigned)grid, kStemThreads, lds_bytes, mr3d_stream(stream_)>>>(a, td, th, tw);
+  return mr3d_launch_status();
+}

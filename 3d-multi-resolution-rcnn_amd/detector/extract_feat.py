@@ -19,6 +19,7 @@ MI355X design (not a module-by-module translation):
     data-gradient kernel applies the ReLU mask of the layer it feeds in its epilogue.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -268,11 +269,17 @@ class ExtractFeat3D(nn.Module):
         fwd.append(prep)
         # ---------------- forward
         P.x_in = self._new((N, 3, D, H, W))
-        P.x4 = self._new((N, D, H, W, 4))
-        fwd.append(_hip.make_op(_hip.OP_VOLUME_PACK, [P.x_in, P.x4], [N, D, H, W]))
         stem = self.specs[0]
-        P.stem_out = self._new(self._out_shape(P.x4.shape, stem))
-        fwd.append(self._conv_fwd(P.x4, stem, P.stem_out, relu=True))
+        P.stem_out = self._new(self._out_shape((N, D, H, W, 4), stem))
+        generic_stem = os.environ.get('MR3D_GENERIC_STEM') == '1'      # A/B switch: generic implicit-GEMM kernels
+        if generic_stem:
+            P.x4 = self._new((N, D, H, W, 4))
+            fwd.append(_hip.make_op(_hip.OP_VOLUME_PACK, [P.x_in, P.x4], [N, D, H, W]))
+            fwd.append(self._conv_fwd(P.x4, stem, P.stem_out, relu=True))
+        else:
+            # the stem kernels read the planar volume directly (no NDHWC repack)
+            fwd.append(_hip.make_op(_hip.OP_STEM_FWD, [P.x_in, self._w(stem, 'wf'), self._w(stem, 'shift'), P.stem_out],
+                                    [N, D, H, W, 1]))
         _, sd, sh, sw, _ = P.stem_out.shape
         pshape = (N, (sd - 1) // 2 + 1, (sh - 1) // 2 + 1, (sw - 1) // 2 + 1, 16)
         P.pool_out = self._new(pshape)
@@ -369,7 +376,11 @@ class ExtractFeat3D(nn.Module):
             g = gx
         g_stem = self._new(P.stem_out.shape)
         bwd.append(_hip.make_op(_hip.OP_MAXPOOL_BWD, [g, P.pool_idx, P.stem_out, g_stem], [N, sd, sh, sw, 16]))
-        bwd.append(self._conv_wgrad(P.x4, g_stem, stem))
+        if generic_stem:
+            bwd.append(self._conv_wgrad(P.x4, g_stem, stem))
+        else:
+            bwd.append(_hip.make_op(_hip.OP_STEM_WGRAD, [P.x_in, g_stem, self._s(stem, 'dwraw'), self._s(stem, 'dbias')],
+                                    [N, D, H, W]))
         bwd.append(_hip.make_op(_hip.OP_FINISH_GRADS, [self._table, self._arena, self._scratch, self._grad_arena],
                                 [nL, self.max_cout]))
         P.fwd_ops, P.bwd_ops = fwd, bwd

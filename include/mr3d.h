@@ -181,6 +181,18 @@ int mr3d_finish_grads(const mr3d_layer_desc *table, int num_layers, int max_cout
                       const float *scratch, float *grads, mr3d_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------
+ * ResNet3D stem -- Conv3d(3, 16, kernel 7, stride (1,2,2), padding 3) + folded BN + ReLU, forward and weight
+ * gradient (mmdet/models/backbones/resnet3d.py:397-409,467-469), specialised: reads the volume in the
+ * reference's own planar [N,3,D,H,W] layout, writes / reads NDHWC [N,D,H/2,W/2,16].
+ * w_packed / dw_packed: [343][4][16] (the generic packing of mr3d_prepare_weights with ci_pad = 4).
+ * dw_packed and dbias must be pre-zeroed (atomic accumulation).
+ * ---------------------------------------------------------------------------------------------- */
+int mr3d_stem_conv_forward(const float *x_ncdhw, const float *w_packed, const float *shift, float *y,
+                           int n, int d, int h, int w, int relu, mr3d_stream_t stream);
+int mr3d_stem_conv_wgrad(const float *x_ncdhw, const float *dy, float *dw_packed, float *dbias,
+                         int n, int d, int h, int w, mr3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Plan executor: runs a pre-built list of the operations above with ONE call (the host-side loop of
  * ~500 launches per training step stays in native code; the call only enqueues, so it can be captured
  * in a hipGraph).  Replaces the Python module-by-module dispatch of ResNet3D.forward / FPN3D.forward
@@ -198,13 +210,15 @@ int mr3d_finish_grads(const mr3d_layer_desc *table, int num_layers, int max_cout
  *   AXPY          p = {dst,src}  f[0] = alpha           i = {count_lo, count_hi}
  *   PREP_WEIGHTS  p = {table,params,packed}             i = {num_layers}
  *   FINISH_GRADS  p = {table,params,scratch,grads}      i = {num_layers,max_cout}
+ *   STEM_FWD      p = {x_ncdhw,w_packed,shift,y}        i = {n,d,h,w,relu}
+ *   STEM_WGRAD    p = {x_ncdhw,dy,dw_packed,dbias}      i = {n,d,h,w}
  * Returns the first non-OK status; *failed_index (host int, may be NULL) receives the op index.
  * ---------------------------------------------------------------------------------------------- */
 typedef enum {
   MR3D_OP_CONV_FWD = 1, MR3D_OP_CONV_WGRAD = 2, MR3D_OP_MAXPOOL_FWD = 3, MR3D_OP_MAXPOOL_BWD = 4,
   MR3D_OP_ZERO_STUFF2 = 5, MR3D_OP_UPSAMPLE_ADJ = 6, MR3D_OP_SUBSAMPLE_FWD = 7, MR3D_OP_SUBSAMPLE_BWD = 8,
   MR3D_OP_VOLUME_PACK = 9, MR3D_OP_MEMSET0 = 10, MR3D_OP_AXPY = 11, MR3D_OP_PREP_WEIGHTS = 12,
-  MR3D_OP_FINISH_GRADS = 13
+  MR3D_OP_FINISH_GRADS = 13, MR3D_OP_STEM_FWD = 14, MR3D_OP_STEM_WGRAD = 15
 } mr3d_op_kind;
 typedef struct {
   int32_t kind;

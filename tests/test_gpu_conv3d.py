@@ -109,3 +109,62 @@ def test_conv3d_wgrad(dev, cin, cout, k, stride, pad, dhw):
     err = (dw.cpu() - ref).abs().max().item()
     scale = ref.abs().max().item()
     assert err <= RTOL * scale, f'wgrad max err {err:.3e} vs scale {scale:.3e}'
+
+
+@pytest.mark.parametrize('n,dhw', [(1, (8, 32, 32)), (1, (16, 64, 64)), (2, (10, 40, 36)), (1, (5, 70, 130)), (1, (9, 17, 23))])
+def test_stem_kernels_forward_and_wgrad(dev, n, dhw):
+    """the specialised 7x7x7 / stride (1,2,2) stem kernels against an fp64 torch conv"""
+    from mr3d_amd import _hip
+    g = torch.Generator().manual_seed(sum(dhw) + n)
+    x = torch.randn((n, 3) + dhw, generator=g)
+    w = (torch.randn((16, 3, 7, 7, 7), generator=g) / np.sqrt(1029)).requires_grad_(True)
+    shift = torch.randn(16, generator=g)
+    ref = F.conv3d(x.double(), w.double(), shift.double(), (1, 2, 2), 3)
+    w4 = torch.zeros(16, 4, 7, 7, 7); w4[:, :3] = w.detach()
+    wp = _hip.pack_conv_weight(w4).to(dev)
+    y = _hip.stem_conv_forward(x.to(dev), wp, shift.to(dev), relu=False)
+    err = (y.permute(0, 4, 1, 2, 3).cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err <= 2e-5, f'stem fwd rel err {err:.3e}'
+    dy = torch.randn(ref.shape, generator=g)
+    ref.backward(dy.double())
+    dw = torch.zeros((343, 4, 16), device=dev); db = torch.zeros(16, device=dev)
+    _hip.stem_conv_wgrad(x.to(dev), _cl(dy).to(dev), dw, db)
+    refp = _hip.pack_conv_weight(torch.cat([w.grad, torch.zeros(16, 1, 7, 7, 7)], 1))
+    errw = (dw.cpu() - refp).abs().max().item() / refp.abs().max().item()
+    errb = (db.cpu() - dy.sum((0, 2, 3, 4))).abs().max().item() / dy.sum((0, 2, 3, 4)).abs().max().item()
+    assert errw <= 2e-5 and errb <= 1e-4, f'stem wgrad rel err {errw:.3e}, dbias {errb:.3e}'
+
+
+# the streaming pointwise kernels (csrc/pointwise.hip) only engage above 32768 positions
+PW_CASES = [(16, 16), (16, 64), (64, 16), (64, 32), (32, 64), (64, 64), (32, 128), (128, 32), (64, 128), (128, 64)]
+
+
+@pytest.mark.parametrize('cin,cout', PW_CASES)
+def test_pointwise_streaming_forward_epilogues_and_wgrad(dev, cin, cout):
+    from mr3d_amd import _hip
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    dhw = (9, 64, 66)                                   # 38016 positions: not a multiple of the 64/32-row tiles
+    x = torch.randn((1, cin) + dhw, generator=g)
+    w = torch.randn((cout, cin, 1, 1, 1), generator=g) / np.sqrt(cin)
+    shift = torch.randn(cout, generator=g)
+    add1, add2, mask = (torch.randn((1, cout) + dhw, generator=g) for _ in range(3))
+    up = torch.randn((1, cout, 5, 32, 33), generator=g)
+    conv = F.conv3d(x.double(), w.double(), shift.double())
+    xc, wp = _cl(x).to(dev), _hip.pack_conv_weight(w).to(dev)
+    k1, s1, p0 = (1, 1, 1), (1, 1, 1), (0, 0, 0)
+    y = _hip.conv3d_forward(xc, wp, k1, s1, p0, shift=shift.to(dev), add1=_cl(add1).to(dev), relu=True)
+    _check(y, torch.relu(conv + add1).float(), 'pw add1+relu')
+    y = _hip.conv3d_forward(xc, wp, k1, s1, p0, add1=_cl(add1).to(dev), add2=_cl(add2).to(dev), mask=_cl(mask).to(dev))
+    _check(y, ((conv - shift.double().view(1, -1, 1, 1, 1) + add1 + add2) * (mask > 0)).float(), 'pw adds+mask')
+    y = _hip.conv3d_forward(xc, wp, k1, s1, p0, shift=shift.to(dev), up=_cl(up).to(dev))
+    _check(y, (conv + F.interpolate(up.double(), size=dhw, mode='nearest')).float(), 'pw upsample-add')
+    wz = torch.zeros_like(w, requires_grad=True)
+    yz = F.conv3d(x, wz)
+    dy = torch.randn(yz.shape, generator=g)
+    yz.backward(dy)
+    dw, db = torch.zeros((1, cin, cout), device=dev), torch.zeros(cout, device=dev)
+    _hip.conv3d_wgrad(xc, _cl(dy).to(dev), dw, k1, s1, p0, dbias=db)
+    ref = _hip.pack_conv_weight(wz.grad)
+    assert (dw.cpu() - ref).abs().max().item() <= RTOL * ref.abs().max().item()
+    sb = dy.sum((0, 2, 3, 4))
+    assert (db.cpu() - sb).abs().max().item() <= 1e-4 * dy.abs().sum((0, 2, 3, 4)).max().item()
