@@ -18,6 +18,7 @@
 //     and no row padding, row i = kw*4 + ci of tap group (kd, kh) is simply halo_float[base + i],
 //     so a 28(32)-row M dimension exists even though Cin is 4.
 #include "conv3d.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -124,28 +125,52 @@ __global__ __launch_bounds__(kThreads) void conv3d_wgrad_kernel(Conv3dWgradArgs 
     constexpr int KSTEPS = C::M / 4;
     constexpr int KPW = C::PW1 ? KSTEPS / 4 : KSTEPS;       // pointwise: waves split the positions
     const int kk0 = C::PW1 ? wave * KPW : 0;
-#pragma unroll 2
-    for (int kq = 0; kq < KPW; ++kq) {
+    // explicit two-stage software pipeline: the LDS operands of k-step q+1 are requested before the MFMAs
+    // of k-step q issue (the compiler does not do this on its own: it waits on every ds_read before its MFMA)
+    auto ld = [&](int kq, float (&a)[C::TPW][C::MT], float (&bf)[C::NT]) {
       const int m = (kk0 + kq) * 4 + lk;
       const int tw = m % C::TW, th = (m / C::TW) % C::TH, td = m / (C::TW * C::TH);
       const int hp = (((td * C::LSD) * C::HH + th * C::LSH) * C::HW + tw * C::LSW) * C::ROW + li;
-      float bf[C::NT];
 #pragma unroll
       for (int nt = 0; nt < C::NT; ++nt) bf[nt] = dyt[m * C::DROW + nt * 16 + li];
 #pragma unroll
-      for (int t = 0; t < C::TPW; ++t) {
+      for (int t = 0; t < C::TPW; ++t)
 #pragma unroll
-        for (int mt = 0; mt < C::MT; ++mt) {
-          const float a = xh[hp + tapoff[t] + mt * 16];
+        for (int mt = 0; mt < C::MT; ++mt) a[t][mt] = xh[hp + tapoff[t] + mt * 16];
+    };
+    auto mm = [&](const float (&a)[C::TPW][C::MT], const float (&bf)[C::NT]) {
+#pragma unroll
+      for (int t = 0; t < C::TPW; ++t)
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
           for (int nt = 0; nt < C::NT; ++nt)
-            acc[t][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf[nt], acc[t][mt][nt], 0, 0, 0);
-        }
-      }
+            acc[t][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][mt], bf[nt], acc[t][mt][nt], 0, 0, 0);
+    };
+    static_assert(KPW % 2 == 0, "k-steps are processed in pairs");
+    float a0[C::TPW][C::MT], a1[C::TPW][C::MT], b0[C::NT], b1[C::NT];
+    ld(0, a0, b0);
+    for (int kq = 0; kq < KPW; kq += 2) {
+      ld(kq + 1, a1, b1);
+      mm(a0, b0);
+      if (kq + 2 < KPW) ld(kq + 2, a0, b0);
+      mm(a1, b1);
     }
   }
 
-  if (p.dbias && blockIdx.y == 0) atomicAdd(p.dbias + n0 + tid % C::NB, bsum);
+  if (p.dbias && blockIdx.y == 0) {
+    // reduce the 256/NB per-thread partials of each channel inside the workgroup first: ONE atomic per channel
+    // per workgroup (256 lanes x 512 workgroups hammering 16 addresses cost more than the MFMA work itself)
+    __syncthreads();
+    lds[tid] = bsum;
+    __syncthreads();
+    if (tid < C::NB) {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < kThreads / C::NB; ++q) s += lds[q * C::NB + tid];
+      atomicAdd(p.dbias + n0 + tid, s);
+    }
+  }
   // ---- add the partial sums into dw[tap][ci][co]
 #pragma unroll
   for (int t = 0; t < C::TPW; ++t) {
@@ -186,7 +211,8 @@ int launch_wgrad(const Conv3dWgradArgs &a, hipStream_t stream) {
     attr_done = true;
   }
   const int chunks = a.Cin / C::CC, ntiles = a.Cout / C::NB;
-  int gx = 512 / (chunks * ntiles);      // ~2 workgroups per CU in total
+  static const int total_wgs = getenv("MR3D_WGRAD_WGS") ? atoi(getenv("MR3D_WGRAD_WGS")) : 512;   // tuning knob
+  int gx = total_wgs / (chunks * ntiles);      // ~2 workgroups per CU in total
   if (gx < 1) gx = 1;
   if (gx > num_tiles) gx = num_tiles;
   dim3 grid((unsigned)gx, (unsigned)chunks, (unsigned)ntiles);

@@ -324,13 +324,19 @@ __global__ __launch_bounds__(256) void pointwise_wgrad_kernel(Conv3dWgradArgs p,
       for (int r = 0; r < 4; ++r)
         atomicAdd(p.dw + (size_t)(mt * 16 + lk * 4 + r) * C::CO + nt * 16 + li, acc[mt][nt][r]);
   if (p.dbias) {
+    // wave-level shuffle reduction, then the 4 waves of the workgroup combine through LDS: one atomic per
+    // channel per workgroup
+    __syncthreads();
 #pragma unroll
     for (int nt = 0; nt < C::NT; ++nt) {
       float s = bsum[nt];
       s += __shfl_xor(s, 16);
       s += __shfl_xor(s, 32);
-      if (lk == 0) atomicAdd(p.dbias + nt * 16 + li, s);
+      if (lk == 0) lds[wave * C::CO + nt * 16 + li] = s;
     }
+    __syncthreads();
+    for (int c = tid; c < C::CO; c += 256)
+      atomicAdd(p.dbias + c, lds[c] + lds[C::CO + c] + lds[2 * C::CO + c] + lds[3 * C::CO + c]);
   }
 }
 

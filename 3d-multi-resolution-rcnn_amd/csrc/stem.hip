@@ -19,7 +19,6 @@
 namespace {
 
 constexpr int kStemThreads = 512;      // 8 waves: 2 per SIMD
-constexpr int SW_ROW = 72;             // LDS row stride in floats (69 used; multiple of 8 keeps b64 alignment)
 
 // ------------------------------------------------------------------------------------------------ forward
 struct StemFwdArgs {
@@ -31,18 +30,22 @@ struct StemFwdArgs {
   int relu;
 };
 
-template <int TD, int TH, int TW>
+// ROW = LDS row stride in floats (69 used).  forward: 72 (multiple of 8 keeps the ds_read_b64 words aligned);
+// wgrad: 80 (== 16 mod 32, so the two tap rows a lane group reads sit 16 banks apart: conflict-free)
+template <int TD, int TH, int TW, int ROW>
 struct StemGeo {
   static constexpr int PD = TD + 6, PH = 2 * (TH - 1) + 7, PW = 2 * (TW - 1) + 7;
-  static constexpr int SLAB = PD * PH * SW_ROW;          // floats of one input channel
-  static_assert(PW <= SW_ROW, "row stride");
+  static constexpr int SW_ROW = ROW;
+  static constexpr int SLAB = PD * PH * ROW;             // floats of one input channel
+  static_assert(PW <= ROW, "row stride");
 };
 
-template <int TD, int TH, int TW, class G>
+template <int NTHREADS, class G>
 __device__ __forceinline__ void stem_stage_channel(float *slab, const float *__restrict__ xc, int D, int H, int W, int d0,
                                                    int h0, int w0, int tid) {
+  constexpr int SW_ROW = G::SW_ROW;
   // xc: base of one (n, ci) plane set; halo origin in input coords: (d0-3, 2*h0-3, 2*w0-3)
-  for (int e = tid; e < G::PD * G::PH * SW_ROW; e += kStemThreads) {
+  for (int e = tid; e < G::PD * G::PH * SW_ROW; e += NTHREADS) {
     const int c = e % SW_ROW, r = (e / SW_ROW) % G::PH, pl = e / (SW_ROW * G::PH);
     const int id = d0 - 3 + pl, ih = 2 * h0 - 3 + r, iw = 2 * w0 - 3 + c;
     float v = 0.f;
@@ -52,9 +55,11 @@ __device__ __forceinline__ void stem_stage_channel(float *slab, const float *__r
   }
 }
 
-__global__ __launch_bounds__(kStemThreads) void stem_fwd_kernel(StemFwdArgs p, int tiles_d, int tiles_h, int tiles_w) {
-  constexpr int TD = 8, TH = 8, TW = 32;
-  using G = StemGeo<TD, TH, TW>;
+template <int TD>
+__global__ __launch_bounds__(TD * 64) void stem_fwd_kernel(StemFwdArgs p, int tiles_d, int tiles_h, int tiles_w) {
+  constexpr int TH = 8, TW = 32;
+  using G = StemGeo<TD, TH, TW, 72>;
+  constexpr int SW_ROW = G::SW_ROW;
   extern __shared__ __attribute__((aligned(16))) float slab[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // = output depth inside the tile
@@ -77,7 +82,7 @@ __global__ __launch_bounds__(kStemThreads) void stem_fwd_kernel(StemFwdArgs p, i
 
   for (int ci = 0; ci < 3; ++ci) {
     __syncthreads();
-    stem_stage_channel<TD, TH, TW, G>(slab, p.x + ((size_t)n * 3 + ci) * vox, p.D, p.H, p.W, d0, h0, w0, tid);
+    stem_stage_channel<TD * 64, G>(slab, p.x + ((size_t)n * 3 + ci) * vox, p.D, p.H, p.W, d0, h0, w0, tid);
     __syncthreads();
     // B for (kd, kh): step s uses kw = 2*lk + s; element wf[((kd*7+kh)*7 + kw)*64 + ci*16 + co]
     auto load_b = [&](int kd, int kh, float &b0, float &b1) {
@@ -85,26 +90,39 @@ __global__ __launch_bounds__(kStemThreads) void stem_fwd_kernel(StemFwdArgs p, i
       b0 = wrow[(2 * lk) * 64];
       b1 = (2 * lk + 1 < 7) ? wrow[(2 * lk + 1) * 64] : 0.f;
     };
-    float bc0, bc1, bn0 = 0.f, bn1 = 0.f;
-    load_b(0, 0, bc0, bc1);
-    for (int kd = 0; kd < 7; ++kd) {
+    // software pipeline over the 49 (kd, kh) rows: the A words (LDS) and B values (L2) of row r+1 are
+    // requested before the 32 MFMAs of row r issue, so neither latency is ever exposed
+    auto load_a = [&](int kd, int kh, float2 (&a)[TH][2]) {
+      const float *rowbase = slab + ((wave + kd) * G::PH + kh) * SW_ROW + lane_off;
 #pragma unroll
-      for (int kh = 0; kh < 7; ++kh) {
-        const int nkh = (kh == 6) ? 0 : kh + 1, nkd = (kh == 6) ? kd + 1 : kd;
-        if (nkd < 7) load_b(nkd, nkh, bn0, bn1);
-        const float *rowbase = slab + ((wave + kd) * G::PH + kh) * SW_ROW + lane_off;
+      for (int th = 0; th < TH; ++th)
 #pragma unroll
-        for (int th = 0; th < TH; ++th) {
+        for (int wb = 0; wb < 2; ++wb) a[th][wb] = *reinterpret_cast<const float2 *>(rowbase + (2 * th) * SW_ROW + wb * 32);
+    };
+    auto mfma_row = [&](const float2 (&a)[TH][2], float b0, float b1) {
 #pragma unroll
-          for (int wb = 0; wb < 2; ++wb) {
-            const float2 a = *reinterpret_cast<const float2 *>(rowbase + (2 * th) * SW_ROW + wb * 32);
-            acc[th][wb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bc0, acc[th][wb], 0, 0, 0);
-            acc[th][wb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bc1, acc[th][wb], 0, 0, 0);
-          }
+      for (int th = 0; th < TH; ++th)
+#pragma unroll
+        for (int wb = 0; wb < 2; ++wb) {
+          acc[th][wb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[th][wb].x, b0, acc[th][wb], 0, 0, 0);
+          acc[th][wb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[th][wb].y, b1, acc[th][wb], 0, 0, 0);
         }
-        bc0 = bn0; bc1 = bn1;
-      }
+    };
+    float2 a0[TH][2], a1[TH][2];
+    float b00, b01, b10 = 0.f, b11 = 0.f;
+    load_b(0, 0, b00, b01);
+    load_a(0, 0, a0);
+    // rows r = kd*7 + kh, processed two at a time (49 = 24 pairs + 1)
+    for (int r = 0; r < 48; r += 2) {
+      const int r1 = r + 1, r2 = r + 2;
+      load_b(r1 / 7, r1 % 7, b10, b11);
+      load_a(r1 / 7, r1 % 7, a1);
+      mfma_row(a0, b00, b01);
+      load_b(r2 / 7, r2 % 7, b00, b01);
+      load_a(r2 / 7, r2 % 7, a0);
+      mfma_row(a1, b10, b11);
     }
+    mfma_row(a0, b00, b01);
   }
 
   // epilogue: + shift, ReLU, NDHWC store (lane: co = li, rows x = wb*16 + lk*4 + r)
@@ -140,9 +158,10 @@ struct StemWgradArgs {
 
 __global__ __launch_bounds__(kStemThreads) void stem_wgrad_kernel(StemWgradArgs p, int tiles_d, int tiles_h, int tiles_w) {
   constexpr int TD = 4, TH = 8, TW = 32;
-  using G = StemGeo<TD, TH, TW>;
+  using G = StemGeo<TD, TH, TW, 80>;
+  constexpr int SW_ROW = G::SW_ROW;
   constexpr int M = TD * TH * TW;          // 1024 positions per tile
-  constexpr int DYROW = 17;
+  constexpr int DYROW = 16;                // lanes (co, k) read word 16k + co: conflict-free
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *slab = lds;
   float *dyt = lds + G::SLAB;
@@ -186,28 +205,36 @@ __global__ __launch_bounds__(kStemThreads) void stem_wgrad_kernel(StemWgradArgs 
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (od < p.D && oh < p.Ho && ow < p.Wo)
         v = *reinterpret_cast<const float4 *>(p.dy + ((((size_t)n * p.D + od) * p.Ho + oh) * p.Wo + ow) * 16 + q4 * 4);
-      float *d = dyt + m * DYROW + q4 * 4;
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      *reinterpret_cast<float4 *>(dyt + m * DYROW + q4 * 4) = v;
     }
     for (int ci = 0; ci < 3; ++ci) {
       if (ci) __syncthreads();
-      stem_stage_channel<TD, TH, TW, G>(slab, p.x + ((size_t)n * 3 + ci) * vox, p.D, p.H, p.W, d0, h0, w0, tid);
+      stem_stage_channel<kStemThreads, G>(slab, p.x + ((size_t)n * 3 + ci) * vox, p.D, p.H, p.W, d0, h0, w0, tid);
       __syncthreads();
-#pragma unroll 2
-      for (int ks = 0; ks < M / 4; ++ks) {
+      auto ld = [&](int ks, float &a, float (&bv)[4]) {
         const int m = ks * 4 + lk;                                  // this lane's position (k index)
         const int tw = m % TW, th = (m / TW) % TH, td = m / (TW * TH);
-        const float a = dyt[m * DYROW + li];                        // A[i = co][k]
-        if (ci == 0 && wave == 0) bsum += a;
+        a = dyt[m * DYROW + li];                                    // A[i = co][k]
         const int pos = (td * G::PH + 2 * th) * SW_ROW + 2 * tw;    // halo origin of that position
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float bv = slab[pos + goff[q]];
-          if (ci == 0) acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[0][q], 0, 0, 0);
-          else if (ci == 1) acc[1][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[1][q], 0, 0, 0);
-          else acc[2][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv, acc[2][q], 0, 0, 0);
+        for (int q = 0; q < 4; ++q) bv[q] = slab[pos + goff[q]];
+      };
+      auto run = [&](f32x4 (&ac)[4], bool count_bias) {
+        float a0, a1, b0[4], b1[4];
+        ld(0, a0, b0);
+        for (int ks = 0; ks < M / 4; ks += 2) {
+          ld(ks + 1, a1, b1);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) ac[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[q], ac[q], 0, 0, 0);
+          if (count_bias) bsum += a0 + a1;
+          if (ks + 2 < M / 4) ld(ks + 2, a0, b0);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) ac[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[q], ac[q], 0, 0, 0);
         }
-      }
+      };
+      if (ci == 0) run(acc[0], wave == 0);
+      else if (ci == 1) run(acc[1], false);
+      else run(acc[2], false);
     }
   }
 
@@ -243,19 +270,21 @@ extern "C" int mr3d_stem_conv_forward(const float *x_ncdhw, const float *w_packe
   a.N = n; a.D = d; a.H = h; a.W = w;
   a.Ho = (h + 6 - 7) / 2 + 1; a.Wo = (w + 6 - 7) / 2 + 1;
   a.relu = relu;
-  using G = StemGeo<8, 8, 32>;
+  // TD = 4: 60 KiB slab, two 4-wave workgroups per CU (one stages while the other computes)
+  constexpr int TD = 4;
+  using G = StemGeo<TD, 8, 32, 72>;
   constexpr int lds_bytes = G::SLAB * 4;
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(stem_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(stem_fwd_kernel<TD>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             lds_bytes) != hipSuccess) {
       (void)hipGetLastError();
       return MR3D_ERR_LAUNCH;
     }
     attr = true;
   }
-  const int td = (d + 7) / 8, th = (a.Ho + 7) / 8, tw = (a.Wo + 31) / 32;
-  stem_fwd_kernel<<<(unsigned)(n * td * th * tw), kStemThreads, lds_bytes, mr3d_stream(stream_)>>>(a, td, th, tw);
+  const int td = (d + TD - 1) / TD, th = (a.Ho + 7) / 8, tw = (a.Wo + 31) / 32;
+  stem_fwd_kernel<TD><<<(unsigned)(n * td * th * tw), TD * 64, lds_bytes, mr3d_stream(stream_)>>>(a, td, th, tw);
   return mr3d_launch_status();
 }
 
@@ -266,8 +295,8 @@ extern "C" int mr3d_stem_conv_wgrad(const float *x_ncdhw, const float *dy, float
   a.x = x_ncdhw; a.dy = dy; a.dw = dw_packed; a.dbias = dbias;
   a.N = n; a.D = d; a.H = h; a.W = w;
   a.Ho = (h + 6 - 7) / 2 + 1; a.Wo = (w + 6 - 7) / 2 + 1;
-  using G = StemGeo<4, 8, 32>;
-  constexpr int lds_bytes = (G::SLAB + 4 * 8 * 32 * 17) * 4;
+  using G = StemGeo<4, 8, 32, 80>;
+  constexpr int lds_bytes = (G::SLAB + 4 * 8 * 32 * 16) * 4;
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(stem_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -40,6 +40,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the cpu_baseline sample')
     ap.add_argument('--per-kernel', action='store_true', help='also print a per-kernel time table to stderr')
+    ap.add_argument('--per-op', action='store_true', help='also print every plan op with its time to stderr')
     return ap.parse_args()
 
 
@@ -192,6 +193,13 @@ def main():
             gk = groups.setdefault(key, {'ms': 0.0, 'flops': 0.0, 'ops': [], 'n': 0})
             gk['ms'] += s.elapsed_time(e); gk['flops'] += flops; gk['n'] += 1; gk['ops'].append((which, k))
     dom = max(groups, key=lambda k: groups[k]['ms'])
+    if a.per_op and rank == 0:
+        for which, events, p in (('f', ev, plan.fwd), ('b', evb, plan.bwd)):
+            for k in sorted(events):
+                key, flops = _hip.op_kernel_key(p.array[k])
+                ms = events[k][0].elapsed_time(events[k][1])
+                i = p.array[k].i
+                print(f'{which}{k:4d} {key:38s} dims={list(i[1:6])} {ms:8.3f} ms {flops / ms / 1e9 if ms > 0 else 0:7.2f} TF', file=sys.stderr)
     if a.per_kernel and rank == 0:
         tot = sum(v['ms'] for v in groups.values())
         for k, v in sorted(groups.items(), key=lambda kv: -kv[1]['ms']):
