@@ -48,7 +48,7 @@ struct FwdCfg {
   static constexpr int MT = WROWS / TM;         // MFMA tiles per wave along M
   static constexpr int KK = CC / KSTEP;         // MFMA k-steps per tap per chunk
   static constexpr int LDS_BYTES = HP * ROW * 4;
-  static_assert(M == 256, "workgroup tile is 256 output positions");
+  static_assert(WROWS >= TM && WROWS % TM == 0, "each wave needs at least one whole MFMA tile of rows");
   static_assert(CC % KSTEP == 0 && CC % 4 == 0, "channel chunk");
   static_assert(LDS_BYTES <= 160 * 1024, "halo block exceeds the CU's LDS");
 };
@@ -188,14 +188,49 @@ int launch_fwd(const Conv3dFwdArgs &a, hipStream_t stream) {
   return mr3d_launch_status();
 }
 
+// Output tile choice.  256 positions (4x8x8) amortise the halo best; small feature maps (layer3/4, P4/P5) would
+// then leave most of the 256 CUs idle, so they take 128- or 64-position tiles: the largest tile that still
+// yields >= 2 workgroups per CU, else the smallest one.
+template <int K, int SD, int SH, int SW, int CC, int NB>
+int dispatch_tile(const Conv3dFwdArgs &a, hipStream_t stream) {
+  auto wgs = [&](int td, int th, int tw) {
+    return (long long)a.N * ((a.Do + td - 1) / td) * ((a.Ho + th - 1) / th) * ((a.Wo + tw - 1) / tw) * (a.Cout / NB);
+  };
+  using T0 = FwdCfg<K, K, K, SD, SH, SW, 4, 8, 8, CC, NB>;
+  using T1 = FwdCfg<K, K, K, SD, SH, SW, 2, 8, 8, CC, NB>;
+  if (wgs(4, 8, 8) >= 512) return launch_fwd<T0>(a, stream);
+  if constexpr (NB == 32) {
+    return launch_fwd<T1>(a, stream);
+  } else {
+    using T2 = FwdCfg<K, K, K, SD, SH, SW, 2, 4, 8, CC, NB>;
+    if (wgs(2, 8, 8) >= 512) return launch_fwd<T1>(a, stream);
+    return launch_fwd<T2>(a, stream);
+  }
+}
+
 template <int K, int SD, int SH, int SW, int CC>
 int dispatch_nb(const Conv3dFwdArgs &a, int nb, hipStream_t stream) {
   switch (nb) {
-    case 16: return launch_fwd<FwdCfg<K, K, K, SD, SH, SW, 4, 8, 8, CC, 16>>(a, stream);
-    case 32: return launch_fwd<FwdCfg<K, K, K, SD, SH, SW, 4, 8, 8, CC, 32>>(a, stream);
-    case 64: return launch_fwd<FwdCfg<K, K, K, SD, SH, SW, 4, 8, 8, CC, 64>>(a, stream);
+    case 16: return dispatch_tile<K, SD, SH, SW, CC, 16>(a, stream);
+    case 32: return dispatch_tile<K, SD, SH, SW, CC, 32>(a, stream);
+    case 64: return dispatch_tile<K, SD, SH, SW, CC, 64>(a, stream);
   }
   return MR3D_ERR_UNSUPPORTED;
+}
+
+// stride-2 3x3x3: the 4x8x8 tile's 9x17x17 halo only fits LDS with 8 channels per chunk; the smaller tiles take 16
+template <int NB>
+int dispatch_s2(const Conv3dFwdArgs &a, hipStream_t stream) {
+  auto wgs = [&](int td, int th, int tw) {
+    return (long long)a.N * ((a.Do + td - 1) / td) * ((a.Ho + th - 1) / th) * ((a.Wo + tw - 1) / tw) * (a.Cout / NB);
+  };
+  if (a.Cin % 16 != 0 || wgs(4, 8, 8) >= 1024) return launch_fwd<FwdCfg<3, 3, 3, 2, 2, 2, 4, 8, 8, 8, NB>>(a, stream);
+  if constexpr (NB == 32) {
+    return launch_fwd<FwdCfg<3, 3, 3, 2, 2, 2, 2, 8, 8, 16, NB>>(a, stream);
+  } else {
+    if (wgs(2, 8, 8) >= 512) return launch_fwd<FwdCfg<3, 3, 3, 2, 2, 2, 2, 8, 8, 16, NB>>(a, stream);
+    return launch_fwd<FwdCfg<3, 3, 3, 2, 2, 2, 2, 4, 8, 16, NB>>(a, stream);
+  }
 }
 
 }  // namespace
@@ -238,7 +273,13 @@ extern "C" int mr3d_conv3d_forward(const mr3d_conv3d_desc *d, mr3d_stream_t stre
   } else if (k == 3 && s == 111) {
     if (a.Cin % 16 == 0) return dispatch_nb<3, 1, 1, 1, 16>(a, nb, stream);
   } else if (k == 3 && s == 222) {
-    if (a.Cin % 8 == 0) return dispatch_nb<3, 2, 2, 2, 8>(a, nb, stream);   // 9x17x17 halo: 8 channels per chunk
+    if (a.Cin % 8 == 0) {
+      switch (nb) {
+        case 16: return dispatch_s2<16>(a, stream);
+        case 32: return dispatch_s2<32>(a, stream);
+        case 64: return dispatch_s2<64>(a, stream);
+      }
+    }
   } else if (k == 7 && s == 122) {
     if (a.Cin == 4 && nb == 16) return launch_fwd<FwdCfg<7, 7, 7, 1, 2, 2, 4, 8, 8, 4, 16>>(a, stream);
   }
