@@ -28,16 +28,20 @@ __device__ __forceinline__ int pw_nearest_src(int dst, int in, int out) {
   return s < in - 1 ? s : in - 1;
 }
 
-template <int CI_, int CO_>
+// EXTRA = the call carries residual / mask streams (add1, add2, mask): 32-row tiles, and the add1 / mask tiles of
+// the CURRENT tile are requested at the top of the iteration so that their HBM latency hides behind the LDS
+// round trip and the MFMAs instead of being exposed in the epilogue.
+template <int CI_, int CO_, bool EXTRA_ = false>
 struct PwCfg {
   static constexpr int CI = CI_, CO = CO_;
+  static constexpr bool EXTRA = EXTRA_;
   static constexpr bool k16 = (CO == 16);
   static constexpr int TM = k16 ? 16 : 32;
   static constexpr int KSTEP = k16 ? 4 : 2;
   static constexpr int KK = CI / KSTEP;
   static constexpr int NT = CO / TM;
   static constexpr bool BREG = (KK * NT <= 64);            // weights resident in VGPRs
-  static constexpr int ROWS = (CI <= 64 && CO <= 64) ? 64 : 32;   // rows per wave tile (register budget)
+  static constexpr int ROWS = (!EXTRA && CI <= 64 && CO <= 64) ? 64 : 32;   // rows per wave tile (register budget)
   static constexpr int MT = ROWS / TM;
   static constexpr int RS = CI + 4;                        // LDS row stride (floats), keeps 16-B alignment
   static constexpr int OS = CO + 4;                        // LDS row stride of the output tile
@@ -89,6 +93,21 @@ __global__ __launch_bounds__(256) void pointwise_fwd_kernel(Conv3dFwdArgs p, lon
   if (tile < ntiles) issue_loads(tile);
 
   for (; tile < ntiles; tile += wstride) {
+    const bool full_tile = (tile + 1) * C::ROWS <= rows_total;
+    float4 e1[C::EXTRA ? C::NOUT : 1], em[C::EXTRA ? C::NOUT : 1];
+    if constexpr (C::EXTRA) {
+      if (full_tile) {
+        const size_t t4e = (size_t)tile * C::ROWS * (C::CO / 4);
+        if (p.add1) {
+#pragma unroll
+          for (int q = 0; q < C::NOUT; ++q) e1[q] = (reinterpret_cast<const float4 *>(p.add1) + t4e)[q * 64 + lane];
+        }
+        if (p.mask) {
+#pragma unroll
+          for (int q = 0; q < C::NOUT; ++q) em[q] = (reinterpret_cast<const float4 *>(p.mask) + t4e)[q * 64 + lane];
+        }
+      }
+    }
     // ---- registers -> this wave's LDS slab (row-padded)
 #pragma unroll
     for (int q = 0; q < C::NLOAD; ++q) {
@@ -156,7 +175,8 @@ __global__ __launch_bounds__(256) void pointwise_fwd_kernel(Conv3dFwdArgs p, lon
         const float4 *a4 = reinterpret_cast<const float4 *>(p.add1) + t4;
 #pragma unroll
         for (int q = 0; q < C::NOUT; ++q) {
-          const float4 a = a4[q * 64 + lane];
+          float4 a;
+          if constexpr (C::EXTRA) a = e1[q]; else a = a4[q * 64 + lane];
           v[q].x += a.x; v[q].y += a.y; v[q].z += a.z; v[q].w += a.w;
         }
       }
@@ -194,7 +214,8 @@ __global__ __launch_bounds__(256) void pointwise_fwd_kernel(Conv3dFwdArgs p, lon
         const float4 *m4 = reinterpret_cast<const float4 *>(p.mask) + t4;
 #pragma unroll
         for (int q = 0; q < C::NOUT; ++q) {
-          const float4 m = m4[q * 64 + lane];
+          float4 m;
+          if constexpr (C::EXTRA) m = em[q]; else m = m4[q * 64 + lane];
           v[q].x = m.x > 0.f ? v[q].x : 0.f; v[q].y = m.y > 0.f ? v[q].y : 0.f;
           v[q].z = m.z > 0.f ? v[q].z : 0.f; v[q].w = m.w > 0.f ? v[q].w : 0.f;
         }
@@ -365,9 +386,9 @@ int set_lds_attr(K kernel) {
   return MR3D_OK;
 }
 
-template <int CI, int CO>
-int launch_pw_fwd(const Conv3dFwdArgs &a, hipStream_t stream) {
-  using C = PwCfg<CI, CO>;
+template <int CI, int CO, bool EXTRA>
+int launch_pw_fwd_impl(const Conv3dFwdArgs &a, hipStream_t stream) {
+  using C = PwCfg<CI, CO, EXTRA>;
   if (set_lds_attr<C>(pointwise_fwd_kernel<C>) != MR3D_OK) return MR3D_ERR_LAUNCH;
   const long long rows = (long long)a.N * a.Do * a.Ho * a.Wo;
   const long long ntiles = (rows + C::ROWS - 1) / C::ROWS;
@@ -377,6 +398,12 @@ int launch_pw_fwd(const Conv3dFwdArgs &a, hipStream_t stream) {
   if (grid > need) grid = need;
   pointwise_fwd_kernel<C><<<(unsigned)grid, 256, C::LDS_BYTES, stream>>>(a, rows);
   return mr3d_launch_status();
+}
+
+template <int CI, int CO>
+int launch_pw_fwd(const Conv3dFwdArgs &a, hipStream_t stream) {
+  if (a.add1 || a.add2 || a.mask) return launch_pw_fwd_impl<CI, CO, true>(a, stream);
+  return launch_pw_fwd_impl<CI, CO, false>(a, stream);
 }
 
 template <int CI, int CO>
