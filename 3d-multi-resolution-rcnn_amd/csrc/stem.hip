@@ -5,9 +5,9 @@
 //
 // GEMM mapping (v_mfma_f32_16x16x4_f32):
 //   forward  D[i = 16 consecutive output x][j = 16 Cout] += A[i][k] * B[k][j],  K = (ci, kd, kh, kw)
-//     kw is padded 7 -> 8 and split as kw = 2*k + s (k = MFMA k index 0..3, s = step 0/1), so the A
-//     operands of BOTH steps of a (ci,kd,kh) row are one aligned ds_read_b64 per lane:
-//        A_s[i][k] = slab[plane d+kd][row 2h+kh][2*x_i + 2*k + s]
+//     kw is padded 7 -> 8 and split as kw = 2*k + s - 1 (k = MFMA k index 0..3, s = step 0/1; kw = -1 has
+//     weight 0), so the A operands of BOTH steps of a (ci,kd,kh) row are one aligned ds_read_b64 per lane:
+//        A_s[i][k] = slab[plane d+kd][row 2h+kh][2*x_i + 2*k + s]      (slab column 0 = input column 2*w0 - 4)
 //     consecutive lanes read consecutive 8-byte words: conflict-free without padding tricks.
 //   wgrad    D[i = Cout][j = (kh pair, kw)] += A[i][k = 4 output x] * B[k][j]:
 //        A = dy[pos][co] (LDS tile), B = slab[d+kd][2h + kh0 + (j>>3)][2*x_k + (j&7)]
@@ -34,31 +34,46 @@ struct StemFwdArgs {
 // wgrad: 80 (== 16 mod 32, so the two tap rows a lane group reads sit 16 banks apart: conflict-free)
 template <int TD, int TH, int TW, int ROW>
 struct StemGeo {
-  static constexpr int PD = TD + 6, PH = 2 * (TH - 1) + 7, PW = 2 * (TW - 1) + 7;
+  static constexpr int PD = TD + 6, PH = 2 * (TH - 1) + 7, PW = 2 * (TW - 1) + 7 + 1;   // +1: slab starts one column early
   static constexpr int SW_ROW = ROW;
   static constexpr int SLAB = PD * PH * ROW;             // floats of one input channel
   static_assert(PW <= ROW, "row stride");
 };
 
+// Slab column c holds input column 2*w0 - 4 + c (one column left of the halo origin 2*w0 - 3): the slab then
+// starts on a 16-byte boundary of the volume row, so a row is staged with aligned float4 loads (W % 4 == 0)
+// instead of 37 scalar ones -- staging VALU work was ~20 % of the MFMA time with scalar loads.
 template <int NTHREADS, class G>
 __device__ __forceinline__ void stem_stage_channel(float *slab, const float *__restrict__ xc, int D, int H, int W, int d0,
                                                    int h0, int w0, int tid) {
   constexpr int SW_ROW = G::SW_ROW;
-  // xc: base of one (n, ci) plane set; halo origin in input coords: (d0-3, 2*h0-3, 2*w0-3)
-  for (int e = tid; e < G::PD * G::PH * SW_ROW; e += NTHREADS) {
-    const int c = e % SW_ROW, r = (e / SW_ROW) % G::PH, pl = e / (SW_ROW * G::PH);
-    const int id = d0 - 3 + pl, ih = 2 * h0 - 3 + r, iw = 2 * w0 - 3 + c;
-    float v = 0.f;
-    if (c < G::PW && (unsigned)id < (unsigned)D && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
-      v = xc[((size_t)id * H + ih) * W + iw];
-    slab[e] = v;
+  static_assert(SW_ROW % 4 == 0, "row stride in whole float4");
+  if ((W & 3) == 0) {
+    constexpr int Q = SW_ROW / 4;
+    for (int e = tid; e < G::PD * G::PH * Q; e += NTHREADS) {
+      const int q = e % Q, r = (e / Q) % G::PH, pl = e / (Q * G::PH);
+      const int id = d0 - 3 + pl, ih = 2 * h0 - 3 + r, iw = 2 * w0 - 4 + 4 * q;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((unsigned)id < (unsigned)D && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+        v = *reinterpret_cast<const float4 *>(xc + ((size_t)id * H + ih) * W + iw);
+      *reinterpret_cast<float4 *>(slab + (pl * G::PH + r) * SW_ROW + 4 * q) = v;
+    }
+  } else {
+    for (int e = tid; e < G::PD * G::PH * SW_ROW; e += NTHREADS) {
+      const int c = e % SW_ROW, r = (e / SW_ROW) % G::PH, pl = e / (SW_ROW * G::PH);
+      const int id = d0 - 3 + pl, ih = 2 * h0 - 3 + r, iw = 2 * w0 - 4 + c;
+      float v = 0.f;
+      if ((unsigned)id < (unsigned)D && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+        v = xc[((size_t)id * H + ih) * W + iw];
+      slab[e] = v;
+    }
   }
 }
 
-template <int TD>
+template <int TD, int TW>
 __global__ __launch_bounds__(TD * 64) void stem_fwd_kernel(StemFwdArgs p, int tiles_d, int tiles_h, int tiles_w) {
-  constexpr int TH = 8, TW = 32;
-  using G = StemGeo<TD, TH, TW, 72>;
+  constexpr int TH = 8, WB = TW / 16;
+  using G = StemGeo<TD, TH, TW, (TW == 32 ? 72 : 40)>;
   constexpr int SW_ROW = G::SW_ROW;
   extern __shared__ __attribute__((aligned(16))) float slab[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -71,10 +86,10 @@ __global__ __launch_bounds__(TD * 64) void stem_fwd_kernel(StemFwdArgs p, int ti
   const int n = b;
   const int d0 = td_i * TD, h0 = th_i * TH, w0 = tw_i * TW;
 
-  f32x4 acc[TH][2];
+  f32x4 acc[TH][WB];
 #pragma unroll
   for (int th = 0; th < TH; ++th)
-    for (int wb = 0; wb < 2; ++wb) acc[th][wb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int wb = 0; wb < WB; ++wb) acc[th][wb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // lane's 8-byte word inside a row: x = wb*16 + li, word index = x + lk  (floats 2x + 2lk, 2x + 2lk + 1)
   const int lane_off = 2 * li + 2 * lk;
@@ -87,28 +102,29 @@ __global__ __launch_bounds__(TD * 64) void stem_fwd_kernel(StemFwdArgs p, int ti
     // B for (kd, kh): step s uses kw = 2*lk + s; element wf[((kd*7+kh)*7 + kw)*64 + ci*16 + co]
     auto load_b = [&](int kd, int kh, float &b0, float &b1) {
       const float *wrow = p.wf + (size_t)((kd * 7 + kh) * 7) * 64 + ci * 16 + li;
-      b0 = wrow[(2 * lk) * 64];
-      b1 = (2 * lk + 1 < 7) ? wrow[(2 * lk + 1) * 64] : 0.f;
+      // slab column 2x + 2k + s is input column 2(w0+x) - 3 + (2k + s - 1): step s of MFMA k index k is tap kw = 2k+s-1
+      b0 = (lk > 0) ? wrow[(2 * lk - 1) * 64] : 0.f;
+      b1 = wrow[(2 * lk) * 64];
     };
     // software pipeline over the 49 (kd, kh) rows: the A words (LDS) and B values (L2) of row r+1 are
     // requested before the 32 MFMAs of row r issue, so neither latency is ever exposed
-    auto load_a = [&](int kd, int kh, float2 (&a)[TH][2]) {
+    auto load_a = [&](int kd, int kh, float2 (&a)[TH][WB]) {
       const float *rowbase = slab + ((wave + kd) * G::PH + kh) * SW_ROW + lane_off;
 #pragma unroll
       for (int th = 0; th < TH; ++th)
 #pragma unroll
-        for (int wb = 0; wb < 2; ++wb) a[th][wb] = *reinterpret_cast<const float2 *>(rowbase + (2 * th) * SW_ROW + wb * 32);
+        for (int wb = 0; wb < WB; ++wb) a[th][wb] = *reinterpret_cast<const float2 *>(rowbase + (2 * th) * SW_ROW + wb * 32);
     };
-    auto mfma_row = [&](const float2 (&a)[TH][2], float b0, float b1) {
+    auto mfma_row = [&](const float2 (&a)[TH][WB], float b0, float b1) {
 #pragma unroll
       for (int th = 0; th < TH; ++th)
 #pragma unroll
-        for (int wb = 0; wb < 2; ++wb) {
+        for (int wb = 0; wb < WB; ++wb) {
           acc[th][wb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[th][wb].x, b0, acc[th][wb], 0, 0, 0);
           acc[th][wb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[th][wb].y, b1, acc[th][wb], 0, 0, 0);
         }
     };
-    float2 a0[TH][2], a1[TH][2];
+    float2 a0[TH][WB], a1[TH][WB];
     float b00, b01, b10 = 0.f, b11 = 0.f;
     load_b(0, 0, b00, b01);
     load_a(0, 0, a0);
@@ -134,7 +150,7 @@ __global__ __launch_bounds__(TD * 64) void stem_fwd_kernel(StemFwdArgs p, int ti
     const int oh = h0 + th;
     if (oh >= p.Ho) continue;
 #pragma unroll
-    for (int wb = 0; wb < 2; ++wb)
+    for (int wb = 0; wb < WB; ++wb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ow = w0 + wb * 16 + lk * 4 + r;
@@ -157,10 +173,10 @@ struct StemWgradArgs {
 };
 
 __global__ __launch_bounds__(kStemThreads) void stem_wgrad_kernel(StemWgradArgs p, int tiles_d, int tiles_h, int tiles_w) {
-  constexpr int TD = 4, TH = 8, TW = 32;
-  using G = StemGeo<TD, TH, TW, 80>;
+  constexpr int TD = 4, TH = 8, TW = 16;
+  using G = StemGeo<TD, TH, TW, 48>;       // 37 columns used; 48 == 16 (mod 32)
   constexpr int SW_ROW = G::SW_ROW;
-  constexpr int M = TD * TH * TW;          // 1024 positions per tile
+  constexpr int M = TD * TH * TW;          // 512 positions per tile
   constexpr int DYROW = 16;                // lanes (co, k) read word 16k + co: conflict-free
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *slab = lds;
@@ -185,7 +201,7 @@ __global__ __launch_bounds__(kStemThreads) void stem_wgrad_kernel(StemWgradArgs 
     const int gg = gok[q] ? g : 27;
     const int kd = gg >> 2, hp = gg & 3;
     // B[k][j]: row kh = 2hp + (j>>3), col kw = j&7 ; lane j = li
-    goff[q] = (kd * G::PH + 2 * hp + (li >> 3)) * SW_ROW + (li & 7);
+    goff[q] = (kd * G::PH + 2 * hp + (li >> 3)) * SW_ROW + (li & 7) + 1;   // +1: slab starts one column early
   }
   float bsum = 0.f;
 
@@ -270,21 +286,14 @@ extern "C" int mr3d_stem_conv_forward(const float *x_ncdhw, const float *w_packe
   a.N = n; a.D = d; a.H = h; a.W = w;
   a.Ho = (h + 6 - 7) / 2 + 1; a.Wo = (w + 6 - 7) / 2 + 1;
   a.relu = relu;
-  // TD = 4: 60 KiB slab, two 4-wave workgroups per CU (one stages while the other computes)
-  constexpr int TD = 4;
-  using G = StemGeo<TD, 8, 32, 72>;
+  // 4x8x16 output tile: 33 KiB slab, four 4-wave workgroups per CU = 4 waves per SIMD, so the matrix pipe
+  // always has a ready wave while others sit at a barrier / wait for LDS (measured: 2 waves per SIMD left it
+  // idle 40 % of the time)
+  constexpr int TD = 4, TW = 16;
+  using G = StemGeo<TD, 8, TW, 40>;
   constexpr int lds_bytes = G::SLAB * 4;
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(stem_fwd_kernel<TD>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            lds_bytes) != hipSuccess) {
-      (void)hipGetLastError();
-      return MR3D_ERR_LAUNCH;
-    }
-    attr = true;
-  }
-  const int td = (d + TD - 1) / TD, th = (a.Ho + 7) / 8, tw = (a.Wo + 31) / 32;
-  stem_fwd_kernel<TD><<<(unsigned)(n * td * th * tw), TD * 64, lds_bytes, mr3d_stream(stream_)>>>(a, td, th, tw);
+  const int td = (d + TD - 1) / TD, th = (a.Ho + 7) / 8, tw = (a.Wo + TW - 1) / TW;
+  stem_fwd_kernel<TD, TW><<<(unsigned)(n * td * th * tw), TD * 64, lds_bytes, mr3d_stream(stream_)>>>(a, td, th, tw);
   return mr3d_launch_status();
 }
 
@@ -295,8 +304,8 @@ extern "C" int mr3d_stem_conv_wgrad(const float *x_ncdhw, const float *dy, float
   a.x = x_ncdhw; a.dy = dy; a.dw = dw_packed; a.dbias = dbias;
   a.N = n; a.D = d; a.H = h; a.W = w;
   a.Ho = (h + 6 - 7) / 2 + 1; a.Wo = (w + 6 - 7) / 2 + 1;
-  using G = StemGeo<4, 8, 32, 80>;
-  constexpr int lds_bytes = (G::SLAB + 4 * 8 * 32 * 16) * 4;
+  using G = StemGeo<4, 8, 16, 48>;
+  constexpr int lds_bytes = (G::SLAB + 4 * 8 * 16 * 16) * 4;       // 72 KiB: two workgroups per CU
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(stem_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -306,13 +315,13 @@ extern "C" int mr3d_stem_conv_wgrad(const float *x_ncdhw, const float *dy, float
     }
     attr = true;
   }
-  const int td = (d + 3) / 4, th = (a.Ho + 7) / 8, tw = (a.Wo + 31) / 32;
+  const int td = (d + 3) / 4, th = (a.Ho + 7) / 8, tw = (a.Wo + 15) / 16;
   int tiles = n * td * th * tw;
   int dev = 0, cus = 256;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
     cus = prop.multiProcessorCount;
-  const int grid = tiles < cus ? tiles : cus;
+  const int grid = tiles < 2 * cus ? tiles : 2 * cus;
   stem_wgrad_kernel<<<(unsigned)grid, kStemThreads, lds_bytes, mr3d_stream(stream_)>>>(a, td, th, tw);
   return mr3d_launch_status();
 }
