@@ -13,5 +13,6 @@ _sys.modules.setdefault('mr3d_amd', _sys.modules[__name__])
 from . import _hip  # noqa: E402,F401
 from . import mmdet_ops  # noqa: E402,F401
 from . import mmdet_ops as ops  # noqa: E402,F401  (`from mmdet import ops` spelling)
+from . import core  # noqa: E402,F401
 
 __version__ = '0.1.0'

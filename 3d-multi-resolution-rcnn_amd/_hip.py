@@ -330,3 +330,81 @@ def stem_conv_wgrad(x_ncdhw, dy, dw_packed, dbias=None):
                                         stream_ptr(x_ncdhw.device))
     check(st, 'mr3d_stem_conv_wgrad')
     return dw_packed
+
+
+# --------------------------------------------------------------------------------------------
+def _f6(v, default):
+    v = list(default if v is None else v)
+    assert len(v) == 6
+    return (ctypes.c_float * 6)(*[float(x) for x in v])
+
+
+def _hwd(max_shape):
+    """max_shape is the reference's img_shape tuple (H, W, 3, D) (coco_3d_2scales.py:253-255) -> int[3] {H, W, D}"""
+    if max_shape is None:
+        return None
+    return (ctypes.c_int * 3)(int(max_shape[0]), int(max_shape[1]), int(max_shape[3]))
+
+
+def _dev_f32(t, what):
+    if not (t.is_cuda and t.dtype == torch.float32):
+        raise RuntimeError(f'{what} must be a float32 CUDAtensor ')
+    return t.contiguous()
+
+
+def delta2bbox3d(rois, deltas, means, stds, max_shape, wh_ratio_clip):
+    rois, deltas = _dev_f32(rois, 'rois'), _dev_f32(deltas, 'deltas')
+    n, k6 = deltas.shape
+    out = torch.empty_like(deltas)
+    with torch.cuda.device(rois.device):
+        st = lib().mr3d_delta2bbox3d(ptr(rois), ptr(deltas), n, k6 // 6, _f6(means, [0.] * 6), _f6(stds, [1.] * 6),
+                                     _hwd(max_shape), ctypes.c_double(wh_ratio_clip), ptr(out), stream_ptr(rois.device))
+    check(st, 'mr3d_delta2bbox3d')
+    return out
+
+
+def bbox2delta3d(proposals, gt, means, stds):
+    proposals, gt = _dev_f32(proposals, 'proposals'), _dev_f32(gt, 'gt')
+    out = torch.empty_like(proposals)
+    with torch.cuda.device(proposals.device):
+        st = lib().mr3d_bbox2delta3d(ptr(proposals), ptr(gt), proposals.size(0), _f6(means, [0.] * 6), _f6(stds, [1.] * 6),
+                                     ptr(out), stream_ptr(proposals.device))
+    check(st, 'mr3d_bbox2delta3d')
+    return out
+
+
+def bbox_overlaps3d(b1, b2):
+    b1, b2 = _dev_f32(b1, 'bboxes1'), _dev_f32(b2, 'bboxes2')
+    out = torch.empty((b1.size(0), b2.size(0)), dtype=torch.float32, device=b1.device)
+    with torch.cuda.device(b1.device):
+        st = lib().mr3d_bbox_overlaps3d(ptr(b1), ptr(b2), b1.size(0), b2.size(0), ptr(out), stream_ptr(b1.device))
+    check(st, 'mr3d_bbox_overlaps3d')
+    return out
+
+
+def grid_anchors3d(base_anchors, featmap_size, stride, depth_stride):
+    base = _dev_f32(base_anchors, 'base_anchors')
+    fd, fh, fw = (int(v) for v in featmap_size)
+    out = torch.empty((fd * fh * fw * base.size(0), 6), dtype=torch.float32, device=base.device)
+    with torch.cuda.device(base.device):
+        st = lib().mr3d_grid_anchors3d(ptr(base), base.size(0), fd, fh, fw, int(stride), int(depth_stride), ptr(out),
+                                       stream_ptr(base.device))
+    check(st, 'mr3d_grid_anchors3d')
+    return out
+
+
+def rpn_decode_level(flat_idx, scores, reg_map, reg_layout, base_anchors, featmap_size, stride, depth_stride, means, stds,
+                     max_shape, wh_ratio_clip=16 / 1000):
+    k = int(flat_idx.numel())
+    dets = torch.empty((k, 7), dtype=torch.float32, device=scores.device)
+    if k == 0:
+        return dets
+    assert flat_idx.dtype == torch.long and flat_idx.is_contiguous() and scores.is_contiguous() and reg_map.is_contiguous()
+    fd, fh, fw = (int(v) for v in featmap_size)
+    with torch.cuda.device(scores.device):
+        st = lib().mr3d_rpn_decode_level(ptr(flat_idx), ptr(scores), k, ptr(reg_map), int(reg_layout), ptr(base_anchors),
+                                         base_anchors.size(0), fd, fh, fw, int(stride), int(depth_stride),
+                                         _f6(means, [0.] * 6), _f6(stds, [1.] * 6), _hwd(max_shape),
+                                         ctypes.c_double(wh_ratio_clip), ptr(dets), stream_ptr(scores.device))
+    check(st, 'mr3d_rpn_decode_level')
+    return dets

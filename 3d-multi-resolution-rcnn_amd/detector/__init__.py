@@ -1,4 +1,5 @@
 """Host-side mirror of the reference's model pieces on the hot path (mmdet/models/...)."""
 from .extract_feat import ExtractFeat3D
+from .rpn_proposals import get_bboxes_single
 
-__all__ = ['ExtractFeat3D']
+__all__ = ['ExtractFeat3D', 'get_bboxes_single']

@@ -1,0 +1,59 @@
+"""RPN proposal generation of one image (RPNHead3D.get_bboxes_single, mmdet/models/anchor_heads/
+rpn_head_3d.py:72-149, called from AnchorHead3D.get_bboxes anchor_head_3d.py:232-268).
+
+Per level: sigmoid -> top-`nms_pre` -> [anchors + delta2bbox3D + score concat in ONE kernel] -> NMS3D -> first
+`nms_post`; across levels: top-`max_num` by score.  The top-k itself is torch.topk (selection plumbing); anchors
+are never materialised for the whole level (the reference builds all 655,360 P2 anchors, then gathers 2000).
+Not reproduced: the reference's stateful `self.pos_indices` filter (rpn_head_3d.py:95-106), which re-uses the
+inside-flags cached by the previous loss() call -- pass `valid_flags` explicitly to get the same effect."""
+from types import SimpleNamespace
+
+import torch
+
+from .. import _hip
+from ..mmdet_ops import nms
+
+
+def _as_cfg(cfg):
+    return cfg if not isinstance(cfg, dict) else SimpleNamespace(**cfg)
+
+
+def get_bboxes_single(cls_scores, bbox_preds, anchor_generators, anchor_strides, anchor_strides_depth, img_shape, cfg,
+                      target_means=(0., 0., 0., 0., 0., 0.), target_stds=(1., 1., 1., 1., 1., 1.), valid_flags=None):
+    """cls_scores[l]: [A, D, H, W] logits (any memory format); bbox_preds[l]: [A*6, D, H, W];
+    img_shape = (H, W, 3, D).  Returns proposals [<= max_num, 7] = [x1,y1,x2,y2,z1,z2,score]."""
+    cfg = _as_cfg(cfg)
+    mlvl = []
+    for lvl, (cls, reg) in enumerate(zip(cls_scores, bbox_preds)):
+        assert cls.shape[-3:] == reg.shape[-3:]
+        A, D, H, W = cls.shape
+        gen = anchor_generators[lvl]
+        scores = cls.permute(2, 3, 1, 0).reshape(-1).sigmoid()                 # flat (h, w, d, a) order (:87-90)
+        flat = None
+        if valid_flags is not None:
+            keep = valid_flags[lvl].nonzero(as_tuple=False).squeeze(1)
+            scores, flat = scores[keep], keep
+        if cfg.nms_pre > 0 and scores.shape[0] > cfg.nms_pre:
+            scores, top = scores.topk(cfg.nms_pre)
+            flat = top if flat is None else flat[top]
+        elif flat is None:
+            flat = torch.arange(scores.shape[0], device=scores.device)
+        # regression map of this level, as the kernel reads it
+        if reg.is_contiguous():
+            reg_map, layout = reg, _hip.LAYOUT_NCDHW
+        else:
+            reg_map, layout = reg.permute(1, 2, 3, 0).contiguous(), _hip.LAYOUT_NDHWC
+        dets = _hip.rpn_decode_level(flat.contiguous(), scores.contiguous(), reg_map, layout,
+                                     gen.base_anchors_on(scores.device), (D, H, W), anchor_strides[lvl],
+                                     anchor_strides_depth[lvl], target_means, target_stds, img_shape)
+        dets, _ = nms(dets, cfg.nms_thr)
+        mlvl.append(dets[:cfg.nms_post, :])
+    proposals = torch.cat(mlvl, 0)
+    if getattr(cfg, 'nms_across_levels', False):
+        proposals, _ = nms(proposals, cfg.nms_thr)
+        proposals = proposals[:cfg.max_num, :]
+    else:
+        num = min(cfg.max_num, proposals.shape[0])
+        _, top = proposals[:, 6].topk(num)
+        proposals = proposals[top, :]
+    return proposals

@@ -181,6 +181,33 @@ int mr3d_finish_grads(const mr3d_layer_desc *table, int num_layers, int max_cout
                       const float *scratch, float *grads, mr3d_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------
+ * Box arithmetic of the proposal path (each replaces a chain of ~10-30 elementwise ATen launches).
+ * Boxes are [x1,y1,x2,y2,z1,z2] fp32 with the reference's inclusive "+1" size convention.
+ *   delta2bbox3d  mmdet/core/bbox/transforms.py:105-160: deltas [n, 6*num_classes] in the order
+ *                 [dx,dy,dw,dh,dz,dd]; dw, dh AND dz, dd are clamped to +-|log(wh_ratio_clip)| (:122-128, the
+ *                 centre delta dz included, reproduced on purpose); max_shape_hwd = {H, W, D} or NULL.
+ *   bbox2delta3d  transforms.py:34-65 (encode).
+ *   bbox_overlaps3d  mmdet/core/bbox/geometry.py:49-60: IoU matrix [m, n].
+ *   grid_anchors3d   mmdet/core/anchor/anchor_generator_3d.py:55-71: flat order ((h*W + w)*D + d)*A + a.
+ *   rpn_decode_level mmdet/models/anchor_heads/rpn_head_3d.py:108-132: for the k selected flat anchor indices
+ *                 (int64, reference order) build anchor, gather the 6 deltas from the regression map
+ *                 ([A*6, D, H, W] NCDHW or [D, H, W, A*6] NDHWC of ONE image), decode, emit dets [k,7] = box + score.
+ * means/stds/max_shape are HOST arrays (6 / 6 / 3 values), copied by value into the launch.
+ * ---------------------------------------------------------------------------------------------- */
+int mr3d_delta2bbox3d(const float *rois, const float *deltas, int n, int num_classes, const float *means_host,
+                      const float *stds_host, const int *max_shape_hwd_host, double wh_ratio_clip, float *out,
+                      mr3d_stream_t s);
+int mr3d_bbox2delta3d(const float *proposals, const float *gt, int n, const float *means_host, const float *stds_host,
+                      float *out, mr3d_stream_t s);
+int mr3d_bbox_overlaps3d(const float *b1, const float *b2, int m, int n, float *out, mr3d_stream_t s);
+int mr3d_grid_anchors3d(const float *base_anchors, int num_base, int feat_d, int feat_h, int feat_w, int stride,
+                        int depth_stride, float *out, mr3d_stream_t s);
+int mr3d_rpn_decode_level(const long long *flat_idx, const float *scores, int k, const float *reg_map, int reg_layout,
+                          const float *base_anchors, int num_base, int feat_d, int feat_h, int feat_w, int stride,
+                          int depth_stride, const float *means_host, const float *stds_host,
+                          const int *max_shape_hwd_host, double wh_ratio_clip, float *dets_out, mr3d_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
  * ResNet3D stem -- Conv3d(3, 16, kernel 7, stride (1,2,2), padding 3) + folded BN + ReLU, forward and weight
  * gradient (mmdet/models/backbones/resnet3d.py:397-409,467-469), specialised: reads the volume in the
  * reference's own planar [N,3,D,H,W] layout, writes / reads NDHWC [N,D,H/2,W/2,16].
