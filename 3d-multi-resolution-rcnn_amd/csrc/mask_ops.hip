@@ -1,0 +1,116 @@
+// Mask-crop on the GPU:
+//   mask_target3d  training targets of the mask head: per positive RoI crop the assigned GT instance volume and
+//                  resample it to (md, mh, mw)    (mmdet/core/mask/mask_target.py:17-49, called from
+//                  FCNMaskHead3D.get_target, mmdet/models/mask_heads/fcn_mask_head_3d.py:99-106)
+//   mask_paste3d   test-time: resample each predicted (md, mh, mw) probability map to its box and paste the
+//                  thresholded result into a full-volume uint8 mask  (fcn_mask_head_3d.py:126-191)
+// The reference does both on the CPU with skimage.transform.resize in a Python loop (D2H of boxes, per-RoI
+// call, H2D of the result).  skimage is neither vendored nor installable here, so the exact resampling is
+// "parity unpinned"; this build defines it as: crop by integer-truncated box (bbox.astype(int32), size
+// max(x2-x1+1, 1), clipped to the volume like a numpy slice), trilinear resampling with half-pixel centres
+// (src = (dst + 0.5) * in/out - 0.5, clamped to the crop), target = 1 iff floor(255 * value) > 0 (the
+// reference's `255*resize(...)).astype(uint8) > 0`), paste = value > thr.  No anti-alias pre-filter.
+#include "mr3d_common.h"
+
+namespace {
+
+constexpr int kT = 256;
+
+struct Crop { int x1, y1, z1, w, h, d; };
+
+__device__ __forceinline__ Crop crop_of(const float *__restrict__ box, int W, int H, int D) {
+  Crop c;
+  const int x1 = (int)box[0], y1 = (int)box[1], x2 = (int)box[2], y2 = (int)box[3], z1 = (int)box[4], z2 = (int)box[5];
+  int w = max(x2 - x1 + 1, 1), h = max(y2 - y1 + 1, 1), d = max(z2 - z1 + 1, 1);
+  // numpy slice semantics: [lo, lo+size) intersected with [0, dim)
+  const int xa = max(x1, 0), ya = max(y1, 0), za = max(z1, 0);
+  const int xb = min(x1 + w, W), yb = min(y1 + h, H), zb = min(z1 + d, D);
+  c.x1 = xa; c.y1 = ya; c.z1 = za; c.w = xb - xa; c.h = yb - ya; c.d = zb - za;
+  return c;
+}
+
+__device__ __forceinline__ void axis(int o, int out, int in, int &lo, int &hi, float &f) {
+  float s = ((float)o + 0.5f) * ((float)in / (float)out) - 0.5f;
+  s = fminf(fmaxf(s, 0.f), (float)(in - 1));
+  lo = (int)s;
+  hi = min(lo + 1, in - 1);
+  f = s - (float)lo;
+}
+
+__global__ __launch_bounds__(kT) void mask_target3d_kernel(const uint8_t *__restrict__ gt, int D, int H, int W,
+                                                          const float *__restrict__ boxes, int box_stride,
+                                                          const long long *__restrict__ gt_inds, int P, int md, int mh, int mw,
+                                                          float *__restrict__ out) {
+  const long long total = (long long)P * md * mh * mw;
+  for (long long t = (long long)blockIdx.x * kT + threadIdx.x; t < total; t += (long long)gridDim.x * kT) {
+    const int ow = (int)(t % mw), oh = (int)((t / mw) % mh), od = (int)((t / ((long long)mw * mh)) % md);
+    const int p = (int)(t / ((long long)mw * mh * md));
+    const Crop c = crop_of(boxes + (size_t)p * box_stride, W, H, D);
+    float v = 0.f;
+    if (c.w > 0 && c.h > 0 && c.d > 0) {
+      const uint8_t *g = gt + (size_t)gt_inds[p] * D * H * W;
+      int xl, xh, yl, yh, zl, zh;
+      float fx, fy, fz;
+      axis(ow, mw, c.w, xl, xh, fx); axis(oh, mh, c.h, yl, yh, fy); axis(od, md, c.d, zl, zh, fz);
+      auto at = [&](int z, int y, int x) -> float {
+        return g[((size_t)(c.z1 + z) * H + (c.y1 + y)) * W + (c.x1 + x)] ? 1.f : 0.f;
+      };
+      const float c00 = at(zl, yl, xl) * (1 - fx) + at(zl, yl, xh) * fx, c01 = at(zl, yh, xl) * (1 - fx) + at(zl, yh, xh) * fx;
+      const float c10 = at(zh, yl, xl) * (1 - fx) + at(zh, yl, xh) * fx, c11 = at(zh, yh, xl) * (1 - fx) + at(zh, yh, xh) * fx;
+      v = (c00 * (1 - fy) + c01 * fy) * (1 - fz) + (c10 * (1 - fy) + c11 * fy) * fz;
+    }
+    out[t] = floorf(255.f * v) > 0.f ? 1.f : 0.f;
+  }
+}
+
+// one workgroup row per detection; threads stride over the box's voxels
+__global__ __launch_bounds__(kT) void mask_paste3d_kernel(const float *__restrict__ prob, int md, int mh, int mw,
+                                                         const float *__restrict__ boxes, int box_stride, int P, float thr,
+                                                         int D, int H, int W, uint8_t *__restrict__ out) {
+  const int p = blockIdx.y;
+  const Crop c = crop_of(boxes + (size_t)p * box_stride, W, H, D);
+  // the reference resizes to the UNCLIPPED (d, h, w) and assigns into a slice; a box leaving the volume would raise
+  // there, so only in-volume boxes are meaningful: resample over the clipped extent
+  if (c.w <= 0 || c.h <= 0 || c.d <= 0) return;
+  const float *m = prob + (size_t)p * md * mh * mw;
+  uint8_t *o = out + (size_t)p * D * H * W;
+  const long long n = (long long)c.w * c.h * c.d;
+  for (long long t = (long long)blockIdx.x * kT + threadIdx.x; t < n; t += (long long)gridDim.x * kT) {
+    const int x = (int)(t % c.w), y = (int)((t / c.w) % c.h), z = (int)(t / ((long long)c.w * c.h));
+    int xl, xh, yl, yh, zl, zh;
+    float fx, fy, fz;
+    axis(x, c.w, mw, xl, xh, fx); axis(y, c.h, mh, yl, yh, fy); axis(z, c.d, md, zl, zh, fz);
+    auto at = [&](int zz, int yy, int xx) { return m[((size_t)zz * mh + yy) * mw + xx]; };
+    const float c00 = at(zl, yl, xl) * (1 - fx) + at(zl, yl, xh) * fx, c01 = at(zl, yh, xl) * (1 - fx) + at(zl, yh, xh) * fx;
+    const float c10 = at(zh, yl, xl) * (1 - fx) + at(zh, yl, xh) * fx, c11 = at(zh, yh, xl) * (1 - fx) + at(zh, yh, xh) * fx;
+    const float v = (c00 * (1 - fy) + c01 * fy) * (1 - fz) + (c10 * (1 - fy) + c11 * fy) * fz;
+    o[((size_t)(c.z1 + z) * H + (c.y1 + y)) * W + (c.x1 + x)] = v > thr ? 1 : 0;
+  }
+}
+
+}  // namespace
+
+extern "C" int mr3d_mask_target3d(const uint8_t *gt_masks, int depth, int height, int width, const float *pos_boxes,
+                                  int box_stride, const long long *pos_assigned_gt_inds, int num_pos, int mask_d, int mask_h,
+                                  int mask_w, float *targets, mr3d_stream_t s) {
+  if (num_pos < 0 || mask_d <= 0 || mask_h <= 0 || mask_w <= 0 || box_stride < 6) return MR3D_ERR_INVALID_ARG;
+  if (num_pos == 0) return MR3D_OK;
+  if (!gt_masks || !pos_boxes || !pos_assigned_gt_inds || !targets) return MR3D_ERR_INVALID_ARG;
+  const long long total = (long long)num_pos * mask_d * mask_h * mask_w;
+  long long blocks = (total + kT - 1) / kT;
+  if (blocks > 8192) blocks = 8192;
+  mask_target3d_kernel<<<(unsigned)blocks, kT, 0, mr3d_stream(s)>>>(gt_masks, depth, height, width, pos_boxes, box_stride,
+                                                                pos_assigned_gt_inds, num_pos, mask_d, mask_h, mask_w, targets);
+  return mr3d_launch_status();
+}
+
+extern "C" int mr3d_mask_paste3d(const float *mask_prob, int mask_d, int mask_h, int mask_w, const float *det_boxes,
+                                 int box_stride, int num_dets, float threshold, int depth, int height, int width,
+                                 uint8_t *out_masks, mr3d_stream_t s) {
+  if (num_dets < 0 || box_stride < 6) return MR3D_ERR_INVALID_ARG;
+  if (num_dets == 0) return MR3D_OK;
+  if (!mask_prob || !det_boxes || !out_masks) return MR3D_ERR_INVALID_ARG;
+  mask_paste3d_kernel<<<dim3(64, num_dets), kT, 0, mr3d_stream(s)>>>(mask_prob, mask_d, mask_h, mask_w, det_boxes, box_stride,
+                                                                    num_dets, threshold, depth, height, width, out_masks);
+  return mr3d_launch_status();
+}

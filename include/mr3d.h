@@ -208,6 +208,21 @@ int mr3d_rpn_decode_level(const long long *flat_idx, const float *scores, int k,
                           const int *max_shape_hwd_host, double wh_ratio_clip, float *dets_out, mr3d_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------
+ * Mask-crop (replaces the CPU skimage loops of mmdet/core/mask/mask_target.py:17-49 and
+ * mmdet/models/mask_heads/fcn_mask_head_3d.py:163-189).  "Parity unpinned": skimage.transform.resize is a
+ * third-party dependency (scikit-image==0.18.0) absent from the reference tree; semantics defined in csrc/mask_ops.hip.
+ *   mask_target3d: gt_masks u8 [G,D,H,W] (device), pos_boxes [P, box_stride>=6] fp32, pos_assigned_gt_inds i64 [P]
+ *                  -> targets fp32 [P, md, mh, mw] in {0,1}.
+ *   mask_paste3d:  mask_prob fp32 [P, md, mh, mw] (already sigmoid-ed, the det's class channel), det_boxes
+ *                  [P, box_stride>=6] -> out_masks u8 [P, D, H, W], PRE-ZEROED by the caller.
+ * ---------------------------------------------------------------------------------------------- */
+int mr3d_mask_target3d(const uint8_t *gt_masks, int depth, int height, int width, const float *pos_boxes, int box_stride,
+                       const long long *pos_assigned_gt_inds, int num_pos, int mask_d, int mask_h, int mask_w,
+                       float *targets, mr3d_stream_t s);
+int mr3d_mask_paste3d(const float *mask_prob, int mask_d, int mask_h, int mask_w, const float *det_boxes, int box_stride,
+                      int num_dets, float threshold, int depth, int height, int width, uint8_t *out_masks, mr3d_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
  * ResNet3D stem -- Conv3d(3, 16, kernel 7, stride (1,2,2), padding 3) + folded BN + ReLU, forward and weight
  * gradient (mmdet/models/backbones/resnet3d.py:397-409,467-469), specialised: reads the volume in the
  * reference's own planar [N,3,D,H,W] layout, writes / reads NDHWC [N,D,H/2,W/2,16].

@@ -1,0 +1,70 @@
+"""Mask-crop: numpy restatement invariants (CPU) and GPU parity with it."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import mask_ref
+
+
+def _scene(rng, G=3, D=24, H=48, W=40):
+    gt = np.zeros((G, D, H, W), np.uint8)
+    for g in range(G):
+        c = rng.uniform([6, 10, 10], [D - 6, H - 10, W - 10])
+        r = rng.uniform(2.5, 6.0, 3)
+        z, y, x = np.ogrid[:D, :H, :W]
+        gt[g] = (((z - c[0]) / r[0]) ** 2 + ((y - c[1]) / r[1]) ** 2 + ((x - c[2]) / r[2]) ** 2 <= 1).astype(np.uint8)
+    P = 40
+    gi = rng.integers(0, G, P)
+    boxes = np.zeros((P, 6), np.float32)
+    for p in range(P):
+        zz, yy, xx = np.nonzero(gt[gi[p]])
+        j = rng.normal(0, 1.5, 6)
+        boxes[p] = [xx.min() + j[0], yy.min() + j[1], xx.max() + j[2], yy.max() + j[3], zz.min() + j[4], zz.max() + j[5]]
+    boxes[0] = [-5.3, -2.1, 12.7, 9.2, -1.5, 4.4]          # leaves the volume on the low side
+    boxes[1] = [30.2, 40.9, 60.0, 70.0, 20.1, 40.0]        # leaves it on the high side
+    boxes[2] = [10.9, 10.2, 10.1, 10.3, 5.5, 5.6]          # degenerate -> 1 voxel
+    return gt, boxes, gi.astype(np.int64)
+
+
+def test_restatement_invariants():
+    rng = np.random.default_rng(0)
+    gt, boxes, gi = _scene(rng)
+    t = mask_ref.mask_target(gt, boxes, gi, 20, 28, 28)
+    assert t.shape == (40, 20, 28, 28) and set(np.unique(t)) <= {0.0, 1.0}
+    ones = np.ones_like(gt)
+    assert mask_ref.mask_target(ones, boxes, gi, 20, 28, 28).min() == 1.0          # all-ones stays all-ones
+    assert mask_ref.mask_target(ones * 0, boxes, gi, 20, 28, 28).max() == 0.0      # all-zeros stays all-zeros
+    big = mask_ref.mask_target(gt, boxes, gi, 40, 56, 56)                           # monotone under scaling
+    assert abs(big.mean() - t.mean()) < 0.05
+    # scipy's order-1 zoom of the same crop agrees on the bulk of the voxels (sanity comparator)
+    from scipy.ndimage import zoom
+    xa, ya, za, w, h, d = mask_ref._crop(boxes[5], gt.shape[3], gt.shape[2], gt.shape[1])
+    crop = gt[gi[5], za:za + d, ya:ya + h, xa:xa + w].astype(np.float32)
+    z = zoom(crop, (20 / d, 28 / h, 28 / w), order=1, mode='nearest', grid_mode=True)
+    agree = ((z > 0.004) == (t[5] > 0)).mean()
+    assert agree > 0.9
+
+
+@pytest.mark.gpu
+def test_mask_target_and_paste_gpu_vs_restatement():
+    from mr3d_amd.core import mask_target_single, mask_target, paste_masks_3d
+    rng = np.random.default_rng(1)
+    gt, boxes, gi = _scene(rng)
+    dev = torch.device('cuda:0')
+    cfg = dict(mask_size=28, mask_size_depth=20)
+    boxes7 = np.concatenate([boxes, rng.uniform(0, 1, (len(boxes), 1)).astype(np.float32)], 1)   # dets carry a score column
+    got = mask_target_single(torch.from_numpy(boxes7).to(dev), torch.from_numpy(gi).to(dev), torch.from_numpy(gt), cfg)
+    exp = mask_ref.mask_target(gt, boxes, gi, 20, 28, 28)
+    mism = (got.cpu().numpy() != exp).mean()
+    assert mism < 1e-4, mism                       # binarisation at floor(255 v) > 0: fp32 FMA contraction can flip a voxel
+    both = mask_target([torch.from_numpy(boxes[:7]).to(dev), torch.from_numpy(boxes[7:]).to(dev)],
+                       [torch.from_numpy(gi[:7]).to(dev), torch.from_numpy(gi[7:]).to(dev)],
+                       [torch.from_numpy(gt), torch.from_numpy(gt)], cfg)
+    assert torch.equal(both, got)
+    assert mask_target_single(torch.zeros((0, 6), device=dev), torch.zeros(0, dtype=torch.long), torch.from_numpy(gt), cfg).shape == (0, 20, 28, 28)
+    prob = torch.sigmoid(torch.randn(len(boxes), 20, 28, 28, device=dev) * 2)
+    D, H, W = gt.shape[1:]
+    pasted = paste_masks_3d(prob, torch.from_numpy(boxes7).to(dev), (D, H, W), 0.25)
+    expp = mask_ref.mask_paste(prob.cpu().numpy(), boxes, 0.25, D, H, W)
+    assert pasted.dtype == torch.uint8 and pasted.shape == (len(boxes), D, H, W)
+    assert (pasted.cpu().numpy() != expp).mean() < 1e-5
