@@ -1,5 +1,7 @@
 """Host-side mirror of the reference's model pieces on the hot path (mmdet/models/...)."""
 from .extract_feat import ExtractFeat3D
 from .rpn_proposals import get_bboxes_single
+from .heads import RPNHead3D, SharedFCBBoxHead3D, FCNMaskHead3D
+from . import layers
 
-__all__ = ['ExtractFeat3D', 'get_bboxes_single']
+__all__ = ['ExtractFeat3D', 'get_bboxes_single', 'RPNHead3D', 'SharedFCBBoxHead3D', 'FCNMaskHead3D', 'layers']

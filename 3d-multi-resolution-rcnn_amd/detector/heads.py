@@ -1,0 +1,138 @@
+"""RPN / bbox / mask head forwards on the HIP conv engine, with the reference's parameter names.
+
+  RPNHead3D            mmdet/models/anchor_heads/rpn_head_3d.py:13-35  (+ proposals: rpn_proposals.py)
+  SharedFCBBoxHead3D   mmdet/models/bbox_heads/convfc_bbox_head_3d.py:9-183 (num_shared_fcs=2 configuration)
+  FCNMaskHead3D        mmdet/models/mask_heads/fcn_mask_head_3d.py:15-97 (+ get_target -> core.mask.mask_target)
+Loss functions stay in PyTorch (elementwise, "next")."""
+import torch
+import torch.nn as nn
+
+from . import layers
+from ..core.mask import mask_target
+from ..core.anchor import AnchorGenerator3D
+from .rpn_proposals import get_bboxes_single
+
+
+class RPNHead3D(nn.Module):
+
+    def __init__(self, in_channels=64, feat_channels=64, anchor_scales=(2,), anchor_depth_scales=(2,), anchor_ratios=(1.0,),
+                 anchor_strides=(4, 8, 16, 32, 64), anchor_strides_depth=(2, 4, 8, 16, 32),
+                 target_means=(0., 0., 0., 0., 0., 0.), target_stds=(1., 1., 1., 1., 1., 1.), use_sigmoid_cls=True):
+        super().__init__()
+        assert use_sigmoid_cls, 'the shipped config uses sigmoid classification (configs/...py:27)'
+        self.anchor_strides, self.anchor_strides_depth = list(anchor_strides), list(anchor_strides_depth)
+        self.target_means, self.target_stds = list(target_means), list(target_stds)
+        self.anchor_generators = [AnchorGenerator3D(s, list(anchor_scales), list(anchor_depth_scales), list(anchor_ratios), d)
+                                  for s, d in zip(anchor_strides, anchor_strides_depth)]       # anchor_head_3d.py:66-70
+        self.num_anchors = len(anchor_ratios) * len(anchor_scales)
+        self.rpn_conv = nn.Conv3d(in_channels, feat_channels, 3, padding=1)
+        self.rpn_cls = nn.Conv3d(feat_channels, self.num_anchors, 1)
+        self.rpn_reg = nn.Conv3d(feat_channels, self.num_anchors * 6, 1)
+        self.init_weights()
+
+    def init_weights(self):
+        for m in (self.rpn_conv, self.rpn_cls, self.rpn_reg):              # normal_init(std=0.01), rpn_head_3d.py:25-28
+            nn.init.normal_(m.weight, 0, 0.01)
+            nn.init.constant_(m.bias, 0)
+
+    def forward_single(self, x):
+        h = layers.conv3d(x, self.rpn_conv.weight, self.rpn_conv.bias, padding=1, relu=True)
+        # the two 1x1x1 heads share their input: one 64 -> (A + 6A) conv, split afterwards
+        w = torch.cat([self.rpn_cls.weight, self.rpn_reg.weight], 0)
+        b = torch.cat([self.rpn_cls.bias, self.rpn_reg.bias], 0)
+        out = layers.conv3d(h, w, b)
+        return out[:, :self.num_anchors], out[:, self.num_anchors:]
+
+    def forward(self, feats):
+        outs = [self.forward_single(f) for f in feats]
+        return [o[0] for o in outs], [o[1] for o in outs]
+
+    def get_bboxes(self, cls_scores, bbox_preds, img_metas, cfg):
+        """per image proposals (anchor_head_3d.py:232-268 -> rpn_head_3d.py:72-149)"""
+        res = []
+        for i, meta in enumerate(img_metas):
+            res.append(get_bboxes_single([c[i] for c in cls_scores], [r[i] for r in bbox_preds], self.anchor_generators,
+                                         self.anchor_strides, self.anchor_strides_depth, meta['img_shape'], cfg,
+                                         self.target_means, self.target_stds))
+        return res
+
+
+class SharedFCBBoxHead3D(nn.Module):
+
+    def __init__(self, in_channels=64, fc_out_channels=1024, roi_feat_size=7, roi_feat_size_depth=3, num_classes=2,
+                 reg_class_agnostic=False, with_cls=True):
+        super().__init__()
+        flat = in_channels * roi_feat_size_depth * roi_feat_size * roi_feat_size
+        self.shared_fcs = nn.ModuleList([nn.Linear(flat, fc_out_channels), nn.Linear(fc_out_channels, fc_out_channels)])
+        self.with_cls = with_cls                     # the refinement head has no classifier (..._refinement_head.py)
+        if with_cls:
+            self.fc_cls = nn.Linear(fc_out_channels, num_classes)
+        self.fc_reg = nn.Linear(fc_out_channels, 6 if reg_class_agnostic else 6 * num_classes)
+        self.init_weights()
+
+    def init_weights(self):
+        for m in self.shared_fcs:                                           # convfc_bbox_head_3d.py:122-128
+            nn.init.xavier_uniform_(m.weight)
+            nn.init.constant_(m.bias, 0)
+        if self.with_cls:
+            nn.init.normal_(self.fc_cls.weight, 0, 0.01)                    # bbox_head_3d.py:59-66
+            nn.init.constant_(self.fc_cls.bias, 0)
+        nn.init.normal_(self.fc_reg.weight, 0, 0.001)
+        nn.init.constant_(self.fc_reg.bias, 0)
+
+    def forward(self, x):
+        x = x.reshape(x.size(0), -1)                                         # (c, d, h, w) flatten order of RoIAlign3D's output
+        for fc in self.shared_fcs:
+            x = layers.linear(x, fc.weight, fc.bias, relu=True)
+        # cls and reg read the same activations: one GEMM with stacked rows
+        if self.with_cls:
+            w = torch.cat([self.fc_cls.weight, self.fc_reg.weight], 0)
+            b = torch.cat([self.fc_cls.bias, self.fc_reg.bias], 0)
+            out = layers.linear(x, w, b)
+            nc = self.fc_cls.weight.shape[0]
+            return out[:, :nc], out[:, nc:]
+        return None, layers.linear(x, self.fc_reg.weight, self.fc_reg.bias)
+
+
+class _ConvModule(nn.Module):
+    """parameter container named like ConvModule3D (`convs.0.conv.weight`, conv_module3d.py:34)"""
+
+    def __init__(self, cin, cout, k, pad):
+        super().__init__()
+        self.conv = nn.Conv3d(cin, cout, k, padding=pad)
+        self.pad = pad
+        nn.init.kaiming_normal_(self.conv.weight, mode='fan_out', nonlinearity='relu')     # conv_module3d.py:70-74
+        nn.init.constant_(self.conv.bias, 0)
+
+    def forward(self, x):
+        return layers.conv3d(x, self.conv.weight, self.conv.bias, padding=self.pad, relu=True)
+
+
+class FCNMaskHead3D(nn.Module):
+
+    def __init__(self, num_convs=4, in_channels=64, conv_kernel_size=3, conv_out_channels=64, upsample_ratio=2,
+                 num_classes=2, class_agnostic=False):
+        super().__init__()
+        assert upsample_ratio == 2, 'deconv kernel 2 / stride 2 (the shipped configuration)'
+        self.num_classes, self.class_agnostic = num_classes, class_agnostic
+        self.convs = nn.ModuleList([_ConvModule(in_channels if i == 0 else conv_out_channels, conv_out_channels,
+                                                conv_kernel_size, (conv_kernel_size - 1) // 2) for i in range(num_convs)])
+        self.upsample = nn.ConvTranspose3d(conv_out_channels, conv_out_channels, 2, stride=2)
+        self.conv_logits = nn.Conv3d(conv_out_channels, 1 if class_agnostic else num_classes, 1)
+        self.init_weights()
+
+    def init_weights(self):
+        for m in (self.upsample, self.conv_logits):                          # fcn_mask_head_3d.py:79-86
+            nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            nn.init.constant_(m.bias, 0)
+
+    def forward(self, x):
+        for conv in self.convs:
+            x = conv(x)
+        x = layers.conv_transpose3d_k2s2(x, self.upsample.weight, self.upsample.bias, relu=True)
+        return layers.conv3d(x, self.conv_logits.weight, self.conv_logits.bias)
+
+    def get_target(self, sampling_results, gt_masks, rcnn_train_cfg):
+        pos_proposals = [res.pos_bboxes for res in sampling_results]
+        pos_assigned_gt_inds = [res.pos_assigned_gt_inds for res in sampling_results]
+        return mask_target(pos_proposals, pos_assigned_gt_inds, gt_masks, rcnn_train_cfg)

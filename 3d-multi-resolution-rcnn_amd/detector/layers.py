@@ -1,0 +1,103 @@
+"""Autograd-aware layers on the HIP conv engine, used by the heads (RPN / bbox / mask).
+
+`conv3d` = stride-1 Conv3d (+ bias, + optional fused ReLU) whose forward, data gradient and weight gradient all
+run on the fp32-MFMA kernels of csrc/conv3d_fwd.hip / conv3d_wgrad.hip (pointwise shapes take the streaming
+kernels of csrc/pointwise.hip).  Tensors keep the reference's logical [N, C, D, H, W] shape; physically they are
+NDHWC (torch.channels_last_3d), so chaining these layers never transposes.  `linear` and `conv_transpose3d_k2s2`
+are expressed through the same kernel: a Linear is a pointwise conv over rows, a kernel-2/stride-2 transposed conv
+is a pointwise conv to 8*Cout channels followed by a pixel shuffle."""
+import torch
+import torch.nn.functional as F
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .. import _hip
+
+
+def _ndhwc(x):
+    """[N,C,D,H,W] (any strides) -> contiguous [N,D,H,W,C] (zero-copy when x is channels_last_3d)"""
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def _pad_to(n, m):
+    return -(-n // m) * m
+
+
+class _Conv3dFn(Function):
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, padding, relu):
+        if not x.is_cuda:
+            raise NotImplementedError('the HIP conv engine has no CPU fallback')
+        co, ci, k = weight.shape[0], weight.shape[1], weight.shape[2]
+        assert weight.shape[2] == weight.shape[3] == weight.shape[4] and ci % 16 == 0, 'cubic kernel, Cin % 16 == 0'
+        cop = _pad_to(co, 16)
+        w = weight.detach()
+        if cop != co:
+            w = F.pad(w, (0, 0, 0, 0, 0, 0, 0, 0, 0, cop - co))
+        shift = None
+        if bias is not None:
+            shift = F.pad(bias.detach(), (0, cop - co)) if cop != co else bias.detach().contiguous()
+        xc = _ndhwc(x.detach())
+        y = _hip.conv3d_forward(xc, _hip.pack_conv_weight(w), (k,) * 3, (1, 1, 1), (padding,) * 3, shift=shift, relu=relu)
+        ctx.save_for_backward(xc, w, y if relu else None)
+        ctx.meta = (co, cop, k, padding, relu, bias is not None)
+        out = y.permute(0, 4, 1, 2, 3)
+        return out[:, :co] if cop != co else out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        xc, w, y = ctx.saved_tensors
+        co, cop, k, padding, relu, has_bias = ctx.meta
+        g = gy.permute(0, 2, 3, 4, 1)
+        if cop != co:
+            gp = torch.zeros(g.shape[:4] + (cop,), dtype=torch.float32, device=g.device)
+            gp[..., :co] = g
+            g = gp
+        else:
+            g = g.contiguous()
+        if relu:
+            g = g * (y > 0)
+        taps, ci = k ** 3, xc.size(4)
+        gw = gb = gx = None
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            dwp = torch.zeros((taps, ci, cop), dtype=torch.float32, device=g.device)
+            db = torch.zeros((cop,), dtype=torch.float32, device=g.device)
+            _hip.conv3d_wgrad(xc, g, dwp, (k,) * 3, (1, 1, 1), (padding,) * 3, dbias=db)
+            gw = dwp.permute(2, 1, 0).reshape(cop, ci, k, k, k)[:co].contiguous()
+            gb = db[:co].contiguous() if has_bias else None
+        if ctx.needs_input_grad[0]:
+            # dgrad = stride-1 conv of dy with flipped taps and swapped channel roles: wb[taps-1-t][co][ci]
+            wb = w.reshape(cop, ci, taps).flip(2).permute(2, 0, 1).contiguous()
+            gxc = _hip.conv3d_forward(g, wb, (k,) * 3, (1, 1, 1), (k - 1 - padding,) * 3)
+            gx = gxc.permute(0, 4, 1, 2, 3)
+        return gx, gw, gb, None, None
+
+
+def conv3d(x, weight, bias=None, padding=0, relu=False):
+    """stride-1 cubic Conv3d (+bias, +ReLU); x [N,Cin,D,H,W] -> [N,Cout,D',H',W'] (channels_last_3d view)"""
+    return _Conv3dFn.apply(x, weight, bias, int(padding), bool(relu))
+
+
+def linear(x, weight, bias=None, relu=False):
+    """y = x @ weight.T + bias for x [R, K] (K % 16 == 0), as a pointwise conv over the rows"""
+    R, K = x.shape
+    rp = _pad_to(max(R, 1), 64)
+    xp = x if rp == R else F.pad(x, (0, 0, 0, rp - R))
+    x5 = xp.reshape(1, rp // 64, 8, 8, K).permute(0, 4, 1, 2, 3)          # logical [1, K, D, H, W], physically NDHWC
+    y5 = conv3d(x5, weight.reshape(weight.shape[0], K, 1, 1, 1), bias, 0, relu)
+    return y5.permute(0, 2, 3, 4, 1).reshape(rp, weight.shape[0])[:R]
+
+
+def conv_transpose3d_k2s2(x, weight, bias=None, relu=False):
+    """ConvTranspose3d(kernel 2, stride 2): weight [Cin, Cout, 2, 2, 2] (torch layout).
+    out[n, co, 2d+a, 2h+b, 2w+c] = sum_ci x[n,ci,d,h,w] * weight[ci,co,a,b,c] + bias[co]"""
+    ci, co = weight.shape[0], weight.shape[1]
+    w8 = weight.permute(2, 3, 4, 1, 0).reshape(8 * co, ci, 1, 1, 1)          # rows ordered (a, b, c, co)
+    b8 = bias.repeat(8) if bias is not None else None
+    y = conv3d(x, w8, b8, 0, relu)                                           # [N, 8*co, D, H, W]
+    N, _, D, H, W = y.shape
+    y = y.permute(0, 2, 3, 4, 1).reshape(N, D, H, W, 2, 2, 2, co)
+    y = y.permute(0, 1, 4, 2, 5, 3, 6, 7).reshape(N, 2 * D, 2 * H, 2 * W, co)
+    return y.permute(0, 4, 1, 2, 3)
