@@ -171,4 +171,5 @@ def test_bbox_head_and_mask_head_vs_torch():
         # though, a pre-activation within fp32 rounding of 0 takes its mask from the summation order, and ONE flipped
         # element moves a weight gradient by |dy*x| / max|dW| ~ 1/150 here (measured: 1.0e-3 with one flip, while the
         # single-layer errors are 4e-7).  The bound therefore only guards against structural errors.
-        assert e_gpu <= max(5e-3, 5 * e_cpu), (k, e_gpu, e_cpu)
+        l2 = float((got[k].cpu().double() - g64[k]).norm() / g64[k].norm())
+        assert l2 <= 2e-3 and e_gpu <= max(3e-2, 5 * e_cpu), (k, l2, e_gpu, e_cpu)
