@@ -7,6 +7,7 @@ so `from mmdet.ops import ...` statements of the reference keep resolving.
 """
 from .nms import nms, soft_nms
 from .roi_align import RoIAlign3D, RoIAlignFunction3D, roi_align_3d, RoIAlign, roi_align
+from .dcn import DeformConv3d, ModulatedDeformConv3d, DeformConvFunction3D, deform_conv3d
 from ._unsupported import (DeformConv, DeformConvPack, ModulatedDeformConv, ModulatedDeformConvPack, DeformRoIPooling,
                            DeformRoIPoolingPack, ModulatedDeformRoIPoolingPack, deform_conv, modulated_deform_conv,
                            deform_roi_pooling, RoIPool, roi_pool, SigmoidFocalLoss, sigmoid_focal_loss)
@@ -15,5 +16,6 @@ __all__ = [
     'nms', 'soft_nms', 'RoIAlign', 'roi_align', 'RoIPool', 'roi_pool', 'DeformConv', 'DeformConvPack',
     'DeformRoIPooling', 'DeformRoIPoolingPack', 'ModulatedDeformRoIPoolingPack', 'ModulatedDeformConv',
     'ModulatedDeformConvPack', 'deform_conv', 'modulated_deform_conv', 'deform_roi_pooling', 'SigmoidFocalLoss',
-    'sigmoid_focal_loss', 'RoIAlign3D', 'RoIAlignFunction3D', 'roi_align_3d'
+    'sigmoid_focal_loss', 'RoIAlign3D', 'RoIAlignFunction3D', 'roi_align_3d', 'DeformConv3d', 'ModulatedDeformConv3d',
+    'DeformConvFunction3D', 'deform_conv3d'
 ]

@@ -223,6 +223,28 @@ int mr3d_mask_paste3d(const float *mask_prob, int mask_d, int mask_h, int mask_w
                       int num_dets, float threshold, int depth, int height, int width, uint8_t *out_masks, mr3d_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------
+ * DeformConv3d (v1) / modulated (v2): the sampling halves of the operator; the GEMM halves are
+ * mr3d_conv3d_forward / mr3d_conv3d_wgrad over the column matrix (see csrc/deform_conv3d.hip).
+ * Extends the reference's 2D operator (mmdet/ops/dcn/src/deform_conv_cuda_kernel.cu:83-435,569-766 and
+ * deform_conv_cuda.cpp:151-479): same sampling rule (0 outside (-1, dim), floor(), corners masked one by one),
+ * offsets per tap as consecutive (d, h, w) values.  Build-defined in 3D: the reference never runs DCN on 5-D input.
+ *   x [N,D,H,W,C] NDHWC; offset [N,Do,Ho,Wo, dg*K*3]; mask [N,Do,Ho,Wo, dg*K] or NULL (K = kd*kh*kw);
+ *   columns / grad_columns [npos][K][C] for the chunk of output positions [pos0, pos0+npos) (flattened n,od,oh,ow).
+ *   col2im: grad_x [N,D,H,W,C] += (fp32 atomics; PRE-ZEROED by the caller; may be NULL), grad_offset / grad_mask
+ *   are WRITTEN for the chunk's positions (may be NULL).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  int n, d, h, w, c;
+  int kd, kh, kw, sd, sh, sw, pd, ph, pw, dil_d, dil_h, dil_w;
+  int dg;
+  long long pos0, npos;
+} mr3d_deform_conv3d_desc;
+int mr3d_deform_im2col3d(const mr3d_deform_conv3d_desc *d, const float *x, const float *offset, const float *mask,
+                         float *columns, mr3d_stream_t s);
+int mr3d_deform_col2im3d(const mr3d_deform_conv3d_desc *d, const float *x, const float *offset, const float *mask,
+                         const float *grad_columns, float *grad_x, float *grad_offset, float *grad_mask, mr3d_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
  * ResNet3D stem -- Conv3d(3, 16, kernel 7, stride (1,2,2), padding 3) + folded BN + ReLU, forward and weight
  * gradient (mmdet/models/backbones/resnet3d.py:397-409,467-469), specialised: reads the volume in the
  * reference's own planar [N,3,D,H,W] layout, writes / reads NDHWC [N,D,H/2,W/2,16].
