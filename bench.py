@@ -117,8 +117,11 @@ def ops_microbench(dev):
         dets = torch.cat([boxes, torch.rand(n, 1, generator=g)], 1).to(dev)
         tot += timed(lambda: nms_cuda.nms_3d(dets, 0.7))
     out['nms3d_us_per_vol'] = 2 * tot
-    # RoIAlign3D: 512 rois x 64 ch x (3,7,7) and 128 rois x (10,14,14) on a channels-last P2 map, forward+backward
-    feat = torch.randn(1, 64, 40, 128, 128, device=dev).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
+    # RoIAlign3D through SingleRoIExtractor over P2..P5: 512 rois x 64 ch x (3,7,7) and 128 rois x
+    # (10,14,14); roi sizes log-uniform [4,128] px in xy and [2,40] in z, mapped to levels by the reference's rule
+    from mr3d_amd.detector import SingleRoIExtractor
+    feats = [torch.randn(1, 64, d, h, h, device=dev).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
+             for d, h in ((40, 128), (20, 64), (10, 32), (5, 16))]
     rng = np.random.default_rng(0)
 
     def rois(n):
@@ -129,13 +132,16 @@ def ops_microbench(dev):
                             dtype=torch.float32, device=dev)
 
     for tag, n, osz, od in (('bbox', 512, 7, 3), ('mask', 128, 14, 10)):
-        layer, r = RoIAlign3D(osz, od, 0.25, 0.5, sample_num=2), rois(n)
-        out[f'roialign3d_{tag}_fwd_us'] = timed(lambda: layer(feat.detach(), r))
+        ext = SingleRoIExtractor(dict(type='RoIAlign3D', out_size=osz, out_size_depth=od, sample_num=2), 64,
+                                 [4, 8, 16, 32], [2, 4, 8, 16])
+        r = rois(n)
+        out[f'roialign3d_{tag}_fwd_us'] = timed(lambda: ext([f.detach() for f in feats], r))
         top = torch.randn(n, 64, od, osz, osz, device=dev)
 
         def fb():
-            feat.grad = None
-            layer(feat, r).backward(top)
+            for f in feats:
+                f.grad = None
+            ext(feats, r).backward(top)
         out[f'roialign3d_{tag}_fwd_bwd_us'] = timed(fb, iters=5)
     return out
 

@@ -178,3 +178,25 @@ def test_roi_align3d_error_conventions(dev):
     with pytest.raises(RuntimeError):
         roi_align_cuda.forward3d(f.permute(0, 1, 3, 2, 4), torch.zeros((2, 7), device=dev), 3, 7, 7, 0.25, 0.5, 2, out)
     assert roi_align_cuda.forward3d(f, torch.zeros((0, 7), device=dev), 3, 7, 7, 0.25, 0.5, 2, out[:0]) == 1
+
+
+def test_single_roi_extractor_levels_golden_and_forward(dev, golden_dir):
+    """SingleRoIExtractor: level map against the reference's map_roi_levels (golden), forward against per-level oracle calls"""
+    from mr3d_amd.detector import SingleRoIExtractor
+    g = np.load(f'{golden_dir}/roi_levels.npz')
+    ext = SingleRoIExtractor(dict(type='RoIAlign3D', out_size=7, out_size_depth=3, sample_num=2), 8, [4, 8, 16, 32], [2, 4, 8, 16])
+    lv = ext.map_roi_levels(torch.from_numpy(g['rois']).to(dev), 4)
+    np.testing.assert_array_equal(lv.cpu().numpy(), g['levels'])
+    rng = np.random.default_rng(8)
+    feats_np = [rng.normal(size=(1, 8, d, h, h)).astype(np.float32) for d, h in ((20, 48), (10, 24), (5, 12), (3, 6))]
+    rois = g['rois'][:60].copy()
+    rois[:, [1, 3]] = np.clip(rois[:, [1, 3]], 0, 191); rois[:, [2, 4]] = np.clip(rois[:, [2, 4]], 0, 191); rois[:, [5, 6]] = np.clip(rois[:, [5, 6]], 0, 39)
+    for fmt in (torch.contiguous_format, torch.channels_last_3d):
+        feats = [torch.from_numpy(f).to(dev).contiguous(memory_format=fmt) for f in feats_np]
+        out = ext(feats, torch.from_numpy(rois).to(dev)).cpu().numpy()
+        lvl = ext.map_roi_levels(torch.from_numpy(rois), 4).numpy()
+        for i in range(4):
+            sel = np.nonzero(lvl == i)[0]
+            if len(sel):
+                exp = orc.roi_align3d_forward(feats_np[i], rois[sel], 3, 7, 7, 1 / [4, 8, 16, 32][i], 1 / [2, 4, 8, 16][i], 2)
+                np.testing.assert_allclose(out[sel], exp, rtol=RTOL, atol=ATOL)
