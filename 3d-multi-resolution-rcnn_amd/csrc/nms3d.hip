@@ -151,14 +151,19 @@ __global__ __launch_bounds__(kSweepThreads) void nms3d_sweep_kernel(const uint64
       const uint64_t diag = (row < n) ? mask[(size_t)row * cb + b] : 0ull;
       const int rows = min(64, n - b * 64);
       const uint64_t valid = (rows == 64) ? ~0ull : ((1ull << rows) - 1ull);
-      uint64_t avail = mr3d_uniform64(~remv[b] & valid);   // wave-uniform: lives in SGPRs
-      uint64_t kept = 0;
-      while (avail) {
-        const int t = __builtin_ctzll(avail);
-        kept |= 1ull << t;
-        avail &= ~mr3d_readlane64(diag, t);
-        avail &= ~(1ull << t);
+      // greedy resolution inside the block.  Only rows whose diagonal word is non-zero can suppress anything, so the
+      // serial chain walks those rows only (a row with an empty word is kept iff nobody before it suppressed it):
+      //   cur = bits suppressed so far;  for t in (rows that may suppress, ascending, still alive): cur |= diag[t]
+      uint64_t cur = mr3d_uniform64(remv[b]);              // wave-uniform: lives in SGPRs
+      uint64_t cand = (uint64_t)__ballot(diag != 0ull) & ~cur & valid;
+      while (cand) {
+        const int t = __builtin_ctzll(cand);
+        const uint64_t d = mr3d_readlane64(diag, t);
+        cur |= d;
+        cand &= ~d;
+        cand &= ~(1ull << t);
       }
+      const uint64_t kept = ~cur & valid;
       if (lane == 0) *bcast = kept;
       if ((kept >> lane) & 1ull) {
         const int oi = order[row];
