@@ -233,6 +233,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
+    def committed_traffic(kernel_key):
+        """HBM bytes per launch of `kernel_key` from the committed rocprofv3 PMC passes of this same command
+        (profiles/<round>/traffic.json: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs, FETCH_SIZE doubled per the
+        gfx950 note of MI355X_MICROARCH.md); None when no pass covers the kernel."""
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*', 'traffic.json')), reverse=True):
+            try:
+                k = json.load(open(path))['kernels'].get(kernel_key)
+            except (OSError, ValueError, KeyError):
+                continue
+            if k:
+                return k['hbm_read_bytes_per_launch'] + k['hbm_write_bytes_per_launch']
+        return None
+
     if rank == 0:
         dom_ms = sum(s.elapsed_time(e) for e1, e2 in dom_events for (s, e) in list(e1.values()) + list(e2.values()))
         launches = a.steps * groups[dom]['n']
@@ -248,7 +262,7 @@ def main():
                                    ('' if world == 1 else ' + flat-gradient all-reduce over RCCL'),
                        'global_batch': world, 'parallelism': f'dp{world}'},
             'roofline': {'bound': 'mfma', 'kernel': dom, 'achieved': ach / 1e12, 'peak': PEAK_FP32_MATRIX / 1e12,
-                         'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_MATRIX, 'traffic': None,
+                         'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_MATRIX, 'traffic': committed_traffic(dom),
                          'avg_launch_ms': dom_ms / launches, 'launches_per_step': groups[dom]['n'],
                          'whole_step_frac': FLOP_FWD_BWD_512 * scale / (ms_per_step * 1e-3) / PEAK_FP32_MATRIX},
         }
