@@ -62,14 +62,83 @@ int run_one(const mr3d_op &o, mr3d_stream_t s) {
 
 }  // namespace
 
+namespace {
+
+// Side stream for weight-gradient kernels.  In the backward pass the data-gradient chain is the critical path;
+// every wgrad only READS (x, dy) and adds into its own scratch slice, so it can run beside the chain.  Many of
+// them are small (layer3/4: tens of workgroups) and would otherwise leave most of the 256 CUs idle one after
+// another.  Fork: event recorded on the caller's stream right before the op -> side stream waits on it.
+// Join: before FINISH_GRADS and at the end of every call.
+struct SideStream {
+  hipStream_t streams[4] = {};
+  int nstreams = 1;
+  hipEvent_t joins[4] = {};
+  hipEvent_t fork[16] = {};
+  int next = 0;
+  bool ok = false;
+  bool init() {
+    if (ok) return true;
+    if (const char *e = getenv("MR3D_SIDE_STREAMS")) nstreams = atoi(e) < 1 ? 1 : (atoi(e) > 4 ? 4 : atoi(e));
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    int prio = 0;
+    if (const char *e = getenv("MR3D_SIDE_PRIO")) prio = atoi(e) > 0 ? lo : (atoi(e) < 0 ? hi : 0);
+    for (int i = 0; i < nstreams; ++i) {
+      if (hipStreamCreateWithPriority(&streams[i], hipStreamNonBlocking, prio) != hipSuccess) return false;
+      if (hipEventCreateWithFlags(&joins[i], hipEventDisableTiming) != hipSuccess) return false;
+    }
+    for (auto &e : fork)
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+    ok = true;
+    return true;
+  }
+};
+SideStream g_side;
+int g_side_enabled = 1;
+
+bool wants_side(const mr3d_op &o) {
+  return o.i[26] == 1 && (o.kind == MR3D_OP_CONV_WGRAD || o.kind == MR3D_OP_STEM_WGRAD);
+}
+
+}  // namespace
+
+extern "C" void mr3d_plan_set_side_stream(int enable) { g_side_enabled = enable; }
+
 extern "C" int mr3d_plan_run(const mr3d_op *ops, int num_ops, int *failed_index, mr3d_stream_t stream) {
   if (!ops || num_ops < 0) return MR3D_ERR_INVALID_ARG;
+  hipStream_t main_s = mr3d_stream(stream);
+  // a single-op call (used to time one kernel) always runs on the caller's stream
+  const bool use_side = g_side_enabled && num_ops > 1 && g_side.init();
+  bool side_busy = false;
+  int nside = 0;
+  auto join = [&]() {
+    if (!side_busy) return true;
+    side_busy = false;
+    for (int i = 0; i < g_side.nstreams; ++i)
+      if (hipEventRecord(g_side.joins[i], g_side.streams[i]) != hipSuccess || hipStreamWaitEvent(main_s, g_side.joins[i], 0) != hipSuccess)
+        return false;
+    return true;
+  };
   for (int k = 0; k < num_ops; ++k) {
-    const int st = run_one(ops[k], stream);
+    int st;
+    if (use_side && wants_side(ops[k])) {
+      hipEvent_t ev = g_side.fork[g_side.next++ & 15];
+      hipStream_t ss = g_side.streams[nside++ % g_side.nstreams];
+      if (hipEventRecord(ev, main_s) != hipSuccess || hipStreamWaitEvent(ss, ev, 0) != hipSuccess) {
+        if (failed_index) *failed_index = k;
+        return MR3D_ERR_LAUNCH;
+      }
+      st = run_one(ops[k], (mr3d_stream_t)ss);
+      side_busy = true;
+    } else {
+      if (ops[k].kind == MR3D_OP_FINISH_GRADS && !join()) st = MR3D_ERR_LAUNCH;
+      else st = run_one(ops[k], stream);
+    }
     if (st != MR3D_OK) {
       if (failed_index) *failed_index = k;
+      join();
       return st;
     }
   }
-  return MR3D_OK;
+  return join() ? MR3D_OK : MR3D_ERR_LAUNCH;
 }

@@ -248,6 +248,7 @@ class ExtractFeat3D(nn.Module):
     def _conv_wgrad(self, x, dy, spec):
         n, d, h, w, _ = x.shape
         ints = [n, d, h, w, spec.cin_pad, spec.cout, spec.k, spec.k, spec.k, *spec.stride, spec.pad, spec.pad, spec.pad]
+        ints = ints + [0] * (26 - len(ints)) + [1]          # i[26] = 1: may run on the plan's side stream
         return _hip.make_op(_hip.OP_CONV_WGRAD, [x, dy, self._s(spec, 'dwraw'), self._s(spec, 'dbias')], ints)
 
     def _new(self, shape, dtype=torch.float32):
@@ -380,7 +381,7 @@ class ExtractFeat3D(nn.Module):
             bwd.append(self._conv_wgrad(P.x4, g_stem, stem))
         else:
             bwd.append(_hip.make_op(_hip.OP_STEM_WGRAD, [P.x_in, g_stem, self._s(stem, 'dwraw'), self._s(stem, 'dbias')],
-                                    [N, D, H, W]))
+                                    [N, D, H, W] + [0] * 22 + [1]))
         bwd.append(_hip.make_op(_hip.OP_FINISH_GRADS, [self._table, self._arena, self._scratch, self._grad_arena],
                                 [nL, self.max_cout]))
         P.fwd_ops, P.bwd_ops = fwd, bwd

@@ -190,7 +190,7 @@ def main():
     # ---- warmup; the last warmup step is bracketed op by op to find the dominant kernel
     for _ in range(max(a.warmup - 1, 0)):
         step()
-    ev, evb = step(list(range(plan.fwd.n)), list(range(plan.bwd.n)))
+    ev, evb = step(list(range(plan.fwd.n)), list(range(plan.bwd.n)))     # op-by-op calls: each runs on the main stream
     torch.cuda.synchronize()
     groups = {}
     for which, events, p in (('f', ev, plan.fwd), ('b', evb, plan.bwd)):

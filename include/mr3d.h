@@ -291,6 +291,10 @@ typedef struct {
   void *p[8];
 } mr3d_op;
 int mr3d_plan_run(const mr3d_op *ops_host, int num_ops, int *failed_index_host, mr3d_stream_t stream);
+/* CONV_WGRAD / STEM_WGRAD records with i[26] == 1 run on an internal side stream beside the data-gradient chain
+ * (fork by event before the op, join before FINISH_GRADS and at the end of the call); they only read activations
+ * and add into their own scratch slice.  0 disables the side stream (everything on `stream`); default 1. */
+void mr3d_plan_set_side_stream(int enable);
 
 #ifdef __cplusplus
 }
