@@ -185,6 +185,29 @@ def conv3d_forward(x, w_packed, k, stride, pad, shift=None, add1=None, add2=None
     return y
 
 
+def conv3d_dgrad_s2k3(dy, wb_packed, dx_shape, add1=None, add2=None, mask=None, out=None):
+    """Data gradient of a kernel-3/stride-2/pad-1 conv without zero-stuffing (mr3d_conv3d_dgrad_s2k3).
+    dy: [N,Do,Ho,Wo,Cout_fwd]; wb_packed: [27,Cout_fwd,Cin_fwd] flipped/transposed taps; returns dx [N,D,H,W,Cin_fwd]."""
+    assert dy.is_cuda and dy.is_contiguous() and dy.dtype == torch.float32 and dy.dim() == 5
+    assert wb_packed.is_contiguous() and wb_packed.size(0) == 27 and wb_packed.size(1) == dy.size(4)
+    dx = out if out is not None else torch.empty(tuple(dx_shape), dtype=torch.float32, device=dy.device)
+    assert tuple(dx.shape) == tuple(dx_shape) and dx.is_contiguous() and dx.size(4) == wb_packed.size(2)
+    for t in (add1, add2, mask):
+        assert t is None or (tuple(t.shape) == tuple(dx.shape) and t.is_contiguous())
+    d = Conv3dDesc()
+    d.x, d.w, d.y = dy.data_ptr(), wb_packed.data_ptr(), dx.data_ptr()
+    d.add1, d.add2, d.mask = _opt(add1), _opt(add2), _opt(mask)
+    d.n, d.d, d.h, d.w_in, d.cin, d.cout = dy.size(0), dy.size(1), dy.size(2), dy.size(3), dy.size(4), dx.size(4)
+    d.kd = d.kh = d.kw = 3
+    d.sd = d.sh = d.sw = 2
+    d.pd = d.ph = d.pw = 1
+    d.y_d, d.y_h, d.y_w = dx.size(1), dx.size(2), dx.size(3)
+    with torch.cuda.device(dy.device):
+        st = lib().mr3d_conv3d_dgrad_s2k3(ctypes.byref(d), stream_ptr(dy.device))
+    check(st, 'mr3d_conv3d_dgrad_s2k3')
+    return dx
+
+
 class Conv3dWgradDesc(ctypes.Structure):
     """mr3d_conv3d_wgrad_desc (include/mr3d.h)"""
     _fields_ = [(n, ctypes.c_void_p) for n in ('x', 'dy', 'dw', 'dbias')] + \
@@ -214,7 +237,7 @@ def conv3d_wgrad(x, dy, dw_packed, k, stride, pad, dbias=None):
 # plan records (mr3d_op / mr3d_layer_desc in include/mr3d.h)
 OP_CONV_FWD, OP_CONV_WGRAD, OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_ZERO_STUFF2, OP_UPSAMPLE_ADJ = 1, 2, 3, 4, 5, 6
 OP_SUBSAMPLE_FWD, OP_SUBSAMPLE_BWD, OP_VOLUME_PACK, OP_MEMSET0, OP_AXPY, OP_PREP_WEIGHTS, OP_FINISH_GRADS = 7, 8, 9, 10, 11, 12, 13
-OP_STEM_FWD, OP_STEM_WGRAD = 14, 15
+OP_STEM_FWD, OP_STEM_WGRAD, OP_CONV_DGRAD_S2 = 14, 15, 16
 
 
 class Op(ctypes.Structure):
@@ -299,6 +322,10 @@ def op_kernel_key(op):
         flops = 2.0 * n * do * ho * wo * cout * real_cin * k ** 3
         name = 'conv3d_fwd' if op.kind == OP_CONV_FWD else 'conv3d_wgrad'
         return f'{name}<k{k},s{sd}{sh}{sw},cc{cc},nb{nb}>', flops
+    if op.kind == OP_CONV_DGRAD_S2:      # i[1:4] = dy's (coarse) grid; every dy element meets each of the 27 taps once
+        n, d, h, w, cin, cout = i[0], i[1], i[2], i[3], i[4], i[5]
+        nb = 64 if cout % 64 == 0 else (32 if cout % 32 == 0 else 16)
+        return f'conv3d_dgrad_s2k3<cc16,nb{nb}>', 2.0 * n * d * h * w * cin * cout * 27
     if op.kind in (OP_STEM_FWD, OP_STEM_WGRAD):
         n, d, h, w = i[0], i[1], i[2], i[3]
         flops = 2.0 * n * d * ((h - 1) // 2 + 1) * ((w - 1) // 2 + 1) * 16 * 3 * 343

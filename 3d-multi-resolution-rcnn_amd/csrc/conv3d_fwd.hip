@@ -25,8 +25,11 @@ namespace {
 
 constexpr int kThreads = 256;
 
-template <int KD, int KH, int KW, int SD_, int SH_, int SW_, int TD_, int TH_, int TW_, int CC_, int NB_>
+// PAR_: the parity-decomposed data gradient of a stride-2 3x3x3 convolution (see conv3d_dgrad_s2k3 below); the
+// kernel extents are then the per-axis MAXIMUM (2) and the taps actually walked are chosen per parity class.
+template <int KD, int KH, int KW, int SD_, int SH_, int SW_, int TD_, int TH_, int TW_, int CC_, int NB_, bool PAR_ = false>
 struct FwdCfg {
+  static constexpr bool PAR = PAR_;
   static constexpr int kD = KD, kH = KH, kW = KW;
   static constexpr int SD = SD_, SH = SH_, SW = SW_, TD = TD_, TH = TH_, TW = TW_, CC = CC_, NB = NB_;
   // halo block: (T-1)*S + K input positions per axis; a pointwise (K == 1) strided conv only
@@ -75,6 +78,16 @@ __global__ __launch_bounds__(kThreads) void conv3d_fwd_kernel(Conv3dFwdArgs p, i
   const int od0 = td_i * C::TD, oh0 = th_i * C::TH, ow0 = tw_i * C::TW;
   const int id0 = od0 * C::SD - p.pd, ih0 = oh0 * C::SH - p.ph, iw0 = ow0 * C::SW - p.pw;
   const int n0 = blockIdx.y * C::NB;
+  // parity class of the outputs this workgroup produces (PAR only); the 8-tap class is scheduled first
+  const int cls = C::PAR ? 7 - (int)blockIdx.z : 0;
+  const int ad = (cls >> 2) & 1, ah = (cls >> 1) & 1, aw = cls & 1;
+  const int nkd = C::PAR ? 1 + ad : C::kD, nkh = C::PAR ? 1 + ah : C::kH, nkw = C::PAR ? 1 + aw : C::kW;
+  const int ntaps = nkd * nkh * nkw;
+  // tap (kd,kh,kw) of the walk -> index into the weight array (PAR: taps {1} or {0,2} of the flipped 3x3x3 kernel)
+  auto wtap = [&](int kd_, int kh_, int kw_) {
+    if constexpr (C::PAR) return (((ad ? 2 * kd_ : 1) * 3 + (ah ? 2 * kh_ : 1)) * 3 + (aw ? 2 * kw_ : 1));
+    else return (kd_ * C::kH + kh_) * C::kW + kw_;
+  };
 
   const int li = lane % C::TM;     // row (A) / column (B) inside the MFMA tile
   const int lk = lane / C::TM;     // k index inside the MFMA k-step
@@ -114,11 +127,13 @@ __global__ __launch_bounds__(kThreads) void conv3d_fwd_kernel(Conv3dFwdArgs p, i
     const float *wc = wlane + (size_t)c0 * p.Cout;
     float bc[C::KK], bn[C::KK];
 #pragma unroll
-    for (int kk = 0; kk < C::KK; ++kk) bc[kk] = wc[(size_t)kk * C::KSTEP * p.Cout];
+    for (int kk = 0; kk < C::KK; ++kk) bc[kk] = (wc + (size_t)wtap(0, 0, 0) * p.Cin * p.Cout)[(size_t)kk * C::KSTEP * p.Cout];
     int kd = 0, kh = 0, kw = 0;
-    for (int tap = 0; tap < C::TAPS; ++tap) {
-      if (tap + 1 < C::TAPS) {
-        const float *wn = wc + (size_t)(tap + 1) * p.Cin * p.Cout;
+    for (int tap = 0; tap < ntaps; ++tap) {
+      if (tap + 1 < ntaps) {
+        int kw2 = kw + 1, kh2 = kh, kd2 = kd;
+        if (kw2 == nkw) { kw2 = 0; if (++kh2 == nkh) { kh2 = 0; ++kd2; } }
+        const float *wn = wc + (size_t)(C::PAR ? wtap(kd2, kh2, kw2) : tap + 1) * p.Cin * p.Cout;
 #pragma unroll
         for (int kk = 0; kk < C::KK; ++kk) bn[kk] = wn[(size_t)kk * C::KSTEP * p.Cout];
       }
@@ -138,7 +153,7 @@ __global__ __launch_bounds__(kThreads) void conv3d_fwd_kernel(Conv3dFwdArgs p, i
       }
 #pragma unroll
       for (int kk = 0; kk < C::KK; ++kk) bc[kk] = bn[kk];
-      if (++kw == C::kW) { kw = 0; if (++kh == C::kH) { kh = 0; ++kd; } }
+      if (++kw == nkw) { kw = 0; if (++kh == nkh) { kh = 0; ++kd; } }
     }
   }
 
@@ -153,8 +168,16 @@ __global__ __launch_bounds__(kThreads) void conv3d_fwd_kernel(Conv3dFwdArgs p, i
       const int m = wave_m * C::WROWS + mt * C::TM + row;
       const int tw = m % C::TW, th = (m / C::TW) % C::TH, td = m / (C::TW * C::TH);
       const int od = od0 + td, oh = oh0 + th, ow = ow0 + tw;
-      if (od < p.Do && oh < p.Ho && ow < p.Wo) {
-        const size_t idx = ((((size_t)n * p.yD + od * p.ysd) * p.yH + oh * p.ysh) * p.yW + ow * p.ysw) * p.Cout + co;
+      bool inside = od < p.Do && oh < p.Ho && ow < p.Wo;
+      size_t idx;
+      if constexpr (C::PAR) {
+        const int fd = 2 * od + ad, fh = 2 * oh + ah, fw = 2 * ow + aw;
+        inside = inside && fd < p.yD && fh < p.yH && fw < p.yW;
+        idx = ((((size_t)n * p.yD + fd) * p.yH + fh) * p.yW + fw) * p.Cout + co;
+      } else {
+        idx = ((((size_t)n * p.yD + od * p.ysd) * p.yH + oh * p.ysh) * p.yW + ow * p.ysw) * p.Cout + co;
+      }
+      if (inside) {
         float v = acc[mt][r] + sh;
         if (p.add1) v += p.add1[idx];
         if (p.add2) v += p.add2[idx];
@@ -183,7 +206,7 @@ int launch_fwd(const Conv3dFwdArgs &a, hipStream_t stream) {
     }
     attr_done = true;
   }
-  dim3 grid((unsigned)(a.N * tiles_d * tiles_h * tiles_w), (unsigned)(a.Cout / C::NB));
+  dim3 grid((unsigned)(a.N * tiles_d * tiles_h * tiles_w), (unsigned)(a.Cout / C::NB), C::PAR ? 8u : 1u);
   conv3d_fwd_kernel<C><<<grid, kThreads, C::LDS_BYTES, stream>>>(a, tiles_d, tiles_h, tiles_w);
   return mr3d_launch_status();
 }
@@ -230,6 +253,24 @@ int dispatch_s2(const Conv3dFwdArgs &a, hipStream_t stream) {
   } else {
     if (wgs(2, 8, 8) >= 512) return launch_fwd<FwdCfg<3, 3, 3, 2, 2, 2, 2, 8, 8, 16, NB>>(a, stream);
     return launch_fwd<FwdCfg<3, 3, 3, 2, 2, 2, 2, 4, 8, 16, NB>>(a, stream);
+  }
+}
+
+// Parity-decomposed data gradient of a stride-2, pad-1 3x3x3 convolution.  Along each axis dx[2j] only meets the
+// centre tap (dy[j] * W[1]) and dx[2j+1] the two outer ones (dy[j] * W[2] + dy[j+1] * W[0]), so the 8 output parity
+// classes are stride-1 correlations of the COARSE dy with 1..8 of the 27 taps (27 tap-visits for 8 outputs instead
+// of the 216 of a zero-stuffed dense pass).  One launch: blockIdx.z = class, outputs scattered to 2*o + parity.
+template <int NB>
+int dispatch_par(const Conv3dFwdArgs &a, hipStream_t stream) {
+  auto wgs = [&](int td, int th, int tw) {
+    return 8LL * a.N * ((a.Do + td - 1) / td) * ((a.Ho + th - 1) / th) * ((a.Wo + tw - 1) / tw) * (a.Cout / NB);
+  };
+  if (wgs(4, 8, 8) >= 1024) return launch_fwd<FwdCfg<2, 2, 2, 1, 1, 1, 4, 8, 8, 16, NB, true>>(a, stream);
+  if constexpr (NB == 32) {
+    return launch_fwd<FwdCfg<2, 2, 2, 1, 1, 1, 2, 8, 8, 16, NB, true>>(a, stream);
+  } else {
+    if (wgs(2, 8, 8) >= 1024) return launch_fwd<FwdCfg<2, 2, 2, 1, 1, 1, 2, 8, 8, 16, NB, true>>(a, stream);
+    return launch_fwd<FwdCfg<2, 2, 2, 1, 1, 1, 2, 4, 8, 16, NB, true>>(a, stream);
   }
 }
 
@@ -282,6 +323,28 @@ extern "C" int mr3d_conv3d_forward(const mr3d_conv3d_desc *d, mr3d_stream_t stre
     }
   } else if (k == 7 && s == 122) {
     if (a.Cin == 4 && nb == 16) return launch_fwd<FwdCfg<7, 7, 7, 1, 2, 2, 4, 8, 8, 4, 16>>(a, stream);
+  }
+  return MR3D_ERR_UNSUPPORTED;
+}
+
+extern "C" int mr3d_conv3d_dgrad_s2k3(const mr3d_conv3d_desc *d, mr3d_stream_t stream_) {
+  if (!d || !d->x || !d->w || !d->y) return MR3D_ERR_INVALID_ARG;
+  if (d->y_d <= 0 || d->y_h <= 0 || d->y_w <= 0 || d->shift || d->up || d->relu) return MR3D_ERR_INVALID_ARG;
+  // dy must be the coarse grid of dx under kernel 3 / stride 2 / pad 1
+  if (d->d != (d->y_d - 1) / 2 + 1 || d->h != (d->y_h - 1) / 2 + 1 || d->w_in != (d->y_w - 1) / 2 + 1) return MR3D_ERR_INVALID_ARG;
+  if (d->n <= 0 || d->cin % 16 != 0) return MR3D_ERR_UNSUPPORTED;
+  Conv3dFwdArgs a;
+  a.x = d->x; a.w = d->w; a.y = d->y; a.shift = nullptr; a.add1 = d->add1; a.add2 = d->add2; a.up = nullptr; a.mask = d->mask;
+  a.N = d->n; a.D = d->d; a.H = d->h; a.W = d->w_in; a.Cin = d->cin; a.Cout = d->cout;
+  a.pd = a.ph = a.pw = 0;
+  a.Do = d->d; a.Ho = d->h; a.Wo = d->w_in;          // class grid = dy's grid
+  a.Du = a.Hu = a.Wu = 0; a.relu = 0;
+  a.ysd = a.ysh = a.ysw = 2; a.yD = d->y_d; a.yH = d->y_h; a.yW = d->y_w;
+  hipStream_t stream = mr3d_stream(stream_);
+  switch (pick_nb(a.Cout)) {
+    case 16: return dispatch_par<16>(a, stream);
+    case 32: return dispatch_par<32>(a, stream);
+    case 64: return dispatch_par<64>(a, stream);
   }
   return MR3D_ERR_UNSUPPORTED;
 }

@@ -20,6 +20,13 @@ int run_one(const mr3d_op &o, mr3d_stream_t s) {
       memcpy(&d.n, i, sizeof(int) * 25);
       return mr3d_conv3d_forward(&d, s);
     }
+    case MR3D_OP_CONV_DGRAD_S2: {
+      mr3d_conv3d_desc d;
+      d.x = (const float *)p[0]; d.w = (const float *)p[1]; d.y = (float *)p[2]; d.shift = nullptr;
+      d.add1 = (const float *)p[4]; d.add2 = (const float *)p[5]; d.up = nullptr; d.mask = (const float *)p[7];
+      memcpy(&d.n, i, sizeof(int) * 25);
+      return mr3d_conv3d_dgrad_s2k3(&d, s);
+    }
     case MR3D_OP_CONV_WGRAD: {
       mr3d_conv3d_wgrad_desc d;
       d.x = (const float *)p[0]; d.dy = (const float *)p[1]; d.dw = (float *)p[2]; d.dbias = (float *)p[3];

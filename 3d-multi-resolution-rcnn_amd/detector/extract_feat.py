@@ -352,11 +352,11 @@ class ExtractFeat3D(nn.Module):
             if b['stride'] == 1:
                 bwd.append(self._conv_dgrad(g_a2, b['conv2'], g_a1, mask=st['a1']))
             else:
-                stuffed = self._new(st['a1'].shape[:4] + (b['planes'],))
-                n_, do_, ho_, wo_, c_ = g_a2.shape
-                bwd.append(_hip.make_op(_hip.OP_ZERO_STUFF2, [g_a2, stuffed],
-                                        [n_, do_, ho_, wo_, stuffed.shape[1], stuffed.shape[2], stuffed.shape[3], c_]))
-                bwd.append(self._conv_dgrad(stuffed, b['conv2'], g_a1, mask=st['a1']))
+                # strided 3x3x3: parity-decomposed data gradient straight from the coarse g_a2 (no zero-stuffing)
+                sp = b['conv2']
+                ints = self._conv_ints(g_a2.shape, sp.cout, sp.cin_pad, 3, (2, 2, 2), 1, ydims=g_a1.shape[1:4])
+                bwd.append(_hip.make_op(_hip.OP_CONV_DGRAD_S2,
+                                        [g_a2, self._w(sp, 'wb'), g_a1, None, None, None, None, st['a1']], ints))
             bwd.append(self._conv_wgrad(x, g_a1, b['conv1']))
             first_of_stage = b['block'] == 0
             lat_part = gC_lat[b['stage'] - 1] if (first_of_stage and b['stage'] > 0) else None

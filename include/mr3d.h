@@ -116,6 +116,13 @@ typedef struct {
 } mr3d_conv3d_desc;
 int mr3d_conv3d_forward(const mr3d_conv3d_desc *desc, mr3d_stream_t stream);
 
+/* Data gradient of a kernel-3 / stride-2 / pad-1 convolution (resnet3d.py:139, the strided conv2 of the first
+ * bottleneck of layer2-4) WITHOUT zero-stuffing: the 8 output parity classes are computed from the coarse dy with the
+ * 1..8 taps each of them meets.  Same descriptor: x = dy [n,d,h,w_in,cin] (cin = the forward conv's Cout), w = the
+ * flipped/transposed 27-tap weights of mr3d_prepare_weights (wb), y = dx [n,y_d,y_h,y_w,cout] with y_d/y_h/y_w
+ * REQUIRED and d == (y_d-1)/2+1 etc.; add1/add2/mask as in mr3d_conv3d_forward; shift/up/relu must be unset. */
+int mr3d_conv3d_dgrad_s2k3(const mr3d_conv3d_desc *desc, mr3d_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * conv3d weight gradient -- the wgrad half of autograd's backward of the torch.nn.Conv3d calls above
  * (reference: loss.backward() in mmdet/core/utils/dist_utils.py:52-53 reaching the Conv3d modules).
@@ -276,13 +283,14 @@ int mr3d_stem_conv_wgrad(const float *x_ncdhw, const float *dy, float *dw_packed
  *   FINISH_GRADS  p = {table,params,scratch,grads}      i = {num_layers,max_cout}
  *   STEM_FWD      p = {x_ncdhw,w_packed,shift,y}        i = {n,d,h,w,relu}
  *   STEM_WGRAD    p = {x_ncdhw,dy,dw_packed,dbias}      i = {n,d,h,w}
+ *   CONV_DGRAD_S2 p / i as CONV_FWD (mr3d_conv3d_dgrad_s2k3: x = dy, w = wb, y = dx; y_d/y_h/y_w = dx's grid)
  * Returns the first non-OK status; *failed_index (host int, may be NULL) receives the op index.
  * ---------------------------------------------------------------------------------------------- */
 typedef enum {
   MR3D_OP_CONV_FWD = 1, MR3D_OP_CONV_WGRAD = 2, MR3D_OP_MAXPOOL_FWD = 3, MR3D_OP_MAXPOOL_BWD = 4,
   MR3D_OP_ZERO_STUFF2 = 5, MR3D_OP_UPSAMPLE_ADJ = 6, MR3D_OP_SUBSAMPLE_FWD = 7, MR3D_OP_SUBSAMPLE_BWD = 8,
   MR3D_OP_VOLUME_PACK = 9, MR3D_OP_MEMSET0 = 10, MR3D_OP_AXPY = 11, MR3D_OP_PREP_WEIGHTS = 12,
-  MR3D_OP_FINISH_GRADS = 13, MR3D_OP_STEM_FWD = 14, MR3D_OP_STEM_WGRAD = 15
+  MR3D_OP_FINISH_GRADS = 13, MR3D_OP_STEM_FWD = 14, MR3D_OP_STEM_WGRAD = 15, MR3D_OP_CONV_DGRAD_S2 = 16
 } mr3d_op_kind;
 typedef struct {
   int32_t kind;

@@ -168,3 +168,33 @@ def test_pointwise_streaming_forward_epilogues_and_wgrad(dev, cin, cout):
     assert (dw.cpu() - ref).abs().max().item() <= RTOL * ref.abs().max().item()
     sb = dy.sum((0, 2, 3, 4))
     assert (db.cpu() - sb).abs().max().item() <= 1e-4 * dy.abs().sum((0, 2, 3, 4)).max().item()
+
+
+@pytest.mark.parametrize('planes,dhw', [(32, (8, 16, 14)), (64, (7, 11, 9)), (128, (5, 16, 16)), (16, (9, 33, 20)),
+                                        (64, (20, 64, 64))])
+def test_conv3d_dgrad_s2k3_parity_decomposed(dev, planes, dhw):
+    """mr3d_conv3d_dgrad_s2k3 == torch's conv_transpose3d data gradient of the strided conv2 (resnet3d.py:139),
+    with the producing layer's ReLU mask and two residual adds fused; odd and even extents, every Cout tile."""
+    from mr3d_amd import _hip
+    g = torch.Generator().manual_seed(planes + dhw[0])
+    n = 1 if dhw[1] >= 64 else 2
+    w = torch.randn((planes, planes, 3, 3, 3), generator=g) / np.sqrt(planes * 27)
+    do = tuple((v - 1) // 2 + 1 for v in dhw)
+    dy = torch.randn((n, planes) + do, generator=g)
+    a1 = torch.randn((n, planes) + dhw, generator=g)          # the conv's input (post-ReLU activation): mask = a1 > 0
+    add = torch.randn((n, planes) + dhw, generator=g)
+    ref = torch.nn.grad.conv3d_input((n, planes) + dhw, w, dy, stride=2, padding=1)
+    # wb[26 - tap][co][ci] = W[co][ci][tap]   (mr3d_prepare_weights layout)
+    wb = w.permute(2, 3, 4, 0, 1).reshape(27, planes, planes).flip(0).contiguous().to(dev)
+    dx = _hip.conv3d_dgrad_s2k3(_cl(dy).to(dev), wb, (n,) + dhw + (planes,))
+    _check(dx, ref, 'plain')
+    dx = _hip.conv3d_dgrad_s2k3(_cl(dy).to(dev), wb, (n,) + dhw + (planes,), add1=_cl(add).to(dev), mask=_cl(a1).to(dev))
+    _check(dx, torch.where(a1 > 0, ref + add, torch.zeros_like(ref)), 'add+mask')
+
+
+def test_conv3d_dgrad_s2k3_rejects_bad_grid(dev):
+    from mr3d_amd import _hip
+    dy = torch.zeros((1, 4, 4, 4, 32), device=dev)
+    wb = torch.zeros((27, 32, 32), device=dev)
+    with pytest.raises(_hip.Mr3dError):
+        _hip.conv3d_dgrad_s2k3(dy, wb, (1, 10, 8, 8, 32))      # 10 -> coarse 5, not 4
