@@ -305,6 +305,16 @@ class Plan:
         return ev
 
 
+def _narrow_nb(n, do, ho, wo, cout, nb):
+    """mirror of narrow_nb() in csrc/conv3d_fwd.hip: the Cout tile the forward/dgrad dispatch really picks"""
+    def wgs(nb_):
+        th = 8 if nb_ == 32 else 4
+        return n * ((do + 1) // 2) * (-(-ho // th)) * (-(-wo // 8)) * (cout // nb_)
+    while nb > 16 and wgs(nb) < 256:
+        nb //= 2
+    return nb
+
+
 def op_kernel_key(op):
     """identity of the device kernel an op launches (template instance for the conv kernels) + its
     algorithmic FLOPs (2*MAC over the REAL channels; the 3-channel stem is stored padded to 4)"""
@@ -314,6 +324,8 @@ def op_kernel_key(op):
         sd, sh, sw, pd = i[9], i[10], i[11], i[12]
         do, ho, wo = (d + 2 * pd - k) // sd + 1, (h + 2 * pd - k) // sh + 1, (w + 2 * pd - k) // sw + 1
         nb = 64 if cout % 64 == 0 else (32 if cout % 32 == 0 else 16)
+        if op.kind == OP_CONV_FWD:
+            nb = _narrow_nb(n, do, ho, wo, cout, nb)
         if k == 1:
             cc = 64 if cin % 64 == 0 else (32 if cin % 32 == 0 else 16)
         else:
@@ -324,7 +336,7 @@ def op_kernel_key(op):
         return f'{name}<k{k},s{sd}{sh}{sw},cc{cc},nb{nb}>', flops
     if op.kind == OP_CONV_DGRAD_S2:      # i[1:4] = dy's (coarse) grid; every dy element meets each of the 27 taps once
         n, d, h, w, cin, cout = i[0], i[1], i[2], i[3], i[4], i[5]
-        nb = 64 if cout % 64 == 0 else (32 if cout % 32 == 0 else 16)
+        nb = _narrow_nb(n, d, h, w, cout, 64 if cout % 64 == 0 else (32 if cout % 32 == 0 else 16))
         return f'conv3d_dgrad_s2k3<cc16,nb{nb}>', 2.0 * n * d * h * w * cin * cout * 27
     if op.kind in (OP_STEM_FWD, OP_STEM_WGRAD):
         n, d, h, w = i[0], i[1], i[2], i[3]

@@ -20,6 +20,7 @@
 //     64-wide Cout tile and 4(M) x 1(N) otherwise.
 #include "conv3d.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace {
 
@@ -82,7 +83,6 @@ __global__ __launch_bounds__(kThreads) void conv3d_fwd_kernel(Conv3dFwdArgs p, i
   const int cls = C::PAR ? 7 - (int)blockIdx.z : 0;
   const int ad = (cls >> 2) & 1, ah = (cls >> 1) & 1, aw = cls & 1;
   const int nkd = C::PAR ? 1 + ad : C::kD, nkh = C::PAR ? 1 + ah : C::kH, nkw = C::PAR ? 1 + aw : C::kW;
-  const int ntaps = nkd * nkh * nkw;
   // tap (kd,kh,kw) of the walk -> index into the weight array (PAR: taps {1} or {0,2} of the flipped 3x3x3 kernel)
   auto wtap = [&](int kd_, int kh_, int kw_) {
     if constexpr (C::PAR) return (((ad ? 2 * kd_ : 1) * 3 + (ah ? 2 * kh_ : 1)) * 3 + (aw ? 2 * kw_ : 1));
@@ -107,53 +107,99 @@ __global__ __launch_bounds__(kThreads) void conv3d_fwd_kernel(Conv3dFwdArgs p, i
   for (int mt = 0; mt < C::MT; ++mt)
     for (int r = 0; r < (C::k16 ? 4 : 16); ++r) acc[mt][r] = 0.f;
 
-  for (int c0 = 0; c0 < p.Cin; c0 += C::CC) {
-    __syncthreads();
-    // ---- stage the halo block of CC channels: global (NDHWC, 16-B vectors) -> LDS [pos][CC+1]
-    constexpr int Q = C::CC / 4;
-    for (int it = tid; it < C::HP * Q; it += kThreads) {
+  // ---- halo staging, software-pipelined over the Cin chunks: the NEXT chunk's halo block is fetched into registers
+  // before the MFMA loop of the current one and only written to LDS after it (global latency hidden behind the math)
+  constexpr int Q = C::CC / 4;
+  constexpr int NIT = (C::HP * Q + kThreads - 1) / kThreads;
+  float4 stage[NIT];
+  auto fetch = [&](int c0) {
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+      const int it = tid + j * kThreads;
       const int pos = it / Q, q = it - pos * Q;
       const int hw = pos % C::HW, hh = (pos / C::HW) % C::HH, hd = pos / (C::HW * C::HH);
       const int id = id0 + hd * C::GSD, ih = ih0 + hh * C::GSH, iw = iw0 + hw * C::GSW;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
+      if (it < C::HP * Q && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
         v = *reinterpret_cast<const float4 *>(p.x + ((((size_t)n * p.D + id) * p.H + ih) * p.W + iw) * p.Cin + c0 + q * 4);
-      float *d = lds + pos * C::ROW + q * 4;
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      stage[j] = v;
     }
-    __syncthreads();
-
-    // ---- K loop over taps; B fragments prefetched one tap ahead
+  };
+  // ---- weight fragments (B): straight from global/L2 into VGPRs, one ROW of taps (kw = 0..KW-1) at a time, fetched
+  // a whole row ahead of its use -- across Cin-chunk boundaries too -- so that the L2 latency stays hidden even when
+  // a tap is only a handful of MFMAs (small tiles, pointwise convs)
+  constexpr int RT = C::PAR ? 2 : C::kW;
+  const int nrt = C::PAR ? nkw : C::kW;
+  const int nrows = nkd * nkh;
+  float bc[RT][C::KK], bn[RT][C::KK];
+  auto load_row = [&](float (&dst)[RT][C::KK], int c0, int kd_, int kh_) {
     const float *wc = wlane + (size_t)c0 * p.Cout;
-    float bc[C::KK], bn[C::KK];
 #pragma unroll
-    for (int kk = 0; kk < C::KK; ++kk) bc[kk] = (wc + (size_t)wtap(0, 0, 0) * p.Cin * p.Cout)[(size_t)kk * C::KSTEP * p.Cout];
-    int kd = 0, kh = 0, kw = 0;
-    for (int tap = 0; tap < ntaps; ++tap) {
-      if (tap + 1 < ntaps) {
-        int kw2 = kw + 1, kh2 = kh, kd2 = kd;
-        if (kw2 == nkw) { kw2 = 0; if (++kh2 == nkh) { kh2 = 0; ++kd2; } }
-        const float *wn = wc + (size_t)(C::PAR ? wtap(kd2, kh2, kw2) : tap + 1) * p.Cin * p.Cout;
+    for (int t = 0; t < RT; ++t)
+      if (t < nrt) {
+        const float *wt = wc + (size_t)wtap(kd_, kh_, t) * p.Cin * p.Cout;
 #pragma unroll
-        for (int kk = 0; kk < C::KK; ++kk) bn[kk] = wn[(size_t)kk * C::KSTEP * p.Cout];
+        for (int kk = 0; kk < C::KK; ++kk) dst[t][kk] = wt[(size_t)kk * C::KSTEP * p.Cout];
       }
-      const int tapoff = ((kd * C::HH + kh) * C::HW + kw) * C::ROW;
+  };
+  auto mma_row = [&](const float (&bw)[RT][C::KK], int kd_, int kh_) {
 #pragma unroll
-      for (int kk = 0; kk < C::KK; ++kk) {
-        float a[C::MT];
+    for (int t = 0; t < RT; ++t)
+      if (t < nrt) {
+        const int tapoff = ((kd_ * C::HH + kh_) * C::HW + t) * C::ROW;
 #pragma unroll
-        for (int mt = 0; mt < C::MT; ++mt) a[mt] = lds[abase[mt] + tapoff + kk * C::KSTEP];
+        for (int kk = 0; kk < C::KK; ++kk) {
+          float a[C::MT];
 #pragma unroll
-        for (int mt = 0; mt < C::MT; ++mt) {
-          if constexpr (C::k16)
-            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], bc[kk], acc[mt], 0, 0, 0);
-          else
-            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], bc[kk], acc[mt], 0, 0, 0);
+          for (int mt = 0; mt < C::MT; ++mt) a[mt] = lds[abase[mt] + tapoff + kk * C::KSTEP];
+#pragma unroll
+          for (int mt = 0; mt < C::MT; ++mt) {
+            if constexpr (C::k16)
+              acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], bw[t][kk], acc[mt], 0, 0, 0);
+            else
+              acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], bw[t][kk], acc[mt], 0, 0, 0);
+          }
         }
       }
+  };
+  // one row: fetch the row after it (maybe the first row of the next chunk) into `nxt`, then multiply with `cur`
+  auto step = [&](const float (&cur)[RT][C::KK], float (&nxt)[RT][C::KK], int c0, int &kd_, int &kh_) {
+    int kh2 = kh_ + 1, kd2 = kd_, c2 = c0;
+    if (kh2 == nkh) { kh2 = 0; if (++kd2 == nkd) { kd2 = 0; c2 = c0 + C::CC; } }
+    if (c2 < p.Cin) load_row(nxt, c2, kd2, kh2);
+    mma_row(cur, kd_, kh_);
+    kd_ = kd2; kh_ = kh2;
+  };
+
+  load_row(bc, 0, 0, 0);
+  fetch(0);
+  for (int c0 = 0; c0 < p.Cin; c0 += C::CC) {
+    __syncthreads();
 #pragma unroll
-      for (int kk = 0; kk < C::KK; ++kk) bc[kk] = bn[kk];
-      if (++kw == nkw) { kw = 0; if (++kh == nkh) { kh = 0; ++kd; } }
+    for (int j = 0; j < NIT; ++j) {
+      const int it = tid + j * kThreads;
+      if (it < C::HP * Q) {
+        const int pos = it / Q, q = it - pos * Q;
+        float *d = lds + pos * C::ROW + q * 4;
+        d[0] = stage[j].x; d[1] = stage[j].y; d[2] = stage[j].z; d[3] = stage[j].w;
+      }
+    }
+    __syncthreads();
+    if (c0 + C::CC < p.Cin) fetch(c0 + C::CC);
+
+    // ---- K loop over tap rows, ping-ponging the two fragment buffers
+    int kd = 0, kh = 0;
+    int row = 0;
+    for (; row + 1 < nrows; row += 2) {
+      step(bc, bn, c0, kd, kh);
+      step(bn, bc, c0, kd, kh);
+    }
+    if (row < nrows) {        // odd row count: the chunk ends on `bn`; move it back
+      step(bc, bn, c0, kd, kh);
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int kk = 0; kk < C::KK; ++kk) bc[t][kk] = bn[t][kk];
     }
   }
 
@@ -231,8 +277,23 @@ int dispatch_tile(const Conv3dFwdArgs &a, hipStream_t stream) {
   }
 }
 
+// Small feature maps (layer3/4, P4/P5): with the widest Cout tile even the smallest position tile yields fewer
+// workgroups than the chip has CUs and every one of them walks the whole K extent alone.  Narrow the Cout tile
+// (64 -> 32 -> 16) until there are at least as many workgroups as CUs; the halo is re-staged per Cout tile, which is
+// cheap exactly when the map is small.
+inline int narrow_nb(const Conv3dFwdArgs &a, int nb) {
+  auto wgs = [&](int nb_) {
+    const int th = nb_ == 32 ? 8 : 4;      // smallest position tile of that Cout tile: (2,8,8) for 32, else (2,4,8)
+    return (long long)a.N * ((a.Do + 1) / 2) * ((a.Ho + th - 1) / th) * ((a.Wo + 7) / 8) * (a.Cout / nb_);
+  };
+  static const int min_wgs = getenv("MR3D_FWD_MIN_WGS") ? atoi(getenv("MR3D_FWD_MIN_WGS")) : 256;
+  while (nb > 16 && wgs(nb) < min_wgs) nb /= 2;
+  return nb;
+}
+
 template <int K, int SD, int SH, int SW, int CC>
 int dispatch_nb(const Conv3dFwdArgs &a, int nb, hipStream_t stream) {
+  nb = narrow_nb(a, nb);
   switch (nb) {
     case 16: return dispatch_tile<K, SD, SH, SW, CC, 16>(a, stream);
     case 32: return dispatch_tile<K, SD, SH, SW, CC, 32>(a, stream);
@@ -315,7 +376,7 @@ extern "C" int mr3d_conv3d_forward(const mr3d_conv3d_desc *d, mr3d_stream_t stre
     if (a.Cin % 16 == 0) return dispatch_nb<3, 1, 1, 1, 16>(a, nb, stream);
   } else if (k == 3 && s == 222) {
     if (a.Cin % 8 == 0) {
-      switch (nb) {
+      switch (narrow_nb(a, nb)) {
         case 16: return dispatch_s2<16>(a, stream);
         case 32: return dispatch_s2<32>(a, stream);
         case 64: return dispatch_s2<64>(a, stream);
@@ -341,7 +402,7 @@ extern "C" int mr3d_conv3d_dgrad_s2k3(const mr3d_conv3d_desc *d, mr3d_stream_t s
   a.Du = a.Hu = a.Wu = 0; a.relu = 0;
   a.ysd = a.ysh = a.ysw = 2; a.yD = d->y_d; a.yH = d->y_h; a.yW = d->y_w;
   hipStream_t stream = mr3d_stream(stream_);
-  switch (pick_nb(a.Cout)) {
+  switch (narrow_nb(a, pick_nb(a.Cout))) {
     case 16: return dispatch_par<16>(a, stream);
     case 32: return dispatch_par<32>(a, stream);
     case 64: return dispatch_par<64>(a, stream);
