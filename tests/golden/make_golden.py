@@ -17,11 +17,16 @@ Vectors written (each is {inputs..., expected...}):
   roi_levels.npz   mmdet/models/roi_extractors/single_level.py:58-82
   backbone_fpn.npz mmdet/models/backbones/resnet3d.py + necks/fpn3d.py forward/backward
                    with a closed-form weight fill (tests/golden/weightfill.py)
+  targets.npz      mmdet/core/bbox/assigners/max_iou_assigner.py:47-196, samplers/random_sampler.py + base_sampler.py
+                   (numpy's randint draws are RECORDED so that they can be replayed), anchor/anchor_target.py:114-216,
+                   bbox/bbox_target.py:139-165
+  losses.npz       mmdet/core/loss/losses.py (weighted BCE / CE / smooth-L1, accuracy, mask BCE): values + gradients
 
 usage: python tests/golden/make_golden.py   (from the repo root)
 """
 import ast
 import importlib
+import importlib.util
 import os
 import sys
 import types
@@ -105,6 +110,25 @@ def import_reference():
     ns = {'np': np}
     exec(compile(ast.Module(body=[fn], type_ignores=[]), 'coco_utils.nms_3d_python', 'exec'), ns)
     ref.nms_3d_python = ns['nms_3d_python']
+    # target assignment / sampling / losses (section 8(f) rank 1)
+    sys.modules['mmdet.ops'].sigmoid_focal_loss = None
+    bb = sys.modules['mmdet.core.bbox']
+    asg = importlib.import_module('mmdet.core.bbox.assigners')
+    smp = importlib.import_module('mmdet.core.bbox.samplers')
+    sys.modules['mmcv.runner'].obj_from_dict = None
+    asmp = importlib.import_module('mmdet.core.bbox.assign_sampling')
+    for k in ('build_assigner', 'build_sampler', 'assign_and_sample'):
+        setattr(bb, k, getattr(asmp, k))
+    bb.PseudoSampler, bb.bbox2delta, bb.bbox2delta3d = smp.PseudoSampler, ref.tr.bbox2delta, ref.tr.bbox2delta3d
+    misc_spec = importlib.util.spec_from_file_location('refmisc', f'{REF}/mmdet/core/utils/misc.py')
+    misc = importlib.util.module_from_spec(misc_spec)
+    misc_spec.loader.exec_module(misc)
+    _stub('mmdet.core.utils', multi_apply=misc.multi_apply)
+    bt = importlib.import_module('mmdet.core.bbox.bbox_target')
+    ref.at = importlib.import_module('mmdet.core.anchor.anchor_target')
+    ref.MaxIoUAssigner, ref.RandomSampler, ref.bt = asg.MaxIoUAssigner, smp.RandomSampler, bt
+    _pkg('mmdet.core.loss', f'{REF}/mmdet/core/loss')
+    ref.losses = importlib.import_module('mmdet.core.loss.losses')
     return ref
 
 
@@ -273,13 +297,167 @@ def make_backbone(ref, out):
     np.savez_compressed(out, **d)
 
 
+class _RecordRandint:
+    """stand-in for numpy.random.randint that records every draw (random_sampler.py:36)"""
+
+    def __init__(self, seed):
+        self.rng, self.draws = np.random.RandomState(seed), []
+
+    def __call__(self, low=0, high=None, size=None):
+        r = self.rng.randint(low=low, high=high, size=size)
+        self.draws.append(np.asarray(r, np.int64).copy())
+        return r
+
+
+def make_targets(ref, out):
+    rng = np.random.default_rng(77)
+    d = {}
+    real_randint = np.random.randint
+    # ---- RPN stage: anchors of a 128x128x32 volume, shipped rpn train_cfg and a low-threshold variant
+    strides, dstrides, scales = [4, 8, 16, 32, 64], [2, 4, 8, 16, 32], [4]
+    img_shape = (128, 128, 3, 32)          # (h, w, c, d): anchor_target.py:196-199 reads [0], [1], [3]
+    levels = []
+    for st, ds in zip(strides, dstrides):
+        g = ref.ag.AnchorGenerator3D(st, scales, scales, [1.0], ds)
+        fs = (max(32 // ds, 1), 128 // st, 128 // st)
+        levels.append(g.grid_anchors(fs, st, ds, device='cpu'))
+    anchors = torch.cat(levels)
+    for tag, (pos_thr, neg_thr, min_pos, num, frac, pos_weight, border, G) in {
+            'rpn_shipped': (0.7, 0.3, 0.3, 256, 0.5, 3, 0, 4),
+            'rpn_manypos': (0.25, 0.1, 0.1, 64, 0.5, -1, 0, 6),
+            'rpn_border': (0.5, 0.3, 0.3, 256, 0.5, 3, 8, 3)}.items():
+        gt = torch.from_numpy(rand_boxes(rng, G, vol=(128, 128, 32), size_xy=(20, 50), size_z=(10, 24)))
+        if tag == 'rpn_shipped':            # one gt equal to an anchor: IoU exactly 1, and a tie for step 4
+            gt[0] = anchors[5000]
+        valid = torch.ones(anchors.size(0), dtype=torch.uint8)
+        cfg = types.SimpleNamespace(
+            assigner=ref.MaxIoUAssigner(pos_iou_thr=pos_thr, neg_iou_thr=neg_thr, min_pos_iou=min_pos, ignore_iof_thr=-1),
+            sampler=ref.RandomSampler(num=num, pos_fraction=frac, neg_pos_ub=-1, add_gt_as_proposals=False),
+            allowed_border=border, pos_weight=pos_weight)
+        rec = _RecordRandint(1234)
+        np.random.randint = rec
+        try:
+            inside = ref.at.anchor_inside_flags(anchors, valid, img_shape, border)
+            ar = cfg.assigner.assign(anchors[inside.bool(), :], gt, None, None)
+            rec.draws.clear(); rec.rng = np.random.RandomState(1234)
+            res = ref.at.anchor_target_single(anchors, valid, gt, None, None, dict(img_shape=img_shape),
+                                              [0.] * 6, [1.] * 6, cfg)
+        finally:
+            np.random.randint = real_randint
+        labels, label_weights, bbox_targets, bbox_weights, pos_inds, neg_inds, inside_flags = res
+        d.update({f'{tag}_anchors': anchors.numpy(), f'{tag}_gt': gt.numpy(), f'{tag}_img_shape': np.array(img_shape),
+                  f'{tag}_cfg': np.array([pos_thr, neg_thr, min_pos, num, frac, pos_weight, border], np.float64),
+                  f'{tag}_assigned_gt_inds': ar.gt_inds.numpy(), f'{tag}_max_overlaps': ar.max_overlaps.numpy(),
+                  f'{tag}_labels': labels.numpy(), f'{tag}_label_weights': label_weights.numpy(),
+                  f'{tag}_bbox_targets': bbox_targets.numpy(), f'{tag}_bbox_weights': bbox_weights.numpy(),
+                  f'{tag}_pos_inds': pos_inds.numpy(), f'{tag}_neg_inds': neg_inds.numpy(),
+                  f'{tag}_inside_flags': inside_flags.numpy().astype(np.uint8),
+                  f'{tag}_num_draws': np.int64(len(rec.draws))})
+        for k, dr in enumerate(rec.draws):
+            d[f'{tag}_draw{k}'] = dr
+        print(f'  targets {tag}: A={anchors.size(0)} inside={int(inside_flags.sum())} pos={pos_inds.numel()} '
+              f'neg={neg_inds.numel()} draws={[len(x) for x in rec.draws]}')
+    # ---- RCNN stage: proposals clustered around the gts, add_gt_as_proposals=True
+    for tag, (P, G, num, frac, cluster) in {'rcnn_shipped': (2000, 5, 512, 0.25, 12), 'rcnn_fewpos': (300, 3, 512, 0.25, 0),
+                                            'rcnn_small': (40, 2, 16, 0.5, 3)}.items():
+        gt = torch.from_numpy(rand_boxes(rng, G, size_xy=(20, 60), size_z=(6, 20)))
+        props = rand_boxes(rng, P, size_xy=(15, 70), size_z=(5, 24), cluster=cluster)
+        k = P // 3                              # a third of the proposals are jittered copies of the gts
+        src = gt.numpy()[rng.integers(0, G, k)]
+        props[:k] = src + rng.normal(0, 2.0, size=(k, 6)).astype(np.float32)
+        props = torch.from_numpy(np.concatenate([props, rng.uniform(0, 1, (P, 1)).astype(np.float32)], 1))   # [P,7] with score
+        gt_labels = torch.ones(G, dtype=torch.long)
+        asg = ref.MaxIoUAssigner(pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.5, ignore_iof_thr=-1)
+        smp = ref.RandomSampler(num=num, pos_fraction=frac, neg_pos_ub=-1, add_gt_as_proposals=True)
+        rec = _RecordRandint(4321)
+        np.random.randint = rec
+        try:
+            ar = asg.assign(props, gt, None, gt_labels)
+            gt_inds0, max_ov0, labels0 = ar.gt_inds.clone(), ar.max_overlaps.clone(), ar.labels.clone()
+            sr = smp.sample(ar, props, gt, gt_labels)
+        finally:
+            np.random.randint = real_randint
+        cfg = types.SimpleNamespace(pos_weight=3)
+        lab, lw, bt_, bw = ref.bt.bbox_target_single_3d(sr.pos_bboxes, sr.neg_bboxes, sr.pos_gt_bboxes, sr.pos_gt_labels, cfg,
+                                                        1, [0.] * 6, [0.1, 0.1, 0.2, 0.2, 0.1, 0.2])
+        rois = ref.tr.bbox2roi3D([sr.bboxes])
+        d.update({f'{tag}_proposals': props.numpy(), f'{tag}_gt': gt.numpy(), f'{tag}_gt_labels': gt_labels.numpy(),
+                  f'{tag}_cfg': np.array([0.5, 0.5, 0.5, num, frac, 3], np.float64),
+                  f'{tag}_assigned_gt_inds': gt_inds0.numpy(), f'{tag}_max_overlaps': max_ov0.numpy(),
+                  f'{tag}_assigned_labels': labels0.numpy(),
+                  f'{tag}_pos_inds': sr.pos_inds.numpy(), f'{tag}_neg_inds': sr.neg_inds.numpy(),
+                  f'{tag}_pos_is_gt': sr.pos_is_gt.numpy(), f'{tag}_pos_assigned_gt_inds': sr.pos_assigned_gt_inds.numpy(),
+                  f'{tag}_rois': rois.numpy(), f'{tag}_labels': lab.numpy(), f'{tag}_label_weights': lw.numpy(),
+                  f'{tag}_bbox_targets': bt_.numpy(), f'{tag}_bbox_weights': bw.numpy(),
+                  f'{tag}_target_stds': np.array([0.1, 0.1, 0.2, 0.2, 0.1, 0.2], np.float32),
+                  f'{tag}_num_draws': np.int64(len(rec.draws))})
+        for k_, dr in enumerate(rec.draws):
+            d[f'{tag}_draw{k_}'] = dr
+        print(f'  targets {tag}: P={P} pos={sr.pos_inds.numel()} neg={sr.neg_inds.numel()} draws={[len(x) for x in rec.draws]}')
+    np.savez_compressed(out, **d)
+
+
+def make_losses(ref, out):
+    L = ref.losses
+    g = torch.Generator().manual_seed(5)
+    d = {}
+    # RPN: weighted BCE with logits on [A,1] scores (sum / avg_factor) and smooth-L1 (beta 1/9) on [A,6]
+    A = 3000
+    score = torch.randn(A, 1, generator=g, requires_grad=True)
+    labels = (torch.rand(A, generator=g) < 0.05).long()
+    weights = torch.where(torch.rand(A, generator=g) < 0.1, torch.tensor(1.0), torch.tensor(0.0))
+    weights = torch.where(labels > 0, torch.tensor(3.0), weights)
+    loss = L.weighted_binary_cross_entropy(score, labels, weights, avg_factor=256)
+    loss.backward()
+    d.update(bce_score=score.detach().numpy(), bce_labels=labels.numpy(), bce_weights=weights.numpy(), bce_avg=np.float64(256),
+             bce_loss=loss.detach().numpy(), bce_grad=score.grad.numpy())
+    pred = torch.randn(A, 6, generator=g, requires_grad=True)
+    tgt = torch.randn(A, 6, generator=g) * 0.5
+    w6 = (labels > 0).float()[:, None].expand(A, 6).contiguous()
+    loss = L.weighted_smoothl1(pred, tgt, w6, beta=1 / 9.0, avg_factor=256)
+    loss.backward()
+    d.update(sl1_pred=pred.detach().numpy(), sl1_target=tgt.numpy(), sl1_weights=w6.numpy(), sl1_beta=np.float64(1 / 9.0),
+             sl1_avg=np.float64(256), sl1_loss=loss.detach().numpy(), sl1_grad=pred.grad.numpy())
+    # RCNN: weighted softmax CE on [R,2] (avg = #weights>0), accuracy, smooth-L1 (beta 1) on the positives with avg = R
+    R = 512
+    cls = torch.randn(R, 2, generator=g, requires_grad=True)
+    lab = (torch.rand(R, generator=g) < 0.2).long()
+    lw = torch.where(lab > 0, torch.tensor(3.0), torch.tensor(1.0))
+    loss = L.weighted_cross_entropy(cls, lab, lw)
+    loss.backward()
+    acc = L.accuracy(cls.detach(), lab)
+    d.update(ce_score=cls.detach().numpy(), ce_labels=lab.numpy(), ce_weights=lw.numpy(), ce_loss=loss.detach().numpy(),
+             ce_grad=cls.grad.numpy(), ce_acc=acc.numpy())
+    bp = torch.randn(R, 6, generator=g, requires_grad=True)
+    btg = torch.randn(R, 6, generator=g)
+    bw = (lab > 0).float()[:, None].expand(R, 6).contiguous()
+    pos = lab > 0
+    loss = L.weighted_smoothl1(bp.view(R, 6)[pos], btg[pos], bw[pos], avg_factor=btg.size(0))
+    loss.backward()
+    d.update(reg_pred=bp.detach().numpy(), reg_target=btg.numpy(), reg_weights=bw.numpy(), reg_loss=loss.detach().numpy(),
+             reg_grad=bp.grad.numpy())
+    # mask: BCE with logits, mean over [P, 10, 14, 14] of the label-selected channel
+    P = 9
+    mp = torch.randn(P, 2, 10, 14, 14, generator=g, requires_grad=True)
+    mt = (torch.rand(P, 10, 14, 14, generator=g) < 0.4).float()
+    ml = torch.ones(P, dtype=torch.long)
+    loss = L.mask_cross_entropy(mp, mt, ml)
+    loss.backward()
+    d.update(mask_pred=mp.detach().numpy(), mask_target=mt.numpy(), mask_labels=ml.numpy(), mask_loss=loss.detach().numpy(),
+             mask_grad=mp.grad.numpy())
+    np.savez_compressed(out, **d)
+    print('  losses:', {k: float(d[k][0]) for k in ('bce_loss', 'sl1_loss', 'ce_loss', 'reg_loss', 'mask_loss')})
+
+
 if __name__ == '__main__':
     ref = import_reference()
-    which = sys.argv[1:] or ['nms', 'iou', 'codec', 'anchors', 'roi_levels', 'backbone']
+    which = sys.argv[1:] or ['nms', 'iou', 'codec', 'anchors', 'roi_levels', 'backbone', 'targets', 'losses']
     if 'nms' in which: make_nms(ref, f'{HERE}/nms3d.npz')
     if 'iou' in which: make_iou(ref, f'{HERE}/iou3d.npz')
     if 'codec' in which: make_codec(ref, f'{HERE}/codec.npz')
     if 'anchors' in which: make_anchors(ref, f'{HERE}/anchors.npz')
     if 'roi_levels' in which: make_roi_levels(ref, f'{HERE}/roi_levels.npz')
     if 'backbone' in which: make_backbone(ref, f'{HERE}/backbone_fpn.npz')
+    if 'targets' in which: make_targets(ref, f'{HERE}/targets.npz')
+    if 'losses' in which: make_losses(ref, f'{HERE}/losses.npz')
     print('golden vectors written to', HERE)
