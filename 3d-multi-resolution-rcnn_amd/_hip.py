@@ -447,3 +447,218 @@ def rpn_decode_level(flat_idx, scores, reg_map, reg_layout, base_anchors, featma
                                          ctypes.c_double(wh_ratio_clip), ptr(dets), stream_ptr(scores.device))
     check(st, 'mr3d_rpn_decode_level')
     return dets
+
+
+# -------------------------------------------------------------------------------------------- training targets
+def _sz(fn, *args):
+    fn.restype = ctypes.c_size_t
+    return int(fn(*args))
+
+
+def _i64(t, what):
+    if not (t.is_cuda and t.dtype == torch.long and t.is_contiguous()):
+        raise RuntimeError(f'{what} must be a contiguous int64 device tensor')
+    return t
+
+
+def max_iou_assign(boxes, gt, pos_iou_thr, neg_iou_thr, min_pos_iou, gt_labels=None, inside=None, gt_max_assign_all=True):
+    """mr3d_max_iou_assign -> (assigned_gt_inds i64 [n], max_overlaps f32 [n], assigned_labels i64 [n] | None)"""
+    if not (boxes.is_cuda and boxes.dtype == torch.float32 and boxes.dim() == 2 and boxes.stride(1) == 1 and boxes.size(1) >= 6):
+        raise RuntimeError('boxes must be a float32 device tensor [n, >=6] with unit inner stride')
+    gt = _dev_f32(gt[:, :6].contiguous(), 'gt_bboxes')
+    n, g = boxes.size(0), gt.size(0)
+    if n == 0 or g == 0:
+        raise ValueError('No gt or bboxes')                       # max_iou_assigner.py:79-80
+    lo, hi = (0.0, float(neg_iou_thr)) if not isinstance(neg_iou_thr, tuple) else (float(neg_iou_thr[0]), float(neg_iou_thr[1]))
+    dev = boxes.device
+    assigned = torch.empty(n, dtype=torch.long, device=dev)
+    max_ov = torch.empty(n, dtype=torch.float32, device=dev)
+    labels = torch.empty(n, dtype=torch.long, device=dev) if gt_labels is not None else None
+    if gt_labels is not None:
+        gt_labels = _i64(gt_labels.contiguous(), 'gt_labels')
+    if inside is not None:
+        inside = inside.to(torch.uint8).contiguous()
+    L = lib()
+    wsb = _sz(L.mr3d_max_iou_assign_workspace_bytes, n, g)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        st = L.mr3d_max_iou_assign(ptr(boxes), int(boxes.stride(0)), n, ctypes.c_void_p(_opt(inside)), ptr(gt), g,
+                                   ctypes.c_void_p(_opt(gt_labels)), ctypes.c_float(pos_iou_thr), ctypes.c_float(lo),
+                                   ctypes.c_float(hi), ctypes.c_float(min_pos_iou), int(bool(gt_max_assign_all)), ptr(assigned),
+                                   ptr(max_ov), ctypes.c_void_p(_opt(labels)), ptr(ws), ctypes.c_size_t(wsb), stream_ptr(dev))
+    check(st, 'mr3d_max_iou_assign')
+    return assigned, max_ov, labels
+
+
+def device_draws(count, device, generator=None):
+    """`count` uniform 31-bit words on the device (the sampler takes them modulo the candidate count)"""
+    return torch.randint(0, 2 ** 31 - 1, (max(int(count), 1),), dtype=torch.int32, device=device, generator=generator)
+
+
+def _draws(t, need, device, what):
+    if t is None:
+        return device_draws(need, device)
+    t = torch.as_tensor(t).to(device=device, dtype=torch.int32).contiguous()
+    if t.numel() < need:          # short draw lists are fine when the candidates fit (the reference then draws nothing)
+        t = torch.cat([t, torch.zeros(need - t.numel(), dtype=torch.int32, device=device)])
+    return t
+
+
+def random_sample(assigned_gt_inds, num, pos_fraction, neg_pos_ub=-1, draws_pos=None, draws_neg=None, want_sel=False):
+    """mr3d_random_sample -> (pos_inds i64 [int(num*pos_fraction)], neg_inds i64 [num], counts i32 [4], sel i32 [n] | None);
+    lists ascending and padded with -1; nothing is synchronised."""
+    a = _i64(assigned_gt_inds, 'assigned_gt_inds')
+    n, dev = a.numel(), a.device
+    cap_pos = int(num * pos_fraction)
+    pos = torch.empty(max(cap_pos, 1), dtype=torch.long, device=dev)
+    neg = torch.empty(num, dtype=torch.long, device=dev)
+    counts = torch.empty(4, dtype=torch.int32, device=dev)
+    sel = torch.empty(n, dtype=torch.int32, device=dev) if want_sel else None
+    dp, dn = _draws(draws_pos, max(cap_pos, 1), dev, 'draws_pos'), _draws(draws_neg, num, dev, 'draws_neg')
+    L = lib()
+    wsb = _sz(L.mr3d_random_sample_workspace_bytes, n)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        st = L.mr3d_random_sample(ptr(a), n, int(num), ctypes.c_float(pos_fraction), ctypes.c_float(neg_pos_ub), ptr(dp), ptr(dn),
+                                  ptr(pos), ptr(neg), ptr(counts), ctypes.c_void_p(_opt(sel)), ptr(ws), ctypes.c_size_t(wsb),
+                                  stream_ptr(dev))
+    check(st, 'mr3d_random_sample')
+    return pos[:cap_pos], neg, counts, sel
+
+
+def anchor_target(anchors, assigned_gt_inds, sel, gt, means, stds, pos_weight, gt_labels=None):
+    """mr3d_anchor_target -> labels i64 [n], label_weights [n], bbox_targets [n,6], bbox_weights [n,6]"""
+    anchors, gt = _dev_f32(anchors, 'anchors'), _dev_f32(gt[:, :6].contiguous(), 'gt_bboxes')
+    n, dev = anchors.size(0), anchors.device
+    labels = torch.empty(n, dtype=torch.long, device=dev)
+    lw = torch.empty(n, dtype=torch.float32, device=dev)
+    bt = torch.empty((n, 6), dtype=torch.float32, device=dev)
+    bw = torch.empty((n, 6), dtype=torch.float32, device=dev)
+    if gt_labels is not None:
+        gt_labels = _i64(gt_labels.contiguous(), 'gt_labels')
+    with torch.cuda.device(dev):
+        st = lib().mr3d_anchor_target(ptr(anchors), int(anchors.stride(0)), n, ptr(_i64(assigned_gt_inds, 'assigned')), ptr(sel),
+                                      ptr(gt), ctypes.c_void_p(_opt(gt_labels)), _f6(means, [0.] * 6), _f6(stds, [1.] * 6),
+                                      ctypes.c_float(pos_weight), ptr(labels), ptr(lw), ptr(bt), ptr(bw), stream_ptr(dev))
+    check(st, 'mr3d_anchor_target')
+    return labels, lw, bt, bw
+
+
+def concat_gt_assign(assigned_proposals, num_gt):
+    a = _i64(assigned_proposals, 'assigned_gt_inds')
+    out = torch.empty(a.numel() + num_gt, dtype=torch.long, device=a.device)
+    with torch.cuda.device(a.device):
+        st = lib().mr3d_concat_gt_assign(ptr(a), a.numel(), int(num_gt), ptr(out), stream_ptr(a.device))
+    check(st, 'mr3d_concat_gt_assign')
+    return out
+
+
+def bbox_target3d(proposals, gt, gt_labels, assigned_all, pos_inds, neg_inds, counts, cap, batch_index, means, stds, pos_weight):
+    """mr3d_bbox_target3d -> rois [cap,7], labels [cap], label_weights [cap], bbox_targets [cap,6], bbox_weights [cap,6],
+    pos_assigned_gt_inds [cap]"""
+    gt = _dev_f32(gt[:, :6].contiguous(), 'gt_bboxes')
+    dev = gt.device
+    if not (proposals.is_cuda and proposals.dtype == torch.float32 and proposals.stride(1) == 1 and proposals.size(1) >= 6):
+        raise RuntimeError('proposals must be a float32 device tensor [p, >=6] with unit inner stride')
+    rois = torch.empty((cap, 7), dtype=torch.float32, device=dev)
+    labels = torch.empty(cap, dtype=torch.long, device=dev)
+    lw = torch.empty(cap, dtype=torch.float32, device=dev)
+    bt = torch.empty((cap, 6), dtype=torch.float32, device=dev)
+    bw = torch.empty((cap, 6), dtype=torch.float32, device=dev)
+    pgi = torch.empty(cap, dtype=torch.long, device=dev)
+    with torch.cuda.device(dev):
+        st = lib().mr3d_bbox_target3d(ptr(proposals), int(proposals.stride(0)), ptr(gt), gt.size(0),
+                                      ptr(_i64(gt_labels.contiguous(), 'gt_labels')), ptr(_i64(assigned_all, 'assigned_all')),
+                                      ptr(_i64(pos_inds.contiguous(), 'pos_inds')), ptr(_i64(neg_inds.contiguous(), 'neg_inds')),
+                                      ptr(counts), int(cap), int(batch_index), _f6(means, [0.] * 6), _f6(stds, [1.] * 6),
+                                      ctypes.c_float(pos_weight), ptr(rois), ptr(labels), ptr(lw), ptr(bt), ptr(bw), ptr(pgi),
+                                      stream_ptr(dev))
+    check(st, 'mr3d_bbox_target3d')
+    return rois, labels, lw, bt, bw, pgi
+
+
+# -------------------------------------------------------------------------------------------- losses
+_loss_ws = {}
+
+
+def _loss_workspace(device):
+    key = (device.type, device.index)
+    if key not in _loss_ws:
+        _loss_ws[key] = torch.empty(_sz(lib().mr3d_loss_workspace_bytes), dtype=torch.uint8, device=device)
+    return _loss_ws[key]
+
+
+def _avg(avg_factor):
+    """avg_factor: python number or a device float tensor -> (dev_ptr_or_None, host_float)"""
+    if torch.is_tensor(avg_factor):
+        assert avg_factor.is_cuda and avg_factor.dtype == torch.float32 and avg_factor.numel() == 1
+        return ctypes.c_void_p(avg_factor.data_ptr()), ctypes.c_float(0.0)
+    return ctypes.c_void_p(0), ctypes.c_float(float(avg_factor))
+
+
+def avg_factor_from_counts(counts, mode):
+    """counts: i32 [num_imgs, >=2] device tensor of {pos, neg, ...} records -> device float scalar"""
+    counts = counts.reshape(-1, counts.shape[-1]).contiguous()
+    out = torch.empty(1, dtype=torch.float32, device=counts.device)
+    with torch.cuda.device(counts.device):
+        st = lib().mr3d_avg_factor_from_counts(ptr(counts), counts.size(1), counts.size(0), int(mode), ptr(out),
+                                               stream_ptr(counts.device))
+    check(st, 'mr3d_avg_factor_from_counts')
+    return out
+
+
+def weighted_bce_logits(score, labels, weights, avg_factor, want_grad=True):
+    score = _dev_f32(score, 'score')
+    n, c = (score.size(0), score.size(1)) if score.dim() == 2 else (score.numel(), 1)
+    loss = torch.empty(1, dtype=torch.float32, device=score.device)
+    grad = torch.empty_like(score) if want_grad else None
+    ap, ah = _avg(avg_factor)
+    with torch.cuda.device(score.device):
+        st = lib().mr3d_weighted_bce_logits(ptr(score), ptr(_i64(labels.contiguous(), 'labels')), ptr(_dev_f32(weights, 'weights')),
+                                            ctypes.c_longlong(n), c, ap, ah, ptr(loss), ctypes.c_void_p(_opt(grad)),
+                                            ptr(_loss_workspace(score.device)), stream_ptr(score.device))
+    check(st, 'mr3d_weighted_bce_logits')
+    return loss, grad
+
+
+def weighted_smoothl1(pred, target, weights, beta, avg_factor, want_grad=True):
+    pred, target, weights = _dev_f32(pred, 'pred'), _dev_f32(target, 'target'), _dev_f32(weights, 'weights')
+    assert pred.shape == target.shape == weights.shape
+    loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+    grad = torch.empty_like(pred) if want_grad else None
+    ap, ah = _avg(avg_factor)
+    with torch.cuda.device(pred.device):
+        st = lib().mr3d_weighted_smoothl1(ptr(pred), ptr(target), ptr(weights), ctypes.c_longlong(pred.numel()), ctypes.c_float(beta),
+                                          ap, ah, ptr(loss), ctypes.c_void_p(_opt(grad)), ptr(_loss_workspace(pred.device)),
+                                          stream_ptr(pred.device))
+    check(st, 'mr3d_weighted_smoothl1')
+    return loss, grad
+
+
+def weighted_softmax_ce(score, labels, weights, valid_rows=None, want_grad=True):
+    score = _dev_f32(score, 'score')
+    loss = torch.empty(1, dtype=torch.float32, device=score.device)
+    acc = torch.empty(1, dtype=torch.float32, device=score.device)
+    grad = torch.empty_like(score) if want_grad else None
+    with torch.cuda.device(score.device):
+        st = lib().mr3d_weighted_softmax_ce(ptr(score), ptr(_i64(labels.contiguous(), 'labels')), ptr(_dev_f32(weights, 'weights')),
+                                            score.size(0), score.size(1), ctypes.c_void_p(_opt(valid_rows)), ptr(loss), ptr(acc),
+                                            ctypes.c_void_p(_opt(grad)), ptr(_loss_workspace(score.device)),
+                                            stream_ptr(score.device))
+    check(st, 'mr3d_weighted_softmax_ce')
+    return loss, acc, grad
+
+
+def mask_bce(pred, target, labels, valid_rows=None, want_grad=True):
+    pred, target = _dev_f32(pred, 'mask_pred'), _dev_f32(target, 'mask_targets')
+    p, c = pred.size(0), pred.size(1)
+    spatial = pred[0, 0].numel()
+    assert target.numel() == p * spatial
+    loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+    grad = torch.empty_like(pred) if want_grad else None
+    with torch.cuda.device(pred.device):
+        st = lib().mr3d_mask_bce(ptr(pred), ptr(target), ptr(_i64(labels.contiguous(), 'labels')), p, c, ctypes.c_longlong(spatial),
+                                 ctypes.c_void_p(_opt(valid_rows)), ptr(loss), ctypes.c_void_p(_opt(grad)),
+                                 ptr(_loss_workspace(pred.device)), stream_ptr(pred.device))
+    check(st, 'mr3d_mask_bce')
+    return loss, grad

@@ -215,6 +215,82 @@ int mr3d_rpn_decode_level(const long long *flat_idx, const float *scores, int k,
                           const int *max_shape_hwd_host, double wh_ratio_clip, float *dets_out, mr3d_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------
+ * Training targets on the device (csrc/assign_ops.hip) -- SURVEY.md section 8(f) rank 1.  Nothing returns to the
+ * host: counts stay in device memory and list outputs have a fixed capacity (padded with -1).
+ *   max_iou_assign   mmdet/core/bbox/assigners/max_iou_assigner.py:47-196.  boxes [n, box_stride>=6], optional
+ *                    `inside` u8 [n] (anchor_target.py:138-144: boxes with 0 do not take part and get -1 / 0.0),
+ *                    gt [g,6], optional gt_labels i64 [g].  neg range = [neg_iou_lo, neg_iou_hi) (lo = 0 for the
+ *                    reference's float form).  Outputs assigned_gt_inds i64 [n] (-1 ignore, 0 negative, k>0 = gt
+ *                    k-1; the IoU matrix is never materialised), max_overlaps f32 [n], assigned_labels i64 [n] or
+ *                    NULL.  On max-IoU ties between gts the lowest gt index wins (torch CPU max).  gt_max_assign_all
+ *                    must be 1 (the only mode the shipped configs use) else MR3D_ERR_UNSUPPORTED; n == 0 or g == 0 is
+ *                    MR3D_ERR_INVALID_ARG (the reference raises ValueError).
+ *   random_sample    samplers/base_sampler.py:31-101 + random_sampler.py:18-59.  The reference draws from numpy's
+ *                    global generator on the host; here the draws are an INPUT: draws_pos u32 [int(num*pos_fraction)],
+ *                    draws_neg u32 [num]; draw j picks candidate draws[j] % #candidates, duplicates collapse.
+ *                    Outputs: pos_inds i64 [int(num*pos_fraction)] and neg_inds i64 [num], ascending, padded with -1;
+ *                    counts i32 [4] = {#pos sampled, #neg sampled, #pos candidates, #neg candidates};
+ *                    sel_out i32 [n] or NULL: 1 = sampled positive, 2 = sampled negative, 0 = neither.
+ *   anchor_target    anchor/anchor_target.py:146-189 on the FULL anchor set (the reference's unmap step): labels
+ *                    i64 [n] (1 or gt_labels[..] for sampled positives), label_weights [n] (pos_weight<=0 -> 1),
+ *                    bbox_targets / bbox_weights [n,6].  means/stds are HOST arrays of 6.
+ *   concat_gt_assign assign_result.py:13-19 add_gt_: assigned_all[0:g] = 1..g, [g:] = assigned_proposals.
+ *   bbox_target3d    two_stage_3d.py:179-190 + bbox/bbox_target.py:139-165 for one image, candidates = [gts; proposals]
+ *                    (add_gt_as_proposals): rois [cap,7] = (batch_index, box), rows = sampled positives, then
+ *                    negatives, then padding (weights 0); labels / label_weights [cap], bbox_targets / bbox_weights
+ *                    [cap,6], pos_assigned_gt_inds i64 [cap] (-1 beyond the positives) or NULL.
+ * ---------------------------------------------------------------------------------------------- */
+size_t mr3d_max_iou_assign_workspace_bytes(int num_boxes, int num_gt);
+int mr3d_max_iou_assign(const float *boxes, int box_stride, int num_boxes, const uint8_t *inside, const float *gt, int num_gt,
+                        const long long *gt_labels, float pos_iou_thr, float neg_iou_lo, float neg_iou_hi, float min_pos_iou,
+                        int gt_max_assign_all, long long *assigned_gt_inds, float *max_overlaps, long long *assigned_labels,
+                        void *workspace, size_t workspace_bytes, mr3d_stream_t s);
+size_t mr3d_random_sample_workspace_bytes(int n);
+int mr3d_random_sample(const long long *assigned_gt_inds, int n, int num, float pos_fraction, float neg_pos_ub,
+                       const uint32_t *draws_pos, const uint32_t *draws_neg, long long *pos_inds, long long *neg_inds,
+                       int *counts, int *sel_out, void *workspace, size_t workspace_bytes, mr3d_stream_t s);
+int mr3d_anchor_target(const float *anchors, int anchor_stride, int n, const long long *assigned_gt_inds, const int *sel,
+                       const float *gt, const long long *gt_labels, const float *means_host, const float *stds_host,
+                       float pos_weight, long long *labels, float *label_weights, float *bbox_targets, float *bbox_weights,
+                       mr3d_stream_t s);
+int mr3d_concat_gt_assign(const long long *assigned_proposals, int num_proposals, int num_gt, long long *assigned_all,
+                          mr3d_stream_t s);
+int mr3d_bbox_target3d(const float *proposals, int proposal_stride, const float *gt, int num_gt, const long long *gt_labels,
+                       const long long *assigned_all, const long long *pos_inds, const long long *neg_inds, const int *counts,
+                       int cap, int batch_index, const float *means_host, const float *stds_host, float pos_weight,
+                       float *rois, long long *labels, float *label_weights, float *bbox_targets, float *bbox_weights,
+                       long long *pos_assigned_gt_inds, mr3d_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * Losses, value + gradient w.r.t. the prediction in one pass (csrc/loss_ops.hip; mmdet/core/loss/losses.py).
+ * `workspace` = mr3d_loss_workspace_bytes() bytes of device memory; loss_out is ONE device float (overwritten);
+ * grad may be NULL.  Sums are reduced in a fixed order (deterministic).  avg_factor: device scalar if
+ * avg_factor_dev != NULL else the host value.
+ *   weighted_bce_logits  losses.py:28-36 (+ _expand_binary_labels :140-147): score [n,c], labels i64 [n], weights [n].
+ *   weighted_smoothl1    losses.py:77-118: pred/target/weights [count] elementwise.
+ *   weighted_softmax_ce  losses.py:17-25 (reduce=True, avg_factor = max(#(weight>0), 1)) + accuracy :121-137 (top-1,
+ *                        percent) over the first *valid_rows_dev rows (NULL: all n).
+ *   mask_bce             losses.py:69-74: pred [p,c,spatial], target [p,spatial], labels i64 [p]; mean over the first
+ *                        *valid_rows_dev rois (NULL: all p).
+ *   avg_factor_from_counts  mode 0: sum_i max(pos_i,1) + max(neg_i,1) (anchor_target.py:69-70, anchor_head_3d.py:213);
+ *                        mode 1: sum_i pos_i + neg_i (number of sampled rois = bbox_targets.size(0), bbox_head_3d.py:122);
+ *                        counts = num_imgs records of count_stride ints, {pos, neg, ...} as written by random_sample.
+ * ---------------------------------------------------------------------------------------------- */
+size_t mr3d_loss_workspace_bytes(void);
+int mr3d_avg_factor_from_counts(const int *counts, int count_stride, int num_imgs, int mode, float *out, mr3d_stream_t s);
+int mr3d_weighted_bce_logits(const float *score, const long long *labels, const float *weights, long long n, int c,
+                             const float *avg_factor_dev, float avg_factor_host, float *loss_out, float *grad,
+                             void *workspace, mr3d_stream_t s);
+int mr3d_weighted_smoothl1(const float *pred, const float *target, const float *weights, long long count, float beta,
+                           const float *avg_factor_dev, float avg_factor_host, float *loss_out, float *grad, void *workspace,
+                           mr3d_stream_t s);
+int mr3d_weighted_softmax_ce(const float *score, const long long *labels, const float *weights, int n, int c,
+                             const int *valid_rows_dev, float *loss_out, float *accuracy_out, float *grad, void *workspace,
+                             mr3d_stream_t s);
+int mr3d_mask_bce(const float *pred, const float *target, const long long *labels, int num_rois, int c, long long spatial,
+                  const int *valid_rows_dev, float *loss_out, float *grad, void *workspace, mr3d_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
  * Mask-crop (replaces the CPU skimage loops of mmdet/core/mask/mask_target.py:17-49 and
  * mmdet/models/mask_heads/fcn_mask_head_3d.py:163-189).  "Parity unpinned": skimage.transform.resize is a
  * third-party dependency (scikit-image==0.18.0) absent from the reference tree; semantics defined in csrc/mask_ops.hip.
