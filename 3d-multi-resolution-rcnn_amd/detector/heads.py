@@ -3,13 +3,17 @@
   RPNHead3D            mmdet/models/anchor_heads/rpn_head_3d.py:13-35  (+ proposals: rpn_proposals.py)
   SharedFCBBoxHead3D   mmdet/models/bbox_heads/convfc_bbox_head_3d.py:9-183 (num_shared_fcs=2 configuration)
   FCNMaskHead3D        mmdet/models/mask_heads/fcn_mask_head_3d.py:15-97 (+ get_target -> core.mask.mask_target)
-Loss functions stay in PyTorch (elementwise, "next")."""
+Target assignment, sampling and the losses run as HIP kernels too (core/anchor, core/bbox, core/loss)."""
+import numpy as np
 import torch
 import torch.nn as nn
 
 from . import layers
 from ..core.mask import mask_target
-from ..core.anchor import AnchorGenerator3D
+from ..core.anchor import AnchorGenerator3D, anchor_target
+from ..core.bbox import bbox_target_3d
+from ..core.loss import (weighted_binary_cross_entropy, weighted_smoothl1, weighted_cross_entropy, accuracy,
+                         mask_cross_entropy)
 from .rpn_proposals import get_bboxes_single
 
 
@@ -47,6 +51,55 @@ class RPNHead3D(nn.Module):
         outs = [self.forward_single(f) for f in feats]
         return [o[0] for o in outs], [o[1] for o in outs]
 
+    # ------------------------------------------------------------------ training (anchor_head_3d.py:83-230)
+    def get_anchors(self, featmap_sizes, img_metas, device='cuda'):
+        """anchor_head_3d.py:83-123; the multi-level anchors of a pyramid shape are generated once and cached"""
+        key = (tuple(tuple(int(v) for v in fs) for fs in featmap_sizes), str(device))
+        if getattr(self, '_anchor_cache_key', None) != key:
+            self._anchor_cache = [g.grid_anchors(fs, s, d, device=device) for g, fs, s, d in
+                                  zip(self.anchor_generators, featmap_sizes, self.anchor_strides, self.anchor_strides_depth)]
+            self._anchor_cache_key = key
+        anchor_list = [list(self._anchor_cache) for _ in img_metas]
+        valid_flag_list = []
+        for meta in img_metas:
+            flags = []
+            for g, (fz, fh, fw), s, ds in zip(self.anchor_generators, featmap_sizes, self.anchor_strides, self.anchor_strides_depth):
+                h, w, _, z = meta['pad_shape']
+                valid = (min(int(np.ceil(z / ds)), fz), min(int(np.ceil(h / s)), fh), min(int(np.ceil(w / s)), fw))
+                flags.append(g.valid_flags((fz, fh, fw), valid, device=device))
+            valid_flag_list.append(flags)
+        return anchor_list, valid_flag_list
+
+    def loss_single(self, cls_score, bbox_pred, labels, label_weights, bbox_targets, bbox_weights, num_total_samples, cfg):
+        """anchor_head_3d.py:125-177 (sigmoid classification, no focal loss)"""
+        cls_score = cls_score.permute(0, 3, 4, 2, 1).reshape(-1, 1)            # (h, w, d, a) anchor order
+        loss_cls = weighted_binary_cross_entropy(cls_score, labels.reshape(-1), label_weights.reshape(-1),
+                                                 avg_factor=num_total_samples)
+        bbox_pred = bbox_pred.permute(0, 3, 4, 2, 1).reshape(-1, 6)
+        beta = cfg['smoothl1_beta'] if isinstance(cfg, dict) else cfg.smoothl1_beta
+        loss_reg = weighted_smoothl1(bbox_pred, bbox_targets.reshape(-1, 6), bbox_weights.reshape(-1, 6), beta=beta,
+                                     avg_factor=num_total_samples)
+        return loss_cls, loss_reg
+
+    def loss(self, cls_scores, bbox_preds, gt_bboxes, img_metas, cfg, gt_bboxes_ignore=None, draws_list=None):
+        """rpn_head_3d.py:36-70 -> anchor_head_3d.py:179-230.  `draws_list`: per image (pos_words, neg_words) for a
+        reproducible sampler; default = the device generator."""
+        featmap_sizes = [tuple(f.shape[-3:]) for f in cls_scores]
+        anchor_list, valid_flag_list = self.get_anchors(featmap_sizes, img_metas, device=cls_scores[0].device)
+        (labels_list, label_weights_list, bbox_targets_list, bbox_weights_list, num_total_pos, num_total_neg, _,
+         inside_flags) = anchor_target(anchor_list, valid_flag_list, gt_bboxes, img_metas, self.target_means, self.target_stds,
+                                       cfg, gt_bboxes_ignore_list=gt_bboxes_ignore, gt_labels_list=None, label_channels=1,
+                                       sampling=True, draws_list=draws_list)
+        self.pos_indices = inside_flags                                          # anchor_head_3d.py:212
+        num_total_samples = (num_total_pos + num_total_neg).float()             # device scalar: no read-back
+        losses_cls, losses_reg = [], []
+        for lvl in range(len(cls_scores)):
+            lc, lr = self.loss_single(cls_scores[lvl], bbox_preds[lvl], labels_list[lvl], label_weights_list[lvl],
+                                      bbox_targets_list[lvl], bbox_weights_list[lvl], num_total_samples, cfg)
+            losses_cls.append(lc)
+            losses_reg.append(lr)
+        return dict(loss_rpn_cls=losses_cls, loss_rpn_reg=losses_reg)
+
     def get_bboxes(self, cls_scores, bbox_preds, img_metas, cfg):
         """per image proposals (anchor_head_3d.py:232-268 -> rpn_head_3d.py:72-149)"""
         res = []
@@ -60,8 +113,11 @@ class RPNHead3D(nn.Module):
 class SharedFCBBoxHead3D(nn.Module):
 
     def __init__(self, in_channels=64, fc_out_channels=1024, roi_feat_size=7, roi_feat_size_depth=3, num_classes=2,
-                 reg_class_agnostic=False, with_cls=True):
+                 reg_class_agnostic=False, with_cls=True, target_means=(0., 0., 0., 0., 0., 0.),
+                 target_stds=(0.1, 0.1, 0.2, 0.2, 0.1, 0.1)):
         super().__init__()
+        self.num_classes, self.reg_class_agnostic = num_classes, reg_class_agnostic
+        self.target_means, self.target_stds = list(target_means), list(target_stds)
         flat = in_channels * roi_feat_size_depth * roi_feat_size * roi_feat_size
         self.shared_fcs = nn.ModuleList([nn.Linear(flat, fc_out_channels), nn.Linear(fc_out_channels, fc_out_channels)])
         self.with_cls = with_cls                     # the refinement head has no classifier (..._refinement_head.py)
@@ -92,6 +148,33 @@ class SharedFCBBoxHead3D(nn.Module):
             nc = self.fc_cls.weight.shape[0]
             return out[:, :nc], out[:, nc:]
         return None, layers.linear(x, self.fc_reg.weight, self.fc_reg.bias)
+
+    def get_target(self, sampling_results, gt_bboxes, gt_labels, rcnn_train_cfg):
+        """bbox_head_3d.py:68-84"""
+        return bbox_target_3d([r.pos_bboxes for r in sampling_results], [r.neg_bboxes for r in sampling_results],
+                              [r.pos_gt_bboxes for r in sampling_results], [r.pos_gt_labels for r in sampling_results],
+                              rcnn_train_cfg, 1 if self.reg_class_agnostic else self.num_classes,
+                              target_means=self.target_means, target_stds=self.target_stds)
+
+    def loss(self, cls_score, bbox_pred, labels, label_weights, bbox_targets, bbox_weights, valid_rows=None, num_rois=None):
+        """bbox_head_3d.py:86-135.  The regression loss is evaluated densely: the reference gathers the positive rows
+        (`bbox_pred.view(R,-1,6)[pos_inds, labels[pos_inds]]`), here every row selects its label's slot and the
+        negatives / padding rows carry weight 0 -- the same sum.  valid_rows / num_rois (device scalars) describe a
+        padded static-shape roi batch: rows >= valid_rows are ignored, avg_factor = num_rois instead of R."""
+        losses = dict()
+        if cls_score is not None:
+            losses['loss_cls'] = weighted_cross_entropy(cls_score, labels, label_weights, valid_rows=valid_rows)
+            losses['acc'] = accuracy(cls_score, labels, valid_rows=valid_rows)
+        if bbox_pred is not None:
+            R = bbox_pred.size(0)
+            if self.reg_class_agnostic:
+                sel = bbox_pred.view(R, 6)
+            else:
+                idx = labels.view(R, 1, 1).expand(R, 1, 6)
+                sel = bbox_pred.view(R, -1, 6).gather(1, idx).squeeze(1)
+            avg = float(bbox_targets.size(0)) if num_rois is None else num_rois
+            losses['loss_reg'] = weighted_smoothl1(sel, bbox_targets, bbox_weights, avg_factor=avg)
+        return losses
 
 
 class _ConvModule(nn.Module):
@@ -136,3 +219,8 @@ class FCNMaskHead3D(nn.Module):
         pos_proposals = [res.pos_bboxes for res in sampling_results]
         pos_assigned_gt_inds = [res.pos_assigned_gt_inds for res in sampling_results]
         return mask_target(pos_proposals, pos_assigned_gt_inds, gt_masks, rcnn_train_cfg)
+
+    def loss(self, mask_pred, mask_targets, labels, valid_rows=None):
+        """fcn_mask_head_3d.py:108-124"""
+        lab = torch.zeros_like(labels) if self.class_agnostic else labels
+        return dict(loss_mask=mask_cross_entropy(mask_pred, mask_targets, lab, valid_rows=valid_rows))

@@ -1,0 +1,124 @@
+"""TwoStageDetector3D.forward_train (mmdet/models/detectors/two_stage_3d.py:114-224): the single-pathway training
+step -- backbone+FPN -> RPN (+loss, proposals) -> assign/sample 512 -> RoIAlign3D (3,7,7) -> bbox head (+loss) ->
+RoIAlign3D (10,14,14) on the positives -> mask head (+loss) -- i.e. pathway 1 of the shipped dual-pathway model
+(two_stage_3d_2scales.py:135-330) and BASELINE.json configs[2]/[3].
+
+Static shapes, device-resident counts: the roi batch always has `sampler.num` rows (sampled positives, negatives,
+then zero-weight padding) and the mask batch int(num * pos_fraction) rows; how many of them are real stays in device
+memory and enters the loss kernels as `valid_rows` / `avg_factor`.  The reference synchronises with the host at every
+`.item()`, `nonzero`, numpy sampler call and boolean-mask gather of this path (~40 per iteration)."""
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+
+from .. import _hip
+from ..core.bbox import build_assigner, build_sampler
+from ..core.mask import mask_target_single
+from .extract_feat import ExtractFeat3D
+from .heads import RPNHead3D, SharedFCBBoxHead3D, FCNMaskHead3D
+from .roi_extractor import SingleRoIExtractor
+
+# configs/3d-multi-resolution-rcnn.py:87-127
+DEFAULT_TRAIN_CFG = dict(
+    rpn=dict(assigner=dict(type='MaxIoUAssigner', pos_iou_thr=0.7, neg_iou_thr=0.3, min_pos_iou=0.3, ignore_iof_thr=-1),
+             sampler=dict(type='RandomSampler', num=256, pos_fraction=0.5, neg_pos_ub=-1, add_gt_as_proposals=False),
+             allowed_border=0, pos_weight=3, smoothl1_beta=1 / 9.0, debug=False),
+    rpn_proposal=dict(nms_across_levels=False, nms_pre=2000, nms_post=2000, max_num=2000, nms_thr=0.7, min_bbox_size=0),
+    rcnn=dict(assigner=dict(type='MaxIoUAssigner', pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.5, ignore_iof_thr=-1),
+              sampler=dict(type='RandomSampler', num=512, pos_fraction=0.25, neg_pos_ub=-1, add_gt_as_proposals=True),
+              mask_size=28, mask_size_depth=20, pos_weight=3, debug=False))
+
+
+class TwoStageDetector3D(nn.Module):
+
+    def __init__(self, device='cuda', train_cfg=None, with_mask=True, anchor_scales=(2,), anchor_depth_scales=(2,)):
+        super().__init__()
+        self.device = torch.device(device)
+        self.train_cfg = train_cfg or DEFAULT_TRAIN_CFG
+        self.extract = ExtractFeat3D(device=device)                       # backbone + neck (module names as the reference)
+        self.rpn_head = RPNHead3D(anchor_scales=anchor_scales, anchor_depth_scales=anchor_depth_scales).to(self.device)
+        strides, dstrides = [4, 8, 16, 32], [2, 4, 8, 16]
+        self.bbox_roi_extractor = SingleRoIExtractor(dict(type='RoIAlign3D', out_size=7, out_size_depth=3, sample_num=2), 64,
+                                                     strides, dstrides)
+        self.bbox_head = SharedFCBBoxHead3D().to(self.device)
+        self.with_mask = with_mask
+        if with_mask:
+            self.mask_roi_extractor = SingleRoIExtractor(dict(type='RoIAlign3D', out_size=14, out_size_depth=10, sample_num=2),
+                                                         64, strides, dstrides)
+            self.mask_head = FCNMaskHead3D().to(self.device)
+        self.iteration = 0
+
+    def extract_feat(self, imgs):
+        return self.extract(imgs)
+
+    def forward_train(self, imgs, img_meta, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_masks=None, proposals=None,
+                      draws=None):
+        """Returns the reference's loss dict (loss_rpn_cls / loss_rpn_reg lists per level, loss_cls, acc, loss_reg,
+        loss_mask).  draws: optional dict(rpn=[(pos, neg) per image], rcnn=[(pos, neg) per image]) of sampler words."""
+        assert imgs.shape[1] == 3                                           # two_stage_3d.py:124
+        draws = draws or {}
+        x = self.extract_feat(imgs)
+        losses = dict()
+        cfg = self.train_cfg
+        rpn_outs = self.rpn_head(x)
+        losses.update(self.rpn_head.loss(*rpn_outs, gt_bboxes, img_meta, cfg['rpn'], gt_bboxes_ignore=gt_bboxes_ignore,
+                                         draws_list=draws.get('rpn')))
+        with torch.no_grad():
+            proposal_list = self.rpn_head.get_bboxes(*rpn_outs, img_meta, SimpleNamespace(**cfg['rpn_proposal'])) \
+                if proposals is None else proposals
+
+        rc = cfg['rcnn']
+        assigner, sampler = build_assigner(rc['assigner']), build_sampler(rc['sampler'])
+        assert sampler.add_gt_as_proposals
+        cap, cap_pos = sampler.num, int(sampler.num * sampler.pos_fraction)
+        num_imgs = imgs.size(0)
+        rois, labels, label_weights, bbox_targets, bbox_weights, pos_gt, counts = [], [], [], [], [], [], []
+        for i in range(num_imgs):
+            gt, gl = gt_bboxes[i].float(), gt_labels[i]
+            ar = assigner.assign(proposal_list[i], gt, None, gl)
+            assigned_all = _hip.concat_gt_assign(ar.gt_inds, gt.size(0))
+            dp, dn = draws['rcnn'][i] if 'rcnn' in draws else (None, None)
+            pos, neg, cnt, _ = _hip.random_sample(assigned_all, cap, sampler.pos_fraction, sampler.neg_pos_ub, dp, dn)
+            r, lab, lw, bt, bw, pgi = _hip.bbox_target3d(proposal_list[i], gt, gl, assigned_all, pos, neg, cnt, cap, i,
+                                                         self.bbox_head.target_means, self.bbox_head.target_stds,
+                                                         float(rc['pos_weight']))
+            rois.append(r); labels.append(lab); label_weights.append(lw); bbox_targets.append(bt); bbox_weights.append(bw)
+            pos_gt.append(pgi); counts.append(cnt)
+        counts = torch.stack(counts)
+        self.last_sample_counts = counts
+
+        # ---- bbox head (two_stage_3d.py:179-192)
+        all_rois = torch.cat(rois)
+        bbox_feats = self.bbox_roi_extractor(x[:self.bbox_roi_extractor.num_inputs], all_rois)
+        cls_score, bbox_pred = self.bbox_head(bbox_feats)
+        lab, lw = torch.cat(labels), torch.cat(label_weights)
+        # padding rows have weight 0 everywhere; accuracy / avg_factor need the real row count
+        if num_imgs > 1:
+            raise NotImplementedError('imgs_per_gpu > 1: per-image padding makes the valid rows non-contiguous '
+                                      '(the shipped config trains with imgs_per_gpu=1, configs/...py:191)')
+        num_rois = _hip.avg_factor_from_counts(counts, 1)
+        valid_rows = (counts[0, 0] + counts[0, 1]).reshape(1).to(torch.int32)
+        losses.update(self.bbox_head.loss(cls_score, bbox_pred, lab, lw, torch.cat(bbox_targets), torch.cat(bbox_weights),
+                                          valid_rows=valid_rows, num_rois=num_rois))
+
+        # ---- mask head on the positives (two_stage_3d.py:194-218): rows [0, cap_pos) of the roi batch, first #pos real
+        if self.with_mask:
+            pos_rois = rois[0][:cap_pos].contiguous()
+            mask_feats = self.mask_roi_extractor(x[:self.mask_roi_extractor.num_inputs], pos_rois)
+            mask_pred = self.mask_head(mask_feats)
+            n_pos = counts[0, 0].reshape(1)
+            gi = pos_gt[0][:cap_pos].clamp(min=0)                        # padding rows point at gt 0; they carry no loss
+            mask_targets = mask_target_single(pos_rois[:, 1:], gi, gt_masks[0], SimpleNamespace(**rc))
+            losses.update(self.mask_head.loss(mask_pred, mask_targets, labels[0][:cap_pos], valid_rows=n_pos))
+        self.iteration += 1
+        return losses
+
+    @staticmethod
+    def total_loss(losses):
+        """mmdet/models/detectors/base.py `_parse_losses`: sum of every entry whose key contains 'loss'"""
+        tot = 0
+        for k, v in losses.items():
+            if 'loss' in k:
+                tot = tot + (sum(t.sum() for t in v) if isinstance(v, (list, tuple)) else v.sum())
+        return tot

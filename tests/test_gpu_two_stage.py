@@ -1,0 +1,116 @@
+"""Single-pathway training step (detector/two_stage.py, reference two_stage_3d.py:114-224) on the GPU: the fused,
+static-shape, sync-free path must give the same losses as the reference's exact-shape flow restated with the numpy
+oracle (targets) + plain torch (losses) on the same head outputs and the same sampler words."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import targets_ref as T
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+def _setup(dev, seed=0):
+    from mr3d_amd.detector import TwoStageDetector3D
+    torch.manual_seed(seed)
+    det = TwoStageDetector3D(device=dev)
+    det.extract.init_weights()
+    rng = np.random.default_rng(seed)
+    img = torch.randn(1, 3, 32, 128, 128, device=dev)
+    gt = np.array([[20, 30, 60, 75, 4, 20], [70, 20, 110, 64, 10, 28], [40, 80, 90, 120, 2, 14]], np.float32)
+    masks = np.zeros((3, 32, 128, 128), np.uint8)
+    for k, b in enumerate(gt.astype(int)):
+        masks[k, b[4]:b[5] + 1, b[1]:b[3] + 1, b[0]:b[2] + 1] = 1
+    meta = [dict(img_shape=(128, 128, 3, 32), pad_shape=(128, 128, 3, 32))]
+    draws = dict(rpn=[(rng.integers(0, 2 ** 31 - 1, 128), rng.integers(0, 2 ** 31 - 1, 256))],
+                 rcnn=[(rng.integers(0, 2 ** 31 - 1, 128), rng.integers(0, 2 ** 31 - 1, 512))])
+    return det, img, torch.from_numpy(gt).to(dev), torch.ones(3, dtype=torch.long, device=dev), torch.from_numpy(masks).to(dev), meta, draws
+
+
+def test_forward_train_losses_match_exact_shape_flow(dev):
+    det, img, gt, gl, masks, meta, draws = _setup(dev)
+    cfg = det.train_cfg
+    losses = det.forward_train(img, meta, [gt], [gl], gt_masks=[masks], draws=draws)
+    assert set(losses) == {'loss_rpn_cls', 'loss_rpn_reg', 'loss_cls', 'acc', 'loss_reg', 'loss_mask'}
+    assert len(losses['loss_rpn_cls']) == 5 and all(torch.isfinite(v).all() for v in losses['loss_rpn_cls'])
+
+    # ---- the reference flow, exact shapes, on the same features
+    with torch.no_grad():
+        x = det.extract_feat(img)
+        cls_scores, bbox_preds = det.rpn_head(x)
+        fs = [tuple(c.shape[-3:]) for c in cls_scores]
+        anchors, flags = det.rpn_head.get_anchors(fs, meta, device=dev)
+        an = torch.cat(anchors[0]).cpu().numpy()
+        r = T.anchor_target_single(an, torch.cat(flags[0]).cpu().numpy(), gt.cpu().numpy(), meta[0]['img_shape'], [0.] * 6, [1.] * 6,
+                                   0.7, 0.3, 0.3, 256, 0.5, 0, 3, *draws['rpn'][0])
+        avg = max(len(r['pos_inds']), 1) + max(len(r['neg_inds']), 1)
+        start = 0
+        for lvl, (c, b) in enumerate(zip(cls_scores, bbox_preds)):
+            n = c[0].numel()
+            sl = slice(start, start + n)
+            start += n
+            cs = c.permute(0, 3, 4, 2, 1).reshape(-1)
+            lc = F.binary_cross_entropy_with_logits(cs, torch.from_numpy(r['labels'][sl]).float().to(dev),
+                                                    torch.from_numpy(r['label_weights'][sl]).to(dev), reduction='sum') / avg
+            bp = b.permute(0, 3, 4, 2, 1).reshape(-1, 6)
+            d = (bp - torch.from_numpy(r['bbox_targets'][sl]).to(dev)).abs()
+            beta = 1 / 9.0
+            lr = (torch.where(d < beta, 0.5 * d * d / beta, d - 0.5 * beta) * torch.from_numpy(r['bbox_weights'][sl]).to(dev)).sum() / avg
+            np.testing.assert_allclose(losses['loss_rpn_cls'][lvl].item(), lc.item(), rtol=2e-5, atol=1e-7)
+            np.testing.assert_allclose(losses['loss_rpn_reg'][lvl].item(), lr.item(), rtol=2e-5, atol=1e-7)
+        from types import SimpleNamespace
+        props = det.rpn_head.get_bboxes(cls_scores, bbox_preds, meta, SimpleNamespace(**cfg['rpn_proposal']))[0]
+        s = T.rcnn_sample(props.cpu().numpy(), gt.cpu().numpy(), gl.cpu().numpy(), 0.5, 0.5, 0.5, 512, 0.25, *draws['rcnn'][0])
+        npos, nneg = len(s['pos_inds']), len(s['neg_inds'])
+        c = det.last_sample_counts.cpu().numpy()[0]
+        assert (c[0], c[1]) == (npos, nneg)
+        boxes = np.concatenate([s['pos_bboxes'], s['neg_bboxes']])
+        rois = torch.from_numpy(np.concatenate([np.zeros((len(boxes), 1), np.float32), boxes], 1)).to(dev)
+        lab, lw, bt, bw = T.bbox_target_single_3d(s['pos_bboxes'], s['neg_bboxes'], s['pos_gt_bboxes'], s['pos_gt_labels'], 3,
+                                                  det.bbox_head.target_means, det.bbox_head.target_stds)
+        feats = det.bbox_roi_extractor(x[:4], rois)
+        cls, reg = det.bbox_head(feats)
+        labt = torch.from_numpy(lab).to(dev)
+        ce = (F.cross_entropy(cls, labt, reduction='none') * torch.from_numpy(lw).to(dev)).sum() / max((lw > 0).sum(), 1)
+        np.testing.assert_allclose(losses['loss_cls'].item(), ce.item(), rtol=2e-5)
+        acc = 100.0 * (cls.argmax(1) == labt).float().mean().item()
+        np.testing.assert_allclose(losses['acc'].item(), acc, rtol=1e-5)
+        pos = labt > 0
+        sel = reg.view(len(lab), -1, 6)[pos, labt[pos]]
+        d = (sel - torch.from_numpy(bt).to(dev)[pos]).abs()
+        lreg = torch.where(d < 1.0, 0.5 * d * d, d - 0.5).sum() / len(lab)
+        np.testing.assert_allclose(losses['loss_reg'].item(), lreg.item(), rtol=2e-5, atol=1e-7)
+        if npos:
+            prois = rois[:npos]
+            mf = det.mask_roi_extractor(x[:4], prois)
+            mp = det.mask_head(mf)
+            from mr3d_amd.core.mask import mask_target_single
+            mt = mask_target_single(prois[:, 1:].contiguous(), torch.from_numpy(s['pos_assigned_gt_inds']).to(dev), masks,
+                                    SimpleNamespace(mask_size=28, mask_size_depth=20))
+            lm = F.binary_cross_entropy_with_logits(mp[torch.arange(npos), labt[:npos]], mt, reduction='mean')
+            np.testing.assert_allclose(losses['loss_mask'].item(), lm.item(), rtol=2e-5)
+
+
+def test_forward_train_backward_reaches_every_parameter(dev):
+    det, img, gt, gl, masks, meta, draws = _setup(dev, seed=1)
+    det.extract.zero_grad()
+    losses = det.forward_train(img, meta, [gt], [gl], gt_masks=[masks], draws=draws)
+    total = det.total_loss(losses)
+    assert torch.isfinite(total)
+    total.backward()
+    for name, p in list(det.rpn_head.named_parameters()) + list(det.bbox_head.named_parameters()) + list(det.mask_head.named_parameters()):
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+        assert p.grad.abs().sum() > 0, name
+    g = det.extract.flat_grads
+    assert torch.isfinite(g).all() and g.abs().sum() > 0
+    # determinism of the whole step with fixed sampler words
+    losses2 = det.forward_train(img, meta, [gt], [gl], gt_masks=[masks], draws=draws)
+    for k in ('loss_cls', 'loss_reg', 'loss_mask'):
+        assert torch.equal(losses[k], losses2[k]), k
