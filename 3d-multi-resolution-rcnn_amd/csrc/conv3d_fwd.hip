@@ -41,7 +41,11 @@ struct FwdCfg {
   static constexpr int HD = (TD - 1) * LSD + KD, HH = (TH - 1) * LSH + KH, HW = (TW - 1) * LSW + KW;
   static constexpr int HP = HD * HH * HW;       // halo positions
   static constexpr int ROW = CC + 1;            // LDS row stride in floats
-  static constexpr int M = TD * TH * TW;        // output positions per workgroup
+  static constexpr int MV = TD * TH * TW;       // output positions of the tile
+  // GEMM rows per workgroup: MV rounded up to whole MFMA tiles per wave (a 5x7x7 tile -- the divisor-friendly shape
+  // for 10x14x14 roi volumes -- has 245 positions and runs as 256 rows, the last 11 idle)
+  static constexpr int MQ = (NB_ == 32) ? 128 : 64;
+  static constexpr int M = (MV + MQ - 1) / MQ * MQ;
   static constexpr int TAPS = KD * KH * KW;
   static constexpr bool k16 = (NB == 16);       // 16x16x4 MFMA, else 32x32x2
   static constexpr int TM = k16 ? 16 : 32;      // MFMA tile edge
@@ -95,7 +99,8 @@ __global__ __launch_bounds__(kThreads) void conv3d_fwd_kernel(Conv3dFwdArgs p, i
   int abase[C::MT];
 #pragma unroll
   for (int mt = 0; mt < C::MT; ++mt) {
-    const int m = wave_m * C::WROWS + mt * C::TM + li;
+    int m = wave_m * C::WROWS + mt * C::TM + li;
+    if (C::MV < C::M && m >= C::MV) m = 0;        // idle padding row: any in-range address, result never stored
     const int tw = m % C::TW, th = (m / C::TW) % C::TH, td = m / (C::TW * C::TH);
     abase[mt] = (((td * C::LSD) * C::HH + th * C::LSH) * C::HW + tw * C::LSW) * C::ROW + lk;
   }
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(kThreads) void conv3d_fwd_kernel(Conv3dFwdArgs p, i
       const int m = wave_m * C::WROWS + mt * C::TM + row;
       const int tw = m % C::TW, th = (m / C::TW) % C::TH, td = m / (C::TW * C::TH);
       const int od = od0 + td, oh = oh0 + th, ow = ow0 + tw;
-      bool inside = od < p.Do && oh < p.Ho && ow < p.Wo;
+      bool inside = od < p.Do && oh < p.Ho && ow < p.Wo && (C::MV == C::M || m < C::MV);
       size_t idx;
       if constexpr (C::PAR) {
         const int fd = 2 * od + ad, fh = 2 * oh + ah, fw = 2 * ow + aw;
@@ -267,6 +272,17 @@ int dispatch_tile(const Conv3dFwdArgs &a, hipStream_t stream) {
   };
   using T0 = FwdCfg<K, K, K, SD, SH, SW, 4, 8, 8, CC, NB>;
   using T1 = FwdCfg<K, K, K, SD, SH, SW, 2, 8, 8, CC, NB>;
+  if constexpr (K == 3 && SD == 1 && SH == 1 && SW == 1) {
+    // volumes whose extents are multiples of 5/7/7 (10x14x14 mask-head rois): a 5x7x7 tile wastes 4 % of the GEMM
+    // rows where the power-of-two tiles waste 23-36 %
+    const long long vol = (long long)a.Do * a.Ho * a.Wo;
+    const long long t577 = (long long)((a.Do + 4) / 5) * ((a.Ho + 6) / 7) * ((a.Wo + 6) / 7);
+    const long long t488 = (long long)((a.Do + 3) / 4) * ((a.Ho + 7) / 8) * ((a.Wo + 7) / 8);
+    const long long t288 = (long long)((a.Do + 1) / 2) * ((a.Ho + 7) / 8) * ((a.Wo + 7) / 8);
+    const double c577 = (double)vol / (t577 * 256.0), c488 = (double)vol / (t488 * 256.0), c288 = (double)vol / (t288 * 128.0);
+    if (c577 > 1.15 * (c488 > c288 ? c488 : c288) && a.N * t577 * (a.Cout / NB) >= 512)
+      return launch_fwd<FwdCfg<3, 3, 3, 1, 1, 1, 5, 7, 7, CC, NB>>(a, stream);
+  }
   if (wgs(4, 8, 8) >= 512) return launch_fwd<T0>(a, stream);
   if constexpr (NB == 32) {
     return launch_fwd<T1>(a, stream);

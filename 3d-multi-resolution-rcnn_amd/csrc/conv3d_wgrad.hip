@@ -24,11 +24,12 @@ namespace {
 
 constexpr int kThreads = 256;
 
-template <int KD_, int KH_, int KW_, int SD_, int SH_, int SW_, int CC_, int NB_, bool MERGEW_, int TD_ = 4>
+template <int KD_, int KH_, int KW_, int SD_, int SH_, int SW_, int CC_, int NB_, bool MERGEW_, int TD_ = 4, int TH_ = 8, int TW_ = 8>
 struct WgCfg {
   static constexpr int KD = KD_, KH = KH_, KW = KW_, SD = SD_, SH = SH_, SW = SW_, CC = CC_, NB = NB_;
   static constexpr bool MERGEW = MERGEW_;
-  static constexpr int TD = TD_, TH = 8, TW = 8, M = TD * 64;
+  // MV real positions per tile, run as M GEMM-K rows (a 5x7x7 tile: 245 of 256; the padding rows carry dy = 0)
+  static constexpr int TD = TD_, TH = TH_, TW = TW_, MV = TD * TH * TW, M = (MV + 63) / 64 * 64;
   static constexpr bool PW1 = (KD == 1 && KH == 1 && KW == 1);
   static constexpr int LSD = PW1 ? 1 : SD, LSH = PW1 ? 1 : SH, LSW = PW1 ? 1 : SW;
   static constexpr int GSD = PW1 ? SD : 1, GSH = PW1 ? SH : 1, GSW = PW1 ? SW : 1;
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(kThreads) void conv3d_wgrad_kernel(Conv3dWgradArgs 
       const int tw = m % C::TW, th = (m / C::TW) % C::TH, td = m / (C::TW * C::TH);
       const int od = od0 + td, oh = oh0 + th, ow = ow0 + tw;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (od < p.Do && oh < p.Ho && ow < p.Wo)
+      if (m < C::MV && od < p.Do && oh < p.Ho && ow < p.Wo)
         v = *reinterpret_cast<const float4 *>(p.dy + ((((size_t)n * p.Do + od) * p.Ho + oh) * p.Wo + ow) * p.Cout + n0 + q * 4);
       float *d = dyt + m * C::DROW + q * 4;
       d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
@@ -129,7 +130,8 @@ __global__ __launch_bounds__(kThreads) void conv3d_wgrad_kernel(Conv3dWgradArgs 
     // of k-step q issue (the compiler does not do this on its own: it waits on every ds_read before its MFMA)
     auto ld = [&](int kq, float (&a)[C::TPW][C::MT], float (&bf)[C::NT]) {
       const int m = (kk0 + kq) * 4 + lk;
-      const int tw = m % C::TW, th = (m / C::TW) % C::TH, td = m / (C::TW * C::TH);
+      const int mx = (C::MV < C::M && m >= C::MV) ? 0 : m;      // padding row: dy is 0 there, any in-range x address
+      const int tw = mx % C::TW, th = (mx / C::TW) % C::TH, td = mx / (C::TW * C::TH);
       const int hp = (((td * C::LSD) * C::HH + th * C::LSH) * C::HW + tw * C::LSW) * C::ROW + li;
 #pragma unroll
       for (int nt = 0; nt < C::NT; ++nt) bf[nt] = dyt[m * C::DROW + nt * 16 + li];
@@ -259,7 +261,19 @@ extern "C" int mr3d_conv3d_wgrad(const mr3d_conv3d_wgrad_desc *d, mr3d_stream_t 
     if (a.Cin % 64 == 0) return dispatch_wg<1, 2, 2, 2, 64>(a, nb, stream);
     if (a.Cin % 16 == 0) return dispatch_wg<1, 2, 2, 2, 16>(a, nb, stream);
   } else if (k == 3 && s == 111) {
-    if (a.Cin % 16 == 0) return dispatch_wg<3, 1, 1, 1, 16>(a, nb, stream);
+    if (a.Cin % 16 == 0) {
+      const long long vol = (long long)a.Do * a.Ho * a.Wo;
+      const long long t577 = (long long)((a.Do + 4) / 5) * ((a.Ho + 6) / 7) * ((a.Wo + 6) / 7);
+      const long long t488 = (long long)((a.Do + 3) / 4) * ((a.Ho + 7) / 8) * ((a.Wo + 7) / 8);
+      if ((double)vol / t577 > 1.15 * (double)vol / t488 && a.N * t577 >= 512) {     // 10x14x14 roi volumes (mask head)
+        switch (nb) {
+          case 16: return launch_wgrad<WgCfg<3, 3, 3, 1, 1, 1, 16, 16, false, 5, 7, 7>>(a, stream);
+          case 32: return launch_wgrad<WgCfg<3, 3, 3, 1, 1, 1, 16, 32, false, 5, 7, 7>>(a, stream);
+          case 64: return launch_wgrad<WgCfg<3, 3, 3, 1, 1, 1, 16, 64, false, 5, 7, 7>>(a, stream);
+        }
+      }
+      return dispatch_wg<3, 1, 1, 1, 16>(a, nb, stream);
+    }
   } else if (k == 3 && s == 222) {
     if (a.Cin % 16 == 0) return dispatch_wg<3, 2, 2, 2, 16, 1>(a, nb, stream);   // 3x17x17 halo: one output plane per tile
   } else if (k == 7 && s == 122) {

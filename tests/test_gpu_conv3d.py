@@ -198,3 +198,27 @@ def test_conv3d_dgrad_s2k3_rejects_bad_grid(dev):
     wb = torch.zeros((27, 32, 32), device=dev)
     with pytest.raises(_hip.Mr3dError):
         _hip.conv3d_dgrad_s2k3(dy, wb, (1, 10, 8, 8, 32))      # 10 -> coarse 5, not 4
+
+
+@pytest.mark.parametrize('cin,cout,n,dhw', [(64, 64, 72, (10, 14, 14)), (16, 32, 80, (10, 14, 14)), (32, 16, 70, (5, 7, 13))])
+def test_conv3d_roi_volumes_5x7x7_tiles(dev, cin, cout, n, dhw):
+    """mask-head shapes (fcn_mask_head_3d.py:45-70 on [R,64,10,14,14] roi features): the 245-position 5x7x7 tile path
+    (forward, data gradient = forward on flipped weights, weight gradient + bias gradient)."""
+    from mr3d_amd import _hip
+    g = torch.Generator().manual_seed(cin + cout + n)
+    x = torch.randn((n, cin) + dhw, generator=g)
+    w = (torch.randn((cout, cin, 3, 3, 3), generator=g) / np.sqrt(cin * 27)).requires_grad_(True)
+    b = torch.randn(cout, generator=g)
+    y = F.conv3d(x, w, b, 1, 1)
+    yd = _hip.conv3d_forward(_cl(x).to(dev), _hip.pack_conv_weight(w.detach()).to(dev), (3,) * 3, (1,) * 3, (1,) * 3,
+                             shift=b.to(dev), relu=True)
+    _check(yd, y.detach().clamp(min=0), 'forward+bias+relu')
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    dw = torch.zeros((27, cin, cout), device=dev)
+    db = torch.zeros(cout, device=dev)
+    _hip.conv3d_wgrad(_cl(x).to(dev), _cl(dy).to(dev), dw, (3,) * 3, (1,) * 3, (1,) * 3, dbias=db)
+    ref = _hip.pack_conv_weight(w.grad)
+    assert (dw.cpu() - ref).abs().max().item() <= RTOL * ref.abs().max().item()
+    refb = dy.sum((0, 2, 3, 4))
+    assert (db.cpu() - refb).abs().max().item() <= RTOL * refb.abs().max().item()

@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Phase timing of the single-pathway training step (BASELINE.json configs[2]) on one MI355X.
+usage: python tools/two_stage_bench.py [--steps 5] [--vol 80,512,512] [--gts 12]"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import mr3d_amd  # noqa: E402
+from mr3d_amd.detector import TwoStageDetector3D  # noqa: E402
+
+
+def synthetic_gt(rng, n, D, H, W, dev):
+    ctr = rng.uniform([30, 30, 8], [W - 30, H - 30, D - 8], size=(n, 3))
+    sz = np.concatenate([rng.uniform(16, 48, (n, 2)), rng.uniform(6, 14, (n, 1))], 1)
+    b = np.stack([ctr[:, 0] - sz[:, 0] / 2, ctr[:, 1] - sz[:, 1] / 2, ctr[:, 0] + sz[:, 0] / 2, ctr[:, 1] + sz[:, 1] / 2,
+                  ctr[:, 2] - sz[:, 2] / 2, ctr[:, 2] + sz[:, 2] / 2], 1).astype(np.float32)
+    masks = torch.zeros((n, D, H, W), dtype=torch.uint8, device=dev)
+    for k, q in enumerate(b.astype(int)):
+        masks[k, q[4]:q[5] + 1, q[1]:q[3] + 1, q[0]:q[2] + 1] = 1
+    return torch.from_numpy(b).to(dev), masks
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--vol', default='80,512,512')
+    ap.add_argument('--gts', type=int, default=12)
+    ap.add_argument('--no-mask', action='store_true')
+    ap.add_argument('--profile', action='store_true', help='torch profiler table of one step')
+    a = ap.parse_args()
+    D, H, W = (int(v) for v in a.vol.split(','))
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    det = TwoStageDetector3D(device=dev, with_mask=not a.no_mask)
+    det.extract.init_weights()
+    rng = np.random.default_rng(0)
+    img = torch.randn(1, 3, D, H, W, device=dev)
+    gt, masks = synthetic_gt(rng, a.gts, D, H, W, dev)
+    gl = torch.ones(a.gts, dtype=torch.long, device=dev)
+    meta = [dict(img_shape=(H, W, 3, D), pad_shape=(H, W, 3, D))]
+
+    def step():
+        det.extract.zero_grad()
+        for p in det.parameters():
+            if p.grad is not None and p.grad.data_ptr() != det.extract.flat_grads.data_ptr():
+                pass
+        losses = det.forward_train(img, meta, [gt], [gl], gt_masks=[masks])
+        tot = det.total_loss(losses)
+        tot.backward()
+        return losses
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if a.profile:
+        from torch.profiler import profile, ProfilerActivity
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+            step()
+            torch.cuda.synchronize()
+        print(prof.key_averages().table(sort_by='cuda_time_total', row_limit=45, max_name_column_width=70))
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        losses = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    print({k: ([round(float(x), 5) for x in v] if isinstance(v, list) else round(float(v), 5)) for k, v in losses.items()})
+    print('sample counts (pos, neg, cand_pos, cand_neg):', det.last_sample_counts.tolist())
+    print(f'two-stage step: {dt * 1e3:.2f} ms  ({1 / dt:.2f} iters/s)  vol {D}x{H}x{W}, {a.gts} gts, mask={not a.no_mask}')
+
+
+if __name__ == '__main__':
+    main()
