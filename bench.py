@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 # algorithmic FLOPs of one forward+backward of backbone+FPN on a 1x3x80x512x512 volume
@@ -38,6 +39,8 @@ def parse():
     ap.add_argument('--vol', type=int, nargs=3, default=[80, 512, 512], metavar=('D', 'H', 'W'),
                     help='volume size (default = the configuration the metric is quoted on)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-aux', action='store_true', help='skip the NMS3D / RoIAlign3D / two-stage-step side measurements '
+                                                          '(profiling runs: only the headline step is traced)')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the cpu_baseline sample')
     ap.add_argument('--per-kernel', action='store_true', help='also print a per-kernel time table to stderr')
     ap.add_argument('--per-op', action='store_true', help='also print every plan op with its time to stderr')
@@ -144,6 +147,20 @@ def ops_microbench(dev):
             ext(feats, r).backward(top)
         out[f'roialign3d_{tag}_fwd_bwd_us'] = timed(fb, iters=5)
     return out
+
+
+def two_stage_step_ms(vol, steps=5):
+    """BASELINE configs[2]: the whole single-pathway training step (backbone+FPN, RPN + loss + proposals/NMS3D,
+    assign/sample 512, RoIAlign3D + bbox head, RoIAlign3D + mask head, all losses, backward) on one volume, timed by
+    tools/two_stage_bench.py in a CHILD process (a fresh allocator / stream state, as a user would run it)."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, 'tools', 'two_stage_bench.py'), '--steps', str(steps), '--warmup', '3', '--json',
+           '--vol', ','.join(str(v) for v in vol)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    for line in reversed(out.stdout.strip().splitlines()):
+        if line.startswith('{'):
+            return json.loads(line)['two_stage_step_ms']
+    raise RuntimeError('two_stage_bench.py failed: ' + out.stderr[-400:])
 
 
 def main():
@@ -266,13 +283,16 @@ def main():
                          'avg_launch_ms': dom_ms / launches, 'launches_per_step': groups[dom]['n'],
                          'whole_step_frac': FLOP_FWD_BWD_512 * scale / (ms_per_step * 1e-3) / PEAK_FP32_MATRIX},
         }
-        if world == 1:
+        if world == 1 and not a.no_aux:
             try:
                 res['aux'] = {k: round(v, 1) for k, v in ops_microbench(dev).items()}
+                ms = two_stage_step_ms((D, H, W))
+                res['aux']['two_stage_step_ms'] = round(ms, 2)           # BASELINE configs[2]
+                res['aux']['two_stage_iters_per_s'] = round(1e3 / ms, 2)
             except Exception as exc:  # the headline number must still print
                 res['aux'] = {'error': repr(exc)}
-            if not a.no_cpu_baseline:
-                res['cpu_baseline'] = cpu_baseline(a.cpu_seconds)
+        if world == 1 and not a.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(a.cpu_seconds)
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

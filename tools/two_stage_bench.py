@@ -31,6 +31,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--vol', default='80,512,512')
     ap.add_argument('--gts', type=int, default=12)
+    ap.add_argument('--repeats', type=int, default=1)
+    ap.add_argument('--none-grads', action='store_true')
+    ap.add_argument('--json', action='store_true', help='print one JSON line with the step time')
     ap.add_argument('--no-mask', action='store_true')
     ap.add_argument('--profile', action='store_true', help='torch profiler table of one step')
     a = ap.parse_args()
@@ -47,9 +50,9 @@ def main():
 
     def step():
         det.extract.zero_grad()
-        for p in det.parameters():
-            if p.grad is not None and p.grad.data_ptr() != det.extract.flat_grads.data_ptr():
-                pass
+        if a.none_grads:
+            for m in (det.rpn_head, det.bbox_head) + ((det.mask_head,) if det.with_mask else ()):
+                m.zero_grad(set_to_none=True)
         losses = det.forward_train(img, meta, [gt], [gl], gt_masks=[masks])
         tot = det.total_loss(losses)
         tot.backward()
@@ -63,12 +66,24 @@ def main():
         with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
             step()
             torch.cuda.synchronize()
-        print(prof.key_averages().table(sort_by='cuda_time_total', row_limit=45, max_name_column_width=70))
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        losses = step()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / a.steps
+        rows = [(e.key, e.self_device_time_total / 1e3, e.count) for e in prof.key_averages() if e.self_device_time_total > 0]
+        rows.sort(key=lambda r: -r[1])
+        tot = sum(r[1] for r in rows)
+        print(f'device time total {tot:.2f} ms')
+        for k, ms, cnt in rows[:60]:
+            print(f'{ms:8.3f} ms {100 * ms / tot:5.1f}% n={cnt:4d}  {k[:150]}')
+    for rep in range(a.repeats):
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            losses = step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / a.steps
+        if a.repeats > 1:
+            print(f'  repeat {rep}: {dt * 1e3:.2f} ms/step')
+    if a.json:
+        import json
+        print(json.dumps({'two_stage_step_ms': dt * 1e3, 'vol': [D, H, W], 'gts': a.gts, 'steps': a.steps}))
+        return
     print({k: ([round(float(x), 5) for x in v] if isinstance(v, list) else round(float(v), 5)) for k, v in losses.items()})
     print('sample counts (pos, neg, cand_pos, cand_neg):', det.last_sample_counts.tolist())
     print(f'two-stage step: {dt * 1e3:.2f} ms  ({1 / dt:.2f} iters/s)  vol {D}x{H}x{W}, {a.gts} gts, mask={not a.no_mask}')
