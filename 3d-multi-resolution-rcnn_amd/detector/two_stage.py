@@ -48,6 +48,33 @@ class TwoStageDetector3D(nn.Module):
                                                          64, strides, dstrides)
             self.mask_head = FCNMaskHead3D().to(self.device)
         self.iteration = 0
+        # checkpoint compatibility (two_stage_3d.py:33-60): the reference names its feature extractor `backbone` / `neck`;
+        # here both live in one engine module, so its prefix is dropped on save and added on load
+        self._register_state_dict_hook(self._strip_extract_prefix)
+        self._register_load_state_dict_pre_hook(self._add_extract_prefix)
+
+    @staticmethod
+    def _strip_extract_prefix(module, state_dict, prefix, local_metadata):
+        for k in [k for k in state_dict if k.startswith(prefix + 'extract.')]:
+            state_dict[prefix + k[len(prefix) + len('extract.'):]] = state_dict.pop(k)
+        return state_dict
+
+    @staticmethod
+    def _add_extract_prefix(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        for k in list(state_dict):
+            bare = k[len(prefix):]
+            if bare.startswith('module.'):                                   # resnet3d.py:431-436 (DataParallel checkpoints)
+                state_dict[prefix + bare[7:]] = state_dict.pop(k)
+                k, bare = prefix + bare[7:], bare[7:]
+            if bare.startswith(('backbone.', 'neck.')):
+                state_dict[prefix + 'extract.' + bare] = state_dict.pop(k)
+
+    def load_checkpoint(self, path_or_dict, strict=False):
+        """mmcv `load_checkpoint` semantics for a reference `.pth` ({'state_dict': ...} or a bare dict): keys of heads this
+        single-pathway detector does not have (rpn_head_2, refinement heads, ...) are reported, not fatal."""
+        sd = torch.load(path_or_dict, map_location='cpu') if isinstance(path_or_dict, str) else path_or_dict
+        sd = sd.get('state_dict', sd)
+        return self.load_state_dict(dict(sd), strict=strict)
 
     def extract_feat(self, imgs):
         return self.extract(imgs)

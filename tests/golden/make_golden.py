@@ -21,6 +21,8 @@ Vectors written (each is {inputs..., expected...}):
                    (numpy's randint draws are RECORDED so that they can be replayed), anchor/anchor_target.py:114-216,
                    bbox/bbox_target.py:139-165
   losses.npz       mmdet/core/loss/losses.py (weighted BCE / CE / smooth-L1, accuracy, mask BCE): values + gradients
+  state_dict_keys.json  checkpoint key -> shape of backbone / neck / rpn_head / bbox_head / mask_head as the shipped
+                   config builds them (checkpoint compatibility)
 
 usage: python tests/golden/make_golden.py   (from the repo root)
 """
@@ -129,6 +131,21 @@ def import_reference():
     ref.MaxIoUAssigner, ref.RandomSampler, ref.bt = asg.MaxIoUAssigner, smp.RandomSampler, bt
     _pkg('mmdet.core.loss', f'{REF}/mmdet/core/loss')
     ref.losses = importlib.import_module('mmdet.core.loss.losses')
+    # heads (state-dict key names / shapes of the shipped single-pathway model): they import names from mmdet.core
+    L = ref.losses
+    sys.modules['mmdet.core'].__dict__.update(
+        AnchorGenerator3D=ref.ag.AnchorGenerator3D, anchor_target=ref.at.anchor_target, delta2bbox=ref.tr.delta2bbox,
+        delta2bbox3D=ref.tr.delta2bbox3D, multi_apply=misc.multi_apply, tensor2img3D=misc.tensor2img3D,
+        weighted_cross_entropy=L.weighted_cross_entropy, weighted_smoothl1=L.weighted_smoothl1,
+        weighted_binary_cross_entropy=L.weighted_binary_cross_entropy, weighted_sigmoid_focal_loss=L.weighted_sigmoid_focal_loss,
+        multiclass_nms=None, multiclass_nms_3d=None, bbox_target_3d=bt.bbox_target_3d, accuracy=L.accuracy,
+        mask_cross_entropy=L.mask_cross_entropy, mask_target=None)
+    sys.modules['skimage.transform'].resize = None
+    for sub in ('anchor_heads', 'bbox_heads', 'mask_heads'):
+        _pkg(f'mmdet.models.{sub}', f'{REF}/mmdet/models/{sub}')
+    ref.RPNHead3D = importlib.import_module('mmdet.models.anchor_heads.rpn_head_3d').RPNHead3D
+    ref.SharedFCBBoxHead3D = importlib.import_module('mmdet.models.bbox_heads.convfc_bbox_head_3d').SharedFCBBoxHead3D
+    ref.FCNMaskHead3D = importlib.import_module('mmdet.models.mask_heads.fcn_mask_head_3d').FCNMaskHead3D
     return ref
 
 
@@ -449,9 +466,29 @@ def make_losses(ref, out):
     print('  losses:', {k: float(d[k][0]) for k in ('bce_loss', 'sl1_loss', 'ce_loss', 'reg_loss', 'mask_loss')})
 
 
+def make_state_dict_keys(ref, out):
+    """key -> shape of the single-pathway detector's checkpoint (module names of two_stage_3d.py:33-60, head kwargs of
+    configs/3d-multi-resolution-rcnn.py:16-79)"""
+    import json
+    import torch.nn as nn
+    m = nn.Module()
+    m.backbone = ref.ResNet3D(depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=-1, style='pytorch')
+    m.neck = ref.FPN3D(in_channels=[64, 128, 256, 512], out_channels=64, num_outs=5)
+    m.rpn_head = ref.RPNHead3D(in_channels=64, feat_channels=64, anchor_scales=[2], anchor_depth_scales=[2], anchor_ratios=[1.0],
+                               anchor_strides=[4, 8, 16, 32, 64], anchor_strides_depth=[2, 4, 8, 16, 32],
+                               target_means=[.0] * 6, target_stds=[1.0] * 6, use_sigmoid_cls=True)
+    m.bbox_head = ref.SharedFCBBoxHead3D(num_fcs=2, in_channels=64, fc_out_channels=1024, roi_feat_size=7, roi_feat_size_depth=3,
+                                         num_classes=2, target_means=[0.] * 6, target_stds=[0.1, 0.1, 0.2, 0.2, 0.1, 0.1],
+                                         reg_class_agnostic=False)
+    m.mask_head = ref.FCNMaskHead3D(num_convs=4, in_channels=64, conv_out_channels=64, num_classes=2)
+    sd = {k: list(v.shape) for k, v in m.state_dict().items()}
+    json.dump(sd, open(out, 'w'), indent=0, sort_keys=True)
+    print(f'  state dict: {len(sd)} entries, {sum(int(np.prod(v)) for v in sd.values())} elements')
+
+
 if __name__ == '__main__':
     ref = import_reference()
-    which = sys.argv[1:] or ['nms', 'iou', 'codec', 'anchors', 'roi_levels', 'backbone', 'targets', 'losses']
+    which = sys.argv[1:] or ['nms', 'iou', 'codec', 'anchors', 'roi_levels', 'backbone', 'targets', 'losses', 'state_dict']
     if 'nms' in which: make_nms(ref, f'{HERE}/nms3d.npz')
     if 'iou' in which: make_iou(ref, f'{HERE}/iou3d.npz')
     if 'codec' in which: make_codec(ref, f'{HERE}/codec.npz')
@@ -460,4 +497,5 @@ if __name__ == '__main__':
     if 'backbone' in which: make_backbone(ref, f'{HERE}/backbone_fpn.npz')
     if 'targets' in which: make_targets(ref, f'{HERE}/targets.npz')
     if 'losses' in which: make_losses(ref, f'{HERE}/losses.npz')
+    if 'state_dict' in which: make_state_dict_keys(ref, f'{HERE}/state_dict_keys.json')
     print('golden vectors written to', HERE)
