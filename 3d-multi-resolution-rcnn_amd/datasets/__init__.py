@@ -1,0 +1,4 @@
+"""Device-side input preparation (the data-dependent half of mmdet/datasets/coco_3d_2scales.py's prepare_train_img)."""
+from .volume import prepare_volume, IMG_NORM_CFG
+
+__all__ = ['prepare_volume', 'IMG_NORM_CFG']

@@ -215,6 +215,18 @@ int mr3d_rpn_decode_level(const long long *flat_idx, const float *scores, int k,
                           const int *max_shape_hwd_host, double wh_ratio_clip, float *dets_out, mr3d_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------
+ * Input preparation on the device (csrc/input_ops.hip) -- SURVEY.md section 8(f) rank 3.  Replaces the per-slice host
+ * loop of mmdet/datasets/coco_3d_2scales.py:245-289 (grey -> 3 channels -> mmcv.imnormalize -> impad_to_multiple ->
+ * [3,D,H,W]; transforms.py:33-51) and, with out_* != d/h/w, the skimage.transform.resize of the second pathway
+ * (coco_3d_2scales.py:219; trilinear, half-pixel centres, edge clamp -- parity unpinned, scikit-image absent).
+ *   grey: ONE-channel volume on the device, u8 or f32, axis order [H,W,D] (the .npy files, src_is_hwd = 1) or [D,H,W];
+ *   out:  [3, out_d, pad_h, pad_w] fp32 planar; channel c = (g - mean[c]) / std[c]; rows/columns beyond out_h/out_w
+ *         are 0 (impad pads AFTER normalisation).  mean/std: HOST arrays of 3.
+ * ---------------------------------------------------------------------------------------------- */
+int mr3d_volume_prepare(const void *grey, int src_is_u8, int src_is_hwd, int d, int h, int w, int out_d, int out_h, int out_w,
+                        int pad_h, int pad_w, const float *mean_host, const float *std_host, float *out, mr3d_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
  * Training targets on the device (csrc/assign_ops.hip) -- SURVEY.md section 8(f) rank 1.  Nothing returns to the
  * host: counts stay in device memory and list outputs have a fixed capacity (padded with -1).
  *   max_iou_assign   mmdet/core/bbox/assigners/max_iou_assigner.py:47-196.  boxes [n, box_stride>=6], optional
