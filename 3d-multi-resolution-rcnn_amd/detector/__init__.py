@@ -3,8 +3,8 @@ from .extract_feat import ExtractFeat3D
 from .rpn_proposals import get_bboxes_single
 from .heads import RPNHead3D, SharedFCBBoxHead3D, FCNMaskHead3D
 from .roi_extractor import SingleRoIExtractor
-from .two_stage import TwoStageDetector3D, DEFAULT_TRAIN_CFG
+from .two_stage import TwoStageDetector3D, DEFAULT_TRAIN_CFG, DEFAULT_TEST_CFG, bbox2result3D
 from . import layers
 
 __all__ = ['ExtractFeat3D', 'get_bboxes_single', 'RPNHead3D', 'SharedFCBBoxHead3D', 'FCNMaskHead3D', 'SingleRoIExtractor', 'layers',
-           'TwoStageDetector3D', 'DEFAULT_TRAIN_CFG']
+           'TwoStageDetector3D', 'DEFAULT_TRAIN_CFG', 'DEFAULT_TEST_CFG', 'bbox2result3D']

@@ -11,7 +11,9 @@ import torch.nn as nn
 from . import layers
 from ..core.mask import mask_target
 from ..core.anchor import AnchorGenerator3D, anchor_target
-from ..core.bbox import bbox_target_3d
+from ..core.bbox import bbox_target_3d, delta2bbox3D
+from ..core.post_processing import multiclass_nms_3d
+from ..core.mask import paste_masks_3d
 from ..core.loss import (weighted_binary_cross_entropy, weighted_smoothl1, weighted_cross_entropy, accuracy,
                          mask_cross_entropy)
 from .rpn_proposals import get_bboxes_single
@@ -156,6 +158,21 @@ class SharedFCBBoxHead3D(nn.Module):
                               rcnn_train_cfg, 1 if self.reg_class_agnostic else self.num_classes,
                               target_means=self.target_means, target_stds=self.target_stds)
 
+    def get_det_bboxes(self, rois, cls_score, bbox_pred, img_shape, scale_factor, rescale=False, cfg=None):
+        """bbox_head_3d.py:136-170: softmax scores, per-class delta2bbox3D decode clipped to img_shape, optional
+        rescale (all 6 coordinates divided, as the reference does), multiclass NMS3D"""
+        scores = torch.softmax(cls_score, dim=1) if cls_score is not None else None
+        if bbox_pred is not None:
+            bboxes = delta2bbox3D(rois[:, 1:].contiguous(), bbox_pred.contiguous(), self.target_means, self.target_stds, img_shape)
+        else:
+            bboxes = rois[:, 1:]
+        if rescale:
+            bboxes = bboxes / scale_factor
+        if cfg is None:
+            return bboxes, scores
+        get = (lambda k: cfg[k]) if isinstance(cfg, dict) else (lambda k: getattr(cfg, k))
+        return multiclass_nms_3d(bboxes, scores, get('score_thr'), dict(get('nms')), get('max_per_img'))
+
     def loss(self, cls_score, bbox_pred, labels, label_weights, bbox_targets, bbox_weights, valid_rows=None, num_rois=None):
         """bbox_head_3d.py:86-135.  The regression loss is evaluated densely: the reference gathers the positive rows
         (`bbox_pred.view(R,-1,6)[pos_inds, labels[pos_inds]]`), here every row selects its label's slot and the
@@ -219,6 +236,26 @@ class FCNMaskHead3D(nn.Module):
         pos_proposals = [res.pos_bboxes for res in sampling_results]
         pos_assigned_gt_inds = [res.pos_assigned_gt_inds for res in sampling_results]
         return mask_target(pos_proposals, pos_assigned_gt_inds, gt_masks, rcnn_train_cfg)
+
+    def get_seg_masks(self, mask_pred, det_bboxes, det_labels, rcnn_test_cfg, ori_shape, scale_factor, rescale):
+        """fcn_mask_head_3d.py:126-191: sigmoid, the label's channel, resize to the (truncated) box, threshold, paste
+        into a [D,H,W] uint8 volume -- all on the device (one kernel); returns per class lists of uint8 numpy volumes
+        like the reference.  ori_shape = (h, w, d) as the reference unpacks it (:155)."""
+        cls_segms = [[] for _ in range(self.num_classes - 1)]
+        if det_bboxes.shape[0] == 0:
+            return cls_segms
+        assert rescale, 'the reference only supports rescale=True here (breakpoint() otherwise, :157)'
+        img_h, img_w, img_d = ori_shape[:3]
+        labels = det_labels + 1
+        idx = torch.arange(mask_pred.size(0), device=mask_pred.device)
+        ch = torch.zeros_like(labels) if self.class_agnostic else labels
+        prob = mask_pred[idx, ch].sigmoid()
+        thr = rcnn_test_cfg['mask_thr_binary'] if isinstance(rcnn_test_cfg, dict) else rcnn_test_cfg.mask_thr_binary
+        masks = paste_masks_3d(prob, det_bboxes[:, :6] / scale_factor, (img_d, img_h, img_w), thr)
+        masks_np, labels_np = masks.cpu().numpy(), labels.cpu().numpy()
+        for i in range(masks_np.shape[0]):
+            cls_segms[labels_np[i] - 1].append(masks_np[i])
+        return cls_segms
 
     def loss(self, mask_pred, mask_targets, labels, valid_rows=None):
         """fcn_mask_head_3d.py:108-124"""

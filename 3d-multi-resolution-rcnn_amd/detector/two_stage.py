@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from .. import _hip
-from ..core.bbox import build_assigner, build_sampler
+from ..core.bbox import build_assigner, build_sampler, bbox2roi3D
 from ..core.mask import mask_target_single
 from .extract_feat import ExtractFeat3D
 from .heads import RPNHead3D, SharedFCBBoxHead3D, FCNMaskHead3D
@@ -30,12 +30,29 @@ DEFAULT_TRAIN_CFG = dict(
               mask_size=28, mask_size_depth=20, pos_weight=3, debug=False))
 
 
+# configs/3d-multi-resolution-rcnn.py:131-144
+DEFAULT_TEST_CFG = dict(
+    rpn=dict(nms_across_levels=False, nms_pre=2000, nms_post=2000, max_num=2000, nms_thr=0.7, min_bbox_size=0),
+    rcnn=dict(score_thr=0.2, nms=dict(type='nms', iou_thr=0.5), max_per_img=2000, mask_thr_binary=0.25))
+
+
+def bbox2result3D(bboxes, labels, num_classes):
+    """mmdet/core/bbox/transforms.py:274-292"""
+    import numpy as np
+    if bboxes.shape[0] == 0:
+        return [np.zeros((0, 7), dtype=np.float32) for _ in range(num_classes - 1)]
+    b, l = bboxes.cpu().numpy(), labels.cpu().numpy()
+    return [b[l == i, :] for i in range(num_classes - 1)]
+
+
 class TwoStageDetector3D(nn.Module):
 
-    def __init__(self, device='cuda', train_cfg=None, with_mask=True, anchor_scales=(2,), anchor_depth_scales=(2,)):
+    def __init__(self, device='cuda', train_cfg=None, test_cfg=None, with_mask=True, anchor_scales=(2,),
+                 anchor_depth_scales=(2,)):
         super().__init__()
         self.device = torch.device(device)
         self.train_cfg = train_cfg or DEFAULT_TRAIN_CFG
+        self.test_cfg = test_cfg or DEFAULT_TEST_CFG
         self.extract = ExtractFeat3D(device=device)                       # backbone + neck (module names as the reference)
         self.rpn_head = RPNHead3D(anchor_scales=anchor_scales, anchor_depth_scales=anchor_depth_scales).to(self.device)
         strides, dstrides = [4, 8, 16, 32], [2, 4, 8, 16]
@@ -140,6 +157,38 @@ class TwoStageDetector3D(nn.Module):
             losses.update(self.mask_head.loss(mask_pred, mask_targets, labels[0][:cap_pos], valid_rows=n_pos))
         self.iteration += 1
         return losses
+
+    @torch.no_grad()
+    def simple_test(self, imgs, img_metas, proposals=None, rescale=False):
+        """two_stage_3d.py:229-264 (+ test_mixins.py:7-11,33-56,94-119): proposals -> bbox head -> per-class decode +
+        NMS3D -> (bbox_results, segm_results); one volume per call (base.py:74-75)."""
+        assert imgs.size(0) == 1
+        cfg = self.test_cfg
+        x = self.extract.forward_features(imgs)
+        if proposals is None:
+            proposal_list = self.rpn_head.get_bboxes(*self.rpn_head(x), img_metas, SimpleNamespace(**cfg['rpn']))
+        else:
+            proposal_list = proposals
+        rois = bbox2roi3D(proposal_list)
+        roi_feats = self.bbox_roi_extractor(x[:self.bbox_roi_extractor.num_inputs], rois)
+        cls_score, bbox_pred = self.bbox_head(roi_feats)
+        meta = img_metas[0]
+        det_bboxes, det_labels = self.bbox_head.get_det_bboxes(rois, cls_score, bbox_pred, meta['img_shape'],
+                                                               meta.get('scale_factor', 1.0), rescale=rescale, cfg=cfg['rcnn'])
+        bbox_results = bbox2result3D(det_bboxes, det_labels, self.bbox_head.num_classes)
+        if not self.with_mask:
+            return bbox_results
+        if det_bboxes.shape[0] == 0:
+            return bbox_results, [[] for _ in range(self.mask_head.num_classes - 1)]
+        scale = meta.get('scale_factor', 1.0)
+        _bboxes = det_bboxes[:, :6] * scale if rescale else det_bboxes[:, :6]
+        mask_rois = bbox2roi3D([_bboxes])
+        mask_feats = self.mask_roi_extractor(x[:self.mask_roi_extractor.num_inputs], mask_rois)
+        mask_pred = self.mask_head(mask_feats)
+        h, w, _, d = meta['img_shape']
+        ori_shape = meta.get('ori_shape_hwd', (h, w, d))
+        segm_results = self.mask_head.get_seg_masks(mask_pred, _bboxes, det_labels, cfg['rcnn'], ori_shape, scale, True)
+        return bbox_results, segm_results
 
     @staticmethod
     def total_loss(losses):

@@ -114,3 +114,26 @@ def test_forward_train_backward_reaches_every_parameter(dev):
     losses2 = det.forward_train(img, meta, [gt], [gl], gt_masks=[masks], draws=draws)
     for k in ('loss_cls', 'loss_reg', 'loss_mask'):
         assert torch.equal(losses[k], losses2[k]), k
+
+
+def test_simple_test_inference_path(dev):
+    """two_stage_3d.py:229-264: result containers, clipping, score order, masks confined to their (truncated) boxes"""
+    det, img, gt, gl, masks, meta, _ = _setup(dev, seed=2)
+    det.test_cfg = dict(rpn=dict(nms_across_levels=False, nms_pre=300, nms_post=300, max_num=300, nms_thr=0.7, min_bbox_size=0),
+                        rcnn=dict(score_thr=0.0, nms=dict(type='nms', iou_thr=0.5), max_per_img=20, mask_thr_binary=0.5))
+    meta[0]['scale_factor'] = 1.0
+    bbox_results, segm_results = det.simple_test(img, meta, rescale=True)
+    assert len(bbox_results) == 1 and len(segm_results) == 1                  # num_classes - 1 foreground classes
+    b = bbox_results[0]
+    assert b.dtype == np.float32 and b.shape[1] == 7 and 0 < b.shape[0] <= 20
+    assert (b[:, [0, 1, 4]] >= 0).all() and (b[:, 2] <= 127).all() and (b[:, 3] <= 127).all() and (b[:, 5] <= 31).all()
+    assert len(segm_results[0]) == b.shape[0]
+    for box, m in zip(b, segm_results[0]):
+        assert m.shape == (32, 128, 128) and m.dtype == np.uint8
+        q = box[:6].astype(np.int32)
+        outside = m.copy()
+        outside[q[4]:q[5] + 1, q[1]:q[3] + 1, q[0]:q[2] + 1] = 0
+        assert outside.sum() == 0
+    # same proposals in, same detections out (no hidden state, deterministic NMS)
+    b2, _ = det.simple_test(img, meta, rescale=True)
+    assert np.array_equal(b, b2[0])
