@@ -81,7 +81,13 @@ __global__ __launch_bounds__(kThreads) void conv3d_wgrad_kernel(Conv3dWgradArgs 
     }
   }
 
-  for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
+  // ---- tile staging, software-pipelined: the NEXT tile's x halo block and dy tile are fetched into registers before
+  // the MFMA loop of the current tile and written to LDS after it (with ~107 KB of LDS per workgroup only one
+  // workgroup fits a CU, so nothing else would hide the global latency)
+  constexpr int Q = C::CC / 4, QN = C::NB / 4;
+  constexpr int NX = (C::HP * Q + kThreads - 1) / kThreads, NDY = (C::M * QN + kThreads - 1) / kThreads;
+  float4 xs[NX], dys[NDY];
+  auto fetch = [&](int tile) {
     int b = tile;
     const int tw_i = b % tiles_w; b /= tiles_w;
     const int th_i = b % tiles_h; b /= tiles_h;
@@ -89,34 +95,54 @@ __global__ __launch_bounds__(kThreads) void conv3d_wgrad_kernel(Conv3dWgradArgs 
     const int n = b;
     const int od0 = td_i * C::TD, oh0 = th_i * C::TH, ow0 = tw_i * C::TW;
     const int id0 = od0 * C::SD - p.pd, ih0 = oh0 * C::SH - p.ph, iw0 = ow0 * C::SW - p.pw;
-    __syncthreads();
-    // ---- stage x halo block (CC channels)
-    constexpr int Q = C::CC / 4;
-    for (int it = tid; it < C::HP * Q; it += kThreads) {
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      const int it = tid + j * kThreads;
       const int pos = it / Q, q = it - pos * Q;
       const int hw = pos % C::HW, hh = (pos / C::HW) % C::HH, hd = pos / (C::HW * C::HH);
       const int id = id0 + hd * C::GSD, ih = ih0 + hh * C::GSH, iw = iw0 + hw * C::GSW;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
+      if (it < C::HP * Q && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
         v = *reinterpret_cast<const float4 *>(p.x + ((((size_t)n * p.D + id) * p.H + ih) * p.W + iw) * p.Cin + c0 + q * 4);
-      float *d = xh + pos * C::ROW + q * 4;
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      xs[j] = v;
     }
-    if (C::MERGEW)
-      for (int it = tid; it < 32; it += kThreads) xh[C::HP * C::ROW + it] = 0.f;
-    // ---- stage dy tile [256][NB] (zeros outside the output volume)
-    constexpr int QN = C::NB / 4;
-    for (int it = tid; it < C::M * QN; it += kThreads) {
+#pragma unroll
+    for (int j = 0; j < NDY; ++j) {
+      const int it = tid + j * kThreads;
       const int m = it / QN, q = it - m * QN;
       const int tw = m % C::TW, th = (m / C::TW) % C::TH, td = m / (C::TW * C::TH);
       const int od = od0 + td, oh = oh0 + th, ow = ow0 + tw;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < C::MV && od < p.Do && oh < p.Ho && ow < p.Wo)
+      if (it < C::M * QN && m < C::MV && od < p.Do && oh < p.Ho && ow < p.Wo)
         v = *reinterpret_cast<const float4 *>(p.dy + ((((size_t)n * p.Do + od) * p.Ho + oh) * p.Wo + ow) * p.Cout + n0 + q * 4);
-      float *d = dyt + m * C::DROW + q * 4;
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      dys[j] = v;
+    }
+  };
+  if ((int)blockIdx.x < num_tiles) fetch(blockIdx.x);
+  for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      const int it = tid + j * kThreads;
+      if (it < C::HP * Q) {
+        const int pos = it / Q, q = it - pos * Q;
+        float *d = xh + pos * C::ROW + q * 4;
+        d[0] = xs[j].x; d[1] = xs[j].y; d[2] = xs[j].z; d[3] = xs[j].w;
+      }
+    }
+    if (C::MERGEW)
+      for (int it = tid; it < 32; it += kThreads) xh[C::HP * C::ROW + it] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NDY; ++j) {
+      const int it = tid + j * kThreads;
+      if (it < C::M * QN) {
+        const int m = it / QN, q = it - m * QN;
+        float *d = dyt + m * C::DROW + q * 4;
+        d[0] = dys[j].x; d[1] = dys[j].y; d[2] = dys[j].z; d[3] = dys[j].w;
+      }
     }
     __syncthreads();
+    if (tile + (int)gridDim.x < num_tiles) fetch(tile + gridDim.x);
 
     if (p.dbias && blockIdx.y == 0) {
       const int co = tid % C::NB;
