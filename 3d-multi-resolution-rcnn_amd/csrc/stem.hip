@@ -9,10 +9,10 @@
 //     weight 0), so the A operands of BOTH steps of a (ci,kd,kh) row are one aligned ds_read_b64 per lane:
 //        A_s[i][k] = slab[plane d+kd][row 2h+kh][2*x_i + 2*k + s]      (slab column 0 = input column 2*w0 - 4)
 //     consecutive lanes read consecutive 8-byte words: conflict-free without padding tricks.
-//   wgrad    D[i = Cout][j = (kh pair, kw)] += A[i][k = 4 output x] * B[k][j]:
-//        A = dy[pos][co] (LDS tile), B = slab[d+kd][2h + kh0 + (j>>3)][2*x_k + (j&7)]
-//     the 3x7x4 (ci, kd, kh-pair) accumulator tiles are split over the 8 waves and live in registers
-//     across a persistent loop over tiles; one atomic pass at the end.
+//   wgrad    D[i = Cout][j = tap] += A[i][k = 4 output x] * B[k][j]   with the 343 taps flattened into 24 groups
+//        of 16 columns: A = dy[pos][co] (LDS tile), B = slab[halo origin of position k + per-lane tap offset];
+//     the 3 x 24 (ci, tap group) accumulator tiles are split over the 8 waves (3 groups each) and live in
+//     registers across a persistent loop over tiles; one atomic pass at the end.
 // One input channel of the halo block ((TD+6) x (2*TH+5) x 72 floats) is resident in LDS at a time.
 #include "conv3d.h"
 
@@ -174,10 +174,11 @@ struct StemWgradArgs {
 
 __global__ __launch_bounds__(kStemThreads) void stem_wgrad_kernel(StemWgradArgs p, int tiles_d, int tiles_h, int tiles_w) {
   constexpr int TD = 4, TH = 8, TW = 16;
-  using G = StemGeo<TD, TH, TW, 48>;       // 37 columns used; 48 == 16 (mod 32)
+  using G = StemGeo<TD, TH, TW, 40>;       // 37 columns used; 40 == 8 (mod 32): four consecutive kh rows sit 8 banks apart
   constexpr int SW_ROW = G::SW_ROW;
   constexpr int M = TD * TH * TW;          // 512 positions per tile
   constexpr int DYROW = 16;                // lanes (co, k) read word 16k + co: conflict-free
+  constexpr int NQ = 3;                    // accumulator groups per wave
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *slab = lds;
   float *dyt = lds + G::SLAB;
@@ -187,21 +188,20 @@ __global__ __launch_bounds__(kStemThreads) void stem_wgrad_kernel(StemWgradArgs 
   const size_t vox = (size_t)p.D * p.H * p.W;
   const int num_tiles = p.N * tiles_d * tiles_h * tiles_w;
 
-  // accumulator tiles: g = q*8 + wave (q = 0..3), g in [0,28): kd = g / 4, kh-pair hp = g % 4 (rows kh = 2hp, 2hp+1)
-  f32x4 acc[3][4];
+  // GEMM columns = the 343 taps FLATTENED: group g = q*8 + wave (q = 0..2, 24 groups of 16 columns), column j = lane
+  // li holds tap t = 16 g + j = (kd*7 + kh)*7 + kw.  B[k][j] is then simply slab[position k + offset(t)] with a
+  // per-lane constant offset, and 343 of 384 issued columns are real (the (kh-pair, kw<8) layout used 49 of 64).
+  f32x4 acc[3][NQ];
 #pragma unroll
   for (int ci = 0; ci < 3; ++ci)
-    for (int q = 0; q < 4; ++q) acc[ci][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-  int goff[4];
-  bool gok[4];
+    for (int q = 0; q < NQ; ++q) acc[ci][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int goff[NQ];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int g = q * 8 + wave;
-    gok[q] = g < 28;
-    const int gg = gok[q] ? g : 27;
-    const int kd = gg >> 2, hp = gg & 3;
-    // B[k][j]: row kh = 2hp + (j>>3), col kw = j&7 ; lane j = li
-    goff[q] = (kd * G::PH + 2 * hp + (li >> 3)) * SW_ROW + (li & 7) + 1;   // +1: slab starts one column early
+  for (int q = 0; q < NQ; ++q) {
+    int t = 16 * (q * 8 + wave) + li;
+    if (t > 342) t = 342;                  // surplus column: recomputes the last tap, result dropped
+    const int kw = t % 7, kh = (t / 7) % 7, kd = t / 49;
+    goff[q] = (kd * G::PH + kh) * SW_ROW + kw + 1;      // +1: slab starts one column early
   }
   float bsum = 0.f;
 
@@ -227,25 +227,25 @@ __global__ __launch_bounds__(kStemThreads) void stem_wgrad_kernel(StemWgradArgs 
       if (ci) __syncthreads();
       stem_stage_channel<kStemThreads, G>(slab, p.x + ((size_t)n * 3 + ci) * vox, p.D, p.H, p.W, d0, h0, w0, tid);
       __syncthreads();
-      auto ld = [&](int ks, float &a, float (&bv)[4]) {
+      auto ld = [&](int ks, float &a, float (&bv)[NQ]) {
         const int m = ks * 4 + lk;                                  // this lane's position (k index)
         const int tw = m % TW, th = (m / TW) % TH, td = m / (TW * TH);
         a = dyt[m * DYROW + li];                                    // A[i = co][k]
         const int pos = (td * G::PH + 2 * th) * SW_ROW + 2 * tw;    // halo origin of that position
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bv[q] = slab[pos + goff[q]];
+        for (int q = 0; q < NQ; ++q) bv[q] = slab[pos + goff[q]];
       };
-      auto run = [&](f32x4 (&ac)[4], bool count_bias) {
-        float a0, a1, b0[4], b1[4];
+      auto run = [&](f32x4 (&ac)[NQ], bool count_bias) {
+        float a0, a1, b0[NQ], b1[NQ];
         ld(0, a0, b0);
         for (int ks = 0; ks < M / 4; ks += 2) {
           ld(ks + 1, a1, b1);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) ac[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[q], ac[q], 0, 0, 0);
+          for (int q = 0; q < NQ; ++q) ac[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[q], ac[q], 0, 0, 0);
           if (count_bias) bsum += a0 + a1;
           if (ks + 2 < M / 4) ld(ks + 2, a0, b0);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) ac[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[q], ac[q], 0, 0, 0);
+          for (int q = 0; q < NQ; ++q) ac[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[q], ac[q], 0, 0, 0);
         }
       };
       if (ci == 0) run(acc[0], wave == 0);
@@ -254,18 +254,15 @@ __global__ __launch_bounds__(kStemThreads) void stem_wgrad_kernel(StemWgradArgs 
     }
   }
 
-  // D[i = co][j]: lane holds col j = li, rows co = lk*4 + r
+  // D[i = co][j]: lane holds column j = li (tap t), rows co = lk*4 + r
 #pragma unroll
   for (int ci = 0; ci < 3; ++ci)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (!gok[q]) continue;
-      const int g = q * 8 + wave;
-      const int kd = g >> 2, kh = 2 * (g & 3) + (li >> 3), kw = li & 7;
-      if (kh < 7 && kw < 7) {
+    for (int q = 0; q < NQ; ++q) {
+      const int t = 16 * (q * 8 + wave) + li;
+      if (t < 343) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          atomicAdd(p.dw + ((size_t)((kd * 7 + kh) * 7 + kw) * 4 + ci) * 16 + lk * 4 + r, acc[ci][q][r]);
+        for (int r = 0; r < 4; ++r) atomicAdd(p.dw + ((size_t)t * 4 + ci) * 16 + lk * 4 + r, acc[ci][q][r]);
       }
     }
   if (p.dbias && wave == 0) {
@@ -304,8 +301,8 @@ extern "C" int mr3d_stem_conv_wgrad(const float *x_ncdhw, const float *dy, float
   a.x = x_ncdhw; a.dy = dy; a.dw = dw_packed; a.dbias = dbias;
   a.N = n; a.D = d; a.H = h; a.W = w;
   a.Ho = (h + 6 - 7) / 2 + 1; a.Wo = (w + 6 - 7) / 2 + 1;
-  using G = StemGeo<4, 8, 16, 48>;
-  constexpr int lds_bytes = (G::SLAB + 4 * 8 * 16 * 16) * 4;       // 72 KiB: two workgroups per CU
+  using G = StemGeo<4, 8, 16, 40>;
+  constexpr int lds_bytes = (G::SLAB + 4 * 8 * 16 * 16) * 4;       // 65.6 KiB: two workgroups per CU
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(stem_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
