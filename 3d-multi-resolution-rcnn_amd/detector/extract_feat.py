@@ -389,28 +389,32 @@ class ExtractFeat3D(nn.Module):
         self._building = None
         return P
 
-    def _plan_for(self, shape):
-        key = tuple(shape)
+    def _plan_for(self, shape, slot=0):
+        """one plan (kernel records + every activation / gradient buffer) per input shape and slot; two forward passes
+        whose backward passes are both still pending (the two pathways of the shipped model,
+        two_stage_3d_2scales.py:149-150) must use different slots if they have the same shape"""
+        key = tuple(shape) + (int(slot),)
         if key not in self._plans:
-            self._plans[key] = self._build_plan(key)
+            self._plans[key] = self._build_plan(tuple(shape))
         return self._plans[key]
 
     # ------------------------------------------------------------------ execution
-    def forward_features(self, img):
+    def forward_features(self, img, slot=0):
         """img: [N,3,D,H,W] fp32 on the engine's device -> (P2..P6) as [N,64,d,h,w] channels_last_3d views."""
         if not img.is_cuda:
             raise NotImplementedError('ExtractFeat3D runs on the MI355X only (no CPU fallback)')
-        P = self._plan_for(img.shape)
+        P = self._plan_for(img.shape, slot)
         P.x_in.copy_(img)
         with torch.cuda.device(self.device):
             P.fwd.run(self.device)
         self._last = P
         return tuple(o.permute(0, 4, 1, 2, 3) for o in P.outs)
 
-    def backward_features(self, grads):
+    def backward_features(self, grads, plan=None):
         """grads: gradients w.r.t. the 5 pyramid outputs (any memory format; None = zero).  Accumulates parameter
-        gradients into the flat gradient arena (== every parameter's .grad)."""
-        P = self._last
+        gradients into the flat gradient arena (== every parameter's .grad).  plan: the forward pass this backward
+        belongs to (default: the most recent one)."""
+        P = plan if plan is not None else self._last
         for gbuf, g in zip(P.gouts, grads):
             if g is None:
                 gbuf.zero_()
@@ -419,10 +423,10 @@ class ExtractFeat3D(nn.Module):
         with torch.cuda.device(self.device):
             P.bwd.run(self.device)
 
-    def forward(self, img):
+    def forward(self, img, slot=0):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            return _ExtractFeatFn.apply(self, img, self._autograd_anchor())
-        return self.forward_features(img)
+            return _ExtractFeatFn.apply(self, img, self._autograd_anchor(), slot)
+        return self.forward_features(img, slot)
 
     def _autograd_anchor(self):
         if not hasattr(self, '_anchor'):
@@ -439,13 +443,14 @@ class _ExtractFeatFn(torch.autograd.Function):
     (p.grad of every parameter is a view of it), so backward returns no tensor gradients."""
 
     @staticmethod
-    def forward(ctx, engine, img, anchor):
+    def forward(ctx, engine, img, anchor, slot=0):
         ctx.engine = engine
-        outs = engine.forward_features(img)
+        outs = engine.forward_features(img, slot)
+        ctx.plan = engine._last
         return tuple(o.clone(memory_format=torch.preserve_format) for o in outs)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, *grads):
-        ctx.engine.backward_features(grads)
-        return None, None, None
+        ctx.engine.backward_features(grads, plan=ctx.plan)
+        return None, None, None, None

@@ -1,0 +1,127 @@
+"""TwoStageDetector3D2Scales.forward_train -- the SHIPPED model (mmdet/models/detectors/two_stage_3d_2scales.py:135-330,
+configs/3d-multi-resolution-rcnn.py): two pathways through ONE backbone+FPN (the region and its 1.5x up-sampled copy),
+an RPN head per pathway (anchor scales 2 / 3), a shared bbox head over both roi batches, a regression-only
+refinement head fed by pathway-2 predictions mapped back to pathway-1 coordinates, and two mask heads.
+
+Same construction as detector/two_stage.py: static shapes, device-resident counts, no host synchronisation between
+the backbone and the loss dict other than SingleRoIExtractor's level histograms.  In particular the reference's
+`.cpu().numpy()` / `torch.from_numpy().cuda()` round trip of the refinement proposals (:263-267) stays on the
+device, and padding rows of the pathway-2 roi batch are masked out of the refinement assigner."""
+from types import SimpleNamespace
+
+import torch
+
+from .. import _hip
+from ..core.bbox import build_assigner, build_sampler, delta2bbox3D
+from ..core.mask import mask_target_single
+from .heads import RPNHead3D, SharedFCBBoxHead3D, FCNMaskHead3D
+from .roi_extractor import SingleRoIExtractor
+from .two_stage import TwoStageDetector3D
+
+
+class TwoStageDetector3D2Scales(TwoStageDetector3D):
+
+    def __init__(self, device='cuda', train_cfg=None, test_cfg=None):
+        super().__init__(device=device, train_cfg=train_cfg, test_cfg=test_cfg, with_mask=True)
+        strides, dstrides = [4, 8, 16, 32], [2, 4, 8, 16]
+        self.rpn_head_2 = RPNHead3D(anchor_scales=(3,), anchor_depth_scales=(3,)).to(self.device)      # configs/...py:28-39
+        self.bbox_roi_extractor_refinement = SingleRoIExtractor(
+            dict(type='RoIAlign3D', out_size=7, out_size_depth=3, sample_num=2), 64, strides, dstrides)
+        self.refinement_head = SharedFCBBoxHead3D(with_cls=False).to(self.device)                      # configs/...py:57-67
+        self.refinement_mask_roi_extractor = SingleRoIExtractor(
+            dict(type='RoIAlign3D', out_size=14, out_size_depth=10, sample_num=2), 64, strides, dstrides)
+        self.refinement_mask_head = FCNMaskHead3D().to(self.device)                                    # configs/...py:80-85
+
+    # ------------------------------------------------------------------ shared pieces
+    def _sample(self, proposals, gt, gl, draws, batch_index, inside=None):
+        """assign + add gts + sample + targets for one image -> dict of fixed-capacity tensors (two_stage_3d_2scales.py
+        :182-226 / :268-288)"""
+        rc = self.train_cfg['rcnn']
+        assigner, sampler = build_assigner(rc['assigner']), build_sampler(rc['sampler'])
+        cap = sampler.num
+        gt = gt.float()
+        ar = assigner.assign(proposals, gt, None, gl, inside_flags=inside)
+        assigned_all = _hip.concat_gt_assign(ar.gt_inds, gt.size(0))
+        dp, dn = draws if draws is not None else (None, None)
+        pos, neg, cnt, _ = _hip.random_sample(assigned_all, cap, sampler.pos_fraction, sampler.neg_pos_ub, dp, dn)
+        rois, lab, lw, bt, bw, pgi = _hip.bbox_target3d(proposals, gt, gl, assigned_all, pos, neg, cnt, cap, batch_index,
+                                                        self.bbox_head.target_means, self.bbox_head.target_stds,
+                                                        float(rc['pos_weight']))
+        return dict(rois=rois, labels=lab, label_weights=lw, bbox_targets=bt, bbox_weights=bw, pos_gt=pgi, counts=cnt,
+                    cap_pos=int(cap * sampler.pos_fraction))
+
+    def _mask_loss(self, extractor, head, x, s, gt_masks, key):
+        rc = self.train_cfg['rcnn']
+        pos_rois = s['rois'][:s['cap_pos']].contiguous()
+        mask_pred = head(extractor(x[:extractor.num_inputs], pos_rois))
+        gi = s['pos_gt'][:s['cap_pos']].clamp(min=0)
+        targets = mask_target_single(pos_rois[:, 1:], gi, gt_masks, SimpleNamespace(**rc))
+        loss = head.loss(mask_pred, targets, s['labels'][:s['cap_pos']], valid_rows=s['counts'][0].reshape(1))
+        return {key: loss['loss_mask']}
+
+    # ------------------------------------------------------------------ forward_train
+    def forward_train(self, imgs, img_meta, imgs_2, img_meta_2, gt_bboxes, gt_bboxes_2, gt_labels, gt_labels_2,
+                      gt_bboxes_ignore=None, gt_masks=None, gt_masks_2=None, proposals=None, draws=None):
+        assert imgs.shape[1] == 3 and imgs_2.shape[1] == 3                     # :148
+        assert imgs.size(0) == 1, 'imgs_per_gpu = 1 (configs/...py:191)'
+        draws = draws or {}
+        cfg = self.train_cfg
+        x = self.extract(imgs, 0)
+        x_2 = self.extract(imgs_2, 1)
+        losses = dict()
+
+        # ---- RPN forward, losses, proposals (:155-176); the second head's loss keys carry the _2 suffix (rpn_head_3d.py:63-65)
+        rpn_outs, rpn_outs_2 = self.rpn_head(x), self.rpn_head_2(x_2)
+        losses.update(self.rpn_head.loss(*rpn_outs, gt_bboxes, img_meta, cfg['rpn'], draws_list=draws.get('rpn')))
+        l2 = self.rpn_head_2.loss(*rpn_outs_2, gt_bboxes_2, img_meta_2, cfg['rpn'], draws_list=draws.get('rpn_2'))
+        losses.update(loss_rpn_cls_2=l2['loss_rpn_cls'], loss_rpn_reg_2=l2['loss_rpn_reg'])
+        with torch.no_grad():
+            pcfg = SimpleNamespace(**cfg['rpn_proposal'])
+            proposal_list = self.rpn_head.get_bboxes(*rpn_outs, img_meta, pcfg)
+            proposal_list_2 = self.rpn_head_2.get_bboxes(*rpn_outs_2, img_meta_2, pcfg)
+
+        # ---- assign / sample both pathways (:182-226)
+        s1 = self._sample(proposal_list[0], gt_bboxes[0], gt_labels[0], draws.get('rcnn', [None])[0], 0)
+        s2 = self._sample(proposal_list_2[0], gt_bboxes_2[0], gt_labels_2[0], draws.get('rcnn_2', [None])[0], 0)
+
+        # ---- shared bbox head over both roi batches (:229-257)
+        feats = self.bbox_roi_extractor(x[:4], s1['rois'])
+        feats_2 = self.bbox_roi_extractor(x_2[:4], s2['rois'])
+        cls_score, bbox_pred = self.bbox_head(feats)
+        cls_score_2, bbox_pred_2 = self.bbox_head(feats_2)
+        cat = lambda k: torch.cat((s1[k], s2[k]), 0)
+        counts12 = torch.stack((s1['counts'], s2['counts']))
+        num_rois = _hip.avg_factor_from_counts(counts12, 1)                  # bbox_targets.size(0) of the concatenated batch
+        lb = self.bbox_head.loss(torch.cat((cls_score, cls_score_2), 0), torch.cat((bbox_pred, bbox_pred_2), 0),
+                                 cat('labels'), cat('label_weights'), cat('bbox_targets'), cat('bbox_weights'), num_rois=num_rois)
+        # accuracy over the REAL rows of both batches: per-batch accuracies weighted by their row counts
+        from ..core.loss import accuracy
+        n1 = (s1['counts'][0] + s1['counts'][1]).reshape(1)
+        n2 = (s2['counts'][0] + s2['counts'][1]).reshape(1)
+        a1 = accuracy(cls_score, s1['labels'], valid_rows=n1.to(torch.int32))
+        a2 = accuracy(cls_score_2, s2['labels'], valid_rows=n2.to(torch.int32))
+        lb['acc'] = (a1 * n1 + a2 * n2) / (n1 + n2).clamp(min=1)
+        losses.update(lb)
+
+        # ---- refinement head (:259-298): pathway-2 class-1 boxes, mapped back to pathway-1 coordinates, + logit as score
+        meta1, meta2 = img_meta[0], img_meta_2[0]
+        upscaled_factor = meta2['ori_shape'][0] / meta1['ori_shape'][0]
+        with torch.no_grad():
+            dec = delta2bbox3D(s2['rois'][:, 1:].contiguous(), bbox_pred_2.detach().contiguous(), self.bbox_head.target_means,
+                               self.bbox_head.target_stds, meta2['img_shape'])[:, 6:] / upscaled_factor
+            pred_2 = torch.cat((dec, cls_score_2.detach()[:, 1, None]), 1).contiguous()
+            real_2 = torch.arange(pred_2.size(0), device=pred_2.device) < n2          # padding rows never become candidates
+        sr = self._sample(pred_2, gt_bboxes[0], gt_labels[0], draws.get('refine', [None])[0], 0, inside=real_2)
+        feats_r = self.bbox_roi_extractor_refinement(x[:4], sr['rois'])
+        _, refined_pred = self.refinement_head(feats_r)
+        lr = self.refinement_head.loss(None, refined_pred, sr['labels'], sr['label_weights'], sr['bbox_targets'],
+                                       sr['bbox_weights'], num_rois=_hip.avg_factor_from_counts(sr['counts'].reshape(1, -1), 1))
+        losses['loss_refinement_reg'] = lr['loss_reg']                                 # bbox_head_3d_refinement.py:113-118
+
+        # ---- mask heads on the positives of pathway 1 and of the refinement samples (:301-327)
+        losses.update(self._mask_loss(self.mask_roi_extractor, self.mask_head, x, s1, gt_masks[0], 'loss_mask'))
+        losses.update(self._mask_loss(self.refinement_mask_roi_extractor, self.refinement_mask_head, x, sr, gt_masks[0],
+                                      'loss_mask_refinement'))
+        self.last_sample_counts = torch.stack((s1['counts'], s2['counts'], sr['counts']))
+        self.iteration += 1
+        return losses

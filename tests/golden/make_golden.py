@@ -146,6 +146,8 @@ def import_reference():
     ref.RPNHead3D = importlib.import_module('mmdet.models.anchor_heads.rpn_head_3d').RPNHead3D
     ref.SharedFCBBoxHead3D = importlib.import_module('mmdet.models.bbox_heads.convfc_bbox_head_3d').SharedFCBBoxHead3D
     ref.FCNMaskHead3D = importlib.import_module('mmdet.models.mask_heads.fcn_mask_head_3d').FCNMaskHead3D
+    ref.SharedFCBBoxHead3DRefinement = importlib.import_module(
+        'mmdet.models.bbox_heads.convfc_bbox_head_3d_refinement_head').SharedFCBBoxHead3DRefinement
     return ref
 
 
@@ -484,6 +486,17 @@ def make_state_dict_keys(ref, out):
     sd = {k: list(v.shape) for k, v in m.state_dict().items()}
     json.dump(sd, open(out, 'w'), indent=0, sort_keys=True)
     print(f'  state dict: {len(sd)} entries, {sum(int(np.prod(v)) for v in sd.values())} elements')
+    # the shipped dual-pathway model (two_stage_3d_2scales.py:33-86, configs/...py:16-85)
+    m.rpn_head_2 = ref.RPNHead3D(in_channels=64, feat_channels=64, anchor_scales=[3], anchor_depth_scales=[3], anchor_ratios=[1.0],
+                                 anchor_strides=[4, 8, 16, 32, 64], anchor_strides_depth=[2, 4, 8, 16, 32],
+                                 target_means=[.0] * 6, target_stds=[1.0] * 6, use_sigmoid_cls=True)
+    m.refinement_head = ref.SharedFCBBoxHead3DRefinement(num_fcs=2, in_channels=64, fc_out_channels=1024, roi_feat_size=7,
+                                                         roi_feat_size_depth=3, num_classes=2, target_means=[0.] * 6,
+                                                         target_stds=[0.1, 0.1, 0.2, 0.2, 0.1, 0.1], reg_class_agnostic=False)
+    m.refinement_mask_head = ref.FCNMaskHead3D(num_convs=4, in_channels=64, conv_out_channels=64, num_classes=2)
+    sd2 = {k: list(v.shape) for k, v in m.state_dict().items()}
+    json.dump(sd2, open(out.replace('.json', '_2scales.json'), 'w'), indent=0, sort_keys=True)
+    print(f'  state dict (2 scales): {len(sd2)} entries')
 
 
 if __name__ == '__main__':

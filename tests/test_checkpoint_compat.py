@@ -42,3 +42,16 @@ def test_reference_checkpoint_round_trip_with_module_prefix_and_extra_heads():
     w = det.extract.get_parameter('backbone.layer2.0.conv2.weight')
     assert torch.equal(w.detach(), ckpt['module.backbone.layer2.0.conv2.weight'])
     assert w.data_ptr() >= det.extract.flat_params.data_ptr()
+
+
+def test_shipped_dual_pathway_model_state_dict_equals_reference():
+    """MaskRCNN3D2Scales as configs/3d-multi-resolution-rcnn.py builds it (rpn_head_2, refinement_head without a
+    classifier, refinement_mask_head): same checkpoint keys and shapes"""
+    import mr3d_amd  # noqa: F401
+    from mr3d_amd.detector import TwoStageDetector3D2Scales
+    det = TwoStageDetector3D2Scales(device='cpu')
+    ref = json.load(open(os.path.join(HERE, 'golden', 'state_dict_keys_2scales.json')))
+    sd = det.state_dict()
+    assert sorted(sd) == sorted(ref)
+    for k, shape in ref.items():
+        assert list(sd[k].shape) == shape, k

@@ -137,3 +137,51 @@ def test_simple_test_inference_path(dev):
     # same proposals in, same detections out (no hidden state, deterministic NMS)
     b2, _ = det.simple_test(img, meta, rescale=True)
     assert np.array_equal(b, b2[0])
+
+
+def test_shipped_dual_pathway_forward_train(dev):
+    """two_stage_3d_2scales.py:135-330 on a 128x128x32 region and its 1.5x copy: loss dict of the reference, finite,
+    deterministic under fixed sampler words, gradients reach every head and the shared backbone from BOTH pathways."""
+    from mr3d_amd.detector import TwoStageDetector3D2Scales
+    from mr3d_amd.datasets import prepare_volume
+    torch.manual_seed(3)
+    det = TwoStageDetector3D2Scales(device=dev)
+    det.extract.init_weights()
+    rng = np.random.default_rng(3)
+    grey = (rng.random((128, 128, 32)) * 255).astype(np.float32)
+    img, meta = prepare_volume(grey)
+    img_2, meta_2 = prepare_volume(grey, upscale=1.5)
+    assert tuple(img_2.shape) == (1, 3, 48, 192, 192)
+    gt = np.array([[20, 30, 60, 75, 4, 20], [70, 20, 110, 64, 10, 28], [40, 80, 90, 120, 2, 14]], np.float32)
+    masks = np.zeros((3, 32, 128, 128), np.uint8)
+    for k, b in enumerate(gt.astype(int)):
+        masks[k, b[4]:b[5] + 1, b[1]:b[3] + 1, b[0]:b[2] + 1] = 1
+    gt_t = torch.from_numpy(gt).to(dev)
+    gl = torch.ones(3, dtype=torch.long, device=dev)
+    w = lambda n: rng.integers(0, 2 ** 31 - 1, n)
+    draws = {k: [(w(128), w(256))] for k in ('rpn', 'rpn_2')}
+    draws.update({k: [(w(128), w(512))] for k in ('rcnn', 'rcnn_2', 'refine')})
+    args = (img, [meta], img_2, [meta_2], [gt_t], [gt_t * 1.5], [gl], [gl])
+    det.extract.zero_grad()
+    losses = det.forward_train(*args, gt_masks=[torch.from_numpy(masks).to(dev)], draws=draws)
+    assert set(losses) == {'loss_rpn_cls', 'loss_rpn_reg', 'loss_rpn_cls_2', 'loss_rpn_reg_2', 'loss_cls', 'acc', 'loss_reg',
+                           'loss_refinement_reg', 'loss_mask', 'loss_mask_refinement'}
+    total = det.total_loss(losses)
+    assert torch.isfinite(total)
+    total.backward()
+    for name, p in det.named_parameters():
+        if name.startswith('extract.'):
+            continue
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+    g = det.extract.flat_grads.clone()
+    assert torch.isfinite(g).all() and g.abs().sum() > 0
+    c = det.last_sample_counts.cpu().numpy()
+    assert (c[:, 0] >= 3).all() and (c[:, 0] + c[:, 1] <= 512).all()          # the gts are always positives
+    # second run: identical losses; and pathway 2 alone contributes backbone gradient (remove it -> different arena)
+    losses2 = det.forward_train(*args, gt_masks=[torch.from_numpy(masks).to(dev)], draws=draws)
+    for k in ('loss_cls', 'loss_reg', 'loss_refinement_reg', 'loss_mask', 'loss_mask_refinement'):
+        assert torch.equal(losses[k], losses2[k]), k
+    det.extract.zero_grad()
+    (sum(t.sum() for t in losses2['loss_rpn_cls_2']) + sum(t.sum() for t in losses2['loss_rpn_reg_2'])).backward()
+    g2 = det.extract.flat_grads
+    assert g2.abs().sum() > 0 and not torch.equal(g2, g)
