@@ -11,7 +11,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mr3d_amd  # noqa: E402
-from mr3d_amd.detector import TwoStageDetector3D  # noqa: E402
+from mr3d_amd.detector import TwoStageDetector3D, TwoStageDetector3D2Scales  # noqa: E402
 
 
 def synthetic_gt(rng, n, D, H, W, dev):
@@ -33,6 +33,7 @@ def main():
     ap.add_argument('--gts', type=int, default=12)
     ap.add_argument('--repeats', type=int, default=1)
     ap.add_argument('--none-grads', action='store_true')
+    ap.add_argument('--two-scales', action='store_true', help='the shipped dual-pathway model (region + its 1.5x copy)')
     ap.add_argument('--json', action='store_true', help='print one JSON line with the step time')
     ap.add_argument('--no-mask', action='store_true')
     ap.add_argument('--profile', action='store_true', help='torch profiler table of one step')
@@ -40,20 +41,27 @@ def main():
     D, H, W = (int(v) for v in a.vol.split(','))
     dev = torch.device('cuda:0')
     torch.manual_seed(0)
-    det = TwoStageDetector3D(device=dev, with_mask=not a.no_mask)
+    det = TwoStageDetector3D2Scales(device=dev) if a.two_scales else TwoStageDetector3D(device=dev, with_mask=not a.no_mask)
     det.extract.init_weights()
     rng = np.random.default_rng(0)
     img = torch.randn(1, 3, D, H, W, device=dev)
     gt, masks = synthetic_gt(rng, a.gts, D, H, W, dev)
     gl = torch.ones(a.gts, dtype=torch.long, device=dev)
-    meta = [dict(img_shape=(H, W, 3, D), pad_shape=(H, W, 3, D))]
+    meta = [dict(img_shape=(H, W, 3, D), pad_shape=(H, W, 3, D), ori_shape=(H, W, 3))]
+    if a.two_scales:
+        D2, H2, W2 = int(round(D * 1.5)), int(round(H * 1.5)), int(round(W * 1.5))
+        img_2 = torch.randn(1, 3, D2, H2, W2, device=dev)
+        meta_2 = [dict(img_shape=(H2, W2, 3, D2), pad_shape=(H2, W2, 3, D2), ori_shape=(H2, W2, 3))]
 
     def step():
         det.extract.zero_grad()
         if a.none_grads:
-            for m in (det.rpn_head, det.bbox_head) + ((det.mask_head,) if det.with_mask else ()):
+            for m in [c for n_, c in det.named_children() if n_ != 'extract']:
                 m.zero_grad(set_to_none=True)
-        losses = det.forward_train(img, meta, [gt], [gl], gt_masks=[masks])
+        if a.two_scales:
+            losses = det.forward_train(img, meta, img_2, meta_2, [gt], [gt * 1.5], [gl], [gl], gt_masks=[masks])
+        else:
+            losses = det.forward_train(img, meta, [gt], [gl], gt_masks=[masks])
         tot = det.total_loss(losses)
         tot.backward()
         return losses
