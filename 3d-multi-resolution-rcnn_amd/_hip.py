@@ -286,11 +286,26 @@ class Plan:
             raise Mr3dError(f'mr3d_plan_run: op #{k} (kind {self.array[k].kind}) failed: '
                             f'{lib().mr3d_status_string(int(st)).decode()}')
 
+    def capture(self):
+        """hipGraph of the whole plan (mr3d_plan_capture); later run() calls without marks replay it"""
+        g = ctypes.c_void_p()
+        check(lib().mr3d_plan_capture(self.array, self.n, ctypes.byref(g)), 'mr3d_plan_capture')
+        self._graph = g
+        return self
+
+    def __del__(self):
+        g = getattr(self, '_graph', None)
+        if g is not None and _lib is not None:
+            _lib.mr3d_graph_destroy(g)
+
     def run(self, device=None, marks=None):
         """Enqueue every op on torch's current stream.  marks: optional sorted op indices to bracket with
         torch.cuda.Event pairs (same stream as the kernels); returns {index: (start_event, end_event)}."""
         if not marks:
-            self._run_range(0, self.n, device)
+            if getattr(self, '_graph', None) is not None:
+                check(lib().mr3d_graph_launch(self._graph, stream_ptr(device)), 'mr3d_graph_launch')
+            else:
+                self._run_range(0, self.n, device)
             return {}
         ev, pos = {}, 0
         for k in marks:

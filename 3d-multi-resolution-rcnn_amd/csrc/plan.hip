@@ -149,3 +149,50 @@ extern "C" int mr3d_plan_run(const mr3d_op *ops, int num_ops, int *failed_index,
   }
   return join() ? MR3D_OK : MR3D_ERR_LAUNCH;
 }
+
+// ---------------------------------------------------------------------------------------------- hipGraph replay
+// A plan touches only pre-allocated buffers and passes every scalar by value, so its whole launch sequence --
+// side-stream forks and joins included -- can be captured ONCE and replayed with a single hipGraphLaunch: the
+// ~170 / ~330 launches of a forward / backward pass then cost no per-kernel host work and the device sees the
+// dependency edges instead of two in-order queues.
+struct mr3d_graph {
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+};
+
+extern "C" int mr3d_plan_capture(const mr3d_op *ops, int num_ops, mr3d_graph **out) {
+  if (!ops || num_ops <= 0 || !out) return MR3D_ERR_INVALID_ARG;
+  static hipStream_t cap = nullptr;
+  if (!cap && hipStreamCreateWithFlags(&cap, hipStreamNonBlocking) != hipSuccess) return MR3D_ERR_LAUNCH;
+  if (hipStreamBeginCapture(cap, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); return MR3D_ERR_LAUNCH; }
+  int failed = -1;
+  const int st = mr3d_plan_run(ops, num_ops, &failed, (mr3d_stream_t)cap);
+  mr3d_graph *g = new mr3d_graph();
+  const hipError_t e = hipStreamEndCapture(cap, &g->graph);
+  if (st != MR3D_OK || e != hipSuccess || !g->graph) {
+    (void)hipGetLastError();
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    delete g;
+    return st != MR3D_OK ? st : MR3D_ERR_LAUNCH;
+  }
+  if (hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipGraphDestroy(g->graph);
+    delete g;
+    return MR3D_ERR_LAUNCH;
+  }
+  *out = g;
+  return MR3D_OK;
+}
+
+extern "C" int mr3d_graph_launch(mr3d_graph *g, mr3d_stream_t stream) {
+  if (!g || !g->exec) return MR3D_ERR_INVALID_ARG;
+  return hipGraphLaunch(g->exec, mr3d_stream(stream)) == hipSuccess ? MR3D_OK : MR3D_ERR_LAUNCH;
+}
+
+extern "C" void mr3d_graph_destroy(mr3d_graph *g) {
+  if (!g) return;
+  if (g->exec) (void)hipGraphExecDestroy(g->exec);
+  if (g->graph) (void)hipGraphDestroy(g->graph);
+  delete g;
+}

@@ -314,10 +314,14 @@ extern "C" int mr3d_stem_conv_wgrad(const float *x_ncdhw, const float *dy, float
   }
   const int td = (d + 3) / 4, th = (a.Ho + 7) / 8, tw = (a.Wo + 15) / 16;
   int tiles = n * td * th * tw;
-  int dev = 0, cus = 256;
-  hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-    cus = prop.multiProcessorCount;
+  static int cus = 0;        // queried once: hipGetDeviceProperties is slow and must not run inside a stream capture
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+  }
   const int grid = tiles < 2 * cus ? tiles : 2 * cus;
   stem_wgrad_kernel<<<(unsigned)grid, kStemThreads, lds_bytes, mr3d_stream(stream_)>>>(a, td, th, tw);
   return mr3d_launch_status();

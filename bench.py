@@ -232,6 +232,10 @@ def main():
     marks_f = sorted(k for w_, k in groups[dom]['ops'] if w_ == 'f')
     marks_b = sorted(k for w_, k in groups[dom]['ops'] if w_ == 'b')
 
+    if os.environ.get('MR3D_BENCH_GRAPH') == '1':          # A/B: hipGraph replay (no per-kernel event brackets possible)
+        plan.fwd.capture(); plan.bwd.capture()
+        marks_f = marks_b = None
+        step(); torch.cuda.synchronize()
     # ---- timed region: exactly K steps between barrier + synchronize on both sides
     if world > 1:
         dist.barrier()
@@ -267,7 +271,7 @@ def main():
     if rank == 0:
         dom_ms = sum(s.elapsed_time(e) for e1, e2 in dom_events for (s, e) in list(e1.values()) + list(e2.values()))
         launches = a.steps * groups[dom]['n']
-        ach = groups[dom]['flops'] * a.steps / (dom_ms * 1e-3)
+        ach = groups[dom]['flops'] * a.steps / (dom_ms * 1e-3) if dom_ms > 0 else 0.0
         ms_per_step = el * 1e3 / a.steps
         res = {
             'metric': 'train iters/sec on 512x512x80 vols (ResNet3D-50+FPN3D forward+backward, fp32)',
@@ -280,7 +284,7 @@ def main():
                        'global_batch': world, 'parallelism': f'dp{world}'},
             'roofline': {'bound': 'mfma', 'kernel': dom, 'achieved': ach / 1e12, 'peak': PEAK_FP32_MATRIX / 1e12,
                          'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_MATRIX, 'traffic': committed_traffic(dom),
-                         'avg_launch_ms': dom_ms / launches, 'launches_per_step': groups[dom]['n'],
+                         'avg_launch_ms': dom_ms / launches if launches else None, 'launches_per_step': groups[dom]['n'],
                          'whole_step_frac': FLOP_FWD_BWD_512 * scale / (ms_per_step * 1e-3) / PEAK_FP32_MATRIX},
         }
         if world == 1 and not a.no_aux:

@@ -391,6 +391,13 @@ int mr3d_plan_run(const mr3d_op *ops_host, int num_ops, int *failed_index_host, 
  * (fork by event before the op, join before FINISH_GRADS and at the end of the call); they only read activations
  * and add into their own scratch slice.  0 disables the side stream (everything on `stream`); default 1. */
 void mr3d_plan_set_side_stream(int enable);
+/* hipGraph replay of a plan: capture the launch sequence once (every buffer it names must stay allocated; run the
+ * plan normally at least once BEFORE capturing so that one-time kernel attributes are set), then replay it with
+ * one call per pass.  The graph is launched into `stream`. */
+typedef struct mr3d_graph mr3d_graph;
+int mr3d_plan_capture(const mr3d_op *ops_host, int num_ops, mr3d_graph **out);
+int mr3d_graph_launch(mr3d_graph *g, mr3d_stream_t stream);
+void mr3d_graph_destroy(mr3d_graph *g);
 
 #ifdef __cplusplus
 }
