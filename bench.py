@@ -173,8 +173,11 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     import torch.distributed as dist
-    if world > 1:
+    force_dist = os.environ.get('MR3D_BENCH_FORCE_DIST') == '1'      # exercise the RCCL path on a 1-GPU box
+    if world > 1 or force_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=dev)          # backend "nccl" is RCCL on ROCm
 
     import mr3d_amd
@@ -202,6 +205,8 @@ def main():
         evb = plan.bwd.run(dev, marks_b)
         if world > 1:
             allreduce_flat_grads(eng.flat_grads, world)
+        elif force_dist:
+            dist.all_reduce(eng.flat_grads)              # world 1: still launches RCCL's kernel on its own stream
         return ev, evb
 
     # ---- warmup; the last warmup step is bracketed op by op to find the dominant kernel
@@ -301,7 +306,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(a.cpu_seconds)
         print(json.dumps(res))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 
