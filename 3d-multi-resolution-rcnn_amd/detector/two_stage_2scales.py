@@ -12,11 +12,12 @@ from types import SimpleNamespace
 import torch
 
 from .. import _hip
-from ..core.bbox import build_assigner, build_sampler, delta2bbox3D
+from ..core.bbox import build_assigner, build_sampler, delta2bbox3D, bbox2roi3D
+from ..core.post_processing import multiclass_nms_3d
 from ..core.mask import mask_target_single
 from .heads import RPNHead3D, SharedFCBBoxHead3D, FCNMaskHead3D
 from .roi_extractor import SingleRoIExtractor
-from .two_stage import TwoStageDetector3D
+from .two_stage import TwoStageDetector3D, bbox2result3D
 
 
 class TwoStageDetector3D2Scales(TwoStageDetector3D):
@@ -125,3 +126,43 @@ class TwoStageDetector3D2Scales(TwoStageDetector3D):
         self.last_sample_counts = torch.stack((s1['counts'], s2['counts'], sr['counts']))
         self.iteration += 1
         return losses
+
+    # ------------------------------------------------------------------ inference
+    @torch.no_grad()
+    def simple_test(self, imgs, img_metas, imgs_2, img_metas_2, proposals=None, rescale=False):
+        """two_stage_3d_2scales.py:335-383 with the shipped `return_bbox_only=True` (configs/...py:144): both pathways'
+        per-class boxes (pathway 2 through the refinement head on pathway-1 features), ONE multiclass NMS3D over the
+        union.  rescale=True divides pathway-2 boxes by img_metas_2[0]['scale_factor'] (1.5), which brings them into
+        pathway-1 coordinates before the refinement RoIAlign, exactly as the reference's get_det_bboxes does."""
+        assert imgs.size(0) == 1
+        cfg = self.test_cfg
+        meta, meta_2 = img_metas[0], img_metas_2[0]
+        x = self.extract.forward_features(imgs, 0)
+        x_2 = self.extract.forward_features(imgs_2, 1)
+        rcfg = SimpleNamespace(**cfg['rpn'])
+        if proposals is None:
+            proposal_list = self.rpn_head.get_bboxes(*self.rpn_head(x), img_metas, rcfg)
+            proposal_list_2 = self.rpn_head_2.get_bboxes(*self.rpn_head_2(x_2), img_metas_2, rcfg)
+        else:
+            proposal_list = proposal_list_2 = proposals
+
+        def bboxes_scores(feats, props, m):                                  # test_mixins_3d.py simple_test_bboxes, cfg=None
+            rois = bbox2roi3D(props)
+            cls_score, bbox_pred = self.bbox_head(self.bbox_roi_extractor(feats[:4], rois))
+            return self.bbox_head.get_det_bboxes(rois, cls_score, bbox_pred, m['img_shape'], m.get('scale_factor', 1.0),
+                                                 rescale=rescale, cfg=None)
+        bboxes, scores = bboxes_scores(x, proposal_list, meta)
+        bboxes_2, scores_2 = bboxes_scores(x_2, proposal_list_2, meta_2)
+        # refinement (test_mixins_3d.py:102-128): class-1 boxes of pathway 2 + their score -> RoIAlign on PATHWAY-1 features
+        ref_in = [torch.cat((bboxes_2[:, 6:], scores_2[:, 1, None]), dim=1)]
+        rois_r = bbox2roi3D(ref_in)
+        _, pred_r = self.refinement_head(self.bbox_roi_extractor_refinement(x[:4], rois_r))
+        bboxes_2_ref = delta2bbox3D(rois_r[:, 1:].contiguous(), pred_r.contiguous(), self.refinement_head.target_means,
+                                    self.refinement_head.target_stds, meta['img_shape'])
+        if rescale:
+            bboxes_2_ref = bboxes_2_ref / meta.get('scale_factor', 1.0)
+        rc = cfg['rcnn']
+        det_bboxes, det_labels = multiclass_nms_3d(torch.cat((bboxes, bboxes_2_ref), 0), torch.cat((scores, scores_2), 0),
+                                                   rc['score_thr'], dict(rc['nms']), rc['max_per_img'])
+        self.last_det = (det_bboxes, det_labels)
+        return bbox2result3D(det_bboxes, det_labels, self.bbox_head.num_classes)

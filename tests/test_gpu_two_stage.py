@@ -185,3 +185,25 @@ def test_shipped_dual_pathway_forward_train(dev):
     (sum(t.sum() for t in losses2['loss_rpn_cls_2']) + sum(t.sum() for t in losses2['loss_rpn_reg_2'])).backward()
     g2 = det.extract.flat_grads
     assert g2.abs().sum() > 0 and not torch.equal(g2, g)
+
+
+def test_shipped_dual_pathway_simple_test(dev):
+    """two_stage_3d_2scales.py:335-383 (return_bbox_only): detections of both pathways in pathway-1 coordinates"""
+    from mr3d_amd.detector import TwoStageDetector3D2Scales
+    from mr3d_amd.datasets import prepare_volume
+    torch.manual_seed(4)
+    det = TwoStageDetector3D2Scales(device=dev)
+    det.extract.init_weights()
+    det.test_cfg = dict(rpn=dict(nms_across_levels=False, nms_pre=200, nms_post=200, max_num=200, nms_thr=0.7, min_bbox_size=0),
+                        rcnn=dict(score_thr=0.0, nms=dict(type='nms', iou_thr=0.5), max_per_img=30, mask_thr_binary=0.5))
+    grey = (np.random.default_rng(4).random((128, 128, 32)) * 255).astype(np.float32)
+    img, meta = prepare_volume(grey)
+    img_2, meta_2 = prepare_volume(grey, upscale=1.5)
+    meta_2['scale_factor'] = 1.5
+    res = det.simple_test(img, [meta], img_2, [meta_2], rescale=True)
+    assert len(res) == 1 and res[0].shape[1] == 7 and 0 < res[0].shape[0] <= 30
+    b = res[0]
+    assert (b[:, [0, 1, 4]] >= 0).all() and (b[:, 2] <= 127).all() and (b[:, 3] <= 127).all() and (b[:, 5] <= 31).all()
+    assert (np.diff(b[:, 6]) <= 1e-7).all() or b.shape[0] < 30          # top-k by score when truncated
+    res2 = det.simple_test(img, [meta], img_2, [meta_2], rescale=True)
+    assert np.array_equal(res[0], res2[0])
