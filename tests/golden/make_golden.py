@@ -21,6 +21,8 @@ Vectors written (each is {inputs..., expected...}):
                    (numpy's randint draws are RECORDED so that they can be replayed), anchor/anchor_target.py:114-216,
                    bbox/bbox_target.py:139-165
   losses.npz       mmdet/core/loss/losses.py (weighted BCE / CE / smooth-L1, accuracy, mask BCE): values + gradients
+  eval3d.npz (+ _input.json, _nms.npz)  pycocotools_local/cocoeval.py COCOeval(is3D=True, 'bbox') precision / recall /
+                   stats on a synthetic set; coco_utils.py:245-282 nms_3d_python on a record list
   state_dict_keys.json  checkpoint key -> shape of backbone / neck / rpn_head / bbox_head / mask_head as the shipped
                    config builds them (checkpoint compatibility)
 
@@ -499,9 +501,79 @@ def make_state_dict_keys(ref, out):
     print(f'  state dict (2 scales): {len(sd2)} entries')
 
 
+class _FakeCOCO:
+    """the four accessors pycocotools_local/cocoeval.py uses (:90-92,:122-135)"""
+
+    def __init__(self, anns):
+        self.anns = {a['id']: a for a in anns}
+
+    def getAnnIds(self, imgIds=(), catIds=()):
+        return [a['id'] for a in self.anns.values() if (len(imgIds) == 0 or a['image_id'] in imgIds) and
+                (len(catIds) == 0 or a['category_id'] in catIds)]
+
+    def loadAnns(self, ids):
+        return [self.anns[i] for i in ids]
+
+    def getImgIds(self):
+        return sorted({a['image_id'] for a in self.anns.values()})
+
+    def getCatIds(self):
+        return sorted({a['category_id'] for a in self.anns.values()})
+
+
+def make_eval(ref, out):
+    """pycocotools_local/cocoeval.py COCOeval(is3D=True, iouType='bbox'): evaluate -> accumulate -> summarize on a synthetic
+    6-volume / 2-category set; boxes in the evaluator's [x, y, w, h, z, d] format (coco_utils.py:233-242)."""
+    import contextlib
+    import copy
+    import io
+    if not hasattr(np, 'float'):
+        np.float = float            # the reference targets numpy < 1.24 (cocoeval.py:597)
+    spec = importlib.util.spec_from_file_location('ref_cocoeval', f'{REF}/pycocotools_local/cocoeval.py')
+    ce = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ce)
+    rng = np.random.default_rng(11)
+    gts, dts, gid, did = [], [], 1, 1
+    for img in range(1, 7):
+        for cat in (1, 2):
+            n = int(rng.integers(0, 6))
+            for _ in range(n):
+                x, y, z = rng.uniform(0, 400, 2).tolist() + [float(rng.uniform(0, 60))]
+                w, h, d = rng.uniform(6, 120, 2).tolist() + [float(rng.uniform(3, 18))]
+                box = [float(x), float(y), float(w), float(h), float(z), float(d)]
+                gts.append(dict(id=gid, image_id=img, category_id=cat, bbox=box, area=float(w * h), iscrowd=int(rng.random() < 0.1)))
+                gid += 1
+                for _ in range(int(rng.integers(0, 3))):        # detections around this gt
+                    j = rng.normal(0, 0.12, 6) * np.array([w, h, w, h, d, d])
+                    b = [box[0] + j[0], box[1] + j[1], max(box[2] + j[2], 1.0), max(box[3] + j[3], 1.0), box[4] + j[4], max(box[5] + j[5], 1.0)]
+                    dts.append(dict(id=did, image_id=img, category_id=cat, bbox=[float(v) for v in b], area=float(b[2] * b[3]),
+                                    score=float(rng.random()), iscrowd=0))
+                    did += 1
+            for _ in range(int(rng.integers(0, 4))):            # false positives
+                b = rng.uniform(0, 400, 2).tolist() + rng.uniform(6, 100, 2).tolist() + [float(rng.uniform(0, 60)), float(rng.uniform(3, 18))]
+                dts.append(dict(id=did, image_id=img, category_id=cat, bbox=[float(v) for v in b], area=float(b[2] * b[3]),
+                                score=float(rng.random()), iscrowd=0))
+                did += 1
+    E = ce.COCOeval(_FakeCOCO(copy.deepcopy(gts)), _FakeCOCO(copy.deepcopy(dts)), 'bbox', is3D=True)
+    with contextlib.redirect_stdout(io.StringIO()):
+        E.evaluate(); E.accumulate(); E.summarize()
+    import json
+    json.dump(dict(gts=gts, dts=dts), open(out.replace('.npz', '_input.json'), 'w'))
+    np.savez_compressed(out, precision=E.eval['precision'], recall=E.eval['recall'], scores=E.eval['scores'], stats=np.asarray(E.stats),
+                        iou_thrs=E.params.iouThrs, rec_thrs=E.params.recThrs, max_dets=np.asarray(E.params.maxDets),
+                        area_rng=np.asarray(E.params.areaRng))
+    print(f'  eval: {len(gts)} gts, {len(dts)} dts, AP={E.stats[0]:.4f} AP50={E.stats[10]:.4f} AR={E.stats[25]:.4f}')
+    # the reference's greedy CPU NMS on a result list (coco_utils.py:245-282), keeping whole records
+    boxes = rand_boxes(rng, 60, cluster=6)
+    boxes = np.concatenate([boxes, rng.random((60, 1)).astype(np.float32)], 1)
+    recs = [dict(k=i) for i in range(60)]
+    kept = ref.nms_3d_python(recs, boxes, 0.1)
+    np.savez_compressed(out.replace('.npz', '_nms.npz'), boxes=boxes, kept=np.array([r['k'] for r in kept]))
+
+
 if __name__ == '__main__':
     ref = import_reference()
-    which = sys.argv[1:] or ['nms', 'iou', 'codec', 'anchors', 'roi_levels', 'backbone', 'targets', 'losses', 'state_dict']
+    which = sys.argv[1:] or ['nms', 'iou', 'codec', 'anchors', 'roi_levels', 'backbone', 'targets', 'losses', 'state_dict', 'eval']
     if 'nms' in which: make_nms(ref, f'{HERE}/nms3d.npz')
     if 'iou' in which: make_iou(ref, f'{HERE}/iou3d.npz')
     if 'codec' in which: make_codec(ref, f'{HERE}/codec.npz')
@@ -511,4 +583,5 @@ if __name__ == '__main__':
     if 'targets' in which: make_targets(ref, f'{HERE}/targets.npz')
     if 'losses' in which: make_losses(ref, f'{HERE}/losses.npz')
     if 'state_dict' in which: make_state_dict_keys(ref, f'{HERE}/state_dict_keys.json')
+    if 'eval' in which: make_eval(ref, f'{HERE}/eval3d.npz')
     print('golden vectors written to', HERE)
