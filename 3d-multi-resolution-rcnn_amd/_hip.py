@@ -153,7 +153,7 @@ def conv3d_out_shape(x_shape, cout, k, stride, pad):
 
 
 def conv3d_forward(x, w_packed, k, stride, pad, shift=None, add1=None, add2=None, up=None, mask=None, relu=False,
-                   out=None, out_stride=None):
+                   out=None, out_stride=None, out_offset=0):
     """x: [N,D,H,W,Cin] contiguous (NDHWC); w_packed: [taps,Cin,Cout]; returns y [N,Do,Ho,Wo,Cout]."""
     assert x.is_cuda and x.is_contiguous() and x.dtype == torch.float32 and x.dim() == 5
     assert w_packed.is_contiguous() and w_packed.dim() == 3 and w_packed.size(1) == x.size(4)
@@ -166,7 +166,8 @@ def conv3d_forward(x, w_packed, k, stride, pad, shift=None, add1=None, add2=None
     for t in (add1, add2, mask):
         assert t is None or (tuple(t.shape) == tuple(y.shape) and t.is_contiguous())
     d = Conv3dDesc()
-    d.x, d.w, d.y = x.data_ptr(), w_packed.data_ptr(), y.data_ptr()
+    # out_offset (elements): with out_stride, the scatter origin inside `out` (e.g. tap (a,b,c) of a stride-2 transposed conv)
+    d.x, d.w, d.y = x.data_ptr(), w_packed.data_ptr(), y.data_ptr() + 4 * int(out_offset)
     d.shift, d.add1, d.add2, d.up, d.mask = _opt(shift), _opt(add1), _opt(add2), _opt(up), _opt(mask)
     d.n, d.d, d.h, d.w_in, d.cin, d.cout = x.size(0), x.size(1), x.size(2), x.size(3), x.size(4), cout
     d.kd, d.kh, d.kw = k
@@ -462,6 +463,19 @@ def rpn_decode_level(flat_idx, scores, reg_map, reg_layout, base_anchors, featma
                                          ctypes.c_double(wh_ratio_clip), ptr(dets), stream_ptr(scores.device))
     check(st, 'mr3d_rpn_decode_level')
     return dets
+
+
+def relu_mask(g, act, want_bias_grad=False):
+    """out = act > 0 ? g : 0 for contiguous [.., C] tensors (mr3d_relu_mask); optionally also sum(out) per channel"""
+    assert g.is_cuda and g.is_contiguous() and act.is_contiguous() and g.shape == act.shape and g.dtype == torch.float32
+    c = g.shape[-1]
+    out = torch.empty_like(g)
+    db = torch.zeros(c, dtype=torch.float32, device=g.device) if want_bias_grad else None
+    with torch.cuda.device(g.device):
+        st = lib().mr3d_relu_mask(ptr(g), ptr(act), ptr(out), ctypes.c_longlong(g.numel() // c), c, ctypes.c_void_p(_opt(db)),
+                                  stream_ptr(g.device))
+    check(st, 'mr3d_relu_mask')
+    return (out, db) if want_bias_grad else out
 
 
 # -------------------------------------------------------------------------------------------- training targets

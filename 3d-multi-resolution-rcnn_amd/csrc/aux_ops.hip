@@ -335,6 +335,62 @@ extern "C" int mr3d_volume_to_ndhwc4(const float *ncdhw3, float *ndhwc4, int n, 
   return mr3d_launch_status();
 }
 
+// out = act > 0 ? g : 0 (the ReLU backward of a layer whose forward output `act` was kept), optionally with the
+// per-channel column sums of `out` (bias gradient) from the same pass.  Rows are [.., C] with C % 4 == 0 and
+// 256 % (C/4) == 0 or (C/4) % 256 == 0 is NOT required: a thread's channel quad changes along its grid-stride
+// walk unless the stride is a multiple of C/4, so the launcher rounds the grid to make it one.
+__global__ __launch_bounds__(kT) void relu_mask_kernel(const float4 *__restrict__ g, const float4 *__restrict__ act,
+                                                       float4 *__restrict__ out, long long n4, int c4, float *__restrict__ dbias) {
+  __shared__ float4 red[kT];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const long long stride = (long long)gridDim.x * kT;
+  for (long long i = (long long)blockIdx.x * kT + threadIdx.x; i < n4; i += stride) {
+    const float4 a = act[i];
+    float4 v = g[i];
+    v.x = a.x > 0.f ? v.x : 0.f; v.y = a.y > 0.f ? v.y : 0.f; v.z = a.z > 0.f ? v.z : 0.f; v.w = a.w > 0.f ? v.w : 0.f;
+    out[i] = v;
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  if (!dbias) return;
+  // stride % c4 == 0 and kT % c4 == 0 or c4 % kT == 0: thread t always sees channel quad (blockIdx.x*kT + t) % c4
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  const int q0 = (int)(((long long)blockIdx.x * kT) % c4);
+  if (c4 <= kT) {
+    // threads t, t + c4, t + 2*c4, ... share a quad (kT % c4 == 0)
+    if (threadIdx.x < c4) {
+      float4 s = red[threadIdx.x];
+      for (int t = threadIdx.x + c4; t < kT; t += c4) { s.x += red[t].x; s.y += red[t].y; s.z += red[t].z; s.w += red[t].w; }
+      const int q = (q0 + threadIdx.x) % c4;
+      atomicAdd(dbias + 4 * q + 0, s.x); atomicAdd(dbias + 4 * q + 1, s.y);
+      atomicAdd(dbias + 4 * q + 2, s.z); atomicAdd(dbias + 4 * q + 3, s.w);
+    }
+  } else {
+    const int q = (q0 + threadIdx.x) % c4;
+    atomicAdd(dbias + 4 * q + 0, acc.x); atomicAdd(dbias + 4 * q + 1, acc.y);
+    atomicAdd(dbias + 4 * q + 2, acc.z); atomicAdd(dbias + 4 * q + 3, acc.w);
+  }
+}
+
+extern "C" int mr3d_relu_mask(const float *g, const float *act, float *out, long long rows, int c, float *dbias,
+                              mr3d_stream_t s) {
+  if (!g || !act || !out || rows <= 0 || c <= 0 || c % 4) return MR3D_ERR_INVALID_ARG;
+  const int c4 = c / 4;
+  if (dbias && !(kT % c4 == 0 || c4 % kT == 0)) return MR3D_ERR_UNSUPPORTED;
+  const long long n4 = rows * c4;
+  long long blocks = (n4 + kT - 1) / kT;
+  if (blocks > 4096) blocks = 4096;
+  if (dbias && c4 > kT) {                 // grid stride must be a multiple of c4
+    const long long m = c4 / kT;
+    blocks = blocks / m * m;
+    if (blocks < m) blocks = m;
+  }
+  relu_mask_kernel<<<(unsigned)blocks, kT, 0, mr3d_stream(s)>>>(reinterpret_cast<const float4 *>(g),
+                                                               reinterpret_cast<const float4 *>(act),
+                                                               reinterpret_cast<float4 *>(out), n4, c4, dbias);
+  return mr3d_launch_status();
+}
+
 extern "C" int mr3d_axpy(float *dst, const float *src, float alpha, long long count, mr3d_stream_t s) {
   if (!dst || !src || count % 4) return MR3D_ERR_INVALID_ARG;
   axpy_kernel<<<grid_for(count / 4), kT, 0, mr3d_stream(s)>>>(dst, src, alpha, count / 4);

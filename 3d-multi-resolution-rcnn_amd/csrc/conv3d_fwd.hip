@@ -400,6 +400,20 @@ extern "C" int mr3d_conv3d_forward(const mr3d_conv3d_desc *d, mr3d_stream_t stre
     }
   } else if (k == 7 && s == 122) {
     if (a.Cin == 4 && nb == 16) return launch_fwd<FwdCfg<7, 7, 7, 1, 2, 2, 4, 8, 8, 4, 16>>(a, stream);
+  } else if (k == 2 && s == 222 && a.pd == 0 && a.ph == 0 && a.pw == 0) {
+    // kernel 2 / stride 2 (non-overlapping windows): the data gradient of ConvTranspose3d(k=2, s=2)
+    // (fcn_mask_head_3d.py:60-66 `upsample`).  The halo is exactly 2T per axis: 8 channels per chunk keep it in LDS.
+    if (a.Cin % 8 == 0 && nb == 64) {
+      const long long t577 = (long long)((a.Do + 4) / 5) * ((a.Ho + 6) / 7) * ((a.Wo + 6) / 7);
+      const long long t488 = (long long)((a.Do + 3) / 4) * ((a.Ho + 7) / 8) * ((a.Wo + 7) / 8);
+      if (t577 < t488) {
+        // 2x7x7 outputs (98 of 128 GEMM rows) with 16 channels per chunk beat 5x7x7 with 8 (292 vs 473 us on the
+        // 128-roi mask-head shape): half as many chunk passes over the 2x-sized halo, three workgroups per CU
+        if (a.Cin % 16 == 0) return launch_fwd<FwdCfg<2, 2, 2, 2, 2, 2, 2, 7, 7, 16, 64>>(a, stream);
+        return launch_fwd<FwdCfg<2, 2, 2, 2, 2, 2, 5, 7, 7, 8, 64>>(a, stream);
+      }
+      return launch_fwd<FwdCfg<2, 2, 2, 2, 2, 2, 4, 8, 8, 8, 64>>(a, stream);
+    }
   }
   return MR3D_ERR_UNSUPPORTED;
 }

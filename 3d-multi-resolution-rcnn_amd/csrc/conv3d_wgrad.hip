@@ -304,6 +304,15 @@ extern "C" int mr3d_conv3d_wgrad(const mr3d_conv3d_wgrad_desc *d, mr3d_stream_t 
     if (a.Cin % 16 == 0) return dispatch_wg<3, 2, 2, 2, 16, 1>(a, nb, stream);   // 3x17x17 halo: one output plane per tile
   } else if (k == 7 && s == 122) {
     if (a.Cin == 4 && nb == 16) return launch_wgrad<WgCfg<7, 7, 7, 1, 2, 2, 4, 16, true>>(a, stream);
+  } else if (k == 2 && s == 222 && a.pd == 0 && a.ph == 0 && a.pw == 0) {
+    // kernel 2 / stride 2: the weight gradient of ConvTranspose3d(k=2, s=2) (roles swapped by the caller)
+    if (a.Cin % 16 == 0 && nb == 64) {
+      const long long t277 = (long long)((a.Do + 1) / 2) * ((a.Ho + 6) / 7) * ((a.Wo + 6) / 7);
+      const long long t288 = (long long)((a.Do + 1) / 2) * ((a.Ho + 7) / 8) * ((a.Wo + 7) / 8);
+      if (t277 * 98 <= t288 * 128 && a.Ho % 7 == 0 && a.Wo % 7 == 0)
+        return launch_wgrad<WgCfg<2, 2, 2, 2, 2, 2, 16, 64, false, 2, 7, 7>>(a, stream);
+      return launch_wgrad<WgCfg<2, 2, 2, 2, 2, 2, 16, 64, false, 2, 8, 8>>(a, stream);
+    }
   }
   return MR3D_ERR_UNSUPPORTED;
 }

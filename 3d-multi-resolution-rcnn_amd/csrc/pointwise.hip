@@ -220,9 +220,25 @@ __global__ __launch_bounds__(256) void pointwise_fwd_kernel(Conv3dFwdArgs p, lon
           v[q].z = m.z > 0.f ? v[q].z : 0.f; v[q].w = m.w > 0.f ? v[q].w : 0.f;
         }
       }
-      float4 *y4 = reinterpret_cast<float4 *>(p.y) + t4;
+      if (p.ysd != 1 || p.ysh != 1 || p.ysw != 1 || p.yD != p.Do || p.yH != p.Ho || p.yW != p.Wo) {
+        // strided scatter of whole rows (the taps of a stride-2 transposed conv, the stride-2 pointwise dgrad): every
+        // row is still one contiguous CO*4-byte run, only its position changes
 #pragma unroll
-      for (int q = 0; q < C::NOUT; ++q) y4[q * 64 + lane] = v[q];
+        for (int q = 0; q < C::NOUT; ++q) {
+          const int f = q * 64 + lane;
+          unsigned pq = (unsigned)(row0 + f / (C::CO / 4));
+          const unsigned ow = pq % (unsigned)p.Wo; pq /= (unsigned)p.Wo;
+          const unsigned oh = pq % (unsigned)p.Ho; pq /= (unsigned)p.Ho;
+          const unsigned od = pq % (unsigned)p.Do;
+          const unsigned n = pq / (unsigned)p.Do;
+          const size_t orow = (((size_t)n * p.yD + od * p.ysd) * p.yH + oh * p.ysh) * p.yW + ow * p.ysw;
+          *reinterpret_cast<float4 *>(p.y + orow * C::CO + (f % (C::CO / 4)) * 4) = v[q];
+        }
+      } else {
+        float4 *y4 = reinterpret_cast<float4 *>(p.y) + t4;
+#pragma unroll
+        for (int q = 0; q < C::NOUT; ++q) y4[q * 64 + lane] = v[q];
+      }
     } else {
       // ragged last tile: per-element predicates (at most one tile per launch)
       for (int nt = 0; nt < C::NT; ++nt) {
@@ -233,7 +249,15 @@ __global__ __launch_bounds__(256) void pointwise_fwd_kernel(Conv3dFwdArgs p, lon
             const int row = C::k16 ? (lk * 4 + r) : ((r & 3) + 8 * (r >> 2) + 4 * lk);
             const long long pos = row0 + mt * C::TM + row;
             if (pos >= rows_total) continue;
-            const size_t idx = (size_t)pos * C::CO + co;
+            size_t idx = (size_t)pos * C::CO + co;
+            if (p.ysd != 1 || p.ysh != 1 || p.ysw != 1 || p.yD != p.Do || p.yH != p.Ho || p.yW != p.Wo) {
+              unsigned q = (unsigned)pos;
+              const unsigned ow = q % (unsigned)p.Wo; q /= (unsigned)p.Wo;
+              const unsigned oh = q % (unsigned)p.Ho; q /= (unsigned)p.Ho;
+              const unsigned od = q % (unsigned)p.Do;
+              const unsigned n = q / (unsigned)p.Do;
+              idx = ((((size_t)n * p.yD + od * p.ysd) * p.yH + oh * p.ysh) * p.yW + ow * p.ysw) * C::CO + co;
+            }
             float v = acc[mt][nt][r] + sh;
             if (p.add1) v += p.add1[idx];
             if (p.add2) v += p.add2[idx];
@@ -426,7 +450,8 @@ int launch_pw_wgrad(const Conv3dWgradArgs &a, hipStream_t stream) {
 // Returns MR3D_ERR_UNSUPPORTED when the shape is not one of the streaming instances: the caller then uses
 // the generic halo-tile kernels of conv3d_fwd.hip / conv3d_wgrad.hip.
 int mr3d_pointwise_fwd_try(const Conv3dFwdArgs &a, hipStream_t stream) {
-  if (a.ysd != 1 || a.ysh != 1 || a.ysw != 1 || a.yD != a.Do || a.yH != a.Ho || a.yW != a.Wo) return MR3D_ERR_UNSUPPORTED;
+  const bool scatter = a.ysd != 1 || a.ysh != 1 || a.ysw != 1 || a.yD != a.Do || a.yH != a.Ho || a.yW != a.Wo;
+  if (scatter && (a.add1 || a.add2 || a.mask || a.up)) return MR3D_ERR_UNSUPPORTED;   // residual streams index like y: generic path
   if (a.D != a.Do || a.H != a.Ho || a.W != a.Wo) return MR3D_ERR_UNSUPPORTED;      // stride 1, no padding
   const long long rows = (long long)a.N * a.Do * a.Ho * a.Wo;
   if (rows < 32768 || rows > 0x7fffffffLL) return MR3D_ERR_UNSUPPORTED;             // small maps: not HBM-bound

@@ -58,7 +58,7 @@ class _Conv3dFn(Function):
         else:
             g = g.contiguous()
         if relu:
-            g = g * (y > 0)
+            g = _hip.relu_mask(g.contiguous(), y)
         taps, ci = k ** 3, xc.size(4)
         gw = gb = gx = None
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
@@ -90,14 +90,61 @@ def linear(x, weight, bias=None, relu=False):
     return y5.permute(0, 2, 3, 4, 1).reshape(rp, weight.shape[0])[:R]
 
 
+class _Deconv2Fn(Function):
+    """ConvTranspose3d(kernel 2, stride 2): windows do not overlap, so
+       forward  = 8 pointwise GEMMs (one per tap) whose epilogue scatters straight to (2d+a, 2h+b, 2w+c) -- no
+                  8*Cout intermediate and no pixel-shuffle copy;
+       dgrad    = a kernel-2 / stride-2 convolution of the output gradient (implicit GEMM, K = 8 taps x Cout);
+       wgrad    = the weight gradient of that same strided convolution with the roles (input = dy, output grad = x)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        if not x.is_cuda:
+            raise NotImplementedError('the HIP conv engine has no CPU fallback')
+        ci, co = weight.shape[0], weight.shape[1]
+        assert tuple(weight.shape[2:]) == (2, 2, 2) and ci % 16 == 0 and co % 64 == 0
+        xc = _ndhwc(x.detach())
+        N, D, H, W, _ = xc.shape
+        w = weight.detach()
+        wf = w.permute(2, 3, 4, 0, 1).reshape(8, ci, co).contiguous()                 # [tap][ci][co]
+        shift = bias.detach().contiguous() if bias is not None else None
+        y = torch.empty((N, 2 * D, 2 * H, 2 * W, co), dtype=torch.float32, device=x.device)
+        for t in range(8):
+            a, b, c = t >> 2, (t >> 1) & 1, t & 1
+            _hip.conv3d_forward(xc, wf[t:t + 1], (1, 1, 1), (1, 1, 1), (0, 0, 0), shift=shift, relu=relu, out=y,
+                                out_stride=(2, 2, 2), out_offset=((a * 2 * H + b) * 2 * W + c) * co)
+        ctx.save_for_backward(xc, w, y if relu else None)
+        ctx.meta = (relu, bias is not None)
+        return y.permute(0, 4, 1, 2, 3)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        xc, w, y = ctx.saved_tensors
+        relu, has_bias = ctx.meta
+        ci, co = w.shape[0], w.shape[1]
+        g = gy.permute(0, 2, 3, 4, 1).contiguous()
+        want_gb = has_bias and ctx.needs_input_grad[2]
+        gb_fused = None
+        if relu:
+            if want_gb:
+                g, gb_fused = _hip.relu_mask(g, y, want_bias_grad=True)     # mask + bias gradient in one pass
+            else:
+                g = _hip.relu_mask(g, y)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[1]:
+            dwp = torch.zeros((8, co, ci), dtype=torch.float32, device=g.device)       # [tap][conv-in = co][conv-out = ci]
+            _hip.conv3d_wgrad(g, xc, dwp, (2, 2, 2), (2, 2, 2), (0, 0, 0))
+            gw = dwp.reshape(2, 2, 2, co, ci).permute(4, 3, 0, 1, 2).contiguous()
+        if want_gb:
+            gb = gb_fused if gb_fused is not None else g.sum((0, 1, 2, 3))
+        if ctx.needs_input_grad[0]:
+            wb = w.permute(2, 3, 4, 1, 0).reshape(8, co, ci).contiguous()
+            gx = _hip.conv3d_forward(g, wb, (2, 2, 2), (2, 2, 2), (0, 0, 0)).permute(0, 4, 1, 2, 3)
+        return gx, gw, gb, None
+
+
 def conv_transpose3d_k2s2(x, weight, bias=None, relu=False):
     """ConvTranspose3d(kernel 2, stride 2): weight [Cin, Cout, 2, 2, 2] (torch layout).
     out[n, co, 2d+a, 2h+b, 2w+c] = sum_ci x[n,ci,d,h,w] * weight[ci,co,a,b,c] + bias[co]"""
-    ci, co = weight.shape[0], weight.shape[1]
-    w8 = weight.permute(2, 3, 4, 1, 0).reshape(8 * co, ci, 1, 1, 1)          # rows ordered (a, b, c, co)
-    b8 = bias.repeat(8) if bias is not None else None
-    y = conv3d(x, w8, b8, 0, relu)                                           # [N, 8*co, D, H, W]
-    N, _, D, H, W = y.shape
-    y = y.permute(0, 2, 3, 4, 1).reshape(N, D, H, W, 2, 2, 2, co)
-    y = y.permute(0, 1, 4, 2, 5, 3, 6, 7).reshape(N, 2 * D, 2 * H, 2 * W, co)
-    return y.permute(0, 4, 1, 2, 3)
+    return _Deconv2Fn.apply(x, weight, bias, bool(relu))

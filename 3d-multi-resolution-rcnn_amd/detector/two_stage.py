@@ -93,6 +93,14 @@ class TwoStageDetector3D(nn.Module):
         sd = sd.get('state_dict', sd)
         return self.load_state_dict(dict(sd), strict=strict)
 
+    def _mark(self, name):
+        """optional phase timing (tools/two_stage_bench.py --phases): records a device event per phase boundary"""
+        t = getattr(self, '_phase_events', None)
+        if t is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            t.append((name, e))
+
     def extract_feat(self, imgs):
         return self.extract(imgs)
 
@@ -102,15 +110,20 @@ class TwoStageDetector3D(nn.Module):
         loss_mask).  draws: optional dict(rpn=[(pos, neg) per image], rcnn=[(pos, neg) per image]) of sampler words."""
         assert imgs.shape[1] == 3                                           # two_stage_3d.py:124
         draws = draws or {}
+        self._mark('start')
         x = self.extract_feat(imgs)
+        self._mark('backbone+fpn fwd')
         losses = dict()
         cfg = self.train_cfg
         rpn_outs = self.rpn_head(x)
+        self._mark('rpn head fwd')
         losses.update(self.rpn_head.loss(*rpn_outs, gt_bboxes, img_meta, cfg['rpn'], gt_bboxes_ignore=gt_bboxes_ignore,
                                          draws_list=draws.get('rpn')))
+        self._mark('rpn targets+loss')
         with torch.no_grad():
             proposal_list = self.rpn_head.get_bboxes(*rpn_outs, img_meta, SimpleNamespace(**cfg['rpn_proposal'])) \
                 if proposals is None else proposals
+        self._mark('proposals (decode+nms3d)')
 
         rc = cfg['rcnn']
         assigner, sampler = build_assigner(rc['assigner']), build_sampler(rc['sampler'])
@@ -131,6 +144,7 @@ class TwoStageDetector3D(nn.Module):
             pos_gt.append(pgi); counts.append(cnt)
         counts = torch.stack(counts)
         self.last_sample_counts = counts
+        self._mark('rcnn assign+sample+targets')
 
         # ---- bbox head (two_stage_3d.py:179-192)
         all_rois = torch.cat(rois)
@@ -145,6 +159,7 @@ class TwoStageDetector3D(nn.Module):
         valid_rows = (counts[0, 0] + counts[0, 1]).reshape(1).to(torch.int32)
         losses.update(self.bbox_head.loss(cls_score, bbox_pred, lab, lw, torch.cat(bbox_targets), torch.cat(bbox_weights),
                                           valid_rows=valid_rows, num_rois=num_rois))
+        self._mark('bbox roialign+head+loss')
 
         # ---- mask head on the positives (two_stage_3d.py:194-218): rows [0, cap_pos) of the roi batch, first #pos real
         if self.with_mask:
@@ -155,6 +170,7 @@ class TwoStageDetector3D(nn.Module):
             gi = pos_gt[0][:cap_pos].clamp(min=0)                        # padding rows point at gt 0; they carry no loss
             mask_targets = mask_target_single(pos_rois[:, 1:], gi, gt_masks[0], SimpleNamespace(**rc))
             losses.update(self.mask_head.loss(mask_pred, mask_targets, labels[0][:cap_pos], valid_rows=n_pos))
+            self._mark('mask roialign+head+targets+loss')
         self.iteration += 1
         return losses
 

@@ -162,6 +162,10 @@ int mr3d_subsample2_forward(const float *x, float *y, int n, int d, int h, int w
 int mr3d_subsample2_backward_add(const float *dy, float *dx, int n, int d, int h, int w, int c, mr3d_stream_t s);
 int mr3d_volume_to_ndhwc4(const float *ncdhw3, float *ndhwc4, int n, int d, int h, int w, mr3d_stream_t s);
 int mr3d_axpy(float *dst, const float *src, float alpha, long long count, mr3d_stream_t s);
+/* ReLU backward of a layer whose forward output `act` [rows, c] was kept: out = act > 0 ? g : 0 (the `grad * (y > 0)`
+ * of torch's ReLU, one pass instead of a compare and a multiply); dbias (may be NULL, PRE-ZEROED, c floats) += the
+ * per-channel column sums of out (bias gradient of the layer below the ReLU).  c % 4 == 0; with dbias 256 % (c/4) == 0. */
+int mr3d_relu_mask(const float *g, const float *act, float *out, long long rows, int c, float *dbias, mr3d_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------
  * Table-driven parameter handling for conv (+ eval-mode BatchNorm3d or bias) layers.  All parameters and

@@ -47,18 +47,19 @@ def test_conv3d_linear_deconv_layers_fwd_bwd():
     assert _rel(outl.detach().cpu(), refl.detach()) <= RTOL
     outl.backward(cl.to(dev))
     assert _rel(xld.grad.cpu(), xl.grad) <= RTOL and _rel(wld.grad.cpu(), wl.grad) <= RTOL and _rel(bld.grad.cpu(), bl.grad) <= RTOL
-    # transposed conv k2 s2
-    xt = torch.randn(3, 16, 3, 5, 4, generator=g, requires_grad=True)
-    wt = (torch.randn(16, 32, 2, 2, 2, generator=g) * 0.2).requires_grad_(True)
-    bt = torch.randn(32, generator=g).requires_grad_(True)
-    reft = F.relu(F.conv_transpose3d(xt, wt, bt, stride=2))
-    ct = torch.randn(reft.shape, generator=g)
-    reft.backward(ct)
-    xtd, wtd, btd = (t.detach().to(dev).requires_grad_(True) for t in (xt, wt, bt))
-    outt = layers.conv_transpose3d_k2s2(xtd, wtd, btd, relu=True)
-    assert outt.shape == reft.shape and _rel(outt.detach().cpu(), reft.detach()) <= RTOL
-    outt.backward(ct.to(dev))
-    assert _rel(xtd.grad.cpu(), xt.grad) <= RTOL and _rel(wtd.grad.cpu(), wt.grad) <= RTOL and _rel(btd.grad.cpu(), bt.grad) <= RTOL
+    # transposed conv k2 s2 (fcn_mask_head_3d.py:60-66: 64 -> 64): generic and roi-shaped (5x7x7 / 2x7x7 tile) volumes
+    for shape in ((3, 64, 3, 5, 4), (9, 64, 10, 14, 14)):
+        xt = torch.randn(shape, generator=g, requires_grad=True)
+        wt = (torch.randn(64, 64, 2, 2, 2, generator=g) * 0.1).requires_grad_(True)
+        bt = torch.randn(64, generator=g).requires_grad_(True)
+        reft = F.relu(F.conv_transpose3d(xt, wt, bt, stride=2))
+        ct = torch.randn(reft.shape, generator=g)
+        reft.backward(ct)
+        xtd, wtd, btd = (t.detach().to(dev).requires_grad_(True) for t in (xt, wt, bt))
+        outt = layers.conv_transpose3d_k2s2(xtd, wtd, btd, relu=True)
+        assert outt.shape == reft.shape and _rel(outt.detach().cpu(), reft.detach()) <= RTOL
+        outt.backward(ct.to(dev))
+        assert _rel(xtd.grad.cpu(), xt.grad) <= RTOL and _rel(wtd.grad.cpu(), wt.grad) <= RTOL and _rel(btd.grad.cpu(), bt.grad) <= RTOL
 
 
 class _RefRPN(nn.Module):          # rpn_head_3d.py:18-35

@@ -34,6 +34,7 @@ def main():
     ap.add_argument('--repeats', type=int, default=1)
     ap.add_argument('--none-grads', action='store_true')
     ap.add_argument('--two-scales', action='store_true', help='the shipped dual-pathway model (region + its 1.5x copy)')
+    ap.add_argument('--phases', action='store_true', help='device-event timing of the phases of one step')
     ap.add_argument('--json', action='store_true', help='print one JSON line with the step time')
     ap.add_argument('--no-mask', action='store_true')
     ap.add_argument('--profile', action='store_true', help='torch profiler table of one step')
@@ -69,6 +70,20 @@ def main():
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
+    if a.phases and not a.two_scales:
+        det._phase_events = []
+        det.extract.zero_grad()
+        losses = det.forward_train(img, meta, [gt], [gl], gt_masks=[masks])
+        tot = det.total_loss(losses)
+        det._mark('sum losses')
+        tot.backward()
+        det._mark('backward (heads + backbone)')
+        torch.cuda.synchronize()
+        ev = det._phase_events
+        det._phase_events = None
+        for (n0, e0), (n1, e1) in zip(ev[:-1], ev[1:]):
+            print(f'  {n1:36s} {e0.elapsed_time(e1):8.3f} ms')
+        print(f'  {"total":36s} {ev[0][1].elapsed_time(ev[-1][1]):8.3f} ms')
     if a.profile:
         from torch.profiler import profile, ProfilerActivity
         with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
