@@ -207,3 +207,26 @@ def test_shipped_dual_pathway_simple_test(dev):
     assert (np.diff(b[:, 6]) <= 1e-7).all() or b.shape[0] < 30          # top-k by score when truncated
     res2 = det.simple_test(img, [meta], img_2, [meta_2], rescale=True)
     assert np.array_equal(res[0], res2[0])
+
+
+def test_training_loop_reduces_the_loss(dev):
+    """end-to-end sanity of every gradient in the step: SGD with momentum (the reference's optimizer type,
+    configs/...py:233) on one fixed sample; the total loss must drop substantially within 25 iterations"""
+    det, img, gt, gl, masks, meta, draws = _setup(dev, seed=5)
+    det.extract.zero_init_residual = False
+    head_params = [p for n, p in det.named_parameters() if not n.startswith('extract.')]
+    opt = torch.optim.SGD([{'params': [det.extract.flat_params]}, {'params': head_params}], lr=0.01, momentum=0.9)
+    det.extract.flat_params.grad = det.extract.flat_grads            # the arena IS the gradient of the flat parameter
+    hist = []
+    for it in range(25):
+        det.extract.zero_grad()
+        for p in head_params:
+            p.grad = None
+        losses = det.forward_train(img, meta, [gt], [gl], gt_masks=[masks], draws=draws)
+        total = det.total_loss(losses)
+        total.backward()
+        torch.nn.utils.clip_grad_norm_([det.extract.flat_params] + head_params, 35.0)     # configs/...py:236
+        opt.step()
+        hist.append(total.item())
+        assert np.isfinite(hist[-1])
+    assert min(hist[-5:]) < 0.6 * hist[0], hist
