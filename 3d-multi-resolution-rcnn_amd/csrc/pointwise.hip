@@ -94,10 +94,25 @@ __global__ __launch_bounds__(256) void pointwise_fwd_kernel(Conv3dFwdArgs p, lon
 
   for (; tile < ntiles; tile += wstride) {
     const bool full_tile = (tile + 1) * C::ROWS <= rows_total;
-    float4 e1[C::EXTRA ? C::NOUT : 1], em[C::EXTRA ? C::NOUT : 1];
+    float4 e1[C::EXTRA ? C::NOUT : 1], em[C::EXTRA ? C::NOUT : 1], eu[C::EXTRA ? C::NOUT : 1];
     if constexpr (C::EXTRA) {
       if (full_tile) {
         const size_t t4e = (size_t)tile * C::ROWS * (C::CO / 4);
+        if (p.up) {        // nearest-upsampled coarser map (FPN top-down add): gathered rows, requested early too
+#pragma unroll
+          for (int q = 0; q < C::NOUT; ++q) {
+            const int f = q * 64 + lane;
+            unsigned pq = (unsigned)(tile * C::ROWS + f / (C::CO / 4));
+            const unsigned ow = pq % (unsigned)p.Wo; pq /= (unsigned)p.Wo;
+            const unsigned oh = pq % (unsigned)p.Ho; pq /= (unsigned)p.Ho;
+            const unsigned od = pq % (unsigned)p.Do;
+            const unsigned n = pq / (unsigned)p.Do;
+            const int ud = pw_nearest_src((int)od, p.Du, p.Do), uh = pw_nearest_src((int)oh, p.Hu, p.Ho),
+                      uw = pw_nearest_src((int)ow, p.Wu, p.Wo);
+            eu[q] = *reinterpret_cast<const float4 *>(
+                p.up + ((((size_t)n * p.Du + ud) * p.Hu + uh) * p.Wu + uw) * C::CO + (f % (C::CO / 4)) * 4);
+          }
+        }
         if (p.add1) {
 #pragma unroll
           for (int q = 0; q < C::NOUT; ++q) e1[q] = (reinterpret_cast<const float4 *>(p.add1) + t4e)[q * 64 + lane];
@@ -188,7 +203,10 @@ __global__ __launch_bounds__(256) void pointwise_fwd_kernel(Conv3dFwdArgs p, lon
           v[q].x += a.x; v[q].y += a.y; v[q].z += a.z; v[q].w += a.w;
         }
       }
-      if (p.up) {
+      if (p.up && C::EXTRA) {
+#pragma unroll
+        for (int q = 0; q < C::NOUT; ++q) { v[q].x += eu[q].x; v[q].y += eu[q].y; v[q].z += eu[q].z; v[q].w += eu[q].w; }
+      } else if (p.up) {
 #pragma unroll
         for (int q = 0; q < C::NOUT; ++q) {
           const int f = q * 64 + lane;
@@ -426,7 +444,7 @@ int launch_pw_fwd_impl(const Conv3dFwdArgs &a, hipStream_t stream) {
 
 template <int CI, int CO>
 int launch_pw_fwd(const Conv3dFwdArgs &a, hipStream_t stream) {
-  if (a.add1 || a.add2 || a.mask) return launch_pw_fwd_impl<CI, CO, true>(a, stream);
+  if (a.add1 || a.add2 || a.mask || a.up) return launch_pw_fwd_impl<CI, CO, true>(a, stream);
   return launch_pw_fwd_impl<CI, CO, false>(a, stream);
 }
 
