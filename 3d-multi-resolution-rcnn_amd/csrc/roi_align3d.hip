@@ -170,7 +170,6 @@ __global__ __launch_bounds__(256) void roi_align3d_bwd_generic(long long total, 
 constexpr int kClThreads = 256;          // 4 waves
 constexpr int kClBins = 64;              // bins per workgroup (one LDS tile)
 constexpr int kAxisCap = 256;            // table entries per axis (P * sample_num)
-constexpr int kBoxCap = 10;              // LDS-box backward: voxels per axis of the accumulation box
 constexpr int kBoxCh = 16;               // LDS-box backward: channels per workgroup
 __host__ __device__ inline bool box_shape_ok(int PD, int PH, int PW) { return PD <= 32 && PH <= 32 && PW <= 32 && PH * PW <= 256; }
 
@@ -201,7 +200,7 @@ __global__ __launch_bounds__(kClThreads) void roi_align3d_cl(const float *__rest
                                                             float *__restrict__ out_or_bottom,
                                                             const float *__restrict__ rois, float scale, float scale_d,
                                                             int ns, int C, int D, int H, int W, int PD, int PH, int PW,
-                                                            int bug_compat) {
+                                                            int bug_compat, const int *__restrict__ owned) {
   __shared__ TabEntry tabx[kAxisCap], taby[kAxisCap], tabz[kAxisCap];
   __shared__ float tile[kClBins][MR3D_WAVE + 1];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -219,20 +218,8 @@ __global__ __launch_bounds__(kClThreads) void roi_align3d_cl(const float *__rest
   build_axis_table(tabz, g.sd, g.bd, PD, ns, D, 1, tid);   // z offsets can exceed int: keep the index, scale below
   __syncthreads();
   if (kBackward) {
-    // RoIs whose footprint fits the LDS box are handled by roi_align3d_bwd_box (same decision, same tables:
-    // table offsets here are index * stride, so extents are compared in voxels)
-    __shared__ int owned;
-    if (tid == 0) {
-      auto fits = [&](const TabEntry *tab, int cnt, int stride) -> bool {
-        long long mn = 0x7fffffffffffLL, mx = -1;
-        for (int e = 0; e < cnt; ++e)
-          if (tab[e].l + tab[e].h != 0.f) { mn = min(mn, (long long)tab[e].lo); mx = max(mx, (long long)tab[e].hi); }
-        return mx < 0 || (mx - mn) / stride + 1 <= kBoxCap;
-      };
-      owned = box_shape_ok(PD, PH, PW) && fits(tabx, PW * ns, sW) && fits(taby, PH * ns, sH) && fits(tabz, PD * ns, 1);
-    }
-    __syncthreads();
-    if (owned) return;
+    // RoIs the separable sub-box kernel owns (decided once per call by roi_box_plan_kernel)
+    if (owned && owned[r]) return;
   }
   const float count = (float)(ns * ns * ns);
   const long long base_n = (long long)g.b * D * sD;
@@ -315,13 +302,18 @@ __global__ __launch_bounds__(kClThreads) void roi_align3d_cl(const float *__rest
 
 
 // ------------------------------------------------------------------------------------------
-// channels-last backward, LDS-box variant.  The global-atomic kernel above issues 64 fp32 atomics per output
-// element and runs at the chip's atomic rate (measured 0.9 TB/s of added bytes: 3-5 ms for the mask extractor).
-// But the 8 samples x 8 corners of neighbouring bins land on the SAME few voxels (an RoI assigned to its pyramid
-// level by the reference's sqrt-of-volume rule covers ~5-10 voxels per axis while it has 7-28 sample points per
-// axis), so the scatter is first accumulated in an LDS box [<=10^3 voxels][16 channels] with ds_add_f32 and only
-// the box is flushed with global atomics: ~30x fewer global atomics.  RoIs whose footprint exceeds the box keep
-// the global-atomic path (both kernels take the same decision from the same tap tables).
+// channels-last backward, separable owner-computes variant.  The global-atomic kernel above issues 64 fp32 atomics
+// per output element and runs at the chip's atomic rate (measured 0.9-1.0 TB/s of added bytes: 3-5 ms for the mask
+// extractor).  But the scatter of one RoI is separable: with Wx[x][pw] = sum over the ns samples of bin pw of their
+// weight on voxel x (h if lo == x, l if hi == x), and Wy, Wz alike,
+//     dX[z][y][x] = 1/count * sum_pd Wz[z][pd] * sum_ph Wy[y][ph] * sum_pw Wx[x][pw] * G[pd][ph][pw]
+// i.e. three tiny dense 1-D contractions per channel.  The RoI's voxel footprint is cut into 8x8x8 sub-boxes; a
+// workgroup evaluates one (sub-box, 16 channels) item owner-computes -- the [8][8][8][16] result lives in REGISTERS
+// (each thread owns its (y, x, channel) entries for every z), the intermediates in ~50 KB of LDS -- and issues ONE
+// global atomic per touched voxel-channel.  A plan kernel lists the (RoI, sub-box) items of the call (RoIs with more
+// than kMaxSub sub-boxes, or unsupported pooled shapes, stay with the global-atomic kernel, which reads the same
+// per-RoI flag); persistent workgroups walk the list.  No LDS atomics: an earlier ds_add_f32 box was slower than
+// the global atomics it replaced.
 // ------------------------------------------------------------------------------------------
 
 struct IdxEntry { int lo, hi; float l, h; };     // plain voxel indices; l = h = 0 marks an out-of-range sample
@@ -338,114 +330,173 @@ __device__ __forceinline__ void build_idx_table(IdxEntry *tab, float start, floa
   }
 }
 
-// [lo, lo+n) of the voxels any valid sample of this axis touches; n = 0 if none
-__device__ __forceinline__ void axis_extent(const IdxEntry *tab, int cnt, int &lo, int &n) {
+constexpr int kBoxP = 32;         // max pooled size per axis handled by the box kernel (PH*PW <= 256 as well)
+constexpr int kSubV = 8;          // voxels per axis of one sub-box
+constexpr int kMaxSub = 64;       // sub-boxes per RoI the box kernel accepts
+
+// [lo, lo+n) of the voxels any valid sample of this axis touches (n = 0 if none), straight from the geometry
+__device__ __forceinline__ void axis_extent_geom(float start, float bin, int P, int ns, int dim, int &lo, int &n) {
   int mn = 0x7fffffff, mx = -1;
-  for (int e = 0; e < cnt; ++e)
-    if (tab[e].l + tab[e].h != 0.f) { mn = min(mn, tab[e].lo); mx = max(mx, tab[e].hi); }
+  for (int e = 0; e < P * ns; ++e) {
+    const int p = e / ns, i = e - p * ns;
+    AxisTap t;
+    if (axis_tap(sample_coord(start, p, bin, i, ns), dim, t)) { mn = min(mn, t.lo); mx = max(mx, t.hi); }
+  }
   lo = mx < 0 ? 0 : mn;
   n = mx < 0 ? 0 : mx - mn + 1;
 }
 
-constexpr int kBoxP = 32;         // max pooled size per axis handled by the box kernel (PH*PW <= 256 as well)
+// one thread per RoI: owned[r] + the list of its non-empty sub-boxes: item = r * kMaxSub + (sz*ny + sy)*nx + sx
+__global__ __launch_bounds__(256) void roi_box_plan_kernel(const float *__restrict__ rois, int num_rois, float scale,
+                                                           float scale_d, int ns, int D, int H, int W, int PD, int PH, int PW,
+                                                           int *__restrict__ counter, int *__restrict__ owned,
+                                                           int *__restrict__ items) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= num_rois) return;
+  const RoiGeom g = roi_geom(rois + (size_t)r * 7, scale, scale_d, ns, PD, PH, PW);
+  int x0, xn, y0, yn, z0, zn;
+  axis_extent_geom(g.sw, g.bw, PW, ns, W, x0, xn);
+  axis_extent_geom(g.sh, g.bh, PH, ns, H, y0, yn);
+  axis_extent_geom(g.sd, g.bd, PD, ns, D, z0, zn);
+  const int nx = (xn + kSubV - 1) / kSubV, ny = (yn + kSubV - 1) / kSubV, nz = (zn + kSubV - 1) / kSubV;
+  const int nsub = nx * ny * nz;
+  const int own = nsub <= kMaxSub;          // nsub == 0: nothing to scatter at all, owned and done
+  owned[r] = own;
+  if (!own || nsub == 0) return;
+  const int base = atomicAdd(counter, nsub);
+  for (int k = 0; k < nsub; ++k) items[base + k] = r * kMaxSub + k;
+}
 
-// The scatter of one RoI is separable: with Wx[x][pw] = sum over the ns samples of bin pw of their weight on voxel
-// x (h if lo == x, l if hi == x), and Wy, Wz alike,
-//     dX[z][y][x] = 1/count * sum_pd Wz[z][pd] * sum_ph Wy[y][ph] * sum_pw Wx[x][pw] * G[pd][ph][pw]
-// i.e. three tiny dense 1-D contractions per channel, evaluated owner-computes in LDS (no LDS atomics: an
-// earlier ds_add_f32 version of this box was slower than the global atomics it replaced).
 __global__ __launch_bounds__(kClThreads) void roi_align3d_bwd_box(const float *__restrict__ top, float *__restrict__ bottom,
                                                                  const float *__restrict__ rois, float scale, float scale_d,
                                                                  int ns, int C, int D, int H, int W, int PD, int PH, int PW,
-                                                                 int bug_compat) {
+                                                                 int bug_compat, const int *__restrict__ counter,
+                                                                 const int *__restrict__ items) {
   __shared__ IdxEntry tx[kAxisCap], ty[kAxisCap], tz[kAxisCap];
-  __shared__ float Wx[kBoxCap][kBoxP], Wy[kBoxCap][kBoxP], Wz[kBoxCap][kBoxP];
+  __shared__ float Wx[kSubV][kBoxP], Wy[kSubV][kBoxP], Wz[kSubV][kBoxP];
   __shared__ float Gp[256][kBoxCh];                                   // one pd plane of top_grad: [ph*PW + pw][ch]
-  __shared__ float T1[kBoxP * kBoxCap][kBoxCh];                       // [ph][x][ch]
-  __shared__ float T2[kBoxCap * kBoxCap][kBoxCh];                     // [y][x][ch]
-  __shared__ float T3[kBoxCap * kBoxCap * kBoxCap][kBoxCh];           // [z][y][x][ch]
-  __shared__ int ext[7];                                              // x0,xn,y0,yn,z0,zn,fits
+  __shared__ float T1[kBoxP * kSubV][kBoxCh];                         // [ph][x][ch]
+  __shared__ float T2[kSubV * kSubV][kBoxCh];                         // [y][x][ch]
+  __shared__ int ext[6];
   const int tid = threadIdx.x;
-  const int r = blockIdx.x, c0 = blockIdx.y * kBoxCh;
+  const int c0 = blockIdx.y * kBoxCh;
   const int B = PD * PH * PW;
-  const RoiGeom g = roi_geom(rois + (size_t)r * 7, scale, scale_d, ns, PD, PH, PW);
-  build_idx_table(tx, g.sw, g.bw, PW, ns, W, tid, kClThreads);
-  build_idx_table(ty, g.sh, g.bh, PH, ns, H, tid, kClThreads);
-  build_idx_table(tz, g.sd, g.bd, PD, ns, D, tid, kClThreads);
-  __syncthreads();
-  if (tid == 0) {
-    axis_extent(tx, PW * ns, ext[0], ext[1]);
-    axis_extent(ty, PH * ns, ext[2], ext[3]);
-    axis_extent(tz, PD * ns, ext[4], ext[5]);
-    ext[6] = ext[1] <= kBoxCap && ext[3] <= kBoxCap && ext[5] <= kBoxCap;
-  }
-  __syncthreads();
-  if (!ext[6]) return;                        // the global-atomic kernel owns this RoI
-  const int x0 = ext[0], xn = ext[1], y0 = ext[2], yn = ext[3], z0 = ext[4], zn = ext[5];
-  if (xn * yn * zn == 0) return;
-  // per-axis weight matrices
-  auto build_w = [&](float (*Wm)[kBoxP], const IdxEntry *tab, int P, int v0, int vn) {
-    for (int e = tid; e < vn * P; e += kClThreads) {
-      const int v = e / P, p = e % P;
-      float a = 0.f;
-      for (int i = 0; i < ns; ++i) {
-        const IdxEntry t = tab[p * ns + i];
-        if (t.l + t.h == 0.f) continue;
-        if (t.lo - v0 == v) a += t.h;
-        if (t.hi - v0 == v) a += t.l;
-      }
-      Wm[v][p] = a;
-    }
-  };
-  build_w(Wx, tx, PW, x0, xn);
-  build_w(Wy, ty, PH, y0, yn);
-  build_w(Wz, tz, PD, z0, zn);
-  for (int i = tid; i < zn * yn * xn * kBoxCh; i += kClThreads) (&T3[0][0])[i] = 0.f;
+  const int count_items = *counter;
+  constexpr int kOwn = kSubV * kSubV * kBoxCh / kClThreads;            // (y, x, ch) entries per thread: 4
   const float inv_count = 1.f / (float)(ns * ns * ns);
 
-  for (int pd = 0; pd < PD; ++pd) {
-    __syncthreads();
-    // Gp[ph*PW+pw][ch] = top_grad[r, c0+ch, (bug-compatible) index] / count
-    const int plane0 = bug_compat ? pd * PD * PW : pd * PH * PW;
-    for (int e = tid; e < PH * PW * kBoxCh; e += kClThreads) {
-      const int cc = e / (PH * PW), q = e % (PH * PW);
-      Gp[q][cc] = (c0 + cc < C) ? top[((size_t)r * C + c0 + cc) * B + plane0 + q] * inv_count : 0.f;
+  for (int it = blockIdx.x; it < count_items; it += gridDim.x) {
+    const int item = items[it];
+    const int r = item / kMaxSub, sub = item % kMaxSub;
+    const RoiGeom g = roi_geom(rois + (size_t)r * 7, scale, scale_d, ns, PD, PH, PW);
+    __syncthreads();                          // previous item fully flushed before the tables are rebuilt
+    build_idx_table(tx, g.sw, g.bw, PW, ns, W, tid, kClThreads);
+    build_idx_table(ty, g.sh, g.bh, PH, ns, H, tid, kClThreads);
+    build_idx_table(tz, g.sd, g.bd, PD, ns, D, tid, kClThreads);
+    if (tid < 3) {
+      const float st = tid == 0 ? g.sw : (tid == 1 ? g.sh : g.sd), bn = tid == 0 ? g.bw : (tid == 1 ? g.bh : g.bd);
+      const int P = tid == 0 ? PW : (tid == 1 ? PH : PD), dim = tid == 0 ? W : (tid == 1 ? H : D);
+      axis_extent_geom(st, bn, P, ns, dim, ext[2 * tid], ext[2 * tid + 1]);
     }
     __syncthreads();
-    // T1[ph][x][ch] = sum_pw Wx[x][pw] * Gp[ph][pw][ch]
-    for (int e = tid; e < PH * xn * kBoxCh; e += kClThreads) {
-      const int ch = e % kBoxCh, x = (e / kBoxCh) % xn, ph = e / (kBoxCh * xn);
-      float a = 0.f;
-      for (int pw = 0; pw < PW; ++pw) a += Wx[x][pw] * Gp[ph * PW + pw][ch];
-      T1[ph * xn + x][ch] = a;
+    const int nx = (ext[1] + kSubV - 1) / kSubV, ny = (ext[3] + kSubV - 1) / kSubV;
+    const int sx = sub % nx, sy = (sub / nx) % ny, sz = sub / (nx * ny);
+    const int x0 = ext[0] + sx * kSubV, y0 = ext[2] + sy * kSubV, z0 = ext[4] + sz * kSubV;
+    const int xn = min(kSubV, ext[0] + ext[1] - x0), yn = min(kSubV, ext[2] + ext[3] - y0), zn = min(kSubV, ext[4] + ext[5] - z0);
+    // per-axis weight matrices of this sub-box
+    auto build_w = [&](float (*Wm)[kBoxP], const IdxEntry *tab, int P, int v0, int vn) {
+      for (int e = tid; e < vn * P; e += kClThreads) {
+        const int v = e / P, p = e % P;
+        float a = 0.f;
+        for (int i = 0; i < ns; ++i) {
+          const IdxEntry t = tab[p * ns + i];
+          if (t.l + t.h == 0.f) continue;
+          if (t.lo - v0 == v) a += t.h;
+          if (t.hi - v0 == v) a += t.l;
+        }
+        Wm[v][p] = a;
+      }
+    };
+    build_w(Wx, tx, PW, x0, xn);
+    build_w(Wy, ty, PH, y0, yn);
+    build_w(Wz, tz, PD, z0, zn);
+    float t3[kOwn][kSubV];
+#pragma unroll
+    for (int j = 0; j < kOwn; ++j)
+#pragma unroll
+      for (int z = 0; z < kSubV; ++z) t3[j][z] = 0.f;
+
+    for (int pd = 0; pd < PD; ++pd) {
+      __syncthreads();
+      // skip planes that do not reach this sub-box in z (Wz column all zero): wave-uniform test on LDS
+      bool any = false;
+      for (int z = 0; z < zn; ++z) any = any || Wz[z][pd] != 0.f;
+      if (!any) continue;
+      // Gp[ph*PW+pw][ch] = top_grad[r, c0+ch, (bug-compatible) index] / count
+      const int plane0 = bug_compat ? pd * PD * PW : pd * PH * PW;
+      for (int e = tid; e < PH * PW * kBoxCh; e += kClThreads) {
+        const int cc = e / (PH * PW), q = e % (PH * PW);
+        Gp[q][cc] = (c0 + cc < C) ? top[((size_t)r * C + c0 + cc) * B + plane0 + q] * inv_count : 0.f;
+      }
+      __syncthreads();
+      // T1[ph][x][ch] = sum_pw Wx[x][pw] * Gp[ph][pw][ch]
+      for (int e = tid; e < PH * xn * kBoxCh; e += kClThreads) {
+        const int ch = e % kBoxCh, x = (e / kBoxCh) % xn, ph = e / (kBoxCh * xn);
+        float a = 0.f;
+        for (int pw = 0; pw < PW; ++pw) a += Wx[x][pw] * Gp[ph * PW + pw][ch];
+        T1[ph * xn + x][ch] = a;
+      }
+      __syncthreads();
+      // T2[y][x][ch] = sum_ph Wy[y][ph] * T1[ph][x][ch]
+      for (int e = tid; e < yn * xn * kBoxCh; e += kClThreads) {
+        const int ch = e % kBoxCh, x = (e / kBoxCh) % xn, y = e / (kBoxCh * xn);
+        float a = 0.f;
+        for (int ph = 0; ph < PH; ++ph) a += Wy[y][ph] * T1[ph * xn + x][ch];
+        T2[y * xn + x][ch] = a;
+      }
+      __syncthreads();
+      // t3[(y,x,ch) owned by this thread][z] += Wz[z][pd] * T2[y][x][ch]
+#pragma unroll
+      for (int j = 0; j < kOwn; ++j) {
+        const int e = tid + j * kClThreads;
+        if (e < yn * xn * kBoxCh) {
+          const float t2 = (&T2[0][0])[e];
+#pragma unroll
+          for (int z = 0; z < kSubV; ++z)
+            if (z < zn) t3[j][z] += Wz[z][pd] * t2;
+        }
+      }
     }
-    __syncthreads();
-    // T2[y][x][ch] = sum_ph Wy[y][ph] * T1[ph][x][ch]
-    for (int e = tid; e < yn * xn * kBoxCh; e += kClThreads) {
-      const int ch = e % kBoxCh, x = (e / kBoxCh) % xn, y = e / (kBoxCh * xn);
-      float a = 0.f;
-      for (int ph = 0; ph < PH; ++ph) a += Wy[y][ph] * T1[ph * xn + x][ch];
-      T2[y * xn + x][ch] = a;
-    }
-    __syncthreads();
-    // T3[z][y][x][ch] += Wz[z][pd] * T2[y][x][ch]   (each thread owns its (y,x,ch) entries for every z: no races)
-    for (int e = tid; e < yn * xn * kBoxCh; e += kClThreads) {
-      const float t2 = (&T2[0][0])[e];
-      for (int z = 0; z < zn; ++z) {
-        const float wz = Wz[z][pd];
-        if (wz != 0.f) (&T3[0][0])[z * yn * xn * kBoxCh + e] += wz * t2;
+    // flush: 16 consecutive channels of one voxel per 16 lanes, one global atomic per touched voxel-channel
+#pragma unroll
+    for (int j = 0; j < kOwn; ++j) {
+      const int e = tid + j * kClThreads;
+      if (e < yn * xn * kBoxCh) {
+        const int cc = e % kBoxCh, x = (e / kBoxCh) % xn, y = e / (kBoxCh * xn);
+        if (c0 + cc < C) {
+#pragma unroll
+          for (int z = 0; z < kSubV; ++z)
+            if (z < zn && t3[j][z] != 0.f)
+              atomicAdd(bottom + ((((size_t)g.b * D + z0 + z) * H + y0 + y) * W + x0 + x) * C + c0 + cc, t3[j][z]);
+        }
       }
     }
   }
-  __syncthreads();
-  // flush: 16 consecutive channels of one voxel per 16 lanes
-  for (int i = tid; i < zn * yn * xn * kBoxCh; i += kClThreads) {
-    const float v = (&T3[0][0])[i];
-    const int cc = i % kBoxCh, vox = i / kBoxCh;
-    const int x = vox % xn, y = (vox / xn) % yn, z = vox / (xn * yn);
-    if (v != 0.f && c0 + cc < C)
-      atomicAdd(bottom + ((((size_t)g.b * D + z0 + z) * H + y0 + y) * W + x0 + x) * C + c0 + cc, v);
+}
+
+// persistent scratch of the backward plan: [0] item counter, [1 .. 1+R) owned flags, then R*kMaxSub items
+int *g_box_scratch = nullptr;
+size_t g_box_scratch_ints = 0;
+int *box_scratch(int num_rois) {
+  const size_t need = 1 + (size_t)num_rois * (1 + kMaxSub);
+  if (need > g_box_scratch_ints) {
+    if (g_box_scratch) (void)hipFree(g_box_scratch);
+    g_box_scratch = nullptr;
+    const size_t cap = need < 65536 ? 65536 : need * 2;
+    if (hipMalloc(reinterpret_cast<void **>(&g_box_scratch), cap * sizeof(int)) != hipSuccess) { g_box_scratch_ints = 0; return nullptr; }
+    g_box_scratch_ints = cap;
   }
+  return g_box_scratch;
 }
 
 int check_common(const void *a, const void *b, const void *c, int num_rois, int batch, int C, int D, int H, int W, int PD,
@@ -489,7 +540,7 @@ extern "C" int mr3d_roi_align3d_forward(const float *features, const float *rois
     dim3 grid(num_rois, (B + kClBins - 1) / kClBins);
     roi_align3d_cl<false><<<grid, kClThreads, 0, stream>>>(features, output, rois, spatial_scale, spatial_scale_depth,
                                                           sample_num, channels, depth, height, width, pooled_depth,
-                                                          pooled_height, pooled_width, 0);
+                                                          pooled_height, pooled_width, 0, nullptr);
   } else {
     const long long total = (long long)num_rois * channels * B;
     const long long blocks = (total + 255) / 256;
@@ -515,13 +566,24 @@ extern "C" int mr3d_roi_align3d_backward(const float *top_grad, const float *roi
   const int B = pooled_depth * pooled_height * pooled_width;
   if (use_cl(layout, sample_num, pooled_depth, pooled_height, pooled_width)) {
     dim3 grid(num_rois, (B + kClBins - 1) / kClBins);
+    int *scratch = box_shape_ok(pooled_depth, pooled_height, pooled_width) ? box_scratch(num_rois) : nullptr;
+    int *owned = nullptr;
+    if (scratch) {
+      // plan: which RoIs (and which 8x8x8 sub-boxes of their footprints) the separable kernel takes
+      owned = scratch + 1;
+      if (hipMemsetAsync(scratch, 0, sizeof(int), stream) != hipSuccess) return MR3D_ERR_LAUNCH;
+      roi_box_plan_kernel<<<(num_rois + 255) / 256, 256, 0, stream>>>(rois, num_rois, spatial_scale, spatial_scale_depth,
+                                                                      sample_num, depth, height, width, pooled_depth,
+                                                                      pooled_height, pooled_width, scratch, owned,
+                                                                      scratch + 1 + num_rois);
+    }
     roi_align3d_cl<true><<<grid, kClThreads, 0, stream>>>(top_grad, bottom_grad, rois, spatial_scale,
                                                          spatial_scale_depth, sample_num, channels, depth, height, width,
-                                                         pooled_depth, pooled_height, pooled_width, bug);
-    if (box_shape_ok(pooled_depth, pooled_height, pooled_width))
-      roi_align3d_bwd_box<<<dim3(num_rois, (channels + kBoxCh - 1) / kBoxCh), kClThreads, 0, stream>>>(
+                                                         pooled_depth, pooled_height, pooled_width, bug, owned);
+    if (scratch)
+      roi_align3d_bwd_box<<<dim3(1024, (channels + kBoxCh - 1) / kBoxCh), kClThreads, 0, stream>>>(
         top_grad, bottom_grad, rois, spatial_scale, spatial_scale_depth, sample_num, channels, depth, height, width,
-        pooled_depth, pooled_height, pooled_width, bug);
+        pooled_depth, pooled_height, pooled_width, bug, scratch, scratch + 1 + num_rois);
   } else {
     const long long total = (long long)num_rois * channels * B;
     const long long blocks = (total + 255) / 256;
