@@ -101,6 +101,44 @@ def nms3d(dets, iou_threshold):
     return keep[:k]
 
 
+def nms3d_batched(dets_list, iou_threshold):
+    """independent NMS3D problems (e.g. the pyramid levels of one image) in ONE launch sequence and ONE 4*S-byte read-back.
+    dets_list: [n_s, 7] fp32 device tensors -> list of int64 kept-index tensors (ascending, relative to their own set).
+    Sets larger than 4096 boxes fall back to one mr3d_nms3d call each."""
+    S = len(dets_list)
+    if S == 0:
+        return []
+    ns = [int(d.size(0)) for d in dets_list]
+    if max(ns) > 4096 or S > 16:
+        return [nms3d(d, iou_threshold) for d in dets_list]
+    dev = dets_list[0].device
+    for d in dets_list:
+        if not (d.is_cuda and d.dtype == torch.float32 and d.dim() == 2 and d.size(1) == 7):
+            raise RuntimeError('nms_3d expects float32 CUDA dets of shape [n, 7]')
+    total = sum(ns)
+    if total == 0:
+        return [torch.empty((0,), dtype=torch.long, device=dev) for _ in ns]
+    dets = torch.cat([d for d in dets_list], 0).contiguous()
+    seg = (ctypes.c_int * S)(*ns)
+    L = lib()
+    L.mr3d_nms3d_batched_workspace_bytes.restype = ctypes.c_size_t
+    with torch.cuda.device(dev):
+        ws_bytes = int(L.mr3d_nms3d_batched_workspace_bytes(seg, S))
+        ws = torch.empty((ws_bytes + 256,), dtype=torch.uint8, device=dev)
+        off = (-ws.data_ptr()) % 256
+        keep = torch.empty((total,), dtype=torch.long, device=dev)
+        num = torch.empty((S,), dtype=torch.int32, device=dev)
+        st = L.mr3d_nms3d_batched(ptr(dets), seg, S, ctypes.c_int(dets.stride(0)), ctypes.c_float(iou_threshold), ptr(keep),
+                                  ptr(num), ctypes.c_void_p(ws.data_ptr() + off), ctypes.c_size_t(ws_bytes), stream_ptr(dev))
+        check(st, 'mr3d_nms3d_batched')
+        counts = num.tolist()                    # one host sync for all segments
+    out, row = [], 0
+    for n, k in zip(ns, counts):
+        out.append(keep[row:row + k])
+        row += n
+    return out
+
+
 def roi_align3d_forward(features, rois, out_d, out_h, out_w, spatial_scale, spatial_scale_depth, sample_num, output):
     layout = feature_layout(features)
     N, C, D, H, W = features.shape

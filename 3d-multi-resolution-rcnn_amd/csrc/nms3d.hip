@@ -16,6 +16,17 @@ namespace {
 
 constexpr int kSortLdsMax = 4096;   // boxes sorted inside one workgroup's LDS (32 KiB of keys)
 constexpr int kSortThreads = 1024;
+constexpr int kMaxSeg = 16;         // independent box sets per batched call (pyramid levels x pathways)
+
+// One launch serves several independent NMS problems ("segments": the 5 pyramid levels of rpn_head_3d.py:81-135 are
+// 5 separate nms() calls in the reference).  Segment s owns rows [row0[s], row0[s] + n[s]) of dets / order / keep and
+// its own slices of the sorted-box and bit-matrix workspaces.
+struct SegTable {
+  int num;
+  int row0[kMaxSeg], n[kMaxSeg];
+  long long box_off[kMaxSeg];       // in float4 units
+  long long mask_off[kMaxSeg];      // in u64 units
+};
 
 // (score desc, index asc) as one ascending u64 key
 __device__ __forceinline__ uint64_t make_key(float s, int idx) {
@@ -37,11 +48,19 @@ __device__ __forceinline__ void store_box(const float *dets, int stride, int src
 }
 
 // ---- sort, n <= kSortLdsMax: one workgroup, bitonic network in LDS -------------------
-__global__ __launch_bounds__(kSortThreads) void nms3d_sort_lds_kernel(const float *__restrict__ dets, int n, int stride,
-                                                                     int np2, int *__restrict__ order,
-                                                                     float4 *__restrict__ boxes) {
+__global__ __launch_bounds__(kSortThreads) void nms3d_sort_lds_kernel(const float *__restrict__ dets_all, SegTable seg,
+                                                                     int stride, int *__restrict__ order_all,
+                                                                     float4 *__restrict__ boxes_all) {
   __shared__ uint64_t keys[kSortLdsMax];
   const int tid = threadIdx.x;
+  const int sg = blockIdx.x;
+  const int n = seg.n[sg];
+  if (n == 0) return;
+  int np2 = 1;
+  while (np2 < n) np2 <<= 1;
+  const float *dets = dets_all + (size_t)seg.row0[sg] * stride;
+  int *order = order_all + seg.row0[sg];
+  float4 *boxes = boxes_all + seg.box_off[sg];
   for (int i = tid; i < np2; i += kSortThreads)
     keys[i] = (i < n) ? make_key(dets[(size_t)i * stride + 6], i) : ~0ull;
   __syncthreads();
@@ -96,10 +115,14 @@ __global__ void nms3d_gather_kernel(const float *__restrict__ dets, int n, int s
 // ---- 64x64 suppression words; one wave per (row block, col block), upper triangle only ---
 // (the reference also fills the blocks below the diagonal, nms_kernel.cu:86, but its sweep
 //  never reads them: `for (j = nblock; ...)`, :244)
-__global__ __launch_bounds__(MR3D_WAVE) void nms3d_mask_kernel(const float4 *__restrict__ boxes, int n, int cb,
-                                                              float thr, uint64_t *__restrict__ mask) {
+__global__ __launch_bounds__(MR3D_WAVE) void nms3d_mask_kernel(const float4 *__restrict__ boxes_all, SegTable seg,
+                                                              float thr, uint64_t *__restrict__ mask_all) {
+  const int sg = blockIdx.z;
+  const int n = seg.n[sg], cb = (n + 63) / 64;
   const int c = blockIdx.x, r = blockIdx.y;
-  if (c < r) return;
+  if (c < r || c >= cb) return;
+  const float4 *boxes = boxes_all + seg.box_off[sg];
+  uint64_t *mask = mask_all + seg.mask_off[sg];
   __shared__ float4 cbx[2 * MR3D_WAVE];
   const int lane = threadIdx.x;
   const int cidx = c * 64 + lane;
@@ -133,11 +156,21 @@ __global__ __launch_bounds__(MR3D_WAVE) void nms3d_mask_kernel(const float4 *__r
 constexpr int kSweepThreads = 256;
 constexpr int kRowsPerItem = 8;     // mask rows OR-ed by one thread per work item
 
-__global__ __launch_bounds__(kSweepThreads) void nms3d_sweep_kernel(const uint64_t *__restrict__ mask,
-                                                                   const int *__restrict__ order, int n, int cb,
-                                                                   int64_t *__restrict__ keep_out,
-                                                                   int32_t *__restrict__ num_keep) {
+__global__ __launch_bounds__(kSweepThreads) void nms3d_sweep_kernel(const uint64_t *__restrict__ mask_all,
+                                                                   const int *__restrict__ order_all, SegTable seg,
+                                                                   int64_t *__restrict__ keep_all,
+                                                                   int32_t *__restrict__ num_keep_all) {
   extern __shared__ __attribute__((aligned(16))) uint64_t sm[];
+  const int sg = blockIdx.x;
+  const int n = seg.n[sg], cb = (n + 63) / 64;
+  int32_t *num_keep = num_keep_all + sg;
+  if (n == 0) {
+    if (threadIdx.x == 0) *num_keep = 0;
+    return;
+  }
+  const uint64_t *mask = mask_all + seg.mask_off[sg];
+  const int *order = order_all + seg.row0[sg];
+  int64_t *keep_out = keep_all + seg.row0[sg];
   uint64_t *remv = sm;
   uint64_t *flags = sm + cb;
   uint64_t *bcast = sm + 2 * cb;
@@ -248,9 +281,11 @@ extern "C" int mr3d_nms3d(const float *dets, int n, int row_stride, float iou_th
   if (sweep_lds > 64 * 1024) return MR3D_ERR_UNSUPPORTED;   // n > ~262k boxes
   NmsWorkspace w = carve(workspace, n);
   const int np2 = mr3d_next_pow2(n);
+  SegTable seg;
+  seg.num = 1; seg.row0[0] = 0; seg.n[0] = n; seg.box_off[0] = 0; seg.mask_off[0] = 0;
 
   if (n <= kSortLdsMax) {
-    nms3d_sort_lds_kernel<<<1, kSortThreads, 0, stream>>>(dets, n, row_stride, np2, w.order, w.boxes);
+    nms3d_sort_lds_kernel<<<1, kSortThreads, 0, stream>>>(dets, seg, row_stride, w.order, w.boxes);
   } else {
     const int th = 256, bl = (np2 + th - 1) / th;
     nms3d_keys_init_kernel<<<bl, th, 0, stream>>>(dets, n, row_stride, np2, w.keys);
@@ -258,7 +293,67 @@ extern "C" int mr3d_nms3d(const float *dets, int n, int row_stride, float iou_th
       for (int j = k >> 1; j > 0; j >>= 1) nms3d_bitonic_step_kernel<<<bl, th, 0, stream>>>(w.keys, np2, j, k);
     nms3d_gather_kernel<<<(n + th - 1) / th, th, 0, stream>>>(dets, n, row_stride, w.keys, w.order, w.boxes);
   }
-  nms3d_mask_kernel<<<dim3(cb, cb), MR3D_WAVE, 0, stream>>>(w.boxes, n, cb, iou_threshold, w.mask);
-  nms3d_sweep_kernel<<<1, kSweepThreads, sweep_lds, stream>>>(w.mask, w.order, n, cb, keep_out, num_keep_out);
+  nms3d_mask_kernel<<<dim3(cb, cb, 1), MR3D_WAVE, 0, stream>>>(w.boxes, seg, iou_threshold, w.mask);
+  nms3d_sweep_kernel<<<1, kSweepThreads, sweep_lds, stream>>>(w.mask, w.order, seg, keep_out, num_keep_out);
+  return mr3d_launch_status();
+}
+
+// ---- batched: several independent box sets in one launch sequence ----------------------------------------------
+namespace {
+struct BatchLayout {
+  SegTable seg;
+  size_t order_off, boxes_off, mask_off, total;
+  int max_cb;
+};
+// 0 on success
+int batch_layout(const int *seg_rows_host, int num_segments, BatchLayout &L) {
+  if (!seg_rows_host || num_segments <= 0 || num_segments > kMaxSeg) return MR3D_ERR_INVALID_ARG;
+  long long rows = 0, boxes = 0, mask = 0;
+  L.max_cb = 0;
+  L.seg.num = num_segments;
+  for (int s = 0; s < num_segments; ++s) {
+    const int n = seg_rows_host[s];
+    if (n < 0) return MR3D_ERR_INVALID_ARG;
+    if (n > kSortLdsMax) return MR3D_ERR_UNSUPPORTED;          // larger sets: one mr3d_nms3d call each
+    const int cb = (n + 63) / 64;
+    L.seg.row0[s] = (int)rows; L.seg.n[s] = n; L.seg.box_off[s] = boxes; L.seg.mask_off[s] = mask;
+    rows += n; boxes += 2LL * n; mask += (long long)n * cb;
+    L.max_cb = cb > L.max_cb ? cb : L.max_cb;
+  }
+  for (int s = num_segments; s < kMaxSeg; ++s) { L.seg.row0[s] = 0; L.seg.n[s] = 0; L.seg.box_off[s] = 0; L.seg.mask_off[s] = 0; }
+  size_t off = 0;
+  L.order_off = off; off += mr3d_align_up(sizeof(int) * (size_t)rows, 256);
+  L.boxes_off = off; off += mr3d_align_up(sizeof(float4) * (size_t)boxes, 256);
+  L.mask_off = off;  off += mr3d_align_up(sizeof(uint64_t) * (size_t)mask, 256);
+  L.total = off + 256;
+  return MR3D_OK;
+}
+}  // namespace
+
+extern "C" size_t mr3d_nms3d_batched_workspace_bytes(const int *seg_rows_host, int num_segments) {
+  BatchLayout L;
+  return batch_layout(seg_rows_host, num_segments, L) == MR3D_OK ? L.total : 0;
+}
+
+extern "C" int mr3d_nms3d_batched(const float *dets, const int *seg_rows_host, int num_segments, int row_stride,
+                                  float iou_threshold, int64_t *keep_out, int32_t *num_keep_out, void *workspace,
+                                  size_t workspace_bytes, mr3d_stream_t stream_) {
+  hipStream_t stream = mr3d_stream(stream_);
+  BatchLayout L;
+  const int st = batch_layout(seg_rows_host, num_segments, L);
+  if (st != MR3D_OK) return st;
+  if (!num_keep_out || row_stride < 7) return MR3D_ERR_INVALID_ARG;
+  if (L.max_cb == 0)          // every segment empty
+    return hipMemsetAsync(num_keep_out, 0, sizeof(int32_t) * num_segments, stream) == hipSuccess ? MR3D_OK : MR3D_ERR_LAUNCH;
+  if (!dets || !keep_out) return MR3D_ERR_INVALID_ARG;
+  if (!workspace || workspace_bytes < L.total || ((uintptr_t)workspace & 255)) return MR3D_ERR_WORKSPACE;
+  char *base = (char *)workspace;
+  int *order = (int *)(base + L.order_off);
+  float4 *boxes = (float4 *)(base + L.boxes_off);
+  uint64_t *mask = (uint64_t *)(base + L.mask_off);
+  const size_t sweep_lds = sizeof(uint64_t) * (2 * (size_t)L.max_cb + 1);
+  nms3d_sort_lds_kernel<<<num_segments, kSortThreads, 0, stream>>>(dets, L.seg, row_stride, order, boxes);
+  nms3d_mask_kernel<<<dim3(L.max_cb, L.max_cb, num_segments), MR3D_WAVE, 0, stream>>>(boxes, L.seg, iou_threshold, mask);
+  nms3d_sweep_kernel<<<num_segments, kSweepThreads, sweep_lds, stream>>>(mask, order, L.seg, keep_out, num_keep_out);
   return mr3d_launch_status();
 }

@@ -46,8 +46,11 @@ def get_bboxes_single(cls_scores, bbox_preds, anchor_generators, anchor_strides,
         dets = _hip.rpn_decode_level(flat.contiguous(), scores.contiguous(), reg_map, layout,
                                      gen.base_anchors_on(scores.device), (D, H, W), anchor_strides[lvl],
                                      anchor_strides_depth[lvl], target_means, target_stds, img_shape)
-        dets, _ = nms(dets, cfg.nms_thr)
-        mlvl.append(dets[:cfg.nms_post, :])
+        mlvl.append(dets)
+    # the reference calls nms() once per level (:134); the levels are independent, so they share one batched launch
+    # sequence and one read-back of the kept counts
+    keeps = _hip.nms3d_batched(mlvl, cfg.nms_thr)
+    mlvl = [d[k][:cfg.nms_post, :] for d, k in zip(mlvl, keeps)]
     proposals = torch.cat(mlvl, 0)
     if getattr(cfg, 'nms_across_levels', False):
         proposals, _ = nms(proposals, cfg.nms_thr)

@@ -110,6 +110,7 @@ def ops_microbench(dev):
 
     # NMS3D: 5 pyramid levels x 2 pathways per volume; per level N in {2000,2000,2000,1280,192}, thr 0.7
     tot = 0.0
+    level_dets = []
     for lvl, (n, stride, zs) in enumerate(zip((2000, 2000, 2000, 1280, 192), (4, 8, 16, 32, 64), (2, 4, 8, 16, 32))):
         size = torch.tensor([stride * 2.0, stride * 2.0, zs * 2.0])
         ctr = torch.rand(n, 3, generator=g) * torch.tensor([512.0, 512.0, 80.0])
@@ -118,8 +119,11 @@ def ops_microbench(dev):
         boxes = torch.stack([ctr[:, 0] - half[:, 0], ctr[:, 1] - half[:, 1], ctr[:, 0] + half[:, 0], ctr[:, 1] + half[:, 1],
                              ctr[:, 2] - half[:, 2], ctr[:, 2] + half[:, 2]], 1)
         dets = torch.cat([boxes, torch.rand(n, 1, generator=g)], 1).to(dev)
+        level_dets.append(dets)
         tot += timed(lambda: nms_cuda.nms_3d(dets, 0.7))
-    out['nms3d_us_per_vol'] = 2 * tot
+    out['nms3d_unbatched_us_per_vol'] = 2 * tot                  # 10 separate calls, as the reference issues them
+    from mr3d_amd import _hip as _h
+    out['nms3d_us_per_vol'] = 2 * timed(lambda: _h.nms3d_batched(level_dets, 0.7))     # the product path: 1 batched call / pathway
     # RoIAlign3D through SingleRoIExtractor over P2..P5: 512 rois x 64 ch x (3,7,7) and 128 rois x
     # (10,14,14); roi sizes log-uniform [4,128] px in xy and [2,40] in z, mapped to levels by the reference's rule
     from mr3d_amd.detector import SingleRoIExtractor

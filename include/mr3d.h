@@ -61,6 +61,16 @@ int mr3d_nms3d(const float *dets, int n, int row_stride, float iou_threshold,
                int64_t *keep_out, int32_t *num_keep_out,
                void *workspace, size_t workspace_bytes, mr3d_stream_t stream);
 
+/* Batched form: `num_segments` (<= 16) independent box sets -- the 5 pyramid levels of RPNHead3D.get_bboxes_single
+ * (rpn_head_3d.py:81-135) are 5 separate nms() calls in the reference -- stored back to back in `dets`
+ * ([sum n_s, row_stride]); seg_rows_host[s] = n_s (HOST array, each <= 4096).  keep_out receives, at the same row
+ * offset as each segment's boxes, that segment's kept indices RELATIVE to the segment (ascending), num_keep_out[s] the
+ * counts.  Same semantics per segment as mr3d_nms3d; one sort / bit-matrix / sweep launch for all of them. */
+size_t mr3d_nms3d_batched_workspace_bytes(const int *seg_rows_host, int num_segments);
+int mr3d_nms3d_batched(const float *dets, const int *seg_rows_host, int num_segments, int row_stride, float iou_threshold,
+                       int64_t *keep_out, int32_t *num_keep_out, void *workspace, size_t workspace_bytes,
+                       mr3d_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * RoIAlign3D forward -- replaces roi_align_cuda.forward3d(features, rois, pooled_depth,
  *   pooled_height, pooled_width, spatial_scale, spatial_scale_depth, sample_num, output)

@@ -200,3 +200,27 @@ def test_single_roi_extractor_levels_golden_and_forward(dev, golden_dir):
             if len(sel):
                 exp = orc.roi_align3d_forward(feats_np[i], rois[sel], 3, 7, 7, 1 / [4, 8, 16, 32][i], 1 / [2, 4, 8, 16][i], 2)
                 np.testing.assert_allclose(out[sel], exp, rtol=RTOL, atol=ATOL)
+
+
+def test_nms3d_batched_equals_per_set_calls():
+    """mr3d_nms3d_batched: the 5 pyramid levels of one image (rpn_head_3d.py:81-135) in one launch sequence; every
+    segment must give exactly the index list of its own mr3d_nms3d call (and of the oracle), empty and 1-box sets
+    included"""
+    import mr3d_amd  # noqa: F401
+    from mr3d_amd import _hip
+    from oracle import binding as ob
+    rng = np.random.default_rng(21)
+    dev = torch.device('cuda:0')
+    sets = []
+    for n in (2000, 0, 1, 777, 64, 1280, 192):
+        b = rng.uniform(0, 200, (n, 3))
+        sz = rng.uniform(4, 40, (n, 3))
+        d = np.concatenate([b[:, :2], b[:, :2] + sz[:, :2], b[:, 2:], b[:, 2:] + sz[:, 2:], rng.random((n, 1))], 1).astype(np.float32)
+        sets.append(d)
+    dl = [torch.from_numpy(d).to(dev) for d in sets]
+    got = _hip.nms3d_batched(dl, 0.3)
+    for d, t, g in zip(sets, dl, got):
+        single = _hip.nms3d(t, 0.3).cpu().numpy()
+        assert np.array_equal(g.cpu().numpy(), single)
+        if len(d):
+            assert np.array_equal(single, ob.nms3d(d, 0.3))
