@@ -101,6 +101,51 @@ def nms3d(dets, iou_threshold):
     return keep[:k]
 
 
+class RoiLevel(ctypes.Structure):
+    """mr3d_roi_level (include/mr3d.h)"""
+    _fields_ = [('features', ctypes.c_void_p), ('grad', ctypes.c_void_p), ('depth', ctypes.c_int), ('height', ctypes.c_int),
+                ('width', ctypes.c_int), ('spatial_scale', ctypes.c_float), ('spatial_scale_depth', ctypes.c_float)]
+
+
+def _roi_levels(tensors, scales, scales_depth, backward):
+    arr = (RoiLevel * len(tensors))()
+    for i, (t, s, sd) in enumerate(zip(tensors, scales, scales_depth)):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 5 and t.is_contiguous(memory_format=torch.channels_last_3d)):
+            raise RuntimeError('multi-level RoIAlign3D needs float32 channels_last_3d feature maps')
+        if backward:
+            arr[i].grad = t.data_ptr()
+        else:
+            arr[i].features = t.data_ptr()
+        arr[i].depth, arr[i].height, arr[i].width = t.size(2), t.size(3), t.size(4)
+        arr[i].spatial_scale, arr[i].spatial_scale_depth = float(s), float(sd)
+    return arr
+
+
+def roi_align3d_forward_ml(feats, rois, out_d, out_h, out_w, scales, scales_depth, sample_num, finest_scale):
+    """SingleRoIExtractor.forward in one launch (mr3d_roi_align3d_forward_ml); feats: logical [N,C,d,h,w] channels_last_3d"""
+    rois = rois.contiguous()
+    C = feats[0].size(1)
+    out = torch.empty((rois.size(0), C, out_d, out_h, out_w), dtype=torch.float32, device=rois.device)
+    lv = _roi_levels(feats, scales, scales_depth, False)
+    with torch.cuda.device(rois.device):
+        st = lib().mr3d_roi_align3d_forward_ml(lv, len(feats), ctypes.c_float(finest_scale), ptr(rois), rois.size(0), C, out_d, out_h,
+                                               out_w, int(sample_num), ptr(out), stream_ptr(rois.device))
+    check(st, 'mr3d_roi_align3d_forward_ml')
+    return out
+
+
+def roi_align3d_backward_ml(top_grad, rois, grads, out_d, out_h, out_w, scales, scales_depth, sample_num, finest_scale,
+                            bug_compat=True):
+    """grads: PRE-ZEROED channels_last_3d buffers, one per level; accumulated in place"""
+    top_grad, rois = top_grad.contiguous(), rois.contiguous()
+    lv = _roi_levels(grads, scales, scales_depth, True)
+    with torch.cuda.device(rois.device):
+        st = lib().mr3d_roi_align3d_backward_ml(lv, len(grads), ctypes.c_float(finest_scale), ptr(top_grad), ptr(rois), rois.size(0),
+                                                top_grad.size(1), out_d, out_h, out_w, int(sample_num),
+                                                ROIALIGN_BUG_COMPAT if bug_compat else 0, stream_ptr(rois.device))
+    check(st, 'mr3d_roi_align3d_backward_ml')
+
+
 def nms3d_batched(dets_list, iou_threshold):
     """independent NMS3D problems (e.g. the pyramid levels of one image) in ONE launch sequence and ONE 4*S-byte read-back.
     dets_list: [n_s, 7] fp32 device tensors -> list of int64 kept-index tensors (ascending, relative to their own set).

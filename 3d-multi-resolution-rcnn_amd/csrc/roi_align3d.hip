@@ -165,6 +165,35 @@ __global__ __launch_bounds__(256) void roi_align3d_bwd_generic(long long total, 
 }
 
 // ------------------------------------------------------------------------------------------
+// multi-level form (SingleRoIExtractor, mmdet/models/roi_extractors/single_level.py:58-104): every RoI reads the
+// pyramid level its size maps to.  The reference builds a boolean mask per level on the host (one sync per level)
+// and launches RoIAlign once per level; here the level is computed in the kernel (same rule: scale = sqrt(w*h*d) --
+// the square root of the VOLUME, :73-76 -- then floor(log2(scale / finest_scale + 1e-6)) clamped to the pyramid) and
+// one launch serves all levels with no host round trip.
+// ------------------------------------------------------------------------------------------
+constexpr int kMaxLevels = 4;
+struct LevelTable {
+  int num;                 // 0: single-level call (the scalar arguments apply)
+  float finest_scale;
+  const float *feat[kMaxLevels];
+  float *grad[kMaxLevels];
+  int D[kMaxLevels], H[kMaxLevels], W[kMaxLevels];
+  float scale[kMaxLevels], scale_d[kMaxLevels];
+};
+
+__device__ __forceinline__ int roi_level(const float *__restrict__ roi, float finest_scale, int num_levels) {
+  const float sc = sqrtf((roi[3] - roi[1] + 1) * (roi[4] - roi[2] + 1) * (roi[6] - roi[5] + 1));
+  const float l = floorf(log2f(sc / finest_scale + 1e-6f));
+  int lvl = (int)fminf(fmaxf(l, 0.f), (float)(num_levels - 1));
+  return lvl;
+}
+
+template <typename T>
+__device__ __forceinline__ T pick4(int i, const T (&a)[kMaxLevels]) {
+  return i == 0 ? a[0] : (i == 1 ? a[1] : (i == 2 ? a[2] : a[3]));
+}
+
+// ------------------------------------------------------------------------------------------
 // channels-last fast path
 // ------------------------------------------------------------------------------------------
 constexpr int kClThreads = 256;          // 4 waves
@@ -196,16 +225,22 @@ __device__ __forceinline__ void build_axis_table(TabEntry *tab, float start, flo
 }
 
 template <bool kBackward>
-__global__ __launch_bounds__(kClThreads) void roi_align3d_cl(const float *__restrict__ feat_or_top_src,
-                                                            float *__restrict__ out_or_bottom,
+__global__ __launch_bounds__(kClThreads) void roi_align3d_cl(const float *feat_or_top_src, float *out_or_bottom,
                                                             const float *__restrict__ rois, float scale, float scale_d,
                                                             int ns, int C, int D, int H, int W, int PD, int PH, int PW,
-                                                            int bug_compat, const int *__restrict__ owned) {
+                                                            int bug_compat, const int *__restrict__ owned, LevelTable lt) {
   __shared__ TabEntry tabx[kAxisCap], taby[kAxisCap], tabz[kAxisCap];
   __shared__ float tile[kClBins][MR3D_WAVE + 1];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = blockIdx.x;
+  if (lt.num) {            // multi-level: this RoI's own feature map / gradient buffer and geometry
+    const int lvl = roi_level(rois + (size_t)r * 7, lt.finest_scale, lt.num);
+    D = pick4(lvl, lt.D); H = pick4(lvl, lt.H); W = pick4(lvl, lt.W);
+    scale = pick4(lvl, lt.scale); scale_d = pick4(lvl, lt.scale_d);
+    if (kBackward) out_or_bottom = pick4(lvl, lt.grad);
+    else feat_or_top_src = pick4(lvl, lt.feat);
+  }
   const int B = PD * PH * PW;
   const int bin0 = blockIdx.y * kClBins;
   const int nb = min(kClBins, B - bin0);
@@ -350,9 +385,14 @@ __device__ __forceinline__ void axis_extent_geom(float start, float bin, int P, 
 __global__ __launch_bounds__(256) void roi_box_plan_kernel(const float *__restrict__ rois, int num_rois, float scale,
                                                            float scale_d, int ns, int D, int H, int W, int PD, int PH, int PW,
                                                            int *__restrict__ counter, int *__restrict__ owned,
-                                                           int *__restrict__ items) {
+                                                           int *__restrict__ items, LevelTable lt) {
   const int r = blockIdx.x * 256 + threadIdx.x;
   if (r >= num_rois) return;
+  if (lt.num) {
+    const int lvl = roi_level(rois + (size_t)r * 7, lt.finest_scale, lt.num);
+    D = pick4(lvl, lt.D); H = pick4(lvl, lt.H); W = pick4(lvl, lt.W);
+    scale = pick4(lvl, lt.scale); scale_d = pick4(lvl, lt.scale_d);
+  }
   const RoiGeom g = roi_geom(rois + (size_t)r * 7, scale, scale_d, ns, PD, PH, PW);
   int x0, xn, y0, yn, z0, zn;
   axis_extent_geom(g.sw, g.bw, PW, ns, W, x0, xn);
@@ -367,11 +407,11 @@ __global__ __launch_bounds__(256) void roi_box_plan_kernel(const float *__restri
   for (int k = 0; k < nsub; ++k) items[base + k] = r * kMaxSub + k;
 }
 
-__global__ __launch_bounds__(kClThreads) void roi_align3d_bwd_box(const float *__restrict__ top, float *__restrict__ bottom,
+__global__ __launch_bounds__(kClThreads) void roi_align3d_bwd_box(const float *__restrict__ top, float *bottom,
                                                                  const float *__restrict__ rois, float scale, float scale_d,
                                                                  int ns, int C, int D, int H, int W, int PD, int PH, int PW,
                                                                  int bug_compat, const int *__restrict__ counter,
-                                                                 const int *__restrict__ items) {
+                                                                 const int *__restrict__ items, LevelTable lt) {
   __shared__ IdxEntry tx[kAxisCap], ty[kAxisCap], tz[kAxisCap];
   __shared__ float Wx[kSubV][kBoxP], Wy[kSubV][kBoxP], Wz[kSubV][kBoxP];
   __shared__ float Gp[256][kBoxCh];                                   // one pd plane of top_grad: [ph*PW + pw][ch]
@@ -388,6 +428,12 @@ __global__ __launch_bounds__(kClThreads) void roi_align3d_bwd_box(const float *_
   for (int it = blockIdx.x; it < count_items; it += gridDim.x) {
     const int item = items[it];
     const int r = item / kMaxSub, sub = item % kMaxSub;
+    if (lt.num) {
+      const int lvl = roi_level(rois + (size_t)r * 7, lt.finest_scale, lt.num);
+      D = pick4(lvl, lt.D); H = pick4(lvl, lt.H); W = pick4(lvl, lt.W);
+      scale = pick4(lvl, lt.scale); scale_d = pick4(lvl, lt.scale_d);
+      bottom = pick4(lvl, lt.grad);
+    }
     const RoiGeom g = roi_geom(rois + (size_t)r * 7, scale, scale_d, ns, PD, PH, PW);
     __syncthreads();                          // previous item fully flushed before the tables are rebuilt
     build_idx_table(tx, g.sw, g.bw, PW, ns, W, tid, kClThreads);
@@ -540,7 +586,7 @@ extern "C" int mr3d_roi_align3d_forward(const float *features, const float *rois
     dim3 grid(num_rois, (B + kClBins - 1) / kClBins);
     roi_align3d_cl<false><<<grid, kClThreads, 0, stream>>>(features, output, rois, spatial_scale, spatial_scale_depth,
                                                           sample_num, channels, depth, height, width, pooled_depth,
-                                                          pooled_height, pooled_width, 0, nullptr);
+                                                          pooled_height, pooled_width, 0, nullptr, LevelTable{});
   } else {
     const long long total = (long long)num_rois * channels * B;
     const long long blocks = (total + 255) / 256;
@@ -575,15 +621,15 @@ extern "C" int mr3d_roi_align3d_backward(const float *top_grad, const float *roi
       roi_box_plan_kernel<<<(num_rois + 255) / 256, 256, 0, stream>>>(rois, num_rois, spatial_scale, spatial_scale_depth,
                                                                       sample_num, depth, height, width, pooled_depth,
                                                                       pooled_height, pooled_width, scratch, owned,
-                                                                      scratch + 1 + num_rois);
+                                                                      scratch + 1 + num_rois, LevelTable{});
     }
     roi_align3d_cl<true><<<grid, kClThreads, 0, stream>>>(top_grad, bottom_grad, rois, spatial_scale,
                                                          spatial_scale_depth, sample_num, channels, depth, height, width,
-                                                         pooled_depth, pooled_height, pooled_width, bug, owned);
+                                                         pooled_depth, pooled_height, pooled_width, bug, owned, LevelTable{});
     if (scratch)
       roi_align3d_bwd_box<<<dim3(1024, (channels + kBoxCh - 1) / kBoxCh), kClThreads, 0, stream>>>(
         top_grad, bottom_grad, rois, spatial_scale, spatial_scale_depth, sample_num, channels, depth, height, width,
-        pooled_depth, pooled_height, pooled_width, bug, scratch, scratch + 1 + num_rois);
+        pooled_depth, pooled_height, pooled_width, bug, scratch, scratch + 1 + num_rois, LevelTable{});
   } else {
     const long long total = (long long)num_rois * channels * B;
     const long long blocks = (total + 255) / 256;
@@ -594,5 +640,73 @@ extern "C" int mr3d_roi_align3d_backward(const float *top_grad, const float *roi
                                                       strides_for(layout, channels, depth, height, width), bug,
                                                       bottom_grad);
   }
+  return mr3d_launch_status();
+}
+
+namespace {
+int fill_levels(const mr3d_roi_level *levels, int num_levels, float finest_scale, bool backward, LevelTable &lt) {
+  if (!levels || num_levels <= 0 || num_levels > kMaxLevels || !(finest_scale > 0.f)) return MR3D_ERR_INVALID_ARG;
+  lt = LevelTable{};
+  lt.num = num_levels;
+  lt.finest_scale = finest_scale;
+  for (int i = 0; i < kMaxLevels; ++i) {
+    const mr3d_roi_level &L = levels[i < num_levels ? i : num_levels - 1];
+    if (L.depth <= 0 || L.height <= 0 || L.width <= 0) return MR3D_ERR_INVALID_ARG;
+    if (backward ? !L.grad : !L.features) return MR3D_ERR_INVALID_ARG;
+    lt.feat[i] = L.features; lt.grad[i] = L.grad;
+    lt.D[i] = L.depth; lt.H[i] = L.height; lt.W[i] = L.width;
+    lt.scale[i] = L.spatial_scale; lt.scale_d[i] = L.spatial_scale_depth;
+  }
+  return MR3D_OK;
+}
+}  // namespace
+
+extern "C" int mr3d_roi_align3d_forward_ml(const mr3d_roi_level *levels_host, int num_levels, float finest_scale,
+                                           const float *rois, int num_rois, int channels, int pooled_depth, int pooled_height,
+                                           int pooled_width, int sample_num, float *output, mr3d_stream_t stream_) {
+  LevelTable lt;
+  const int st = fill_levels(levels_host, num_levels, finest_scale, false, lt);
+  if (st != MR3D_OK) return st;
+  if (num_rois < 0 || channels <= 0 || pooled_depth <= 0 || pooled_height <= 0 || pooled_width <= 0) return MR3D_ERR_INVALID_ARG;
+  if (num_rois == 0) return MR3D_OK;
+  if (!rois || !output) return MR3D_ERR_INVALID_ARG;
+  if (!use_cl(MR3D_LAYOUT_NDHWC, sample_num, pooled_depth, pooled_height, pooled_width)) return MR3D_ERR_UNSUPPORTED;
+  const int B = pooled_depth * pooled_height * pooled_width;
+  dim3 grid(num_rois, (B + kClBins - 1) / kClBins);
+  roi_align3d_cl<false><<<grid, kClThreads, 0, mr3d_stream(stream_)>>>(nullptr, output, rois, 0.f, 0.f, sample_num, channels, 1, 1, 1,
+                                                                      pooled_depth, pooled_height, pooled_width, 0, nullptr, lt);
+  return mr3d_launch_status();
+}
+
+extern "C" int mr3d_roi_align3d_backward_ml(const mr3d_roi_level *levels_host, int num_levels, float finest_scale,
+                                            const float *top_grad, const float *rois, int num_rois, int channels,
+                                            int pooled_depth, int pooled_height, int pooled_width, int sample_num, int flags,
+                                            mr3d_stream_t stream_) {
+  LevelTable lt;
+  const int st = fill_levels(levels_host, num_levels, finest_scale, true, lt);
+  if (st != MR3D_OK) return st;
+  if (num_rois < 0 || channels <= 0 || pooled_depth <= 0 || pooled_height <= 0 || pooled_width <= 0) return MR3D_ERR_INVALID_ARG;
+  if (num_rois == 0) return MR3D_OK;
+  if (!rois || !top_grad) return MR3D_ERR_INVALID_ARG;
+  if (!use_cl(MR3D_LAYOUT_NDHWC, sample_num, pooled_depth, pooled_height, pooled_width)) return MR3D_ERR_UNSUPPORTED;
+  hipStream_t stream = mr3d_stream(stream_);
+  const int bug = (flags & MR3D_ROIALIGN_BUG_COMPAT) ? 1 : 0;
+  const int B = pooled_depth * pooled_height * pooled_width;
+  int *scratch = box_shape_ok(pooled_depth, pooled_height, pooled_width) ? box_scratch(num_rois) : nullptr;
+  int *owned = nullptr;
+  if (scratch) {
+    owned = scratch + 1;
+    if (hipMemsetAsync(scratch, 0, sizeof(int), stream) != hipSuccess) return MR3D_ERR_LAUNCH;
+    roi_box_plan_kernel<<<(num_rois + 255) / 256, 256, 0, stream>>>(rois, num_rois, 0.f, 0.f, sample_num, 1, 1, 1, pooled_depth,
+                                                                    pooled_height, pooled_width, scratch, owned,
+                                                                    scratch + 1 + num_rois, lt);
+  }
+  dim3 grid(num_rois, (B + kClBins - 1) / kClBins);
+  roi_align3d_cl<true><<<grid, kClThreads, 0, stream>>>(top_grad, nullptr, rois, 0.f, 0.f, sample_num, channels, 1, 1, 1,
+                                                       pooled_depth, pooled_height, pooled_width, bug, owned, lt);
+  if (scratch)
+    roi_align3d_bwd_box<<<dim3(1024, (channels + kBoxCh - 1) / kBoxCh), kClThreads, 0, stream>>>(
+      top_grad, nullptr, rois, 0.f, 0.f, sample_num, channels, 1, 1, 1, pooled_depth, pooled_height, pooled_width, bug, scratch,
+      scratch + 1 + num_rois, lt);
   return mr3d_launch_status();
 }

@@ -3,13 +3,39 @@ RoIAlign3D, results scattered into one [R, C, PD, PH, PW] tensor.
 
 Kept: the level rule (sqrt of the box VOLUME -- not its cube root -- against finest_scale, :73-81), one
 RoIAlign3D per level built through `getattr(ops, layer_type)` with spatial_scale = 1/stride and
-spatial_scale_depth = 1/depth_stride (:45-56).  Changed for the MI355X path: the output buffer takes the
-features' dtype/device (the reference hard-codes torch.cuda.FloatTensor, :93); rois are grouped by level with one
-stable sort (one host sync per call instead of ~8) and results return to input order with one index_copy."""
+spatial_scale_depth = 1/depth_stride (:45-56).  MI355X path: when the pyramid is channels-last on the device the whole
+extractor is ONE multi-level kernel launch (forward) / one plan + two kernels (backward) -- the level of every RoI is
+computed inside the kernel, so there is no host synchronisation, no per-level boolean mask, no gather / scatter of
+RoI subsets (the reference pays a sync per level for `inds.any()` and allocates with torch.cuda.FloatTensor, :93).
+Other layouts keep a per-level path: rois grouped by level with one stable sort + one bincount read-back."""
 import torch
 import torch.nn as nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
 
+from .. import _hip
 from .. import mmdet_ops as ops
+
+
+class _MultiLevelRoIAlign3D(Function):
+    """the whole extractor as one op: level choice inside the kernel (csrc/roi_align3d.hip, multi-level form)"""
+
+    @staticmethod
+    def forward(ctx, rois, cfg, *feats):
+        out_d, out_h, out_w, scales, scales_d, sample_num, finest, bug = cfg
+        ctx.cfg, ctx.shapes = cfg, [f.shape for f in feats]
+        ctx.save_for_backward(rois)
+        return _hip.roi_align3d_forward_ml([f.detach() for f in feats], rois, out_d, out_h, out_w, scales, scales_d, sample_num, finest)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        (rois,) = ctx.saved_tensors
+        out_d, out_h, out_w, scales, scales_d, sample_num, finest, bug = ctx.cfg
+        grads = [torch.empty(sh, dtype=torch.float32, device=rois.device, memory_format=torch.channels_last_3d).zero_()
+                 for sh in ctx.shapes]
+        _hip.roi_align3d_backward_ml(grad_output, rois, grads, out_d, out_h, out_w, scales, scales_d, sample_num, finest, bug)
+        return (None, None) + tuple(g if need else None for g, need in zip(grads, ctx.needs_input_grad[2:]))
 
 
 class SingleRoIExtractor(nn.Module):
@@ -50,6 +76,14 @@ class SingleRoIExtractor(nn.Module):
             return self.roi_layers[0](feats[0], rois)
         layer0 = self.roi_layers[0]
         num_levels = len(feats)
+        # fast path: channels-last pyramid on the device -> ONE multi-level launch, no host synchronisation
+        if (num_levels <= 4 and layer0.sample_num > 0 and isinstance(layer0.out_size, int) and rois.is_cuda and
+                all(f.is_cuda and f.dtype == torch.float32 and f.dim() == 5 and
+                    f.is_contiguous(memory_format=torch.channels_last_3d) for f in feats)):
+            cfg = (layer0.out_size_depth, layer0.out_size, layer0.out_size, tuple(l.spatial_scale for l in self.roi_layers),
+                   tuple(l.spatial_scale_depth for l in self.roi_layers), layer0.sample_num, float(self.finest_scale),
+                   layer0.bug_compat)
+            return _MultiLevelRoIAlign3D.apply(rois.float(), cfg, *feats)
         target_lvls = self.map_roi_levels(rois, num_levels)
         # group the rois by level once (stable sort + one bincount read-back = ONE host sync per call; the
         # reference's boolean-mask loop costs one per level for `inds.any()` plus one per masked gather)

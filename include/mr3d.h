@@ -101,6 +101,25 @@ int mr3d_roi_align3d_backward(const float *top_grad, const float *rois, int num_
                               float spatial_scale, float spatial_scale_depth, int sample_num,
                               int layout, int flags, float *bottom_grad, mr3d_stream_t stream);
 
+/* Multi-level form = the whole SingleRoIExtractor.forward / backward (mmdet/models/roi_extractors/single_level.py:58-104)
+ * in ONE launch without a host round trip: every RoI reads (scatters into) the pyramid level its size maps to --
+ * scale = sqrt(w*h*d) (the square root of the VOLUME, :73-76), level = clamp(floor(log2(scale / finest_scale + 1e-6)))
+ * -- with that level's spatial scales.  levels_host: HOST array of num_levels (<= 4) records; features / grad are
+ * NDHWC [batch, d, h, w, channels] device buffers (grad PRE-ZEROED by the caller, accumulated atomically);
+ * sample_num > 0.  Other arguments as in the single-level calls. */
+typedef struct {
+  const float *features;     /* forward */
+  float *grad;               /* backward */
+  int depth, height, width;
+  float spatial_scale, spatial_scale_depth;
+} mr3d_roi_level;
+int mr3d_roi_align3d_forward_ml(const mr3d_roi_level *levels_host, int num_levels, float finest_scale, const float *rois,
+                                int num_rois, int channels, int pooled_depth, int pooled_height, int pooled_width,
+                                int sample_num, float *output, mr3d_stream_t stream);
+int mr3d_roi_align3d_backward_ml(const mr3d_roi_level *levels_host, int num_levels, float finest_scale,
+                                 const float *top_grad, const float *rois, int num_rois, int channels, int pooled_depth,
+                                 int pooled_height, int pooled_width, int sample_num, int flags, mr3d_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * conv3d forward (+ fused epilogue) -- replaces the torch.nn.Conv3d / cuDNN calls on the reference's
  * backbone-neck path and the elementwise ops that follow them:

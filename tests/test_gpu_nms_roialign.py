@@ -224,3 +224,37 @@ def test_nms3d_batched_equals_per_set_calls():
         assert np.array_equal(g.cpu().numpy(), single)
         if len(d):
             assert np.array_equal(single, ob.nms3d(d, 0.3))
+
+
+def test_multilevel_roialign_level_rule_and_backward(dev, golden_dir):
+    """the one-launch multi-level extractor: (1) the in-kernel level rule picks the level the reference's map_roi_levels
+    picks, for every golden roi (features = constant level id make the choice visible); (2) forward and backward equal
+    the per-level path (NCDHW features take it) on mixed-size rois"""
+    from mr3d_amd.detector import SingleRoIExtractor
+    g = np.load(f'{golden_dir}/roi_levels.npz')
+    ext = SingleRoIExtractor(dict(type='RoIAlign3D', out_size=7, out_size_depth=3, sample_num=2), 64, [4, 8, 16, 32], [2, 4, 8, 16])
+    rois = torch.from_numpy(g['rois']).to(dev)
+    const_feats = [torch.full((1, 64, d, h, h), float(i + 1), device=dev).contiguous(memory_format=torch.channels_last_3d)
+                   for i, (d, h) in enumerate(((40, 128), (20, 64), (10, 32), (5, 16)))]
+    out = ext(const_feats, rois)
+    # a roi entirely outside its level's map yields 0; inside, the level id: take the max over the bins
+    seen = out.amax(dim=(1, 2, 3, 4)).cpu().numpy()
+    inside = seen > 0
+    assert inside.mean() > 0.5
+    assert np.array_equal(seen[inside].astype(np.int64) - 1, g['levels'][inside])
+
+    rng = np.random.default_rng(5)
+    r = g['rois'][:200].copy()
+    r[:, [1, 3]] = np.clip(r[:, [1, 3]], 0, 511); r[:, [2, 4]] = np.clip(r[:, [2, 4]], 0, 511); r[:, [5, 6]] = np.clip(r[:, [5, 6]], 0, 79)
+    rt = torch.from_numpy(r).to(dev)
+    feats_np = [rng.normal(size=(1, 64, d, h, h)).astype(np.float32) for d, h in ((40, 128), (20, 64), (10, 32), (5, 16))]
+    top = torch.from_numpy(rng.normal(size=(200, 64, 3, 7, 7)).astype(np.float32)).to(dev)
+    res = {}
+    for name, fmt in (('ml', torch.channels_last_3d), ('per_level', torch.contiguous_format)):
+        feats = [torch.from_numpy(f).to(dev).contiguous(memory_format=fmt).requires_grad_(True) for f in feats_np]
+        o = ext(feats, rt)
+        o.backward(top)
+        res[name] = (o.detach().cpu().numpy(), [f.grad.cpu().numpy() for f in feats])
+    np.testing.assert_allclose(res['ml'][0], res['per_level'][0], rtol=RTOL, atol=ATOL)
+    for a, b in zip(res['ml'][1], res['per_level'][1]):
+        assert np.abs(a - b).max() <= 1e-4 * max(np.abs(b).max(), 1e-6)
