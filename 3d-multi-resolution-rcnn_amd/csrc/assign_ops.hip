@@ -33,13 +33,15 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // pass 1: per box max / argmax over the gts; per gt max over the boxes (IoU >= 0, so the uint order of the bits is
-// the float order)
+// the float order).  The per-gt maxima are carried in registers for a chunk of 16 gts and reduced per WAVE at the end
+// of the chunk, then across the 4 waves through LDS: two barriers per 16 gts instead of two per gt.
+constexpr int kGtChunk = 16;
 __global__ __launch_bounds__(kT) void assign_pass1(const float *__restrict__ boxes, int stride, int n,
                                                    const uint8_t *__restrict__ inside, const float *__restrict__ gt, int G,
                                                    float *__restrict__ max_ov, int *__restrict__ argmax_ov,
                                                    unsigned *__restrict__ gt_max_bits) {
   __shared__ float sgt[kMaxGtLds * 6];
-  __shared__ float wmax[kT / 64];
+  __shared__ float wmax[kT / 64][kGtChunk];
   const int i = blockIdx.x * kT + threadIdx.x;
   const bool live = i < n && (!inside || inside[i]);
   float b[6] = {0, 0, 0, 0, 0, 0};
@@ -52,16 +54,27 @@ __global__ __launch_bounds__(kT) void assign_pass1(const float *__restrict__ box
     __syncthreads();
     for (int t = threadIdx.x; t < gc * 6; t += kT) sgt[t] = gt[(size_t)g0 * 6 + t];
     __syncthreads();
-    for (int g = 0; g < gc; ++g) {
-      const float v = live ? iou3d(sgt + g * 6, b) : -1.f;
-      if (v > best) { best = v; arg = g0 + g; }
-      const float wm = wave_max(v);
-      if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = wm;
+    for (int c0 = 0; c0 < gc; c0 += kGtChunk) {
+      float gm[kGtChunk];
+#pragma unroll
+      for (int q = 0; q < kGtChunk; ++q) {
+        const int g = c0 + q;
+        float v = -1.f;
+        if (g < gc && live) v = iou3d(sgt + g * 6, b);
+        if (v > best) { best = v; arg = g0 + g; }
+        gm[q] = v;
+      }
+#pragma unroll
+      for (int q = 0; q < kGtChunk; ++q) {
+        const float wm = wave_max(gm[q]);
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6][q] = wm;
+      }
       __syncthreads();
-      if (threadIdx.x == 0) {
-        float m = wmax[0];
-        for (int w = 1; w < kT / 64; ++w) m = fmaxf(m, wmax[w]);
-        if (m >= 0.f) atomicMax(gt_max_bits + g0 + g, __float_as_uint(m));
+      // ONE atomic per workgroup and gt: same-address atomics from every wave of 2926 workgroups serialise badly
+      if (threadIdx.x < kGtChunk && c0 + threadIdx.x < gc) {
+        float m = wmax[0][threadIdx.x];
+        for (int w = 1; w < kT / 64; ++w) m = fmaxf(m, wmax[w][threadIdx.x]);
+        if (m >= 0.f) atomicMax(gt_max_bits + g0 + c0 + threadIdx.x, __float_as_uint(m));
       }
       __syncthreads();
     }
