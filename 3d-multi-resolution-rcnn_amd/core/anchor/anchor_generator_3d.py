@@ -24,26 +24,24 @@ class AnchorGenerator3D(object):
     def num_base_anchors(self):
         return self.base_anchors.size(0)
 
+    def _extents(self, base, ratio_factor, scales):
+        """flattened [ratio x scale] (scale_major) or [scale x ratio] table of box extents along one axis; the product is
+        taken in the reference's order ((base * first) * second) so that the rounded anchors are identical"""
+        first, second = (ratio_factor, scales) if self.scale_major else (scales, ratio_factor)
+        return ((base * first).unsqueeze(1) * second.unsqueeze(0)).reshape(-1)
+
     def gen_base_anchors(self):
-        w = h = self.base_size
-        z = self.anchor_depth_base
-        if self.ctr is None:
-            x_ctr, y_ctr, z_ctr = 0.5 * (w - 1), 0.5 * (h - 1), 0.5 * (z - 1)
-        else:
-            x_ctr, y_ctr, z_ctr = self.ctr
-        h_ratios = torch.sqrt(self.ratios)
-        w_ratios = 1 / h_ratios
-        z_ratios = h_ratios
-        if self.scale_major:
-            ws = (w * w_ratios[:, None] * self.scales[None, :]).view(-1)
-            hs = (h * h_ratios[:, None] * self.scales[None, :]).view(-1)
-            zs = (z * z_ratios[:, None] * self.anchor_depth_scales[None, :]).view(-1)
-        else:
-            ws = (w * self.scales[:, None] * w_ratios[None, :]).view(-1)
-            hs = (h * self.scales[:, None] * h_ratios[None, :]).view(-1)
-            zs = (z * self.anchor_depth_scales[:, None] * z_ratios[None, :]).view(-1)
-        return torch.stack([x_ctr - 0.5 * (ws - 1), y_ctr - 0.5 * (hs - 1), x_ctr + 0.5 * (ws - 1), y_ctr + 0.5 * (hs - 1),
-                            z_ctr - 0.5 * (zs - 1), z_ctr + 0.5 * (zs - 1)], dim=-1).round()
+        """anchor_generator_3d.py:22-53: one box per (ratio, scale) pair centred on the stride cell; xy use `scales`, z
+        uses `depth_scales`; h and z grow with sqrt(ratio), w shrinks with it; corners = centre -/+ (extent - 1) / 2,
+        rounded.  Columns: x1, y1, x2, y2, z1, z2."""
+        sizes = (self.base_size, self.base_size, self.anchor_depth_base)               # w, h, z of the cell
+        centres = self.ctr if self.ctr is not None else tuple(0.5 * (v - 1) for v in sizes)
+        root = torch.sqrt(self.ratios)
+        ext = (self._extents(sizes[0], 1 / root, self.scales), self._extents(sizes[1], root, self.scales),
+               self._extents(sizes[2], root, self.anchor_depth_scales))
+        lo = [c - 0.5 * (e - 1) for c, e in zip(centres, ext)]
+        hi = [c + 0.5 * (e - 1) for c, e in zip(centres, ext)]
+        return torch.stack([lo[0], lo[1], hi[0], hi[1], lo[2], hi[2]], dim=-1).round()
 
     def base_anchors_on(self, device):
         key = str(device)

@@ -1,0 +1,1 @@
+"""Test-infrastructure package: CPU restatements of the reference (see the module docstrings)."""
