@@ -102,13 +102,19 @@ class RPNHead3D(nn.Module):
             losses_reg.append(lr)
         return dict(loss_rpn_cls=losses_cls, loss_rpn_reg=losses_reg)
 
-    def get_bboxes(self, cls_scores, bbox_preds, img_metas, cfg):
-        """per image proposals (anchor_head_3d.py:232-268 -> rpn_head_3d.py:72-149)"""
+    def get_bboxes(self, cls_scores, bbox_preds, img_metas, cfg, use_pos_indices=False):
+        """per image proposals (anchor_head_3d.py:232-268 -> rpn_head_3d.py:72-149).  use_pos_indices: apply the
+        inside-flags cached by the last loss() call on the levels with more than nms_pre anchors, as the reference does
+        implicitly whenever the shapes match (rpn_head_3d.py:97-101, anchor_head_3d.py:212)"""
+        flags = getattr(self, 'pos_indices', None) if use_pos_indices else None
         res = []
         for i, meta in enumerate(img_metas):
+            vf = None
+            if flags is not None:
+                vf = [f if f.dim() == 1 else f[i] for f in flags]
             res.append(get_bboxes_single([c[i] for c in cls_scores], [r[i] for r in bbox_preds], self.anchor_generators,
                                          self.anchor_strides, self.anchor_strides_depth, meta['img_shape'], cfg,
-                                         self.target_means, self.target_stds))
+                                         self.target_means, self.target_stds, valid_flags=vf))
         return res
 
 

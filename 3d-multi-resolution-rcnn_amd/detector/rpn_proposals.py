@@ -4,8 +4,9 @@ rpn_head_3d.py:72-149, called from AnchorHead3D.get_bboxes anchor_head_3d.py:232
 Per level: sigmoid -> top-`nms_pre` -> [anchors + delta2bbox3D + score concat in ONE kernel] -> NMS3D -> first
 `nms_post`; across levels: top-`max_num` by score.  The top-k itself is torch.topk (selection plumbing); anchors
 are never materialised for the whole level (the reference builds all 655,360 P2 anchors, then gathers 2000).
-Not reproduced: the reference's stateful `self.pos_indices` filter (rpn_head_3d.py:95-106), which re-uses the
-inside-flags cached by the previous loss() call -- pass `valid_flags` explicitly to get the same effect."""
+The reference's stateful `self.pos_indices` filter (rpn_head_3d.py:95-106: the inside-flags cached by the previous
+loss() call drop border-crossing anchors before the top-k) is reproduced through the explicit `valid_flags`
+argument; RPNHead3D.get_bboxes passes the cached flags when asked to (forward_train does)."""
 from types import SimpleNamespace
 
 import torch
@@ -29,14 +30,15 @@ def get_bboxes_single(cls_scores, bbox_preds, anchor_generators, anchor_strides,
         A, D, H, W = cls.shape
         gen = anchor_generators[lvl]
         scores = cls.permute(2, 3, 1, 0).reshape(-1).sigmoid()                 # flat (h, w, d, a) order (:87-90)
-        flat = None
-        if valid_flags is not None:
-            keep = valid_flags[lvl].nonzero(as_tuple=False).squeeze(1)
-            scores, flat = scores[keep], keep
         if cfg.nms_pre > 0 and scores.shape[0] > cfg.nms_pre:
-            scores, top = scores.topk(cfg.nms_pre)
-            flat = top if flat is None else flat[top]
-        elif flat is None:
+            # rpn_head_3d.py:95-106: on levels with more anchors than nms_pre the anchors flagged out (the inside-flags
+            # cached by the previous loss() call) are dropped BEFORE the top-k.  Masking their score keeps the selection
+            # on the device (the reference's boolean gather synchronises once per level); it only differs if fewer
+            # than nms_pre anchors are flagged in, when the surplus picks carry score -1 and sort last.
+            if valid_flags is not None and valid_flags[lvl].shape == scores.shape:
+                scores = torch.where(valid_flags[lvl].bool(), scores, scores.new_full((), -1.0))
+            scores, flat = scores.topk(cfg.nms_pre)
+        else:
             flat = torch.arange(scores.shape[0], device=scores.device)
         # regression map of this level, as the kernel reads it
         if reg.is_contiguous():

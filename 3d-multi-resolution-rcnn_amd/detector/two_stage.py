@@ -121,7 +121,8 @@ class TwoStageDetector3D(nn.Module):
                                          draws_list=draws.get('rpn')))
         self._mark('rpn targets+loss')
         with torch.no_grad():
-            proposal_list = self.rpn_head.get_bboxes(*rpn_outs, img_meta, SimpleNamespace(**cfg['rpn_proposal'])) \
+            proposal_list = self.rpn_head.get_bboxes(*rpn_outs, img_meta, SimpleNamespace(**cfg['rpn_proposal']),
+                                                      use_pos_indices=True) \
                 if proposals is None else proposals
         self._mark('proposals (decode+nms3d)')
 

@@ -78,8 +78,8 @@ class TwoStageDetector3D2Scales(TwoStageDetector3D):
         losses.update(loss_rpn_cls_2=l2['loss_rpn_cls'], loss_rpn_reg_2=l2['loss_rpn_reg'])
         with torch.no_grad():
             pcfg = SimpleNamespace(**cfg['rpn_proposal'])
-            proposal_list = self.rpn_head.get_bboxes(*rpn_outs, img_meta, pcfg)
-            proposal_list_2 = self.rpn_head_2.get_bboxes(*rpn_outs_2, img_meta_2, pcfg)
+            proposal_list = self.rpn_head.get_bboxes(*rpn_outs, img_meta, pcfg, use_pos_indices=True)
+            proposal_list_2 = self.rpn_head_2.get_bboxes(*rpn_outs_2, img_meta_2, pcfg, use_pos_indices=True)
 
         # ---- assign / sample both pathways (:182-226)
         s1 = self._sample(proposal_list[0], gt_bboxes[0], gt_labels[0], draws.get('rcnn', [None])[0], 0)

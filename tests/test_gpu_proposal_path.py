@@ -81,7 +81,7 @@ def test_anchor_generator_golden(dev, golden_dir):
                     k += 1
 
 
-def _ref_get_bboxes_single(cls_scores, bbox_preds, gens, strides, dstrides, img_shape, cfg):
+def _ref_get_bboxes_single(cls_scores, bbox_preds, gens, strides, dstrides, img_shape, cfg, pos_indices=None):
     """line-by-line torch/CPU restatement of rpn_head_3d.py:72-149 with the C oracle as `nms`"""
     mlvl = []
     for lvl, (cls, reg) in enumerate(zip(cls_scores, bbox_preds)):
@@ -90,8 +90,12 @@ def _ref_get_bboxes_single(cls_scores, bbox_preds, gens, strides, dstrides, img_
         scores = cls.cpu().permute(2, 3, 1, 0).reshape(-1).sigmoid()
         pred = reg.cpu().permute(2, 3, 1, 0).reshape(-1, 6)
         if cfg['nms_pre'] > 0 and scores.shape[0] > cfg['nms_pre']:
-            scores, top = scores.topk(cfg['nms_pre'])
-            pred, anchors = pred[top], anchors[top]
+            if pos_indices is not None and pos_indices[lvl].shape == scores.shape:       # :97-101
+                m = pos_indices[lvl].cpu().bool()
+                scores, pred, anchors = scores[m], pred[m], anchors[m]
+            if scores.shape[0] > cfg['nms_pre']:
+                scores, top = scores.topk(cfg['nms_pre'])
+                pred, anchors = pred[top], anchors[top]
         props = torch.from_numpy(orc.delta2bbox3d(anchors.numpy(), pred.numpy(), [0.] * 6, [1.] * 6, img_shape))
         dets = torch.cat([props, scores[:, None]], 1)
         keep = orc.nms3d(dets.numpy(), cfg['nms_thr'])
@@ -102,7 +106,7 @@ def _ref_get_bboxes_single(cls_scores, bbox_preds, gens, strides, dstrides, img_
     return props[top]
 
 
-@pytest.mark.parametrize('channels_last', [False, True])
+@pytest.mark.parametrize('channels_last', [False, True, 'flags'])
 def test_rpn_get_bboxes_single_vs_restatement(dev, channels_last):
     from mr3d_amd.core import AnchorGenerator3D
     from mr3d_amd.detector import get_bboxes_single
@@ -115,12 +119,15 @@ def test_rpn_get_bboxes_single_vs_restatement(dev, channels_last):
     for (d, h, w) in sizes:
         c = torch.randn(1, d, h, w, device=dev) * 2
         r = torch.randn(6, d, h, w, device=dev) * 0.4
-        if channels_last:    # what the conv engine hands over: [C, D, H, W] views of an NDHWC buffer
+        if channels_last is True:    # what the conv engine hands over: [C, D, H, W] views of an NDHWC buffer
             r = r.permute(1, 2, 3, 0).contiguous().permute(3, 0, 1, 2)
         cls.append(c); reg.append(r)
     cfg = dict(nms_across_levels=False, nms_pre=1500, nms_post=700, max_num=1000, nms_thr=0.7, min_bbox_size=0)
-    got = get_bboxes_single(cls, reg, gens, strides, dstrides, img_shape, cfg)
-    exp = _ref_get_bboxes_single(cls, reg, gens, strides, dstrides, img_shape, cfg)
+    flags = None
+    if channels_last == 'flags':     # the reference's cached inside-flags (rpn_head_3d.py:97-101): random 70 % here
+        flags = [(torch.rand(d * h * w, device=dev) < 0.7).to(torch.uint8) for (d, h, w) in sizes]
+    got = get_bboxes_single(cls, reg, gens, strides, dstrides, img_shape, cfg, valid_flags=flags)
+    exp = _ref_get_bboxes_single(cls, reg, gens, strides, dstrides, img_shape, cfg, pos_indices=flags)
     assert got.shape == exp.shape
     # same proposals, score-descending; sigmoid saturates, so equal fp32 scores occur and torch.topk orders ties
     # differently on host and device: compare in a canonical order (score desc, then coordinates).  Coordinates

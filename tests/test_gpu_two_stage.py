@@ -66,7 +66,7 @@ def test_forward_train_losses_match_exact_shape_flow(dev):
             np.testing.assert_allclose(losses['loss_rpn_cls'][lvl].item(), lc.item(), rtol=2e-5, atol=1e-7)
             np.testing.assert_allclose(losses['loss_rpn_reg'][lvl].item(), lr.item(), rtol=2e-5, atol=1e-7)
         from types import SimpleNamespace
-        props = det.rpn_head.get_bboxes(cls_scores, bbox_preds, meta, SimpleNamespace(**cfg['rpn_proposal']))[0]
+        props = det.rpn_head.get_bboxes(cls_scores, bbox_preds, meta, SimpleNamespace(**cfg['rpn_proposal']), use_pos_indices=True)[0]
         s = T.rcnn_sample(props.cpu().numpy(), gt.cpu().numpy(), gl.cpu().numpy(), 0.5, 0.5, 0.5, 512, 0.25, *draws['rcnn'][0])
         npos, nneg = len(s['pos_inds']), len(s['neg_inds'])
         c = det.last_sample_counts.cpu().numpy()[0]
