@@ -222,3 +222,31 @@ def test_conv3d_roi_volumes_5x7x7_tiles(dev, cin, cout, n, dhw):
     assert (dw.cpu() - ref).abs().max().item() <= RTOL * ref.abs().max().item()
     refb = dy.sum((0, 2, 3, 4))
     assert (db.cpu() - refb).abs().max().item() <= RTOL * refb.abs().max().item()
+
+
+def test_dominant_kernel_full_size_vs_miopen(dev):
+    """BASELINE configs[1] size: the P2 3x3x3 64->64 conv ([1,64,40,128,128], the roofline's dominant kernel), forward,
+    data gradient and weight gradient, against torch's own GPU convolution (MIOpen) -- an implementation that shares
+    nothing with this one -- plus linearity of the weight gradient in dy (size-independent property)."""
+    from mr3d_amd import _hip
+    g = torch.Generator(device='cpu').manual_seed(99)
+    x = torch.randn((1, 64, 40, 128, 128), generator=g).to(dev)
+    w = (torch.randn((64, 64, 3, 3, 3), generator=g) / np.sqrt(64 * 27)).to(dev)
+    dy = torch.randn((1, 64, 40, 128, 128), generator=g).to(dev)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ref = F.conv3d(xr, wr, None, 1, 1)
+    ref.backward(dy)
+    xc = x.permute(0, 2, 3, 4, 1).contiguous()
+    dyc = dy.permute(0, 2, 3, 4, 1).contiguous()
+    y = _hip.conv3d_forward(xc, _hip.pack_conv_weight(w), (3,) * 3, (1,) * 3, (1,) * 3)
+    rel = lambda a, b: ((a - b).abs().max() / b.abs().max()).item()
+    assert rel(y.permute(0, 4, 1, 2, 3), ref.detach()) <= RTOL
+    wb = w.reshape(64, 64, 27).flip(2).permute(2, 0, 1).contiguous()
+    dx = _hip.conv3d_forward(dyc, wb, (3,) * 3, (1,) * 3, (1,) * 3)
+    assert rel(dx.permute(0, 4, 1, 2, 3), xr.grad) <= RTOL
+    dw = torch.zeros((27, 64, 64), device=dev)
+    _hip.conv3d_wgrad(xc, dyc, dw, (3,) * 3, (1,) * 3, (1,) * 3)
+    assert rel(dw, _hip.pack_conv_weight(wr.grad)) <= RTOL
+    dw2 = torch.zeros_like(dw)
+    _hip.conv3d_wgrad(xc, (dyc * 2.0).contiguous(), dw2, (3,) * 3, (1,) * 3, (1,) * 3)
+    assert rel(dw2, 2.0 * dw) <= 1e-5
