@@ -19,6 +19,87 @@ from ..core.loss import (weighted_binary_cross_entropy, weighted_smoothl1, weigh
 from .rpn_proposals import get_bboxes_single
 
 
+class _RPNHeadPlanFn(torch.autograd.Function):
+    """All pyramid levels of the RPN head as TWO plan runs (forward, backward) instead of ~10 autograd conv nodes:
+    the shared 3x3x3 conv (+bias+ReLU fused), the fused cls+reg 1x1x1 conv; in backward the ReLU mask rides in the
+    epilogue of the 1x1x1 data gradient (no separate mask pass), the four weight gradients of a level run on the
+    plan's side stream beside the data-gradient chain, and the shared weights accumulate over the levels in one scratch
+    (the kernels add atomically).  Returns, per level, the padded [N, 16, D, H, W] map (channels-last storage): channel
+    0..A-1 = cls, A..7A-1 = reg."""
+
+    @staticmethod
+    def forward(ctx, w3, b3, w1, b1, *feats):
+        from .. import _hip
+        dev = feats[0].device
+        co1 = w1.shape[0]
+        cop = -(-co1 // 16) * 16
+        c = w3.shape[0]
+        wf3 = _hip.pack_conv_weight(w3.detach())                                         # [27][64][64]
+        w1p = torch.zeros((cop, c, 1, 1, 1), dtype=torch.float32, device=dev)
+        w1p[:co1] = w1.detach()
+        wf1 = _hip.pack_conv_weight(w1p)                                                 # [1][64][16]
+        sh3 = b3.detach().contiguous()
+        sh1 = torch.zeros(cop, dtype=torch.float32, device=dev)
+        sh1[:co1] = b1.detach()
+        xs = [f.detach().permute(0, 2, 3, 4, 1).contiguous() for f in feats]             # NDHWC (zero-copy for the engine's maps)
+        hs = [torch.empty(x.shape, dtype=torch.float32, device=dev) for x in xs]
+        outs = [torch.empty(x.shape[:4] + (cop,), dtype=torch.float32, device=dev) for x in xs]
+        ops = []
+        for x, h, o in zip(xs, hs, outs):
+            n, d, hh, w, _ = x.shape
+            i3 = [n, d, hh, w, c, c, 3, 3, 3, 1, 1, 1, 1, 1, 1, 0, 0, 0, 1]              # ..., up dims, relu = 1
+            ops.append(_hip.make_op(_hip.OP_CONV_FWD, [x, wf3, h, sh3, None, None, None, None], i3))
+            i1 = [n, d, hh, w, c, cop, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0]
+            ops.append(_hip.make_op(_hip.OP_CONV_FWD, [h, wf1, o, sh1, None, None, None, None], i1))
+        keep = (wf3, wf1, sh3, sh1)
+        with torch.cuda.device(dev):
+            _hip.Plan(ops).run(dev)
+        ctx.save_for_backward(w3, w1p, *xs, *hs)
+        ctx.meta = (len(xs), co1, cop, c)
+        ctx.keep = keep
+        return tuple(o.permute(0, 4, 1, 2, 3) for o in outs)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *gouts):
+        from .. import _hip
+        L, co1, cop, c = ctx.meta
+        saved = ctx.saved_tensors
+        w3, w1p = saved[0], saved[1]
+        xs, hs = saved[2:2 + L], saved[2 + L:2 + 2 * L]
+        dev = xs[0].device
+        wb3 = w3.detach().reshape(c, c, 27).flip(2).permute(2, 0, 1).contiguous()       # [26-tap][co][ci]
+        wb1 = w1p.reshape(cop, c, 1).permute(2, 0, 1).contiguous()                       # [1][16][64]
+        dw3 = torch.zeros((27, c, c), dtype=torch.float32, device=dev)
+        db3 = torch.zeros(c, dtype=torch.float32, device=dev)
+        dw1 = torch.zeros((1, c, cop), dtype=torch.float32, device=dev)
+        db1 = torch.zeros(cop, dtype=torch.float32, device=dev)
+        gxs, ops, keep = [], [], []
+        for x, h, g in zip(xs, hs, gouts):
+            n, d, hh, w, _ = x.shape
+            if g is None:
+                gxs.append(None)
+                continue
+            g16 = g.permute(0, 2, 3, 4, 1).contiguous()
+            gh = torch.empty(x.shape, dtype=torch.float32, device=dev)
+            gx = torch.empty(x.shape, dtype=torch.float32, device=dev)
+            keep += [g16, gh]
+            side = [0] * 11 + [1]                                                        # i[26] = 1: side stream
+            ops.append(_hip.make_op(_hip.OP_CONV_WGRAD, [h, g16, dw1, db1], [n, d, hh, w, c, cop, 1, 1, 1, 1, 1, 1, 0, 0, 0] + side))
+            ops.append(_hip.make_op(_hip.OP_CONV_FWD, [g16, wb1, gh, None, None, None, None, h],
+                                    [n, d, hh, w, cop, c, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0]))      # dgrad 1x1, mask = h (ReLU)
+            ops.append(_hip.make_op(_hip.OP_CONV_WGRAD, [x, gh, dw3, db3], [n, d, hh, w, c, c, 3, 3, 3, 1, 1, 1, 1, 1, 1] + side))
+            ops.append(_hip.make_op(_hip.OP_CONV_FWD, [gh, wb3, gx, None, None, None, None, None],
+                                    [n, d, hh, w, c, c, 3, 3, 3, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0]))
+            gxs.append(gx.permute(0, 4, 1, 2, 3))
+        if ops:
+            with torch.cuda.device(dev):
+                _hip.Plan(ops).run(dev)
+        gw3 = dw3.permute(2, 1, 0).reshape(c, c, 3, 3, 3).contiguous()
+        gw1 = dw1.permute(2, 1, 0).reshape(cop, c, 1, 1, 1)[:co1].contiguous()
+        return (gw3, db3, gw1, db1[:co1].contiguous()) + tuple(gxs)
+
+
 class RPNHead3D(nn.Module):
 
     def __init__(self, in_channels=64, feat_channels=64, anchor_scales=(2,), anchor_depth_scales=(2,), anchor_ratios=(1.0,),
@@ -50,6 +131,13 @@ class RPNHead3D(nn.Module):
         return out[:, :self.num_anchors], out[:, self.num_anchors:]
 
     def forward(self, feats):
+        if feats[0].is_cuda and self.rpn_conv.in_channels % 16 == 0 and self.rpn_conv.out_channels % 64 == 0:
+            # every level in one plan run (two for backward): see _RPNHeadPlanFn
+            w1 = torch.cat([self.rpn_cls.weight, self.rpn_reg.weight], 0)
+            b1 = torch.cat([self.rpn_cls.bias, self.rpn_reg.bias], 0)
+            outs = _RPNHeadPlanFn.apply(self.rpn_conv.weight, self.rpn_conv.bias, w1, b1, *feats)
+            A = self.num_anchors
+            return [o[:, :A] for o in outs], [o[:, A:7 * A] for o in outs]
         outs = [self.forward_single(f) for f in feats]
         return [o[0] for o in outs], [o[1] for o in outs]
 
