@@ -43,7 +43,7 @@ def test_conv3d_linear_deconv_layers_fwd_bwd():
     cl = torch.randn(refl.shape, generator=g)
     refl.backward(cl)
     xld, wld, bld = (t.detach().to(dev).requires_grad_(True) for t in (xl, wl, bl))
-    outl = layers.linear(xld, wld, bld)
+    outl = layers.linear(xld, wld, bld, impl='hip')            # the conv-kernel form; the default is the library GEMM
     assert _rel(outl.detach().cpu(), refl.detach()) <= RTOL
     outl.backward(cl.to(dev))
     assert _rel(xld.grad.cpu(), xl.grad) <= RTOL and _rel(wld.grad.cpu(), wl.grad) <= RTOL and _rel(bld.grad.cpu(), bl.grad) <= RTOL
