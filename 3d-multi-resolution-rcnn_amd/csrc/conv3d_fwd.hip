@@ -55,7 +55,14 @@ struct FwdCfg {
   static constexpr int WROWS = M / WM;          // rows per wave
   static constexpr int MT = WROWS / TM;         // MFMA tiles per wave along M
   static constexpr int KK = CC / KSTEP;         // MFMA k-steps per tap per chunk
-  static constexpr int LDS_BYTES = HP * ROW * 4;
+  // Small tiles (64 positions: layer3/4, P4/P5 after the tile narrowing) have ONE MFMA tile per wave, so a
+  // tap row is 12 MFMAs = 384 cycles -- less than an L2 round trip: fetching weight fragments a row ahead cannot hide
+  // the latency and the kernel crawls at ~1 us per row.  There the chunk's whole weight tile [taps][CC][NB] (if <= 32 KB)
+  // is staged in LDS with the same register pipeline as the halo, one Cin chunk ahead.
+  static constexpr int WTAPS = PAR_ ? 27 : TAPS;
+  static constexpr bool BLDS = (!PAR_ && M == 64 && WTAPS * CC_ * NB_ * 4 <= 32 * 1024);   // PAR walks <= 8 of its 27 taps
+  static constexpr int WLDS = BLDS ? WTAPS * CC_ * NB_ : 0;       // floats
+  static constexpr int LDS_BYTES = (HP * ROW + WLDS) * 4;
   static_assert(WROWS >= TM && WROWS % TM == 0, "each wave needs at least one whole MFMA tile of rows");
   static_assert(CC % KSTEP == 0 && CC % 4 == 0, "channel chunk");
   static_assert(LDS_BYTES <= 160 * 1024, "halo block exceeds the CU's LDS");
@@ -117,7 +124,22 @@ __global__ __launch_bounds__(kThreads) void conv3d_fwd_kernel(Conv3dFwdArgs p, i
   constexpr int Q = C::CC / 4;
   constexpr int NIT = (C::HP * Q + kThreads - 1) / kThreads;
   float4 stage[NIT];
+  float *wl = lds + C::HP * C::ROW;                                // weight tile of the chunk (BLDS only)
+  constexpr int WQ = C::BLDS ? C::WTAPS * C::CC * C::NB / 4 : 0;   // float4 per chunk
+  constexpr int NWV = C::BLDS ? (WQ + kThreads - 1) / kThreads : 1;
+  float4 wstage[NWV];
   auto fetch = [&](int c0) {
+    if constexpr (C::BLDS) {
+#pragma unroll
+      for (int j = 0; j < NWV; ++j) {
+        const int e = tid + j * kThreads;
+        constexpr int PER_TAP = C::CC * C::NB / 4, PER_ROW = C::NB / 4;
+        const int tap = e / PER_TAP, rem = e - tap * PER_TAP;
+        const int ci = rem / PER_ROW, q = rem - ci * PER_ROW;
+        wstage[j] = (e < WQ) ? *reinterpret_cast<const float4 *>(p.w + ((size_t)tap * p.Cin + c0 + ci) * p.Cout + n0 + q * 4)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < NIT; ++j) {
       const int it = tid + j * kThreads;
@@ -176,7 +198,7 @@ __global__ __launch_bounds__(kThreads) void conv3d_fwd_kernel(Conv3dFwdArgs p, i
     kd_ = kd2; kh_ = kh2;
   };
 
-  load_row(bc, 0, 0, 0);
+  if constexpr (!C::BLDS) load_row(bc, 0, 0, 0);
   fetch(0);
   for (int c0 = 0; c0 < p.Cin; c0 += C::CC) {
     __syncthreads();
@@ -189,8 +211,40 @@ __global__ __launch_bounds__(kThreads) void conv3d_fwd_kernel(Conv3dFwdArgs p, i
         d[0] = stage[j].x; d[1] = stage[j].y; d[2] = stage[j].z; d[3] = stage[j].w;
       }
     }
+    if constexpr (C::BLDS) {
+#pragma unroll
+      for (int j = 0; j < NWV; ++j) {
+        const int e = tid + j * kThreads;
+        if (e < WQ) *reinterpret_cast<float4 *>(wl + e * 4) = wstage[j];
+      }
+    }
     __syncthreads();
     if (c0 + C::CC < p.Cin) fetch(c0 + C::CC);
+
+    if constexpr (C::BLDS) {
+      // ---- K loop with both operands in LDS
+      for (int kd = 0; kd < nkd; ++kd)
+        for (int kh = 0; kh < nkh; ++kh)
+#pragma unroll
+          for (int t = 0; t < RT; ++t)
+            if (t < nrt) {
+              const int tapoff = ((kd * C::HH + kh) * C::HW + t) * C::ROW;
+              const float *wt = wl + (wtap(kd, kh, t) * C::CC + lk) * C::NB + wave_n * C::TM + li;
+#pragma unroll
+              for (int kk = 0; kk < C::KK; ++kk) {
+                const float b = wt[kk * C::KSTEP * C::NB];
+#pragma unroll
+                for (int mt = 0; mt < C::MT; ++mt) {
+                  const float a = lds[abase[mt] + tapoff + kk * C::KSTEP];
+                  if constexpr (C::k16)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[mt], 0, 0, 0);
+                  else
+                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mt], 0, 0, 0);
+                }
+              }
+            }
+      continue;
+    }
 
     // ---- K loop over tap rows, ping-ponging the two fragment buffers
     int kd = 0, kh = 0;
