@@ -27,7 +27,10 @@ DEFAULT_TRAIN_CFG = dict(
     rpn_proposal=dict(nms_across_levels=False, nms_pre=2000, nms_post=2000, max_num=2000, nms_thr=0.7, min_bbox_size=0),
     rcnn=dict(assigner=dict(type='MaxIoUAssigner', pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.5, ignore_iof_thr=-1),
               sampler=dict(type='RandomSampler', num=512, pos_fraction=0.25, neg_pos_ub=-1, add_gt_as_proposals=True),
-              mask_size=28, mask_size_depth=20, pos_weight=3, debug=False))
+              mask_size=28, mask_size_depth=20, pos_weight=3, debug=False,
+              # not in the reference: row capacities of the mask-head batch (see PosCountReadback); None = always the
+              # full int(num * pos_fraction) rows with no host synchronisation at all
+              mask_batch_buckets=(16, 32, 64, 128)))
 
 
 # configs/3d-multi-resolution-rcnn.py:131-144
@@ -43,6 +46,39 @@ def bbox2result3D(bboxes, labels, num_classes):
         return [np.zeros((0, 7), dtype=np.float32) for _ in range(num_classes - 1)]
     b, l = bboxes.cpu().numpy(), labels.cpu().numpy()
     return [b[l == i, :] for i in range(num_classes - 1)]
+
+
+MASK_BATCH_BUCKETS = (16, 32, 64, 128)
+
+
+class PosCountReadback(object):
+    """The reference runs its mask head on exactly #positives rois (two_stage_3d.py:194-199), a number the host only
+    learns by synchronising.  Here the roi batch has a static capacity with the real rows first, so the mask head could
+    run sync-free on all int(num * pos_fraction) = 128 rows -- but while the RPN is young there are far fewer positives
+    than that, and 128 rows of a 4-conv + deconv head are ~9 ms of MFMA work on rows that carry no loss.  Compromise:
+    the positive count is copied to pinned host memory right after sampling (asynchronously, BEFORE the bbox head is
+    enqueued), and read just before the mask head is enqueued -- by then the copy finished long ago relative to the
+    device's queue, so the wait does not drain the device -- and the batch is cut to the next bucket capacity.  Rows
+    beyond the count still carry zero weight, so the losses do not depend on the bucket."""
+
+    def __init__(self, counts, buckets, cap_pos):
+        self.buckets, self.cap_pos = buckets, cap_pos
+        if buckets is None:
+            return
+        self.host = torch.empty(1, dtype=counts.dtype).pin_memory()
+        self.host.copy_(counts[:1], non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+
+    def rows(self):
+        if self.buckets is None:
+            return self.cap_pos
+        self.event.synchronize()
+        n = int(self.host[0])
+        for b in sorted(self.buckets):
+            if b >= n:
+                return min(b, self.cap_pos)
+        return self.cap_pos
 
 
 class TwoStageDetector3D(nn.Module):
@@ -143,6 +179,8 @@ class TwoStageDetector3D(nn.Module):
                                                          float(rc['pos_weight']))
             rois.append(r); labels.append(lab); label_weights.append(lw); bbox_targets.append(bt); bbox_weights.append(bw)
             pos_gt.append(pgi); counts.append(cnt)
+        readback = PosCountReadback(counts[0], rc.get('mask_batch_buckets', MASK_BATCH_BUCKETS), cap_pos) \
+            if self.with_mask else None
         counts = torch.stack(counts)
         self.last_sample_counts = counts
         self._mark('rcnn assign+sample+targets')
@@ -162,8 +200,9 @@ class TwoStageDetector3D(nn.Module):
                                           valid_rows=valid_rows, num_rois=num_rois))
         self._mark('bbox roialign+head+loss')
 
-        # ---- mask head on the positives (two_stage_3d.py:194-218): rows [0, cap_pos) of the roi batch, first #pos real
+        # ---- mask head on the positives (two_stage_3d.py:194-218): rows [0, rows) of the roi batch, first #pos real
         if self.with_mask:
+            cap_pos = readback.rows()
             pos_rois = rois[0][:cap_pos].contiguous()
             mask_feats = self.mask_roi_extractor(x[:self.mask_roi_extractor.num_inputs], pos_rois)
             mask_pred = self.mask_head(mask_feats)

@@ -17,7 +17,7 @@ from ..core.post_processing import multiclass_nms_3d
 from ..core.mask import mask_target_single
 from .heads import RPNHead3D, SharedFCBBoxHead3D, FCNMaskHead3D
 from .roi_extractor import SingleRoIExtractor
-from .two_stage import TwoStageDetector3D, bbox2result3D
+from .two_stage import TwoStageDetector3D, bbox2result3D, PosCountReadback, MASK_BATCH_BUCKETS
 
 
 class TwoStageDetector3D2Scales(TwoStageDetector3D):
@@ -34,7 +34,7 @@ class TwoStageDetector3D2Scales(TwoStageDetector3D):
         self.refinement_mask_head = FCNMaskHead3D().to(self.device)                                    # configs/...py:80-85
 
     # ------------------------------------------------------------------ shared pieces
-    def _sample(self, proposals, gt, gl, draws, batch_index, inside=None):
+    def _sample(self, proposals, gt, gl, draws, batch_index, inside=None, want_mask=False):
         """assign + add gts + sample + targets for one image -> dict of fixed-capacity tensors (two_stage_3d_2scales.py
         :182-226 / :268-288)"""
         rc = self.train_cfg['rcnn']
@@ -48,16 +48,19 @@ class TwoStageDetector3D2Scales(TwoStageDetector3D):
         rois, lab, lw, bt, bw, pgi = _hip.bbox_target3d(proposals, gt, gl, assigned_all, pos, neg, cnt, cap, batch_index,
                                                         self.bbox_head.target_means, self.bbox_head.target_stds,
                                                         float(rc['pos_weight']))
+        cap_pos = int(cap * sampler.pos_fraction)
+        readback = PosCountReadback(cnt, rc.get('mask_batch_buckets', MASK_BATCH_BUCKETS) if want_mask else None, cap_pos)
         return dict(rois=rois, labels=lab, label_weights=lw, bbox_targets=bt, bbox_weights=bw, pos_gt=pgi, counts=cnt,
-                    cap_pos=int(cap * sampler.pos_fraction))
+                    cap_pos=cap_pos, readback=readback)
 
     def _mask_loss(self, extractor, head, x, s, gt_masks, key):
         rc = self.train_cfg['rcnn']
-        pos_rois = s['rois'][:s['cap_pos']].contiguous()
+        rows = s['readback'].rows()                                            # bucketed row capacity (two_stage.PosCountReadback)
+        pos_rois = s['rois'][:rows].contiguous()
         mask_pred = head(extractor(x[:extractor.num_inputs], pos_rois))
-        gi = s['pos_gt'][:s['cap_pos']].clamp(min=0)
+        gi = s['pos_gt'][:rows].clamp(min=0)
         targets = mask_target_single(pos_rois[:, 1:], gi, gt_masks, SimpleNamespace(**rc))
-        loss = head.loss(mask_pred, targets, s['labels'][:s['cap_pos']], valid_rows=s['counts'][0].reshape(1))
+        loss = head.loss(mask_pred, targets, s['labels'][:rows], valid_rows=s['counts'][0].reshape(1))
         return {key: loss['loss_mask']}
 
     # ------------------------------------------------------------------ forward_train
@@ -82,7 +85,7 @@ class TwoStageDetector3D2Scales(TwoStageDetector3D):
             proposal_list_2 = self.rpn_head_2.get_bboxes(*rpn_outs_2, img_meta_2, pcfg, use_pos_indices=True)
 
         # ---- assign / sample both pathways (:182-226)
-        s1 = self._sample(proposal_list[0], gt_bboxes[0], gt_labels[0], draws.get('rcnn', [None])[0], 0)
+        s1 = self._sample(proposal_list[0], gt_bboxes[0], gt_labels[0], draws.get('rcnn', [None])[0], 0, want_mask=True)
         s2 = self._sample(proposal_list_2[0], gt_bboxes_2[0], gt_labels_2[0], draws.get('rcnn_2', [None])[0], 0)
 
         # ---- shared bbox head over both roi batches (:229-257)
@@ -112,7 +115,7 @@ class TwoStageDetector3D2Scales(TwoStageDetector3D):
                                self.bbox_head.target_stds, meta2['img_shape'])[:, 6:] / upscaled_factor
             pred_2 = torch.cat((dec, cls_score_2.detach()[:, 1, None]), 1).contiguous()
             real_2 = torch.arange(pred_2.size(0), device=pred_2.device) < n2          # padding rows never become candidates
-        sr = self._sample(pred_2, gt_bboxes[0], gt_labels[0], draws.get('refine', [None])[0], 0, inside=real_2)
+        sr = self._sample(pred_2, gt_bboxes[0], gt_labels[0], draws.get('refine', [None])[0], 0, inside=real_2, want_mask=True)
         feats_r = self.bbox_roi_extractor_refinement(x[:4], sr['rois'])
         _, refined_pred = self.refinement_head(feats_r)
         lr = self.refinement_head.loss(None, refined_pred, sr['labels'], sr['label_weights'], sr['bbox_targets'],

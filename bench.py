@@ -153,13 +153,14 @@ def ops_microbench(dev):
     return out
 
 
-def two_stage_step_ms(vol, steps=5, two_scales=False):
+def two_stage_step_ms(vol, steps=5, two_scales=False, static_mask_batch=False):
     """BASELINE configs[2]: the whole single-pathway training step (backbone+FPN, RPN + loss + proposals/NMS3D,
     assign/sample 512, RoIAlign3D + bbox head, RoIAlign3D + mask head, all losses, backward) on one volume, timed by
     tools/two_stage_bench.py in a CHILD process (a fresh allocator / stream state, as a user would run it)."""
     import subprocess
     cmd = [sys.executable, os.path.join(ROOT, 'tools', 'two_stage_bench.py'), '--steps', str(steps), '--warmup', '3', '--json',
-           '--vol', ','.join(str(v) for v in vol)] + (['--two-scales'] if two_scales else [])
+           '--vol', ','.join(str(v) for v in vol)] + (['--two-scales'] if two_scales else []) + \
+          (['--static-mask-batch'] if static_mask_batch else [])
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     for line in reversed(out.stdout.strip().splitlines()):
         if line.startswith('{'):
@@ -302,6 +303,8 @@ def main():
                 ms = two_stage_step_ms((D, H, W))
                 res['aux']['two_stage_step_ms'] = round(ms, 2)           # BASELINE configs[2]
                 res['aux']['two_stage_iters_per_s'] = round(1e3 / ms, 2)
+                # same step with the mask head always on its full 128-row capacity (no positive-count read-back)
+                res['aux']['two_stage_step_static_mask_batch_ms'] = round(two_stage_step_ms((D, H, W), static_mask_batch=True), 2)
                 ms2 = two_stage_step_ms((D, H, W), steps=3, two_scales=True)  # the shipped model: region + its 1.5x copy
                 res['aux']['shipped_2scales_step_ms'] = round(ms2, 2)
                 res['aux']['shipped_2scales_iters_per_s'] = round(1e3 / ms2, 2)

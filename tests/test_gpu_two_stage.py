@@ -116,6 +116,32 @@ def test_forward_train_backward_reaches_every_parameter(dev):
         assert torch.equal(losses[k], losses2[k]), k
 
 
+def test_mask_batch_buckets_do_not_change_losses_or_gradients(dev):
+    """PosCountReadback: cutting the mask batch to the next bucket above #positives (the reference runs the head on
+    exactly #positives rois, two_stage_3d.py:194-199) leaves loss_mask and every gradient unchanged -- the dropped rows
+    carry zero weight in the static 128-row form"""
+    import copy
+    det, img, gt, gl, masks, meta, draws = _setup(dev, seed=2)
+    res = {}
+    for tag, buckets in (('static', None), ('bucket', (16, 32, 64, 128)), ('tight', (1, 2, 3, 4, 5, 6, 8, 128))):
+        det.train_cfg = copy.deepcopy(det.train_cfg)
+        det.train_cfg['rcnn']['mask_batch_buckets'] = buckets
+        det.extract.zero_grad()
+        det.mask_head.zero_grad(set_to_none=True)
+        losses = det.forward_train(img, meta, [gt], [gl], gt_masks=[masks], draws=draws)
+        det.total_loss(losses).backward()
+        res[tag] = (losses['loss_mask'].item(), det.extract.flat_grads.clone(),
+                    [p.grad.clone() for p in det.mask_head.parameters()])
+    n_pos = int(det.last_sample_counts[0, 0])
+    assert 0 < n_pos < 128
+    for tag in ('bucket', 'tight'):
+        assert abs(res[tag][0] - res['static'][0]) <= 1e-6 * max(1.0, abs(res['static'][0]))
+        scale = res['static'][1].abs().max().item()
+        assert (res[tag][1] - res['static'][1]).abs().max().item() <= 2e-5 * scale
+        for a, b in zip(res[tag][2], res['static'][2]):
+            assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-12)
+
+
 def test_simple_test_inference_path(dev):
     """two_stage_3d.py:229-264: result containers, clipping, score order, masks confined to their (truncated) boxes"""
     det, img, gt, gl, masks, meta, _ = _setup(dev, seed=2)

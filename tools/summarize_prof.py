@@ -32,6 +32,13 @@ def main():
                 a[0] += float(r['Counter_Value']); a[1] += 1
         pmc[key] = {k: v[0] / v[1] for k, v in acc.items()}
     total = sum(float(r['TotalDurationNs']) for r in stats)
+    if not pmc:                                             # timing only: no counter passes were given
+        print('| kernel | calls | total ms | avg us | % |')
+        print('|---|---|---|---|---|')
+        for r in sorted(stats, key=lambda r: -float(r['TotalDurationNs']))[:40]:
+            print(f'| {short(r["Name"])} | {r["Calls"]} | {float(r["TotalDurationNs"]) / 1e6:.3f} | '
+                  f'{float(r["AverageNs"]) / 1e3:.1f} | {100 * float(r["TotalDurationNs"]) / total:.1f} |')
+        return
     print('| kernel | calls | total ms | avg us | % | HBM read MiB/launch (2x FETCH_SIZE) | HBM write MiB/launch | GB/s (r+w) |')
     print('|---|---|---|---|---|---|---|---|')
     for r in sorted(stats, key=lambda r: -float(r['TotalDurationNs']))[:40]:

@@ -37,6 +37,8 @@ def main():
     ap.add_argument('--phases', action='store_true', help='device-event timing of the phases of one step')
     ap.add_argument('--json', action='store_true', help='print one JSON line with the step time')
     ap.add_argument('--no-mask', action='store_true')
+    ap.add_argument('--static-mask-batch', action='store_true',
+                    help='mask heads always on the full 128-row batch (no positive-count read-back, no host sync)')
     ap.add_argument('--profile', action='store_true', help='torch profiler table of one step')
     a = ap.parse_args()
     D, H, W = (int(v) for v in a.vol.split(','))
@@ -44,6 +46,10 @@ def main():
     torch.manual_seed(0)
     det = TwoStageDetector3D2Scales(device=dev) if a.two_scales else TwoStageDetector3D(device=dev, with_mask=not a.no_mask)
     det.extract.init_weights()
+    if a.static_mask_batch:
+        import copy
+        det.train_cfg = copy.deepcopy(det.train_cfg)
+        det.train_cfg['rcnn']['mask_batch_buckets'] = None
     rng = np.random.default_rng(0)
     img = torch.randn(1, 3, D, H, W, device=dev)
     gt, masks = synthetic_gt(rng, a.gts, D, H, W, dev)
@@ -105,7 +111,8 @@ def main():
             print(f'  repeat {rep}: {dt * 1e3:.2f} ms/step')
     if a.json:
         import json
-        print(json.dumps({'two_stage_step_ms': dt * 1e3, 'vol': [D, H, W], 'gts': a.gts, 'steps': a.steps}))
+        print(json.dumps({'two_stage_step_ms': dt * 1e3, 'vol': [D, H, W], 'gts': a.gts, 'steps': a.steps,
+                          'sample_counts': det.last_sample_counts.tolist(), 'static_mask_batch': a.static_mask_batch}))
         return
     print({k: ([round(float(x), 5) for x in v] if isinstance(v, list) else round(float(v), 5)) for k, v in losses.items()})
     print('sample counts (pos, neg, cand_pos, cand_neg):', det.last_sample_counts.tolist())
