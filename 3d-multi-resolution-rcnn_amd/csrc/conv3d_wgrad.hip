@@ -43,12 +43,14 @@ struct WgCfg {
   static constexpr int MT = MROWS / 16, NT = NB / 16;
   static constexpr int TAPG = MERGEW ? KD * KH : KD * KH * KW;   // accumulator groups
   static constexpr int TPW = PW1 ? 1 : (TAPG + 3) / 4;           // tap groups per wave
+  // two workgroups per CU (one hides the other's staging) where LDS allows it and the register budget nearly does
+  static constexpr int MINWG = (KD == 3 && SD == 1 && NB == 32 && LDS_BYTES * 2 <= 160 * 1024) ? 2 : 1;
   static_assert(!MERGEW || CC == 4, "kw-merge needs 4 channels, unpadded rows");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
 template <class C>
-__global__ __launch_bounds__(kThreads) void conv3d_wgrad_kernel(Conv3dWgradArgs p, int tiles_d, int tiles_h, int tiles_w) {
+__global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_wgrad_kernel(Conv3dWgradArgs p, int tiles_d, int tiles_h, int tiles_w) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *xh = lds;
   float *dyt = lds + C::XF;
@@ -65,7 +67,11 @@ __global__ __launch_bounds__(kThreads) void conv3d_wgrad_kernel(Conv3dWgradArgs 
     for (int mt = 0; mt < C::MT; ++mt)
       for (int nt = 0; nt < C::NT; ++nt) acc[t][mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  float bsum = 0.f;   // this thread's share of sum_p dy[p][co] (only the first Cin chunk reduces it)
+  // this thread's share of sum_p dy[p][co] (only the first Cin chunk reduces it): taken from the staging registers,
+  // where a thread always holds the same four channels (kThreads % QN == 0) -- 64 adds per tile instead of 64
+  // dependent LDS reads
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool want_bias = p.dbias && blockIdx.y == 0;
   // LDS offset of each of this wave's tap groups (wave-uniform)
   int tapoff[C::TPW];
 #pragma unroll
@@ -83,10 +89,32 @@ __global__ __launch_bounds__(kThreads) void conv3d_wgrad_kernel(Conv3dWgradArgs 
 
   // ---- tile staging, software-pipelined: the NEXT tile's x halo block and dy tile are fetched into registers before
   // the MFMA loop of the current tile and written to LDS after it (with ~107 KB of LDS per workgroup only one
-  // workgroup fits a CU, so nothing else would hide the global latency)
+  // workgroup fits a CU, so nothing else would hide the global latency).  Everything about a staging slot that does not
+  // depend on the tile is tabulated once per thread: its element offset from the tile's corner (32-bit) and its packed
+  // halo coordinates for the bounds test; per tile only a wave-uniform 64-bit base remains.
   constexpr int Q = C::CC / 4, QN = C::NB / 4;
+  static_assert(kThreads % QN == 0, "a thread keeps the same dy channels in every staging slot");
   constexpr int NX = (C::HP * Q + kThreads - 1) / kThreads, NDY = (C::M * QN + kThreads - 1) / kThreads;
+  constexpr unsigned kNoSlot = 0xffffffffu;
   float4 xs[NX], dys[NDY];
+  int xoff[NX], doff[NDY];
+  unsigned xc[NX], dc[NDY];
+#pragma unroll
+  for (int j = 0; j < NX; ++j) {
+    const int it = tid + j * kThreads;
+    const int pos = it / Q, q = it - pos * Q;
+    const int hw = (pos % C::HW) * C::GSW, hh = ((pos / C::HW) % C::HH) * C::GSH, hd = (pos / (C::HW * C::HH)) * C::GSD;
+    xoff[j] = ((hd * p.H + hh) * p.W + hw) * p.Cin + q * 4;
+    xc[j] = it < C::HP * Q ? (unsigned)(hd | (hh << 8) | (hw << 16)) : kNoSlot;
+  }
+#pragma unroll
+  for (int j = 0; j < NDY; ++j) {
+    const int it = tid + j * kThreads;
+    const int m = it / QN, q = it - m * QN;
+    const int tw = m % C::TW, th = (m / C::TW) % C::TH, td = m / (C::TW * C::TH);
+    doff[j] = ((td * p.Ho + th) * p.Wo + tw) * p.Cout + q * 4;
+    dc[j] = (it < C::M * QN && m < C::MV) ? (unsigned)(td | (th << 8) | (tw << 16)) : kNoSlot;
+  }
   auto fetch = [&](int tile) {
     int b = tile;
     const int tw_i = b % tiles_w; b /= tiles_w;
@@ -95,27 +123,22 @@ __global__ __launch_bounds__(kThreads) void conv3d_wgrad_kernel(Conv3dWgradArgs 
     const int n = b;
     const int od0 = td_i * C::TD, oh0 = th_i * C::TH, ow0 = tw_i * C::TW;
     const int id0 = od0 * C::SD - p.pd, ih0 = oh0 * C::SH - p.ph, iw0 = ow0 * C::SW - p.pw;
+    // corner of the halo block / of the dy tile (may lie outside the tensor: only in-range slots are dereferenced)
+    const float *xb = p.x + ((((long long)n * p.D + id0) * p.H + ih0) * p.W + iw0) * (long long)p.Cin + c0;
+    const float *db = p.dy + ((((long long)n * p.Do + od0) * p.Ho + oh0) * p.Wo + ow0) * (long long)p.Cout + n0;
 #pragma unroll
     for (int j = 0; j < NX; ++j) {
-      const int it = tid + j * kThreads;
-      const int pos = it / Q, q = it - pos * Q;
-      const int hw = pos % C::HW, hh = (pos / C::HW) % C::HH, hd = pos / (C::HW * C::HH);
-      const int id = id0 + hd * C::GSD, ih = ih0 + hh * C::GSH, iw = iw0 + hw * C::GSW;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (it < C::HP * Q && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
-        v = *reinterpret_cast<const float4 *>(p.x + ((((size_t)n * p.D + id) * p.H + ih) * p.W + iw) * p.Cin + c0 + q * 4);
-      xs[j] = v;
+      const unsigned c = xc[j];
+      const bool ok = c != kNoSlot && (unsigned)(id0 + (int)(c & 255u)) < (unsigned)p.D &&
+                      (unsigned)(ih0 + (int)((c >> 8) & 255u)) < (unsigned)p.H && (unsigned)(iw0 + (int)(c >> 16)) < (unsigned)p.W;
+      xs[j] = ok ? *reinterpret_cast<const float4 *>(xb + xoff[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int j = 0; j < NDY; ++j) {
-      const int it = tid + j * kThreads;
-      const int m = it / QN, q = it - m * QN;
-      const int tw = m % C::TW, th = (m / C::TW) % C::TH, td = m / (C::TW * C::TH);
-      const int od = od0 + td, oh = oh0 + th, ow = ow0 + tw;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (it < C::M * QN && m < C::MV && od < p.Do && oh < p.Ho && ow < p.Wo)
-        v = *reinterpret_cast<const float4 *>(p.dy + ((((size_t)n * p.Do + od) * p.Ho + oh) * p.Wo + ow) * p.Cout + n0 + q * 4);
-      dys[j] = v;
+      const unsigned c = dc[j];
+      const bool ok = c != kNoSlot && od0 + (int)(c & 255u) < p.Do && oh0 + (int)((c >> 8) & 255u) < p.Ho &&
+                      ow0 + (int)(c >> 16) < p.Wo;
+      dys[j] = ok ? *reinterpret_cast<const float4 *>(db + doff[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   if ((int)blockIdx.x < num_tiles) fetch(blockIdx.x);
@@ -140,14 +163,10 @@ __global__ __launch_bounds__(kThreads) void conv3d_wgrad_kernel(Conv3dWgradArgs 
         float *d = dyt + m * C::DROW + q * 4;
         d[0] = dys[j].x; d[1] = dys[j].y; d[2] = dys[j].z; d[3] = dys[j].w;
       }
+      if (want_bias) { bsum.x += dys[j].x; bsum.y += dys[j].y; bsum.z += dys[j].z; bsum.w += dys[j].w; }
     }
     __syncthreads();
     if (tile + (int)gridDim.x < num_tiles) fetch(tile + gridDim.x);
-
-    if (p.dbias && blockIdx.y == 0) {
-      const int co = tid % C::NB;
-      for (int m = tid / C::NB; m < C::M; m += kThreads / C::NB) bsum += dyt[m * C::DROW + co];
-    }
     // ---- K loop: 4 positions per MFMA
     constexpr int KSTEPS = C::M / 4;
     constexpr int KPW = C::PW1 ? KSTEPS / 4 : KSTEPS;       // pointwise: waves split the positions
@@ -186,16 +205,17 @@ __global__ __launch_bounds__(kThreads) void conv3d_wgrad_kernel(Conv3dWgradArgs 
     }
   }
 
-  if (p.dbias && blockIdx.y == 0) {
-    // reduce the 256/NB per-thread partials of each channel inside the workgroup first: ONE atomic per channel
-    // per workgroup (256 lanes x 512 workgroups hammering 16 addresses cost more than the MFMA work itself)
+  if (want_bias) {
+    // reduce the per-thread partials of each channel inside the workgroup first: ONE atomic per channel per
+    // workgroup (256 lanes x 512 workgroups hammering 16 addresses cost more than the MFMA work itself).
+    // Thread t holds channels 4*(t % QN) .. +3; slots that were out of range added zeros.
     __syncthreads();
-    lds[tid] = bsum;
+    lds[tid * 4 + 0] = bsum.x; lds[tid * 4 + 1] = bsum.y; lds[tid * 4 + 2] = bsum.z; lds[tid * 4 + 3] = bsum.w;
     __syncthreads();
     if (tid < C::NB) {
       float s = 0.f;
 #pragma unroll
-      for (int q = 0; q < kThreads / C::NB; ++q) s += lds[q * C::NB + tid];
+      for (int r = 0; r < kThreads / QN; ++r) s += lds[(r * QN + (tid >> 2)) * 4 + (tid & 3)];
       atomicAdd(p.dbias + n0 + tid, s);
     }
   }
@@ -275,6 +295,9 @@ extern "C" int mr3d_conv3d_wgrad(const mr3d_conv3d_wgrad_desc *d, mr3d_stream_t 
   if (!nb) return MR3D_ERR_UNSUPPORTED;
   hipStream_t stream = mr3d_stream(stream_);
   const int k = d->kd, s = d->sd * 100 + d->sh * 10 + d->sw;
+  // 3x3x3, Cout % 64 == 0: the 32-wide Cout tile (two workgroups per CU, twice the workgroups) wins on maps with few
+  // tiles (P3: 100 vs 79 TFLOP/s, layer4: 31 vs 25), the 64-wide one on the big maps (P2: 111 vs 106)
+  static const int nb3_env = getenv("MR3D_WGRAD_NB3") ? atoi(getenv("MR3D_WGRAD_NB3")) : 0;   // tuning knob
   if (k == 1 && s == 111) {
     if (a.pd == 0 && a.ph == 0 && a.pw == 0) {
       const int st = mr3d_pointwise_wgrad_try(a, stream);
@@ -298,7 +321,8 @@ extern "C" int mr3d_conv3d_wgrad(const mr3d_conv3d_wgrad_desc *d, mr3d_stream_t 
           case 64: return launch_wgrad<WgCfg<3, 3, 3, 1, 1, 1, 16, 64, false, 5, 7, 7>>(a, stream);
         }
       }
-      return dispatch_wg<3, 1, 1, 1, 16>(a, nb, stream);
+      const int nb3 = nb3_env ? nb3_env : (a.N * t488 < 2048 ? 32 : 64);
+      return dispatch_wg<3, 1, 1, 1, 16>(a, nb < nb3 ? nb : nb3, stream);
     }
   } else if (k == 3 && s == 222) {
     if (a.Cin % 16 == 0) return dispatch_wg<3, 2, 2, 2, 16, 1>(a, nb, stream);   // 3x17x17 halo: one output plane per tile

@@ -30,8 +30,8 @@ struct StemFwdArgs {
   int relu;
 };
 
-// ROW = LDS row stride in floats (69 used).  forward: 72 (multiple of 8 keeps the ds_read_b64 words aligned);
-// wgrad: 80 (== 16 mod 32, so the two tap rows a lane group reads sit 16 banks apart: conflict-free)
+// ROW = LDS row stride in floats of the FORWARD slab (multiple of 8 keeps the ds_read_b64 words aligned); the weight
+// gradient has its own geometry (StemWgGeo)
 template <int TD, int TH, int TW, int ROW>
 struct StemGeo {
   static constexpr int PD = TD + 6, PH = 2 * (TH - 1) + 7, PW = 2 * (TW - 1) + 7 + 1;   // +1: slab starts one column early
@@ -172,16 +172,53 @@ struct StemWgradArgs {
   int N, D, H, W, Ho, Wo;
 };
 
+// LDS geometry of the weight-gradient slab.  Row stride 39 (== 7 mod 32) and plane stride 849 (== 17 == 49 - 32 mod 32)
+// make the bank of tap t's halo offset equal to (t + const) mod 32: the 16 consecutive taps of a column group hit 16
+// consecutive banks.  The four GEMM-k positions of a step are output columns (x, x+8, x+1, x+9): lanes of one 32-lane
+// half differ by 8 columns = 16 floats = 16 banks, so every B read is conflict-free (with the 40-float rows and four
+// consecutive columns 12 of 16 lanes collided pairwise and each read took two LDS passes).
+struct StemWgGeo {
+  static constexpr int TD = 4, TH = 8, TW = 16;
+  static constexpr int PD = TD + 6, PH = 2 * (TH - 1) + 7, PW = 2 * (TW - 1) + 7 + 1;     // 10 x 21 x 38 (one spare column on the left)
+  static constexpr int ROW = 39, PLANE = PH * ROW + 30, SLAB = PD * PLANE;
+  static_assert(PW <= ROW && ROW % 32 == 7 && PLANE % 32 == 17, "bank layout");
+};
+
+__device__ __forceinline__ void stem_wgrad_stage_channel(float *slab, const float *__restrict__ xc, int D, int H, int W, int d0,
+                                                         int h0, int w0, int tid) {
+  using G = StemWgGeo;
+  constexpr int Q = 10;                                  // float4 per row: slab columns 0..39, column 39 is not stored
+  const bool vec = (W & 3) == 0;
+  for (int e = tid; e < G::PD * G::PH * Q; e += kStemThreads) {
+    const int q = e % Q, r = (e / Q) % G::PH, pl = e / (Q * G::PH);
+    const int id = d0 - 3 + pl, ih = 2 * h0 - 3 + r, iw = 2 * w0 - 4 + 4 * q;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((unsigned)id < (unsigned)D && (unsigned)ih < (unsigned)H) {
+      const float *src = xc + ((size_t)id * H + ih) * W;
+      if (vec) {
+        if ((unsigned)iw < (unsigned)W) v = *reinterpret_cast<const float4 *>(src + iw);
+      } else {
+        if ((unsigned)iw < (unsigned)W) v.x = src[iw];
+        if ((unsigned)(iw + 1) < (unsigned)W) v.y = src[iw + 1];
+        if ((unsigned)(iw + 2) < (unsigned)W) v.z = src[iw + 2];
+        if ((unsigned)(iw + 3) < (unsigned)W) v.w = src[iw + 3];
+      }
+    }
+    float *d = slab + pl * G::PLANE + r * G::ROW + 4 * q;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z;
+    if (q < Q - 1) d[3] = v.w;
+  }
+}
+
 __global__ __launch_bounds__(kStemThreads) void stem_wgrad_kernel(StemWgradArgs p, int tiles_d, int tiles_h, int tiles_w) {
-  constexpr int TD = 4, TH = 8, TW = 16;
-  using G = StemGeo<TD, TH, TW, 40>;       // 37 columns used; 40 == 8 (mod 32): four consecutive kh rows sit 8 banks apart
-  constexpr int SW_ROW = G::SW_ROW;
+  using G = StemWgGeo;
+  constexpr int TD = G::TD, TH = G::TH, TW = G::TW;
   constexpr int M = TD * TH * TW;          // 512 positions per tile
   constexpr int DYROW = 16;                // lanes (co, k) read word 16k + co: conflict-free
   constexpr int NQ = 3;                    // accumulator groups per wave
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float *slab = lds;
-  float *dyt = lds + G::SLAB;
+  float *dyt = lds;                        // [M][16], rows in GEMM-k order (see ld)
+  float *slab = lds + M * DYROW;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lk = lane >> 4;
@@ -201,8 +238,10 @@ __global__ __launch_bounds__(kStemThreads) void stem_wgrad_kernel(StemWgradArgs 
     int t = 16 * (q * 8 + wave) + li;
     if (t > 342) t = 342;                  // surplus column: recomputes the last tap, result dropped
     const int kw = t % 7, kh = (t / 7) % 7, kd = t / 49;
-    goff[q] = (kd * G::PH + kh) * SW_ROW + kw + 1;      // +1: slab starts one column early
+    goff[q] = kd * G::PLANE + kh * G::ROW + kw + 1;      // +1: slab starts one column early
   }
+  // GEMM-k order: step ks = (td*TH + th)*4 + j covers output columns 2j + (lk >> 1) + 8*(lk & 1) of row (td, th)
+  const int lane_col = (lk >> 1) + 8 * (lk & 1);
   float bsum = 0.f;
 
   for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
@@ -213,10 +252,11 @@ __global__ __launch_bounds__(kStemThreads) void stem_wgrad_kernel(StemWgradArgs 
     const int n = b;
     const int d0 = td_i * TD, h0 = th_i * TH, w0 = tw_i * TW;
     __syncthreads();
-    // dy tile [m][16] (m = (td*TH + th)*TW + tw), zeros outside
+    // dy tile [m'][16], m' = ks*4 + k in GEMM-k order, zeros outside
     for (int it = tid; it < M * 4; it += kStemThreads) {
       const int m = it >> 2, q4 = it & 3;
-      const int tw = m % TW, th = (m / TW) % TH, td = m / (TW * TH);
+      const int k = m & 3, j = (m >> 2) & 3, th = (m >> 4) & 7, td = m >> 7;
+      const int tw = 2 * j + (k >> 1) + 8 * (k & 1);
       const int od = d0 + td, oh = h0 + th, ow = w0 + tw;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (od < p.D && oh < p.Ho && ow < p.Wo)
@@ -225,13 +265,12 @@ __global__ __launch_bounds__(kStemThreads) void stem_wgrad_kernel(StemWgradArgs 
     }
     for (int ci = 0; ci < 3; ++ci) {
       if (ci) __syncthreads();
-      stem_stage_channel<kStemThreads, G>(slab, p.x + ((size_t)n * 3 + ci) * vox, p.D, p.H, p.W, d0, h0, w0, tid);
+      stem_wgrad_stage_channel(slab, p.x + ((size_t)n * 3 + ci) * vox, p.D, p.H, p.W, d0, h0, w0, tid);
       __syncthreads();
       auto ld = [&](int ks, float &a, float (&bv)[NQ]) {
-        const int m = ks * 4 + lk;                                  // this lane's position (k index)
-        const int tw = m % TW, th = (m / TW) % TH, td = m / (TW * TH);
-        a = dyt[m * DYROW + li];                                    // A[i = co][k]
-        const int pos = (td * G::PH + 2 * th) * SW_ROW + 2 * tw;    // halo origin of that position
+        const int j = ks & 3, th = (ks >> 2) & 7, td = ks >> 5;
+        a = dyt[(ks * 4 + lk) * DYROW + li];                        // A[i = co][k]
+        const int pos = td * G::PLANE + 2 * th * G::ROW + 2 * (2 * j + lane_col);   // halo origin of that position
 #pragma unroll
         for (int q = 0; q < NQ; ++q) bv[q] = slab[pos + goff[q]];
       };
@@ -301,8 +340,7 @@ extern "C" int mr3d_stem_conv_wgrad(const float *x_ncdhw, const float *dy, float
   a.x = x_ncdhw; a.dy = dy; a.dw = dw_packed; a.dbias = dbias;
   a.N = n; a.D = d; a.H = h; a.W = w;
   a.Ho = (h + 6 - 7) / 2 + 1; a.Wo = (w + 6 - 7) / 2 + 1;
-  using G = StemGeo<4, 8, 16, 40>;
-  constexpr int lds_bytes = (G::SLAB + 4 * 8 * 16 * 16) * 4;       // 65.6 KiB: two workgroups per CU
+  constexpr int lds_bytes = (StemWgGeo::SLAB + 4 * 8 * 16 * 16) * 4;       // 66.0 KiB: two workgroups per CU
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(stem_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
