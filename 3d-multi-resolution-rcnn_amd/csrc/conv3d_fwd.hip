@@ -63,6 +63,9 @@ struct FwdCfg {
   static constexpr bool BLDS = (!PAR_ && M == 64 && WTAPS * CC_ * NB_ * 4 <= 32 * 1024);   // PAR walks <= 8 of its 27 taps
   static constexpr int WLDS = BLDS ? WTAPS * CC_ * NB_ : 0;       // floats
   static constexpr int LDS_BYTES = (HP * ROW + WLDS) * 4;
+  // single-chunk 16-wide kernels (layer1's 3x3x3 16->16: load -> compute -> store with nothing to overlap inside a
+  // workgroup) want a third workgroup per CU; they sit just above the 170-register line without the hint
+  static constexpr int MINWG = (NB_ == 16 && !PAR_ && MV == 256 && TAPS == 27 && SD_ == 1) ? 3 : 1;
   static_assert(WROWS >= TM && WROWS % TM == 0, "each wave needs at least one whole MFMA tile of rows");
   static_assert(CC % KSTEP == 0 && CC % 4 == 0, "channel chunk");
   static_assert(LDS_BYTES <= 160 * 1024, "halo block exceeds the CU's LDS");
@@ -75,7 +78,7 @@ __device__ __forceinline__ int nearest_src(int dst, int in, int out) {
 }
 
 template <class C>
-__global__ __launch_bounds__(kThreads) void conv3d_fwd_kernel(Conv3dFwdArgs p, int tiles_d, int tiles_h, int tiles_w) {
+__global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_fwd_kernel(Conv3dFwdArgs p, int tiles_d, int tiles_h, int tiles_w) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
