@@ -370,6 +370,16 @@ class Plan:
             raise Mr3dError(f'mr3d_plan_run: op #{k} (kind {self.array[k].kind}) failed: '
                             f'{lib().mr3d_status_string(int(st)).decode()}')
 
+    def find_ptr(self, address):
+        """[(op index, pointer slot)] of every reference to a device address -- the places to re-point when a caller's
+        tensor is bound in place of a plan-owned staging buffer"""
+        return [(k, j) for k in range(self.n) for j in range(8) if self.array[k].p[j] == address]
+
+    def repoint(self, where, address):
+        assert getattr(self, '_graph', None) is None, 'a captured plan has its addresses baked in'
+        for k, j in where:
+            self.array[k].p[j] = address
+
     def capture(self):
         """hipGraph of the whole plan (mr3d_plan_capture); later run() calls without marks replay it"""
         g = ctypes.c_void_p()

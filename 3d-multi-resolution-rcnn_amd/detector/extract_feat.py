@@ -386,6 +386,11 @@ class ExtractFeat3D(nn.Module):
                                 [nL, self.max_cout]))
         P.fwd_ops, P.bwd_ops = fwd, bwd
         P.fwd, P.bwd = _hip.Plan(fwd), _hip.Plan(bwd)
+        # zero-copy binding (see bind_input / bind_grads): where the plans refer to the input volume and to the
+        # read-only output gradients (P2..P4; the P5 buffer also receives P6's gradient in place, so it stays owned)
+        P.x_refs = (P.fwd.find_ptr(P.x_in.data_ptr()), P.bwd.find_ptr(P.x_in.data_ptr()))
+        P.g_refs = [P.bwd.find_ptr(g.data_ptr()) for g in P.gouts[:3]]
+        P.bound_x, P.bound_g = None, [None, None, None]
         self._building = None
         return P
 
@@ -404,22 +409,71 @@ class ExtractFeat3D(nn.Module):
         if not img.is_cuda:
             raise NotImplementedError('ExtractFeat3D runs on the MI355X only (no CPU fallback)')
         P = self._plan_for(img.shape, slot)
-        P.x_in.copy_(img)
+        self.bind_input(P, img)
         with torch.cuda.device(self.device):
             P.fwd.run(self.device)
         self._last = P
         return tuple(o.permute(0, 4, 1, 2, 3) for o in P.outs)
+
+    def capture(self, P):
+        """hipGraph replay of both passes of a plan (mr3d_plan_capture).  A graph bakes its addresses in, so the plan
+        is first re-pointed at its own staging buffers; from then on inputs and output gradients are copied."""
+        P.fwd.repoint(P.x_refs[0], P.x_in.data_ptr())
+        P.bwd.repoint(P.x_refs[1], P.x_in.data_ptr())
+        for refs, g in zip(P.g_refs, P.gouts):
+            P.bwd.repoint(refs, g.data_ptr())
+        P.bound_x, P.bound_g = None, [None, None, None]
+        P.fwd.capture()
+        P.bwd.capture()
+
+    @staticmethod
+    def _captured(P):
+        return getattr(P.fwd, '_graph', None) is not None or getattr(P.bwd, '_graph', None) is not None
+
+    def bind_input(self, P, img):
+        """Point the stem kernels (forward, and the weight gradient of the matching backward) at the caller's volume
+        when it is a dense fp32 NCDHW tensor -- no 252 MB staging copy; the plan keeps a reference until the next bind,
+        and the caller must leave the tensor unmodified until the backward pass has run (as for any tensor autograd
+        saves).  Other layouts / dtypes, and plans captured into a hipGraph, take the copy."""
+        direct = (img.dtype == torch.float32 and img.is_contiguous() and img.device == P.x_in.device and
+                  img.data_ptr() % 16 == 0 and not self._captured(P))
+        src = img if direct else P.x_in
+        if not direct:
+            P.x_in.copy_(img)
+        if P.bound_x is None or P.bound_x.data_ptr() != src.data_ptr():
+            if not self._captured(P):
+                P.fwd.repoint(P.x_refs[0], src.data_ptr())
+                P.bwd.repoint(P.x_refs[1], src.data_ptr())
+        P.bound_x, P.bound_x_version = src, src._version
+
+    def bind_grads(self, P, grads):
+        """Output gradients: P2..P4 are read in place when they arrive as dense channels-last fp32 tensors (they
+        are only read); P5 / P6 (and anything else) are copied into the plan's buffers."""
+        for i, (gbuf, g) in enumerate(zip(P.gouts, grads)):
+            if g is None:
+                gbuf.zero_()
+                src = gbuf
+            else:
+                gl = g.permute(0, 2, 3, 4, 1)
+                direct = (i < 3 and g.dtype == torch.float32 and gl.is_contiguous() and g.device == gbuf.device and
+                          g.data_ptr() % 16 == 0 and not self._captured(P))
+                src = gl if direct else gbuf
+                if not direct:
+                    gbuf.copy_(gl)
+            if i < 3:
+                if (P.bound_g[i] is None or P.bound_g[i].data_ptr() != src.data_ptr()) and not self._captured(P):
+                    P.bwd.repoint(P.g_refs[i], src.data_ptr())
+                P.bound_g[i] = src
 
     def backward_features(self, grads, plan=None):
         """grads: gradients w.r.t. the 5 pyramid outputs (any memory format; None = zero).  Accumulates parameter
         gradients into the flat gradient arena (== every parameter's .grad).  plan: the forward pass this backward
         belongs to (default: the most recent one)."""
         P = plan if plan is not None else self._last
-        for gbuf, g in zip(P.gouts, grads):
-            if g is None:
-                gbuf.zero_()
-            else:
-                gbuf.copy_(g.permute(0, 2, 3, 4, 1))
+        if P.bound_x is not P.x_in and P.bound_x._version != P.bound_x_version:
+            raise RuntimeError('the input volume bound to this plan was modified in place between forward and backward '
+                               '(the stem weight gradient reads it)')
+        self.bind_grads(P, grads)
         with torch.cuda.device(self.device):
             P.bwd.run(self.device)
 

@@ -203,10 +203,9 @@ def main():
 
     def step(marks_f=None, marks_b=None):
         eng.zero_grad()
-        plan.x_in.copy_(x)
+        eng.bind_input(plan, x)                  # dense NCDHW fp32: read in place, no staging copy
         ev = plan.fwd.run(dev, marks_f)
-        for gbuf, g in zip(plan.gouts, cots):
-            gbuf.copy_(g.permute(0, 2, 3, 4, 1))
+        eng.bind_grads(plan, cots)               # channels-last P2..P4 gradients are read in place, P5/P6 copied
         evb = plan.bwd.run(dev, marks_b)
         if world > 1:
             allreduce_flat_grads(eng.flat_grads, world)
@@ -243,7 +242,7 @@ def main():
     marks_b = sorted(k for w_, k in groups[dom]['ops'] if w_ == 'b')
 
     if os.environ.get('MR3D_BENCH_GRAPH') == '1':          # A/B: hipGraph replay (no per-kernel event brackets possible)
-        plan.fwd.capture(); plan.bwd.capture()
+        eng.capture(plan)
         marks_f = marks_b = None
         step(); torch.cuda.synchronize()
     # ---- timed region: exactly K steps between barrier + synchronize on both sides

@@ -163,7 +163,7 @@ def test_plan_graph_replay_equals_stream_launch():
     eng.backward_features(cots)
     g_ref = eng.flat_grads.clone()
     P = eng._plan_for(x.shape)
-    P.fwd.capture(); P.bwd.capture()
+    eng.capture(P)
     outs2 = eng.forward_features(x)
     for a, b in zip(outs, outs2):
         assert torch.equal(a, b)
@@ -172,3 +172,42 @@ def test_plan_graph_replay_equals_stream_launch():
     torch.cuda.synchronize()
     scale = g_ref.abs().max().item()
     assert (eng.flat_grads - g_ref).abs().max().item() <= 1e-5 * scale
+
+
+@pytest.mark.gpu
+def test_zero_copy_binding_equals_staged_copy():
+    """bind_input / bind_grads: a dense NCDHW volume and channels-last P2..P4 gradients are read in place; any other
+    layout goes through the plan's staging buffers -- same outputs and gradients either way; an in-place change of a
+    bound volume before backward is refused"""
+    import mr3d_amd  # noqa: F401
+    from mr3d_amd.detector import ExtractFeat3D
+    dev = torch.device('cuda:0')
+    torch.manual_seed(5)
+    eng = ExtractFeat3D(device=dev)
+    eng.init_weights()
+    x = torch.randn(1, 3, 16, 64, 64, device=dev)
+    outs = [o.clone() for o in eng.forward_features(x)]
+    P = eng._last
+    assert P.bound_x is x                                                    # read in place
+    cots_cl = [torch.randn(o.shape, device=dev).contiguous(memory_format=torch.channels_last_3d) for o in outs]
+    eng.zero_grad()
+    eng.backward_features(cots_cl)
+    assert all(P.bound_g[i].data_ptr() == cots_cl[i].data_ptr() for i in range(3))
+    g_direct = eng.flat_grads.clone()
+    # the same pass through the staging copies: a strided (non-dense) view of the volume, NCDHW-contiguous gradients
+    xs = torch.zeros(1, 3, 16, 64, 128, device=dev)[..., ::2]
+    xs.copy_(x)
+    outs2 = eng.forward_features(xs)
+    assert eng._last.bound_x is eng._last.x_in
+    for a, b in zip(outs, outs2):
+        assert torch.equal(a, b)
+    eng.zero_grad()
+    eng.backward_features([c.contiguous() for c in cots_cl])
+    assert all(P.bound_g[i] is P.gouts[i] for i in range(3))
+    scale = g_direct.abs().max().item()
+    assert (eng.flat_grads - g_direct).abs().max().item() <= 1e-5 * scale
+    # modified in place after forward: refused
+    eng.forward_features(x)
+    x.add_(1.0)
+    with pytest.raises(RuntimeError):
+        eng.backward_features(cots_cl)
