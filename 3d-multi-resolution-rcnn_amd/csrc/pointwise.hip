@@ -378,14 +378,25 @@ __global__ __launch_bounds__(256) void pointwise_wgrad_kernel(Conv3dWgradArgs p,
     }
   }
 
-  // ---- one atomic pass: dw[ci][co] and dbias[co]
+  // ---- the four waves' [CI x CO] partials are summed through LDS first, then ONE atomic per element per workgroup:
+  // every workgroup of the launch adds into the same CI*CO addresses, and same-address device-scope atomics serialise
+  // (per-wave atomics: 2048 waves x 1024 elements on the 16->64 layer)
+  static_assert(kWavesPerWG * C::CI * C::CO * 4 <= C::LDS_BYTES, "partials fit the slab storage");
+  __syncthreads();
 #pragma unroll
   for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < C::NT; ++nt)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        atomicAdd(p.dw + (size_t)(mt * 16 + lk * 4 + r) * C::CO + nt * 16 + li, acc[mt][nt][r]);
+        lds[wave * (C::CI * C::CO) + (mt * 16 + lk * 4 + r) * C::CO + nt * 16 + li] = acc[mt][nt][r];
+  __syncthreads();
+  for (int e = tid; e < C::CI * C::CO; e += 256) {
+    float s = lds[e];
+#pragma unroll
+    for (int w = 1; w < kWavesPerWG; ++w) s += lds[w * (C::CI * C::CO) + e];
+    atomicAdd(p.dw + e, s);
+  }
   if (p.dbias) {
     // wave-level shuffle reduction, then the 4 waves of the workgroup combine through LDS: one atomic per
     // channel per workgroup
