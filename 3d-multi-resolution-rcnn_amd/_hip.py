@@ -296,11 +296,27 @@ class Conv3dWgradDesc(ctypes.Structure):
     """mr3d_conv3d_wgrad_desc (include/mr3d.h)"""
     _fields_ = [(n, ctypes.c_void_p) for n in ('x', 'dy', 'dw', 'dbias')] + \
                [(n, ctypes.c_int) for n in ('n', 'd', 'h', 'w_in', 'cin', 'cout', 'kd', 'kh', 'kw', 'sd', 'sh', 'sw',
-                                            'pd', 'ph', 'pw')]
+                                            'pd', 'ph', 'pw', 'reserved')] + \
+               [('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_longlong)]
 
 
-def conv3d_wgrad(x, dy, dw_packed, k, stride, pad, dbias=None):
-    """dw_packed [taps,Cin,Cout] += wgrad(x [N,D,H,W,Cin], dy [N,Do,Ho,Wo,Cout]); dw must be pre-zeroed."""
+WGRAD_WORKSPACE_BYTES = 64 << 20        # MR3D_WGRAD_WORKSPACE_BYTES
+_wgrad_ws = {}
+
+
+def wgrad_workspace(device):
+    """The partial-sum workspace lent to the weight-gradient kernels of PLAN records (one per device): all of them
+    run in order on the plan executor's single side stream, so they can share it.  Direct calls on other streams must
+    bring their own (or none: atomics)."""
+    key = torch.device(device).index or 0
+    if key not in _wgrad_ws:
+        _wgrad_ws[key] = torch.empty(WGRAD_WORKSPACE_BYTES // 4, dtype=torch.float32, device=torch.device('cuda', key))
+    return _wgrad_ws[key]
+
+
+def conv3d_wgrad(x, dy, dw_packed, k, stride, pad, dbias=None, workspace=None):
+    """dw_packed [taps,Cin,Cout] += wgrad(x [N,D,H,W,Cin], dy [N,Do,Ho,Wo,Cout]); dw must be pre-zeroed.
+    workspace: optional fp32 tensor (>= WGRAD_WORKSPACE_BYTES) for the two-stage reduction; None = atomics."""
     assert x.is_cuda and x.is_contiguous() and dy.is_contiguous() and dw_packed.is_contiguous()
     cout = dw_packed.size(2)
     assert tuple(dy.shape) == tuple(conv3d_out_shape(x.shape, cout, k, stride, pad))
@@ -311,6 +327,8 @@ def conv3d_wgrad(x, dy, dw_packed, k, stride, pad, dbias=None):
     d.kd, d.kh, d.kw = k
     d.sd, d.sh, d.sw = stride
     d.pd, d.ph, d.pw = pad
+    if workspace is not None:
+        d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * 4
     with torch.cuda.device(x.device):
         st = lib().mr3d_conv3d_wgrad(ctypes.byref(d), stream_ptr(x.device))
     check(st, 'mr3d_conv3d_wgrad')
@@ -343,6 +361,17 @@ def make_op(kind, ptrs=(), ints=(), alpha=0.0):
     for k, v in enumerate(ints):
         o.i[k] = int(v)
     o.f[0] = float(alpha)
+    # Two-stage reduction of the weight-gradient partial sums (private blocks + a summing kernel, bit-reproducible)
+    # instead of atomics.  Measured per layer it only pays where ALL workgroups finish at once on a small address
+    # set; MR3D_WGRAD_TWO_STAGE = "stem" / "all" / "none" selects the records that borrow the device workspace
+    # (side-stream records only: they run in order on ONE stream and can share it).
+    mode = os.environ.get('MR3D_WGRAD_TWO_STAGE', 'none')
+    if o.i[26] == 1 and not o.p[4] and ((kind == OP_STEM_WGRAD and mode in ('stem', 'all')) or
+                                        (kind == OP_CONV_WGRAD and mode == 'all')):
+        ws = wgrad_workspace(next(v.device for v in ptrs if hasattr(v, 'device')))
+        at = 15 if kind == OP_CONV_WGRAD else 4
+        o.p[4] = ws.data_ptr()
+        o.i[at], o.i[at + 1] = split64(ws.numel() * 4)
     return o
 
 
@@ -470,12 +499,14 @@ def stem_conv_forward(x_ncdhw, w_packed, shift=None, relu=False):
     return y
 
 
-def stem_conv_wgrad(x_ncdhw, dy, dw_packed, dbias=None):
+def stem_conv_wgrad(x_ncdhw, dy, dw_packed, dbias=None, workspace=None):
     n, _, d, h, w = x_ncdhw.shape
     assert dy.is_contiguous() and tuple(dw_packed.shape) == (343, 4, 16)
     with torch.cuda.device(x_ncdhw.device):
-        st = lib().mr3d_stem_conv_wgrad(ptr(x_ncdhw), ptr(dy), ptr(dw_packed), ctypes.c_void_p(_opt(dbias)), n, d, h, w,
-                                        stream_ptr(x_ncdhw.device))
+        st = lib().mr3d_stem_conv_wgrad_ws(ptr(x_ncdhw), ptr(dy), ptr(dw_packed), ctypes.c_void_p(_opt(dbias)), n, d, h, w,
+                                           ctypes.c_void_p(_opt(workspace)),
+                                           ctypes.c_longlong(0 if workspace is None else workspace.numel() * 4),
+                                           stream_ptr(x_ncdhw.device))
     check(st, 'mr3d_stem_conv_wgrad')
     return dw_packed
 

@@ -31,7 +31,16 @@ struct Conv3dWgradArgs {
   int N, D, H, W, Cin;
   int Do, Ho, Wo, Cout;
   int pd, ph, pw;
+  // optional two-stage reduction: every workgroup stores its partial sums to its own block of `part` with plain
+  // stores and a second kernel adds the blocks into dw (null or too small: fp32 atomics straight into dw)
+  float *part;
+  long long part_bytes;
 };
+
+// adds `nparts` partial blocks per (chunk y, Cout tile z) into dw: block element e = (g*R + row)*NBc + col goes to
+// dw[(g*Cin + y*cstep + row)*Cout + z*nstep + col]
+int mr3d_reduce_partials(const float *part, int nparts, int G, int R, int NBc, int chunks, int ntiles, int cstep, int nstep,
+                         int Cin, int Cout, float *dw, hipStream_t stream);
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x16 = __attribute__((ext_vector_type(16))) float;

@@ -7,8 +7,11 @@
 //
 // GEMM view per tap: M = Cin (a chunk of CC channels), N = Cout, K = output positions -- the long
 // dimension, so every workgroup walks many 256-position tiles and keeps its accumulators in
-// registers the whole time; one fp32 atomic pass at the end adds them into dw (few workgroups, so
-// atomic bytes are tiny next to the MFMA work).
+// registers the whole time.  At the end the partial sums go either straight into dw with fp32 atomics or --
+// when the caller supplies a workspace -- to a private block per workgroup with plain stores, and a second kernel
+// adds the blocks: all workgroups of a (chunk, Cout tile) add into the SAME taps*CC*NB addresses, device-scope
+// atomics are executed at the memory side one after another per address, and 512 workgroups x 27,648 elements =
+// 14 M of them cost more than 0.2 ms per launch whatever the size of the map (on P3..P5 more than the MFMA work).
 //   * per tile the x halo block [halo position][CC] and the dy tile [position][NB] are staged in LDS
 //     (the same halo block serves all taps: a tap is a constant LDS offset);
 //   * v_mfma_f32_16x16x4_f32: A[i = ci][k = 4 consecutive positions], B[k][j = co];
@@ -44,6 +47,9 @@ struct WgCfg {
   static constexpr int TAPG = MERGEW ? KD * KH : KD * KH * KW;   // accumulator groups
   static constexpr int TPW = PW1 ? 1 : (TAPG + 3) / 4;           // tap groups per wave
   // two workgroups per CU (one hides the other's staging) where LDS allows it and the register budget nearly does
+  // partial-sum block of one workgroup: [tap group][row][NB]; a pointwise conv has one block per WAVE (waves split positions)
+  static constexpr int PER_BLOCK = (PW1 ? 1 : TAPG) * MROWS * NB;
+  static constexpr int BLOCKS_PER_WG = PW1 ? 4 : 1;
   static constexpr int MINWG = (KD == 3 && SD == 1 && NB == 32 && LDS_BYTES * 2 <= 160 * 1024) ? 2 : 1;
   static_assert(!MERGEW || CC == 4, "kw-merge needs 4 channels, unpadded rows");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
@@ -219,7 +225,43 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_wgrad_kernel(Conv3d
       atomicAdd(p.dbias + n0 + tid, s);
     }
   }
-  // ---- add the partial sums into dw[tap][ci][co]
+  // ---- partial sums: private block (two-stage reduction) or atomics into dw[tap][ci][co]
+  if (p.part && !C::MERGEW) {
+    const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    float *dst = p.part + (wg * C::BLOCKS_PER_WG + (C::PW1 ? wave : 0)) * C::PER_BLOCK;
+#pragma unroll
+    for (int t = 0; t < C::TPW; ++t) {
+      const int g = t * 4 + wave;
+      if (!C::PW1 && g >= C::TAPG) continue;
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            dst[((C::PW1 ? 0 : g) * C::MROWS + mt * 16 + lk * 4 + r) * C::NB + nt * 16 + li] = acc[t][mt][nt][r];
+    }
+    return;
+  }
+  if constexpr (C::PW1) {
+    // pointwise: the four waves hold partials of the SAME [CC x NB] block (they split the positions): sum them in LDS
+    // and issue one atomic per element per workgroup (four waves adding to the same addresses at the same moment
+    // serialise at the memory side)
+    static_assert(4 * C::CC * C::NB * 4 <= C::LDS_BYTES, "partials fit the tile storage");
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lds[(wave * C::CC + mt * 16 + lk * 4 + r) * C::NB + nt * 16 + li] = acc[0][mt][nt][r];
+    __syncthreads();
+    for (int e = tid; e < C::CC * C::NB; e += kThreads) {
+      const float s = (lds[e] + lds[C::CC * C::NB + e]) + (lds[2 * C::CC * C::NB + e] + lds[3 * C::CC * C::NB + e]);
+      atomicAdd(p.dw + (size_t)(c0 + e / C::NB) * p.Cout + n0 + e % C::NB, s);
+    }
+    return;
+  }
 #pragma unroll
   for (int t = 0; t < C::TPW; ++t) {
     const int g = t * 4 + wave;
@@ -245,6 +287,34 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_wgrad_kernel(Conv3d
   }
 }
 
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__restrict__ part, int nparts, int per, int R, int NBc,
+                                                              int cstep, int nstep, int Cin, int Cout, float *__restrict__ dw) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= per) return;
+  const int y = blockIdx.y, z = blockIdx.z;
+  const float *src = part + ((size_t)z * gridDim.y + y) * nparts * per + e;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = 0;
+  for (; b + 3 < nparts; b += 4) {
+    s0 += src[(size_t)b * per]; s1 += src[(size_t)(b + 1) * per]; s2 += src[(size_t)(b + 2) * per]; s3 += src[(size_t)(b + 3) * per];
+  }
+  for (; b < nparts; ++b) s0 += src[(size_t)b * per];
+  const int col = e % NBc, row = (e / NBc) % R, g = e / (NBc * R);
+  dw[((size_t)g * Cin + y * cstep + row) * Cout + z * nstep + col] += (s0 + s1) + (s2 + s3);
+}
+
+}  // namespace
+
+int mr3d_reduce_partials(const float *part, int nparts, int G, int R, int NBc, int chunks, int ntiles, int cstep, int nstep,
+                         int Cin, int Cout, float *dw, hipStream_t stream) {
+  const int per = G * R * NBc;
+  dim3 grid((unsigned)((per + 255) / 256), (unsigned)chunks, (unsigned)ntiles);
+  reduce_partials_kernel<<<grid, 256, 0, stream>>>(part, nparts, per, R, NBc, cstep, nstep, Cin, Cout, dw);
+  return mr3d_launch_status();
+}
+
+namespace {
+
 template <class C>
 int launch_wgrad(const Conv3dWgradArgs &a, hipStream_t stream) {
   const int tiles_d = (a.Do + C::TD - 1) / C::TD, tiles_h = (a.Ho + C::TH - 1) / C::TH, tiles_w = (a.Wo + C::TW - 1) / C::TW;
@@ -264,8 +334,14 @@ int launch_wgrad(const Conv3dWgradArgs &a, hipStream_t stream) {
   if (gx < 1) gx = 1;
   if (gx > num_tiles) gx = num_tiles;
   dim3 grid((unsigned)gx, (unsigned)chunks, (unsigned)ntiles);
-  conv3d_wgrad_kernel<C><<<grid, kThreads, C::LDS_BYTES, stream>>>(a, tiles_d, tiles_h, tiles_w);
-  return mr3d_launch_status();
+  Conv3dWgradArgs k = a;
+  const long long need = (long long)gx * chunks * ntiles * C::BLOCKS_PER_WG * C::PER_BLOCK * 4;
+  if (C::MERGEW || !k.part || k.part_bytes < need) k.part = nullptr;
+  conv3d_wgrad_kernel<C><<<grid, kThreads, C::LDS_BYTES, stream>>>(k, tiles_d, tiles_h, tiles_w);
+  const int st = mr3d_launch_status();
+  if (st != MR3D_OK || !k.part) return st;
+  return mr3d_reduce_partials(k.part, gx * C::BLOCKS_PER_WG, C::PW1 ? 1 : C::TAPG, C::MROWS, C::NB, chunks, ntiles, C::CC, C::NB,
+                              a.Cin, a.Cout, a.dw, stream);
 }
 
 template <int K, int SD, int SH, int SW, int CC, int TD = 4>
@@ -285,6 +361,7 @@ extern "C" int mr3d_conv3d_wgrad(const mr3d_conv3d_wgrad_desc *d, mr3d_stream_t 
   if (d->kd != d->kh || d->kh != d->kw) return MR3D_ERR_UNSUPPORTED;
   Conv3dWgradArgs a;
   a.x = d->x; a.dy = d->dy; a.dw = d->dw; a.dbias = d->dbias;
+  a.part = d->workspace; a.part_bytes = d->workspace ? d->workspace_bytes : 0;
   a.N = d->n; a.D = d->d; a.H = d->h; a.W = d->w_in; a.Cin = d->cin; a.Cout = d->cout;
   a.pd = d->pd; a.ph = d->ph; a.pw = d->pw;
   a.Do = (d->d + 2 * d->pd - d->kd) / d->sd + 1;

@@ -9,7 +9,9 @@ long long i64_of(const int32_t *lo_hi) {
   return (long long)(((unsigned long long)(uint32_t)lo_hi[1] << 32) | (uint32_t)lo_hi[0]);
 }
 
-int run_one(const mr3d_op &o, mr3d_stream_t s) {
+// shared_ws: the partial-sum workspace of weight-gradient records may be used (records that can run concurrently on
+// DIFFERENT streams must not share it: see mr3d_plan_run)
+int run_one(const mr3d_op &o, mr3d_stream_t s, bool shared_ws = true) {
   const int32_t *i = o.i;
   void *const *p = o.p;
   switch (o.kind) {
@@ -31,6 +33,8 @@ int run_one(const mr3d_op &o, mr3d_stream_t s) {
       mr3d_conv3d_wgrad_desc d;
       d.x = (const float *)p[0]; d.dy = (const float *)p[1]; d.dw = (float *)p[2]; d.dbias = (float *)p[3];
       memcpy(&d.n, i, sizeof(int) * 15);
+      d.reserved = 0;
+      d.workspace = shared_ws ? (float *)p[4] : nullptr; d.workspace_bytes = d.workspace ? i64_of(i + 15) : 0;
       return mr3d_conv3d_wgrad(&d, s);
     }
     case MR3D_OP_MAXPOOL_FWD:
@@ -62,7 +66,8 @@ int run_one(const mr3d_op &o, mr3d_stream_t s) {
       return mr3d_stem_conv_forward((const float *)p[0], (const float *)p[1], (const float *)p[2], (float *)p[3], i[0], i[1], i[2],
                                     i[3], i[4], s);
     case MR3D_OP_STEM_WGRAD:
-      return mr3d_stem_conv_wgrad((const float *)p[0], (const float *)p[1], (float *)p[2], (float *)p[3], i[0], i[1], i[2], i[3], s);
+      return mr3d_stem_conv_wgrad_ws((const float *)p[0], (const float *)p[1], (float *)p[2], (float *)p[3], i[0], i[1], i[2], i[3],
+                                     shared_ws ? (float *)p[4] : nullptr, (shared_ws && p[4]) ? i64_of(i + 4) : 0, s);
   }
   return MR3D_ERR_INVALID_ARG;
 }
@@ -139,7 +144,8 @@ extern "C" int mr3d_plan_run(const mr3d_op *ops, int num_ops, int *failed_index,
         if (failed_index) *failed_index = k;
         return MR3D_ERR_LAUNCH;
       }
-      st = run_one(ops[k], (mr3d_stream_t)ss);
+      // one side stream: its records run in order and may share the partial-sum workspace; with several they could overlap
+      st = run_one(ops[k], (mr3d_stream_t)ss, g_side.nstreams == 1);
       side_busy = true;
     } else {
       if (ops[k].kind == MR3D_OP_FINISH_GRADS && !join()) st = MR3D_ERR_LAUNCH;

@@ -391,11 +391,13 @@ __global__ __launch_bounds__(256) void pointwise_wgrad_kernel(Conv3dWgradArgs p,
       for (int r = 0; r < 4; ++r)
         lds[wave * (C::CI * C::CO) + (mt * 16 + lk * 4 + r) * C::CO + nt * 16 + li] = acc[mt][nt][r];
   __syncthreads();
+  float *part = p.part ? p.part + (size_t)blockIdx.x * (C::CI * C::CO) : nullptr;
   for (int e = tid; e < C::CI * C::CO; e += 256) {
     float s = lds[e];
 #pragma unroll
     for (int w = 1; w < kWavesPerWG; ++w) s += lds[w * (C::CI * C::CO) + e];
-    atomicAdd(p.dw + e, s);
+    if (part) part[e] = s;               // two-stage reduction: a second kernel adds the workgroups' blocks
+    else atomicAdd(p.dw + e, s);
   }
   if (p.dbias) {
     // wave-level shuffle reduction, then the 4 waves of the workgroup combine through LDS: one atomic per
@@ -470,8 +472,12 @@ int launch_pw_wgrad(const Conv3dWgradArgs &a, hipStream_t stream) {
   const long long need = (ntiles + kWavesPerWG * 4 - 1) / (kWavesPerWG * 4);   // >= 4 tiles per wave before the atomics
   if (grid > need) grid = need;
   if (grid < 1) grid = 1;
-  pointwise_wgrad_kernel<C><<<(unsigned)grid, 256, C::LDS_BYTES, stream>>>(a, rows);
-  return mr3d_launch_status();
+  Conv3dWgradArgs k = a;
+  if (!k.part || k.part_bytes < grid * (long long)(CI * CO * 4)) k.part = nullptr;
+  pointwise_wgrad_kernel<C><<<(unsigned)grid, 256, C::LDS_BYTES, stream>>>(k, rows);
+  const int st = mr3d_launch_status();
+  if (st != MR3D_OK || !k.part) return st;
+  return mr3d_reduce_partials(k.part, (int)grid, 1, CI, CO, 1, 1, 0, 0, CI, CO, a.dw, stream);
 }
 
 }  // namespace

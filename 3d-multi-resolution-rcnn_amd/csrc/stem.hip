@@ -170,6 +170,7 @@ struct StemWgradArgs {
   float *dw;           // packed [343][4][16], pre-zeroed (ci 3 stays 0)
   float *dbias;        // [16] or null
   int N, D, H, W, Ho, Wo;
+  float *part;         // per-workgroup partial blocks [343][3][16] (two-stage reduction) or null (atomics)
 };
 
 // LDS geometry of the weight-gradient slab.  Row stride 39 (== 7 mod 32) and plane stride 849 (== 17 == 49 - 32 mod 32)
@@ -294,14 +295,20 @@ __global__ __launch_bounds__(kStemThreads) void stem_wgrad_kernel(StemWgradArgs 
   }
 
   // D[i = co][j]: lane holds column j = li (tap t), rows co = lk*4 + r
+  float *part = p.part ? p.part + (size_t)blockIdx.x * (343 * 3 * 16) : nullptr;
 #pragma unroll
   for (int ci = 0; ci < 3; ++ci)
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int t = 16 * (q * 8 + wave) + li;
       if (t < 343) {
+        if (part) {
+          *reinterpret_cast<float4 *>(part + ((size_t)t * 3 + ci) * 16 + lk * 4) =
+              make_float4(acc[ci][q][0], acc[ci][q][1], acc[ci][q][2], acc[ci][q][3]);
+        } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(p.dw + ((size_t)t * 4 + ci) * 16 + lk * 4 + r, acc[ci][q][r]);
+          for (int r = 0; r < 4; ++r) atomicAdd(p.dw + ((size_t)t * 4 + ci) * 16 + lk * 4 + r, acc[ci][q][r]);
+        }
       }
     }
   if (p.dbias && wave == 0) {
@@ -335,6 +342,11 @@ extern "C" int mr3d_stem_conv_forward(const float *x_ncdhw, const float *w_packe
 
 extern "C" int mr3d_stem_conv_wgrad(const float *x_ncdhw, const float *dy, float *dw_packed, float *dbias, int n, int d, int h,
                                     int w, mr3d_stream_t stream_) {
+  return mr3d_stem_conv_wgrad_ws(x_ncdhw, dy, dw_packed, dbias, n, d, h, w, nullptr, 0, stream_);
+}
+
+extern "C" int mr3d_stem_conv_wgrad_ws(const float *x_ncdhw, const float *dy, float *dw_packed, float *dbias, int n, int d, int h,
+                                       int w, float *workspace, long long workspace_bytes, mr3d_stream_t stream_) {
   if (!x_ncdhw || !dy || !dw_packed || n <= 0 || d <= 0 || h <= 0 || w <= 0) return MR3D_ERR_INVALID_ARG;
   StemWgradArgs a;
   a.x = x_ncdhw; a.dy = dy; a.dw = dw_packed; a.dbias = dbias;
@@ -361,6 +373,10 @@ extern "C" int mr3d_stem_conv_wgrad(const float *x_ncdhw, const float *dy, float
       cus = prop.multiProcessorCount;
   }
   const int grid = tiles < 2 * cus ? tiles : 2 * cus;
+  // two-stage reduction when the caller lends a workspace: 512 workgroups x 16,464 same-address atomics are ~0.13 ms
+  a.part = (workspace && workspace_bytes >= (long long)grid * 343 * 3 * 16 * 4) ? workspace : nullptr;
   stem_wgrad_kernel<<<(unsigned)grid, kStemThreads, lds_bytes, mr3d_stream(stream_)>>>(a, td, th, tw);
-  return mr3d_launch_status();
+  const int st = mr3d_launch_status();
+  if (st != MR3D_OK || !a.part) return st;
+  return mr3d_reduce_partials(a.part, grid, 343, 3, 16, 1, 1, 0, 0, 4, 16, dw_packed, mr3d_stream(stream_));
 }

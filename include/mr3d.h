@@ -158,13 +158,20 @@ int mr3d_conv3d_dgrad_s2k3(const mr3d_conv3d_desc *desc, mr3d_stream_t stream);
  *   dw[tap][ci][co] += sum_{n,p} x[n, p*stride + tap - pad][ci] * dy[n, p][co]
  * x, dy NDHWC fp32; dw packed [kd*kh*kw][Cin][Cout], PRE-ZEROED by the caller (partial sums of the
  * workgroups are added with fp32 atomics: last-bit nondeterministic like any atomic reduction).
+ * workspace (optional, MR3D_WGRAD_WORKSPACE_BYTES is always enough): the workgroups store their partial sums there
+ * with plain stores and a second kernel adds them into dw -- deterministic, and faster than ~10^7 same-address
+ * atomics; it must not be shared by calls that can run concurrently (different streams).
  * Same kernel-size / stride / channel support as mr3d_conv3d_forward.
  * ---------------------------------------------------------------------------------------------- */
+#define MR3D_WGRAD_WORKSPACE_BYTES (64ll << 20)
 typedef struct {
   const float *x; const float *dy; float *dw;
   float *dbias;   /* [cout] += sum_p dy[p][co] (bias / BN-beta gradient); pre-zeroed; may be NULL */
   int n, d, h, w_in, cin, cout;
   int kd, kh, kw, sd, sh, sw, pd, ph, pw;
+  int reserved;
+  float *workspace;             /* NULL: atomics */
+  long long workspace_bytes;
 } mr3d_conv3d_wgrad_desc;
 int mr3d_conv3d_wgrad(const mr3d_conv3d_wgrad_desc *desc, mr3d_stream_t stream);
 
@@ -383,6 +390,9 @@ int mr3d_stem_conv_forward(const float *x_ncdhw, const float *w_packed, const fl
                            int n, int d, int h, int w, int relu, mr3d_stream_t stream);
 int mr3d_stem_conv_wgrad(const float *x_ncdhw, const float *dy, float *dw_packed, float *dbias,
                          int n, int d, int h, int w, mr3d_stream_t stream);
+/* same, with the optional partial-sum workspace of mr3d_conv3d_wgrad_desc (NULL / too small: atomics) */
+int mr3d_stem_conv_wgrad_ws(const float *x_ncdhw, const float *dy, float *dw_packed, float *dbias,
+                            int n, int d, int h, int w, float *workspace, long long workspace_bytes, mr3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Plan executor: runs a pre-built list of the operations above with ONE call (the host-side loop of
@@ -391,7 +401,7 @@ int mr3d_stem_conv_wgrad(const float *x_ncdhw, const float *dy, float *dw_packed
  * (resnet3d.py:467-478, fpn3d.py:95-134) and of autograd's backward over them.
  * Field use per kind (unused = 0):
  *   CONV_FWD      p = {x,w,y,shift,add1,add2,up,mask}   i = the 25 ints of mr3d_conv3d_desc in order
- *   CONV_WGRAD    p = {x,dy,dw,dbias}                   i = the 15 ints of mr3d_conv3d_wgrad_desc
+ *   CONV_WGRAD    p = {x,dy,dw,dbias,workspace}         i = the 15 ints of mr3d_conv3d_wgrad_desc, i[15..16] = workspace bytes (lo, hi)
  *   MAXPOOL_FWD   p = {x,y,argmax}                      i = {n,d,h,w,c}
  *   MAXPOOL_BWD   p = {dy,argmax,relu_of,dx}            i = {n,d,h,w,c}
  *   ZERO_STUFF2   p = {src,dst}                         i = {n,do,ho,wo,d,h,w,c}
@@ -403,7 +413,7 @@ int mr3d_stem_conv_wgrad(const float *x_ncdhw, const float *dy, float *dw_packed
  *   PREP_WEIGHTS  p = {table,params,packed}             i = {num_layers}
  *   FINISH_GRADS  p = {table,params,scratch,grads}      i = {num_layers,max_cout}
  *   STEM_FWD      p = {x_ncdhw,w_packed,shift,y}        i = {n,d,h,w,relu}
- *   STEM_WGRAD    p = {x_ncdhw,dy,dw_packed,dbias}      i = {n,d,h,w}
+ *   STEM_WGRAD    p = {x_ncdhw,dy,dw_packed,dbias,workspace}  i = {n,d,h,w, workspace bytes lo, hi}
  *   CONV_DGRAD_S2 p / i as CONV_FWD (mr3d_conv3d_dgrad_s2k3: x = dy, w = wb, y = dx; y_d/y_h/y_w = dx's grid)
  * Returns the first non-OK status; *failed_index (host int, may be NULL) receives the op index.
  * ---------------------------------------------------------------------------------------------- */

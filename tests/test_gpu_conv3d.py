@@ -109,6 +109,17 @@ def test_conv3d_wgrad(dev, cin, cout, k, stride, pad, dhw):
     err = (dw.cpu() - ref).abs().max().item()
     scale = ref.abs().max().item()
     assert err <= RTOL * scale, f'wgrad max err {err:.3e} vs scale {scale:.3e}'
+    # two-stage reduction (private partial blocks + a summing kernel) instead of atomics: same result, accumulating
+    # into dw, and bit-identical from run to run
+    ws = _hip.wgrad_workspace(dev)
+    dw2 = dw.clone()
+    _hip.conv3d_wgrad(_cl(x).to(dev), _cl(dy).to(dev), dw2, (k,) * 3, stride, (pad,) * 3, workspace=ws)
+    assert (dw2.cpu() - 2 * ref).abs().max().item() <= 2 * RTOL * scale
+    dw3, dw4 = torch.zeros_like(dw), torch.zeros_like(dw)
+    _hip.conv3d_wgrad(_cl(x).to(dev), _cl(dy).to(dev), dw3, (k,) * 3, stride, (pad,) * 3, workspace=ws)
+    _hip.conv3d_wgrad(_cl(x).to(dev), _cl(dy).to(dev), dw4, (k,) * 3, stride, (pad,) * 3, workspace=ws)
+    if not (k == 7 and cin == 4):              # the kw-merged 7x7x7 fallback keeps atomics
+        assert torch.equal(dw3, dw4)
 
 
 @pytest.mark.parametrize('n,dhw', [(1, (8, 32, 32)), (1, (16, 64, 64)), (2, (10, 40, 36)), (1, (5, 70, 130)), (1, (9, 17, 23))])
@@ -129,6 +140,9 @@ def test_stem_kernels_forward_and_wgrad(dev, n, dhw):
     ref.backward(dy.double())
     dw = torch.zeros((343, 4, 16), device=dev); db = torch.zeros(16, device=dev)
     _hip.stem_conv_wgrad(x.to(dev), _cl(dy).to(dev), dw, db)
+    dw_ws = torch.zeros_like(dw)
+    _hip.stem_conv_wgrad(x.to(dev), _cl(dy).to(dev), dw_ws, None, workspace=_hip.wgrad_workspace(dev))
+    assert (dw_ws - dw).abs().max().item() <= 2e-5 * dw.abs().max().item()
     refp = _hip.pack_conv_weight(torch.cat([w.grad, torch.zeros(16, 1, 7, 7, 7)], 1))
     errw = (dw.cpu() - refp).abs().max().item() / refp.abs().max().item()
     errb = (db.cpu() - dy.sum((0, 2, 3, 4))).abs().max().item() / dy.sum((0, 2, 3, 4)).abs().max().item()
@@ -166,6 +180,9 @@ def test_pointwise_streaming_forward_epilogues_and_wgrad(dev, cin, cout):
     _hip.conv3d_wgrad(xc, _cl(dy).to(dev), dw, k1, s1, p0, dbias=db)
     ref = _hip.pack_conv_weight(wz.grad)
     assert (dw.cpu() - ref).abs().max().item() <= RTOL * ref.abs().max().item()
+    dw_ws = torch.zeros_like(dw)
+    _hip.conv3d_wgrad(xc, _cl(dy).to(dev), dw_ws, k1, s1, p0, workspace=_hip.wgrad_workspace(dev))
+    assert (dw_ws.cpu() - ref).abs().max().item() <= RTOL * ref.abs().max().item()
     sb = dy.sum((0, 2, 3, 4))
     assert (db.cpu() - sb).abs().max().item() <= 1e-4 * dy.abs().sum((0, 2, 3, 4)).max().item()
 

@@ -61,7 +61,8 @@ def main():
         else:
             dy = torch.randn(oshape, device=dev)
             dw = torch.zeros_like(w)
-            ms = timeit(lambda: _hip.conv3d_wgrad(x, dy, dw, (k,) * 3, st, (pad,) * 3))
+            ws = _hip.wgrad_workspace(dev) if os.environ.get('MR3D_LB_WS') == '1' else None     # two-stage reduction A/B
+            ms = timeit(lambda: _hip.conv3d_wgrad(x, dy, dw, (k,) * 3, st, (pad,) * 3, workspace=ws))
         tot_t += ms; tot_f += flops
         print(f'{name:22s} {ms:8.3f} ms  {flops / ms / 1e9:8.2f} TFLOP/s  {byts / ms / 1e6:8.1f} GB/s(min traffic)')
     print(f'total {tot_t:.3f} ms, {tot_f / tot_t / 1e9:.2f} TFLOP/s')
