@@ -28,9 +28,10 @@ constexpr int kThreads = 256;
 
 // PAR_: the parity-decomposed data gradient of a stride-2 3x3x3 convolution (see conv3d_dgrad_s2k3 below); the
 // kernel extents are then the per-axis MAXIMUM (2) and the taps actually walked are chosen per parity class.
-template <int KD, int KH, int KW, int SD_, int SH_, int SW_, int TD_, int TH_, int TW_, int CC_, int NB_, bool PAR_ = false>
+// ONE_: Cin == CC, a single chunk -- no next-chunk prefetch, so the staging registers are dead during the MFMA loop.
+template <int KD, int KH, int KW, int SD_, int SH_, int SW_, int TD_, int TH_, int TW_, int CC_, int NB_, bool PAR_ = false, bool ONE_ = false>
 struct FwdCfg {
-  static constexpr bool PAR = PAR_;
+  static constexpr bool PAR = PAR_, ONE = ONE_;
   static constexpr int kD = KD, kH = KH, kW = KW;
   static constexpr int SD = SD_, SH = SH_, SW = SW_, TD = TD_, TH = TH_, TW = TW_, CC = CC_, NB = NB_;
   // halo block: (T-1)*S + K input positions per axis; a pointwise (K == 1) strided conv only
@@ -63,9 +64,10 @@ struct FwdCfg {
   static constexpr bool BLDS = (!PAR_ && M == 64 && WTAPS * CC_ * NB_ * 4 <= 32 * 1024);   // PAR walks <= 8 of its 27 taps
   static constexpr int WLDS = BLDS ? WTAPS * CC_ * NB_ : 0;       // floats
   static constexpr int LDS_BYTES = (HP * ROW + WLDS) * 4;
-  // single-chunk 16-wide kernels (layer1's 3x3x3 16->16: load -> compute -> store with nothing to overlap inside a
-  // workgroup) want a third workgroup per CU; they sit just above the 170-register line without the hint
-  static constexpr int MINWG = (NB_ == 16 && !PAR_ && MV == 256 && TAPS == 27 && SD_ == 1) ? 3 : 1;
+  // single-chunk kernels (layer1's 3x3x3 16->16: load -> compute -> store with nothing to overlap inside a workgroup)
+  // want a third workgroup per CU; without the prefetch registers they fit the 170-register budget without spilling
+  // (a kernel that touches scratch stalls the queue for ~19 us at dispatch)
+  static constexpr int MINWG = ONE_ ? 3 : 1;
   static_assert(WROWS >= TM && WROWS % TM == 0, "each wave needs at least one whole MFMA tile of rows");
   static_assert(CC % KSTEP == 0 && CC % 4 == 0, "channel chunk");
   static_assert(LDS_BYTES <= 160 * 1024, "halo block exceeds the CU's LDS");
@@ -222,7 +224,9 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_fwd_kernel(Conv3dFw
       }
     }
     __syncthreads();
-    if (c0 + C::CC < p.Cin) fetch(c0 + C::CC);
+    if constexpr (!C::ONE) {
+      if (c0 + C::CC < p.Cin) fetch(c0 + C::CC);
+    }
 
     if constexpr (C::BLDS) {
       // ---- K loop with both operands in LDS
@@ -339,6 +343,9 @@ int dispatch_tile(const Conv3dFwdArgs &a, hipStream_t stream) {
     const double c577 = (double)vol / (t577 * 256.0), c488 = (double)vol / (t488 * 256.0), c288 = (double)vol / (t288 * 128.0);
     if (c577 > 1.15 * (c488 > c288 ? c488 : c288) && a.N * t577 * (a.Cout / NB) >= 512)
       return launch_fwd<FwdCfg<3, 3, 3, 1, 1, 1, 5, 7, 7, CC, NB>>(a, stream);
+  }
+  if constexpr (K == 3 && SD == 1 && SH == 1 && SW == 1 && NB == 16 && CC == 16) {
+    if (a.Cin == CC && wgs(4, 8, 8) >= 512) return launch_fwd<FwdCfg<3, 3, 3, 1, 1, 1, 4, 8, 8, CC, NB, false, true>>(a, stream);
   }
   if (wgs(4, 8, 8) >= 512) return launch_fwd<T0>(a, stream);
   if constexpr (NB == 32) {

@@ -51,6 +51,10 @@ struct WgCfg {
   static constexpr int PER_BLOCK = (PW1 ? 1 : TAPG) * MROWS * NB;
   static constexpr int BLOCKS_PER_WG = PW1 ? 4 : 1;
   static constexpr int MINWG = (KD == 3 && SD == 1 && NB == 32 && LDS_BYTES * 2 <= 160 * 1024) ? 2 : 1;
+  // one workgroup per CU: the next tile is fetched into registers before the MFMA loop (nothing else hides the global
+  // latency).  Two per CU hide each other's staging, and holding 18 float4 across the MFMA loop would not fit the
+  // halved register budget (it spilled 132 B/lane, and a kernel that uses scratch stalls the queue ~19 us at dispatch)
+  static constexpr bool PREFETCH = (MINWG == 1);
   static_assert(!MERGEW || CC == 4, "kw-merge needs 4 channels, unpadded rows");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
@@ -147,9 +151,10 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_wgrad_kernel(Conv3d
       dys[j] = ok ? *reinterpret_cast<const float4 *>(db + doff[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  if ((int)blockIdx.x < num_tiles) fetch(blockIdx.x);
+  if (C::PREFETCH && (int)blockIdx.x < num_tiles) fetch(blockIdx.x);
   for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
     __syncthreads();
+    if (!C::PREFETCH) fetch(tile);
 #pragma unroll
     for (int j = 0; j < NX; ++j) {
       const int it = tid + j * kThreads;
@@ -172,7 +177,7 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_wgrad_kernel(Conv3d
       if (want_bias) { bsum.x += dys[j].x; bsum.y += dys[j].y; bsum.z += dys[j].z; bsum.w += dys[j].w; }
     }
     __syncthreads();
-    if (tile + (int)gridDim.x < num_tiles) fetch(tile + gridDim.x);
+    if (C::PREFETCH && tile + (int)gridDim.x < num_tiles) fetch(tile + gridDim.x);
     // ---- K loop: 4 positions per MFMA
     constexpr int KSTEPS = C::M / 4;
     constexpr int KPW = C::PW1 ? KSTEPS / 4 : KSTEPS;       // pointwise: waves split the positions
