@@ -48,14 +48,19 @@ struct PwCfg {
   static constexpr int SLAB = ROWS * (RS > OS ? RS : OS);  // floats per wave: x tile, later reused for the y tile
   static constexpr int NOUT = ROWS * CO / 4 / 64;          // float4 per lane of the output tile
   static constexpr int WLDS = BREG ? 0 : CI * CO;          // floats of weights in LDS
-  static constexpr int LDS_BYTES = (WLDS + kWavesPerWG * SLAB) * 4;
+  // Waves never talk to each other (weights in registers): ONE wave per workgroup, so that a workgroup needs 9-35 KB of
+  // LDS and fits beside a 107 KB weight-gradient workgroup of the side stream -- with four waves (70-140 KB) the
+  // data-gradient chain waited for whole CUs to drain (the 64->64 lateral data gradient took 460 us beside the P2
+  // weight gradient, 80 us alone).  Weights in LDS (64x128, 128x64): four waves share one copy.
+  static constexpr int WPW = BREG ? 1 : kWavesPerWG;
+  static constexpr int LDS_BYTES = (WLDS + WPW * SLAB) * 4;
   static constexpr int NLOAD = ROWS * CI / 4 / 64;         // float4 loads per lane per tile
   static constexpr int ACC = k16 ? 4 : 16;
   static_assert(ROWS * CI % 256 == 0 && ROWS * CO % 256 == 0, "tiles must be whole numbers of wave-wide float4 accesses");
 };
 
 template <class C>
-__global__ __launch_bounds__(256) void pointwise_fwd_kernel(Conv3dFwdArgs p, long long rows_total) {
+__global__ __launch_bounds__(64 * C::WPW) void pointwise_fwd_kernel(Conv3dFwdArgs p, long long rows_total) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -71,14 +76,14 @@ __global__ __launch_bounds__(256) void pointwise_fwd_kernel(Conv3dFwdArgs p, lon
 #pragma unroll
       for (int nt = 0; nt < C::NT; ++nt) breg[kk][nt] = p.w[(size_t)(kk * C::KSTEP + lk) * C::CO + nt * C::TM + li];
   } else {
-    for (int e = tid; e < C::CI * C::CO / 4; e += 256)
+    for (int e = tid; e < C::CI * C::CO / 4; e += 64 * C::WPW)
       *reinterpret_cast<float4 *>(lds + e * 4) = *reinterpret_cast<const float4 *>(p.w + (size_t)e * 4);
     __syncthreads();
   }
 
   const long long ntiles = (rows_total + C::ROWS - 1) / C::ROWS;
-  const long long wstride = (long long)gridDim.x * kWavesPerWG;
-  long long tile = (long long)blockIdx.x * kWavesPerWG + wave;
+  const long long wstride = (long long)gridDim.x * C::WPW;
+  long long tile = (long long)blockIdx.x * C::WPW + wave;
 
   float4 pre[C::NLOAD];
   auto issue_loads = [&](long long t) {
@@ -447,11 +452,14 @@ int launch_pw_fwd_impl(const Conv3dFwdArgs &a, hipStream_t stream) {
   if (set_lds_attr<C>(pointwise_fwd_kernel<C>) != MR3D_OK) return MR3D_ERR_LAUNCH;
   const long long rows = (long long)a.N * a.Do * a.Ho * a.Wo;
   const long long ntiles = (rows + C::ROWS - 1) / C::ROWS;
-  const int wg_per_cu = (160 * 1024) / C::LDS_BYTES > 2 ? 2 : ((160 * 1024) / C::LDS_BYTES < 1 ? 1 : (160 * 1024) / C::LDS_BYTES);
+  // about 8 waves per CU (as many as the four-wave form had), fewer when LDS does not allow it
+  constexpr int lds_wgs = (160 * 1024) / C::LDS_BYTES < 1 ? 1 : (160 * 1024) / C::LDS_BYTES;
+  constexpr int want_wgs = 8 / C::WPW;
+  const int wg_per_cu = lds_wgs < want_wgs ? lds_wgs : want_wgs;
   long long grid = (long long)num_cus() * wg_per_cu;
-  const long long need = (ntiles + kWavesPerWG - 1) / kWavesPerWG;
+  const long long need = (ntiles + C::WPW - 1) / C::WPW;
   if (grid > need) grid = need;
-  pointwise_fwd_kernel<C><<<(unsigned)grid, 256, C::LDS_BYTES, stream>>>(a, rows);
+  pointwise_fwd_kernel<C><<<(unsigned)grid, 64 * C::WPW, C::LDS_BYTES, stream>>>(a, rows);
   return mr3d_launch_status();
 }
 
