@@ -454,7 +454,8 @@ int launch_pw_fwd_impl(const Conv3dFwdArgs &a, hipStream_t stream) {
   const long long ntiles = (rows + C::ROWS - 1) / C::ROWS;
   // about 8 waves per CU (as many as the four-wave form had), fewer when LDS does not allow it
   constexpr int lds_wgs = (160 * 1024) / C::LDS_BYTES < 1 ? 1 : (160 * 1024) / C::LDS_BYTES;
-  constexpr int want_wgs = 8 / C::WPW;
+  static const int waves_per_cu = getenv("MR3D_PW_WAVES") ? atoi(getenv("MR3D_PW_WAVES")) : 8;   // tuning knob
+  const int want_wgs = waves_per_cu / C::WPW < 1 ? 1 : waves_per_cu / C::WPW;
   const int wg_per_cu = lds_wgs < want_wgs ? lds_wgs : want_wgs;
   long long grid = (long long)num_cus() * wg_per_cu;
   const long long need = (ntiles + C::WPW - 1) / C::WPW;
