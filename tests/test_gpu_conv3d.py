@@ -35,6 +35,9 @@ CASES = [
     (32, 128, 1, (1, 1, 1), 0, (3, 8, 9)),
     (128, 64, 1, (1, 1, 1), 0, (3, 5, 8)),
     (512, 128, 1, (1, 1, 1), 0, (2, 4, 5)),
+    (256, 64, 1, (1, 1, 1), 0, (5, 16, 15)),
+    (128, 512, 1, (1, 1, 1), 0, (3, 8, 9)),
+    (256, 256, 1, (1, 1, 1), 0, (2, 5, 7)),
     (64, 128, 1, (2, 2, 2), 0, (6, 10, 12)),
     (16, 16, 3, (1, 1, 1), 1, (6, 10, 12)),
     (32, 32, 3, (1, 1, 1), 1, (5, 9, 9)),
