@@ -29,9 +29,15 @@ constexpr int kThreads = 256;
 // PAR_: the parity-decomposed data gradient of a stride-2 3x3x3 convolution (see conv3d_dgrad_s2k3 below); the
 // kernel extents are then the per-axis MAXIMUM (2) and the taps actually walked are chosen per parity class.
 // ONE_: Cin == CC, a single chunk -- no next-chunk prefetch, so the staging registers are dead during the MFMA loop.
-template <int KD, int KH, int KW, int SD_, int SH_, int SW_, int TD_, int TH_, int TW_, int CC_, int NB_, bool PAR_ = false, bool ONE_ = false>
+// WINO_: Winograd F(2,3) along W for 3x3x3 / stride 1: a GEMM row is a PAIR of adjacent outputs (x = 2p, 2p+1); per tap
+// row (kd,kh) the three kw taps become four products m_f = (B^T d)_f * (G g)_f over the inputs d = x[2p .. 2p+3]:
+//   B^T d = (d0-d2, d1+d2, d2-d1, d1-d3),  G g = (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2),
+//   y[2p] = m0+m1+m2, y[2p+1] = m1-m2-m3  -- 4 MFMAs per two outputs instead of 6.  Both transforms are done on the fly
+// from the same LDS halo and the same weight-row registers as the direct form (one ds_read + one v_sub/v_add per MFMA).
+template <int KD, int KH, int KW, int SD_, int SH_, int SW_, int TD_, int TH_, int TW_, int CC_, int NB_, bool PAR_ = false, bool ONE_ = false,
+          bool WINO_ = false>
 struct FwdCfg {
-  static constexpr bool PAR = PAR_, ONE = ONE_;
+  static constexpr bool PAR = PAR_, ONE = ONE_, WINO = WINO_;
   static constexpr int kD = KD, kH = KH, kW = KW;
   static constexpr int SD = SD_, SH = SH_, SW = SW_, TD = TD_, TH = TH_, TW = TW_, CC = CC_, NB = NB_;
   // halo block: (T-1)*S + K input positions per axis; a pointwise (K == 1) strided conv only
@@ -42,7 +48,9 @@ struct FwdCfg {
   static constexpr int HD = (TD - 1) * LSD + KD, HH = (TH - 1) * LSH + KH, HW = (TW - 1) * LSW + KW;
   static constexpr int HP = HD * HH * HW;       // halo positions
   static constexpr int ROW = CC + 1;            // LDS row stride in floats
-  static constexpr int MV = TD * TH * TW;       // output positions of the tile
+  static constexpr int MV = TD * TH * TW / (WINO_ ? 2 : 1);       // GEMM rows of the tile: output positions (WINO: pairs)
+  static constexpr int NF = WINO_ ? 4 : 1;      // accumulator sets per MFMA tile (Winograd products)
+  static_assert(!WINO_ || (KD == 3 && KH == 3 && KW == 3 && SD_ == 1 && SH_ == 1 && SW_ == 1 && TW_ % 2 == 0 && !PAR_), "WINO: 3x3x3 stride 1");
   // GEMM rows per workgroup: MV rounded up to whole MFMA tiles per wave (a 5x7x7 tile -- the divisor-friendly shape
   // for 10x14x14 roi volumes -- has 245 positions and runs as 256 rows, the last 11 idle)
   static constexpr int MQ = (NB_ == 32) ? 128 : 64;
@@ -61,7 +69,7 @@ struct FwdCfg {
   // the latency and the kernel crawls at ~1 us per row.  There the chunk's whole weight tile [taps][CC][NB] (if <= 32 KB)
   // is staged in LDS with the same register pipeline as the halo, one Cin chunk ahead.
   static constexpr int WTAPS = PAR_ ? 27 : TAPS;
-  static constexpr bool BLDS = (!PAR_ && M == 64 && WTAPS * CC_ * NB_ * 4 <= 32 * 1024);   // PAR walks <= 8 of its 27 taps
+  static constexpr bool BLDS = (!PAR_ && !WINO_ && M == 64 && WTAPS * CC_ * NB_ * 4 <= 32 * 1024);   // PAR walks <= 8 of its 27 taps
   static constexpr int WLDS = BLDS ? WTAPS * CC_ * NB_ : 0;       // floats
   static constexpr int LDS_BYTES = (HP * ROW + WLDS) * 4;
   // single-chunk kernels (layer1's 3x3x3 16->16: load -> compute -> store with nothing to overlap inside a workgroup)
@@ -113,15 +121,16 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_fwd_kernel(Conv3dFw
   for (int mt = 0; mt < C::MT; ++mt) {
     int m = wave_m * C::WROWS + mt * C::TM + li;
     if (C::MV < C::M && m >= C::MV) m = 0;        // idle padding row: any in-range address, result never stored
-    const int tw = m % C::TW, th = (m / C::TW) % C::TH, td = m / (C::TW * C::TH);
+    constexpr int RW = C::WINO ? C::TW / 2 : C::TW;       // GEMM rows per tile row
+    const int tw = (m % RW) * (C::WINO ? 2 : 1), th = (m / RW) % C::TH, td = m / (RW * C::TH);
     abase[mt] = (((td * C::LSD) * C::HH + th * C::LSH) * C::HW + tw * C::LSW) * C::ROW + lk;
   }
   const float *wlane = p.w + (size_t)lk * p.Cout + n0 + wave_n * C::TM + li;
 
   using acc_t = typename std::conditional<C::k16, f32x4, f32x16>::type;
-  acc_t acc[C::MT];
+  acc_t acc[C::NF * C::MT];                    // WINO: [f][mt]
 #pragma unroll
-  for (int mt = 0; mt < C::MT; ++mt)
+  for (int mt = 0; mt < C::NF * C::MT; ++mt)
     for (int r = 0; r < (C::k16 ? 4 : 16); ++r) acc[mt][r] = 0.f;
 
   // ---- halo staging, software-pipelined over the Cin chunks: the NEXT chunk's halo block is fetched into registers
@@ -175,6 +184,31 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_fwd_kernel(Conv3dFw
       }
   };
   auto mma_row = [&](const float (&bw)[RT][C::KK], int kd_, int kh_) {
+    if constexpr (C::WINO) {
+      const int rowoff = (kd_ * C::HH + kh_) * C::HW * C::ROW;
+#pragma unroll
+      for (int kk = 0; kk < C::KK; ++kk) {
+        const float g0 = bw[0][kk], g1 = bw[1][kk], g2 = bw[2][kk];
+        const float u[4] = {g0, 0.5f * ((g0 + g2) + g1), 0.5f * ((g0 + g2) - g1), g2};
+        float a[C::MT][4];
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt) {
+          const float *src = lds + abase[mt] + rowoff + kk * C::KSTEP;
+          const float d0 = src[0], d1 = src[C::ROW], d2 = src[2 * C::ROW], d3 = src[3 * C::ROW];
+          a[mt][0] = d0 - d2; a[mt][1] = d1 + d2; a[mt][2] = d2 - d1; a[mt][3] = d1 - d3;
+        }
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int mt = 0; mt < C::MT; ++mt) {
+            if constexpr (C::k16)
+              acc[f * C::MT + mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][f], u[f], acc[f * C::MT + mt], 0, 0, 0);
+            else
+              acc[f * C::MT + mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][f], u[f], acc[f * C::MT + mt], 0, 0, 0);
+          }
+      }
+      return;
+    }
 #pragma unroll
     for (int t = 0; t < RT; ++t)
       if (t < nrt) {
@@ -272,34 +306,44 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_fwd_kernel(Conv3dFw
   // ---- epilogue: shift, residual adds, nearest-upsample add, ReLU / ReLU-mask; NDHWC store
   const int co = n0 + wave_n * C::TM + li;
   const float sh = p.shift ? p.shift[co] : 0.f;
+  auto emit = [&](int od, int oh, int ow, bool inside, float val) {
+    size_t idx;
+    if constexpr (C::PAR) {
+      const int fd = 2 * od + ad, fh = 2 * oh + ah, fw = 2 * ow + aw;
+      inside = inside && fd < p.yD && fh < p.yH && fw < p.yW;
+      idx = ((((size_t)n * p.yD + fd) * p.yH + fh) * p.yW + fw) * p.Cout + co;
+    } else {
+      idx = ((((size_t)n * p.yD + od * p.ysd) * p.yH + oh * p.ysh) * p.yW + ow * p.ysw) * p.Cout + co;
+    }
+    if (inside) {
+      float v = val + sh;
+      if (p.add1) v += p.add1[idx];
+      if (p.add2) v += p.add2[idx];
+      if (p.up) {
+        const int ud = nearest_src(od, p.Du, p.Do), uh = nearest_src(oh, p.Hu, p.Ho), uw = nearest_src(ow, p.Wu, p.Wo);
+        v += p.up[((((size_t)n * p.Du + ud) * p.Hu + uh) * p.Wu + uw) * p.Cout + co];
+      }
+      if (p.relu) v = fmaxf(v, 0.f);
+      if (p.mask) v = p.mask[idx] > 0.f ? v : 0.f;
+      p.y[idx] = v;
+    }
+  };
 #pragma unroll
   for (int mt = 0; mt < C::MT; ++mt) {
 #pragma unroll
     for (int r = 0; r < (C::k16 ? 4 : 16); ++r) {
       const int row = C::k16 ? (lk * 4 + r) : ((r & 3) + 8 * (r >> 2) + 4 * lk);
       const int m = wave_m * C::WROWS + mt * C::TM + row;
-      const int tw = m % C::TW, th = (m / C::TW) % C::TH, td = m / (C::TW * C::TH);
+      constexpr int RW = C::WINO ? C::TW / 2 : C::TW;
+      const int tw = (m % RW) * (C::WINO ? 2 : 1), th = (m / RW) % C::TH, td = m / (RW * C::TH);
       const int od = od0 + td, oh = oh0 + th, ow = ow0 + tw;
-      bool inside = od < p.Do && oh < p.Ho && ow < p.Wo && (C::MV == C::M || m < C::MV);
-      size_t idx;
-      if constexpr (C::PAR) {
-        const int fd = 2 * od + ad, fh = 2 * oh + ah, fw = 2 * ow + aw;
-        inside = inside && fd < p.yD && fh < p.yH && fw < p.yW;
-        idx = ((((size_t)n * p.yD + fd) * p.yH + fh) * p.yW + fw) * p.Cout + co;
+      const bool inside = od < p.Do && oh < p.Ho && ow < p.Wo && (C::MV == C::M || m < C::MV);
+      if constexpr (C::WINO) {
+        const float m0 = acc[mt][r], m1 = acc[C::MT + mt][r], m2 = acc[2 * C::MT + mt][r], m3 = acc[3 * C::MT + mt][r];
+        emit(od, oh, ow, inside, (m0 + m1) + m2);
+        emit(od, oh, ow + 1, inside && ow + 1 < p.Wo, (m1 - m2) - m3);
       } else {
-        idx = ((((size_t)n * p.yD + od * p.ysd) * p.yH + oh * p.ysh) * p.yW + ow * p.ysw) * p.Cout + co;
-      }
-      if (inside) {
-        float v = acc[mt][r] + sh;
-        if (p.add1) v += p.add1[idx];
-        if (p.add2) v += p.add2[idx];
-        if (p.up) {
-          const int ud = nearest_src(od, p.Du, p.Do), uh = nearest_src(oh, p.Hu, p.Ho), uw = nearest_src(ow, p.Wu, p.Wo);
-          v += p.up[((((size_t)n * p.Du + ud) * p.Hu + uh) * p.Wu + uw) * p.Cout + co];
-        }
-        if (p.relu) v = fmaxf(v, 0.f);
-        if (p.mask) v = p.mask[idx] > 0.f ? v : 0.f;
-        p.y[idx] = v;
+        emit(od, oh, ow, inside, acc[mt][r]);
       }
     }
   }
@@ -346,6 +390,14 @@ int dispatch_tile(const Conv3dFwdArgs &a, hipStream_t stream) {
   }
   if constexpr (K == 3 && SD == 1 && SH == 1 && SW == 1 && NB == 16 && CC == 16) {
     if (a.Cin == CC && wgs(4, 8, 8) >= 512) return launch_fwd<FwdCfg<3, 3, 3, 1, 1, 1, 4, 8, 8, CC, NB, false, true>>(a, stream);
+  }
+  if constexpr (K == 3 && SD == 1 && SH == 1 && SW == 1 && CC == 16 && NB == 64) {
+    // Winograd F(2,3) along W (see FwdCfg): 4 MFMAs per output pair and tap row instead of 6.  64-wide tile: 2x8x8
+    // outputs = 64 pair rows keep the accumulators at 64 registers and two workgroups per CU (P2 3x3x3 64->64:
+    // 1.19 -> 1.02 ms; the 4x8x8 form needs 128 accumulator registers, one workgroup per CU: 1.11 ms).
+    // The 16-wide single-chunk kernel (layer1) gains nothing from it (96 vs 96 TFLOP/s: not MFMA-bound).
+    static const int wino = getenv("MR3D_FWD_WINO") ? atoi(getenv("MR3D_FWD_WINO")) : 1;     // 0: direct form only
+    if (wino && wgs(2, 8, 8) >= 512) return launch_fwd<FwdCfg<3, 3, 3, 1, 1, 1, 2, 8, 8, CC, NB, false, false, true>>(a, stream);
   }
   if (wgs(4, 8, 8) >= 512) return launch_fwd<T0>(a, stream);
   if constexpr (NB == 32) {
