@@ -27,10 +27,17 @@ namespace {
 
 constexpr int kThreads = 256;
 
-template <int KD_, int KH_, int KW_, int SD_, int SH_, int SW_, int CC_, int NB_, bool MERGEW_, int TD_ = 4, int TH_ = 8, int TW_ = 8>
+// WINO_: Winograd F(3,2) along W for 3x3x3 / stride 1.  A GEMM-K row is a PAIR of adjacent outputs; per tap row (kd,kh)
+// the three kw gradients come from four products M_f = sum_pairs (B^T d)_f (G g)_f with d = x[2p .. 2p+3] and
+// g = dy[2p], dy[2p+1]:  B^T d = (d0-d2, d1+d2, d2-d1, d3-d1),  G g = (g0, (g0+g1)/2, (g0-g1)/2, g1),
+//   dw[kw=0] = M0+M1+M2, dw[1] = M1-M2, dw[2] = M1+M2+M3  -- 4 MFMAs per pair instead of 6.
+// Wave f owns product f for all nine (kd,kh) (9 accumulator groups per wave, an even split where the direct form
+// has 7/7/7/6); both transforms happen on the fly from the same LDS tiles; the final combination rides on the atomics.
+template <int KD_, int KH_, int KW_, int SD_, int SH_, int SW_, int CC_, int NB_, bool MERGEW_, int TD_ = 4, int TH_ = 8, int TW_ = 8,
+          bool WINO_ = false>
 struct WgCfg {
   static constexpr int KD = KD_, KH = KH_, KW = KW_, SD = SD_, SH = SH_, SW = SW_, CC = CC_, NB = NB_;
-  static constexpr bool MERGEW = MERGEW_;
+  static constexpr bool MERGEW = MERGEW_, WINO = WINO_;
   // MV real positions per tile, run as M GEMM-K rows (a 5x7x7 tile: 245 of 256; the padding rows carry dy = 0)
   static constexpr int TD = TD_, TH = TH_, TW = TW_, MV = TD * TH * TW, M = (MV + 63) / 64 * 64;
   static constexpr bool PW1 = (KD == 1 && KH == 1 && KW == 1);
@@ -38,13 +45,17 @@ struct WgCfg {
   static constexpr int GSD = PW1 ? SD : 1, GSH = PW1 ? SH : 1, GSW = PW1 ? SW : 1;
   static constexpr int HD = (TD - 1) * LSD + KD, HH = (TH - 1) * LSH + KH, HW = (TW - 1) * LSW + KW;
   static constexpr int HP = HD * HH * HW;
-  static constexpr int ROW = MERGEW ? CC : CC + 1;
-  static constexpr int DROW = NB + 1;
+  // WINO: a k-step's lane groups read output pairs, i.e. rows 2*ROW (2*DROW) apart: 24 / 72 floats put them 16 banks
+  // apart (conflict-free with the 16 channel lanes), and keep the rows 16-byte aligned for vector staging stores
+  static constexpr int ROW = WINO_ ? CC + 8 : (MERGEW ? CC : CC + 1);
+  static constexpr int DROW = WINO_ ? NB + 8 : NB + 1;
   static constexpr int XF = HP * ROW + (MERGEW ? 32 : 0);   // merged rows of the last halo position read past it
-  static constexpr int LDS_BYTES = (XF + M * DROW) * 4;
+  // WINO: the epilogue combines the four waves' products in LDS (4 x 9 x CC x NB floats) before the atomics
+  static constexpr int LDS_TILES = (XF + M * DROW) * 4, LDS_COMB = WINO_ ? 4 * KD * KH * CC * NB * 4 : 0;
+  static constexpr int LDS_BYTES = LDS_TILES > LDS_COMB ? LDS_TILES : LDS_COMB;
   static constexpr int MROWS = MERGEW ? 32 : CC;
   static constexpr int MT = MROWS / 16, NT = NB / 16;
-  static constexpr int TAPG = MERGEW ? KD * KH : KD * KH * KW;   // accumulator groups
+  static constexpr int TAPG = WINO_ ? KD * KH * 4 : (MERGEW ? KD * KH : KD * KH * KW);   // accumulator groups
   static constexpr int TPW = PW1 ? 1 : (TAPG + 3) / 4;           // tap groups per wave
   // two workgroups per CU (one hides the other's staging) where LDS allows it and the register budget nearly does
   // partial-sum block of one workgroup: [tap group][row][NB]; a pointwise conv has one block per WAVE (waves split positions)
@@ -56,6 +67,8 @@ struct WgCfg {
   // halved register budget (it spilled 132 B/lane, and a kernel that uses scratch stalls the queue ~19 us at dispatch)
   static constexpr bool PREFETCH = (MINWG == 1);
   static_assert(!MERGEW || CC == 4, "kw-merge needs 4 channels, unpadded rows");
+  static_assert(!WINO_ || (KD_ == 3 && KH_ == 3 && KW_ == 3 && SD_ == 1 && SH_ == 1 && SW_ == 1 && TW_ % 2 == 0 && !MERGEW_ &&
+                           TD_ * TH_ * TW_ % 64 == 0), "WINO: 3x3x3 stride 1, whole tiles");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
@@ -88,7 +101,9 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_wgrad_kernel(Conv3d
   for (int t = 0; t < C::TPW; ++t) {
     int g = t * 4 + wave;
     if (g >= C::TAPG) g = C::TAPG - 1;          // surplus slot: recomputes the last group, result dropped
-    if (C::MERGEW) {
+    if (C::WINO) {
+      tapoff[t] = (((t / C::KH) * C::HH + t % C::KH) * C::HW) * C::ROW;      // group t = (kd, kh); this wave's product f = wave
+    } else if (C::MERGEW) {
       const int kd = g / C::KH, kh = g % C::KH;
       tapoff[t] = ((kd * C::HH + kh) * C::HW) * C::ROW;
     } else {
@@ -161,7 +176,8 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_wgrad_kernel(Conv3d
       if (it < C::HP * Q) {
         const int pos = it / Q, q = it - pos * Q;
         float *d = xh + pos * C::ROW + q * 4;
-        d[0] = xs[j].x; d[1] = xs[j].y; d[2] = xs[j].z; d[3] = xs[j].w;
+        if constexpr (C::WINO) *reinterpret_cast<float4 *>(d) = xs[j];
+        else { d[0] = xs[j].x; d[1] = xs[j].y; d[2] = xs[j].z; d[3] = xs[j].w; }
       }
     }
     if (C::MERGEW)
@@ -172,19 +188,41 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_wgrad_kernel(Conv3d
       if (it < C::M * QN) {
         const int m = it / QN, q = it - m * QN;
         float *d = dyt + m * C::DROW + q * 4;
-        d[0] = dys[j].x; d[1] = dys[j].y; d[2] = dys[j].z; d[3] = dys[j].w;
+        if constexpr (C::WINO) *reinterpret_cast<float4 *>(d) = dys[j];
+        else { d[0] = dys[j].x; d[1] = dys[j].y; d[2] = dys[j].z; d[3] = dys[j].w; }
       }
       if (want_bias) { bsum.x += dys[j].x; bsum.y += dys[j].y; bsum.z += dys[j].z; bsum.w += dys[j].w; }
     }
     __syncthreads();
     if (C::PREFETCH && tile + (int)gridDim.x < num_tiles) fetch(tile + gridDim.x);
     // ---- K loop: 4 positions per MFMA
-    constexpr int KSTEPS = C::M / 4;
+    constexpr int KSTEPS = C::M / 4 / (C::WINO ? 2 : 1);    // WINO: a k row is an output pair
     constexpr int KPW = C::PW1 ? KSTEPS / 4 : KSTEPS;       // pointwise: waves split the positions
+    // WINO, wave-uniform: a = x[oA] + sB * x[oB] and b = cg0 * dy[2p] + cg1 * dy[2p+1] of this wave's product
+    const int woA = wave * C::ROW, woB = (wave <= 1 ? 2 : 1) * C::ROW;
+    const float wsB = wave == 1 ? 1.f : -1.f;
+    const float cg0 = wave == 0 ? 1.f : (wave == 3 ? 0.f : 0.5f), cg1 = wave == 0 ? 0.f : (wave == 3 ? 1.f : (wave == 1 ? 0.5f : -0.5f));
     const int kk0 = C::PW1 ? wave * KPW : 0;
     // explicit two-stage software pipeline: the LDS operands of k-step q+1 are requested before the MFMAs
     // of k-step q issue (the compiler does not do this on its own: it waits on every ds_read before its MFMA)
     auto ld = [&](int kq, float (&a)[C::TPW][C::MT], float (&bf)[C::NT]) {
+      if constexpr (C::WINO) {
+        const int mp = kq * 4 + lk;                              // pair index inside the tile
+        constexpr int PW_ = C::TW / 2;
+        const int tp = mp % PW_, th = (mp / PW_) % C::TH, td = mp / (PW_ * C::TH);
+        const int hp = ((td * C::HH + th) * C::HW + 2 * tp) * C::ROW + li;
+        const float *dp = dyt + (2 * mp) * C::DROW + li;
+#pragma unroll
+        for (int nt = 0; nt < C::NT; ++nt) bf[nt] = cg0 * dp[nt * 16] + cg1 * dp[C::DROW + nt * 16];
+#pragma unroll
+        for (int t = 0; t < C::TPW; ++t)
+#pragma unroll
+          for (int mt = 0; mt < C::MT; ++mt) {
+            const float *xp = xh + hp + tapoff[t] + mt * 16;
+            a[t][mt] = xp[woA] + wsB * xp[woB];
+          }
+        return;
+      }
       const int m = (kk0 + kq) * 4 + lk;
       const int mx = (C::MV < C::M && m >= C::MV) ? 0 : m;      // padding row: dy is 0 there, any in-range x address
       const int tw = mx % C::TW, th = (mx / C::TW) % C::TH, td = mx / (C::TW * C::TH);
@@ -231,7 +269,7 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_wgrad_kernel(Conv3d
     }
   }
   // ---- partial sums: private block (two-stage reduction) or atomics into dw[tap][ci][co]
-  if (p.part && !C::MERGEW) {
+  if (p.part && !C::MERGEW && !C::WINO) {
     const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     float *dst = p.part + (wg * C::BLOCKS_PER_WG + (C::PW1 ? wave : 0)) * C::PER_BLOCK;
 #pragma unroll
@@ -245,6 +283,32 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_wgrad_kernel(Conv3d
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             dst[((C::PW1 ? 0 : g) * C::MROWS + mt * 16 + lk * 4 + r) * C::NB + nt * 16 + li] = acc[t][mt][nt][r];
+    }
+    return;
+  }
+  if constexpr (C::WINO) {
+    // dw[kd][kh][0] = M0+M1+M2, [1] = M1-M2, [2] = M1+M2+M3: the four waves' products meet in LDS, then one atomic per
+    // element per workgroup (as many as the direct form issues; adding coefficient * M_f from every wave would be 2.7x)
+    constexpr int BLK = C::CC * C::NB, NG = C::KD * C::KH;
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < C::TPW; ++t)
+#pragma unroll
+      for (int mt = 0; mt < C::MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            lds[(wave * NG + t) * BLK + (mt * 16 + lk * 4 + r) * C::NB + nt * 16 + li] = acc[t][mt][nt][r];
+    __syncthreads();
+    for (int e = tid; e < NG * BLK; e += kThreads) {
+      const int t = e / BLK, rc = e - t * BLK;
+      const float m0 = lds[e], m1 = lds[NG * BLK + e], m2 = lds[2 * NG * BLK + e], m3 = lds[3 * NG * BLK + e];
+      float *dst = p.dw + ((size_t)(t * 3) * p.Cin + c0 + rc / C::NB) * p.Cout + n0 + rc % C::NB;
+      const size_t tap = (size_t)p.Cin * p.Cout;
+      atomicAdd(dst, (m0 + m1) + m2);
+      atomicAdd(dst + tap, m1 - m2);
+      atomicAdd(dst + 2 * tap, (m1 + m2) + m3);
     }
     return;
   }
@@ -341,7 +405,7 @@ int launch_wgrad(const Conv3dWgradArgs &a, hipStream_t stream) {
   dim3 grid((unsigned)gx, (unsigned)chunks, (unsigned)ntiles);
   Conv3dWgradArgs k = a;
   const long long need = (long long)gx * chunks * ntiles * C::BLOCKS_PER_WG * C::PER_BLOCK * 4;
-  if (C::MERGEW || !k.part || k.part_bytes < need) k.part = nullptr;
+  if (C::MERGEW || C::WINO || !k.part || k.part_bytes < need) k.part = nullptr;
   conv3d_wgrad_kernel<C><<<grid, kThreads, C::LDS_BYTES, stream>>>(k, tiles_d, tiles_h, tiles_w);
   const int st = mr3d_launch_status();
   if (st != MR3D_OK || !k.part) return st;
@@ -404,6 +468,8 @@ extern "C" int mr3d_conv3d_wgrad(const mr3d_conv3d_wgrad_desc *d, mr3d_stream_t 
         }
       }
       const int nb3 = nb3_env ? nb3_env : (a.N * t488 < 2048 ? 32 : 64);
+      static const int wino = getenv("MR3D_WGRAD_WINO") ? atoi(getenv("MR3D_WGRAD_WINO")) : 1;    // 0: direct form only
+      if (wino && nb == 64 && nb3 == 64) return launch_wgrad<WgCfg<3, 3, 3, 1, 1, 1, 16, 64, false, 4, 8, 8, true>>(a, stream);
       return dispatch_wg<3, 1, 1, 1, 16>(a, nb < nb3 ? nb : nb3, stream);
     }
   } else if (k == 3 && s == 222) {

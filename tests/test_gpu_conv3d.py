@@ -298,3 +298,27 @@ def test_conv3d_winograd_w_path_matches_direct_and_reference(dev, monkeypatch):
     w2 = torch.randn((128, c, 3, 3, 3), generator=g) / np.sqrt(27 * c)
     y = _hip.conv3d_forward(xc, _hip.pack_conv_weight(w2).to(dev), (3,) * 3, (1,) * 3, (1,) * 3)
     _check(y, F.conv3d(x.double(), w2.double(), None, 1, 1).float(), 'winograd 128 cout')
+
+
+def test_conv3d_wgrad_winograd_path_ragged_volume(dev):
+    """3x3x3 / stride 1 weight gradient on >= 2048 tiles takes the Winograd F(3,2)-along-W form (WgCfg<..., WINO>):
+    checked on a volume whose extents are NOT multiples of the 4x8x8 tile (half-valid output pairs, tiles hanging over
+    every face) against torch's own GPU convolution backward, plus the bias gradient and accumulation into dw"""
+    from mr3d_amd import _hip
+    g = torch.Generator(device='cpu').manual_seed(77)
+    x = torch.randn((1, 64, 41, 127, 125), generator=g).to(dev)
+    dy = torch.randn((1, 64, 41, 127, 125), generator=g).to(dev)
+    wr = torch.zeros((64, 64, 3, 3, 3), device=dev, requires_grad=True)
+    try:
+        F.conv3d(x, wr, None, 1, 1).backward(dy)
+    except RuntimeError as exc:
+        pytest.skip(f'torch/MIOpen convolution unavailable: {exc}')
+    ref = _hip.pack_conv_weight(wr.grad)
+    xc, dyc = x.permute(0, 2, 3, 4, 1).contiguous(), dy.permute(0, 2, 3, 4, 1).contiguous()
+    dw, db = torch.zeros((27, 64, 64), device=dev), torch.zeros(64, device=dev)
+    _hip.conv3d_wgrad(xc, dyc, dw, (3,) * 3, (1,) * 3, (1,) * 3, dbias=db)
+    rel = lambda a, b: ((a - b).abs().max() / b.abs().max()).item()
+    assert rel(dw, ref) <= RTOL
+    assert rel(db, dy.sum((0, 2, 3, 4))) <= 1e-4
+    _hip.conv3d_wgrad(xc, dyc, dw, (3,) * 3, (1,) * 3, (1,) * 3)            # accumulates
+    assert rel(dw, 2 * ref) <= RTOL
