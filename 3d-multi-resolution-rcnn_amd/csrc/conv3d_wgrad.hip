@@ -47,8 +47,10 @@ struct WgCfg {
   static constexpr int HP = HD * HH * HW;
   // WINO: a k-step's lane groups read output pairs, i.e. rows 2*ROW (2*DROW) apart: 24 / 72 floats put them 16 banks
   // apart (conflict-free with the 16 channel lanes), and keep the rows 16-byte aligned for vector staging stores
-  static constexpr int ROW = WINO_ ? CC + 8 : (MERGEW ? CC : CC + 1);
-  static constexpr int DROW = WINO_ ? NB + 8 : NB + 1;
+  // (the 32-wide tile keeps the compact odd strides: two workgroups per CU matter more than the conflicts)
+  static constexpr bool WALIGN = WINO_ && NB_ == 64;
+  static constexpr int ROW = WALIGN ? CC + 8 : (MERGEW ? CC : CC + 1);
+  static constexpr int DROW = WALIGN ? NB + 8 : NB + 1;
   static constexpr int XF = HP * ROW + (MERGEW ? 32 : 0);   // merged rows of the last halo position read past it
   // WINO: the epilogue combines the four waves' products in LDS (4 x 9 x CC x NB floats) before the atomics
   static constexpr int LDS_TILES = (XF + M * DROW) * 4, LDS_COMB = WINO_ ? 4 * KD * KH * CC * NB * 4 : 0;
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_wgrad_kernel(Conv3d
       if (it < C::HP * Q) {
         const int pos = it / Q, q = it - pos * Q;
         float *d = xh + pos * C::ROW + q * 4;
-        if constexpr (C::WINO) *reinterpret_cast<float4 *>(d) = xs[j];
+        if constexpr (C::WALIGN) *reinterpret_cast<float4 *>(d) = xs[j];
         else { d[0] = xs[j].x; d[1] = xs[j].y; d[2] = xs[j].z; d[3] = xs[j].w; }
       }
     }
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_wgrad_kernel(Conv3d
       if (it < C::M * QN) {
         const int m = it / QN, q = it - m * QN;
         float *d = dyt + m * C::DROW + q * 4;
-        if constexpr (C::WINO) *reinterpret_cast<float4 *>(d) = dys[j];
+        if constexpr (C::WALIGN) *reinterpret_cast<float4 *>(d) = dys[j];
         else { d[0] = dys[j].x; d[1] = dys[j].y; d[2] = dys[j].z; d[3] = dys[j].w; }
       }
       if (want_bias) { bsum.x += dys[j].x; bsum.y += dys[j].y; bsum.z += dys[j].z; bsum.w += dys[j].w; }
@@ -468,8 +470,11 @@ extern "C" int mr3d_conv3d_wgrad(const mr3d_conv3d_wgrad_desc *d, mr3d_stream_t 
         }
       }
       const int nb3 = nb3_env ? nb3_env : (a.N * t488 < 2048 ? 32 : 64);
-      static const int wino = getenv("MR3D_WGRAD_WINO") ? atoi(getenv("MR3D_WGRAD_WINO")) : 1;    // 0: direct form only
+      // Winograd forms (a caller that lends a workspace wants the bit-reproducible two-stage reduction: direct form)
+      static const int wino_env = getenv("MR3D_WGRAD_WINO") ? atoi(getenv("MR3D_WGRAD_WINO")) : 2;    // 0: direct form only
+      const int wino = a.part ? 0 : wino_env;
       if (wino && nb == 64 && nb3 == 64) return launch_wgrad<WgCfg<3, 3, 3, 1, 1, 1, 16, 64, false, 4, 8, 8, true>>(a, stream);
+      if (wino >= 2 && nb >= 32 && nb3 == 32) return launch_wgrad<WgCfg<3, 3, 3, 1, 1, 1, 16, 32, false, 4, 8, 8, true>>(a, stream);
       return dispatch_wg<3, 1, 1, 1, 16>(a, nb < nb3 ? nb : nb3, stream);
     }
   } else if (k == 3 && s == 222) {
