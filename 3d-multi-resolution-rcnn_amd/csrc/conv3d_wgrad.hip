@@ -471,10 +471,11 @@ extern "C" int mr3d_conv3d_wgrad(const mr3d_conv3d_wgrad_desc *d, mr3d_stream_t 
       }
       const int nb3 = nb3_env ? nb3_env : (a.N * t488 < 2048 ? 32 : 64);
       // Winograd forms (a caller that lends a workspace wants the bit-reproducible two-stage reduction: direct form)
-      static const int wino_env = getenv("MR3D_WGRAD_WINO") ? atoi(getenv("MR3D_WGRAD_WINO")) : 2;    // 0: direct form only
+      static const int wino_env = getenv("MR3D_WGRAD_WINO") ? atoi(getenv("MR3D_WGRAD_WINO")) : 3;    // 0: direct form only; 1/2/3: 64- / +32- / +16-wide tiles
       const int wino = a.part ? 0 : wino_env;
       if (wino && nb == 64 && nb3 == 64) return launch_wgrad<WgCfg<3, 3, 3, 1, 1, 1, 16, 64, false, 4, 8, 8, true>>(a, stream);
       if (wino >= 2 && nb >= 32 && nb3 == 32) return launch_wgrad<WgCfg<3, 3, 3, 1, 1, 1, 16, 32, false, 4, 8, 8, true>>(a, stream);
+      if (wino >= 3 && nb == 16) return launch_wgrad<WgCfg<3, 3, 3, 1, 1, 1, 16, 16, false, 4, 8, 8, true>>(a, stream);
       return dispatch_wg<3, 1, 1, 1, 16>(a, nb < nb3 ? nb : nb3, stream);
     }
   } else if (k == 3 && s == 222) {
