@@ -75,7 +75,9 @@ struct FwdCfg {
   // single-chunk kernels (layer1's 3x3x3 16->16: load -> compute -> store with nothing to overlap inside a workgroup)
   // want a third workgroup per CU; without the prefetch registers they fit the 170-register budget without spilling
   // (a kernel that touches scratch stalls the queue for ~19 us at dispatch)
-  static constexpr int MINWG = ONE_ ? 3 : 1;
+  // NOPF: no register prefetch of the next chunk (two workgroups per CU hide each other's staging instead)
+  static constexpr bool NOPF = WINO_ && TD_ == 4;
+  static constexpr int MINWG = ONE_ ? 3 : (NOPF ? 2 : 1);
   static_assert(WROWS >= TM && WROWS % TM == 0, "each wave needs at least one whole MFMA tile of rows");
   static_assert(CC % KSTEP == 0 && CC % 4 == 0, "channel chunk");
   static_assert(LDS_BYTES <= 160 * 1024, "halo block exceeds the CU's LDS");
@@ -238,9 +240,10 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_fwd_kernel(Conv3dFw
   };
 
   if constexpr (!C::BLDS) load_row(bc, 0, 0, 0);
-  fetch(0);
+  if constexpr (!C::NOPF) fetch(0);
   for (int c0 = 0; c0 < p.Cin; c0 += C::CC) {
     __syncthreads();
+    if constexpr (C::NOPF) fetch(c0);
 #pragma unroll
     for (int j = 0; j < NIT; ++j) {
       const int it = tid + j * kThreads;
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_fwd_kernel(Conv3dFw
       }
     }
     __syncthreads();
-    if constexpr (!C::ONE) {
+    if constexpr (!C::ONE && !C::NOPF) {
       if (c0 + C::CC < p.Cin) fetch(c0 + C::CC);
     }
 
@@ -396,7 +399,10 @@ int dispatch_tile(const Conv3dFwdArgs &a, hipStream_t stream) {
     // outputs = 64 pair rows keep the accumulators at 64 registers and two workgroups per CU (P2 3x3x3 64->64:
     // 1.19 -> 1.02 ms; the 4x8x8 form needs 128 accumulator registers, one workgroup per CU: 1.11 ms).
     // The 16-wide single-chunk kernel (layer1) gains nothing from it (96 vs 96 TFLOP/s: not MFMA-bound).
-    static const int wino = getenv("MR3D_FWD_WINO") ? atoi(getenv("MR3D_FWD_WINO")) : 1;     // 0: direct form only
+    static const int wino = getenv("MR3D_FWD_WINO") ? atoi(getenv("MR3D_FWD_WINO")) : 2;     // 0: direct form only; 1: 2x8x8 only
+    // 4x8x8 outputs = 128 pair rows: 128 accumulator registers; without the next-chunk register prefetch it still fits
+    // two workgroups per CU, which hide each other's staging: P2 0.91 ms (159 TFLOP/s of algorithmic work)
+    if (wino >= 2 && wgs(4, 8, 8) >= 512) return launch_fwd<FwdCfg<3, 3, 3, 1, 1, 1, 4, 8, 8, CC, NB, false, false, true>>(a, stream);
     if (wino && wgs(2, 8, 8) >= 512) return launch_fwd<FwdCfg<3, 3, 3, 1, 1, 1, 2, 8, 8, CC, NB, false, false, true>>(a, stream);
   }
   if (wgs(4, 8, 8) >= 512) return launch_fwd<T0>(a, stream);
