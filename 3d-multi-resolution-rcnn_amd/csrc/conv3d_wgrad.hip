@@ -47,13 +47,15 @@ struct WgCfg {
   static constexpr int HP = HD * HH * HW;
   // WINO: a k-step's lane groups read output pairs, i.e. rows 2*ROW (2*DROW) apart: 24 / 72 floats put them 16 banks
   // apart (conflict-free with the 16 channel lanes), and keep the rows 16-byte aligned for vector staging stores
-  // (the 32-wide tile keeps the compact odd strides: two workgroups per CU matter more than the conflicts)
-  static constexpr bool WALIGN = WINO_ && NB_ == 64;
+  // (kept compact: a workgroup of <= 107 KB leaves room for a streaming pointwise wave of the other stream on the CU)
+  static constexpr bool WALIGN = false;      // measured: the conflict-free 24 / 72-float rows buy nothing, and cost 24 KB of LDS
   static constexpr int ROW = WALIGN ? CC + 8 : (MERGEW ? CC : CC + 1);
   static constexpr int DROW = WALIGN ? NB + 8 : NB + 1;
   static constexpr int XF = HP * ROW + (MERGEW ? 32 : 0);   // merged rows of the last halo position read past it
   // WINO: the epilogue combines the four waves' products in LDS (4 x 9 x CC x NB floats) before the atomics
-  static constexpr int LDS_TILES = (XF + M * DROW) * 4, LDS_COMB = WINO_ ? 4 * KD * KH * CC * NB * 4 : 0;
+  // (in two passes over the tap rows, so that it fits the tile storage)
+  static constexpr int COMB_PASSES = 2, COMB_G = (KD * KH + COMB_PASSES - 1) / COMB_PASSES;
+  static constexpr int LDS_TILES = (XF + M * DROW) * 4, LDS_COMB = WINO_ ? 4 * COMB_G * CC * NB * 4 : 0;
   static constexpr int LDS_BYTES = LDS_TILES > LDS_COMB ? LDS_TILES : LDS_COMB;
   static constexpr int MROWS = MERGEW ? 32 : CC;
   static constexpr int MT = MROWS / 16, NT = NB / 16;
@@ -291,26 +293,32 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_wgrad_kernel(Conv3d
   if constexpr (C::WINO) {
     // dw[kd][kh][0] = M0+M1+M2, [1] = M1-M2, [2] = M1+M2+M3: the four waves' products meet in LDS, then one atomic per
     // element per workgroup (as many as the direct form issues; adding coefficient * M_f from every wave would be 2.7x)
-    constexpr int BLK = C::CC * C::NB, NG = C::KD * C::KH;
-    __syncthreads();
+    constexpr int BLK = C::CC * C::NB, NG = C::COMB_G;
 #pragma unroll
-    for (int t = 0; t < C::TPW; ++t)
+    for (int pass = 0; pass < C::COMB_PASSES; ++pass) {
+      __syncthreads();
 #pragma unroll
-      for (int mt = 0; mt < C::MT; ++mt)
+      for (int t = 0; t < C::TPW; ++t) {
+        if (t / NG != pass) continue;
 #pragma unroll
-        for (int nt = 0; nt < C::NT; ++nt)
+        for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            lds[(wave * NG + t) * BLK + (mt * 16 + lk * 4 + r) * C::NB + nt * 16 + li] = acc[t][mt][nt][r];
-    __syncthreads();
-    for (int e = tid; e < NG * BLK; e += kThreads) {
-      const int t = e / BLK, rc = e - t * BLK;
-      const float m0 = lds[e], m1 = lds[NG * BLK + e], m2 = lds[2 * NG * BLK + e], m3 = lds[3 * NG * BLK + e];
-      float *dst = p.dw + ((size_t)(t * 3) * p.Cin + c0 + rc / C::NB) * p.Cout + n0 + rc % C::NB;
-      const size_t tap = (size_t)p.Cin * p.Cout;
-      atomicAdd(dst, (m0 + m1) + m2);
-      atomicAdd(dst + tap, m1 - m2);
-      atomicAdd(dst + 2 * tap, (m1 + m2) + m3);
+          for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              lds[(wave * NG + t % NG) * BLK + (mt * 16 + lk * 4 + r) * C::NB + nt * 16 + li] = acc[t][mt][nt][r];
+      }
+      __syncthreads();
+      const int ng = (pass + 1) * NG <= C::TPW ? NG : C::TPW - pass * NG;       // tap rows in this pass
+      for (int e = tid; e < ng * BLK; e += kThreads) {
+        const int t = pass * NG + e / BLK, rc = e % BLK;
+        const float m0 = lds[e], m1 = lds[NG * BLK + e], m2 = lds[2 * NG * BLK + e], m3 = lds[3 * NG * BLK + e];
+        float *dst = p.dw + ((size_t)(t * 3) * p.Cin + c0 + rc / C::NB) * p.Cout + n0 + rc % C::NB;
+        const size_t tap = (size_t)p.Cin * p.Cout;
+        atomicAdd(dst, (m0 + m1) + m2);
+        atomicAdd(dst + tap, m1 - m2);
+        atomicAdd(dst + 2 * tap, (m1 + m2) + m3);
+      }
     }
     return;
   }
