@@ -35,9 +35,12 @@ constexpr int kThreads = 256;
 //   y[2p] = m0+m1+m2, y[2p+1] = m1-m2-m3  -- 4 MFMAs per two outputs instead of 6.  Both transforms are done on the fly
 // from the same LDS halo and the same weight-row registers as the direct form (one ds_read + one v_sub/v_add per MFMA).
 template <int KD, int KH, int KW, int SD_, int SH_, int SW_, int TD_, int TH_, int TW_, int CC_, int NB_, bool PAR_ = false, bool ONE_ = false,
-          bool WINO_ = false>
+          int WINO_ = 0>
 struct FwdCfg {
-  static constexpr bool PAR = PAR_, ONE = ONE_, WINO = WINO_;
+  static constexpr bool PAR = PAR_, ONE = ONE_;
+  // WINO: 0 = direct, 2 = F(2,3) (above), 4 = F(4,3): a GEMM row is FOUR adjacent outputs, six products per tap row
+  // instead of twelve (Lavin & Gray's matrices; fp32 error ~5e-6 of the output scale at K = 1728, direct 3e-7)
+  static constexpr int WINO = WINO_;
   static constexpr int kD = KD, kH = KH, kW = KW;
   static constexpr int SD = SD_, SH = SH_, SW = SW_, TD = TD_, TH = TH_, TW = TW_, CC = CC_, NB = NB_;
   // halo block: (T-1)*S + K input positions per axis; a pointwise (K == 1) strided conv only
@@ -48,9 +51,10 @@ struct FwdCfg {
   static constexpr int HD = (TD - 1) * LSD + KD, HH = (TH - 1) * LSH + KH, HW = (TW - 1) * LSW + KW;
   static constexpr int HP = HD * HH * HW;       // halo positions
   static constexpr int ROW = CC + 1;            // LDS row stride in floats
-  static constexpr int MV = TD * TH * TW / (WINO_ ? 2 : 1);       // GEMM rows of the tile: output positions (WINO: pairs)
-  static constexpr int NF = WINO_ ? 4 : 1;      // accumulator sets per MFMA tile (Winograd products)
-  static_assert(!WINO_ || (KD == 3 && KH == 3 && KW == 3 && SD_ == 1 && SH_ == 1 && SW_ == 1 && TW_ % 2 == 0 && !PAR_), "WINO: 3x3x3 stride 1");
+  static constexpr int OPR = WINO_ ? WINO_ : 1; // outputs per GEMM row
+  static constexpr int MV = TD * TH * TW / OPR;  // GEMM rows of the tile
+  static constexpr int NF = WINO_ == 2 ? 4 : (WINO_ == 4 ? 6 : 1);      // accumulator sets per MFMA tile (Winograd products)
+  static_assert(!WINO_ || (KD == 3 && KH == 3 && KW == 3 && SD_ == 1 && SH_ == 1 && SW_ == 1 && TW_ % (WINO_ ? WINO_ : 1) == 0 && !PAR_), "WINO: 3x3x3 stride 1");
   // GEMM rows per workgroup: MV rounded up to whole MFMA tiles per wave (a 5x7x7 tile -- the divisor-friendly shape
   // for 10x14x14 roi volumes -- has 245 positions and runs as 256 rows, the last 11 idle)
   static constexpr int MQ = (NB_ == 32) ? 128 : 64;
@@ -69,14 +73,14 @@ struct FwdCfg {
   // the latency and the kernel crawls at ~1 us per row.  There the chunk's whole weight tile [taps][CC][NB] (if <= 32 KB)
   // is staged in LDS with the same register pipeline as the halo, one Cin chunk ahead.
   static constexpr int WTAPS = PAR_ ? 27 : TAPS;
-  static constexpr bool BLDS = (!PAR_ && !WINO_ && M == 64 && WTAPS * CC_ * NB_ * 4 <= 32 * 1024);   // PAR walks <= 8 of its 27 taps
+  static constexpr bool BLDS = (!PAR_ && WINO_ == 0 && M == 64 && WTAPS * CC_ * NB_ * 4 <= 32 * 1024);   // PAR walks <= 8 of its 27 taps
   static constexpr int WLDS = BLDS ? WTAPS * CC_ * NB_ : 0;       // floats
   static constexpr int LDS_BYTES = (HP * ROW + WLDS) * 4;
   // single-chunk kernels (layer1's 3x3x3 16->16: load -> compute -> store with nothing to overlap inside a workgroup)
   // want a third workgroup per CU; without the prefetch registers they fit the 170-register budget without spilling
   // (a kernel that touches scratch stalls the queue for ~19 us at dispatch)
   // NOPF: no register prefetch of the next chunk (two workgroups per CU hide each other's staging instead)
-  static constexpr bool NOPF = WINO_ && TD_ == 4;
+  static constexpr bool NOPF = WINO_ != 0 && TD_ == 4;
   static constexpr int MINWG = ONE_ ? 3 : (NOPF ? 2 : 1);
   static_assert(WROWS >= TM && WROWS % TM == 0, "each wave needs at least one whole MFMA tile of rows");
   static_assert(CC % KSTEP == 0 && CC % 4 == 0, "channel chunk");
@@ -123,8 +127,8 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_fwd_kernel(Conv3dFw
   for (int mt = 0; mt < C::MT; ++mt) {
     int m = wave_m * C::WROWS + mt * C::TM + li;
     if (C::MV < C::M && m >= C::MV) m = 0;        // idle padding row: any in-range address, result never stored
-    constexpr int RW = C::WINO ? C::TW / 2 : C::TW;       // GEMM rows per tile row
-    const int tw = (m % RW) * (C::WINO ? 2 : 1), th = (m / RW) % C::TH, td = m / (RW * C::TH);
+    constexpr int RW = C::TW / C::OPR;       // GEMM rows per tile row
+    const int tw = (m % RW) * C::OPR, th = (m / RW) % C::TH, td = m / (RW * C::TH);
     abase[mt] = (((td * C::LSD) * C::HH + th * C::LSH) * C::HW + tw * C::LSW) * C::ROW + lk;
   }
   const float *wlane = p.w + (size_t)lk * p.Cout + n0 + wave_n * C::TM + li;
@@ -186,7 +190,40 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_fwd_kernel(Conv3dFw
       }
   };
   auto mma_row = [&](const float (&bw)[RT][C::KK], int kd_, int kh_) {
-    if constexpr (C::WINO) {
+    if constexpr (C::WINO == 4) {
+      const int rowoff = (kd_ * C::HH + kh_) * C::HW * C::ROW;
+#pragma unroll
+      for (int kk = 0; kk < C::KK; ++kk) {
+        const float g0 = bw[0][kk], g1 = bw[1][kk], g2 = bw[2][kk];
+        const float s02 = g0 + g2, h = g0 * (1.f / 24.f) + g2 * (1.f / 6.f), q = g1 * (1.f / 12.f);
+        const float u[6] = {0.25f * g0, (s02 + g1) * (-1.f / 6.f), (s02 - g1) * (-1.f / 6.f), h + q, h - q, g2};
+        float a[C::MT][6];
+#pragma unroll
+        for (int mt = 0; mt < C::MT; ++mt) {
+          const float *src = lds + abase[mt] + rowoff + kk * C::KSTEP;
+          const float d0 = src[0], d1 = src[C::ROW], d2 = src[2 * C::ROW], d3 = src[3 * C::ROW], d4 = src[4 * C::ROW], d5 = src[5 * C::ROW];
+          const float e = d4 - d2, f4 = 4.f * d2, o = d3 - d1;       // shared terms
+          a[mt][0] = 4.f * d0 - 5.f * d2 + d4;
+          a[mt][1] = (d3 + d4) - 4.f * (d1 + d2);
+          a[mt][2] = (d4 - d3) + 4.f * (d1 - d2);
+          a[mt][3] = e + 2.f * o;
+          a[mt][4] = e - 2.f * o;
+          a[mt][5] = 4.f * d1 - 5.f * d3 + d5;
+          (void)f4;
+        }
+#pragma unroll
+        for (int f = 0; f < 6; ++f)
+#pragma unroll
+          for (int mt = 0; mt < C::MT; ++mt) {
+            if constexpr (C::k16)
+              acc[f * C::MT + mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][f], u[f], acc[f * C::MT + mt], 0, 0, 0);
+            else
+              acc[f * C::MT + mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][f], u[f], acc[f * C::MT + mt], 0, 0, 0);
+          }
+      }
+      return;
+    }
+    if constexpr (C::WINO == 2) {
       const int rowoff = (kd_ * C::HH + kh_) * C::HW * C::ROW;
 #pragma unroll
       for (int kk = 0; kk < C::KK; ++kk) {
@@ -337,11 +374,19 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_fwd_kernel(Conv3dFw
     for (int r = 0; r < (C::k16 ? 4 : 16); ++r) {
       const int row = C::k16 ? (lk * 4 + r) : ((r & 3) + 8 * (r >> 2) + 4 * lk);
       const int m = wave_m * C::WROWS + mt * C::TM + row;
-      constexpr int RW = C::WINO ? C::TW / 2 : C::TW;
-      const int tw = (m % RW) * (C::WINO ? 2 : 1), th = (m / RW) % C::TH, td = m / (RW * C::TH);
+      constexpr int RW = C::TW / C::OPR;
+      const int tw = (m % RW) * C::OPR, th = (m / RW) % C::TH, td = m / (RW * C::TH);
       const int od = od0 + td, oh = oh0 + th, ow = ow0 + tw;
       const bool inside = od < p.Do && oh < p.Ho && ow < p.Wo && (C::MV == C::M || m < C::MV);
-      if constexpr (C::WINO) {
+      if constexpr (C::WINO == 4) {
+        const float m0 = acc[mt][r], m1 = acc[C::MT + mt][r], m2 = acc[2 * C::MT + mt][r], m3 = acc[3 * C::MT + mt][r],
+                    m4 = acc[4 * C::MT + mt][r], m5 = acc[5 * C::MT + mt][r];
+        const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+        emit(od, oh, ow, inside, (m0 + s12) + s34);
+        emit(od, oh, ow + 1, inside && ow + 1 < p.Wo, d12 + 2.f * d34);
+        emit(od, oh, ow + 2, inside && ow + 2 < p.Wo, s12 + 4.f * s34);
+        emit(od, oh, ow + 3, inside && ow + 3 < p.Wo, (d12 + 8.f * d34) + m5);
+      } else if constexpr (C::WINO == 2) {
         const float m0 = acc[mt][r], m1 = acc[C::MT + mt][r], m2 = acc[2 * C::MT + mt][r], m3 = acc[3 * C::MT + mt][r];
         emit(od, oh, ow, inside, (m0 + m1) + m2);
         emit(od, oh, ow + 1, inside && ow + 1 < p.Wo, (m1 - m2) - m3);
@@ -399,12 +444,13 @@ int dispatch_tile(const Conv3dFwdArgs &a, hipStream_t stream) {
     // outputs = 64 pair rows keep the accumulators at 64 registers and two workgroups per CU (P2 3x3x3 64->64:
     // 1.19 -> 1.02 ms; the 4x8x8 form needs 128 accumulator registers, one workgroup per CU: 1.11 ms).
     // The 16-wide single-chunk kernel (layer1) gains nothing from it (96 vs 96 TFLOP/s: not MFMA-bound).
-    static const int wino = getenv("MR3D_FWD_WINO") ? atoi(getenv("MR3D_FWD_WINO")) : 2;     // 0: direct form only; 1: 2x8x8 only
+    static const int wino = getenv("MR3D_FWD_WINO") ? atoi(getenv("MR3D_FWD_WINO")) : 3;     // 0: direct form only; 1: F(2,3) 2x8x8 only; 2: + F(2,3) 4x8x8; 3: F(4,3) 4x8x8
     // 4x8x8 outputs = 128 pair rows: 128 accumulator registers; without the next-chunk register prefetch it still fits
     // two workgroups per CU, which hide each other's staging: P2 0.91 ms (159 TFLOP/s of algorithmic work)
-    if (wino >= 2 && wgs(4, 8, 8) >= 512) return launch_fwd<FwdCfg<3, 3, 3, 1, 1, 1, 4, 8, 8, CC, NB, false, false, true>>(a, stream);
+    if (wino >= 3 && wgs(4, 8, 8) >= 512) return launch_fwd<FwdCfg<3, 3, 3, 1, 1, 1, 4, 8, 8, CC, NB, false, false, 4>>(a, stream);
+    if (wino >= 2 && wgs(4, 8, 8) >= 512) return launch_fwd<FwdCfg<3, 3, 3, 1, 1, 1, 4, 8, 8, CC, NB, false, false, 2>>(a, stream);
     static const int wino_min = getenv("MR3D_FWD_WINO_MIN") ? atoi(getenv("MR3D_FWD_WINO_MIN")) : 256;   // 16-roi mask batches (320 tiles): 133 -> 109 us
-    if (wino && wgs(2, 8, 8) >= wino_min) return launch_fwd<FwdCfg<3, 3, 3, 1, 1, 1, 2, 8, 8, CC, NB, false, false, true>>(a, stream);
+    if (wino && wgs(2, 8, 8) >= wino_min) return launch_fwd<FwdCfg<3, 3, 3, 1, 1, 1, 2, 8, 8, CC, NB, false, false, 2>>(a, stream);
   }
   if (wgs(4, 8, 8) >= 512) return launch_fwd<T0>(a, stream);
   if constexpr (NB == 32) {

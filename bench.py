@@ -296,11 +296,13 @@ def main():
                          'avg_launch_ms': dom_ms / launches if launches else None, 'launches_per_step': groups[dom]['n'],
                          'whole_step_frac': FLOP_FWD_BWD_512 * scale / (ms_per_step * 1e-3) / PEAK_FP32_MATRIX},
         }
-        if dom.startswith('conv3d_fwd<k3,s111,cc16,nb64') and os.environ.get('MR3D_FWD_WINO', '2') != '0':
-            # `achieved` / `frac` are ALGORITHMIC FLOP/s (2*MAC of the convolution) as the contract asks; this kernel is
-            # the Winograd F(2,3)-along-W form, which issues 2/3 of them as MFMA work -- the matrix pipe's own load is:
-            res['roofline']['algorithm'] = 'winograd F(2,3) along W: MFMA FLOPs issued = 2/3 of the algorithmic FLOPs'
-            res['roofline']['mfma_issued_frac'] = res['roofline']['frac'] * 2.0 / 3.0
+        if dom.startswith('conv3d_fwd<k3,s111,cc16,nb64') and os.environ.get('MR3D_FWD_WINO', '3') not in ('0', '1', '2'):
+            # `achieved` / `frac` are ALGORITHMIC FLOP/s (2*MAC of the convolution) as the contract asks; these launches
+            # run the Winograd-along-W forms of the kernel, which issue fewer FLOPs as MFMA work: F(4,3) on the P2 map
+            # (1/2 of the algorithmic FLOPs), F(2,3) on P3 (2/3) -- FLOP-weighted 0.5185.  The matrix pipe's own load:
+            res['roofline']['algorithm'] = ('winograd along W: F(4,3) on P2 (MFMA FLOPs issued = 1/2 of the algorithmic '
+                                            'FLOPs), F(2,3) on P3 (2/3)')
+            res['roofline']['mfma_issued_frac'] = res['roofline']['frac'] * (145.0 * 0.5 + 18.1 * 2.0 / 3.0) / 163.1
         if world == 1 and not a.no_aux:
             try:
                 res['aux'] = {k: round(v, 1) for k, v in ops_microbench(dev).items()}
