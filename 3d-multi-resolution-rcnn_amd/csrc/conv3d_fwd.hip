@@ -433,6 +433,7 @@ int dispatch_tile(const Conv3dFwdArgs &a, hipStream_t stream) {
     const long long t488 = (long long)((a.Do + 3) / 4) * ((a.Ho + 7) / 8) * ((a.Wo + 7) / 8);
     const long long t288 = (long long)((a.Do + 1) / 2) * ((a.Ho + 7) / 8) * ((a.Wo + 7) / 8);
     const double c577 = (double)vol / (t577 * 256.0), c488 = (double)vol / (t488 * 256.0), c288 = (double)vol / (t288 * 128.0);
+    // (the F(4,3) form on padded 4x8x8 tiles was measured equal on these volumes: 463 vs 463 us for 128 rois)
     if (c577 > 1.15 * (c488 > c288 ? c488 : c288) && a.N * t577 * (a.Cout / NB) >= 512)
       return launch_fwd<FwdCfg<3, 3, 3, 1, 1, 1, 5, 7, 7, CC, NB>>(a, stream);
   }
@@ -447,7 +448,8 @@ int dispatch_tile(const Conv3dFwdArgs &a, hipStream_t stream) {
     static const int wino = getenv("MR3D_FWD_WINO") ? atoi(getenv("MR3D_FWD_WINO")) : 3;     // 0: direct form only; 1: F(2,3) 2x8x8 only; 2: + F(2,3) 4x8x8; 3: F(4,3) 4x8x8
     // 4x8x8 outputs = 128 pair rows: 128 accumulator registers; without the next-chunk register prefetch it still fits
     // two workgroups per CU, which hide each other's staging: P2 0.91 ms (159 TFLOP/s of algorithmic work)
-    if (wino >= 3 && wgs(4, 8, 8) >= 512) return launch_fwd<FwdCfg<3, 3, 3, 1, 1, 1, 4, 8, 8, CC, NB, false, false, 4>>(a, stream);
+    static const int min43 = getenv("MR3D_FWD_WINO43_MIN") ? atoi(getenv("MR3D_FWD_WINO43_MIN")) : 256;   // P3 (320 tiles): 0.164 -> 0.157 ms
+    if (wino >= 3 && wgs(4, 8, 8) >= min43) return launch_fwd<FwdCfg<3, 3, 3, 1, 1, 1, 4, 8, 8, CC, NB, false, false, 4>>(a, stream);
     if (wino >= 2 && wgs(4, 8, 8) >= 512) return launch_fwd<FwdCfg<3, 3, 3, 1, 1, 1, 4, 8, 8, CC, NB, false, false, 2>>(a, stream);
     static const int wino_min = getenv("MR3D_FWD_WINO_MIN") ? atoi(getenv("MR3D_FWD_WINO_MIN")) : 256;   // 16-roi mask batches (320 tiles): 133 -> 109 us
     if (wino && wgs(2, 8, 8) >= wino_min) return launch_fwd<FwdCfg<3, 3, 3, 1, 1, 1, 2, 8, 8, CC, NB, false, false, 2>>(a, stream);
