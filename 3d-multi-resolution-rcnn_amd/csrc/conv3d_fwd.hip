@@ -454,6 +454,11 @@ int dispatch_tile(const Conv3dFwdArgs &a, hipStream_t stream) {
     static const int wino_min = getenv("MR3D_FWD_WINO_MIN") ? atoi(getenv("MR3D_FWD_WINO_MIN")) : 256;   // 16-roi mask batches (320 tiles): 133 -> 109 us
     if (wino && wgs(2, 8, 8) >= wino_min) return launch_fwd<FwdCfg<3, 3, 3, 1, 1, 1, 2, 8, 8, CC, NB, false, false, 2>>(a, stream);
   }
+  if constexpr (K == 3 && SD == 1 && SH == 1 && SW == 1 && CC == 16 && NB == 32) {
+    // 32-wide Cout tile (layer2 32->32 on 20x64x64): F(2,3) on 4x8x8 tiles, 128 pair rows: 67 -> 57 us
+    static const int wino32 = getenv("MR3D_FWD_WINO") ? atoi(getenv("MR3D_FWD_WINO")) : 3;
+    if (wino32 && wgs(4, 8, 8) >= 256) return launch_fwd<FwdCfg<3, 3, 3, 1, 1, 1, 4, 8, 8, CC, NB, false, false, 2>>(a, stream);
+  }
   if (wgs(4, 8, 8) >= 512) return launch_fwd<T0>(a, stream);
   if constexpr (NB == 32) {
     return launch_fwd<T1>(a, stream);

@@ -275,19 +275,20 @@ def test_dominant_kernel_full_size_vs_miopen(dev):
     assert rel(dw2, 2.0 * dw) <= 1e-5
 
 
-@pytest.mark.parametrize('n,dhw,form', [(2, (16, 61, 63), 'F(4,3), 4x8x8 tiles'), (1, (9, 61, 63), 'F(2,3), 2x8x8 tiles')])
-def test_conv3d_winograd_w_path_matches_direct_and_reference(dev, n, dhw, form):
+@pytest.mark.parametrize('n,c,dhw,form', [(2, 64, (16, 61, 63), 'F(4,3), 4x8x8 tiles'), (1, 64, (9, 61, 63), 'F(2,3), 2x8x8 tiles'),
+                                          (1, 32, (16, 61, 63), 'F(2,3), 4x8x8 tiles, 32-wide Cout tile')])
+def test_conv3d_winograd_w_path_matches_direct_and_reference(dev, n, c, dhw, form):
     """3x3x3 / stride 1 / 64-wide Cout tile takes a Winograd-along-W form of the kernel (FwdCfg<..., WINO>): F(4,3) on
     4x8x8 tiles when there are >= 512 of them, else F(2,3) on 2x8x8 tiles (>= 256).  Same results as an fp64 torch
     convolution within the kernel tolerance, on volumes with an ODD width (the last output group is partly valid) and
     with every fused epilogue stream; the measured error must also leave a margin under the tolerance."""
     from mr3d_amd import _hip
-    g = torch.Generator().manual_seed(4242 + n)
-    c = 64
+    g = torch.Generator().manual_seed(4242 + n + c)
+    co = c                                              # 64 -> 64 (FPN / RPN / mask head), 32 -> 32 (layer2)
     x = torch.randn((n, c) + dhw, generator=g)
-    w = torch.randn((64, c, 3, 3, 3), generator=g) / np.sqrt(27 * c)
-    shift = torch.randn(64, generator=g)
-    add1, mask = torch.randn((n, 64) + dhw, generator=g), torch.randn((n, 64) + dhw, generator=g)
+    w = torch.randn((co, c, 3, 3, 3), generator=g) / np.sqrt(27 * c)
+    shift = torch.randn(co, generator=g)
+    add1, mask = torch.randn((n, co) + dhw, generator=g), torch.randn((n, co) + dhw, generator=g)
     ref = F.conv3d(x.double(), w.double(), shift.double(), 1, 1)
     xc, wp = _cl(x).to(dev), _hip.pack_conv_weight(w).to(dev)
     y = _hip.conv3d_forward(xc, wp, (3,) * 3, (1,) * 3, (1,) * 3, shift=shift.to(dev))
@@ -298,6 +299,8 @@ def test_conv3d_winograd_w_path_matches_direct_and_reference(dev, n, dhw, form):
     _check(y, torch.relu(ref + add1).float(), f'winograd {form} add+relu')
     y = _hip.conv3d_forward(xc, wp, (3,) * 3, (1,) * 3, (1,) * 3, add1=_cl(add1).to(dev), mask=_cl(mask).to(dev))
     _check(y, ((ref - shift.double().view(1, -1, 1, 1, 1) + add1) * (mask > 0)).float(), f'winograd {form} add+mask')
+    if c != 64:
+        return
     # 128 output channels: two Cout tiles per position tile
     w2 = torch.randn((128, c, 3, 3, 3), generator=g) / np.sqrt(27 * c)
     y = _hip.conv3d_forward(xc, _hip.pack_conv_weight(w2).to(dev), (3,) * 3, (1,) * 3, (1,) * 3)
