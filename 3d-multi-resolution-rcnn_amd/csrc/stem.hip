@@ -15,6 +15,7 @@
 //     registers across a persistent loop over tiles; one atomic pass at the end.
 // One input channel of the halo block ((TD+6) x (2*TH+5) x 72 floats) is resident in LDS at a time.
 #include "conv3d.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -160,6 +161,122 @@ __global__ __launch_bounds__(TD * 64) void stem_fwd_kernel(StemFwdArgs p, int ti
           p.y[((((size_t)n * p.D + od) * p.Ho + oh) * p.Wo + ow) * 16 + li] = v;
         }
       }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ forward, Winograd along D
+// The stem has stride 1 along depth, so its seven depth taps split as 3 + 3 + 1 and each 3-tap group takes the
+// F(2,3) form over a PAIR of output depths (d, d+1):  with slab planes P_j = plane(d + j),
+//   group kd 0..2: (P0-P2, P1+P2, P2-P1, P1-P3) x G(g0,g1,g2),   group kd 3..5: (P3-P5, P4+P5, P5-P4, P4-P6) x G(g3,g4,g5),
+//   tap kd 6: P6*g6 belongs to y[d] only and P7*g6 to y[d+1] only, i.e. to M0 and (negated) M3 of
+//   y[d] = M0+M1+M2, y[d+1] = M1-M2-M3 -- no extra accumulators.
+// 10 MFMA groups per (kh, kw step) and depth pair instead of 14.  A wave owns a depth pair and four of the tile's
+// eight output rows; everything else (slab, kw split, B from L2) is as in stem_fwd_kernel.
+template <int TW>
+__global__ __launch_bounds__(256, 3) void stem_fwd_wino_kernel(StemFwdArgs p, int tiles_d, int tiles_h, int tiles_w) {
+  constexpr int TD = 4, TH = 8, THW = 4;                       // THW: output rows per wave
+  static_assert(TW == 16, "one 16-column MFMA tile per row");
+  using G = StemGeo<TD, TH, TW, 40>;
+  constexpr int SW_ROW = G::SW_ROW;
+  extern __shared__ __attribute__((aligned(16))) float slab[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int dp = wave >> 1, hh = wave & 1;                      // depth pair, row half
+  const int li = lane & 15, lk = lane >> 4;
+  int b = blockIdx.x;
+  const int tw_i = b % tiles_w; b /= tiles_w;
+  const int th_i = b % tiles_h; b /= tiles_h;
+  const int td_i = b % tiles_d; b /= tiles_d;
+  const int n = b;
+  const int d0 = td_i * TD, h0 = th_i * TH, w0 = tw_i * TW;
+
+  f32x4 acc[4][THW];                                            // [Winograd product f][row]
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int t = 0; t < THW; ++t) acc[f][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int lane_off = 2 * li + 2 * lk;
+  const size_t vox = (size_t)p.D * p.H * p.W;
+
+  for (int ci = 0; ci < 3; ++ci) {
+    __syncthreads();
+    stem_stage_channel<256, G>(slab, p.x + ((size_t)n * 3 + ci) * vox, p.D, p.H, p.W, d0, h0, w0, tid);
+    __syncthreads();
+    // raw weights of one kh row: g[kd][step]; step s of MFMA k index lk is tap kw = 2*lk + s - 1 (kw = -1: weight 0)
+    auto load_g = [&](int kh, float (&g)[7][2]) {
+#pragma unroll
+      for (int kd = 0; kd < 7; ++kd) {
+        const float *wrow = p.wf + (size_t)((kd * 7 + kh) * 7) * 64 + ci * 16 + li;
+        g[kd][0] = (lk > 0) ? wrow[(2 * lk - 1) * 64] : 0.f;
+        g[kd][1] = wrow[(2 * lk) * 64];
+      }
+    };
+    float g0[7][2], g1[7][2];
+    load_g(0, g0);
+    auto row = [&](int kh, const float (&g)[7][2]) {
+      // B values: [group][f][step]
+      float u1[4][2], u2[4][2], u6[2];
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) {
+        const float a0 = g[0][s_], a1 = g[1][s_], a2 = g[2][s_], b0 = g[3][s_], b1 = g[4][s_], b2 = g[5][s_];
+        u1[0][s_] = a0; u1[1][s_] = 0.5f * ((a0 + a2) + a1); u1[2][s_] = 0.5f * ((a0 + a2) - a1); u1[3][s_] = a2;
+        u2[0][s_] = b0; u2[1][s_] = 0.5f * ((b0 + b2) + b1); u2[2][s_] = 0.5f * ((b0 + b2) - b1); u2[3][s_] = b2;
+        u6[s_] = g[6][s_];
+      }
+#pragma unroll
+      for (int t = 0; t < THW; ++t) {
+        const float *base = slab + ((2 * dp) * G::PH + kh + 2 * (hh * THW + t)) * SW_ROW + lane_off;
+        float2 P[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) P[j] = *reinterpret_cast<const float2 *>(base + j * G::PH * SW_ROW);
+        auto mm = [&](f32x4 &c, float2 a, const float (&bb)[2]) {
+          c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bb[0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bb[1], c, 0, 0, 0);
+        };
+        auto sub = [](float2 a, float2 b_) { return make_float2(a.x - b_.x, a.y - b_.y); };
+        auto add = [](float2 a, float2 b_) { return make_float2(a.x + b_.x, a.y + b_.y); };
+        mm(acc[0][t], sub(P[0], P[2]), u1[0]);
+        mm(acc[1][t], add(P[1], P[2]), u1[1]);
+        mm(acc[2][t], sub(P[2], P[1]), u1[2]);
+        mm(acc[3][t], sub(P[1], P[3]), u1[3]);
+        mm(acc[0][t], sub(P[3], P[5]), u2[0]);
+        mm(acc[1][t], add(P[4], P[5]), u2[1]);
+        mm(acc[2][t], sub(P[5], P[4]), u2[2]);
+        mm(acc[3][t], sub(P[4], P[6]), u2[3]);
+        mm(acc[0][t], P[6], u6);
+        mm(acc[3][t], make_float2(-P[7].x, -P[7].y), u6);
+      }
+    };
+    // kh rows two at a time, the next row's weights requested before the current row's MFMAs
+    for (int kh = 0; kh < 6; kh += 2) {
+      load_g(kh + 1, g1);
+      row(kh, g0);
+      load_g(kh + 2, g0);
+      row(kh + 1, g1);
+    }
+    row(6, g0);
+  }
+
+  const float sh = p.shift ? p.shift[li] : 0.f;
+#pragma unroll
+  for (int t = 0; t < THW; ++t) {
+    const int oh = h0 + hh * THW + t;
+    if (oh >= p.Ho) continue;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int od = d0 + 2 * dp + e;
+      if (od >= p.D) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ow = w0 + lk * 4 + r;
+        if (ow < p.Wo) {
+          const float m0 = acc[0][t][r], m1 = acc[1][t][r], m2 = acc[2][t][r], m3 = acc[3][t][r];
+          float v = (e == 0 ? (m0 + m1) + m2 : (m1 - m2) - m3) + sh;
+          if (p.relu) v = fmaxf(v, 0.f);
+          p.y[((((size_t)n * p.D + od) * p.Ho + oh) * p.Wo + ow) * 16 + li] = v;
+        }
+      }
+    }
   }
 }
 
@@ -329,14 +446,17 @@ extern "C" int mr3d_stem_conv_forward(const float *x_ncdhw, const float *w_packe
   a.N = n; a.D = d; a.H = h; a.W = w;
   a.Ho = (h + 6 - 7) / 2 + 1; a.Wo = (w + 6 - 7) / 2 + 1;
   a.relu = relu;
-  // 4x8x16 output tile: 33 KiB slab, four 4-wave workgroups per CU = 4 waves per SIMD, so the matrix pipe
-  // always has a ready wave while others sit at a barrier / wait for LDS (measured: 2 waves per SIMD left it
-  // idle 40 % of the time)
+  // 4x8x16 output tile: 33 KiB slab; direct form: four 4-wave workgroups per CU = 4 waves per SIMD, so the matrix
+  // pipe always has a ready wave while others sit at a barrier / wait for LDS (measured: 2 waves per SIMD left it idle
+  // 40 % of the time); the Winograd form needs 166 registers: three workgroups per CU
   constexpr int TD = 4, TW = 16;
   using G = StemGeo<TD, 8, TW, 40>;
   constexpr int lds_bytes = G::SLAB * 4;
   const int td = (d + TD - 1) / TD, th = (a.Ho + 7) / 8, tw = (a.Wo + TW - 1) / TW;
-  stem_fwd_kernel<TD, TW><<<(unsigned)(n * td * th * tw), TD * 64, lds_bytes, mr3d_stream(stream_)>>>(a, td, th, tw);
+  // Winograd-along-depth form by default (1.79 -> 1.43 ms on the 512 volume); MR3D_STEM_WINO=0: direct form
+  static const int wino = getenv("MR3D_STEM_WINO") ? atoi(getenv("MR3D_STEM_WINO")) : 1;
+  if (wino) stem_fwd_wino_kernel<TW><<<(unsigned)(n * td * th * tw), 256, lds_bytes, mr3d_stream(stream_)>>>(a, td, th, tw);
+  else stem_fwd_kernel<TD, TW><<<(unsigned)(n * td * th * tw), TD * 64, lds_bytes, mr3d_stream(stream_)>>>(a, td, th, tw);
   return mr3d_launch_status();
 }
 
