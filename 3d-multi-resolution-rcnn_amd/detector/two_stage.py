@@ -81,6 +81,17 @@ class PosCountReadback(object):
         return self.cap_pos
 
 
+def front_pack_order(valid_counts, rows_per_img):
+    """imgs_per_gpu > 1: every image contributes a fixed-capacity block whose first `valid_counts[i]` rows are real.
+    Returns the permutation that moves the real rows of ALL images to the front (stable, so the per-image order is kept)
+    without reading the counts back: the packed batch then has one contiguous valid prefix like the single-image one."""
+    n = len(valid_counts)
+    dev = valid_counts[0].device
+    local = torch.arange(rows_per_img, device=dev).repeat(n)
+    limit = torch.stack([c.reshape(()) for c in valid_counts]).repeat_interleave(rows_per_img)
+    return torch.argsort((local >= limit).to(torch.int8), stable=True)
+
+
 class TwoStageDetector3D(nn.Module):
 
     def __init__(self, device='cuda', train_cfg=None, test_cfg=None, with_mask=True, anchor_scales=(2,),
@@ -179,37 +190,45 @@ class TwoStageDetector3D(nn.Module):
                                                          float(rc['pos_weight']))
             rois.append(r); labels.append(lab); label_weights.append(lw); bbox_targets.append(bt); bbox_weights.append(bw)
             pos_gt.append(pgi); counts.append(cnt)
-        readback = PosCountReadback(counts[0], rc.get('mask_batch_buckets', MASK_BATCH_BUCKETS), cap_pos) \
+        counts = torch.stack(counts)                                        # [num_imgs, 4]: pos, neg, candidates
+        n_pos_total = counts[:, 0].sum().reshape(1).to(counts.dtype)
+        readback = PosCountReadback(n_pos_total, rc.get('mask_batch_buckets', MASK_BATCH_BUCKETS), cap_pos * num_imgs) \
             if self.with_mask else None
-        counts = torch.stack(counts)
         self.last_sample_counts = counts
         self._mark('rcnn assign+sample+targets')
 
-        # ---- bbox head (two_stage_3d.py:179-192)
-        all_rois = torch.cat(rois)
+        # ---- bbox head (two_stage_3d.py:179-192).  Several images: their real rows are packed to the front of the
+        # concatenated batch (bbox2roi3D's layout minus the per-image padding) so that one valid prefix remains.
+        cat = lambda ts: torch.cat(ts)
+        all_rois, lab, lw, bt, bw = cat(rois), cat(labels), cat(label_weights), cat(bbox_targets), cat(bbox_weights)
+        if num_imgs > 1:
+            order = front_pack_order([counts[i, 0] + counts[i, 1] for i in range(num_imgs)], cap)
+            all_rois, lab, lw, bt, bw = all_rois[order], lab[order], lw[order], bt[order], bw[order]
         bbox_feats = self.bbox_roi_extractor(x[:self.bbox_roi_extractor.num_inputs], all_rois)
         cls_score, bbox_pred = self.bbox_head(bbox_feats)
-        lab, lw = torch.cat(labels), torch.cat(label_weights)
         # padding rows have weight 0 everywhere; accuracy / avg_factor need the real row count
-        if num_imgs > 1:
-            raise NotImplementedError('imgs_per_gpu > 1: per-image padding makes the valid rows non-contiguous '
-                                      '(the shipped config trains with imgs_per_gpu=1, configs/...py:191)')
         num_rois = _hip.avg_factor_from_counts(counts, 1)
-        valid_rows = (counts[0, 0] + counts[0, 1]).reshape(1).to(torch.int32)
-        losses.update(self.bbox_head.loss(cls_score, bbox_pred, lab, lw, torch.cat(bbox_targets), torch.cat(bbox_weights),
-                                          valid_rows=valid_rows, num_rois=num_rois))
+        valid_rows = (counts[:, 0] + counts[:, 1]).sum().reshape(1).to(torch.int32)
+        losses.update(self.bbox_head.loss(cls_score, bbox_pred, lab, lw, bt, bw, valid_rows=valid_rows, num_rois=num_rois))
         self._mark('bbox roialign+head+loss')
 
-        # ---- mask head on the positives (two_stage_3d.py:194-218): rows [0, rows) of the roi batch, first #pos real
+        # ---- mask head on the positives (two_stage_3d.py:194-218): rows [0, cap_pos) of every image's roi batch, the
+        # first #pos of them real; targets are cropped per image (each has its own gt masks), then packed like the rois
         if self.with_mask:
-            cap_pos = readback.rows()
-            pos_rois = rois[0][:cap_pos].contiguous()
+            rows = readback.rows()
+            if num_imgs == 1:                  # only the bucket's rows are ever touched
+                pos_rois, pos_labels = rois[0][:rows].contiguous(), labels[0][:rows]
+                mask_targets = mask_target_single(pos_rois[:, 1:], pos_gt[0][:rows].clamp(min=0), gt_masks[0], SimpleNamespace(**rc))
+            else:
+                pos_rois = cat([r[:cap_pos] for r in rois])
+                pos_labels = cat([l[:cap_pos] for l in labels])
+                mask_targets = cat([mask_target_single(rois[i][:cap_pos, 1:].contiguous(), pos_gt[i][:cap_pos].clamp(min=0),
+                                                       gt_masks[i], SimpleNamespace(**rc)) for i in range(num_imgs)])
+                order = front_pack_order([counts[i, 0] for i in range(num_imgs)], cap_pos)[:rows]
+                pos_rois, pos_labels, mask_targets = pos_rois[order].contiguous(), pos_labels[order], mask_targets[order]
             mask_feats = self.mask_roi_extractor(x[:self.mask_roi_extractor.num_inputs], pos_rois)
             mask_pred = self.mask_head(mask_feats)
-            n_pos = counts[0, 0].reshape(1)
-            gi = pos_gt[0][:cap_pos].clamp(min=0)                        # padding rows point at gt 0; they carry no loss
-            mask_targets = mask_target_single(pos_rois[:, 1:], gi, gt_masks[0], SimpleNamespace(**rc))
-            losses.update(self.mask_head.loss(mask_pred, mask_targets, labels[0][:cap_pos], valid_rows=n_pos))
+            losses.update(self.mask_head.loss(mask_pred, mask_targets, pos_labels, valid_rows=n_pos_total))
             self._mark('mask roialign+head+targets+loss')
         self.iteration += 1
         return losses

@@ -144,6 +144,32 @@ def test_mask_batch_buckets_do_not_change_losses_or_gradients(dev):
             assert (a - b).abs().max().item() <= 1e-4 * max(b.abs().max().item(), 1e-12)
 
 
+def test_two_images_per_gpu_pack_valid_rows(dev):
+    """imgs_per_gpu = 2 (bbox2roi3D's multi-image layout, two_stage_3d.py:179-218): every image keeps its fixed-capacity
+    roi block and the real rows of both are packed to the front on the device.  With the SAME volume, boxes and sampler
+    words twice, every loss equals the single-image loss (all of them are means over identical sets), and the backbone
+    gradient doubles."""
+    det, img, gt, gl, masks, meta, draws = _setup(dev, seed=4)
+    det.extract.zero_grad()
+    l1 = det.forward_train(img, meta, [gt], [gl], gt_masks=[masks], draws=draws)
+    det.total_loss(l1).backward()
+    g1 = det.extract.flat_grads.clone()
+    c1 = det.last_sample_counts.clone()
+    draws2 = {k: [v[0], v[0]] for k, v in draws.items()}
+    det.extract.zero_grad()
+    l2 = det.forward_train(torch.cat([img, img]), meta * 2, [gt, gt], [gl, gl], gt_masks=[masks, masks], draws=draws2)
+    det.total_loss(l2).backward()
+    assert torch.equal(det.last_sample_counts, torch.cat([c1, c1]))
+    flat = lambda v: torch.stack(list(v)) if isinstance(v, (list, tuple)) else v.reshape(1)
+    for k in l1:
+        a, b = flat(l1[k]).detach().float(), flat(l2[k]).detach().float()
+        assert (a - b).abs().max().item() <= 2e-5 * max(1.0, a.abs().max().item()), (k, a, b)
+    # each loss is a mean over twice the rows of the same values: the summed gradient equals the single-image one (up to
+    # the rounding of different kernel forms / tile counts for the two batch sizes, accumulated through the backbone)
+    scale = g1.abs().max().item()
+    assert (det.extract.flat_grads - g1).abs().max().item() <= 5e-3 * scale
+
+
 def test_simple_test_inference_path(dev):
     """two_stage_3d.py:229-264: result containers, clipping, score order, masks confined to their (truncated) boxes"""
     det, img, gt, gl, masks, meta, _ = _setup(dev, seed=2)
