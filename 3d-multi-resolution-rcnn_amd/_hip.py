@@ -184,6 +184,37 @@ def nms3d_batched(dets_list, iou_threshold):
     return out
 
 
+def multiclass_nms3d(multi_bboxes, multi_scores, score_thr, iou_thr, max_num):
+    """mr3d_multiclass_nms3d -> (dets [k,7], labels int64 [k]); one 4-byte read-back (the output's row count)"""
+    for t, what in ((multi_bboxes, 'multi_bboxes'), (multi_scores, 'multi_scores')):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2):
+            raise RuntimeError(f'{what} must be a 2-D float32 CUDAtensor ')
+    b, sc = multi_bboxes.contiguous(), multi_scores.contiguous()
+    n, C = sc.shape
+    dev = sc.device
+    if b.size(0) != n or b.size(1) not in (6, 6 * C):
+        raise RuntimeError('multi_bboxes must be [n, 6] or [n, 6 * num_classes]')
+    if n == 0 or C < 2:
+        return b.new_zeros((0, 7)), torch.zeros((0,), dtype=torch.long, device=dev)
+    L = lib()
+    wsb = _sz(L.mr3d_multiclass_nms3d_workspace_bytes, n, C)
+    if wsb == 0:
+        raise Mr3dError(f'mr3d_multiclass_nms3d: {n} rows x {C - 1} classes exceeds the 4096-row / 16-class device limits')
+    cap = (C - 1) * n if max_num < 0 else min((C - 1) * n, int(max_num))
+    dets = torch.empty((max(cap, 1), 7), dtype=torch.float32, device=dev)
+    labels = torch.empty((max(cap, 1),), dtype=torch.long, device=dev)
+    count = torch.empty((1,), dtype=torch.int32, device=dev)
+    ws = torch.empty((wsb + 256,), dtype=torch.uint8, device=dev)
+    off = (-ws.data_ptr()) % 256
+    with torch.cuda.device(dev):
+        st = L.mr3d_multiclass_nms3d(ptr(b), int(b.size(1)), ptr(sc), n, C, ctypes.c_float(score_thr), ctypes.c_float(iou_thr),
+                                     int(max_num), ptr(dets), ptr(labels), ptr(count), ctypes.c_void_p(ws.data_ptr() + off),
+                                     ctypes.c_size_t(wsb), stream_ptr(dev))
+        check(st, 'mr3d_multiclass_nms3d')
+        k = int(count.item())
+    return dets[:k], labels[:k]
+
+
 def roi_align3d_forward(features, rois, out_d, out_h, out_w, spatial_scale, spatial_scale_depth, sample_num, output):
     layout = feature_layout(features)
     N, C, D, H, W = features.shape

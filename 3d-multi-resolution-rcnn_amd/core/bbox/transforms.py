@@ -17,14 +17,14 @@ def bbox2delta3d(proposals, gt, means=[0, 0, 0, 0, 0, 0], stds=[1, 1, 1, 1, 1, 1
 
 
 def bbox2roi3D(bbox_list):
-    """list of per-image [k_i, >=6] boxes -> [sum k_i, 7] rows [batch_ind, x1, y1, x2, y2, z1, z2]
-    (pure indexing: stays in PyTorch, transforms.py:220-239)"""
-    rois_list = []
-    for img_id, bboxes in enumerate(bbox_list):
-        if bboxes.size(0) > 0:
-            img_inds = bboxes.new_full((bboxes.size(0), 1), img_id)
-            rois = torch.cat([img_inds, bboxes[:, :6]], dim=-1)
-        else:
-            rois = bboxes.new_zeros((0, 7))
-        rois_list.append(rois)
-    return torch.cat(rois_list, 0)
+    """per-image boxes [k_i, >=6] -> rois [sum k_i, 7] = (image index, x1, y1, x2, y2, z1, z2) (transforms.py:220-239);
+    one output allocation filled block by block"""
+    counts = [int(b.size(0)) for b in bbox_list]
+    rois = bbox_list[0].new_empty((sum(counts), 7))
+    row = 0
+    for img_id, (boxes, k) in enumerate(zip(bbox_list, counts)):
+        block = rois[row:row + k]
+        block[:, 0] = img_id
+        block[:, 1:] = boxes[:, :6]
+        row += k
+    return rois

@@ -8,8 +8,12 @@
 // call, H2D of the result).  skimage is neither vendored nor installable here, so the exact resampling is
 // "parity unpinned"; this build defines it as: crop by integer-truncated box (bbox.astype(int32), size
 // max(x2-x1+1, 1), clipped to the volume like a numpy slice), trilinear resampling with half-pixel centres
-// (src = (dst + 0.5) * in/out - 0.5, clamped to the crop), target = 1 iff floor(255 * value) > 0 (the
-// reference's `255*resize(...)).astype(uint8) > 0`), paste = value > thr.  No anti-alias pre-filter.
+// (src = (dst + 0.5) * in/out - 0.5, clamped to the crop), paste = value > thr.  No anti-alias pre-filter.
+// Target rule: the reference feeds a uint8 0/1 crop to resize() with preserve_range=False, so skimage first scales it
+// by 1/255 (img_as_float); `(255 * resize(...)).astype(uint8)` is therefore floor(coverage) and `> 0` keeps only
+// voxels whose interpolated coverage reaches 1 -- an ERODED mask (mask_target.py:41-44).  target = 1 iff
+// coverage >= 1 - 2^-16 (the slack absorbs the fp32 rounding of the three lerps; the reference's own float64 sums
+// are just as close to 1).
 #include "mr3d_common.h"
 
 namespace {
@@ -59,7 +63,7 @@ __global__ __launch_bounds__(kT) void mask_target3d_kernel(const uint8_t *__rest
       const float c10 = at(zh, yl, xl) * (1 - fx) + at(zh, yl, xh) * fx, c11 = at(zh, yh, xl) * (1 - fx) + at(zh, yh, xh) * fx;
       v = (c00 * (1 - fy) + c01 * fy) * (1 - fz) + (c10 * (1 - fy) + c11 * fy) * fz;
     }
-    out[t] = floorf(255.f * v) > 0.f ? 1.f : 0.f;
+    out[t] = v >= 1.f - 1.52587890625e-5f ? 1.f : 0.f;
   }
 }
 

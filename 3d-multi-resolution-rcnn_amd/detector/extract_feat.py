@@ -109,44 +109,115 @@ class ExtractFeat3D(nn.Module):
             s.index = k
         self.specs = S
 
-    def _build_arena(self):
-        entries = []            # (name, shape, is_param)
+    def _arena_entries(self):
+        """(name, shape) of every trainable tensor, then of every BatchNorm running statistic, in arena order"""
+        train, stats = [], []
         for s in self.specs:
-            entries.append((s.name + '.weight', (s.cout, s.cin, s.k, s.k, s.k), True))
+            train.append((s.name + '.weight', (s.cout, s.cin, s.k, s.k, s.k)))
             if s.bias:
-                entries.append((s.name + '.bias', (s.cout,), True))
+                train.append((s.name + '.bias', (s.cout,)))
             if s.bn:
-                entries.append((s.bn + '.weight', (s.cout,), True))
-                entries.append((s.bn + '.bias', (s.cout,), True))
-                entries.append((s.bn + '.running_mean', (s.cout,), False))
-                entries.append((s.bn + '.running_var', (s.cout,), False))
-        off, self.offsets = 0, {}
-        for name, shape, _ in entries:
-            self.offsets[name] = off
-            off += -(-int(np.prod(shape)) // _ALIGN) * _ALIGN
-        self.arena_size = off
-        arena = torch.zeros(off, dtype=torch.float32, device=self.device)
-        grads = torch.zeros(off, dtype=torch.float32, device=self.device)
-        self.register_buffer('_arena', arena, persistent=False)
-        self.register_buffer('_grad_arena', grads, persistent=False)
-        for name, shape, is_param in entries:
-            o, n = self.offsets[name], int(np.prod(shape))
-            view = arena[o:o + n].view(shape)
-            if is_param:
-                p = nn.Parameter(view)
-                p.grad = grads[o:o + n].view(shape)
-                _attach(self, name, p, True)
-            else:
-                _attach(self, name, view, False)
+                train.append((s.bn + '.weight', (s.cout,)))
+                train.append((s.bn + '.bias', (s.cout,)))
+                stats.append((s.bn + '.running_mean', (s.cout,)))
+                stats.append((s.bn + '.running_var', (s.cout,)))
+        return train, stats
+
+    def _build_arena(self):
+        """Arena layout: [every trainable tensor | every BN running statistic].  `flat_params` / `flat_grads` are the
+        TRAINABLE prefix only -- the range the optimiser steps and the data-parallel all-reduce exchanges; the running
+        statistics (frozen: norm_eval=True, resnet3d.py:330,480-486) sit behind it, so weight decay / momentum never touch
+        them.  The kernels address both regions through offsets from one base pointer (mr3d_layer_desc)."""
+        train, stats = self._arena_entries()
+        al = lambda v: -(-v // _ALIGN) * _ALIGN
+        self.rel_offsets, off = {}, 0
+        for name, shape in train:
+            self.rel_offsets[name] = off
+            off += al(int(np.prod(shape)))
+        self.num_trainable = off
+        soff = 0
+        for name, shape in stats:
+            self.rel_offsets[name] = soff
+            soff += al(int(np.prod(shape)))
+        self.num_stats = soff
+        arena = torch.zeros(self.num_trainable + self.num_stats, dtype=torch.float32, device=self.device)
+        grads = torch.zeros(self.num_trainable, dtype=torch.float32, device=self.device)
+        self._bind_storage(arena, grads, 0, self.num_trainable, first=True)
         for s in self.specs:
             if s.bn:
                 _attach(self, s.bn + '.num_batches_tracked', torch.zeros((), dtype=torch.long, device=self.device), False)
-        # packed-weight arena and wgrad scratch arena + the layer table
+        # packed-weight arena and wgrad scratch arena
         poff = soff = 0
+        self._layer_offsets = []
+        for s in self.specs:
+            nw = s.taps * s.cin_pad * s.cout
+            L = dict(wf=poff); poff += al(nw)
+            if s.need_dgrad:
+                L['wb'] = poff; poff += al(nw)
+            else:
+                L['wb'] = -1
+            L['shift'] = poff; poff += al(s.cout)
+            L['scale'] = poff; poff += al(s.cout)
+            L['dwraw'] = soff; soff += al(nw)
+            L['dbias'] = soff; soff += al(s.cout)
+            self._layer_offsets.append(L)
+        self.register_buffer('_packed', torch.zeros(poff, dtype=torch.float32, device=self.device), persistent=False)
+        self.register_buffer('_scratch', torch.zeros(soff, dtype=torch.float32, device=self.device), persistent=False)
+        self.max_cout = max(s.cout for s in self.specs)
+        self._build_table()
+
+    def _bind_storage(self, arena, grads, param_off, stats_off, first=False):
+        """Point every parameter / running statistic (and every parameter's .grad) at `arena` / `grads`: trainable
+        tensors from element `param_off`, running statistics from `stats_off`; `grads` mirrors the arena's offsets over
+        the trainable range.  Current values are carried over."""
+        train, stats = self._arena_entries()
+        old = None if first else {n: self._tensor_by_name(n).detach().clone() for n, _ in train + stats}
+        self.offsets = {}
+        for n, _ in train:
+            self.offsets[n] = param_off + self.rel_offsets[n]
+        for n, _ in stats:
+            self.offsets[n] = stats_off + self.rel_offsets[n]
+        self._param_off, self._stats_off = param_off, stats_off
+        if first:
+            self.register_buffer('_arena', arena, persistent=False)
+            self.register_buffer('_grad_arena', grads, persistent=False)
+        else:
+            self._arena, self._grad_arena = arena, grads
+        self._grad_views = {}
+        # one persistent view object each (callers attach `.grad` to flat_params and hand it to an optimiser)
+        object.__setattr__(self, '_flat_params_view', arena[param_off:param_off + self.num_trainable])
+        object.__setattr__(self, '_flat_grads_view', grads[param_off:param_off + self.num_trainable])
+        with torch.no_grad():
+            for name, shape in train:
+                o, n = self.offsets[name], int(np.prod(shape))
+                view, gview = arena[o:o + n].view(shape), grads[o:o + n].view(shape)
+                if first:
+                    p = nn.Parameter(view)
+                    _attach(self, name, p, True)
+                else:
+                    view.copy_(old[name])
+                    p = self.get_parameter(name)
+                    p.data = view
+                p.grad = gview
+                self._grad_views[name] = (p, gview)
+            for name, shape in stats:
+                o, n = self.offsets[name], int(np.prod(shape))
+                view = arena[o:o + n].view(shape)
+                if first:
+                    _attach(self, name, view, False)
+                else:
+                    view.copy_(old[name])
+                    holder, leaf = name.rsplit('.', 1)
+                    setattr(self.get_submodule(holder), leaf, view)
+
+    def _tensor_by_name(self, name):
+        holder, leaf = name.rsplit('.', 1)
+        return getattr(self.get_submodule(holder), leaf)
+
+    def _build_table(self):
         table = (_hip.LayerDesc * len(self.specs))()
         for s in self.specs:
-            L = table[s.index]
-            nw = s.taps * s.cin_pad * s.cout
+            L, o = table[s.index], self._layer_offsets[s.index]
             L.w_off = self.offsets[s.name + '.weight']
             L.bias_off = self.offsets[s.name + '.bias'] if s.bias else -1
             if s.bn:
@@ -154,23 +225,28 @@ class ExtractFeat3D(nn.Module):
                 L.mean_off, L.var_off = self.offsets[s.bn + '.running_mean'], self.offsets[s.bn + '.running_var']
             else:
                 L.gamma_off = L.beta_off = L.mean_off = L.var_off = -1
-            al = lambda v: -(-v // _ALIGN) * _ALIGN
-            L.wf_off = poff; poff += al(nw)
-            if s.need_dgrad:
-                L.wb_off = poff; poff += al(nw)
-            else:
-                L.wb_off = -1
-            L.shift_off = poff; poff += al(s.cout)
-            L.scale_off = poff; poff += al(s.cout)
-            L.dwraw_off = soff; soff += al(nw)
-            L.dbias_off = soff; soff += al(s.cout)
+            L.wf_off, L.wb_off, L.shift_off, L.scale_off = o['wf'], o['wb'], o['shift'], o['scale']
+            L.dwraw_off, L.dbias_off = o['dwraw'], o['dbias']
             L.co, L.ci, L.ci_pad, L.taps, L.eps = s.cout, s.cin, s.cin_pad, s.taps, self.eps
         self._table_host = table
-        raw = np.frombuffer(bytes(table), dtype=np.uint8).copy()
-        self.register_buffer('_table', torch.from_numpy(raw).to(self.device), persistent=False)
-        self.register_buffer('_packed', torch.zeros(poff, dtype=torch.float32, device=self.device), persistent=False)
-        self.register_buffer('_scratch', torch.zeros(soff, dtype=torch.float32, device=self.device), persistent=False)
-        self.max_cout = max(s.cout for s in self.specs)
+        raw = torch.from_numpy(np.frombuffer(bytes(table), dtype=np.uint8).copy()).to(self.device)
+        if hasattr(self, '_table'):
+            self._table.copy_(raw)            # same address: plans built earlier stay valid as far as the table goes
+        else:
+            self.register_buffer('_table', raw, persistent=False)
+
+    def rehome(self, arena, grads, param_off, stats_off):
+        """Move the engine's parameters into a caller-owned flat arena (and gradient mirror) so that the WHOLE detector
+        -- backbone, neck and every head -- is one buffer and one all-reduce (mmdet/core/utils/dist_utils.py:22-28;
+        dist_utils.DetectorArena).  `arena` needs num_trainable floats at param_off and num_stats floats at stats_off
+        (both multiples of 64 floats); `grads` mirrors the trainable range.  Plans built before are dropped."""
+        assert arena.dtype == torch.float32 and grads.dtype == torch.float32 and arena.device == self._arena.device
+        assert param_off % _ALIGN == 0 and stats_off % _ALIGN == 0 and arena.data_ptr() % 256 == 0 and grads.data_ptr() % 256 == 0
+        assert arena.numel() >= max(param_off + self.num_trainable, stats_off + self.num_stats)
+        assert grads.numel() >= param_off + self.num_trainable
+        self._bind_storage(arena, grads, param_off, stats_off)
+        self._build_table()
+        self._plans = {}
 
     # ------------------------------------------------------------------ parameters
     def init_weights(self, pretrained=None):
@@ -201,14 +277,28 @@ class ExtractFeat3D(nn.Module):
 
     @property
     def flat_params(self):
-        return self._arena
+        """the TRAINABLE range of the arena (no BN running statistics): what an optimiser may step"""
+        return self._flat_params_view
 
     @property
     def flat_grads(self):
-        return self._grad_arena
+        return self._flat_grads_view
 
     def zero_grad(self, set_to_none=False):
-        self._grad_arena.zero_()
+        """gradients live in the arena for good: they are zeroed in place, never detached (set_to_none is ignored)"""
+        self.flat_grads.zero_()
+        self._relink_grads()
+
+    def _relink_grads(self):
+        """`optimizer.zero_grad()` / `nn.Module.zero_grad()` of a parent default to set_to_none=True on torch 2.x, which
+        would orphan every parameter from the gradient arena (the engine does not hand gradients to autograd).  Returns
+        True when some parameter had lost its view -- the caller then treats the arena as freshly zeroed."""
+        lost = False
+        for p, gview in self._grad_views.values():
+            if p.grad is None or p.grad.data_ptr() != gview.data_ptr():
+                p.grad = gview
+                lost = True
+        return lost
 
     # ------------------------------------------------------------------ plan construction
     def _w(self, spec, kind):
@@ -474,6 +564,10 @@ class ExtractFeat3D(nn.Module):
             raise RuntimeError('the input volume bound to this plan was modified in place between forward and backward '
                                '(the stem weight gradient reads it)')
         self.bind_grads(P, grads)
+        if self._relink_grads():
+            # someone set the parameters' .grad to None (torch's zero_grad default): that means "zero", and the arena
+            # must not keep the previous step's sums
+            self.flat_grads.zero_()
         with torch.cuda.device(self.device):
             P.bwd.run(self.device)
 

@@ -36,29 +36,88 @@ def broadcast_params(flat, src=0, group=None):
     return flat
 
 
+def _keep_grad_in_arena(p, gview):
+    """torch's zero_grad (set_to_none=True by default on 2.x) detaches a parameter from its arena slot and autograd then
+    allocates a fresh gradient.  This hook moves such a gradient back: `None` meant zero, so the slot is overwritten."""
+    def hook(param):
+        if param.grad is not None and param.grad.data_ptr() != gview.data_ptr():
+            gview.copy_(param.grad)
+            param.grad = gview
+    p.register_post_accumulate_grad_hook(hook)
+
+
 class FlatArena:
     """Re-homes the parameters (and their .grad) of arbitrary nn.Modules into two persistent flat fp32
-    buffers, so that heads written in plain PyTorch join the same single all-reduce as the conv engine."""
+    buffers, so that heads written in plain PyTorch join the same single all-reduce as the conv engine.
+    storage = (flat_params, flat_grads, offset): use a slice of caller-owned buffers instead of allocating."""
 
-    def __init__(self, params):
+    def __init__(self, params, storage=None):
         params = [p for p in params if p.requires_grad]
         assert params, 'no trainable parameters'
         dev = params[0].device
         n = sum(p.numel() for p in params)
-        self.flat_params = torch.empty(n, dtype=torch.float32, device=dev)
-        self.flat_grads = torch.zeros(n, dtype=torch.float32, device=dev)
+        if storage is None:
+            self.flat_params = torch.empty(n, dtype=torch.float32, device=dev)
+            self.flat_grads = torch.zeros(n, dtype=torch.float32, device=dev)
+        else:
+            fp, fg, at = storage
+            self.flat_params, self.flat_grads = fp[at:at + n], fg[at:at + n]
         off = 0
         with torch.no_grad():
             for p in params:
                 k = p.numel()
                 self.flat_params[off:off + k].copy_(p.detach().reshape(-1))
                 p.data = self.flat_params[off:off + k].view(p.shape)
-                p.grad = self.flat_grads[off:off + k].view(p.shape)
+                gview = self.flat_grads[off:off + k].view(p.shape)
+                p.grad = gview
+                _keep_grad_in_arena(p, gview)
                 off += k
         self.params = params
+        self.numel = n
 
     def zero_grad(self):
         self.flat_grads.zero_()
+        for p in self.params:
+            if p.grad is None:
+                off = p.data.storage_offset() - self.flat_params.storage_offset()
+                p.grad = self.flat_grads[off:off + p.numel()].view(p.shape)
+
+
+class DetectorArena:
+    """ONE flat fp32 buffer for the whole detector -- conv engine (backbone + neck) first, then every head -- and one
+    mirror buffer for its gradients: the single ~26 M-element message of the reference's `_allreduce_coalesced`
+    (mmdet/core/utils/dist_utils.py:22-28; 103.9 MB for the shipped model) without its per-iteration flatten and
+    copy-back.  Layout: [engine trainables | head parameters | engine BN running statistics]; `flat_params` /
+    `flat_grads` are the trainable prefix (what the optimiser steps and the all-reduce exchanges), so weight decay and
+    momentum never reach the frozen BN statistics."""
+
+    def __init__(self, detector, engine_attr='extract'):
+        eng = getattr(detector, engine_attr, None) if engine_attr else None
+        prefix = (engine_attr + '.') if eng is not None else '\0'
+        heads = [p for n, p in detector.named_parameters() if not n.startswith(prefix) and p.requires_grad]
+        n_heads = -(-sum(p.numel() for p in heads) // 64) * 64
+        n_eng, n_stats = (eng.num_trainable, eng.num_stats) if eng is not None else (0, 0)
+        n_train = n_eng + n_heads
+        dev = eng.flat_params.device if eng is not None else heads[0].device
+        self.storage = torch.zeros(n_train + n_stats, dtype=torch.float32, device=dev)
+        self.grad_storage = torch.zeros(n_train, dtype=torch.float32, device=dev)
+        if eng is not None:
+            eng.rehome(self.storage, self.grad_storage, 0, n_train)
+        self.heads = FlatArena(heads, storage=(self.storage, self.grad_storage, n_eng)) if heads else None
+        self.flat_params = self.storage[:n_train]
+        self.flat_grads = self.grad_storage
+        self.flat_params.grad = self.flat_grads          # an optimiser over [flat_params] steps the whole detector
+        self.engine = eng
+
+    def zero_grad(self):
+        self.flat_grads.zero_()
+        if self.engine is not None:
+            self.engine._relink_grads()
+        if self.heads is not None:
+            self.heads.zero_grad()
+
+    def allreduce(self, world_size=None, group=None):
+        return allreduce_flat_grads(self.flat_grads, world_size, group)
 
 
 def _allreduce_coalesced(tensors, world_size, bucket_size_mb=-1, group=None):
@@ -131,22 +190,41 @@ def clip_grad_norm_flat(flat_grads_list, max_norm, norm_type=2):
 
 class DistOptimizerStep:
     """`DistOptimizerHook.after_train_iter` (dist_utils.py:44-57) as a callable:
-    zero_grad -> loss.backward() -> allreduce_grads -> clip -> optimizer.step()."""
+    zero_grad -> loss.backward() -> allreduce_grads -> clip -> optimizer.step().
+    Gradients that live in a flat arena (the conv engine's, FlatArena's, DetectorArena's) are zeroed IN PLACE and stay
+    attached to their parameters -- `optimizer.zero_grad()` with torch 2.x's set_to_none=True default would orphan
+    them from the buffer the all-reduce, the clip and the optimiser read."""
 
     def __init__(self, model, optimizer, grad_clip=None, coalesce=True, bucket_size_mb=-1):
         self.model, self.optimizer, self.grad_clip = model, optimizer, grad_clip
         self.coalesce, self.bucket_size_mb = coalesce, bucket_size_mb
 
     def __call__(self, loss):
-        self.optimizer.zero_grad()
+        self.optimizer.zero_grad(set_to_none=False)
         for m in self.model.modules():
-            if hasattr(m, 'flat_grads') and m is not self.model:
+            if hasattr(m, 'flat_grads'):
                 m.zero_grad()
-        if hasattr(self.model, 'flat_grads'):
-            self.model.zero_grad()
         loss.backward()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             allreduce_grads(self.model, self.coalesce, self.bucket_size_mb)
         if self.grad_clip is not None:
             torch.nn.utils.clip_grad_norm_([p for p in self.model.parameters() if p.requires_grad], **self.grad_clip)
         self.optimizer.step()
+
+
+def train_step(detector, arena, optimizer, batch, world_size=1, grad_clip=35.0, group=None):
+    """One iteration of the reference's hot loop (mmdet/apis/train.py:37-48 batch_processor + dist_utils.py:51-57):
+    zero -> forward_train -> sum of the losses -> backward -> ONE all-reduce of the detector's gradient arena -> L2 clip
+    (configs/...py:236) -> optimizer.step().  `batch` = (args, kwargs) of detector.forward_train.  Returns
+    (total loss, loss dict) as device tensors: nothing is synchronised here."""
+    arena.zero_grad()
+    args, kwargs = batch
+    losses = detector.forward_train(*args, **kwargs)
+    total = detector.total_loss(losses)
+    total.backward()
+    if world_size > 1:
+        arena.allreduce(world_size, group)
+    if grad_clip is not None:
+        clip_grad_norm_flat([arena.flat_grads], grad_clip)
+    optimizer.step()
+    return total, losses

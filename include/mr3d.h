@@ -71,6 +71,19 @@ int mr3d_nms3d_batched(const float *dets, const int *seg_rows_host, int num_segm
                        int64_t *keep_out, int32_t *num_keep_out, void *workspace, size_t workspace_bytes,
                        mr3d_stream_t stream);
 
+/* multiclass_nms_3d (mmdet/core/post_processing/bbox_nms.py:57-106) as ONE device op: per foreground class c = 1..C-1
+ * keep rows with multi_scores[r][c] > score_thr, NMS3D them (boxes multi_bboxes[r][6c..6c+5], or [0..5] when
+ * box_cols == 6), label c-1, concatenate the classes (each in ascending row order, as nms() returns them) and, if more
+ * than max_num survive, keep the max_num best by score (ties: earlier position first; torch.sort leaves them
+ * unspecified).  max_num < 0 reproduces the reference's `inds[:max_num]` slice on an always-true test (:96-98).
+ * multi_bboxes [n, box_cols], multi_scores [n, num_classes] fp32 contiguous; dets_out [(C-1)*n, 7] (or max_num rows if
+ * smaller and >= 0), labels_out int64 same rows; count_out device int32[1].  n <= 4096, C-1 <= 16.
+ * workspace: mr3d_multiclass_nms3d_workspace_bytes(n, num_classes) bytes, 256-byte aligned. */
+size_t mr3d_multiclass_nms3d_workspace_bytes(int n, int num_classes);
+int mr3d_multiclass_nms3d(const float *multi_bboxes, int box_cols, const float *multi_scores, int n, int num_classes,
+                          float score_thr, float iou_thr, int max_num, float *dets_out, long long *labels_out,
+                          int *count_out, void *workspace, size_t workspace_bytes, mr3d_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * RoIAlign3D forward -- replaces roi_align_cuda.forward3d(features, rois, pooled_depth,
  *   pooled_height, pooled_width, spatial_scale, spatial_scale_depth, sample_num, output)

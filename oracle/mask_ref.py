@@ -49,7 +49,9 @@ def mask_target(gt_masks, boxes, gt_inds, md, mh, mw):
             continue
         crop = (gt_masks[gt_inds[p], za:za + d, ya:ya + h, xa:xa + w] > 0)
         v = _resample(crop, (md, mh, mw))
-        out[p] = (np.floor(np.float32(255) * v) > 0).astype(np.float32)
+        # uint8 0/1 crop -> img_as_float (x/255) -> resize -> *255 -> astype(uint8) -> > 0  ==  floor(coverage) > 0
+        # (mask_target.py:41-44): only full coverage survives; 2^-16 of slack for the rounding of the lerps
+        out[p] = (v >= np.float32(1.0 - 2.0 ** -16)).astype(np.float32)
     return out
 
 

@@ -91,3 +91,101 @@ def test_clip_grad_norm_flat_matches_torch():
     n_ref = torch.nn.utils.clip_grad_norm_([pa, pb], max_norm=35, norm_type=2)
     n = clip_grad_norm_flat([a, b], 35)
     assert torch.allclose(n, n_ref) and torch.allclose(a, pa.grad, atol=1e-6) and torch.allclose(b, pb.grad, atol=1e-6)
+
+
+class _StubDetector(torch.nn.Module):
+    """CPU stand-in with the detector's training interface (forward_train -> loss dict, total_loss)"""
+
+    def __init__(self):
+        super().__init__()
+        self.backbone = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 8))
+        self.rpn_head = torch.nn.Linear(8, 1)
+        self.bbox_head = torch.nn.Linear(8, 6)
+
+    def forward_train(self, x, cls_t, reg_t):
+        f = self.backbone(x)
+        return dict(loss_rpn_cls=[torch.nn.functional.binary_cross_entropy_with_logits(self.rpn_head(f), cls_t)],
+                    loss_reg=torch.nn.functional.smooth_l1_loss(self.bbox_head(f), reg_t), acc=torch.tensor(50.0))
+
+    @staticmethod
+    def total_loss(losses):
+        from mr3d_amd.detector.two_stage import TwoStageDetector3D
+        return TwoStageDetector3D.total_loss(losses)
+
+
+def _train_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import mr3d_amd
+        from mr3d_amd.dist_utils import DetectorArena, broadcast_params, train_step
+        torch.manual_seed(7 + rank)                      # different initial weights per rank until the broadcast
+        det = _StubDetector()
+        arena = DetectorArena(det, engine_attr=None)
+        broadcast_params(arena.flat_params)
+        opt = torch.optim.SGD([arena.flat_params], lr=0.05, momentum=0.9, weight_decay=1e-4)
+        one_storage = all(p.data.untyped_storage().data_ptr() == arena.storage.untyped_storage().data_ptr() and
+                          p.grad.untyped_storage().data_ptr() == arena.grad_storage.untyped_storage().data_ptr()
+                          for p in det.parameters())
+        gen = torch.Generator().manual_seed(1000 + rank)  # every rank sees its own samples (DistributedSampler)
+        w_start = arena.flat_params.clone()
+        local_grads = []
+        for it in range(3):
+            x = torch.randn(5, 6, generator=gen)
+            batch = ((x, (torch.rand(5, 1, generator=gen) > 0.5).float(), torch.randn(5, 6, generator=gen)), {})
+            if it == 1:
+                det.zero_grad()                          # torch's set_to_none=True default: grads must find their way back
+            total, losses = train_step(det, arena, opt, batch, world, grad_clip=35.0)
+            local_grads.append(arena.flat_grads.clone())
+        still_views = all(p.grad is not None and p.grad.untyped_storage().data_ptr() == arena.grad_storage.untyped_storage().data_ptr()
+                          for p in det.parameters())
+        ws = [torch.empty_like(arena.flat_params) for _ in range(world)]
+        dist.all_gather(ws, arena.flat_params)
+        same = all(torch.equal(ws[0], w) for w in ws)
+        moved = not torch.equal(arena.flat_params, w_start)
+        gs = [torch.empty_like(local_grads[-1]) for _ in range(world)]
+        dist.all_gather(gs, local_grads[-1])
+        same_g = all(torch.equal(gs[0], g) for g in gs)        # after the exchange every rank holds the same mean gradient
+        q.put((rank, one_storage, still_views, same, moved, same_g, bool(torch.isfinite(total))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_train_step_world2_identical_parameters():
+    """drive the training step (zero -> forward_train -> backward -> ONE arena all-reduce -> clip -> SGD) on
+    two gloo ranks with different data; after 3 steps both ranks hold bit-identical parameters."""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in res:
+        assert all(r[1:]), r
+
+
+def test_dist_optimizer_step_keeps_arena_grads_attached():
+    """DistOptimizerStep must not orphan arena-backed gradients (torch 2.x zero_grad sets them to None)."""
+    from mr3d_amd.dist_utils import DistOptimizerStep, FlatArena
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.ReLU(), torch.nn.Linear(3, 2))
+    arena = FlatArena(model.parameters())
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    step = DistOptimizerStep(model, opt, grad_clip=dict(max_norm=35, norm_type=2))
+    w0 = arena.flat_params.clone()
+    for _ in range(2):
+        step(model(torch.randn(8, 4)).pow(2).sum())
+    assert not torch.equal(arena.flat_params, w0)
+    base = arena.flat_grads.untyped_storage().data_ptr()
+    assert all(p.grad is not None and p.grad.untyped_storage().data_ptr() == base for p in model.parameters())
+    # and the plain torch idiom (set_to_none=True) finds its way back into the arena through the hook
+    opt.zero_grad()
+    model(torch.randn(8, 4)).pow(2).sum().backward()
+    assert all(p.grad.untyped_storage().data_ptr() == base for p in model.parameters())
+    assert arena.flat_grads.abs().sum() > 0

@@ -163,3 +163,48 @@ def test_multiclass_nms_3d_vs_restatement(dev):
     e_b, e_l = multiclass_nms_3d(torch.from_numpy(b).to(dev), torch.from_numpy(scores * 0).to(dev), 0.2,
                                  dict(type='nms', iou_thr=0.5), 200)
     assert e_b.shape == (0, 7) and e_l.shape == (0,)
+
+
+def _ref_multiclass(b_cols, scores, thr, iou_thr, max_num):
+    """bbox_nms.py:57-106 restated with the NMS3D oracle: per class filter -> nms -> concat -> optional top-k"""
+    n, C = scores.shape
+    dets_all, labels_all = [], []
+    for c in range(1, C):
+        sel = scores[:, c] > thr
+        if not sel.any():
+            continue
+        bx = b_cols[sel, :6] if b_cols.shape[1] == 6 else b_cols[sel, 6 * c:6 * c + 6]
+        dets = np.concatenate([bx, scores[sel, c:c + 1]], 1).astype(np.float32)
+        kept = dets[orc.nms3d(dets, iou_thr)]
+        dets_all.append(kept); labels_all.append(np.full(len(kept), c - 1, np.int64))
+    if not dets_all:
+        return np.zeros((0, 7), np.float32), np.zeros((0,), np.int64)
+    d, l = np.concatenate(dets_all), np.concatenate(labels_all)
+    if d.shape[0] > max_num:
+        order = np.argsort(-d[:, 6], kind='stable')
+        order = order[:max_num]                      # max_num = -1: drops the last row, like the reference's slice
+        d, l = d[order], l[order]
+    return d, l
+
+
+@pytest.mark.parametrize('max_num', [10000, 150, -1])
+@pytest.mark.parametrize('shared_boxes', [False, True])
+def test_multiclass_nms_3d_several_classes(dev, max_num, shared_boxes):
+    from mr3d_amd.core import multiclass_nms_3d
+    rng = np.random.default_rng(9)
+    n, C = 700, 4
+    ctr = rng.uniform([10, 10, 4], [200, 200, 50], (30, 3))[rng.integers(0, 30, n)] + rng.normal(0, 2, (n, 3))
+    half = rng.uniform([4, 4, 2], [14, 14, 6], (n, 3))
+    b = np.stack([ctr[:, 0] - half[:, 0], ctr[:, 1] - half[:, 1], ctr[:, 0] + half[:, 0], ctr[:, 1] + half[:, 1],
+                  ctr[:, 2] - half[:, 2], ctr[:, 2] + half[:, 2]], 1).astype(np.float32)
+    cols = b if shared_boxes else np.concatenate([b + 500 * c + rng.normal(0, 1, b.shape).astype(np.float32) * (c > 0)
+                                                  for c in range(C)], 1).astype(np.float32)
+    scores = rng.permutation(n * C).reshape(n, C).astype(np.float32) / (n * C)          # distinct scores
+    scores[:, 3] *= 0.1                                                                  # class 3: nothing above threshold
+    got_b, got_l = multiclass_nms_3d(torch.from_numpy(cols).to(dev), torch.from_numpy(scores).to(dev), 0.3,
+                                     dict(type='nms', iou_thr=0.5), max_num)
+    exp_b, exp_l = _ref_multiclass(cols, scores, 0.3, 0.5, max_num)
+    np.testing.assert_array_equal(got_b.cpu().numpy(), exp_b)
+    np.testing.assert_array_equal(got_l.cpu().numpy(), exp_l)
+    with pytest.raises(NotImplementedError):
+        multiclass_nms_3d(torch.from_numpy(cols).to(dev), torch.from_numpy(scores).to(dev), 0.3, dict(type='soft_nms', iou_thr=0.5), 10)

@@ -41,7 +41,7 @@ def test_restatement_invariants():
     xa, ya, za, w, h, d = mask_ref._crop(boxes[5], gt.shape[3], gt.shape[2], gt.shape[1])
     crop = gt[gi[5], za:za + d, ya:ya + h, xa:xa + w].astype(np.float32)
     z = zoom(crop, (20 / d, 28 / h, 28 / w), order=1, mode='nearest', grid_mode=True)
-    agree = ((z > 0.004) == (t[5] > 0)).mean()
+    agree = ((z >= 1 - 1e-4) == (t[5] > 0)).mean()        # the reference's rule keeps full-coverage voxels only
     assert agree > 0.9
 
 
@@ -56,7 +56,7 @@ def test_mask_target_and_paste_gpu_vs_restatement():
     got = mask_target_single(torch.from_numpy(boxes7).to(dev), torch.from_numpy(gi).to(dev), torch.from_numpy(gt), cfg)
     exp = mask_ref.mask_target(gt, boxes, gi, 20, 28, 28)
     mism = (got.cpu().numpy() != exp).mean()
-    assert mism < 1e-4, mism                       # binarisation at floor(255 v) > 0: fp32 FMA contraction can flip a voxel
+    assert mism < 1e-4, mism                       # binarisation at coverage >= 1 - 2^-16: fp32 FMA contraction can flip a voxel
     both = mask_target([torch.from_numpy(boxes[:7]).to(dev), torch.from_numpy(boxes[7:]).to(dev)],
                        [torch.from_numpy(gi[:7]).to(dev), torch.from_numpy(gi[7:]).to(dev)],
                        [torch.from_numpy(gt), torch.from_numpy(gt)], cfg)

@@ -6,8 +6,10 @@ reduced to its hot loop: forward_train -> sum of losses -> backward -> gradient 
     python tools/train_synthetic.py --iters 20 --vol 32,128,128
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 tools/train_synthetic.py --iters 50
 
-All parameters live in TWO flat fp32 arenas (backbone+neck inside the engine, every head through FlatArena), so the
-exchange is two in-place RCCL all-reduces per iteration and the optimizer steps two tensors."""
+All parameters of the detector live in ONE flat fp32 arena (dist_utils.DetectorArena: backbone + neck + every head;
+BN running statistics behind the trainable range), so the exchange is ONE in-place RCCL all-reduce per iteration --
+the reference's single coalesced buffer (mmdet/core/utils/dist_utils.py:22-28) without its flatten / copy-back -- and
+the optimizer steps one tensor."""
 import argparse
 import os
 import sys
@@ -21,7 +23,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mr3d_amd  # noqa: E402
 from mr3d_amd.datasets import prepare_volume  # noqa: E402
 from mr3d_amd.detector import TwoStageDetector3D2Scales  # noqa: E402
-from mr3d_amd.dist_utils import FlatArena, allreduce_flat_grads, broadcast_params, clip_grad_norm_flat  # noqa: E402
+from mr3d_amd.dist_utils import DetectorArena, broadcast_params, train_step  # noqa: E402
 
 
 def synthetic_sample(rng, D, H, W, dev, n_gt=6):
@@ -44,7 +46,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--vol', default='32,128,128', help='D,H,W of the region (the reference trains on 128x128 crops)')
-    ap.add_argument('--lr', type=float, default=0.02)           # configs/...py:233 (SGD lr 0.02, momentum 0.9, wd 1e-4)
+    ap.add_argument('--lr', type=float, default=0.001)          # configs/...py:235 (SGD lr 0.001, momentum 0.9, wd 1e-4)
     a = ap.parse_args()
     D, H, W = (int(v) for v in a.vol.split(','))
     rank, local, world = (int(os.environ.get(k, d)) for k, d in (('RANK', 0), ('LOCAL_RANK', 0), ('WORLD_SIZE', 1)))
@@ -56,26 +58,15 @@ def main():
     torch.manual_seed(0)
     det = TwoStageDetector3D2Scales(device=dev)
     det.extract.init_weights()
-    heads = FlatArena([p for n, p in det.named_parameters() if not n.startswith('extract.')])
-    arenas = [(det.extract.flat_params, det.extract.flat_grads), (heads.flat_params, heads.flat_grads)]
-    for fp, fg in arenas:
-        broadcast_params(fp)                                     # identical initial weights (mmcv DDP init)
-        fp.grad = fg
-    opt = torch.optim.SGD([fp for fp, _ in arenas], lr=a.lr, momentum=0.9, weight_decay=1e-4)
+    arena = DetectorArena(det)
+    broadcast_params(arena.flat_params)                          # identical initial weights (mmcv DDP init)
+    opt = torch.optim.SGD([arena.flat_params], lr=a.lr, momentum=0.9, weight_decay=1e-4)
     rng = np.random.default_rng(100 + rank)                      # every rank draws its own volumes (DistributedSampler)
     t0 = time.perf_counter()
     for it in range(a.iters):
         img, meta, img_2, meta_2, gt, gl, masks = synthetic_sample(rng, D, H, W, dev)
-        for _, fg in arenas:
-            fg.zero_()
-        losses = det.forward_train(img, [meta], img_2, [meta_2], [gt], [gt * 1.5], [gl], [gl], gt_masks=[masks])
-        total = det.total_loss(losses)
-        total.backward()
-        if world > 1:
-            for _, fg in arenas:
-                allreduce_flat_grads(fg, world)                  # dist_utils.py:24-25: SUM, then / world
-        clip_grad_norm_flat([fg for _, fg in arenas], 35.0)      # configs/...py:236
-        opt.step()
+        batch = ((img, [meta], img_2, [meta_2], [gt], [gt * 1.5], [gl], [gl]), dict(gt_masks=[masks]))
+        total, losses = train_step(det, arena, opt, batch, world, grad_clip=35.0)
         if rank == 0 and (it % 5 == 0 or it == a.iters - 1):
             print(f'iter {it:4d}  loss {total.item():8.4f}  ' +
                   '  '.join(f'{k} {float(sum(t.sum() for t in v) if isinstance(v, list) else v.sum()):.4f}'
