@@ -474,6 +474,24 @@ class Plan:
         return ev
 
 
+class Conv3dVariant(ctypes.Structure):
+    """mr3d_conv3d_variant (include/mr3d.h)"""
+    _fields_ = [(n, ctypes.c_int) for n in ('streaming_pointwise', 'winograd', 'tile_d', 'tile_h', 'tile_w', 'cin_chunk',
+                                            'cout_tile', 'parity_decomposed')] + [('mfma_issue_factor', ctypes.c_float)]
+
+
+def op_conv_variant(op):
+    """the kernel instance a CONV_FWD plan record dispatches to (mr3d_conv3d_forward_variant; nothing is launched)"""
+    assert op.kind == OP_CONV_FWD
+    d = Conv3dDesc()
+    for k, name in enumerate(('x', 'w', 'y', 'shift', 'add1', 'add2', 'up', 'mask')):
+        setattr(d, name, op.p[k])
+    ctypes.memmove(ctypes.addressof(d) + Conv3dDesc.n.offset, ctypes.addressof(op.i), 25 * 4)
+    v = Conv3dVariant()
+    check(lib().mr3d_conv3d_forward_variant(ctypes.byref(d), ctypes.byref(v)), 'mr3d_conv3d_forward_variant')
+    return v
+
+
 def _narrow_nb(n, do, ho, wo, cout, nb):
     """mirror of narrow_nb() in csrc/conv3d_fwd.hip: the Cout tile the forward/dgrad dispatch really picks"""
     def wgs(nb_):

@@ -46,5 +46,5 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 // streaming pointwise instances (pointwise.hip); MR3D_ERR_UNSUPPORTED = use the generic kernels
-int mr3d_pointwise_fwd_try(const Conv3dFwdArgs &a, hipStream_t stream);
+int mr3d_pointwise_fwd_try(const Conv3dFwdArgs &a, hipStream_t stream, bool probe_only = false);
 int mr3d_pointwise_wgrad_try(const Conv3dWgradArgs &a, hipStream_t stream);

@@ -398,8 +398,20 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_fwd_kernel(Conv3dFw
 }
 
 
+// mr3d_conv3d_forward_variant: the dispatch below runs unchanged but records the instance it would launch
+thread_local mr3d_conv3d_variant *g_variant_probe = nullptr;
+
 template <class C>
 int launch_fwd(const Conv3dFwdArgs &a, hipStream_t stream) {
+  if (g_variant_probe) {
+    mr3d_conv3d_variant &v = *g_variant_probe;
+    v.streaming_pointwise = 0;
+    v.winograd = C::WINO; v.tile_d = C::TD; v.tile_h = C::TH; v.tile_w = C::TW; v.cin_chunk = C::CC; v.cout_tile = C::NB;
+    v.parity_decomposed = C::PAR ? 1 : 0;
+    // MFMA work issued per algorithmic FLOP: F(2,3) 4 products per 2 outputs x 3 taps, F(4,3) 6 per 4 x 3
+    v.mfma_issue_factor = C::WINO == 4 ? 0.5f : (C::WINO == 2 ? 2.f / 3.f : 1.f);
+    return MR3D_OK;
+  }
   const int tiles_d = (a.Do + C::TD - 1) / C::TD, tiles_h = (a.Ho + C::TH - 1) / C::TH, tiles_w = (a.Wo + C::TW - 1) / C::TW;
   static bool attr_done = false;   // LDS above 64 KiB needs the opt-in attribute (one CU has 160 KiB)
   if (!attr_done && C::LDS_BYTES > 64 * 1024) {
@@ -555,8 +567,15 @@ extern "C" int mr3d_conv3d_forward(const mr3d_conv3d_desc *d, mr3d_stream_t stre
   const int k = d->kd, s = d->sd * 100 + d->sh * 10 + d->sw;
   if (k == 1 && s == 111) {
     if (a.pd == 0 && a.ph == 0 && a.pw == 0) {
-      const int st = mr3d_pointwise_fwd_try(a, stream);
-      if (st != MR3D_ERR_UNSUPPORTED) return st;
+      const int st = mr3d_pointwise_fwd_try(a, g_variant_probe ? nullptr : stream, g_variant_probe != nullptr);
+      if (st != MR3D_ERR_UNSUPPORTED) {
+        if (g_variant_probe && st == MR3D_OK) {
+          *g_variant_probe = mr3d_conv3d_variant{};
+          g_variant_probe->streaming_pointwise = 1; g_variant_probe->mfma_issue_factor = 1.f;
+          g_variant_probe->cin_chunk = a.Cin; g_variant_probe->cout_tile = a.Cout;
+        }
+        return st;
+      }
     }
     if (a.Cin % 64 == 0) return dispatch_nb<1, 1, 1, 1, 64>(a, nb, stream);
     if (a.Cin % 32 == 0) return dispatch_nb<1, 1, 1, 1, 32>(a, nb, stream);
@@ -614,4 +633,19 @@ extern "C" int mr3d_conv3d_dgrad_s2k3(const mr3d_conv3d_desc *d, mr3d_stream_t s
     case 64: return dispatch_par<64>(a, stream);
   }
   return MR3D_ERR_UNSUPPORTED;
+}
+
+extern "C" int mr3d_conv3d_forward_variant(const mr3d_conv3d_desc *d, mr3d_conv3d_variant *out) {
+  if (!d || !out) return MR3D_ERR_INVALID_ARG;
+  *out = mr3d_conv3d_variant{};
+  mr3d_conv3d_desc probe = *d;
+  // the dispatch only looks at shapes; give it non-null operands so that the argument checks pass
+  static float dummy;
+  if (!probe.x) probe.x = &dummy;
+  if (!probe.w) probe.w = &dummy;
+  if (!probe.y) probe.y = &dummy;
+  g_variant_probe = out;
+  const int st = mr3d_conv3d_forward(&probe, nullptr);
+  g_variant_probe = nullptr;
+  return st;
 }

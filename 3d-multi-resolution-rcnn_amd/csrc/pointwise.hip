@@ -493,13 +493,20 @@ int launch_pw_wgrad(const Conv3dWgradArgs &a, hipStream_t stream) {
 
 // Returns MR3D_ERR_UNSUPPORTED when the shape is not one of the streaming instances: the caller then uses
 // the generic halo-tile kernels of conv3d_fwd.hip / conv3d_wgrad.hip.
-int mr3d_pointwise_fwd_try(const Conv3dFwdArgs &a, hipStream_t stream) {
+int mr3d_pointwise_fwd_try(const Conv3dFwdArgs &a, hipStream_t stream, bool probe_only) {
   const bool scatter = a.ysd != 1 || a.ysh != 1 || a.ysw != 1 || a.yD != a.Do || a.yH != a.Ho || a.yW != a.Wo;
   if (scatter && (a.add1 || a.add2 || a.mask || a.up)) return MR3D_ERR_UNSUPPORTED;   // residual streams index like y: generic path
   if (a.D != a.Do || a.H != a.Ho || a.W != a.Wo) return MR3D_ERR_UNSUPPORTED;      // stride 1, no padding
   const long long rows = (long long)a.N * a.Do * a.Ho * a.Wo;
   if (rows < 32768 || rows > 0x7fffffffLL) return MR3D_ERR_UNSUPPORTED;             // small maps: not HBM-bound
   const int key = a.Cin * 1000 + a.Cout;
+  if (probe_only) {          // would a streaming instance take this shape? (mr3d_conv3d_forward_variant)
+    switch (key) {
+      case 16016: case 16064: case 64016: case 64032: case 32064: case 64064: case 32128: case 128032: case 64128: case 128064:
+        return MR3D_OK;
+    }
+    return MR3D_ERR_UNSUPPORTED;
+  }
   switch (key) {
     case 16016: return launch_pw_fwd<16, 16>(a, stream);
     case 16064: return launch_pw_fwd<16, 64>(a, stream);

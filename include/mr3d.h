@@ -158,6 +158,19 @@ typedef struct {
 } mr3d_conv3d_desc;
 int mr3d_conv3d_forward(const mr3d_conv3d_desc *desc, mr3d_stream_t stream);
 
+/* Which kernel instance mr3d_conv3d_forward would launch for `desc` (nothing is launched; pointers may be NULL):
+ * the measurement harness prices a launch with it -- a Winograd instance issues only `mfma_issue_factor` of the
+ * convolution's algorithmic FLOPs (2*MAC) as MFMA work. */
+typedef struct {
+  int streaming_pointwise;      /* 1: the HBM-bound 1x1x1 streaming kernel (csrc/pointwise.hip) */
+  int winograd;                 /* 0 direct, 2 = F(2,3) along W, 4 = F(4,3) along W */
+  int tile_d, tile_h, tile_w;   /* output positions per workgroup */
+  int cin_chunk, cout_tile;
+  int parity_decomposed;
+  float mfma_issue_factor;      /* MFMA FLOPs issued / algorithmic FLOPs: 1, 2/3 or 1/2 */
+} mr3d_conv3d_variant;
+int mr3d_conv3d_forward_variant(const mr3d_conv3d_desc *desc, mr3d_conv3d_variant *out);
+
 /* Data gradient of a kernel-3 / stride-2 / pad-1 convolution (resnet3d.py:139, the strided conv2 of the first
  * bottleneck of layer2-4) WITHOUT zero-stuffing: the 8 output parity classes are computed from the coarse dy with the
  * 1..8 taps each of them meets.  Same descriptor: x = dy [n,d,h,w_in,cin] (cin = the forward conv's Cout), w = the

@@ -138,3 +138,7 @@ def conv3d(x, w, bias, stride, padding):
 
 def num_threads():
     return int(lib().oracle_num_threads())
+
+
+def set_num_threads(n):
+    lib().oracle_set_num_threads(ctypes.c_int(int(n)))

@@ -337,6 +337,14 @@ void oracle_conv3d(const float *x, const float *w, const float *bias, int N, int
           }
 }
 
+void oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+  omp_set_num_threads(n > 0 ? n : 1);
+#else
+  (void)n;
+#endif
+}
+
 int oracle_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

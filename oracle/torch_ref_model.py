@@ -10,7 +10,32 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+class _MaskedReLU(torch.autograd.Function):
+    """ReLU linearised at a GIVEN activation pattern: y = x * mask, dx = g * mask.  Used by the parity tests to evaluate
+    the fp64 restatement at the engine's own ReLU pattern: an fp32 pre-activation within rounding of 0 may land on either
+    side, and a flipped mask routes a whole gradient contribution differently -- that is a property of the point the
+    function is evaluated at, not an arithmetic error of the backward pass."""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        ctx.save_for_backward(mask)
+        return x * mask
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        return g * mask, None
+
+
+def _relu(x, pattern, key):
+    if pattern is None:
+        return F.relu(x)
+    return _MaskedReLU.apply(x, pattern[key].to(x.dtype))
+
+
 class Bottleneck(nn.Module):
+    pattern, key = None, ''          # optional activation pattern (see _MaskedReLU), set by RefExtractFeat.linearize_at
+
     def __init__(self, inplanes, planes, stride, downsample):
         super().__init__()
         self.conv1 = nn.Conv3d(inplanes, planes, 1, bias=False)
@@ -23,15 +48,17 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         idn = x
-        out = F.relu(self.bn3d1(self.conv1(x)))
-        out = F.relu(self.bn3d2(self.conv2(out)))
+        out = _relu(self.bn3d1(self.conv1(x)), self.pattern, self.key + '.relu1')
+        out = _relu(self.bn3d2(self.conv2(out)), self.pattern, self.key + '.relu2')
         out = self.bn3d3(self.conv3(out))
         if self.downsample is not None:
             idn = self.downsample(x)
-        return F.relu(out + idn)
+        return _relu(out + idn, self.pattern, self.key + '.relu3')
 
 
 class ResNet3D50(nn.Module):
+    pattern = None
+
     def __init__(self, blocks=(3, 4, 6, 3)):
         super().__init__()
         self.conv1 = nn.Conv3d(3, 16, 7, stride=(1, 2, 2), padding=3, bias=False)
@@ -50,7 +77,12 @@ class ResNet3D50(nn.Module):
             setattr(self, f'layer{i + 1}', nn.Sequential(*layers))
 
     def forward(self, x):
-        x = F.max_pool3d(F.relu(self.bn3d1(self.conv1(x))), 3, 2, 1)
+        x = _relu(self.bn3d1(self.conv1(x)), self.pattern, 'stem')
+        if self.pattern is None:
+            x = F.max_pool3d(x, 3, 2, 1)
+        else:       # max-pool with a GIVEN arg-max (flat D*H*W index per output element): a gather
+            idx = self.pattern['pool_index']
+            x = x.flatten(2).gather(2, idx.flatten(2)).view(idx.shape)
         outs = []
         for i in range(4):
             x = getattr(self, f'layer{i + 1}')(x)
@@ -88,6 +120,15 @@ class RefExtractFeat(nn.Module):
         self.backbone = ResNet3D50()
         self.neck = FPN3D()
         self.eval()            # BN eval mode (norm_eval=True); parameters still receive gradients
+
+    def linearize_at(self, pattern):
+        """pattern: None (plain ReLU / max-pool) or a dict {'stem', 'layer{s}.{b}.relu{1,2,3}': 0/1 masks [N,C,D,H,W],
+        'pool_index': int64 [N,16,Do,Ho,Wo]} -- evaluate forward/backward at that activation pattern"""
+        self.backbone.pattern = pattern
+        for s in range(4):
+            for b, blk in enumerate(getattr(self.backbone, f'layer{s + 1}')):
+                blk.pattern, blk.key = pattern, f'layer{s + 1}.{b}'
+        return self
 
     def forward(self, x):
         return self.neck(self.backbone(x))

@@ -1,4 +1,9 @@
-"""BASELINE configs[1] size, end to end: the engine's ResNet3D-50+FPN3D forward and backward on a 1x3x80x512x512 volume
+"""BASELINE configs[1] size.  Default-on: the dominant kernels and a sub-stack of the engine at 1x3x80x512x512 against
+float64 torch on the host, evaluated on WINDOWS (corners, borders, interior) -- a convolution's output window only depends
+on its input halo, so the fp64 reference runs on crops in milliseconds while the device kernels run at production extents
+(32-bit index overflow, tile edges, grid-size limits are what small shapes cannot catch); weight gradients are made local
+by a cotangent that is zero outside the windows.  RoIAlign3D forward + backward at the bench size against the OpenMP
+oracle, every roi, both index modes.  Opt-in (MR3D_FULLSIZE=1): end to end: the engine's ResNet3D-50+FPN3D forward and backward on a 1x3x80x512x512 volume
 against the plain-PyTorch restatement (oracle/torch_ref_model.py, pinned to the reference by the goldens) run on the
 SAME GPU through PyTorch-ROCm/MIOpen, with identical random weights.  It catches what small shapes cannot (32-bit
 index overflow, tile-edge handling at production extents).  MIOpen needs minutes to pick its 3D kernels, so the test
@@ -52,3 +57,211 @@ def test_engine_full_size_vs_torch_on_gpu():
             worst = (k, e)
     print(f'full-size parity: worst output rel err {worst_out:.2e}; worst parameter-gradient L2 rel err {worst[1]:.2e} ({worst[0]})')
     assert worst[1] <= 3e-2, worst
+
+
+# ------------------------------------------------------------------------------------------------ default-on, windowed
+import numpy as np  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+RTOL = 1e-4
+
+
+def _crop_conv(x, w, b, stride, pad, win):
+    """fp64 conv3d of x [1,C,D,H,W] (cpu) restricted to the OUTPUT window win = ((d0,d1),(h0,h1),(w0,w1)): crops the
+    input halo (zero-filled outside the volume) and convolves without padding"""
+    k = w.shape[2:]
+    sl, pads = [], []
+    for ax, (o0, o1) in enumerate(win):
+        i0, i1 = o0 * stride[ax] - pad[ax], (o1 - 1) * stride[ax] - pad[ax] + k[ax]
+        lo, hi = max(i0, 0), min(i1, x.shape[2 + ax])
+        sl.append(slice(lo, hi)); pads.append((lo - i0, i1 - hi))
+    crop = F.pad(x[:, :, sl[0], sl[1], sl[2]].double(), (pads[2][0], pads[2][1], pads[1][0], pads[1][1], pads[0][0], pads[0][1]))
+    return crop, F.conv3d(crop, w.double(), None if b is None else b.double(), stride, 0)
+
+
+def _windows(dims, size):
+    """corner, far corner, interior and two border-straddling windows of a [D,H,W] map"""
+    D, H, W = dims
+    sd, sh, sw = (min(size[0], D), min(size[1], H), min(size[2], W))
+    starts = [(0, 0, 0), (D - sd, H - sh, W - sw), ((D - sd) // 2, (H - sh) // 2 + 1, (W - sw) // 2 - 1),
+              (D - sd, 0, (W - sw) // 3), (0, H - sh, W - sw)]
+    return [tuple((a, a + s_) for a, s_ in zip(st, (sd, sh, sw))) for st in starts]
+
+
+def _win(t_ndhwc, win):
+    (d0, d1), (h0, h1), (w0, w1) = win
+    return t_ndhwc[:, d0:d1, h0:h1, w0:w1, :].permute(0, 4, 1, 2, 3).cpu().double()
+
+
+def _assert_close(got, exp, what, rtol=RTOL):
+    scale = exp.abs().max().clamp(min=1e-30)
+    e_max = ((got - exp).abs().max() / scale).item()
+    e_l2 = ((got - exp).norm() / exp.norm().clamp(min=1e-30)).item()
+    assert e_max <= rtol and e_l2 <= rtol, f'{what}: max-norm rel {e_max:.2e}, L2 rel {e_l2:.2e}'
+    return e_max, e_l2
+
+
+def _random_stats(ref):
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if p.dim() == 1:
+                p.copy_(torch.rand_like(p) * 0.5 + 0.5 if n.endswith('weight') else torch.randn_like(p) * 0.1)
+        for n, b in ref.named_buffers():
+            if n.endswith('running_mean'):
+                b.copy_(torch.randn_like(b) * 0.1)
+            elif n.endswith('running_var'):
+                b.copy_(torch.rand_like(b) + 0.5)
+
+
+def test_full_size_forward_substack_windows():
+    """stem (7x7x7 s(1,2,2) + BN + ReLU) -> max-pool -> layer1.0 bottleneck, and the P2 FPN 3x3x3 conv (the dominant
+    kernel, Winograd F(4,3) at this size), at 1x3x80x512x512: every stage against fp64 on windows, each stage fed with
+    the engine's own previous buffer so that errors do not compound"""
+    import mr3d_amd  # noqa: F401
+    from mr3d_amd.detector import ExtractFeat3D
+    dev = torch.device('cuda:0')
+    torch.manual_seed(17)
+    ref = RefExtractFeat()
+    _random_stats(ref)
+    eng = ExtractFeat3D(device=dev)
+    eng.load_state_dict(ref.state_dict())
+    ref = ref.double().eval()
+    x = torch.randn(1, 3, 80, 512, 512)
+    eng.forward_features(x.to(dev))
+    P = eng._last
+    bb = ref.backbone
+    worst = {}
+    with torch.no_grad():
+        # stem
+        for win in _windows(P.stem_out.shape[1:4], (6, 12, 20)):
+            _, y = _crop_conv(x, bb.conv1.weight, None, (1, 2, 2), (3, 3, 3), win)
+            exp = F.relu(bb.bn3d1(y))
+            worst['stem'] = max(worst.get('stem', 0), _assert_close(_win(P.stem_out, win), exp, f'stem {win}')[0])
+        # max-pool: exact
+        stem_cpu = P.stem_out.permute(0, 4, 1, 2, 3).cpu()
+        for win in _windows(P.pool_out.shape[1:4], (5, 9, 11)):
+            sl = [slice(max(2 * a - 1, 0), min(2 * (b - 1) + 2, n)) for (a, b), n in zip(win, stem_cpu.shape[2:])]
+            crop = stem_cpu[:, :, sl[0], sl[1], sl[2]]
+            pad = [(sl_.start - (2 * a - 1), (2 * (b - 1) + 2) - sl_.stop) for sl_, (a, b) in zip(sl, win)]
+            crop = F.pad(crop, (pad[2][0], pad[2][1], pad[1][0], pad[1][1], pad[0][0], pad[0][1]), value=float('-inf'))
+            exp = F.max_pool3d(crop, 3, 2, 0)
+            assert torch.equal(_win(P.pool_out, win).float(), exp), f'maxpool {win}'
+        # layer1.0 (1x1x1 16->16, 3x3x3 16->16, 1x1x1 16->64, downsample 1x1x1 16->64, + ReLU)
+        blk = bb.layer1[0]
+        pool_cpu = P.pool_out.permute(0, 4, 1, 2, 3).cpu()
+        for win in _windows(P.pool_out.shape[1:4], (5, 9, 11)):
+            crop, _ = _crop_conv(pool_cpu, blk.conv2.weight[:, :, :, :, :], None, (1, 1, 1), (1, 1, 1), win)
+            a1 = F.relu(blk.bn3d1(blk.conv1(crop)))
+            # the 3x3x3 conv pads with zeros OUTSIDE THE VOLUME only: zero the halo cells that lie outside it
+            (d0, d1), (h0, h1), (w0, w1) = win
+            Dp, Hp, Wp = pool_cpu.shape[2:]
+            zd = [i for i, g_ in enumerate(range(d0 - 1, d1 + 1)) if not 0 <= g_ < Dp]
+            zh = [i for i, g_ in enumerate(range(h0 - 1, h1 + 1)) if not 0 <= g_ < Hp]
+            zw = [i for i, g_ in enumerate(range(w0 - 1, w1 + 1)) if not 0 <= g_ < Wp]
+            a1[:, :, zd] = 0; a1[:, :, :, zh] = 0; a1[:, :, :, :, zw] = 0
+            a2 = F.relu(blk.bn3d2(F.conv3d(a1, blk.conv2.weight, None, 1, 0)))
+            inner = crop[:, :, 1:-1, 1:-1, 1:-1]
+            exp = F.relu(blk.bn3d3(blk.conv3(a2)) + blk.downsample(inner))
+            worst['layer1.0'] = max(worst.get('layer1.0', 0), _assert_close(_win(P.blk[0]['out'], win), exp, f'layer1.0 {win}')[0])
+        # P2 FPN conv on the engine's own lateral sum
+        lat_cpu = P.lat[0].permute(0, 4, 1, 2, 3).cpu()
+        conv = ref.neck.fpn_convs[0].conv
+        for win in _windows(P.outs[0].shape[1:4], (6, 10, 14)):
+            _, exp = _crop_conv(lat_cpu, conv.weight, conv.bias, (1, 1, 1), (1, 1, 1), win)
+            worst['fpn_convs.0'] = max(worst.get('fpn_convs.0', 0), _assert_close(_win(P.outs[0], win), exp, f'fpn_convs.0 {win}')[0])
+    print('full-size windowed forward parity (max-norm rel):', {k: f'{v:.1e}' for k, v in worst.items()})
+
+
+def test_full_size_backward_kernels_windows():
+    """the backward kernels of the dominant layers at production extents: P2 3x3x3 64->64 data gradient (Winograd form) and
+    weight gradient, stem 7x7x7 weight gradient; weight gradients are made window-local by a cotangent that is zero
+    outside five windows, so their fp64 reference is a sum over crops"""
+    import mr3d_amd  # noqa: F401
+    from mr3d_amd import _hip
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(3)
+    # ---- P2 conv: x, dy [1,40,128,128,64]
+    w = torch.randn(64, 64, 3, 3, 3, generator=g) / np.sqrt(64 * 27)
+    dy = torch.randn(1, 64, 40, 128, 128, generator=g)
+    wb = _hip.pack_conv_weight(w.flip(2, 3, 4).transpose(0, 1).contiguous())          # dgrad = conv with flipped, transposed taps
+    dx = _hip.conv3d_forward(dy.permute(0, 2, 3, 4, 1).contiguous().to(dev), wb.to(dev), (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    for win in _windows((40, 128, 128), (6, 10, 14)):
+        _, exp = _crop_conv(dy, w.flip(2, 3, 4).transpose(0, 1), None, (1, 1, 1), (1, 1, 1), win)
+        _assert_close(_win(dx, win), exp, f'P2 dgrad {win}')
+    x = torch.randn(1, 64, 40, 128, 128, generator=g)
+    dyw = torch.zeros_like(dy)
+    wins = _windows((40, 128, 128), (6, 10, 14))
+    exp_dw = torch.zeros(64, 64, 3, 3, 3, dtype=torch.float64)
+    for win in wins:
+        (d0, d1), (h0, h1), (w0, w1) = win
+        if dyw[:, :, d0:d1, h0:h1, w0:w1].abs().sum() > 0:
+            continue                                                   # overlapping windows would be counted twice
+        dyw[:, :, d0:d1, h0:h1, w0:w1] = dy[:, :, d0:d1, h0:h1, w0:w1]
+        crop, _ = _crop_conv(x, w, None, (1, 1, 1), (1, 1, 1), win)
+        exp_dw += torch.nn.grad.conv3d_weight(crop, (64, 64, 3, 3, 3), dy[:, :, d0:d1, h0:h1, w0:w1].double(), 1, 0)
+    dw = torch.zeros(27, 64, 64, device=dev)
+    db = torch.zeros(64, device=dev)
+    _hip.conv3d_wgrad(x.permute(0, 2, 3, 4, 1).contiguous().to(dev), dyw.permute(0, 2, 3, 4, 1).contiguous().to(dev), dw,
+                      (3, 3, 3), (1, 1, 1), (1, 1, 1), dbias=db)
+    got = dw.permute(2, 1, 0).reshape(64, 64, 3, 3, 3).cpu().double()
+    _assert_close(got, exp_dw, 'P2 wgrad (windowed cotangent)')
+    _assert_close(db.cpu().double(), dyw.double().sum(dim=(0, 2, 3, 4)), 'P2 dbias')
+    del dx, dw, dy, dyw, x
+    # ---- stem weight gradient: x [1,3,80,512,512], dy [1,80,256,256,16]
+    xs = torch.randn(1, 3, 80, 512, 512, generator=g)
+    dys = torch.zeros(1, 16, 80, 256, 256)
+    exp_dw = torch.zeros(16, 3, 7, 7, 7, dtype=torch.float64)
+    for win in _windows((80, 256, 256), (6, 12, 20)):
+        (d0, d1), (h0, h1), (w0, w1) = win
+        if dys[:, :, d0:d1, h0:h1, w0:w1].abs().sum() > 0:
+            continue
+        blk = torch.randn(1, 16, d1 - d0, h1 - h0, w1 - w0, generator=g)
+        dys[:, :, d0:d1, h0:h1, w0:w1] = blk
+        crop, _ = _crop_conv(xs, torch.zeros(16, 3, 7, 7, 7), None, (1, 2, 2), (3, 3, 3), win)
+        exp_dw += torch.nn.grad.conv3d_weight(crop, (16, 3, 7, 7, 7), blk.double(), (1, 2, 2), 0)
+    dws = torch.zeros(343, 4, 16, device=dev)
+    dbs = torch.zeros(16, device=dev)
+    _hip.stem_conv_wgrad(xs.to(dev), dys.permute(0, 2, 3, 4, 1).contiguous().to(dev), dws, dbias=dbs)
+    got = dws[:, :3, :].permute(2, 1, 0).reshape(16, 3, 7, 7, 7).cpu().double()
+    _assert_close(got, exp_dw, 'stem wgrad (windowed cotangent)')
+    assert dws[:, 3, :].abs().max().item() == 0.0                      # the padding channel stays zero
+
+
+@pytest.mark.parametrize('case', ['bbox', 'mask'])
+def test_full_size_roialign_forward_backward_vs_oracle(case):
+    """the RoIAlign3D bench shapes (512 rois x 64 ch x (3,7,7); 128 rois x (10,14,14)) over P2..P5 of a 512x512x80 volume
+    through SingleRoIExtractor's one-launch multi-level kernels: EVERY roi, forward and backward in both index modes,
+    against the OpenMP oracle run level by level"""
+    import mr3d_amd  # noqa: F401
+    from mr3d_amd.detector import SingleRoIExtractor
+    from oracle import binding as orc
+    import ref_impls as ri
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(12)
+    n, osz, od = (512, 7, 3) if case == 'bbox' else (128, 14, 10)
+    rois = ri.rand_rois(rng, n, 1, (512, 512, 80))
+    dims = ((40, 128), (20, 64), (10, 32), (5, 16))
+    feats_np = [rng.normal(size=(1, 64, d, h, h)).astype(np.float32) for d, h in dims]
+    top = rng.normal(size=(n, 64, od, osz, osz)).astype(np.float32)
+    strides, dstrides = [4, 8, 16, 32], [2, 4, 8, 16]
+    for bug in (True, False):
+        ext = SingleRoIExtractor(dict(type='RoIAlign3D', out_size=osz, out_size_depth=od, sample_num=2, bug_compat=bug), 64,
+                                 strides, dstrides)
+        feats = [torch.from_numpy(f).to(dev).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True) for f in feats_np]
+        rt = torch.from_numpy(rois).to(dev)
+        out = ext(feats, rt)
+        out.backward(torch.from_numpy(top).to(dev))
+        lvl = ext.map_roi_levels(torch.from_numpy(rois), 4).numpy()
+        got = out.detach().cpu().numpy()
+        for i in range(4):
+            sel = np.nonzero(lvl == i)[0]
+            gi = feats[i].grad.cpu().numpy()
+            if not len(sel):
+                assert np.abs(gi).max() == 0
+                continue
+            exp = orc.roi_align3d_forward(feats_np[i], rois[sel], od, osz, osz, 1 / strides[i], 1 / dstrides[i], 2)
+            np.testing.assert_allclose(got[sel], exp, rtol=1e-4, atol=1e-5)
+            expb = orc.roi_align3d_backward(top[sel], rois[sel], feats_np[i].shape, 1 / strides[i], 1 / dstrides[i], 2, bug_compat=bug)
+            scale = np.abs(expb).max()
+            assert np.abs(gi - expb).max() <= 1e-4 * scale, (case, bug, i)
+            assert np.linalg.norm((gi - expb).ravel()) <= 1e-4 * np.linalg.norm(expb.ravel()), (case, bug, i)

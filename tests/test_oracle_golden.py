@@ -20,6 +20,16 @@ def test_nms3d_oracle_matches_reference_python(golden_dir):
         np.testing.assert_array_equal(keep, g[f'keep_{k}'], err_msg=f'case {k}')
 
 
+def test_nms3d_numpy_restatement_matches_reference_python(golden_dir):
+    """oracle/nms_ref.py (the CPU baseline timed by bench.py) against the same reference-made fixtures"""
+    from oracle.nms_ref import nms3d_numpy
+    g = _load(golden_dir, 'nms3d.npz')
+    for k in range(int(g['num_cases'])):
+        picked = nms3d_numpy(g[f'dets_{k}'], float(g[f'thr_{k}']))
+        np.testing.assert_array_equal(np.sort(picked), g[f'keep_{k}'], err_msg=f'case {k}')
+    assert nms3d_numpy(np.zeros((0, 7)), 0.5).shape == (0,)
+
+
 def test_nms3d_edge_cases():
     assert orc.nms3d(np.zeros((0, 7), np.float32), 0.5).shape == (0,)
     one = np.array([[0, 0, 4, 4, 0, 4, 0.3]], np.float32)
