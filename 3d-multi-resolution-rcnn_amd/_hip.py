@@ -300,6 +300,60 @@ def conv3d_forward(x, w_packed, k, stride, pad, shift=None, add1=None, add2=None
     return y
 
 
+def pack_conv_weight_bf16(w):
+    """torch Conv3d weight [Cout, Cin, kd, kh, kw] -> bf16 [taps, Cin16/8, Cout32, 8]: the B-operand layout of
+    mr3d_conv3d_forward_bf16 (8 consecutive input channels of one output channel are one 16-byte fragment; channel counts
+    rounded up to 16 / 32 with zeros).  The data-gradient operand is pack_conv_weight_bf16(w.flip(2, 3, 4).transpose(0, 1))."""
+    co, ci = w.shape[:2]
+    taps = w[0, 0].numel()
+    ci16, co32 = -(-ci // 16) * 16, -(-co // 32) * 32
+    buf = torch.zeros(taps, ci16, co32, dtype=torch.float32, device=w.device)
+    buf[:, :ci, :co] = w.reshape(co, ci, taps).permute(2, 1, 0)
+    return buf.view(taps, ci16 // 8, 8, co32).permute(0, 1, 3, 2).contiguous().to(torch.bfloat16)
+
+
+def conv3d_forward_bf16(x, w16, cout, k, stride, pad, shift=None, add1=None, add2=None, up=None, mask=None, relu=False):
+    """x: [N,D,H,W,Cin] bf16 (NDHWC); w16: pack_conv_weight_bf16 layout; returns y [N,Do,Ho,Wo,cout] bf16."""
+    assert x.is_cuda and x.is_contiguous() and x.dtype == torch.bfloat16 and x.dim() == 5 and w16.dtype == torch.bfloat16
+    oshape = conv3d_out_shape(x.shape, cout, k, stride, pad)
+    y = torch.empty(oshape, dtype=torch.bfloat16, device=x.device)
+    for t in (add1, add2, mask):
+        assert t is None or (tuple(t.shape) == tuple(y.shape) and t.is_contiguous() and t.dtype == torch.bfloat16)
+    d = Conv3dDesc()
+    d.x, d.w, d.y = x.data_ptr(), w16.data_ptr(), y.data_ptr()
+    d.shift, d.add1, d.add2, d.up, d.mask = _opt(shift), _opt(add1), _opt(add2), _opt(up), _opt(mask)
+    d.n, d.d, d.h, d.w_in, d.cin, d.cout = x.size(0), x.size(1), x.size(2), x.size(3), x.size(4), cout
+    d.kd, d.kh, d.kw = k
+    d.sd, d.sh, d.sw = stride
+    d.pd, d.ph, d.pw = pad
+    if up is not None:
+        assert up.is_contiguous() and up.size(4) == cout and up.dtype == torch.bfloat16
+        d.up_d, d.up_h, d.up_w = up.size(1), up.size(2), up.size(3)
+    d.relu = int(bool(relu))
+    with torch.cuda.device(x.device):
+        st = lib().mr3d_conv3d_forward_bf16(ctypes.byref(d), stream_ptr(x.device))
+    check(st, 'mr3d_conv3d_forward_bf16')
+    return y
+
+
+def conv3d_wgrad_bf16(x, dy, dw_packed, k, stride, pad, dbias=None):
+    """dw_packed fp32 [taps,Cin,Cout] += wgrad(x bf16 [N,D,H,W,Cin], dy bf16 [N,Do,Ho,Wo,Cout]); dw pre-zeroed"""
+    assert x.is_cuda and x.is_contiguous() and dy.is_contiguous() and x.dtype == dy.dtype == torch.bfloat16
+    assert dw_packed.dtype == torch.float32 and dw_packed.is_contiguous()
+    cout = dw_packed.size(2)
+    assert tuple(dy.shape) == tuple(conv3d_out_shape(x.shape, cout, k, stride, pad))
+    d = Conv3dWgradDesc()
+    d.x, d.dy, d.dw, d.dbias = x.data_ptr(), dy.data_ptr(), dw_packed.data_ptr(), _opt(dbias)
+    d.n, d.d, d.h, d.w_in, d.cin, d.cout = x.size(0), x.size(1), x.size(2), x.size(3), x.size(4), cout
+    d.kd, d.kh, d.kw = k
+    d.sd, d.sh, d.sw = stride
+    d.pd, d.ph, d.pw = pad
+    with torch.cuda.device(x.device):
+        st = lib().mr3d_conv3d_wgrad_bf16(ctypes.byref(d), stream_ptr(x.device))
+    check(st, 'mr3d_conv3d_wgrad_bf16')
+    return dw_packed
+
+
 def conv3d_dgrad_s2k3(dy, wb_packed, dx_shape, add1=None, add2=None, mask=None, out=None):
     """Data gradient of a kernel-3/stride-2/pad-1 conv without zero-stuffing (mr3d_conv3d_dgrad_s2k3).
     dy: [N,Do,Ho,Wo,Cout_fwd]; wb_packed: [27,Cout_fwd,Cin_fwd] flipped/transposed taps; returns dx [N,D,H,W,Cin_fwd]."""
@@ -370,7 +424,8 @@ def conv3d_wgrad(x, dy, dw_packed, k, stride, pad, dbias=None, workspace=None):
 # plan records (mr3d_op / mr3d_layer_desc in include/mr3d.h)
 OP_CONV_FWD, OP_CONV_WGRAD, OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_ZERO_STUFF2, OP_UPSAMPLE_ADJ = 1, 2, 3, 4, 5, 6
 OP_SUBSAMPLE_FWD, OP_SUBSAMPLE_BWD, OP_VOLUME_PACK, OP_MEMSET0, OP_AXPY, OP_PREP_WEIGHTS, OP_FINISH_GRADS = 7, 8, 9, 10, 11, 12, 13
-OP_STEM_FWD, OP_STEM_WGRAD, OP_CONV_DGRAD_S2 = 14, 15, 16
+OP_STEM_FWD, OP_STEM_WGRAD, OP_CONV_DGRAD_S2, OP_PREP_WEIGHTS_BF16 = 14, 15, 16, 17
+DTYPE_BF16 = 1          # mr3d_op.i[25]: MR3D_DTYPE_BF16
 
 
 class Op(ctypes.Structure):
@@ -520,6 +575,8 @@ def op_kernel_key(op):
         real_cin = 3 if (cin == 4 and k == 7) else cin
         flops = 2.0 * n * do * ho * wo * cout * real_cin * k ** 3
         name = 'conv3d_fwd' if op.kind == OP_CONV_FWD else 'conv3d_wgrad'
+        if i[25] == DTYPE_BF16:
+            return f'{name}_bf16<k{k},s{sd}{sh}{sw},cin{cin},cout{cout}>', flops
         return f'{name}<k{k},s{sd}{sh}{sw},cc{cc},nb{nb}>', flops
     if op.kind == OP_CONV_DGRAD_S2:      # i[1:4] = dy's (coarse) grid; every dy element meets each of the 27 taps once
         n, d, h, w, cin, cout = i[0], i[1], i[2], i[3], i[4], i[5]

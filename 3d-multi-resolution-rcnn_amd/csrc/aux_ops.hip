@@ -13,10 +13,29 @@ constexpr int kT = 256;
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+// bf16 storage (configs[4]): the same kernels on 4 x bf16 = 8-byte accesses, arithmetic in fp32
+using bf16_t = uint16_t;
+__device__ __forceinline__ float4 ld4(const bf16_t *p) {
+  const uint2 q = *reinterpret_cast<const uint2 *>(p);
+  return make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16),
+                     __uint_as_float(q.y & 0xffff0000u));
+}
+__device__ __forceinline__ uint32_t bf16_rne(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void st4(bf16_t *p, float4 v) {
+  uint2 q;
+  q.x = bf16_rne(v.x) | (bf16_rne(v.y) << 16);
+  q.y = bf16_rne(v.z) | (bf16_rne(v.w) << 16);
+  *reinterpret_cast<uint2 *>(p) = q;
+}
 
 // ---------------------------------------------------------------- maxpool k3 s2 p1
 // scan order (kd, kh, kw); the FIRST maximum wins (torch: `val > maxval`), its tap id is stored.
-__global__ __launch_bounds__(kT) void maxpool_fwd_kernel(const float *__restrict__ x, float *__restrict__ y,
+template <typename T>
+__global__ __launch_bounds__(kT) void maxpool_fwd_kernel(const T *__restrict__ x, T *__restrict__ y,
                                                         uint32_t *__restrict__ idx, int N, int D, int H, int W, int C,
                                                         int Do, int Ho, int Wo) {
   const int C4 = C / 4;
@@ -54,8 +73,9 @@ __global__ __launch_bounds__(kT) void maxpool_fwd_kernel(const float *__restrict
 }
 
 // dx[i] = relu'(xact[i]) * sum over the (<= 8) windows o that cover i and whose argmax is i, of dy[o]
-__global__ __launch_bounds__(kT) void maxpool_bwd_kernel(const float *__restrict__ dy, const uint32_t *__restrict__ idx,
-                                                        const float *__restrict__ xact, float *__restrict__ dx, int N,
+template <typename T>
+__global__ __launch_bounds__(kT) void maxpool_bwd_kernel(const T *__restrict__ dy, const uint32_t *__restrict__ idx,
+                                                        const T *__restrict__ xact, T *__restrict__ dx, int N,
                                                         int D, int H, int W, int C, int Do, int Ho, int Wo) {
   const int C4 = C / 4;
   const long long total = (long long)N * D * H * W * C4;
@@ -97,7 +117,8 @@ __global__ __launch_bounds__(kT) void maxpool_bwd_kernel(const float *__restrict
 }
 
 // ---------------------------------------------------------------- zero-stuffing: dst[2o] = src[o], else 0
-__global__ __launch_bounds__(kT) void zero_stuff_kernel(const float *__restrict__ src, float *__restrict__ dst, int N, int Do,
+template <typename T>
+__global__ __launch_bounds__(kT) void zero_stuff_kernel(const T *__restrict__ src, T *__restrict__ dst, int N, int Do,
                                                        int Ho, int Wo, int D, int H, int W, int C) {
   const int C4 = C / 4;
   const long long total = (long long)N * D * H * W * C4;
@@ -131,7 +152,8 @@ __device__ __forceinline__ void child_range(int u, int in, int out, int &lo, int
   hi = f;
 }
 
-__global__ __launch_bounds__(kT) void upsample_adjoint_add_kernel(const float *__restrict__ gf, float *__restrict__ gc, int N,
+template <typename T>
+__global__ __launch_bounds__(kT) void upsample_adjoint_add_kernel(const T *__restrict__ gf, T *__restrict__ gc, int N,
                                                                  int Df, int Hf, int Wf, int Dc, int Hc, int Wc, int C) {
   const int C4 = C / 4;
   const long long total = (long long)N * Dc * Hc * Wc * C4;
@@ -158,8 +180,8 @@ __global__ __launch_bounds__(kT) void upsample_adjoint_add_kernel(const float *_
 }
 
 // ---------------------------------------------------------------- stride-2 subsample (max_pool3d k=1 s=2)
-template <bool kBackward>
-__global__ __launch_bounds__(kT) void subsample2_kernel(const float *__restrict__ src, float *__restrict__ dst, int N, int D,
+template <bool kBackward, typename T>
+__global__ __launch_bounds__(kT) void subsample2_kernel(const T *__restrict__ src, T *__restrict__ dst, int N, int D,
                                                        int H, int W, int C, int Do, int Ho, int Wo) {
   // forward: dst[o] = src[2o] (dst is the coarse grid); backward: dst[2o] += src[o] (dst is the fine grid)
   const int C4 = C / 4;
@@ -271,6 +293,36 @@ __global__ __launch_bounds__(kT) void finish_affine_kernel(const mr3d_layer_desc
     const float invstd = 1.f / sqrtf(params[L.var_off + c] + L.eps);
     grads[L.gamma_off + c] += invstd * (dot - params[L.mean_off + c] * sumdy);
     grads[L.beta_off + c] += sumdy;
+  }
+}
+
+// bf16 operand packing for conv3d_bf16.hip / conv3d_wgrad_bf16.hip: a B fragment of v_mfma_f32_32x32x16_bf16 is 8
+// consecutive K values of one N column, so K-groups of 8 are the innermost run:
+//   forward  wf16[tap][ci16/8][co32][8]           = s[co] * W[co][ci][tap]   (K = input channel, N = output channel)
+//   dgrad    wb16[taps-1-tap][co16/8][ci32][8]    = same value               (K = output channel, N = input channel)
+// ci16 / co16 = channel counts rounded up to 16, co32 / ci32 to 32 (zero filled).  wf_off / wb_off of the table are
+// offsets in bf16 ELEMENTS into `packed16`; shift / scale stay in the fp32 packed arena (mr3d_prepare_weights).
+__global__ __launch_bounds__(kT) void prep_weights_bf16_kernel(const mr3d_layer_desc *__restrict__ table,
+                                                              const float *__restrict__ params, bf16_t *__restrict__ packed) {
+  const mr3d_layer_desc L = table[blockIdx.y];
+  const int ci16 = (L.ci_pad + 15) / 16 * 16, co32 = (L.co + 31) / 32 * 32;
+  const int co16 = (L.co + 15) / 16 * 16, ci32 = (L.ci_pad + 31) / 32 * 32;
+  const int total_f = L.taps * ci16 * co32;
+  for (int e = blockIdx.x * kT + threadIdx.x; e < total_f; e += gridDim.x * kT) {
+    const int j = e & 7, co = (e >> 3) % co32, g = (e >> 3) / co32 % (ci16 / 8), tap = e / (ci16 * co32);
+    const int ci = g * 8 + j;
+    float v = 0.f;
+    if (ci < L.ci && co < L.co) v = layer_scale(L, params, co) * params[L.w_off + ((long long)co * L.ci + ci) * L.taps + tap];
+    packed[L.wf_off + e] = (bf16_t)bf16_rne(v);
+  }
+  if (L.wb_off < 0) return;
+  const int total_b = L.taps * co16 * ci32;
+  for (int e = blockIdx.x * kT + threadIdx.x; e < total_b; e += gridDim.x * kT) {
+    const int j = e & 7, ci = (e >> 3) % ci32, g = (e >> 3) / ci32 % (co16 / 8), tapb = e / (co16 * ci32);
+    const int co = g * 8 + j, tap = L.taps - 1 - tapb;
+    float v = 0.f;
+    if (ci < L.ci && co < L.co) v = layer_scale(L, params, co) * params[L.w_off + ((long long)co * L.ci + ci) * L.taps + tap];
+    packed[L.wb_off + e] = (bf16_t)bf16_rne(v);
   }
 }
 
@@ -409,5 +461,65 @@ extern "C" int mr3d_finish_grads(const mr3d_layer_desc *table, int num_layers, i
   if (!table || !params || !scratch || !grads || num_layers <= 0 || max_cout <= 0) return MR3D_ERR_INVALID_ARG;
   finish_wgrads_kernel<<<dim3(64, num_layers), kT, 0, mr3d_stream(s)>>>(table, params, scratch, grads);
   finish_affine_kernel<<<dim3((max_cout + 3) / 4, num_layers), kT, 0, mr3d_stream(s)>>>(table, params, scratch, grads);
+  return mr3d_launch_status();
+}
+
+
+// ------------------------------------------------------------------------------------------------ bf16 storage variants
+extern "C" int mr3d_maxpool3d_forward_bf16(const void *x, void *y, uint32_t *argmax, int n, int d, int h, int w, int c,
+                                           mr3d_stream_t s) {
+  if (!x || !y || !argmax || c % 4) return MR3D_ERR_INVALID_ARG;
+  const int Do = (d - 1) / 2 + 1, Ho = (h - 1) / 2 + 1, Wo = (w - 1) / 2 + 1;
+  maxpool_fwd_kernel<<<grid_for((long long)n * Do * Ho * Wo * c / 4), kT, 0, mr3d_stream(s)>>>((const bf16_t *)x, (bf16_t *)y, argmax,
+                                                                                          n, d, h, w, c, Do, Ho, Wo);
+  return mr3d_launch_status();
+}
+
+extern "C" int mr3d_maxpool3d_backward_bf16(const void *dy, const uint32_t *argmax, const void *relu_of, void *dx, int n, int d,
+                                            int h, int w, int c, mr3d_stream_t s) {
+  if (!dy || !dx || !argmax || c % 4) return MR3D_ERR_INVALID_ARG;
+  const int Do = (d - 1) / 2 + 1, Ho = (h - 1) / 2 + 1, Wo = (w - 1) / 2 + 1;
+  maxpool_bwd_kernel<<<grid_for((long long)n * d * h * w * c / 4), kT, 0, mr3d_stream(s)>>>((const bf16_t *)dy, argmax,
+                                                                                         (const bf16_t *)relu_of, (bf16_t *)dx, n, d, h,
+                                                                                         w, c, Do, Ho, Wo);
+  return mr3d_launch_status();
+}
+
+extern "C" int mr3d_zero_stuff2_bf16(const void *src, void *dst, int n, int do_, int ho, int wo, int d, int h, int w, int c,
+                                     mr3d_stream_t s) {
+  if (!src || !dst || c % 4) return MR3D_ERR_INVALID_ARG;
+  zero_stuff_kernel<<<grid_for((long long)n * d * h * w * c / 4), kT, 0, mr3d_stream(s)>>>((const bf16_t *)src, (bf16_t *)dst, n, do_,
+                                                                                        ho, wo, d, h, w, c);
+  return mr3d_launch_status();
+}
+
+extern "C" int mr3d_upsample_nearest_adjoint_add_bf16(const void *grad_fine, void *grad_coarse, int n, int df, int hf, int wf,
+                                                      int dc, int hc, int wc, int c, mr3d_stream_t s) {
+  if (!grad_fine || !grad_coarse || c % 4) return MR3D_ERR_INVALID_ARG;
+  upsample_adjoint_add_kernel<<<grid_for((long long)n * dc * hc * wc * c / 4), kT, 0, mr3d_stream(s)>>>(
+      (const bf16_t *)grad_fine, (bf16_t *)grad_coarse, n, df, hf, wf, dc, hc, wc, c);
+  return mr3d_launch_status();
+}
+
+extern "C" int mr3d_subsample2_forward_bf16(const void *x, void *y, int n, int d, int h, int w, int c, mr3d_stream_t s) {
+  if (!x || !y || c % 4) return MR3D_ERR_INVALID_ARG;
+  const int Do = (d - 1) / 2 + 1, Ho = (h - 1) / 2 + 1, Wo = (w - 1) / 2 + 1;
+  subsample2_kernel<false><<<grid_for((long long)n * Do * Ho * Wo * c / 4), kT, 0, mr3d_stream(s)>>>((const bf16_t *)x, (bf16_t *)y, n,
+                                                                                                  d, h, w, c, Do, Ho, Wo);
+  return mr3d_launch_status();
+}
+
+extern "C" int mr3d_subsample2_backward_add_bf16(const void *dy, void *dx, int n, int d, int h, int w, int c, mr3d_stream_t s) {
+  if (!dy || !dx || c % 4) return MR3D_ERR_INVALID_ARG;
+  const int Do = (d - 1) / 2 + 1, Ho = (h - 1) / 2 + 1, Wo = (w - 1) / 2 + 1;
+  subsample2_kernel<true><<<grid_for((long long)n * Do * Ho * Wo * c / 4), kT, 0, mr3d_stream(s)>>>((const bf16_t *)dy, (bf16_t *)dx, n,
+                                                                                                 d, h, w, c, Do, Ho, Wo);
+  return mr3d_launch_status();
+}
+
+extern "C" int mr3d_prepare_weights_bf16(const mr3d_layer_desc *table, int num_layers, const float *params, void *packed16,
+                                         mr3d_stream_t s) {
+  if (!table || !params || !packed16 || num_layers <= 0) return MR3D_ERR_INVALID_ARG;
+  prep_weights_bf16_kernel<<<dim3(64, num_layers), kT, 0, mr3d_stream(s)>>>(table, params, (bf16_t *)packed16);
   return mr3d_launch_status();
 }

@@ -1,0 +1,319 @@
+// bf16 3D convolution forward / data gradient on the gfx950 matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulate)
+// -- BASELINE.json configs[4] ("bf16"): the same layers as conv3d_fwd.hip (mmdet/models/backbones/resnet3d.py:126,139,
+// 173,251; utils/conv_module3d.py:34; necks/fpn3d.py:99-108 with the norm / ReLU / residual / upsample-add epilogue) with
+// activations stored as bf16 NDHWC in HBM (half the bytes of every map) and 16x the fp32 matrix rate.
+//
+// GEMM view: M = output positions of a (TD x TH x TW) tile, N = Cout, K = taps x Cin.
+//   * A: the tile's input halo for CC channels sits in LDS as [halo position][CC] bf16 (rows padded by 16 B); an
+//     A fragment (8 consecutive channels of one position = 16 B) is ONE ds_read_b128, a tap is a constant LDS offset.
+//   * B: weights pre-packed [tap][Cin/8][Cout32][8]: a lane's fragment (8 consecutive input channels of one output
+//     channel) is one 16-B global load, 512 contiguous bytes per half-wave; fetched one tap ahead into registers.
+//     Weights never touch LDS.
+//   * a wave owns (M/128) x NT MFMA tiles of 32 x 32; 4 waves split the tile's positions.
+//   * epilogue as in the fp32 kernel: + shift (folded BN / bias, fp32) + add1 + add2 + nearest-upsampled map, ReLU or
+//     the ReLU mask of the layer a data gradient feeds; bf16 store (round to nearest even).
+#include "conv3d.h"
+#include <cstdlib>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+using bf16_t = uint16_t;
+
+constexpr int kThreads = 256;
+
+struct BfArgs {
+  const bf16_t *x; const bf16_t *w; bf16_t *y;
+  const float *shift; const bf16_t *add1; const bf16_t *add2; const bf16_t *up; const bf16_t *mask;
+  int N, D, H, W, Cin;
+  int Do, Ho, Wo, Cout, CoutPad;
+  int pd, ph, pw;
+  int Du, Hu, Wu;
+  int relu;
+  int ysd, ysh, ysw, yD, yH, yW;
+};
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float((uint32_t)v << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {          // round to nearest even; NaN stays NaN
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ int nearest_src(int dst, int in, int out) {
+  int s = (int)floorf((float)dst * ((float)in / (float)out));      // F.interpolate(mode='nearest'), fpn3d.py:106-108
+  return s < in - 1 ? s : in - 1;
+}
+
+template <int K_, int S_, int TD_, int TH_, int TW_, int CC_, int NT_>
+struct BfCfg {
+  static constexpr int K = K_, S = S_, TD = TD_, TH = TH_, TW = TW_, CC = CC_, NT = NT_;
+  static constexpr bool PW1 = (K_ == 1);
+  static constexpr int LS = PW1 ? 1 : S_;          // LDS step per output position
+  static constexpr int GS = PW1 ? S_ : 1;          // global step per halo position (a strided 1x1x1 reads every S-th voxel)
+  static constexpr int HD = (TD - 1) * LS + K, HH = (TH - 1) * LS + K, HW = (TW - 1) * LS + K, HP = HD * HH * HW;
+  static constexpr int ROWB = CC * 2 + 16;         // bytes per halo position (16 B of padding staggers the banks)
+  static constexpr int M = TD * TH * TW;
+  static constexpr int MTW = M / 128;              // 32-row MFMA tiles per wave
+  static constexpr int KK = CC / 16;               // MFMA k-steps per tap and chunk
+  static constexpr int TAPS = K * K * K;
+  static constexpr int NB = 32 * NT;
+  static constexpr int LDS_BYTES = (HP * ROWB > M * 36 * 4) ? HP * ROWB : M * 36 * 4;    // halo, later the epilogue's rows
+  static constexpr int PIECES = HP * (CC / 8);     // 16-byte pieces of a halo chunk
+  static constexpr int NIT = (PIECES + kThreads - 1) / kThreads;
+  static_assert(M % 128 == 0 && CC % 16 == 0, "tile");
+  static_assert(LDS_BYTES <= 160 * 1024, "halo exceeds LDS");
+};
+
+template <class C>
+__global__ __launch_bounds__(kThreads, 2) void conv3d_bf16_kernel(BfArgs p, int tiles_d, int tiles_h, int tiles_w) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+
+  int b = blockIdx.x;
+  const int tw_i = b % tiles_w; b /= tiles_w;
+  const int th_i = b % tiles_h; b /= tiles_h;
+  const int td_i = b % tiles_d; b /= tiles_d;
+  const int n = b;
+  const int od0 = td_i * C::TD, oh0 = th_i * C::TH, ow0 = tw_i * C::TW;
+  const int id0 = od0 * C::S - p.pd, ih0 = oh0 * C::S - p.ph, iw0 = ow0 * C::S - p.pw;
+  const int n0 = blockIdx.y * C::NB;
+
+  int abase[C::MTW];
+#pragma unroll
+  for (int mt = 0; mt < C::MTW; ++mt) {
+    const int m = (wave * C::MTW + mt) * 32 + r;
+    const int tw = m % C::TW, th = (m / C::TW) % C::TH, td = m / (C::TW * C::TH);
+    abase[mt] = (((td * C::LS) * C::HH + th * C::LS) * C::HW + tw * C::LS) * C::ROWB + 16 * h;
+  }
+  // this lane's B fragment: rows of 8 input channels (k = 8h .. 8h+7 of a 16-wide k-step), column n0 + nt*32 + r
+  const int cin8 = p.Cin >> 3;
+  const bf16x8 *wlane = reinterpret_cast<const bf16x8 *>(p.w) + (size_t)h * p.CoutPad + n0 + r;
+
+  f32x16_t acc[C::MTW][C::NT];
+#pragma unroll
+  for (int mt = 0; mt < C::MTW; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < C::NT; ++nt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mt][nt][e] = 0.f;
+
+  // ---- halo staging through registers (the next chunk is fetched before the MFMA loop of the current one)
+  uint4 stage[C::NIT];
+  auto fetch = [&](int c0) {
+#pragma unroll
+    for (int j = 0; j < C::NIT; ++j) {
+      const int it = tid + j * kThreads;
+      constexpr int Q = C::CC / 8;
+      const int pos = it / Q, q = it - pos * Q;
+      const int hw = pos % C::HW, hh = (pos / C::HW) % C::HH, hd = pos / (C::HW * C::HH);
+      const int id = id0 + hd * C::GS, ih = ih0 + hh * C::GS, iw = iw0 + hw * C::GS;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (it < C::PIECES && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
+        v = *reinterpret_cast<const uint4 *>(p.x + ((((size_t)n * p.D + id) * p.H + ih) * p.W + iw) * p.Cin + c0 + q * 8);
+      stage[j] = v;
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < C::NIT; ++j) {
+      const int it = tid + j * kThreads;
+      constexpr int Q = C::CC / 8;
+      if (it < C::PIECES) {
+        const int pos = it / Q, q = it - pos * Q;
+        *reinterpret_cast<uint4 *>(lds + pos * C::ROWB + q * 16) = stage[j];
+      }
+    }
+  };
+  // weight fragments of one tap (all k-steps of the chunk, all N tiles)
+  auto load_b = [&](bf16x8 (&dst)[C::KK][C::NT], int c0, int tap) {
+    const bf16x8 *wt = wlane + ((size_t)tap * cin8 + (c0 >> 3)) * p.CoutPad;
+#pragma unroll
+    for (int kk = 0; kk < C::KK; ++kk)
+#pragma unroll
+      for (int nt = 0; nt < C::NT; ++nt) dst[kk][nt] = wt[(size_t)kk * 2 * p.CoutPad + nt * 32];
+  };
+  auto mma_tap = [&](const bf16x8 (&bw)[C::KK][C::NT], int tap) {
+    const int kw = tap % C::K, kh = (tap / C::K) % C::K, kd = tap / (C::K * C::K);
+    const int tapoff = ((kd * C::HH + kh) * C::HW + kw) * C::ROWB;
+#pragma unroll
+    for (int kk = 0; kk < C::KK; ++kk) {
+      bf16x8 a[C::MTW];
+#pragma unroll
+      for (int mt = 0; mt < C::MTW; ++mt) a[mt] = *reinterpret_cast<const bf16x8 *>(lds + abase[mt] + tapoff + kk * 32);
+#pragma unroll
+      for (int mt = 0; mt < C::MTW; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < C::NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mt], bw[kk][nt], acc[mt][nt], 0, 0, 0);
+    }
+  };
+
+  bf16x8 b0[C::KK][C::NT], b1[C::KK][C::NT];
+  const int nchunks = p.Cin / C::CC;
+  const int total = nchunks * C::TAPS;          // flattened (chunk, tap) walk; the B registers ping-pong across it
+  fetch(0);
+  load_b(b0, 0, 0);
+  for (int it = 0; it < total; it += 2) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int cur = it + half;
+      if (cur >= total) break;
+      const int chunk = cur / C::TAPS, tap = cur - chunk * C::TAPS;
+      if (tap == 0) {
+        __syncthreads();                        // every wave is done reading the previous chunk's halo
+        commit();
+        __syncthreads();
+        if (chunk + 1 < nchunks) fetch((chunk + 1) * C::CC);
+      }
+      const int nxt = cur + 1;
+      if (nxt < total) {
+        const int nchunk = nxt / C::TAPS, ntap = nxt - nchunk * C::TAPS;
+        if (half == 0) load_b(b1, nchunk * C::CC, ntap); else load_b(b0, nchunk * C::CC, ntap);
+      }
+      if (half == 0) mma_tap(b0, tap); else mma_tap(b1, tap);
+    }
+  }
+
+  // ---- epilogue through LDS: the accumulators (column = Cout on the lane, rows = positions in the registers) are
+  // transposed to [position][32 Cout] fp32 rows so that every thread finishes 8 consecutive channels of one position
+  // with 16-byte bf16 loads / stores (4 adjacent lanes cover a position's 64 contiguous bytes)
+  float *eps = reinterpret_cast<float *>(lds);
+  constexpr int EROW = 36;                           // floats per position row (32 + 4: float4-aligned, bank-staggered)
+  constexpr int ITEMS = C::M * 4;                    // (position, 8-channel group) pairs per N tile
+#pragma unroll
+  for (int nt = 0; nt < C::NT; ++nt) {
+    __syncthreads();                                 // halo reads (first pass) / previous pass's row reads are done
+#pragma unroll
+    for (int mt = 0; mt < C::MTW; ++mt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+        eps[((wave * C::MTW + mt) * 32 + row) * EROW + r] = acc[mt][nt][e];
+      }
+    __syncthreads();
+    for (int item = tid; item < ITEMS; item += kThreads) {
+      const int m = item >> 2, grp = item & 3;
+      const int co = n0 + nt * 32 + grp * 8;
+      const int tw = m % C::TW, th = (m / C::TW) % C::TH, td = m / (C::TW * C::TH);
+      const int od = od0 + td, oh = oh0 + th, ow = ow0 + tw;
+      if (co >= p.Cout || od >= p.Do || oh >= p.Ho || ow >= p.Wo) continue;
+      const float4 v0 = *reinterpret_cast<const float4 *>(eps + m * EROW + grp * 8);
+      const float4 v1 = *reinterpret_cast<const float4 *>(eps + m * EROW + grp * 8 + 4);
+      float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      const size_t idx = ((((size_t)n * p.yD + od * p.ysd) * p.yH + oh * p.ysh) * p.yW + ow * p.ysw) * p.Cout + co;
+      if (p.shift) {
+        const float4 s0 = *reinterpret_cast<const float4 *>(p.shift + co), s1 = *reinterpret_cast<const float4 *>(p.shift + co + 4);
+        v[0] += s0.x; v[1] += s0.y; v[2] += s0.z; v[3] += s0.w; v[4] += s1.x; v[5] += s1.y; v[6] += s1.z; v[7] += s1.w;
+      }
+      auto add8 = [&](const bf16_t *src, size_t at) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(src + at);
+        const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[2 * j] += __uint_as_float(wds[j] << 16);
+          v[2 * j + 1] += __uint_as_float(wds[j] & 0xffff0000u);
+        }
+      };
+      if (p.add1) add8(p.add1, idx);
+      if (p.add2) add8(p.add2, idx);
+      if (p.up) {
+        const int ud = nearest_src(od, p.Du, p.Do), uh = nearest_src(oh, p.Hu, p.Ho), uw = nearest_src(ow, p.Wu, p.Wo);
+        add8(p.up, ((((size_t)n * p.Du + ud) * p.Hu + uh) * p.Wu + uw) * p.Cout + co);
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
+      if (p.mask) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(p.mask + idx);
+        const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (!(__uint_as_float(wds[j] << 16) > 0.f)) v[2 * j] = 0.f;
+          if (!(__uint_as_float(wds[j] & 0xffff0000u) > 0.f)) v[2 * j + 1] = 0.f;
+        }
+      }
+      uint4 o;
+      o.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+      o.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+      o.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+      o.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+      *reinterpret_cast<uint4 *>(p.y + idx) = o;
+    }
+  }
+}
+
+template <class C>
+int launch_bf(const BfArgs &a, hipStream_t stream) {
+  const int tiles_d = (a.Do + C::TD - 1) / C::TD, tiles_h = (a.Ho + C::TH - 1) / C::TH, tiles_w = (a.Wo + C::TW - 1) / C::TW;
+  static bool attr_done = false;
+  if (!attr_done && C::LDS_BYTES > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3d_bf16_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            C::LDS_BYTES) != hipSuccess) {
+      (void)hipGetLastError();
+      return MR3D_ERR_LAUNCH;
+    }
+    attr_done = true;
+  }
+  dim3 grid((unsigned)(a.N * tiles_d * tiles_h * tiles_w), (unsigned)(a.CoutPad / C::NB));
+  conv3d_bf16_kernel<C><<<grid, kThreads, C::LDS_BYTES, stream>>>(a, tiles_d, tiles_h, tiles_w);
+  return mr3d_launch_status();
+}
+
+template <int K, int S, int CC, int NT>
+int dispatch_tile(const BfArgs &a, hipStream_t stream) {
+  const long long wg488 = (long long)a.N * ((a.Do + 3) / 4) * ((a.Ho + 7) / 8) * ((a.Wo + 7) / 8) * (a.CoutPad / (32 * NT));
+  if constexpr (K == 3 && S == 2) {
+    return launch_bf<BfCfg<K, S, 2, 8, 8, CC, NT>>(a, stream);       // the 4x8x8 halo of a stride-2 3x3x3 does not fit LDS
+  } else {
+    if (wg488 >= 512) return launch_bf<BfCfg<K, S, 4, 8, 8, CC, NT>>(a, stream);
+    return launch_bf<BfCfg<K, S, 2, 8, 8, CC, NT>>(a, stream);
+  }
+}
+
+template <int K, int S>
+int dispatch_cc(const BfArgs &a, hipStream_t stream) {
+  const bool wide = a.CoutPad % 64 == 0;
+  if constexpr (K == 3 && S == 2) {
+    return wide ? dispatch_tile<K, S, 16, 2>(a, stream) : dispatch_tile<K, S, 16, 1>(a, stream);
+  } else {
+    if (a.Cin % 32 == 0) return wide ? dispatch_tile<K, S, 32, 2>(a, stream) : dispatch_tile<K, S, 32, 1>(a, stream);
+    return wide ? dispatch_tile<K, S, 16, 2>(a, stream) : dispatch_tile<K, S, 16, 1>(a, stream);
+  }
+}
+
+}  // namespace
+
+extern "C" int mr3d_conv3d_forward_bf16(const mr3d_conv3d_desc *d, mr3d_stream_t stream_) {
+  if (!d || !d->x || !d->w || !d->y) return MR3D_ERR_INVALID_ARG;
+  if (d->kd != d->kh || d->kh != d->kw || d->sd != d->sh || d->sh != d->sw) return MR3D_ERR_UNSUPPORTED;
+  BfArgs a;
+  a.x = (const bf16_t *)d->x; a.w = (const bf16_t *)d->w; a.y = (bf16_t *)d->y; a.shift = d->shift;
+  a.add1 = (const bf16_t *)d->add1; a.add2 = (const bf16_t *)d->add2; a.up = (const bf16_t *)d->up; a.mask = (const bf16_t *)d->mask;
+  a.N = d->n; a.D = d->d; a.H = d->h; a.W = d->w_in; a.Cin = d->cin; a.Cout = d->cout;
+  a.CoutPad = (d->cout + 31) / 32 * 32;
+  a.pd = d->pd; a.ph = d->ph; a.pw = d->pw;
+  a.Do = (d->d + 2 * d->pd - d->kd) / d->sd + 1;
+  a.Ho = (d->h + 2 * d->ph - d->kh) / d->sh + 1;
+  a.Wo = (d->w_in + 2 * d->pw - d->kw) / d->sw + 1;
+  a.Du = d->up_d; a.Hu = d->up_h; a.Wu = d->up_w;
+  a.relu = d->relu;
+  a.ysd = d->ys_d > 0 ? d->ys_d : 1; a.ysh = d->ys_h > 0 ? d->ys_h : 1; a.ysw = d->ys_w > 0 ? d->ys_w : 1;
+  a.yD = d->y_d > 0 ? d->y_d : a.Do; a.yH = d->y_h > 0 ? d->y_h : a.Ho; a.yW = d->y_w > 0 ? d->y_w : a.Wo;
+  if ((a.Do - 1) * a.ysd >= a.yD || (a.Ho - 1) * a.ysh >= a.yH || (a.Wo - 1) * a.ysw >= a.yW) return MR3D_ERR_INVALID_ARG;
+  if (a.N <= 0 || a.Do <= 0 || a.Ho <= 0 || a.Wo <= 0) return MR3D_ERR_INVALID_ARG;
+  if (a.up && (a.Du <= 0 || a.Hu <= 0 || a.Wu <= 0)) return MR3D_ERR_INVALID_ARG;
+  if (a.Cin % 16 != 0 || a.Cout % 8 != 0) return MR3D_ERR_UNSUPPORTED;
+  hipStream_t stream = mr3d_stream(stream_);
+  const int k = d->kd, s = d->sd;
+  if (k == 1 && s == 1) return dispatch_cc<1, 1>(a, stream);
+  if (k == 1 && s == 2) return dispatch_cc<1, 2>(a, stream);
+  if (k == 3 && s == 1) return dispatch_cc<3, 1>(a, stream);
+  if (k == 3 && s == 2) return dispatch_cc<3, 2>(a, stream);
+  return MR3D_ERR_UNSUPPORTED;
+}

@@ -1,0 +1,228 @@
+// bf16 weight gradient of the 3D convolutions (configs[4]; the wgrad half of autograd's backward of the Conv3d calls of
+// mmdet/models/backbones/resnet3d.py:126,139,173,251 and necks/fpn3d.py:48-64):
+//   dw[tap][ci][co] += sum_p x[p*stride + tap - pad][ci] * dy[p][co]         (fp32 accumulation, fp32 dw)
+// GEMM per tap: M = input channels, N = output channels, K = positions.  x and dy are bf16 NDHWC, i.e. both operands have
+// K as their SLOW axis in memory; the tile's x halo [position][32 ci] and dy tile [position][32 co] are staged in LDS as they
+// come (coalesced 16-byte rows) and the MFMA fragments -- 8 consecutive positions of one channel -- are read with gfx950's
+// transposing LDS read (ds_read_b64_tr_b16: a 4-position x 16-channel block per 16 lanes, delivered channel-major), two per
+// fragment.  A k-step (16 positions) is one W-row of the tile (TW = 16).
+//   * 3x3x3: the four waves split the 27 taps (7/7/7/6), one 32x32 fp32 accumulator tile per tap in registers; the dy
+//     fragment of a k-step is shared by all taps; wave 3's spare slot multiplies a fragment of ones with dy: sum_p dy
+//     (bias / BN-beta gradient) from the matrix pipe;
+//   * 1x1x1: the waves split the k-steps and their tiles meet in LDS before ONE atomic per element and workgroup.
+// Workgroups are persistent over position tiles and add their sums to dw with fp32 atomics at the end.
+#include "conv3d.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+using bf16_t = uint16_t;
+typedef __attribute__((address_space(3))) s16x4 *lds_s16x4_ptr;
+
+constexpr int kThreads = 256;
+constexpr int ROWB = 80;             // 32 channels x 2 B + 16 B of padding per staged position
+
+struct WgArgs {
+  const bf16_t *x; const bf16_t *dy; float *dw; float *dbias;
+  int N, D, H, W, Cin;
+  int Do, Ho, Wo, Cout;
+  int pd, ph, pw;
+};
+
+template <int K_, int S_, int TD_, int TH_>
+struct WgCfg {
+  static constexpr int K = K_, S = S_, TD = TD_, TH = TH_, TW = 16;
+  static constexpr bool PW1 = (K_ == 1);
+  static constexpr int LS = PW1 ? 1 : S_, GS = PW1 ? S_ : 1;
+  static constexpr int HD = (TD - 1) * LS + K, HH = (TH - 1) * LS + K, HW = (TW - 1) * LS + K, HP = HD * HH * HW;
+  static constexpr int M = TD * TH * TW, KS = TD * TH;          // positions, k-steps per tile
+  static constexpr int TAPS = K * K * K;
+  static constexpr int NTW = PW1 ? 1 : (TAPS + 3) / 4;          // accumulator slots per wave (taps, + the ones slot)
+  static constexpr int XBYTES = HP * ROWB, YBYTES = M * ROWB;
+  static constexpr int RED_BYTES = PW1 ? 4 * 2 * 32 * 33 * 4 : 0;   // 1x1x1: the four waves' (dw, sum dy) tiles meet here
+  static constexpr int LDS_BYTES = (XBYTES + YBYTES > RED_BYTES) ? XBYTES + YBYTES : RED_BYTES;
+  static_assert(LDS_BYTES <= 160 * 1024, "tile exceeds LDS");
+};
+
+__device__ __forceinline__ bf16x8 tr_frag(unsigned char *lds, int off0, int off1) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds + off0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds + off1));
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <class C>
+__global__ __launch_bounds__(kThreads, 2) void conv3d_wgrad_bf16_kernel(WgArgs p, int tiles_d, int tiles_h, int tiles_w, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char *xs = lds, *ys = lds + C::XBYTES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // transposing-read roles of this lane: 16-lane group g reads channel block cb = g&1 for k half hh = g>>1;
+  // inside the group lane 4q+pp supplies the address of row q (a position), channels 4pp..4pp+3
+  const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3, cb = g & 1, hh = g >> 1;
+  const int ci0 = blockIdx.y * 32, co0 = blockIdx.z * 32;
+  const int a_lane = ((8 * hh + q) * C::LS) * ROWB + (16 * cb + 4 * pp) * 2;     // x halo: k-th position of a row is LS apart
+  const int b_lane = (8 * hh + q) * ROWB + (16 * cb + 4 * pp) * 2;
+  const bool want_bias = p.dbias != nullptr && blockIdx.y == 0;
+
+  f32x16_t acc[C::NTW + (C::PW1 ? 1 : 0)];
+#pragma unroll
+  for (int t = 0; t < C::NTW + (C::PW1 ? 1 : 0); ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int b = tile;
+    const int tw_i = b % tiles_w; b /= tiles_w;
+    const int th_i = b % tiles_h; b /= tiles_h;
+    const int td_i = b % tiles_d; b /= tiles_d;
+    const int n = b;
+    const int od0 = td_i * C::TD, oh0 = th_i * C::TH, ow0 = tw_i * C::TW;
+    const int id0 = od0 * C::S - p.pd, ih0 = oh0 * C::S - p.ph, iw0 = ow0 * C::S - p.pw;
+    __syncthreads();                                    // the previous tile's fragments have been read
+    for (int it = tid; it < C::HP * 4; it += kThreads) {
+      const int pos = it >> 2, qq = it & 3;
+      const int hw = pos % C::HW, hh_ = (pos / C::HW) % C::HH, hd = pos / (C::HW * C::HH);
+      const int id = id0 + hd * C::GS, ih = ih0 + hh_ * C::GS, iw = iw0 + hw * C::GS;
+      const int ci = ci0 + qq * 8;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (ci < p.Cin && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
+        v = *reinterpret_cast<const uint4 *>(p.x + ((((size_t)n * p.D + id) * p.H + ih) * p.W + iw) * p.Cin + ci);
+      *reinterpret_cast<uint4 *>(xs + pos * ROWB + qq * 16) = v;
+    }
+    for (int it = tid; it < C::M * 4; it += kThreads) {
+      const int m = it >> 2, qq = it & 3;
+      const int tw = m % C::TW, th = (m / C::TW) % C::TH, td = m / (C::TW * C::TH);
+      const int od = od0 + td, oh = oh0 + th, ow = ow0 + tw;
+      const int co = co0 + qq * 8;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (co < p.Cout && od < p.Do && oh < p.Ho && ow < p.Wo)
+        v = *reinterpret_cast<const uint4 *>(p.dy + ((((size_t)n * p.Do + od) * p.Ho + oh) * p.Wo + ow) * p.Cout + co);
+      *reinterpret_cast<uint4 *>(ys + m * ROWB + qq * 16) = v;
+    }
+    __syncthreads();
+
+    if constexpr (C::PW1) {
+      for (int ks = wave; ks < C::KS; ks += 4) {        // waves split the k-steps
+        const bf16x8 bf = tr_frag(ys, b_lane + ks * 16 * ROWB, b_lane + (ks * 16 + 4) * ROWB);
+        const bf16x8 af = tr_frag(xs, a_lane + ks * 16 * ROWB, a_lane + (ks * 16 + 4) * ROWB);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[0], 0, 0, 0);
+        if (want_bias) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bf, acc[1], 0, 0, 0);
+      }
+    } else {
+      for (int ks = 0; ks < C::KS; ++ks) {
+        const int th = ks % C::TH, td = ks / C::TH;
+        const bf16x8 bf = tr_frag(ys, b_lane + ks * 16 * ROWB, b_lane + (ks * 16 + 4) * ROWB);
+        const int rowbase = a_lane + (((td * C::LS) * C::HH + th * C::LS) * C::HW) * ROWB;
+#pragma unroll
+        for (int ti = 0; ti < C::NTW; ++ti) {
+          const int tap = wave + 4 * ti;                 // wave-uniform
+          if (tap < C::TAPS) {
+            const int kw = tap % C::K, kh = (tap / C::K) % C::K, kd = tap / (C::K * C::K);
+            const int off = rowbase + ((kd * C::HH + kh) * C::HW + kw) * ROWB;
+            const bf16x8 af = tr_frag(xs, off, off + 4 * C::LS * ROWB);
+            acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[ti], 0, 0, 0);
+          } else if (tap == C::TAPS && want_bias) {
+            acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bf, acc[ti], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- write-out: C/D layout of the 32x32 tile: column (co) = lane & 31, row (ci) = (e&3) + 8*(e>>2) + 4*(lane>>5)
+  const int col = lane & 31, h2 = lane >> 5;
+  if constexpr (C::PW1) {
+    __syncthreads();
+    float *red = reinterpret_cast<float *>(lds);        // [wave][2][32][33]
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * h2;
+        red[((wave * 2 + t) * 32 + row) * 33 + col] = acc[t][e];
+      }
+    __syncthreads();
+    for (int it = tid; it < 32 * 32; it += kThreads) {
+      const int row = it >> 5, c = it & 31;
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) s += red[((w * 2 + 0) * 32 + row) * 33 + c];
+      if (ci0 + row < p.Cin && co0 + c < p.Cout) atomicAdd(p.dw + (size_t)(ci0 + row) * p.Cout + co0 + c, s);
+    }
+    if (want_bias && tid < 32 && co0 + tid < p.Cout) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) s += red[((w * 2 + 1) * 32 + 0) * 33 + tid];
+      atomicAdd(p.dbias + co0 + tid, s);
+    }
+  } else {
+#pragma unroll
+    for (int ti = 0; ti < C::NTW; ++ti) {
+      const int tap = wave + 4 * ti;
+      if (tap < C::TAPS) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = (e & 3) + 8 * (e >> 2) + 4 * h2;
+          if (ci0 + row < p.Cin && co0 + col < p.Cout)
+            atomicAdd(p.dw + ((size_t)tap * p.Cin + ci0 + row) * p.Cout + co0 + col, acc[ti][e]);
+        }
+      } else if (tap == C::TAPS && want_bias) {
+        if (h2 == 0 && co0 + col < p.Cout) atomicAdd(p.dbias + co0 + col, acc[ti][0]);      // every row of the ones tile is sum_p dy
+      }
+    }
+  }
+}
+
+template <class C>
+int launch_wg(const WgArgs &a, hipStream_t stream) {
+  const int tiles_d = (a.Do + C::TD - 1) / C::TD, tiles_h = (a.Ho + C::TH - 1) / C::TH, tiles_w = (a.Wo + C::TW - 1) / C::TW;
+  static bool attr_done = false;
+  if (!attr_done && C::LDS_BYTES > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3d_wgrad_bf16_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            C::LDS_BYTES) != hipSuccess) {
+      (void)hipGetLastError();
+      return MR3D_ERR_LAUNCH;
+    }
+    attr_done = true;
+  }
+  const long long ntiles = (long long)a.N * tiles_d * tiles_h * tiles_w;
+  if (ntiles > 0x7fffffffLL) return MR3D_ERR_UNSUPPORTED;
+  const int by = (a.Cin + 31) / 32, bz = (a.Cout + 31) / 32;
+  // persistent workgroups: about two per CU across the (ci, co) blocks, each walking many position tiles
+  long long gx = 512 / ((long long)by * bz);
+  if (gx < 1) gx = 1;
+  if (gx > ntiles) gx = ntiles;
+  dim3 grid((unsigned)gx, (unsigned)by, (unsigned)bz);
+  conv3d_wgrad_bf16_kernel<C><<<grid, kThreads, C::LDS_BYTES, stream>>>(a, tiles_d, tiles_h, tiles_w, (int)ntiles);
+  return mr3d_launch_status();
+}
+
+}  // namespace
+
+extern "C" int mr3d_conv3d_wgrad_bf16(const mr3d_conv3d_wgrad_desc *d, mr3d_stream_t stream_) {
+  if (!d || !d->x || !d->dy || !d->dw) return MR3D_ERR_INVALID_ARG;
+  if (d->kd != d->kh || d->kh != d->kw || d->sd != d->sh || d->sh != d->sw) return MR3D_ERR_UNSUPPORTED;
+  WgArgs a;
+  a.x = (const bf16_t *)d->x; a.dy = (const bf16_t *)d->dy; a.dw = d->dw; a.dbias = d->dbias;
+  a.N = d->n; a.D = d->d; a.H = d->h; a.W = d->w_in; a.Cin = d->cin; a.Cout = d->cout;
+  a.pd = d->pd; a.ph = d->ph; a.pw = d->pw;
+  a.Do = (d->d + 2 * d->pd - d->kd) / d->sd + 1;
+  a.Ho = (d->h + 2 * d->ph - d->kh) / d->sh + 1;
+  a.Wo = (d->w_in + 2 * d->pw - d->kw) / d->sw + 1;
+  if (a.N <= 0 || a.Do <= 0 || a.Ho <= 0 || a.Wo <= 0) return MR3D_ERR_INVALID_ARG;
+  if (a.Cin % 8 != 0 || a.Cout % 8 != 0) return MR3D_ERR_UNSUPPORTED;
+  hipStream_t stream = mr3d_stream(stream_);
+  const int k = d->kd, s = d->sd;
+  if (k == 3 && s == 1) return launch_wg<WgCfg<3, 1, 2, 8>>(a, stream);
+  if (k == 3 && s == 2) return launch_wg<WgCfg<3, 2, 1, 4>>(a, stream);
+  if (k == 1 && s == 1) return launch_wg<WgCfg<1, 1, 2, 8>>(a, stream);
+  if (k == 1 && s == 2) return launch_wg<WgCfg<1, 2, 2, 8>>(a, stream);
+  return MR3D_ERR_UNSUPPORTED;
+}

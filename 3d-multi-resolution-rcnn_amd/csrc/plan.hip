@@ -14,13 +14,14 @@ long long i64_of(const int32_t *lo_hi) {
 int run_one(const mr3d_op &o, mr3d_stream_t s, bool shared_ws = true) {
   const int32_t *i = o.i;
   void *const *p = o.p;
+  const bool bf16 = i[25] == MR3D_DTYPE_BF16;        // storage type of the activations the record touches
   switch (o.kind) {
     case MR3D_OP_CONV_FWD: {
       mr3d_conv3d_desc d;
       d.x = (const float *)p[0]; d.w = (const float *)p[1]; d.y = (float *)p[2]; d.shift = (const float *)p[3];
       d.add1 = (const float *)p[4]; d.add2 = (const float *)p[5]; d.up = (const float *)p[6]; d.mask = (const float *)p[7];
       memcpy(&d.n, i, sizeof(int) * 25);
-      return mr3d_conv3d_forward(&d, s);
+      return bf16 ? mr3d_conv3d_forward_bf16(&d, s) : mr3d_conv3d_forward(&d, s);
     }
     case MR3D_OP_CONV_DGRAD_S2: {
       mr3d_conv3d_desc d;
@@ -35,21 +36,27 @@ int run_one(const mr3d_op &o, mr3d_stream_t s, bool shared_ws = true) {
       memcpy(&d.n, i, sizeof(int) * 15);
       d.reserved = 0;
       d.workspace = shared_ws ? (float *)p[4] : nullptr; d.workspace_bytes = d.workspace ? i64_of(i + 15) : 0;
-      return mr3d_conv3d_wgrad(&d, s);
+      return bf16 ? mr3d_conv3d_wgrad_bf16(&d, s) : mr3d_conv3d_wgrad(&d, s);
     }
     case MR3D_OP_MAXPOOL_FWD:
+      if (bf16) return mr3d_maxpool3d_forward_bf16(p[0], p[1], (uint32_t *)p[2], i[0], i[1], i[2], i[3], i[4], s);
       return mr3d_maxpool3d_forward((const float *)p[0], (float *)p[1], (uint32_t *)p[2], i[0], i[1], i[2], i[3], i[4], s);
     case MR3D_OP_MAXPOOL_BWD:
+      if (bf16) return mr3d_maxpool3d_backward_bf16(p[0], (const uint32_t *)p[1], p[2], p[3], i[0], i[1], i[2], i[3], i[4], s);
       return mr3d_maxpool3d_backward((const float *)p[0], (const uint32_t *)p[1], (const float *)p[2], (float *)p[3], i[0],
                                      i[1], i[2], i[3], i[4], s);
     case MR3D_OP_ZERO_STUFF2:
+      if (bf16) return mr3d_zero_stuff2_bf16(p[0], p[1], i[0], i[1], i[2], i[3], i[4], i[5], i[6], i[7], s);
       return mr3d_zero_stuff2((const float *)p[0], (float *)p[1], i[0], i[1], i[2], i[3], i[4], i[5], i[6], i[7], s);
     case MR3D_OP_UPSAMPLE_ADJ:
+      if (bf16) return mr3d_upsample_nearest_adjoint_add_bf16(p[0], p[1], i[0], i[1], i[2], i[3], i[4], i[5], i[6], i[7], s);
       return mr3d_upsample_nearest_adjoint_add((const float *)p[0], (float *)p[1], i[0], i[1], i[2], i[3], i[4], i[5], i[6],
                                                i[7], s);
     case MR3D_OP_SUBSAMPLE_FWD:
+      if (bf16) return mr3d_subsample2_forward_bf16(p[0], p[1], i[0], i[1], i[2], i[3], i[4], s);
       return mr3d_subsample2_forward((const float *)p[0], (float *)p[1], i[0], i[1], i[2], i[3], i[4], s);
     case MR3D_OP_SUBSAMPLE_BWD:
+      if (bf16) return mr3d_subsample2_backward_add_bf16(p[0], p[1], i[0], i[1], i[2], i[3], i[4], s);
       return mr3d_subsample2_backward_add((const float *)p[0], (float *)p[1], i[0], i[1], i[2], i[3], i[4], s);
     case MR3D_OP_VOLUME_PACK:
       return mr3d_volume_to_ndhwc4((const float *)p[0], (float *)p[1], i[0], i[1], i[2], i[3], s);
@@ -62,10 +69,15 @@ int run_one(const mr3d_op &o, mr3d_stream_t s, bool shared_ws = true) {
     case MR3D_OP_FINISH_GRADS:
       return mr3d_finish_grads((const mr3d_layer_desc *)p[0], i[0], i[1], (const float *)p[1], (const float *)p[2],
                                (float *)p[3], s);
+    case MR3D_OP_PREP_WEIGHTS_BF16:
+      return mr3d_prepare_weights_bf16((const mr3d_layer_desc *)p[0], i[0], (const float *)p[1], p[2], s);
     case MR3D_OP_STEM_FWD:
+      if (bf16) return mr3d_stem_conv_forward_bf16out((const float *)p[0], (const float *)p[1], (const float *)p[2], p[3], i[0], i[1],
+                                                      i[2], i[3], i[4], s);
       return mr3d_stem_conv_forward((const float *)p[0], (const float *)p[1], (const float *)p[2], (float *)p[3], i[0], i[1], i[2],
                                     i[3], i[4], s);
     case MR3D_OP_STEM_WGRAD:
+      if (bf16) return mr3d_stem_conv_wgrad_bf16dy((const float *)p[0], p[1], (float *)p[2], (float *)p[3], i[0], i[1], i[2], i[3], s);
       return mr3d_stem_conv_wgrad_ws((const float *)p[0], (const float *)p[1], (float *)p[2], (float *)p[3], i[0], i[1], i[2], i[3],
                                      shared_ws ? (float *)p[4] : nullptr, (shared_ws && p[4]) ? i64_of(i + 4) : 0, s);
   }

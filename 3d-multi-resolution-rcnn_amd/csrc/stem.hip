@@ -29,7 +29,18 @@ struct StemFwdArgs {
   float *y;            // [N, D, Ho, Wo, 16]
   int N, D, H, W, Ho, Wo;
   int relu;
+  int y_bf16;          // configs[4]: y is a bf16 buffer (round to nearest even); the arithmetic stays fp32
 };
+
+__device__ __forceinline__ uint16_t stem_f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ void stem_store(const StemFwdArgs &p, size_t idx, float v) {
+  if (p.y_bf16) reinterpret_cast<uint16_t *>(p.y)[idx] = stem_f2bf(v);
+  else p.y[idx] = v;
+}
 
 // ROW = LDS row stride in floats of the FORWARD slab (multiple of 8 keeps the ds_read_b64 words aligned); the weight
 // gradient has its own geometry (StemWgGeo)
@@ -158,7 +169,7 @@ __global__ __launch_bounds__(TD * 64) void stem_fwd_kernel(StemFwdArgs p, int ti
         if (ow < p.Wo) {
           float v = acc[th][wb][r] + sh;
           if (p.relu) v = fmaxf(v, 0.f);
-          p.y[((((size_t)n * p.D + od) * p.Ho + oh) * p.Wo + ow) * 16 + li] = v;
+          stem_store(p, ((((size_t)n * p.D + od) * p.Ho + oh) * p.Wo + ow) * 16 + li, v);
         }
       }
   }
@@ -273,7 +284,7 @@ __global__ __launch_bounds__(256, 3) void stem_fwd_wino_kernel(StemFwdArgs p, in
           const float m0 = acc[0][t][r], m1 = acc[1][t][r], m2 = acc[2][t][r], m3 = acc[3][t][r];
           float v = (e == 0 ? (m0 + m1) + m2 : (m1 - m2) - m3) + sh;
           if (p.relu) v = fmaxf(v, 0.f);
-          p.y[((((size_t)n * p.D + od) * p.Ho + oh) * p.Wo + ow) * 16 + li] = v;
+          stem_store(p, ((((size_t)n * p.D + od) * p.Ho + oh) * p.Wo + ow) * 16 + li, v);
         }
       }
     }
@@ -288,6 +299,7 @@ struct StemWgradArgs {
   float *dbias;        // [16] or null
   int N, D, H, W, Ho, Wo;
   float *part;         // per-workgroup partial blocks [343][3][16] (two-stage reduction) or null (atomics)
+  int dy_bf16;         // configs[4]: dy is a bf16 buffer
 };
 
 // LDS geometry of the weight-gradient slab.  Row stride 39 (== 7 mod 32) and plane stride 849 (== 17 == 49 - 32 mod 32)
@@ -377,8 +389,16 @@ __global__ __launch_bounds__(kStemThreads) void stem_wgrad_kernel(StemWgradArgs 
       const int tw = 2 * j + (k >> 1) + 8 * (k & 1);
       const int od = d0 + td, oh = h0 + th, ow = w0 + tw;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (od < p.D && oh < p.Ho && ow < p.Wo)
-        v = *reinterpret_cast<const float4 *>(p.dy + ((((size_t)n * p.D + od) * p.Ho + oh) * p.Wo + ow) * 16 + q4 * 4);
+      if (od < p.D && oh < p.Ho && ow < p.Wo) {
+        const size_t at = ((((size_t)n * p.D + od) * p.Ho + oh) * p.Wo + ow) * 16 + q4 * 4;
+        if (p.dy_bf16) {
+          const uint2 q = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(p.dy) + at);
+          v = make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16),
+                          __uint_as_float(q.y & 0xffff0000u));
+        } else {
+          v = *reinterpret_cast<const float4 *>(p.dy + at);
+        }
+      }
       *reinterpret_cast<float4 *>(dyt + m * DYROW + q4 * 4) = v;
     }
     for (int ci = 0; ci < 3; ++ci) {
@@ -438,11 +458,11 @@ __global__ __launch_bounds__(kStemThreads) void stem_wgrad_kernel(StemWgradArgs 
 
 }  // namespace
 
-extern "C" int mr3d_stem_conv_forward(const float *x_ncdhw, const float *w_packed, const float *shift, float *y, int n, int d,
-                                      int h, int w, int relu, mr3d_stream_t stream_) {
+static int stem_forward_impl(const float *x_ncdhw, const float *w_packed, const float *shift, float *y, int y_bf16, int n, int d,
+                             int h, int w, int relu, mr3d_stream_t stream_) {
   if (!x_ncdhw || !w_packed || !y || n <= 0 || d <= 0 || h <= 0 || w <= 0) return MR3D_ERR_INVALID_ARG;
   StemFwdArgs a;
-  a.x = x_ncdhw; a.wf = w_packed; a.shift = shift; a.y = y;
+  a.x = x_ncdhw; a.wf = w_packed; a.shift = shift; a.y = y; a.y_bf16 = y_bf16;
   a.N = n; a.D = d; a.H = h; a.W = w;
   a.Ho = (h + 6 - 7) / 2 + 1; a.Wo = (w + 6 - 7) / 2 + 1;
   a.relu = relu;
@@ -460,6 +480,24 @@ extern "C" int mr3d_stem_conv_forward(const float *x_ncdhw, const float *w_packe
   return mr3d_launch_status();
 }
 
+extern "C" int mr3d_stem_conv_forward(const float *x_ncdhw, const float *w_packed, const float *shift, float *y, int n, int d,
+                                      int h, int w, int relu, mr3d_stream_t stream_) {
+  return stem_forward_impl(x_ncdhw, w_packed, shift, y, 0, n, d, h, w, relu, stream_);
+}
+
+extern "C" int mr3d_stem_conv_forward_bf16out(const float *x_ncdhw, const float *w_packed, const float *shift, void *y_bf16, int n,
+                                              int d, int h, int w, int relu, mr3d_stream_t stream_) {
+  return stem_forward_impl(x_ncdhw, w_packed, shift, (float *)y_bf16, 1, n, d, h, w, relu, stream_);
+}
+
+static int stem_wgrad_impl(const float *x_ncdhw, const float *dy, int dy_bf16, float *dw_packed, float *dbias, int n, int d, int h,
+                           int w, float *workspace, long long workspace_bytes, mr3d_stream_t stream_);
+
+extern "C" int mr3d_stem_conv_wgrad_bf16dy(const float *x_ncdhw, const void *dy_bf16, float *dw_packed, float *dbias, int n, int d,
+                                           int h, int w, mr3d_stream_t stream_) {
+  return stem_wgrad_impl(x_ncdhw, (const float *)dy_bf16, 1, dw_packed, dbias, n, d, h, w, nullptr, 0, stream_);
+}
+
 extern "C" int mr3d_stem_conv_wgrad(const float *x_ncdhw, const float *dy, float *dw_packed, float *dbias, int n, int d, int h,
                                     int w, mr3d_stream_t stream_) {
   return mr3d_stem_conv_wgrad_ws(x_ncdhw, dy, dw_packed, dbias, n, d, h, w, nullptr, 0, stream_);
@@ -467,9 +505,14 @@ extern "C" int mr3d_stem_conv_wgrad(const float *x_ncdhw, const float *dy, float
 
 extern "C" int mr3d_stem_conv_wgrad_ws(const float *x_ncdhw, const float *dy, float *dw_packed, float *dbias, int n, int d, int h,
                                        int w, float *workspace, long long workspace_bytes, mr3d_stream_t stream_) {
+  return stem_wgrad_impl(x_ncdhw, dy, 0, dw_packed, dbias, n, d, h, w, workspace, workspace_bytes, stream_);
+}
+
+static int stem_wgrad_impl(const float *x_ncdhw, const float *dy, int dy_bf16, float *dw_packed, float *dbias, int n, int d, int h,
+                           int w, float *workspace, long long workspace_bytes, mr3d_stream_t stream_) {
   if (!x_ncdhw || !dy || !dw_packed || n <= 0 || d <= 0 || h <= 0 || w <= 0) return MR3D_ERR_INVALID_ARG;
   StemWgradArgs a;
-  a.x = x_ncdhw; a.dy = dy; a.dw = dw_packed; a.dbias = dbias;
+  a.x = x_ncdhw; a.dy = dy; a.dw = dw_packed; a.dbias = dbias; a.dy_bf16 = dy_bf16;
   a.N = n; a.D = d; a.H = h; a.W = w;
   a.Ho = (h + 6 - 7) / 2 + 1; a.Wo = (w + 6 - 7) / 2 + 1;
   constexpr int lds_bytes = (StemWgGeo::SLAB + 4 * 8 * 16 * 16) * 4;       // 66.0 KiB: two workgroups per CU

@@ -59,8 +59,16 @@ class _ConvSpec:
 class ExtractFeat3D(nn.Module):
     STAGE_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
 
-    def __init__(self, depth=50, fpn_out_channels=64, num_outs=5, zero_init_residual=True, device='cuda'):
+    def __init__(self, depth=50, fpn_out_channels=64, num_outs=5, zero_init_residual=True, device='cuda',
+                 dtype=torch.float32):
+        """dtype: storage type of activations and activation gradients -- torch.float32 (the reference's arithmetic, the
+        headline path) or torch.bfloat16 (BASELINE configs[4]: bf16 maps in HBM, v_mfma_f32_32x32x16_bf16 with fp32
+        accumulation; parameters, their gradients, the folded BN shifts and the stem's arithmetic stay fp32).  The pyramid
+        is handed out in fp32 either way."""
         super().__init__()
+        assert dtype in (torch.float32, torch.bfloat16)
+        self.act_dtype = dtype
+        self.bf16 = dtype == torch.bfloat16
         if depth not in self.STAGE_BLOCKS:
             raise KeyError(f'invalid depth {depth} for the bottleneck ResNet3D engine')
         assert num_outs == 5, 'the shipped config uses 4 pyramid levels + 1 max-pooled level (configs/...py:11-15)'
@@ -165,6 +173,21 @@ class ExtractFeat3D(nn.Module):
         self.register_buffer('_scratch', torch.zeros(soff, dtype=torch.float32, device=self.device), persistent=False)
         self.max_cout = max(s.cout for s in self.specs)
         self._build_table()
+        if self.bf16:
+            # bf16 operand arena (csrc/aux_ops.hip prep_weights_bf16_kernel): every conv but the stem (fp32 arithmetic)
+            r16, r32 = (lambda v: -(-v // 16) * 16), (lambda v: -(-v // 32) * 32)
+            off16, self._layer_offsets16 = 0, {}
+            for s in self.specs:
+                if s.k == 7:
+                    continue
+                o = dict(wf=off16); off16 += -(-s.taps * r16(s.cin_pad) * r32(s.cout) // 128) * 128
+                if s.need_dgrad:
+                    o['wb'] = off16; off16 += -(-s.taps * r16(s.cout) * r32(s.cin_pad) // 128) * 128
+                else:
+                    o['wb'] = -1
+                self._layer_offsets16[s.index] = o
+            self.register_buffer('_packed16', torch.zeros(off16, dtype=torch.bfloat16, device=self.device), persistent=False)
+            self._build_table16()
 
     def _bind_storage(self, arena, grads, param_off, stats_off, first=False):
         """Point every parameter / running statistic (and every parameter's .grad) at `arena` / `grads`: trainable
@@ -235,6 +258,22 @@ class ExtractFeat3D(nn.Module):
         else:
             self.register_buffer('_table', raw, persistent=False)
 
+    def _build_table16(self):
+        """layer table of mr3d_prepare_weights_bf16: parameter offsets as in the fp32 table, wf_off / wb_off = offsets in
+        bf16 elements into the bf16 operand arena"""
+        idx = sorted(self._layer_offsets16)
+        table = (_hip.LayerDesc * len(idx))()
+        for k, li in enumerate(idx):
+            L, src, o = table[k], self._table_host[li], self._layer_offsets16[li]
+            ctypes.memmove(ctypes.addressof(L), ctypes.addressof(src), ctypes.sizeof(_hip.LayerDesc))
+            L.wf_off, L.wb_off, L.shift_off, L.scale_off = o['wf'], o['wb'], -1, -1
+        self._table16_len = len(idx)
+        raw = torch.from_numpy(np.frombuffer(bytes(table), dtype=np.uint8).copy()).to(self.device)
+        if hasattr(self, '_table16'):
+            self._table16.copy_(raw)
+        else:
+            self.register_buffer('_table16', raw, persistent=False)
+
     def rehome(self, arena, grads, param_off, stats_off):
         """Move the engine's parameters into a caller-owned flat arena (and gradient mirror) so that the WHOLE detector
         -- backbone, neck and every head -- is one buffer and one all-reduce (mmdet/core/utils/dist_utils.py:22-28;
@@ -246,6 +285,8 @@ class ExtractFeat3D(nn.Module):
         assert grads.numel() >= param_off + self.num_trainable
         self._bind_storage(arena, grads, param_off, stats_off)
         self._build_table()
+        if self.bf16:
+            self._build_table16()
         self._plans = {}
 
     # ------------------------------------------------------------------ parameters
@@ -302,9 +343,20 @@ class ExtractFeat3D(nn.Module):
 
     # ------------------------------------------------------------------ plan construction
     def _w(self, spec, kind):
+        if self.bf16 and kind in ('wf', 'wb') and spec.k != 7:
+            off = self._layer_offsets16[spec.index][kind]
+            assert off >= 0
+            return self._packed16.data_ptr() + 2 * off
         off = getattr(self._table_host[spec.index], kind + '_off')
         assert off >= 0
         return self._packed.data_ptr() + 4 * off
+
+    def _op(self, kind, ptrs=(), ints=(), alpha=0.0):
+        """plan record whose activations have the engine's storage type (mr3d_op.i[25])"""
+        o = _hip.make_op(kind, ptrs, ints, alpha)
+        if self.bf16:
+            o.i[25] = _hip.DTYPE_BF16
+        return o
 
     def _s(self, spec, kind):
         return self._scratch.data_ptr() + 4 * getattr(self._table_host[spec.index], kind + '_off')
@@ -322,7 +374,7 @@ class ExtractFeat3D(nn.Module):
     def _conv_fwd(self, x, spec, y, add1=None, add2=None, up=None, relu=False):
         ints = self._conv_ints(x.shape, spec.cin_pad, spec.cout, spec.k, spec.stride, spec.pad,
                                up=None if up is None else up.shape[1:4], relu=relu)
-        return _hip.make_op(_hip.OP_CONV_FWD, [x, self._w(spec, 'wf'), y, self._w(spec, 'shift'), add1, add2, up, None], ints)
+        return self._op(_hip.OP_CONV_FWD, [x, self._w(spec, 'wf'), y, self._w(spec, 'shift'), add1, add2, up, None], ints)
 
     def _conv_dgrad(self, dy, spec, dx, add1=None, add2=None, mask=None, scatter=False):
         """dx = conv_transpose(dy) as a stride-1 conv with flipped/transposed folded weights.  `dy` must already
@@ -333,16 +385,16 @@ class ExtractFeat3D(nn.Module):
             ints = self._conv_ints(dy.shape, spec.cout, spec.cin_pad, k, (1, 1, 1), pad, ys=spec.stride, ydims=dx.shape[1:4])
         else:
             ints = self._conv_ints(dy.shape, spec.cout, spec.cin_pad, k, (1, 1, 1), pad)
-        return _hip.make_op(_hip.OP_CONV_FWD, [dy, self._w(spec, 'wb'), dx, None, add1, add2, None, mask], ints)
+        return self._op(_hip.OP_CONV_FWD, [dy, self._w(spec, 'wb'), dx, None, add1, add2, None, mask], ints)
 
     def _conv_wgrad(self, x, dy, spec):
         n, d, h, w, _ = x.shape
         ints = [n, d, h, w, spec.cin_pad, spec.cout, spec.k, spec.k, spec.k, *spec.stride, spec.pad, spec.pad, spec.pad]
         ints = ints + [0] * (26 - len(ints)) + [1]          # i[26] = 1: may run on the plan's side stream
-        return _hip.make_op(_hip.OP_CONV_WGRAD, [x, dy, self._s(spec, 'dwraw'), self._s(spec, 'dbias')], ints)
+        return self._op(_hip.OP_CONV_WGRAD, [x, dy, self._s(spec, 'dwraw'), self._s(spec, 'dbias')], ints)
 
-    def _new(self, shape, dtype=torch.float32):
-        t = torch.empty(tuple(shape), dtype=dtype, device=self.device)
+    def _new(self, shape, dtype=None):
+        t = torch.empty(tuple(shape), dtype=dtype or self.act_dtype, device=self.device)
         self._building.append(t)      # plans hold raw pointers: every buffer must outlive them
         return t
 
@@ -358,24 +410,26 @@ class ExtractFeat3D(nn.Module):
         nL = len(self.specs)
         prep = _hip.make_op(_hip.OP_PREP_WEIGHTS, [self._table, self._arena, self._packed], [nL])
         fwd.append(prep)
+        if self.bf16:
+            fwd.append(_hip.make_op(_hip.OP_PREP_WEIGHTS_BF16, [self._table16, self._arena, self._packed16], [self._table16_len]))
         # ---------------- forward
-        P.x_in = self._new((N, 3, D, H, W))
+        P.x_in = self._new((N, 3, D, H, W), torch.float32)
         stem = self.specs[0]
         P.stem_out = self._new(self._out_shape((N, D, H, W, 4), stem))
-        generic_stem = os.environ.get('MR3D_GENERIC_STEM') == '1'      # A/B switch: generic implicit-GEMM kernels
+        generic_stem = os.environ.get('MR3D_GENERIC_STEM') == '1' and not self.bf16     # A/B switch: generic implicit-GEMM kernels
         if generic_stem:
             P.x4 = self._new((N, D, H, W, 4))
             fwd.append(_hip.make_op(_hip.OP_VOLUME_PACK, [P.x_in, P.x4], [N, D, H, W]))
             fwd.append(self._conv_fwd(P.x4, stem, P.stem_out, relu=True))
         else:
             # the stem kernels read the planar volume directly (no NDHWC repack)
-            fwd.append(_hip.make_op(_hip.OP_STEM_FWD, [P.x_in, self._w(stem, 'wf'), self._w(stem, 'shift'), P.stem_out],
-                                    [N, D, H, W, 1]))
+            fwd.append(self._op(_hip.OP_STEM_FWD, [P.x_in, self._w(stem, 'wf'), self._w(stem, 'shift'), P.stem_out],
+                                [N, D, H, W, 1]))
         _, sd, sh, sw, _ = P.stem_out.shape
         pshape = (N, (sd - 1) // 2 + 1, (sh - 1) // 2 + 1, (sw - 1) // 2 + 1, 16)
         P.pool_out = self._new(pshape)
         P.pool_idx = self._new(pshape[:4] + (4,), torch.int32)
-        fwd.append(_hip.make_op(_hip.OP_MAXPOOL_FWD, [P.stem_out, P.pool_out, P.pool_idx], [N, sd, sh, sw, 16]))
+        fwd.append(self._op(_hip.OP_MAXPOOL_FWD, [P.stem_out, P.pool_out, P.pool_idx], [N, sd, sh, sw, 16]))
         x = P.pool_out
         P.blk = []
         stage_outs = []
@@ -411,13 +465,13 @@ class ExtractFeat3D(nn.Module):
             P.outs.append(o)
         _, d5, h5, w5, _ = P.outs[3].shape
         p6 = self._new((N, (d5 - 1) // 2 + 1, (h5 - 1) // 2 + 1, (w5 - 1) // 2 + 1, self.fpn_out))
-        fwd.append(_hip.make_op(_hip.OP_SUBSAMPLE_FWD, [P.outs[3], p6], [N, d5, h5, w5, self.fpn_out]))
+        fwd.append(self._op(_hip.OP_SUBSAMPLE_FWD, [P.outs[3], p6], [N, d5, h5, w5, self.fpn_out]))
         P.outs.append(p6)
 
         # ---------------- backward
         P.gouts = [self._new(o.shape) for o in P.outs]
         bwd.append(_hip.make_op(_hip.OP_MEMSET0, [self._scratch], _hip.split64(self._scratch.numel() * 4)))
-        bwd.append(_hip.make_op(_hip.OP_SUBSAMPLE_BWD, [P.gouts[4], P.gouts[3]], [N, d5, h5, w5, self.fpn_out]))
+        bwd.append(self._op(_hip.OP_SUBSAMPLE_BWD, [P.gouts[4], P.gouts[3]], [N, d5, h5, w5, self.fpn_out]))
         glat = [self._new(l.shape) for l in P.lat]
         gC_lat = [self._new(c.shape) for c in P.C]
         for i in range(4):
@@ -425,8 +479,8 @@ class ExtractFeat3D(nn.Module):
             bwd.append(self._conv_dgrad(P.gouts[i], self.fpnconv[i], glat[i]))
             if i > 0:
                 nf, df, hf, wf, c = glat[i - 1].shape
-                bwd.append(_hip.make_op(_hip.OP_UPSAMPLE_ADJ, [glat[i - 1], glat[i]],
-                                        [N, df, hf, wf, glat[i].shape[1], glat[i].shape[2], glat[i].shape[3], c]))
+                bwd.append(self._op(_hip.OP_UPSAMPLE_ADJ, [glat[i - 1], glat[i]],
+                                    [N, df, hf, wf, glat[i].shape[1], glat[i].shape[2], glat[i].shape[3], c]))
             bwd.append(self._conv_wgrad(P.C[i], glat[i], self.lateral[i]))
             # the gradient of the LAST stage output only comes through its lateral conv: apply its ReLU mask here
             bwd.append(self._conv_dgrad(glat[i], self.lateral[i], gC_lat[i], mask=P.C[3] if i == 3 else None))
@@ -441,6 +495,11 @@ class ExtractFeat3D(nn.Module):
             g_a1 = self._new(st['a1'].shape)
             if b['stride'] == 1:
                 bwd.append(self._conv_dgrad(g_a2, b['conv2'], g_a1, mask=st['a1']))
+            elif self.bf16:
+                # strided 3x3x3, bf16: zero-stuff the coarse gradient onto a1's grid, then the stride-1 data-gradient kernel
+                stuffed = self._new(st['a1'].shape[:4] + (b['conv2'].cout,))
+                bwd.append(self._op(_hip.OP_ZERO_STUFF2, [g_a2, stuffed], [N, *g_a2.shape[1:4], *stuffed.shape[1:4], b['conv2'].cout]))
+                bwd.append(self._conv_dgrad(stuffed, b['conv2'], g_a1, mask=st['a1']))
             else:
                 # strided 3x3x3: parity-decomposed data gradient straight from the coarse g_a2 (no zero-stuffing)
                 sp = b['conv2']
@@ -458,7 +517,7 @@ class ExtractFeat3D(nn.Module):
                 if b['stride'] == 1:
                     bwd.append(self._conv_dgrad(g, b['dsconv'], t))
                 else:
-                    bwd.append(_hip.make_op(_hip.OP_MEMSET0, [t], _hip.split64(t.numel() * 4)))
+                    bwd.append(_hip.make_op(_hip.OP_MEMSET0, [t], _hip.split64(t.numel() * t.element_size())))
                     bwd.append(self._conv_dgrad(g, b['dsconv'], t, scatter=True))
                 bwd.append(self._conv_dgrad(g_a1, b['conv1'], gx, add1=t, add2=lat_part, mask=mask))
             else:
@@ -466,12 +525,12 @@ class ExtractFeat3D(nn.Module):
                 bwd.append(self._conv_dgrad(g_a1, b['conv1'], gx, add1=g, mask=mask))
             g = gx
         g_stem = self._new(P.stem_out.shape)
-        bwd.append(_hip.make_op(_hip.OP_MAXPOOL_BWD, [g, P.pool_idx, P.stem_out, g_stem], [N, sd, sh, sw, 16]))
+        bwd.append(self._op(_hip.OP_MAXPOOL_BWD, [g, P.pool_idx, P.stem_out, g_stem], [N, sd, sh, sw, 16]))
         if generic_stem:
             bwd.append(self._conv_wgrad(P.x4, g_stem, stem))
         else:
-            bwd.append(_hip.make_op(_hip.OP_STEM_WGRAD, [P.x_in, g_stem, self._s(stem, 'dwraw'), self._s(stem, 'dbias')],
-                                    [N, D, H, W] + [0] * 22 + [1]))
+            bwd.append(self._op(_hip.OP_STEM_WGRAD, [P.x_in, g_stem, self._s(stem, 'dwraw'), self._s(stem, 'dbias')],
+                                [N, D, H, W] + [0] * 22 + [1]))
         bwd.append(_hip.make_op(_hip.OP_FINISH_GRADS, [self._table, self._arena, self._scratch, self._grad_arena],
                                 [nL, self.max_cout]))
         P.fwd_ops, P.bwd_ops = fwd, bwd
@@ -503,6 +562,8 @@ class ExtractFeat3D(nn.Module):
         with torch.cuda.device(self.device):
             P.fwd.run(self.device)
         self._last = P
+        if self.bf16:       # the pyramid leaves in fp32 (heads, RoIAlign3D and the losses compute in fp32)
+            return tuple(o.permute(0, 4, 1, 2, 3).float() for o in P.outs)
         return tuple(o.permute(0, 4, 1, 2, 3) for o in P.outs)
 
     def capture(self, P):
@@ -545,7 +606,7 @@ class ExtractFeat3D(nn.Module):
                 src = gbuf
             else:
                 gl = g.permute(0, 2, 3, 4, 1)
-                direct = (i < 3 and g.dtype == torch.float32 and gl.is_contiguous() and g.device == gbuf.device and
+                direct = (i < 3 and g.dtype == gbuf.dtype and gl.is_contiguous() and g.device == gbuf.device and
                           g.data_ptr() % 16 == 0 and not self._captured(P))
                 src = gl if direct else gbuf
                 if not direct:
@@ -595,6 +656,8 @@ class _ExtractFeatFn(torch.autograd.Function):
         ctx.engine = engine
         outs = engine.forward_features(img, slot)
         ctx.plan = engine._last
+        if engine.bf16:
+            return outs                   # already fp32 copies of the plan's bf16 buffers
         return tuple(o.clone(memory_format=torch.preserve_format) for o in outs)
 
     @staticmethod

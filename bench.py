@@ -29,6 +29,7 @@ import torch  # noqa: E402
 # algorithmic FLOPs of one forward+backward of backbone+FPN on a 1x3x80x512x512 volume
 FLOP_FWD_BWD_512 = 1124.38e9
 PEAK_FP32_MATRIX = 157.3e12          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32 peak
+PEAK_BF16_MATRIX = 2516.6e12         # dense bf16 MFMA (16x the fp32 matrix rate; no sparsity)
 
 
 def parse():
@@ -44,6 +45,9 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the cpu_baseline sample')
     ap.add_argument('--per-kernel', action='store_true', help='also print a per-kernel time table to stderr')
     ap.add_argument('--per-op', action='store_true', help='also print every plan op with its time to stderr')
+    ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32',
+                    help='storage type of the activations: f32 = the headline metric (the reference arithmetic); bf16 = BASELINE '
+                         'configs[4] (bf16 maps in HBM, bf16 MFMA with fp32 accumulation)')
     ap.add_argument('--config', choices=['backbone', 'two_stage'], default='backbone',
                     help="backbone = BASELINE configs[1] (the headline metric); two_stage = configs[2]/[3]: the whole "
                          "single-pathway training step with ONE all-reduce of the detector's 26 M-element gradient arena")
@@ -372,7 +376,7 @@ def main():
     D, H, W = a.vol
     if a.config == 'two_stage':
         return two_stage_main(a, rank, world, dev)
-    eng = ExtractFeat3D(device=dev)
+    eng = ExtractFeat3D(device=dev, dtype=torch.bfloat16 if a.dtype == 'bf16' else torch.float32)
     reduce_buf = eng.flat_grads
     if (world > 1 or force_dist) and not a.backbone_only_allreduce:
         # The reference exchanges ONE flat buffer holding every gradient of the detector (dist_utils.py:22-28): 25.98 M fp32
@@ -388,7 +392,7 @@ def main():
         broadcast_params(eng.flat_params)                       # identical initial weights on all ranks (mmcv DDP init)
     x = torch.randn(1, 3, D, H, W, device=dev)
     outs = eng.forward_features(x)
-    cots = [torch.randn(o.shape, device=dev).contiguous(memory_format=torch.channels_last_3d) for o in outs]
+    cots = [torch.randn(o.shape, device=dev).to(eng.act_dtype).contiguous(memory_format=torch.channels_last_3d) for o in outs]
     plan = eng._plan_for(x.shape)
     scale = (D * H * W) / (80.0 * 512 * 512)
 
@@ -480,7 +484,7 @@ def main():
             op = (plan.fwd if which == 'f' else plan.bwd).array[k]
             _, fl = _hip.op_kernel_key(op)
             factor, tag = 1.0, 'direct'
-            if op.kind == _hip.OP_CONV_FWD:
+            if op.kind == _hip.OP_CONV_FWD and op.i[25] == 0:
                 v = _hip.op_conv_variant(op)
                 factor = float(v.mfma_issue_factor)
                 tag = ('streaming pointwise' if v.streaming_pointwise else
@@ -491,29 +495,30 @@ def main():
         issue_factor = issued_flops / groups[dom]['flops'] if groups[dom]['flops'] else 1.0
         ach = alg * issue_factor
         ms_per_step = el * 1e3 / a.steps
+        peak = PEAK_BF16_MATRIX if '_bf16<' in dom else PEAK_FP32_MATRIX
         msg = reduce_buf.numel() * 4 / 1e6
         res = {
-            'metric': 'train iters/sec on 512x512x80 vols (ResNet3D-50+FPN3D forward+backward, fp32)',
+            'metric': f'train iters/sec on 512x512x80 vols (ResNet3D-50+FPN3D forward+backward, {"fp32" if a.dtype == "f32" else "bf16 storage / fp32 accumulate"})',
             'value': world * a.steps / el, 'unit': 'iters/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
-            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype,
             'data': 'synthetic',
-            'config': {'workload': f'BASELINE configs[1]: 1x3x{D}x{H}x{W} fp32 volume per GPU, ResNet3D-50 + FPN3D '
-                                   'forward+backward (eval-mode BN, random-init weights)' +
+            'config': {'workload': f'BASELINE configs[{1 if a.dtype == "f32" else 4}] backbone: 1x3x{D}x{H}x{W} fp32 volume per GPU, ResNet3D-50 + FPN3D '
+                                   'forward+backward (eval-mode BN, random-init weights' + ('' if a.dtype == 'f32' else '; bf16 activations') + ')' +
                                    ('' if world == 1 else f' + one SUM all-reduce of a {msg:.1f} MB flat fp32 gradient arena over RCCL' +
                                     ('' if a.backbone_only_allreduce else " (the whole detector's message size, SURVEY 8e)")),
                        'global_batch': world, 'parallelism': f'dp{world}'},
             # frac = MFMA FLOP/s actually ISSUED by the dominant kernel / fp32 matrix peak (a utilisation, <= 1);
             # algorithmic_* = 2*MAC of the convolutions it computes / time (exceeds `achieved` for Winograd instances)
-            'roofline': {'bound': 'mfma', 'kernel': dom, 'achieved': ach / 1e12, 'peak': PEAK_FP32_MATRIX / 1e12,
-                         'unit': 'TFLOP/s', 'frac': ach / PEAK_FP32_MATRIX, 'traffic': committed_traffic(dom),
-                         'algorithmic_achieved': alg / 1e12, 'algorithmic_frac': alg / PEAK_FP32_MATRIX,
+            'roofline': {'bound': 'mfma', 'kernel': dom, 'achieved': ach / 1e12, 'peak': peak / 1e12,
+                         'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': committed_traffic(dom),
+                         'algorithmic_achieved': alg / 1e12, 'algorithmic_frac': alg / peak,
                          'mfma_issue_factor': issue_factor, 'variants': variants,
                          'avg_launch_ms': dom_ms / launches if launches else None, 'launches_per_step': groups[dom]['n'],
                          'timing': 'HIP events on the launch stream around every launch of this kernel inside the timed steps '
                                    '(the side-stream weight gradients overlap them, as in production)',
                          'whole_step_frac': FLOP_FWD_BWD_512 * scale / (ms_per_step * 1e-3) / PEAK_FP32_MATRIX},
         }
-        if world == 1 and not a.no_aux:
+        if world == 1 and not a.no_aux and a.dtype == 'f32':
             try:
                 res['aux'] = {k: (round(v, 4) if ('frac' in k or 'per_s' in k) else round(v, 1)) for k, v in ops_microbench(dev).items()}
                 ms = two_stage_step_ms((D, H, W))
@@ -526,7 +531,7 @@ def main():
                 res['aux']['shipped_2scales_iters_per_s'] = round(1e3 / ms2, 2)
             except Exception as exc:  # the headline number must still print
                 res['aux'] = {'error': repr(exc)}
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and a.dtype == 'f32':
             res['cpu_baseline'] = cpu_baseline(a.cpu_seconds)
             try:        # C2 (numpy NMS3D) and C3 (C RoIAlign3D, 1 thread / OpenMP)
                 res['cpu_baseline']['ops'] = cpu_baseline_ops(min(a.cpu_seconds, 12.0))

@@ -421,6 +421,37 @@ int mr3d_stem_conv_wgrad_ws(const float *x_ncdhw, const float *dy, float *dw_pac
                             int n, int d, int h, int w, float *workspace, long long workspace_bytes, mr3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * bf16 storage path (BASELINE.json configs[4]): the same layers with activations and activation gradients stored as bf16
+ * NDHWC in HBM, multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; parameters, parameter gradients, folded
+ * shifts and the stem's input volume stay fp32.  Descriptors are the fp32 ones with every activation / weight pointer
+ * reinterpreted as bf16 (shift, dw, dbias: fp32).  Reference: the autocast-style run of the Conv3d / BatchNorm3d / ReLU
+ * graph of resnet3d.py:198-233,467-478 and fpn3d.py:95-134 (the reference itself ships fp32 only; its RoIAlign kernels
+ * dispatch half, roi_align_kernel.cu:323).
+ *   conv3d_forward_bf16   cubic kernels 1 / 3, stride 1 / 2, Cin % 16 == 0, Cout % 8 == 0; weights packed by
+ *                         mr3d_prepare_weights_bf16: wf16[tap][Cin16/8][Cout32][8] (dgrad: wb16[taps-1-tap][Cout16/8][Cin32][8]),
+ *                         channel counts rounded up to 16 (K) / 32 (N), zero filled.
+ *   conv3d_wgrad_bf16     x, dy bf16; dw fp32 [taps][Cin][Cout] PRE-ZEROED (atomics), dbias fp32 or NULL.
+ *   prepare_weights_bf16  table as mr3d_prepare_weights with wf_off / wb_off = offsets in bf16 ELEMENTS into packed16
+ *                         (shift / scale are produced by the fp32 call).
+ *   stem: fp32 volume and fp32 MFMA arithmetic, bf16 output (forward) / bf16 dy (weight gradient).
+ * ---------------------------------------------------------------------------------------------- */
+int mr3d_conv3d_forward_bf16(const mr3d_conv3d_desc *desc, mr3d_stream_t stream);
+int mr3d_conv3d_wgrad_bf16(const mr3d_conv3d_wgrad_desc *desc, mr3d_stream_t stream);
+int mr3d_prepare_weights_bf16(const mr3d_layer_desc *table, int num_layers, const float *params, void *packed16, mr3d_stream_t s);
+int mr3d_maxpool3d_forward_bf16(const void *x, void *y, uint32_t *argmax, int n, int d, int h, int w, int c, mr3d_stream_t s);
+int mr3d_maxpool3d_backward_bf16(const void *dy, const uint32_t *argmax, const void *relu_of, void *dx, int n, int d, int h, int w,
+                                 int c, mr3d_stream_t s);
+int mr3d_zero_stuff2_bf16(const void *src, void *dst, int n, int do_, int ho, int wo, int d, int h, int w, int c, mr3d_stream_t s);
+int mr3d_upsample_nearest_adjoint_add_bf16(const void *grad_fine, void *grad_coarse, int n, int df, int hf, int wf, int dc, int hc,
+                                           int wc, int c, mr3d_stream_t s);
+int mr3d_subsample2_forward_bf16(const void *x, void *y, int n, int d, int h, int w, int c, mr3d_stream_t s);
+int mr3d_subsample2_backward_add_bf16(const void *dy, void *dx, int n, int d, int h, int w, int c, mr3d_stream_t s);
+int mr3d_stem_conv_forward_bf16out(const float *x_ncdhw, const float *w_packed, const float *shift, void *y_bf16, int n, int d,
+                                   int h, int w, int relu, mr3d_stream_t stream);
+int mr3d_stem_conv_wgrad_bf16dy(const float *x_ncdhw, const void *dy_bf16, float *dw_packed, float *dbias, int n, int d, int h,
+                                int w, mr3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Plan executor: runs a pre-built list of the operations above with ONE call (the host-side loop of
  * ~500 launches per training step stays in native code; the call only enqueues, so it can be captured
  * in a hipGraph).  Replaces the Python module-by-module dispatch of ResNet3D.forward / FPN3D.forward
@@ -447,8 +478,13 @@ typedef enum {
   MR3D_OP_CONV_FWD = 1, MR3D_OP_CONV_WGRAD = 2, MR3D_OP_MAXPOOL_FWD = 3, MR3D_OP_MAXPOOL_BWD = 4,
   MR3D_OP_ZERO_STUFF2 = 5, MR3D_OP_UPSAMPLE_ADJ = 6, MR3D_OP_SUBSAMPLE_FWD = 7, MR3D_OP_SUBSAMPLE_BWD = 8,
   MR3D_OP_VOLUME_PACK = 9, MR3D_OP_MEMSET0 = 10, MR3D_OP_AXPY = 11, MR3D_OP_PREP_WEIGHTS = 12,
-  MR3D_OP_FINISH_GRADS = 13, MR3D_OP_STEM_FWD = 14, MR3D_OP_STEM_WGRAD = 15, MR3D_OP_CONV_DGRAD_S2 = 16
+  MR3D_OP_FINISH_GRADS = 13, MR3D_OP_STEM_FWD = 14, MR3D_OP_STEM_WGRAD = 15, MR3D_OP_CONV_DGRAD_S2 = 16,
+  MR3D_OP_PREP_WEIGHTS_BF16 = 17      /* p = {table16, params, packed16}   i = {num_layers} */
 } mr3d_op_kind;
+/* i[25] of a record = storage type of the activations it touches: 0 = fp32, MR3D_DTYPE_BF16 = bf16 (the *_bf16 entry
+ * points below; CONV_FWD / CONV_WGRAD / MAXPOOL_* / ZERO_STUFF2 / UPSAMPLE_ADJ / SUBSAMPLE_* / STEM_FWD (bf16 output) /
+ * STEM_WGRAD (bf16 dy)).  CONV_DGRAD_S2 has no bf16 form: strided 3x3x3 data gradients take ZERO_STUFF2 + CONV_FWD. */
+#define MR3D_DTYPE_BF16 1
 typedef struct {
   int32_t kind;
   int32_t i[27];

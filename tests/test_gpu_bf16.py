@@ -1,0 +1,186 @@
+"""bf16 storage path (BASELINE.json configs[4]): v_mfma_f32_32x32x16_bf16 kernels against float64 torch.
+
+Tolerances (stated, not tuned to pass):
+  * a kernel's own arithmetic is exact products of bf16 inputs accumulated in fp32, so against a float64 reference computed
+    FROM THE SAME bf16-rounded inputs the only error of a forward / data-gradient launch is the final rounding of the output
+    to bf16: <= 2^-8 relative per element (asserted as 2^-8 of the tensor's scale + 1e-3 L2); weight gradients leave in
+    fp32: 1e-4 like the fp32 kernels;
+  * the whole engine in bf16 against the fp32 restatement accumulates one such rounding per layer (~70 layers): pyramid
+    outputs within 3e-2 of their scale, parameter gradients within 8e-2 in L2 (evaluated at the engine's own activation
+    pattern, tests/test_extract_feat.py)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+BF16_EPS = 2.0 ** -8
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _cl(x):
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def _close(got, exp, what, max_rel, l2_rel):
+    got, exp = got.double(), exp.double()
+    scale = exp.abs().max().clamp(min=1e-30)
+    e_max = ((got - exp).abs().max() / scale).item()
+    e_l2 = ((got - exp).norm() / exp.norm().clamp(min=1e-30)).item()
+    assert e_max <= max_rel and e_l2 <= l2_rel, f'{what}: max-norm rel {e_max:.2e} (<= {max_rel:.1e}), L2 rel {e_l2:.2e} (<= {l2_rel:.1e})'
+
+
+CASES = [
+    # (Cin, Cout, k, stride, pad, (D,H,W))
+    (16, 16, 1, 1, 0, (5, 9, 11)),
+    (16, 64, 1, 1, 0, (4, 8, 8)),
+    (64, 16, 1, 1, 0, (6, 10, 7)),
+    (128, 32, 1, 1, 0, (4, 9, 8)),
+    (256, 64, 1, 1, 0, (5, 16, 15)),
+    (512, 128, 1, 1, 0, (2, 4, 5)),
+    (64, 128, 1, 2, 0, (6, 10, 12)),
+    (256, 512, 1, 2, 0, (5, 8, 7)),
+    (16, 16, 3, 1, 1, (6, 10, 12)),
+    (32, 32, 3, 1, 1, (5, 9, 9)),
+    (64, 64, 3, 1, 1, (8, 16, 17)),
+    (64, 64, 3, 1, 1, (12, 40, 40)),          # enough tiles for the 4x8x8 instance
+    (128, 128, 3, 1, 1, (3, 6, 8)),
+    (32, 32, 3, 2, 1, (8, 16, 14)),
+    (64, 64, 3, 2, 1, (7, 11, 9)),
+    (64, 8, 1, 1, 0, (4, 8, 8)),              # Cout % 8 only (RPN regression head 64 -> 6 padded to 8)
+]
+
+
+@pytest.mark.parametrize('cin,cout,k,stride,pad,dhw', CASES)
+def test_conv3d_bf16_forward_and_dgrad(dev, cin, cout, k, stride, pad, dhw):
+    from mr3d_amd import _hip
+    g = torch.Generator().manual_seed(cin * 1000 + cout + k + stride)
+    x = _bf(torch.randn((2, cin) + dhw, generator=g))
+    w = _bf(torch.randn((cout, cin, k, k, k), generator=g) / np.sqrt(cin * k ** 3))
+    ref = F.conv3d(x.double(), w.double(), None, stride, pad)
+    y = _hip.conv3d_forward_bf16(_cl(x).to(dev).bfloat16(), _hip.pack_conv_weight_bf16(w).to(dev), cout, (k,) * 3, (stride,) * 3, (pad,) * 3)
+    assert y.dtype == torch.bfloat16 and tuple(y.shape) == (2,) + tuple(ref.shape[2:]) + (cout,)
+    _close(y.float().permute(0, 4, 1, 2, 3).cpu(), ref, 'forward', BF16_EPS, 3e-3)
+    if stride == 1 and cout % 16 == 0:
+        # data gradient = stride-1 conv of dy with flipped, transposed taps (padding k-1-pad)
+        dy = _bf(torch.randn(ref.shape, generator=g))
+        wt = w.flip(2, 3, 4).transpose(0, 1).contiguous()
+        refd = F.conv3d(dy.double(), wt.double(), None, 1, k - 1 - pad)
+        dx = _hip.conv3d_forward_bf16(_cl(dy).to(dev).bfloat16(), _hip.pack_conv_weight_bf16(wt).to(dev), cin, (k,) * 3, (1, 1, 1),
+                                      (k - 1 - pad,) * 3)
+        _close(dx.float().permute(0, 4, 1, 2, 3).cpu(), refd, 'dgrad', BF16_EPS, 3e-3)
+
+
+def test_conv3d_bf16_fused_epilogue(dev):
+    from mr3d_amd import _hip
+    g = torch.Generator().manual_seed(1)
+    x = _bf(torch.randn((1, 64, 6, 10, 12), generator=g))
+    w = _bf(torch.randn((64, 64, 3, 3, 3), generator=g) / np.sqrt(64 * 27))
+    shift = torch.randn(64, generator=g)
+    add1, add2 = _bf(torch.randn((1, 64, 6, 10, 12), generator=g)), _bf(torch.randn((1, 64, 6, 10, 12), generator=g))
+    up = _bf(torch.randn((1, 64, 3, 5, 6), generator=g))
+    mask = _bf(torch.randn((1, 64, 6, 10, 12), generator=g))
+    conv = F.conv3d(x.double(), w.double(), shift.double(), 1, 1)
+    ref = torch.relu(conv + add1 + add2 + F.interpolate(up.double(), size=(6, 10, 12), mode='nearest'))
+    b = lambda t: _cl(t).to(dev).bfloat16()
+    w16 = _hip.pack_conv_weight_bf16(w).to(dev)
+    y = _hip.conv3d_forward_bf16(b(x), w16, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), shift=shift.to(dev), add1=b(add1), add2=b(add2),
+                                 up=b(up), relu=True)
+    _close(y.float().permute(0, 4, 1, 2, 3).cpu(), ref, 'fused relu', BF16_EPS, 3e-3)
+    ref2 = (conv + add1) * (mask > 0)
+    y2 = _hip.conv3d_forward_bf16(b(x), w16, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), shift=shift.to(dev), add1=b(add1), mask=b(mask))
+    _close(y2.float().permute(0, 4, 1, 2, 3).cpu(), ref2, 'fused mask', BF16_EPS, 3e-3)
+
+
+WG_CASES = [
+    (16, 16, 1, 1, 0, (5, 9, 11)),
+    (64, 16, 1, 1, 0, (6, 10, 20)),
+    (16, 64, 1, 1, 0, (9, 17, 33)),
+    (256, 64, 1, 1, 0, (5, 16, 15)),
+    (64, 128, 1, 2, 0, (6, 10, 12)),
+    (16, 16, 3, 1, 1, (6, 10, 12)),
+    (32, 32, 3, 1, 1, (5, 9, 19)),
+    (64, 64, 3, 1, 1, (8, 16, 17)),
+    (128, 128, 3, 1, 1, (3, 6, 8)),
+    (32, 32, 3, 2, 1, (8, 16, 14)),
+    (64, 64, 3, 2, 1, (7, 11, 35)),
+]
+
+
+@pytest.mark.parametrize('cin,cout,k,stride,pad,dhw', WG_CASES)
+def test_conv3d_bf16_wgrad(dev, cin, cout, k, stride, pad, dhw):
+    """transposing LDS reads (ds_read_b64_tr_b16) feed positions as the GEMM K axis: weight gradient + sum dy vs float64"""
+    from mr3d_amd import _hip
+    g = torch.Generator().manual_seed(cin * 7 + cout + k)
+    x = _bf(torch.randn((2, cin) + dhw, generator=g))
+    oshape = F.conv3d(torch.zeros((1, 1) + dhw), torch.zeros(1, 1, k, k, k), None, stride, pad).shape[2:]
+    dy = _bf(torch.randn((2, cout) + tuple(oshape), generator=g))
+    ref = torch.nn.grad.conv3d_weight(x.double(), (cout, cin, k, k, k), dy.double(), stride, pad)
+    dw = torch.zeros(k ** 3, cin, cout, device=dev)
+    db = torch.zeros(cout, device=dev)
+    _hip.conv3d_wgrad_bf16(_cl(x).to(dev).bfloat16(), _cl(dy).to(dev).bfloat16(), dw, (k,) * 3, (stride,) * 3, (pad,) * 3, dbias=db)
+    got = dw.permute(2, 1, 0).reshape(cout, cin, k, k, k).cpu()
+    _close(got, ref, 'wgrad', 1e-4, 1e-4)
+    _close(db.cpu(), dy.double().sum(dim=(0, 2, 3, 4)), 'dbias', 1e-4, 1e-4)
+    # accumulation semantics: a second call adds
+    _hip.conv3d_wgrad_bf16(_cl(x).to(dev).bfloat16(), _cl(dy).to(dev).bfloat16(), dw, (k,) * 3, (stride,) * 3, (pad,) * 3)
+    _close(dw.permute(2, 1, 0).reshape(cout, cin, k, k, k).cpu(), 2 * ref, 'wgrad x2', 1e-4, 1e-4)
+
+
+@pytest.mark.parametrize('shape', [(1, 3, 16, 64, 64), (2, 3, 10, 40, 36)])
+def test_engine_bf16_vs_fp32_restatement(dev, shape):
+    """ExtractFeat3D(dtype=bfloat16): pyramid outputs against the fp32/fp64 restatement; parameter gradients against the fp64
+    restatement linearised at the bf16 engine's own activation pattern"""
+    from oracle.torch_ref_model import RefExtractFeat
+    from mr3d_amd.detector import ExtractFeat3D
+    from test_extract_feat import engine_activation_pattern
+    torch.manual_seed(31)
+    ref = RefExtractFeat()
+    with torch.no_grad():
+        for n, p in ref.named_parameters():
+            if p.dim() == 1:
+                p.copy_(torch.rand_like(p) * 0.5 + 0.5 if n.endswith('weight') else torch.randn_like(p) * 0.1)
+        for n, b in ref.named_buffers():
+            if n.endswith('running_mean'):
+                b.copy_(torch.randn_like(b) * 0.1)
+            elif n.endswith('running_var'):
+                b.copy_(torch.rand_like(b) + 0.5)
+    eng = ExtractFeat3D(dtype=torch.bfloat16)
+    eng.load_state_dict(ref.state_dict())
+    x = torch.randn(*shape)
+    outs = [o.clone() for o in eng.forward_features(x.cuda())]
+    assert all(o.dtype == torch.float32 for o in outs)
+    P = eng._last
+    assert P.stem_out.dtype == torch.bfloat16 and P.outs[0].dtype == torch.bfloat16
+    P.blocks_meta = eng.blocks
+    cots = [torch.randn(o.shape) for o in outs]
+    eng.zero_grad()
+    eng.backward_features([c.cuda() for c in cots])
+    with torch.no_grad():
+        outs_ref = ref.double()(x.double())
+    worst_out = 0.0
+    for o, r in zip(outs, outs_ref):
+        worst_out = max(worst_out, ((o.cpu().double() - r).abs().max() / r.abs().max()).item())
+    pattern = engine_activation_pattern(P)
+    ref64 = copy.deepcopy(ref).double().linearize_at(pattern)
+    outs64 = ref64(x.double())
+    sum((o * c.double()).sum() for o, c in zip(outs64, cots)).backward()
+    worst = ('', 0.0)
+    for k, q in ref64.named_parameters():
+        got, exp = eng.get_parameter(k).grad.cpu().double(), q.grad
+        e = ((got - exp).norm() / exp.norm().clamp(min=1e-30)).item()
+        worst = max(worst, (k, e), key=lambda t: t[1])
+    print(f'bf16 engine {shape}: worst pyramid output rel err {worst_out:.2e}; worst parameter-gradient L2 rel err {worst[1]:.2e} ({worst[0]})')
+    assert worst_out <= 3e-2, worst_out
+    assert worst[1] <= 8e-2, worst
