@@ -107,11 +107,11 @@ class RoiLevel(ctypes.Structure):
                 ('width', ctypes.c_int), ('spatial_scale', ctypes.c_float), ('spatial_scale_depth', ctypes.c_float)]
 
 
-def _roi_levels(tensors, scales, scales_depth, backward):
+def _roi_levels(tensors, scales, scales_depth, backward, dtype=torch.float32):
     arr = (RoiLevel * len(tensors))()
     for i, (t, s, sd) in enumerate(zip(tensors, scales, scales_depth)):
-        if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 5 and t.is_contiguous(memory_format=torch.channels_last_3d)):
-            raise RuntimeError('multi-level RoIAlign3D needs float32 channels_last_3d feature maps')
+        if not (t.is_cuda and t.dtype == dtype and t.dim() == 5 and t.is_contiguous(memory_format=torch.channels_last_3d)):
+            raise RuntimeError(f'multi-level RoIAlign3D needs {dtype} channels_last_3d feature maps')
         if backward:
             arr[i].grad = t.data_ptr()
         else:
@@ -126,9 +126,11 @@ def roi_align3d_forward_ml(feats, rois, out_d, out_h, out_w, scales, scales_dept
     rois = rois.contiguous()
     C = feats[0].size(1)
     out = torch.empty((rois.size(0), C, out_d, out_h, out_w), dtype=torch.float32, device=rois.device)
-    lv = _roi_levels(feats, scales, scales_depth, False)
+    bf16 = feats[0].dtype == torch.bfloat16            # configs[4]: bf16 pyramid, fp32 roi features
+    lv = _roi_levels(feats, scales, scales_depth, False, feats[0].dtype)
+    fn = lib().mr3d_roi_align3d_forward_ml_bf16 if bf16 else lib().mr3d_roi_align3d_forward_ml
     with torch.cuda.device(rois.device):
-        st = lib().mr3d_roi_align3d_forward_ml(lv, len(feats), ctypes.c_float(finest_scale), ptr(rois), rois.size(0), C, out_d, out_h,
+        st = fn(lv, len(feats), ctypes.c_float(finest_scale), ptr(rois), rois.size(0), C, out_d, out_h,
                                                out_w, int(sample_num), ptr(out), stream_ptr(rois.device))
     check(st, 'mr3d_roi_align3d_forward_ml')
     return out

@@ -336,6 +336,173 @@ __global__ __launch_bounds__(kClThreads) void roi_align3d_cl(const float *feat_o
 }
 
 
+struct IdxEntry { int lo, hi; float l, h; };     // plain voxel indices; l = h = 0 marks an out-of-range sample
+
+__device__ __forceinline__ void build_idx_table(IdxEntry *tab, float start, float bin, int P, int ns, int dim, int tid,
+                                                int nthreads) {
+  for (int e = tid; e < P * ns; e += nthreads) {
+    const int p = e / ns, i = e - p * ns;
+    AxisTap t;
+    IdxEntry te;
+    if (axis_tap(sample_coord(start, p, bin, i, ns), dim, t)) { te.lo = t.lo; te.hi = t.hi; te.l = t.l; te.h = t.h; }
+    else { te.lo = 0; te.hi = 0; te.l = 0.f; te.h = 0.f; }
+    tab[e] = te;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// channels-last FORWARD, footprint staged in LDS.  The wave-per-bin kernel above re-reads every trilinear tap from
+// L2 -- 64 x 256 B per output bin, ~22x the bytes the op has to move (the distinct voxels under a RoI's
+// sample footprint once + the output once).  Here a workgroup owns (RoI, 16 channels): it finds the voxel box the RoI's
+// samples touch (from the per-axis tap tables), stages that box ONCE as [z][y][x][16 ch] fp32 in LDS (64-byte rows
+// from HBM; the other channel groups of the RoI read the rest of the same lines out of L2), evaluates every bin from LDS
+// (a wave = 4 bins x 16 channels), and writes [R,C,PD,PH,PW] rows in 256-B runs through an LDS transpose.  Same
+// arithmetic expression per sample as above.  Features may be fp32 or bf16 (configs[4]; the reference's kernel
+// dispatches float / double / half, roi_align_kernel.cu:323); output fp32.  A RoI whose box exceeds the LDS budget
+// (never with the shipped level rule) reads its taps from global memory instead.
+// ------------------------------------------------------------------------------------------
+constexpr int kStCh = 16;            // channels per workgroup
+constexpr int kStCap = 1024;         // voxels of the staged box (64 KB of fp32 at 16 channels)
+constexpr int kStAxis = 64;          // tap-table entries per axis (P * sample_num)
+constexpr int kStLdsBytes = 3 * kStAxis * 16 + 64 + kStCap * kStCh * 4 + 64 * (kStCh + 1) * 4;
+
+__device__ __forceinline__ float4 ld_feat4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ float4 ld_feat4(const uint16_t *p) {
+  const uint2 q = *reinterpret_cast<const uint2 *>(p);
+  return make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16),
+                     __uint_as_float(q.y & 0xffff0000u));
+}
+__device__ __forceinline__ float ld_feat1(const float *p) { return *p; }
+__device__ __forceinline__ float ld_feat1(const uint16_t *p) { return __uint_as_float((uint32_t)*p << 16); }
+
+template <typename T>
+__global__ __launch_bounds__(kClThreads) void roi_align3d_fwd_staged(const T *feat, float *__restrict__ out,
+                                                                    const float *__restrict__ rois, float scale, float scale_d,
+                                                                    int ns, int C, int D, int H, int W, int PD, int PH, int PW,
+                                                                    LevelTable lt) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char st_lds[];
+  IdxEntry *tabx = reinterpret_cast<IdxEntry *>(st_lds), *taby = tabx + kStAxis, *tabz = taby + kStAxis;
+  int *ext = reinterpret_cast<int *>(tabz + kStAxis);                 // x0,nx, y0,ny, z0,nz
+  float *box = reinterpret_cast<float *>(st_lds + 3 * kStAxis * 16 + 64);
+  float (*tile)[kStCh + 1] = reinterpret_cast<float (*)[kStCh + 1]>(box + kStCap * kStCh);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = blockIdx.x, c0 = blockIdx.y * kStCh;
+  if (lt.num) {
+    const int lvl = roi_level(rois + (size_t)r * 7, lt.finest_scale, lt.num);
+    D = pick4(lvl, lt.D); H = pick4(lvl, lt.H); W = pick4(lvl, lt.W);
+    scale = pick4(lvl, lt.scale); scale_d = pick4(lvl, lt.scale_d);
+    feat = reinterpret_cast<const T *>(pick4(lvl, lt.feat));
+  }
+  const RoiGeom g = roi_geom(rois + (size_t)r * 7, scale, scale_d, ns, PD, PH, PW);
+  build_idx_table(tabx, g.sw, g.bw, PW, ns, W, tid, kClThreads);
+  build_idx_table(taby, g.sh, g.bh, PH, ns, H, tid, kClThreads);
+  build_idx_table(tabz, g.sd, g.bd, PD, ns, D, tid, kClThreads);
+  __syncthreads();
+  if (tid < 3) {            // voxel range of the valid samples of one axis
+    const IdxEntry *tab = tid == 0 ? tabx : (tid == 1 ? taby : tabz);
+    const int n = (tid == 0 ? PW : (tid == 1 ? PH : PD)) * ns;
+    int mn = 0x7fffffff, mx = -1;
+    for (int e = 0; e < n; ++e)
+      if (tab[e].l + tab[e].h != 0.f) { mn = min(mn, tab[e].lo); mx = max(mx, tab[e].hi); }
+    ext[2 * tid] = mx < 0 ? 0 : mn;
+    ext[2 * tid + 1] = mx < 0 ? 0 : mx - mn + 1;
+  }
+  __syncthreads();
+  const int x0 = ext[0], nx = ext[1], y0 = ext[2], ny = ext[3], z0 = ext[4], nz = ext[5];
+  const long long vox = (long long)nx * ny * nz;
+  const bool staged = vox > 0 && vox <= kStCap;
+  const size_t base_n = (size_t)g.b * D * H * W * C + c0;
+  __syncthreads();                                                   // everyone has read ext / the absolute tables
+  // tables -> element offsets: into the staged box, or into the feature map
+  {
+    const long long mx_ = staged ? kStCh : C, my_ = staged ? (long long)nx * kStCh : (long long)W * C;
+    for (int e = tid; e < PW * ns; e += kClThreads) { tabx[e].lo = (int)((tabx[e].lo - (staged ? x0 : 0)) * mx_); tabx[e].hi = (int)((tabx[e].hi - (staged ? x0 : 0)) * mx_); }
+    for (int e = tid; e < PH * ns; e += kClThreads) { taby[e].lo = (int)((taby[e].lo - (staged ? y0 : 0)) * my_); taby[e].hi = (int)((taby[e].hi - (staged ? y0 : 0)) * my_); }
+    if (staged)
+      for (int e = tid; e < PD * ns; e += kClThreads) { tabz[e].lo = (tabz[e].lo - z0) * ny * nx * kStCh; tabz[e].hi = (tabz[e].hi - z0) * ny * nx * kStCh; }
+  }
+  if (staged) {
+    const int pieces = (int)vox * 4;
+    for (int it = tid; it < pieces; it += kClThreads) {
+      const int q = it & 3, v = it >> 2;
+      const int x = v % nx, y = (v / nx) % ny, z = v / (nx * ny);
+      const float4 f = ld_feat4(feat + base_n + (((size_t)(z0 + z) * H + (y0 + y)) * W + (x0 + x)) * C + q * 4);
+      *reinterpret_cast<float4 *>(box + v * kStCh + q * 4) = f;
+    }
+  }
+  __syncthreads();
+
+  const int B = PD * PH * PW;
+  const float count = (float)(ns * ns * ns);
+  const int bs = lane >> 4, ch = lane & 15;
+  const long long sD = (long long)H * W * C;
+  for (int pass0 = 0; pass0 < B; pass0 += 64) {
+    const int nb = min(64, B - pass0);
+    for (int bg = wave; bg * 4 < nb; bg += kClThreads / MR3D_WAVE) {
+      const int bl = bg * 4 + bs;
+      if (bl < nb) {
+        const int bin = pass0 + bl;
+        const int pw = bin % PW, ph = (bin / PW) % PH, pd = bin / (PW * PH);
+        float acc = 0.f;
+        for (int iz = 0; iz < ns; ++iz) {
+          const IdxEntry tz = tabz[pd * ns + iz];
+          for (int iy = 0; iy < ns; ++iy) {
+            const IdxEntry ty = taby[ph * ns + iy];
+            for (int ix = 0; ix < ns; ++ix) {
+              const IdxEntry tx = tabx[pw * ns + ix];
+              if ((tx.l + tx.h) * (ty.l + ty.h) * (tz.l + tz.h) == 0.f) continue;
+              const float w1 = tx.h * ty.h * tz.h, w5 = tx.h * ty.h * tz.l;
+              const float w2 = tx.l * ty.h * tz.h, w6 = tx.l * ty.h * tz.l;
+              const float w3 = tx.h * ty.l * tz.h, w7 = tx.h * ty.l * tz.l;
+              const float w4 = tx.l * ty.l * tz.h, w8 = tx.l * ty.l * tz.l;
+              float v1, v2, v3, v4, v5, v6, v7, v8;
+              if (staged) {
+                const float *bl_ = box + tz.lo + ch, *bh_ = box + tz.hi + ch;
+                v1 = bl_[ty.lo + tx.lo]; v2 = bl_[ty.lo + tx.hi]; v3 = bl_[ty.hi + tx.lo]; v4 = bl_[ty.hi + tx.hi];
+                v5 = bh_[ty.lo + tx.lo]; v6 = bh_[ty.lo + tx.hi]; v7 = bh_[ty.hi + tx.lo]; v8 = bh_[ty.hi + tx.hi];
+              } else {
+                const T *fl = feat + base_n + tz.lo * sD + ch, *fh = feat + base_n + tz.hi * sD + ch;
+                v1 = ld_feat1(fl + ty.lo + tx.lo); v2 = ld_feat1(fl + ty.lo + tx.hi); v3 = ld_feat1(fl + ty.hi + tx.lo); v4 = ld_feat1(fl + ty.hi + tx.hi);
+                v5 = ld_feat1(fh + ty.lo + tx.lo); v6 = ld_feat1(fh + ty.lo + tx.hi); v7 = ld_feat1(fh + ty.hi + tx.lo); v8 = ld_feat1(fh + ty.hi + tx.hi);
+              }
+              acc += (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4 + w5 * v5 + w6 * v6 + w7 * v7 + w8 * v8);
+            }
+          }
+        }
+        tile[bl][ch] = acc / count;
+      }
+    }
+    __syncthreads();
+    // tile[bin][channel] -> out[r, c0 + channel, pass0 + bin]: 256-B runs of consecutive bins per channel
+    for (int cc = wave; cc < kStCh; cc += kClThreads / MR3D_WAVE)
+      if (lane < nb) out[((size_t)r * C + c0 + cc) * B + pass0 + lane] = tile[lane][cc];
+    __syncthreads();
+  }
+}
+
+template <typename T>
+int launch_fwd_staged(const T *feat, float *out, const float *rois, int num_rois, float scale, float scale_d, int ns, int C,
+                      int D, int H, int W, int PD, int PH, int PW, const LevelTable &lt, hipStream_t stream) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(roi_align3d_fwd_staged<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kStLdsBytes) != hipSuccess) {
+      (void)hipGetLastError();
+      return MR3D_ERR_LAUNCH;
+    }
+    attr_done = true;
+  }
+  roi_align3d_fwd_staged<T><<<dim3(num_rois, C / kStCh), kClThreads, kStLdsBytes, stream>>>(feat, out, rois, scale, scale_d, ns, C, D,
+                                                                                         H, W, PD, PH, PW, lt);
+  return mr3d_launch_status();
+}
+
+inline bool staged_ok(int C, int ns, int PD, int PH, int PW) {
+  static const int off = getenv("MR3D_ROIALIGN_STAGED") ? !atoi(getenv("MR3D_ROIALIGN_STAGED")) : 0;     // A/B switch
+  return !off && C % kStCh == 0 && ns > 0 && PD * ns <= kStAxis && PH * ns <= kStAxis && PW * ns <= kStAxis;
+}
+
 // ------------------------------------------------------------------------------------------
 // channels-last backward, separable owner-computes variant.  The global-atomic kernel above issues 64 fp32 atomics
 // per output element and runs at the chip's atomic rate (measured 0.9-1.0 TB/s of added bytes: 3-5 ms for the mask
@@ -350,20 +517,6 @@ __global__ __launch_bounds__(kClThreads) void roi_align3d_cl(const float *feat_o
 // per-RoI flag); persistent workgroups walk the list.  No LDS atomics: an earlier ds_add_f32 box was slower than
 // the global atomics it replaced.
 // ------------------------------------------------------------------------------------------
-
-struct IdxEntry { int lo, hi; float l, h; };     // plain voxel indices; l = h = 0 marks an out-of-range sample
-
-__device__ __forceinline__ void build_idx_table(IdxEntry *tab, float start, float bin, int P, int ns, int dim, int tid,
-                                                int nthreads) {
-  for (int e = tid; e < P * ns; e += nthreads) {
-    const int p = e / ns, i = e - p * ns;
-    AxisTap t;
-    IdxEntry te;
-    if (axis_tap(sample_coord(start, p, bin, i, ns), dim, t)) { te.lo = t.lo; te.hi = t.hi; te.l = t.l; te.h = t.h; }
-    else { te.lo = 0; te.hi = 0; te.l = 0.f; te.h = 0.f; }
-    tab[e] = te;
-  }
-}
 
 constexpr int kBoxP = 32;         // max pooled size per axis handled by the box kernel (PH*PW <= 256 as well)
 constexpr int kSubV = 8;          // voxels per axis of one sub-box
@@ -582,6 +735,10 @@ extern "C" int mr3d_roi_align3d_forward(const float *features, const float *rois
   if (num_rois == 0) return MR3D_OK;
   hipStream_t stream = mr3d_stream(stream_);
   const int B = pooled_depth * pooled_height * pooled_width;
+  if (use_cl(layout, sample_num, pooled_depth, pooled_height, pooled_width) &&
+      staged_ok(channels, sample_num, pooled_depth, pooled_height, pooled_width))
+    return launch_fwd_staged<float>(features, output, rois, num_rois, spatial_scale, spatial_scale_depth, sample_num, channels, depth,
+                                    height, width, pooled_depth, pooled_height, pooled_width, LevelTable{}, stream);
   if (use_cl(layout, sample_num, pooled_depth, pooled_height, pooled_width)) {
     dim3 grid(num_rois, (B + kClBins - 1) / kClBins);
     roi_align3d_cl<false><<<grid, kClThreads, 0, stream>>>(features, output, rois, spatial_scale, spatial_scale_depth,
@@ -671,6 +828,9 @@ extern "C" int mr3d_roi_align3d_forward_ml(const mr3d_roi_level *levels_host, in
   if (num_rois == 0) return MR3D_OK;
   if (!rois || !output) return MR3D_ERR_INVALID_ARG;
   if (!use_cl(MR3D_LAYOUT_NDHWC, sample_num, pooled_depth, pooled_height, pooled_width)) return MR3D_ERR_UNSUPPORTED;
+  if (staged_ok(channels, sample_num, pooled_depth, pooled_height, pooled_width))
+    return launch_fwd_staged<float>(nullptr, output, rois, num_rois, 0.f, 0.f, sample_num, channels, 1, 1, 1, pooled_depth,
+                                    pooled_height, pooled_width, lt, mr3d_stream(stream_));
   const int B = pooled_depth * pooled_height * pooled_width;
   dim3 grid(num_rois, (B + kClBins - 1) / kClBins);
   roi_align3d_cl<false><<<grid, kClThreads, 0, mr3d_stream(stream_)>>>(nullptr, output, rois, 0.f, 0.f, sample_num, channels, 1, 1, 1,
@@ -709,4 +869,23 @@ extern "C" int mr3d_roi_align3d_backward_ml(const mr3d_roi_level *levels_host, i
       top_grad, nullptr, rois, 0.f, 0.f, sample_num, channels, 1, 1, 1, pooled_depth, pooled_height, pooled_width, bug, scratch,
       scratch + 1 + num_rois, lt);
   return mr3d_launch_status();
+}
+
+// bf16 feature maps (configs[4]; roi_align_kernel.cu:323 dispatches half as well): same call, `features` of every level
+// record points to bf16 NDHWC data; output fp32.  channels % 16 == 0, pooled * sample_num <= 64 per axis.
+extern "C" int mr3d_roi_align3d_forward_ml_bf16(const mr3d_roi_level *levels_host, int num_levels, float finest_scale,
+                                                const float *rois, int num_rois, int channels, int pooled_depth,
+                                                int pooled_height, int pooled_width, int sample_num, float *output,
+                                                mr3d_stream_t stream_) {
+  LevelTable lt;
+  const int st = fill_levels(levels_host, num_levels, finest_scale, false, lt);
+  if (st != MR3D_OK) return st;
+  if (num_rois < 0 || channels <= 0 || pooled_depth <= 0 || pooled_height <= 0 || pooled_width <= 0) return MR3D_ERR_INVALID_ARG;
+  if (num_rois == 0) return MR3D_OK;
+  if (!rois || !output) return MR3D_ERR_INVALID_ARG;
+  if (channels % kStCh != 0 || sample_num <= 0 || pooled_depth * sample_num > kStAxis || pooled_height * sample_num > kStAxis ||
+      pooled_width * sample_num > kStAxis)
+    return MR3D_ERR_UNSUPPORTED;
+  return launch_fwd_staged<uint16_t>(nullptr, output, rois, num_rois, 0.f, 0.f, sample_num, channels, 1, 1, 1, pooled_depth,
+                                     pooled_height, pooled_width, lt, mr3d_stream(stream_));
 }

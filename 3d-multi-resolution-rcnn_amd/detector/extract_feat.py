@@ -60,8 +60,11 @@ class ExtractFeat3D(nn.Module):
     STAGE_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
 
     def __init__(self, depth=50, fpn_out_channels=64, num_outs=5, zero_init_residual=True, device='cuda',
-                 dtype=torch.float32):
-        """dtype: storage type of activations and activation gradients -- torch.float32 (the reference's arithmetic, the
+                 dtype=torch.float32, neck_dcn=False):
+        """neck_dcn: BASELINE configs[4]'s "DeformConv3d neck" -- the four FPN output convs (fpn3d.py:56-64) are NOT part of
+        the engine: it hands out the top-down lateral sums (4 maps) and takes their gradients; detector/dcn_neck.DCNNeck3D
+        applies offset conv + DeformConv3d on them (build-defined: the reference never runs DCN on 5-D input).
+        dtype: storage type of activations and activation gradients -- torch.float32 (the reference's arithmetic, the
         headline path) or torch.bfloat16 (BASELINE configs[4]: bf16 maps in HBM, v_mfma_f32_32x32x16_bf16 with fp32
         accumulation; parameters, their gradients, the folded BN shifts and the stem's arithmetic stay fp32).  The pyramid
         is handed out in fp32 either way."""
@@ -69,6 +72,7 @@ class ExtractFeat3D(nn.Module):
         assert dtype in (torch.float32, torch.bfloat16)
         self.act_dtype = dtype
         self.bf16 = dtype == torch.bfloat16
+        self.neck_dcn = bool(neck_dcn)
         if depth not in self.STAGE_BLOCKS:
             raise KeyError(f'invalid depth {depth} for the bottleneck ResNet3D engine')
         assert num_outs == 5, 'the shipped config uses 4 pyramid levels + 1 max-pooled level (configs/...py:11-15)'
@@ -111,8 +115,10 @@ class ExtractFeat3D(nn.Module):
         self.lateral, self.fpnconv = [], []
         for i, c in enumerate(self.stage_out_channels):
             self.lateral.append(_ConvSpec(f'neck.lateral_convs.{i}.conv', c, self.fpn_out, 1, (1, 1, 1), 0, bias=True))
-            self.fpnconv.append(_ConvSpec(f'neck.fpn_convs.{i}.conv', self.fpn_out, self.fpn_out, 3, (1, 1, 1), 1, bias=True))
-            add(self.lateral[-1]); add(self.fpnconv[-1])
+            add(self.lateral[-1])
+            if not self.neck_dcn:
+                self.fpnconv.append(_ConvSpec(f'neck.fpn_convs.{i}.conv', self.fpn_out, self.fpn_out, 3, (1, 1, 1), 1, bias=True))
+                add(self.fpnconv[-1])
         for k, s in enumerate(S):
             s.index = k
         self.specs = S
@@ -459,24 +465,33 @@ class ExtractFeat3D(nn.Module):
             P.lat[i] = self._new(self._out_shape(P.C[i].shape, self.lateral[i]))
             fwd.append(self._conv_fwd(P.C[i], self.lateral[i], P.lat[i], up=P.lat[i + 1] if i < 3 else None))
         P.outs = []
-        for i in range(4):
-            o = self._new(self._out_shape(P.lat[i].shape, self.fpnconv[i]))
-            fwd.append(self._conv_fwd(P.lat[i], self.fpnconv[i], o))
-            P.outs.append(o)
-        _, d5, h5, w5, _ = P.outs[3].shape
-        p6 = self._new((N, (d5 - 1) // 2 + 1, (h5 - 1) // 2 + 1, (w5 - 1) // 2 + 1, self.fpn_out))
-        fwd.append(self._op(_hip.OP_SUBSAMPLE_FWD, [P.outs[3], p6], [N, d5, h5, w5, self.fpn_out]))
-        P.outs.append(p6)
+        if self.neck_dcn:
+            P.outs = list(P.lat)                    # the deformable neck (detector/dcn_neck.py) takes over from here
+        else:
+            for i in range(4):
+                o = self._new(self._out_shape(P.lat[i].shape, self.fpnconv[i]))
+                fwd.append(self._conv_fwd(P.lat[i], self.fpnconv[i], o))
+                P.outs.append(o)
+            _, d5, h5, w5, _ = P.outs[3].shape
+            p6 = self._new((N, (d5 - 1) // 2 + 1, (h5 - 1) // 2 + 1, (w5 - 1) // 2 + 1, self.fpn_out))
+            fwd.append(self._op(_hip.OP_SUBSAMPLE_FWD, [P.outs[3], p6], [N, d5, h5, w5, self.fpn_out]))
+            P.outs.append(p6)
 
         # ---------------- backward
         P.gouts = [self._new(o.shape) for o in P.outs]
         bwd.append(_hip.make_op(_hip.OP_MEMSET0, [self._scratch], _hip.split64(self._scratch.numel() * 4)))
-        bwd.append(self._op(_hip.OP_SUBSAMPLE_BWD, [P.gouts[4], P.gouts[3]], [N, d5, h5, w5, self.fpn_out]))
-        glat = [self._new(l.shape) for l in P.lat]
+        if self.neck_dcn:
+            glat = P.gouts                          # gradients w.r.t. the lateral sums arrive from the deformable neck
+            P.n_direct = 1                          # glat[1..3] also receive the upsample adjoint in place: plan-owned
+        else:
+            bwd.append(self._op(_hip.OP_SUBSAMPLE_BWD, [P.gouts[4], P.gouts[3]], [N, d5, h5, w5, self.fpn_out]))
+            glat = [self._new(l.shape) for l in P.lat]
+            P.n_direct = 3                          # P2..P4 gradients are only read; the P5 buffer also takes P6's
         gC_lat = [self._new(c.shape) for c in P.C]
         for i in range(4):
-            bwd.append(self._conv_wgrad(P.lat[i], P.gouts[i], self.fpnconv[i]))
-            bwd.append(self._conv_dgrad(P.gouts[i], self.fpnconv[i], glat[i]))
+            if not self.neck_dcn:
+                bwd.append(self._conv_wgrad(P.lat[i], P.gouts[i], self.fpnconv[i]))
+                bwd.append(self._conv_dgrad(P.gouts[i], self.fpnconv[i], glat[i]))
             if i > 0:
                 nf, df, hf, wf, c = glat[i - 1].shape
                 bwd.append(self._op(_hip.OP_UPSAMPLE_ADJ, [glat[i - 1], glat[i]],
@@ -538,8 +553,8 @@ class ExtractFeat3D(nn.Module):
         # zero-copy binding (see bind_input / bind_grads): where the plans refer to the input volume and to the
         # read-only output gradients (P2..P4; the P5 buffer also receives P6's gradient in place, so it stays owned)
         P.x_refs = (P.fwd.find_ptr(P.x_in.data_ptr()), P.bwd.find_ptr(P.x_in.data_ptr()))
-        P.g_refs = [P.bwd.find_ptr(g.data_ptr()) for g in P.gouts[:3]]
-        P.bound_x, P.bound_g = None, [None, None, None]
+        P.g_refs = [P.bwd.find_ptr(g.data_ptr()) for g in P.gouts[:P.n_direct]]
+        P.bound_x, P.bound_g = None, [None] * P.n_direct
         self._building = None
         return P
 
@@ -573,7 +588,7 @@ class ExtractFeat3D(nn.Module):
         P.bwd.repoint(P.x_refs[1], P.x_in.data_ptr())
         for refs, g in zip(P.g_refs, P.gouts):
             P.bwd.repoint(refs, g.data_ptr())
-        P.bound_x, P.bound_g = None, [None, None, None]
+        P.bound_x, P.bound_g = None, [None] * P.n_direct
         P.fwd.capture()
         P.bwd.capture()
 
@@ -606,12 +621,12 @@ class ExtractFeat3D(nn.Module):
                 src = gbuf
             else:
                 gl = g.permute(0, 2, 3, 4, 1)
-                direct = (i < 3 and g.dtype == gbuf.dtype and gl.is_contiguous() and g.device == gbuf.device and
+                direct = (i < P.n_direct and g.dtype == gbuf.dtype and gl.is_contiguous() and g.device == gbuf.device and
                           g.data_ptr() % 16 == 0 and not self._captured(P))
                 src = gl if direct else gbuf
                 if not direct:
                     gbuf.copy_(gl)
-            if i < 3:
+            if i < P.n_direct:
                 if (P.bound_g[i] is None or P.bound_g[i].data_ptr() != src.data_ptr()) and not self._captured(P):
                     P.bwd.repoint(P.g_refs[i], src.data_ptr())
                 P.bound_g[i] = src

@@ -7,6 +7,7 @@ Static shapes, device-resident counts: the roi batch always has `sampler.num` ro
 then zero-weight padding) and the mask batch int(num * pos_fraction) rows; how many of them are real stays in device
 memory and enters the loss kernels as `valid_rows` / `avg_factor`.  The reference synchronises with the host at every
 `.item()`, `nonzero`, numpy sampler call and boolean-mask gather of this path (~40 per iteration)."""
+import re
 from types import SimpleNamespace
 
 import torch
@@ -95,12 +96,18 @@ def front_pack_order(valid_counts, rows_per_img):
 class TwoStageDetector3D(nn.Module):
 
     def __init__(self, device='cuda', train_cfg=None, test_cfg=None, with_mask=True, anchor_scales=(2,),
-                 anchor_depth_scales=(2,)):
+                 anchor_depth_scales=(2,), dtype=torch.float32, neck_dcn=False):
+        """dtype / neck_dcn: BASELINE configs[4] switches -- bf16 activation storage in backbone + FPN, and DeformConv3d in
+        place of the FPN output convs (detector/dcn_neck.py).  Defaults = the reference's fp32 model."""
         super().__init__()
         self.device = torch.device(device)
         self.train_cfg = train_cfg or DEFAULT_TRAIN_CFG
         self.test_cfg = test_cfg or DEFAULT_TEST_CFG
-        self.extract = ExtractFeat3D(device=device)                       # backbone + neck (module names as the reference)
+        self.extract = ExtractFeat3D(device=device, dtype=dtype, neck_dcn=neck_dcn)   # backbone + neck (module names as the reference)
+        self.neck_dcn = bool(neck_dcn)
+        if neck_dcn:
+            from .dcn_neck import DCNNeck3D
+            self.dcn_neck = DCNNeck3D().to(self.device)
         self.rpn_head = RPNHead3D(anchor_scales=anchor_scales, anchor_depth_scales=anchor_depth_scales).to(self.device)
         strides, dstrides = [4, 8, 16, 32], [2, 4, 8, 16]
         self.bbox_roi_extractor = SingleRoIExtractor(dict(type='RoIAlign3D', out_size=7, out_size_depth=3, sample_num=2), 64,
@@ -117,20 +124,28 @@ class TwoStageDetector3D(nn.Module):
         self._register_state_dict_hook(self._strip_extract_prefix)
         self._register_load_state_dict_pre_hook(self._add_extract_prefix)
 
+    _DCN_KEY = re.compile(r'^dcn_neck\.(conv|conv_offset)\.(\d+)\.(.+)$')
+    _DCN_REF_KEY = re.compile(r'^neck\.fpn_convs\.(\d+)\.(conv|conv_offset)\.(.+)$')
+
     @staticmethod
     def _strip_extract_prefix(module, state_dict, prefix, local_metadata):
         for k in [k for k in state_dict if k.startswith(prefix + 'extract.')]:
             state_dict[prefix + k[len(prefix) + len('extract.'):]] = state_dict.pop(k)
+        for k in [k for k in state_dict if k.startswith(prefix + 'dcn_neck.')]:         # -> neck.fpn_convs.<i>.{conv,conv_offset}.*
+            m = TwoStageDetector3D._DCN_KEY.match(k[len(prefix):])
+            state_dict[f'{prefix}neck.fpn_convs.{m.group(2)}.{m.group(1)}.{m.group(3)}'] = state_dict.pop(k)
         return state_dict
 
-    @staticmethod
-    def _add_extract_prefix(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+    def _add_extract_prefix(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
         for k in list(state_dict):
             bare = k[len(prefix):]
             if bare.startswith('module.'):                                   # resnet3d.py:431-436 (DataParallel checkpoints)
                 state_dict[prefix + bare[7:]] = state_dict.pop(k)
                 k, bare = prefix + bare[7:], bare[7:]
-            if bare.startswith(('backbone.', 'neck.')):
+            m = TwoStageDetector3D._DCN_REF_KEY.match(bare)
+            if m is not None and (m.group(2) == 'conv_offset' or self.neck_dcn):
+                state_dict[f'{prefix}dcn_neck.{m.group(2)}.{m.group(1)}.{m.group(3)}'] = state_dict.pop(k)
+            elif bare.startswith(('backbone.', 'neck.')):
                 state_dict[prefix + 'extract.' + bare] = state_dict.pop(k)
 
     def load_checkpoint(self, path_or_dict, strict=False):
@@ -148,8 +163,11 @@ class TwoStageDetector3D(nn.Module):
             e.record()
             t.append((name, e))
 
-    def extract_feat(self, imgs):
-        return self.extract(imgs)
+    def extract_feat(self, imgs, slot=0, train=True):
+        """backbone + neck (two_stage_3d.py:108-112); with neck_dcn the engine hands out the lateral sums and the deformable
+        output stage runs here"""
+        x = self.extract(imgs, slot) if train else self.extract.forward_features(imgs, slot)
+        return self.dcn_neck(x) if self.neck_dcn else x
 
     def forward_train(self, imgs, img_meta, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_masks=None, proposals=None,
                       draws=None):
@@ -239,7 +257,7 @@ class TwoStageDetector3D(nn.Module):
         NMS3D -> (bbox_results, segm_results); one volume per call (base.py:74-75)."""
         assert imgs.size(0) == 1
         cfg = self.test_cfg
-        x = self.extract.forward_features(imgs)
+        x = self.extract_feat(imgs, train=False)
         if proposals is None:
             proposal_list = self.rpn_head.get_bboxes(*self.rpn_head(x), img_metas, SimpleNamespace(**cfg['rpn']))
         else:

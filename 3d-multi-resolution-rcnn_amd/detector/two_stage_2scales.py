@@ -22,8 +22,8 @@ from .two_stage import TwoStageDetector3D, bbox2result3D, PosCountReadback, MASK
 
 class TwoStageDetector3D2Scales(TwoStageDetector3D):
 
-    def __init__(self, device='cuda', train_cfg=None, test_cfg=None):
-        super().__init__(device=device, train_cfg=train_cfg, test_cfg=test_cfg, with_mask=True)
+    def __init__(self, device='cuda', train_cfg=None, test_cfg=None, dtype=torch.float32, neck_dcn=False):
+        super().__init__(device=device, train_cfg=train_cfg, test_cfg=test_cfg, with_mask=True, dtype=dtype, neck_dcn=neck_dcn)
         strides, dstrides = [4, 8, 16, 32], [2, 4, 8, 16]
         self.rpn_head_2 = RPNHead3D(anchor_scales=(3,), anchor_depth_scales=(3,)).to(self.device)      # configs/...py:28-39
         self.bbox_roi_extractor_refinement = SingleRoIExtractor(
@@ -70,8 +70,8 @@ class TwoStageDetector3D2Scales(TwoStageDetector3D):
         assert imgs.size(0) == 1, 'imgs_per_gpu = 1 (configs/...py:191)'
         draws = draws or {}
         cfg = self.train_cfg
-        x = self.extract(imgs, 0)
-        x_2 = self.extract(imgs_2, 1)
+        x = self.extract_feat(imgs, 0)
+        x_2 = self.extract_feat(imgs_2, 1)
         losses = dict()
 
         # ---- RPN forward, losses, proposals (:155-176); the second head's loss keys carry the _2 suffix (rpn_head_3d.py:63-65)
@@ -140,8 +140,8 @@ class TwoStageDetector3D2Scales(TwoStageDetector3D):
         assert imgs.size(0) == 1
         cfg = self.test_cfg
         meta, meta_2 = img_metas[0], img_metas_2[0]
-        x = self.extract.forward_features(imgs, 0)
-        x_2 = self.extract.forward_features(imgs_2, 1)
+        x = self.extract_feat(imgs, 0, train=False)
+        x_2 = self.extract_feat(imgs_2, 1, train=False)
         rcfg = SimpleNamespace(**cfg['rpn'])
         if proposals is None:
             proposal_list = self.rpn_head.get_bboxes(*self.rpn_head(x), img_metas, rcfg)

@@ -133,6 +133,13 @@ int mr3d_roi_align3d_backward_ml(const mr3d_roi_level *levels_host, int num_leve
                                  const float *top_grad, const float *rois, int num_rois, int channels, int pooled_depth,
                                  int pooled_height, int pooled_width, int sample_num, int flags, mr3d_stream_t stream);
 
+/* bf16 feature maps (BASELINE configs[4]; the reference's kernel dispatches half too, roi_align_kernel.cu:323): as
+ * mr3d_roi_align3d_forward_ml with every level's `features` pointing to bf16 NDHWC data; output fp32.
+ * channels % 16 == 0, pooled * sample_num <= 64 per axis. */
+int mr3d_roi_align3d_forward_ml_bf16(const mr3d_roi_level *levels_host, int num_levels, float finest_scale, const float *rois,
+                                     int num_rois, int channels, int pooled_depth, int pooled_height, int pooled_width,
+                                     int sample_num, float *output, mr3d_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * conv3d forward (+ fused epilogue) -- replaces the torch.nn.Conv3d / cuDNN calls on the reference's
  * backbone-neck path and the elementwise ops that follow them:

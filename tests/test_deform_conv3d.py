@@ -97,3 +97,86 @@ def test_deform_conv3d_zero_offset_equals_conv3d_and_errors():
         layer(x[0], off)                                   # the reference raises on non-(N+2)-D input (deform_conv.py:21-24)
     with pytest.raises(NotImplementedError):
         layer(x.cpu(), off.cpu())
+
+
+@pytest.mark.gpu
+def test_dcn_neck_forward_backward_vs_restatement():
+    """detector/dcn_neck.DCNNeck3D (BASELINE configs[4] "DeformConv3d neck"): offset conv + DeformConv3d per level and the
+    stride-2 P6, forward and every gradient, against float64 torch (F.conv3d for the offsets + the DCN restatement); a
+    zero-initialised neck equals the plain 3x3x3 FPN conv it replaces (fpn3d.py:56-64,111-123)"""
+    from mr3d_amd.detector.dcn_neck import DCNNeck3D
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(5)
+    neck = DCNNeck3D(channels=16, num_levels=2).to(dev)
+    lats = [torch.randn(1, 16, 6, 10, 8, generator=g), torch.randn(1, 16, 3, 5, 4, generator=g)]
+    # (a) fresh neck == plain conv with the DCN weights
+    with torch.no_grad():
+        outs = neck([l.to(dev).contiguous(memory_format=torch.channels_last_3d) for l in lats])
+    assert len(outs) == 3
+    for o, l, conv in zip(outs, lats, neck.conv):
+        ref = F.conv3d(l.double(), conv.weight.detach().cpu().double(), None, 1, 1)
+        assert float((o.cpu().double() - ref).abs().max() / ref.abs().max()) <= 1e-4
+    assert torch.equal(outs[2], outs[1][:, :, ::2, ::2, ::2])
+    # (b) trained-looking offsets: every gradient
+    with torch.no_grad():
+        for off in neck.conv_offset:
+            off.weight.copy_(torch.randn(off.weight.shape, generator=g) * 0.05)
+            off.bias.copy_(torch.randn(off.bias.shape, generator=g) * 0.3)
+    xs = [l.to(dev).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True) for l in lats]
+    outs = neck(xs)
+    cots = [torch.randn(o.shape, generator=g) for o in outs]
+    sum((o * c.to(dev)).sum() for o, c in zip(outs, cots)).backward()
+    x64 = [l.double().requires_grad_(True) for l in lats]
+    p64 = {n: p.detach().cpu().double().requires_grad_(True) for n, p in neck.named_parameters()}
+    outs64 = []
+    for i, x in enumerate(x64):
+        offset = F.conv3d(x, p64[f'conv_offset.{i}.weight'], p64[f'conv_offset.{i}.bias'], 1, 1)
+        outs64.append(dr.deform_conv3d_torch(x, offset, p64[f'conv.{i}.weight'], pad=(1, 1, 1)))
+    outs64.append(outs64[-1][:, :, ::2, ::2, ::2])
+    sum((o * c.double()).sum() for o, c in zip(outs64, cots)).backward()
+    for o, r in zip(outs, outs64):
+        assert float((o.detach().cpu().double() - r.detach()).abs().max() / r.detach().abs().max()) <= 1e-4
+    for x, r in zip(xs, x64):
+        assert float((x.grad.cpu().double() - r.grad).abs().max() / r.grad.abs().max()) <= 2e-4
+    for n, p in neck.named_parameters():
+        e = float((p.grad.cpu().double() - p64[n].grad).abs().max() / p64[n].grad.abs().max().clamp(min=1e-30))
+        assert e <= 2e-4, (n, e)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('bf16', [False, True])
+def test_detector_with_dcn_neck_trains(bf16):
+    """BASELINE configs[4] switches on the single-pathway detector: DeformConv3d neck (+ bf16 backbone/FPN storage) -- the
+    loss dict is finite, every parameter incl. the neck's offset convs and the backbone receives a gradient, the state
+    dict uses the reference's `neck.fpn_convs.<i>.{conv,conv_offset}` names and round-trips"""
+    from mr3d_amd.detector import TwoStageDetector3D
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    det = TwoStageDetector3D(device=dev, dtype=torch.bfloat16 if bf16 else torch.float32, neck_dcn=True)
+    det.extract.zero_init_residual = False
+    det.extract.init_weights()
+    with torch.no_grad():
+        for off in det.dcn_neck.conv_offset:
+            off.weight.normal_(0, 0.01)
+    img = torch.randn(1, 3, 32, 128, 128, device=dev)
+    gt = torch.tensor([[20, 30, 60, 75, 4, 20], [70, 20, 110, 64, 10, 28]], dtype=torch.float32, device=dev)
+    masks = torch.zeros((2, 32, 128, 128), dtype=torch.uint8, device=dev)
+    for k, b in enumerate(gt.int().tolist()):
+        masks[k, b[4]:b[5] + 1, b[1]:b[3] + 1, b[0]:b[2] + 1] = 1
+    meta = [dict(img_shape=(128, 128, 3, 32), pad_shape=(128, 128, 3, 32))]
+    det.extract.zero_grad()
+    losses = det.forward_train(img, meta, [gt], [torch.ones(2, dtype=torch.long, device=dev)], gt_masks=[masks])
+    total = det.total_loss(losses)
+    assert torch.isfinite(total)
+    total.backward()
+    for n, p in det.dcn_neck.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().sum() > 0, n
+    g = det.extract.flat_grads
+    assert torch.isfinite(g).all() and g.abs().sum() > 0
+    assert det.extract.get_parameter('backbone.conv1.weight').grad.abs().sum() > 0
+    sd = det.state_dict()
+    assert 'neck.fpn_convs.0.conv.weight' in sd and 'neck.fpn_convs.3.conv_offset.bias' in sd and 'neck.lateral_convs.0.conv.weight' in sd
+    assert not any(k.startswith(('extract.', 'dcn_neck.')) for k in sd)
+    det2 = TwoStageDetector3D(device=dev, dtype=torch.bfloat16 if bf16 else torch.float32, neck_dcn=True)
+    missing, unexpected = det2.load_state_dict(sd, strict=True)
+    assert torch.equal(det2.dcn_neck.conv[2].weight, det.dcn_neck.conv[2].weight)

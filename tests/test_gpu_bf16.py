@@ -184,3 +184,27 @@ def test_engine_bf16_vs_fp32_restatement(dev, shape):
     print(f'bf16 engine {shape}: worst pyramid output rel err {worst_out:.2e}; worst parameter-gradient L2 rel err {worst[1]:.2e} ({worst[0]})')
     assert worst_out <= 3e-2, worst_out
     assert worst[1] <= 8e-2, worst
+
+
+def test_roialign3d_bf16_features_vs_oracle(dev):
+    """RoIAlign3D on a bf16 pyramid (mr3d_roi_align3d_forward_ml_bf16): equals the oracle run on the same bf16-rounded
+    features to fp32 accuracy (the taps are exact conversions; interpolation and the mean are fp32)"""
+    from mr3d_amd import _hip
+    from oracle import binding as orc
+    import ref_impls as ri
+    rng = np.random.default_rng(3)
+    dims = ((20, 48), (10, 24), (5, 12), (3, 6))
+    strides, dstrides = [4, 8, 16, 32], [2, 4, 8, 16]
+    feats_np = [_bf(torch.from_numpy(rng.normal(size=(1, 64, d, h, h)).astype(np.float32))).numpy() for d, h in dims]
+    rois = ri.rand_rois(rng, 96, 1, (192, 192, 40), max_xy=120, max_z=30)
+    feats = [torch.from_numpy(f).to(dev).bfloat16().contiguous(memory_format=torch.channels_last_3d) for f in feats_np]
+    for (od, osz) in ((3, 7), (10, 14)):
+        out = _hip.roi_align3d_forward_ml(feats, torch.from_numpy(rois).to(dev), od, osz, osz, [1 / s for s in strides],
+                                          [1 / s for s in dstrides], 2, 56.0).cpu().numpy()
+        sc = np.sqrt((rois[:, 3] - rois[:, 1] + 1) * (rois[:, 4] - rois[:, 2] + 1) * (rois[:, 6] - rois[:, 5] + 1))
+        lvl = np.clip(np.floor(np.log2(sc / 56 + 1e-6)), 0, 3).astype(int)
+        for i in range(4):
+            sel = np.nonzero(lvl == i)[0]
+            if len(sel):
+                exp = orc.roi_align3d_forward(feats_np[i], rois[sel], od, osz, osz, 1 / strides[i], 1 / dstrides[i], 2)
+                np.testing.assert_allclose(out[sel], exp, rtol=1e-4, atol=1e-5 * np.abs(exp).max())

@@ -40,11 +40,14 @@ def main():
     ap.add_argument('--static-mask-batch', action='store_true',
                     help='mask heads always on the full 128-row batch (no positive-count read-back, no host sync)')
     ap.add_argument('--profile', action='store_true', help='torch profiler table of one step')
+    ap.add_argument('--bf16', action='store_true', help='BASELINE configs[4]: bf16 activation storage in backbone + FPN')
+    ap.add_argument('--dcn-neck', action='store_true', help='BASELINE configs[4]: DeformConv3d in place of the FPN output convs')
     a = ap.parse_args()
     D, H, W = (int(v) for v in a.vol.split(','))
     dev = torch.device('cuda:0')
     torch.manual_seed(0)
-    det = TwoStageDetector3D2Scales(device=dev) if a.two_scales else TwoStageDetector3D(device=dev, with_mask=not a.no_mask)
+    kw = dict(dtype=torch.bfloat16 if a.bf16 else torch.float32, neck_dcn=a.dcn_neck)
+    det = TwoStageDetector3D2Scales(device=dev, **kw) if a.two_scales else TwoStageDetector3D(device=dev, with_mask=not a.no_mask, **kw)
     det.extract.init_weights()
     if a.static_mask_batch:
         import copy
@@ -112,7 +115,8 @@ def main():
     if a.json:
         import json
         print(json.dumps({'two_stage_step_ms': dt * 1e3, 'vol': [D, H, W], 'gts': a.gts, 'steps': a.steps,
-                          'sample_counts': det.last_sample_counts.tolist(), 'static_mask_batch': a.static_mask_batch}))
+                          'sample_counts': det.last_sample_counts.tolist(), 'static_mask_batch': a.static_mask_batch,
+                          'bf16': a.bf16, 'dcn_neck': a.dcn_neck}))
         return
     print({k: ([round(float(x), 5) for x in v] if isinstance(v, list) else round(float(v), 5)) for k, v in losses.items()})
     print('sample counts (pos, neg, cand_pos, cand_neg):', det.last_sample_counts.tolist())
