@@ -426,7 +426,7 @@ def conv3d_wgrad(x, dy, dw_packed, k, stride, pad, dbias=None, workspace=None):
 # plan records (mr3d_op / mr3d_layer_desc in include/mr3d.h)
 OP_CONV_FWD, OP_CONV_WGRAD, OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_ZERO_STUFF2, OP_UPSAMPLE_ADJ = 1, 2, 3, 4, 5, 6
 OP_SUBSAMPLE_FWD, OP_SUBSAMPLE_BWD, OP_VOLUME_PACK, OP_MEMSET0, OP_AXPY, OP_PREP_WEIGHTS, OP_FINISH_GRADS = 7, 8, 9, 10, 11, 12, 13
-OP_STEM_FWD, OP_STEM_WGRAD, OP_CONV_DGRAD_S2, OP_PREP_WEIGHTS_BF16 = 14, 15, 16, 17
+OP_STEM_FWD, OP_STEM_WGRAD, OP_CONV_DGRAD_S2, OP_PREP_WEIGHTS_BF16, OP_STEM_PACK_BF16 = 14, 15, 16, 17, 18
 DTYPE_BF16 = 1          # mr3d_op.i[25]: MR3D_DTYPE_BF16
 
 
@@ -605,6 +605,30 @@ def stem_conv_forward(x_ncdhw, w_packed, shift=None, relu=False):
                                           int(bool(relu)), stream_ptr(x_ncdhw.device))
     check(st, 'mr3d_stem_conv_forward')
     return y
+
+
+def stem_conv_forward_bf16(x_ncdhw, w_packed, shift=None, relu=False):
+    """bf16-MFMA stem: x [N,3,D,H,W] fp32, w_packed fp32 [343,4,16] (packed to bf16 here) -> y bf16 [N,D,Ho,Wo,16]"""
+    assert x_ncdhw.is_cuda and x_ncdhw.is_contiguous() and x_ncdhw.size(1) == 3 and tuple(w_packed.shape) == (343, 4, 16)
+    n, _, d, h, w = x_ncdhw.shape
+    w16 = torch.empty(49 * 4 * 16 * 8, dtype=torch.bfloat16, device=x_ncdhw.device)
+    y = torch.empty((n, d, (h - 1) // 2 + 1, (w - 1) // 2 + 1, 16), dtype=torch.bfloat16, device=x_ncdhw.device)
+    with torch.cuda.device(x_ncdhw.device):
+        check(lib().mr3d_stem_pack_weights_bf16(ptr(w_packed), ptr(w16), stream_ptr(x_ncdhw.device)), 'mr3d_stem_pack_weights_bf16')
+        st = lib().mr3d_stem_conv_forward_bf16(ptr(x_ncdhw), ptr(w16), ctypes.c_void_p(_opt(shift)), ptr(y), n, d, h, w,
+                                               int(bool(relu)), stream_ptr(x_ncdhw.device))
+    check(st, 'mr3d_stem_conv_forward_bf16')
+    return y
+
+
+def stem_conv_wgrad_bf16(x_ncdhw, dy, dw_packed, dbias=None):
+    n, _, d, h, w = x_ncdhw.shape
+    assert dy.is_contiguous() and dy.dtype == torch.bfloat16 and tuple(dw_packed.shape) == (343, 4, 16)
+    with torch.cuda.device(x_ncdhw.device):
+        st = lib().mr3d_stem_conv_wgrad_bf16(ptr(x_ncdhw), ptr(dy), ptr(dw_packed), ctypes.c_void_p(_opt(dbias)), n, d, h, w,
+                                             stream_ptr(x_ncdhw.device))
+    check(st, 'mr3d_stem_conv_wgrad_bf16')
+    return dw_packed
 
 
 def stem_conv_wgrad(x_ncdhw, dy, dw_packed, dbias=None, workspace=None):

@@ -71,12 +71,16 @@ int run_one(const mr3d_op &o, mr3d_stream_t s, bool shared_ws = true) {
                                (float *)p[3], s);
     case MR3D_OP_PREP_WEIGHTS_BF16:
       return mr3d_prepare_weights_bf16((const mr3d_layer_desc *)p[0], i[0], (const float *)p[1], p[2], s);
+    case MR3D_OP_STEM_PACK_BF16:
+      return mr3d_stem_pack_weights_bf16((const float *)p[0], p[1], s);
     case MR3D_OP_STEM_FWD:
+      if (bf16 && i[5] == 1) return mr3d_stem_conv_forward_bf16((const float *)p[0], p[1], (const float *)p[2], p[3], i[0], i[1], i[2], i[3], i[4], s);
       if (bf16) return mr3d_stem_conv_forward_bf16out((const float *)p[0], (const float *)p[1], (const float *)p[2], p[3], i[0], i[1],
                                                       i[2], i[3], i[4], s);
       return mr3d_stem_conv_forward((const float *)p[0], (const float *)p[1], (const float *)p[2], (float *)p[3], i[0], i[1], i[2],
                                     i[3], i[4], s);
     case MR3D_OP_STEM_WGRAD:
+      if (bf16 && i[6] == 1) return mr3d_stem_conv_wgrad_bf16((const float *)p[0], p[1], (float *)p[2], (float *)p[3], i[0], i[1], i[2], i[3], s);
       if (bf16) return mr3d_stem_conv_wgrad_bf16dy((const float *)p[0], p[1], (float *)p[2], (float *)p[3], i[0], i[1], i[2], i[3], s);
       return mr3d_stem_conv_wgrad_ws((const float *)p[0], (const float *)p[1], (float *)p[2], (float *)p[3], i[0], i[1], i[2], i[3],
                                      shared_ws ? (float *)p[4] : nullptr, (shared_ws && p[4]) ? i64_of(i + 4) : 0, s);

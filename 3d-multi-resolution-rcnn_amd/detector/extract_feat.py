@@ -193,6 +193,7 @@ class ExtractFeat3D(nn.Module):
                     o['wb'] = -1
                 self._layer_offsets16[s.index] = o
             self.register_buffer('_packed16', torch.zeros(off16, dtype=torch.bfloat16, device=self.device), persistent=False)
+            self.register_buffer('_stem_w16', torch.zeros(49 * 4 * 16 * 8, dtype=torch.bfloat16, device=self.device), persistent=False)
             self._build_table16()
 
     def _bind_storage(self, arena, grads, param_off, stats_off, first=False):
@@ -429,8 +430,15 @@ class ExtractFeat3D(nn.Module):
             fwd.append(self._conv_fwd(P.x4, stem, P.stem_out, relu=True))
         else:
             # the stem kernels read the planar volume directly (no NDHWC repack)
-            fwd.append(self._op(_hip.OP_STEM_FWD, [P.x_in, self._w(stem, 'wf'), self._w(stem, 'shift'), P.stem_out],
-                                [N, D, H, W, 1]))
+            # bf16 engine: the stem runs on the bf16 matrix cores too (csrc/stem_bf16.hip); MR3D_STEM_BF16=0 keeps the fp32-MFMA
+            # stem kernels with bf16 output / dy (A/B switch)
+            P.stem_bf16 = self.bf16 and os.environ.get('MR3D_STEM_BF16', '1') != '0'
+            if P.stem_bf16:
+                fwd.append(_hip.make_op(_hip.OP_STEM_PACK_BF16, [self._w(stem, 'wf'), self._stem_w16], []))
+                fwd.append(self._op(_hip.OP_STEM_FWD, [P.x_in, self._stem_w16, self._w(stem, 'shift'), P.stem_out], [N, D, H, W, 1, 1]))
+            else:
+                fwd.append(self._op(_hip.OP_STEM_FWD, [P.x_in, self._w(stem, 'wf'), self._w(stem, 'shift'), P.stem_out],
+                                    [N, D, H, W, 1]))
         _, sd, sh, sw, _ = P.stem_out.shape
         pshape = (N, (sd - 1) // 2 + 1, (sh - 1) // 2 + 1, (sw - 1) // 2 + 1, 16)
         P.pool_out = self._new(pshape)
@@ -545,7 +553,7 @@ class ExtractFeat3D(nn.Module):
             bwd.append(self._conv_wgrad(P.x4, g_stem, stem))
         else:
             bwd.append(self._op(_hip.OP_STEM_WGRAD, [P.x_in, g_stem, self._s(stem, 'dwraw'), self._s(stem, 'dbias')],
-                                [N, D, H, W] + [0] * 22 + [1]))
+                                [N, D, H, W, 0, 0, 1 if getattr(P, 'stem_bf16', False) else 0] + [0] * 19 + [1]))
         bwd.append(_hip.make_op(_hip.OP_FINISH_GRADS, [self._table, self._arena, self._scratch, self._grad_arena],
                                 [nL, self.max_cout]))
         P.fwd_ops, P.bwd_ops = fwd, bwd

@@ -457,6 +457,15 @@ int mr3d_stem_conv_forward_bf16out(const float *x_ncdhw, const float *w_packed, 
                                    int h, int w, int relu, mr3d_stream_t stream);
 int mr3d_stem_conv_wgrad_bf16dy(const float *x_ncdhw, const void *dy_bf16, float *dw_packed, float *dbias, int n, int d, int h,
                                 int w, mr3d_stream_t stream);
+/* The stem on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16; csrc/stem_bf16.hip): the fp32 volume is converted to bf16 while
+ * it is staged, accumulation fp32.  w16 = mr3d_stem_pack_weights_bf16(w_packed): [49 (kd,kh)][4 c][16 cout][8 kw] bf16 (50 KB)
+ * from the generic fp32 packing [343][4][16].  Plan records: STEM_FWD with i[25] = bf16 and i[5] = 1 (p[1] = w16), STEM_WGRAD with
+ * i[25] = bf16 and i[6] = 1; dw_packed / dbias fp32, PRE-ZEROED, same layout as the fp32 stem's. */
+int mr3d_stem_pack_weights_bf16(const float *w_packed, void *w16, mr3d_stream_t stream);
+int mr3d_stem_conv_forward_bf16(const float *x_ncdhw, const void *w16, const float *shift, void *y_bf16, int n, int d, int h, int w,
+                                int relu, mr3d_stream_t stream);
+int mr3d_stem_conv_wgrad_bf16(const float *x_ncdhw, const void *dy_bf16, float *dw_packed, float *dbias, int n, int d, int h, int w,
+                              mr3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Plan executor: runs a pre-built list of the operations above with ONE call (the host-side loop of
@@ -486,7 +495,8 @@ typedef enum {
   MR3D_OP_ZERO_STUFF2 = 5, MR3D_OP_UPSAMPLE_ADJ = 6, MR3D_OP_SUBSAMPLE_FWD = 7, MR3D_OP_SUBSAMPLE_BWD = 8,
   MR3D_OP_VOLUME_PACK = 9, MR3D_OP_MEMSET0 = 10, MR3D_OP_AXPY = 11, MR3D_OP_PREP_WEIGHTS = 12,
   MR3D_OP_FINISH_GRADS = 13, MR3D_OP_STEM_FWD = 14, MR3D_OP_STEM_WGRAD = 15, MR3D_OP_CONV_DGRAD_S2 = 16,
-  MR3D_OP_PREP_WEIGHTS_BF16 = 17      /* p = {table16, params, packed16}   i = {num_layers} */
+  MR3D_OP_PREP_WEIGHTS_BF16 = 17,     /* p = {table16, params, packed16}   i = {num_layers} */
+  MR3D_OP_STEM_PACK_BF16 = 18         /* p = {w_packed (fp32 [343][4][16]), w16} */
 } mr3d_op_kind;
 /* i[25] of a record = storage type of the activations it touches: 0 = fp32, MR3D_DTYPE_BF16 = bf16 (the *_bf16 entry
  * points below; CONV_FWD / CONV_WGRAD / MAXPOOL_* / ZERO_STUFF2 / UPSAMPLE_ADJ / SUBSAMPLE_* / STEM_FWD (bf16 output) /

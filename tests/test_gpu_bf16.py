@@ -208,3 +208,29 @@ def test_roialign3d_bf16_features_vs_oracle(dev):
             if len(sel):
                 exp = orc.roi_align3d_forward(feats_np[i], rois[sel], od, osz, osz, 1 / strides[i], 1 / dstrides[i], 2)
                 np.testing.assert_allclose(out[sel], exp, rtol=1e-4, atol=1e-5 * np.abs(exp).max())
+
+
+@pytest.mark.parametrize('dhw', [(6, 20, 24), (9, 34, 70), (5, 17, 33)])
+def test_stem_bf16_forward_and_wgrad(dev, dhw):
+    """csrc/stem_bf16.hip: 7x7x7 s(1,2,2) stem on v_mfma_f32_16x16x32_bf16 (unaligned 16-byte LDS fragments, parity-split
+    slab + transposing dy reads in the weight gradient) vs float64 on the same bf16-rounded operands"""
+    from mr3d_amd import _hip
+    g = torch.Generator().manual_seed(sum(dhw))
+    x = torch.randn((2, 3) + dhw, generator=g)
+    w = torch.randn((16, 3, 7, 7, 7), generator=g) / np.sqrt(3 * 343)
+    shift = torch.randn(16, generator=g)
+    wp = torch.zeros(343, 4, 16)
+    wp[:, :3, :] = w.reshape(16, 3, 343).permute(2, 1, 0)
+    ref = torch.relu(F.conv3d(_bf(x).double(), _bf(w).double(), shift.double(), (1, 2, 2), 3))
+    y = _hip.stem_conv_forward_bf16(x.to(dev), wp.to(dev), shift=shift.to(dev), relu=True)
+    assert y.dtype == torch.bfloat16 and tuple(y.shape) == (2,) + tuple(ref.shape[2:]) + (16,)
+    _close(y.float().permute(0, 4, 1, 2, 3).cpu(), ref, 'stem fwd', BF16_EPS, 3e-3)
+    dy = _bf(torch.randn(ref.shape, generator=g))
+    refw = torch.nn.grad.conv3d_weight(_bf(x).double(), (16, 3, 7, 7, 7), dy.double(), (1, 2, 2), 3)
+    dw = torch.zeros(343, 4, 16, device=dev)
+    db = torch.zeros(16, device=dev)
+    _hip.stem_conv_wgrad_bf16(x.to(dev), _cl(dy).to(dev).bfloat16(), dw, dbias=db)
+    got = dw[:, :3, :].permute(2, 1, 0).reshape(16, 3, 7, 7, 7).cpu()
+    _close(got, refw, 'stem wgrad', 1e-4, 1e-4)
+    assert dw[:, 3, :].abs().max().item() == 0.0
+    _close(db.cpu(), dy.double().sum(dim=(0, 2, 3, 4)), 'stem dbias', 1e-4, 1e-4)
