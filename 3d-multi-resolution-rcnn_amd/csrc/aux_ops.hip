@@ -20,10 +20,8 @@ __device__ __forceinline__ float4 ld4(const bf16_t *p) {
   return make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16),
                      __uint_as_float(q.y & 0xffff0000u));
 }
-__device__ __forceinline__ uint32_t bf16_rne(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
-  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+__device__ __forceinline__ uint32_t bf16_rne(float f) {     // round to nearest even, NaN stays NaN (v_cvt_pk_bf16_f32)
+  return (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)f);
 }
 __device__ __forceinline__ void st4(bf16_t *p, float4 v) {
   uint2 q;

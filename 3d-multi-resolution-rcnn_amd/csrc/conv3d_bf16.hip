@@ -35,11 +35,8 @@ struct BfArgs {
 };
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float((uint32_t)v << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {          // round to nearest even; NaN stays NaN
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+__device__ __forceinline__ bf16_t f2bf(float f) {          // round to nearest even, NaN stays NaN: v_cvt_pk_bf16_f32
+  return __builtin_bit_cast(bf16_t, (__bf16)f);
 }
 
 __device__ __forceinline__ int nearest_src(int dst, int in, int out) {

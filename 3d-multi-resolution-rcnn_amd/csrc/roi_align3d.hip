@@ -351,9 +351,10 @@ __device__ __forceinline__ void build_idx_table(IdxEntry *tab, float start, floa
 }
 
 // ------------------------------------------------------------------------------------------
-// channels-last FORWARD, footprint staged in LDS.  The wave-per-bin kernel above re-reads every trilinear tap from
-// L2 -- 64 x 256 B per output bin, ~22x the bytes the op has to move (the distinct voxels under a RoI's
-// sample footprint once + the output once).  Here a workgroup owns (RoI, 16 channels): it finds the voxel box the RoI's
+// channels-last FORWARD, footprint staged in LDS (the bf16-feature path; opt-in for fp32, see staged_ok).  The
+// wave-per-bin kernel above re-reads every trilinear tap from L2 -- 64 x 256 B per output bin, ~22x the bytes the op has
+// to move (the distinct voxels under a RoI's sample footprint once + the output once).  Here a workgroup owns
+// (RoI, 16 channels): it finds the voxel box the RoI's
 // samples touch (from the per-axis tap tables), stages that box ONCE as [z][y][x][16 ch] fp32 in LDS (64-byte rows
 // from HBM; the other channel groups of the RoI read the rest of the same lines out of L2), evaluates every bin from LDS
 // (a wave = 4 bins x 16 channels), and writes [R,C,PD,PH,PW] rows in 256-B runs through an LDS transpose.  Same
@@ -499,8 +500,12 @@ int launch_fwd_staged(const T *feat, float *out, const float *rois, int num_rois
 }
 
 inline bool staged_ok(int C, int ns, int PD, int PH, int PW) {
-  static const int off = getenv("MR3D_ROIALIGN_STAGED") ? !atoi(getenv("MR3D_ROIALIGN_STAGED")) : 0;     // A/B switch
-  return !off && C % kStCh == 0 && ns > 0 && PD * ns <= kStAxis && PH * ns <= kStAxis && PW * ns <= kStAxis;
+  // Measured on the SURVEY 8(d) bench shapes (MI355X): staging LOSES for fp32 features -- bbox 141 vs 87 us, mask 326 vs 230 us
+  // with the wave-per-bin kernel, whose 256-B tap reads are L2 hits at ~14 TB/s while the staged form pays 4x the
+  // workgroups (16-channel groups), 64-byte global segments and 4-address LDS reads.  It stays the bf16-feature path and an
+  // opt-in (MR3D_ROIALIGN_STAGED=1) for fp32.
+  static const int on = getenv("MR3D_ROIALIGN_STAGED") ? atoi(getenv("MR3D_ROIALIGN_STAGED")) : 0;
+  return on && C % kStCh == 0 && ns > 0 && PD * ns <= kStAxis && PH * ns <= kStAxis && PW * ns <= kStAxis;
 }
 
 // ------------------------------------------------------------------------------------------

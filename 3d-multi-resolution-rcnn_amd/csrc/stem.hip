@@ -33,9 +33,7 @@ struct StemFwdArgs {
 };
 
 __device__ __forceinline__ uint16_t stem_f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-  return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+  return __builtin_bit_cast(uint16_t, (__bf16)f);          // round to nearest even, NaN stays NaN
 }
 __device__ __forceinline__ void stem_store(const StemFwdArgs &p, size_t idx, float v) {
   if (p.y_bf16) reinterpret_cast<uint16_t *>(p.y)[idx] = stem_f2bf(v);

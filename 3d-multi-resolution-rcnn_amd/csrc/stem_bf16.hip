@@ -26,10 +26,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 using bf16_t = uint16_t;
 typedef __attribute__((address_space(3))) s16x4 *lds_s16x4_ptr;
 
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+__device__ __forceinline__ bf16_t f2bf(float f) {          // round to nearest even, NaN stays NaN: v_cvt_pk_bf16_f32
+  return __builtin_bit_cast(bf16_t, (__bf16)f);
 }
 
 struct __attribute__((packed, aligned(2))) U16x8 { uint16_t v[8]; };       // 16 bytes at 2-byte alignment
@@ -79,23 +77,42 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_bf16_kernel(StemBfArgs p, int
   const int id0 = d0 - 3, ih0 = 2 * h0 - 3, iw0 = 2 * w0 - 3;
   const size_t vox = (size_t)p.D * p.H * p.W;
 
-  // ---- stage the slab: threads take (row, column pair); global pairs start at an even column (8-byte aligned float2 when W is even)
-  constexpr int ROWS = 3 * G::HD * G::HH, PAIRS = 20;
-  for (int it = tid; it < ROWS * PAIRS; it += 256) {
-    const int row = it / PAIRS, pr = it - row * PAIRS;
-    const int hh = row % G::HH, hd = (row / G::HH) % G::HD, c = row / (G::HH * G::HD);
-    const int id = id0 + hd, ih = ih0 + hh;
-    const int s0 = 2 * pr - 1;                          // slab columns s0, s0 + 1  <->  input columns iw0 + s0 (even), + 1
-    const int iw = iw0 + s0;
-    float a = 0.f, bq = 0.f;
-    if ((unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H) {
-      const float *src = p.x + ((size_t)n * 3 + c) * vox + ((size_t)id * p.H + ih) * p.W;
-      if ((unsigned)iw < (unsigned)p.W) a = src[iw];
-      if ((unsigned)(iw + 1) < (unsigned)p.W) bq = src[iw + 1];
+  // ---- stage the slab: threads take (row, column pair); global pairs start at an even column (one 8-byte load when W is
+  // even).  Loads are issued in batches of 8 before any of them is consumed: a load -> convert -> store loop would keep ONE
+  // load in flight per thread and cost a full memory latency per pair (measured: 22 us per workgroup that way).
+  constexpr int ROWS = 3 * G::HD * G::HH, PAIRS = 20, TOTAL = ROWS * PAIRS, NIT = (TOTAL + 255) / 256;
+  const bool even_w = (p.W & 1) == 0;
+  for (int base = 0; base < NIT; base += 8) {
+    float2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int it = tid + (base + u) * 256;
+      v[u] = make_float2(0.f, 0.f);
+      if (it < TOTAL) {
+        const int row = it / PAIRS, pr = it - row * PAIRS;
+        const int hh = row % G::HH, hd = (row / G::HH) % G::HD, c = row / (G::HH * G::HD);
+        const int id = id0 + hd, ih = ih0 + hh, iw = iw0 + 2 * pr - 1;
+        if ((unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H) {
+          const float *src = p.x + ((size_t)n * 3 + c) * vox + ((size_t)id * p.H + ih) * p.W;
+          if (even_w && iw >= 0 && iw + 1 < p.W) {
+            v[u] = *reinterpret_cast<const float2 *>(src + iw);
+          } else {
+            if ((unsigned)iw < (unsigned)p.W) v[u].x = src[iw];
+            if ((unsigned)(iw + 1) < (unsigned)p.W) v[u].y = src[iw + 1];
+          }
+        }
+      }
     }
-    bf16_t *dst = slab + (size_t)row * G::HW;
-    if (s0 >= 0) dst[s0] = f2bf(a);
-    dst[s0 + 1] = f2bf(bq);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int it = tid + (base + u) * 256;
+      if (it < TOTAL) {
+        const int row = it / PAIRS, pr = it - row * PAIRS;
+        bf16_t *dst = slab + (size_t)row * G::HW;          // slab columns 2*pr - 1, 2*pr
+        if (pr >= 1) dst[2 * pr - 1] = f2bf(v[u].x);
+        dst[2 * pr] = f2bf(v[u].y);
+      }
+    }
   }
   __syncthreads();
 
@@ -215,22 +232,41 @@ __global__ __launch_bounds__(512, 2) void stem_wgrad_bf16_kernel(StemBfWgArgs p,
     const int id0 = d0 - 3, ih0 = 2 * h0 - 3, iw0 = 2 * w0 - 3;
     __syncthreads();
     // slab: column s = iw - iw0; even s -> plane 0 index s/2, odd s -> plane 1 index (s-1)/2.  Threads take aligned global pairs
-    // (iw0 + s0 even for s0 = 2*pr - 1): s0 odd -> plane 1 index pr - 1, s0 + 1 even -> plane 0 index pr.
-    constexpr int ROWS = 3 * G::HD * G::HH, PAIRS = G::HALF;
-    for (int it = tid; it < ROWS * PAIRS; it += 512) {
-      const int row = it / PAIRS, pr = it - row * PAIRS;
-      const int hh = row % G::HH, hd = (row / G::HH) % G::HD, c = row / (G::HH * G::HD);
-      const int id = id0 + hd, ih = ih0 + hh;
-      const int iw = iw0 + 2 * pr - 1;
-      float a = 0.f, bq = 0.f;
-      if ((unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H) {
-        const float *src = p.x + ((size_t)n * 3 + c) * vox + ((size_t)id * p.H + ih) * p.W;
-        if ((unsigned)iw < (unsigned)p.W) a = src[iw];
-        if ((unsigned)(iw + 1) < (unsigned)p.W) bq = src[iw + 1];
+    // (iw0 + s0 even for s0 = 2*pr - 1): s0 odd -> plane 1 index pr - 1, s0 + 1 even -> plane 0 index pr.  Loads in batches
+    // of 8 (see the forward kernel).
+    constexpr int ROWS = 3 * G::HD * G::HH, PAIRS = G::HALF, TOTAL = ROWS * PAIRS, NIT = (TOTAL + 511) / 512;
+    const bool even_w = (p.W & 1) == 0;
+    for (int base = 0; base < NIT; base += 8) {
+      float2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int it = tid + (base + u) * 512;
+        v[u] = make_float2(0.f, 0.f);
+        if (it < TOTAL) {
+          const int row = it / PAIRS, pr = it - row * PAIRS;
+          const int hh = row % G::HH, hd = (row / G::HH) % G::HD, c = row / (G::HH * G::HD);
+          const int id = id0 + hd, ih = ih0 + hh, iw = iw0 + 2 * pr - 1;
+          if ((unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H) {
+            const float *src = p.x + ((size_t)n * 3 + c) * vox + ((size_t)id * p.H + ih) * p.W;
+            if (even_w && iw >= 0 && iw + 1 < p.W) {
+              v[u] = *reinterpret_cast<const float2 *>(src + iw);
+            } else {
+              if ((unsigned)iw < (unsigned)p.W) v[u].x = src[iw];
+              if ((unsigned)(iw + 1) < (unsigned)p.W) v[u].y = src[iw + 1];
+            }
+          }
+        }
       }
-      bf16_t *dst = slab + (size_t)row * G::ROW;
-      if (pr >= 1) dst[G::HALF + pr - 1] = f2bf(a);
-      dst[pr] = f2bf(bq);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int it = tid + (base + u) * 512;
+        if (it < TOTAL) {
+          const int row = it / PAIRS, pr = it - row * PAIRS;
+          bf16_t *dst = slab + (size_t)row * G::ROW;
+          if (pr >= 1) dst[G::HALF + pr - 1] = f2bf(v[u].x);
+          dst[pr] = f2bf(v[u].y);
+        }
+      }
     }
     // dy tile [m][16] (m = (td*TH + th)*32 + tw), zeros outside the volume
     for (int it = tid; it < G::M * 2; it += 512) {
