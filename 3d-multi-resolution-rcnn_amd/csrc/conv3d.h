@@ -48,3 +48,8 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 // streaming pointwise instances (pointwise.hip); MR3D_ERR_UNSUPPORTED = use the generic kernels
 int mr3d_pointwise_fwd_try(const Conv3dFwdArgs &a, hipStream_t stream, bool probe_only = false);
 int mr3d_pointwise_wgrad_try(const Conv3dWgradArgs &a, hipStream_t stream);
+
+// streaming bf16 pointwise instances (pointwise_bf16.hip); MR3D_ERR_UNSUPPORTED = use the generic bf16 kernel
+int mr3d_pointwise_bf16_try(const void *x, const void *w, void *y, const float *shift, const void *add1, const void *add2,
+                            const void *up, const void *mask, long long rows, int cin, int cout, int cout_pad, int D, int H, int W,
+                            int Du, int Hu, int Wu, int relu, hipStream_t stream);

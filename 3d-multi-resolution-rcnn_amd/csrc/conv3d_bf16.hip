@@ -308,7 +308,16 @@ extern "C" int mr3d_conv3d_forward_bf16(const mr3d_conv3d_desc *d, mr3d_stream_t
   if (a.Cin % 16 != 0 || a.Cout % 8 != 0) return MR3D_ERR_UNSUPPORTED;
   hipStream_t stream = mr3d_stream(stream_);
   const int k = d->kd, s = d->sd;
-  if (k == 1 && s == 1) return dispatch_cc<1, 1>(a, stream);
+  if (k == 1 && s == 1) {
+    const bool dense = a.pd == 0 && a.ph == 0 && a.pw == 0 && a.ysd == 1 && a.ysh == 1 && a.ysw == 1 && a.yD == a.Do && a.yH == a.Ho &&
+                       a.yW == a.Wo;
+    if (dense) {      // HBM-bound layers on the large maps: the barrier-free streaming kernel (csrc/pointwise_bf16.hip)
+      const int st = mr3d_pointwise_bf16_try(a.x, a.w, a.y, a.shift, a.add1, a.add2, a.up, a.mask, (long long)a.N * a.Do * a.Ho * a.Wo,
+                                             a.Cin, a.Cout, a.CoutPad, a.Do, a.Ho, a.Wo, a.Du, a.Hu, a.Wu, a.relu, stream);
+      if (st != MR3D_ERR_UNSUPPORTED) return st;
+    }
+    return dispatch_cc<1, 1>(a, stream);
+  }
   if (k == 1 && s == 2) return dispatch_cc<1, 2>(a, stream);
   if (k == 3 && s == 1) return dispatch_cc<3, 1>(a, stream);
   if (k == 3 && s == 2) return dispatch_cc<3, 2>(a, stream);

@@ -1,0 +1,166 @@
+// Streaming 1x1x1 convolutions in bf16 (BASELINE configs[4]): the HBM-bound pointwise layers of the bottlenecks on the
+// large maps (resnet3d.py:126,173,251 conv1 / conv3 / downsample, fpn3d.py lateral convs; forward and data gradient).
+//
+// No LDS, no workgroup barriers.  The GEMM is issued TRANSPOSED: A = weights (M = output channels), B = activations
+// (N = 32 positions), so that
+//   * a lane's B fragment -- 8 consecutive input channels of ONE position -- is a single 16-byte global load of the
+//     NDHWC row (a wave's slab of 32 positions x Cin is read as full contiguous rows);
+//   * the whole weight matrix lives in REGISTERS as A fragments (<= 16 fragments for the shapes taken here);
+//   * the 32x32 result has the position on the lane and 16 output channels in its registers, in runs of 4 consecutive
+//     channels: residual / mask reads and the bf16 store are 8-byte accesses, two lanes covering 16 contiguous bytes.
+// Waves are persistent over slabs and fetch the next slab's fragments before multiplying the current one.
+// Epilogue as everywhere: + shift + add1 + add2 + nearest-upsampled map, ReLU / ReLU mask.
+#include "conv3d.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+using bf16_t = uint16_t;
+
+struct PwBfArgs {
+  const bf16_t *x; const bf16_t *w; bf16_t *y;
+  const float *shift; const bf16_t *add1; const bf16_t *add2; const bf16_t *up; const bf16_t *mask;
+  long long rows;
+  int D, H, W, Du, Hu, Wu;
+  int relu, CoutPad;
+};
+
+__device__ __forceinline__ int nearest_src(int dst, int in, int out) {
+  int s = (int)floorf((float)dst * ((float)in / (float)out));
+  return s < in - 1 ? s : in - 1;
+}
+
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+  return (uint32_t)__builtin_bit_cast(uint16_t, (__bf16)a) | ((uint32_t)__builtin_bit_cast(uint16_t, (__bf16)b) << 16);
+}
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void pointwise_bf16_kernel(PwBfArgs p, long long nslabs) {
+  constexpr int KK = CIN / 16, MT = (COUT + 31) / 32;
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  const long long wave0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
+
+  // weights as A fragments: row (output channel) mt*32 + r, k = 8h .. 8h+7 of k-step kk
+  bf16x8 wf[MT][KK];
+  const bf16x8 *wl = reinterpret_cast<const bf16x8 *>(p.w) + (size_t)h * p.CoutPad + r;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) wf[mt][kk] = wl[(size_t)kk * 2 * p.CoutPad + mt * 32];
+
+  auto load_x = [&](bf16x8 (&dst)[KK], long long slab) {
+    const long long row = slab * 32 + r;
+    const bool ok = slab < nslabs && row < p.rows;
+    const bf16x8 *src = reinterpret_cast<const bf16x8 *>(p.x + (size_t)(ok ? row : 0) * CIN) + h;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      bf16x8 v = src[kk * 2];
+      if (!ok) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.0f;
+      }
+      dst[kk] = v;
+    }
+  };
+
+  bf16x8 xc[KK], xn[KK];
+  load_x(xc, wave0);
+  for (long long slab = wave0; slab < nslabs; slab += nwaves) {
+    load_x(xn, slab + nwaves);
+    f32x16_t acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[mt][e] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[mt][kk], xc[kk], acc[mt], 0, 0, 0);
+    }
+    const long long row = slab * 32 + r;
+    if (row < p.rows) {
+      size_t upbase = 0;
+      if (p.up) {
+        long long t = row;
+        const int ow = (int)(t % p.W); t /= p.W;
+        const int oh = (int)(t % p.H); t /= p.H;
+        const int od = (int)(t % p.D);
+        const long long n = t / p.D;
+        const int ud = nearest_src(od, p.Du, p.D), uh = nearest_src(oh, p.Hu, p.H), uw = nearest_src(ow, p.Wu, p.W);
+        upbase = ((((size_t)n * p.Du + ud) * p.Hu + uh) * p.Wu + uw) * COUT;
+      }
+      const size_t base = (size_t)row * COUT;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int co = mt * 32 + 8 * g + 4 * h;            // registers 4g .. 4g+3: four consecutive output channels
+          if (co >= COUT) continue;
+          float v[4] = {acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
+          if (p.shift) {
+            const float4 s = *reinterpret_cast<const float4 *>(p.shift + co);
+            v[0] += s.x; v[1] += s.y; v[2] += s.z; v[3] += s.w;
+          }
+          auto add4 = [&](const bf16_t *src, size_t at) {
+            const uint2 q = *reinterpret_cast<const uint2 *>(src + at);
+            v[0] += __uint_as_float(q.x << 16); v[1] += __uint_as_float(q.x & 0xffff0000u);
+            v[2] += __uint_as_float(q.y << 16); v[3] += __uint_as_float(q.y & 0xffff0000u);
+          };
+          if (p.add1) add4(p.add1, base + co);
+          if (p.add2) add4(p.add2, base + co);
+          if (p.up) add4(p.up, upbase + co);
+          if (p.relu) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+          }
+          if (p.mask) {
+            const uint2 q = *reinterpret_cast<const uint2 *>(p.mask + base + co);
+            if (!(__uint_as_float(q.x << 16) > 0.f)) v[0] = 0.f;
+            if (!(__uint_as_float(q.x & 0xffff0000u) > 0.f)) v[1] = 0.f;
+            if (!(__uint_as_float(q.y << 16) > 0.f)) v[2] = 0.f;
+            if (!(__uint_as_float(q.y & 0xffff0000u) > 0.f)) v[3] = 0.f;
+          }
+          uint2 o;
+          o.x = pack2(v[0], v[1]); o.y = pack2(v[2], v[3]);
+          *reinterpret_cast<uint2 *>(p.y + base + co) = o;
+        }
+    }
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) xc[kk] = xn[kk];
+  }
+}
+
+template <int CIN, int COUT>
+int launch_pw(const PwBfArgs &a, hipStream_t stream) {
+  const long long nslabs = (a.rows + 31) / 32;
+  long long grid = (nslabs + 3) / 4;
+  if (grid > 2048) grid = 2048;            // 8 workgroups (32 waves) per CU at most: persistent over the slabs
+  pointwise_bf16_kernel<CIN, COUT><<<(unsigned)grid, 256, 0, stream>>>(a, nslabs);
+  return mr3d_launch_status();
+}
+
+}  // namespace
+
+// MR3D_ERR_UNSUPPORTED = the generic bf16 kernel takes the shape
+int mr3d_pointwise_bf16_try(const void *x, const void *w, void *y, const float *shift, const void *add1, const void *add2,
+                            const void *up, const void *mask, long long rows, int cin, int cout, int cout_pad, int D, int H, int W,
+                            int Du, int Hu, int Wu, int relu, hipStream_t stream) {
+  static const int off = getenv("MR3D_PW_BF16_STREAM") ? !atoi(getenv("MR3D_PW_BF16_STREAM")) : 0;      // A/B switch
+  if (off || rows < 32768) return MR3D_ERR_UNSUPPORTED;
+  PwBfArgs a;
+  a.x = (const bf16_t *)x; a.w = (const bf16_t *)w; a.y = (bf16_t *)y; a.shift = shift;
+  a.add1 = (const bf16_t *)add1; a.add2 = (const bf16_t *)add2; a.up = (const bf16_t *)up; a.mask = (const bf16_t *)mask;
+  a.rows = rows; a.D = D; a.H = H; a.W = W; a.Du = Du; a.Hu = Hu; a.Wu = Wu; a.relu = relu; a.CoutPad = cout_pad;
+  switch (cin * 1000 + cout) {
+    case 16016: return launch_pw<16, 16>(a, stream);
+    case 16064: return launch_pw<16, 64>(a, stream);
+    case 64016: return launch_pw<64, 16>(a, stream);
+    case 64032: return launch_pw<64, 32>(a, stream);
+    case 32064: return launch_pw<32, 64>(a, stream);
+    case 64064: return launch_pw<64, 64>(a, stream);
+    case 32128: return launch_pw<32, 128>(a, stream);
+    case 128032: return launch_pw<128, 32>(a, stream);
+    case 64128: return launch_pw<64, 128>(a, stream);
+    case 128064: return launch_pw<128, 64>(a, stream);
+  }
+  return MR3D_ERR_UNSUPPORTED;
+}

@@ -234,3 +234,28 @@ def test_stem_bf16_forward_and_wgrad(dev, dhw):
     _close(got, refw, 'stem wgrad', 1e-4, 1e-4)
     assert dw[:, 3, :].abs().max().item() == 0.0
     _close(db.cpu(), dy.double().sum(dim=(0, 2, 3, 4)), 'stem dbias', 1e-4, 1e-4)
+
+
+@pytest.mark.parametrize('cin,cout', [(16, 64), (64, 16), (64, 64), (32, 128), (128, 64), (16, 16)])
+def test_pointwise_bf16_streaming(dev, cin, cout):
+    """>= 32768 positions: the barrier-free streaming kernel (csrc/pointwise_bf16.hip, transposed GEMM, weights in registers)
+    with the full epilogue (shift, two residuals, nearest-upsample add, ReLU; then the mask form) and a ragged last slab"""
+    from mr3d_amd import _hip
+    g = torch.Generator().manual_seed(cin + cout)
+    dhw = (9, 61, 63)                               # 34,587 positions: not a multiple of 32
+    x = _bf(torch.randn((1, cin) + dhw, generator=g))
+    w = _bf(torch.randn((cout, cin, 1, 1, 1), generator=g) / np.sqrt(cin))
+    shift = torch.randn(cout, generator=g)
+    add1, add2 = _bf(torch.randn((1, cout) + dhw, generator=g)), _bf(torch.randn((1, cout) + dhw, generator=g))
+    up = _bf(torch.randn((1, cout, 5, 31, 32), generator=g))
+    mask = _bf(torch.randn((1, cout) + dhw, generator=g))
+    conv = F.conv3d(x.double(), w.double(), shift.double())
+    b = lambda t: _cl(t).to(dev).bfloat16()
+    w16 = _hip.pack_conv_weight_bf16(w).to(dev)
+    y = _hip.conv3d_forward_bf16(b(x), w16, cout, (1, 1, 1), (1, 1, 1), (0, 0, 0), shift=shift.to(dev), add1=b(add1), add2=b(add2),
+                                 up=b(up), relu=True)
+    ref = torch.relu(conv + add1 + add2 + F.interpolate(up.double(), size=dhw, mode='nearest'))
+    _close(y.float().permute(0, 4, 1, 2, 3).cpu(), ref, 'streaming fused relu', BF16_EPS, 3e-3)
+    y2 = _hip.conv3d_forward_bf16(b(x), w16, cout, (1, 1, 1), (1, 1, 1), (0, 0, 0), add1=b(add1), mask=b(mask))
+    _close(y2.float().permute(0, 4, 1, 2, 3).cpu(), (conv - shift.double().view(1, -1, 1, 1, 1) + add1) * (mask > 0), 'streaming mask',
+           BF16_EPS, 3e-3)

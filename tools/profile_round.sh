@@ -11,10 +11,10 @@ cd /tmp && export TMPDIR=/tmp
 B="$REPO/bench.py"
 python3 "$B" --steps 20 --warmup 5 > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
 python3 "$B" --steps 2000 --warmup 20 --no-aux --no-cpu-baseline > "$OUT/bench_sustained_2000.json" 2>/dev/null
-rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o kt -- python3 "$B" --steps 20 --warmup 5 --no-aux --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/kt.err"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/fetch" -o fetch -- python3 "$B" --steps 2 --warmup 2 --no-aux --no-cpu-baseline > /dev/null 2> "$OUT/fetch.err"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$OUT/write" -o write -- python3 "$B" --steps 2 --warmup 2 --no-aux --no-cpu-baseline > /dev/null 2> "$OUT/write.err"
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-trace -d "$OUT/sq" -o sq -- python3 "$B" --steps 2 --warmup 2 --no-aux --no-cpu-baseline > /dev/null 2> "$OUT/sq.err"
+rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/kt" -o kt -- python3 "$B" --steps 20 --warmup 5 --no-aux --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/kt.err"
+rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d "$OUT/fetch" -o fetch -- python3 "$B" --steps 2 --warmup 2 --no-aux --no-cpu-baseline > /dev/null 2> "$OUT/fetch.err"
+rocprofv3 --output-format csv --pmc WRITE_SIZE --kernel-trace -d "$OUT/write" -o write -- python3 "$B" --steps 2 --warmup 2 --no-aux --no-cpu-baseline > /dev/null 2> "$OUT/write.err"
+rocprofv3 --output-format csv --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-trace -d "$OUT/sq" -o sq -- python3 "$B" --steps 2 --warmup 2 --no-aux --no-cpu-baseline > /dev/null 2> "$OUT/sq.err"
 cd "$REPO"
 KS=$(find "$OUT/kt" -name '*kernel_stats.csv' | head -1)
 FC=$(find "$OUT/fetch" -name '*counter_collection.csv' | head -1)
