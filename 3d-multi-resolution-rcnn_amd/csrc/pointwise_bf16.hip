@@ -1,14 +1,14 @@
 // Streaming 1x1x1 convolutions in bf16 (BASELINE configs[4]): the HBM-bound pointwise layers of the bottlenecks on the
 // large maps (resnet3d.py:126,173,251 conv1 / conv3 / downsample, fpn3d.py lateral convs; forward and data gradient).
 //
-// No LDS, no workgroup barriers.  The GEMM is issued TRANSPOSED: A = weights (M = output channels), B = activations
+// The GEMM is issued TRANSPOSED: A = weights (M = output channels), B = activations
 // (N = 32 positions), so that
 //   * a lane's B fragment -- 8 consecutive input channels of ONE position -- is a single 16-byte global load of the
 //     NDHWC row (a wave's slab of 32 positions x Cin is read as full contiguous rows);
 //   * the whole weight matrix lives in REGISTERS as A fragments (<= 16 fragments for the shapes taken here);
-//   * the 32x32 result has the position on the lane and 16 output channels in its registers, in runs of 4 consecutive
-//     channels: residual / mask reads and the bf16 store are 8-byte accesses, two lanes covering 16 contiguous bytes.
-// Waves are persistent over slabs and fetch the next slab's fragments before multiplying the current one.
+//   * the 32x32 result (position on the lane, output channels in the registers) is turned row-major through a
+//     WAVE-PRIVATE LDS tile, so residual / mask reads and the bf16 store are 16-byte accesses covering whole 128-byte rows.
+// No workgroup barriers.  Waves are persistent over slabs and fetch the next slab's fragments before multiplying the current one.
 // Epilogue as everywhere: + shift + add1 + add2 + nearest-upsampled map, ReLU / ReLU mask.
 #include "conv3d.h"
 
@@ -38,6 +38,8 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void pointwise_bf16_kernel(PwBfArgs p, long long nslabs) {
   constexpr int KK = CIN / 16, MT = (COUT + 31) / 32;
+  constexpr int TROW = COUT + 4;                          // fp32 per position row of the epilogue tile (float4-aligned, staggered)
+  extern __shared__ __attribute__((aligned(16))) unsigned char pw_lds[];
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
   const long long wave0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
 
@@ -76,9 +78,44 @@ __global__ __launch_bounds__(256) void pointwise_bf16_kernel(PwBfArgs p, long lo
 #pragma unroll
       for (int kk = 0; kk < KK; ++kk) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[mt][kk], xc[kk], acc[mt], 0, 0, 0);
     }
-    const long long row = slab * 32 + r;
-    if (row < p.rows) {
-      size_t upbase = 0;
+    // ---- epilogue through a WAVE-PRIVATE LDS tile [32 positions][COUT] fp32: the accumulators have the position on the lane
+    // (8-byte stores 128 B apart: 8x the write requests, measured 2.6x slower than the generic kernel); row-major, 8 lanes
+    // finish one position's 128 contiguous bytes with 16-byte accesses.  No workgroup barrier: only this wave touches the tile.
+    float *tile = reinterpret_cast<float *>(pw_lds) + (threadIdx.x >> 6) * (32 * TROW);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = mt * 32 + 8 * g + 4 * h;
+        if (co < COUT)
+          *reinterpret_cast<float4 *>(tile + r * TROW + co) = make_float4(acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]);
+      }
+    __builtin_amdgcn_s_waitcnt(0xc07f);                   // lgkmcnt(0): the wave's own LDS writes have landed
+    __builtin_amdgcn_wave_barrier();
+    constexpr int G8 = COUT / 8;                           // 16-byte output groups per position
+    constexpr int ITEMS = 32 * G8;
+#pragma unroll
+    for (int it0 = 0; it0 < ITEMS; it0 += 64) {
+      const int item = it0 + lane;
+      if (ITEMS % 64 != 0 && item >= ITEMS) break;
+      const int rr = item / G8, co = (item % G8) * 8;
+      const long long row = slab * 32 + rr;
+      if (row >= p.rows) continue;
+      const float4 v0 = *reinterpret_cast<const float4 *>(tile + rr * TROW + co), v1 = *reinterpret_cast<const float4 *>(tile + rr * TROW + co + 4);
+      float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      if (p.shift) {
+        const float4 s0 = *reinterpret_cast<const float4 *>(p.shift + co), s1 = *reinterpret_cast<const float4 *>(p.shift + co + 4);
+        v[0] += s0.x; v[1] += s0.y; v[2] += s0.z; v[3] += s0.w; v[4] += s1.x; v[5] += s1.y; v[6] += s1.z; v[7] += s1.w;
+      }
+      auto add8 = [&](const bf16_t *src, size_t at) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(src + at);
+        const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[2 * j] += __uint_as_float(wds[j] << 16); v[2 * j + 1] += __uint_as_float(wds[j] & 0xffff0000u); }
+      };
+      const size_t base = (size_t)row * COUT + co;
+      if (p.add1) add8(p.add1, base);
+      if (p.add2) add8(p.add2, base);
       if (p.up) {
         long long t = row;
         const int ow = (int)(t % p.W); t /= p.W;
@@ -86,44 +123,26 @@ __global__ __launch_bounds__(256) void pointwise_bf16_kernel(PwBfArgs p, long lo
         const int od = (int)(t % p.D);
         const long long n = t / p.D;
         const int ud = nearest_src(od, p.Du, p.D), uh = nearest_src(oh, p.Hu, p.H), uw = nearest_src(ow, p.Wu, p.W);
-        upbase = ((((size_t)n * p.Du + ud) * p.Hu + uh) * p.Wu + uw) * COUT;
+        add8(p.up, ((((size_t)n * p.Du + ud) * p.Hu + uh) * p.Wu + uw) * COUT + co);
       }
-      const size_t base = (size_t)row * COUT;
+      if (p.relu) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+      }
+      if (p.mask) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(p.mask + base);
+        const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int co = mt * 32 + 8 * g + 4 * h;            // registers 4g .. 4g+3: four consecutive output channels
-          if (co >= COUT) continue;
-          float v[4] = {acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
-          if (p.shift) {
-            const float4 s = *reinterpret_cast<const float4 *>(p.shift + co);
-            v[0] += s.x; v[1] += s.y; v[2] += s.z; v[3] += s.w;
-          }
-          auto add4 = [&](const bf16_t *src, size_t at) {
-            const uint2 q = *reinterpret_cast<const uint2 *>(src + at);
-            v[0] += __uint_as_float(q.x << 16); v[1] += __uint_as_float(q.x & 0xffff0000u);
-            v[2] += __uint_as_float(q.y << 16); v[3] += __uint_as_float(q.y & 0xffff0000u);
-          };
-          if (p.add1) add4(p.add1, base + co);
-          if (p.add2) add4(p.add2, base + co);
-          if (p.up) add4(p.up, upbase + co);
-          if (p.relu) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-          }
-          if (p.mask) {
-            const uint2 q = *reinterpret_cast<const uint2 *>(p.mask + base + co);
-            if (!(__uint_as_float(q.x << 16) > 0.f)) v[0] = 0.f;
-            if (!(__uint_as_float(q.x & 0xffff0000u) > 0.f)) v[1] = 0.f;
-            if (!(__uint_as_float(q.y << 16) > 0.f)) v[2] = 0.f;
-            if (!(__uint_as_float(q.y & 0xffff0000u) > 0.f)) v[3] = 0.f;
-          }
-          uint2 o;
-          o.x = pack2(v[0], v[1]); o.y = pack2(v[2], v[3]);
-          *reinterpret_cast<uint2 *>(p.y + base + co) = o;
+        for (int j = 0; j < 4; ++j) {
+          if (!(__uint_as_float(wds[j] << 16) > 0.f)) v[2 * j] = 0.f;
+          if (!(__uint_as_float(wds[j] & 0xffff0000u) > 0.f)) v[2 * j + 1] = 0.f;
         }
+      }
+      uint4 o;
+      o.x = pack2(v[0], v[1]); o.y = pack2(v[2], v[3]); o.z = pack2(v[4], v[5]); o.w = pack2(v[6], v[7]);
+      *reinterpret_cast<uint4 *>(p.y + base) = o;
     }
+    __builtin_amdgcn_wave_barrier();                      // the tile is rewritten by the next slab
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) xc[kk] = xn[kk];
   }
@@ -134,7 +153,17 @@ int launch_pw(const PwBfArgs &a, hipStream_t stream) {
   const long long nslabs = (a.rows + 31) / 32;
   long long grid = (nslabs + 3) / 4;
   if (grid > 2048) grid = 2048;            // 8 workgroups (32 waves) per CU at most: persistent over the slabs
-  pointwise_bf16_kernel<CIN, COUT><<<(unsigned)grid, 256, 0, stream>>>(a, nslabs);
+  constexpr int lds_bytes = 4 * 32 * (COUT + 4) * 4;     // one [32][COUT + 4] fp32 tile per wave
+  static bool attr_done = false;
+  if (!attr_done && lds_bytes > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(pointwise_bf16_kernel<CIN, COUT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            lds_bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      return MR3D_ERR_LAUNCH;
+    }
+    attr_done = true;
+  }
+  pointwise_bf16_kernel<CIN, COUT><<<(unsigned)grid, 256, lds_bytes, stream>>>(a, nslabs);
   return mr3d_launch_status();
 }
 
