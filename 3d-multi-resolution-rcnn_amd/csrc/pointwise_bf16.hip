@@ -66,10 +66,31 @@ __global__ __launch_bounds__(256) void pointwise_bf16_kernel(PwBfArgs p, long lo
     }
   };
 
+  // epilogue geometry: item = (position rr, 8-channel group) of the row-major tile; 64 lanes take 64 items per step.  G8 divides
+  // 64, so a lane keeps the SAME channel group in every step: its 8 shift values are loaded once.
+  constexpr int G8 = COUT / 8, NITEM = (32 * G8 + 63) / 64, RSTEP = 64 / G8;
+  const int e_co = (lane % G8) * 8, e_r0 = lane / G8;
+  float sh8[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) sh8[j] = p.shift ? p.shift[e_co + j] : 0.f;
+  float *tile = reinterpret_cast<float *>(pw_lds) + (threadIdx.x >> 6) * (32 * TROW);
+
   bf16x8 xc[KK], xn[KK];
   load_x(xc, wave0);
   for (long long slab = wave0; slab < nslabs; slab += nwaves) {
     load_x(xn, slab + nwaves);
+    // residual / mask operands of this slab: ALL loads are issued before anything waits on them (a load -> use -> store
+    // loop costs one memory round trip per step: measured 27 us per slab that way)
+    uint4 ea[NITEM], em[NITEM];
+#pragma unroll
+    for (int it = 0; it < NITEM; ++it) {
+      const int rr = e_r0 + it * RSTEP;
+      const long long row = slab * 32 + rr;
+      const bool ok = rr < 32 && row < p.rows;
+      const size_t at = (size_t)(ok ? row : 0) * COUT + e_co;
+      ea[it] = p.add1 ? *reinterpret_cast<const uint4 *>(p.add1 + at) : make_uint4(0u, 0u, 0u, 0u);
+      em[it] = p.mask ? *reinterpret_cast<const uint4 *>(p.mask + at) : make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+    }
     f32x16_t acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -79,9 +100,8 @@ __global__ __launch_bounds__(256) void pointwise_bf16_kernel(PwBfArgs p, long lo
       for (int kk = 0; kk < KK; ++kk) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[mt][kk], xc[kk], acc[mt], 0, 0, 0);
     }
     // ---- epilogue through a WAVE-PRIVATE LDS tile [32 positions][COUT] fp32: the accumulators have the position on the lane
-    // (8-byte stores 128 B apart: 8x the write requests, measured 2.6x slower than the generic kernel); row-major, 8 lanes
-    // finish one position's 128 contiguous bytes with 16-byte accesses.  No workgroup barrier: only this wave touches the tile.
-    float *tile = reinterpret_cast<float *>(pw_lds) + (threadIdx.x >> 6) * (32 * TROW);
+    // (8-byte stores 128 B apart would be 8x the write requests); row-major, 8 lanes finish one position's 128 contiguous
+    // bytes with 16-byte accesses.  No workgroup barrier: only this wave touches the tile (LDS ops of a wave execute in order).
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -90,57 +110,49 @@ __global__ __launch_bounds__(256) void pointwise_bf16_kernel(PwBfArgs p, long lo
         if (co < COUT)
           *reinterpret_cast<float4 *>(tile + r * TROW + co) = make_float4(acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]);
       }
-    __builtin_amdgcn_s_waitcnt(0xc07f);                   // lgkmcnt(0): the wave's own LDS writes have landed
     __builtin_amdgcn_wave_barrier();
-    constexpr int G8 = COUT / 8;                           // 16-byte output groups per position
-    constexpr int ITEMS = 32 * G8;
 #pragma unroll
-    for (int it0 = 0; it0 < ITEMS; it0 += 64) {
-      const int item = it0 + lane;
-      if (ITEMS % 64 != 0 && item >= ITEMS) break;
-      const int rr = item / G8, co = (item % G8) * 8;
+    for (int it = 0; it < NITEM; ++it) {
+      const int rr = e_r0 + it * RSTEP;
       const long long row = slab * 32 + rr;
-      if (row >= p.rows) continue;
-      const float4 v0 = *reinterpret_cast<const float4 *>(tile + rr * TROW + co), v1 = *reinterpret_cast<const float4 *>(tile + rr * TROW + co + 4);
-      float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-      if (p.shift) {
-        const float4 s0 = *reinterpret_cast<const float4 *>(p.shift + co), s1 = *reinterpret_cast<const float4 *>(p.shift + co + 4);
-        v[0] += s0.x; v[1] += s0.y; v[2] += s0.z; v[3] += s0.w; v[4] += s1.x; v[5] += s1.y; v[6] += s1.z; v[7] += s1.w;
-      }
-      auto add8 = [&](const bf16_t *src, size_t at) {
-        const uint4 q = *reinterpret_cast<const uint4 *>(src + at);
+      const bool ok = rr < 32 && row < p.rows;
+      const int rc = rr < 32 ? rr : 0;
+      const float4 v0 = *reinterpret_cast<const float4 *>(tile + rc * TROW + e_co), v1 = *reinterpret_cast<const float4 *>(tile + rc * TROW + e_co + 4);
+      float v[8] = {v0.x + sh8[0], v0.y + sh8[1], v0.z + sh8[2], v0.w + sh8[3], v1.x + sh8[4], v1.y + sh8[5], v1.z + sh8[6], v1.w + sh8[7]};
+      auto add8 = [&](const uint4 q) {
         const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) { v[2 * j] += __uint_as_float(wds[j] << 16); v[2 * j + 1] += __uint_as_float(wds[j] & 0xffff0000u); }
       };
-      const size_t base = (size_t)row * COUT + co;
-      if (p.add1) add8(p.add1, base);
-      if (p.add2) add8(p.add2, base);
+      add8(ea[it]);
+      const size_t base = (size_t)(ok ? row : 0) * COUT + e_co;
+      if (p.add2) add8(*reinterpret_cast<const uint4 *>(p.add2 + base));
       if (p.up) {
-        long long t = row;
+        long long t = ok ? row : 0;
         const int ow = (int)(t % p.W); t /= p.W;
         const int oh = (int)(t % p.H); t /= p.H;
         const int od = (int)(t % p.D);
         const long long n = t / p.D;
         const int ud = nearest_src(od, p.Du, p.D), uh = nearest_src(oh, p.Hu, p.H), uw = nearest_src(ow, p.Wu, p.W);
-        add8(p.up, ((((size_t)n * p.Du + ud) * p.Hu + uh) * p.Wu + uw) * COUT + co);
+        add8(*reinterpret_cast<const uint4 *>(p.up + ((((size_t)n * p.Du + ud) * p.Hu + uh) * p.Wu + uw) * COUT + e_co));
       }
       if (p.relu) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
       }
-      if (p.mask) {
-        const uint4 q = *reinterpret_cast<const uint4 *>(p.mask + base);
-        const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
+      {
+        const uint32_t wds[4] = {em[it].x, em[it].y, em[it].z, em[it].w};          // all-ones (bf16 1.0) when there is no mask
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if (!(__uint_as_float(wds[j] << 16) > 0.f)) v[2 * j] = 0.f;
           if (!(__uint_as_float(wds[j] & 0xffff0000u) > 0.f)) v[2 * j + 1] = 0.f;
         }
       }
-      uint4 o;
-      o.x = pack2(v[0], v[1]); o.y = pack2(v[2], v[3]); o.z = pack2(v[4], v[5]); o.w = pack2(v[6], v[7]);
-      *reinterpret_cast<uint4 *>(p.y + base) = o;
+      if (ok) {
+        uint4 o;
+        o.x = pack2(v[0], v[1]); o.y = pack2(v[2], v[3]); o.z = pack2(v[4], v[5]); o.w = pack2(v[6], v[7]);
+        *reinterpret_cast<uint4 *>(p.y + base) = o;
+      }
     }
     __builtin_amdgcn_wave_barrier();                      // the tile is rewritten by the next slab
 #pragma unroll

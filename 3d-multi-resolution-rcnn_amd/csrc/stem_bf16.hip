@@ -49,11 +49,17 @@ __global__ __launch_bounds__(256) void stem_pack_bf16_kernel(const float *__rest
 }
 
 // ------------------------------------------------------------------------------------------------ forward
+// Persistent workgroups (one per CU, 8 waves) walk the 4x8x16 output tiles.  The packed weights (50 KB) are staged in LDS
+// once; the input slab of the NEXT tile is fetched into registers (all loads in flight at once) while the current tile is
+// multiplied, then converted to bf16 and written to LDS -- the global latency never sits between two MFMA phases.
 struct FwdGeo {
-  static constexpr int TD = 2, TH = 8, TW = 16;
+  static constexpr int TD = 4, TH = 8, TW = 16, NT = 512;
   static constexpr int HD = TD + 6, HH = 2 * (TH - 1) + 7, HW = 40;          // 38 columns used (+1 read by the zero kw slot)
   static constexpr int PLANE = HD * HH * HW;                                  // bf16 elements per channel
-  static constexpr int LDS_BYTES = 3 * PLANE * 2 + 64;
+  static constexpr int W_BYTES = 49 * 4 * 16 * 8 * 2;
+  static constexpr int LDS_BYTES = W_BYTES + 3 * PLANE * 2 + 64;
+  static constexpr int PAIRS = 20;                                           // 21 rows x 20 pairs = 420 of the 512 threads stage a plane
+  static_assert(HH * PAIRS <= NT, "one (channel, depth) plane per staging step");
 };
 
 struct StemBfArgs {
@@ -61,64 +67,63 @@ struct StemBfArgs {
   int N, D, H, W, Ho, Wo, relu;
 };
 
-__global__ __launch_bounds__(256, 2) void stem_fwd_bf16_kernel(StemBfArgs p, int tiles_d, int tiles_h, int tiles_w) {
+__global__ __launch_bounds__(512, 1) void stem_fwd_bf16_kernel(StemBfArgs p, int tiles_d, int tiles_h, int tiles_w, int ntiles) {
   using G = FwdGeo;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  bf16_t *slab = reinterpret_cast<bf16_t *>(lds);
+  unsigned char *wl = lds;
+  unsigned char *slab_b = lds + G::W_BYTES;
+  bf16_t *slab = reinterpret_cast<bf16_t *>(slab_b);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
-  int b = blockIdx.x;
-  const int tw_i = b % tiles_w; b /= tiles_w;
-  const int th_i = b % tiles_h; b /= tiles_h;
-  const int td_i = b % tiles_d; b /= tiles_d;
-  const int n = b;
-  const int d0 = td_i * G::TD, h0 = th_i * G::TH, w0 = tw_i * G::TW;
-  const int id0 = d0 - 3, ih0 = 2 * h0 - 3, iw0 = 2 * w0 - 3;
   const size_t vox = (size_t)p.D * p.H * p.W;
-
-  // ---- stage the slab: threads take (row, column pair); global pairs start at an even column (one 8-byte load when W is
-  // even).  Loads are issued in batches of 8 before any of them is consumed: a load -> convert -> store loop would keep ONE
-  // load in flight per thread and cost a full memory latency per pair (measured: 22 us per workgroup that way).
-  constexpr int ROWS = 3 * G::HD * G::HH, PAIRS = 20, TOTAL = ROWS * PAIRS, NIT = (TOTAL + 255) / 256;
   const bool even_w = (p.W & 1) == 0;
-  for (int base = 0; base < NIT; base += 8) {
-    float2 v[8];
+
+  for (int i = tid; i < G::W_BYTES / 16; i += G::NT)
+    reinterpret_cast<uint4 *>(wl)[i] = reinterpret_cast<const uint4 *>(p.w16)[i];
+
+  // staging map: iteration u = one (channel, depth) plane of the slab (compile-time), thread = (row hh, column pair pr) of it:
+  // the per-thread part of every address is ONE register, the plane part is wave-uniform
+  constexpr int NPL = 3 * G::HD;
+  const int s_hh = tid / G::PAIRS, s_pr = tid - s_hh * G::PAIRS;
+  const bool s_act = s_hh < G::HH;
+  float2 st[NPL];
+  auto fetch = [&](int tile) {
+    int b = tile;
+    const int tw_i = b % tiles_w; b /= tiles_w;
+    const int th_i = b % tiles_h; b /= tiles_h;
+    const int td_i = b % tiles_d; b /= tiles_d;
+    const int n = b;
+    const int id0 = td_i * G::TD - 3, ih = 2 * th_i * G::TH - 3 + s_hh, iw = 2 * tw_i * G::TW - 3 + 2 * s_pr - 1;   // iw is even
+    const bool row_ok = s_act && tile < ntiles && (unsigned)ih < (unsigned)p.H;
+    const bool pair_ok = even_w && iw >= 0 && iw + 1 < p.W;
+    const long long off = (long long)ih * p.W + iw;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int it = tid + (base + u) * 256;
-      v[u] = make_float2(0.f, 0.f);
-      if (it < TOTAL) {
-        const int row = it / PAIRS, pr = it - row * PAIRS;
-        const int hh = row % G::HH, hd = (row / G::HH) % G::HD, c = row / (G::HH * G::HD);
-        const int id = id0 + hd, ih = ih0 + hh, iw = iw0 + 2 * pr - 1;
-        if ((unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H) {
-          const float *src = p.x + ((size_t)n * 3 + c) * vox + ((size_t)id * p.H + ih) * p.W;
-          if (even_w && iw >= 0 && iw + 1 < p.W) {
-            v[u] = *reinterpret_cast<const float2 *>(src + iw);
-          } else {
-            if ((unsigned)iw < (unsigned)p.W) v[u].x = src[iw];
-            if ((unsigned)(iw + 1) < (unsigned)p.W) v[u].y = src[iw + 1];
-          }
+    for (int u = 0; u < NPL; ++u) {
+      const int c = u / G::HD, hd = u % G::HD;
+      const int id = id0 + hd;                                        // wave-uniform
+      st[u] = make_float2(0.f, 0.f);
+      if (row_ok && (unsigned)id < (unsigned)p.D) {
+        const float *src = p.x + ((size_t)n * 3 + c) * vox + (size_t)id * p.H * p.W + off;
+        if (pair_ok) {
+          st[u] = *reinterpret_cast<const float2 *>(src);
+        } else {
+          if ((unsigned)iw < (unsigned)p.W) st[u].x = src[0];
+          if ((unsigned)(iw + 1) < (unsigned)p.W) st[u].y = src[1];
         }
       }
     }
+  };
+  auto commit = [&]() {
+    if (!s_act) return;
+    bf16_t *dst = slab + s_hh * G::HW;                                // slab columns 2*pr - 1, 2*pr
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int it = tid + (base + u) * 256;
-      if (it < TOTAL) {
-        const int row = it / PAIRS, pr = it - row * PAIRS;
-        bf16_t *dst = slab + (size_t)row * G::HW;          // slab columns 2*pr - 1, 2*pr
-        if (pr >= 1) dst[2 * pr - 1] = f2bf(v[u].x);
-        dst[2 * pr] = f2bf(v[u].y);
-      }
+    for (int u = 0; u < NPL; ++u) {
+      if (s_pr >= 1) dst[u * G::HH * G::HW + 2 * s_pr - 1] = f2bf(st[u].x);
+      dst[u * G::HH * G::HW + 2 * s_pr] = f2bf(st[u].y);
     }
-  }
-  __syncthreads();
+  };
 
-  f32x4_t acc[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   // this wave's four (td, th) rows of 16 outputs; lane (r, q): output column r, channel slot q (slot 3: zeros)
   int abase[4];
 #pragma unroll
@@ -126,41 +131,55 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_bf16_kernel(StemBfArgs p, int
     const int mt = wave * 4 + i, td = mt >> 3, th = mt & 7;
     abase[i] = ((((q < 3 ? q : 0) * G::HD + td) * G::HH + 2 * th) * G::HW + 2 * r) * 2;
   }
-  const bf16x8 *wl = reinterpret_cast<const bf16x8 *>(p.w16) + q * 16 + r;
+  const unsigned char *wlane = wl + (q * 16 + r) * 16;
   bf16x8 zero;
 #pragma unroll
   for (int e = 0; e < 8; ++e) zero[e] = (__bf16)0.0f;
-  bf16x8 bcur = wl[0];
-#pragma unroll 1
-  for (int kd = 0; kd < 7; ++kd) {
-#pragma unroll
-    for (int kh = 0; kh < 7; ++kh) {
-      const int ks = kd * 7 + kh;
-      const bf16x8 bnext = wl[(size_t)((ks + 1 < 49) ? ks + 1 : 48) * 64];
-      const int off = ((kd * G::HH + kh) * G::HW) * 2;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        bf16x8 a = lds_frag_unaligned(lds + abase[i] + off);
-        if (q == 3) a = zero;
-        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bcur, acc[i], 0, 0, 0);
-      }
-      bcur = bnext;
-    }
-  }
-  // ---- epilogue: C/D layout of 16x16: column (cout) = lane & 15, row (output column) = 4 * (lane >> 4) + reg
   const float sh = p.shift ? p.shift[r] : 0.f;
+
+  fetch(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();                       // the previous tile's fragments have been read
+    commit();
+    __syncthreads();
+    fetch(tile + gridDim.x);               // in flight during the MFMA phase
+    f32x4_t acc[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int mt = wave * 4 + i, td = mt >> 3, th = mt & 7;
-    const int od = d0 + td, oh = h0 + th;
-    if (od >= p.D || oh >= p.Ho) continue;
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int kd = 0; kd < 7; ++kd) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int ow = w0 + 4 * q + e;
-      if (ow < p.Wo) {
-        float v = acc[i][e] + sh;
-        if (p.relu) v = fmaxf(v, 0.f);
-        p.y[((((size_t)n * p.D + od) * p.Ho + oh) * p.Wo + ow) * 16 + r] = f2bf(v);
+      for (int kh = 0; kh < 7; ++kh) {
+        const bf16x8 bw = *reinterpret_cast<const bf16x8 *>(wlane + (kd * 7 + kh) * 1024);
+        const int off = ((kd * G::HH + kh) * G::HW) * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          bf16x8 a = lds_frag_unaligned(slab_b + abase[i] + off);
+          if (q == 3) a = zero;
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bw, acc[i], 0, 0, 0);
+        }
+      }
+    }
+    // ---- epilogue: C/D layout of 16x16: column (cout) = lane & 15, row (output column) = 4 * (lane >> 4) + reg
+    int b = tile;
+    const int tw_i = b % tiles_w; b /= tiles_w;
+    const int th_i = b % tiles_h; b /= tiles_h;
+    const int td_i = b % tiles_d; b /= tiles_d;
+    const int n = b;
+    const int d0 = td_i * G::TD, h0 = th_i * G::TH, w0 = tw_i * G::TW;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int mt = wave * 4 + i, td = mt >> 3, th = mt & 7;
+      const int od = d0 + td, oh = h0 + th;
+      if (od >= p.D || oh >= p.Ho) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int ow = w0 + 4 * q + e;
+        if (ow < p.Wo) {
+          float v = acc[i][e] + sh;
+          if (p.relu) v = fmaxf(v, 0.f);
+          p.y[((((size_t)n * p.D + od) * p.Ho + oh) * p.Wo + ow) * 16 + r] = f2bf(v);
+        }
       }
     }
   }
@@ -168,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_bf16_kernel(StemBfArgs p, int
 
 // ------------------------------------------------------------------------------------------------ weight gradient
 struct WgGeo {
-  static constexpr int TD = 4, TH = 4, TW = 32;
+  static constexpr int TD = 4, TH = 4, TW = 32, NT = 512;
   static constexpr int HD = TD + 6, HH = 2 * (TH - 1) + 7;                    // 10 x 13 rows
   static constexpr int HALF = 40;                                             // columns per parity plane (35 used + slack)
   static constexpr int ROW = 2 * HALF;                                        // even plane | odd plane
@@ -179,6 +198,8 @@ struct WgGeo {
   static constexpr int LDS_BYTES = SLAB_BYTES + DY_BYTES + 64;
   static constexpr int ROWS = 49 * 24, MT = (ROWS + 15) / 16;                 // 1176 GEMM rows -> 74 tiles (+ 1 of ones)
   static constexpr int MTW = 10;                                              // row tiles per wave (8 waves x 10 >= 75)
+  static constexpr int PAIRS = 36;                                            // columns -1 .. 70; 13 rows x 36 pairs = 468 threads per plane
+  static_assert(HH * PAIRS <= NT, "one (channel, depth) plane per staging step");
 };
 
 struct StemBfWgArgs {
@@ -186,7 +207,7 @@ struct StemBfWgArgs {
   int N, D, H, W, Ho, Wo;
 };
 
-__global__ __launch_bounds__(512, 2) void stem_wgrad_bf16_kernel(StemBfWgArgs p, int tiles_d, int tiles_h, int tiles_w, int ntiles) {
+__global__ __launch_bounds__(512, 1) void stem_wgrad_bf16_kernel(StemBfWgArgs p, int tiles_d, int tiles_h, int tiles_w, int ntiles) {
   using G = WgGeo;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   bf16_t *slab = reinterpret_cast<bf16_t *>(lds);
@@ -195,6 +216,7 @@ __global__ __launch_bounds__(512, 2) void stem_wgrad_bf16_kernel(StemBfWgArgs p,
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
   const size_t vox = (size_t)p.D * p.H * p.W;
+  const bool even_w = (p.W & 1) == 0;
 
   // per-lane slab offset (bytes) of GEMM row R = 16*m + r for every row tile of this wave, k = 8q (+ j) folded in
   int aoff[G::MTW];
@@ -222,66 +244,75 @@ __global__ __launch_bounds__(512, 2) void stem_wgrad_bf16_kernel(StemBfWgArgs p,
 #pragma unroll
   for (int e = 0; e < 8; ++e) { one8[e] = (__bf16)1.0f; zero8[e] = (__bf16)0.0f; }
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // next tile's operands in registers: x as aligned float2 pairs, dy as two 16-byte halves of one position row.
+  // Staging map as in the forward kernel: iteration u = one (channel, depth) plane, thread = (row hh, column pair pr).
+  constexpr int NPL = 3 * G::HD;
+  const int s_hh = tid / G::PAIRS, s_pr = tid - s_hh * G::PAIRS;
+  const bool s_act = s_hh < G::HH;
+  float2 st[NPL];
+  uint4 sdy[2];
+  auto fetch = [&](int tile) {
     int b = tile;
     const int tw_i = b % tiles_w; b /= tiles_w;
     const int th_i = b % tiles_h; b /= tiles_h;
     const int td_i = b % tiles_d; b /= tiles_d;
     const int n = b;
     const int d0 = td_i * G::TD, h0 = th_i * G::TH, w0 = tw_i * G::TW;
-    const int id0 = d0 - 3, ih0 = 2 * h0 - 3, iw0 = 2 * w0 - 3;
-    __syncthreads();
-    // slab: column s = iw - iw0; even s -> plane 0 index s/2, odd s -> plane 1 index (s-1)/2.  Threads take aligned global pairs
-    // (iw0 + s0 even for s0 = 2*pr - 1): s0 odd -> plane 1 index pr - 1, s0 + 1 even -> plane 0 index pr.  Loads in batches
-    // of 8 (see the forward kernel).
-    constexpr int ROWS = 3 * G::HD * G::HH, PAIRS = G::HALF, TOTAL = ROWS * PAIRS, NIT = (TOTAL + 511) / 512;
-    const bool even_w = (p.W & 1) == 0;
-    for (int base = 0; base < NIT; base += 8) {
-      float2 v[8];
+    const int id0 = d0 - 3, ih = 2 * h0 - 3 + s_hh, iw = 2 * w0 - 3 + 2 * s_pr - 1;
+    const bool tile_ok = tile < ntiles;
+    const bool row_ok = s_act && tile_ok && (unsigned)ih < (unsigned)p.H;
+    const bool pair_ok = even_w && iw >= 0 && iw + 1 < p.W;
+    const long long off = (long long)ih * p.W + iw;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int it = tid + (base + u) * 512;
-        v[u] = make_float2(0.f, 0.f);
-        if (it < TOTAL) {
-          const int row = it / PAIRS, pr = it - row * PAIRS;
-          const int hh = row % G::HH, hd = (row / G::HH) % G::HD, c = row / (G::HH * G::HD);
-          const int id = id0 + hd, ih = ih0 + hh, iw = iw0 + 2 * pr - 1;
-          if ((unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H) {
-            const float *src = p.x + ((size_t)n * 3 + c) * vox + ((size_t)id * p.H + ih) * p.W;
-            if (even_w && iw >= 0 && iw + 1 < p.W) {
-              v[u] = *reinterpret_cast<const float2 *>(src + iw);
-            } else {
-              if ((unsigned)iw < (unsigned)p.W) v[u].x = src[iw];
-              if ((unsigned)(iw + 1) < (unsigned)p.W) v[u].y = src[iw + 1];
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int it = tid + (base + u) * 512;
-        if (it < TOTAL) {
-          const int row = it / PAIRS, pr = it - row * PAIRS;
-          bf16_t *dst = slab + (size_t)row * G::ROW;
-          if (pr >= 1) dst[G::HALF + pr - 1] = f2bf(v[u].x);
-          dst[pr] = f2bf(v[u].y);
+    for (int u = 0; u < NPL; ++u) {
+      const int c = u / G::HD, hd = u % G::HD;
+      const int id = id0 + hd;
+      st[u] = make_float2(0.f, 0.f);
+      if (row_ok && (unsigned)id < (unsigned)p.D) {
+        const float *src = p.x + ((size_t)n * 3 + c) * vox + (size_t)id * p.H * p.W + off;
+        if (pair_ok) {
+          st[u] = *reinterpret_cast<const float2 *>(src);
+        } else {
+          if ((unsigned)iw < (unsigned)p.W) st[u].x = src[0];
+          if ((unsigned)(iw + 1) < (unsigned)p.W) st[u].y = src[1];
         }
       }
     }
-    // dy tile [m][16] (m = (td*TH + th)*32 + tw), zeros outside the volume
-    for (int it = tid; it < G::M * 2; it += 512) {
-      const int m = it >> 1, half = it & 1;
+    {
+      const int m = tid;                                 // 512 positions, one per thread
       const int tw = m & 31, th = (m >> 5) % G::TH, td = m / (32 * G::TH);
       const int od = d0 + td, oh = h0 + th, ow = w0 + tw;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (od < p.D && oh < p.Ho && ow < p.Wo)
-        v = *reinterpret_cast<const uint4 *>(p.dy + ((((size_t)n * p.D + od) * p.Ho + oh) * p.Wo + ow) * 16 + half * 8);
-      *reinterpret_cast<uint4 *>(dyt + m * (G::DYROW * 2) + half * 16) = v;
+      sdy[0] = sdy[1] = make_uint4(0u, 0u, 0u, 0u);
+      if (tile_ok && od < p.D && oh < p.Ho && ow < p.Wo) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.dy + ((((size_t)n * p.D + od) * p.Ho + oh) * p.Wo + ow) * 16);
+        sdy[0] = src[0]; sdy[1] = src[1];
+      }
     }
+  };
+  auto commit = [&]() {
+    // slab: column s = iw - iw0; even s -> plane 0 index s/2, odd s -> plane 1 index (s-1)/2; the pair (2*pr - 1, 2*pr)
+    // lands at plane 1 index pr - 1 and plane 0 index pr
+    if (s_act) {
+      bf16_t *dst = slab + s_hh * G::ROW;
+#pragma unroll
+      for (int u = 0; u < NPL; ++u) {
+        if (s_pr >= 1) dst[u * G::HH * G::ROW + G::HALF + s_pr - 1] = f2bf(st[u].x);
+        dst[u * G::HH * G::ROW + s_pr] = f2bf(st[u].y);
+      }
+    }
+    *reinterpret_cast<uint4 *>(dyt + tid * (G::DYROW * 2)) = sdy[0];
+    *reinterpret_cast<uint4 *>(dyt + tid * (G::DYROW * 2) + 16) = sdy[1];
+  };
+
+  fetch(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     __syncthreads();
+    commit();
+    __syncthreads();
+    fetch(tile + gridDim.x);                             // in flight during the MFMA phase
     for (int ks = 0; ks < G::KS; ++ks) {
       const int th = ks % G::TH, td = ks / G::TH;
-      const unsigned char *yb = dyt + ks * 32 * (G::DYROW * 2) + b_lane;
+      unsigned char *yb = dyt + ks * 32 * (G::DYROW * 2) + b_lane;
       const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(yb));
       const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(yb + 4 * (G::DYROW * 2)));
       const bf16x8 bf = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
@@ -328,8 +359,26 @@ extern "C" int mr3d_stem_conv_forward_bf16(const float *x_ncdhw, const void *w16
   a.x = x_ncdhw; a.w16 = (const bf16_t *)w16; a.shift = shift; a.y = (bf16_t *)y_bf16;
   a.N = n; a.D = d; a.H = h; a.W = w; a.Ho = (h - 1) / 2 + 1; a.Wo = (w - 1) / 2 + 1; a.relu = relu;
   using G = FwdGeo;
+  static bool attr = false;
+  static int cus = 0;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(stem_fwd_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            G::LDS_BYTES) != hipSuccess) {
+      (void)hipGetLastError();
+      return MR3D_ERR_LAUNCH;
+    }
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+    attr = true;
+  }
   const int td = (d + G::TD - 1) / G::TD, th = (a.Ho + G::TH - 1) / G::TH, tw = (a.Wo + G::TW - 1) / G::TW;
-  stem_fwd_bf16_kernel<<<(unsigned)(n * td * th * tw), 256, G::LDS_BYTES, mr3d_stream(stream_)>>>(a, td, th, tw);
+  const long long ntiles = (long long)n * td * th * tw;
+  if (ntiles > 0x7fffffffLL) return MR3D_ERR_UNSUPPORTED;
+  const int grid = ntiles < cus ? (int)ntiles : cus;         // one persistent 8-wave workgroup per CU (100 KB of LDS)
+  stem_fwd_bf16_kernel<<<(unsigned)grid, G::NT, G::LDS_BYTES, mr3d_stream(stream_)>>>(a, td, th, tw, (int)ntiles);
   return mr3d_launch_status();
 }
 
@@ -341,18 +390,24 @@ extern "C" int mr3d_stem_conv_wgrad_bf16(const float *x_ncdhw, const void *dy_bf
   a.N = n; a.D = d; a.H = h; a.W = w; a.Ho = (h - 1) / 2 + 1; a.Wo = (w - 1) / 2 + 1;
   using G = WgGeo;
   static bool attr = false;
+  static int cus = 0;
   if (!attr) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(stem_wgrad_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             G::LDS_BYTES) != hipSuccess) {
       (void)hipGetLastError();
       return MR3D_ERR_LAUNCH;
     }
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
     attr = true;
   }
   const int td = (d + G::TD - 1) / G::TD, th = (a.Ho + G::TH - 1) / G::TH, tw = (a.Wo + G::TW - 1) / G::TW;
   const long long ntiles = (long long)n * td * th * tw;
   if (ntiles > 0x7fffffffLL) return MR3D_ERR_UNSUPPORTED;
-  const int grid = ntiles < 512 ? (int)ntiles : 512;
+  const int grid = ntiles < cus ? (int)ntiles : cus;         // one persistent workgroup per CU (87 KB of LDS)
   stem_wgrad_bf16_kernel<<<(unsigned)grid, 512, G::LDS_BYTES, mr3d_stream(stream_)>>>(a, td, th, tw, (int)ntiles);
   return mr3d_launch_status();
 }
