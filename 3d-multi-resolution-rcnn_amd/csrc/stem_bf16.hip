@@ -30,7 +30,10 @@ __device__ __forceinline__ bf16_t f2bf(float f) {          // round to nearest e
   return __builtin_bit_cast(bf16_t, (__bf16)f);
 }
 
-struct __attribute__((packed, aligned(2))) U16x8 { uint16_t v[8]; };       // 16 bytes at 2-byte alignment
+// 16 bytes at 4-byte alignment: the compiler emits dword-granular LDS reads (ds_read2_b32 pairs).  A 16-byte read whose address
+// is only 2-byte aligned does execute on gfx950, but the DS unit then stays busy ~8x longer (SQ_LDS_IDX_ACTIVE: 79 % of the
+// weight-gradient kernel's run time) -- every fragment address in this file is an even bf16 element.
+struct __attribute__((packed, aligned(4))) U16x8 { uint16_t v[8]; };
 
 __device__ __forceinline__ bf16x8 lds_frag_unaligned(const unsigned char *p) {
   const U16x8 raw = *reinterpret_cast<const U16x8 *>(p);
@@ -190,7 +193,10 @@ struct WgGeo {
   static constexpr int TD = 4, TH = 4, TW = 32, NT = 512;
   static constexpr int HD = TD + 6, HH = 2 * (TH - 1) + 7;                    // 10 x 13 rows
   static constexpr int HALF = 40;                                             // columns per parity plane (35 used + slack)
-  static constexpr int ROW = 2 * HALF;                                        // even plane | odd plane
+  // A row holds FOUR images: even columns, even columns shifted by one, odd columns, odd columns shifted by one.  A fragment
+  // starts at plane index ow + (kw >> 1): with the shifted copy every start is an EVEN element = 4-byte aligned.  (2-byte
+  // aligned 16-byte LDS reads work on gfx950 but were measured ~10x slower than dword-aligned ones: 1.68 ms for this kernel.)
+  static constexpr int ROW = 4 * HALF;
   static constexpr int PLANE = HD * HH * ROW;
   static constexpr int DYROW = 24;                                            // bf16 per dy row: 16 + 8 of padding (48 B)
   static constexpr int M = TD * TH * TW, KS = TD * TH;
@@ -231,7 +237,8 @@ __global__ __launch_bounds__(512, 1) void stem_wgrad_bf16_kernel(StemBfWgArgs p,
     live[i] = (m < G::MT) && R < G::ROWS && kw < 7;
     // input column 2*ow + kw (relative to the slab origin): parity plane kw & 1, index ow + (kw >> 1)
     const int cc = live[i] ? c : 0, kk = live[i] ? kw : 0, dd = live[i] ? kd : 0, hh_ = live[i] ? kh : 0;
-    aoff[i] = (((cc * G::HD + dd) * G::HH + hh_) * G::ROW + (kk & 1) * G::HALF + (kk >> 1) + 8 * q) * 2;
+    const int sft = kk >> 1;                             // odd start -> the copy shifted by one, one element earlier
+    aoff[i] = (((cc * G::HD + dd) * G::HH + hh_) * G::ROW + (kk & 1) * 2 * G::HALF + (sft & 1) * G::HALF + (sft & ~1) + 8 * q) * 2;
   }
   // transposing read of dy [position][16]: group q reads positions 8q..8q+7; inside the group lane 4a+b gives row a, columns 4b..4b+3
   const int i16 = lane & 15, ra = i16 >> 2, cb = i16 & 3;
@@ -290,14 +297,18 @@ __global__ __launch_bounds__(512, 1) void stem_wgrad_bf16_kernel(StemBfWgArgs p,
     }
   };
   auto commit = [&]() {
-    // slab: column s = iw - iw0; even s -> plane 0 index s/2, odd s -> plane 1 index (s-1)/2; the pair (2*pr - 1, 2*pr)
-    // lands at plane 1 index pr - 1 and plane 0 index pr
+    // slab: column s = iw - iw0; even s -> even image index s/2, odd s -> odd image index (s-1)/2; the pair (2*pr - 1, 2*pr)
+    // lands at odd index pr - 1 and even index pr (and one element earlier in the shifted copies)
     if (s_act) {
       bf16_t *dst = slab + s_hh * G::ROW;
 #pragma unroll
       for (int u = 0; u < NPL; ++u) {
-        if (s_pr >= 1) dst[u * G::HH * G::ROW + G::HALF + s_pr - 1] = f2bf(st[u].x);
-        dst[u * G::HH * G::ROW + s_pr] = f2bf(st[u].y);
+        bf16_t *d = dst + u * G::HH * G::ROW;
+        const bf16_t vo = f2bf(st[u].x), ve = f2bf(st[u].y);          // odd-plane index pr - 1, even-plane index pr
+        if (s_pr >= 1) d[2 * G::HALF + s_pr - 1] = vo;
+        if (s_pr >= 2) d[3 * G::HALF + s_pr - 2] = vo;                // shifted copy: X1[i] = X0[i + 1]
+        d[s_pr] = ve;
+        if (s_pr >= 1) d[G::HALF + s_pr - 1] = ve;
       }
     }
     *reinterpret_cast<uint4 *>(dyt + tid * (G::DYROW * 2)) = sdy[0];
