@@ -2,6 +2,7 @@
 // kernel on the given stream (no allocation, no synchronisation: capturable in a hipGraph).
 #include "mr3d_common.h"
 #include <string.h>
+#include <mutex>
 
 namespace {
 
@@ -125,7 +126,11 @@ struct SideStream {
     return true;
   }
 };
-SideStream g_side;
+// one set of side streams / events per DEVICE (a process that drives several GPUs must not fork onto another device's
+// stream), and one enqueue at a time per device (the fork-event ring is shared by the plans of that device)
+constexpr int kMaxDevices = 16;
+SideStream g_sides[kMaxDevices];
+std::mutex g_side_mu[kMaxDevices];
 int g_side_enabled = 1;
 
 bool wants_side(const mr3d_op &o) {
@@ -139,6 +144,10 @@ extern "C" void mr3d_plan_set_side_stream(int enable) { g_side_enabled = enable;
 extern "C" int mr3d_plan_run(const mr3d_op *ops, int num_ops, int *failed_index, mr3d_stream_t stream) {
   if (!ops || num_ops < 0) return MR3D_ERR_INVALID_ARG;
   hipStream_t main_s = mr3d_stream(stream);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+  std::lock_guard<std::mutex> lock(g_side_mu[dev]);
+  SideStream &g_side = g_sides[dev];
   // a single-op call (used to time one kernel) always runs on the caller's stream
   const bool use_side = g_side_enabled && num_ops > 1 && g_side.init();
   bool side_busy = false;

@@ -16,6 +16,9 @@
 //               [bin][channel] tile is transposed through LDS so the [R,C,PD,PH,PW] output /
 //               top_grad side is accessed in 256-B runs as well.
 #include "mr3d_common.h"
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace {
 
@@ -689,18 +692,26 @@ __global__ __launch_bounds__(kClThreads) void roi_align3d_bwd_box(const float *_
 }
 
 // persistent scratch of the backward plan: [0] item counter, [1 .. 1+R) owned flags, then R*kMaxSub items
-int *g_box_scratch = nullptr;
-size_t g_box_scratch_ints = 0;
-int *box_scratch(int num_rois) {
+// plan scratch of the separable backward: one buffer per (device, stream) -- calls on the same stream are ordered, so
+// they may share it; another stream or another GPU gets its own (a process-global buffer raced there).  Growing a buffer
+// frees the old one with hipFree, which waits for the device: rare (capacity doubles).
+struct BoxScratch { int *p = nullptr; size_t ints = 0; };
+std::mutex g_box_mu;
+std::map<std::pair<int, hipStream_t>, BoxScratch> g_box_scratch;
+int *box_scratch(int num_rois, hipStream_t stream) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(g_box_mu);
+  BoxScratch &b = g_box_scratch[{dev, stream}];
   const size_t need = 1 + (size_t)num_rois * (1 + kMaxSub);
-  if (need > g_box_scratch_ints) {
-    if (g_box_scratch) (void)hipFree(g_box_scratch);
-    g_box_scratch = nullptr;
+  if (need > b.ints) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
     const size_t cap = need < 65536 ? 65536 : need * 2;
-    if (hipMalloc(reinterpret_cast<void **>(&g_box_scratch), cap * sizeof(int)) != hipSuccess) { g_box_scratch_ints = 0; return nullptr; }
-    g_box_scratch_ints = cap;
+    if (hipMalloc(reinterpret_cast<void **>(&b.p), cap * sizeof(int)) != hipSuccess) { b.ints = 0; return nullptr; }
+    b.ints = cap;
   }
-  return g_box_scratch;
+  return b.p;
 }
 
 int check_common(const void *a, const void *b, const void *c, int num_rois, int batch, int C, int D, int H, int W, int PD,
@@ -774,7 +785,7 @@ extern "C" int mr3d_roi_align3d_backward(const float *top_grad, const float *roi
   const int B = pooled_depth * pooled_height * pooled_width;
   if (use_cl(layout, sample_num, pooled_depth, pooled_height, pooled_width)) {
     dim3 grid(num_rois, (B + kClBins - 1) / kClBins);
-    int *scratch = box_shape_ok(pooled_depth, pooled_height, pooled_width) ? box_scratch(num_rois) : nullptr;
+    int *scratch = box_shape_ok(pooled_depth, pooled_height, pooled_width) ? box_scratch(num_rois, stream) : nullptr;
     int *owned = nullptr;
     if (scratch) {
       // plan: which RoIs (and which 8x8x8 sub-boxes of their footprints) the separable kernel takes
@@ -857,7 +868,7 @@ extern "C" int mr3d_roi_align3d_backward_ml(const mr3d_roi_level *levels_host, i
   hipStream_t stream = mr3d_stream(stream_);
   const int bug = (flags & MR3D_ROIALIGN_BUG_COMPAT) ? 1 : 0;
   const int B = pooled_depth * pooled_height * pooled_width;
-  int *scratch = box_shape_ok(pooled_depth, pooled_height, pooled_width) ? box_scratch(num_rois) : nullptr;
+  int *scratch = box_shape_ok(pooled_depth, pooled_height, pooled_width) ? box_scratch(num_rois, stream) : nullptr;
   int *owned = nullptr;
   if (scratch) {
     owned = scratch + 1;

@@ -274,14 +274,14 @@ def ops_microbench(dev):
     return out
 
 
-def two_stage_step_ms(vol, steps=5, two_scales=False, static_mask_batch=False):
+def two_stage_step_ms(vol, steps=5, two_scales=False, static_mask_batch=False, bf16=False, dcn_neck=False):
     """BASELINE configs[2]: the whole single-pathway training step (backbone+FPN, RPN + loss + proposals/NMS3D,
     assign/sample 512, RoIAlign3D + bbox head, RoIAlign3D + mask head, all losses, backward) on one volume, timed by
     tools/two_stage_bench.py in a CHILD process (a fresh allocator / stream state, as a user would run it)."""
     import subprocess
     cmd = [sys.executable, os.path.join(ROOT, 'tools', 'two_stage_bench.py'), '--steps', str(steps), '--warmup', '3', '--json',
            '--vol', ','.join(str(v) for v in vol)] + (['--two-scales'] if two_scales else []) + \
-          (['--static-mask-batch'] if static_mask_batch else [])
+          (['--static-mask-batch'] if static_mask_batch else []) + (['--bf16'] if bf16 else []) + (['--dcn-neck'] if dcn_neck else [])
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     for line in reversed(out.stdout.strip().splitlines()):
         if line.startswith('{'):
@@ -529,6 +529,17 @@ def main():
                 ms2 = two_stage_step_ms((D, H, W), steps=3, two_scales=True)  # the shipped model: region + its 1.5x copy
                 res['aux']['shipped_2scales_step_ms'] = round(ms2, 2)
                 res['aux']['shipped_2scales_iters_per_s'] = round(1e3 / ms2, 2)
+                # BASELINE configs[4] (build-defined: bf16 activation storage in backbone + FPN, DeformConv3d neck); NOT the
+                # headline: the reference's arithmetic is fp32
+                import subprocess
+                o = subprocess.run([sys.executable, os.path.abspath(__file__), '--dtype', 'bf16', '--steps', '20', '--warmup', '5', '--no-aux',
+                                    '--no-cpu-baseline'], capture_output=True, text=True, timeout=600)
+                bf = json.loads([l for l in o.stdout.splitlines() if l.startswith('{')][-1])
+                res['aux']['bf16_backbone_iters_per_s'] = round(bf['value'], 2)
+                res['aux']['bf16_backbone_step_ms'] = round(bf['ms_per_step'], 3)
+                res['aux']['bf16_two_stage_step_ms'] = round(two_stage_step_ms((D, H, W), bf16=True), 2)
+                res['aux']['bf16_shipped_2scales_step_ms'] = round(two_stage_step_ms((D, H, W), steps=3, two_scales=True, bf16=True), 2)
+                res['aux']['bf16_dcn_neck_2scales_step_ms'] = round(two_stage_step_ms((D, H, W), steps=2, two_scales=True, bf16=True, dcn_neck=True), 2)
             except Exception as exc:  # the headline number must still print
                 res['aux'] = {'error': repr(exc)}
         if world == 1 and not a.no_cpu_baseline and a.dtype == 'f32':
