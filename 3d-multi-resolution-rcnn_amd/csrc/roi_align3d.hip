@@ -512,6 +512,221 @@ inline bool staged_ok(int C, int ns, int PD, int PH, int PW) {
 }
 
 // ------------------------------------------------------------------------------------------
+// channels-last FORWARD, separable.  The pooled value of bin (pd, ph, pw) is a sum over ns^3 samples of a trilinear tap sum:
+// 64 loads per output element in the reference (and in the wave-per-bin kernel above).  But weights factor per axis
+// (w = wz * wy * wx, a sample is dropped iff one of its axes is out of range), so per channel
+//     out[pd][ph][pw] = 1/count * sum_z Wz[pd][z] * sum_y Wy[ph][y] * sum_x Wx[pw][x] * F[z][y][x]
+// with Wx[pw][x] = the summed weights of bin pw's valid x-samples on voxel x (<= 2*ns non-zeros), Wy, Wz alike: three 1-D
+// contractions.  A workgroup owns (RoI, 16 channels, a chunk of PDC pooled depths) and walks the z-planes that chunk touches:
+//   stage 1  T1[y][pw] = sum_x Wx[pw][x] F[z][y][x]        one item per (row y, bin pw): <= 2*ns 64-byte global reads (16 ch)
+//   stage 2  t2 = sum_y Wy[ph][y] T1[y][pw]                one item per (ph, pw): <= 2*ns LDS reads
+//   stage 3  acc[pd][(ph,pw)] += Wz[pd][z] * t2            in REGISTERS (the thread that made t2 owns that bin column)
+// so a (3,7,7) bin costs ~3+3+3 taps instead of 64, a (10,14,14) bin even fewer (its planes are shared by more bins).  The
+// result goes through an LDS tile [bin][channel] so that [R,C,PD,PH,PW] rows are written in 256-byte runs.
+// Same tap rule as bilinear_interpolate_3d (axis_tap); the fp32 sums are associated differently from the reference's
+// per-sample order (~1e-6 relative, inside the 1e-4 parity bound).  RoIs whose footprint rows exceed the T1 tile fall back to
+// the direct per-bin evaluation inside the same kernel.
+// ------------------------------------------------------------------------------------------
+constexpr int kSepCh = 16;                 // channels per workgroup
+template <int PDC_, int J_, int T1CAP_>
+struct SepCfg {
+  static constexpr int PDC = PDC_, J = J_;                  // pooled depths per workgroup; (ph,pw) items per thread (16 workers)
+  static constexpr int T1CAP = T1CAP_;                      // T1 items (rows y x bins pw) per z-plane
+  static constexpr int T1_FLOATS = 2 * T1CAP * kSepCh;      // double-buffered
+  static constexpr int TILE_FLOATS = PDC * J * 16 * (kSepCh + 1);
+  static constexpr int BODY_FLOATS = T1_FLOATS > TILE_FLOATS ? T1_FLOATS : TILE_FLOATS;
+  static constexpr int LDS_BYTES = 3 * kStAxis * 16 + 64 + BODY_FLOATS * 4;
+};
+
+template <typename T, class S>
+__global__ __launch_bounds__(kClThreads) void roi_align3d_fwd_sep(const T *feat, float *__restrict__ out, const float *__restrict__ rois,
+                                                                 float scale, float scale_d, int ns, int C, int D, int H, int W,
+                                                                 int PD, int PH, int PW, LevelTable lt) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sp_lds[];
+  IdxEntry *tabx = reinterpret_cast<IdxEntry *>(sp_lds), *taby = tabx + kStAxis, *tabz = taby + kStAxis;
+  int *ext = reinterpret_cast<int *>(tabz + kStAxis);                 // x0,nx, y0,ny
+  float *body = reinterpret_cast<float *>(sp_lds + 3 * kStAxis * 16 + 64);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ch = tid & 15, worker = tid >> 4;                         // 16 channels x 16 workers
+  const int r = blockIdx.x, c0 = blockIdx.y * kSepCh, pd0 = blockIdx.z * S::PDC;
+  const int npd = min(S::PDC, PD - pd0);
+  if (lt.num) {
+    const int lvl = roi_level(rois + (size_t)r * 7, lt.finest_scale, lt.num);
+    D = pick4(lvl, lt.D); H = pick4(lvl, lt.H); W = pick4(lvl, lt.W);
+    scale = pick4(lvl, lt.scale); scale_d = pick4(lvl, lt.scale_d);
+    feat = reinterpret_cast<const T *>(pick4(lvl, lt.feat));
+  }
+  const RoiGeom g = roi_geom(rois + (size_t)r * 7, scale, scale_d, ns, PD, PH, PW);
+  build_idx_table(tabx, g.sw, g.bw, PW, ns, W, tid, kClThreads);
+  build_idx_table(taby, g.sh, g.bh, PH, ns, H, tid, kClThreads);
+  build_idx_table(tabz, g.sd, g.bd, PD, ns, D, tid, kClThreads);
+  __syncthreads();
+  if (tid < 2) {            // voxel range of the valid samples along x (tid 0) and y (tid 1)
+    const IdxEntry *tab = tid == 0 ? tabx : taby;
+    const int n = (tid == 0 ? PW : PH) * ns;
+    int mn = 0x7fffffff, mx = -1;
+    for (int e = 0; e < n; ++e)
+      if (tab[e].l + tab[e].h != 0.f) { mn = min(mn, tab[e].lo); mx = max(mx, tab[e].hi); }
+    ext[2 * tid] = mx < 0 ? 0 : mn;
+    ext[2 * tid + 1] = mx < 0 ? 0 : mx - mn + 1;
+  }
+  __syncthreads();
+  const int y0 = ext[2], ny = ext[3];
+  // z range of this chunk's pooled depths (wave-uniform scalars)
+  int zmin = 0x7fffffff, zmax = -1;
+  for (int e = pd0 * ns; e < (pd0 + npd) * ns; ++e)
+    if (tabz[e].l + tabz[e].h != 0.f) { zmin = min(zmin, tabz[e].lo); zmax = max(zmax, tabz[e].hi); }
+  const int B = PD * PH * PW, PHW = PH * PW;
+  const float inv_count = 1.f / (float)(ns * ns * ns);
+  const size_t base_n = (size_t)g.b * D * H * W * C + c0 + ch;
+  const long long sH = (long long)W * C, sD = (long long)H * W * C;
+
+  float acc[S::PDC][S::J];
+#pragma unroll
+  for (int a = 0; a < S::PDC; ++a)
+#pragma unroll
+    for (int j = 0; j < S::J; ++j) acc[a][j] = 0.f;
+
+  const bool separable = ns == 2 && ny * PW <= S::T1CAP && PHW <= 16 * S::J;
+  if (separable) {
+    int buf = 0;
+    for (int z = zmin; z <= zmax; ++z, buf ^= 1) {
+      float *T1 = body + buf * (S::T1CAP * kSepCh);
+      // ---- stage 1: x-contraction of plane z, rows y0 .. y0+ny-1.  Four items per thread and batch, all 16 tap loads issued
+      // before the first is used (one item at a time costs an L2 round trip per item).
+      for (int it0 = 0; it0 < ny * PW; it0 += 64) {
+        float v[4][4], w[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int item = it0 + worker + 16 * u;
+          const bool ok = item < ny * PW;
+          const int yy = ok ? item / PW : 0, pw = ok ? item - yy * PW : 0;
+          const T *row = feat + base_n + z * sD + (y0 + yy) * sH;
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const IdxEntry tx = tabx[pw * 2 + i];                   // an out-of-range sample has l = h = 0 and lo = hi = 0
+            w[u][2 * i] = tx.h; w[u][2 * i + 1] = tx.l;
+            v[u][2 * i] = ld_feat1(row + (long long)tx.lo * C);
+            v[u][2 * i + 1] = ld_feat1(row + (long long)tx.hi * C);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int item = it0 + worker + 16 * u;
+          if (item < ny * PW) T1[item * kSepCh + ch] = (w[u][0] * v[u][0] + w[u][1] * v[u][1]) + (w[u][2] * v[u][2] + w[u][3] * v[u][3]);
+        }
+      }
+      __syncthreads();
+      // ---- stages 2 + 3: y-contraction, then the z-weights of this plane into the register accumulators
+      float wz[S::PDC];
+#pragma unroll
+      for (int a = 0; a < S::PDC; ++a) {
+        float w = 0.f;
+        if (a < npd)
+          for (int i = 0; i < ns; ++i) {
+            const IdxEntry tz = tabz[(pd0 + a) * ns + i];
+            w += (tz.lo == z ? tz.h : 0.f) + (tz.hi == z ? tz.l : 0.f);       // l = h = 0 for an out-of-range sample
+          }
+        wz[a] = w;
+      }
+#pragma unroll
+      for (int j = 0; j < S::J; ++j) {
+        const int item = worker + 16 * j;
+        if (item < PHW) {
+          const int ph = item / PW, pw = item - ph * PW;
+          float t2 = 0.f;
+          for (int i = 0; i < ns; ++i) {
+            const IdxEntry ty = taby[ph * ns + i];
+            if (ty.l + ty.h != 0.f)
+              t2 += ty.h * T1[((ty.lo - y0) * PW + pw) * kSepCh + ch] + ty.l * T1[((ty.hi - y0) * PW + pw) * kSepCh + ch];
+          }
+#pragma unroll
+          for (int a = 0; a < S::PDC; ++a) acc[a][j] += wz[a] * t2;
+        }
+      }
+      // the other T1 buffer is written next: one barrier per plane is enough (its readers passed the barrier above)
+    }
+  } else {
+    // ---- fallback: direct per-bin evaluation (footprint rows do not fit the T1 tile)
+#pragma unroll
+    for (int a = 0; a < S::PDC; ++a)
+#pragma unroll
+      for (int j = 0; j < S::J; ++j) {
+        const int item = worker + 16 * j;
+        if (a < npd && item < PHW) {
+          const int ph = item / PW, pw = item - ph * PW;
+          float v = 0.f;
+          for (int iz = 0; iz < ns; ++iz) {
+            const IdxEntry tz = tabz[(pd0 + a) * ns + iz];
+            for (int iy = 0; iy < ns; ++iy) {
+              const IdxEntry ty = taby[ph * ns + iy];
+              for (int ix = 0; ix < ns; ++ix) {
+                const IdxEntry tx = tabx[pw * ns + ix];
+                if ((tx.l + tx.h) * (ty.l + ty.h) * (tz.l + tz.h) == 0.f) continue;
+                const T *f = feat + base_n;
+                auto at = [&](int zz, int yy, int xx) { return ld_feat1(f + zz * sD + yy * sH + (long long)xx * C); };
+                v += tz.h * (ty.h * (tx.h * at(tz.lo, ty.lo, tx.lo) + tx.l * at(tz.lo, ty.lo, tx.hi)) +
+                             ty.l * (tx.h * at(tz.lo, ty.hi, tx.lo) + tx.l * at(tz.lo, ty.hi, tx.hi))) +
+                     tz.l * (ty.h * (tx.h * at(tz.hi, ty.lo, tx.lo) + tx.l * at(tz.hi, ty.lo, tx.hi)) +
+                             ty.l * (tx.h * at(tz.hi, ty.hi, tx.lo) + tx.l * at(tz.hi, ty.hi, tx.hi)));
+              }
+            }
+          }
+          acc[a][j] = v;
+        }
+      }
+  }
+  // ---- accumulators -> LDS tile [local bin][channel] -> out[r, c0 + channel, pd0 .. , :, :] in 256-byte runs
+  __syncthreads();
+  float (*tile)[kSepCh + 1] = reinterpret_cast<float (*)[kSepCh + 1]>(body);
+#pragma unroll
+  for (int a = 0; a < S::PDC; ++a)
+#pragma unroll
+    for (int j = 0; j < S::J; ++j) {
+      const int item = worker + 16 * j;
+      if (a < npd && item < PHW) tile[a * PHW + item][ch] = acc[a][j] * inv_count;
+    }
+  __syncthreads();
+  const int nbins = npd * PHW;
+  for (int cc = wave; cc < kSepCh; cc += kClThreads / MR3D_WAVE) {
+    float *dst = out + ((size_t)r * C + c0 + cc) * B + (size_t)pd0 * PHW;
+    for (int bI = lane; bI < nbins; bI += MR3D_WAVE) dst[bI] = tile[bI][cc];
+  }
+}
+
+template <typename T, class S>
+int launch_fwd_sep(const T *feat, float *out, const float *rois, int num_rois, float scale, float scale_d, int ns, int C, int D,
+                   int H, int W, int PD, int PH, int PW, const LevelTable &lt, hipStream_t stream) {
+  static bool attr_done = false;
+  if (!attr_done && S::LDS_BYTES > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(roi_align3d_fwd_sep<T, S>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            S::LDS_BYTES) != hipSuccess) {
+      (void)hipGetLastError();
+      return MR3D_ERR_LAUNCH;
+    }
+    attr_done = true;
+  }
+  dim3 grid(num_rois, C / kSepCh, (PD + S::PDC - 1) / S::PDC);
+  roi_align3d_fwd_sep<T, S><<<grid, kClThreads, S::LDS_BYTES, stream>>>(feat, out, rois, scale, scale_d, ns, C, D, H, W, PD, PH, PW, lt);
+  return mr3d_launch_status();
+}
+
+// picks the separable instance for a pooled shape: MR3D_ERR_UNSUPPORTED = none (the caller takes the wave-per-bin kernel)
+template <typename T>
+int try_fwd_sep(const T *feat, float *out, const float *rois, int num_rois, float scale, float scale_d, int ns, int C, int D, int H,
+                int W, int PD, int PH, int PW, const LevelTable &lt, hipStream_t stream) {
+  static const int off = getenv("MR3D_ROIALIGN_SEPARABLE") ? !atoi(getenv("MR3D_ROIALIGN_SEPARABLE")) : 0;     // A/B switch
+  if (off || C % kSepCh != 0 || ns != 2 || PD * ns > kStAxis || PH * ns > kStAxis || PW * ns > kStAxis || PW > 14) return MR3D_ERR_UNSUPPORTED;
+  const int phw = PH * PW;
+  if (phw <= 64 && PD <= 4)       // bbox extractor (3,7,7): every pooled depth in one workgroup
+    return launch_fwd_sep<T, SepCfg<4, 4, 224>>(feat, out, rois, num_rois, scale, scale_d, ns, C, D, H, W, PD, PH, PW, lt, stream);
+  if (phw <= 208)                 // mask extractor (10,14,14): chunks of 5 pooled depths
+    return launch_fwd_sep<T, SepCfg<5, 13, 448>>(feat, out, rois, num_rois, scale, scale_d, ns, C, D, H, W, PD, PH, PW, lt, stream);
+  return MR3D_ERR_UNSUPPORTED;
+}
+
+// ------------------------------------------------------------------------------------------
 // channels-last backward, separable owner-computes variant.  The global-atomic kernel above issues 64 fp32 atomics
 // per output element and runs at the chip's atomic rate (measured 0.9-1.0 TB/s of added bytes: 3-5 ms for the mask
 // extractor).  But the scatter of one RoI is separable: with Wx[x][pw] = sum over the ns samples of bin pw of their
@@ -751,6 +966,11 @@ extern "C" int mr3d_roi_align3d_forward(const float *features, const float *rois
   if (num_rois == 0) return MR3D_OK;
   hipStream_t stream = mr3d_stream(stream_);
   const int B = pooled_depth * pooled_height * pooled_width;
+  if (use_cl(layout, sample_num, pooled_depth, pooled_height, pooled_width)) {
+    const int st2 = try_fwd_sep<float>(features, output, rois, num_rois, spatial_scale, spatial_scale_depth, sample_num, channels, depth,
+                                       height, width, pooled_depth, pooled_height, pooled_width, LevelTable{}, stream);
+    if (st2 != MR3D_ERR_UNSUPPORTED) return st2;
+  }
   if (use_cl(layout, sample_num, pooled_depth, pooled_height, pooled_width) &&
       staged_ok(channels, sample_num, pooled_depth, pooled_height, pooled_width))
     return launch_fwd_staged<float>(features, output, rois, num_rois, spatial_scale, spatial_scale_depth, sample_num, channels, depth,
@@ -844,6 +1064,11 @@ extern "C" int mr3d_roi_align3d_forward_ml(const mr3d_roi_level *levels_host, in
   if (num_rois == 0) return MR3D_OK;
   if (!rois || !output) return MR3D_ERR_INVALID_ARG;
   if (!use_cl(MR3D_LAYOUT_NDHWC, sample_num, pooled_depth, pooled_height, pooled_width)) return MR3D_ERR_UNSUPPORTED;
+  {
+    const int st2 = try_fwd_sep<float>(nullptr, output, rois, num_rois, 0.f, 0.f, sample_num, channels, 1, 1, 1, pooled_depth,
+                                       pooled_height, pooled_width, lt, mr3d_stream(stream_));
+    if (st2 != MR3D_ERR_UNSUPPORTED) return st2;
+  }
   if (staged_ok(channels, sample_num, pooled_depth, pooled_height, pooled_width))
     return launch_fwd_staged<float>(nullptr, output, rois, num_rois, 0.f, 0.f, sample_num, channels, 1, 1, 1, pooled_depth,
                                     pooled_height, pooled_width, lt, mr3d_stream(stream_));
@@ -902,6 +1127,11 @@ extern "C" int mr3d_roi_align3d_forward_ml_bf16(const mr3d_roi_level *levels_hos
   if (channels % kStCh != 0 || sample_num <= 0 || pooled_depth * sample_num > kStAxis || pooled_height * sample_num > kStAxis ||
       pooled_width * sample_num > kStAxis)
     return MR3D_ERR_UNSUPPORTED;
+  {
+    const int st2 = try_fwd_sep<uint16_t>(nullptr, output, rois, num_rois, 0.f, 0.f, sample_num, channels, 1, 1, 1, pooled_depth,
+                                          pooled_height, pooled_width, lt, mr3d_stream(stream_));
+    if (st2 != MR3D_ERR_UNSUPPORTED) return st2;
+  }
   return launch_fwd_staged<uint16_t>(nullptr, output, rois, num_rois, 0.f, 0.f, sample_num, channels, 1, 1, 1, pooled_depth,
                                      pooled_height, pooled_width, lt, mr3d_stream(stream_));
 }
