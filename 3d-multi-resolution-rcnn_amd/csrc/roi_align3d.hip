@@ -518,8 +518,7 @@ inline bool staged_ok(int C, int ns, int PD, int PH, int PW) {
 //     out[pd][ph][pw] = 1/count * sum_z Wz[pd][z] * sum_y Wy[ph][y] * sum_x Wx[pw][x] * F[z][y][x]
 // with Wx[pw][x] = the summed weights of bin pw's valid x-samples on voxel x (<= 2*ns non-zeros), Wy, Wz alike: three 1-D
 // contractions.  A workgroup owns (RoI, 16 channels, a chunk of PDC pooled depths) and walks the z-planes that chunk touches:
-//   stage 1  T1[y][pw] = sum_x Wx[pw][x] F[z][y][x]        one item per (touched row y, bin pw): <= 2*ns 64-byte global reads
-//            (16 ch), for as many touched planes at once as fit the LDS tile, all loads of a batch in flight together
+//   stage 1  T1[y][pw] = sum_x Wx[pw][x] F[z][y][x]        one item per (row y, bin pw): <= 2*ns 64-byte global reads (16 ch)
 //   stage 2  t2 = sum_y Wy[ph][y] T1[y][pw]                one item per (ph, pw): <= 2*ns LDS reads
 //   stage 3  acc[pd][(ph,pw)] += Wz[pd][z] * t2            in REGISTERS (the thread that made t2 owns that bin column)
 // so a (3,7,7) bin costs ~3+3+3 taps instead of 64, a (10,14,14) bin even fewer (its planes are shared by more bins).  The
@@ -532,12 +531,11 @@ constexpr int kSepCh = 16;                 // channels per workgroup
 template <int PDC_, int J_, int T1CAP_>
 struct SepCfg {
   static constexpr int PDC = PDC_, J = J_;                  // pooled depths per workgroup; (ph,pw) items per thread (16 workers)
-  static constexpr int T1CAP = T1CAP_;                      // T1 items (plane, row, bin pw) held in LDS at a time
-  static constexpr int T1_FLOATS = T1CAP * kSepCh;
+  static constexpr int T1CAP = T1CAP_;                      // T1 items (rows y x bins pw) per z-plane
+  static constexpr int T1_FLOATS = 2 * T1CAP * kSepCh;      // double-buffered
   static constexpr int TILE_FLOATS = PDC * J * 16 * (kSepCh + 1);
   static constexpr int BODY_FLOATS = T1_FLOATS > TILE_FLOATS ? T1_FLOATS : TILE_FLOATS;
-  static constexpr int LISTS = 4 * 64 * 4;                  // zlist, ylist, ymap (ints) + spare
-  static constexpr int LDS_BYTES = 3 * kStAxis * 16 + 64 + LISTS + BODY_FLOATS * 4;
+  static constexpr int LDS_BYTES = 3 * kStAxis * 16 + 64 + BODY_FLOATS * 4;
 };
 
 template <typename T, class S>
@@ -546,9 +544,8 @@ __global__ __launch_bounds__(kClThreads) void roi_align3d_fwd_sep(const T *feat,
                                                                  int PD, int PH, int PW, LevelTable lt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sp_lds[];
   IdxEntry *tabx = reinterpret_cast<IdxEntry *>(sp_lds), *taby = tabx + kStAxis, *tabz = taby + kStAxis;
-  int *ext = reinterpret_cast<int *>(tabz + kStAxis);                 // nplanes, nrows
-  int *zlist = reinterpret_cast<int *>(sp_lds + 3 * kStAxis * 16 + 64), *ylist = zlist + 64, *ymap = ylist + 64, *zmark = ymap + 64;
-  float *body = reinterpret_cast<float *>(sp_lds + 3 * kStAxis * 16 + 64 + S::LISTS);
+  int *ext = reinterpret_cast<int *>(tabz + kStAxis);                 // x0,nx, y0,ny
+  float *body = reinterpret_cast<float *>(sp_lds + 3 * kStAxis * 16 + 64);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ch = tid & 15, worker = tid >> 4;                         // 16 channels x 16 workers
@@ -565,29 +562,21 @@ __global__ __launch_bounds__(kClThreads) void roi_align3d_fwd_sep(const T *feat,
   build_idx_table(taby, g.sh, g.bh, PH, ns, H, tid, kClThreads);
   build_idx_table(tabz, g.sd, g.bd, PD, ns, D, tid, kClThreads);
   __syncthreads();
-  // ---- the planes z this chunk's pooled depths touch and the rows y any bin touches, as sorted lists (<= 2*ns*P entries
-  // each; one thread per axis: the lists are tiny).  Sparse sampling (a bin wider than two voxels) leaves planes and rows in
-  // between untouched: they are never read.
-  if (tid < 2) {
-    const bool zax = tid == 0;
-    const IdxEntry *tab = zax ? tabz + pd0 * ns : taby;
-    const int n = (zax ? npd : PH) * ns;
-    int *list = zax ? zlist : ylist;
-    int cnt = 0, last = -1;
-    // per-axis sample coordinates are non-decreasing in the entry index, so lo / hi come out sorted: merge on the fly
-    for (int e = 0; e < n; ++e) {
-      if (tab[e].l + tab[e].h == 0.f) continue;
-      if (tab[e].lo > last && cnt < 64) { list[cnt++] = tab[e].lo; last = tab[e].lo; }
-      if (tab[e].hi > last && cnt < 64) { list[cnt++] = tab[e].hi; last = tab[e].hi; }
-    }
-    ext[tid] = cnt;
+  if (tid < 2) {            // voxel range of the valid samples along x (tid 0) and y (tid 1)
+    const IdxEntry *tab = tid == 0 ? tabx : taby;
+    const int n = (tid == 0 ? PW : PH) * ns;
+    int mn = 0x7fffffff, mx = -1;
+    for (int e = 0; e < n; ++e)
+      if (tab[e].l + tab[e].h != 0.f) { mn = min(mn, tab[e].lo); mx = max(mx, tab[e].hi); }
+    ext[2 * tid] = mx < 0 ? 0 : mn;
+    ext[2 * tid + 1] = mx < 0 ? 0 : mx - mn + 1;
   }
   __syncthreads();
-  const int nplanes = ext[0], nrows = ext[1];
-  const int y0 = nrows ? ylist[0] : 0, yspan = nrows ? ylist[nrows - 1] - y0 + 1 : 0;
-  if (tid < 64) ymap[tid] = 0;
-  __syncthreads();
-  if (tid < nrows && ylist[tid] - y0 < 64) ymap[ylist[tid] - y0] = tid;
+  const int y0 = ext[2], ny = ext[3];
+  // z range of this chunk's pooled depths (wave-uniform scalars)
+  int zmin = 0x7fffffff, zmax = -1;
+  for (int e = pd0 * ns; e < (pd0 + npd) * ns; ++e)
+    if (tabz[e].l + tabz[e].h != 0.f) { zmin = min(zmin, tabz[e].lo); zmax = max(zmax, tabz[e].hi); }
   const int B = PD * PH * PW, PHW = PH * PW;
   const float inv_count = 1.f / (float)(ns * ns * ns);
   const size_t base_n = (size_t)g.b * D * H * W * C + c0 + ch;
@@ -599,25 +588,21 @@ __global__ __launch_bounds__(kClThreads) void roi_align3d_fwd_sep(const T *feat,
 #pragma unroll
     for (int j = 0; j < S::J; ++j) acc[a][j] = 0.f;
 
-  const int per_plane = nrows * PW;
-  const bool separable = ns == 2 && per_plane > 0 && per_plane <= S::T1CAP && PHW <= 16 * S::J && yspan <= 64 && nrows < 64 && nplanes < 64;
+  const bool separable = ns == 2 && ny * PW <= S::T1CAP && PHW <= 16 * S::J;
   if (separable) {
-    const int group = S::T1CAP / per_plane;                       // planes whose x-contraction fits the LDS tile at once
-    for (int k0 = 0; k0 < nplanes; k0 += group) {
-      const int gk = min(group, nplanes - k0);
-      const int nitems = gk * per_plane;
-      __syncthreads();                                             // ymap is set / the previous group's T1 has been consumed
-      // ---- stage 1: x-contraction of gk planes x touched rows.  Four items per thread and batch, all 16 tap loads issued
+    int buf = 0;
+    for (int z = zmin; z <= zmax; ++z, buf ^= 1) {
+      float *T1 = body + buf * (S::T1CAP * kSepCh);
+      // ---- stage 1: x-contraction of plane z, rows y0 .. y0+ny-1.  Four items per thread and batch, all 16 tap loads issued
       // before the first is used (one item at a time costs an L2 round trip per item).
-      for (int it0 = 0; it0 < nitems; it0 += 64) {
+      for (int it0 = 0; it0 < ny * PW; it0 += 64) {
         float v[4][4], w[4][4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int item = it0 + worker + 16 * u;
-          const bool ok = item < nitems;
-          const int kk = ok ? item / per_plane : 0, rem = ok ? item - kk * per_plane : 0;
-          const int jj = rem / PW, pw = rem - jj * PW;
-          const T *row = feat + base_n + zlist[k0 + kk] * sD + ylist[jj] * sH;
+          const bool ok = item < ny * PW;
+          const int yy = ok ? item / PW : 0, pw = ok ? item - yy * PW : 0;
+          const T *row = feat + base_n + z * sD + (y0 + yy) * sH;
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
             const IdxEntry tx = tabx[pw * 2 + i];                   // an out-of-range sample has l = h = 0 and lo = hi = 0
@@ -629,45 +614,41 @@ __global__ __launch_bounds__(kClThreads) void roi_align3d_fwd_sep(const T *feat,
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int item = it0 + worker + 16 * u;
-          if (item < nitems) body[item * kSepCh + ch] = (w[u][0] * v[u][0] + w[u][1] * v[u][1]) + (w[u][2] * v[u][2] + w[u][3] * v[u][3]);
+          if (item < ny * PW) T1[item * kSepCh + ch] = (w[u][0] * v[u][0] + w[u][1] * v[u][1]) + (w[u][2] * v[u][2] + w[u][3] * v[u][3]);
         }
       }
       __syncthreads();
-      // ---- stages 2 + 3 per plane of the group: y-contraction, then this plane's z-weights into the register accumulators
-      for (int kk = 0; kk < gk; ++kk) {
-        const int z = zlist[k0 + kk];
-        const float *T1 = body + kk * per_plane * kSepCh;
-        float wz[S::PDC];
+      // ---- stages 2 + 3: y-contraction, then the z-weights of this plane into the register accumulators
+      float wz[S::PDC];
 #pragma unroll
-        for (int a = 0; a < S::PDC; ++a) {
-          float wsum = 0.f;
-          if (a < npd)
-            for (int i = 0; i < 2; ++i) {
-              const IdxEntry tz = tabz[(pd0 + a) * 2 + i];
-              wsum += (tz.lo == z ? tz.h : 0.f) + (tz.hi == z ? tz.l : 0.f);       // l = h = 0 for an out-of-range sample
-            }
-          wz[a] = wsum;
-        }
-#pragma unroll
-        for (int j = 0; j < S::J; ++j) {
-          const int item = worker + 16 * j;
-          if (item < PHW) {
-            const int ph = item / PW, pw = item - ph * PW;
-            float t2 = 0.f;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-              const IdxEntry ty = taby[ph * 2 + i];
-              if (ty.l + ty.h != 0.f)
-                t2 += ty.h * T1[(ymap[ty.lo - y0] * PW + pw) * kSepCh + ch] + ty.l * T1[(ymap[ty.hi - y0] * PW + pw) * kSepCh + ch];
-            }
-#pragma unroll
-            for (int a = 0; a < S::PDC; ++a) acc[a][j] += wz[a] * t2;
+      for (int a = 0; a < S::PDC; ++a) {
+        float w = 0.f;
+        if (a < npd)
+          for (int i = 0; i < ns; ++i) {
+            const IdxEntry tz = tabz[(pd0 + a) * ns + i];
+            w += (tz.lo == z ? tz.h : 0.f) + (tz.hi == z ? tz.l : 0.f);       // l = h = 0 for an out-of-range sample
           }
+        wz[a] = w;
+      }
+#pragma unroll
+      for (int j = 0; j < S::J; ++j) {
+        const int item = worker + 16 * j;
+        if (item < PHW) {
+          const int ph = item / PW, pw = item - ph * PW;
+          float t2 = 0.f;
+          for (int i = 0; i < ns; ++i) {
+            const IdxEntry ty = taby[ph * ns + i];
+            if (ty.l + ty.h != 0.f)
+              t2 += ty.h * T1[((ty.lo - y0) * PW + pw) * kSepCh + ch] + ty.l * T1[((ty.hi - y0) * PW + pw) * kSepCh + ch];
+          }
+#pragma unroll
+          for (int a = 0; a < S::PDC; ++a) acc[a][j] += wz[a] * t2;
         }
       }
+      // the other T1 buffer is written next: one barrier per plane is enough (its readers passed the barrier above)
     }
   } else {
-    // ---- fallback: direct per-bin evaluation (general sample_num, or a footprint whose rows do not fit the T1 tile)
+    // ---- fallback: direct per-bin evaluation (footprint rows do not fit the T1 tile)
 #pragma unroll
     for (int a = 0; a < S::PDC; ++a)
 #pragma unroll
@@ -712,7 +693,6 @@ __global__ __launch_bounds__(kClThreads) void roi_align3d_fwd_sep(const T *feat,
     float *dst = out + ((size_t)r * C + c0 + cc) * B + (size_t)pd0 * PHW;
     for (int bI = lane; bI < nbins; bI += MR3D_WAVE) dst[bI] = tile[bI][cc];
   }
-  (void)zmark;
 }
 
 template <typename T, class S>
@@ -739,10 +719,17 @@ int try_fwd_sep(const T *feat, float *out, const float *rois, int num_rois, floa
   static const int off = getenv("MR3D_ROIALIGN_SEPARABLE") ? !atoi(getenv("MR3D_ROIALIGN_SEPARABLE")) : 0;     // A/B switch
   if (off || C % kSepCh != 0 || ns != 2 || PD * ns > kStAxis || PH * ns > kStAxis || PW * ns > kStAxis || PW > 14) return MR3D_ERR_UNSUPPORTED;
   const int phw = PH * PW;
-  if (phw <= 64 && PD <= 4)       // bbox extractor (3,7,7): every pooled depth in one workgroup
-    return launch_fwd_sep<T, SepCfg<4, 4, 640>>(feat, out, rois, num_rois, scale, scale_d, ns, C, D, H, W, PD, PH, PW, lt, stream);
+  // Measured on the SURVEY 8(d) bench inputs: the separable form wins where many bins share the planes of a RoI -- the mask
+  // extractor (10,14,14): 137 vs 232 us -- and only ties on the bbox extractor (3,7,7): 88 vs 88 us (3 pooled depths over up
+  // to 20 planes: as many stage-1 taps as the direct form has in total; a variant that walks only the touched planes / rows in
+  // groups was slower still, 110 us).  bf16 features take it for both shapes (there is no bf16 wave-per-bin kernel).
+  static const int sep_bbox = getenv("MR3D_ROIALIGN_SEPARABLE_BBOX") ? atoi(getenv("MR3D_ROIALIGN_SEPARABLE_BBOX")) : 0;
+  if (phw <= 64 && PD <= 4) {     // bbox extractor (3,7,7): every pooled depth in one workgroup
+    if (!sep_bbox && sizeof(T) == 4) return MR3D_ERR_UNSUPPORTED;
+    return launch_fwd_sep<T, SepCfg<4, 4, 224>>(feat, out, rois, num_rois, scale, scale_d, ns, C, D, H, W, PD, PH, PW, lt, stream);
+  }
   if (phw <= 208)                 // mask extractor (10,14,14): chunks of 5 pooled depths
-    return launch_fwd_sep<T, SepCfg<5, 13, 896>>(feat, out, rois, num_rois, scale, scale_d, ns, C, D, H, W, PD, PH, PW, lt, stream);
+    return launch_fwd_sep<T, SepCfg<5, 13, 448>>(feat, out, rois, num_rois, scale, scale_d, ns, C, D, H, W, PD, PH, PW, lt, stream);
   return MR3D_ERR_UNSUPPORTED;
 }
 
