@@ -72,6 +72,9 @@ class ExtractFeat3D(nn.Module):
         assert dtype in (torch.float32, torch.bfloat16)
         self.act_dtype = dtype
         self.bf16 = dtype == torch.bfloat16
+        # dtype of the pyramid handed out: fp32 (any consumer), or bf16 for consumers that read bf16 maps directly (the RPN
+        # head's bf16 plan, RoIAlign3D's bf16-feature kernel): no fp32 copy of the five maps, bf16 gradients come straight back
+        self.pyramid_dtype = torch.float32
         self.neck_dcn = bool(neck_dcn)
         if depth not in self.STAGE_BLOCKS:
             raise KeyError(f'invalid depth {depth} for the bottleneck ResNet3D engine')
@@ -585,7 +588,9 @@ class ExtractFeat3D(nn.Module):
         with torch.cuda.device(self.device):
             P.fwd.run(self.device)
         self._last = P
-        if self.bf16:       # the pyramid leaves in fp32 (heads, RoIAlign3D and the losses compute in fp32)
+        if self.bf16 and self.pyramid_dtype == torch.bfloat16:
+            return tuple(o.permute(0, 4, 1, 2, 3).clone(memory_format=torch.preserve_format) for o in P.outs)
+        if self.bf16:       # the pyramid leaves in fp32 (any head, RoIAlign3D and the losses compute in fp32)
             return tuple(o.permute(0, 4, 1, 2, 3).float() for o in P.outs)
         return tuple(o.permute(0, 4, 1, 2, 3) for o in P.outs)
 
@@ -680,7 +685,7 @@ class _ExtractFeatFn(torch.autograd.Function):
         outs = engine.forward_features(img, slot)
         ctx.plan = engine._last
         if engine.bf16:
-            return outs                   # already fp32 copies of the plan's bf16 buffers
+            return outs                   # already copies of the plan's bf16 buffers (fp32 or bf16, see pyramid_dtype)
         return tuple(o.clone(memory_format=torch.preserve_format) for o in outs)
 
     @staticmethod

@@ -31,19 +31,24 @@ class _RPNHeadPlanFn(torch.autograd.Function):
     def forward(ctx, w3, b3, w1, b1, *feats):
         from .. import _hip
         dev = feats[0].device
+        # a bf16 pyramid (BASELINE configs[4]) runs the head on the bf16 kernels: bf16 activations / activation gradients,
+        # fp32 weights, biases, weight gradients and accumulation; the score / delta maps leave in fp32
+        bf = feats[0].dtype == torch.bfloat16
+        adt = torch.bfloat16 if bf else torch.float32
+        pack = _hip.pack_conv_weight_bf16 if bf else _hip.pack_conv_weight
         co1 = w1.shape[0]
         cop = -(-co1 // 16) * 16
         c = w3.shape[0]
-        wf3 = _hip.pack_conv_weight(w3.detach())                                         # [27][64][64]
+        wf3 = pack(w3.detach())                                                          # [27][64][64]
         w1p = torch.zeros((cop, c, 1, 1, 1), dtype=torch.float32, device=dev)
         w1p[:co1] = w1.detach()
-        wf1 = _hip.pack_conv_weight(w1p)                                                 # [1][64][16]
+        wf1 = pack(w1p)                                                                  # [1][64][16]
         sh3 = b3.detach().contiguous()
         sh1 = torch.zeros(cop, dtype=torch.float32, device=dev)
         sh1[:co1] = b1.detach()
         xs = [f.detach().permute(0, 2, 3, 4, 1).contiguous() for f in feats]             # NDHWC (zero-copy for the engine's maps)
-        hs = [torch.empty(x.shape, dtype=torch.float32, device=dev) for x in xs]
-        outs = [torch.empty(x.shape[:4] + (cop,), dtype=torch.float32, device=dev) for x in xs]
+        hs = [torch.empty(x.shape, dtype=adt, device=dev) for x in xs]
+        outs = [torch.empty(x.shape[:4] + (cop,), dtype=adt, device=dev) for x in xs]
         ops = []
         for x, h, o in zip(xs, hs, outs):
             n, d, hh, w, _ = x.shape
@@ -51,25 +56,35 @@ class _RPNHeadPlanFn(torch.autograd.Function):
             ops.append(_hip.make_op(_hip.OP_CONV_FWD, [x, wf3, h, sh3, None, None, None, None], i3))
             i1 = [n, d, hh, w, c, cop, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0]
             ops.append(_hip.make_op(_hip.OP_CONV_FWD, [h, wf1, o, sh1, None, None, None, None], i1))
+        if bf:
+            for o_ in ops:
+                o_.i[25] = _hip.DTYPE_BF16
         keep = (wf3, wf1, sh3, sh1)
         with torch.cuda.device(dev):
             _hip.Plan(ops).run(dev)
         ctx.save_for_backward(w3, w1p, *xs, *hs)
-        ctx.meta = (len(xs), co1, cop, c)
+        ctx.meta = (len(xs), co1, cop, c, bf)
         ctx.keep = keep
+        if bf:
+            return tuple(o.float().permute(0, 4, 1, 2, 3) for o in outs)
         return tuple(o.permute(0, 4, 1, 2, 3) for o in outs)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, *gouts):
         from .. import _hip
-        L, co1, cop, c = ctx.meta
+        L, co1, cop, c, bf = ctx.meta
+        adt = torch.bfloat16 if bf else torch.float32
         saved = ctx.saved_tensors
         w3, w1p = saved[0], saved[1]
         xs, hs = saved[2:2 + L], saved[2 + L:2 + 2 * L]
         dev = xs[0].device
-        wb3 = w3.detach().reshape(c, c, 27).flip(2).permute(2, 0, 1).contiguous()       # [26-tap][co][ci]
-        wb1 = w1p.reshape(cop, c, 1).permute(2, 0, 1).contiguous()                       # [1][16][64]
+        if bf:
+            wb3 = _hip.pack_conv_weight_bf16(w3.detach().flip(2, 3, 4).transpose(0, 1).contiguous())
+            wb1 = _hip.pack_conv_weight_bf16(w1p.transpose(0, 1).contiguous())
+        else:
+            wb3 = w3.detach().reshape(c, c, 27).flip(2).permute(2, 0, 1).contiguous()   # [26-tap][co][ci]
+            wb1 = w1p.reshape(cop, c, 1).permute(2, 0, 1).contiguous()                   # [1][16][64]
         dw3 = torch.zeros((27, c, c), dtype=torch.float32, device=dev)
         db3 = torch.zeros(c, dtype=torch.float32, device=dev)
         dw1 = torch.zeros((1, c, cop), dtype=torch.float32, device=dev)
@@ -80,9 +95,9 @@ class _RPNHeadPlanFn(torch.autograd.Function):
             if g is None:
                 gxs.append(None)
                 continue
-            g16 = g.permute(0, 2, 3, 4, 1).contiguous()
-            gh = torch.empty(x.shape, dtype=torch.float32, device=dev)
-            gx = torch.empty(x.shape, dtype=torch.float32, device=dev)
+            g16 = g.permute(0, 2, 3, 4, 1).to(adt).contiguous()
+            gh = torch.empty(x.shape, dtype=adt, device=dev)
+            gx = torch.empty(x.shape, dtype=adt, device=dev)
             keep += [g16, gh]
             side = [0] * 11 + [1]                                                        # i[26] = 1: side stream
             ops.append(_hip.make_op(_hip.OP_CONV_WGRAD, [h, g16, dw1, db1], [n, d, hh, w, c, cop, 1, 1, 1, 1, 1, 1, 0, 0, 0] + side))
@@ -92,6 +107,9 @@ class _RPNHeadPlanFn(torch.autograd.Function):
             ops.append(_hip.make_op(_hip.OP_CONV_FWD, [gh, wb3, gx, None, None, None, None, None],
                                     [n, d, hh, w, c, c, 3, 3, 3, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0]))
             gxs.append(gx.permute(0, 4, 1, 2, 3))
+        if bf:
+            for o_ in ops:
+                o_.i[25] = _hip.DTYPE_BF16
         if ops:
             with torch.cuda.device(dev):
                 _hip.Plan(ops).run(dev)

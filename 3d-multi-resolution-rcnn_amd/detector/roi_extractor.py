@@ -23,7 +23,7 @@ class _MultiLevelRoIAlign3D(Function):
     @staticmethod
     def forward(ctx, rois, cfg, *feats):
         out_d, out_h, out_w, scales, scales_d, sample_num, finest, bug = cfg
-        ctx.cfg, ctx.shapes = cfg, [f.shape for f in feats]
+        ctx.cfg, ctx.shapes, ctx.feat_dtype = cfg, [f.shape for f in feats], feats[0].dtype
         ctx.save_for_backward(rois)
         return _hip.roi_align3d_forward_ml([f.detach() for f in feats], rois, out_d, out_h, out_w, scales, scales_d, sample_num, finest)
 
@@ -35,6 +35,8 @@ class _MultiLevelRoIAlign3D(Function):
         grads = [torch.empty(sh, dtype=torch.float32, device=rois.device, memory_format=torch.channels_last_3d).zero_()
                  for sh in ctx.shapes]
         _hip.roi_align3d_backward_ml(grad_output, rois, grads, out_d, out_h, out_w, scales, scales_d, sample_num, finest, bug)
+        if ctx.feat_dtype != torch.float32:       # bf16 pyramid (configs[4]): the scatter accumulates in fp32, the gradient leaves in bf16
+            grads = [g.to(ctx.feat_dtype) for g in grads]
         return (None, None) + tuple(g if need else None for g, need in zip(grads, ctx.needs_input_grad[2:]))
 
 
@@ -78,7 +80,7 @@ class SingleRoIExtractor(nn.Module):
         num_levels = len(feats)
         # fast path: channels-last pyramid on the device -> ONE multi-level launch, no host synchronisation
         if (num_levels <= 4 and layer0.sample_num > 0 and isinstance(layer0.out_size, int) and rois.is_cuda and
-                all(f.is_cuda and f.dtype == torch.float32 and f.dim() == 5 and
+                all(f.is_cuda and f.dtype in (torch.float32, torch.bfloat16) and f.dtype == feats[0].dtype and f.dim() == 5 and
                     f.is_contiguous(memory_format=torch.channels_last_3d) for f in feats)):
             cfg = (layer0.out_size_depth, layer0.out_size, layer0.out_size, tuple(l.spatial_scale for l in self.roi_layers),
                    tuple(l.spatial_scale_depth for l in self.roi_layers), layer0.sample_num, float(self.finest_scale),

@@ -105,6 +105,8 @@ class TwoStageDetector3D(nn.Module):
         self.test_cfg = test_cfg or DEFAULT_TEST_CFG
         self.extract = ExtractFeat3D(device=device, dtype=dtype, neck_dcn=neck_dcn)   # backbone + neck (module names as the reference)
         self.neck_dcn = bool(neck_dcn)
+        if dtype == torch.bfloat16 and not neck_dcn:
+            self.extract.pyramid_dtype = torch.bfloat16          # RPN head and RoIAlign3D read the bf16 pyramid directly
         if neck_dcn:
             from .dcn_neck import DCNNeck3D
             self.dcn_neck = DCNNeck3D().to(self.device)

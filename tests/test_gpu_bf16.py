@@ -259,3 +259,68 @@ def test_pointwise_bf16_streaming(dev, cin, cout):
     y2 = _hip.conv3d_forward_bf16(b(x), w16, cout, (1, 1, 1), (1, 1, 1), (0, 0, 0), add1=b(add1), mask=b(mask))
     _close(y2.float().permute(0, 4, 1, 2, 3).cpu(), (conv - shift.double().view(1, -1, 1, 1, 1) + add1) * (mask > 0), 'streaming mask',
            BF16_EPS, 3e-3)
+
+
+def test_rpn_head_bf16_plan_vs_fp32_plan(dev):
+    """RPNHead3D on a bf16 pyramid (configs[4]) against the same head on the fp32 copy of the same maps: score / delta maps,
+    input gradients (returned in bf16) and parameter gradients"""
+    from mr3d_amd.detector import RPNHead3D
+    torch.manual_seed(2)
+    head = RPNHead3D().to(dev)
+    with torch.no_grad():
+        for p in head.parameters():
+            p.normal_(0, 0.05)
+    shapes = [(1, 64, 8, 24, 20), (1, 64, 4, 12, 10), (1, 64, 2, 6, 5)]
+    feats32 = [_bf(torch.randn(s)).to(dev).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True) for s in shapes]
+    feats16 = [f.detach().bfloat16().contiguous(memory_format=torch.channels_last_3d).requires_grad_(True) for f in feats32]
+    res = {}
+    for tag, feats in (('f32', feats32), ('bf16', feats16)):
+        head.zero_grad()
+        cls, reg = head(feats)
+        assert all(c.dtype == torch.float32 for c in cls + reg)
+        cots = [torch.sin(torch.arange(c.numel(), device=dev, dtype=torch.float32)).view_as(c) for c in cls + reg]
+        sum((o * c).sum() for o, c in zip(cls + reg, cots)).backward()
+        res[tag] = ([o.detach().float().cpu() for o in cls + reg], [f.grad.float().cpu() for f in feats],
+                    {n: p.grad.detach().cpu().clone() for n, p in head.named_parameters()})
+        assert all(f.grad.dtype == f.dtype for f in feats)
+    for a, b in zip(res['bf16'][0], res['f32'][0]):
+        _close(a, b, 'rpn outputs', 2e-2, 1e-2)          # two chained bf16 roundings (hidden map, output map)
+    for a, b in zip(res['bf16'][1], res['f32'][1]):
+        _close(a, b, 'rpn input grads', 3e-2, 1.5e-2)
+    for n in res['f32'][2]:
+        _close(res['bf16'][2][n], res['f32'][2][n], f'rpn grad {n}', 3e-2, 1.5e-2)
+
+
+def test_detector_bf16_pyramid_trains(dev):
+    """TwoStageDetector3D(dtype=bfloat16): backbone + FPN + RPN head on bf16 maps, RoIAlign3D reading the bf16 pyramid; the loss
+    dict is finite and close to the fp32 detector's with identical weights and sampler words; gradients reach everything"""
+    from mr3d_amd.detector import TwoStageDetector3D
+    rng = np.random.default_rng(0)
+    img = torch.randn(1, 3, 32, 128, 128, device=dev)
+    gt = torch.tensor([[20, 30, 60, 75, 4, 20], [70, 20, 110, 64, 10, 28]], dtype=torch.float32, device=dev)
+    masks = torch.zeros((2, 32, 128, 128), dtype=torch.uint8, device=dev)
+    for k, b in enumerate(gt.int().tolist()):
+        masks[k, b[4]:b[5] + 1, b[1]:b[3] + 1, b[0]:b[2] + 1] = 1
+    meta = [dict(img_shape=(128, 128, 3, 32), pad_shape=(128, 128, 3, 32))]
+    draws = dict(rpn=[(rng.integers(0, 2 ** 31 - 1, 128), rng.integers(0, 2 ** 31 - 1, 256))],
+                 rcnn=[(rng.integers(0, 2 ** 31 - 1, 128), rng.integers(0, 2 ** 31 - 1, 512))])
+    gl = torch.ones(2, dtype=torch.long, device=dev)
+    torch.manual_seed(0)
+    d32 = TwoStageDetector3D(device=dev)
+    d32.extract.zero_init_residual = False
+    d32.extract.init_weights()
+    d16 = TwoStageDetector3D(device=dev, dtype=torch.bfloat16)
+    d16.load_state_dict(d32.state_dict())
+    assert d16.extract.pyramid_dtype == torch.bfloat16
+    out = {}
+    for tag, det in (('f32', d32), ('bf16', d16)):
+        det.extract.zero_grad()
+        losses = det.forward_train(img, meta, [gt], [gl], gt_masks=[masks], draws=draws)
+        total = det.total_loss(losses)
+        assert torch.isfinite(total)
+        total.backward()
+        out[tag] = (total.item(), det.extract.flat_grads.clone())
+        assert det.extract.flat_grads.abs().sum() > 0 and torch.isfinite(det.extract.flat_grads).all()
+        for n, p in list(det.rpn_head.named_parameters()) + list(det.bbox_head.named_parameters()):
+            assert p.grad is not None and torch.isfinite(p.grad).all(), n
+    assert abs(out['bf16'][0] - out['f32'][0]) <= 5e-2 * abs(out['f32'][0]), out
