@@ -270,6 +270,11 @@ def test_rpn_head_bf16_plan_vs_fp32_plan(dev):
     with torch.no_grad():
         for p in head.parameters():
             p.normal_(0, 0.05)
+        # keep the hidden pre-activations away from 0: a bf16 vs fp32 difference of 1e-2 flips ReLU masks near 0 and re-routes
+        # whole gradient contributions (3e-2 in L2 with a zero-centred hidden map) -- a property of the evaluation point, not
+        # of the kernels; the ReLU-mask epilogues themselves are covered by test_conv3d_bf16_fused_epilogue
+        head.rpn_conv.weight.normal_(0, 0.01)
+        head.rpn_conv.bias.fill_(2.0)
     shapes = [(1, 64, 8, 24, 20), (1, 64, 4, 12, 10), (1, 64, 2, 6, 5)]
     feats32 = [_bf(torch.randn(s)).to(dev).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True) for s in shapes]
     feats16 = [f.detach().bfloat16().contiguous(memory_format=torch.channels_last_3d).requires_grad_(True) for f in feats32]
