@@ -25,6 +25,7 @@
 namespace {
 
 constexpr int kThreads = 256;
+constexpr bool getenv_free_wpad() { return true; }     // compile-time switch of FwdCfg::WPAD (A/B: set to false and rebuild)
 
 // PAR_: the parity-decomposed data gradient of a stride-2 3x3x3 convolution (see conv3d_dgrad_s2k3 below); the
 // kernel extents are then the per-axis MAXIMUM (2) and the taps actually walked are chosen per parity class.
@@ -48,7 +49,11 @@ struct FwdCfg {
   static constexpr bool PW1 = (KD == 1 && KH == 1 && KW == 1);
   static constexpr int LSD = PW1 ? 1 : SD, LSH = PW1 ? 1 : SH, LSW = PW1 ? 1 : SW;   // LDS step per output position
   static constexpr int GSD = PW1 ? SD : 1, GSH = PW1 ? SH : 1, GSW = PW1 ? SW : 1;   // global step per halo position
-  static constexpr int HD = (TD - 1) * LSD + KD, HH = (TH - 1) * LSH + KH, HW = (TW - 1) * LSW + KW;
+  // WPAD: one spare column per halo row in the F(4,3) form.  Their GEMM rows step 2 or 4 positions along W, and with the
+  // natural 10-position rows the 32 lanes of a ds_read_b32 group fall 3-way onto the 32 banks; 11-position rows make it 2-way
+  // (the best any row pitch reaches: SQ_LDS_BANK_CONFLICT was 66 % of the LDS-active cycles of the F(4,3) kernel).
+  static constexpr int WPAD = (WINO_ == 4 && getenv_free_wpad()) ? 1 : 0;        // F(4,3): 0.480 -> 0.477 ms on P2; the F(2,3) 4x8x8 instance would spill
+  static constexpr int HD = (TD - 1) * LSD + KD, HH = (TH - 1) * LSH + KH, HW = (TW - 1) * LSW + KW + WPAD;
   static constexpr int HP = HD * HH * HW;       // halo positions
   static constexpr int ROW = CC + 1;            // LDS row stride in floats
   static constexpr int OPR = WINO_ ? WINO_ : 1; // outputs per GEMM row
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_fwd_kernel(Conv3dFw
       const int hw = pos % C::HW, hh = (pos / C::HW) % C::HH, hd = pos / (C::HW * C::HH);
       const int id = id0 + hd * C::GSD, ih = ih0 + hh * C::GSH, iw = iw0 + hw * C::GSW;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (it < C::HP * Q && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
+      if (it < C::HP * Q && hw < C::HW - C::WPAD && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
         v = *reinterpret_cast<const float4 *>(p.x + ((((size_t)n * p.D + id) * p.H + ih) * p.W + iw) * p.Cin + c0 + q * 4);
       stage[j] = v;
     }
