@@ -1,0 +1,801 @@
+// DeformConv3d, fused form for the FPN neck shape (Cin = Cout = 64, one deformable group, no modulation):
+// forward, weight gradient and input/offset gradient WITHOUT the column matrix of csrc/deform_conv3d.hip.
+//
+// The column matrix of one 3x3x3 DeformConv3d over P2 of a 512x512x80 volume is 327,680 x 1,728 fp32 = 2.3 GB (7.6 GB on
+// the 1.5x pathway); the im2col form writes it, reads it twice and writes its gradient.  Here a workgroup owns a tile of
+// 128 consecutive output positions and walks the taps:
+//     sample table  one thread per position: the 8 corner offsets + trilinear weights of (position, tap) -> LDS
+//     gather        16 lanes x float4 = the 64 channels of one corner (256-B coalesced read); 4 positions per wave
+//                   instruction; the weighted sum of the 8 corners = one row of the tap's column tile  -> LDS [128][64]
+//     MFMA          v_mfma_f32_32x32x2_f32:  out[128 x 64] += columns[128 x 64] * W[tap][64 x 64]
+// so the columns never leave the CU.  The sampling rule is the one of csrc/deform_conv3d.hip (the reference's 2D rule,
+// mmdet/ops/dcn/src/deform_conv_cuda_kernel.cu:83-108,228: 0 unless -1 < p < dim on every axis, floor(), corners masked
+// one by one); like the reference every IN-RANGE corner is read even when its weight is 0.
+//
+//   forward   y[pos][co]   = sum_tap col_tap[pos][:] . W[tap][:][co]
+//   wgrad     dW[tap]      = col_tap^T dy       a workgroup keeps 3 taps x (64 x 64) in registers over its share of the
+//                                               position tiles and adds them to dW once (fp32 atomics)
+//   dgrad     dcol_tap     = dy W[tap]^T  (MFMA, tile in LDS), then per (position, tap):
+//               dx[corner] += w_corner * dcol            (fp32 atomics, 256-B contiguous per corner)
+//               doffset     = sum_c dcol[c] * d(sample[c]) / d(coordinate)     (16-lane shuffle reduction)
+//
+// K permutation: the MFMA A operand of k-step j holds A[row][2j + (lane >> 5)]; reading the column tile with one
+// ds_read_b128 per four k-steps needs a lane's four values adjacent, so GEMM-k index r = 2j + h is mapped to channel
+//     sigma(r) = 8 * (j >> 2) + 4 * h + (j & 3)
+// and the packed weights (mr3d_deform_conv3d_pack_weights) are stored in that order.
+#include "mr3d_common.h"
+#include <stdlib.h>
+#include <string.h>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kC = 64;             // Cin = Cout
+constexpr int kM = 128;            // output positions per tile
+constexpr int kRow = kC + 4;       // LDS row stride (floats) of the column / dcol tile: 16-lane b128 groups hit 64 distinct banks
+constexpr int kThreads = 256;
+constexpr int kTapsPerWg = 3;      // weight gradient: taps whose 64x64 accumulators one workgroup holds
+
+struct FGeo {
+  int N, D, H, W, Do, Ho, Wo;
+  int kd, kh, kw, sd, sh, sw, pd, ph, pw, dd, dh, dw;
+  int K;
+  long long total;                 // N * Do * Ho * Wo
+  int tiles_d, tiles_h, tiles_w, ntiles;       // 4 x 4 x 8 position blocks of the gather kernels
+};
+
+struct Sample {
+  bool any;
+  int z[2], y[2], x[2];            // clamped corner coordinates
+  bool vz[2], vy[2], vx[2];
+  float lz, ly, lx;
+  int n;
+};
+
+// an output position, decoded once per tile (32-bit arithmetic: total < 2^31 is checked on the host)
+struct Coord {
+  int n, od, oh, ow;
+  unsigned pos;
+  bool in;
+};
+
+// The gather kernels tile the output positions in 4 x 4 x 8 blocks (128 positions): the 27 x 8 corner reads of a block
+// stay inside a 6 x 6 x 10 voxel neighbourhood (+ offsets), and blocks are handed to the 8 XCDs in contiguous ranges
+// (hardware deals workgroups round-robin: blockIdx & 7 = XCD) so that the blocks in flight on one XCD are neighbours
+// and share their halos in that XCD's L2.
+constexpr int kGd = 4, kGh = 4, kGw = 8;
+static_assert(kGd * kGh * kGw == kM, "tile");
+
+struct TileOrg { int n, od0, oh0, ow0; };
+
+__device__ __forceinline__ int xcd_contiguous(int bid, int ntiles) {     // -> tile id, or -1
+  const int per = (ntiles + 7) >> 3;
+  const int tile = (bid & 7) * per + (bid >> 3);
+  return ((bid >> 3) < per && tile < ntiles) ? tile : -1;
+}
+
+__device__ __forceinline__ TileOrg tile_origin(const FGeo &g, int tile) {
+  TileOrg o;
+  o.ow0 = (tile % g.tiles_w) * kGw; tile /= g.tiles_w;
+  o.oh0 = (tile % g.tiles_h) * kGh; tile /= g.tiles_h;
+  o.od0 = (tile % g.tiles_d) * kGd;
+  o.n = tile / g.tiles_d;
+  return o;
+}
+
+__device__ __forceinline__ Coord tile_pos(const FGeo &g, const TileOrg &o, int m) {
+  Coord c;
+  c.n = o.n; c.ow = o.ow0 + (m & (kGw - 1)); c.oh = o.oh0 + ((m >> 3) & (kGh - 1)); c.od = o.od0 + (m >> 5);
+  c.in = c.od < g.Do && c.oh < g.Ho && c.ow < g.Wo;
+  c.pos = c.in ? (unsigned)(((o.n * g.Do + c.od) * g.Ho + c.oh) * g.Wo + c.ow) : 0u;
+  return c;
+}
+
+// the three offsets of (position, tap), requested one tap ahead of their use
+struct OffsetStream {
+  const float *p;
+  float nx[3];
+  bool on;
+  __device__ __forceinline__ void start(const float *__restrict__ offset, const Coord &c, int K, bool active, int tap) {
+    on = active && c.in;
+    p = offset + (size_t)c.pos * (K * 3);
+    nx[0] = nx[1] = nx[2] = 0.f;
+    if (on) { nx[0] = p[3 * tap]; nx[1] = p[3 * tap + 1]; nx[2] = p[3 * tap + 2]; }
+  }
+  __device__ __forceinline__ void take(float &oz, float &oy, float &ox, int next_tap, int K) {
+    oz = nx[0]; oy = nx[1]; ox = nx[2];
+    if (on && next_tap < K) { nx[0] = p[3 * next_tap]; nx[1] = p[3 * next_tap + 1]; nx[2] = p[3 * next_tap + 2]; }
+  }
+};
+
+__device__ __forceinline__ Sample sample_at(const FGeo &g, const Coord &c, int kd_, int kh_, int kw_, float oz, float oy, float ox) {
+  Sample s;
+  s.any = false;
+  s.lz = s.ly = s.lx = 0.f;
+  s.n = c.n;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) { s.z[a] = s.y[a] = s.x[a] = 0; s.vz[a] = s.vy[a] = s.vx[a] = false; }
+  if (!c.in) return s;
+  const float pz = (float)(c.od * g.sd - g.pd + kd_ * g.dd) + oz;
+  const float py = (float)(c.oh * g.sh - g.ph + kh_ * g.dh) + oy;
+  const float px = (float)(c.ow * g.sw - g.pw + kw_ * g.dw) + ox;
+  s.any = pz > -1.f && py > -1.f && px > -1.f && pz < (float)g.D && py < (float)g.H && px < (float)g.W;
+  if (!s.any) return s;
+  const int z0 = (int)floorf(pz), y0 = (int)floorf(py), x0 = (int)floorf(px);
+  s.lz = pz - (float)z0; s.ly = py - (float)y0; s.lx = px - (float)x0;
+  s.vz[0] = z0 >= 0; s.vz[1] = z0 + 1 <= g.D - 1;
+  s.vy[0] = y0 >= 0; s.vy[1] = y0 + 1 <= g.H - 1;
+  s.vx[0] = x0 >= 0; s.vx[1] = x0 + 1 <= g.W - 1;
+  s.z[0] = max(z0, 0); s.z[1] = min(z0 + 1, g.D - 1);
+  s.y[0] = max(y0, 0); s.y[1] = min(y0 + 1, g.H - 1);
+  s.x[0] = max(x0, 0); s.x[1] = min(x0 + 1, g.W - 1);
+  return s;
+}
+
+// tap -> (kd, kh, kw), advanced incrementally by the tap loops (no division per tap)
+struct TapIdx {
+  int kd, kh, kw;
+  __device__ __forceinline__ void set(const FGeo &g, int tap) { kw = tap % g.kw; kh = (tap / g.kw) % g.kh; kd = tap / (g.kw * g.kh); }
+  __device__ __forceinline__ void next(const FGeo &g) {
+    if (++kw == g.kw) { kw = 0; if (++kh == g.kh) { kh = 0; ++kd; } }
+  }
+};
+
+// table entry of the forward / weight-gradient kernels: off[8] (element offsets of channel 0; off[0] = -1 marks a sample
+// outside the validity box), w[8]
+__device__ __forceinline__ void fill_entry(const FGeo &g, const Coord &c, const TapIdx &ti, float oz, float oy, float ox, int *eo,
+                                           float *ew) {
+  const Sample s = sample_at(g, c, ti.kd, ti.kh, ti.kw, oz, oy, ox);
+  int o[8];
+  float w[8];
+  const float wz[2] = {1.f - s.lz, s.lz}, wy[2] = {1.f - s.ly, s.ly}, wx[2] = {1.f - s.lx, s.lx};
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int i = a * 4 + b * 2 + e;
+        const bool v = s.any && s.vz[a] && s.vy[b] && s.vx[e];
+        w[i] = v ? wz[a] * wy[b] * wx[e] : 0.f;
+        o[i] = s.any ? (((s.n * g.D + s.z[a]) * g.H + s.y[b]) * g.W + s.x[e]) * kC : 0;
+      }
+  if (!s.any) o[0] = -1;
+  *reinterpret_cast<int4 *>(eo) = make_int4(o[0], o[1], o[2], o[3]);
+  *reinterpret_cast<int4 *>(eo + 4) = make_int4(o[4], o[5], o[6], o[7]);
+  *reinterpret_cast<float4 *>(ew) = make_float4(w[0], w[1], w[2], w[3]);
+  *reinterpret_cast<float4 *>(ew + 4) = make_float4(w[4], w[5], w[6], w[7]);
+}
+
+// the weighted corner sum of G consecutive 4-position groups of this wave: rows row0 + 4 * gi + (lane >> 4)
+template <int G>
+__device__ __forceinline__ void gather_rows(const float *__restrict__ x, const int *__restrict__ toff, const float *__restrict__ tw,
+                                            float *__restrict__ tile, int row0, int lane) {
+  const int p = lane >> 4, q = lane & 15;
+  int o[G][8];
+  float w[G][8];
+  float4 v[G][8];
+#pragma unroll
+  for (int gi = 0; gi < G; ++gi) {
+    const int row = row0 + 4 * gi + p;
+    const int4 oa = *reinterpret_cast<const int4 *>(toff + row * 8), ob = *reinterpret_cast<const int4 *>(toff + row * 8 + 4);
+    const float4 wa = *reinterpret_cast<const float4 *>(tw + row * 8), wb = *reinterpret_cast<const float4 *>(tw + row * 8 + 4);
+    o[gi][0] = oa.x; o[gi][1] = oa.y; o[gi][2] = oa.z; o[gi][3] = oa.w; o[gi][4] = ob.x; o[gi][5] = ob.y; o[gi][6] = ob.z; o[gi][7] = ob.w;
+    w[gi][0] = wa.x; w[gi][1] = wa.y; w[gi][2] = wa.z; w[gi][3] = wa.w; w[gi][4] = wb.x; w[gi][5] = wb.y; w[gi][6] = wb.z; w[gi][7] = wb.w;
+  }
+#pragma unroll
+  for (int gi = 0; gi < G; ++gi)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[gi][i] = *reinterpret_cast<const float4 *>(x + (i == 0 ? max(o[gi][0], 0) : o[gi][i]) + 4 * q);
+#pragma unroll
+  for (int gi = 0; gi < G; ++gi) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      s.x = fmaf(w[gi][i], v[gi][i].x, s.x); s.y = fmaf(w[gi][i], v[gi][i].y, s.y);
+      s.z = fmaf(w[gi][i], v[gi][i].z, s.z); s.w = fmaf(w[gi][i], v[gi][i].w, s.w);
+    }
+    if (o[gi][0] < 0) s = make_float4(0.f, 0.f, 0.f, 0.f);      // outside the validity box: 0 whatever voxel 0 holds
+    *reinterpret_cast<float4 *>(tile + (row0 + 4 * gi + p) * kRow + 4 * q) = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- forward
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void dcn_fwd_kernel(const float *__restrict__ x, const float *__restrict__ offset,
+                                                              const float *__restrict__ wf, float *__restrict__ y, FGeo g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *tile = lds;                                   // [128][kRow]
+  float *bs = tile + kM * kRow;                        // [64 r][64 co]
+  int *toff = reinterpret_cast<int *>(bs + kC * kC);   // [2][128][8]
+  float *tw = reinterpret_cast<float *>(toff + 2 * kM * 8);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  const int tile_id = xcd_contiguous(blockIdx.x, g.ntiles);
+  if (tile_id < 0) return;
+  const TileOrg org = tile_origin(g, tile_id);
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[nb][e] = 0.f;
+
+  const Coord me = tile_pos(g, org, tid & (kM - 1));
+  OffsetStream os;
+  os.start(offset, me, g.K, tid < kM, 0);
+  TapIdx ti;
+  ti.set(g, 0);
+  for (int tap = 0; tap < g.K; ++tap, ti.next(g)) {
+    const int buf = tap & 1;
+    if (tid < kM) {
+      float oz, oy, ox;
+      os.take(oz, oy, ox, tap + 1, g.K);
+      fill_entry(g, me, ti, oz, oy, ox, toff + (buf * kM + tid) * 8, tw + (buf * kM + tid) * 8);
+    }
+    __syncthreads();
+    // the tap's weights ride along with the gather (nobody reads bs between the two barriers)
+    {
+      const float4 *src = reinterpret_cast<const float4 *>(wf + (size_t)tap * kC * kC);
+      float4 t[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) t[i] = src[tid + i * kThreads];
+      gather_rows<4>(x, toff + buf * kM * 8, tw + buf * kM * 8, tile, wave * 32, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) reinterpret_cast<float4 *>(bs)[tid + i * kThreads] = t[i];
+      gather_rows<4>(x, toff + buf * kM * 8, tw + buf * kM * 8, tile, wave * 32 + 16, lane);
+    }
+    __syncthreads();
+    const float *arow = tile + (wave * 32 + l31) * kRow + 4 * h;
+    const float *bcol = bs + h * kC + l31;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float4 a = *reinterpret_cast<const float4 *>(arow + 8 * i);
+      const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int j = 4 * i + jj;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+          acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[jj], bcol[(2 * j) * kC + nb * 32], acc[nb], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const Coord c = tile_pos(g, org, wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h);
+      if (c.in) y[(size_t)c.pos * kC + nb * 32 + l31] = acc[nb][e];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- weight gradient
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void dcn_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ offset,
+                                                                const float *__restrict__ dy, float *__restrict__ dw, FGeo g,
+                                                                int nsplit, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *tile = lds;                                   // [128 pos][kRow]
+  int *toff = reinterpret_cast<int *>(tile + kM * kRow);
+  float *tw = reinterpret_cast<float *>(toff + 2 * kM * 8);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  const int mb = wave >> 1, nb = wave & 1;             // this wave's (ci block, co block)
+  // workgroup -> (chunk of consecutive tiles, tap group): the tap groups of one chunk gather the same voxels for
+  // different taps, so they sit on the same XCD (blockIdx & 7) and walk the chunk together
+  const int groups = (g.K + kTapsPerWg - 1) / kTapsPerWg;
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int tg = slot % groups, chunk = xcd * nsplit + slot / groups;          // nsplit = chunks per XCD
+  const int nchunks = 8 * nsplit;
+  const int per = (ntiles + nchunks - 1) / nchunks;
+  const int t_begin = chunk * per, t_end = min(ntiles, t_begin + per);
+  const int tap0 = tg * kTapsPerWg;
+
+  f32x16 acc[kTapsPerWg];
+#pragma unroll
+  for (int t = 0; t < kTapsPerWg; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+  int buf = 0;
+  for (int tile_id = t_begin; tile_id < t_end; ++tile_id) {
+    const TileOrg org = tile_origin(g, tile_id);
+    const Coord me = tile_pos(g, org, tid & (kM - 1));
+    OffsetStream os;
+    os.start(offset, me, g.K, tid < kM, tap0);
+    TapIdx tx;
+    tx.set(g, tap0);
+    float bfr[kM / 2];                                 // B[k = position 2j + h][n = co]
+#pragma unroll
+    for (int j = 0; j < kM / 2; ++j) {
+      const Coord c = tile_pos(g, org, 2 * j + h);
+      bfr[j] = c.in ? dy[(size_t)c.pos * kC + nb * 32 + l31] : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < kTapsPerWg; ++t) {
+      const int tap = tap0 + t;
+      if (tap >= g.K) break;
+      if (tid < kM) {
+        float oz, oy, ox;
+        os.take(oz, oy, ox, t + 1 < kTapsPerWg ? tap + 1 : g.K, g.K);
+        fill_entry(g, me, tx, oz, oy, ox, toff + (buf * kM + tid) * 8, tw + (buf * kM + tid) * 8);
+      }
+      tx.next(g);
+      __syncthreads();
+#pragma unroll
+      for (int part = 0; part < 4; ++part)
+        gather_rows<2>(x, toff + buf * kM * 8, tw + buf * kM * 8, tile, wave * 32 + part * 8, lane);
+      __syncthreads();
+      const float *acol = tile + h * kRow + mb * 32 + l31;       // A[m = ci][k = position]
+#pragma unroll
+      for (int j = 0; j < kM / 2; ++j) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(acol[(2 * j) * kRow], bfr[j], acc[t], 0, 0, 0);
+      buf ^= 1;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < kTapsPerWg; ++t) {
+    const int tap = tap0 + t;
+    if (tap >= g.K) break;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int ci = mb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      atomicAdd(dw + ((size_t)tap * kC + ci) * kC + nb * 32 + l31, acc[t][e]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- input / offset gradient
+// table entry: off[8], (lz, ly, lx), flags (bit 0..5: vz0 vz1 vy0 vy1 vx0 vx1, bit 6: inside the validity box)
+constexpr int kEntD = 12;
+
+__device__ __forceinline__ void fill_entry_d(const FGeo &g, const Coord &cd, const TapIdx &ti, float oz, float oy, float ox, int *e) {
+  const Sample s = sample_at(g, cd, ti.kd, ti.kh, ti.kw, oz, oy, ox);
+  int o[8];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        o[a * 4 + b * 2 + c] = s.any ? (((s.n * g.D + s.z[a]) * g.H + s.y[b]) * g.W + s.x[c]) * kC : 0;
+  const int flags = (int)s.vz[0] | ((int)s.vz[1] << 1) | ((int)s.vy[0] << 2) | ((int)s.vy[1] << 3) | ((int)s.vx[0] << 4) |
+                    ((int)s.vx[1] << 5) | ((int)s.any << 6);
+  *reinterpret_cast<int4 *>(e) = make_int4(o[0], o[1], o[2], o[3]);
+  *reinterpret_cast<int4 *>(e + 4) = make_int4(o[4], o[5], o[6], o[7]);
+  *reinterpret_cast<int4 *>(e + 8) = make_int4(__float_as_int(s.lz), __float_as_int(s.ly), __float_as_int(s.lx), flags);
+}
+
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void dcn_dgrad_kernel(const float *__restrict__ x, const float *__restrict__ offset,
+                                                                const float *__restrict__ dy, const float *__restrict__ wb,
+                                                                float *__restrict__ dx, float *__restrict__ doffset, FGeo g) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *tile = lds;                                   // dcol [128][kRow]
+  float *bs = tile + kM * kRow;                        // W[tap]^T: [64 r (co, permuted)][64 ci]
+  int *tab = reinterpret_cast<int *>(bs + kC * kC);    // [2][128][kEntD]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, h = lane >> 5;
+  const int p = lane >> 4, q = lane & 15;
+  const int tile_id = xcd_contiguous(blockIdx.x, g.ntiles);
+  if (tile_id < 0) return;
+  const TileOrg org = tile_origin(g, tile_id);
+
+  // A operand: this wave's 32 rows of dy, all 64 co, in the permuted k order -- registers for the whole tap loop
+  float4 afr[8];
+  {
+    const Coord c = tile_pos(g, org, wave * 32 + l31);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      afr[i] = c.in ? *reinterpret_cast<const float4 *>(dy + (size_t)c.pos * kC + 8 * i + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+
+  const Coord me = tile_pos(g, org, tid & (kM - 1));
+  OffsetStream os;
+  os.start(offset, me, g.K, tid < kM, 0);
+  TapIdx ti;
+  ti.set(g, 0);
+  for (int tap = 0; tap < g.K; ++tap, ti.next(g)) {
+    const int buf = tap & 1;
+    if (tid < kM) {
+      float oz, oy, ox;
+      os.take(oz, oy, ox, tap + 1, g.K);
+      fill_entry_d(g, me, ti, oz, oy, ox, tab + (buf * kM + tid) * kEntD);
+    }
+    {
+      const float4 *src = reinterpret_cast<const float4 *>(wb + (size_t)tap * kC * kC);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) reinterpret_cast<float4 *>(bs)[tid + i * kThreads] = src[tid + i * kThreads];
+    }
+    __syncthreads();
+    {
+      f32x16 acc[2];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[nb][e] = 0.f;
+      const float *bcol = bs + h * kC + l31;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float av[4] = {afr[i].x, afr[i].y, afr[i].z, afr[i].w};
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int j = 4 * i + jj;
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+            acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[jj], bcol[(2 * j) * kC + nb * 32], acc[nb], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          tile[(wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * kRow + nb * 32 + l31] = acc[nb][e];
+    }
+    __syncthreads();
+    const int *tb = tab + buf * kM * kEntD;
+#pragma unroll 2
+    for (int gi = 0; gi < 8; ++gi) {
+      const int row = wave * 32 + 4 * gi + p;
+      const int4 oa = *reinterpret_cast<const int4 *>(tb + row * kEntD), ob = *reinterpret_cast<const int4 *>(tb + row * kEntD + 4);
+      const int4 fr = *reinterpret_cast<const int4 *>(tb + row * kEntD + 8);
+      const int o[8] = {oa.x, oa.y, oa.z, oa.w, ob.x, ob.y, ob.z, ob.w};
+      const float lz = __int_as_float(fr.x), ly = __int_as_float(fr.y), lx = __int_as_float(fr.z);
+      const int flags = fr.w;
+      const bool any = (flags >> 6) & 1;
+      float4 v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float4 *>(x + o[i] + 4 * q);
+      const float4 gc = *reinterpret_cast<const float4 *>(tile + row * kRow + 4 * q);
+      const float wz[2] = {1.f - lz, lz}, wy[2] = {1.f - ly, ly}, wx[2] = {1.f - lx, lx};
+      const float sg[2] = {-1.f, 1.f};
+      float gz = 0.f, gy = 0.f, gx = 0.f;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const int i = a * 4 + b * 2 + c;
+            const bool valid = any && ((flags >> a) & 1) && ((flags >> (2 + b)) & 1) && ((flags >> (4 + c)) & 1);
+            if (valid) {
+              const float dot = gc.x * v[i].x + gc.y * v[i].y + gc.z * v[i].z + gc.w * v[i].w;
+              gz = fmaf(sg[a] * wy[b] * wx[c], dot, gz);
+              gy = fmaf(wz[a] * sg[b] * wx[c], dot, gy);
+              gx = fmaf(wz[a] * wy[b] * sg[c], dot, gx);
+              const float w = wz[a] * wy[b] * wx[c];
+              if (dx && w != 0.f) {
+                float *d = dx + o[i] + 4 * q;
+                atomicAdd(d + 0, w * gc.x); atomicAdd(d + 1, w * gc.y); atomicAdd(d + 2, w * gc.z); atomicAdd(d + 3, w * gc.w);
+              }
+            }
+          }
+#pragma unroll
+      for (int m = 8; m > 0; m >>= 1) {
+        gz += __shfl_xor(gz, m); gy += __shfl_xor(gy, m); gx += __shfl_xor(gx, m);
+      }
+      const Coord rc = tile_pos(g, org, row);
+      if (doffset && q == 0 && rc.in) {
+        float *d = doffset + (size_t)rc.pos * (g.K * 3) + tap * 3;
+        d[0] = gz; d[1] = gy; d[2] = gx;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- input gradient, tiled
+// The direct kernel above runs at the chip's fp32 atomic rate (~1 TB/s of added bytes: 216 corner adds per position and
+// channel = 18 GB for P2).  Tiled form of the dx half: a workgroup owns a 2 x 4 x 8 block of output positions and one
+// 16-channel slice of dx; the voxels its samples can reach with |offset| < 1 -- the block's tap footprint plus one voxel
+// on every side -- are an LDS accumulator [Rz*Ry*Rx][16]; corners outside the box fall back to global atomics, and the box
+// is added to dx once at the end (non-zero entries only): ~30x fewer global atomics.  (The offset gradient needs the
+// corner VALUES of all 64 channels and no scatter: it comes from the direct kernel run without dx.)
+//   dcol slice = dy[64 pos x 64 co] * W[tap]^T[64 co x 16 ci]     v_mfma_f32_16x16x4_f32, one 16-row block per wave
+//   GEMM-k index kk = 4 * step + (lane >> 4)  <->  co = sigma16(kk) = 16 * (step >> 2) + 4 * (lane >> 4) + (step & 3)
+//   (a lane's dy values of four steps are one float4); the third block of w_packed is stored in that order and a lane's
+//   16 B values of a tap are loaded straight into registers one tap ahead.
+// LDS fp32 adds are read + compare-and-swap: ds_add_f32 serialises its 64 lanes (~190 cycles per instruction on gfx950,
+// tools/lds_atomic_probe.hip) while integer LDS atomics take ~6.  The 8 reads and the 8 swaps of a position group are
+// issued back to back; a swap that lost against another lane / wave retries on its own.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+constexpr int kTd = 2, kTh = 4, kTw = 8, kTm = kTd * kTh * kTw;     // 64 positions
+constexpr int kCs = 16;                                             // channels per slice
+constexpr int kEntT = 16;                                           // loc[8], w[8]
+constexpr size_t kTiledLdsMax = 53 * 1024;                          // three workgroups per CU
+
+struct TGeo {
+  FGeo g;
+  int tiles_d, tiles_h, tiles_w;
+  int rz, ry, rx;                 // box extent
+};
+
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void dcn_dx_tiled_kernel(const float *__restrict__ offset, const float *__restrict__ dy, const float *__restrict__ wb16,
+                         float *__restrict__ dx, TGeo t) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const FGeo &g = t.g;
+  const int nbox = t.rz * t.ry * t.rx;
+  float *box = lds;                                         // [nbox][16] + 64 per-lane dummy slots
+  int *ibox = reinterpret_cast<int *>(box);
+  float *dt = box + nbox * kCs + 64;                        // [64][16]
+  int *tab = reinterpret_cast<int *>(dt + kTm * kCs);       // [2][64][kEntT]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int dummy = nbox * kCs + lane;                      // where a lane with nothing to add swaps a value with itself
+  int b = blockIdx.x;
+  const int slice = b & 3; b >>= 2;
+  const int tw_i = b % t.tiles_w; b /= t.tiles_w;
+  const int th_i = b % t.tiles_h; b /= t.tiles_h;
+  const int td_i = b % t.tiles_d; b /= t.tiles_d;
+  const int n = b;
+  const int od0 = td_i * kTd, oh0 = th_i * kTh, ow0 = tw_i * kTw;
+  // box origin: first tap of the first position, one voxel lower
+  const int bz0 = od0 * g.sd - g.pd - 1, by0 = oh0 * g.sh - g.ph - 1, bx0 = ow0 * g.sw - g.pw - 1;
+
+  auto coord_of = [&](int m) {
+    Coord c;
+    c.n = n; c.ow = ow0 + (m & (kTw - 1)); c.oh = oh0 + ((m >> 3) & (kTh - 1)); c.od = od0 + (m >> 5);
+    c.in = c.od < g.Do && c.oh < g.Ho && c.ow < g.Wo;
+    c.pos = c.in ? (unsigned)(((n * g.Do + c.od) * g.Ho + c.oh) * g.Wo + c.ow) : 0u;
+    return c;
+  };
+  const Coord me = coord_of(tid & (kTm - 1));               // the position whose table entries this thread fills
+  // A operand: this wave's 16 positions x 64 co (permuted), registers for the whole kernel
+  float4 afr[4];
+  {
+    const Coord c = coord_of(wave * 16 + l15);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      afr[i] = c.in ? *reinterpret_cast<const float4 *>(dy + (size_t)c.pos * kC + 16 * i + 4 * kq) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int e = tid; e < nbox * kCs / 4 + 16; e += kThreads) reinterpret_cast<float4 *>(box)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  // B operand of a tap: B[kk = 4 * step + kq][ci = l15], 16 values per lane
+  const float *bsrc = wb16 + (size_t)kq * kC + slice * kCs + l15;
+  float bcur[16], bnxt[16];
+#pragma unroll
+  for (int st = 0; st < 16; ++st) bcur[st] = bsrc[(size_t)(4 * st) * kC];
+  // the offsets of this thread's position: the next tap's three values are requested one tap ahead
+  const float *op = offset + (size_t)me.pos * (g.K * 3);
+  float onx[3] = {0.f, 0.f, 0.f};
+  if (tid < kTm && me.in) { onx[0] = op[0]; onx[1] = op[1]; onx[2] = op[2]; }
+
+  TapIdx ti;
+  ti.set(g, 0);
+  for (int tap = 0; tap < g.K; ++tap, ti.next(g)) {
+    const int buf = tap & 1;
+    if (tid < kTm) {
+      const float oz = onx[0], oy = onx[1], ox = onx[2];
+      if (me.in && tap + 1 < g.K) { onx[0] = op[3 * tap + 3]; onx[1] = op[3 * tap + 4]; onx[2] = op[3 * tap + 5]; }
+      int lc[8];
+      float w[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { lc[i] = -1; w[i] = 0.f; }
+      const float pz = (float)(me.od * g.sd - g.pd + ti.kd * g.dd) + oz;
+      const float py = (float)(me.oh * g.sh - g.ph + ti.kh * g.dh) + oy;
+      const float px = (float)(me.ow * g.sw - g.pw + ti.kw * g.dw) + ox;
+      if (me.in && pz > -1.f && py > -1.f && px > -1.f && pz < (float)g.D && py < (float)g.H && px < (float)g.W) {
+        const int z0 = (int)floorf(pz), y0 = (int)floorf(py), x0 = (int)floorf(px);
+        const float lz = pz - (float)z0, ly = py - (float)y0, lx = px - (float)x0;
+        const float wz[2] = {1.f - lz, lz}, wy[2] = {1.f - ly, ly}, wx[2] = {1.f - lx, lx};
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+              const int i = a * 4 + bb * 2 + c;
+              const int z = z0 + a, y = y0 + bb, xx = x0 + c;
+              const bool valid = (unsigned)z < (unsigned)g.D && (unsigned)y < (unsigned)g.H && (unsigned)xx < (unsigned)g.W;
+              const float wi = wz[a] * wy[bb] * wx[c];
+              if (valid && wi != 0.f) {
+                const int bz = z - bz0, by = y - by0, bx = xx - bx0;
+                const bool inb = (unsigned)bz < (unsigned)t.rz && (unsigned)by < (unsigned)t.ry && (unsigned)bx < (unsigned)t.rx;
+                w[i] = wi;
+                lc[i] = inb ? ((bz * t.ry + by) * t.rx + bx) * kCs : -2 - (((n * g.D + z) * g.H + y) * g.W + xx);
+              }
+            }
+      }
+      int *e = tab + (buf * kTm + tid) * kEntT;
+      *reinterpret_cast<int4 *>(e) = make_int4(lc[0], lc[1], lc[2], lc[3]);
+      *reinterpret_cast<int4 *>(e + 4) = make_int4(lc[4], lc[5], lc[6], lc[7]);
+      *reinterpret_cast<float4 *>(e + 8) = make_float4(w[0], w[1], w[2], w[3]);
+      *reinterpret_cast<float4 *>(e + 12) = make_float4(w[4], w[5], w[6], w[7]);
+    }
+    if (tap + 1 < g.K) {
+#pragma unroll
+      for (int st = 0; st < 16; ++st) bnxt[st] = bsrc[((size_t)(tap + 1) * kC + 4 * st) * kC];
+    }
+    {
+      f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float av[4] = {afr[i].x, afr[i].y, afr[i].z, afr[i].w};
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[jj], bcur[4 * i + jj], acc, 0, 0, 0);
+      }
+      // rows 16 * wave .. + 15 of dt are written and read by this wave only (previous tap's reads are complete: they
+      // fed the swaps this wave already waited for)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dt[(wave * 16 + 4 * kq + e) * kCs + l15] = acc[e];
+    }
+    __syncthreads();
+    const int *tb = tab + buf * kTm * kEntT;
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) {
+      const int row = wave * 16 + 4 * gi + kq;
+      const int4 la = *reinterpret_cast<const int4 *>(tb + row * kEntT), lb = *reinterpret_cast<const int4 *>(tb + row * kEntT + 4);
+      const float4 wa = *reinterpret_cast<const float4 *>(tb + row * kEntT + 8), wb = *reinterpret_cast<const float4 *>(tb + row * kEntT + 12);
+      const int lc[8] = {la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w};
+      const float w[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+      const float gc = dt[row * kCs + l15];
+      int ai[8];
+      float av[8];
+      bool far = false;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        ai[i] = lc[i] >= 0 ? lc[i] + l15 : dummy;
+        av[i] = lc[i] >= 0 ? w[i] * gc : 0.f;
+        far |= lc[i] < -1;
+      }
+      int seen[8], got[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) seen[i] = ibox[ai[i]];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) got[i] = atomicCAS(ibox + ai[i], seen[i], __float_as_int(__int_as_float(seen[i]) + av[i]));
+      int lost = 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) lost |= got[i] ^ seen[i];
+      if (lost != 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          int cur = got[i];
+          bool again = cur != seen[i];
+          while (again) {
+            const int want = cur;
+            cur = atomicCAS(ibox + ai[i], want, __float_as_int(__int_as_float(want) + av[i]));
+            again = cur != want;
+          }
+        }
+      }
+      if (far) {                          // some corner beyond the box (|offset| >= 1): straight to dx
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (lc[i] < -1) atomicAdd(dx + (size_t)(-2 - lc[i]) * kC + slice * kCs + l15, w[i] * gc);
+      }
+    }
+#pragma unroll
+    for (int st = 0; st < 16; ++st) bcur[st] = bnxt[st];
+  }
+  __syncthreads();
+  for (int e = tid; e < nbox * kCs; e += kThreads) {
+    const float val = box[e];
+    if (val != 0.f) {
+      const int c = e & (kCs - 1);
+      int vox = e >> 4;
+      const int lx = vox % t.rx; vox /= t.rx;
+      const int ly = vox % t.ry;
+      const int lz = vox / t.ry;
+      atomicAdd(dx + ((((size_t)n * g.D + (bz0 + lz)) * g.H + (by0 + ly)) * g.W + (bx0 + lx)) * kC + slice * kCs + c, val);
+    }
+  }
+}
+
+__global__ void dcn_pack_weights_kernel(const float *__restrict__ w, int K, float *__restrict__ wf, float *__restrict__ wb,
+                                        float *__restrict__ wb16) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;            // (tap, r, n)
+  if (idx >= K * kC * kC) return;
+  const int n = idx % kC, r = (idx / kC) % kC, tap = idx / (kC * kC);
+  const int j = r >> 1, hh = r & 1;
+  const int c = 8 * (j >> 2) + 4 * hh + (j & 3);                    // sigma(r)
+  wf[idx] = w[((size_t)n * kC + c) * K + tap];                      // W[co = n][ci = sigma(r)][tap]
+  wb[idx] = w[((size_t)c * kC + n) * K + tap];                      // W[co = sigma(r)][ci = n][tap]
+  const int step = r >> 2, q = r & 3;
+  const int c16 = 16 * (step >> 2) + 4 * q + (step & 3);            // sigma16(r)
+  wb16[idx] = w[((size_t)c16 * kC + n) * K + tap];
+}
+
+int fused_geo(const mr3d_deform_conv3d_desc *d, int cout, FGeo &g) {
+  if (!d || d->n <= 0 || d->c != kC || cout != kC || d->dg != 1) return MR3D_ERR_UNSUPPORTED;
+  g.N = d->n; g.D = d->d; g.H = d->h; g.W = d->w;
+  g.kd = d->kd; g.kh = d->kh; g.kw = d->kw; g.sd = d->sd; g.sh = d->sh; g.sw = d->sw;
+  g.pd = d->pd; g.ph = d->ph; g.pw = d->pw; g.dd = d->dil_d; g.dh = d->dil_h; g.dw = d->dil_w;
+  g.K = d->kd * d->kh * d->kw;
+  if (g.K <= 0 || g.D <= 0 || g.H <= 0 || g.W <= 0 || g.sd <= 0 || g.sh <= 0 || g.sw <= 0) return MR3D_ERR_INVALID_ARG;
+  g.Do = (d->d + 2 * d->pd - (d->dil_d * (d->kd - 1) + 1)) / d->sd + 1;
+  g.Ho = (d->h + 2 * d->ph - (d->dil_h * (d->kh - 1) + 1)) / d->sh + 1;
+  g.Wo = (d->w + 2 * d->pw - (d->dil_w * (d->kw - 1) + 1)) / d->sw + 1;
+  if (g.Do <= 0 || g.Ho <= 0 || g.Wo <= 0) return MR3D_ERR_INVALID_ARG;
+  if ((long long)g.N * g.D * g.H * g.W * kC >= (1ll << 31)) return MR3D_ERR_UNSUPPORTED;      // 32-bit element offsets in the tables
+  g.total = (long long)g.N * g.Do * g.Ho * g.Wo;
+  if (g.total >= (1ll << 31) / (g.K * 3)) return MR3D_ERR_UNSUPPORTED;                        // 32-bit position / offset indices
+  g.tiles_d = (g.Do + kGd - 1) / kGd; g.tiles_h = (g.Ho + kGh - 1) / kGh; g.tiles_w = (g.Wo + kGw - 1) / kGw;
+  g.ntiles = g.N * g.tiles_d * g.tiles_h * g.tiles_w;
+  return MR3D_OK;
+}
+
+constexpr size_t kFwdLds = (size_t)(kM * kRow + kC * kC) * 4 + 2 * kM * 8 * 4 * 2;
+constexpr size_t kWgLds = (size_t)(kM * kRow) * 4 + 2 * kM * 8 * 4 * 2;
+constexpr size_t kDgLds = (size_t)(kM * kRow + kC * kC) * 4 + 2 * kM * kEntD * 4;
+
+template <class Kern>
+int allow_lds(Kern k, size_t bytes) {
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess
+             ? MR3D_OK : MR3D_ERR_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" int mr3d_deform_conv3d_fused_supported(const mr3d_deform_conv3d_desc *d, int cout) {
+  FGeo g;
+  return fused_geo(d, cout, g) == MR3D_OK ? 1 : 0;
+}
+
+extern "C" int mr3d_deform_conv3d_pack_weights(const float *w, int cout, int cin, int taps, float *w_packed, mr3d_stream_t s) {
+  if (!w || !w_packed || taps <= 0) return MR3D_ERR_INVALID_ARG;
+  if (cout != kC || cin != kC) return MR3D_ERR_UNSUPPORTED;
+  const int n = taps * kC * kC;
+  dcn_pack_weights_kernel<<<(n + 255) / 256, 256, 0, mr3d_stream(s)>>>(w, taps, w_packed, w_packed + n, w_packed + 2 * (size_t)n);
+  return mr3d_launch_status();
+}
+
+extern "C" int mr3d_deform_conv3d_forward_fused(const mr3d_deform_conv3d_desc *d, int cout, const float *x, const float *offset,
+                                                const float *w_packed, float *y, mr3d_stream_t s) {
+  FGeo g;
+  const int st = fused_geo(d, cout, g);
+  if (st != MR3D_OK) return st;
+  if (!x || !offset || !w_packed || !y) return MR3D_ERR_INVALID_ARG;
+  if (allow_lds(dcn_fwd_kernel, kFwdLds) != MR3D_OK) return MR3D_ERR_LAUNCH;
+  const unsigned tiles = 8u * (unsigned)((g.ntiles + 7) / 8);                  // XCD-contiguous tile ranges (xcd_contiguous)
+  dcn_fwd_kernel<<<tiles, kThreads, kFwdLds, mr3d_stream(s)>>>(x, offset, w_packed, y, g);
+  return mr3d_launch_status();
+}
+
+extern "C" int mr3d_deform_conv3d_wgrad_fused(const mr3d_deform_conv3d_desc *d, int cout, const float *x, const float *offset,
+                                              const float *dy, float *dw_packed, mr3d_stream_t s) {
+  FGeo g;
+  const int st = fused_geo(d, cout, g);
+  if (st != MR3D_OK) return st;
+  if (!x || !offset || !dy || !dw_packed) return MR3D_ERR_INVALID_ARG;
+  if (allow_lds(dcn_wgrad_kernel, kWgLds) != MR3D_OK) return MR3D_ERR_LAUNCH;
+  const int groups = (g.K + kTapsPerWg - 1) / kTapsPerWg;
+  int per_xcd = 64 / groups;                            // chunks per XCD: two workgroups on each of its 32 CUs
+  if (per_xcd < 1) per_xcd = 1;
+  while (per_xcd > 1 && 8 * (per_xcd - 1) >= g.ntiles) --per_xcd;
+  dcn_wgrad_kernel<<<(unsigned)(8 * per_xcd * groups), kThreads, kWgLds, mr3d_stream(s)>>>(x, offset, dy, dw_packed, g, per_xcd,
+                                                                                           g.ntiles);
+  return mr3d_launch_status();
+}
+
+extern "C" int mr3d_deform_conv3d_dgrad_fused(const mr3d_deform_conv3d_desc *d, int cout, const float *x, const float *offset,
+                                              const float *dy, const float *w_packed, float *dx, float *doffset, mr3d_stream_t s) {
+  TGeo t;
+  FGeo &g = t.g;
+  const int st = fused_geo(d, cout, g);
+  if (st != MR3D_OK) return st;
+  if (!x || !offset || !dy || !w_packed || (!dx && !doffset)) return MR3D_ERR_INVALID_ARG;
+  const size_t wn = (size_t)g.K * kC * kC;
+  // tiled form when the reach of a 2x4x8 block of positions (+1 voxel each side) fits the LDS accumulator
+  t.rz = (kTd - 1) * g.sd + (g.kd - 1) * g.dd + 3;
+  t.ry = (kTh - 1) * g.sh + (g.kh - 1) * g.dh + 3;
+  t.rx = (kTw - 1) * g.sw + (g.kw - 1) * g.dw + 3;
+  const size_t lds_tiled = ((size_t)t.rz * t.ry * t.rx * kCs + 64 + kTm * kCs + 2 * kTm * kEntT) * 4;
+  bool tiled = dx && lds_tiled <= kTiledLdsMax;
+  if (const char *e = getenv("MR3D_DCN_DGRAD")) tiled = tiled && strcmp(e, "direct") != 0;
+  if (allow_lds(dcn_dgrad_kernel, kDgLds) != MR3D_OK) return MR3D_ERR_LAUNCH;
+  const unsigned tiles = 8u * (unsigned)((g.ntiles + 7) / 8);
+  if (tiled) {
+    t.tiles_d = (g.Do + kTd - 1) / kTd; t.tiles_h = (g.Ho + kTh - 1) / kTh; t.tiles_w = (g.Wo + kTw - 1) / kTw;
+    const long long wgs = 4ll * g.N * t.tiles_d * t.tiles_h * t.tiles_w;
+    if (wgs >= (1ll << 31)) return MR3D_ERR_UNSUPPORTED;
+    if (allow_lds(dcn_dx_tiled_kernel, lds_tiled) != MR3D_OK) return MR3D_ERR_LAUNCH;
+    if (doffset) dcn_dgrad_kernel<<<tiles, kThreads, kDgLds, mr3d_stream(s)>>>(x, offset, dy, w_packed + wn, nullptr, doffset, g);
+    dcn_dx_tiled_kernel<<<(unsigned)wgs, kThreads, lds_tiled, mr3d_stream(s)>>>(offset, dy, w_packed + 2 * wn, dx, t);
+    return mr3d_launch_status();
+  }
+  dcn_dgrad_kernel<<<tiles, kThreads, kDgLds, mr3d_stream(s)>>>(x, offset, dy, w_packed + wn, dx, doffset, g);
+  return mr3d_launch_status();
+}

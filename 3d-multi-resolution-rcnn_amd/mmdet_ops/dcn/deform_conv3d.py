@@ -11,6 +11,7 @@ autograd: backward returns (grad_input, grad_offset, grad_weight[, grad_mask, gr
 (functions/deform_conv.py:88-89).  `groups > 1` is not built (the reference's 3D path never instantiates it)."""
 import ctypes
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -49,6 +50,14 @@ def _cl(t):
     return t.permute(0, 2, 3, 4, 1).contiguous()
 
 
+def _fused_desc(xc_shape, k, stride, pad, dil, dg, co, has_mask, has_bias):
+    """the descriptor of the fused (column-free) kernels if they take this shape (csrc/deform_conv3d_fused.hip), else None"""
+    if has_mask or has_bias or os.environ.get('MR3D_DCN_FUSED', '1') == '0':
+        return None
+    d = _desc(xc_shape, k, stride, pad, dil, dg, 0, 1)
+    return d if _hip.lib().mr3d_deform_conv3d_fused_supported(ctypes.byref(d), int(co)) == 1 else None
+
+
 class DeformConvFunction3D(Function):
 
     @staticmethod
@@ -70,6 +79,24 @@ class DeformConvFunction3D(Function):
         assert tuple(offset.shape) == (N, deformable_groups * 3 * K) + osz, 'offset shape'
         oc = _cl(offset.detach())
         mc = _cl(mask.detach()) if mask is not None else None
+        fd = _fused_desc(xc.shape, k, stride, padding, dilation, deformable_groups, co, mask is not None, bias is not None)
+        if fd is not None:
+            L = _hip.lib()
+            total = N * osz[0] * osz[1] * osz[2]
+            w = weight.detach().contiguous()
+            packed = torch.empty((3, K, ci, co), dtype=torch.float32, device=x.device)
+            y = torch.empty((total, co), dtype=torch.float32, device=x.device)
+            with torch.cuda.device(x.device):
+                st = _hip.stream_ptr(x.device)
+                _hip.check(L.mr3d_deform_conv3d_pack_weights(_hip.ptr(w), co, ci, K, _hip.ptr(packed), st),
+                           'mr3d_deform_conv3d_pack_weights')
+                _hip.check(L.mr3d_deform_conv3d_forward_fused(ctypes.byref(fd), co, _hip.ptr(xc), _hip.ptr(oc), _hip.ptr(packed),
+                                                              _hip.ptr(y), st), 'mr3d_deform_conv3d_forward_fused')
+            ctx.save_for_backward(xc, oc, None, packed)
+            ctx.meta = (k, stride, padding, dilation, deformable_groups, co, co, ci, osz, False, False)
+            ctx.fused = True
+            return y.view(N, *osz, co).permute(0, 4, 1, 2, 3)
+        ctx.fused = False
         cop = -(-co // 16) * 16
         wp = weight.detach().reshape(co, ci, K).permute(2, 1, 0).reshape(1, K * ci, co)          # packed [1][K*Cin][Cout]
         if cop != co:
@@ -105,6 +132,22 @@ class DeformConvFunction3D(Function):
         N = xc.size(0)
         total = N * osz[0] * osz[1] * osz[2]
         g = gy.permute(0, 2, 3, 4, 1).reshape(total, co)
+        if ctx.fused:
+            g = g.contiguous()
+            fd = _desc(xc.shape, k, stride, padding, dilation, dg, 0, 1)
+            gx = torch.zeros_like(xc)
+            goff = torch.zeros_like(oc)
+            dwp = torch.zeros((K, ci, co), dtype=torch.float32, device=g.device)
+            L = _hip.lib()
+            with torch.cuda.device(g.device):
+                st = _hip.stream_ptr(g.device)
+                _hip.check(L.mr3d_deform_conv3d_wgrad_fused(ctypes.byref(fd), co, _hip.ptr(xc), _hip.ptr(oc), _hip.ptr(g),
+                                                            _hip.ptr(dwp), st), 'mr3d_deform_conv3d_wgrad_fused')
+                _hip.check(L.mr3d_deform_conv3d_dgrad_fused(ctypes.byref(fd), co, _hip.ptr(xc), _hip.ptr(oc), _hip.ptr(g),
+                                                            _hip.ptr(wp), _hip.ptr(gx), _hip.ptr(goff), st),
+                           'mr3d_deform_conv3d_dgrad_fused')
+            gw = dwp.permute(2, 1, 0).reshape(co, ci, *k).contiguous()
+            return (gx.permute(0, 4, 1, 2, 3), goff.permute(0, 4, 1, 2, 3), gw, None, None, None, None, None, None, None)
         if cop != co:
             g = torch.nn.functional.pad(g, (0, cop - co))
         g = g.contiguous()

@@ -83,6 +83,55 @@ def test_deform_conv3d_gpu_forward_backward(ci, co, k, stride, pad, dil, dg, mod
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('k,stride,pad,dil,scale', [
+    (3, 1, 1, 1, 1.2),                       # the neck's shape (tiled dgrad, some corners beyond the LDS box); samples leave the volume
+    (3, 1, 1, 1, 0.3),                       # every corner inside the LDS box
+    (3, (1, 2, 2), 1, 1, 0.4),               # reach of a position block > 640 voxels: direct-atomic dgrad
+    ((1, 3, 3), 1, (0, 2, 2), 2, 2.5),
+])
+def test_deform_conv3d_fused_path(k, stride, pad, dil, scale):
+    """Cin = Cout = 64, one deformable group: the column-free kernels (csrc/deform_conv3d_fused.hip) -- forward and all three
+    gradients against the float64 restatement, and the library reports the shape as fused"""
+    import importlib
+    from mr3d_amd.mmdet_ops import DeformConv3d
+    mod = importlib.import_module('mr3d_amd.mmdet_ops.dcn.deform_conv3d')
+    from torch.nn.modules.utils import _triple
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(11)
+    k3, s3, p3, d3 = _triple(k), _triple(stride), _triple(pad), _triple(dil)
+    K = k3[0] * k3[1] * k3[2]
+    N, D, H, W, C = 2, 5, 9, 8, 64
+    assert mod._fused_desc((N, D, H, W, C), k3, s3, p3, d3, 1, 64, False, False) is not None
+    assert mod._fused_desc((N, D, H, W, 32), k3, s3, p3, d3, 1, 64, False, False) is None
+    x = torch.randn(N, C, D, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+    osz = tuple((s_ + 2 * p_ - (d_ * (k_ - 1) + 1)) // st_ + 1 for s_, p_, d_, k_, st_ in zip((D, H, W), p3, d3, k3, s3))
+    off = (torch.randn(N, 3 * K, *osz, generator=g, dtype=torch.float64) * scale).requires_grad_(True)
+    layer = DeformConv3d(C, C, k, stride=stride, padding=pad, dilation=dil).to(dev)
+    w64 = layer.weight.detach().cpu().double().requires_grad_(True)
+    ref = dr.deform_conv3d_torch(x, off, w64, None, None, s3, p3, d3, 1)
+    cot = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    ref.backward(cot)
+    xd = x.detach().float().to(dev).requires_grad_(True)
+    od = off.detach().float().to(dev).requires_grad_(True)
+    out = layer(xd, od)
+
+    def rel(a, b):
+        return float((a.cpu().double() - b).abs().max() / b.abs().max())
+    assert out.shape == ref.shape and rel(out.detach(), ref.detach()) <= 1e-4
+    out.backward(cot.float().to(dev))
+    assert rel(xd.grad, x.grad) <= 1e-4
+    assert rel(layer.weight.grad, w64.grad) <= 1e-4
+    l2 = float((od.grad.cpu().double() - off.grad).norm() / off.grad.norm())
+    assert l2 <= 1e-4 and rel(od.grad, off.grad) <= 1e-3
+    # samples outside the validity box read nothing: a non-finite voxel 0 must not leak into them
+    with torch.no_grad():
+        x2 = xd.detach().clone()
+        far = torch.full_like(od, 1e4)
+        x2[0, :, 0, 0, 0] = float('inf')
+        assert torch.equal(layer(x2, far), torch.zeros_like(out))
+
+
+@pytest.mark.gpu
 def test_deform_conv3d_zero_offset_equals_conv3d_and_errors():
     from mr3d_amd.mmdet_ops import DeformConv3d
     dev = torch.device('cuda:0')
