@@ -487,21 +487,28 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
 // ---------------------------------------------------------------------------------------------------- input gradient, tiled
 // The direct kernel above runs at the chip's fp32 atomic rate (~1 TB/s of added bytes: 216 corner adds per position and
 // channel = 18 GB for P2).  Tiled form of the dx half: a workgroup owns a 2 x 4 x 8 block of output positions and one
-// 16-channel slice of dx; the voxels its samples can reach with |offset| < 1 -- the block's tap footprint plus one voxel
-// on every side -- are an LDS accumulator [Rz*Ry*Rx][16]; corners outside the box fall back to global atomics, and the box
-// is added to dx once at the end (non-zero entries only): ~30x fewer global atomics.  (The offset gradient needs the
-// corner VALUES of all 64 channels and no scatter: it comes from the direct kernel run without dx.)
-//   dcol slice = dy[64 pos x 64 co] * W[tap]^T[64 co x 16 ci]     v_mfma_f32_16x16x4_f32, one 16-row block per wave
+// 8-channel slice of dx; the voxels its samples can reach with |offset| < 1 -- the block's tap footprint plus one voxel
+// on every side -- are an LDS accumulator; corners outside the box fall back to global atomics, and the box is added to dx
+// once at the end (non-zero entries only): ~30x fewer global atomics.  (The offset gradient needs the corner VALUES of
+// all 64 channels and no scatter: it comes from the direct kernel run without dx.)
+//
+// LDS accumulation is integer: ds_add_f32 serialises its 64 lanes on gfx950 (~190 cycles per instruction, against ~6 for
+// ds_add_u32 / ds_max_f32 and ~14 for a read + compare-and-swap pair that then has to retry whenever two positions meet
+// in a voxel, which neighbouring positions do all the time -- tools/lds_atomic_probe.hip).  A contribution v = w * dcol is
+// scaled by 2^S, S = 40 - E with 2^E >= |dcol| for every value this workgroup can produce (Cauchy-Schwarz:
+// |dcol[pos][tap][ci]| <= ||dy[pos]||_2 * max_(tap,ci) ||W[tap][:,ci]||_2), and split into two words
+//     hi = floor(v 2^S / 2^20)     (|sum| < 2^31: at most 64 x 27 = 1728 < 2^11 contributions reach one voxel, each < 2^20)
+//     lo = v 2^S - hi 2^20  in [0, 2^20]          (sum < 1728 * 2^20 < 2^31; carries are resolved at the end)
+// each added with ds_add_u32.  The split is exact in fp32, so the sum is the exact sum of the contributions rounded to
+// 2^(E-40) -- 16 bits below an fp32 ulp of the largest value -- independent of the order: the LDS part is deterministic.
+//   dcol = dy[64 pos x 64 co] * [W[tap]^T | W[tap+1]^T][64 co x (8 + 8) ci]     v_mfma_f32_16x16x4_f32, two taps per pass
 //   GEMM-k index kk = 4 * step + (lane >> 4)  <->  co = sigma16(kk) = 16 * (step >> 2) + 4 * (lane >> 4) + (step & 3)
 //   (a lane's dy values of four steps are one float4); the third block of w_packed is stored in that order and a lane's
-//   16 B values of a tap are loaded straight into registers one tap ahead.
-// LDS fp32 adds are read + compare-and-swap: ds_add_f32 serialises its 64 lanes (~190 cycles per instruction on gfx950,
-// tools/lds_atomic_probe.hip) while integer LDS atomics take ~6.  The 8 reads and the 8 swaps of a position group are
-// issued back to back; a swap that lost against another lane / wave retries on its own.
+//   16 B values of a tap pair are loaded straight into registers one pair ahead.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 constexpr int kTd = 2, kTh = 4, kTw = 8, kTm = kTd * kTh * kTw;     // 64 positions
-constexpr int kCs = 16;                                             // channels per slice
+constexpr int kCs = 8;                                              // channels per slice
 constexpr int kEntT = 16;                                           // loc[8], w[8]
 constexpr size_t kTiledLdsMax = 53 * 1024;                          // three workgroups per CU
 
@@ -509,24 +516,26 @@ struct TGeo {
   FGeo g;
   int tiles_d, tiles_h, tiles_w;
   int rz, ry, rx;                 // box extent
+  const float *wnorm;             // max over (tap, ci) of ||W[tap][:, ci]||_2
 };
 
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void dcn_dx_tiled_kernel(const float *__restrict__ offset, const float *__restrict__ dy, const float *__restrict__ wb16,
                          float *__restrict__ dx, TGeo t) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ float red[4];
   const FGeo &g = t.g;
   const int nbox = t.rz * t.ry * t.rx;
-  float *box = lds;                                         // [nbox][16] + 64 per-lane dummy slots
-  int *ibox = reinterpret_cast<int *>(box);
-  float *dt = box + nbox * kCs + 64;                        // [64][16]
-  int *tab = reinterpret_cast<int *>(dt + kTm * kCs);       // [2][64][kEntT]
+  int *bhi = reinterpret_cast<int *>(lds);                  // [nbox][8]
+  int *blo = bhi + nbox * kCs;                              // [nbox][8]
+  float *dt = reinterpret_cast<float *>(blo + nbox * kCs);  // [64][16]: columns 0-7 tap t, 8-15 tap t + 1
+  int *tab = reinterpret_cast<int *>(dt + kTm * 16);        // [2 taps][64][kEntT]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, kq = lane >> 4;
-  const int dummy = nbox * kCs + lane;                      // where a lane with nothing to add swaps a value with itself
+  const int p8 = lane >> 3, c8 = lane & 7;
   int b = blockIdx.x;
-  const int slice = b & 3; b >>= 2;
+  const int slice = b & 7; b >>= 3;
   const int tw_i = b % t.tiles_w; b /= t.tiles_w;
   const int th_i = b % t.tiles_h; b /= t.tiles_h;
   const int td_i = b % t.tiles_d; b /= t.tiles_d;
@@ -542,34 +551,52 @@ void dcn_dx_tiled_kernel(const float *__restrict__ offset, const float *__restri
     c.pos = c.in ? (unsigned)(((n * g.Do + c.od) * g.Ho + c.oh) * g.Wo + c.ow) : 0u;
     return c;
   };
-  const Coord me = coord_of(tid & (kTm - 1));               // the position whose table entries this thread fills
   // A operand: this wave's 16 positions x 64 co (permuted), registers for the whole kernel
   float4 afr[4];
+  float nrm = 0.f;
   {
     const Coord c = coord_of(wave * 16 + l15);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
       afr[i] = c.in ? *reinterpret_cast<const float4 *>(dy + (size_t)c.pos * kC + 16 * i + 4 * kq) : make_float4(0.f, 0.f, 0.f, 0.f);
+      nrm += afr[i].x * afr[i].x + afr[i].y * afr[i].y + afr[i].z * afr[i].z + afr[i].w * afr[i].w;
+    }
   }
-  for (int e = tid; e < nbox * kCs / 4 + 16; e += kThreads) reinterpret_cast<float4 *>(box)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-
-  // B operand of a tap: B[kk = 4 * step + kq][ci = l15], 16 values per lane
-  const float *bsrc = wb16 + (size_t)kq * kC + slice * kCs + l15;
-  float bcur[16], bnxt[16];
+  // ||dy[pos]||_2^2: the four kq lanes of a row, then the largest row of the workgroup
+  nrm += __shfl_xor(nrm, 16);
+  nrm += __shfl_xor(nrm, 32);
 #pragma unroll
-  for (int st = 0; st < 16; ++st) bcur[st] = bsrc[(size_t)(4 * st) * kC];
-  // the offsets of this thread's position: the next tap's three values are requested one tap ahead
-  const float *op = offset + (size_t)me.pos * (g.K * 3);
-  float onx[3] = {0.f, 0.f, 0.f};
-  if (tid < kTm && me.in) { onx[0] = op[0]; onx[1] = op[1]; onx[2] = op[2]; }
+  for (int m = 8; m > 0; m >>= 1) nrm = fmaxf(nrm, __shfl_xor(nrm, m));
+  if (lane == 0) red[wave] = nrm;
+  for (int e = tid; e < 2 * nbox * kCs / 4; e += kThreads) reinterpret_cast<int4 *>(bhi)[e] = make_int4(0, 0, 0, 0);
+  __syncthreads();
+  const float bound = sqrtf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))) * t.wnorm[0] * 1.0001f;
+  if (bound == 0.f) return;                                 // dy == 0 on the whole block
+  const bool finite = bound < 3.0e38f;                      // non-finite dy / weights: every add goes straight to dx (fp32 atomics)
+  int E = 0;
+  if (finite) frexpf(bound, &E);                            // bound < 2^E
+  const float up_hi = ldexpf(1.f, 20 - E);                  // v -> v 2^S / 2^20
+  const float kLo = 1048576.f;
 
+  const Coord me = coord_of(tid & (kTm - 1));               // the position whose table entries this thread fills
+  const int my_tap = tid >> 6;                              // threads 0-63: first tap of the pair, 64-127: second
+  OffsetStream os;
+  os.start(offset, me, g.K, tid < 2 * kTm && my_tap < g.K, my_tap);
   TapIdx ti;
-  ti.set(g, 0);
-  for (int tap = 0; tap < g.K; ++tap, ti.next(g)) {
-    const int buf = tap & 1;
-    if (tid < kTm) {
-      const float oz = onx[0], oy = onx[1], ox = onx[2];
-      if (me.in && tap + 1 < g.K) { onx[0] = op[3 * tap + 3]; onx[1] = op[3 * tap + 4]; onx[2] = op[3 * tap + 5]; }
+  ti.set(g, tid < 2 * kTm ? min(my_tap, g.K - 1) : 0);
+
+  // B operand of a tap pair: B[kk = 4 * step + kq][n = l15]: n < 8 -> tap t, channel slice * 8 + n; else tap t + 1
+  const int bt = l15 >> 3;
+  const float *bsrc = wb16 + (size_t)kq * kC + slice * kCs + (l15 & 7);
+  float bcur[16];
+#pragma unroll
+  for (int st = 0; st < 16; ++st) bcur[st] = bt < g.K ? bsrc[((size_t)bt * kC + 4 * st) * kC] : 0.f;
+
+  for (int tap = 0; tap < g.K; tap += 2) {
+    if (tid < 2 * kTm) {
+      const int mt = tap + my_tap;
+      float oz, oy, ox;
+      os.take(oz, oy, ox, mt + 2, g.K);
       int lc[8];
       float w[8];
 #pragma unroll
@@ -577,7 +604,7 @@ void dcn_dx_tiled_kernel(const float *__restrict__ offset, const float *__restri
       const float pz = (float)(me.od * g.sd - g.pd + ti.kd * g.dd) + oz;
       const float py = (float)(me.oh * g.sh - g.ph + ti.kh * g.dh) + oy;
       const float px = (float)(me.ow * g.sw - g.pw + ti.kw * g.dw) + ox;
-      if (me.in && pz > -1.f && py > -1.f && px > -1.f && pz < (float)g.D && py < (float)g.H && px < (float)g.W) {
+      if (mt < g.K && me.in && pz > -1.f && py > -1.f && px > -1.f && pz < (float)g.D && py < (float)g.H && px < (float)g.W) {
         const int z0 = (int)floorf(pz), y0 = (int)floorf(py), x0 = (int)floorf(px);
         const float lz = pz - (float)z0, ly = py - (float)y0, lx = px - (float)x0;
         const float wz[2] = {1.f - lz, lz}, wy[2] = {1.f - ly, ly}, wx[2] = {1.f - lx, lx};
@@ -593,21 +620,18 @@ void dcn_dx_tiled_kernel(const float *__restrict__ offset, const float *__restri
               const float wi = wz[a] * wy[bb] * wx[c];
               if (valid && wi != 0.f) {
                 const int bz = z - bz0, by = y - by0, bx = xx - bx0;
-                const bool inb = (unsigned)bz < (unsigned)t.rz && (unsigned)by < (unsigned)t.ry && (unsigned)bx < (unsigned)t.rx;
+                const bool inb = finite && (unsigned)bz < (unsigned)t.rz && (unsigned)by < (unsigned)t.ry && (unsigned)bx < (unsigned)t.rx;
                 w[i] = wi;
                 lc[i] = inb ? ((bz * t.ry + by) * t.rx + bx) * kCs : -2 - (((n * g.D + z) * g.H + y) * g.W + xx);
               }
             }
       }
-      int *e = tab + (buf * kTm + tid) * kEntT;
+      ti.next(g); ti.next(g);
+      int *e = tab + tid * kEntT;
       *reinterpret_cast<int4 *>(e) = make_int4(lc[0], lc[1], lc[2], lc[3]);
       *reinterpret_cast<int4 *>(e + 4) = make_int4(lc[4], lc[5], lc[6], lc[7]);
       *reinterpret_cast<float4 *>(e + 8) = make_float4(w[0], w[1], w[2], w[3]);
       *reinterpret_cast<float4 *>(e + 12) = make_float4(w[4], w[5], w[6], w[7]);
-    }
-    if (tap + 1 < g.K) {
-#pragma unroll
-      for (int st = 0; st < 16; ++st) bnxt[st] = bsrc[((size_t)(tap + 1) * kC + 4 * st) * kC];
     }
     {
       f32x4v acc = {0.f, 0.f, 0.f, 0.f};
@@ -617,65 +641,53 @@ void dcn_dx_tiled_kernel(const float *__restrict__ offset, const float *__restri
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[jj], bcur[4 * i + jj], acc, 0, 0, 0);
       }
-      // rows 16 * wave .. + 15 of dt are written and read by this wave only (previous tap's reads are complete: they
-      // fed the swaps this wave already waited for)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) dt[(wave * 16 + 4 * kq + e) * kCs + l15] = acc[e];
+      for (int e = 0; e < 4; ++e) dt[(wave * 16 + 4 * kq + e) * 16 + l15] = acc[e];
+    }
+    {                                     // next pair's B operand: in flight during the adds below
+      const int nt = tap + 2 + bt;
+#pragma unroll
+      for (int st = 0; st < 16; ++st) bcur[st] = nt < g.K ? bsrc[((size_t)nt * kC + 4 * st) * kC] : 0.f;
     }
     __syncthreads();
-    const int *tb = tab + buf * kTm * kEntT;
 #pragma unroll
-    for (int gi = 0; gi < 4; ++gi) {
-      const int row = wave * 16 + 4 * gi + kq;
-      const int4 la = *reinterpret_cast<const int4 *>(tb + row * kEntT), lb = *reinterpret_cast<const int4 *>(tb + row * kEntT + 4);
-      const float4 wa = *reinterpret_cast<const float4 *>(tb + row * kEntT + 8), wb = *reinterpret_cast<const float4 *>(tb + row * kEntT + 12);
+    for (int u = 0; u < 4; ++u) {         // (tap of the pair, half of the wave's 16 positions)
+      const int tp = u >> 1;
+      const int row = wave * 16 + 8 * (u & 1) + p8;
+      const int *ent = tab + (tp * kTm + row) * kEntT;
+      const int4 la = *reinterpret_cast<const int4 *>(ent), lb = *reinterpret_cast<const int4 *>(ent + 4);
+      const float4 wa = *reinterpret_cast<const float4 *>(ent + 8), wb = *reinterpret_cast<const float4 *>(ent + 12);
       const int lc[8] = {la.x, la.y, la.z, la.w, lb.x, lb.y, lb.z, lb.w};
       const float w[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
-      const float gc = dt[row * kCs + l15];
-      int ai[8];
-      float av[8];
+      const float gc = dt[row * 16 + tp * 8 + c8];
+      const float gs = gc * up_hi;
       bool far = false;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        ai[i] = lc[i] >= 0 ? lc[i] + l15 : dummy;
-        av[i] = lc[i] >= 0 ? w[i] * gc : 0.f;
-        far |= lc[i] < -1;
-      }
-      int seen[8], got[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) seen[i] = ibox[ai[i]];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) got[i] = atomicCAS(ibox + ai[i], seen[i], __float_as_int(__int_as_float(seen[i]) + av[i]));
-      int lost = 0;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) lost |= got[i] ^ seen[i];
-      if (lost != 0) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          int cur = got[i];
-          bool again = cur != seen[i];
-          while (again) {
-            const int want = cur;
-            cur = atomicCAS(ibox + ai[i], want, __float_as_int(__int_as_float(want) + av[i]));
-            again = cur != want;
-          }
+        if (lc[i] >= 0) {
+          const float sv = w[i] * gs;                       // v 2^S / 2^20
+          const float fh = floorf(sv);
+          const int lo = (int)rintf((sv - fh) * kLo);       // exact difference, [0, 2^20]
+          atomicAdd(bhi + lc[i] + c8, (int)fh);
+          atomicAdd(blo + lc[i] + c8, lo);
         }
+        far |= lc[i] < -1;
       }
       if (far) {                          // some corner beyond the box (|offset| >= 1): straight to dx
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-          if (lc[i] < -1) atomicAdd(dx + (size_t)(-2 - lc[i]) * kC + slice * kCs + l15, w[i] * gc);
+          if (lc[i] < -1) atomicAdd(dx + (size_t)(-2 - lc[i]) * kC + slice * kCs + c8, w[i] * gc);
       }
     }
-#pragma unroll
-    for (int st = 0; st < 16; ++st) bcur[st] = bnxt[st];
+    __syncthreads();
   }
-  __syncthreads();
+  const double down = (double)ldexpf(1.f, E - 40);
   for (int e = tid; e < nbox * kCs; e += kThreads) {
-    const float val = box[e];
-    if (val != 0.f) {
+    const int hi = bhi[e], lo = blo[e];
+    if ((hi | lo) != 0) {
+      const float val = (float)(((double)hi * 1048576.0 + (double)lo) * down);
       const int c = e & (kCs - 1);
-      int vox = e >> 4;
+      int vox = e >> 3;
       const int lx = vox % t.rx; vox /= t.rx;
       const int ly = vox % t.ry;
       const int lz = vox / t.ry;
@@ -696,6 +708,19 @@ __global__ void dcn_pack_weights_kernel(const float *__restrict__ w, int K, floa
   const int step = r >> 2, q = r & 3;
   const int c16 = 16 * (step >> 2) + 4 * q + (step & 3);            // sigma16(r)
   wb16[idx] = w[((size_t)c16 * kC + n) * K + tap];
+}
+
+// max over (tap, ci) of ||W[:, ci, tap]||_2 (the bound of the tiled input gradient's fixed-point scale)
+__global__ void dcn_weight_norm_kernel(const float *__restrict__ w, int K, float *__restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;            // (tap, ci)
+  if (idx >= K * kC) return;
+  const int ci = idx % kC, tap = idx / kC;
+  float s = 0.f;
+  for (int co = 0; co < kC; ++co) {
+    const float v = w[((size_t)co * kC + ci) * K + tap];
+    s = fmaf(v, v, s);
+  }
+  atomicMax(reinterpret_cast<unsigned *>(out), __float_as_uint(sqrtf(s)));       // non-negative floats order like their bits
 }
 
 int fused_geo(const mr3d_deform_conv3d_desc *d, int cout, FGeo &g) {
@@ -739,6 +764,8 @@ extern "C" int mr3d_deform_conv3d_pack_weights(const float *w, int cout, int cin
   if (cout != kC || cin != kC) return MR3D_ERR_UNSUPPORTED;
   const int n = taps * kC * kC;
   dcn_pack_weights_kernel<<<(n + 255) / 256, 256, 0, mr3d_stream(s)>>>(w, taps, w_packed, w_packed + n, w_packed + 2 * (size_t)n);
+  if (hipMemsetAsync(w_packed + 3 * (size_t)n, 0, 4, mr3d_stream(s)) != hipSuccess) return MR3D_ERR_LAUNCH;
+  dcn_weight_norm_kernel<<<(taps * kC + 255) / 256, 256, 0, mr3d_stream(s)>>>(w, taps, w_packed + 3 * (size_t)n);
   return mr3d_launch_status();
 }
 
@@ -782,14 +809,15 @@ extern "C" int mr3d_deform_conv3d_dgrad_fused(const mr3d_deform_conv3d_desc *d, 
   t.rz = (kTd - 1) * g.sd + (g.kd - 1) * g.dd + 3;
   t.ry = (kTh - 1) * g.sh + (g.kh - 1) * g.dh + 3;
   t.rx = (kTw - 1) * g.sw + (g.kw - 1) * g.dw + 3;
-  const size_t lds_tiled = ((size_t)t.rz * t.ry * t.rx * kCs + 64 + kTm * kCs + 2 * kTm * kEntT) * 4;
+  const size_t lds_tiled = ((size_t)2 * t.rz * t.ry * t.rx * kCs + kTm * 16 + 2 * kTm * kEntT) * 4;
+  t.wnorm = w_packed + 3 * wn;
   bool tiled = dx && lds_tiled <= kTiledLdsMax;
   if (const char *e = getenv("MR3D_DCN_DGRAD")) tiled = tiled && strcmp(e, "direct") != 0;
   if (allow_lds(dcn_dgrad_kernel, kDgLds) != MR3D_OK) return MR3D_ERR_LAUNCH;
   const unsigned tiles = 8u * (unsigned)((g.ntiles + 7) / 8);
   if (tiled) {
     t.tiles_d = (g.Do + kTd - 1) / kTd; t.tiles_h = (g.Ho + kTh - 1) / kTh; t.tiles_w = (g.Wo + kTw - 1) / kTw;
-    const long long wgs = 4ll * g.N * t.tiles_d * t.tiles_h * t.tiles_w;
+    const long long wgs = 8ll * g.N * t.tiles_d * t.tiles_h * t.tiles_w;
     if (wgs >= (1ll << 31)) return MR3D_ERR_UNSUPPORTED;
     if (allow_lds(dcn_dx_tiled_kernel, lds_tiled) != MR3D_OK) return MR3D_ERR_LAUNCH;
     if (doffset) dcn_dgrad_kernel<<<tiles, kThreads, kDgLds, mr3d_stream(s)>>>(x, offset, dy, w_packed + wn, nullptr, doffset, g);

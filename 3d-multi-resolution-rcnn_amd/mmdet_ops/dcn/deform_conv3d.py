@@ -84,7 +84,7 @@ class DeformConvFunction3D(Function):
             L = _hip.lib()
             total = N * osz[0] * osz[1] * osz[2]
             w = weight.detach().contiguous()
-            packed = torch.empty((3, K, ci, co), dtype=torch.float32, device=x.device)
+            packed = torch.empty((3 * K * ci * co + 1,), dtype=torch.float32, device=x.device)
             y = torch.empty((total, co), dtype=torch.float32, device=x.device)
             with torch.cuda.device(x.device):
                 st = _hip.stream_ptr(x.device)

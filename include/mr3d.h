@@ -416,13 +416,15 @@ int mr3d_deform_col2im3d(const mr3d_deform_conv3d_desc *d, const float *x, const
  * no column matrix -- a workgroup samples a 128-position tile tap by tap into LDS and multiplies it on the MFMA units
  * (csrc/deform_conv3d_fused.hip).  pos0 / npos of the descriptor are ignored (whole output).  Same sampling rule as above.
  *   mr3d_deform_conv3d_fused_supported: 1 if the three entry points accept the descriptor, else 0 (use the column form).
- *   pack_weights: w [cout][cin][taps] (the reference's OIDHW weight flattened) -> w_packed [3][taps][64][64] fp32: the forward
- *                 operand and the two backward operands (direct / tiled kernel), each in its kernel's GEMM-k order.
+ *   pack_weights: w [cout][cin][taps] (the reference's OIDHW weight flattened) -> w_packed, 3 * taps * 64 * 64 + 1 floats: the
+ *                 forward operand and the two backward operands (direct / tiled kernel), each [taps][64][64] in its kernel's
+ *                 GEMM-k order, then max_(tap,ci) ||W[:,ci,tap]||_2 (the tiled kernel's accumulation scale).
  *   forward:  y [N*Do*Ho*Wo][64] written.
  *   wgrad:    dw_packed [taps][cin][cout] += (fp32 atomics, PRE-ZEROED by the caller).
  *   dgrad:    dx [N,D,H,W,64] += (fp32 atomics, PRE-ZEROED; may be NULL), doffset [N,Do,Ho,Wo,taps*3] += (PRE-ZEROED; may
- *             be NULL).  A 2x4x8 block of positions whose reach fits 640 voxels (the neck: 6x8x12) accumulates dx in LDS
- *             and touches HBM once per voxel; wider kernels / strides use direct atomics (MR3D_DCN_DGRAD=direct forces it).
+ *             be NULL).  A 2x4x8 block of positions whose reach fits the LDS budget (the neck: 6x8x12 voxels) accumulates
+ *             dx in LDS (exact two-word integer sums, see the kernel) and touches HBM once per voxel; wider kernels /
+ *             strides use direct atomics (MR3D_DCN_DGRAD=direct forces it).
  * Other shapes: MR3D_ERR_UNSUPPORTED. */
 int mr3d_deform_conv3d_fused_supported(const mr3d_deform_conv3d_desc *d, int cout);
 int mr3d_deform_conv3d_pack_weights(const float *w, int cout, int cin, int taps, float *w_packed, mr3d_stream_t s);

@@ -25,6 +25,10 @@ __global__ __launch_bounds__(256) void probe(float *out, int iters) {
         if (got != seen) v += 1e-30f;
       } else if (MODE == 5) {
         atomicAdd(reinterpret_cast<unsigned long long *>(box) + (idx >> 1), (unsigned long long)(long long)v);
+      } else if (MODE == 7) {
+        atomicAdd(reinterpret_cast<double *>(box) + (idx >> 1), (double)v);
+      } else if (MODE == 8) {
+        __hip_atomic_fetch_max(box + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       } else if (MODE == 6) {
         int r = atomicAdd(reinterpret_cast<int *>(box) + idx, (int)v); v += r * 1e-30f;
       }
@@ -66,5 +70,7 @@ int main() {
   run<6, 1>("ds_add_rtn_u32");
   run<4, 1>("read + ds_cmpst_rtn_b32");
   run<5, 1>("ds_add_u64");
+  run<7, 1>("ds_add_f64");
+  run<8, 1>("ds_max_f32");
   return 0;
 }
