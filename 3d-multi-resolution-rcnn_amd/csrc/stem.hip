@@ -21,6 +21,34 @@ namespace {
 
 constexpr int kStemThreads = 512;      // 8 waves: 2 per SIMD
 
+// Tile order of the stem kernels.  The 7-tap depth halo makes a 4-plane tile read 10 input planes: dealt out in
+// blockIdx order (w fastest, round-robin over the 8 XCDs) a tile's depth neighbours ran 64 slots apart on their XCD
+// and the shared planes had left its 4 MB L2 by then -- 2.0 GB of HBM reads per launch for 0.59 GB of input.  Here
+// tiles are ordered depth-fastest inside a (n, h, w) column, and each XCD (= blockIdx & 7) owns a contiguous range of
+// columns: the tiles in flight on one XCD are whole columns, whose planes are fetched once.
+struct StemTile { int n, td, th, tw; bool valid; };
+
+__device__ __forceinline__ StemTile stem_tile_of(int seq, int tiles_d, int tiles_h, int tiles_w) {      // seq: depth-fastest order
+  StemTile t;
+  t.valid = true;
+  t.td = seq % tiles_d; seq /= tiles_d;
+  t.tw = seq % tiles_w; seq /= tiles_w;
+  t.th = seq % tiles_h;
+  t.n = seq / tiles_h;
+  return t;
+}
+
+// one-tile-per-workgroup kernels: grid = 8 * cols_per_xcd * tiles_d
+__device__ __forceinline__ StemTile stem_tile_xcd(int bid, int ncols, int tiles_d, int tiles_h, int tiles_w) {
+  const int cols_per = (ncols + 7) >> 3;
+  const int xcd = bid & 7, s = bid >> 3;
+  const int col = xcd * cols_per + s / tiles_d;
+  StemTile t;
+  if (s >= cols_per * tiles_d || col >= ncols) { t.valid = false; t.n = t.td = t.th = t.tw = 0; return t; }
+  t = stem_tile_of(col * tiles_d + s % tiles_d, tiles_d, tiles_h, tiles_w);
+  return t;
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 struct StemFwdArgs {
   const float *x;      // [N,3,D,H,W] planar
@@ -89,12 +117,10 @@ __global__ __launch_bounds__(TD * 64) void stem_fwd_kernel(StemFwdArgs p, int ti
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // = output depth inside the tile
   const int li = lane & 15, lk = lane >> 4;
-  int b = blockIdx.x;
-  const int tw_i = b % tiles_w; b /= tiles_w;
-  const int th_i = b % tiles_h; b /= tiles_h;
-  const int td_i = b % tiles_d; b /= tiles_d;
-  const int n = b;
-  const int d0 = td_i * TD, h0 = th_i * TH, w0 = tw_i * TW;
+  const StemTile st = stem_tile_xcd(blockIdx.x, p.N * tiles_h * tiles_w, tiles_d, tiles_h, tiles_w);
+  if (!st.valid) return;
+  const int n = st.n;
+  const int d0 = st.td * TD, h0 = st.th * TH, w0 = st.tw * TW;
 
   f32x4 acc[TH][WB];
 #pragma unroll
@@ -192,12 +218,10 @@ __global__ __launch_bounds__(256, 3) void stem_fwd_wino_kernel(StemFwdArgs p, in
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int dp = wave >> 1, hh = wave & 1;                      // depth pair, row half
   const int li = lane & 15, lk = lane >> 4;
-  int b = blockIdx.x;
-  const int tw_i = b % tiles_w; b /= tiles_w;
-  const int th_i = b % tiles_h; b /= tiles_h;
-  const int td_i = b % tiles_d; b /= tiles_d;
-  const int n = b;
-  const int d0 = td_i * TD, h0 = th_i * TH, w0 = tw_i * TW;
+  const StemTile st = stem_tile_xcd(blockIdx.x, p.N * tiles_h * tiles_w, tiles_d, tiles_h, tiles_w);
+  if (!st.valid) return;
+  const int n = st.n;
+  const int d0 = st.td * TD, h0 = st.th * TH, w0 = st.tw * TW;
 
   f32x4 acc[4][THW];                                            // [Winograd product f][row]
 #pragma unroll
@@ -372,13 +396,24 @@ __global__ __launch_bounds__(kStemThreads) void stem_wgrad_kernel(StemWgradArgs 
   const int lane_col = (lk >> 1) + 8 * (lk & 1);
   float bsum = 0.f;
 
-  for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
-    int b = tile;
-    const int tw_i = b % tiles_w; b /= tiles_w;
-    const int th_i = b % tiles_h; b /= tiles_h;
-    const int td_i = b % tiles_d; b /= tiles_d;
-    const int n = b;
-    const int d0 = td_i * TD, h0 = th_i * TH, w0 = tw_i * TW;
+  // a workgroup walks a contiguous run of the depth-fastest tile order (a column, or part of one); the runs of one
+  // XCD's workgroups are adjacent (gridDim.x is a multiple of 8 whenever it is >= 8)
+  int t_begin, t_end;
+  if ((gridDim.x & 7) == 0) {
+    const int per_xcd = (num_tiles + 7) >> 3, wgs = gridDim.x >> 3;
+    const int per_wg = (per_xcd + wgs - 1) / wgs;
+    const int x0 = (blockIdx.x & 7) * per_xcd;
+    t_begin = x0 + (int)(blockIdx.x >> 3) * per_wg;
+    t_end = min(min(t_begin + per_wg, x0 + per_xcd), num_tiles);
+  } else {
+    const int per_wg = (num_tiles + gridDim.x - 1) / gridDim.x;
+    t_begin = blockIdx.x * per_wg;
+    t_end = min(t_begin + per_wg, num_tiles);
+  }
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const StemTile st = stem_tile_of(tile, tiles_d, tiles_h, tiles_w);
+    const int n = st.n;
+    const int d0 = st.td * TD, h0 = st.th * TH, w0 = st.tw * TW;
     __syncthreads();
     // dy tile [m'][16], m' = ks*4 + k in GEMM-k order, zeros outside
     for (int it = tid; it < M * 4; it += kStemThreads) {
@@ -473,8 +508,9 @@ static int stem_forward_impl(const float *x_ncdhw, const float *w_packed, const 
   const int td = (d + TD - 1) / TD, th = (a.Ho + 7) / 8, tw = (a.Wo + TW - 1) / TW;
   // Winograd-along-depth form by default (1.79 -> 1.43 ms on the 512 volume); MR3D_STEM_WINO=0: direct form
   static const int wino = getenv("MR3D_STEM_WINO") ? atoi(getenv("MR3D_STEM_WINO")) : 1;
-  if (wino) stem_fwd_wino_kernel<TW><<<(unsigned)(n * td * th * tw), 256, lds_bytes, mr3d_stream(stream_)>>>(a, td, th, tw);
-  else stem_fwd_kernel<TD, TW><<<(unsigned)(n * td * th * tw), TD * 64, lds_bytes, mr3d_stream(stream_)>>>(a, td, th, tw);
+  const unsigned grid = 8u * (unsigned)((n * th * tw + 7) / 8) * (unsigned)td;           // stem_tile_xcd
+  if (wino) stem_fwd_wino_kernel<TW><<<grid, 256, lds_bytes, mr3d_stream(stream_)>>>(a, td, th, tw);
+  else stem_fwd_kernel<TD, TW><<<grid, TD * 64, lds_bytes, mr3d_stream(stream_)>>>(a, td, th, tw);
   return mr3d_launch_status();
 }
 
@@ -533,7 +569,8 @@ static int stem_wgrad_impl(const float *x_ncdhw, const float *dy, int dy_bf16, f
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
       cus = prop.multiProcessorCount;
   }
-  const int grid = tiles < 2 * cus ? tiles : 2 * cus;
+  int grid = tiles < 2 * cus ? tiles : 2 * cus;
+  if (grid >= 8) grid &= ~7;                                 // XCD-contiguous tile runs need a multiple of 8
   // two-stage reduction when the caller lends a workspace: 512 workgroups x 16,464 same-address atomics are ~0.13 ms
   a.part = (workspace && workspace_bytes >= (long long)grid * 343 * 3 * 16 * 4) ? workspace : nullptr;
   stem_wgrad_kernel<<<(unsigned)grid, kStemThreads, lds_bytes, mr3d_stream(stream_)>>>(a, td, th, tw);
