@@ -70,6 +70,34 @@ struct StemBfArgs {
   int N, D, H, W, Ho, Wo, relu;
 };
 
+
+// Tile sequence of the persistent stem kernels: depth-fastest inside a (n, h, w) column; a workgroup walks a contiguous
+// run, and the runs of one XCD's workgroups (blockIdx & 7 = XCD) are adjacent -- the input planes shared by depth
+// neighbours (10 of 10 + 4 ...) then come from that XCD's L2 (see csrc/stem.hip).
+struct BfTile { int n, td, th, tw; };
+__device__ __forceinline__ BfTile bf_tile_of(int seq, int tiles_d, int tiles_h, int tiles_w) {
+  BfTile t;
+  t.td = seq % tiles_d; seq /= tiles_d;
+  t.tw = seq % tiles_w; seq /= tiles_w;
+  t.th = seq % tiles_h;
+  t.n = seq / tiles_h;
+  return t;
+}
+__device__ __forceinline__ void bf_tile_run(int bid, int nwg, int ntiles, int &begin, int &end) {
+  if ((nwg & 7) == 0) {
+    const int per_xcd = (ntiles + 7) >> 3, wgs = nwg >> 3;
+    const int per_wg = (per_xcd + wgs - 1) / wgs;
+    const int x0 = (bid & 7) * per_xcd;
+    begin = x0 + (bid >> 3) * per_wg;
+    end = min(min(begin + per_wg, x0 + per_xcd), ntiles);
+  } else {
+    const int per_wg = (ntiles + nwg - 1) / nwg;
+    begin = bid * per_wg;
+    end = min(begin + per_wg, ntiles);
+  }
+  if (begin > end) begin = end;
+}
+
 __global__ __launch_bounds__(512, 1) void stem_fwd_bf16_kernel(StemBfArgs p, int tiles_d, int tiles_h, int tiles_w, int ntiles) {
   using G = FwdGeo;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -92,11 +120,8 @@ __global__ __launch_bounds__(512, 1) void stem_fwd_bf16_kernel(StemBfArgs p, int
   const bool s_act = s_hh < G::HH;
   float2 st[NPL];
   auto fetch = [&](int tile) {
-    int b = tile;
-    const int tw_i = b % tiles_w; b /= tiles_w;
-    const int th_i = b % tiles_h; b /= tiles_h;
-    const int td_i = b % tiles_d; b /= tiles_d;
-    const int n = b;
+    const BfTile bt = bf_tile_of(tile < ntiles ? tile : 0, tiles_d, tiles_h, tiles_w);
+    const int tw_i = bt.tw, th_i = bt.th, td_i = bt.td, n = bt.n;
     const int id0 = td_i * G::TD - 3, ih = 2 * th_i * G::TH - 3 + s_hh, iw = 2 * tw_i * G::TW - 3 + 2 * s_pr - 1;   // iw is even
     const bool row_ok = s_act && tile < ntiles && (unsigned)ih < (unsigned)p.H;
     const bool pair_ok = even_w && iw >= 0 && iw + 1 < p.W;
@@ -140,12 +165,14 @@ __global__ __launch_bounds__(512, 1) void stem_fwd_bf16_kernel(StemBfArgs p, int
   for (int e = 0; e < 8; ++e) zero[e] = (__bf16)0.0f;
   const float sh = p.shift ? p.shift[r] : 0.f;
 
-  fetch(blockIdx.x);
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  int t_begin, t_end;
+  bf_tile_run((int)blockIdx.x, (int)gridDim.x, ntiles, t_begin, t_end);
+  fetch(t_begin < t_end ? t_begin : ntiles);
+  for (int tile = t_begin; tile < t_end; ++tile) {
     __syncthreads();                       // the previous tile's fragments have been read
     commit();
     __syncthreads();
-    fetch(tile + gridDim.x);               // in flight during the MFMA phase
+    fetch(tile + 1 < t_end ? tile + 1 : ntiles);      // in flight during the MFMA phase
     f32x4_t acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -164,11 +191,8 @@ __global__ __launch_bounds__(512, 1) void stem_fwd_bf16_kernel(StemBfArgs p, int
       }
     }
     // ---- epilogue: C/D layout of 16x16: column (cout) = lane & 15, row (output column) = 4 * (lane >> 4) + reg
-    int b = tile;
-    const int tw_i = b % tiles_w; b /= tiles_w;
-    const int th_i = b % tiles_h; b /= tiles_h;
-    const int td_i = b % tiles_d; b /= tiles_d;
-    const int n = b;
+    const BfTile bt = bf_tile_of(tile < ntiles ? tile : 0, tiles_d, tiles_h, tiles_w);
+    const int tw_i = bt.tw, th_i = bt.th, td_i = bt.td, n = bt.n;
     const int d0 = td_i * G::TD, h0 = th_i * G::TH, w0 = tw_i * G::TW;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -259,11 +283,8 @@ __global__ __launch_bounds__(512, 1) void stem_wgrad_bf16_kernel(StemBfWgArgs p,
   float2 st[NPL];
   uint4 sdy[2];
   auto fetch = [&](int tile) {
-    int b = tile;
-    const int tw_i = b % tiles_w; b /= tiles_w;
-    const int th_i = b % tiles_h; b /= tiles_h;
-    const int td_i = b % tiles_d; b /= tiles_d;
-    const int n = b;
+    const BfTile bt = bf_tile_of(tile < ntiles ? tile : 0, tiles_d, tiles_h, tiles_w);
+    const int tw_i = bt.tw, th_i = bt.th, td_i = bt.td, n = bt.n;
     const int d0 = td_i * G::TD, h0 = th_i * G::TH, w0 = tw_i * G::TW;
     const int id0 = d0 - 3, ih = 2 * h0 - 3 + s_hh, iw = 2 * w0 - 3 + 2 * s_pr - 1;
     const bool tile_ok = tile < ntiles;
@@ -315,12 +336,14 @@ __global__ __launch_bounds__(512, 1) void stem_wgrad_bf16_kernel(StemBfWgArgs p,
     *reinterpret_cast<uint4 *>(dyt + tid * (G::DYROW * 2) + 16) = sdy[1];
   };
 
-  fetch(blockIdx.x);
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  int t_begin, t_end;
+  bf_tile_run((int)blockIdx.x, (int)gridDim.x, ntiles, t_begin, t_end);
+  fetch(t_begin < t_end ? t_begin : ntiles);
+  for (int tile = t_begin; tile < t_end; ++tile) {
     __syncthreads();
     commit();
     __syncthreads();
-    fetch(tile + gridDim.x);                             // in flight during the MFMA phase
+    fetch(tile + 1 < t_end ? tile + 1 : ntiles);         // in flight during the MFMA phase
     for (int ks = 0; ks < G::KS; ++ks) {
       const int th = ks % G::TH, td = ks / G::TH;
       unsigned char *yb = dyt + ks * 32 * (G::DYROW * 2) + b_lane;
@@ -388,7 +411,8 @@ extern "C" int mr3d_stem_conv_forward_bf16(const float *x_ncdhw, const void *w16
   const int td = (d + G::TD - 1) / G::TD, th = (a.Ho + G::TH - 1) / G::TH, tw = (a.Wo + G::TW - 1) / G::TW;
   const long long ntiles = (long long)n * td * th * tw;
   if (ntiles > 0x7fffffffLL) return MR3D_ERR_UNSUPPORTED;
-  const int grid = ntiles < cus ? (int)ntiles : cus;         // one persistent 8-wave workgroup per CU (100 KB of LDS)
+  int grid = ntiles < cus ? (int)ntiles : cus;               // one persistent 8-wave workgroup per CU (100 KB of LDS)
+  if (grid >= 8) grid &= ~7;                                 // XCD-contiguous tile runs (bf_tile_run)
   stem_fwd_bf16_kernel<<<(unsigned)grid, G::NT, G::LDS_BYTES, mr3d_stream(stream_)>>>(a, td, th, tw, (int)ntiles);
   return mr3d_launch_status();
 }
@@ -418,7 +442,8 @@ extern "C" int mr3d_stem_conv_wgrad_bf16(const float *x_ncdhw, const void *dy_bf
   const int td = (d + G::TD - 1) / G::TD, th = (a.Ho + G::TH - 1) / G::TH, tw = (a.Wo + G::TW - 1) / G::TW;
   const long long ntiles = (long long)n * td * th * tw;
   if (ntiles > 0x7fffffffLL) return MR3D_ERR_UNSUPPORTED;
-  const int grid = ntiles < cus ? (int)ntiles : cus;         // one persistent workgroup per CU (87 KB of LDS)
+  int grid = ntiles < cus ? (int)ntiles : cus;               // one persistent workgroup per CU (87 KB of LDS)
+  if (grid >= 8) grid &= ~7;
   stem_wgrad_bf16_kernel<<<(unsigned)grid, 512, G::LDS_BYTES, mr3d_stream(stream_)>>>(a, td, th, tw, (int)ntiles);
   return mr3d_launch_status();
 }
