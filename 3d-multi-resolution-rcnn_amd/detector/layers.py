@@ -11,11 +11,12 @@ import torch.nn.functional as F
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
+import ctypes
 import os
 
 from .. import _hip
 
-_LINEAR_IMPL = os.environ.get('MR3D_LINEAR', 'blas')
+_LINEAR_IMPL = os.environ.get('MR3D_LINEAR', 'hip')
 
 
 def _ndhwc(x):
@@ -84,14 +85,87 @@ def conv3d(x, weight, bias=None, padding=0, relu=False):
     return _Conv3dFn.apply(x, weight, bias, int(padding), bool(relu))
 
 
+_LINEAR_WS = {}
+
+
+def _linear_workspace(device, rows, k, o):
+    """scratch for the split-K launches of csrc/linear.hip (fixed-order summation instead of atomics); one buffer per device,
+    grown on demand -- launches on one stream use it one after the other"""
+    fn = _hip.lib().mr3d_linear_workspace_bytes
+    fn.restype = ctypes.c_size_t
+    need = int(fn(int(rows), int(k), int(o)))
+    if need == 0:
+        return None, 0
+    ws = _LINEAR_WS.get(device)
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.empty(((need + 3) // 4,), dtype=torch.float32, device=device)
+        _LINEAR_WS[device] = ws
+    return ws, ws.numel() * 4
+
+
+class _LinearFn(Function):
+    """torch.nn.Linear (+ReLU) on the fp32 MFMA GEMM of csrc/linear.hip: forward, data gradient and weight gradient read x, dy
+    and weight in their torch layouts"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        if not x.is_cuda:
+            raise NotImplementedError('the HIP linear layer has no CPU fallback')
+        xc = x.detach().contiguous().float()
+        w = weight.detach().contiguous()
+        b = bias.detach().contiguous() if bias is not None else None
+        R, K = xc.shape
+        O = w.shape[0]
+        y = torch.empty((R, O), dtype=torch.float32, device=x.device)
+        if R > 0:
+            ws, wsb = _linear_workspace(x.device, R, K, O)
+            with torch.cuda.device(x.device):
+                _hip.check(_hip.lib().mr3d_linear_forward(_hip.ptr(xc), _hip.ptr(w), ctypes.c_void_p(_hip._opt(b)), _hip.ptr(y),
+                                                          R, K, O, int(relu), ctypes.c_void_p(_hip._opt(ws)), ctypes.c_longlong(wsb),
+                                                          _hip.stream_ptr(x.device)), 'mr3d_linear_forward')
+        ctx.save_for_backward(xc, w, y if relu else None)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        xc, w, y = ctx.saved_tensors
+        R, K = xc.shape
+        O = w.shape[0]
+        g = g.contiguous().float()
+        if y is not None:
+            g = g * (y > 0)
+        gx = gw = gb = None
+        L = _hip.lib()
+        ws, wsb = _linear_workspace(g.device, R, K, O) if R > 0 else (None, 0)
+        wsp, wsl = ctypes.c_void_p(_hip._opt(ws)), ctypes.c_longlong(wsb)
+        with torch.cuda.device(g.device):
+            st = _hip.stream_ptr(g.device)
+            if ctx.needs_input_grad[0]:
+                gx = torch.zeros((R, K), dtype=torch.float32, device=g.device) if R == 0 else torch.empty((R, K), dtype=torch.float32, device=g.device)
+                if R > 0:
+                    _hip.check(L.mr3d_linear_dgrad(_hip.ptr(g), _hip.ptr(w), _hip.ptr(gx), R, K, O, wsp, wsl, st), 'mr3d_linear_dgrad')
+            if ctx.needs_input_grad[1]:
+                gw = torch.zeros((O, K), dtype=torch.float32, device=g.device)
+                if R > 0:
+                    _hip.check(L.mr3d_linear_wgrad(_hip.ptr(g), _hip.ptr(xc), _hip.ptr(gw), R, K, O, wsp, wsl, st), 'mr3d_linear_wgrad')
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g.sum(0)
+        return gx, gw, gb, None
+
+
 def linear(x, weight, bias=None, relu=False, impl=None):
-    """y = x @ weight.T + bias for x [R, K].  A fully connected layer is a PLAIN GEMM, so by default it goes to the
-    library (hipBLASLt through torch.addmm: 81-100 TFLOP/s fp32 on the 512 x 9408 x 1024 bbox-head shapes, against
-    27-58 for the conv kernels, which are built for long position axes, not for K = 9408); impl='hip' (or
-    MR3D_LINEAR=hip) runs it as a pointwise conv over the rows on the MFMA conv kernels instead (K % 16 == 0)."""
-    if (impl or _LINEAR_IMPL) != 'hip':
+    """y = x @ weight.T + bias for x [R, K] -- torch.nn.Linear of the reference's bbox heads
+    (convfc_bbox_head_3d.py:104-140).  Default: the hand-written fp32 MFMA GEMM of csrc/linear.hip (forward / dgrad / wgrad,
+    split-K where the output has few tiles).  impl='blas' (or MR3D_LINEAR=blas): torch.addmm (hipBLASLt), kept for A/B
+    timing; impl='conv' (MR3D_LINEAR=conv): the pointwise-conv route of the first round."""
+    mode = impl or _LINEAR_IMPL
+    if mode == 'blas':
         y = torch.addmm(bias, x, weight.t()) if bias is not None else x @ weight.t()
         return torch.relu(y) if relu else y
+    if mode != 'conv':
+        return _LinearFn.apply(x, weight, bias, bool(relu))
     R, K = x.shape
     rp = _pad_to(max(R, 1), 64)
     xp = x if rp == R else F.pad(x, (0, 0, 0, rp - R))

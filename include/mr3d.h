@@ -391,6 +391,25 @@ int mr3d_mask_paste3d(const float *mask_prob, int mask_d, int mask_h, int mask_w
                       int num_dets, float threshold, int depth, int height, int width, uint8_t *out_masks, mr3d_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------
+ * Fully connected layers of the bbox heads (mmdet/models/bbox_heads/convfc_bbox_head_3d.py:104-140: shared_fcs, fc_cls,
+ * fc_reg -- torch.nn.Linear in the reference): fp32 MFMA GEMMs, row-major operands exactly as torch.nn.Linear holds them,
+ * no transposed copies (csrc/linear.hip).
+ *   forward: y [rows][out] = x [rows][in] * weight[out][in]^T + bias (bias may be NULL), optional ReLU
+ *   dgrad:   dx [rows][in] = dy [rows][out] * weight[out][in]
+ *   wgrad:   dw [out][in]  = dy^T x          (the bias gradient is a column sum of dy: mr3d callers use torch.sum)
+ * Outputs are WRITTEN.  Launches whose output has few tiles split the K loop: with `workspace` (>= mr3d_linear_workspace_bytes
+ * of the layer; device memory, contents irrelevant) the partial products are summed in a fixed order -- bit-reproducible;
+ * with workspace == NULL they are added with fp32 atomics (last-bit run-to-run differences).
+ * ---------------------------------------------------------------------------------------------- */
+size_t mr3d_linear_workspace_bytes(int rows, int in_features, int out_features);
+int mr3d_linear_forward(const float *x, const float *weight, const float *bias, float *y, int rows, int in_features,
+                        int out_features, int relu, float *workspace, long long workspace_bytes, mr3d_stream_t s);
+int mr3d_linear_dgrad(const float *dy, const float *weight, float *dx, int rows, int in_features, int out_features,
+                      float *workspace, long long workspace_bytes, mr3d_stream_t s);
+int mr3d_linear_wgrad(const float *dy, const float *x, float *dw, int rows, int in_features, int out_features,
+                      float *workspace, long long workspace_bytes, mr3d_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
  * DeformConv3d (v1) / modulated (v2): the sampling halves of the operator; the GEMM halves are
  * mr3d_conv3d_forward / mr3d_conv3d_wgrad over the column matrix (see csrc/deform_conv3d.hip).
  * Extends the reference's 2D operator (mmdet/ops/dcn/src/deform_conv_cuda_kernel.cu:83-435,569-766 and

@@ -43,7 +43,7 @@ def test_conv3d_linear_deconv_layers_fwd_bwd():
     cl = torch.randn(refl.shape, generator=g)
     refl.backward(cl)
     xld, wld, bld = (t.detach().to(dev).requires_grad_(True) for t in (xl, wl, bl))
-    outl = layers.linear(xld, wld, bld, impl='hip')            # the conv-kernel form; the default is the library GEMM
+    outl = layers.linear(xld, wld, bld, impl='conv')           # the pointwise-conv form of the first round
     assert _rel(outl.detach().cpu(), refl.detach()) <= RTOL
     outl.backward(cl.to(dev))
     assert _rel(xld.grad.cpu(), xl.grad) <= RTOL and _rel(wld.grad.cpu(), wl.grad) <= RTOL and _rel(bld.grad.cpu(), bl.grad) <= RTOL
@@ -60,6 +60,40 @@ def test_conv3d_linear_deconv_layers_fwd_bwd():
         assert outt.shape == reft.shape and _rel(outt.detach().cpu(), reft.detach()) <= RTOL
         outt.backward(ct.to(dev))
         assert _rel(xtd.grad.cpu(), xt.grad) <= RTOL and _rel(wtd.grad.cpu(), wt.grad) <= RTOL and _rel(btd.grad.cpu(), bt.grad) <= RTOL
+
+
+@pytest.mark.parametrize('rows,k,o,relu,bias', [
+    (512, 9408, 1024, True, True),       # shared_fcs[0] of the bbox head: split-K forward, unsplit dgrad / wgrad
+    (469, 1024, 1024, True, True),       # rows not a multiple of anything
+    (512, 1024, 2, False, True),         # fc_cls
+    (512, 1024, 12, False, True),        # fc_reg
+    (37, 100, 6, False, False),          # K, N, ld not multiples of 4 / 16: scalar edge loads
+    (1, 16, 1, True, True),
+])
+def test_linear_gemm_kernels(rows, k, o, relu, bias):
+    """csrc/linear.hip (the default of layers.linear): forward / dgrad / wgrad against float64 torch"""
+    from mr3d_amd.detector import layers
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(rows + k + o)
+    x = torch.randn(rows, k, generator=g, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(o, k, generator=g, dtype=torch.float64) / k ** 0.5).requires_grad_(True)
+    b = torch.randn(o, generator=g, dtype=torch.float64).requires_grad_(True) if bias else None
+    ref = F.linear(x, w, b)
+    if relu:
+        ref = F.relu(ref)
+    cot = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    ref.backward(cot)
+    xd, wd = (t.detach().float().to(dev).requires_grad_(True) for t in (x, w))
+    bd = b.detach().float().to(dev).requires_grad_(True) if bias else None
+    out = layers.linear(xd, wd, bd, relu=relu)
+    assert out.shape == ref.shape and _rel(out.detach().cpu().double(), ref.detach()) <= 2e-5
+    out.backward(cot.float().to(dev))
+    assert _rel(xd.grad.cpu().double(), x.grad) <= 2e-5 and _rel(wd.grad.cpu().double(), w.grad) <= 2e-5
+    if bias:
+        assert _rel(bd.grad.cpu().double(), b.grad) <= 2e-5
+    # no rows (an image without sampled rois): empty output, zero weight gradient
+    e = layers.linear(torch.zeros(0, k, device=dev, requires_grad=True), wd, bd)
+    assert e.shape == (0, o)
 
 
 class _RefRPN(nn.Module):          # rpn_head_3d.py:18-35
