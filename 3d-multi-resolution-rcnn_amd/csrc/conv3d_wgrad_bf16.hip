@@ -77,7 +77,15 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wgrad_bf16_kernel(WgArgs p
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // ---- tile staging, software-pipelined: the NEXT tile's x halo block and dy tile are fetched into registers before the
+  // MFMA loop of the current tile and written to LDS after it.  (Fetched and stored in one loop, the global round trip of
+  // every tile sat between two barriers with the matrix pipe idle: 16 k-steps x 7 MFMAs are 1.5 us, the fetch 2-3 us.)
+  // register budget (two workgroups per CU: 256): 1x1x1 prefetches both operands; 3x3x3 stride 1 the x halo block only
+  // (its dy tile is fetched at the start of the commit and lands while the x block is being written); stride 2 neither.
+  constexpr bool PFX = C::PW1 || C::S == 1, PFY = C::PW1;
+  constexpr int NXR = (C::HP * 4 + kThreads - 1) / kThreads, NYR = (C::M * 4 + kThreads - 1) / kThreads;
+  uint4 xr[NXR], yr[NYR];
+  auto fetch_part = [&](int tile, bool do_x, bool do_y) {
     int b = tile;
     const int tw_i = b % tiles_w; b /= tiles_w;
     const int th_i = b % tiles_h; b /= tiles_h;
@@ -85,7 +93,56 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wgrad_bf16_kernel(WgArgs p
     const int n = b;
     const int od0 = td_i * C::TD, oh0 = th_i * C::TH, ow0 = tw_i * C::TW;
     const int id0 = od0 * C::S - p.pd, ih0 = oh0 * C::S - p.ph, iw0 = ow0 * C::S - p.pw;
-    __syncthreads();                                    // the previous tile's fragments have been read
+    const bool live = tile < ntiles;
+    if (do_x)
+#pragma unroll
+    for (int j = 0; j < NXR; ++j) {
+      const int it = tid + j * kThreads;
+      const int pos = it >> 2, qq = it & 3;
+      const int hw = pos % C::HW, hh_ = (pos / C::HW) % C::HH, hd = pos / (C::HW * C::HH);
+      const int id = id0 + hd * C::GS, ih = ih0 + hh_ * C::GS, iw = iw0 + hw * C::GS;
+      const int ci = ci0 + qq * 8;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (live && it < C::HP * 4 && ci < p.Cin && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
+        v = *reinterpret_cast<const uint4 *>(p.x + ((((size_t)n * p.D + id) * p.H + ih) * p.W + iw) * p.Cin + ci);
+      xr[j] = v;
+    }
+    if (do_y)
+#pragma unroll
+    for (int j = 0; j < NYR; ++j) {
+      const int it = tid + j * kThreads;
+      const int m = it >> 2, qq = it & 3;
+      const int tw = m % C::TW, th = (m / C::TW) % C::TH, td = m / (C::TW * C::TH);
+      const int od = od0 + td, oh = oh0 + th, ow = ow0 + tw;
+      const int co = co0 + qq * 8;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (live && it < C::M * 4 && co < p.Cout && od < p.Do && oh < p.Ho && ow < p.Wo)
+        v = *reinterpret_cast<const uint4 *>(p.dy + ((((size_t)n * p.Do + od) * p.Ho + oh) * p.Wo + ow) * p.Cout + co);
+      yr[j] = v;
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < NXR; ++j) {
+      const int it = tid + j * kThreads;
+      if (it < C::HP * 4) *reinterpret_cast<uint4 *>(xs + (it >> 2) * ROWB + (it & 3) * 16) = xr[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NYR; ++j) {
+      const int it = tid + j * kThreads;
+      if (it < C::M * 4) *reinterpret_cast<uint4 *>(ys + (it >> 2) * ROWB + (it & 3) * 16) = yr[j];
+    }
+  };
+
+  // stride 2: the first round's plain staging (global -> LDS slot by slot, nothing held across the MFMA loop)
+  auto stage_direct = [&](int tile) {
+    int b = tile;
+    const int tw_i = b % tiles_w; b /= tiles_w;
+    const int th_i = b % tiles_h; b /= tiles_h;
+    const int td_i = b % tiles_d; b /= tiles_d;
+    const int n = b;
+    const int od0 = td_i * C::TD, oh0 = th_i * C::TH, ow0 = tw_i * C::TW;
+    const int id0 = od0 * C::S - p.pd, ih0 = oh0 * C::S - p.ph, iw0 = ow0 * C::S - p.pw;
     for (int it = tid; it < C::HP * 4; it += kThreads) {
       const int pos = it >> 2, qq = it & 3;
       const int hw = pos % C::HW, hh_ = (pos / C::HW) % C::HH, hd = pos / (C::HW * C::HH);
@@ -106,7 +163,20 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wgrad_bf16_kernel(WgArgs p
         v = *reinterpret_cast<const uint4 *>(p.dy + ((((size_t)n * p.Do + od) * p.Ho + oh) * p.Wo + ow) * p.Cout + co);
       *reinterpret_cast<uint4 *>(ys + m * ROWB + qq * 16) = v;
     }
-    __syncthreads();
+  };
+
+  if constexpr (PFX) fetch_part(blockIdx.x, PFX, PFY);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();                                    // the previous tile's fragments have been read
+    if constexpr (PFX) {
+      fetch_part(tile, false, !PFY);                    // the dy tile where it is not prefetched
+      commit();
+      __syncthreads();
+      fetch_part(tile + gridDim.x, PFX, PFY);           // in flight during the MFMA loop
+    } else {
+      stage_direct(tile);
+      __syncthreads();
+    }
 
     if constexpr (C::PW1) {
       for (int ks = wave; ks < C::KS; ks += 4) {        // waves split the k-steps
