@@ -44,6 +44,9 @@ struct WgCfg {
   static constexpr int XBYTES = HP * ROWB, YBYTES = M * ROWB;
   static constexpr int RED_BYTES = PW1 ? 4 * 2 * 32 * 33 * 4 : 0;   // 1x1x1: the four waves' (dw, sum dy) tiles meet here
   static constexpr int LDS_BYTES = (XBYTES + YBYTES > RED_BYTES) ? XBYTES + YBYTES : RED_BYTES;
+  // 3x3x3 stride 1: ONE workgroup per CU with the whole 512-register budget -- both operands of the next tile prefetched and the
+  // MFMA fragments double-buffered across k-steps (nothing else on the CU would hide their latencies)
+  static constexpr int MINWG = (!PW1 && S_ == 1) ? 1 : 2;
   static_assert(LDS_BYTES <= 160 * 1024, "tile exceeds LDS");
 };
 
@@ -55,7 +58,7 @@ __device__ __forceinline__ bf16x8 tr_frag(unsigned char *lds, int off0, int off1
 }
 
 template <class C>
-__global__ __launch_bounds__(kThreads, 2) void conv3d_wgrad_bf16_kernel(WgArgs p, int tiles_d, int tiles_h, int tiles_w, int ntiles) {
+__global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_wgrad_bf16_kernel(WgArgs p, int tiles_d, int tiles_h, int tiles_w, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char *xs = lds, *ys = lds + C::XBYTES;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -80,11 +83,30 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wgrad_bf16_kernel(WgArgs p
   // ---- tile staging, software-pipelined: the NEXT tile's x halo block and dy tile are fetched into registers before the
   // MFMA loop of the current tile and written to LDS after it.  (Fetched and stored in one loop, the global round trip of
   // every tile sat between two barriers with the matrix pipe idle: 16 k-steps x 7 MFMAs are 1.5 us, the fetch 2-3 us.)
-  // register budget (two workgroups per CU: 256): 1x1x1 prefetches both operands; 3x3x3 stride 1 the x halo block only
-  // (its dy tile is fetched at the start of the commit and lands while the x block is being written); stride 2 neither.
-  constexpr bool PFX = C::PW1 || C::S == 1, PFY = C::PW1;
+  // register budget: 1x1x1 (two workgroups per CU) and 3x3x3 stride 1 (one per CU) prefetch both operands; stride 2 neither.
+  constexpr bool PFX = C::PW1 || C::S == 1, PFY = C::PW1 || C::MINWG == 1;
   constexpr int NXR = (C::HP * 4 + kThreads - 1) / kThreads, NYR = (C::M * 4 + kThreads - 1) / kThreads;
   uint4 xr[NXR], yr[NYR];
+  // per-thread staging slots, tabulated once: element offset from the tile's corner and packed halo / tile coordinates
+  int xoff[NXR], yoff[NYR];
+  unsigned xcrd[NXR], ycrd[NYR];
+  constexpr unsigned kNoSlot = 0xffffffffu;
+#pragma unroll
+  for (int j = 0; j < NXR; ++j) {
+    const int it = tid + j * kThreads;
+    const int pos = it >> 2, qq = it & 3;
+    const int hw = (pos % C::HW) * C::GS, hh_ = ((pos / C::HW) % C::HH) * C::GS, hd = (pos / (C::HW * C::HH)) * C::GS;
+    xoff[j] = ((hd * p.H + hh_) * p.W + hw) * p.Cin + qq * 8;
+    xcrd[j] = (it < C::HP * 4 && ci0 + qq * 8 < p.Cin) ? (unsigned)(hd | (hh_ << 8) | (hw << 16)) : kNoSlot;
+  }
+#pragma unroll
+  for (int j = 0; j < NYR; ++j) {
+    const int it = tid + j * kThreads;
+    const int m = it >> 2, qq = it & 3;
+    const int tw = m % C::TW, th = (m / C::TW) % C::TH, td = m / (C::TW * C::TH);
+    yoff[j] = ((td * p.Ho + th) * p.Wo + tw) * p.Cout + qq * 8;
+    ycrd[j] = (it < C::M * 4 && co0 + qq * 8 < p.Cout) ? (unsigned)(td | (th << 8) | (tw << 16)) : kNoSlot;
+  }
   auto fetch_part = [&](int tile, bool do_x, bool do_y) {
     int b = tile;
     const int tw_i = b % tiles_w; b /= tiles_w;
@@ -94,32 +116,25 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wgrad_bf16_kernel(WgArgs p
     const int od0 = td_i * C::TD, oh0 = th_i * C::TH, ow0 = tw_i * C::TW;
     const int id0 = od0 * C::S - p.pd, ih0 = oh0 * C::S - p.ph, iw0 = ow0 * C::S - p.pw;
     const bool live = tile < ntiles;
+    // corners of the halo block / dy tile (may lie outside the tensor: only in-range slots are dereferenced)
+    const bf16_t *xb = p.x + ((((long long)n * p.D + id0) * p.H + ih0) * p.W + iw0) * (long long)p.Cin + ci0;
+    const bf16_t *yb = p.dy + ((((long long)n * p.Do + od0) * p.Ho + oh0) * p.Wo + ow0) * (long long)p.Cout + co0;
     if (do_x)
 #pragma unroll
-    for (int j = 0; j < NXR; ++j) {
-      const int it = tid + j * kThreads;
-      const int pos = it >> 2, qq = it & 3;
-      const int hw = pos % C::HW, hh_ = (pos / C::HW) % C::HH, hd = pos / (C::HW * C::HH);
-      const int id = id0 + hd * C::GS, ih = ih0 + hh_ * C::GS, iw = iw0 + hw * C::GS;
-      const int ci = ci0 + qq * 8;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (live && it < C::HP * 4 && ci < p.Cin && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
-        v = *reinterpret_cast<const uint4 *>(p.x + ((((size_t)n * p.D + id) * p.H + ih) * p.W + iw) * p.Cin + ci);
-      xr[j] = v;
-    }
+      for (int j = 0; j < NXR; ++j) {
+        const unsigned c = xcrd[j];
+        const bool ok = live && c != kNoSlot && (unsigned)(id0 + (int)(c & 255u)) < (unsigned)p.D &&
+                        (unsigned)(ih0 + (int)((c >> 8) & 255u)) < (unsigned)p.H && (unsigned)(iw0 + (int)(c >> 16)) < (unsigned)p.W;
+        xr[j] = ok ? *reinterpret_cast<const uint4 *>(xb + xoff[j]) : make_uint4(0u, 0u, 0u, 0u);
+      }
     if (do_y)
 #pragma unroll
-    for (int j = 0; j < NYR; ++j) {
-      const int it = tid + j * kThreads;
-      const int m = it >> 2, qq = it & 3;
-      const int tw = m % C::TW, th = (m / C::TW) % C::TH, td = m / (C::TW * C::TH);
-      const int od = od0 + td, oh = oh0 + th, ow = ow0 + tw;
-      const int co = co0 + qq * 8;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (live && it < C::M * 4 && co < p.Cout && od < p.Do && oh < p.Ho && ow < p.Wo)
-        v = *reinterpret_cast<const uint4 *>(p.dy + ((((size_t)n * p.Do + od) * p.Ho + oh) * p.Wo + ow) * p.Cout + co);
-      yr[j] = v;
-    }
+      for (int j = 0; j < NYR; ++j) {
+        const unsigned c = ycrd[j];
+        const bool ok = live && c != kNoSlot && od0 + (int)(c & 255u) < p.Do && oh0 + (int)((c >> 8) & 255u) < p.Ho &&
+                        ow0 + (int)(c >> 16) < p.Wo;
+        yr[j] = ok ? *reinterpret_cast<const uint4 *>(yb + yoff[j]) : make_uint4(0u, 0u, 0u, 0u);
+      }
   };
   auto commit = [&]() {
 #pragma unroll
@@ -186,22 +201,45 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wgrad_bf16_kernel(WgArgs p
         if (want_bias) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bf, acc[1], 0, 0, 0);
       }
     } else {
-      for (int ks = 0; ks < C::KS; ++ks) {
+      // fragments of k-step ks + 1 are requested before the MFMAs of k-step ks issue (read-then-multiply per tap left every
+      // MFMA waiting for a full LDS round trip: 14 us per 256-position tile for 1.5 us of matrix work)
+      // slot ti of wave w is tap w + 4 ti; only the LAST slot can fall off the tap list (27 taps: wave 3's seventh slot),
+      // and it is handled without a branch: the fragment of tap 26 is read anyway and replaced by ones
+      constexpr int LAST = C::NTW - 1;
+      const bool spare = wave + 4 * LAST >= C::TAPS;
+      int tapoff[C::NTW];
+#pragma unroll
+      for (int ti = 0; ti < C::NTW; ++ti) {
+        int tap = wave + 4 * ti;
+        if (tap >= C::TAPS) tap = C::TAPS - 1;
+        const int kw = tap % C::K, kh = (tap / C::K) % C::K, kd = tap / (C::K * C::K);
+        tapoff[ti] = ((kd * C::HH + kh) * C::HW + kw) * ROWB;
+      }
+      auto load_frags = [&](int ks, bf16x8 (&af)[C::NTW], bf16x8 &bf) {
         const int th = ks % C::TH, td = ks / C::TH;
-        const bf16x8 bf = tr_frag(ys, b_lane + ks * 16 * ROWB, b_lane + (ks * 16 + 4) * ROWB);
+        bf = tr_frag(ys, b_lane + ks * 16 * ROWB, b_lane + (ks * 16 + 4) * ROWB);
         const int rowbase = a_lane + (((td * C::LS) * C::HH + th * C::LS) * C::HW) * ROWB;
 #pragma unroll
         for (int ti = 0; ti < C::NTW; ++ti) {
-          const int tap = wave + 4 * ti;                 // wave-uniform
-          if (tap < C::TAPS) {
-            const int kw = tap % C::K, kh = (tap / C::K) % C::K, kd = tap / (C::K * C::K);
-            const int off = rowbase + ((kd * C::HH + kh) * C::HW + kw) * ROWB;
-            const bf16x8 af = tr_frag(xs, off, off + 4 * C::LS * ROWB);
-            acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[ti], 0, 0, 0);
-          } else if (tap == C::TAPS && want_bias) {
-            acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bf, acc[ti], 0, 0, 0);
-          }
+          const int off = rowbase + tapoff[ti];
+          af[ti] = tr_frag(xs, off, off + 4 * C::LS * ROWB);
         }
+        if (spare) af[LAST] = ones;                      // sum_p dy on the matrix pipe (wave-uniform select)
+      };
+      auto mma = [&](const bf16x8 (&af)[C::NTW], const bf16x8 &bf) {
+#pragma unroll
+        for (int ti = 0; ti < C::NTW; ++ti) acc[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ti], bf, acc[ti], 0, 0, 0);
+      };
+      static_assert(C::KS % 2 == 0, "k-steps are processed in pairs");
+      bf16x8 afA[C::NTW], afB[C::NTW], bfA, bfB;
+      load_frags(0, afA, bfA);
+      for (int ks = 0; ks < C::KS; ks += 2) {
+        load_frags(ks + 1, afB, bfB);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(afA, bfA);
+        if (ks + 2 < C::KS) load_frags(ks + 2, afA, bfA);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(afB, bfB);
       }
     }
   }
@@ -266,7 +304,7 @@ int launch_wg(const WgArgs &a, hipStream_t stream) {
   if (ntiles > 0x7fffffffLL) return MR3D_ERR_UNSUPPORTED;
   const int by = (a.Cin + 31) / 32, bz = (a.Cout + 31) / 32;
   // persistent workgroups: about two per CU across the (ci, co) blocks, each walking many position tiles
-  long long gx = 512 / ((long long)by * bz);
+  long long gx = (C::MINWG == 1 ? 256 : 512) / ((long long)by * bz);
   if (gx < 1) gx = 1;
   if (gx > ntiles) gx = ntiles;
   dim3 grid((unsigned)gx, (unsigned)by, (unsigned)bz);
