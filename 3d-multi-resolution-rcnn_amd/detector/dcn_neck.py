@@ -19,9 +19,12 @@ from . import layers
 
 class DCNNeck3D(nn.Module):
 
-    def __init__(self, channels=64, num_levels=4, deformable_groups=1):
+    def __init__(self, channels=64, num_levels=4, deformable_groups=1, offset_bf16=False):
+        """offset_bf16: the offset-predicting convs run with bf16 activation storage (the detector's bf16 mode: they are a third
+        of the neck's time in fp32); the sampling itself stays fp32."""
         super().__init__()
         self.channels, self.num_levels, self.dg = channels, num_levels, deformable_groups
+        self.offset_bf16 = bool(offset_bf16)
         self.conv_offset = nn.ModuleList([nn.Conv3d(channels, deformable_groups * 3 * 27, 3, padding=1) for _ in range(num_levels)])
         self.conv = nn.ModuleList([DeformConv3d(channels, channels, 3, padding=1, deformable_groups=deformable_groups)
                                    for _ in range(num_levels)])
@@ -36,7 +39,10 @@ class DCNNeck3D(nn.Module):
         """laterals: the 4 top-down lateral sums [N,64,d,h,w] (channels_last_3d, fp32) -> (P2..P6)"""
         outs = []
         for lat, off, conv in zip(laterals, self.conv_offset, self.conv):
-            offset = layers.conv3d(lat, off.weight, off.bias, padding=1)
+            if self.offset_bf16:
+                offset = layers.conv3d_bf16(lat, off.weight, off.bias, padding=1)
+            else:
+                offset = layers.conv3d(lat, off.weight, off.bias, padding=1)
             outs.append(conv(lat, offset))
         outs.append(outs[-1][:, :, ::2, ::2, ::2])                          # F.max_pool3d(x, 1, stride=2) == subsample
         return tuple(outs)

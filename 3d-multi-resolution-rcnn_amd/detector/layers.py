@@ -80,6 +80,58 @@ class _Conv3dFn(Function):
         return gx, gw, gb, None, None
 
 
+class _Conv3dBf16Fn(Function):
+    """stride-1 cubic Conv3d (+bias) with bf16 activation storage (BASELINE configs[4]): x and the result are rounded to bf16,
+    products accumulate in fp32 on the bf16 MFMA kernels (csrc/conv3d_bf16.hip, conv3d_wgrad_bf16.hip); parameters and their
+    gradients stay fp32.  Output channels are padded to a multiple of 32 inside (the kernels' N tile)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, padding):
+        if not x.is_cuda:
+            raise NotImplementedError('the HIP conv engine has no CPU fallback')
+        co, ci, k = weight.shape[0], weight.shape[1], weight.shape[2]
+        assert weight.shape[2] == weight.shape[3] == weight.shape[4] and ci % 16 == 0, 'cubic kernel, Cin % 16 == 0'
+        cop = _pad_to(co, 32)
+        w = weight.detach()
+        if cop != co:
+            w = F.pad(w, (0, 0, 0, 0, 0, 0, 0, 0, 0, cop - co))
+        shift = None
+        if bias is not None:
+            shift = F.pad(bias.detach().float(), (0, cop - co)).contiguous()
+        x16 = _ndhwc(x.detach()).to(torch.bfloat16)
+        y16 = _hip.conv3d_forward_bf16(x16, _hip.pack_conv_weight_bf16(w), cop, (k,) * 3, (1, 1, 1), (padding,) * 3, shift=shift)
+        ctx.save_for_backward(x16, w)
+        ctx.meta = (co, cop, k, padding, bias is not None)
+        return y16.permute(0, 4, 1, 2, 3)[:, :co].float()
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x16, w = ctx.saved_tensors
+        co, cop, k, padding, has_bias = ctx.meta
+        g = gy.permute(0, 2, 3, 4, 1)
+        g16 = torch.zeros(g.shape[:4] + (cop,), dtype=torch.bfloat16, device=g.device)
+        g16[..., :co] = g
+        taps, ci = k ** 3, x16.size(4)
+        gw = gb = gx = None
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            dwp = torch.zeros((taps, ci, cop), dtype=torch.float32, device=g.device)
+            db = torch.zeros((cop,), dtype=torch.float32, device=g.device)
+            _hip.conv3d_wgrad_bf16(x16, g16, dwp, (k,) * 3, (1, 1, 1), (padding,) * 3, dbias=db)
+            gw = dwp.permute(2, 1, 0).reshape(cop, ci, k, k, k)[:co].contiguous()
+            gb = db[:co].contiguous() if has_bias else None
+        if ctx.needs_input_grad[0]:
+            wb16 = _hip.pack_conv_weight_bf16(w.flip(2, 3, 4).transpose(0, 1))          # [ci][cop][k,k,k]: dgrad operand
+            gx16 = _hip.conv3d_forward_bf16(g16, wb16, _pad_to(ci, 32), (k,) * 3, (1, 1, 1), (k - 1 - padding,) * 3)
+            gx = gx16.permute(0, 4, 1, 2, 3)[:, :ci].float()
+        return gx, gw, gb, None
+
+
+def conv3d_bf16(x, weight, bias=None, padding=0):
+    """conv3d with bf16 activation storage (configs[4]); fp32 in / out at the Python boundary"""
+    return _Conv3dBf16Fn.apply(x, weight, bias, int(padding))
+
+
 def conv3d(x, weight, bias=None, padding=0, relu=False):
     """stride-1 cubic Conv3d (+bias, +ReLU); x [N,Cin,D,H,W] -> [N,Cout,D',H',W'] (channels_last_3d view)"""
     return _Conv3dFn.apply(x, weight, bias, int(padding), bool(relu))

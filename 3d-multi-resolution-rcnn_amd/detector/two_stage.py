@@ -109,7 +109,7 @@ class TwoStageDetector3D(nn.Module):
             self.extract.pyramid_dtype = torch.bfloat16          # RPN head and RoIAlign3D read the bf16 pyramid directly
         if neck_dcn:
             from .dcn_neck import DCNNeck3D
-            self.dcn_neck = DCNNeck3D().to(self.device)
+            self.dcn_neck = DCNNeck3D(offset_bf16=(dtype == torch.bfloat16)).to(self.device)
         self.rpn_head = RPNHead3D(anchor_scales=anchor_scales, anchor_depth_scales=anchor_depth_scales).to(self.device)
         strides, dstrides = [4, 8, 16, 32], [2, 4, 8, 16]
         self.bbox_roi_extractor = SingleRoIExtractor(dict(type='RoIAlign3D', out_size=7, out_size_depth=3, sample_num=2), 64,

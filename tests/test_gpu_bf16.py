@@ -330,3 +330,29 @@ def test_detector_bf16_pyramid_trains(dev):
         for n, p in list(det.rpn_head.named_parameters()) + list(det.bbox_head.named_parameters()):
             assert p.grad is not None and torch.isfinite(p.grad).all(), n
     assert abs(out['bf16'][0] - out['f32'][0]) <= 5e-2 * abs(out['f32'][0]), out
+
+
+def test_layers_conv3d_bf16_autograd_offset_conv_shape():
+    """layers.conv3d_bf16 (the DeformConv3d neck's offset convs in bf16 mode): 64 -> 81 channels, 3x3x3, against fp32 torch
+    evaluated on the bf16-rounded input; output is rounded to bf16 (2^-8 relative), gradients accumulate in fp32"""
+    import torch.nn.functional as F
+    from mr3d_amd.detector import layers
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 64, 6, 10, 9, generator=g).bfloat16().float().requires_grad_(True)
+    w = (torch.randn(81, 64, 3, 3, 3, generator=g) * 0.03).bfloat16().float().requires_grad_(True)
+    b = torch.randn(81, generator=g).requires_grad_(True)
+    ref = F.conv3d(x, w, b, padding=1)
+    cot = torch.randn(ref.shape, generator=g).bfloat16().float()
+    ref.backward(cot)
+    xd, wd, bd = (t.detach().to(dev).requires_grad_(True) for t in (x, w, b))
+    out = layers.conv3d_bf16(xd, wd, bd, padding=1)
+    assert out.shape == ref.shape and out.dtype == torch.float32
+
+    def rel(a, r):
+        return float((a.cpu() - r).abs().max() / r.abs().max())
+    assert rel(out.detach(), ref.detach()) <= 2.0 ** -7
+    out.backward(cot.to(dev))
+    assert rel(xd.grad, x.grad) <= 2.0 ** -6          # dx is stored in bf16
+    assert rel(wd.grad, w.grad) <= 2e-3 and rel(bd.grad, b.grad) <= 1e-4
+
