@@ -169,7 +169,12 @@ class TwoStageDetector3D(nn.Module):
         """backbone + neck (two_stage_3d.py:108-112); with neck_dcn the engine hands out the lateral sums and the deformable
         output stage runs here"""
         x = self.extract(imgs, slot) if train else self.extract.forward_features(imgs, slot)
-        return self.dcn_neck(x) if self.neck_dcn else x
+        if not self.neck_dcn:
+            return x
+        outs = self.dcn_neck(x)
+        if self.extract.bf16:            # bf16 mode: the heads read a bf16 pyramid, as without the deformable neck
+            outs = tuple(o.to(torch.bfloat16) for o in outs)
+        return outs
 
     def forward_train(self, imgs, img_meta, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_masks=None, proposals=None,
                       draws=None):
