@@ -344,20 +344,32 @@ __global__ __launch_bounds__(512, 1) void stem_wgrad_bf16_kernel(StemBfWgArgs p,
     commit();
     __syncthreads();
     fetch(tile + 1 < t_end ? tile + 1 : ntiles);         // in flight during the MFMA phase
-    for (int ks = 0; ks < G::KS; ++ks) {
+    // the ten row-tile fragments and the dy fragment of a k-step are requested together, before its first MFMA
+    // (read-then-multiply per tile left every 16-cycle MFMA waiting for an LDS round trip; double-buffering them across
+    // k-steps as well needs 80 more registers and spills); tiles past the end of a wave's list multiply a valid but unused
+    // fragment instead of branching
+    auto load_step = [&](int ks, bf16x8 (&a)[G::MTW], bf16x8 &bf) {
       const int th = ks % G::TH, td = ks / G::TH;
       unsigned char *yb = dyt + ks * 32 * (G::DYROW * 2) + b_lane;
       const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(yb));
       const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(yb + 4 * (G::DYROW * 2)));
-      const bf16x8 bf = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      bf = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
       const int rowoff = ((td * G::HH + 2 * th) * G::ROW) * 2;
 #pragma unroll
       for (int i = 0; i < G::MTW; ++i) {
-        if (wave + 8 * i > G::MT) continue;               // wave-uniform
-        bf16x8 a = lds_frag_unaligned(lds + aoff[i] + rowoff);
-        if (!live[i]) a = ones[i] ? one8 : zero8;
-        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf, acc[i], 0, 0, 0);
+        a[i] = lds_frag_unaligned(lds + aoff[i] + rowoff);
+        if (!live[i]) a[i] = ones[i] ? one8 : zero8;
       }
+    };
+    auto mma_step = [&](const bf16x8 (&a)[G::MTW], const bf16x8 &bf) {
+#pragma unroll
+      for (int i = 0; i < G::MTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bf, acc[i], 0, 0, 0);
+    };
+    bf16x8 aA[G::MTW], bA;
+    for (int ks = 0; ks < G::KS; ++ks) {
+      load_step(ks, aA, bA);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_step(aA, bA);
     }
   }
   // ---- write-out: column (cout) = lane & 15, GEMM row = 16*m + 4*(lane>>4) + reg
