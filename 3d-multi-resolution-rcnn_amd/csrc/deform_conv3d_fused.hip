@@ -26,6 +26,7 @@
 #include "mr3d_common.h"
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 
 namespace {
 
@@ -746,10 +747,26 @@ constexpr size_t kFwdLds = (size_t)(kM * kRow + kC * kC) * 4 + 2 * kM * 8 * 4 * 
 constexpr size_t kWgLds = (size_t)(kM * kRow) * 4 + 2 * kM * 8 * 4 * 2;
 constexpr size_t kDgLds = (size_t)(kM * kRow + kC * kC) * 4 + 2 * kM * kEntD * 4;
 
+// dynamic LDS above 64 KB needs the opt-in attribute; set once per kernel and size (the largest request so far)
 template <class Kern>
 int allow_lds(Kern k, size_t bytes) {
-  return hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess
-             ? MR3D_OK : MR3D_ERR_LAUNCH;
+  static const void *fns[8];
+  static size_t granted[8];
+  static int n = 0;
+  static std::mutex mu;
+  const void *f = reinterpret_cast<const void *>(k);
+  std::lock_guard<std::mutex> lock(mu);
+  int at = -1;
+  for (int i = 0; i < n; ++i)
+    if (fns[i] == f) at = i;
+  if (at >= 0 && bytes <= granted[at]) return MR3D_OK;
+  if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return MR3D_ERR_LAUNCH;
+  }
+  if (at < 0 && n < 8) { at = n++; fns[at] = f; }
+  if (at >= 0) granted[at] = bytes;
+  return MR3D_OK;
 }
 
 }  // namespace

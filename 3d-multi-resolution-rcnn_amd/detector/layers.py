@@ -141,17 +141,19 @@ _LINEAR_WS = {}
 
 
 def _linear_workspace(device, rows, k, o):
-    """scratch for the split-K launches of csrc/linear.hip (fixed-order summation instead of atomics); one buffer per device,
-    grown on demand -- launches on one stream use it one after the other"""
+    """scratch for the split-K launches of csrc/linear.hip (fixed-order summation instead of atomics): one buffer per
+    (device, stream), grown on demand -- launches on one stream use it one after the other"""
     fn = _hip.lib().mr3d_linear_workspace_bytes
-    fn.restype = ctypes.c_size_t
+    if fn.restype is not ctypes.c_size_t:
+        fn.restype = ctypes.c_size_t
     need = int(fn(int(rows), int(k), int(o)))
     if need == 0:
         return None, 0
-    ws = _LINEAR_WS.get(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    ws = _LINEAR_WS.get(key)
     if ws is None or ws.numel() * 4 < need:
         ws = torch.empty(((need + 3) // 4,), dtype=torch.float32, device=device)
-        _LINEAR_WS[device] = ws
+        _LINEAR_WS[key] = ws
     return ws, ws.numel() * 4
 
 
