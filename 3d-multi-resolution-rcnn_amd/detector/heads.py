@@ -324,11 +324,16 @@ class _MaskHeadPlanFn(torch.autograd.Function):
     """FCNMaskHead3D.forward (fcn_mask_head_3d.py:88-97: 4 x [3x3x3 conv + ReLU] -> ConvTranspose3d(2, stride 2) + ReLU
     -> 1x1x1 logits) as ONE plan run, and its backward as one more: every ReLU mask rides in the epilogue of the data
     gradient that produces the masked tensor, the six weight gradients run on the plan's side stream, and the 8 taps of
-    the transposed conv scatter straight into the up-sampled map.  args: x, then (weight, bias) of the convs, the
-    deconv and the logits conv."""
+    the transposed conv scatter straight into the up-sampled map.  args: x, bf16 flag, then (weight, bias) of the convs, the
+    deconv and the logits conv.
+    bf16 = True (BASELINE configs[4]): activations and activation gradients of the head are stored in bf16 and every product
+    runs on the bf16 MFMA kernels (fp32 accumulation; weights, biases and their gradients stay fp32; the logits leave in
+    fp32).  The bf16 kernels have no kernel-2 instance, so the transposed conv's backward is written as 8 stride-2 POINTWISE
+    passes: its data gradient accumulates the taps through the residual-add epilogue (the ReLU mask on the last one), its
+    weight gradient is one stride-2 pointwise weight gradient per tap with the roles of input and output swapped."""
 
     @staticmethod
-    def forward(ctx, x, *params):
+    def forward(ctx, x, bf, *params):
         from .. import _hip
         dev = x.device
         nconv = (len(params) - 4) // 2
@@ -337,46 +342,60 @@ class _MaskHeadPlanFn(torch.autograd.Function):
         c = convs[0][0].shape[0]
         col = wl.shape[0]
         colp = -(-col // 16) * 16
-        xc = x.detach().permute(0, 2, 3, 4, 1).contiguous()
+        adt = torch.bfloat16 if bf else torch.float32
+        esz = 2 if bf else 4
+        pack = _hip.pack_conv_weight_bf16 if bf else _hip.pack_conv_weight
+        xc = x.detach().permute(0, 2, 3, 4, 1).to(adt).contiguous()
         N, D, H, W, cin = xc.shape
         acts, ops, keep = [xc], [], []
         for w, b in convs:
-            wf, sh = _hip.pack_conv_weight(w.detach()), b.detach().contiguous()
-            a = torch.empty((N, D, H, W, c), dtype=torch.float32, device=dev)
+            wf, sh = pack(w.detach()), b.detach().contiguous()
+            a = torch.empty((N, D, H, W, c), dtype=adt, device=dev)
             ops.append(_hip.make_op(_hip.OP_CONV_FWD, [acts[-1], wf, a, sh, None, None, None, None],
                                     [N, D, H, W, acts[-1].shape[4], c, 3, 3, 3, 1, 1, 1, 1, 1, 1, 0, 0, 0, 1]))
             keep += [wf, sh]
             acts.append(a)
-        wdf = wd.detach().permute(2, 3, 4, 0, 1).reshape(8, c, c).contiguous()          # [tap][ci][co]
         shd = bd.detach().contiguous()
-        up = torch.empty((N, 2 * D, 2 * H, 2 * W, c), dtype=torch.float32, device=dev)
+        up = torch.empty((N, 2 * D, 2 * H, 2 * W, c), dtype=adt, device=dev)
+        if bf:
+            wdf = _hip.pack_conv_weight_bf16(wd.detach().transpose(0, 1).contiguous())     # [8 taps][ci/8][co][8]
+            tap_bytes = wdf[0].numel() * 2
+        else:
+            wdf = wd.detach().permute(2, 3, 4, 0, 1).reshape(8, c, c).contiguous()          # [tap][ci][co]
+            tap_bytes = 4 * c * c
         for t in range(8):
             a_, b_, c_ = t >> 2, (t >> 1) & 1, t & 1
             off = ((a_ * 2 * H + b_) * 2 * W + c_) * c
-            ops.append(_hip.make_op(_hip.OP_CONV_FWD, [acts[-1], wdf.data_ptr() + 4 * t * c * c, up.data_ptr() + 4 * off, shd,
+            ops.append(_hip.make_op(_hip.OP_CONV_FWD, [acts[-1], wdf.data_ptr() + t * tap_bytes, up.data_ptr() + esz * off, shd,
                                                         None, None, None, None],
                                     [N, D, H, W, c, c, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 2, 2, 2, 2 * D, 2 * H, 2 * W]))
         wlp = torch.zeros((colp, c, 1, 1, 1), dtype=torch.float32, device=dev)
         wlp[:col] = wl.detach()
-        wlf = _hip.pack_conv_weight(wlp)
+        wlf = pack(wlp)
         shl = torch.zeros(colp, dtype=torch.float32, device=dev)
         shl[:col] = bl.detach()
-        out = torch.empty((N, 2 * D, 2 * H, 2 * W, colp), dtype=torch.float32, device=dev)
+        out = torch.empty((N, 2 * D, 2 * H, 2 * W, colp), dtype=adt, device=dev)
         ops.append(_hip.make_op(_hip.OP_CONV_FWD, [up, wlf, out, shl, None, None, None, None],
                                 [N, 2 * D, 2 * H, 2 * W, c, colp, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0]))
         keep += [wdf, shd, wlf, shl]
+        if bf:
+            for o_ in ops:
+                o_.i[25] = _hip.DTYPE_BF16
         with torch.cuda.device(dev):
             _hip.Plan(ops).run(dev)
         ctx.save_for_backward(*params, *acts, up, wlp)
-        ctx.meta = (nconv, c, col, colp)
+        ctx.meta = (nconv, c, col, colp, bf)
         ctx.keep = keep
+        out = out.float() if bf else out
         return out.permute(0, 4, 1, 2, 3)[:, :col]
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, gout):
         from .. import _hip
-        nconv, c, col, colp = ctx.meta
+        nconv, c, col, colp, bf = ctx.meta
+        adt = torch.bfloat16 if bf else torch.float32
+        esz = 2 if bf else 4
         sv = ctx.saved_tensors
         params = sv[:2 * nconv + 4]
         acts = sv[2 * nconv + 4:2 * nconv + 4 + nconv + 1]
@@ -386,32 +405,47 @@ class _MaskHeadPlanFn(torch.autograd.Function):
         N, D, H, W, cin = acts[0].shape
         side = [1]
         z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
-        g16 = z(N, 2 * D, 2 * H, 2 * W, colp)
+        g16 = torch.zeros((N, 2 * D, 2 * H, 2 * W, colp), dtype=adt, device=dev)
         g16[..., :col] = gout.permute(0, 2, 3, 4, 1)
         ops, keep = [], [g16]
 
-        def wgrad(xin, dy, dw, db, k, s, p, xdims):
+        def wgrad(xin, dy, dw, db, k, s, p, xdims, cin_, cout_):
             n_, d_, h_, w_ = xdims
-            ints = [n_, d_, h_, w_, xin.shape[4], dy.shape[4], k, k, k, s, s, s, p, p, p] + [0] * 11 + side
+            ints = [n_, d_, h_, w_, cin_, cout_, k, k, k, s, s, s, p, p, p] + [0] * 11 + side
             ops.append(_hip.make_op(_hip.OP_CONV_WGRAD, [xin, dy, dw, db], ints))
 
-        def dgrad(dy, wb, dx, mask, k, s, p, dims):
+        def dgrad(dy, wb, dx, mask, k, s, p, dims, cin_, cout_, add1=None):
             n_, d_, h_, w_ = dims
-            ops.append(_hip.make_op(_hip.OP_CONV_FWD, [dy, wb, dx, None, None, None, None, mask],
-                                    [n_, d_, h_, w_, dy.shape[4], dx.shape[4], k, k, k, s, s, s, p, p, p, 0, 0, 0, 0]))
+            ops.append(_hip.make_op(_hip.OP_CONV_FWD, [dy, wb, dx, None, add1, None, None, mask],
+                                    [n_, d_, h_, w_, cin_, cout_, k, k, k, s, s, s, p, p, p, 0, 0, 0, 0]))
 
         # logits 1x1x1
         dwl, dbl = z(1, c, colp), z(colp)
-        wgrad(up, g16, dwl, dbl, 1, 1, 0, (N, 2 * D, 2 * H, 2 * W))
-        gup = torch.empty(up.shape, dtype=torch.float32, device=dev)
-        wbl = wlp.reshape(colp, c, 1).permute(2, 0, 1).contiguous()
-        dgrad(g16, wbl, gup, up, 1, 1, 0, (N, 2 * D, 2 * H, 2 * W))                      # ReLU mask of the deconv output
-        # transposed conv = kernel-2 / stride-2 conv of the gradient (roles swapped for the weight gradient)
+        wgrad(up, g16, dwl, dbl, 1, 1, 0, (N, 2 * D, 2 * H, 2 * W), c, colp)
+        gup = torch.empty(up.shape, dtype=adt, device=dev)
+        if bf:
+            wbl = _hip.pack_conv_weight_bf16(wlp.transpose(0, 1).contiguous())
+        else:
+            wbl = wlp.reshape(colp, c, 1).permute(2, 0, 1).contiguous()
+        dgrad(g16, wbl, gup, up, 1, 1, 0, (N, 2 * D, 2 * H, 2 * W), colp, c)             # ReLU mask of the deconv output
         dwd = z(8, c, c)                                                                 # [tap][conv-in = co][conv-out = ci]
-        wgrad(gup, acts[-1], dwd, None, 2, 2, 0, (N, 2 * D, 2 * H, 2 * W))
-        g = torch.empty(acts[-1].shape, dtype=torch.float32, device=dev)
-        wbd = wd.detach().permute(2, 3, 4, 1, 0).reshape(8, c, c).contiguous()
-        dgrad(gup, wbd, g, acts[-1], 2, 2, 0, (N, 2 * D, 2 * H, 2 * W))
+        g = torch.empty(acts[-1].shape, dtype=adt, device=dev)
+        if bf:
+            # transposed conv backward as 8 stride-2 pointwise passes over gup shifted by the tap (no kernel-2 bf16 instance)
+            wbd = _hip.pack_conv_weight_bf16(wd.detach().contiguous())                   # conv weight (out = ci, in = co) per tap
+            tap_bytes = wbd[0].numel() * 2
+            for t in range(8):
+                a_, b_, c_ = t >> 2, (t >> 1) & 1, t & 1
+                off = ((a_ * 2 * H + b_) * 2 * W + c_) * c
+                gsh = gup.data_ptr() + esz * off
+                wgrad(gsh, acts[-1], dwd.data_ptr() + 4 * t * c * c, None, 1, 2, 0, (N, 2 * D, 2 * H, 2 * W), c, c)
+                dgrad(gsh, wbd.data_ptr() + t * tap_bytes, g, acts[-1] if t == 7 else None, 1, 2, 0, (N, 2 * D, 2 * H, 2 * W), c, c,
+                      add1=g if t > 0 else None)
+        else:
+            # transposed conv = kernel-2 / stride-2 conv of the gradient (roles swapped for the weight gradient)
+            wgrad(gup, acts[-1], dwd, None, 2, 2, 0, (N, 2 * D, 2 * H, 2 * W), c, c)
+            wbd = wd.detach().permute(2, 3, 4, 1, 0).reshape(8, c, c).contiguous()
+            dgrad(gup, wbd, g, acts[-1], 2, 2, 0, (N, 2 * D, 2 * H, 2 * W), c, c)
         keep += [gup, wbl, wbd]
         # the 3x3x3 convs, last to first
         dws, dbs = [], []
@@ -419,22 +453,28 @@ class _MaskHeadPlanFn(torch.autograd.Function):
             w = params[2 * i]
             ci = acts[i].shape[4]
             dw, db = z(27, ci, c), z(c)
-            wgrad(acts[i], g, dw, db, 3, 1, 1, (N, D, H, W))
-            wb = w.detach().reshape(c, ci, 27).flip(2).permute(2, 0, 1).contiguous()
-            gprev = torch.empty(acts[i].shape, dtype=torch.float32, device=dev)
-            dgrad(g, wb, gprev, acts[i] if i > 0 else None, 3, 1, 1, (N, D, H, W))
+            wgrad(acts[i], g, dw, db, 3, 1, 1, (N, D, H, W), ci, c)
+            if bf:
+                wb = _hip.pack_conv_weight_bf16(w.detach().flip(2, 3, 4).transpose(0, 1).contiguous())
+            else:
+                wb = w.detach().reshape(c, ci, 27).flip(2).permute(2, 0, 1).contiguous()
+            gprev = torch.empty(acts[i].shape, dtype=adt, device=dev)
+            dgrad(g, wb, gprev, acts[i] if i > 0 else None, 3, 1, 1, (N, D, H, W), c, ci)
             keep += [wb, g]
             dws.append((dw, ci)); dbs.append(db)
             g = gprev
+        if bf:
+            for o_ in ops:
+                o_.i[25] = _hip.DTYPE_BF16
         with torch.cuda.device(dev):
             _hip.Plan(ops).run(dev)
         grads = []
         for (dw, ci), db in zip(reversed(dws), reversed(dbs)):
             grads += [dw.permute(2, 1, 0).reshape(c, ci, 3, 3, 3).contiguous(), db]
         gwd = dwd.reshape(2, 2, 2, c, c).permute(4, 3, 0, 1, 2).contiguous()
-        gbd = gup.sum((0, 1, 2, 3))
+        gbd = gup.float().sum((0, 1, 2, 3))
         gwl = dwl.permute(2, 1, 0).reshape(colp, c, 1, 1, 1)[:col].contiguous()
-        return (g.permute(0, 4, 1, 2, 3),) + tuple(grads) + (gwd, gbd, gwl, dbl[:col].contiguous())
+        return (g.float().permute(0, 4, 1, 2, 3), None) + tuple(grads) + (gwd, gbd, gwl, dbl[:col].contiguous())
 
 
 class FCNMaskHead3D(nn.Module):
@@ -462,7 +502,7 @@ class FCNMaskHead3D(nn.Module):
             for m in self.convs:
                 params += [m.conv.weight, m.conv.bias]
             params += [self.upsample.weight, self.upsample.bias, self.conv_logits.weight, self.conv_logits.bias]
-            return _MaskHeadPlanFn.apply(x, *params)                          # the whole head: one plan run per pass
+            return _MaskHeadPlanFn.apply(x, bool(getattr(self, 'bf16', False)), *params)      # the whole head: one plan run per pass
         for conv in self.convs:
             x = conv(x)
         x = layers.conv_transpose3d_k2s2(x, self.upsample.weight, self.upsample.bias, relu=True)

@@ -120,6 +120,7 @@ class TwoStageDetector3D(nn.Module):
             self.mask_roi_extractor = SingleRoIExtractor(dict(type='RoIAlign3D', out_size=14, out_size_depth=10, sample_num=2),
                                                          64, strides, dstrides)
             self.mask_head = FCNMaskHead3D().to(self.device)
+            self.mask_head.bf16 = dtype == torch.bfloat16            # configs[4]: the head's activations in bf16 too
         self.iteration = 0
         # checkpoint compatibility (two_stage_3d.py:33-60): the reference names its feature extractor `backbone` / `neck`;
         # here both live in one engine module, so its prefix is dropped on save and added on load

@@ -32,6 +32,7 @@ class TwoStageDetector3D2Scales(TwoStageDetector3D):
         self.refinement_mask_roi_extractor = SingleRoIExtractor(
             dict(type='RoIAlign3D', out_size=14, out_size_depth=10, sample_num=2), 64, strides, dstrides)
         self.refinement_mask_head = FCNMaskHead3D().to(self.device)                                    # configs/...py:80-85
+        self.refinement_mask_head.bf16 = dtype == torch.bfloat16
 
     # ------------------------------------------------------------------ shared pieces
     def _sample(self, proposals, gt, gl, draws, batch_index, inside=None, want_mask=False):

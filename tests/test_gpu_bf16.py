@@ -356,3 +356,36 @@ def test_layers_conv3d_bf16_autograd_offset_conv_shape():
     assert rel(xd.grad, x.grad) <= 2.0 ** -6          # dx is stored in bf16
     assert rel(wd.grad, w.grad) <= 2e-3 and rel(bd.grad, b.grad) <= 1e-4
 
+
+def test_mask_head_bf16_plan_vs_fp32_plan(dev):
+    """FCNMaskHead3D with bf16 activation storage (configs[4]) against the same head in fp32 on the bf16-rounded input: logits,
+    input gradient and every parameter gradient (3x3x3 convs, the transposed conv written as 8 stride-2 pointwise passes, logits)"""
+    from mr3d_amd.detector import FCNMaskHead3D
+    torch.manual_seed(4)
+    head = FCNMaskHead3D().to(dev)
+    with torch.no_grad():
+        for m in head.convs:                       # hidden pre-activations away from 0 (see the RPN test)
+            m.conv.weight.normal_(0, 0.01)
+            m.conv.bias.fill_(1.0)
+        head.upsample.weight.normal_(0, 0.02)
+        head.upsample.bias.fill_(1.0)
+        head.conv_logits.weight.normal_(0, 0.05)
+    x = _bf(torch.randn(5, 64, 10, 14, 14)).to(dev)
+    res = {}
+    for tag in ('f32', 'bf16'):
+        head.bf16 = tag == 'bf16'
+        head.zero_grad()
+        xi = x.clone().requires_grad_(True)
+        out = head(xi)
+        assert out.dtype == torch.float32 and out.shape == (5, 2, 20, 28, 28)
+        # a cotangent with a non-zero mean: the bias gradients are sums over all positions, and a sign-alternating cotangent
+        # makes them cancelling sums of bf16-rounded terms (a property of the evaluation point, not of the kernels)
+        cot = (1.0 + 0.5 * torch.sin(torch.arange(out.numel(), device=dev, dtype=torch.float32))).view_as(out)
+        (out * cot).sum().backward()
+        res[tag] = (out.detach().cpu(), xi.grad.cpu(), {n: p.grad.detach().cpu().clone() for n, p in head.named_parameters()})
+    _close(res['bf16'][0], res['f32'][0], 'mask logits', 3e-2, 1.5e-2)        # six chained bf16 roundings
+    # the gradient passes six bf16-stored maps, and the transposed conv's data gradient adds its 8 taps through a bf16 buffer
+    _close(res['bf16'][1], res['f32'][1], 'mask input grad', 8e-2, 3e-2)
+    for n in res['f32'][2]:
+        _close(res['bf16'][2][n], res['f32'][2][n], f'mask grad {n}', 5e-2, 3e-2)
+
