@@ -4,8 +4,9 @@
 // skimage.transform.resize of the whole volume (coco_3d_2scales.py:219), then ships 3 fp32 channels over PCIe.
 // Here the grey volume goes up once (1 channel, u8 or f32, the .npy's own [H, W, D] axis order or [D, H, W]) and
 // one kernel writes the normalised, zero-padded planar [3, D', Hp, Wp] tensor the stem kernel reads -- optionally
-// resampled (trilinear, half-pixel centres, edge clamp: the order-1 / upscaling behaviour of skimage's resize;
-// parity unpinned, scikit-image is not in the reference tree).
+// resampled exactly as skimage.transform.resize does with its defaults when up-scaling (order 1, half-pixel centres,
+// mode 'reflect' = ndimage 'mirror', anti-aliasing sigma 0): pinned against scipy.ndimage.map_coordinates, the routine
+// skimage calls (tests/test_input_prepare_cpu.py); scikit-image itself is not installed.
 // HBM-bound: bytes = |grey| read + 12 * D'*Hp*Wp written.
 #include "mr3d_common.h"
 
@@ -30,12 +31,23 @@ __device__ __forceinline__ float load_src(const PrepArgs &p, int d, int h, int w
   return p.src_u8 ? (float)((const uint8_t *)p.src)[i] : ((const float *)p.src)[i];
 }
 
+// skimage.transform.resize (scikit-image 0.18, n-dimensional branch: transform/_warps.py) samples the volume at
+// c = (o + 0.5) * in/out - 0.5 with scipy.ndimage.map_coordinates(order=1, mode='mirror'): its default mode 'reflect' is
+// ndimage's 'mirror' (_shared/utils.py mode table) -- the signal is mirrored about the CENTRE of the edge voxel, so a sample
+// up to half a voxel outside mixes the edge voxel with its inner neighbour (index -1 -> 1, index n -> n - 2).
+__device__ __forceinline__ int mirror_index(int i, int n) {
+  if (n == 1) return 0;
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * (n - 1) - i;
+  return i < 0 ? 0 : (i >= n ? n - 1 : i);
+}
+
 __device__ __forceinline__ void axis_taps(int o, float step, int n, int &i0, int &i1, float &t) {
-  float c = ((float)o + 0.5f) * step - 0.5f;
-  c = fminf(fmaxf(c, 0.f), (float)(n - 1));
-  i0 = (int)floorf(c);
-  i1 = i0 + 1 < n ? i0 + 1 : n - 1;
-  t = c - (float)i0;
+  const float c = ((float)o + 0.5f) * step - 0.5f;
+  const int f = (int)floorf(c);
+  t = c - (float)f;
+  i0 = mirror_index(f, n);
+  i1 = mirror_index(f + 1, n);
 }
 
 // one thread per output voxel (w fastest: coalesced planar stores); the [H,W,D] source is read through a 32x32 LDS
