@@ -6,14 +6,10 @@
 //                  thresholded result into a full-volume uint8 mask  (fcn_mask_head_3d.py:126-191)
 // The reference does both on the CPU with skimage.transform.resize in a Python loop (D2H of boxes, per-RoI
 // call, H2D of the result).  skimage is neither vendored nor installable here, so the exact resampling is
-// "parity unpinned"; this build defines it as: crop by integer-truncated box (bbox.astype(int32), size
-// max(x2-x1+1, 1), clipped to the volume like a numpy slice), trilinear resampling with half-pixel centres
-// (src = (dst + 0.5) * in/out - 0.5, clamped to the crop), paste = value > thr.  No anti-alias pre-filter.
-// Target rule: the reference feeds a uint8 0/1 crop to resize() with preserve_range=False, so skimage first scales it
-// by 1/255 (img_as_float); `(255 * resize(...)).astype(uint8)` is therefore floor(coverage) and `> 0` keeps only
-// voxels whose interpolated coverage reaches 1 -- an ERODED mask (mask_target.py:41-44).  target = 1 iff
-// coverage >= 1 - 2^-16 (the slack absorbs the fp32 rounding of the three lerps; the reference's own float64 sums
-// are just as close to 1).
+// "parity unpinned".  The TARGET rule follows skimage's published algorithm (see mask_target3d_kernel); the test-time
+// paste is build-defined: crop by integer-truncated box (bbox.astype(int32), size max(x2-x1+1, 1), clipped to the volume
+// like a numpy slice), trilinear resampling with half-pixel centres (src = (dst + 0.5) * in/out - 0.5, clamped to the
+// crop), paste = value > thr, no anti-alias pre-filter.
 #include "mr3d_common.h"
 
 namespace {
@@ -41,6 +37,36 @@ __device__ __forceinline__ void axis(int o, int out, int in, int &lo, int &hi, f
   f = s - (float)lo;
 }
 
+// Target rule, restated from the published source of what the reference calls (scikit-image 0.18 transform/_warps.py
+// resize(), n-dimensional branch, defaults): the uint8 0/1 crop becomes x/255 (img_as_float), is Gaussian-filtered along
+// every axis that is being shrunk (anti_aliasing: sigma = (in/out - 1) / 2, scipy radius int(4 sigma + 0.5), mode
+// 'mirror'), sampled at c = (o + 0.5) in/out - 0.5 with order-1 interpolation in mode 'mirror', clipped to the input
+// range, multiplied by 255, truncated to uint8 and compared with 0 (mask_target.py:41-44).  All weights are positive and
+// sum to 1, so the truncated value is 1 only where EVERY crop voxel the two stencils touch is set: an eroded mask.
+//   target(o) = AND over axes-product of crop[mirror(i)], i in [floor(c) - r, (frac(c) > 0 ? floor(c) + 1 : floor(c)) + r]
+// (In the reference the float64 sums of an all-ones stencil come out as 1/255 or one ulp below it depending on the
+// interpolation weights, and one ulp below truncates to 0: its targets are a rounding-dependent SUBSET of this rule --
+// tests/test_mask_crop.py reproduces that with scipy.ndimage, the routines scikit-image calls.)
+struct AxisStencil { int lo, hi; };
+
+__device__ __forceinline__ AxisStencil stencil_of(int o, int out, int in) {
+  const double f = (double)in / (double)out;
+  const double c = f * ((double)o + 0.5) - 0.5;      // numpy's two roundings: this file is built with -ffp-contract=off
+  const double fl = floor(c);
+  const int r = in > out ? (int)(4.0 * ((f - 1.0) / 2.0) + 0.5) : 0;
+  AxisStencil a;
+  a.lo = (int)fl - r;
+  a.hi = (int)fl + (c > fl ? 1 : 0) + r;
+  return a;
+}
+
+__device__ __forceinline__ int mirror_idx(int i, int n) {          // scipy.ndimage 'mirror': about the centre of the edge voxel
+  if (n == 1) return 0;
+  const int p = 2 * (n - 1);
+  i = (i < 0 ? -i : i) % p;
+  return i >= n ? p - i : i;
+}
+
 __global__ __launch_bounds__(kT) void mask_target3d_kernel(const uint8_t *__restrict__ gt, int D, int H, int W,
                                                           const float *__restrict__ boxes, int box_stride,
                                                           const long long *__restrict__ gt_inds, int P, int md, int mh, int mw,
@@ -50,20 +76,21 @@ __global__ __launch_bounds__(kT) void mask_target3d_kernel(const uint8_t *__rest
     const int ow = (int)(t % mw), oh = (int)((t / mw) % mh), od = (int)((t / ((long long)mw * mh)) % md);
     const int p = (int)(t / ((long long)mw * mh * md));
     const Crop c = crop_of(boxes + (size_t)p * box_stride, W, H, D);
-    float v = 0.f;
+    bool all = false;
     if (c.w > 0 && c.h > 0 && c.d > 0) {
       const uint8_t *g = gt + (size_t)gt_inds[p] * D * H * W;
-      int xl, xh, yl, yh, zl, zh;
-      float fx, fy, fz;
-      axis(ow, mw, c.w, xl, xh, fx); axis(oh, mh, c.h, yl, yh, fy); axis(od, md, c.d, zl, zh, fz);
-      auto at = [&](int z, int y, int x) -> float {
-        return g[((size_t)(c.z1 + z) * H + (c.y1 + y)) * W + (c.x1 + x)] ? 1.f : 0.f;
-      };
-      const float c00 = at(zl, yl, xl) * (1 - fx) + at(zl, yl, xh) * fx, c01 = at(zl, yh, xl) * (1 - fx) + at(zl, yh, xh) * fx;
-      const float c10 = at(zh, yl, xl) * (1 - fx) + at(zh, yl, xh) * fx, c11 = at(zh, yh, xl) * (1 - fx) + at(zh, yh, xh) * fx;
-      v = (c00 * (1 - fy) + c01 * fy) * (1 - fz) + (c10 * (1 - fy) + c11 * fy) * fz;
+      const AxisStencil sx = stencil_of(ow, mw, c.w), sy = stencil_of(oh, mh, c.h), sz = stencil_of(od, md, c.d);
+      all = true;
+      for (int z = sz.lo; z <= sz.hi && all; ++z) {
+        const int zz = c.z1 + mirror_idx(z, c.d);
+        for (int y = sy.lo; y <= sy.hi && all; ++y) {
+          const uint8_t *row = g + ((size_t)zz * H + (c.y1 + mirror_idx(y, c.h))) * W + c.x1;
+          for (int x = sx.lo; x <= sx.hi; ++x)
+            if (!row[mirror_idx(x, c.w)]) { all = false; break; }
+        }
+      }
     }
-    out[t] = v >= 1.f - 1.52587890625e-5f ? 1.f : 0.f;
+    out[t] = all ? 1.f : 0.f;
   }
 }
 
