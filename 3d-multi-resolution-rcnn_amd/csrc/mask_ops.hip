@@ -6,10 +6,9 @@
 //                  thresholded result into a full-volume uint8 mask  (fcn_mask_head_3d.py:126-191)
 // The reference does both on the CPU with skimage.transform.resize in a Python loop (D2H of boxes, per-RoI
 // call, H2D of the result).  skimage is neither vendored nor installable here, so the exact resampling is
-// "parity unpinned".  The TARGET rule follows skimage's published algorithm (see mask_target3d_kernel); the test-time
-// paste is build-defined: crop by integer-truncated box (bbox.astype(int32), size max(x2-x1+1, 1), clipped to the volume
-// like a numpy slice), trilinear resampling with half-pixel centres (src = (dst + 0.5) * in/out - 0.5, clamped to the
-// crop), paste = value > thr, no anti-alias pre-filter.
+// "parity unpinned" in the strict sense; both ops follow scikit-image 0.18's published resize() algorithm (restated at the
+// kernels below) and are checked against scipy.ndimage, the routines it calls.  Crop / box arithmetic: bbox.astype(int32),
+// size max(x2 - x1 + 1, 1); the target crop is clipped to the volume like a numpy slice.
 #include "mr3d_common.h"
 
 namespace {
@@ -27,14 +26,6 @@ __device__ __forceinline__ Crop crop_of(const float *__restrict__ box, int W, in
   const int xb = min(x1 + w, W), yb = min(y1 + h, H), zb = min(z1 + d, D);
   c.x1 = xa; c.y1 = ya; c.z1 = za; c.w = xb - xa; c.h = yb - ya; c.d = zb - za;
   return c;
-}
-
-__device__ __forceinline__ void axis(int o, int out, int in, int &lo, int &hi, float &f) {
-  float s = ((float)o + 0.5f) * ((float)in / (float)out) - 0.5f;
-  s = fminf(fmaxf(s, 0.f), (float)(in - 1));
-  lo = (int)s;
-  hi = min(lo + 1, in - 1);
-  f = s - (float)lo;
 }
 
 // Target rule, restated from the published source of what the reference calls (scikit-image 0.18 transform/_warps.py
@@ -94,28 +85,78 @@ __global__ __launch_bounds__(kT) void mask_target3d_kernel(const uint8_t *__rest
   }
 }
 
-// one workgroup row per detection; threads stride over the box's voxels
-__global__ __launch_bounds__(kT) void mask_paste3d_kernel(const float *__restrict__ prob, int md, int mh, int mw,
-                                                         const float *__restrict__ boxes, int box_stride, int P, float thr,
-                                                         int D, int H, int W, uint8_t *__restrict__ out) {
-  const int p = blockIdx.y;
-  const Crop c = crop_of(boxes + (size_t)p * box_stride, W, H, D);
-  // the reference resizes to the UNCLIPPED (d, h, w) and assigns into a slice; a box leaving the volume would raise
-  // there, so only in-volume boxes are meaningful: resample over the clipped extent
-  if (c.w <= 0 || c.h <= 0 || c.d <= 0) return;
-  const float *m = prob + (size_t)p * md * mh * mw;
+// Test-time paste (fcn_mask_head_3d.py:163-189): bbox_mask = resize(prob, (d, h, w)) > thr with (d, h, w) the UNCLIPPED box
+// size, assigned to im_mask[z1:z1+d, y1:y1+h, x1:x1+w].  resize() = scikit-image 0.18's n-dimensional branch (see above):
+// on every axis where the box is SMALLER than the mask map a Gaussian pre-filter (sigma = (in/out - 1) / 2, radius
+// int(4 sigma + 0.5), mode 'mirror', axes in order z, y, x, every pass rounded to the map's float32), then order-1
+// sampling at c = (o + 0.5) in/out - 0.5 in mode 'mirror', double arithmetic, result rounded to float32, compared with thr.
+// One workgroup per detection: the (md, mh, mw) map and its filtered copy live in LDS.  Voxels of a box that leave the
+// volume are skipped (the reference's slice assignment raises there).
+constexpr int kPasteT = 512;
+
+__device__ __forceinline__ void gauss_axis(const float *__restrict__ src, float *__restrict__ dst, int nd, int nh, int nw, int axis,
+                                           double sigma, int tid) {
+  const int n = axis == 0 ? nd : (axis == 1 ? nh : nw);
+  const int stride = axis == 0 ? nh * nw : (axis == 1 ? nw : 1);
+  const int r = (int)(4.0 * sigma + 0.5);
+  // scipy.ndimage._gaussian_kernel1d: exp(-0.5 / sigma^2 * x^2) / sum
+  double wsum = 0.0;
+  for (int k = -r; k <= r; ++k) wsum += exp(-0.5 / (sigma * sigma) * (double)(k * k));
+  const int total = nd * nh * nw;
+  for (int e = tid; e < total; e += kPasteT) {
+    const int x = e % nw, y = (e / nw) % nh, z = e / (nw * nh);
+    const int l = axis == 0 ? z : (axis == 1 ? y : x);
+    const float *line = src + (e - l * stride);
+    // correlate1d's symmetric form: centre tap, then pairs from the farthest to the nearest
+    double acc = (double)line[l * stride] * (1.0 / wsum);
+    for (int k = r; k >= 1; --k) {
+      const double w = exp(-0.5 / (sigma * sigma) * (double)(k * k)) / wsum;
+      acc += ((double)line[mirror_idx(l - k, n) * stride] + (double)line[mirror_idx(l + k, n) * stride]) * w;
+    }
+    dst[e] = (float)acc;
+  }
+}
+
+__global__ __launch_bounds__(kPasteT) void mask_paste3d_kernel(const float *__restrict__ prob, int md, int mh, int mw,
+                                                              const float *__restrict__ boxes, int box_stride, int P, float thr,
+                                                              int D, int H, int W, uint8_t *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float pl[];
+  const int p = blockIdx.x, tid = threadIdx.x;
+  const float *box = boxes + (size_t)p * box_stride;
+  const int x1 = (int)box[0], y1 = (int)box[1], x2 = (int)box[2], y2 = (int)box[3], z1 = (int)box[4], z2 = (int)box[5];
+  const int bw = max(x2 - x1 + 1, 1), bh = max(y2 - y1 + 1, 1), bd = max(z2 - z1 + 1, 1);
+  const int M = md * mh * mw;
+  float *cur = pl, *nxt = pl + M;
+  for (int e = tid; e < M; e += kPasteT) cur[e] = prob[(size_t)p * M + e];
+  __syncthreads();
+  const int sizes[3] = {bd, bh, bw}, maps[3] = {md, mh, mw};
+  for (int axis = 0; axis < 3; ++axis) {
+    const double f = (double)maps[axis] / (double)sizes[axis];
+    const double sigma = fmax(0.0, (f - 1.0) / 2.0);
+    if (sigma > 1e-15) {
+      gauss_axis(cur, nxt, md, mh, mw, axis, sigma, tid);
+      __syncthreads();
+      float *t = cur; cur = nxt; nxt = t;
+    }
+  }
   uint8_t *o = out + (size_t)p * D * H * W;
-  const long long n = (long long)c.w * c.h * c.d;
-  for (long long t = (long long)blockIdx.x * kT + threadIdx.x; t < n; t += (long long)gridDim.x * kT) {
-    const int x = (int)(t % c.w), y = (int)((t / c.w) % c.h), z = (int)(t / ((long long)c.w * c.h));
-    int xl, xh, yl, yh, zl, zh;
-    float fx, fy, fz;
-    axis(x, c.w, mw, xl, xh, fx); axis(y, c.h, mh, yl, yh, fy); axis(z, c.d, md, zl, zh, fz);
-    auto at = [&](int zz, int yy, int xx) { return m[((size_t)zz * mh + yy) * mw + xx]; };
-    const float c00 = at(zl, yl, xl) * (1 - fx) + at(zl, yl, xh) * fx, c01 = at(zl, yh, xl) * (1 - fx) + at(zl, yh, xh) * fx;
-    const float c10 = at(zh, yl, xl) * (1 - fx) + at(zh, yl, xh) * fx, c11 = at(zh, yh, xl) * (1 - fx) + at(zh, yh, xh) * fx;
-    const float v = (c00 * (1 - fy) + c01 * fy) * (1 - fz) + (c10 * (1 - fy) + c11 * fy) * fz;
-    o[((size_t)(c.z1 + z) * H + (c.y1 + y)) * W + (c.x1 + x)] = v > thr ? 1 : 0;
+  const double fz = (double)md / (double)bd, fy = (double)mh / (double)bh, fx = (double)mw / (double)bw;
+  const long long n = (long long)bw * bh * bd;
+  for (long long t = tid; t < n; t += kPasteT) {
+    const int x = (int)(t % bw), y = (int)((t / bw) % bh), z = (int)(t / ((long long)bw * bh));
+    const int vx = x1 + x, vy = y1 + y, vz = z1 + z;
+    if ((unsigned)vx >= (unsigned)W || (unsigned)vy >= (unsigned)H || (unsigned)vz >= (unsigned)D) continue;
+    const double cz = fz * ((double)z + 0.5) - 0.5, cy = fy * ((double)y + 0.5) - 0.5, cx = fx * ((double)x + 0.5) - 0.5;
+    const double flz = floor(cz), fly = floor(cy), flx = floor(cx);
+    const double tz = cz - flz, ty = cy - fly, tx = cx - flx;
+    const int z0 = mirror_idx((int)flz, md), z1i = mirror_idx((int)flz + 1, md);
+    const int y0 = mirror_idx((int)fly, mh), y1i = mirror_idx((int)fly + 1, mh);
+    const int x0 = mirror_idx((int)flx, mw), x1i = mirror_idx((int)flx + 1, mw);
+    auto at = [&](int zz, int yy, int xx) { return (double)cur[(zz * mh + yy) * mw + xx]; };
+    const double c00 = at(z0, y0, x0) * (1.0 - tx) + at(z0, y0, x1i) * tx, c01 = at(z0, y1i, x0) * (1.0 - tx) + at(z0, y1i, x1i) * tx;
+    const double c10 = at(z1i, y0, x0) * (1.0 - tx) + at(z1i, y0, x1i) * tx, c11 = at(z1i, y1i, x0) * (1.0 - tx) + at(z1i, y1i, x1i) * tx;
+    const float v = (float)((c00 * (1.0 - ty) + c01 * ty) * (1.0 - tz) + (c10 * (1.0 - ty) + c11 * ty) * tz);
+    o[((size_t)vz * H + vy) * W + vx] = v > thr ? 1 : 0;
   }
 }
 
@@ -141,7 +182,19 @@ extern "C" int mr3d_mask_paste3d(const float *mask_prob, int mask_d, int mask_h,
   if (num_dets < 0 || box_stride < 6) return MR3D_ERR_INVALID_ARG;
   if (num_dets == 0) return MR3D_OK;
   if (!mask_prob || !det_boxes || !out_masks) return MR3D_ERR_INVALID_ARG;
-  mask_paste3d_kernel<<<dim3(64, num_dets), kT, 0, mr3d_stream(s)>>>(mask_prob, mask_d, mask_h, mask_w, det_boxes, box_stride,
-                                                                    num_dets, threshold, depth, height, width, out_masks);
+  const size_t lds = (size_t)2 * mask_d * mask_h * mask_w * 4;
+  if (lds > 160 * 1024) return MR3D_ERR_UNSUPPORTED;                 // the shipped 20 x 28 x 28 map: 125 KB
+  static size_t granted = 0;
+  if (lds > granted) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(mask_paste3d_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess) {
+      (void)hipGetLastError();
+      return MR3D_ERR_LAUNCH;
+    }
+    granted = lds;
+  }
+  mask_paste3d_kernel<<<(unsigned)num_dets, kPasteT, lds, mr3d_stream(s)>>>(mask_prob, mask_d, mask_h, mask_w, det_boxes,
+                                                                             box_stride, num_dets, threshold, depth, height, width,
+                                                                             out_masks);
   return mr3d_launch_status();
 }

@@ -15,32 +15,6 @@ def _crop(box, W, H, D):
     return xa, ya, za, xb - xa, yb - ya, zb - za
 
 
-def _axis(out, inn):
-    o = np.arange(out, dtype=np.float32)
-    s = (o + np.float32(0.5)) * (np.float32(inn) / np.float32(out)) - np.float32(0.5)
-    s = np.clip(s, np.float32(0), np.float32(inn - 1)).astype(np.float32)
-    lo = s.astype(np.int32)
-    hi = np.minimum(lo + 1, inn - 1)
-    return lo, hi, (s - lo.astype(np.float32)).astype(np.float32)
-
-
-def _resample(src, out_shape):
-    """trilinear, half-pixel centres, edge clamp; same evaluation order as the kernel (x, then y, then z), fp32"""
-    src = src.astype(np.float32)
-    zl, zh, fz = _axis(out_shape[0], src.shape[0])
-    yl, yh, fy = _axis(out_shape[1], src.shape[1])
-    xl, xh, fx = _axis(out_shape[2], src.shape[2])
-    one = np.float32(1)
-
-    def lerp_x(z, y):
-        a = src[z][:, y][:, :, xl] if False else src[np.ix_(z, y, xl)]
-        b = src[np.ix_(z, y, xh)]
-        return a * (one - fx)[None, None, :] + b * fx[None, None, :]
-    c00, c01, c10, c11 = lerp_x(zl, yl), lerp_x(zl, yh), lerp_x(zh, yl), lerp_x(zh, yh)
-    fyb, fzb = fy[None, :, None], fz[:, None, None]
-    return ((c00 * (one - fyb) + c01 * fyb) * (one - fzb) + (c10 * (one - fyb) + c11 * fyb) * fzb).astype(np.float32)
-
-
 def _stencil(out, inn):
     """per output index the source index range [lo, hi] (before mirroring) that skimage.transform.resize touches with its
     defaults: order-1 taps at c = (o + 0.5) in/out - 0.5, widened by the radius of the anti-aliasing Gaussian where the axis
@@ -101,12 +75,31 @@ def mask_target_literal_scipy(crop_u8, out_shape):
     return (255 * res).astype(np.uint8) > 0
 
 
+def skimage_resize_float(img, out_shape):
+    """scikit-image 0.18 transform.resize(img, out_shape) for a 3-D float32 image with its defaults, through the scipy.ndimage
+    routines it calls (transform/_warps.py, n-dimensional branch): Gaussian pre-filter on shrinking axes, order-1 'mirror'
+    sampling, clip to the input range; the result has the image's dtype"""
+    from scipy import ndimage as ndi
+    img = np.asarray(img, np.float32)
+    factors = np.asarray(img.shape, float) / np.asarray(out_shape, float)
+    sigma = np.maximum(0, (factors - 1) / 2)
+    filt = ndi.gaussian_filter(img, sigma, cval=0, mode='mirror') if sigma.any() else img
+    coords = [factors[i] * (np.arange(n) + 0.5) - 0.5 for i, n in enumerate(out_shape)]
+    cmap = np.array(np.meshgrid(*coords, sparse=False, indexing='ij'))
+    res = ndi.map_coordinates(filt, cmap, order=1, mode='mirror', cval=0)
+    return np.clip(res, img.min(), img.max())
+
+
 def mask_paste(prob, boxes, thr, D, H, W):
+    """fcn_mask_head_3d.py:163-189: bbox_mask = resize(prob, (d, h, w)) > thr pasted at the integer box; voxels of a box that
+    leave the volume are skipped (the reference's slice assignment raises there)"""
     out = np.zeros((len(boxes), D, H, W), np.uint8)
     for p, box in enumerate(boxes):
-        xa, ya, za, w, h, d = _crop(box, W, H, D)
-        if w <= 0 or h <= 0 or d <= 0:
-            continue
-        v = _resample(prob[p], (d, h, w))
-        out[p, za:za + d, ya:ya + h, xa:xa + w] = (v > np.float32(thr)).astype(np.uint8)
+        x1, y1, x2, y2, z1, z2 = (int(v) for v in np.asarray(box[:6], np.float32).astype(np.int32))
+        w, h, d = max(x2 - x1 + 1, 1), max(y2 - y1 + 1, 1), max(z2 - z1 + 1, 1)
+        m = (skimage_resize_float(prob[p], (d, h, w)) > np.float32(thr)).astype(np.uint8)
+        za, ya, xa = max(z1, 0), max(y1, 0), max(x1, 0)
+        zb, yb, xb = min(z1 + d, D), min(y1 + h, H), min(x1 + w, W)
+        if zb > za and yb > ya and xb > xa:
+            out[p, za:zb, ya:yb, xa:xb] = m[za - z1:zb - z1, ya - y1:yb - y1, xa - x1:xb - x1]
     return out
