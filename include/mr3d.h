@@ -291,7 +291,8 @@ int mr3d_rpn_decode_level(const long long *flat_idx, const float *scores, int k,
  * Input preparation on the device (csrc/input_ops.hip) -- SURVEY.md section 8(f) rank 3.  Replaces the per-slice host
  * loop of mmdet/datasets/coco_3d_2scales.py:245-289 (grey -> 3 channels -> mmcv.imnormalize -> impad_to_multiple ->
  * [3,D,H,W]; transforms.py:33-51) and, with out_* != d/h/w, the skimage.transform.resize of the second pathway
- * (coco_3d_2scales.py:219; trilinear, half-pixel centres, edge clamp -- parity unpinned, scikit-image absent).
+ * (coco_3d_2scales.py:219; scikit-image 0.18's algorithm for an up-scaling: order 1, half-pixel centres, 'mirror' border --
+ * checked against scipy.ndimage.map_coordinates, the routine it calls; scikit-image itself is absent).
  *   grey: ONE-channel volume on the device, u8 or f32, axis order [H,W,D] (the .npy files, src_is_hwd = 1) or [D,H,W];
  *   out:  [3, out_d, pad_h, pad_w] fp32 planar; channel c = (g - mean[c]) / std[c]; rows/columns beyond out_h/out_w
  *         are 0 (impad pads AFTER normalisation).  mean/std: HOST arrays of 3.
@@ -377,8 +378,9 @@ int mr3d_mask_bce(const float *pred, const float *target, const long long *label
 
 /* ------------------------------------------------------------------------------------------------
  * Mask-crop (replaces the CPU skimage loops of mmdet/core/mask/mask_target.py:17-49 and
- * mmdet/models/mask_heads/fcn_mask_head_3d.py:163-189).  "Parity unpinned": skimage.transform.resize is a
- * third-party dependency (scikit-image==0.18.0) absent from the reference tree; semantics defined in csrc/mask_ops.hip.
+ * mmdet/models/mask_heads/fcn_mask_head_3d.py:163-189).  skimage.transform.resize is a third-party dependency
+ * (scikit-image==0.18.0) absent from the reference tree: both ops restate its published algorithm (Gaussian pre-filter on
+ * shrinking axes, order-1 'mirror' sampling; csrc/mask_ops.hip) and are checked against scipy.ndimage, which it calls.
  *   mask_target3d: gt_masks u8 [G,D,H,W] (device), pos_boxes [P, box_stride>=6] fp32, pos_assigned_gt_inds i64 [P]
  *                  -> targets fp32 [P, md, mh, mw] in {0,1}.
  *   mask_paste3d:  mask_prob fp32 [P, md, mh, mw] (already sigmoid-ed, the det's class channel), det_boxes
