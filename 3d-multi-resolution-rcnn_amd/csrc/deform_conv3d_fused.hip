@@ -368,6 +368,9 @@ __device__ __forceinline__ void fill_entry_d(const FGeo &g, const Coord &cd, con
   *reinterpret_cast<int4 *>(e + 8) = make_int4(__float_as_int(s.lz), __float_as_int(s.ly), __float_as_int(s.lx), flags);
 }
 
+// WITH_DX = false: the offset gradient alone (the dx half then runs in the tiled kernel below): four position groups of
+// corner reads in flight per step, reductions on DPP row shifts
+template <bool WITH_DX>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void dcn_dgrad_kernel(const float *__restrict__ x, const float *__restrict__ offset,
                                                                 const float *__restrict__ dy, const float *__restrict__ wb,
                                                                 float *__restrict__ dx, float *__restrict__ doffset, FGeo g) {
@@ -436,50 +439,70 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
     __syncthreads();
     const int *tb = tab + buf * kM * kEntD;
-#pragma unroll 2
-    for (int gi = 0; gi < 8; ++gi) {
-      const int row = wave * 32 + 4 * gi + p;
-      const int4 oa = *reinterpret_cast<const int4 *>(tb + row * kEntD), ob = *reinterpret_cast<const int4 *>(tb + row * kEntD + 4);
-      const int4 fr = *reinterpret_cast<const int4 *>(tb + row * kEntD + 8);
-      const int o[8] = {oa.x, oa.y, oa.z, oa.w, ob.x, ob.y, ob.z, ob.w};
-      const float lz = __int_as_float(fr.x), ly = __int_as_float(fr.y), lx = __int_as_float(fr.z);
-      const int flags = fr.w;
-      const bool any = (flags >> 6) & 1;
-      float4 v[8];
+    constexpr int GB = WITH_DX ? 2 : 4;              // position groups whose corner reads are in flight together
+#pragma unroll 1
+    for (int g0 = 0; g0 < 8; g0 += GB) {
+      int o[GB][8];
+      float lzyx[GB][3];
+      int flg[GB];
+      float4 v[GB][8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float4 *>(x + o[i] + 4 * q);
-      const float4 gc = *reinterpret_cast<const float4 *>(tile + row * kRow + 4 * q);
-      const float wz[2] = {1.f - lz, lz}, wy[2] = {1.f - ly, ly}, wx[2] = {1.f - lx, lx};
-      const float sg[2] = {-1.f, 1.f};
-      float gz = 0.f, gy = 0.f, gx = 0.f;
+      for (int u = 0; u < GB; ++u) {
+        const int row = wave * 32 + 4 * (g0 + u) + p;
+        const int4 oa = *reinterpret_cast<const int4 *>(tb + row * kEntD), ob = *reinterpret_cast<const int4 *>(tb + row * kEntD + 4);
+        const int4 fr = *reinterpret_cast<const int4 *>(tb + row * kEntD + 8);
+        o[u][0] = oa.x; o[u][1] = oa.y; o[u][2] = oa.z; o[u][3] = oa.w; o[u][4] = ob.x; o[u][5] = ob.y; o[u][6] = ob.z; o[u][7] = ob.w;
+        lzyx[u][0] = __int_as_float(fr.x); lzyx[u][1] = __int_as_float(fr.y); lzyx[u][2] = __int_as_float(fr.z);
+        flg[u] = fr.w;
+      }
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int u = 0; u < GB; ++u)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int i = 0; i < 8; ++i) v[u][i] = *reinterpret_cast<const float4 *>(x + o[u][i] + 4 * q);
 #pragma unroll
-          for (int c = 0; c < 2; ++c) {
-            const int i = a * 4 + b * 2 + c;
-            const bool valid = any && ((flags >> a) & 1) && ((flags >> (2 + b)) & 1) && ((flags >> (4 + c)) & 1);
-            if (valid) {
-              const float dot = gc.x * v[i].x + gc.y * v[i].y + gc.z * v[i].z + gc.w * v[i].w;
+      for (int u = 0; u < GB; ++u) {
+        const int row = wave * 32 + 4 * (g0 + u) + p;
+        const float lz = lzyx[u][0], ly = lzyx[u][1], lx = lzyx[u][2];
+        const int flags = flg[u];
+        const bool any = (flags >> 6) & 1;
+        const float4 gc = *reinterpret_cast<const float4 *>(tile + row * kRow + 4 * q);
+        const float wz[2] = {1.f - lz, lz}, wy[2] = {1.f - ly, ly}, wx[2] = {1.f - lx, lx};
+        const float sg[2] = {-1.f, 1.f};
+        float gz = 0.f, gy = 0.f, gx = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+              const int i = a * 4 + b * 2 + c;
+              const bool valid = any && ((flags >> a) & 1) && ((flags >> (2 + b)) & 1) && ((flags >> (4 + c)) & 1);
+              const float dot = valid ? gc.x * v[u][i].x + gc.y * v[u][i].y + gc.z * v[u][i].z + gc.w * v[u][i].w : 0.f;
               gz = fmaf(sg[a] * wy[b] * wx[c], dot, gz);
               gy = fmaf(wz[a] * sg[b] * wx[c], dot, gy);
               gx = fmaf(wz[a] * wy[b] * sg[c], dot, gx);
-              const float w = wz[a] * wy[b] * wx[c];
-              if (dx && w != 0.f) {
-                float *d = dx + o[i] + 4 * q;
-                atomicAdd(d + 0, w * gc.x); atomicAdd(d + 1, w * gc.y); atomicAdd(d + 2, w * gc.z); atomicAdd(d + 3, w * gc.w);
+              if constexpr (WITH_DX) {
+                const float w = wz[a] * wy[b] * wx[c];
+                if (valid && w != 0.f) {
+                  float *d = dx + o[u][i] + 4 * q;
+                  atomicAdd(d + 0, w * gc.x); atomicAdd(d + 1, w * gc.y); atomicAdd(d + 2, w * gc.z); atomicAdd(d + 3, w * gc.w);
+                }
               }
             }
-          }
-#pragma unroll
-      for (int m = 8; m > 0; m >>= 1) {
-        gz += __shfl_xor(gz, m); gy += __shfl_xor(gy, m); gx += __shfl_xor(gx, m);
-      }
-      const Coord rc = tile_pos(g, org, row);
-      if (doffset && q == 0 && rc.in) {
-        float *d = doffset + (size_t)rc.pos * (g.K * 3) + tap * 3;
-        d[0] = gz; d[1] = gy; d[2] = gx;
+        // sum over the 16 lanes of the position (one DPP row): the total lands in lane 15 of the row
+        auto row_sum = [](float t) {
+          t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x111, 0xf, 0xf, true));
+          t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x112, 0xf, 0xf, true));
+          t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x114, 0xf, 0xf, true));
+          t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x118, 0xf, 0xf, true));
+          return t;
+        };
+        gz = row_sum(gz); gy = row_sum(gy); gx = row_sum(gx);
+        const Coord rc = tile_pos(g, org, row);
+        if (doffset && q == 15 && rc.in) {
+          float *d = doffset + (size_t)rc.pos * (g.K * 3) + tap * 3;
+          d[0] = gz; d[1] = gy; d[2] = gx;
+        }
       }
     }
   }
@@ -830,17 +853,18 @@ extern "C" int mr3d_deform_conv3d_dgrad_fused(const mr3d_deform_conv3d_desc *d, 
   t.wnorm = w_packed + 3 * wn;
   bool tiled = dx && lds_tiled <= kTiledLdsMax;
   if (const char *e = getenv("MR3D_DCN_DGRAD")) tiled = tiled && strcmp(e, "direct") != 0;
-  if (allow_lds(dcn_dgrad_kernel, kDgLds) != MR3D_OK) return MR3D_ERR_LAUNCH;
+  if (allow_lds(dcn_dgrad_kernel<true>, kDgLds) != MR3D_OK || allow_lds(dcn_dgrad_kernel<false>, kDgLds) != MR3D_OK) return MR3D_ERR_LAUNCH;
   const unsigned tiles = 8u * (unsigned)((g.ntiles + 7) / 8);
   if (tiled) {
     t.tiles_d = (g.Do + kTd - 1) / kTd; t.tiles_h = (g.Ho + kTh - 1) / kTh; t.tiles_w = (g.Wo + kTw - 1) / kTw;
     const long long wgs = 8ll * g.N * t.tiles_d * t.tiles_h * t.tiles_w;
     if (wgs >= (1ll << 31)) return MR3D_ERR_UNSUPPORTED;
     if (allow_lds(dcn_dx_tiled_kernel, lds_tiled) != MR3D_OK) return MR3D_ERR_LAUNCH;
-    if (doffset) dcn_dgrad_kernel<<<tiles, kThreads, kDgLds, mr3d_stream(s)>>>(x, offset, dy, w_packed + wn, nullptr, doffset, g);
+    if (doffset) dcn_dgrad_kernel<false><<<tiles, kThreads, kDgLds, mr3d_stream(s)>>>(x, offset, dy, w_packed + wn, nullptr, doffset, g);
     dcn_dx_tiled_kernel<<<(unsigned)wgs, kThreads, lds_tiled, mr3d_stream(s)>>>(offset, dy, w_packed + 2 * wn, dx, t);
     return mr3d_launch_status();
   }
-  dcn_dgrad_kernel<<<tiles, kThreads, kDgLds, mr3d_stream(s)>>>(x, offset, dy, w_packed + wn, dx, doffset, g);
+  if (dx) dcn_dgrad_kernel<true><<<tiles, kThreads, kDgLds, mr3d_stream(s)>>>(x, offset, dy, w_packed + wn, dx, doffset, g);
+  else dcn_dgrad_kernel<false><<<tiles, kThreads, kDgLds, mr3d_stream(s)>>>(x, offset, dy, w_packed + wn, nullptr, doffset, g);
   return mr3d_launch_status();
 }
