@@ -301,7 +301,8 @@ def two_stage_main(a, rank, world, dev):
     from mr3d_amd.dist_utils import DetectorArena, broadcast_params, train_step
     D, H, W = a.vol
     torch.manual_seed(0)
-    det = TwoStageDetector3D(device=dev)
+    bf = getattr(a, 'dtype', 'f32') == 'bf16'           # BASELINE configs[4] storage type on the configs[2] / [3] step
+    det = TwoStageDetector3D(device=dev, dtype=torch.bfloat16 if bf else torch.float32)
     det.extract.init_weights()
     arena = DetectorArena(det)
     if world > 1:
@@ -335,16 +336,18 @@ def two_stage_main(a, rank, world, dev):
         # the sampled batch and are left out of the fraction
         flops = (FLOP_FWD_BWD_512 + 3 * 165.8e9) * (D * H * W) / (80.0 * 512 * 512)
         print(json.dumps({
-            'metric': 'train iters/sec on 512x512x80 vols (full two-stage step: RPN3D + RoIAlign3D + NMS3D + bbox/mask heads, fp32)',
+            'metric': 'train iters/sec on 512x512x80 vols (full two-stage step: RPN3D + RoIAlign3D + NMS3D + bbox/mask heads, ' +
+                      ('bf16 storage / fp32 accumulate)' if bf else 'fp32)'),
             'value': world * a.steps / el, 'unit': 'iters/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
-            'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if bf else 'f32',
+            'data': 'synthetic',
             'config': {'workload': f'BASELINE configs[{2 if world == 1 else 3}]: 1x3x{D}x{H}x{W} fp32 volume per GPU, whole '
                                    'single-pathway training step + SGD' +
                                    ('' if world == 1 else f' + ONE all-reduce of the {arena.flat_grads.numel() * 4 / 1e6:.1f} MB detector arena over RCCL'),
                        'global_batch': world, 'parallelism': f'dp{world}'},
             'roofline': {'bound': 'mfma', 'kernel': 'whole step (backbone+FPN+RPN convolutions)', 'achieved': flops / (ms * 1e-3) / 1e12,
-                         'peak': PEAK_FP32_MATRIX / 1e12, 'unit': 'TFLOP/s', 'frac': flops / (ms * 1e-3) / PEAK_FP32_MATRIX,
-                         'traffic': None},
+                         'peak': (PEAK_BF16_MATRIX if bf else PEAK_FP32_MATRIX) / 1e12, 'unit': 'TFLOP/s',
+                         'frac': flops / (ms * 1e-3) / (PEAK_BF16_MATRIX if bf else PEAK_FP32_MATRIX), 'traffic': None},
             'arena_mbytes': arena.flat_grads.numel() * 4 / 1e6}))
     if dist.is_initialized():
         dist.destroy_process_group()
