@@ -47,6 +47,8 @@ def main():
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--vol', default='32,128,128', help='D,H,W of the region (the reference trains on 128x128 crops)')
     ap.add_argument('--lr', type=float, default=0.001)          # configs/...py:235 (SGD lr 0.001, momentum 0.9, wd 1e-4)
+    ap.add_argument('--bf16', action='store_true', help='BASELINE configs[4]: bf16 activation storage')
+    ap.add_argument('--dcn-neck', action='store_true', help='BASELINE configs[4]: DeformConv3d neck')
     a = ap.parse_args()
     D, H, W = (int(v) for v in a.vol.split(','))
     rank, local, world = (int(os.environ.get(k, d)) for k, d in (('RANK', 0), ('LOCAL_RANK', 0), ('WORLD_SIZE', 1)))
@@ -56,7 +58,7 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', device_id=dev)
     torch.manual_seed(0)
-    det = TwoStageDetector3D2Scales(device=dev)
+    det = TwoStageDetector3D2Scales(device=dev, dtype=torch.bfloat16 if a.bf16 else torch.float32, neck_dcn=a.dcn_neck)
     det.extract.init_weights()
     arena = DetectorArena(det)
     broadcast_params(arena.flat_params)                          # identical initial weights (mmcv DDP init)
