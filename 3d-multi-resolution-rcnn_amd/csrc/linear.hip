@@ -17,7 +17,6 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kBM = 128, kBN = 128, kBK = 16;
-constexpr int kNF = kBK * 128 / 4 / 256;      // float4 per thread per operand block
 constexpr int kLdsRow = kBM + 4;          // floats per k row (16-byte aligned rows for float4 stores)
 constexpr int kGemmThreads = 256;
 
@@ -33,11 +32,13 @@ struct GemmArgs {
 };
 
 // stage one 16 x 128 operand block into registers.  KMAJ: stored [rows][K] (k contiguous); else stored [K][rows]
-template <bool KMAJ>
-__device__ __forceinline__ void gload(const float *__restrict__ p, long long ld, int row0, int rows, int k0, int K, int tid, float4 (&r)[kNF]) {
+// TR = tile extent along the operand's non-k axis (128, or 64 for the narrow M tile); kBK * TR / 4 float4 per block
+template <bool KMAJ, int TR>
+__device__ __forceinline__ void gload(const float *__restrict__ p, long long ld, int row0, int rows, int k0, int K, int tid,
+                                      float4 (&r)[kBK * TR / 4 / kGemmThreads]) {
 #pragma unroll
-  for (int u = 0; u < kNF; ++u) {
-    const int f = tid + u * kGemmThreads;                     // kBK * 32 float4 per block
+  for (int u = 0; u < kBK * TR / 4 / kGemmThreads; ++u) {
+    const int f = tid + u * kGemmThreads;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if constexpr (KMAJ) {
       const int m = f / (kBK / 4), kq = f % (kBK / 4);        // kBK / 4 lanes read the contiguous k run of a row
@@ -53,7 +54,7 @@ __device__ __forceinline__ void gload(const float *__restrict__ p, long long ld,
         }
       }
     } else {
-      const int kr = f >> 5, q = f & 31;                      // a k row is 128 contiguous floats
+      const int kr = f / (TR / 4), q = f % (TR / 4);          // a k row is TR contiguous floats
       const int k = k0 + kr, col = row0 + 4 * q;
       if (k < K) {
         const float *src = p + (size_t)k * ld + col;
@@ -70,73 +71,76 @@ __device__ __forceinline__ void gload(const float *__restrict__ p, long long ld,
   }
 }
 
-template <bool KMAJ>
-__device__ __forceinline__ void lstore(float *__restrict__ t, int tid, const float4 (&r)[kNF]) {
+template <bool KMAJ, int TR>
+__device__ __forceinline__ void lstore(float *__restrict__ t, int tid, const float4 (&r)[kBK * TR / 4 / kGemmThreads]) {
 #pragma unroll
-  for (int u = 0; u < kNF; ++u) {
+  for (int u = 0; u < kBK * TR / 4 / kGemmThreads; ++u) {
     const int f = tid + u * kGemmThreads;
     if constexpr (KMAJ) {
       const int m = f / (kBK / 4), kq = f % (kBK / 4);
       float *d = t + (4 * kq) * kLdsRow + m;
       d[0] = r[u].x; d[kLdsRow] = r[u].y; d[2 * kLdsRow] = r[u].z; d[3 * kLdsRow] = r[u].w;
     } else {
-      const int kr = f >> 5, q = f & 31;
+      const int kr = f / (TR / 4), q = f % (TR / 4);
       *reinterpret_cast<float4 *>(t + kr * kLdsRow + 4 * q) = r[u];
     }
   }
 }
 
-template <bool AK, bool BK>
+// BM = 128: waves 2 x 2, each 64 x 64 (2 x 2 MFMA blocks).  BM = 64: waves 1 x 4, each 64 x 32 (2 x 1 blocks) -- the narrow tile for
+// shapes whose 128-row tiling leaves a long tail (296 / 592 tiles on 256 CUs x 2 resident workgroups).
+template <bool AK, bool BK, int BM>
 __global__ __launch_bounds__(kGemmThreads, 2) void linear_gemm_kernel(GemmArgs p) {
+  constexpr int NBW = BM == 128 ? 2 : 1;                   // 32-column blocks per wave
   __shared__ __attribute__((aligned(16))) float lds[2][2][kBK * kLdsRow];       // [buffer][A / B][k][m or n]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = BM == 128 ? wave >> 1 : 0, wn = BM == 128 ? wave & 1 : wave;
   const int l31 = lane & 31, h = lane >> 5;
-  const int m0 = blockIdx.y * kBM, n0 = blockIdx.x * kBN;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * kBN;
   // this workgroup's share of the k-steps
   const int s_begin = (int)(((long long)p.ksteps_total * blockIdx.z) / gridDim.z);
   const int s_end = (int)(((long long)p.ksteps_total * (blockIdx.z + 1)) / gridDim.z);
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NBW];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NBW; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  float4 ra[kNF], rb[kNF];
+  float4 ra[kBK * BM / 4 / kGemmThreads], rb[kBK * kBN / 4 / kGemmThreads];
   if (s_begin < s_end) {
-    gload<AK>(p.a, p.lda, m0, p.M, s_begin * kBK, p.K, tid, ra);
-    gload<BK>(p.b, p.ldb, n0, p.N, s_begin * kBK, p.K, tid, rb);
+    gload<AK, BM>(p.a, p.lda, m0, p.M, s_begin * kBK, p.K, tid, ra);
+    gload<BK, kBN>(p.b, p.ldb, n0, p.N, s_begin * kBK, p.K, tid, rb);
   }
   for (int s = s_begin; s < s_end; ++s) {
     const int buf = (s - s_begin) & 1;
-    lstore<AK>(lds[buf][0], tid, ra);
-    lstore<BK>(lds[buf][1], tid, rb);
+    lstore<AK, BM>(lds[buf][0], tid, ra);
+    lstore<BK, kBN>(lds[buf][1], tid, rb);
     __syncthreads();
     if (s + 1 < s_end) {
-      gload<AK>(p.a, p.lda, m0, p.M, (s + 1) * kBK, p.K, tid, ra);
-      gload<BK>(p.b, p.ldb, n0, p.N, (s + 1) * kBK, p.K, tid, rb);
+      gload<AK, BM>(p.a, p.lda, m0, p.M, (s + 1) * kBK, p.K, tid, ra);
+      gload<BK, kBN>(p.b, p.ldb, n0, p.N, (s + 1) * kBK, p.K, tid, rb);
     }
     const float *ta = lds[buf][0] + h * kLdsRow + wm * 64 + l31;
-    const float *tb = lds[buf][1] + h * kLdsRow + wn * 64 + l31;
+    const float *tb = lds[buf][1] + h * kLdsRow + wn * (32 * NBW) + l31;
     // all fragments of the step are requested before its first MFMA (one LDS latency per step, not one per k pair)
-    float fa[kBK / 2][2], fb[kBK / 2][2];
+    float fa[kBK / 2][2], fb[kBK / 2][NBW];
 #pragma unroll
     for (int ks = 0; ks < kBK / 2; ++ks) {
       fa[ks][0] = ta[(2 * ks) * kLdsRow]; fa[ks][1] = ta[(2 * ks) * kLdsRow + 32];
-      fb[ks][0] = tb[(2 * ks) * kLdsRow]; fb[ks][1] = tb[(2 * ks) * kLdsRow + 32];
-    }
-    __builtin_amdgcn_sched_barrier(0);            // (the scheduler otherwise sinks each pair of reads next to its four MFMAs)
 #pragma unroll
-    for (int ks = 0; ks < kBK / 2; ++ks) {
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ks][0], fb[ks][0], acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ks][0], fb[ks][1], acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ks][1], fb[ks][0], acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ks][1], fb[ks][1], acc[1][1], 0, 0, 0);
+      for (int j = 0; j < NBW; ++j) fb[ks][j] = tb[(2 * ks) * kLdsRow + 32 * j];
     }
+    __builtin_amdgcn_sched_barrier(0);            // (the scheduler otherwise sinks each pair of reads next to its MFMAs)
+#pragma unroll
+    for (int ks = 0; ks < kBK / 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
     // the buffer written two steps from now is this one: the barrier of the NEXT step orders its reads before that
   }
 
@@ -144,8 +148,8 @@ __global__ __launch_bounds__(kGemmThreads, 2) void linear_gemm_kernel(GemmArgs p
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wn * 64 + j * 32 + l31;
+    for (int j = 0; j < NBW; ++j) {
+      const int col = n0 + wn * (32 * NBW) + j * 32 + l31;
       if (col >= p.N) continue;
       const float bs = (!p.atomic && p.bias) ? p.bias[col] : 0.f;
 #pragma unroll
@@ -166,7 +170,6 @@ __global__ __launch_bounds__(kGemmThreads, 2) void linear_gemm_kernel(GemmArgs p
     }
 }
 
-// bias + ReLU after a split launch; with a workspace also the sum of the `parts` partial products, in a fixed order
 __global__ void linear_finish_kernel(float *__restrict__ c, const float *__restrict__ part, int parts, const float *__restrict__ bias,
                                      int M, int N, long long ldc, int relu) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -185,8 +188,17 @@ __global__ void linear_finish_kernel(float *__restrict__ c, const float *__restr
   *d = v;
 }
 
+// 64-row tiles (a) where the 128-row tiling has between one and four rounds of workgroups -- the tail of the last round
+// dominates there (fc1 dgrad: 296 tiles, wgrad: 592) -- and (b) under a K split: twice the tiles need half the split, i.e.
+// half the partial-product traffic (fc1 forward: 64 tiles x 4 instead of 32 x 8)
+bool narrow_m(int M, int N) {
+  const int tiles = ((M + kBM - 1) / kBM) * ((N + kBN - 1) / kBN);
+  return M > 64 && tiles < 1024;
+}
+
 int split_of(int M, int N, int K) {
-  const int tiles = ((M + kBM - 1) / kBM) * ((N + kBN - 1) / kBN), ksteps = (K + kBK - 1) / kBK;
+  const int bm = narrow_m(M, N) ? 64 : kBM;
+  const int tiles = ((M + bm - 1) / bm) * ((N + kBN - 1) / kBN), ksteps = (K + kBK - 1) / kBK;
   int split = 1;
   if (tiles < 256) {      // split the K loop until one workgroup per CU is in flight, keeping at least 8 k-steps per workgroup
     split = (256 + tiles - 1) / tiles;
@@ -198,7 +210,9 @@ int split_of(int M, int N, int K) {
 
 template <bool AK, bool BK>
 int launch_gemm(GemmArgs p, float *workspace, long long workspace_bytes, hipStream_t stream) {
-  const int tm = (p.M + kBM - 1) / kBM, tn = (p.N + kBN - 1) / kBN;
+  const bool narrow = narrow_m(p.M, p.N);
+  const int bm = narrow ? 64 : kBM;
+  const int tm = (p.M + bm - 1) / bm, tn = (p.N + kBN - 1) / kBN;
   p.ksteps_total = (p.K + kBK - 1) / kBK;
   const int split = split_of(p.M, p.N, p.K);
   p.atomic = split > 1;
@@ -207,7 +221,8 @@ int launch_gemm(GemmArgs p, float *workspace, long long workspace_bytes, hipStre
     if (hipMemset2DAsync(p.c, (size_t)p.ldc * 4, 0, (size_t)p.N * 4, (size_t)p.M, stream) != hipSuccess) return MR3D_ERR_LAUNCH;
   }
   dim3 grid((unsigned)tn, (unsigned)tm, (unsigned)split);
-  linear_gemm_kernel<AK, BK><<<grid, kGemmThreads, 0, stream>>>(p);
+  if (narrow) linear_gemm_kernel<AK, BK, 64><<<grid, kGemmThreads, 0, stream>>>(p);
+  else linear_gemm_kernel<AK, BK, 128><<<grid, kGemmThreads, 0, stream>>>(p);
   if (p.part || (p.atomic && (p.bias || p.relu))) {
     const long long n = (long long)p.M * p.N;
     linear_finish_kernel<<<(unsigned)((n + 255) / 256), 256, 0, stream>>>(p.c, p.part, split, p.bias, p.M, p.N, p.ldc, p.relu);
