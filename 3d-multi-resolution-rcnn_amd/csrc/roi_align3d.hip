@@ -734,6 +734,280 @@ int try_fwd_sep(const T *feat, float *out, const float *rois, int num_rois, floa
 }
 
 // ------------------------------------------------------------------------------------------
+// channels-last FORWARD, whole-voxel box in LDS.  A workgroup owns (RoI, CH = 64 or 32 channels, a chunk of pooled depths).  Its
+// bins are walked in SEGMENTS of whole pooled depths whose sample footprint -- a dense voxel box [z][y][x] -- fits the LDS
+// budget (as many consecutive depths as fit).  A segment's box is staged
+// ONCE as fp32 -- whole x-rows of the NDHWC map, up to 16 row pieces per wave in flight -- and every bin of the segment is
+// evaluated from LDS by CH/4 lanes x float4 channels (at CH = 64 a voxel is all 64 LDS banks, so the 16-byte reads never
+// conflict; the per-sample weights are computed once per 4 channels; packed fp32 FMAs).  A pooled depth whose box alone does
+// not fit reads its taps from global memory.  Same per-sample expression as the wave-per-bin kernel.  Results
+// leave through an LDS tile [channel][tbins] so that [R,C,PD,PH,PW] rows are written in runs of tbins consecutive bins.
+// Measurements: try_fwd_box below.
+// ------------------------------------------------------------------------------------------
+constexpr int kBxTabBytes = 5 * kStAxis * 16 + 64;      // tap tables (x, y in two forms; z) + extents
+constexpr int kBxUnits = 8;                // row pieces (64 float4) a wave keeps in flight while staging
+
+struct BoxRange { int lo, n; };
+
+// voxels touched by the valid samples of pooled indices [a, b) of one axis (table with plain voxel indices)
+__device__ __forceinline__ BoxRange tap_range(const IdxEntry *tab, int a, int b, int ns) {
+  int mn = 0x7fffffff, mx = -1;
+  for (int e = a * ns; e < b * ns; ++e)
+    if (tab[e].l + tab[e].h != 0.f) { mn = min(mn, tab[e].lo); mx = max(mx, tab[e].hi); }
+  BoxRange r;
+  r.lo = mx < 0 ? 0 : mn;
+  r.n = mx < 0 ? 0 : mx - mn + 1;
+  return r;
+}
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// one bin (pd, ph, pw) of 4 channels.  STAGED: x / y tables hold float4 offsets into the box, `box` points at this lane's
+// channel quad of voxel (z0, segment's first row, x0), plane4 = float4 per box plane; else they hold element offsets into the
+// feature map and fbase points at this lane's channels of the RoI's image.  NS > 0 unrolls the sample loops; GUARD keeps the
+// reference's "an out-of-range sample adds nothing" as a branch (without it every sample is known valid).
+template <typename T, int NS, bool STAGED, bool GUARD>
+__device__ __forceinline__ float4 box_bin(const IdxEntry *tabx, const IdxEntry *taby, const IdxEntry *tabz, int pd, int ph, int pw,
+                                          int ns_rt, const float4 *box, int z0, int plane4, const T *fbase, long long sD) {
+  const int ns = NS > 0 ? NS : ns_rt;
+  v2f a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+#pragma unroll NS > 0 ? NS : 1
+  for (int iz = 0; iz < ns; ++iz) {
+    const IdxEntry tz = tabz[pd * ns + iz];
+#pragma unroll NS > 0 ? NS : 1
+    for (int iy = 0; iy < ns; ++iy) {
+      const IdxEntry ty = taby[ph * ns + iy];
+#pragma unroll NS > 0 ? NS : 1
+      for (int ix = 0; ix < ns; ++ix) {
+        const IdxEntry tx = tabx[pw * ns + ix];
+        if (GUARD && (tx.l + tx.h) * (ty.l + ty.h) * (tz.l + tz.h) == 0.f) continue;
+        const float w1 = tx.h * ty.h * tz.h, w5 = tx.h * ty.h * tz.l;
+        const float w2 = tx.l * ty.h * tz.h, w6 = tx.l * ty.h * tz.l;
+        const float w3 = tx.h * ty.l * tz.h, w7 = tx.h * ty.l * tz.l;
+        const float w4 = tx.l * ty.l * tz.h, w8 = tx.l * ty.l * tz.l;
+        float4 v1, v2, v3, v4, v5, v6, v7, v8;
+        if (STAGED) {
+          const float4 *bl_ = box + (tz.lo - z0) * plane4, *bh_ = box + (tz.hi - z0) * plane4;
+          v1 = bl_[ty.lo + tx.lo]; v2 = bl_[ty.lo + tx.hi]; v3 = bl_[ty.hi + tx.lo]; v4 = bl_[ty.hi + tx.hi];
+          v5 = bh_[ty.lo + tx.lo]; v6 = bh_[ty.lo + tx.hi]; v7 = bh_[ty.hi + tx.lo]; v8 = bh_[ty.hi + tx.hi];
+        } else {
+          const T *fl = fbase + tz.lo * sD, *fh = fbase + tz.hi * sD;
+          v1 = ld_feat4(fl + ty.lo + tx.lo); v2 = ld_feat4(fl + ty.lo + tx.hi); v3 = ld_feat4(fl + ty.hi + tx.lo); v4 = ld_feat4(fl + ty.hi + tx.hi);
+          v5 = ld_feat4(fh + ty.lo + tx.lo); v6 = ld_feat4(fh + ty.lo + tx.hi); v7 = ld_feat4(fh + ty.hi + tx.lo); v8 = ld_feat4(fh + ty.hi + tx.hi);
+        }
+#define MR3D_LO(v) ((v2f){(v).x, (v).y})
+#define MR3D_HI(v) ((v2f){(v).z, (v).w})
+        v2f s0 = w1 * MR3D_LO(v1), s1 = w1 * MR3D_HI(v1);
+        s0 += w2 * MR3D_LO(v2); s1 += w2 * MR3D_HI(v2);
+        s0 += w3 * MR3D_LO(v3); s1 += w3 * MR3D_HI(v3);
+        s0 += w4 * MR3D_LO(v4); s1 += w4 * MR3D_HI(v4);
+        s0 += w5 * MR3D_LO(v5); s1 += w5 * MR3D_HI(v5);
+        s0 += w6 * MR3D_LO(v6); s1 += w6 * MR3D_HI(v6);
+        s0 += w7 * MR3D_LO(v7); s1 += w7 * MR3D_HI(v7);
+        s0 += w8 * MR3D_LO(v8); s1 += w8 * MR3D_HI(v8);
+#undef MR3D_LO
+#undef MR3D_HI
+        a0 += s0; a1 += s1;
+      }
+    }
+  }
+  return make_float4(a0.x, a0.y, a1.x, a1.y);
+}
+
+template <typename T, int NS, int CH>
+__global__ __launch_bounds__(kClThreads) void roi_align3d_fwd_box(const T *feat, float *__restrict__ out,
+                                                                 const float *__restrict__ rois, float scale, float scale_d,
+                                                                 int ns, int C, int D, int H, int W, int PD, int PH, int PW,
+                                                                 int pdc, int cap, int tbins, LevelTable lt) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bx_lds[];
+  // tabx / taby: voxel indices at first, then float4 offsets into the box; tabxg / tabyg: element offsets into the map
+  IdxEntry *tabx = reinterpret_cast<IdxEntry *>(bx_lds), *taby = tabx + kStAxis, *tabz = taby + kStAxis;
+  IdxEntry *tabxg = tabz + kStAxis, *tabyg = tabxg + kStAxis;
+  int *ext = reinterpret_cast<int *>(tabyg + kStAxis);                // x0,nx, y0,ny, -, -, invalid samples on x, y, z
+  float4 *box = reinterpret_cast<float4 *>(bx_lds + kBxTabBytes);
+  float *tile = reinterpret_cast<float *>(bx_lds + kBxTabBytes + (size_t)cap * CH * 4);   // [CH][tbins + 1] results
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int L = CH / 4, SLOTS = kClThreads / L;                   // lanes per voxel, bin slots
+  const int TS = tbins + 1;
+  const int q = tid % L, slot = tid / L;                              // float4 of channels, bin slot
+  const int r = blockIdx.x, c0 = blockIdx.y * CH, pd0 = blockIdx.z * pdc;
+  const int pd1 = min(pd0 + pdc, PD);
+  if (lt.num) {
+    const int lvl = roi_level(rois + (size_t)r * 7, lt.finest_scale, lt.num);
+    D = pick4(lvl, lt.D); H = pick4(lvl, lt.H); W = pick4(lvl, lt.W);
+    scale = pick4(lvl, lt.scale); scale_d = pick4(lvl, lt.scale_d);
+    feat = reinterpret_cast<const T *>(pick4(lvl, lt.feat));
+  }
+  const RoiGeom g = roi_geom(rois + (size_t)r * 7, scale, scale_d, ns, PD, PH, PW);
+  build_idx_table(tabx, g.sw, g.bw, PW, ns, W, tid, kClThreads);
+  build_idx_table(taby, g.sh, g.bh, PH, ns, H, tid, kClThreads);
+  build_idx_table(tabz, g.sd, g.bd, PD, ns, D, tid, kClThreads);
+  __syncthreads();
+  if (tid < 3) {            // voxel range of the valid samples along x (tid 0), y (tid 1); are all samples of the axis valid?
+    const IdxEntry *tab = tid == 0 ? tabx : (tid == 1 ? taby : tabz);
+    const int n = (tid == 0 ? PW : (tid == 1 ? PH : PD)) * ns;
+    int mn = 0x7fffffff, mx = -1, bad = 0;
+    for (int e = 0; e < n; ++e) {
+      if (tab[e].l + tab[e].h != 0.f) { mn = min(mn, tab[e].lo); mx = max(mx, tab[e].hi); }
+      else bad = 1;
+    }
+    ext[2 * tid] = mx < 0 ? 0 : mn;
+    ext[2 * tid + 1] = mx < 0 ? 0 : mx - mn + 1;
+    ext[6 + tid] = bad;
+  }
+  // element-offset copies of the x / y tables for rows that read from global memory
+  for (int e = tid; e < PW * ns; e += kClThreads) { IdxEntry t = tabx[e]; t.lo *= C; t.hi *= C; tabxg[e] = t; }
+  for (int e = tid; e < PH * ns; e += kClThreads) { IdxEntry t = taby[e]; t.lo *= W * C; t.hi *= W * C; tabyg[e] = t; }
+  __syncthreads();
+  const int x0 = ext[0], nx = ext[1], y0 = ext[2], ny = ext[3];
+  const bool guard = (ext[6] | ext[7] | ext[8]) != 0;
+  const int B = PD * PH * PW, PHW = PH * PW;
+  const float inv_count = 1.f / (float)(ns * ns * ns);
+  const size_t base_n = (size_t)g.b * D * H * W * C + c0;
+  const long long sD = (long long)H * W * C;
+  const int rowlen4 = nx * L, pieces = (rowlen4 + 63) >> 6;
+  const T *fq = feat + base_n + q * 4;
+
+  int flushed = pd0 * PHW;                                           // first bin not yet written to out
+  bool rel = false;                                                  // tabx / taby already converted to box offsets?
+  for (int row = pd0 * PH; row < pd1 * PH;) {                        // rows = (pd, ph) pairs in bin order
+    const int pd = row / PH, ph = row - pd * PH;
+    // ---- next segment [row, row_end): whole pooled depths from a depth boundary, else ph rows of this depth (wave-uniform)
+    int row_end = row + 1;
+    BoxRange zr = tap_range(tabz, pd, pd + 1, ns), yr;
+    bool staged = false;
+    if (ph == 0 && (long long)zr.n * ny * nx <= cap) {
+      staged = true;
+      int sb = pd + 1;
+      while (sb < pd1) {
+        const BoxRange nxt = tap_range(tabz, pd, sb + 1, ns);
+        if ((long long)nxt.n * ny * nx > cap) break;
+        zr = nxt; ++sb;
+      }
+      row_end = sb * PH;
+    } else {                                                           // pooled depths that read their taps from global memory
+      int sb = pd + 1;
+      while (sb < pd1 && (long long)tap_range(tabz, sb, sb + 1, ns).n * ny * nx > cap) ++sb;
+      row_end = sb * PH;
+    }
+    yr.lo = y0; yr.n = ny;
+    __syncthreads();                                                 // the previous segment's bins are done with box and tables
+    if (staged && !rel) {           // first staged segment: x / y tables -> float4 offsets relative to (y0, x0)
+      for (int e = tid; e < PW * ns; e += kClThreads) { tabx[e].lo = (tabx[e].lo - x0) * L; tabx[e].hi = (tabx[e].hi - x0) * L; }
+      for (int e = tid; e < PH * ns; e += kClThreads) { taby[e].lo = (taby[e].lo - y0) * rowlen4; taby[e].hi = (taby[e].hi - y0) * rowlen4; }
+      rel = true;
+    }
+    if (staged) {
+      const int units = zr.n * yr.n * pieces;
+      for (int u0 = wave; u0 < units; u0 += (kClThreads / MR3D_WAVE) * kBxUnits) {
+        float4 v[kBxUnits];
+#pragma unroll
+        for (int k = 0; k < kBxUnits; ++k) {
+          const int u = u0 + k * (kClThreads / MR3D_WAVE);
+          const int rr = u / pieces, idx = (u - rr * pieces) * 64 + lane;
+          if (u < units && idx < rowlen4) {
+            const int zz = rr / yr.n, yy = rr - zz * yr.n;
+            v[k] = ld_feat4(feat + base_n + (((size_t)(zr.lo + zz) * H + (yr.lo + yy)) * W + x0 + idx / L) * C + (idx % L) * 4);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < kBxUnits; ++k) {
+          const int u = u0 + k * (kClThreads / MR3D_WAVE);
+          const int rr = u / pieces, idx = (u - rr * pieces) * 64 + lane;
+          if (u < units && idx < rowlen4) box[rr * rowlen4 + idx] = v[k];
+        }
+      }
+    }
+    __syncthreads();
+    // ---- bins of the segment: results go to tile[channel][bin - flushed], flushed to out[r, c0 + channel, ...] in runs
+    const int bin_end = row_end * PW, plane4 = yr.n * rowlen4;
+    const float4 *boxq = box + q - (yr.lo - y0) * rowlen4;            // taby offsets are relative to y0
+    for (int b0 = row * PW; b0 < bin_end; b0 += SLOTS) {
+      const int bin = b0 + slot;
+      if (bin < bin_end) {
+        const int bpd = bin / PHW, rem = bin - bpd * PHW, bph = rem / PW, bpw = rem - bph * PW;
+        float4 acc;
+        if (staged) {
+          if (!guard) acc = box_bin<T, NS, true, false>(tabx, taby, tabz, bpd, bph, bpw, ns, boxq, zr.lo, plane4, fq, sD);
+          else acc = box_bin<T, NS, true, true>(tabx, taby, tabz, bpd, bph, bpw, ns, boxq, zr.lo, plane4, fq, sD);
+        } else {
+          if (!guard) acc = box_bin<T, NS, false, false>(tabxg, tabyg, tabz, bpd, bph, bpw, ns, boxq, zr.lo, plane4, fq, sD);
+          else acc = box_bin<T, NS, false, true>(tabxg, tabyg, tabz, bpd, bph, bpw, ns, boxq, zr.lo, plane4, fq, sD);
+        }
+        float *t = tile + (4 * q) * TS + (bin - flushed);
+        t[0] = acc.x * inv_count; t[TS] = acc.y * inv_count; t[2 * TS] = acc.z * inv_count; t[3 * TS] = acc.w * inv_count;
+      }
+      const int done = min(b0 + SLOTS, bin_end);                     // bins [flushed, done) are in the tile
+      if (done - flushed + SLOTS > tbins || done == pd1 * PHW) {
+        __syncthreads();
+        const int nb = done - flushed;
+        if (tbins <= 32) {                                           // two channels x 32 bins per wave store
+          for (int ch = wave * 2 + (lane >> 5); ch < CH; ch += 2 * (kClThreads / MR3D_WAVE))
+            if ((lane & 31) < nb) out[((size_t)r * C + c0 + ch) * B + flushed + (lane & 31)] = tile[ch * TS + (lane & 31)];
+        } else {
+          for (int ch = wave; ch < CH; ch += kClThreads / MR3D_WAVE)
+            for (int bI = lane; bI < nb; bI += MR3D_WAVE) out[((size_t)r * C + c0 + ch) * B + flushed + bI] = tile[ch * TS + bI];
+        }
+        flushed = done;
+        __syncthreads();
+      }
+    }
+    row = row_end;
+  }
+}
+
+// launch of one (NS, CH) instance; the LDS attribute is raised once per instance
+template <typename T, int NS, int CH>
+int launch_fwd_box(const T *feat, float *out, const float *rois, int num_rois, float scale, float scale_d, int ns, int C, int D,
+                   int H, int W, int PD, int PH, int PW, int pdc, int lds_budget, const LevelTable &lt, hipStream_t stream) {
+  // results tile: 32 bins (two passes of the 16 bin slots at CH = 64); the box gets what is left of the LDS budget
+  const int tbins = 32;
+  const int tile_bytes = CH * (tbins + 1) * 4;
+  const int cap = (lds_budget - kBxTabBytes - tile_bytes) / (CH * 4);
+  if (cap < 16) return MR3D_ERR_UNSUPPORTED;
+  const int lds = kBxTabBytes + cap * CH * 4 + tile_bytes;
+  static std::mutex mu;
+  static int attr_bytes = 0;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    if (lds > attr_bytes) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void *>(roi_align3d_fwd_box<T, NS, CH>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              lds) != hipSuccess) {
+        (void)hipGetLastError();
+        return MR3D_ERR_LAUNCH;
+      }
+      attr_bytes = lds;
+    }
+  }
+  dim3 grid(num_rois, C / CH, (PD + pdc - 1) / pdc);
+  roi_align3d_fwd_box<T, NS, CH><<<grid, kClThreads, lds, stream>>>(feat, out, rois, scale, scale_d, ns, C, D, H, W, PD, PH, PW, pdc, cap, tbins, lt);
+  return mr3d_launch_status();
+}
+
+// Measured on the SURVEY 8(d) inputs (MI355X, kernel time): bbox extractor (3,7,7) x 512 rois 57 us against 86 us wave-per-bin
+// and 88 us separable (bf16 features 60 against 87); mask extractor (10,14,14) x 128 rois 157 us against 138 us separable, so
+// only shapes with PD <= 4 come here by default (MR3D_ROIALIGN_BOX=2 sends every shape, =0 none).  Every workgroup of the bbox
+// case is resident at once (512 workgroups, two per CU), so the launch lasts as long as its slowest RoI: median workgroup 22 us
+// (geometry + tables 4.6, staging 5, bins 10, stores 2), RoIs whose pooled depths do not fit the box ~45 us.  Tried and not
+// kept: 32 channels per workgroup with a 160-bin tile (two rounds of workgroups: 62 us), one pooled depth per workgroup
+// (61 us), splitting a pooled depth that does not fit into ph rows (each segment pays a staging latency: 90 us), contracting
+// the x-taps before the y/z weights (less VALU, 76 us: the bins are latency-, not issue-bound).
+template <typename T>
+int try_fwd_box(const T *feat, float *out, const float *rois, int num_rois, float scale, float scale_d, int ns, int C, int D,
+                int H, int W, int PD, int PH, int PW, const LevelTable &lt, hipStream_t stream) {
+  static const int mode = getenv("MR3D_ROIALIGN_BOX") ? atoi(getenv("MR3D_ROIALIGN_BOX")) : 1;
+  static const int lds_env = getenv("MR3D_ROIALIGN_BOX_LDS") ? atoi(getenv("MR3D_ROIALIGN_BOX_LDS")) : 0;
+  static const int pdc_env = getenv("MR3D_ROIALIGN_BOX_PDC") ? atoi(getenv("MR3D_ROIALIGN_BOX_PDC")) : 0;
+  if (mode <= 0 || (mode == 1 && PD > 4)) return MR3D_ERR_UNSUPPORTED;
+  if (C % 64 != 0 || ns <= 0 || PD * ns > kStAxis || PH * ns > kStAxis || PW * ns > kStAxis) return MR3D_ERR_UNSUPPORTED;
+  const int budget = lds_env > 0 ? lds_env : 80 * 1024;               // two workgroups per CU
+  const int pdc = pdc_env > 0 ? pdc_env : (PD <= 4 ? PD : 2);
+  if (ns == 2) return launch_fwd_box<T, 2, 64>(feat, out, rois, num_rois, scale, scale_d, ns, C, D, H, W, PD, PH, PW, pdc, budget, lt, stream);
+  return launch_fwd_box<T, 0, 64>(feat, out, rois, num_rois, scale, scale_d, ns, C, D, H, W, PD, PH, PW, pdc, budget, lt, stream);
+}
+
+// ------------------------------------------------------------------------------------------
 // channels-last backward, separable owner-computes variant.  The global-atomic kernel above issues 64 fp32 atomics
 // per output element and runs at the chip's atomic rate (measured 0.9-1.0 TB/s of added bytes: 3-5 ms for the mask
 // extractor).  But the scatter of one RoI is separable: with Wx[x][pw] = sum over the ns samples of bin pw of their
@@ -974,6 +1248,9 @@ extern "C" int mr3d_roi_align3d_forward(const float *features, const float *rois
   hipStream_t stream = mr3d_stream(stream_);
   const int B = pooled_depth * pooled_height * pooled_width;
   if (use_cl(layout, sample_num, pooled_depth, pooled_height, pooled_width)) {
+    const int st1 = try_fwd_box<float>(features, output, rois, num_rois, spatial_scale, spatial_scale_depth, sample_num, channels, depth,
+                                         height, width, pooled_depth, pooled_height, pooled_width, LevelTable{}, stream);
+    if (st1 != MR3D_ERR_UNSUPPORTED) return st1;
     const int st2 = try_fwd_sep<float>(features, output, rois, num_rois, spatial_scale, spatial_scale_depth, sample_num, channels, depth,
                                        height, width, pooled_depth, pooled_height, pooled_width, LevelTable{}, stream);
     if (st2 != MR3D_ERR_UNSUPPORTED) return st2;
@@ -1072,6 +1349,9 @@ extern "C" int mr3d_roi_align3d_forward_ml(const mr3d_roi_level *levels_host, in
   if (!rois || !output) return MR3D_ERR_INVALID_ARG;
   if (!use_cl(MR3D_LAYOUT_NDHWC, sample_num, pooled_depth, pooled_height, pooled_width)) return MR3D_ERR_UNSUPPORTED;
   {
+    const int st1 = try_fwd_box<float>(nullptr, output, rois, num_rois, 0.f, 0.f, sample_num, channels, 1, 1, 1, pooled_depth,
+                                         pooled_height, pooled_width, lt, mr3d_stream(stream_));
+    if (st1 != MR3D_ERR_UNSUPPORTED) return st1;
     const int st2 = try_fwd_sep<float>(nullptr, output, rois, num_rois, 0.f, 0.f, sample_num, channels, 1, 1, 1, pooled_depth,
                                        pooled_height, pooled_width, lt, mr3d_stream(stream_));
     if (st2 != MR3D_ERR_UNSUPPORTED) return st2;
@@ -1135,6 +1415,9 @@ extern "C" int mr3d_roi_align3d_forward_ml_bf16(const mr3d_roi_level *levels_hos
       pooled_width * sample_num > kStAxis)
     return MR3D_ERR_UNSUPPORTED;
   {
+    const int st1 = try_fwd_box<uint16_t>(nullptr, output, rois, num_rois, 0.f, 0.f, sample_num, channels, 1, 1, 1, pooled_depth,
+                                            pooled_height, pooled_width, lt, mr3d_stream(stream_));
+    if (st1 != MR3D_ERR_UNSUPPORTED) return st1;
     const int st2 = try_fwd_sep<uint16_t>(nullptr, output, rois, num_rois, 0.f, 0.f, sample_num, channels, 1, 1, 1, pooled_depth,
                                           pooled_height, pooled_width, lt, mr3d_stream(stream_));
     if (st2 != MR3D_ERR_UNSUPPORTED) return st2;
