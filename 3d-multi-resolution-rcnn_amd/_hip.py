@@ -217,9 +217,21 @@ def multiclass_nms3d(multi_bboxes, multi_scores, score_thr, iou_thr, max_num):
     return dets[:k], labels[:k]
 
 
+_ROI_DTYPES = {torch.float32: 0, torch.float16: 2, torch.float64: 3}      # MR3D_DTYPE_F32 / _F16 / _F64
+
+
 def roi_align3d_forward(features, rois, out_d, out_h, out_w, spatial_scale, spatial_scale_depth, sample_num, output):
     layout = feature_layout(features)
     N, C, D, H, W = features.shape
+    if features.dtype != torch.float32:          # double / half: features, rois and output share the type (roi_align_kernel.cu:323)
+        with torch.cuda.device(features.device):
+            st = lib().mr3d_roi_align3d_forward_dtype(
+                ptr(features), ptr(rois), ctypes.c_int(rois.size(0)), ctypes.c_int(N), ctypes.c_int(C), ctypes.c_int(D),
+                ctypes.c_int(H), ctypes.c_int(W), ctypes.c_int(out_d), ctypes.c_int(out_h), ctypes.c_int(out_w),
+                ctypes.c_float(spatial_scale), ctypes.c_float(spatial_scale_depth), ctypes.c_int(sample_num),
+                ctypes.c_int(layout), ctypes.c_int(_ROI_DTYPES[features.dtype]), ptr(output), stream_ptr(features.device))
+        check(st, 'mr3d_roi_align3d_forward_dtype')
+        return
     with torch.cuda.device(features.device):
         st = lib().mr3d_roi_align3d_forward(
             ptr(features), ptr(rois), ctypes.c_int(rois.size(0)), ctypes.c_int(N), ctypes.c_int(C), ctypes.c_int(D),
@@ -233,6 +245,16 @@ def roi_align3d_backward(top_grad, rois, out_d, out_h, out_w, spatial_scale, spa
                          bottom_grad, bug_compat=True):
     layout = feature_layout(bottom_grad)
     N, C, D, H, W = bottom_grad.shape
+    if bottom_grad.dtype != torch.float32:
+        with torch.cuda.device(bottom_grad.device):
+            st = lib().mr3d_roi_align3d_backward_dtype(
+                ptr(top_grad), ptr(rois), ctypes.c_int(rois.size(0)), ctypes.c_int(N), ctypes.c_int(C), ctypes.c_int(D),
+                ctypes.c_int(H), ctypes.c_int(W), ctypes.c_int(out_d), ctypes.c_int(out_h), ctypes.c_int(out_w),
+                ctypes.c_float(spatial_scale), ctypes.c_float(spatial_scale_depth), ctypes.c_int(sample_num),
+                ctypes.c_int(layout), ctypes.c_int(ROIALIGN_BUG_COMPAT if bug_compat else 0),
+                ctypes.c_int(_ROI_DTYPES[bottom_grad.dtype]), ptr(bottom_grad), stream_ptr(bottom_grad.device))
+        check(st, 'mr3d_roi_align3d_backward_dtype')
+        return
     with torch.cuda.device(bottom_grad.device):
         st = lib().mr3d_roi_align3d_backward(
             ptr(top_grad), ptr(rois), ctypes.c_int(rois.size(0)), ctypes.c_int(N), ctypes.c_int(C), ctypes.c_int(D),

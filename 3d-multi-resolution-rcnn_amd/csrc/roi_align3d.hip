@@ -16,6 +16,7 @@
 //               [bin][channel] tile is transposed through LDS so the [R,C,PD,PH,PW] output /
 //               top_grad side is accessed in 256-B runs as well.
 #include "mr3d_common.h"
+#include <hip/hip_fp16.h>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -164,6 +165,118 @@ __global__ __launch_bounds__(256) void roi_align3d_bwd_generic(long long total, 
         }
       }
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// typed generic forms.  The reference dispatches float / double / half (AT_DISPATCH_FLOATING_TYPES_AND_HALF,
+// roi_align_kernel.cu:323,674): features, rois and output share the element type T.  double computes in double; half
+// computes in fp32 and rounds once per output element (forward) / per atomic add (backward; a 32-bit compare-and-swap on the
+// word holding the half, as the reference's gpuAtomicAdd(Half*) does) -- the reference rounds after every half operation.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float rd_as(const __half *p, float) { return __half2float(*p); }
+__device__ __forceinline__ double rd_as(const double *p, double) { return *p; }
+__device__ __forceinline__ void wr_as(__half *p, float v) { *p = __float2half(v); }
+__device__ __forceinline__ void wr_as(double *p, double v) { *p = v; }
+__device__ __forceinline__ void add_as(double *p, double v) { atomicAdd(p, v); }
+__device__ __forceinline__ void add_as(__half *p, float v) {
+  unsigned int *word = reinterpret_cast<unsigned int *>(reinterpret_cast<size_t>(p) & ~(size_t)3);
+  const bool hi = (reinterpret_cast<size_t>(p) & 2) != 0;
+  unsigned int old = *word, assumed;
+  do {
+    assumed = old;
+    const unsigned short cur = hi ? (unsigned short)(assumed >> 16) : (unsigned short)(assumed & 0xffffu);
+    const unsigned short nxt = __half_as_ushort(__float2half(__half2float(__ushort_as_half(cur)) + v));
+    const unsigned int repl = hi ? ((assumed & 0xffffu) | ((unsigned int)nxt << 16)) : ((assumed & 0xffff0000u) | nxt);
+    old = atomicCAS(word, assumed, repl);
+  } while (old != assumed);
+}
+
+template <typename A>
+struct RoiGeomT {
+  int b;
+  A sw, sh, sd, bw, bh, bd;
+  int nw, nh, nd;
+};
+
+template <typename T, typename A>
+__device__ __forceinline__ RoiGeomT<A> roi_geom_t(const T *roi, A scale, A scale_d, int sample_num, int PD, int PH, int PW) {
+  RoiGeomT<A> g;
+  const A zero = 0, one = 1;
+  g.b = (int)rd_as(roi, zero);
+  g.sw = rd_as(roi + 1, zero) * scale;
+  g.sh = rd_as(roi + 2, zero) * scale;
+  const A ew = (rd_as(roi + 3, zero) + one) * scale, eh = (rd_as(roi + 4, zero) + one) * scale;
+  g.sd = rd_as(roi + 5, zero) * scale_d;
+  const A ed = (rd_as(roi + 6, zero) + one) * scale_d;
+  const A rw = ew - g.sw > zero ? ew - g.sw : zero, rh = eh - g.sh > zero ? eh - g.sh : zero, rd = ed - g.sd > zero ? ed - g.sd : zero;
+  g.bd = rd / PD; g.bh = rh / PH; g.bw = rw / PW;
+  g.nd = sample_num > 0 ? sample_num : (int)ceil(rd / PD);
+  g.nh = sample_num > 0 ? sample_num : (int)ceil(rh / PH);
+  g.nw = sample_num > 0 ? sample_num : (int)ceil(rw / PW);
+  return g;
+}
+
+template <typename A>
+struct AxisTapT { int lo, hi; A l, h; };
+
+template <typename A>
+__device__ __forceinline__ bool axis_tap_t(A v, int dim, AxisTapT<A> &t) {
+  if (v < (A)-1 || v > (A)dim) return false;
+  if (v <= 0) v = 0;
+  const int lo = (int)v;
+  if (lo >= dim - 1) { t.hi = t.lo = dim - 1; v = (A)t.lo; }
+  else { t.lo = lo; t.hi = lo + 1; }
+  t.l = v - (A)t.lo;
+  t.h = (A)1 - t.l;
+  return true;
+}
+
+template <typename T, typename A, bool kBackward>
+__global__ __launch_bounds__(256) void roi_align3d_typed(long long total, const T *feat_or_top, const T *__restrict__ rois, A scale,
+                                                        A scale_d, int sample_num, int C, int D, int H, int W, int PD, int PH, int PW,
+                                                        Strides st, int bug_compat, T *out_or_bottom) {
+  for (long long index = (long long)blockIdx.x * blockDim.x + threadIdx.x; index < total; index += (long long)blockDim.x * gridDim.x) {
+    const int pw = (int)(index % PW), ph = (int)((index / PW) % PH), pd = (int)((index / PW / PH) % PD);
+    const int c = (int)((index / PW / PH / PD) % C), n = (int)(index / PW / PH / PD / C);
+    const RoiGeomT<A> g = roi_geom_t<T, A>(rois + (size_t)n * 7, scale, scale_d, sample_num, PD, PH, PW);
+    const long long base = g.b * st.n + c * st.c;
+    const A count = (A)(g.nd * g.nh * g.nw);
+    A acc = 0, tg = 0;
+    if (kBackward) {
+      const long long off = (long long)(n * C + c) * PD * PH * PW + (bug_compat ? pd * PD * PW : pd * PH * PW) + ph * PW + pw;
+      tg = rd_as(feat_or_top + off, acc);
+    }
+    for (int iz = 0; iz < g.nd; ++iz) {
+      AxisTapT<A> tz;
+      const bool vz = axis_tap_t<A>(g.sd + pd * g.bd + (A)(iz + .5f) * g.bd / (A)g.nd, D, tz);
+      for (int iy = 0; iy < g.nh; ++iy) {
+        AxisTapT<A> ty;
+        const bool vy = axis_tap_t<A>(g.sh + ph * g.bh + (A)(iy + .5f) * g.bh / (A)g.nh, H, ty);
+        for (int ix = 0; ix < g.nw; ++ix) {
+          AxisTapT<A> tx;
+          const bool vx = axis_tap_t<A>(g.sw + pw * g.bw + (A)(ix + .5f) * g.bw / (A)g.nw, W, tx);
+          if (!(vz && vy && vx)) continue;
+          const long long zl = base + tz.lo * st.d, zh = base + tz.hi * st.d;
+          const long long yl = ty.lo * st.h, yh = ty.hi * st.h, xl = tx.lo * st.w, xh = tx.hi * st.w;
+          const A w1 = tx.h * ty.h * tz.h, w5 = tx.h * ty.h * tz.l, w2 = tx.l * ty.h * tz.h, w6 = tx.l * ty.h * tz.l;
+          const A w3 = tx.h * ty.l * tz.h, w7 = tx.h * ty.l * tz.l, w4 = tx.l * ty.l * tz.h, w8 = tx.l * ty.l * tz.l;
+          if (!kBackward) {
+            const T *f = feat_or_top;
+            acc += (w1 * rd_as(f + zl + yl + xl, acc) + w2 * rd_as(f + zl + yl + xh, acc) + w3 * rd_as(f + zl + yh + xl, acc) +
+                    w4 * rd_as(f + zl + yh + xh, acc) + w5 * rd_as(f + zh + yl + xl, acc) + w6 * rd_as(f + zh + yl + xh, acc) +
+                    w7 * rd_as(f + zh + yh + xl, acc) + w8 * rd_as(f + zh + yh + xh, acc));
+          } else {
+            T *bt = out_or_bottom;
+            add_as(bt + zl + yl + xl, tg * w1 / count); add_as(bt + zl + yl + xh, tg * w2 / count);
+            add_as(bt + zl + yh + xl, tg * w3 / count); add_as(bt + zl + yh + xh, tg * w4 / count);
+            add_as(bt + zh + yl + xl, tg * w5 / count); add_as(bt + zh + yl + xh, tg * w6 / count);
+            add_as(bt + zh + yh + xl, tg * w7 / count); add_as(bt + zh + yh + xh, tg * w8 / count);
+          }
+        }
+      }
+    }
+    if (!kBackward) wr_as(out_or_bottom + index, acc / count);
   }
 }
 
@@ -1317,6 +1430,65 @@ extern "C" int mr3d_roi_align3d_backward(const float *top_grad, const float *roi
                                                       strides_for(layout, channels, depth, height, width), bug,
                                                       bottom_grad);
   }
+  return mr3d_launch_status();
+}
+
+extern "C" int mr3d_roi_align3d_forward_dtype(const void *features, const void *rois, int num_rois, int batch, int channels, int depth,
+                                              int height, int width, int pooled_depth, int pooled_height, int pooled_width,
+                                              float spatial_scale, float spatial_scale_depth, int sample_num, int layout, int dtype,
+                                              void *output, mr3d_stream_t stream_) {
+  if (dtype == MR3D_DTYPE_F32)
+    return mr3d_roi_align3d_forward(static_cast<const float *>(features), static_cast<const float *>(rois), num_rois, batch, channels,
+                                    depth, height, width, pooled_depth, pooled_height, pooled_width, spatial_scale,
+                                    spatial_scale_depth, sample_num, layout, static_cast<float *>(output), stream_);
+  if (dtype != MR3D_DTYPE_F16 && dtype != MR3D_DTYPE_F64) return MR3D_ERR_INVALID_ARG;
+  const int st = check_common(features, rois, output, num_rois, batch, channels, depth, height, width, pooled_depth, pooled_height,
+                              pooled_width, sample_num, layout);
+  if (st != MR3D_OK) return st;
+  if (num_rois == 0) return MR3D_OK;
+  hipStream_t stream = mr3d_stream(stream_);
+  const long long total = (long long)num_rois * channels * pooled_depth * pooled_height * pooled_width;
+  const long long blocks = (total + 255) / 256;
+  const int grid = (int)(blocks < 65536 ? blocks : 65536);
+  const Strides sd = strides_for(layout, channels, depth, height, width);
+  if (dtype == MR3D_DTYPE_F64)
+    roi_align3d_typed<double, double, false><<<grid, 256, 0, stream>>>(total, static_cast<const double *>(features),
+        static_cast<const double *>(rois), (double)spatial_scale, (double)spatial_scale_depth, sample_num, channels, depth, height, width,
+        pooled_depth, pooled_height, pooled_width, sd, 0, static_cast<double *>(output));
+  else
+    roi_align3d_typed<__half, float, false><<<grid, 256, 0, stream>>>(total, static_cast<const __half *>(features),
+        static_cast<const __half *>(rois), spatial_scale, spatial_scale_depth, sample_num, channels, depth, height, width,
+        pooled_depth, pooled_height, pooled_width, sd, 0, static_cast<__half *>(output));
+  return mr3d_launch_status();
+}
+
+extern "C" int mr3d_roi_align3d_backward_dtype(const void *top_grad, const void *rois, int num_rois, int batch, int channels, int depth,
+                                               int height, int width, int pooled_depth, int pooled_height, int pooled_width,
+                                               float spatial_scale, float spatial_scale_depth, int sample_num, int layout, int flags,
+                                               int dtype, void *bottom_grad, mr3d_stream_t stream_) {
+  if (dtype == MR3D_DTYPE_F32)
+    return mr3d_roi_align3d_backward(static_cast<const float *>(top_grad), static_cast<const float *>(rois), num_rois, batch, channels,
+                                     depth, height, width, pooled_depth, pooled_height, pooled_width, spatial_scale,
+                                     spatial_scale_depth, sample_num, layout, flags, static_cast<float *>(bottom_grad), stream_);
+  if (dtype != MR3D_DTYPE_F16 && dtype != MR3D_DTYPE_F64) return MR3D_ERR_INVALID_ARG;
+  const int st = check_common(top_grad, rois, bottom_grad, num_rois, batch, channels, depth, height, width, pooled_depth,
+                              pooled_height, pooled_width, sample_num, layout);
+  if (st != MR3D_OK) return st;
+  if (num_rois == 0) return MR3D_OK;
+  hipStream_t stream = mr3d_stream(stream_);
+  const int bug = (flags & MR3D_ROIALIGN_BUG_COMPAT) ? 1 : 0;
+  const long long total = (long long)num_rois * channels * pooled_depth * pooled_height * pooled_width;
+  const long long blocks = (total + 255) / 256;
+  const int grid = (int)(blocks < 65536 ? blocks : 65536);
+  const Strides sd = strides_for(layout, channels, depth, height, width);
+  if (dtype == MR3D_DTYPE_F64)
+    roi_align3d_typed<double, double, true><<<grid, 256, 0, stream>>>(total, static_cast<const double *>(top_grad),
+        static_cast<const double *>(rois), (double)spatial_scale, (double)spatial_scale_depth, sample_num, channels, depth, height, width,
+        pooled_depth, pooled_height, pooled_width, sd, bug, static_cast<double *>(bottom_grad));
+  else
+    roi_align3d_typed<__half, float, true><<<grid, 256, 0, stream>>>(total, static_cast<const __half *>(top_grad),
+        static_cast<const __half *>(rois), spatial_scale, spatial_scale_depth, sample_num, channels, depth, height, width,
+        pooled_depth, pooled_height, pooled_width, sd, bug, static_cast<__half *>(bottom_grad));
   return mr3d_launch_status();
 }
 

@@ -6,17 +6,23 @@ import torch
 from ... import _hip
 
 
-def _check(t, name):
+_DTYPES = (torch.float32, torch.float64, torch.float16)      # AT_DISPATCH_FLOATING_TYPES_AND_HALF (roi_align_kernel.cu:323,674)
+
+
+def _check(t, name, like=None):
     # CHECK_INPUT = CHECK_CUDA + CHECK_CONTIGUOUS (roi_align_cuda.cpp:34-39) -> RuntimeError
     if not t.is_cuda:
         raise RuntimeError(f'{name} must be a CUDAtensor ')
-    if t.dtype != torch.float32:
-        raise RuntimeError(f'{name} must be float32 (half/double are not built for gfx950 yet)')
+    if t.dtype not in _DTYPES:
+        raise RuntimeError(f'{name} must be float32, float64 or float16')
+    if like is not None and t.dtype != like.dtype:
+        # the reference reads all three through data<scalar_t>() of the features' type
+        raise RuntimeError(f'{name} must have the dtype of the features ({like.dtype})')
 
 
 def forward3d(features, rois, pooled_depth, pooled_height, pooled_width, spatial_scale, spatial_scale_depth,
               sample_num, output):
-    _check(features, 'features'); _check(rois, 'rois'); _check(output, 'output')
+    _check(features, 'features'); _check(rois, 'rois', features); _check(output, 'output', features)
     if not (rois.is_contiguous() and output.is_contiguous()):
         raise RuntimeError('rois/output must be contiguous ')
     if rois.dim() != 2 or rois.size(1) != 7:
@@ -30,7 +36,7 @@ def forward3d(features, rois, pooled_depth, pooled_height, pooled_width, spatial
 
 def backward3d(top_grad, rois, pooled_depth, pooled_height, pooled_width, spatial_scale, spatial_scale_depth,
                sample_num, bottom_grad, bug_compat=True):
-    _check(top_grad, 'top_grad'); _check(rois, 'rois'); _check(bottom_grad, 'bottom_grad')
+    _check(top_grad, 'top_grad'); _check(rois, 'rois', top_grad); _check(bottom_grad, 'bottom_grad', top_grad)
     if not (rois.is_contiguous() and top_grad.is_contiguous()):
         raise RuntimeError('rois/top_grad must be contiguous ')
     if rois.dim() != 2 or rois.size(1) != 7:

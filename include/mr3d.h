@@ -114,6 +114,24 @@ int mr3d_roi_align3d_backward(const float *top_grad, const float *rois, int num_
                               float spatial_scale, float spatial_scale_depth, int sample_num,
                               int layout, int flags, float *bottom_grad, mr3d_stream_t stream);
 
+/* Typed forms: the reference dispatches float, double and half (AT_DISPATCH_FLOATING_TYPES_AND_HALF,
+ * roi_align_kernel.cu:323,674); features / top_grad, rois and output / bottom_grad share the element type `dtype`.
+ * MR3D_DTYPE_F32 forwards to the calls above; MR3D_DTYPE_F64 computes in double (double atomics); MR3D_DTYPE_F16 computes in
+ * fp32 and rounds once per output element / per accumulated contribution (a compare-and-swap on the 32-bit word holding the
+ * half, like the reference's gpuAtomicAdd(Half*); the reference rounds after every half operation).  Both take the
+ * one-lane-per-output-element kernels (any layout). */
+#define MR3D_DTYPE_F32 0
+#define MR3D_DTYPE_F16 2
+#define MR3D_DTYPE_F64 3
+int mr3d_roi_align3d_forward_dtype(const void *features, const void *rois, int num_rois, int batch, int channels, int depth,
+                                   int height, int width, int pooled_depth, int pooled_height, int pooled_width,
+                                   float spatial_scale, float spatial_scale_depth, int sample_num, int layout, int dtype,
+                                   void *output, mr3d_stream_t stream);
+int mr3d_roi_align3d_backward_dtype(const void *top_grad, const void *rois, int num_rois, int batch, int channels, int depth,
+                                    int height, int width, int pooled_depth, int pooled_height, int pooled_width,
+                                    float spatial_scale, float spatial_scale_depth, int sample_num, int layout, int flags,
+                                    int dtype, void *bottom_grad, mr3d_stream_t stream);
+
 /* Multi-level form = the whole SingleRoIExtractor.forward / backward (mmdet/models/roi_extractors/single_level.py:58-104)
  * in ONE launch without a host round trip: every RoI reads (scatters into) the pyramid level its size maps to --
  * scale = sqrt(w*h*d) (the square root of the VOLUME, :73-76), level = clamp(floor(log2(scale / finest_scale + 1e-6)))

@@ -141,6 +141,52 @@ def test_roi_align3d_forward_backward_vs_oracle(dev, fmt, C, P, sample_num):
         np.testing.assert_allclose(f.grad.cpu().numpy(), expb, rtol=RTOL, atol=RTOL * np.abs(expb).max())
 
 
+@pytest.mark.parametrize('fmt', [torch.contiguous_format, torch.channels_last_3d])
+def test_roi_align3d_double_and_half_dispatch(dev, fmt):
+    """The reference dispatches float, double and half (roi_align_kernel.cu:323,674): features, rois and output share the type.
+    double: against the float64 restatement (forward) and its autograd gradient (the correct backward); half: against the
+    fp32 oracle on the half-rounded inputs, at half resolution."""
+    from mr3d_amd.mmdet_ops import RoIAlign3D
+    rng = np.random.default_rng(11)
+    N, C, D, H, W = 2, 6, 8, 20, 18
+    P = (2, 5, 4)
+    feat32 = rng.normal(size=(N, C, D, H, W)).astype(np.float32)
+    rois = ri.rand_rois(rng, 21, N, (W * 4, H * 4, D * 2), max_xy=70, max_z=14)
+    rois[0, 1:] = [-20, -20, 30, 30, -6, 8]
+    rois[1, 1:] = [10, 10, 10, 10, 3, 3]
+    top = rng.normal(size=(21, C) + P).astype(np.float32)
+    # ---- double
+    f = torch.from_numpy(feat32.astype(np.float64)).to(dev).contiguous(memory_format=fmt).requires_grad_(True)
+    layer = RoIAlign3D((P[1], P[2]), P[0], 0.25, 0.5, sample_num=2, bug_compat=False)
+    out = layer(f, torch.from_numpy(rois.astype(np.float64)).to(dev))
+    assert out.dtype == torch.float64
+    exp = ri.roi_align3d_f64(feat32, rois, *P, 0.25, 0.5, 2)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), exp, rtol=1e-12, atol=1e-12)
+    out.backward(torch.from_numpy(top.astype(np.float64)).to(dev))
+    ft = torch.from_numpy(feat32.astype(np.float64)).requires_grad_(True)
+    ri.roi_align3d_torch(ft, torch.from_numpy(rois), *P, 0.25, 0.5, 2).backward(torch.from_numpy(top.astype(np.float64)))
+    assert f.grad.dtype == torch.float64 and f.grad.is_contiguous(memory_format=fmt)
+    np.testing.assert_allclose(f.grad.cpu().numpy(), ft.grad.numpy(), rtol=1e-11, atol=1e-11)
+    # ---- half (roi coordinates are kept to values a half holds exactly: integers below 2048)
+    rois_h = np.round(rois).astype(np.float32)
+    feat_h = feat32.astype(np.float16)
+    fh = torch.from_numpy(feat_h).to(dev).contiguous(memory_format=fmt).requires_grad_(True)
+    for bug in (True, False):
+        layer = RoIAlign3D((P[1], P[2]), P[0], 0.25, 0.5, sample_num=2, bug_compat=bug)
+        fh.grad = None
+        outh = layer(fh, torch.from_numpy(rois_h.astype(np.float16)).to(dev))
+        assert outh.dtype == torch.float16
+        exph = orc.roi_align3d_forward(feat_h.astype(np.float32), rois_h, *P, 0.25, 0.5, 2)
+        np.testing.assert_allclose(outh.detach().float().cpu().numpy(), exph, rtol=2e-3, atol=2e-3)
+        top_h = top.astype(np.float16)
+        outh.backward(torch.from_numpy(top_h).to(dev))
+        expb = orc.roi_align3d_backward(top_h.astype(np.float32), rois_h, feat_h.shape, 0.25, 0.5, 2, bug_compat=bug)
+        # every accumulated contribution is rounded to half: error ~ (number of contributions) x half ulp of the sum
+        np.testing.assert_allclose(fh.grad.float().cpu().numpy(), expb, rtol=2e-2, atol=2e-2 * np.abs(expb).max())
+    with pytest.raises(RuntimeError):            # mixed types: the reference reads everything as the features' scalar_t
+        layer(fh, torch.from_numpy(rois_h).to(dev))
+
+
 def test_roi_align3d_benchmark_shapes_properties(dev):
     """Full BASELINE sizes (512 rois x 64 ch x (3,7,7) on a P2-sized map): properties that need no oracle run:
     a constant feature map pools to the same constant wherever all taps are in range, and the

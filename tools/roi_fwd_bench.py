@@ -36,6 +36,7 @@ def timed(fn, iters=20):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--bf16', action='store_true')
+    ap.add_argument('--backward', action='store_true', help='also time forward + backward (fp32 features)')
     ap.add_argument('--sizes', default='', help='xy_lo,xy_hi,z_lo,z_hi in pixels: log-uniform roi sizes instead of the SURVEY 8(d) ranges')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
@@ -58,6 +59,16 @@ def main():
         r = torch.from_numpy(r_host).to(dev)
         us = timed(lambda: ext(feats, r))
         lb, wr, rd = bench.roialign_lb_bytes(r_host, 64, od, osz, osz)
+        if a.backward and not a.bf16:
+            fg = [f.clone().requires_grad_(True) for f in feats]
+            top = torch.randn(n, 64, od, osz, osz, device=dev)
+
+            def fb():
+                for f in fg:
+                    f.grad = None
+                ext(fg, r).backward(top)
+            fbus = timed(fb, iters=10)
+            print(f'{tag}: forward + backward {fbus:8.1f} us (backward ~{fbus - us:.1f})')
         print(f'{tag}: {us:8.1f} us   LB {lb / 1e6:6.1f} MB   {lb / us * 1e-6:5.2f} TB/s   {lb / us * 1e-6 / 8.0:5.3f} of the HBM roof'
               f'   checksum {float(ext(feats, r).double().sum()):.6f}')
 
