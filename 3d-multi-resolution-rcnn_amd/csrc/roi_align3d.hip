@@ -1300,6 +1300,197 @@ __global__ __launch_bounds__(kClThreads) void roi_align3d_bwd_box(const float *_
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// channels-last backward, voxel-owner form (C % 64 == 0).  A workgroup owns (RoI, 64 channels, a chunk of pooled depths): the
+// chunk's top-gradient planes are staged once as G[bin][64 ch] in LDS, the per-axis weight matrices Wx[x][pw] (Wy, Wz alike:
+// the summed tap weights of bin pw on voxel x) are built once together with the range of bins that reach each voxel (the
+// bins touching a voxel are consecutive), and then every voxel of the RoI's footprint is evaluated by 16 lanes x float4
+// channels:   dX[z][y][x] = 1/count * sum_{pd in range(z)} Wz[z][pd] * sum_{ph in range(y)} Wy[y][ph] * sum_{pw in range(x)} Wx[x][pw] * G[pd][ph][pw]
+// -- on the SURVEY 8(d) rois ~8 non-zero terms per voxel, where the scatter form issues 64 atomics per output element and
+// the separable sub-box kernel above pays four barriers per pooled depth and (sub-box, 16 channels) item.  One global atomic per
+// touched voxel-channel (RoIs overlap).  No plan kernel, no sub-boxes; footprints longer than 64 voxels on an axis are walked
+// in 64-voxel segments.  Same weights as the scatter form (l / h of axis_tap, dropped samples contribute nothing); the fp32
+// sums are associated differently (per voxel instead of per atomic arrival order).
+// ------------------------------------------------------------------------------------------
+constexpr int kVxSeg = 64;                 // voxels per axis covered by one set of weight matrices
+constexpr int kVxRow = 68;                 // floats per G row: 64 channels + 4 (16-byte aligned rows, 4-way instead of 32-way store conflicts)
+
+__host__ __device__ inline int vox_lds_bytes(int pdc, int PH, int PW) {
+  return 3 * kStAxis * 16 + 64 + (kVxSeg * (PW + PH + pdc)) * 4 + 3 * kVxSeg * 8 + 16 * 64 * 4 + pdc * PH * PW * kVxRow * 4;
+}
+
+__global__ __launch_bounds__(kClThreads) void roi_align3d_bwd_vox(const float *__restrict__ top, float *bottom,
+                                                                 const float *__restrict__ rois, float scale, float scale_d,
+                                                                 int ns, int C, int D, int H, int W, int PD, int PH, int PW,
+                                                                 int pdc, int parts, int bug_compat, LevelTable lt) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char vx_lds[];
+  IdxEntry *tabx = reinterpret_cast<IdxEntry *>(vx_lds), *taby = tabx + kStAxis, *tabz = taby + kStAxis;
+  int *ext = reinterpret_cast<int *>(tabz + kStAxis);                 // x0,nx, y0,ny, z0,nz
+  float *Wx = reinterpret_cast<float *>(vx_lds + 3 * kStAxis * 16 + 64), *Wy = Wx + kVxSeg * PW, *Wz = Wy + kVxSeg * PH;
+  int2 *rx = reinterpret_cast<int2 *>(Wz + kVxSeg * pdc), *ry = rx + kVxSeg, *rz = ry + kVxSeg;   // [first, last] bin per voxel
+  float *F = reinterpret_cast<float *>(rz + kVxSeg);                  // [16 voxel slots][64 channels]: flush transpose, per wave
+  float *G = F + 16 * 64;                                             // [local bin][kVxRow]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = tid & 15, slot = tid >> 4;                            // float4 of channels, voxel slot
+  const int r = blockIdx.x, c0 = blockIdx.y * 64, pd0 = ((int)blockIdx.z / parts) * pdc;
+  int part = (int)blockIdx.z % parts;
+  const int pd1 = min(pd0 + pdc, PD), npd = pd1 - pd0;
+  if (lt.num) {
+    const int lvl = roi_level(rois + (size_t)r * 7, lt.finest_scale, lt.num);
+    D = pick4(lvl, lt.D); H = pick4(lvl, lt.H); W = pick4(lvl, lt.W);
+    scale = pick4(lvl, lt.scale); scale_d = pick4(lvl, lt.scale_d);
+    bottom = pick4(lvl, lt.grad);
+  }
+  const RoiGeom g = roi_geom(rois + (size_t)r * 7, scale, scale_d, ns, PD, PH, PW);
+  // `parts` workgroups share the voxel passes of a LARGE footprint (every workgroup of the launch is resident at once, so the
+  // launch lasts as long as its largest RoI); a small one is done by part 0 alone.  The rule only has to be the same in all
+  // parts: an upper bound of the footprint from the RoI's size.
+  if (parts > 1) {
+    const float bound = (fminf(ceilf(g.bw * PW), (float)W) + 2.f) * (fminf(ceilf(g.bh * PH), (float)H) + 2.f) *
+                        (fminf(ceilf(g.bd * npd), (float)D) + 2.f);
+    if (bound <= 384.f) {
+      if (part > 0) return;
+      parts = 1;
+    }
+  }
+  const int B = PD * PH * PW, PHW = PH * PW;
+  const float inv_count = 1.f / (float)(ns * ns * ns);
+  // ---- this chunk's top-gradient planes -> G[(pd - pd0) * PHW + ph * PW + pw][channel], pre-divided by the sample count.
+  // The RoI's [64][B] block is walked flat (coalesced dwords); the reference's index bug reads plane pd at pd*PD*PW.
+  {
+    const float *src = top + ((size_t)r * C + c0) * B;
+    const int nb = npd * PHW;
+    for (int lb0 = 0; lb0 < nb; lb0 += MR3D_WAVE) {                  // a wave = 64 consecutive bins of one channel: 256-byte runs
+      const int lb = lb0 + lane;
+      const int pd = pd0 + lb / PHW, rem = lb % PHW;
+      const int off = (bug_compat ? pd * PD * PW : pd * PHW) + rem;
+      if (lb < nb) {
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = src[(size_t)(wave + 4 * k) * B + off];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) G[lb * kVxRow + wave + 4 * k] = v[k] * inv_count;
+      }
+    }
+  }
+  build_idx_table(tabx, g.sw, g.bw, PW, ns, W, tid, kClThreads);
+  build_idx_table(taby, g.sh, g.bh, PH, ns, H, tid, kClThreads);
+  build_idx_table(tabz, g.sd, g.bd, PD, ns, D, tid, kClThreads);
+  __syncthreads();
+  if (tid < 3) {            // voxel range of the valid samples along x, y (all bins) and z (this chunk's pooled depths)
+    const IdxEntry *tab = tid == 0 ? tabx : (tid == 1 ? taby : tabz);
+    const int a = tid == 2 ? pd0 * ns : 0, b = tid == 0 ? PW * ns : (tid == 1 ? PH * ns : pd1 * ns);
+    int mn = 0x7fffffff, mx = -1;
+    for (int e = a; e < b; ++e)
+      if (tab[e].l + tab[e].h != 0.f) { mn = min(mn, tab[e].lo); mx = max(mx, tab[e].hi); }
+    ext[2 * tid] = mx < 0 ? 0 : mn;
+    ext[2 * tid + 1] = mx < 0 ? 0 : mx - mn + 1;
+  }
+  __syncthreads();
+  const int x0 = ext[0], nx = ext[1], y0 = ext[2], ny = ext[3], z0 = ext[4], nz = ext[5];
+  if (nx == 0 || ny == 0 || nz == 0) return;                         // nothing of this chunk lands in the map (uniform)
+  const float4 *Gq = reinterpret_cast<const float4 *>(G) + q;
+
+  // weight matrix + bin range of one axis segment: one thread per voxel index
+  auto build_axis = [&](float *Wm, int2 *rng, const IdxEntry *tab, int p0, int np, int v0, int vn, int t) {
+    if (t < vn) {
+      int first = np, last = -1;
+      for (int p = 0; p < np; ++p) {
+        float a = 0.f;
+        for (int i = 0; i < ns; ++i) {
+          const IdxEntry te = tab[(p0 + p) * ns + i];
+          if (te.l + te.h == 0.f) continue;
+          if (te.lo == v0 + t) a += te.h;
+          if (te.hi == v0 + t) a += te.l;
+        }
+        Wm[t * np + p] = a;
+        if (a != 0.f) { first = min(first, p); last = p; }
+      }
+      rng[t] = make_int2(first, last);
+    }
+  };
+  for (int zs = 0; zs < nz; zs += kVxSeg)
+    for (int ys = 0; ys < ny; ys += kVxSeg)
+      for (int xs = 0; xs < nx; xs += kVxSeg) {
+        const int sz = min(kVxSeg, nz - zs), sy = min(kVxSeg, ny - ys), sx = min(kVxSeg, nx - xs);
+        __syncthreads();                                             // the previous segment is done with the matrices
+        if (tid < 64) build_axis(Wx, rx, tabx, 0, PW, x0 + xs, sx, tid);
+        else if (tid < 128) build_axis(Wy, ry, taby, 0, PH, y0 + ys, sy, tid - 64);
+        else if (tid < 192) build_axis(Wz, rz, tabz, pd0, npd, z0 + zs, sz, tid - 128);
+        __syncthreads();
+        const int nvox = sz * sy * sx;
+        for (int vb = part * (kClThreads / 16); vb < nvox; vb += parts * (kClThreads / 16)) {      // 16 voxels per pass, 4 per wave
+          const int v = vb + slot;
+          const bool live = v < nvox;
+          const int vv = live ? v : 0;
+          const int x = vv % sx, y = (vv / sx) % sy, z = vv / (sx * sy);
+          int2 bz = rz[z], by = ry[y], bx = rx[x];
+          if (!live) bz.y = bz.x - 1;                                   // empty range
+          v2f a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+          for (int pd = bz.x; pd <= bz.y; ++pd) {
+            const float wz = Wz[z * npd + pd];
+            for (int ph = by.x; ph <= by.y; ++ph) {
+              const float wzy = wz * Wy[y * PH + ph];
+              const float4 *row = Gq + (size_t)((pd * PH + ph) * PW) * (kVxRow / 4);
+              for (int pw = bx.x; pw <= bx.y; ++pw) {
+                const float w = wzy * Wx[x * PW + pw];
+                const float4 gv = row[pw * (kVxRow / 4)];
+                a0 += w * (v2f){gv.x, gv.y};
+                a1 += w * (v2f){gv.z, gv.w};
+              }
+            }
+          }
+          // flush: the wave's 4 voxels x 64 channels go through LDS so that one atomic instruction adds the 64 consecutive
+          // channels of ONE voxel (the full-rate atomic shape; 16 lanes x 4 strided dwords ran at 0.4 of it)
+          *reinterpret_cast<float4 *>(F + slot * 64 + q * 4) = make_float4(a0.x, a0.y, a1.x, a1.y);
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int vk = v - (slot & 3) + k;                       // voxel of the wave's k-th slot in this pass
+            if (vk < nvox) {
+              const int xk = vk % sx, yk = (vk / sx) % sy, zk = vk / (sx * sy);
+              const float val = F[(wave * 4 + k) * 64 + lane];
+              if (val != 0.f)
+                atomicAdd(bottom + (size_t)g.b * D * H * W * C + ((((size_t)(z0 + zs + zk)) * H + (y0 + ys + yk)) * W + (x0 + xs + xk)) * C + c0 + lane, val);
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+}
+
+// the voxel-owner backward for a pooled shape: MR3D_ERR_UNSUPPORTED = not applicable (the caller takes the plan + sub-box path)
+int try_bwd_vox(const float *top, float *bottom, const float *rois, int num_rois, float scale, float scale_d, int ns, int C, int D,
+                int H, int W, int PD, int PH, int PW, int bug, const LevelTable &lt, hipStream_t stream) {
+  static const int off = getenv("MR3D_ROIALIGN_BWD_VOX") ? !atoi(getenv("MR3D_ROIALIGN_BWD_VOX")) : 0;
+  static const int lds_env = getenv("MR3D_ROIALIGN_BWD_VOX_LDS") ? atoi(getenv("MR3D_ROIALIGN_BWD_VOX_LDS")) : 0;
+  if (off || C % 64 != 0 || ns <= 0 || PD * ns > kStAxis || PH * ns > kStAxis || PW * ns > kStAxis) return MR3D_ERR_UNSUPPORTED;
+  const int budget = lds_env > 0 ? lds_env : 80 * 1024;               // two workgroups per CU
+  int pdc = PD;
+  while (pdc > 1 && vox_lds_bytes(pdc, PH, PW) > budget) --pdc;
+  const int lds = vox_lds_bytes(pdc, PH, PW);
+  if (lds > 160 * 1024) return MR3D_ERR_UNSUPPORTED;
+  static std::mutex mu;
+  static int attr_bytes = 0;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    if (lds > attr_bytes) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void *>(roi_align3d_bwd_vox), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+        (void)hipGetLastError();
+        return MR3D_ERR_LAUNCH;
+      }
+      attr_bytes = lds;
+    }
+  }
+  static const int parts_env = getenv("MR3D_ROIALIGN_BWD_VOX_PARTS") ? atoi(getenv("MR3D_ROIALIGN_BWD_VOX_PARTS")) : 0;
+  const int chunks = (PD + pdc - 1) / pdc;
+  const int parts = parts_env > 0 ? parts_env : (chunks == 1 ? 3 : 1);   // bbox extractor: 105 (1 part) -> 84 -> 76 us; mask extractor (10 chunks): 1
+  dim3 grid(num_rois, C / 64, chunks * parts);
+  roi_align3d_bwd_vox<<<grid, kClThreads, lds, stream>>>(top, bottom, rois, scale, scale_d, ns, C, D, H, W, PD, PH, PW, pdc, parts, bug, lt);
+  return mr3d_launch_status();
+}
+
 // persistent scratch of the backward plan: [0] item counter, [1 .. 1+R) owned flags, then R*kMaxSub items
 // plan scratch of the separable backward: one buffer per (device, stream) -- calls on the same stream are ordered, so
 // they may share it; another stream or another GPU gets its own (a process-global buffer raced there).  Growing a buffer
@@ -1401,6 +1592,9 @@ extern "C" int mr3d_roi_align3d_backward(const float *top_grad, const float *roi
   const int bug = (flags & MR3D_ROIALIGN_BUG_COMPAT) ? 1 : 0;
   const int B = pooled_depth * pooled_height * pooled_width;
   if (use_cl(layout, sample_num, pooled_depth, pooled_height, pooled_width)) {
+    const int stv = try_bwd_vox(top_grad, bottom_grad, rois, num_rois, spatial_scale, spatial_scale_depth, sample_num, channels, depth,
+                                height, width, pooled_depth, pooled_height, pooled_width, bug, LevelTable{}, stream);
+    if (stv != MR3D_ERR_UNSUPPORTED) return stv;
     dim3 grid(num_rois, (B + kClBins - 1) / kClBins);
     int *scratch = box_shape_ok(pooled_depth, pooled_height, pooled_width) ? box_scratch(num_rois, stream) : nullptr;
     int *owned = nullptr;
@@ -1552,6 +1746,11 @@ extern "C" int mr3d_roi_align3d_backward_ml(const mr3d_roi_level *levels_host, i
   hipStream_t stream = mr3d_stream(stream_);
   const int bug = (flags & MR3D_ROIALIGN_BUG_COMPAT) ? 1 : 0;
   const int B = pooled_depth * pooled_height * pooled_width;
+  {
+    const int stv = try_bwd_vox(top_grad, nullptr, rois, num_rois, 0.f, 0.f, sample_num, channels, 1, 1, 1, pooled_depth, pooled_height,
+                                pooled_width, bug, lt, stream);
+    if (stv != MR3D_ERR_UNSUPPORTED) return stv;
+  }
   int *scratch = box_shape_ok(pooled_depth, pooled_height, pooled_width) ? box_scratch(num_rois, stream) : nullptr;
   int *owned = nullptr;
   if (scratch) {

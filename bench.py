@@ -266,11 +266,15 @@ def ops_microbench(dev):
             for f in feats:
                 f.grad = None
             ext(feats, r).backward(top)
-        out[f'roialign3d_{tag}_fwd_bwd_us'] = timed(fb, iters=5)
-        # backward LB = read top_grad + read-modify-write of the touched voxels (2x the read term)
+        out[f'roialign3d_{tag}_fwd_bwd_us'] = timed(fb, iters=5)          # through autograd: + zero-fill of the 4 level gradients
+        # the backward launch alone (mr3d_roi_align3d_backward_ml into the same pre-zeroed buffers: adds accumulate, timing only).
+        # backward LB = read top_grad + read-modify-write of the touched voxels (2x the forward's read term)
+        grads = [torch.zeros_like(f) for f in feats]
+        scales, scales_d = [1.0 / s_ for s_ in (4, 8, 16, 32)], [1.0 / s_ for s_ in (2, 4, 8, 16)]
+        out[f'roialign3d_{tag}_bwd_us'] = timed(lambda: _h.roi_align3d_backward_ml(top, r, grads, od, osz, osz, scales, scales_d, 2, 56.0))
         lb_b = wr + 2 * rd
-        bwd_us = max(out[f'roialign3d_{tag}_fwd_bwd_us'] - out[f'roialign3d_{tag}_fwd_us'], 1e-3)
-        out[f'roialign3d_{tag}_bwd_hbm_frac'] = lb_b / bwd_us * 1e-6 / 8.0
+        out[f'roialign3d_{tag}_bwd_lb_mbytes'] = lb_b / 1e6
+        out[f'roialign3d_{tag}_bwd_hbm_frac'] = lb_b / out[f'roialign3d_{tag}_bwd_us'] * 1e-6 / 8.0
     return out
 
 

@@ -68,7 +68,13 @@ def main():
                     f.grad = None
                 ext(fg, r).backward(top)
             fbus = timed(fb, iters=10)
-            print(f'{tag}: forward + backward {fbus:8.1f} us (backward ~{fbus - us:.1f})')
+            from mr3d_amd import _hip
+            grads = [torch.zeros_like(f) for f in feats]
+            bus = timed(lambda: _hip.roi_align3d_backward_ml(top, r, grads, od, osz, osz, [1 / 4, 1 / 8, 1 / 16, 1 / 32],
+                                                             [1 / 2, 1 / 4, 1 / 8, 1 / 16], 2, 56.0))
+            lb_f, wr_f, rd_f = bench.roialign_lb_bytes(r_host, 64, od, osz, osz)
+            print(f'{tag}: forward + backward through autograd {fbus:8.1f} us; backward launch alone {bus:8.1f} us = '
+                  f'{(wr_f + 2 * rd_f) / bus * 1e-6 / 8.0:5.3f} of the HBM roof of its {(wr_f + 2 * rd_f) / 1e6:.1f} MB')
         print(f'{tag}: {us:8.1f} us   LB {lb / 1e6:6.1f} MB   {lb / us * 1e-6:5.2f} TB/s   {lb / us * 1e-6 / 8.0:5.3f} of the HBM roof'
               f'   checksum {float(ext(feats, r).double().sum()):.6f}')
 
