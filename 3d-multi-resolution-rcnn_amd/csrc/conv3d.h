@@ -45,6 +45,10 @@ int mr3d_reduce_partials(const float *part, int nparts, int G, int R, int NBc, i
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
+// two-dimensional Winograd form of the 3x3x3 / stride-1 convolution (conv3d_wino2d.hip): F(4,3) along W x F(2,3) along H
+bool mr3d_conv3d_wino2d_ok(const Conv3dFwdArgs &a);
+int mr3d_conv3d_wino2d(const Conv3dFwdArgs &a, hipStream_t stream);
+
 // streaming pointwise instances (pointwise.hip); MR3D_ERR_UNSUPPORTED = use the generic kernels
 int mr3d_pointwise_fwd_try(const Conv3dFwdArgs &a, hipStream_t stream, bool probe_only = false);
 int mr3d_pointwise_wgrad_try(const Conv3dWgradArgs &a, hipStream_t stream);

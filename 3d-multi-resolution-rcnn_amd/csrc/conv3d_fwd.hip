@@ -462,10 +462,22 @@ int dispatch_tile(const Conv3dFwdArgs &a, hipStream_t stream) {
     // outputs = 64 pair rows keep the accumulators at 64 registers and two workgroups per CU (P2 3x3x3 64->64:
     // 1.19 -> 1.02 ms; the 4x8x8 form needs 128 accumulator registers, one workgroup per CU: 1.11 ms).
     // The 16-wide single-chunk kernel (layer1) gains nothing from it (96 vs 96 TFLOP/s: not MFMA-bound).
-    static const int wino = getenv("MR3D_FWD_WINO") ? atoi(getenv("MR3D_FWD_WINO")) : 3;     // 0: direct form only; 1: F(2,3) 2x8x8 only; 2: + F(2,3) 4x8x8; 3: F(4,3) 4x8x8
+    static const int wino = getenv("MR3D_FWD_WINO") ? atoi(getenv("MR3D_FWD_WINO")) : 4;     // 0: direct form only; 1: F(2,3) 2x8x8 only; 2: + F(2,3) 4x8x8; 3: F(4,3) 4x8x8; 4: + F(4,3) x F(2,3) on large maps
     // 4x8x8 outputs = 128 pair rows: 128 accumulator registers; without the next-chunk register prefetch it still fits
     // two workgroups per CU, which hide each other's staging: P2 0.91 ms (159 TFLOP/s of algorithmic work)
     static const int min43 = getenv("MR3D_FWD_WINO43_MIN") ? atoi(getenv("MR3D_FWD_WINO43_MIN")) : 256;   // P3 (320 tiles): 0.164 -> 0.157 ms
+    // 4: F(4,3) along W x F(2,3) along H (conv3d_wino2d.hip) on maps with >= min2d tiles of 2x8x8: P2 64->64 834 -> 720 us,
+    // backbone step 12.52 -> 12.10 ms, with P3 (640 tiles) as well 12.04 ms
+    static const int min2d = getenv("MR3D_FWD_WINO2D_MIN") ? atoi(getenv("MR3D_FWD_WINO2D_MIN")) : 256;
+    if (wino >= 4 && wgs(2, 8, 8) >= min2d && mr3d_conv3d_wino2d_ok(a)) {
+      if (g_variant_probe) {
+        mr3d_conv3d_variant &v = *g_variant_probe;
+        v.streaming_pointwise = 0; v.winograd = 8; v.tile_d = 2; v.tile_h = 8; v.tile_w = 8; v.cin_chunk = 16; v.cout_tile = 64;
+        v.parity_decomposed = 0; v.mfma_issue_factor = 1.f / 3.f;
+        return MR3D_OK;
+      }
+      return mr3d_conv3d_wino2d(a, stream);
+    }
     if (wino >= 3 && wgs(4, 8, 8) >= min43) return launch_fwd<FwdCfg<3, 3, 3, 1, 1, 1, 4, 8, 8, CC, NB, false, false, 4>>(a, stream);
     if (wino >= 2 && wgs(4, 8, 8) >= 512) return launch_fwd<FwdCfg<3, 3, 3, 1, 1, 1, 4, 8, 8, CC, NB, false, false, 2>>(a, stream);
     static const int wino_min = getenv("MR3D_FWD_WINO_MIN") ? atoi(getenv("MR3D_FWD_WINO_MIN")) : 256;   // 16-roi mask batches (320 tiles): 133 -> 109 us

@@ -1,0 +1,265 @@
+// 3x3x3 / stride-1 convolution (forward and, with flipped transposed weights, data gradient) as a TWO-dimensional Winograd
+// form on the fp32 matrix cores: F(4,3) along W x F(2,3) along H.  Same contract as conv3d_fwd.hip's kernels (Conv3dFwdArgs:
+// NDHWC fp32 activations, [tap][Cin][Cout] weights, the fused epilogue: shift / residual adds / nearest-upsample add / ReLU /
+// ReLU mask / strided output grid); replaces cuDNN's conv3d of the FPN output convs and the RPN conv on the large maps
+// (mmdet/models/necks/fpn3d.py:56-64,111-113, anchor_heads/rpn_head_3d.py:19-24) where the one-dimensional F(4,3) kernel of
+// conv3d_fwd.hip issues 1/2 of the algorithmic MFMA work: this form issues 1/3.
+//
+// A GEMM row is a 2 (h) x 4 (w) patch of outputs.  Per kd tap and input channel the patch needs the 4 x 6 input window d;
+//   V = Bh^T d Bw        (24 values; Bh^T = F(2,3)'s (d0-d2, d1+d2, d2-d1, d1-d3), Bw^T = Lavin & Gray's F(4,3) matrix)
+//   U = Gh g Gw^T        (24 values per (kd, ci, co), from the 3 x 3 (kh, kw) taps g: computed once per launch by
+//                         wino2d_weights_kernel into a scratch buffer, [kd][Cin][6][Cout][4]: product f = fh*6+fw at [f/4][co][f%4])
+//   M[fh][fw] += V[fh][fw] * U[fh][fw]   summed over kd and ci on the matrix cores: 24 accumulator sets,
+//   Y = Ah^T M Aw        (8 outputs) in the epilogue -- 72 MFMA products per 8 outputs and input channel instead of 216 (direct)
+//                         or 108 (F(4,3) along W only).
+// v_mfma_f32_16x16x4_f32: a wave owns 16 GEMM rows x 16 output channels (24 x 4 accumulator registers); the four waves of a
+// workgroup share the 16 rows (2 x 8 x 8 outputs) and split a 64-wide Cout tile, so every wave forms the same V from the LDS
+// halo ([4][10][10] positions x 16 channels per Cin chunk, odd row pitch) -- 88 VALU operations per 24 MFMAs (768 matrix-pipe
+// cycles) -- and reads its own U fragments straight from L2, one (kd, k-step) ahead.
+#include "conv3d.h"
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <utility>
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int MT = 1;                                  // MFMA tiles (16 GEMM rows = 2 output planes) per wave
+constexpr int TD = 2 * MT, TH = 8, TW = 8;             // output tile
+constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;   // halo
+constexpr int HHP = HH + 1;                            // one spare row per halo plane: 2-way instead of 3-way LDS bank conflicts
+constexpr int CC = 16, ROW = CC + 1;                   // Cin chunk, LDS row pitch in floats
+constexpr int HP = HD * HHP * HW;
+constexpr int LDS_BYTES = HP * ROW * 4;
+constexpr int NF = 24;                                 // products per patch and kd tap
+
+// U(kd, f = fh*6+fw, ci, co) = sum_kh sum_kw Gh[fh][kh] Gw[fw][kw] w[(kd*3+kh)*3+kw][ci][co]
+__global__ __launch_bounds__(256) void wino2d_weights_kernel(const float *__restrict__ w, float *__restrict__ U, int cin, int cout) {
+  const int e = blockIdx.x * 256 + threadIdx.x;          // (kd, ci, co)
+  if (e >= 3 * cin * cout) return;
+  const int kd = e / (cin * cout), cc = e - kd * (cin * cout);
+  float g[3][3];
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) g[kh][kw] = w[(size_t)((kd * 3 + kh) * 3 + kw) * cin * cout + cc];
+  float t[3][6];                                         // along W first: t[kh][fw]
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const float g0 = g[kh][0], g1 = g[kh][1], g2 = g[kh][2];
+    const float s02 = g0 + g2, h = g0 * (1.f / 24.f) + g2 * (1.f / 6.f), q = g1 * (1.f / 12.f);
+    t[kh][0] = 0.25f * g0; t[kh][1] = (s02 + g1) * (-1.f / 6.f); t[kh][2] = (s02 - g1) * (-1.f / 6.f);
+    t[kh][3] = h + q; t[kh][4] = h - q; t[kh][5] = g2;
+  }
+#pragma unroll
+  for (int fw = 0; fw < 6; ++fw) {
+    const float a = t[0][fw], b = t[1][fw], c = t[2][fw];
+    const float u[4] = {a, 0.5f * ((a + c) + b), 0.5f * ((a + c) - b), c};
+#pragma unroll
+    for (int fh = 0; fh < 4; ++fh) {                       // [kd][ci][f / 4][co][f % 4]: a lane's four consecutive products in 16 bytes
+      const int f = fh * 6 + fw, ci = cc / cout, co = cc - ci * cout;
+      U[((((size_t)kd * cin + ci) * (NF / 4) + f / 4) * cout + co) * 4 + (f & 3)] = u[fh];
+    }
+  }
+}
+
+__global__ __launch_bounds__(kThreads, MT == 1 ? 2 : 1) void conv3d_wino2d_kernel(Conv3dFwdArgs p, const float *__restrict__ U, int tiles_d,
+                                                                   int tiles_h, int tiles_w) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int b = blockIdx.x;
+  const int tw_i = b % tiles_w; b /= tiles_w;
+  const int th_i = b % tiles_h; b /= tiles_h;
+  const int td_i = b % tiles_d; b /= tiles_d;
+  const int n = b;
+  const int od0 = td_i * TD, oh0 = th_i * TH, ow0 = tw_i * TW;
+  const int id0 = od0 - p.pd, ih0 = oh0 - p.ph, iw0 = ow0 - p.pw;
+  const int li = lane & 15, lk = lane >> 4;
+  const int co = blockIdx.y * 64 + wave * 16 + li;
+  // A operand: this lane's GEMM row (li) = patch (td, th2, tw4) and its k index inside the k-step (lk)
+  const int abase = ((((li >> 3) * HHP) + ((li >> 1) & 3) * 2) * HW + (li & 1) * 4) * ROW + lk;
+  const float *ul = U + ((size_t)lk * (NF / 4) * p.Cout + co) * 4;
+
+  f32x4 acc[MT][NF];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int f = 0; f < NF; ++f) acc[mt][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float b0[NF], b1[NF], a0[MT][NF], a1[MT][NF], d[MT][4][6];
+  auto load_b = [&](float (&dst)[NF], int c0, int kd, int kk) {
+    const float *src = ul + ((size_t)kd * p.Cin + c0 + kk * 4) * (NF / 4) * p.Cout * 4;
+#pragma unroll
+    for (int f4 = 0; f4 < NF / 4; ++f4) {
+      const float4 v = *reinterpret_cast<const float4 *>(src + (size_t)f4 * p.Cout * 4);
+      dst[f4 * 4] = v.x; dst[f4 * 4 + 1] = v.y; dst[f4 * 4 + 2] = v.z; dst[f4 * 4 + 3] = v.w;
+    }
+  };
+  auto read_d = [&](int kd, int kk) {                    // the 4 x 6 input window of this lane's patch and channel
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const float *src = lds + abase + ((kd + 2 * mt) * HHP * HW) * ROW + kk * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) d[mt][i][j] = src[(i * HW + j) * ROW];
+    }
+  };
+  auto xform = [&](int mt, int fh, float (&dst)[NF]) {   // row fh of V = Bh^T d Bw
+    float t[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+      t[j] = fh == 0 ? d[mt][0][j] - d[mt][2][j] : (fh == 1 ? d[mt][1][j] + d[mt][2][j] : (fh == 2 ? d[mt][2][j] - d[mt][1][j] : d[mt][1][j] - d[mt][3][j]));
+    const float e = t[4] - t[2], o = t[3] - t[1];
+    dst[fh * 6 + 0] = 4.f * t[0] - 5.f * t[2] + t[4];
+    dst[fh * 6 + 1] = (t[3] + t[4]) - 4.f * (t[1] + t[2]);
+    dst[fh * 6 + 2] = (t[4] - t[3]) + 4.f * (t[1] - t[2]);
+    dst[fh * 6 + 3] = e + 2.f * o;
+    dst[fh * 6 + 4] = e - 2.f * o;
+    dst[fh * 6 + 5] = 4.f * t[1] - 5.f * t[3] + t[5];
+  };
+  auto mma = [&](int mt, int fh, const float (&av)[NF], const float (&bw)[NF]) {
+#pragma unroll
+    for (int fw = 0; fw < 6; ++fw)
+      acc[mt][fh * 6 + fw] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[fh * 6 + fw], bw[fh * 6 + fw], acc[mt][fh * 6 + fw], 0, 0, 0);
+  };
+  // one (kd, k-step): the 24 MFMAs of step s on (av, bw), interleaved with the transform of step s + 1's window into an
+  // (its LDS reads and the U fragments of step s + 1 are requested first) -- the wave's own VALU work rides in the shadow
+  // of its MFMAs instead of waiting for the other wave of the SIMD to be out of phase
+  auto step = [&](int s, int c0, const float (&av)[MT][NF], const float (&bw)[NF], float (&an)[MT][NF], float (&bnx)[NF]) {
+    const bool more = s + 1 < 12;
+    if (more) load_b(bnx, c0, (s + 1) / 4, (s + 1) % 4);
+    else if (c0 + CC < p.Cin) load_b(bnx, c0 + CC, 0, 0);
+    if (more) read_d((s + 1) / 4, (s + 1) % 4);
+    __builtin_amdgcn_sched_barrier(0);                   // the requests stay up here: the scheduler would sink them next to their uses
+#pragma unroll
+    for (int fh = 0; fh < 4; ++fh)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        mma(mt, fh, av[mt], bw);
+        if (more) xform(mt, fh, an[mt]);
+      }
+  };
+
+  constexpr int Q = CC / 4;
+  constexpr int NIT = (HD * HH * HW * Q + kThreads - 1) / kThreads;
+  load_b(b0, 0, 0, 0);
+  for (int c0 = 0; c0 < p.Cin; c0 += CC) {
+    __syncthreads();
+    {
+      float4 stage[NIT];
+#pragma unroll
+      for (int j = 0; j < NIT; ++j) {
+        const int it = tid + j * kThreads;
+        const int pos = it / Q, q = it - pos * Q;
+        const int hw = pos % HW, hh = (pos / HW) % HH, hd = pos / (HW * HH);
+        const int id = id0 + hd, ih = ih0 + hh, iw = iw0 + hw;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (it < HD * HH * HW * Q && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
+          v = *reinterpret_cast<const float4 *>(p.x + ((((size_t)n * p.D + id) * p.H + ih) * p.W + iw) * p.Cin + c0 + q * 4);
+        stage[j] = v;
+      }
+#pragma unroll
+      for (int j = 0; j < NIT; ++j) {
+        const int it = tid + j * kThreads;
+        if (it < HD * HH * HW * Q) {
+          const int pos = it / Q, q = it - pos * Q;
+          const int hw = pos % HW, hh = (pos / HW) % HH, hd = pos / (HW * HH);
+          float *dd = lds + ((hd * HHP + hh) * HW + hw) * ROW + q * 4;
+          dd[0] = stage[j].x; dd[1] = stage[j].y; dd[2] = stage[j].z; dd[3] = stage[j].w;
+        }
+      }
+    }
+    __syncthreads();
+    read_d(0, 0);                                         // the chunk's first window: exposed once per chunk
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int fh = 0; fh < 4; ++fh) xform(mt, fh, a0[mt]);
+    // 12 (kd, k-step) steps per chunk; after an even number of steps the live buffers are (a0, b0) again
+#pragma unroll
+    for (int s = 0; s < 12; s += 2) {
+      step(s, c0, a0, b0, a1, b1);
+      step(s + 1, c0, a1, b1, a0, b0);
+    }
+  }
+
+  // ---- epilogue: Y = Ah^T M Aw per accumulator element, then shift / adds / upsample add / ReLU / mask; NDHWC store
+  const float sh = p.shift ? p.shift[co] : 0.f;
+  auto emit = [&](int od, int oh, int ow, float val) {
+    if (od < p.Do && oh < p.Ho && ow < p.Wo) {
+      const size_t idx = ((((size_t)n * p.yD + od * p.ysd) * p.yH + oh * p.ysh) * p.yW + ow * p.ysw) * p.Cout + co;
+      float v = val + sh;
+      if (p.add1) v += p.add1[idx];
+      if (p.add2) v += p.add2[idx];
+      if (p.up) {
+        auto nearest = [](int dst, int in, int out) {          // torch nearest: min(floor(dst * (in/out)), in-1)
+          const int s_ = (int)floorf((float)dst * ((float)in / (float)out));
+          return s_ < in - 1 ? s_ : in - 1;
+        };
+        const int ud = nearest(od, p.Du, p.Do), uh = nearest(oh, p.Hu, p.Ho), uw = nearest(ow, p.Wu, p.Wo);
+        v += p.up[((((size_t)n * p.Du + ud) * p.Hu + uh) * p.Wu + uw) * p.Cout + co];
+      }
+      if (p.relu) v = fmaxf(v, 0.f);
+      if (p.mask) v = p.mask[idx] > 0.f ? v : 0.f;
+      p.y[idx] = v;
+    }
+  };
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = lk * 4 + r;
+    const int od = od0 + 2 * mt + (row >> 3), oh = oh0 + ((row >> 1) & 3) * 2, ow = ow0 + (row & 1) * 4;
+    float z[4][4];                                       // along W: z[fh][x]
+#pragma unroll
+    for (int fh = 0; fh < 4; ++fh) {
+      const float m0 = acc[mt][fh * 6][r], m1 = acc[mt][fh * 6 + 1][r], m2 = acc[mt][fh * 6 + 2][r], m3 = acc[mt][fh * 6 + 3][r],
+                  m4 = acc[mt][fh * 6 + 4][r], m5 = acc[mt][fh * 6 + 5][r];
+      const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+      z[fh][0] = (m0 + s12) + s34; z[fh][1] = d12 + 2.f * d34; z[fh][2] = s12 + 4.f * s34; z[fh][3] = (d12 + 8.f * d34) + m5;
+    }
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      emit(od, oh, ow + x, (z[0][x] + z[1][x]) + z[2][x]);
+      emit(od, oh + 1, ow + x, (z[1][x] - z[2][x]) - z[3][x]);
+    }
+  }
+}
+
+// U scratch: one buffer per (device, stream) -- launches on one stream are ordered, so they may share it
+struct Scratch { float *p = nullptr; size_t floats = 0; };
+std::mutex g_mu;
+std::map<std::pair<int, hipStream_t>, Scratch> g_scratch;
+float *u_scratch(size_t floats, hipStream_t stream) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(g_mu);
+  Scratch &s = g_scratch[{dev, stream}];
+  if (floats > s.floats) {
+    if (s.p) (void)hipFree(s.p);
+    s.p = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&s.p), floats * sizeof(float)) != hipSuccess) { s.floats = 0; return nullptr; }
+    s.floats = floats;
+  }
+  return s.p;
+}
+
+}  // namespace
+
+bool mr3d_conv3d_wino2d_ok(const Conv3dFwdArgs &a) {
+  return a.Cin % CC == 0 && a.Cout % 64 == 0 && a.Do == a.D + 2 * a.pd - 2 && a.Ho == a.H + 2 * a.ph - 2 && a.Wo == a.W + 2 * a.pw - 2;
+}
+
+int mr3d_conv3d_wino2d(const Conv3dFwdArgs &a, hipStream_t stream) {
+  float *U = u_scratch((size_t)3 * NF * a.Cin * a.Cout, stream);
+  if (!U) return MR3D_ERR_LAUNCH;
+  const int nw = 3 * a.Cin * a.Cout;
+  wino2d_weights_kernel<<<(nw + 255) / 256, 256, 0, stream>>>(a.w, U, a.Cin, a.Cout);
+  const int tiles_d = (a.Do + TD - 1) / TD, tiles_h = (a.Ho + TH - 1) / TH, tiles_w = (a.Wo + TW - 1) / TW;
+  dim3 grid((unsigned)(a.N * tiles_d * tiles_h * tiles_w), (unsigned)(a.Cout / 64));
+  conv3d_wino2d_kernel<<<grid, kThreads, LDS_BYTES, stream>>>(a, U, tiles_d, tiles_h, tiles_w);
+  return mr3d_launch_status();
+}

@@ -495,7 +495,8 @@ def main():
                 v = _hip.op_conv_variant(op)
                 factor = float(v.mfma_issue_factor)
                 tag = ('streaming pointwise' if v.streaming_pointwise else
-                       (f'winograd F({v.winograd},3) along W' if v.winograd else 'direct') +
+                       ('winograd F(4,3) along W x F(2,3) along H' if v.winograd == 8 else
+                        (f'winograd F({v.winograd},3) along W' if v.winograd else 'direct')) +
                        f' tile {v.tile_d}x{v.tile_h}x{v.tile_w} cout {v.cout_tile}')
             issued_flops += fl * factor
             variants[tag] = variants.get(tag, 0) + 1

@@ -188,11 +188,11 @@ int mr3d_conv3d_forward(const mr3d_conv3d_desc *desc, mr3d_stream_t stream);
  * convolution's algorithmic FLOPs (2*MAC) as MFMA work. */
 typedef struct {
   int streaming_pointwise;      /* 1: the HBM-bound 1x1x1 streaming kernel (csrc/pointwise.hip) */
-  int winograd;                 /* 0 direct, 2 = F(2,3) along W, 4 = F(4,3) along W */
+  int winograd;                 /* 0 direct, 2 = F(2,3) along W, 4 = F(4,3) along W, 8 = F(4,3) along W x F(2,3) along H */
   int tile_d, tile_h, tile_w;   /* output positions per workgroup */
   int cin_chunk, cout_tile;
   int parity_decomposed;
-  float mfma_issue_factor;      /* MFMA FLOPs issued / algorithmic FLOPs: 1, 2/3 or 1/2 */
+  float mfma_issue_factor;      /* MFMA FLOPs issued / algorithmic FLOPs: 1, 2/3, 1/2 or 1/3 */
 } mr3d_conv3d_variant;
 int mr3d_conv3d_forward_variant(const mr3d_conv3d_desc *desc, mr3d_conv3d_variant *out);
 

@@ -93,6 +93,32 @@ def test_conv3d_forward_fused_epilogue(dev):
     _check(y3, ref3, 'fused upsample odd')
 
 
+def test_conv3d_forward_winograd_2d_large_map(dev):
+    """3x3x3 64 -> 64 on a map with >= 256 tiles of 2x8x8 takes the F(4,3) x F(2,3) kernel (csrc/conv3d_wino2d.hip): odd
+    extents (partial tiles on every axis), the whole fused epilogue, and the data-gradient use (ReLU mask) against an fp64 conv"""
+    from mr3d_amd import _hip
+    g = torch.Generator().manual_seed(5)
+    dhw = (17, 45, 51)
+    x = torch.randn((1, 64) + dhw, generator=g)
+    w = torch.randn((64, 64, 3, 3, 3), generator=g) / np.sqrt(64 * 27)
+    shift = torch.randn(64, generator=g)
+    add1 = torch.randn((1, 64) + dhw, generator=g)
+    up = torch.randn((1, 64, 9, 23, 26), generator=g)
+    mask = torch.randn((1, 64) + dhw, generator=g)
+    conv = F.conv3d(x.double(), w.double(), shift.double(), 1, 1)
+    ref = torch.relu(conv + add1.double() + F.interpolate(up.double(), size=dhw, mode='nearest'))
+    wp = _hip.pack_conv_weight(w).to(dev)
+    y = _hip.conv3d_forward(_cl(x).to(dev), wp, (3, 3, 3), (1, 1, 1), (1, 1, 1), shift=shift.to(dev), add1=_cl(add1).to(dev),
+                            up=_cl(up).to(dev), relu=True)
+    _check(y, ref.float(), 'winograd 2d fused relu')
+    ref2 = (conv + add1.double()) * (mask > 0)
+    y2 = _hip.conv3d_forward(_cl(x).to(dev), wp, (3, 3, 3), (1, 1, 1), (1, 1, 1), shift=shift.to(dev), add1=_cl(add1).to(dev),
+                             mask=_cl(mask).to(dev))
+    _check(y2, ref2.float(), 'winograd 2d fused mask')
+    l2 = ((y2.permute(0, 4, 1, 2, 3).cpu().double() - ref2).norm() / ref2.norm()).item()
+    assert l2 <= 1e-5, f'L2-relative error {l2:.3e}'
+
+
 def test_conv3d_unsupported_is_loud(dev):
     from mr3d_amd import _hip
     x = torch.zeros((1, 2, 4, 4, 12), device=dev)      # Cin = 12
