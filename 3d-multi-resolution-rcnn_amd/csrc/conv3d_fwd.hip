@@ -466,8 +466,8 @@ int dispatch_tile(const Conv3dFwdArgs &a, hipStream_t stream) {
     // 4x8x8 outputs = 128 pair rows: 128 accumulator registers; without the next-chunk register prefetch it still fits
     // two workgroups per CU, which hide each other's staging: P2 0.91 ms (159 TFLOP/s of algorithmic work)
     static const int min43 = getenv("MR3D_FWD_WINO43_MIN") ? atoi(getenv("MR3D_FWD_WINO43_MIN")) : 256;   // P3 (320 tiles): 0.164 -> 0.157 ms
-    // 4: F(4,3) along W x F(2,3) along H (conv3d_wino2d.hip) on maps with >= min2d tiles of 2x8x8: P2 64->64 834 -> 720 us,
-    // backbone step 12.52 -> 12.10 ms, with P3 (640 tiles) as well 12.04 ms
+    // 4: F(4,3) along W x F(2,3) along H (conv3d_wino2d.hip) on maps with >= min2d tiles of 2x8x8: P2 64->64 834 -> 640-660 us,
+    // backbone step 12.52 -> 11.8 ms (P3, 640 tiles, included)
     static const int min2d = getenv("MR3D_FWD_WINO2D_MIN") ? atoi(getenv("MR3D_FWD_WINO2D_MIN")) : 256;
     if (wino >= 4 && wgs(2, 8, 8) >= min2d && mr3d_conv3d_wino2d_ok(a)) {
       if (g_variant_probe) {

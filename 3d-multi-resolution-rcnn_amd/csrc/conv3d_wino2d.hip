@@ -13,9 +13,12 @@
 //   Y = Ah^T M Aw        (8 outputs) in the epilogue -- 72 MFMA products per 8 outputs and input channel instead of 216 (direct)
 //                         or 108 (F(4,3) along W only).
 // v_mfma_f32_16x16x4_f32: a wave owns 16 GEMM rows x 16 output channels (24 x 4 accumulator registers); the four waves of a
-// workgroup share the 16 rows (2 x 8 x 8 outputs) and split a 64-wide Cout tile, so every wave forms the same V from the LDS
-// halo ([4][10][10] positions x 16 channels per Cin chunk, odd row pitch) -- 88 VALU operations per 24 MFMAs (768 matrix-pipe
-// cycles) -- and reads its own U fragments straight from L2, one (kd, k-step) ahead.
+// workgroup share the 16 rows (2 x 8 x 8 outputs) and split a 64-wide Cout tile.  Per Cin chunk (16 channels) the workgroup
+// stages the halo ([4][10][10] positions, odd row pitch) in LDS, forms V ONCE for its 4 planes x 8 patches x 16 channels
+// (two items per thread, 88 VALU operations each) into a second LDS region laid out for conflict-free fragment reads, and then
+// runs 12 (kd, k-step) steps of 24 MFMAs whose A fragments are plain LDS reads (one step ahead) and whose U fragments come
+// straight from L2, two steps ahead (an L2 round trip is longer than one step).  The halo of the next chunk is fetched at the
+// chunk boundary (the second workgroup of the CU covers it; fetching it piecewise under the MFMA steps was measured equal).
 #include "conv3d.h"
 #include <cstdlib>
 #include <map>
@@ -25,13 +28,15 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int MT = 1;                                  // MFMA tiles (16 GEMM rows = 2 output planes) per wave
-constexpr int TD = 2 * MT, TH = 8, TW = 8;             // output tile
+constexpr int TD = 2, TH = 8, TW = 8;                  // output tile: 16 GEMM rows (patches of 2 x 4 outputs)
 constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;   // halo
 constexpr int HHP = HH + 1;                            // one spare row per halo plane: 2-way instead of 3-way LDS bank conflicts
 constexpr int CC = 16, ROW = CC + 1;                   // Cin chunk, LDS row pitch in floats
 constexpr int HP = HD * HHP * HW;
-constexpr int LDS_BYTES = HP * ROW * 4;
+constexpr int NFC = 24;
+constexpr int VPITCH = NFC * CC + 2;                    // floats per (plane, patch) of V: 2 * (plane * 8 + patch) + k spreads a read over all 32 banks
+constexpr int VFLOATS = HD * 8 * VPITCH;
+constexpr int LDS_BYTES = (HP * ROW + VFLOATS) * 4;
 constexpr int NF = 24;                                 // products per patch and kd tap
 
 // U(kd, f = fh*6+fw, ci, co) = sum_kh sum_kw Gh[fh][kh] Gw[fw][kw] w[(kd*3+kh)*3+kw][ci][co]
@@ -64,9 +69,10 @@ __global__ __launch_bounds__(256) void wino2d_weights_kernel(const float *__rest
   }
 }
 
-__global__ __launch_bounds__(kThreads, MT == 1 ? 2 : 1) void conv3d_wino2d_kernel(Conv3dFwdArgs p, const float *__restrict__ U, int tiles_d,
+__global__ __launch_bounds__(kThreads, 2) void conv3d_wino2d_kernel(Conv3dFwdArgs p, const float *__restrict__ U, int tiles_d,
                                                                    int tiles_h, int tiles_w) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *vl = lds + HP * ROW;                            // V[(plane * 8 + patch)][f][ci], pitch VPITCH per (plane, patch)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int b = blockIdx.x;
@@ -78,17 +84,15 @@ __global__ __launch_bounds__(kThreads, MT == 1 ? 2 : 1) void conv3d_wino2d_kerne
   const int id0 = od0 - p.pd, ih0 = oh0 - p.ph, iw0 = ow0 - p.pw;
   const int li = lane & 15, lk = lane >> 4;
   const int co = blockIdx.y * 64 + wave * 16 + li;
-  // A operand: this lane's GEMM row (li) = patch (td, th2, tw4) and its k index inside the k-step (lk)
-  const int abase = ((((li >> 3) * HHP) + ((li >> 1) & 3) * 2) * HW + (li & 1) * 4) * ROW + lk;
+  // A operand: this lane's GEMM row li = (output plane li >> 3, patch li & 7) and its k index inside the k-step (lk)
+  const float *vlane = vl + li * VPITCH + lk;
   const float *ul = U + ((size_t)lk * (NF / 4) * p.Cout + co) * 4;
 
-  f32x4 acc[MT][NF];
+  f32x4 acc[NF];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int f = 0; f < NF; ++f) acc[mt][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int f = 0; f < NF; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  float b0[NF], b1[NF], a0[MT][NF], a1[MT][NF], d[MT][4][6];
+  float bq[3][NF], aq[2][NF / 2];
   auto load_b = [&](float (&dst)[NF], int c0, int kd, int kk) {
     const float *src = ul + ((size_t)kd * p.Cin + c0 + kk * 4) * (NF / 4) * p.Cout * 4;
 #pragma unroll
@@ -97,93 +101,99 @@ __global__ __launch_bounds__(kThreads, MT == 1 ? 2 : 1) void conv3d_wino2d_kerne
       dst[f4 * 4] = v.x; dst[f4 * 4 + 1] = v.y; dst[f4 * 4 + 2] = v.z; dst[f4 * 4 + 3] = v.w;
     }
   };
-  auto read_d = [&](int kd, int kk) {                    // the 4 x 6 input window of this lane's patch and channel
+  // half h of step s: products f = 12 h .. 12 h + 11 of V(plane (li >> 3) + kd, this lane's patch, channel kk * 4 + lk)
+  auto load_a = [&](float (&dst)[NF / 2], int s, int h) {
+    const float *src = vlane + (s / 4) * 8 * VPITCH + (s % 4) * 4 + h * (NF / 2) * CC;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const float *src = lds + abase + ((kd + 2 * mt) * HHP * HW) * ROW + kk * 4;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 6; ++j) d[mt][i][j] = src[(i * HW + j) * ROW];
-    }
+    for (int f = 0; f < NF / 2; ++f) dst[f] = src[f * CC];
   };
-  auto xform = [&](int mt, int fh, float (&dst)[NF]) {   // row fh of V = Bh^T d Bw
-    float t[6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j)
-      t[j] = fh == 0 ? d[mt][0][j] - d[mt][2][j] : (fh == 1 ? d[mt][1][j] + d[mt][2][j] : (fh == 2 ? d[mt][2][j] - d[mt][1][j] : d[mt][1][j] - d[mt][3][j]));
-    const float e = t[4] - t[2], o = t[3] - t[1];
-    dst[fh * 6 + 0] = 4.f * t[0] - 5.f * t[2] + t[4];
-    dst[fh * 6 + 1] = (t[3] + t[4]) - 4.f * (t[1] + t[2]);
-    dst[fh * 6 + 2] = (t[4] - t[3]) + 4.f * (t[1] - t[2]);
-    dst[fh * 6 + 3] = e + 2.f * o;
-    dst[fh * 6 + 4] = e - 2.f * o;
-    dst[fh * 6 + 5] = 4.f * t[1] - 5.f * t[3] + t[5];
-  };
-  auto mma = [&](int mt, int fh, const float (&av)[NF], const float (&bw)[NF]) {
-#pragma unroll
-    for (int fw = 0; fw < 6; ++fw)
-      acc[mt][fh * 6 + fw] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[fh * 6 + fw], bw[fh * 6 + fw], acc[mt][fh * 6 + fw], 0, 0, 0);
-  };
-  // one (kd, k-step): the 24 MFMAs of step s on (av, bw), interleaved with the transform of step s + 1's window into an
-  // (its LDS reads and the U fragments of step s + 1 are requested first) -- the wave's own VALU work rides in the shadow
-  // of its MFMAs instead of waiting for the other wave of the SIMD to be out of phase
-  auto step = [&](int s, int c0, const float (&av)[MT][NF], const float (&bw)[NF], float (&an)[MT][NF], float (&bnx)[NF]) {
-    const bool more = s + 1 < 12;
-    if (more) load_b(bnx, c0, (s + 1) / 4, (s + 1) % 4);
-    else if (c0 + CC < p.Cin) load_b(bnx, c0 + CC, 0, 0);
-    if (more) read_d((s + 1) / 4, (s + 1) % 4);
-    __builtin_amdgcn_sched_barrier(0);                   // the requests stay up here: the scheduler would sink them next to their uses
-#pragma unroll
-    for (int fh = 0; fh < 4; ++fh)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        mma(mt, fh, av[mt], bw);
-        if (more) xform(mt, fh, an[mt]);
-      }
-  };
-
   constexpr int Q = CC / 4;
   constexpr int NIT = (HD * HH * HW * Q + kThreads - 1) / kThreads;
-  load_b(b0, 0, 0, 0);
+  // halo staging, piece j of NIT (one float4 per thread): fetch into a register, commit to LDS.  The addresses are
+  // recomputed per use: hoisted out of the chunk loop they sit in 20 registers across the MFMA steps and the kernel spills (a
+  // kernel that touches scratch stalls the queue at its dispatch).
+  auto fetch = [&](int j, int c0) {
+    int tv = tid;
+    asm volatile("" : "+v"(tv));
+    const int it = tv + j * kThreads;
+    const int pos = it / Q, q = it - pos * Q;
+    const int hw = pos % HW, hh = (pos / HW) % HH, hd = pos / (HW * HH);
+    const int id = id0 + hd, ih = ih0 + hh, iw = iw0 + hw;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (it < HD * HH * HW * Q && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
+      v = *reinterpret_cast<const float4 *>(p.x + ((((size_t)n * p.D + id) * p.H + ih) * p.W + iw) * p.Cin + c0 + q * 4);
+    return v;
+  };
+  auto commit = [&](int j, const float4 &v) {
+    int tv = tid;
+    asm volatile("" : "+v"(tv));
+    const int it = tv + j * kThreads;
+    if (it < HD * HH * HW * Q) {
+      const int pos = it / Q, q = it - pos * Q;
+      const int hw = pos % HW, hh = (pos / HW) % HH, hd = pos / (HW * HH);
+      float *dd = lds + ((hd * HHP + hh) * HW + hw) * ROW + q * 4;
+      dd[0] = v.x; dd[1] = v.y; dd[2] = v.z; dd[3] = v.w;
+    }
+  };
+  // one (kd, k-step) s of a chunk in two halves of 12 MFMAs on aq[half & 1] and bq[s % 3]: the A fragments of the next half
+  // (LDS) are requested before a half's MFMAs, the U fragments of step s + 2 (L2) before the step's
+  auto step = [&](int s, int c0) {
+    const int s2 = s + 2;
+    if (s2 < 12) load_b(bq[s2 % 3], c0, s2 / 4, s2 % 4);
+    else if (c0 + CC < p.Cin) load_b(bq[s2 % 3], c0 + CC, (s2 - 12) / 4, (s2 - 12) % 4);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (h == 0) load_a(aq[1], s, 1);
+      else if (s + 1 < 12) load_a(aq[0], s + 1, 0);
+      __builtin_amdgcn_sched_barrier(0);                 // the requests stay up here: the scheduler would sink them next to their uses
+#pragma unroll
+      for (int f = 0; f < NF / 2; ++f)
+        acc[h * (NF / 2) + f] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[h][f], bq[s % 3][h * (NF / 2) + f], acc[h * (NF / 2) + f], 0, 0, 0);
+    }
+  };
+  load_b(bq[0], 0, 0, 0);
+  load_b(bq[1], 0, 0, 1);
   for (int c0 = 0; c0 < p.Cin; c0 += CC) {
-    __syncthreads();
+    __syncthreads();                                     // the previous chunk's steps are done with V (and its V phase with the halo)
     {
       float4 stage[NIT];
 #pragma unroll
-      for (int j = 0; j < NIT; ++j) {
-        const int it = tid + j * kThreads;
-        const int pos = it / Q, q = it - pos * Q;
-        const int hw = pos % HW, hh = (pos / HW) % HH, hd = pos / (HW * HH);
-        const int id = id0 + hd, ih = ih0 + hh, iw = iw0 + hw;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (it < HD * HH * HW * Q && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
-          v = *reinterpret_cast<const float4 *>(p.x + ((((size_t)n * p.D + id) * p.H + ih) * p.W + iw) * p.Cin + c0 + q * 4);
-        stage[j] = v;
-      }
+      for (int j = 0; j < NIT; ++j) stage[j] = fetch(j, c0);
 #pragma unroll
-      for (int j = 0; j < NIT; ++j) {
-        const int it = tid + j * kThreads;
-        if (it < HD * HH * HW * Q) {
-          const int pos = it / Q, q = it - pos * Q;
-          const int hw = pos % HW, hh = (pos / HW) % HH, hd = pos / (HW * HH);
-          float *dd = lds + ((hd * HHP + hh) * HW + hw) * ROW + q * 4;
-          dd[0] = stage[j].x; dd[1] = stage[j].y; dd[2] = stage[j].z; dd[3] = stage[j].w;
-        }
+      for (int j = 0; j < NIT; ++j) commit(j, stage[j]);
+    }
+    __syncthreads();
+    // ---- V = Bh^T d Bw of every (plane, patch, channel) of the chunk: 4 * 8 * 16 = 512 items, two per thread
+#pragma unroll 1
+    for (int rep = 0; rep < HD * 8 * CC / kThreads; ++rep) {   // one item at a time: two in flight spill
+      const int item = tid + rep * kThreads;
+      const int ci = item & 15, patch = (item >> 4) & 7, plane = item >> 7;
+      const float *src = lds + (((plane * HHP) + (patch >> 1) * 2) * HW + (patch & 1) * 4) * ROW + ci;
+      float d[4][6];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) d[i][j] = src[(i * HW + j) * ROW];
+      float *dst = vl + (plane * 8 + patch) * VPITCH + ci;
+#pragma unroll
+      for (int fh = 0; fh < 4; ++fh) {
+        float t[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+          t[j] = fh == 0 ? d[0][j] - d[2][j] : (fh == 1 ? d[1][j] + d[2][j] : (fh == 2 ? d[2][j] - d[1][j] : d[1][j] - d[3][j]));
+        const float e = t[4] - t[2], o = t[3] - t[1];
+        dst[(fh * 6 + 0) * CC] = 4.f * t[0] - 5.f * t[2] + t[4];
+        dst[(fh * 6 + 1) * CC] = (t[3] + t[4]) - 4.f * (t[1] + t[2]);
+        dst[(fh * 6 + 2) * CC] = (t[4] - t[3]) + 4.f * (t[1] - t[2]);
+        dst[(fh * 6 + 3) * CC] = e + 2.f * o;
+        dst[(fh * 6 + 4) * CC] = e - 2.f * o;
+        dst[(fh * 6 + 5) * CC] = 4.f * t[1] - 5.f * t[3] + t[5];
       }
     }
     __syncthreads();
-    read_d(0, 0);                                         // the chunk's first window: exposed once per chunk
+    load_a(aq[0], 0, 0);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int fh = 0; fh < 4; ++fh) xform(mt, fh, a0[mt]);
-    // 12 (kd, k-step) steps per chunk; after an even number of steps the live buffers are (a0, b0) again
-#pragma unroll
-    for (int s = 0; s < 12; s += 2) {
-      step(s, c0, a0, b0, a1, b1);
-      step(s + 1, c0, a1, b1, a0, b0);
-    }
+    for (int s = 0; s < 12; ++s) step(s, c0);             // the U buffers rotate with period 3, the A buffers with period 2
   }
 
   // ---- epilogue: Y = Ah^T M Aw per accumulator element, then shift / adds / upsample add / ReLU / mask; NDHWC store
@@ -208,16 +218,14 @@ __global__ __launch_bounds__(kThreads, MT == 1 ? 2 : 1) void conv3d_wino2d_kerne
     }
   };
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = lk * 4 + r;
-    const int od = od0 + 2 * mt + (row >> 3), oh = oh0 + ((row >> 1) & 3) * 2, ow = ow0 + (row & 1) * 4;
+    const int od = od0 + (row >> 3), oh = oh0 + ((row >> 1) & 3) * 2, ow = ow0 + (row & 1) * 4;
     float z[4][4];                                       // along W: z[fh][x]
 #pragma unroll
     for (int fh = 0; fh < 4; ++fh) {
-      const float m0 = acc[mt][fh * 6][r], m1 = acc[mt][fh * 6 + 1][r], m2 = acc[mt][fh * 6 + 2][r], m3 = acc[mt][fh * 6 + 3][r],
-                  m4 = acc[mt][fh * 6 + 4][r], m5 = acc[mt][fh * 6 + 5][r];
+      const float m0 = acc[fh * 6][r], m1 = acc[fh * 6 + 1][r], m2 = acc[fh * 6 + 2][r], m3 = acc[fh * 6 + 3][r],
+                  m4 = acc[fh * 6 + 4][r], m5 = acc[fh * 6 + 5][r];
       const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
       z[fh][0] = (m0 + s12) + s34; z[fh][1] = d12 + 2.f * d34; z[fh][2] = s12 + 4.f * s34; z[fh][3] = (d12 + 8.f * d34) + m5;
     }
@@ -259,6 +267,14 @@ int mr3d_conv3d_wino2d(const Conv3dFwdArgs &a, hipStream_t stream) {
   const int nw = 3 * a.Cin * a.Cout;
   wino2d_weights_kernel<<<(nw + 255) / 256, 256, 0, stream>>>(a.w, U, a.Cin, a.Cout);
   const int tiles_d = (a.Do + TD - 1) / TD, tiles_h = (a.Ho + TH - 1) / TH, tiles_w = (a.Wo + TW - 1) / TW;
+  static std::once_flag attr_once;                       // LDS above 64 KiB needs the opt-in attribute (one CU has 160 KiB)
+  static bool attr_ok = false;
+  std::call_once(attr_once, [] {
+    attr_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(conv3d_wino2d_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  LDS_BYTES) == hipSuccess;
+    if (!attr_ok) (void)hipGetLastError();
+  });
+  if (!attr_ok) return MR3D_ERR_LAUNCH;
   dim3 grid((unsigned)(a.N * tiles_d * tiles_h * tiles_w), (unsigned)(a.Cout / 64));
   conv3d_wino2d_kernel<<<grid, kThreads, LDS_BYTES, stream>>>(a, U, tiles_d, tiles_h, tiles_w);
   return mr3d_launch_status();
