@@ -19,6 +19,11 @@
 // runs 12 (kd, k-step) steps of 24 MFMAs whose A fragments are plain LDS reads (one step ahead) and whose U fragments come
 // straight from L2, two steps ahead (an L2 round trip is longer than one step).  The halo of the next chunk is fetched at the
 // chunk boundary (the second workgroup of the CU covers it; fetching it piecewise under the MFMA steps was measured equal).
+// Measured on the P2 FPN / RPN conv (40 x 128 x 128, 64 -> 64): 640-660 us against 834 us for the F(4,3) kernel; with every
+// operand load removed from the steps 570 us, with the staging and V phases of chunks 1-3 removed as well 492 us (the bare MFMA
+// stream: 0.62 of the 2.4 GHz matrix peak).  Tried and not kept: every wave forming its own V under its MFMAs (720 us: four
+// times the VALU work, U one step ahead for lack of registers), two MFMA tiles per wave at one wave per SIMD (925), a
+// producer / consumer split of a 512-thread workgroup (770: one MFMA wave per SIMD does not fill the pipe), staggered starts.
 #include "conv3d.h"
 #include <cstdlib>
 #include <map>
@@ -30,13 +35,13 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int TD = 2, TH = 8, TW = 8;                  // output tile: 16 GEMM rows (patches of 2 x 4 outputs)
 constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;   // halo
-constexpr int HHP = HH + 1;                            // one spare row per halo plane: 2-way instead of 3-way LDS bank conflicts
+constexpr int HHP = HH + 1;                            // one spare row per halo plane: 2-way instead of 3-way LDS bank conflicts in the V phase
 constexpr int CC = 16, ROW = CC + 1;                   // Cin chunk, LDS row pitch in floats
 constexpr int HP = HD * HHP * HW;
 constexpr int NFC = 24;
 constexpr int VPITCH = NFC * CC + 2;                    // floats per (plane, patch) of V: 2 * (plane * 8 + patch) + k spreads a read over all 32 banks
 constexpr int VFLOATS = HD * 8 * VPITCH;
-constexpr int LDS_BYTES = (HP * ROW + VFLOATS) * 4;
+constexpr int LDS_BYTES = (VFLOATS > HP * ROW ? VFLOATS : HP * ROW) * 4;      // V overlays the halo
 constexpr int NF = 24;                                 // products per patch and kd tap
 
 // U(kd, f = fh*6+fw, ci, co) = sum_kh sum_kw Gh[fh][kh] Gw[fw][kw] w[(kd*3+kh)*3+kw][ci][co]
@@ -72,7 +77,7 @@ __global__ __launch_bounds__(256) void wino2d_weights_kernel(const float *__rest
 __global__ __launch_bounds__(kThreads, 2) void conv3d_wino2d_kernel(Conv3dFwdArgs p, const float *__restrict__ U, int tiles_d,
                                                                    int tiles_h, int tiles_w) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float *vl = lds + HP * ROW;                            // V[(plane * 8 + patch)][f][ci], pitch VPITCH per (plane, patch)
+  float *vl = lds;                                       // V[(plane * 8 + patch)][f][ci], pitch VPITCH per (plane, patch): OVER the halo (see below)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int b = blockIdx.x;
@@ -163,24 +168,32 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wino2d_kernel(Conv3dFwdArg
       for (int j = 0; j < NIT; ++j) commit(j, stage[j]);
     }
     __syncthreads();
-    // ---- V = Bh^T d Bw of every (plane, patch, channel) of the chunk: 4 * 8 * 16 = 512 items, two per thread
-#pragma unroll 1
-    for (int rep = 0; rep < HD * 8 * CC / kThreads; ++rep) {   // one item at a time: two in flight spill
+    // ---- V = Bh^T d Bw of every (plane, patch, channel) of the chunk: 4 * 8 * 16 = 512 items, two per thread.  V is written
+    // over the halo (49 KB of LDS instead of 76): every thread first pulls its two 4 x 6 windows into registers.
+    constexpr int REP = HD * 8 * CC / kThreads;
+    float d[REP][4][6];
+#pragma unroll
+    for (int rep = 0; rep < REP; ++rep) {
       const int item = tid + rep * kThreads;
       const int ci = item & 15, patch = (item >> 4) & 7, plane = item >> 7;
       const float *src = lds + (((plane * HHP) + (patch >> 1) * 2) * HW + (patch & 1) * 4) * ROW + ci;
-      float d[4][6];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 6; ++j) d[i][j] = src[(i * HW + j) * ROW];
+        for (int j = 0; j < 6; ++j) d[rep][i][j] = src[(i * HW + j) * ROW];
+    }
+    __syncthreads();                                     // every window is in registers: the halo may be overwritten
+#pragma unroll
+    for (int rep = 0; rep < REP; ++rep) {
+      const int item = tid + rep * kThreads;
+      const int ci = item & 15, patch = (item >> 4) & 7, plane = item >> 7;
       float *dst = vl + (plane * 8 + patch) * VPITCH + ci;
 #pragma unroll
       for (int fh = 0; fh < 4; ++fh) {
         float t[6];
 #pragma unroll
         for (int j = 0; j < 6; ++j)
-          t[j] = fh == 0 ? d[0][j] - d[2][j] : (fh == 1 ? d[1][j] + d[2][j] : (fh == 2 ? d[2][j] - d[1][j] : d[1][j] - d[3][j]));
+          t[j] = fh == 0 ? d[rep][0][j] - d[rep][2][j] : (fh == 1 ? d[rep][1][j] + d[rep][2][j] : (fh == 2 ? d[rep][2][j] - d[rep][1][j] : d[rep][1][j] - d[rep][3][j]));
         const float e = t[4] - t[2], o = t[3] - t[1];
         dst[(fh * 6 + 0) * CC] = 4.f * t[0] - 5.f * t[2] + t[4];
         dst[(fh * 6 + 1) * CC] = (t[3] + t[4]) - 4.f * (t[1] + t[2]);
