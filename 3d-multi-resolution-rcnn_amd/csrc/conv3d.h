@@ -48,6 +48,11 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 // two-dimensional Winograd form of the 3x3x3 / stride-1 convolution (conv3d_wino2d.hip): F(4,3) along W x F(2,3) along H
 bool mr3d_conv3d_wino2d_ok(const Conv3dFwdArgs &a);
 int mr3d_conv3d_wino2d(const Conv3dFwdArgs &a, hipStream_t stream);
+bool mr3d_conv3d_wino2d_rows_ok(const Conv3dFwdArgs &a);          // Cout 16 / 32
+int mr3d_conv3d_wino2d_rows(const Conv3dFwdArgs &a, hipStream_t stream);
+// plan pre-pass: the weight transforms of n convolutions in one launch (see conv3d_wino2d.hip)
+int mr3d_conv3d_wino2d_prepare(const float *const *w, const int *cin, const int *cout, int n, hipStream_t stream);
+void mr3d_conv3d_wino2d_prepare_end();
 
 // streaming pointwise instances (pointwise.hip); MR3D_ERR_UNSUPPORTED = use the generic kernels
 int mr3d_pointwise_fwd_try(const Conv3dFwdArgs &a, hipStream_t stream, bool probe_only = false);

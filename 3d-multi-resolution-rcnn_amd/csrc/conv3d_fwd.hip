@@ -454,6 +454,20 @@ int dispatch_tile(const Conv3dFwdArgs &a, hipStream_t stream) {
     if (c577 > 1.15 * (c488 > c288 ? c488 : c288) && a.N * t577 * (a.Cout / NB) >= 512)
       return launch_fwd<FwdCfg<3, 3, 3, 1, 1, 1, 5, 7, 7, CC, NB>>(a, stream);
   }
+  if constexpr (K == 3 && SD == 1 && SH == 1 && SW == 1 && CC == 16 && (NB == 16 || NB == 32)) {
+    // narrow Cout (layer1 16 -> 16, layer2 32 -> 32 on the large maps): F(4,3) x F(2,3) with the waves split over GEMM rows
+    static const int wino_r = getenv("MR3D_FWD_WINO") ? atoi(getenv("MR3D_FWD_WINO")) : 4;
+    static const int min2d_r = getenv("MR3D_FWD_WINO2D_ROWS_MIN") ? atoi(getenv("MR3D_FWD_WINO2D_ROWS_MIN")) : 256;   // backbone step 11.83 -> 11.69 (layer1) -> 11.64 ms (+ layer2)
+    if (wino_r >= 4 && a.Cout == NB && wgs(NB == 16 ? 8 : 4, 8, 8) >= min2d_r && mr3d_conv3d_wino2d_rows_ok(a)) {
+      if (g_variant_probe) {
+        mr3d_conv3d_variant &v = *g_variant_probe;
+        v.streaming_pointwise = 0; v.winograd = 8; v.tile_d = NB == 16 ? 8 : 4; v.tile_h = 8; v.tile_w = 8; v.cin_chunk = 16; v.cout_tile = NB;
+        v.parity_decomposed = 0; v.mfma_issue_factor = 1.f / 3.f;
+        return MR3D_OK;
+      }
+      return mr3d_conv3d_wino2d_rows(a, stream);
+    }
+  }
   if constexpr (K == 3 && SD == 1 && SH == 1 && SW == 1 && NB == 16 && CC == 16) {
     if (a.Cin == CC && wgs(4, 8, 8) >= 512) return launch_fwd<FwdCfg<3, 3, 3, 1, 1, 1, 4, 8, 8, CC, NB, false, true>>(a, stream);
   }

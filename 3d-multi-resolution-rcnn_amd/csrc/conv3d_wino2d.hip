@@ -250,15 +250,231 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wino2d_kernel(Conv3dFwdArg
   }
 }
 
+// Narrow Cout tiles (16 or 32 output channels: the 3x3x3 convs of layer1 / layer2 on the large maps).  WN waves split the Cout
+// tile, the other 4 / WN waves split the GEMM rows: a wave owns 16 rows = 2 output planes x 8 patches of its own, so no two
+// waves need the same V and every wave forms it itself, under the MFMAs of the previous step (88 VALU operations per 24 MFMAs).
+// Workgroup tile: (8 / WN) x 8 x 8 outputs; U (3 x 24 x Cin x Cout floats) stays L1 / L2 resident.
+template <int WN>
+__global__ __launch_bounds__(kThreads, 2) void conv3d_wino2d_rows_kernel(Conv3dFwdArgs p, const float *__restrict__ U, int tiles_d,
+                                                                        int tiles_h, int tiles_w) {
+  constexpr int WM = 4 / WN, TDr = 2 * WM, HDr = TDr + 2, HHr = HH;   // no spare halo row here: 68 KB at WN = 1
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int b = blockIdx.x;
+  const int tw_i = b % tiles_w; b /= tiles_w;
+  const int th_i = b % tiles_h; b /= tiles_h;
+  const int td_i = b % tiles_d; b /= tiles_d;
+  const int n = b;
+  const int od0 = td_i * TDr, oh0 = th_i * TH, ow0 = tw_i * TW;
+  const int id0 = od0 - p.pd, ih0 = oh0 - p.ph, iw0 = ow0 - p.pw;
+  const int li = lane & 15, lk = lane >> 4;
+  const int wave_m = wave / WN, wave_n = wave % WN;
+  const int co = blockIdx.y * (16 * WN) + wave_n * 16 + li;
+  // A operand: this lane's GEMM row (li) = patch (td, th2, tw4) and its k index inside the k-step (lk)
+  const int abase = ((((2 * wave_m + (li >> 3)) * HHr) + ((li >> 1) & 3) * 2) * HW + (li & 1) * 4) * ROW + lk;
+  const float *ul = U + ((size_t)lk * (NF / 4) * p.Cout + co) * 4;
+
+  constexpr int MT = 1;
+  f32x4 acc[MT][NF];
+#pragma unroll
+  for (int f = 0; f < NF; ++f) acc[0][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float b0[NF], b1[NF], a0[MT][NF], a1[MT][NF], d[MT][4][6];
+  auto load_b = [&](float (&dst)[NF], int c0, int kd, int kk) {
+    const float *src = ul + ((size_t)kd * p.Cin + c0 + kk * 4) * (NF / 4) * p.Cout * 4;
+#pragma unroll
+    for (int f4 = 0; f4 < NF / 4; ++f4) {
+      const float4 v = *reinterpret_cast<const float4 *>(src + (size_t)f4 * p.Cout * 4);
+      dst[f4 * 4] = v.x; dst[f4 * 4 + 1] = v.y; dst[f4 * 4 + 2] = v.z; dst[f4 * 4 + 3] = v.w;
+    }
+  };
+  auto read_d = [&](int kd, int kk) {                    // the 4 x 6 input window of this lane's patch and channel
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const float *src = lds + abase + ((kd + 2 * mt) * HHr * HW) * ROW + kk * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) d[mt][i][j] = src[(i * HW + j) * ROW];
+    }
+  };
+  auto xform = [&](int mt, int fh, float (&dst)[NF]) {   // row fh of V = Bh^T d Bw
+    float t[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+      t[j] = fh == 0 ? d[mt][0][j] - d[mt][2][j] : (fh == 1 ? d[mt][1][j] + d[mt][2][j] : (fh == 2 ? d[mt][2][j] - d[mt][1][j] : d[mt][1][j] - d[mt][3][j]));
+    const float e = t[4] - t[2], o = t[3] - t[1];
+    dst[fh * 6 + 0] = 4.f * t[0] - 5.f * t[2] + t[4];
+    dst[fh * 6 + 1] = (t[3] + t[4]) - 4.f * (t[1] + t[2]);
+    dst[fh * 6 + 2] = (t[4] - t[3]) + 4.f * (t[1] - t[2]);
+    dst[fh * 6 + 3] = e + 2.f * o;
+    dst[fh * 6 + 4] = e - 2.f * o;
+    dst[fh * 6 + 5] = 4.f * t[1] - 5.f * t[3] + t[5];
+  };
+  auto mma = [&](int mt, int fh, const float (&av)[NF], const float (&bw)[NF]) {
+#pragma unroll
+    for (int fw = 0; fw < 6; ++fw)
+      acc[mt][fh * 6 + fw] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[fh * 6 + fw], bw[fh * 6 + fw], acc[mt][fh * 6 + fw], 0, 0, 0);
+  };
+  // one (kd, k-step): the 24 MFMAs of step s on (av, bw), interleaved with the transform of step s + 1's window into an
+  // (its LDS reads and the U fragments of step s + 1 are requested first) -- the wave's own VALU work rides in the shadow
+  // of its MFMAs instead of waiting for the other wave of the SIMD to be out of phase
+  auto step = [&](int s, int c0, const float (&av)[MT][NF], const float (&bw)[NF], float (&an)[MT][NF], float (&bnx)[NF]) {
+    const bool more = s + 1 < 12;
+    if (more) load_b(bnx, c0, (s + 1) / 4, (s + 1) % 4);
+    else if (c0 + CC < p.Cin) load_b(bnx, c0 + CC, 0, 0);
+    if (more) read_d((s + 1) / 4, (s + 1) % 4);
+    __builtin_amdgcn_sched_barrier(0);                   // the requests stay up here: the scheduler would sink them next to their uses
+#pragma unroll
+    for (int fh = 0; fh < 4; ++fh)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        mma(mt, fh, av[mt], bw);
+        if (more) xform(mt, fh, an[mt]);
+      }
+  };
+
+  constexpr int Q = CC / 4;
+  constexpr int NIT = (HDr * HH * HW * Q + kThreads - 1) / kThreads;
+  load_b(b0, 0, 0, 0);
+  for (int c0 = 0; c0 < p.Cin; c0 += CC) {
+    __syncthreads();
+    {
+      // four pieces at a time (16 in flight would spill), addresses recomputed per chunk (hoisted they spill too)
+      int tv = tid;
+      asm volatile("" : "+v"(tv));
+#pragma unroll 1
+      for (int j0 = 0; j0 < NIT; j0 += 4) {
+        float4 stage[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int it = tv + (j0 + jj) * kThreads;
+          const int pos = it / Q, q = it - pos * Q;
+          const int hw = pos % HW, hh = (pos / HW) % HH, hd = pos / (HW * HH);
+          const int id = id0 + hd, ih = ih0 + hh, iw = iw0 + hw;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (it < HDr * HH * HW * Q && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
+            v = *reinterpret_cast<const float4 *>(p.x + ((((size_t)n * p.D + id) * p.H + ih) * p.W + iw) * p.Cin + c0 + q * 4);
+          stage[jj] = v;
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int it = tv + (j0 + jj) * kThreads;
+          if (it < HDr * HH * HW * Q) {
+            const int pos = it / Q, q = it - pos * Q;
+            const int hw = pos % HW, hh = (pos / HW) % HH, hd = pos / (HW * HH);
+            float *dd = lds + ((hd * HHr + hh) * HW + hw) * ROW + q * 4;
+            dd[0] = stage[jj].x; dd[1] = stage[jj].y; dd[2] = stage[jj].z; dd[3] = stage[jj].w;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    read_d(0, 0);                                         // the chunk's first window: exposed once per chunk
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int fh = 0; fh < 4; ++fh) xform(mt, fh, a0[mt]);
+    // 12 (kd, k-step) steps per chunk; after an even number of steps the live buffers are (a0, b0) again
+#pragma unroll
+    for (int s = 0; s < 12; s += 2) {
+      step(s, c0, a0, b0, a1, b1);
+      step(s + 1, c0, a1, b1, a0, b0);
+    }
+  }
+
+  // ---- epilogue: Y = Ah^T M Aw per accumulator element, then shift / adds / upsample add / ReLU / mask; NDHWC store
+  const float sh = p.shift ? p.shift[co] : 0.f;
+  auto emit = [&](int od, int oh, int ow, float val) {
+    if (od < p.Do && oh < p.Ho && ow < p.Wo) {
+      const size_t idx = ((((size_t)n * p.yD + od * p.ysd) * p.yH + oh * p.ysh) * p.yW + ow * p.ysw) * p.Cout + co;
+      float v = val + sh;
+      if (p.add1) v += p.add1[idx];
+      if (p.add2) v += p.add2[idx];
+      if (p.up) {
+        auto nearest = [](int dst, int in, int out) {          // torch nearest: min(floor(dst * (in/out)), in-1)
+          const int s_ = (int)floorf((float)dst * ((float)in / (float)out));
+          return s_ < in - 1 ? s_ : in - 1;
+        };
+        const int ud = nearest(od, p.Du, p.Do), uh = nearest(oh, p.Hu, p.Ho), uw = nearest(ow, p.Wu, p.Wo);
+        v += p.up[((((size_t)n * p.Du + ud) * p.Hu + uh) * p.Wu + uw) * p.Cout + co];
+      }
+      if (p.relu) v = fmaxf(v, 0.f);
+      if (p.mask) v = p.mask[idx] > 0.f ? v : 0.f;
+      p.y[idx] = v;
+    }
+  };
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = lk * 4 + r;
+    const int od = od0 + 2 * wave_m + (row >> 3), oh = oh0 + ((row >> 1) & 3) * 2, ow = ow0 + (row & 1) * 4;
+    float z[4][4];                                       // along W: z[fh][x]
+#pragma unroll
+    for (int fh = 0; fh < 4; ++fh) {
+      const float m0 = acc[mt][fh * 6][r], m1 = acc[mt][fh * 6 + 1][r], m2 = acc[mt][fh * 6 + 2][r], m3 = acc[mt][fh * 6 + 3][r],
+                  m4 = acc[mt][fh * 6 + 4][r], m5 = acc[mt][fh * 6 + 5][r];
+      const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+      z[fh][0] = (m0 + s12) + s34; z[fh][1] = d12 + 2.f * d34; z[fh][2] = s12 + 4.f * s34; z[fh][3] = (d12 + 8.f * d34) + m5;
+    }
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      emit(od, oh, ow + x, (z[0][x] + z[1][x]) + z[2][x]);
+      emit(od, oh + 1, ow + x, (z[1][x] - z[2][x]) - z[3][x]);
+    }
+  }
+}
+
+// ---- batched form of wino2d_weights_kernel for a plan run: one launch transforms the weights of every convolution of the
+// plan that will take these kernels (16 launches of ~33 us each sat between the convolutions of a step: 0.5 ms of 11.8)
+constexpr int kPrepMax = 32;
+struct PrepTable { const float *w[kPrepMax]; float *U[kPrepMax]; int cin[kPrepMax], cout[kPrepMax]; };
+__global__ __launch_bounds__(256) void wino2d_weights_batched_kernel(PrepTable t) {
+  const int k = blockIdx.y, cin = t.cin[k], cout = t.cout[k];
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= 3 * cin * cout) return;
+  const float *w = t.w[k];
+  float *U = t.U[k];
+  const int kd = e / (cin * cout), cc = e - kd * (cin * cout);
+  float g[3][3];
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) g[kh][kw] = w[(size_t)((kd * 3 + kh) * 3 + kw) * cin * cout + cc];
+  float tt[3][6];
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const float g0 = g[kh][0], g1 = g[kh][1], g2 = g[kh][2];
+    const float s02 = g0 + g2, h = g0 * (1.f / 24.f) + g2 * (1.f / 6.f), q = g1 * (1.f / 12.f);
+    tt[kh][0] = 0.25f * g0; tt[kh][1] = (s02 + g1) * (-1.f / 6.f); tt[kh][2] = (s02 - g1) * (-1.f / 6.f);
+    tt[kh][3] = h + q; tt[kh][4] = h - q; tt[kh][5] = g2;
+  }
+#pragma unroll
+  for (int fw = 0; fw < 6; ++fw) {
+    const float a = tt[0][fw], b = tt[1][fw], c = tt[2][fw];
+    const float u[4] = {a, 0.5f * ((a + c) + b), 0.5f * ((a + c) - b), c};
+#pragma unroll
+    for (int fh = 0; fh < 4; ++fh) {
+      const int f = fh * 6 + fw, ci = cc / cout, co = cc - ci * cout;
+      U[((((size_t)kd * cin + ci) * (NF / 4) + f / 4) * cout + co) * 4 + (f & 3)] = u[fh];
+    }
+  }
+}
+
+// weights already transformed for the plan run in progress on this thread: packed-weight pointer -> U
+thread_local std::map<const float *, const float *> g_prepared;
+
 // U scratch: one buffer per (device, stream) -- launches on one stream are ordered, so they may share it
 struct Scratch { float *p = nullptr; size_t floats = 0; };
 std::mutex g_mu;
-std::map<std::pair<int, hipStream_t>, Scratch> g_scratch;
-float *u_scratch(size_t floats, hipStream_t stream) {
+std::map<std::pair<int, hipStream_t>, Scratch> g_scratch, g_scratch_plan;
+float *u_scratch(size_t floats, hipStream_t stream, bool plan = false) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   std::lock_guard<std::mutex> lock(g_mu);
-  Scratch &s = g_scratch[{dev, stream}];
+  Scratch &s = (plan ? g_scratch_plan : g_scratch)[{dev, stream}];
   if (floats > s.floats) {
     if (s.p) (void)hipFree(s.p);
     s.p = nullptr;
@@ -270,15 +486,78 @@ float *u_scratch(size_t floats, hipStream_t stream) {
 
 }  // namespace
 
+// narrow Cout tiles: Cout 16 or 32 exactly (a wider Cout takes the 64-wide kernel or the one-dimensional forms)
+bool mr3d_conv3d_wino2d_rows_ok(const Conv3dFwdArgs &a) {
+  return a.Cin % CC == 0 && (a.Cout == 16 || a.Cout == 32) && a.Do == a.D + 2 * a.pd - 2 && a.Ho == a.H + 2 * a.ph - 2 &&
+         a.Wo == a.W + 2 * a.pw - 2;
+}
+
+template <int WN>
+static int launch_rows(const Conv3dFwdArgs &a, const float *U, hipStream_t stream) {
+  constexpr int TDr = 2 * (4 / WN), lds = (TDr + 2) * HH * HW * ROW * 4;
+  static std::once_flag once;
+  static bool ok = false;
+  std::call_once(once, [] {
+    ok = hipFuncSetAttribute(reinterpret_cast<const void *>(conv3d_wino2d_rows_kernel<WN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+  });
+  if (!ok) return MR3D_ERR_LAUNCH;
+  const int tiles_d = (a.Do + TDr - 1) / TDr, tiles_h = (a.Ho + TH - 1) / TH, tiles_w = (a.Wo + TW - 1) / TW;
+  dim3 grid((unsigned)(a.N * tiles_d * tiles_h * tiles_w), (unsigned)(a.Cout / (16 * WN)));
+  conv3d_wino2d_rows_kernel<WN><<<grid, kThreads, lds, stream>>>(a, U, tiles_d, tiles_h, tiles_w);
+  return mr3d_launch_status();
+}
+
+// U of a launch: prepared by the plan run in progress, else transformed now into the per-stream scratch
+static const float *u_for(const Conv3dFwdArgs &a, hipStream_t stream) {
+  const auto it = g_prepared.find(a.w);
+  if (it != g_prepared.end()) return it->second;
+  float *U = u_scratch((size_t)3 * NF * a.Cin * a.Cout, stream);
+  if (!U) return nullptr;
+  const int nw = 3 * a.Cin * a.Cout;
+  wino2d_weights_kernel<<<(nw + 255) / 256, 256, 0, stream>>>(a.w, U, a.Cin, a.Cout);
+  return U;
+}
+
+int mr3d_conv3d_wino2d_rows(const Conv3dFwdArgs &a, hipStream_t stream) {
+  const float *U = u_for(a, stream);
+  if (!U) return MR3D_ERR_LAUNCH;
+  return a.Cout == 16 ? launch_rows<1>(a, U, stream) : launch_rows<2>(a, U, stream);
+}
+
+// plan pre-pass: transform the weights of n convolutions (packed [27][cin][cout] each) in ONE launch; until
+// mr3d_conv3d_wino2d_prepare_end() the launches of this thread that use one of these weight buffers skip their own transform
+int mr3d_conv3d_wino2d_prepare(const float *const *w, const int *cin, const int *cout, int n, hipStream_t stream) {
+  if (n <= 0) return MR3D_OK;
+  if (n > kPrepMax) n = kPrepMax;                          // the rest transform at their launch
+  size_t total = 0;
+  for (int k = 0; k < n; ++k) total += (size_t)3 * NF * cin[k] * cout[k];
+  float *base = u_scratch(total, stream, true);
+  if (!base) return MR3D_ERR_LAUNCH;
+  PrepTable t{};
+  size_t off = 0;
+  int maxw = 0;
+  for (int k = 0; k < n; ++k) {
+    t.w[k] = w[k]; t.U[k] = base + off; t.cin[k] = cin[k]; t.cout[k] = cout[k];
+    off += (size_t)3 * NF * cin[k] * cout[k];
+    maxw = maxw > 3 * cin[k] * cout[k] ? maxw : 3 * cin[k] * cout[k];
+  }
+  wino2d_weights_batched_kernel<<<dim3((maxw + 255) / 256, n), 256, 0, stream>>>(t);
+  const int st = mr3d_launch_status();
+  if (st != MR3D_OK) return st;
+  for (int k = 0; k < n; ++k) g_prepared[w[k]] = t.U[k];
+  return MR3D_OK;
+}
+
+void mr3d_conv3d_wino2d_prepare_end() { g_prepared.clear(); }
+
 bool mr3d_conv3d_wino2d_ok(const Conv3dFwdArgs &a) {
   return a.Cin % CC == 0 && a.Cout % 64 == 0 && a.Do == a.D + 2 * a.pd - 2 && a.Ho == a.H + 2 * a.ph - 2 && a.Wo == a.W + 2 * a.pw - 2;
 }
 
 int mr3d_conv3d_wino2d(const Conv3dFwdArgs &a, hipStream_t stream) {
-  float *U = u_scratch((size_t)3 * NF * a.Cin * a.Cout, stream);
+  const float *U = u_for(a, stream);
   if (!U) return MR3D_ERR_LAUNCH;
-  const int nw = 3 * a.Cin * a.Cout;
-  wino2d_weights_kernel<<<(nw + 255) / 256, 256, 0, stream>>>(a.w, U, a.Cin, a.Cout);
   const int tiles_d = (a.Do + TD - 1) / TD, tiles_h = (a.Ho + TH - 1) / TH, tiles_w = (a.Wo + TW - 1) / TW;
   static std::once_flag attr_once;                       // LDS above 64 KiB needs the opt-in attribute (one CU has 160 KiB)
   static bool attr_ok = false;

@@ -119,6 +119,26 @@ def test_conv3d_forward_winograd_2d_large_map(dev):
     assert l2 <= 1e-5, f'L2-relative error {l2:.3e}'
 
 
+@pytest.mark.parametrize('c,dhw', [(16, (19, 67, 75)), (32, (13, 61, 70))])
+def test_conv3d_forward_winograd_2d_narrow_cout(dev, c, dhw):
+    """3x3x3 16 -> 16 / 32 -> 32 on maps with >= 256 tiles take the row-split F(4,3) x F(2,3) kernels (conv3d_wino2d_rows_kernel):
+    ragged extents, fused epilogue in both uses (forward: ReLU; data gradient: ReLU mask), against an fp64 conv"""
+    from mr3d_amd import _hip
+    g = torch.Generator().manual_seed(c)
+    x = torch.randn((1, c) + dhw, generator=g)
+    w = torch.randn((c, c, 3, 3, 3), generator=g) / np.sqrt(c * 27)
+    shift = torch.randn(c, generator=g)
+    add1 = torch.randn((1, c) + dhw, generator=g)
+    mask = torch.randn((1, c) + dhw, generator=g)
+    conv = F.conv3d(x.double(), w.double(), shift.double(), 1, 1)
+    wp = _hip.pack_conv_weight(w).to(dev)
+    y = _hip.conv3d_forward(_cl(x).to(dev), wp, (3, 3, 3), (1, 1, 1), (1, 1, 1), shift=shift.to(dev), add1=_cl(add1).to(dev), relu=True)
+    _check(y, torch.relu(conv + add1.double()).float(), 'winograd 2d rows relu')
+    y2 = _hip.conv3d_forward(_cl(x).to(dev), wp, (3, 3, 3), (1, 1, 1), (1, 1, 1), shift=shift.to(dev), add1=_cl(add1).to(dev),
+                             mask=_cl(mask).to(dev))
+    _check(y2, ((conv + add1.double()) * (mask > 0)).float(), 'winograd 2d rows mask')
+
+
 def test_conv3d_unsupported_is_loud(dev):
     from mr3d_amd import _hip
     x = torch.zeros((1, 2, 4, 4, 12), device=dev)      # Cin = 12
