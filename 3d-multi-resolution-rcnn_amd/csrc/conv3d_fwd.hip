@@ -451,7 +451,13 @@ int dispatch_tile(const Conv3dFwdArgs &a, hipStream_t stream) {
     const long long t288 = (long long)((a.Do + 1) / 2) * ((a.Ho + 7) / 8) * ((a.Wo + 7) / 8);
     const double c577 = (double)vol / (t577 * 256.0), c488 = (double)vol / (t488 * 256.0), c288 = (double)vol / (t288 * 128.0);
     // (the F(4,3) form on padded 4x8x8 tiles was measured equal on these volumes: 463 vs 463 us for 128 rois)
-    if (c577 > 1.15 * (c488 > c288 ? c488 : c288) && a.N * t577 * (a.Cout / NB) >= 512)
+    // large roi batches (mask heads on >= ~52 rois): the two-dimensional Winograd kernel (2x8x8 tiles on a 10x14x14 volume use
+    // 77 % of their rows, at 1/3 of the MFMA work) instead of the direct 5x7x7 tiles: 128-row step 26.3 -> 24.9 ms; on 16-row
+    // batches the two are equal
+    static const int roi2d_min = getenv("MR3D_FWD_WINO2D_ROI_MIN") ? atoi(getenv("MR3D_FWD_WINO2D_ROI_MIN")) : 1024;
+    static const int wino_roi = getenv("MR3D_FWD_WINO") ? atoi(getenv("MR3D_FWD_WINO")) : 4;
+    const bool skip577 = wino_roi >= 4 && NB == 64 && CC == 16 && a.N * t288 >= roi2d_min && mr3d_conv3d_wino2d_ok(a);
+    if (!skip577 && c577 > 1.15 * (c488 > c288 ? c488 : c288) && a.N * t577 * (a.Cout / NB) >= 512)
       return launch_fwd<FwdCfg<3, 3, 3, 1, 1, 1, 5, 7, 7, CC, NB>>(a, stream);
   }
   if constexpr (K == 3 && SD == 1 && SH == 1 && SW == 1 && CC == 16 && (NB == 16 || NB == 32)) {
