@@ -278,6 +278,18 @@ def ops_microbench(dev):
     return out
 
 
+
+def emit_json_line(obj):
+    """the ONE JSON line, as the LAST line of stdout: RCCL writes its version banner through C stdio (block-buffered on a pipe,
+    flushed at exit -- after Python's own line); flush C stdio first, then print"""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    print(json.dumps(obj), flush=True)
+
+
 def two_stage_step_ms(vol, steps=5, two_scales=False, static_mask_batch=False, bf16=False, dcn_neck=False):
     """BASELINE configs[2]: the whole single-pathway training step (backbone+FPN, RPN + loss + proposals/NMS3D,
     assign/sample 512, RoIAlign3D + bbox head, RoIAlign3D + mask head, all losses, backward) on one volume, timed by
@@ -339,7 +351,7 @@ def two_stage_main(a, rank, world, dev):
         # algorithmic FLOPs of the step: backbone+FPN fwd+bwd 1124.38 + RPN head 3 x 165.8; roi heads depend on
         # the sampled batch and are left out of the fraction
         flops = (FLOP_FWD_BWD_512 + 3 * 165.8e9) * (D * H * W) / (80.0 * 512 * 512)
-        print(json.dumps({
+        emit_json_line({
             'metric': 'train iters/sec on 512x512x80 vols (full two-stage step: RPN3D + RoIAlign3D + NMS3D + bbox/mask heads, ' +
                       ('bf16 storage / fp32 accumulate)' if bf else 'fp32)'),
             'value': world * a.steps / el, 'unit': 'iters/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
@@ -352,7 +364,7 @@ def two_stage_main(a, rank, world, dev):
             'roofline': {'bound': 'mfma', 'kernel': 'whole step (backbone+FPN+RPN convolutions)', 'achieved': flops / (ms * 1e-3) / 1e12,
                          'peak': (PEAK_BF16_MATRIX if bf else PEAK_FP32_MATRIX) / 1e12, 'unit': 'TFLOP/s',
                          'frac': flops / (ms * 1e-3) / (PEAK_BF16_MATRIX if bf else PEAK_FP32_MATRIX), 'traffic': None},
-            'arena_mbytes': arena.flat_grads.numel() * 4 / 1e6}))
+            'arena_mbytes': arena.flat_grads.numel() * 4 / 1e6})
     if dist.is_initialized():
         dist.destroy_process_group()
 
@@ -556,7 +568,7 @@ def main():
                 res['cpu_baseline']['ops'] = cpu_baseline_ops(min(a.cpu_seconds, 12.0))
             except Exception as exc:
                 res['cpu_baseline']['ops'] = {'error': repr(exc)}
-        print(json.dumps(res))
+        emit_json_line(res)
     if world > 1 or force_dist:
         dist.destroy_process_group()
 
