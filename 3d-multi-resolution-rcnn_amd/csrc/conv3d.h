@@ -54,6 +54,10 @@ int mr3d_conv3d_wino2d_rows(const Conv3dFwdArgs &a, hipStream_t stream);
 int mr3d_conv3d_wino2d_prepare(const float *const *w, const int *cin, const int *cout, int n, hipStream_t stream);
 void mr3d_conv3d_wino2d_prepare_end();
 
+// two-dimensional Winograd form of the 3x3x3 / stride-1 weight gradient (conv3d_wgrad_wino2d.hip): F(3,2) along H x F(3,4) along W
+bool mr3d_conv3d_wgrad_wino2d_ok(const Conv3dWgradArgs &a);
+int mr3d_conv3d_wgrad_wino2d(const Conv3dWgradArgs &a, hipStream_t stream);
+
 // streaming pointwise instances (pointwise.hip); MR3D_ERR_UNSUPPORTED = use the generic kernels
 int mr3d_pointwise_fwd_try(const Conv3dFwdArgs &a, hipStream_t stream, bool probe_only = false);
 int mr3d_pointwise_wgrad_try(const Conv3dWgradArgs &a, hipStream_t stream);

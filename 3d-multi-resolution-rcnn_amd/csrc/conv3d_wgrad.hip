@@ -479,8 +479,14 @@ extern "C" int mr3d_conv3d_wgrad(const mr3d_conv3d_wgrad_desc *d, mr3d_stream_t 
       }
       const int nb3 = nb3_env ? nb3_env : (a.N * t488 < 2048 ? 32 : 64);
       // Winograd forms (a caller that lends a workspace wants the bit-reproducible two-stage reduction: direct form)
-      static const int wino_env = getenv("MR3D_WGRAD_WINO") ? atoi(getenv("MR3D_WGRAD_WINO")) : 3;    // 0: direct form only; 1/2/3: 64- / +32- / +16-wide tiles
+      static const int wino_env = getenv("MR3D_WGRAD_WINO") ? atoi(getenv("MR3D_WGRAD_WINO")) : 4;    // 0: direct form only; 1/2/3: F(3,2) along W on 64- / +32- / +16-wide tiles; 4: + the two-dimensional form
       const int wino = a.part ? 0 : wino_env;
+      // 4: the two-dimensional form (conv3d_wgrad_wino2d.hip) on maps with >= min2d tiles of 2x8x8: P2 64->64 1096 -> 857 us
+      // standalone, backbone step 11.68 -> 11.48 ms, configs[2] step 19.7 -> 19.3 ms
+      static const int min2d = getenv("MR3D_WGRAD_WINO2D_MIN") ? atoi(getenv("MR3D_WGRAD_WINO2D_MIN")) : 256;
+      if (wino >= 4 && nb == 64 && (long long)a.N * ((a.Do + 1) / 2) * ((a.Ho + 7) / 8) * ((a.Wo + 7) / 8) >= min2d &&
+          mr3d_conv3d_wgrad_wino2d_ok(a))
+        return mr3d_conv3d_wgrad_wino2d(a, stream);
       if (wino && nb == 64 && nb3 == 64) return launch_wgrad<WgCfg<3, 3, 3, 1, 1, 1, 16, 64, false, 4, 8, 8, true>>(a, stream);
       if (wino >= 2 && nb >= 32 && nb3 == 32) return launch_wgrad<WgCfg<3, 3, 3, 1, 1, 1, 16, 32, false, 4, 8, 8, true>>(a, stream);
       if (wino >= 3 && nb == 16) return launch_wgrad<WgCfg<3, 3, 3, 1, 1, 1, 16, 16, false, 4, 8, 8, true>>(a, stream);

@@ -175,6 +175,29 @@ def test_conv3d_wgrad(dev, cin, cout, k, stride, pad, dhw):
         assert torch.equal(dw3, dw4)
 
 
+def test_conv3d_wgrad_winograd_2d_large_map(dev):
+    """3x3x3 64 -> 64 weight gradient on a map with >= 256 tiles of 2x8x8 takes the F(3,2) x F(3,4) kernel
+    (csrc/conv3d_wgrad_wino2d.hip): ragged extents, two images, bias gradient, accumulation into a non-zero dw; vs an fp64 conv"""
+    from mr3d_amd import _hip
+    g = torch.Generator().manual_seed(9)
+    dhw = (11, 45, 51)
+    x = torch.randn((2, 64) + dhw, generator=g)
+    w = torch.zeros((64, 64, 3, 3, 3), dtype=torch.float64, requires_grad=True)
+    y = F.conv3d(x.double(), w, None, 1, 1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy.double())
+    ref = _hip.pack_conv_weight(w.grad.float()).double()
+    dw = torch.zeros((27, 64, 64), device=dev)
+    db = torch.zeros(64, device=dev)
+    for rep in (1, 2):                                   # the second call accumulates on top of the first
+        _hip.conv3d_wgrad(_cl(x).to(dev), _cl(dy).to(dev), dw, (3, 3, 3), (1, 1, 1), (1, 1, 1), dbias=db)
+        err = (dw.cpu().double() - rep * ref).abs().max().item() / ref.abs().max().item()
+        l2 = ((dw.cpu().double() - rep * ref).norm() / ref.norm()).item()
+        assert err <= rep * RTOL and l2 <= rep * 1e-5, f'wgrad 2d: max err {err:.3e}, L2 {l2:.3e}'
+    refb = dy.double().sum((0, 2, 3, 4))
+    assert (db.cpu().double() - 2 * refb).abs().max().item() <= 2e-5 * refb.abs().max().item()
+
+
 @pytest.mark.parametrize('n,dhw', [(1, (8, 32, 32)), (1, (16, 64, 64)), (2, (10, 40, 36)), (1, (5, 70, 130)), (1, (9, 17, 23))])
 def test_stem_kernels_forward_and_wgrad(dev, n, dhw):
     """the specialised 7x7x7 / stride (1,2,2) stem kernels against an fp64 torch conv"""
