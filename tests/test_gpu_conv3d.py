@@ -139,6 +139,27 @@ def test_conv3d_forward_winograd_2d_narrow_cout(dev, c, dhw):
     _check(y2, ((conv + add1.double()) * (mask > 0)).float(), 'winograd 2d rows mask')
 
 
+def test_conv3d_winograd_2d_other_channel_counts(dev):
+    """the two-dimensional Winograd kernels with two Cin chunks and two 64-wide Cout tiles (32 -> 128): forward and weight gradient"""
+    from mr3d_amd import _hip
+    g = torch.Generator().manual_seed(21)
+    dhw = (9, 41, 50)                                    # 5 x 6 x 7 = 210 tiles of 2x8x8 per image, two images
+    x = torch.randn((2, 32) + dhw, generator=g)
+    w = (torch.randn((128, 32, 3, 3, 3), generator=g) / np.sqrt(32 * 27)).double().requires_grad_(True)
+    shift = torch.randn(128, generator=g)
+    y = F.conv3d(x.double(), w, shift.double(), 1, 1)
+    got = _hip.conv3d_forward(_cl(x).to(dev), _hip.pack_conv_weight(w.detach().float()).to(dev), (3, 3, 3), (1, 1, 1), (1, 1, 1),
+                              shift=shift.to(dev))
+    _check(got, y.detach().float(), 'winograd 2d 32 -> 128')
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy.double())
+    ref = _hip.pack_conv_weight(w.grad.float()).double()
+    dw = torch.zeros((27, 32, 128), device=dev)
+    _hip.conv3d_wgrad(_cl(x).to(dev), _cl(dy).to(dev), dw, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    err = (dw.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err <= RTOL, f'wgrad 2d 32 -> 128: max err {err:.3e}'
+
+
 def test_conv3d_unsupported_is_loud(dev):
     from mr3d_amd import _hip
     x = torch.zeros((1, 2, 4, 4, 12), device=dev)      # Cin = 12
