@@ -155,9 +155,12 @@ def test_conv3d_winograd_2d_other_channel_counts(dev):
     y.backward(dy.double())
     ref = _hip.pack_conv_weight(w.grad.float()).double()
     dw = torch.zeros((27, 32, 128), device=dev)
-    _hip.conv3d_wgrad(_cl(x).to(dev), _cl(dy).to(dev), dw, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    db = torch.zeros(128, device=dev)
+    _hip.conv3d_wgrad(_cl(x).to(dev), _cl(dy).to(dev), dw, (3, 3, 3), (1, 1, 1), (1, 1, 1), dbias=db)
     err = (dw.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
     assert err <= RTOL, f'wgrad 2d 32 -> 128: max err {err:.3e}'
+    refb = dy.double().sum((0, 2, 3, 4))
+    assert (db.cpu().double() - refb).abs().max().item() <= 2e-5 * refb.abs().max().item()
 
 
 def test_conv3d_unsupported_is_loud(dev):
