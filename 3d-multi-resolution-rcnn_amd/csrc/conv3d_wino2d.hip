@@ -7,16 +7,17 @@
 //
 // A GEMM row is a 2 (h) x 4 (w) patch of outputs.  Per kd tap and input channel the patch needs the 4 x 6 input window d;
 //   V = Bh^T d Bw        (24 values; Bh^T = F(2,3)'s (d0-d2, d1+d2, d2-d1, d1-d3), Bw^T = Lavin & Gray's F(4,3) matrix)
-//   U = Gh g Gw^T        (24 values per (kd, ci, co), from the 3 x 3 (kh, kw) taps g: computed once per launch by
-//                         wino2d_weights_kernel into a scratch buffer, [kd][Cin][6][Cout][4]: product f = fh*6+fw at [f/4][co][f%4])
+//   U = Gh g Gw^T        (24 values per (kd, ci, co), from the 3 x 3 (kh, kw) taps g: computed once per launch -- once per plan
+//                         stretch for all such convolutions, mr3d_conv3d_wino2d_prepare -- into a scratch buffer, [kd][Cin][6][Cout][4]: product f = fh*6+fw at [f/4][co][f%4])
 //   M[fh][fw] += V[fh][fw] * U[fh][fw]   summed over kd and ci on the matrix cores: 24 accumulator sets,
 //   Y = Ah^T M Aw        (8 outputs) in the epilogue -- 72 MFMA products per 8 outputs and input channel instead of 216 (direct)
 //                         or 108 (F(4,3) along W only).
 // v_mfma_f32_16x16x4_f32: a wave owns 16 GEMM rows x 16 output channels (24 x 4 accumulator registers); the four waves of a
 // workgroup share the 16 rows (2 x 8 x 8 outputs) and split a 64-wide Cout tile.  Per Cin chunk (16 channels) the workgroup
 // stages the halo ([4][10][10] positions, odd row pitch) in LDS, forms V ONCE for its 4 planes x 8 patches x 16 channels
-// (two items per thread, 88 VALU operations each) into a second LDS region laid out for conflict-free fragment reads, and then
-// runs 12 (kd, k-step) steps of 24 MFMAs whose A fragments are plain LDS reads (one step ahead) and whose U fragments come
+// (two items per thread, 88 VALU operations each; the windows are pulled into registers first and V is written OVER the halo:
+// 49 KB of LDS) in a layout whose fragment reads are conflict-free, and then runs 12 (kd, k-step) steps of 24 MFMAs whose A
+// fragments are plain LDS reads (half a step ahead) and whose U fragments come
 // straight from L2, two steps ahead (an L2 round trip is longer than one step).  The halo of the next chunk is fetched at the
 // chunk boundary (the second workgroup of the CU covers it; fetching it piecewise under the MFMA steps was measured equal).
 // Measured on the P2 FPN / RPN conv (40 x 128 x 128, 64 -> 64): 640-660 us against 834 us for the F(4,3) kernel; with every
@@ -24,6 +25,7 @@
 // stream: 0.62 of the 2.4 GHz matrix peak).  Tried and not kept: every wave forming its own V under its MFMAs (720 us: four
 // times the VALU work, U one step ahead for lack of registers), two MFMA tiles per wave at one wave per SIMD (925), a
 // producer / consumer split of a 512-thread workgroup (770: one MFMA wave per SIMD does not fill the pipe), staggered starts.
+// The narrow-Cout kernels further down (conv3d_wino2d_rows_kernel) keep the per-wave V: their waves own different rows.
 #include "conv3d.h"
 #include <cstdlib>
 #include <map>
