@@ -148,16 +148,23 @@ def roi_align3d_backward_ml(top_grad, rois, grads, out_d, out_h, out_w, scales, 
     check(st, 'mr3d_roi_align3d_backward_ml')
 
 
-def nms3d_batched(dets_list, iou_threshold):
+def nms3d_batched(dets_list, iou_threshold, real_rows=None):
     """independent NMS3D problems (e.g. the pyramid levels of one image) in ONE launch sequence and ONE 4*S-byte read-back.
     dets_list: [n_s, 7] fp32 device tensors -> list of int64 kept-index tensors (ascending, relative to their own set).
-    Sets larger than 4096 boxes fall back to one mr3d_nms3d call each."""
+    Sets larger than 4096 boxes fall back to one mr3d_nms3d call each.
+    real_rows: optional list (None or a 0-d device integer tensor per set): only the first real_rows[s] rows of set s are
+    real, the rows behind them are fillers that score below every real row.  Fillers cannot suppress a real row (suppression
+    flows from higher to lower scores), so the kept real rows are exactly those of an NMS over the real rows alone; kept
+    fillers are cut from the returned list.  The counts travel in the same read-back."""
     S = len(dets_list)
     if S == 0:
         return []
     ns = [int(d.size(0)) for d in dets_list]
     if max(ns) > 4096 or S > 16:
-        return [nms3d(d, iou_threshold) for d in dets_list]
+        outs = [nms3d(d, iou_threshold) for d in dets_list]
+        if real_rows is not None:
+            outs = [o if r is None else o[o < r] for o, r in zip(outs, real_rows)]
+        return outs
     dev = dets_list[0].device
     for d in dets_list:
         if not (d.is_cuda and d.dtype == torch.float32 and d.dim() == 2 and d.size(1) == 7):
@@ -178,6 +185,17 @@ def nms3d_batched(dets_list, iou_threshold):
         st = L.mr3d_nms3d_batched(ptr(dets), seg, S, ctypes.c_int(dets.stride(0)), ctypes.c_float(iou_threshold), ptr(keep),
                                   ptr(num), ctypes.c_void_p(ws.data_ptr() + off), ctypes.c_size_t(ws_bytes), stream_ptr(dev))
         check(st, 'mr3d_nms3d_batched')
+        if real_rows is not None and any(r is not None for r in real_rows):
+            # kept indices are ascending, so the kept fillers are the tail of each list: count the kept REAL rows on the device
+            row, cut = 0, []
+            for s_, (n, r) in enumerate(zip(ns, real_rows)):
+                if r is None or n == 0:
+                    cut.append(num[s_])
+                else:
+                    live = torch.arange(n, device=dev) < num[s_]
+                    cut.append(((keep[row:row + n] < r) & live).sum().to(torch.int32))
+                row += n
+            num = torch.stack(cut)
         counts = num.tolist()                    # one host sync for all segments
     out, row = [], 0
     for n, k in zip(ns, counts):

@@ -24,7 +24,7 @@ def get_bboxes_single(cls_scores, bbox_preds, anchor_generators, anchor_strides,
     """cls_scores[l]: [A, D, H, W] logits (any memory format); bbox_preds[l]: [A*6, D, H, W];
     img_shape = (H, W, 3, D).  Returns proposals [<= max_num, 7] = [x1,y1,x2,y2,z1,z2,score]."""
     cfg = _as_cfg(cfg)
-    mlvl = []
+    mlvl, real = [], [None] * len(cls_scores)
     for lvl, (cls, reg) in enumerate(zip(cls_scores, bbox_preds)):
         assert cls.shape[-3:] == reg.shape[-3:]
         A, D, H, W = cls.shape
@@ -33,10 +33,14 @@ def get_bboxes_single(cls_scores, bbox_preds, anchor_generators, anchor_strides,
         if cfg.nms_pre > 0 and scores.shape[0] > cfg.nms_pre:
             # rpn_head_3d.py:95-106: on levels with more anchors than nms_pre the anchors flagged out (the inside-flags
             # cached by the previous loss() call) are dropped BEFORE the top-k.  Masking their score keeps the selection
-            # on the device (the reference's boolean gather synchronises once per level); it only differs if fewer
-            # than nms_pre anchors are flagged in, when the surplus picks carry score -1 and sort last.
+            # on the device (the reference's boolean gather synchronises once per level).  When fewer than nms_pre
+            # anchors are flagged in, the surplus picks carry score -1 and sort last: they ride through the NMS as
+            # fillers behind the real rows (they cannot suppress one) and are cut from its kept list on the device
+            # (`real_rows`), so the level contributes exactly the reference's rows (:95-112).
             if valid_flags is not None and valid_flags[lvl].shape == scores.shape:
-                scores = torch.where(valid_flags[lvl].bool(), scores, scores.new_full((), -1.0))
+                vf = valid_flags[lvl].bool()
+                scores = torch.where(vf, scores, scores.new_full((), -1.0))
+                real[lvl] = vf.sum().clamp(max=cfg.nms_pre)
             scores, flat = scores.topk(cfg.nms_pre)
         else:
             flat = torch.arange(scores.shape[0], device=scores.device)
@@ -51,7 +55,7 @@ def get_bboxes_single(cls_scores, bbox_preds, anchor_generators, anchor_strides,
         mlvl.append(dets)
     # the reference calls nms() once per level (:134); the levels are independent, so they share one batched launch
     # sequence and one read-back of the kept counts
-    keeps = _hip.nms3d_batched(mlvl, cfg.nms_thr)
+    keeps = _hip.nms3d_batched(mlvl, cfg.nms_thr, real_rows=real)
     mlvl = [d[k][:cfg.nms_post, :] for d, k in zip(mlvl, keeps)]
     proposals = torch.cat(mlvl, 0)
     if getattr(cfg, 'nms_across_levels', False):

@@ -81,9 +81,13 @@ class TwoStageDetector3D2Scales(TwoStageDetector3D):
         l2 = self.rpn_head_2.loss(*rpn_outs_2, gt_bboxes_2, img_meta_2, cfg['rpn'], draws_list=draws.get('rpn_2'))
         losses.update(loss_rpn_cls_2=l2['loss_rpn_cls'], loss_rpn_reg_2=l2['loss_rpn_reg'])
         with torch.no_grad():
-            pcfg = SimpleNamespace(**cfg['rpn_proposal'])
-            proposal_list = self.rpn_head.get_bboxes(*rpn_outs, img_meta, pcfg, use_pos_indices=True)
-            proposal_list_2 = self.rpn_head_2.get_bboxes(*rpn_outs_2, img_meta_2, pcfg, use_pos_indices=True)
+            if proposals is None:
+                pcfg = SimpleNamespace(**cfg['rpn_proposal'])
+                proposal_list = self.rpn_head.get_bboxes(*rpn_outs, img_meta, pcfg, use_pos_indices=True)
+                proposal_list_2 = self.rpn_head_2.get_bboxes(*rpn_outs_2, img_meta_2, pcfg, use_pos_indices=True)
+            else:                       # (proposal lists of pathway 1, of pathway 2): the `else` branch of :176-177
+                proposal_list, proposal_list_2 = proposals
+        self.last_proposals = (proposal_list, proposal_list_2)
 
         # ---- assign / sample both pathways (:182-226)
         s1 = self._sample(proposal_list[0], gt_bboxes[0], gt_labels[0], draws.get('rcnn', [None])[0], 0, want_mask=True)

@@ -515,7 +515,8 @@ def main():
         issue_factor = issued_flops / groups[dom]['flops'] if groups[dom]['flops'] else 1.0
         ach = alg * issue_factor
         ms_per_step = el * 1e3 / a.steps
-        peak = PEAK_BF16_MATRIX if '_bf16<' in dom else PEAK_FP32_MATRIX
+        # the engine's arithmetic decides the peak: every kernel of a bf16 run (stem included) multiplies on the bf16 matrix cores
+        peak = PEAK_BF16_MATRIX if a.dtype == 'bf16' else PEAK_FP32_MATRIX
         msg = reduce_buf.numel() * 4 / 1e6
         res = {
             'metric': f'train iters/sec on 512x512x80 vols (ResNet3D-50+FPN3D forward+backward, {"fp32" if a.dtype == "f32" else "bf16 storage / fp32 accumulate"})',
@@ -536,7 +537,7 @@ def main():
                          'avg_launch_ms': dom_ms / launches if launches else None, 'launches_per_step': groups[dom]['n'],
                          'timing': 'HIP events on the launch stream around every launch of this kernel inside the timed steps '
                                    '(the side-stream weight gradients overlap them, as in production)',
-                         'whole_step_frac': FLOP_FWD_BWD_512 * scale / (ms_per_step * 1e-3) / PEAK_FP32_MATRIX},
+                         'whole_step_frac': FLOP_FWD_BWD_512 * scale / (ms_per_step * 1e-3) / peak},
         }
         if world == 1 and not a.no_aux and a.dtype == 'f32':
             try:

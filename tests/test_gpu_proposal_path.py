@@ -106,7 +106,7 @@ def _ref_get_bboxes_single(cls_scores, bbox_preds, gens, strides, dstrides, img_
     return props[top]
 
 
-@pytest.mark.parametrize('channels_last', [False, True, 'flags'])
+@pytest.mark.parametrize('channels_last', [False, True, 'flags', 'few_flags'])
 def test_rpn_get_bboxes_single_vs_restatement(dev, channels_last):
     from mr3d_amd.core import AnchorGenerator3D
     from mr3d_amd.detector import get_bboxes_single
@@ -126,6 +126,11 @@ def test_rpn_get_bboxes_single_vs_restatement(dev, channels_last):
     flags = None
     if channels_last == 'flags':     # the reference's cached inside-flags (rpn_head_3d.py:97-101): random 70 % here
         flags = [(torch.rand(d * h * w, device=dev) < 0.7).to(torch.uint8) for (d, h, w) in sizes]
+    if channels_last == 'few_flags':
+        # fewer than nms_pre anchors of the large level are flagged in (10240 * 0.1 < 1500): the reference takes ALL of them,
+        # unsorted, and nothing else (rpn_head_3d.py:95-112); the masked surplus picks must not reach the output
+        flags = [(torch.rand(d * h * w, device=dev) < 0.1).to(torch.uint8) for (d, h, w) in sizes]
+        assert int(flags[0].sum()) < 1500
     got = get_bboxes_single(cls, reg, gens, strides, dstrides, img_shape, cfg, valid_flags=flags)
     exp = _ref_get_bboxes_single(cls, reg, gens, strides, dstrides, img_shape, cfg, pos_indices=flags)
     assert got.shape == exp.shape

@@ -82,3 +82,56 @@ def test_mask_target_and_paste_gpu_vs_restatement():
     # the kernel evaluates exp() and the double sums on the device: a voxel whose value sits within float32 rounding of the
     # threshold can flip
     assert (pasted.cpu().numpy() != expp).mean() < 1e-5
+
+
+def _microbleeds(rng, D=32, H=128, W=128):
+    """cerebral-microbleed-sized lesions: spheres of 2-5 voxels radius in-plane (2-10 mm at SWI's 0.5-1 mm pixels), 1-3 slices
+    of radius in depth (2 mm slices) -- the GTs the reference trains on -- with proposals the rcnn sampler would call
+    positive (the GT box itself, as add_gt_as_proposals does, and jittered copies with IoU >= 0.5)"""
+    G = 6
+    gt = np.zeros((G, D, H, W), np.uint8)
+    boxes, gi = [], []
+    z, y, x = np.ogrid[:D, :H, :W]
+    for g in range(G):
+        r_xy, r_z = rng.uniform(2.0, 5.0), rng.uniform(1.0, 3.0)
+        c = rng.uniform([r_z + 1, r_xy + 1, r_xy + 1], [D - r_z - 2, H - r_xy - 2, W - r_xy - 2])
+        gt[g] = (((z - c[0]) / r_z) ** 2 + ((y - c[1]) / r_xy) ** 2 + ((x - c[2]) / r_xy) ** 2 <= 1).astype(np.uint8)
+        zz, yy, xx = np.nonzero(gt[g])
+        b = np.array([xx.min(), yy.min(), xx.max(), yy.max(), zz.min(), zz.max()], np.float32)
+        boxes.append(b); gi.append(g)
+        for _ in range(3):                               # jitter by up to ~10 % of the size per face: IoU stays >= 0.5
+            size = np.array([b[2] - b[0] + 1, b[3] - b[1] + 1, b[2] - b[0] + 1, b[3] - b[1] + 1, b[5] - b[4] + 1, b[5] - b[4] + 1])
+            boxes.append(b + rng.uniform(-0.1, 0.1, 6).astype(np.float32) * size); gi.append(g)
+    return gt, np.stack(boxes).astype(np.float32), np.array(gi, np.int64)
+
+
+def test_microbleed_sized_gt_yields_positive_mask_target_voxels():
+    """The target rule is an AND over the voxels under both stencils (an eroded mask when a crop SHRINKS).  Lesions of the size
+    the reference trains on are far smaller than the 20x28x28 target, so every axis is up-sampled and the rule keeps a positive
+    core: (1) the GT box itself -- always among the sampled positives (add_gt_as_proposals, configs/...py:113) -- gives a
+    non-empty target for EVERY lesion, down to 2 slices x 4 x 4 pixels; (2) so does every IoU >= 0.5 proposal of a lesion
+    that spans >= 3 slices.  What the rule cannot rescue (and neither can the reference expression, a subset of it): a proposal
+    whose truncated corner (mask_target.py:37-40 `astype(np.int32)`) cuts one of the only two slices of a 2-slice lesion --
+    the order-1 taps then always straddle an empty slice.  That case is counted, not hidden."""
+    gt, boxes, gi = _microbleeds(np.random.default_rng(7))
+    t = mask_ref.mask_target(gt, boxes, gi, 20, 28, 28)
+    frac = t.reshape(len(boxes), -1).mean(1)
+    exact = frac[::4]                                    # proposals that ARE the GT box
+    assert (exact > 0.05).all(), exact
+    depth = np.array([np.ptp(np.nonzero(gt[g])[0]) + 1 for g in gi])
+    assert depth.min() == 2 and depth.max() >= 4
+    assert (frac[depth >= 3] > 0.1).all(), frac          # an ellipsoid fills pi/6 of its box; the AND rule erodes its rim
+    assert frac.max() < 0.75
+    assert (frac[depth < 3] > 0).mean() >= 0.75          # 2-slice lesions: most jittered proposals still carry signal
+
+
+@pytest.mark.gpu
+def test_microbleed_sized_gt_positive_voxels_gpu():
+    from mr3d_amd.core import mask_target_single
+    gt, boxes, gi = _microbleeds(np.random.default_rng(7))
+    dev = torch.device('cuda:0')
+    got = mask_target_single(torch.from_numpy(boxes).to(dev), torch.from_numpy(gi).to(dev), torch.from_numpy(gt),
+                             dict(mask_size=28, mask_size_depth=20))
+    exp = mask_ref.mask_target(gt, boxes, gi, 20, 28, 28)
+    assert np.array_equal(got.cpu().numpy(), exp)
+    assert (got.flatten(1).sum(1)[::4] >= 1).all()           # the GT boxes themselves: never an empty target
