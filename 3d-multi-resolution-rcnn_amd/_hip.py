@@ -289,7 +289,20 @@ class Conv3dDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n in ('x', 'w', 'y', 'shift', 'add1', 'add2', 'up', 'mask')] + \
                [(n, ctypes.c_int) for n in ('n', 'd', 'h', 'w_in', 'cin', 'cout', 'kd', 'kh', 'kw', 'sd', 'sh', 'sw',
                                             'pd', 'ph', 'pw', 'up_d', 'up_h', 'up_w', 'relu',
-                                            'ys_d', 'ys_h', 'ys_w', 'y_d', 'y_h', 'y_w')]
+                                            'ys_d', 'ys_h', 'ys_w', 'y_d', 'y_h', 'y_w')] + \
+               [('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_longlong)]
+
+
+def _aligned_bytes(nbytes, device):
+    """torch-owned device scratch of `nbytes`, 256-byte aligned: (tensor to keep alive, address)"""
+    t = torch.empty((int(nbytes) + 256,), dtype=torch.uint8, device=device)
+    return t, t.data_ptr() + (-t.data_ptr()) % 256
+
+
+def wino2d_workspace_bytes(cin, cout):
+    fn = lib().mr3d_conv3d_wino2d_workspace_bytes
+    fn.restype = ctypes.c_size_t
+    return int(fn(int(cin), int(cout)))
 
 
 def _opt(t):
@@ -336,9 +349,17 @@ def conv3d_forward(x, w_packed, k, stride, pad, shift=None, add1=None, add2=None
     if out_stride is not None:
         d.ys_d, d.ys_h, d.ys_w = out_stride
         d.y_d, d.y_h, d.y_w = y.size(1), y.size(2), y.size(3)
+    keep = None
+    if tuple(k) == (3, 3, 3) and tuple(stride) == (1, 1, 1):
+        # scratch for the weight-transforming instances (two-dimensional Winograd): lent per call, from torch's caching
+        # allocator (stream-ordered: the next user of the block runs behind this launch)
+        nbytes = wino2d_workspace_bytes(d.cin, d.cout)
+        keep, d.workspace = _aligned_bytes(nbytes, x.device)
+        d.workspace_bytes = nbytes
     with torch.cuda.device(x.device):
         st = lib().mr3d_conv3d_forward(ctypes.byref(d), stream_ptr(x.device))
     check(st, 'mr3d_conv3d_forward')
+    del keep
     return y
 
 
@@ -466,7 +487,8 @@ def conv3d_wgrad(x, dy, dw_packed, k, stride, pad, dbias=None, workspace=None):
 # plan records (mr3d_op / mr3d_layer_desc in include/mr3d.h)
 OP_CONV_FWD, OP_CONV_WGRAD, OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_ZERO_STUFF2, OP_UPSAMPLE_ADJ = 1, 2, 3, 4, 5, 6
 OP_SUBSAMPLE_FWD, OP_SUBSAMPLE_BWD, OP_VOLUME_PACK, OP_MEMSET0, OP_AXPY, OP_PREP_WEIGHTS, OP_FINISH_GRADS = 7, 8, 9, 10, 11, 12, 13
-OP_STEM_FWD, OP_STEM_WGRAD, OP_CONV_DGRAD_S2, OP_PREP_WEIGHTS_BF16, OP_STEM_PACK_BF16 = 14, 15, 16, 17, 18
+OP_STEM_FWD, OP_STEM_WGRAD, OP_CONV_DGRAD_S2, OP_PREP_WEIGHTS_BF16, OP_STEM_PACK_BF16, OP_SYNC, OP_WINO2D_PREP = 14, 15, 16, 17, 18, 19, 20
+SYNC_JOIN, SYNC_MARK, SYNC_WAIT = 0, 1, 2      # mr3d_op.i[0] of an OP_SYNC record
 DTYPE_BF16 = 1          # mr3d_op.i[25]: MR3D_DTYPE_BF16
 
 
@@ -481,25 +503,17 @@ class LayerDesc(ctypes.Structure):
                 ('eps', ctypes.c_float), ('reserved', ctypes.c_int)]
 
 
-def make_op(kind, ptrs=(), ints=(), alpha=0.0):
+def make_op(kind, ptrs=(), ints=(), alpha=0.0, side=False):
+    """side: the record may run on the plan's side stream (mr3d_op.i[26], see mr3d_plan_set_side_stream)"""
     o = Op()
     o.kind = kind
+    if side:
+        o.i[26] = 1
     for k, v in enumerate(ptrs):
         o.p[k] = None if v is None else (v.data_ptr() if hasattr(v, 'data_ptr') else int(v))
     for k, v in enumerate(ints):
         o.i[k] = int(v)
     o.f[0] = float(alpha)
-    # Two-stage reduction of the weight-gradient partial sums (private blocks + a summing kernel, bit-reproducible)
-    # instead of atomics.  Measured per layer it only pays where ALL workgroups finish at once on a small address
-    # set; MR3D_WGRAD_TWO_STAGE = "stem" / "all" / "none" selects the records that borrow the device workspace
-    # (side-stream records only: they run in order on ONE stream and can share it).
-    mode = os.environ.get('MR3D_WGRAD_TWO_STAGE', 'none')
-    if o.i[26] == 1 and not o.p[4] and ((kind == OP_STEM_WGRAD and mode in ('stem', 'all')) or
-                                        (kind == OP_CONV_WGRAD and mode == 'all')):
-        ws = wgrad_workspace(next(v.device for v in ptrs if hasattr(v, 'device')))
-        at = 15 if kind == OP_CONV_WGRAD else 4
-        o.p[4] = ws.data_ptr()
-        o.i[at], o.i[at + 1] = split64(ws.numel() * 4)
     return o
 
 
@@ -509,17 +523,88 @@ def split64(v):
     return (lo - (1 << 32) if lo >= (1 << 31) else lo), (hi - (1 << 32) if hi >= (1 << 31) else hi)
 
 
+class EventPair(ctypes.Structure):
+    """mr3d_event_pair (include/mr3d.h)"""
+    _fields_ = [('start', ctypes.c_void_p), ('stop', ctypes.c_void_p)]
+
+
+class _PairOwner:
+    def __init__(self, pair):
+        self.pair = EventPair(pair.start, pair.stop)
+
+    def __del__(self):
+        if _lib is not None and self.pair.start:
+            _lib.mr3d_event_pair_destroy(ctypes.byref(self.pair))
+
+
+class HipEvent:
+    """one end of a library-created event pair; mirrors torch.cuda.Event.elapsed_time for the pair's two ends"""
+
+    def __init__(self, owner, is_start):
+        self.owner, self.is_start = owner, is_start
+
+    def elapsed_time(self, other):
+        assert self.is_start and other.owner is self.owner and not other.is_start
+        ms = ctypes.c_float()
+        check(lib().mr3d_event_pair_elapsed_ms(ctypes.byref(self.owner.pair), ctypes.byref(ms)), 'mr3d_event_pair_elapsed_ms')
+        return float(ms.value)
+
+
 class Plan:
     """A list of mr3d_op records executed by one mr3d_plan_run call on the current stream."""
 
+    _variant_cache = {}
+
     def __init__(self, ops):
+        ops = self._with_wino2d_prep(list(ops))
         self.n = len(ops)
         self.array = (Op * self.n)(*ops)
         self._failed = ctypes.c_int(-1)
 
+    def _with_wino2d_prep(self, ops):
+        """The two-dimensional Winograd kernels read pre-transformed weights.  The library allocates nothing: the plan owns
+        ONE scratch buffer for the transformed weights of all its qualifying convolutions and a WINO2D_PREP record (inserted
+        in front of the first of them in every stretch between weight-writing records) fills it in one launch.  The buffer
+        lives as long as the plan -- and therefore as long as any hipGraph captured from it."""
+        out, self._u_ws = [], []
+        k = 0
+        while k < len(ops):
+            # one stretch: [k, e) up to (not including) the next weight-writing record behind a conv
+            e, first, need, seen = k, None, 0, set()
+            while e < len(ops) and not (ops[e].kind in (OP_PREP_WEIGHTS, OP_PREP_WEIGHTS_BF16) and first is not None):
+                o = ops[e]
+                if o.kind == OP_CONV_FWD and o.i[25] != DTYPE_BF16 and o.i[6] == 3 and o.p[1] not in seen:
+                    key = tuple(o.i[0:25])
+                    if key not in Plan._variant_cache:
+                        Plan._variant_cache[key] = op_conv_variant(o).winograd
+                    if Plan._variant_cache[key] == 8:
+                        first = e if first is None else first
+                        seen.add(o.p[1])
+                        need += wino2d_workspace_bytes(o.i[4], o.i[5])
+                e += 1
+            if first is not None:
+                dev = torch.device('cuda', torch.cuda.current_device())
+                keep, addr = _aligned_bytes(need, dev)
+                self._u_ws.append(keep)
+                out += ops[k:first] + [make_op(OP_WINO2D_PREP, [addr], split64(need))] + ops[first:e]
+            else:
+                out += ops[k:e]
+            k = e
+        return out
+
     def _run_range(self, lo, hi, device):
         if hi <= lo:
             return
+        if hi == lo + 1 and self.array[lo].kind == OP_CONV_FWD and self._u_ws:
+            # a conv record run on its own (per-op timing): the transformed weights only live during the run that prepared
+            # them, so the nearest WINO2D_PREP record in front of it rides along (it prepares exactly this conv)
+            prep = next((j for j in range(lo - 1, -1, -1) if self.array[j].kind == OP_WINO2D_PREP), None)
+            if prep is not None:
+                pair = (Op * 2)(self.array[prep], self.array[lo])
+                st = lib().mr3d_plan_run(pair, ctypes.c_int(2), ctypes.byref(self._failed), stream_ptr(device))
+                if st != OK:
+                    raise Mr3dError(f'mr3d_plan_run: op #{lo} failed: {lib().mr3d_status_string(int(st)).decode()}')
+                return
         base = ctypes.cast(ctypes.byref(self.array, lo * ctypes.sizeof(Op)), ctypes.POINTER(Op))
         st = lib().mr3d_plan_run(base, ctypes.c_int(hi - lo), ctypes.byref(self._failed), stream_ptr(device))
         if st != OK:
@@ -548,6 +633,22 @@ class Plan:
         g = getattr(self, '_graph', None)
         if g is not None and _lib is not None:
             _lib.mr3d_graph_destroy(g)
+
+    def run_marked(self, marks, device=None):
+        """The whole plan in ONE mr3d_plan_run_marked call -- the production launch sequence, side stream and all -- with HIP
+        timing events around the records `marks`, each on the stream its record really runs on.  Returns {index: (start,
+        stop)} of HipEvent objects; `start.elapsed_time(stop)` is valid once the device has been synchronised."""
+        marks = sorted(marks)
+        arr = (ctypes.c_int * len(marks))(*marks)
+        pairs = (EventPair * len(marks))()
+        st = lib().mr3d_plan_run_marked(self.array, self.n, ctypes.byref(self._failed), stream_ptr(device), arr, len(marks), pairs)
+        if st != OK:
+            raise Mr3dError(f'mr3d_plan_run_marked: op #{self._failed.value} failed: {lib().mr3d_status_string(int(st)).decode()}')
+        out = {}
+        for k, m in enumerate(marks):
+            owner = _PairOwner(pairs[k])
+            out[m] = (HipEvent(owner, True), HipEvent(owner, False))
+        return out
 
     def run(self, device=None, marks=None):
         """Enqueue every op on torch's current stream.  marks: optional sorted op indices to bracket with
@@ -584,6 +685,7 @@ def op_conv_variant(op):
     for k, name in enumerate(('x', 'w', 'y', 'shift', 'add1', 'add2', 'up', 'mask')):
         setattr(d, name, op.p[k])
     ctypes.memmove(ctypes.addressof(d) + Conv3dDesc.n.offset, ctypes.addressof(op.i), 25 * 4)
+    d.workspace_bytes = -1                 # a plan lends the scratch of the weight-transforming instances (WINO2D_PREP)
     v = Conv3dVariant()
     check(lib().mr3d_conv3d_forward_variant(ctypes.byref(d), ctypes.byref(v)), 'mr3d_conv3d_forward_variant')
     return v

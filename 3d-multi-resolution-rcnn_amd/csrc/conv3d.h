@@ -21,6 +21,10 @@ struct Conv3dFwdArgs {
   // y is a [N, yD, yH, yW, Cout] buffer; output (od,oh,ow) lands at (od*ysd, oh*ysh, ow*ysw): lets a
   // coarse-grid result be scattered onto the even positions of a pre-zeroed fine grid (stride-2 dgrad)
   int ysd, ysh, ysw, yD, yH, yW;
+  // caller-lent scratch for instances that transform the weights (two-dimensional Winograd); ws_bytes = -1: variant query
+  // that assumes it
+  float *ws = nullptr;
+  long long ws_bytes = 0;
 };
 
 struct Conv3dWgradArgs {
@@ -50,8 +54,9 @@ bool mr3d_conv3d_wino2d_ok(const Conv3dFwdArgs &a);
 int mr3d_conv3d_wino2d(const Conv3dFwdArgs &a, hipStream_t stream);
 bool mr3d_conv3d_wino2d_rows_ok(const Conv3dFwdArgs &a);          // Cout 16 / 32
 int mr3d_conv3d_wino2d_rows(const Conv3dFwdArgs &a, hipStream_t stream);
-// plan pre-pass: the weight transforms of n convolutions in one launch (see conv3d_wino2d.hip)
-int mr3d_conv3d_wino2d_prepare(const float *const *w, const int *cin, const int *cout, int n, hipStream_t stream);
+// plan pre-pass: the weight transforms of n convolutions in one launch into the caller's workspace (see conv3d_wino2d.hip)
+int mr3d_conv3d_wino2d_prepare(const float *const *w, const int *cin, const int *cout, int n, float *ws, long long ws_bytes,
+                               hipStream_t stream);
 void mr3d_conv3d_wino2d_prepare_end();
 
 // two-dimensional Winograd form of the 3x3x3 / stride-1 weight gradient (conv3d_wgrad_wino2d.hip): F(3,2) along H x F(3,4) along W

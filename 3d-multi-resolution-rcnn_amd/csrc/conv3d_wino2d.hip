@@ -468,22 +468,14 @@ __global__ __launch_bounds__(256) void wino2d_weights_batched_kernel(PrepTable t
 // weights already transformed for the plan run in progress on this thread: packed-weight pointer -> U
 thread_local std::map<const float *, const float *> g_prepared;
 
-// U scratch: one buffer per (device, stream) -- launches on one stream are ordered, so they may share it
-struct Scratch { float *p = nullptr; size_t floats = 0; };
-std::mutex g_mu;
-std::map<std::pair<int, hipStream_t>, Scratch> g_scratch, g_scratch_plan;
-float *u_scratch(size_t floats, hipStream_t stream, bool plan = false) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  std::lock_guard<std::mutex> lock(g_mu);
-  Scratch &s = (plan ? g_scratch_plan : g_scratch)[{dev, stream}];
-  if (floats > s.floats) {
-    if (s.p) (void)hipFree(s.p);
-    s.p = nullptr;
-    if (hipMalloc(reinterpret_cast<void **>(&s.p), floats * sizeof(float)) != hipSuccess) { s.floats = 0; return nullptr; }
-    s.floats = floats;
-  }
-  return s.p;
+size_t u_floats(int cin, int cout) { return ((size_t)3 * NF * cin * cout + 63) / 64 * 64; }
+
+// Where the transformed weights of a launch come from: the plan run in progress prepared them (WINO2D_PREP), or the
+// caller lent a scratch buffer with the call; nothing is allocated here.
+bool u_available(const Conv3dFwdArgs &a) {
+  if (a.ws_bytes == -1) return true;                                   // variant query: assume the scratch
+  if (g_prepared.find(a.w) != g_prepared.end()) return true;
+  return a.ws && a.ws_bytes >= (long long)(u_floats(a.Cin, a.Cout) * sizeof(float));
 }
 
 }  // namespace
@@ -491,7 +483,7 @@ float *u_scratch(size_t floats, hipStream_t stream, bool plan = false) {
 // narrow Cout tiles: Cout 16 or 32 exactly (a wider Cout takes the 64-wide kernel or the one-dimensional forms)
 bool mr3d_conv3d_wino2d_rows_ok(const Conv3dFwdArgs &a) {
   return a.Cin % CC == 0 && (a.Cout == 16 || a.Cout == 32) && a.Do == a.D + 2 * a.pd - 2 && a.Ho == a.H + 2 * a.ph - 2 &&
-         a.Wo == a.W + 2 * a.pw - 2;
+         a.Wo == a.W + 2 * a.pw - 2 && u_available(a);
 }
 
 template <int WN>
@@ -510,12 +502,12 @@ static int launch_rows(const Conv3dFwdArgs &a, const float *U, hipStream_t strea
   return mr3d_launch_status();
 }
 
-// U of a launch: prepared by the plan run in progress, else transformed now into the per-stream scratch
+// U of a launch: prepared by the plan run in progress, else transformed now into the scratch the caller lent
 static const float *u_for(const Conv3dFwdArgs &a, hipStream_t stream) {
   const auto it = g_prepared.find(a.w);
   if (it != g_prepared.end()) return it->second;
-  float *U = u_scratch((size_t)3 * NF * a.Cin * a.Cout, stream);
-  if (!U) return nullptr;
+  if (!a.ws || a.ws_bytes < (long long)(u_floats(a.Cin, a.Cout) * sizeof(float))) return nullptr;
+  float *U = a.ws;
   const int nw = 3 * a.Cin * a.Cout;
   wino2d_weights_kernel<<<(nw + 255) / 256, 256, 0, stream>>>(a.w, U, a.Cin, a.Cout);
   return U;
@@ -529,19 +521,20 @@ int mr3d_conv3d_wino2d_rows(const Conv3dFwdArgs &a, hipStream_t stream) {
 
 // plan pre-pass: transform the weights of n convolutions (packed [27][cin][cout] each) in ONE launch; until
 // mr3d_conv3d_wino2d_prepare_end() the launches of this thread that use one of these weight buffers skip their own transform
-int mr3d_conv3d_wino2d_prepare(const float *const *w, const int *cin, const int *cout, int n, hipStream_t stream) {
+int mr3d_conv3d_wino2d_prepare(const float *const *w, const int *cin, const int *cout, int n, float *ws, long long ws_bytes,
+                               hipStream_t stream) {
   if (n <= 0) return MR3D_OK;
-  if (n > kPrepMax) n = kPrepMax;                          // the rest transform at their launch
+  if (n > kPrepMax) n = kPrepMax;                          // the rest take the kernels that need no transform
   size_t total = 0;
-  for (int k = 0; k < n; ++k) total += (size_t)3 * NF * cin[k] * cout[k];
-  float *base = u_scratch(total, stream, true);
-  if (!base) return MR3D_ERR_LAUNCH;
+  for (int k = 0; k < n; ++k) total += u_floats(cin[k], cout[k]);
+  if (!ws || ((uintptr_t)ws & 255) || ws_bytes < (long long)(total * sizeof(float))) return MR3D_ERR_WORKSPACE;
+  float *base = ws;
   PrepTable t{};
   size_t off = 0;
   int maxw = 0;
   for (int k = 0; k < n; ++k) {
     t.w[k] = w[k]; t.U[k] = base + off; t.cin[k] = cin[k]; t.cout[k] = cout[k];
-    off += (size_t)3 * NF * cin[k] * cout[k];
+    off += u_floats(cin[k], cout[k]);
     maxw = maxw > 3 * cin[k] * cout[k] ? maxw : 3 * cin[k] * cout[k];
   }
   wino2d_weights_batched_kernel<<<dim3((maxw + 255) / 256, n), 256, 0, stream>>>(t);
@@ -553,8 +546,14 @@ int mr3d_conv3d_wino2d_prepare(const float *const *w, const int *cin, const int 
 
 void mr3d_conv3d_wino2d_prepare_end() { g_prepared.clear(); }
 
+extern "C" size_t mr3d_conv3d_wino2d_workspace_bytes(int cin, int cout) {
+  if (cin <= 0 || cout <= 0) return 0;
+  return u_floats(cin, cout) * sizeof(float);
+}
+
 bool mr3d_conv3d_wino2d_ok(const Conv3dFwdArgs &a) {
-  return a.Cin % CC == 0 && a.Cout % 64 == 0 && a.Do == a.D + 2 * a.pd - 2 && a.Ho == a.H + 2 * a.ph - 2 && a.Wo == a.W + 2 * a.pw - 2;
+  return a.Cin % CC == 0 && a.Cout % 64 == 0 && a.Do == a.D + 2 * a.pd - 2 && a.Ho == a.H + 2 * a.ph - 2 && a.Wo == a.W + 2 * a.pw - 2 &&
+         u_available(a);
 }
 
 int mr3d_conv3d_wino2d(const Conv3dFwdArgs &a, hipStream_t stream) {

@@ -23,6 +23,7 @@ int run_one(const mr3d_op &o, mr3d_stream_t s, bool shared_ws = true) {
       d.x = (const float *)p[0]; d.w = (const float *)p[1]; d.y = (float *)p[2]; d.shift = (const float *)p[3];
       d.add1 = (const float *)p[4]; d.add2 = (const float *)p[5]; d.up = (const float *)p[6]; d.mask = (const float *)p[7];
       memcpy(&d.n, i, sizeof(int) * 25);
+      d.workspace = nullptr; d.workspace_bytes = 0;      // transformed weights come from the plan's WINO2D_PREP record, if any
       return bf16 ? mr3d_conv3d_forward_bf16(&d, s) : mr3d_conv3d_forward(&d, s);
     }
     case MR3D_OP_CONV_DGRAD_S2: {
@@ -30,6 +31,7 @@ int run_one(const mr3d_op &o, mr3d_stream_t s, bool shared_ws = true) {
       d.x = (const float *)p[0]; d.w = (const float *)p[1]; d.y = (float *)p[2]; d.shift = nullptr;
       d.add1 = (const float *)p[4]; d.add2 = (const float *)p[5]; d.up = nullptr; d.mask = (const float *)p[7];
       memcpy(&d.n, i, sizeof(int) * 25);
+      d.workspace = nullptr; d.workspace_bytes = 0;
       return mr3d_conv3d_dgrad_s2k3(&d, s);
     }
     case MR3D_OP_CONV_WGRAD: {
@@ -100,28 +102,25 @@ namespace {
 // another.  Fork: event recorded on the caller's stream right before the op -> side stream waits on it.
 // Join: before FINISH_GRADS and at the end of every call.
 struct SideStream {
-  hipStream_t streams[4] = {};
-  int nstreams = 1;
-  hipEvent_t joins[4] = {};
+  hipStream_t stream = nullptr;
+  hipEvent_t join_ev = nullptr;
   hipEvent_t fork[16] = {};
+  hipEvent_t mark[4] = {};          // MR3D_OP_SYNC slots: a point of the side queue the caller's stream can wait for
   int next = 0;
   bool ok = false;
   bool init() {
     if (ok) return true;
-    if (const char *e = getenv("MR3D_SIDE_STREAMS")) nstreams = atoi(e) < 1 ? 1 : (atoi(e) > 4 ? 4 : atoi(e));
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     // The side stream asks for the HIGH priority class so that the runtime gives it a hardware queue of its own: a
     // default-priority stream can be folded onto the same hardware queue as the caller's stream once other
     // libraries hold streams too -- measured with an RCCL communicator alive: 17.4 instead of 15.6 ms/step, all of
-    // the weight-gradient overlap gone (kernel durations unchanged).  MR3D_SIDE_PRIO=0 / 1 select normal / low.
-    int prio = hi;
-    if (const char *e = getenv("MR3D_SIDE_PRIO")) prio = atoi(e) > 0 ? lo : (atoi(e) < 0 ? hi : 0);
-    for (int i = 0; i < nstreams; ++i) {
-      if (hipStreamCreateWithPriority(&streams[i], hipStreamNonBlocking, prio) != hipSuccess) return false;
-      if (hipEventCreateWithFlags(&joins[i], hipEventDisableTiming) != hipSuccess) return false;
-    }
+    // the weight-gradient overlap gone (kernel durations unchanged).
+    if (hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, hi) != hipSuccess) return false;
+    if (hipEventCreateWithFlags(&join_ev, hipEventDisableTiming) != hipSuccess) return false;
     for (auto &e : fork)
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+    for (auto &e : mark)
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
     ok = true;
     return true;
@@ -134,15 +133,22 @@ SideStream g_sides[kMaxDevices];
 std::mutex g_side_mu[kMaxDevices];
 int g_side_enabled = 1;
 
+// records that may run beside the caller's stream: they read finished tensors and write buffers nobody on the main chain
+// touches before the next join / wait (weight gradients, the table-driven weight preparation and gradient finishing, the
+// zero-fill of the weight-gradient scratch)
 bool wants_side(const mr3d_op &o) {
-  return o.i[26] == 1 && (o.kind == MR3D_OP_CONV_WGRAD || o.kind == MR3D_OP_STEM_WGRAD);
+  return o.i[26] == 1 && (o.kind == MR3D_OP_CONV_WGRAD || o.kind == MR3D_OP_STEM_WGRAD || o.kind == MR3D_OP_PREP_WEIGHTS ||
+                          o.kind == MR3D_OP_PREP_WEIGHTS_BF16 || o.kind == MR3D_OP_MEMSET0 || o.kind == MR3D_OP_FINISH_GRADS);
 }
 
 }  // namespace
 
 extern "C" void mr3d_plan_set_side_stream(int enable) { g_side_enabled = enable; }
 
-extern "C" int mr3d_plan_run(const mr3d_op *ops, int num_ops, int *failed_index, mr3d_stream_t stream) {
+namespace {
+
+int plan_run_impl(const mr3d_op *ops, int num_ops, int *failed_index, mr3d_stream_t stream, const int *marks, int num_marks,
+                  mr3d_event_pair *pairs) {
   if (!ops || num_ops < 0) return MR3D_ERR_INVALID_ARG;
   hipStream_t main_s = mr3d_stream(stream);
   int dev = 0;
@@ -152,70 +158,116 @@ extern "C" int mr3d_plan_run(const mr3d_op *ops, int num_ops, int *failed_index,
   // a single-op call (used to time one kernel) always runs on the caller's stream
   const bool use_side = g_side_enabled && num_ops > 1 && g_side.init();
   bool side_busy = false;
-  int nside = 0;
   auto join = [&]() {
     if (!side_busy) return true;
     side_busy = false;
-    for (int i = 0; i < g_side.nstreams; ++i)
-      if (hipEventRecord(g_side.joins[i], g_side.streams[i]) != hipSuccess || hipStreamWaitEvent(main_s, g_side.joins[i], 0) != hipSuccess)
-        return false;
-    return true;
+    return hipEventRecord(g_side.join_ev, g_side.stream) == hipSuccess && hipStreamWaitEvent(main_s, g_side.join_ev, 0) == hipSuccess;
   };
-  // Weight transforms of the two-dimensional Winograd convolutions (conv3d_wino2d.hip): ONE launch per stretch of records
-  // between weight-writing records instead of one in front of every such convolution (16 per step: 0.5 ms of 11.8).
-  int prepared_upto = 0;
-  auto prepare_wino2d = [&](int k0) {
-    int k1 = k0;
+  // WINO2D_PREP record at k0: the weight transforms of the two-dimensional Winograd convolutions (conv3d_wino2d.hip) of the
+  // records behind it, up to the next weight-writing record, in ONE launch into the plan-owned workspace (one launch in
+  // front of every such convolution cost 0.5 ms of an 11.8 ms step)
+  auto prepare_wino2d = [&](int k0, float *ws, long long ws_bytes) {
     const float *w[32];
     int cin[32], cout[32], n = 0;
-    for (; k1 < num_ops; ++k1) {
+    for (int k1 = k0 + 1; k1 < num_ops; ++k1) {
       const mr3d_op &o = ops[k1];
-      if (k1 > k0 && (o.kind == MR3D_OP_PREP_WEIGHTS || o.kind == MR3D_OP_PREP_WEIGHTS_BF16)) break;      // they rewrite weights
+      if (o.kind == MR3D_OP_PREP_WEIGHTS || o.kind == MR3D_OP_PREP_WEIGHTS_BF16 || o.kind == MR3D_OP_WINO2D_PREP) break;
       if (o.kind != MR3D_OP_CONV_FWD || o.i[25] == MR3D_DTYPE_BF16 || n == 32) continue;
       mr3d_conv3d_desc d{};
       d.w = (const float *)o.p[1];
       memcpy(&d.n, o.i, sizeof(int) * 25);
+      d.workspace_bytes = -1;
       mr3d_conv3d_variant v;
       if (mr3d_conv3d_forward_variant(&d, &v) != MR3D_OK || v.winograd != 8) continue;
       bool seen = false;
       for (int j = 0; j < n; ++j) seen = seen || w[j] == d.w;
       if (!seen) { w[n] = d.w; cin[n] = d.cin; cout[n] = d.cout; ++n; }
     }
-    prepared_upto = k1;
-    return mr3d_conv3d_wino2d_prepare(w, cin, cout, n, main_s);
+    return mr3d_conv3d_wino2d_prepare(w, cin, cout, n, ws, ws_bytes, main_s);
   };
   struct PrepEnd { ~PrepEnd() { mr3d_conv3d_wino2d_prepare_end(); } } prep_end;
+  int next_mark = 0;
+  auto fail = [&](int k, int st) {
+    if (failed_index) *failed_index = k;
+    join();
+    return st;
+  };
   for (int k = 0; k < num_ops; ++k) {
-    int st;
-    if (ops[k].kind == MR3D_OP_CONV_FWD && k >= prepared_upto && num_ops > 1) {
-      st = prepare_wino2d(k);
-      if (st != MR3D_OK) {
-        if (failed_index) *failed_index = k;
-        join();
-        return st;
+    int st = MR3D_OK;
+    if (ops[k].kind == MR3D_OP_SYNC) {
+      // 0: the caller's stream waits for everything queued on the side stream so far; 1: remember this point of the side
+      // queue in slot i[1]; 2: the caller's stream waits for the point remembered in slot i[1]
+      const int mode = ops[k].i[0], slot = ops[k].i[1] & 3;
+      if (use_side) {
+        bool ok = true;
+        if (mode == 0) ok = join();
+        else if (mode == 1) ok = hipEventRecord(g_side.mark[slot], g_side.stream) == hipSuccess;
+        else if (mode == 2) ok = hipStreamWaitEvent(main_s, g_side.mark[slot], 0) == hipSuccess;
+        if (!ok) return fail(k, MR3D_ERR_LAUNCH);
       }
+      continue;
     }
-    if (use_side && wants_side(ops[k])) {
+    if (ops[k].kind == MR3D_OP_WINO2D_PREP) {
+      mr3d_conv3d_wino2d_prepare_end();
+      st = prepare_wino2d(k, (float *)ops[k].p[0], i64_of(ops[k].i));
+      if (st != MR3D_OK) return fail(k, st);
+      continue;
+    }
+    const bool on_side = use_side && wants_side(ops[k]);
+    hipStream_t run_s = on_side ? g_side.stream : main_s;
+    const bool marked = marks && next_mark < num_marks && marks[next_mark] == k;
+    if (on_side) {
       hipEvent_t ev = g_side.fork[g_side.next++ & 15];
-      hipStream_t ss = g_side.streams[nside++ % g_side.nstreams];
-      if (hipEventRecord(ev, main_s) != hipSuccess || hipStreamWaitEvent(ss, ev, 0) != hipSuccess) {
-        if (failed_index) *failed_index = k;
-        return MR3D_ERR_LAUNCH;
-      }
-      // one side stream: its records run in order and may share the partial-sum workspace; with several they could overlap
-      st = run_one(ops[k], (mr3d_stream_t)ss, g_side.nstreams == 1);
+      if (hipEventRecord(ev, main_s) != hipSuccess || hipStreamWaitEvent(g_side.stream, ev, 0) != hipSuccess)
+        return fail(k, MR3D_ERR_LAUNCH);
       side_busy = true;
-    } else {
-      if (ops[k].kind == MR3D_OP_FINISH_GRADS && !join()) st = MR3D_ERR_LAUNCH;
-      else st = run_one(ops[k], stream);
+    } else if (ops[k].kind == MR3D_OP_FINISH_GRADS && !join()) {
+      return fail(k, MR3D_ERR_LAUNCH);
     }
-    if (st != MR3D_OK) {
-      if (failed_index) *failed_index = k;
-      join();
-      return st;
+    if (marked) {        // timing events on the stream the record really runs on; the caller reads them after a sync
+      hipEvent_t a = nullptr, b = nullptr;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return fail(k, MR3D_ERR_LAUNCH);
+      pairs[next_mark].start = a; pairs[next_mark].stop = b;
+      if (hipEventRecord(a, run_s) != hipSuccess) return fail(k, MR3D_ERR_LAUNCH);
     }
+    st = run_one(ops[k], (mr3d_stream_t)run_s);
+    if (marked) {
+      if (hipEventRecord((hipEvent_t)pairs[next_mark].stop, run_s) != hipSuccess && st == MR3D_OK) st = MR3D_ERR_LAUNCH;
+      ++next_mark;
+    }
+    if (st != MR3D_OK) return fail(k, st);
   }
   return join() ? MR3D_OK : MR3D_ERR_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" int mr3d_plan_run(const mr3d_op *ops, int num_ops, int *failed_index, mr3d_stream_t stream) {
+  return plan_run_impl(ops, num_ops, failed_index, stream, nullptr, 0, nullptr);
+}
+
+extern "C" int mr3d_plan_run_marked(const mr3d_op *ops, int num_ops, int *failed_index, mr3d_stream_t stream, const int *marks,
+                                    int num_marks, mr3d_event_pair *pairs) {
+  if (num_marks < 0 || (num_marks > 0 && (!marks || !pairs))) return MR3D_ERR_INVALID_ARG;
+  for (int j = 0; j < num_marks; ++j) {
+    if (marks[j] < 0 || marks[j] >= num_ops || (j > 0 && marks[j] <= marks[j - 1]) || ops[marks[j]].kind == MR3D_OP_SYNC ||
+        ops[marks[j]].kind == MR3D_OP_WINO2D_PREP)
+      return MR3D_ERR_INVALID_ARG;
+    pairs[j].start = pairs[j].stop = nullptr;
+  }
+  return plan_run_impl(ops, num_ops, failed_index, stream, marks, num_marks, pairs);
+}
+
+extern "C" int mr3d_event_pair_elapsed_ms(const mr3d_event_pair *pair, float *ms) {
+  if (!pair || !pair->start || !pair->stop || !ms) return MR3D_ERR_INVALID_ARG;
+  return hipEventElapsedTime(ms, (hipEvent_t)pair->start, (hipEvent_t)pair->stop) == hipSuccess ? MR3D_OK : MR3D_ERR_LAUNCH;
+}
+
+extern "C" void mr3d_event_pair_destroy(mr3d_event_pair *pair) {
+  if (!pair) return;
+  if (pair->start) (void)hipEventDestroy((hipEvent_t)pair->start);
+  if (pair->stop) (void)hipEventDestroy((hipEvent_t)pair->stop);
+  pair->start = pair->stop = nullptr;
 }
 
 // ---------------------------------------------------------------------------------------------- hipGraph replay

@@ -418,35 +418,32 @@ class ExtractFeat3D(nn.Module):
         self._building = P.buffers = []
         fwd, bwd = [], []
         nL = len(self.specs)
-        prep = _hip.make_op(_hip.OP_PREP_WEIGHTS, [self._table, self._arena, self._packed], [nL])
-        fwd.append(prep)
+        dsz = ctypes.sizeof(_hip.LayerDesc)
+        # Weight preparation (BN fold + repack of all 61 layers, ~60 us): only the stem's descriptor is needed before the stem
+        # kernel, so the rest runs on the plan's side stream underneath it and is joined in front of the first other conv
+        fwd.append(_hip.make_op(_hip.OP_PREP_WEIGHTS, [self._table.data_ptr() + dsz, self._arena, self._packed], [nL - 1], side=True))
+        fwd.append(_hip.make_op(_hip.OP_PREP_WEIGHTS, [self._table, self._arena, self._packed], [1]))
         if self.bf16:
-            fwd.append(_hip.make_op(_hip.OP_PREP_WEIGHTS_BF16, [self._table16, self._arena, self._packed16], [self._table16_len]))
+            fwd.append(_hip.make_op(_hip.OP_PREP_WEIGHTS_BF16, [self._table16, self._arena, self._packed16], [self._table16_len], side=True))
         # ---------------- forward
         P.x_in = self._new((N, 3, D, H, W), torch.float32)
         stem = self.specs[0]
         P.stem_out = self._new(self._out_shape((N, D, H, W, 4), stem))
-        generic_stem = os.environ.get('MR3D_GENERIC_STEM') == '1' and not self.bf16     # A/B switch: generic implicit-GEMM kernels
-        if generic_stem:
-            P.x4 = self._new((N, D, H, W, 4))
-            fwd.append(_hip.make_op(_hip.OP_VOLUME_PACK, [P.x_in, P.x4], [N, D, H, W]))
-            fwd.append(self._conv_fwd(P.x4, stem, P.stem_out, relu=True))
+        # the stem kernels read the planar volume directly (no NDHWC repack)
+        # bf16 engine: the stem runs on the bf16 matrix cores too (csrc/stem_bf16.hip)
+        P.stem_bf16 = self.bf16
+        if P.stem_bf16:
+            fwd.append(_hip.make_op(_hip.OP_STEM_PACK_BF16, [self._w(stem, 'wf'), self._stem_w16], []))
+            fwd.append(self._op(_hip.OP_STEM_FWD, [P.x_in, self._stem_w16, self._w(stem, 'shift'), P.stem_out], [N, D, H, W, 1, 1]))
         else:
-            # the stem kernels read the planar volume directly (no NDHWC repack)
-            # bf16 engine: the stem runs on the bf16 matrix cores too (csrc/stem_bf16.hip); MR3D_STEM_BF16=0 keeps the fp32-MFMA
-            # stem kernels with bf16 output / dy (A/B switch)
-            P.stem_bf16 = self.bf16 and os.environ.get('MR3D_STEM_BF16', '1') != '0'
-            if P.stem_bf16:
-                fwd.append(_hip.make_op(_hip.OP_STEM_PACK_BF16, [self._w(stem, 'wf'), self._stem_w16], []))
-                fwd.append(self._op(_hip.OP_STEM_FWD, [P.x_in, self._stem_w16, self._w(stem, 'shift'), P.stem_out], [N, D, H, W, 1, 1]))
-            else:
-                fwd.append(self._op(_hip.OP_STEM_FWD, [P.x_in, self._w(stem, 'wf'), self._w(stem, 'shift'), P.stem_out],
-                                    [N, D, H, W, 1]))
+            fwd.append(self._op(_hip.OP_STEM_FWD, [P.x_in, self._w(stem, 'wf'), self._w(stem, 'shift'), P.stem_out],
+                                [N, D, H, W, 1]))
         _, sd, sh, sw, _ = P.stem_out.shape
         pshape = (N, (sd - 1) // 2 + 1, (sh - 1) // 2 + 1, (sw - 1) // 2 + 1, 16)
         P.pool_out = self._new(pshape)
         P.pool_idx = self._new(pshape[:4] + (4,), torch.int32)
         fwd.append(self._op(_hip.OP_MAXPOOL_FWD, [P.stem_out, P.pool_out, P.pool_idx], [N, sd, sh, sw, 16]))
+        fwd.append(_hip.make_op(_hip.OP_SYNC, [], [_hip.SYNC_JOIN]))          # the other layers' weights are ready from here on
         x = P.pool_out
         P.blk = []
         stage_outs = []
@@ -490,7 +487,10 @@ class ExtractFeat3D(nn.Module):
 
         # ---------------- backward
         P.gouts = [self._new(o.shape) for o in P.outs]
-        bwd.append(_hip.make_op(_hip.OP_MEMSET0, [self._scratch], _hip.split64(self._scratch.numel() * 4)))
+        # the weight-gradient scratch is zeroed on the side stream (every conv weight gradient queues behind it there); the
+        # stem weight gradient, which runs on the main stream, waits for that point of the side queue (slot 0)
+        bwd.append(_hip.make_op(_hip.OP_MEMSET0, [self._scratch], _hip.split64(self._scratch.numel() * 4), side=True))
+        bwd.append(_hip.make_op(_hip.OP_SYNC, [], [_hip.SYNC_MARK, 0]))
         if self.neck_dcn:
             glat = P.gouts                          # gradients w.r.t. the lateral sums arrive from the deformable neck
             P.n_direct = 1                          # glat[1..3] also receive the upsample adjoint in place: plan-owned
@@ -552,13 +552,16 @@ class ExtractFeat3D(nn.Module):
             g = gx
         g_stem = self._new(P.stem_out.shape)
         bwd.append(self._op(_hip.OP_MAXPOOL_BWD, [g, P.pool_idx, P.stem_out, g_stem], [N, sd, sh, sw, 16]))
-        if generic_stem:
-            bwd.append(self._conv_wgrad(P.x4, g_stem, stem))
-        else:
-            bwd.append(self._op(_hip.OP_STEM_WGRAD, [P.x_in, g_stem, self._s(stem, 'dwraw'), self._s(stem, 'dbias')],
-                                [N, D, H, W, 0, 0, 1 if getattr(P, 'stem_bf16', False) else 0] + [0] * 19 + [1]))
-        bwd.append(_hip.make_op(_hip.OP_FINISH_GRADS, [self._table, self._arena, self._scratch, self._grad_arena],
-                                [nL, self.max_cout]))
+        # The stem weight gradient (1.8 ms) needs the last data gradient, so it closes the main chain; the gradient finishing
+        # of every OTHER layer (dW = s dW', BN gamma / beta from the raw sums, ~0.11 ms) queues on the side stream behind the
+        # last conv weight gradient and runs underneath it; only the stem's own 16 channels are finished after the join.
+        bwd.append(_hip.make_op(_hip.OP_SYNC, [], [_hip.SYNC_WAIT, 0]))
+        bwd.append(self._op(_hip.OP_STEM_WGRAD, [P.x_in, g_stem, self._s(stem, 'dwraw'), self._s(stem, 'dbias')],
+                            [N, D, H, W, 0, 0, 1 if P.stem_bf16 else 0]))
+        bwd.append(_hip.make_op(_hip.OP_FINISH_GRADS, [self._table.data_ptr() + dsz, self._arena, self._scratch, self._grad_arena],
+                                [nL - 1, self.max_cout], side=True))
+        bwd.append(_hip.make_op(_hip.OP_SYNC, [], [_hip.SYNC_JOIN]))
+        bwd.append(_hip.make_op(_hip.OP_FINISH_GRADS, [self._table, self._arena, self._scratch, self._grad_arena], [1, stem.cout]))
         P.fwd_ops, P.bwd_ops = fwd, bwd
         P.fwd, P.bwd = _hip.Plan(fwd), _hip.Plan(bwd)
         # zero-copy binding (see bind_input / bind_grads): where the plans refer to the input volume and to the

@@ -180,8 +180,17 @@ typedef struct {
   /* optional output scatter: y is a [n, y_d, y_h, y_w, cout] buffer and output (od,oh,ow) is written at
    * (od*ys_d, oh*ys_h, ow*ys_w) (0 = dense: ys = 1, y dims = output dims); add1/add2/mask index like y */
   int ys_d, ys_h, ys_w, y_d, y_h, y_w;
+  /* Caller-lent device scratch (256-byte aligned) for kernel instances that transform the weights first: the two-dimensional
+   * Winograd forms of the 3x3x3 / stride-1 convolution need mr3d_conv3d_wino2d_workspace_bytes(cin, cout).  NULL or too
+   * small: the dispatch takes an instance that needs none (nothing is ever allocated inside a call).  Inside a plan run
+   * the WINO2D_PREP record serves every convolution of the plan from ONE plan-owned buffer instead.
+   * workspace_bytes = -1 in a mr3d_conv3d_forward_variant query means "assume the scratch is there". */
+  void *workspace;
+  long long workspace_bytes;
 } mr3d_conv3d_desc;
 int mr3d_conv3d_forward(const mr3d_conv3d_desc *desc, mr3d_stream_t stream);
+/* bytes of transformed weights U = Gh g Gw^T of one cin -> cout 3x3x3 convolution (72 floats per (ci, co), rounded up to 256 B) */
+size_t mr3d_conv3d_wino2d_workspace_bytes(int cin, int cout);
 
 /* Which kernel instance mr3d_conv3d_forward would launch for `desc` (nothing is launched; pointers may be NULL):
  * the measurement harness prices a launch with it -- a Winograd instance issues only `mfma_issue_factor` of the
@@ -550,6 +559,13 @@ int mr3d_stem_conv_wgrad_bf16(const float *x_ncdhw, const void *dy_bf16, float *
  *   STEM_FWD      p = {x_ncdhw,w_packed,shift,y}        i = {n,d,h,w,relu}
  *   STEM_WGRAD    p = {x_ncdhw,dy,dw_packed,dbias,workspace}  i = {n,d,h,w, workspace bytes lo, hi}
  *   CONV_DGRAD_S2 p / i as CONV_FWD (mr3d_conv3d_dgrad_s2k3: x = dy, w = wb, y = dx; y_d/y_h/y_w = dx's grid)
+ *   SYNC          i = {mode, slot}: ordering between the caller's stream and the internal side stream (see below)
+ *   WINO2D_PREP   p = {workspace}  i = {bytes_lo, bytes_hi}: transforms, in ONE launch, the weights of every fp32 CONV_FWD
+ *                 record between here and the next PREP_WEIGHTS record that qualifies for the two-dimensional Winograd
+ *                 kernels, into the caller's workspace (sum of mr3d_conv3d_wino2d_workspace_bytes over the distinct weight
+ *                 pointers; MR3D_ERR_WORKSPACE if too small).  CONV_FWD records whose weights were not prepared take the
+ *                 one-dimensional Winograd / direct instances.
+ * PREP_WEIGHTS / FINISH_GRADS take any sub-range of the layer table (p[0] = first descriptor of the range).
  * Returns the first non-OK status; *failed_index (host int, may be NULL) receives the op index.
  * ---------------------------------------------------------------------------------------------- */
 typedef enum {
@@ -558,7 +574,12 @@ typedef enum {
   MR3D_OP_VOLUME_PACK = 9, MR3D_OP_MEMSET0 = 10, MR3D_OP_AXPY = 11, MR3D_OP_PREP_WEIGHTS = 12,
   MR3D_OP_FINISH_GRADS = 13, MR3D_OP_STEM_FWD = 14, MR3D_OP_STEM_WGRAD = 15, MR3D_OP_CONV_DGRAD_S2 = 16,
   MR3D_OP_PREP_WEIGHTS_BF16 = 17,     /* p = {table16, params, packed16}   i = {num_layers} */
-  MR3D_OP_STEM_PACK_BF16 = 18         /* p = {w_packed (fp32 [343][4][16]), w16} */
+  MR3D_OP_STEM_PACK_BF16 = 18,        /* p = {w_packed (fp32 [343][4][16]), w16} */
+  MR3D_OP_WINO2D_PREP = 20,
+  MR3D_OP_SYNC = 19,                  /* i[0] = 0: the caller's stream waits for everything queued on the side stream;
+                                         1: remember this point of the side queue in slot i[1] (0..3);
+                                         2: the caller's stream waits for the point remembered in slot i[1] */
+  MR3D_OP_KIND_END
 } mr3d_op_kind;
 /* i[25] of a record = storage type of the activations it touches: 0 = fp32, MR3D_DTYPE_BF16 = bf16 (the *_bf16 entry
  * points below; CONV_FWD / CONV_WGRAD / MAXPOOL_* / ZERO_STUFF2 / UPSAMPLE_ADJ / SUBSAMPLE_* / STEM_FWD (bf16 output) /
@@ -571,10 +592,20 @@ typedef struct {
   void *p[8];
 } mr3d_op;
 int mr3d_plan_run(const mr3d_op *ops_host, int num_ops, int *failed_index_host, mr3d_stream_t stream);
-/* CONV_WGRAD / STEM_WGRAD records with i[26] == 1 run on an internal side stream beside the data-gradient chain
- * (fork by event before the op, join before FINISH_GRADS and at the end of the call); they only read activations
- * and add into their own scratch slice.  0 disables the side stream (everything on `stream`); default 1. */
+/* CONV_WGRAD / STEM_WGRAD / PREP_WEIGHTS(_BF16) / MEMSET0 / FINISH_GRADS records with i[26] == 1 run on an internal side
+ * stream beside the caller's chain (fork by event before the op; the side stream is one in-order queue).  The caller's
+ * stream re-joins it at SYNC records, before a FINISH_GRADS record that runs on the caller's stream, and at the end of
+ * the call.  0 disables the side stream (everything on `stream`, in list order); default 1. */
 void mr3d_plan_set_side_stream(int enable);
+/* mr3d_plan_run with HIP timing events around the records `marks[0..num_marks)` (ascending op indices, no SYNC records),
+ * recorded on the stream each record really runs on -- the plan is NOT split, so the timed step is the production step.
+ * pairs[j] receives two events the library creates; read them with mr3d_event_pair_elapsed_ms after synchronising the
+ * device and release them with mr3d_event_pair_destroy. */
+typedef struct { void *start, *stop; } mr3d_event_pair;
+int mr3d_plan_run_marked(const mr3d_op *ops_host, int num_ops, int *failed_index_host, mr3d_stream_t stream, const int *marks,
+                         int num_marks, mr3d_event_pair *pairs);
+int mr3d_event_pair_elapsed_ms(const mr3d_event_pair *pair, float *ms);
+void mr3d_event_pair_destroy(mr3d_event_pair *pair);
 /* hipGraph replay of a plan: capture the launch sequence once (every buffer it names must stay allocated; run the
  * plan normally at least once BEFORE capturing so that one-time kernel attributes are set), then replay it with
  * one call per pass.  The graph is launched into `stream`. */

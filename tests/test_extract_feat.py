@@ -175,6 +175,71 @@ def test_plan_graph_replay_equals_stream_launch():
 
 
 @pytest.mark.gpu
+def test_captured_graphs_keep_their_own_transformed_weight_scratch():
+    """The two-dimensional Winograd kernels read pre-transformed weights from a scratch buffer.  It is plan-owned (a torch
+    buffer the Plan keeps alive, filled by its WINO2D_PREP record): capturing a small plan, then a larger one (more
+    qualifying convolutions, a bigger scratch) must leave the first graph's addresses valid -- replaying the first graph
+    after the second was captured and run reproduces its stream-launched outputs bit for bit."""
+    import mr3d_amd  # noqa: F401
+    from mr3d_amd import _hip
+    from mr3d_amd.detector import ExtractFeat3D
+    dev = torch.device('cuda:0')
+    torch.manual_seed(12)
+    eng = ExtractFeat3D(device=dev)
+    eng.init_weights()
+    xs = torch.randn(1, 3, 16, 64, 64, device=dev)
+    xl = torch.randn(1, 3, 32, 128, 128, device=dev)
+    ref_s = [o.clone() for o in eng.forward_features(xs)]
+    ref_l = [o.clone() for o in eng.forward_features(xl)]
+    Ps, Pl = eng._plan_for(xs.shape), eng._plan_for(xl.shape)
+    n_prep = lambda plan: sum(1 for k in range(plan.n) if plan.array[k].kind == _hip.OP_WINO2D_PREP)
+    ws = lambda plan: sum(t.numel() for t in plan._u_ws)
+    assert n_prep(Pl.fwd) >= 1 and ws(Pl.fwd) > ws(Ps.fwd)                       # the larger volume takes more such convolutions
+    assert not (set(t.data_ptr() for t in Ps.fwd._u_ws) & set(t.data_ptr() for t in Pl.fwd._u_ws))
+    eng.capture(Ps)
+    eng.capture(Pl)
+    out_l = eng.forward_features(xl)
+    for a, b in zip(ref_l, out_l):
+        assert torch.equal(a, b)
+    out_s = eng.forward_features(xs)                                             # replay of the FIRST graph
+    for a, b in zip(ref_s, out_s):
+        assert torch.equal(a, b)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_conv3d_forward_without_scratch_takes_an_instance_that_needs_none():
+    """mr3d_conv3d_forward never allocates: with no workspace in the descriptor a 3x3x3 64->64 convolution on a large map
+    runs on the one-dimensional Winograd / direct kernels; with the scratch lent it takes the two-dimensional form; both
+    agree with each other to the 1e-4 parity bound"""
+    import ctypes
+    import mr3d_amd  # noqa: F401
+    from mr3d_amd import _hip
+    dev = torch.device('cuda:0')
+    torch.manual_seed(3)
+    x = torch.randn(1, 20, 64, 64, 64, device=dev)
+    w = _hip.pack_conv_weight(torch.randn(64, 64, 3, 3, 3, device=dev) * 0.05)
+    y2d = _hip.conv3d_forward(x, w, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    d = _hip.Conv3dDesc()
+    y = torch.empty_like(y2d)
+    d.x, d.w, d.y = x.data_ptr(), w.data_ptr(), y.data_ptr()
+    d.n, d.d, d.h, d.w_in, d.cin, d.cout = 1, 20, 64, 64, 64, 64
+    d.kd = d.kh = d.kw = 3
+    d.sd = d.sh = d.sw = 1
+    d.pd = d.ph = d.pw = 1
+    v = _hip.Conv3dVariant()
+    _hip.check(_hip.lib().mr3d_conv3d_forward_variant(ctypes.byref(d), ctypes.byref(v)), 'variant')
+    assert v.winograd in (2, 4)                                                  # no scratch: not the weight-transforming form
+    d.workspace_bytes = -1
+    _hip.check(_hip.lib().mr3d_conv3d_forward_variant(ctypes.byref(d), ctypes.byref(v)), 'variant')
+    assert v.winograd == 8
+    d.workspace_bytes = 0
+    _hip.check(_hip.lib().mr3d_conv3d_forward(ctypes.byref(d), _hip.stream_ptr(dev)), 'mr3d_conv3d_forward')
+    torch.cuda.synchronize()
+    assert (y - y2d).abs().max().item() <= 1e-4 * y2d.abs().max().item()
+
+
+@pytest.mark.gpu
 def test_zero_copy_binding_equals_staged_copy():
     """bind_input / bind_grads: a dense NCDHW volume and channels-last P2..P4 gradients are read in place; any other
     layout goes through the plan's staging buffers -- same outputs and gradients either way; an in-place change of a

@@ -66,7 +66,9 @@ def test_config2_forward_train_backward_at_512x512x80(dev):
     assert 0 < props.size(0) <= 2000 and props.size(1) == 7
     assert (props[:, [0, 1, 4]] >= 0).all() and (props[:, 2] <= W - 1).all() and (props[:, 3] <= H - 1).all() and (props[:, 5] <= D - 1).all()
     c = det.last_sample_counts.cpu().numpy()[0]
-    assert c[0] >= 12 and c[0] + c[1] == 512, c          # 12 gts are always positives; the sampler fills the 512-row batch
+    # 12 gts are always positives; negatives are drawn WITH replacement and then made unique (random_sampler.py:36,
+    # base_sampler.py:89), so 500 draws out of 2000 candidates leave ~440 distinct rows of the static 512-row batch real
+    assert c[0] >= 12 and 400 <= c[0] + c[1] <= 512 and c[3] > 0, c
     assert torch.isfinite(g).all()
     # every parameter's arena range carries gradient
     dead = [n for n, p in det.named_parameters() if p.requires_grad and not (p.grad is not None and p.grad.abs().sum() > 0)]
