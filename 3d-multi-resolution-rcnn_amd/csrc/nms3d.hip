@@ -47,7 +47,58 @@ __device__ __forceinline__ void store_box(const float *dets, int stride, int src
   boxes[2 * dst + 1] = make_float4(z1, z2, vol, 0.f);
 }
 
-// ---- sort, n <= kSortLdsMax: one workgroup, bitonic network in LDS -------------------
+// ---- sort, n <= kSortLdsMax: one workgroup, bitonic network in registers ---------------------
+// A thread keeps E consecutive keys in registers.  A compare-exchange step with partner distance j is then
+//   j < E        inside the thread,
+//   j < 64 * E   inside the wave: the partner key comes through two ds_bpermute (no LDS memory, no barrier),
+//   otherwise    across waves: one round trip through LDS with two barriers.
+// For 2048 keys (E = 2) only 10 of the 66 steps of the network touch LDS; the all-LDS form spent 66 barriers (32 us).
+__device__ __forceinline__ uint64_t shfl_xor64(uint64_t v, int lane_mask) {
+  const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, lane_mask);
+  const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), lane_mask);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+template <int E>
+__device__ __forceinline__ void bitonic_sort_regs(uint64_t (&v)[E], int tid, int np2, uint64_t *keys) {
+  for (int k = 2; k <= np2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j >= 64 * E) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) keys[tid * E + e] = v[e];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const int i = tid * E + e;
+          const uint64_t o = keys[i ^ j];
+          const bool lower = (i & j) == 0, up = (i & k) == 0;
+          v[e] = (lower == up) ? (v[e] < o ? v[e] : o) : (v[e] > o ? v[e] : o);
+        }
+        __syncthreads();
+      } else if (j >= E) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const int i = tid * E + e;
+          const uint64_t o = shfl_xor64(v[e], j / E);
+          const bool lower = (i & j) == 0, up = (i & k) == 0;
+          v[e] = (lower == up) ? (v[e] < o ? v[e] : o) : (v[e] > o ? v[e] : o);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+          if ((e & j) == 0) {
+            const int i = tid * E + e;
+            const uint64_t x = v[e], y = v[e ^ j];
+            const bool up = (i & k) == 0;
+            const bool sw = (x > y) == up;
+            v[e] = sw ? y : x;
+            v[e ^ j] = sw ? x : y;
+          }
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(kSortThreads) void nms3d_sort_lds_kernel(const float *__restrict__ dets_all, SegTable seg,
                                                                      int stride, int *__restrict__ order_all,
                                                                      float4 *__restrict__ boxes_all) {
@@ -61,26 +112,31 @@ __global__ __launch_bounds__(kSortThreads) void nms3d_sort_lds_kernel(const floa
   const float *dets = dets_all + (size_t)seg.row0[sg] * stride;
   int *order = order_all + seg.row0[sg];
   float4 *boxes = boxes_all + seg.box_off[sg];
-  for (int i = tid; i < np2; i += kSortThreads)
-    keys[i] = (i < n) ? make_key(dets[(size_t)i * stride + 6], i) : ~0ull;
-  __syncthreads();
-  for (int k = 2; k <= np2; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < np2; i += kSortThreads) {
-        int p = i ^ j;
-        if (p > i) {
-          uint64_t a = keys[i], b = keys[p];
-          bool up = (i & k) == 0;
-          if ((a > b) == up) { keys[i] = b; keys[p] = a; }
-        }
+  auto key_of = [&](int i) { return (i < n) ? make_key(dets[(size_t)i * stride + 6], i) : ~0ull; };
+  if (np2 <= 2 * kSortThreads) {
+    uint64_t v[2] = {key_of(tid * 2), key_of(tid * 2 + 1)};
+    bitonic_sort_regs<2>(v, tid, np2 < 2 ? 2 : np2, keys);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int i = tid * 2 + e;
+      if (i < n) {
+        const int src = (int)(uint32_t)v[e];
+        order[i] = src;
+        store_box(dets, stride, src, boxes, i);
       }
-      __syncthreads();
     }
-  }
-  for (int i = tid; i < n; i += kSortThreads) {
-    int src = (int)(uint32_t)keys[i];
-    order[i] = src;
-    store_box(dets, stride, src, boxes, i);
+  } else {
+    uint64_t v[4] = {key_of(tid * 4), key_of(tid * 4 + 1), key_of(tid * 4 + 2), key_of(tid * 4 + 3)};
+    bitonic_sort_regs<4>(v, tid, np2, keys);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = tid * 4 + e;
+      if (i < n) {
+        const int src = (int)(uint32_t)v[e];
+        order[i] = src;
+        store_box(dets, stride, src, boxes, i);
+      }
+    }
   }
 }
 
@@ -237,6 +293,125 @@ __global__ __launch_bounds__(kSweepThreads) void nms3d_sweep_kernel(const uint64
   }
 }
 
+// ---- greedy sweep, cb <= 64 blocks (n <= 4096: every batched call): the serial chain without global latency ---------
+// The generic sweep above pays two dependent global round trips per 64-box block (the diagonal words, then the mask rows
+// of the kept boxes): 32 blocks x ~1.4 us.  Here (a) all diagonal words sit in LDS before the chain starts, (b) the mask
+// rows a block MAY need are fetched one block ahead, unconditionally (which rows are kept is only known later; the words
+// of dropped rows are masked out after the fact), so the chain itself is LDS + scalar work between two barriers per block,
+// (c) the order[] gather for the output flags happens once, after the chain.
+constexpr int kFastMaxCb = 64;
+__global__ __launch_bounds__(kSweepThreads) void nms3d_sweep_fast_kernel(const uint64_t *__restrict__ mask_all,
+                                                                        const int *__restrict__ order_all, SegTable seg,
+                                                                        int64_t *__restrict__ keep_all,
+                                                                        int32_t *__restrict__ num_keep_all) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t sm[];
+  const int sg = blockIdx.x;
+  const int n = seg.n[sg], cb = (n + 63) / 64;
+  int32_t *num_keep = num_keep_all + sg;
+  if (n == 0) {
+    if (threadIdx.x == 0) *num_keep = 0;
+    return;
+  }
+  const uint64_t *mask = mask_all + seg.mask_off[sg];
+  const int *order = order_all + seg.row0[sg];
+  int64_t *keep_out = keep_all + seg.row0[sg];
+  uint64_t *remv = sm;                     // [cb] suppressed bits per sorted block
+  uint64_t *flags = sm + cb;               // [cb] kept bits in ORIGINAL index space
+  uint64_t *keptb = sm + 2 * cb;           // [cb] kept bits per sorted block
+  uint64_t *diag = sm + 3 * cb;            // [cb * 64] diagonal word of every row
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < 3 * cb; i += kSweepThreads) sm[i] = 0;
+  for (int r = tid; r < cb * 64; r += kSweepThreads) diag[r] = r < n ? mask[(size_t)r * cb + (r >> 6)] : 0ull;
+
+  // work items of block b: (word w in (b, cb), group g of kRowsPerItem rows); this thread's items: tid, tid + 256
+  constexpr int G = 64 / kRowsPerItem;
+  uint64_t pre[2][kRowsPerItem];
+  auto fetch = [&](int b) {
+    const int later = cb - (b + 1);
+    const int items = later * G;
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+      const int it = tid + s_ * kSweepThreads;
+      const bool on = it < items;
+      const int w = on ? b + 1 + it % later : 0, g = on ? it / later : 0;
+#pragma unroll
+      for (int q = 0; q < kRowsPerItem; ++q) {
+        const int row = b * 64 + g * kRowsPerItem + q;
+        pre[s_][q] = (on && row < n) ? mask[(size_t)row * cb + w] : 0ull;
+      }
+    }
+  };
+  fetch(0);
+  __syncthreads();
+  for (int b = 0; b < cb; ++b) {
+    uint64_t cur_rows[2][kRowsPerItem];
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+      for (int q = 0; q < kRowsPerItem; ++q) cur_rows[s_][q] = pre[s_][q];
+    if (b + 1 < cb) fetch(b + 1);          // in flight while this block is resolved
+    if (wave == 0) {
+      const int row = b * 64 + lane;
+      const uint64_t d = diag[row];
+      const int rows = min(64, n - b * 64);
+      const uint64_t valid = (rows == 64) ? ~0ull : ((1ull << rows) - 1ull);
+      uint64_t cur = mr3d_uniform64(remv[b]);
+      uint64_t cand = (uint64_t)__ballot(d != 0ull) & ~cur & valid;
+      while (cand) {
+        const int t = __builtin_ctzll(cand);
+        const uint64_t dd = mr3d_readlane64(d, t);
+        cur |= dd;
+        cand &= ~dd;
+        cand &= ~(1ull << t);
+      }
+      if (lane == 0) keptb[b] = ~cur & valid;
+    }
+    __syncthreads();
+    const uint64_t kept = keptb[b];
+    const int later = cb - (b + 1);
+    const int items = later * G;
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+      const int it = tid + s_ * kSweepThreads;
+      if (it < items) {
+        const int w = b + 1 + it % later, g = it / later;
+        uint64_t acc = 0;
+#pragma unroll
+        for (int q = 0; q < kRowsPerItem; ++q) acc |= ((kept >> (g * kRowsPerItem + q)) & 1ull) ? cur_rows[s_][q] : 0ull;
+        if (acc) atomicOr((unsigned long long *)&remv[w], (unsigned long long)acc);
+      }
+    }
+    __syncthreads();
+  }
+  // kept bits -> ORIGINAL index space (one gather of order[] for the whole set), then ascending compaction
+  for (int r = tid; r < n; r += kSweepThreads)
+    if ((keptb[r >> 6] >> (r & 63)) & 1ull) {
+      const int oi = order[r];
+      atomicOr((unsigned int *)flags + (oi >> 5), 1u << (oi & 31));
+    }
+  __syncthreads();
+  if (wave == 0) {
+    int base = 0;
+    for (int w = 0; w < cb; ++w) {
+      const uint64_t f = flags[w];
+      if ((f >> lane) & 1ull) keep_out[base + __popcll(f & ((1ull << lane) - 1ull))] = (int64_t)w * 64 + lane;
+      base += __popcll(f);
+    }
+    if (lane == 0) *num_keep = base;
+  }
+}
+
+void launch_sweep(const uint64_t *mask, const int *order, const SegTable &seg, int num_segments, int max_cb, int64_t *keep,
+                  int32_t *num_keep, hipStream_t stream) {
+  if (max_cb <= kFastMaxCb) {
+    const size_t lds = sizeof(uint64_t) * (3 * (size_t)max_cb + 64 * (size_t)max_cb);
+    nms3d_sweep_fast_kernel<<<num_segments, kSweepThreads, lds, stream>>>(mask, order, seg, keep, num_keep);
+  } else {
+    const size_t lds = sizeof(uint64_t) * (2 * (size_t)max_cb + 1);
+    nms3d_sweep_kernel<<<num_segments, kSweepThreads, lds, stream>>>(mask, order, seg, keep, num_keep);
+  }
+}
+
 struct NmsWorkspace {
   uint64_t *keys;
   int *order;
@@ -294,7 +469,7 @@ extern "C" int mr3d_nms3d(const float *dets, int n, int row_stride, float iou_th
     nms3d_gather_kernel<<<(n + th - 1) / th, th, 0, stream>>>(dets, n, row_stride, w.keys, w.order, w.boxes);
   }
   nms3d_mask_kernel<<<dim3(cb, cb, 1), MR3D_WAVE, 0, stream>>>(w.boxes, seg, iou_threshold, w.mask);
-  nms3d_sweep_kernel<<<1, kSweepThreads, sweep_lds, stream>>>(w.mask, w.order, seg, keep_out, num_keep_out);
+  launch_sweep(w.mask, w.order, seg, 1, cb, keep_out, num_keep_out, stream);
   return mr3d_launch_status();
 }
 
@@ -351,9 +526,8 @@ extern "C" int mr3d_nms3d_batched(const float *dets, const int *seg_rows_host, i
   int *order = (int *)(base + L.order_off);
   float4 *boxes = (float4 *)(base + L.boxes_off);
   uint64_t *mask = (uint64_t *)(base + L.mask_off);
-  const size_t sweep_lds = sizeof(uint64_t) * (2 * (size_t)L.max_cb + 1);
   nms3d_sort_lds_kernel<<<num_segments, kSortThreads, 0, stream>>>(dets, L.seg, row_stride, order, boxes);
   nms3d_mask_kernel<<<dim3(L.max_cb, L.max_cb, num_segments), MR3D_WAVE, 0, stream>>>(boxes, L.seg, iou_threshold, mask);
-  nms3d_sweep_kernel<<<num_segments, kSweepThreads, sweep_lds, stream>>>(mask, order, L.seg, keep_out, num_keep_out);
+  launch_sweep(mask, order, L.seg, num_segments, L.max_cb, keep_out, num_keep_out, stream);
   return mr3d_launch_status();
 }

@@ -187,14 +187,16 @@ def test_captured_graphs_keep_their_own_transformed_weight_scratch():
     torch.manual_seed(12)
     eng = ExtractFeat3D(device=dev)
     eng.init_weights()
-    xs = torch.randn(1, 3, 16, 64, 64, device=dev)
-    xl = torch.randn(1, 3, 32, 128, 128, device=dev)
+    # P2 of a 48x192x192 volume (24x48x48: 432 tiles of 2x8x8) is the smallest map here that takes the two-dimensional form
+    # (>= 256 tiles); at 80x256x256 layer1's 16 -> 16 convolutions qualify too
+    xs = torch.randn(1, 3, 48, 192, 192, device=dev)
+    xl = torch.randn(1, 3, 80, 256, 256, device=dev)
     ref_s = [o.clone() for o in eng.forward_features(xs)]
     ref_l = [o.clone() for o in eng.forward_features(xl)]
     Ps, Pl = eng._plan_for(xs.shape), eng._plan_for(xl.shape)
     n_prep = lambda plan: sum(1 for k in range(plan.n) if plan.array[k].kind == _hip.OP_WINO2D_PREP)
     ws = lambda plan: sum(t.numel() for t in plan._u_ws)
-    assert n_prep(Pl.fwd) >= 1 and ws(Pl.fwd) > ws(Ps.fwd)                       # the larger volume takes more such convolutions
+    assert n_prep(Ps.fwd) == 1 and n_prep(Pl.fwd) == 1 and ws(Pl.fwd) > ws(Ps.fwd) > 0       # the larger volume takes more such convolutions
     assert not (set(t.data_ptr() for t in Ps.fwd._u_ws) & set(t.data_ptr() for t in Pl.fwd._u_ws))
     eng.capture(Ps)
     eng.capture(Pl)

@@ -100,6 +100,16 @@ def test_rcnn_sampling_and_targets_match_reference(dev, tg, tag):
     assert np.array_equal(bw.cpu().numpy()[:r], tg[f'{tag}_bbox_weights']) and (bw.cpu().numpy()[r:] == 0).all()
     np.testing.assert_allclose(bt.cpu().numpy()[:r], tg[f'{tag}_bbox_targets'], rtol=0, atol=2e-5)
     assert np.array_equal(pgi.cpu().numpy()[:c[0]], tg[f'{tag}_pos_assigned_gt_inds']) and (pgi.cpu().numpy()[c[0]:] == -1).all()
+    # the list-in / tensor-out form of the reference (bbox_target.py:118-145), a call into the same kernel: identical rows
+    from mr3d_amd.core.bbox import bbox_target_single_3d
+    npos = int(c[0])
+    gi = pgi[:npos].clamp(min=0)
+    lab2, lw2, bt2, bw2 = bbox_target_single_3d(rois[:npos, 1:], rois[npos:r, 1:], gt[gi], gl[gi], dict(pos_weight=float(pos_weight)),
+                                                target_stds=tg[f'{tag}_target_stds'])
+    assert torch.equal(lab2, lab[:r]) and torch.equal(lw2, lw[:r]) and torch.equal(bt2, bt[:r]) and torch.equal(bw2, bw[:r])
+    e = rois[:0, 1:]
+    lab0, lw0, bt0, bw0 = bbox_target_single_3d(e, rois[npos:r, 1:], e, gl[:0], dict(pos_weight=float(pos_weight)))
+    assert lab0.numel() == r - npos and (lab0 == 0).all() and (lw0 == 1).all() and (bw0 == 0).all()
 
 
 def test_assign_and_sample_full_size_vs_oracle(dev):
