@@ -550,16 +550,18 @@ class ExtractFeat3D(nn.Module):
                 assert lat_part is None
                 bwd.append(self._conv_dgrad(g_a1, b['conv1'], gx, add1=g, mask=mask))
             g = gx
+        # Gradient finishing (dW = s dW', BN gamma / beta from the raw sums, ~0.11 ms) of every layer but the stem: queued on
+        # the side stream behind the last conv weight gradient -- a side record waits for the main chain only up to the point
+        # where it is issued, so it is issued HERE, in front of the max-pool backward and the stem weight gradient, and runs
+        # underneath them.  The stem weight gradient (1.8 ms) needs the last data gradient and closes the main chain; only its
+        # own 16 channels are finished after the join.
+        bwd.append(_hip.make_op(_hip.OP_FINISH_GRADS, [self._table.data_ptr() + dsz, self._arena, self._scratch, self._grad_arena],
+                                [nL - 1, self.max_cout], side=True))
         g_stem = self._new(P.stem_out.shape)
-        bwd.append(self._op(_hip.OP_MAXPOOL_BWD, [g, P.pool_idx, P.stem_out, g_stem], [N, sd, sh, sw, 16]))
-        # The stem weight gradient (1.8 ms) needs the last data gradient, so it closes the main chain; the gradient finishing
-        # of every OTHER layer (dW = s dW', BN gamma / beta from the raw sums, ~0.11 ms) queues on the side stream behind the
-        # last conv weight gradient and runs underneath it; only the stem's own 16 channels are finished after the join.
+        bwd.append(self._op(_hip.OP_MAXPOOL_BWD, [g, P.pool_idx, P.pool_out, g_stem], [N, sd, sh, sw, 16]))
         bwd.append(_hip.make_op(_hip.OP_SYNC, [], [_hip.SYNC_WAIT, 0]))
         bwd.append(self._op(_hip.OP_STEM_WGRAD, [P.x_in, g_stem, self._s(stem, 'dwraw'), self._s(stem, 'dbias')],
                             [N, D, H, W, 0, 0, 1 if P.stem_bf16 else 0]))
-        bwd.append(_hip.make_op(_hip.OP_FINISH_GRADS, [self._table.data_ptr() + dsz, self._arena, self._scratch, self._grad_arena],
-                                [nL - 1, self.max_cout], side=True))
         bwd.append(_hip.make_op(_hip.OP_SYNC, [], [_hip.SYNC_JOIN]))
         bwd.append(_hip.make_op(_hip.OP_FINISH_GRADS, [self._table, self._arena, self._scratch, self._grad_arena], [1, stem.cout]))
         P.fwd_ops, P.bwd_ops = fwd, bwd

@@ -24,7 +24,7 @@ def get_bboxes_single(cls_scores, bbox_preds, anchor_generators, anchor_strides,
     """cls_scores[l]: [A, D, H, W] logits (any memory format); bbox_preds[l]: [A*6, D, H, W];
     img_shape = (H, W, 3, D).  Returns proposals [<= max_num, 7] = [x1,y1,x2,y2,z1,z2,score]."""
     cfg = _as_cfg(cfg)
-    mlvl, real = [], [None] * len(cls_scores)
+    mlvl, real = [], {}
     for lvl, (cls, reg) in enumerate(zip(cls_scores, bbox_preds)):
         assert cls.shape[-3:] == reg.shape[-3:]
         A, D, H, W = cls.shape
@@ -42,6 +42,15 @@ def get_bboxes_single(cls_scores, bbox_preds, anchor_generators, anchor_strides,
                 scores = torch.where(vf, scores, scores.new_full((), -1.0))
                 real[lvl] = vf.sum().clamp(max=cfg.nms_pre)
             scores, flat = scores.topk(cfg.nms_pre)
+            if lvl in real and cfg.nms_post < cfg.nms_pre:
+                # Fewer valid anchors than nms_pre: the reference skips the top-k and runs its NMS on ALL of them in ANCHOR
+                # order (:103-107), so its `[:nms_post]` cut (:135) keeps the first rows by anchor index, not by score.  Only
+                # observable when nms_post < nms_pre (the shipped config has both at 2000): the real rows are then re-ordered
+                # by anchor index whenever they are all that is valid (decided on the device).
+                key = torch.where(scores >= 0, flat, torch.full_like(flat, torch.iinfo(flat.dtype).max))
+                by_anchor = torch.argsort(key)
+                pick = torch.where(real[lvl] < cfg.nms_pre, by_anchor, torch.arange(flat.numel(), device=flat.device))
+                scores, flat = scores[pick], flat[pick]
         else:
             flat = torch.arange(scores.shape[0], device=scores.device)
         # regression map of this level, as the kernel reads it
@@ -55,7 +64,7 @@ def get_bboxes_single(cls_scores, bbox_preds, anchor_generators, anchor_strides,
         mlvl.append(dets)
     # the reference calls nms() once per level (:134); the levels are independent, so they share one batched launch
     # sequence and one read-back of the kept counts
-    keeps = _hip.nms3d_batched(mlvl, cfg.nms_thr, real_rows=real)
+    keeps = _hip.nms3d_batched(mlvl, cfg.nms_thr, real_rows=[real.get(l) for l in range(len(mlvl))] if real else None)
     mlvl = [d[k][:cfg.nms_post, :] for d, k in zip(mlvl, keeps)]
     proposals = torch.cat(mlvl, 0)
     if getattr(cfg, 'nms_across_levels', False):

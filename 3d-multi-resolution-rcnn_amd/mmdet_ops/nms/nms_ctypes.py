@@ -1,5 +1,5 @@
-"""Stand-in for the reference's compiled `nms_cuda` extension module
-(mmdet/ops/nms/src/nms_cuda.cpp:23-26: `nms`, `nms_3d`)."""
+"""ctypes form of the `nms_cuda` extension module (mmdet/ops/nms/src/nms_cuda.cpp:23-26: `nms`, `nms_3d`): same entry points
+as the compiled PYBIND11 module csrc/torch_ext/nms_cuda.cpp, used when that module has not been built."""
 from ... import _hip
 
 

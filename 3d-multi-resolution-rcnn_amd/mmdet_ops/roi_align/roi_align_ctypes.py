@@ -1,6 +1,6 @@
-"""Stand-in for the reference's compiled `roi_align_cuda` extension module
-(mmdet/ops/roi_align/src/roi_align_cuda.cpp:152-157: forward, forward3d, backward, backward3d).
-Same positional signatures; outputs are written in place; returns 1 like the reference."""
+"""ctypes form of the `roi_align_cuda` extension module (mmdet/ops/roi_align/src/roi_align_cuda.cpp:152-157: forward,
+forward3d, backward, backward3d): same entry points as the compiled PYBIND11 module csrc/torch_ext/roi_align_cuda.cpp, used
+when that module has not been built.  Same positional signatures; outputs are written in place; returns 1 like the reference."""
 import torch
 
 from ... import _hip

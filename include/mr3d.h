@@ -239,8 +239,9 @@ int mr3d_conv3d_wgrad(const mr3d_conv3d_wgrad_desc *desc, mr3d_stream_t stream);
  * HBM-bound helpers of the backbone / neck path (activations NDHWC fp32, channels % 4 == 0).
  *   maxpool3d: nn.MaxPool3d(kernel 3, stride 2, padding 1) (mmdet/models/backbones/resnet3d.py:409,471);
  *     forward stores the argmax tap (4 x u8 per 4 channels; first maximum in (kd,kh,kw) scan order, as
- *     torch); backward gathers dy through it and, if relu_of != NULL, zeroes positions where relu_of <= 0
- *     (the stem ReLU that precedes the pool).  Output size floor((in-1)/2)+1 per axis.
+ *     torch); backward gathers dy through it and, if pooled != NULL (the forward's output y), drops the windows whose
+ *     pooled value is <= 0: the ReLU in front of the pool (the stem's) seen through the argmax -- y[o] IS the input at the
+ *     argmax, so no un-pooled activation has to be read.  Output size floor((in-1)/2)+1 per axis.
  *   zero_stuff2: dst[2o] = src[o], 0 elsewhere (stride-2 data gradient as a stride-1 conv).
  *   upsample_nearest_adjoint_add: grad_coarse[u] += sum of grad_fine[f] over f with nearest_src(f) == u
  *     (backward of F.interpolate(mode='nearest') in mmdet/models/necks/fpn3d.py:106-108).
@@ -249,7 +250,7 @@ int mr3d_conv3d_wgrad(const mr3d_conv3d_wgrad_desc *desc, mr3d_stream_t stream);
  *   axpy: dst += alpha * src (count % 4 == 0).
  * ---------------------------------------------------------------------------------------------- */
 int mr3d_maxpool3d_forward(const float *x, float *y, uint32_t *argmax, int n, int d, int h, int w, int c, mr3d_stream_t s);
-int mr3d_maxpool3d_backward(const float *dy, const uint32_t *argmax, const float *relu_of, float *dx,
+int mr3d_maxpool3d_backward(const float *dy, const uint32_t *argmax, const float *pooled, float *dx,
                             int n, int d, int h, int w, int c, mr3d_stream_t s);
 int mr3d_zero_stuff2(const float *src, float *dst, int n, int do_, int ho, int wo, int d, int h, int w, int c, mr3d_stream_t s);
 int mr3d_upsample_nearest_adjoint_add(const float *grad_fine, float *grad_coarse, int n, int df, int hf, int wf,
@@ -517,7 +518,7 @@ int mr3d_conv3d_forward_bf16(const mr3d_conv3d_desc *desc, mr3d_stream_t stream)
 int mr3d_conv3d_wgrad_bf16(const mr3d_conv3d_wgrad_desc *desc, mr3d_stream_t stream);
 int mr3d_prepare_weights_bf16(const mr3d_layer_desc *table, int num_layers, const float *params, void *packed16, mr3d_stream_t s);
 int mr3d_maxpool3d_forward_bf16(const void *x, void *y, uint32_t *argmax, int n, int d, int h, int w, int c, mr3d_stream_t s);
-int mr3d_maxpool3d_backward_bf16(const void *dy, const uint32_t *argmax, const void *relu_of, void *dx, int n, int d, int h, int w,
+int mr3d_maxpool3d_backward_bf16(const void *dy, const uint32_t *argmax, const void *pooled, void *dx, int n, int d, int h, int w,
                                  int c, mr3d_stream_t s);
 int mr3d_zero_stuff2_bf16(const void *src, void *dst, int n, int do_, int ho, int wo, int d, int h, int w, int c, mr3d_stream_t s);
 int mr3d_upsample_nearest_adjoint_add_bf16(const void *grad_fine, void *grad_coarse, int n, int df, int hf, int wf, int dc, int hc,
@@ -547,7 +548,7 @@ int mr3d_stem_conv_wgrad_bf16(const float *x_ncdhw, const void *dy_bf16, float *
  *   CONV_FWD      p = {x,w,y,shift,add1,add2,up,mask}   i = the 25 ints of mr3d_conv3d_desc in order
  *   CONV_WGRAD    p = {x,dy,dw,dbias,workspace}         i = the 15 ints of mr3d_conv3d_wgrad_desc, i[15..16] = workspace bytes (lo, hi)
  *   MAXPOOL_FWD   p = {x,y,argmax}                      i = {n,d,h,w,c}
- *   MAXPOOL_BWD   p = {dy,argmax,relu_of,dx}            i = {n,d,h,w,c}
+ *   MAXPOOL_BWD   p = {dy,argmax,pooled,dx}             i = {n,d,h,w,c}
  *   ZERO_STUFF2   p = {src,dst}                         i = {n,do,ho,wo,d,h,w,c}
  *   UPSAMPLE_ADJ  p = {grad_fine,grad_coarse}           i = {n,df,hf,wf,dc,hc,wc,c}
  *   SUBSAMPLE_FWD p = {x,y}   SUBSAMPLE_BWD p = {dy,dx} i = {n,d,h,w,c}

@@ -65,3 +65,22 @@ def test_error_conventions_without_gpu():
         RoIAlign3D('7', 3, 0.25, 0.5, 2)(torch.zeros(1, 2, 4, 8, 8), torch.zeros(1, 7))
     with pytest.raises(NotImplementedError):
         RoIAlign(7, 0.25)
+
+
+def test_compiled_extension_modules_export_the_reference_entry_points():
+    """roi_align_cuda / nms_cuda are compiled PYBIND11 modules (csrc/torch_ext, built by `make ext` / build()) with the
+    reference's entry points (roi_align_cuda.cpp:152-157, nms_cuda.cpp:23-26); the ctypes forms offer the same names"""
+    import mr3d_amd  # noqa: F401
+    from mr3d_amd.mmdet_ops.roi_align import roi_align_cuda, roi_align_ctypes
+    from mr3d_amd.mmdet_ops.nms import nms_cuda, nms_ctypes
+    assert roi_align_cuda.__file__.endswith('.so') and nms_cuda.__file__.endswith('.so'), 'extension modules not built'
+    for m in (roi_align_cuda, roi_align_ctypes):
+        assert all(callable(getattr(m, n)) for n in ('forward', 'forward3d', 'backward', 'backward3d'))
+    for m in (nms_cuda, nms_ctypes):
+        assert all(callable(getattr(m, n)) for n in ('nms', 'nms_3d'))
+    with pytest.raises(RuntimeError, match='must be a CUDAtensor'):          # CHECK_CUDA (nms_cuda.cpp:4,17)
+        nms_cuda.nms_3d(torch.zeros((3, 7)), 0.5)
+    with pytest.raises(RuntimeError, match='must be a CUDAtensor'):          # CHECK_INPUT (roi_align_cuda.cpp:34-39)
+        roi_align_cuda.forward3d(torch.zeros(1, 4, 2, 4, 4), torch.zeros(1, 7), 1, 2, 2, 1.0, 1.0, 2, torch.zeros(1, 4, 1, 2, 2))
+    with pytest.raises(NotImplementedError):
+        nms_cuda.nms(torch.zeros((3, 5)), 0.5)

@@ -47,11 +47,11 @@ def test_maxpool_forward_backward(hip, shape):
     dx = torch.empty_like(xc)
     _run(hip, hip.make_op(hip.OP_MAXPOOL_BWD, [_cl(dy), am, None, dx], [n, d, h, w, c]))
     np.testing.assert_allclose(_nc(dx).numpy(), x.grad.numpy(), rtol=1e-6, atol=1e-6)
-    # with relu_of: pool relu(x), route, then mask by x > 0
+    # with the pooled map: pool relu(x), route, and apply the ReLU mask through the argmax (y[o] > 0 <=> x[argmax(o)] > 0)
     xrc = _cl(xr.detach())
     _run(hip, hip.make_op(hip.OP_MAXPOOL_FWD, [xrc, yo, am], [n, d, h, w, c]))
     yr.backward(dy)
-    _run(hip, hip.make_op(hip.OP_MAXPOOL_BWD, [_cl(dy), am, xrc, dx], [n, d, h, w, c]))
+    _run(hip, hip.make_op(hip.OP_MAXPOOL_BWD, [_cl(dy), am, yo, dx], [n, d, h, w, c]))
     expect = xr.grad * (xr.detach() > 0)
     # windows of relu(x) that are entirely 0 tie at 0: torch and this kernel both take the first tap, and the mask zeroes it
     np.testing.assert_allclose(_nc(dx).numpy(), expect.numpy(), rtol=1e-6, atol=1e-6)
