@@ -490,6 +490,7 @@ OP_SUBSAMPLE_FWD, OP_SUBSAMPLE_BWD, OP_VOLUME_PACK, OP_MEMSET0, OP_AXPY, OP_PREP
 OP_STEM_FWD, OP_STEM_WGRAD, OP_CONV_DGRAD_S2, OP_PREP_WEIGHTS_BF16, OP_STEM_PACK_BF16, OP_SYNC, OP_WINO2D_PREP = 14, 15, 16, 17, 18, 19, 20
 SYNC_JOIN, SYNC_MARK, SYNC_WAIT = 0, 1, 2      # mr3d_op.i[0] of an OP_SYNC record
 DTYPE_BF16 = 1          # mr3d_op.i[25]: MR3D_DTYPE_BF16
+CONV_RELU, CONV_UP_EVEN = 1, 2      # mr3d_conv3d_desc.relu flags (i[18] of a CONV_FWD record)
 
 
 class Op(ctypes.Structure):

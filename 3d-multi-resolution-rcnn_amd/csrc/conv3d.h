@@ -18,6 +18,9 @@ struct Conv3dFwdArgs {
   int pd, ph, pw;
   int Du, Hu, Wu;
   int relu;
+  // up_even: `up` is the COARSE result of a stride-2 adjoint (a zero-stuffed map that is never materialised): it is added at
+  // the even positions (2u) only, nothing elsewhere.  0: nearest-neighbour replication (the FPN top-down add).
+  int up_even = 0;
   // y is a [N, yD, yH, yW, Cout] buffer; output (od,oh,ow) lands at (od*ysd, oh*ysh, ow*ysw): lets a
   // coarse-grid result be scattered onto the even positions of a pre-zeroed fine grid (stride-2 dgrad)
   int ysd, ysh, ysw, yD, yH, yW;

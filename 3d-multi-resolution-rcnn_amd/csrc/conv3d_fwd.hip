@@ -365,8 +365,12 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_fwd_kernel(Conv3dFw
       if (p.add1) v += p.add1[idx];
       if (p.add2) v += p.add2[idx];
       if (p.up) {
-        const int ud = nearest_src(od, p.Du, p.Do), uh = nearest_src(oh, p.Hu, p.Ho), uw = nearest_src(ow, p.Wu, p.Wo);
-        v += p.up[((((size_t)n * p.Du + ud) * p.Hu + uh) * p.Wu + uw) * p.Cout + co];
+        if (p.up_even) {
+          if (!((od | oh | ow) & 1)) v += p.up[((((size_t)n * p.Du + (od >> 1)) * p.Hu + (oh >> 1)) * p.Wu + (ow >> 1)) * p.Cout + co];
+        } else {
+          const int ud = nearest_src(od, p.Du, p.Do), uh = nearest_src(oh, p.Hu, p.Ho), uw = nearest_src(ow, p.Wu, p.Wo);
+          v += p.up[((((size_t)n * p.Du + ud) * p.Hu + uh) * p.Wu + uw) * p.Cout + co];
+        }
       }
       if (p.relu) v = fmaxf(v, 0.f);
       if (p.mask) v = p.mask[idx] > 0.f ? v : 0.f;
@@ -592,7 +596,7 @@ extern "C" int mr3d_conv3d_forward(const mr3d_conv3d_desc *d, mr3d_stream_t stre
   a.Ho = (d->h + 2 * d->ph - d->kh) / d->sh + 1;
   a.Wo = (d->w_in + 2 * d->pw - d->kw) / d->sw + 1;
   a.Du = d->up_d; a.Hu = d->up_h; a.Wu = d->up_w;
-  a.relu = d->relu;
+  a.relu = d->relu & MR3D_CONV_RELU; a.up_even = (d->relu & MR3D_CONV_UP_EVEN) ? 1 : 0;
   a.ysd = d->ys_d > 0 ? d->ys_d : 1; a.ysh = d->ys_h > 0 ? d->ys_h : 1; a.ysw = d->ys_w > 0 ? d->ys_w : 1;
   a.yD = d->y_d > 0 ? d->y_d : a.Do; a.yH = d->y_h > 0 ? d->y_h : a.Ho; a.yW = d->y_w > 0 ? d->y_w : a.Wo;
   a.ws = (float *)d->workspace; a.ws_bytes = d->workspace_bytes;
@@ -600,6 +604,8 @@ extern "C" int mr3d_conv3d_forward(const mr3d_conv3d_desc *d, mr3d_stream_t stre
   if ((a.Do - 1) * a.ysd >= a.yD || (a.Ho - 1) * a.ysh >= a.yH || (a.Wo - 1) * a.ysw >= a.yW) return MR3D_ERR_INVALID_ARG;
   if (a.N <= 0 || a.Do <= 0 || a.Ho <= 0 || a.Wo <= 0) return MR3D_ERR_INVALID_ARG;
   if (a.up && (a.Du <= 0 || a.Hu <= 0 || a.Wu <= 0)) return MR3D_ERR_INVALID_ARG;
+  if (a.up && a.up_even && (a.Du != (a.Do + 1) / 2 || a.Hu != (a.Ho + 1) / 2 || a.Wu != (a.Wo + 1) / 2 || a.ysd != 1 || a.ysh != 1 || a.ysw != 1))
+    return MR3D_ERR_INVALID_ARG;
   const int nb = pick_nb(a.Cout);
   if (!nb) return MR3D_ERR_UNSUPPORTED;
   hipStream_t stream = mr3d_stream(stream_);

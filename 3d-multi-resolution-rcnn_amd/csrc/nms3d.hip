@@ -11,6 +11,7 @@
 // and lane == bit position; the sweep resolves one 64-box block at a time with scalar
 // (SGPR) bit tricks and v_readlane instead of a 64k-iteration host loop.
 #include "mr3d_common.h"
+#include "sort_regs.h"
 
 namespace {
 
@@ -47,58 +48,7 @@ __device__ __forceinline__ void store_box(const float *dets, int stride, int src
   boxes[2 * dst + 1] = make_float4(z1, z2, vol, 0.f);
 }
 
-// ---- sort, n <= kSortLdsMax: one workgroup, bitonic network in registers ---------------------
-// A thread keeps E consecutive keys in registers.  A compare-exchange step with partner distance j is then
-//   j < E        inside the thread,
-//   j < 64 * E   inside the wave: the partner key comes through two ds_bpermute (no LDS memory, no barrier),
-//   otherwise    across waves: one round trip through LDS with two barriers.
-// For 2048 keys (E = 2) only 10 of the 66 steps of the network touch LDS; the all-LDS form spent 66 barriers (32 us).
-__device__ __forceinline__ uint64_t shfl_xor64(uint64_t v, int lane_mask) {
-  const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, lane_mask);
-  const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), lane_mask);
-  return ((uint64_t)hi << 32) | lo;
-}
-
-template <int E>
-__device__ __forceinline__ void bitonic_sort_regs(uint64_t (&v)[E], int tid, int np2, uint64_t *keys) {
-  for (int k = 2; k <= np2; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      if (j >= 64 * E) {
-#pragma unroll
-        for (int e = 0; e < E; ++e) keys[tid * E + e] = v[e];
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-          const int i = tid * E + e;
-          const uint64_t o = keys[i ^ j];
-          const bool lower = (i & j) == 0, up = (i & k) == 0;
-          v[e] = (lower == up) ? (v[e] < o ? v[e] : o) : (v[e] > o ? v[e] : o);
-        }
-        __syncthreads();
-      } else if (j >= E) {
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-          const int i = tid * E + e;
-          const uint64_t o = shfl_xor64(v[e], j / E);
-          const bool lower = (i & j) == 0, up = (i & k) == 0;
-          v[e] = (lower == up) ? (v[e] < o ? v[e] : o) : (v[e] > o ? v[e] : o);
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < E; ++e)
-          if ((e & j) == 0) {
-            const int i = tid * E + e;
-            const uint64_t x = v[e], y = v[e ^ j];
-            const bool up = (i & k) == 0;
-            const bool sw = (x > y) == up;
-            v[e] = sw ? y : x;
-            v[e ^ j] = sw ? x : y;
-          }
-      }
-    }
-  }
-}
-
+// ---- sort, n <= kSortLdsMax: one workgroup, bitonic network in registers (sort_regs.h) ---------------------
 __global__ __launch_bounds__(kSortThreads) void nms3d_sort_lds_kernel(const float *__restrict__ dets_all, SegTable seg,
                                                                      int stride, int *__restrict__ order_all,
                                                                      float4 *__restrict__ boxes_all) {
@@ -401,9 +351,121 @@ __global__ __launch_bounds__(kSweepThreads) void nms3d_sweep_fast_kernel(const u
   }
 }
 
+// ---- greedy sweep, cb <= 32 blocks (n <= 2048: the RPN's nms_pre = 2000 sets): the whole upper triangle on chip -----------
+// Prefetching one block ahead still waits ~1 us per block for the mask rows (44 us for 32 blocks).  Here the chain never
+// touches global memory: 1024 threads fetch ALL words above the diagonal once -- an item = 8 mask rows x 1 word, <= 4 items
+// per thread, two of them kept in registers and two in LDS (128 KB; all four in registers spill) -- with every load in
+// flight at the same time; then per block: wave 0 resolves the diagonal from LDS, one barrier, the threads that own items
+// of this block OR their kept rows into the later blocks' suppression words in LDS, one barrier.
+constexpr int kRegThreads = 1024;
+constexpr int kRegMaxCb = 32;
+constexpr int kRegSlots = 4;        // ceil(31 * 32 / 2 * 8 items / 1024 threads)
+constexpr int kRegSlotsR = 2;       // slots held in registers; the rest in LDS as [slot][row][thread]
+constexpr size_t kRegLdsBytes = sizeof(uint64_t) * (3 * kRegMaxCb + kRegMaxCb * 64 + (kRegSlots - kRegSlotsR) * kRowsPerItem * kRegThreads);
+__global__ __launch_bounds__(kRegThreads) void nms3d_sweep_reg_kernel(const uint64_t *__restrict__ mask_all,
+                                                                     const int *__restrict__ order_all, SegTable seg,
+                                                                     int64_t *__restrict__ keep_all,
+                                                                     int32_t *__restrict__ num_keep_all) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t sm[];
+  uint64_t *remv = sm, *flags = sm + kRegMaxCb, *keptb = sm + 2 * kRegMaxCb, *diag = sm + 3 * kRegMaxCb;
+  uint64_t *lrows = diag + kRegMaxCb * 64;
+  const int sg = blockIdx.x;
+  const int n = seg.n[sg], cb = (n + 63) / 64;
+  int32_t *num_keep = num_keep_all + sg;
+  if (n == 0) {
+    if (threadIdx.x == 0) *num_keep = 0;
+    return;
+  }
+  const uint64_t *mask = mask_all + seg.mask_off[sg];
+  const int *order = order_all + seg.row0[sg];
+  int64_t *keep_out = keep_all + seg.row0[sg];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < 3 * kRegMaxCb) sm[tid] = 0;
+  for (int r = tid; r < cb * 64; r += kRegThreads) diag[r] = r < n ? mask[(size_t)r * cb + (r >> 6)] : 0ull;
+  // item id -> (block b, word w > b, row group g): ids run block by block; block b has (cb - 1 - b) * 8 items
+  constexpr int G = 64 / kRowsPerItem;
+  uint64_t rows[kRegSlotsR][kRowsPerItem];
+  int meta[kRegSlots];                 // b << 16 | w << 8 | g, or -1
+#pragma unroll
+  for (int s_ = kRegSlots - 1; s_ >= 0; --s_) {      // the LDS-resident slots first: their data passes through registers
+    int id = s_ * kRegThreads + tid, b = 0;
+    while (b < cb && id >= (cb - 1 - b) * G) { id -= (cb - 1 - b) * G; ++b; }
+    const bool on = b < cb - 1;
+    const int later = cb - 1 - b;
+    const int w = on ? b + 1 + id % later : 0, g = on ? id / later : 0;
+    meta[s_] = on ? (b << 16 | w << 8 | g) : -1;
+    const unsigned off = (unsigned)((b * 64 + g * kRowsPerItem) * cb + w);
+#pragma unroll
+    for (int q = 0; q < kRowsPerItem; ++q) {
+      const int row = b * 64 + g * kRowsPerItem + q;
+      const uint64_t v = (on && row < n) ? mask[off + (unsigned)(q * cb)] : 0ull;
+      if (s_ >= kRegSlotsR) lrows[((s_ - kRegSlotsR) * kRowsPerItem + q) * kRegThreads + tid] = v;
+      else rows[s_][q] = v;
+    }
+  }
+  __syncthreads();
+  for (int b = 0; b < cb; ++b) {
+    if (wave == 0) {
+      const uint64_t d = diag[b * 64 + lane];
+      const int nr = min(64, n - b * 64);
+      const uint64_t valid = (nr == 64) ? ~0ull : ((1ull << nr) - 1ull);
+      uint64_t cur = mr3d_uniform64(remv[b]);
+      uint64_t cand = (uint64_t)__ballot(d != 0ull) & ~cur & valid;
+      while (cand) {
+        const int t = __builtin_ctzll(cand);
+        const uint64_t dd = mr3d_readlane64(d, t);
+        cur |= dd;
+        cand &= ~dd;
+        cand &= ~(1ull << t);
+      }
+      if (lane == 0) keptb[b] = ~cur & valid;
+    }
+    __syncthreads();
+    const uint64_t kept = keptb[b];
+#pragma unroll
+    for (int s_ = 0; s_ < kRegSlots; ++s_)
+      if ((meta[s_] >> 16) == b) {
+        const int w = (meta[s_] >> 8) & 255, g = meta[s_] & 255;
+        const unsigned kb = (unsigned)(kept >> (g * kRowsPerItem)) & 255u;
+        uint64_t acc = 0;
+#pragma unroll
+        for (int q = 0; q < kRowsPerItem; ++q) {
+          const uint64_t v = s_ >= kRegSlotsR ? lrows[((s_ - kRegSlotsR) * kRowsPerItem + q) * kRegThreads + tid] : rows[s_ < kRegSlotsR ? s_ : 0][q];
+          acc |= ((kb >> q) & 1u) ? v : 0ull;
+        }
+        if (acc) atomicOr((unsigned long long *)&remv[w], (unsigned long long)acc);
+      }
+    __syncthreads();
+  }
+  for (int r = tid; r < n; r += kRegThreads)
+    if ((keptb[r >> 6] >> (r & 63)) & 1ull) {
+      const int oi = order[r];
+      atomicOr((unsigned int *)flags + (oi >> 5), 1u << (oi & 31));
+    }
+  __syncthreads();
+  if (wave == 0) {
+    int base = 0;
+    for (int w = 0; w < cb; ++w) {
+      const uint64_t f = flags[w];
+      if ((f >> lane) & 1ull) keep_out[base + __popcll(f & ((1ull << lane) - 1ull))] = (int64_t)w * 64 + lane;
+      base += __popcll(f);
+    }
+    if (lane == 0) *num_keep = base;
+  }
+}
+
 void launch_sweep(const uint64_t *mask, const int *order, const SegTable &seg, int num_segments, int max_cb, int64_t *keep,
                   int32_t *num_keep, hipStream_t stream) {
-  if (max_cb <= kFastMaxCb) {
+  static bool reg_ok = false, reg_tried = false;      // 144 KB of LDS needs the opt-in attribute (one CU has 160 KB)
+  if (!reg_tried) {
+    reg_tried = true;
+    reg_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(nms3d_sweep_reg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)kRegLdsBytes) == hipSuccess;
+    if (!reg_ok) (void)hipGetLastError();
+  }
+  if (max_cb <= kRegMaxCb && reg_ok) {
+    nms3d_sweep_reg_kernel<<<num_segments, kRegThreads, kRegLdsBytes, stream>>>(mask, order, seg, keep, num_keep);
+  } else if (max_cb <= kFastMaxCb) {
     const size_t lds = sizeof(uint64_t) * (3 * (size_t)max_cb + 64 * (size_t)max_cb);
     nms3d_sweep_fast_kernel<<<num_segments, kSweepThreads, lds, stream>>>(mask, order, seg, keep, num_keep);
   } else {

@@ -112,9 +112,10 @@ __global__ __launch_bounds__(64 * C::WPW) void pointwise_fwd_kernel(Conv3dFwdArg
             const unsigned oh = pq % (unsigned)p.Ho; pq /= (unsigned)p.Ho;
             const unsigned od = pq % (unsigned)p.Do;
             const unsigned n = pq / (unsigned)p.Do;
-            const int ud = pw_nearest_src((int)od, p.Du, p.Do), uh = pw_nearest_src((int)oh, p.Hu, p.Ho),
-                      uw = pw_nearest_src((int)ow, p.Wu, p.Wo);
-            eu[q] = *reinterpret_cast<const float4 *>(
+            const bool ev = p.up_even != 0;
+            const int ud = ev ? (int)(od >> 1) : pw_nearest_src((int)od, p.Du, p.Do), uh = ev ? (int)(oh >> 1) : pw_nearest_src((int)oh, p.Hu, p.Ho),
+                      uw = ev ? (int)(ow >> 1) : pw_nearest_src((int)ow, p.Wu, p.Wo);
+            eu[q] = (ev && ((od | oh | ow) & 1u)) ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4 *>(
                 p.up + ((((size_t)n * p.Du + ud) * p.Hu + uh) * p.Wu + uw) * C::CO + (f % (C::CO / 4)) * 4);
           }
         }
@@ -220,9 +221,10 @@ __global__ __launch_bounds__(64 * C::WPW) void pointwise_fwd_kernel(Conv3dFwdArg
           const unsigned oh = pq % (unsigned)p.Ho; pq /= (unsigned)p.Ho;
           const unsigned od = pq % (unsigned)p.Do;
           const unsigned n = pq / (unsigned)p.Do;
-          const int ud = pw_nearest_src((int)od, p.Du, p.Do), uh = pw_nearest_src((int)oh, p.Hu, p.Ho),
-                    uw = pw_nearest_src((int)ow, p.Wu, p.Wo);
-          const float4 a = *reinterpret_cast<const float4 *>(
+          const bool ev = p.up_even != 0;
+          const int ud = ev ? (int)(od >> 1) : pw_nearest_src((int)od, p.Du, p.Do), uh = ev ? (int)(oh >> 1) : pw_nearest_src((int)oh, p.Hu, p.Ho),
+                    uw = ev ? (int)(ow >> 1) : pw_nearest_src((int)ow, p.Wu, p.Wo);
+          const float4 a = (ev && ((od | oh | ow) & 1u)) ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4 *>(
               p.up + ((((size_t)n * p.Du + ud) * p.Hu + uh) * p.Wu + uw) * C::CO + (f % (C::CO / 4)) * 4);
           v[q].x += a.x; v[q].y += a.y; v[q].z += a.z; v[q].w += a.w;
         }
@@ -290,9 +292,13 @@ __global__ __launch_bounds__(64 * C::WPW) void pointwise_fwd_kernel(Conv3dFwdArg
               const unsigned oh = q % (unsigned)p.Ho; q /= (unsigned)p.Ho;
               const unsigned od = q % (unsigned)p.Do;
               const unsigned n = q / (unsigned)p.Do;
-              const int ud = pw_nearest_src((int)od, p.Du, p.Do), uh = pw_nearest_src((int)oh, p.Hu, p.Ho),
-                        uw = pw_nearest_src((int)ow, p.Wu, p.Wo);
-              v += p.up[((((size_t)n * p.Du + ud) * p.Hu + uh) * p.Wu + uw) * C::CO + co];
+              if (p.up_even) {
+                if (!((od | oh | ow) & 1u)) v += p.up[((((size_t)n * p.Du + (od >> 1)) * p.Hu + (oh >> 1)) * p.Wu + (ow >> 1)) * C::CO + co];
+              } else {
+                const int ud = pw_nearest_src((int)od, p.Du, p.Do), uh = pw_nearest_src((int)oh, p.Hu, p.Ho),
+                          uw = pw_nearest_src((int)ow, p.Wu, p.Wo);
+                v += p.up[((((size_t)n * p.Du + ud) * p.Hu + uh) * p.Wu + uw) * C::CO + co];
+              }
             }
             if (p.relu) v = fmaxf(v, 0.f);
             if (p.mask) v = p.mask[idx] > 0.f ? v : 0.f;

@@ -539,13 +539,27 @@ class ExtractFeat3D(nn.Module):
             gx = self._new(x.shape)
             if b['ds']:
                 bwd.append(self._conv_wgrad(x, g, b['dsconv']))
-                t = self._new(x.shape)
                 if b['stride'] == 1:
+                    t = self._new(x.shape)
                     bwd.append(self._conv_dgrad(g, b['dsconv'], t))
-                else:
+                    bwd.append(self._conv_dgrad(g_a1, b['conv1'], gx, add1=t, add2=lat_part, mask=mask))
+                elif self.bf16:
+                    t = self._new(x.shape)
                     bwd.append(_hip.make_op(_hip.OP_MEMSET0, [t], _hip.split64(t.numel() * t.element_size())))
                     bwd.append(self._conv_dgrad(g, b['dsconv'], t, scatter=True))
-                bwd.append(self._conv_dgrad(g_a1, b['conv1'], gx, add1=t, add2=lat_part, mask=mask))
+                    bwd.append(self._conv_dgrad(g_a1, b['conv1'], gx, add1=t, add2=lat_part, mask=mask))
+                else:
+                    # strided 1x1x1 downsample conv: its data gradient lives on the COARSE grid (one value per 2x2x2 cell of
+                    # x, at the even positions).  It is computed there and the conv1 data gradient adds it at the even
+                    # positions in its epilogue (MR3D_CONV_UP_EVEN): the zero-stuffed fine map (168 MB at layer2) is neither
+                    # zero-filled, nor scattered into, nor read back.
+                    tc = self._new(g.shape[:4] + (b['dsconv'].cin_pad,))
+                    bwd.append(self._conv_dgrad(g, b['dsconv'], tc))
+                    op = self._conv_dgrad(g_a1, b['conv1'], gx, add1=lat_part, mask=mask)
+                    op.p[6] = tc.data_ptr()
+                    op.i[15], op.i[16], op.i[17] = tc.shape[1:4]
+                    op.i[18] |= _hip.CONV_UP_EVEN
+                    bwd.append(op)
             else:
                 assert lat_part is None
                 bwd.append(self._conv_dgrad(g_a1, b['conv1'], gx, add1=g, mask=mask))

@@ -170,13 +170,18 @@ int mr3d_roi_align3d_forward_ml_bf16(const mr3d_roi_level *levels_host, int num_
  * Supported here: cubic kernels 1 / 3 (stride 1 or 2, Cin % 16 == 0) and 7 (stride (1,2,2), Cin == 4,
  * i.e. the 3-channel stem zero-padded to 4); Cout % 16 == 0.  Anything else: MR3D_ERR_UNSUPPORTED.
  * ---------------------------------------------------------------------------------------------- */
+#define MR3D_CONV_RELU 1      /* y = max(y, 0) */
+/* `up` is the COARSE result of a stride-2 adjoint (e.g. the data gradient of a strided 1x1x1 downsample conv,
+ * resnet3d.py:251): added at the even positions (2u) of y only -- the zero-stuffed fine map is never materialised.
+ * up_d/h/w = ceil(out / 2).  fp32 kernels only. */
+#define MR3D_CONV_UP_EVEN 2
 typedef struct {
   const float *x; const float *w; float *y;
   const float *shift; const float *add1; const float *add2; const float *up; const float *mask;
   int n, d, h, w_in, cin, cout;
   int kd, kh, kw, sd, sh, sw, pd, ph, pw;
   int up_d, up_h, up_w;
-  int relu;
+  int relu;            /* flags: MR3D_CONV_RELU | MR3D_CONV_UP_EVEN */
   /* optional output scatter: y is a [n, y_d, y_h, y_w, cout] buffer and output (od,oh,ow) is written at
    * (od*ys_d, oh*ys_h, ow*ys_w) (0 = dense: ys = 1, y dims = output dims); add1/add2/mask index like y */
   int ys_d, ys_h, ys_w, y_d, y_h, y_w;
