@@ -204,6 +204,88 @@ def nms3d_batched(dets_list, iou_threshold, real_rows=None):
     return out
 
 
+class RpnLevel(ctypes.Structure):
+    """mr3d_rpn_level (include/mr3d.h)"""
+    _fields_ = [('logits', ctypes.c_void_p), ('valid', ctypes.c_void_p)] + \
+               [(n, ctypes.c_longlong) for n in ('stride_a', 'stride_d', 'stride_h', 'stride_w')] + \
+               [(n, ctypes.c_int) for n in ('anchors', 'depth', 'height', 'width')]
+
+
+def rpn_select_topk(cls_maps, valid_flags, nms_pre):
+    """mr3d_rpn_select_topk over all pyramid levels at once.  cls_maps[l]: [A, D, H, W] fp32 device logits (any strides);
+    valid_flags[l]: uint8 / bool [A*D*H*W] in flat (h, w, d, a) order or None.  Returns (caps, flat int64 [sum caps], scores
+    fp32 [sum caps], counts int32 [L] ON THE DEVICE): level l owns rows [sum caps[:l], +caps[l]), the first counts[l] real."""
+    L = len(cls_maps)
+    dev = cls_maps[0].device
+    lv = (RpnLevel * L)()
+    keep = []
+    for l, c in enumerate(cls_maps):
+        if not (c.is_cuda and c.dtype == torch.float32 and c.dim() == 4):
+            raise RuntimeError('rpn_select_topk: cls maps must be float32 device tensors [A, D, H, W]')
+        lv[l].logits = c.data_ptr()
+        lv[l].stride_a, lv[l].stride_d, lv[l].stride_h, lv[l].stride_w = c.stride()
+        lv[l].anchors, lv[l].depth, lv[l].height, lv[l].width = c.shape
+        vf = None if valid_flags is None else valid_flags[l]
+        if vf is not None and vf.numel() == c.numel():
+            vf = vf.reshape(-1)
+            vf = (vf if vf.dtype in (torch.uint8, torch.bool) else (vf != 0)).contiguous()
+            keep.append(vf)
+            lv[l].valid = vf.data_ptr()
+    caps = [min(int(c.numel()), int(nms_pre)) for c in cls_maps]
+    K = sum(caps)
+    flat = torch.empty(K, dtype=torch.long, device=dev)
+    scores = torch.empty(K, dtype=torch.float32, device=dev)
+    counts = torch.empty(L, dtype=torch.int32, device=dev)
+    lib_ = lib()
+    wsb = _sz(lib_.mr3d_rpn_select_topk_workspace_bytes, lv, L, int(nms_pre))
+    if wsb == 0:
+        raise Mr3dError('mr3d_rpn_select_topk: unsupported level table')
+    ws_keep, ws = _aligned_bytes(wsb, dev)
+    with torch.cuda.device(dev):
+        st = lib_.mr3d_rpn_select_topk(lv, L, int(nms_pre), ptr(flat), ptr(scores), ptr(counts), ctypes.c_void_p(ws),
+                                       ctypes.c_size_t(wsb), stream_ptr(dev))
+    check(st, 'mr3d_rpn_select_topk')
+    del ws_keep, keep
+    return caps, flat, scores, counts
+
+
+def nms3d_batched_dev(dets, caps, counts, iou_threshold):
+    """mr3d_nms3d_batched_dev: set s = rows [sum caps[:s], +caps[s]) of dets [K, 7], of which the first counts[s] (device
+    int32) are real.  Returns (keep int64 [K] -- per set, ascending, relative to the set -- and num_keep int32 [S]), both
+    on the device: nothing is read back."""
+    S = len(caps)
+    dev = dets.device
+    assert dets.is_contiguous() and dets.dtype == torch.float32 and dets.size(1) == 7 and dets.size(0) == sum(caps)
+    seg = (ctypes.c_int * S)(*caps)
+    L = lib()
+    L.mr3d_nms3d_batched_workspace_bytes.restype = ctypes.c_size_t
+    wsb = int(L.mr3d_nms3d_batched_workspace_bytes(seg, S))
+    if wsb == 0:
+        raise Mr3dError('mr3d_nms3d_batched_dev: sets of more than 4096 boxes / more than 16 sets')
+    ws_keep, ws = _aligned_bytes(wsb, dev)
+    keep = torch.empty(max(sum(caps), 1), dtype=torch.long, device=dev)
+    num = torch.empty(S, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        st = L.mr3d_nms3d_batched_dev(ptr(dets), seg, ctypes.c_void_p(_opt(counts)), S, 7, ctypes.c_float(iou_threshold), ptr(keep),
+                                      ptr(num), ctypes.c_void_p(ws), ctypes.c_size_t(wsb), stream_ptr(dev))
+    check(st, 'mr3d_nms3d_batched_dev')
+    del ws_keep
+    return keep, num
+
+
+def rpn_merge_levels(dets, caps, keep, num_keep, nms_post, max_num):
+    """mr3d_rpn_merge_levels -> (proposals [max_num, 7], zero rows behind the count; count int32 [1] on the device)"""
+    S = len(caps)
+    seg = (ctypes.c_int * S)(*caps)
+    out = torch.empty((int(max_num), 7), dtype=torch.float32, device=dets.device)
+    count = torch.empty(1, dtype=torch.int32, device=dets.device)
+    with torch.cuda.device(dets.device):
+        st = lib().mr3d_rpn_merge_levels(ptr(dets), seg, S, ptr(keep), ptr(num_keep), int(nms_post), int(max_num), ptr(out),
+                                         ptr(count), stream_ptr(dets.device))
+    check(st, 'mr3d_rpn_merge_levels')
+    return out, count
+
+
 def multiclass_nms3d(multi_bboxes, multi_scores, score_thr, iou_thr, max_num):
     """mr3d_multiclass_nms3d -> (dets [k,7], labels int64 [k]); one 4-byte read-back (the output's row count)"""
     for t, what in ((multi_bboxes, 'multi_bboxes'), (multi_scores, 'multi_scores')):
@@ -848,9 +930,10 @@ def grid_anchors3d(base_anchors, featmap_size, stride, depth_stride):
 
 
 def rpn_decode_level(flat_idx, scores, reg_map, reg_layout, base_anchors, featmap_size, stride, depth_stride, means, stds,
-                     max_shape, wh_ratio_clip=16 / 1000):
+                     max_shape, wh_ratio_clip=16 / 1000, out=None):
     k = int(flat_idx.numel())
-    dets = torch.empty((k, 7), dtype=torch.float32, device=scores.device)
+    dets = out if out is not None else torch.empty((k, 7), dtype=torch.float32, device=scores.device)
+    assert dets.is_contiguous() and tuple(dets.shape) == (k, 7)
     if k == 0:
         return dets
     assert flat_idx.dtype == torch.long and flat_idx.is_contiguous() and scores.is_contiguous() and reg_map.is_contiguous()

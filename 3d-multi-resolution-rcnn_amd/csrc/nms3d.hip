@@ -27,7 +27,17 @@ struct SegTable {
   int row0[kMaxSeg], n[kMaxSeg];
   long long box_off[kMaxSeg];       // in float4 units
   long long mask_off[kMaxSeg];      // in u64 units
+  const int32_t *n_dev;             // optional device array: only the first n_dev[s] (<= n[s]) rows of set s are real
 };
+
+__device__ __forceinline__ int seg_rows(const SegTable &seg, int sg) {
+  int n = seg.n[sg];
+  if (seg.n_dev) {
+    const int m = seg.n_dev[sg];
+    n = m < 0 ? 0 : (m < n ? m : n);
+  }
+  return n;
+}
 
 // (score desc, index asc) as one ascending u64 key
 __device__ __forceinline__ uint64_t make_key(float s, int idx) {
@@ -55,7 +65,7 @@ __global__ __launch_bounds__(kSortThreads) void nms3d_sort_lds_kernel(const floa
   __shared__ uint64_t keys[kSortLdsMax];
   const int tid = threadIdx.x;
   const int sg = blockIdx.x;
-  const int n = seg.n[sg];
+  const int n = seg_rows(seg, sg);
   if (n == 0) return;
   int np2 = 1;
   while (np2 < n) np2 <<= 1;
@@ -124,7 +134,7 @@ __global__ void nms3d_gather_kernel(const float *__restrict__ dets, int n, int s
 __global__ __launch_bounds__(MR3D_WAVE) void nms3d_mask_kernel(const float4 *__restrict__ boxes_all, SegTable seg,
                                                               float thr, uint64_t *__restrict__ mask_all) {
   const int sg = blockIdx.z;
-  const int n = seg.n[sg], cb = (n + 63) / 64;
+  const int n = seg_rows(seg, sg), cb = (n + 63) / 64;
   const int c = blockIdx.x, r = blockIdx.y;
   if (c < r || c >= cb) return;
   const float4 *boxes = boxes_all + seg.box_off[sg];
@@ -168,7 +178,7 @@ __global__ __launch_bounds__(kSweepThreads) void nms3d_sweep_kernel(const uint64
                                                                    int32_t *__restrict__ num_keep_all) {
   extern __shared__ __attribute__((aligned(16))) uint64_t sm[];
   const int sg = blockIdx.x;
-  const int n = seg.n[sg], cb = (n + 63) / 64;
+  const int n = seg_rows(seg, sg), cb = (n + 63) / 64;
   int32_t *num_keep = num_keep_all + sg;
   if (n == 0) {
     if (threadIdx.x == 0) *num_keep = 0;
@@ -256,7 +266,7 @@ __global__ __launch_bounds__(kSweepThreads) void nms3d_sweep_fast_kernel(const u
                                                                         int32_t *__restrict__ num_keep_all) {
   extern __shared__ __attribute__((aligned(16))) uint64_t sm[];
   const int sg = blockIdx.x;
-  const int n = seg.n[sg], cb = (n + 63) / 64;
+  const int n = seg_rows(seg, sg), cb = (n + 63) / 64;
   int32_t *num_keep = num_keep_all + sg;
   if (n == 0) {
     if (threadIdx.x == 0) *num_keep = 0;
@@ -370,7 +380,7 @@ __global__ __launch_bounds__(kRegThreads) void nms3d_sweep_reg_kernel(const uint
   uint64_t *remv = sm, *flags = sm + kRegMaxCb, *keptb = sm + 2 * kRegMaxCb, *diag = sm + 3 * kRegMaxCb;
   uint64_t *lrows = diag + kRegMaxCb * 64;
   const int sg = blockIdx.x;
-  const int n = seg.n[sg], cb = (n + 63) / 64;
+  const int n = seg_rows(seg, sg), cb = (n + 63) / 64;
   int32_t *num_keep = num_keep_all + sg;
   if (n == 0) {
     if (threadIdx.x == 0) *num_keep = 0;
@@ -519,7 +529,7 @@ extern "C" int mr3d_nms3d(const float *dets, int n, int row_stride, float iou_th
   NmsWorkspace w = carve(workspace, n);
   const int np2 = mr3d_next_pow2(n);
   SegTable seg;
-  seg.num = 1; seg.row0[0] = 0; seg.n[0] = n; seg.box_off[0] = 0; seg.mask_off[0] = 0;
+  seg.num = 1; seg.row0[0] = 0; seg.n[0] = n; seg.box_off[0] = 0; seg.mask_off[0] = 0; seg.n_dev = nullptr;
 
   if (n <= kSortLdsMax) {
     nms3d_sort_lds_kernel<<<1, kSortThreads, 0, stream>>>(dets, seg, row_stride, w.order, w.boxes);
@@ -575,10 +585,18 @@ extern "C" size_t mr3d_nms3d_batched_workspace_bytes(const int *seg_rows_host, i
 extern "C" int mr3d_nms3d_batched(const float *dets, const int *seg_rows_host, int num_segments, int row_stride,
                                   float iou_threshold, int64_t *keep_out, int32_t *num_keep_out, void *workspace,
                                   size_t workspace_bytes, mr3d_stream_t stream_) {
+  return mr3d_nms3d_batched_dev(dets, seg_rows_host, nullptr, num_segments, row_stride, iou_threshold, keep_out, num_keep_out,
+                                workspace, workspace_bytes, stream_);
+}
+
+extern "C" int mr3d_nms3d_batched_dev(const float *dets, const int *seg_rows_host, const int32_t *seg_rows_dev, int num_segments,
+                                      int row_stride, float iou_threshold, int64_t *keep_out, int32_t *num_keep_out,
+                                      void *workspace, size_t workspace_bytes, mr3d_stream_t stream_) {
   hipStream_t stream = mr3d_stream(stream_);
   BatchLayout L;
   const int st = batch_layout(seg_rows_host, num_segments, L);
   if (st != MR3D_OK) return st;
+  L.seg.n_dev = seg_rows_dev;
   if (!num_keep_out || row_stride < 7) return MR3D_ERR_INVALID_ARG;
   if (L.max_cb == 0)          // every segment empty
     return hipMemsetAsync(num_keep_out, 0, sizeof(int32_t) * num_segments, stream) == hipSuccess ? MR3D_OK : MR3D_ERR_LAUNCH;

@@ -2,8 +2,9 @@
 // Host-only C++ (g++): the device code lives in libmr3d_hip.so, which these modules link against.
 #pragma once
 #include <torch/extension.h>
-#include <c10/hip/HIPStream.h>
-#include <c10/hip/HIPGuard.h>
+// PyTorch-ROCm presents its devices with the device type "cuda": the stream / guard types that carry that type
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 
 #include "../../../include/mr3d.h"
 
@@ -12,9 +13,11 @@
 #define MR3D_CHECK_CONTIGUOUS(x) TORCH_CHECK((x).is_contiguous(), #x, " must be contiguous ")
 
 inline mr3d_stream_t mr3d_current_stream(const at::Tensor &t) {
-  return (mr3d_stream_t)c10::hip::getCurrentHIPStream(t.get_device()).stream();
+  return (mr3d_stream_t)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.get_device()).stream();
 }
 
 inline void mr3d_check_status(int st, const char *what) {
   TORCH_CHECK(st == MR3D_OK, what, ": ", mr3d_status_string(st), " (status ", st, ")");
 }
+
+using Mr3dDeviceGuard = c10::hip::HIPGuardMasqueradingAsCUDA;

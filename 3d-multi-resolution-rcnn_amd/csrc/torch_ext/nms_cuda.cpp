@@ -12,7 +12,7 @@ at::Tensor nms_3d(const at::Tensor &dets, const float threshold) {
   TORCH_CHECK(dets.scalar_type() == at::kFloat, "nms_3d expects float32 dets");     // nms_kernel.cu:197,207 (data<float>())
   const at::Tensor d = dets.stride(1) == 1 ? dets : dets.contiguous();
   const int n = d.size(0);
-  c10::hip::HIPGuard guard(d.device());
+  Mr3dDeviceGuard guard(d.device());
   const size_t ws_bytes = mr3d_nms3d_workspace_bytes(n);
   at::Tensor ws = at::empty({(int64_t)ws_bytes + 256}, d.options().dtype(at::kByte));
   char *base = (char *)ws.data_ptr();

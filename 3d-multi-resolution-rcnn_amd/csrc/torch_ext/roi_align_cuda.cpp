@@ -39,7 +39,7 @@ int roi_align_forward_3d(at::Tensor features, at::Tensor rois, int pooled_depth,
             W = features.size(4);
   TORCH_CHECK(output.dim() == 5 && output.size(0) == R && output.size(1) == C && output.size(2) == pooled_depth &&
               output.size(3) == pooled_height && output.size(4) == pooled_width, "output must be [num_rois, C, pd, ph, pw]");
-  c10::hip::HIPGuard guard(features.device());
+  Mr3dDeviceGuard guard(features.device());
   int st;
   if (dt == MR3D_DTYPE_F32)
     st = mr3d_roi_align3d_forward(features.data_ptr<float>(), rois.data_ptr<float>(), R, N, C, D, H, W, pooled_depth, pooled_height,
@@ -69,7 +69,7 @@ int roi_align_backward_3d(at::Tensor top_grad, at::Tensor rois, int pooled_depth
             W = bottom_grad.size(4);
   TORCH_CHECK(top_grad.dim() == 5 && top_grad.size(0) == R && top_grad.size(1) == C && top_grad.size(2) == pooled_depth &&
               top_grad.size(3) == pooled_height && top_grad.size(4) == pooled_width, "top_grad must be [num_rois, C, pd, ph, pw]");
-  c10::hip::HIPGuard guard(bottom_grad.device());
+  Mr3dDeviceGuard guard(bottom_grad.device());
   const int flags = bug_compat ? MR3D_ROIALIGN_BUG_COMPAT : 0;
   int st;
   if (dt == MR3D_DTYPE_F32)

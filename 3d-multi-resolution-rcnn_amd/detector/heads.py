@@ -208,20 +208,34 @@ class RPNHead3D(nn.Module):
             losses_reg.append(lr)
         return dict(loss_rpn_cls=losses_cls, loss_rpn_reg=losses_reg)
 
-    def get_bboxes(self, cls_scores, bbox_preds, img_metas, cfg, use_pos_indices=False):
+    def get_bboxes(self, cls_scores, bbox_preds, img_metas, cfg, use_pos_indices=False, with_counts=False):
         """per image proposals (anchor_head_3d.py:232-268 -> rpn_head_3d.py:72-149).  use_pos_indices: apply the
         inside-flags cached by the last loss() call on the levels with more than nms_pre anchors, as the reference does
-        implicitly whenever the shapes match (rpn_head_3d.py:97-101, anchor_head_3d.py:212)"""
+        implicitly whenever the shapes match (rpn_head_3d.py:97-101, anchor_head_3d.py:212).
+        with_counts: static shapes for the detectors -- returns (list of [max_num, 7] blocks whose rows behind the count are
+        zero, list of int32 [1] device counts) and never synchronises with the host where the sync-free path applies."""
+        from .rpn_proposals import get_bboxes_single_device, _device_path_ok, _as_cfg
         flags = getattr(self, 'pos_indices', None) if use_pos_indices else None
-        res = []
+        res, counts = [], []
         for i, meta in enumerate(img_metas):
             vf = None
             if flags is not None:
                 vf = [f if f.dim() == 1 else f[i] for f in flags]
-            res.append(get_bboxes_single([c[i] for c in cls_scores], [r[i] for r in bbox_preds], self.anchor_generators,
-                                         self.anchor_strides, self.anchor_strides_depth, meta['img_shape'], cfg,
-                                         self.target_means, self.target_stds, valid_flags=vf))
-        return res
+            args = ([c[i] for c in cls_scores], [r[i] for r in bbox_preds], self.anchor_generators, self.anchor_strides,
+                    self.anchor_strides_depth, meta['img_shape'], cfg, self.target_means, self.target_stds)
+            if with_counts and _device_path_ok(args[0], _as_cfg(cfg)):
+                p, c = get_bboxes_single_device(*args, valid_flags=vf)
+            else:
+                p = get_bboxes_single(*args, valid_flags=vf)
+                if with_counts:
+                    c = torch.full((1,), p.size(0), dtype=torch.int32, device=p.device)
+                    cap = int(_as_cfg(cfg).max_num)
+                    if p.size(0) < cap:
+                        p = torch.cat((p, p.new_zeros((cap - p.size(0), 7))))
+            res.append(p)
+            if with_counts:
+                counts.append(c)
+        return (res, counts) if with_counts else res
 
 
 class SharedFCBBoxHead3D(nn.Module):
@@ -270,10 +284,14 @@ class SharedFCBBoxHead3D(nn.Module):
                               rcnn_train_cfg, 1 if self.reg_class_agnostic else self.num_classes,
                               target_means=self.target_means, target_stds=self.target_stds)
 
-    def get_det_bboxes(self, rois, cls_score, bbox_pred, img_shape, scale_factor, rescale=False, cfg=None):
+    def get_det_bboxes(self, rois, cls_score, bbox_pred, img_shape, scale_factor, rescale=False, cfg=None, valid_rows=None):
         """bbox_head_3d.py:136-170: softmax scores, per-class delta2bbox3D decode clipped to img_shape, optional
-        rescale (all 6 coordinates divided, as the reference does), multiclass NMS3D"""
+        rescale (all 6 coordinates divided, as the reference does), multiclass NMS3D.  valid_rows (device scalar): rows
+        behind it are the zero padding of a fixed-capacity proposal block; their scores are set to -1, below any score_thr."""
         scores = torch.softmax(cls_score, dim=1) if cls_score is not None else None
+        if valid_rows is not None and scores is not None:
+            live = torch.arange(scores.size(0), device=scores.device) < valid_rows.reshape(())
+            scores = torch.where(live[:, None], scores, scores.new_full((), -1.0))
         if bbox_pred is not None:
             bboxes = delta2bbox3D(rois[:, 1:].contiguous(), bbox_pred.contiguous(), self.target_means, self.target_stds, img_shape)
         else:

@@ -19,11 +19,49 @@ def _as_cfg(cfg):
     return cfg if not isinstance(cfg, dict) else SimpleNamespace(**cfg)
 
 
+def _device_path_ok(cls_scores, cfg):
+    """The sync-free path serves the configurations whose per-level `[:nms_post]` cut can never bite (nms_post >= nms_pre: the
+    shipped train and test configs have both at 2000) -- the cut keeps rows in the order the NMS saw them, which the
+    reference makes score order or anchor order depending on a data-dependent branch (:103-112)."""
+    return (not getattr(cfg, 'nms_across_levels', False) and 0 < cfg.nms_pre <= cfg.nms_post and cfg.nms_pre <= 4096 and
+            len(cls_scores) <= 8 and 0 < cfg.max_num and len(cls_scores) * min(cfg.nms_pre, cfg.nms_post) <= 16384 and
+            all(c.dtype == torch.float32 for c in cls_scores))
+
+
+def get_bboxes_single_device(cls_scores, bbox_preds, anchor_generators, anchor_strides, anchor_strides_depth, img_shape, cfg,
+                             target_means=(0., 0., 0., 0., 0., 0.), target_stds=(1., 1., 1., 1., 1., 1.), valid_flags=None):
+    """get_bboxes_single without a host round trip: (proposals [max_num, 7] with zero rows behind the count, count int32 [1] on
+    the device).  Launch sequence: radix select of the nms_pre best valid anchors of all levels (mr3d_rpn_select_topk), one
+    decode per level, batched NMS3D with device-side row counts, merge of the levels' kept rows into the max_num best."""
+    cfg = _as_cfg(cfg)
+    caps, flat, scores, counts = _hip.rpn_select_topk(cls_scores, valid_flags, cfg.nms_pre)
+    dets = torch.empty((sum(caps), 7), dtype=torch.float32, device=flat.device)
+    row = 0
+    for lvl, (cls, reg) in enumerate(zip(cls_scores, bbox_preds)):
+        A, D, H, W = cls.shape
+        if reg.is_contiguous():
+            reg_map, layout = reg, _hip.LAYOUT_NCDHW
+        else:
+            reg_map, layout = reg.permute(1, 2, 3, 0).contiguous(), _hip.LAYOUT_NDHWC
+        k = caps[lvl]
+        _hip.rpn_decode_level(flat[row:row + k], scores[row:row + k], reg_map, layout, anchor_generators[lvl].base_anchors_on(flat.device),
+                              (D, H, W), anchor_strides[lvl], anchor_strides_depth[lvl], target_means, target_stds, img_shape,
+                              out=dets[row:row + k])
+        row += k
+    keep, num_keep = _hip.nms3d_batched_dev(dets, caps, counts, cfg.nms_thr)
+    return _hip.rpn_merge_levels(dets, caps, keep, num_keep, cfg.nms_post, cfg.max_num)
+
+
 def get_bboxes_single(cls_scores, bbox_preds, anchor_generators, anchor_strides, anchor_strides_depth, img_shape, cfg,
                       target_means=(0., 0., 0., 0., 0., 0.), target_stds=(1., 1., 1., 1., 1., 1.), valid_flags=None):
     """cls_scores[l]: [A, D, H, W] logits (any memory format); bbox_preds[l]: [A*6, D, H, W];
-    img_shape = (H, W, 3, D).  Returns proposals [<= max_num, 7] = [x1,y1,x2,y2,z1,z2,score]."""
+    img_shape = (H, W, 3, D).  Returns proposals [<= max_num, 7] = [x1,y1,x2,y2,z1,z2,score] (exact row count: one 4-byte
+    read-back; the detectors use get_bboxes_single_device and never read it)."""
     cfg = _as_cfg(cfg)
+    if _device_path_ok(cls_scores, cfg):
+        props, count = get_bboxes_single_device(cls_scores, bbox_preds, anchor_generators, anchor_strides, anchor_strides_depth,
+                                                img_shape, cfg, target_means, target_stds, valid_flags)
+        return props[:int(count.item())]
     mlvl, real = [], {}
     for lvl, (cls, reg) in enumerate(zip(cls_scores, bbox_preds)):
         assert cls.shape[-3:] == reg.shape[-3:]

@@ -194,9 +194,13 @@ class TwoStageDetector3D(nn.Module):
                                          draws_list=draws.get('rpn')))
         self._mark('rpn targets+loss')
         with torch.no_grad():
-            proposal_list = self.rpn_head.get_bboxes(*rpn_outs, img_meta, SimpleNamespace(**cfg['rpn_proposal']),
-                                                      use_pos_indices=True) \
-                if proposals is None else proposals
+            # fixed-capacity proposal blocks + device-side row counts: no host round trip (detector/rpn_proposals.py)
+            if proposals is None:
+                proposal_list, proposal_counts = self.rpn_head.get_bboxes(*rpn_outs, img_meta, SimpleNamespace(**cfg['rpn_proposal']),
+                                                                          use_pos_indices=True, with_counts=True)
+            else:
+                proposal_list, proposal_counts = proposals, [None] * len(proposals)
+        self.last_proposals = (proposal_list, proposal_counts)
         self._mark('proposals (decode+nms3d)')
 
         rc = cfg['rcnn']
@@ -207,7 +211,9 @@ class TwoStageDetector3D(nn.Module):
         rois, labels, label_weights, bbox_targets, bbox_weights, pos_gt, counts = [], [], [], [], [], [], []
         for i in range(num_imgs):
             gt, gl = gt_bboxes[i].float(), gt_labels[i]
-            ar = assigner.assign(proposal_list[i], gt, None, gl)
+            real = None if proposal_counts[i] is None else \
+                torch.arange(proposal_list[i].size(0), device=proposal_list[i].device) < proposal_counts[i]
+            ar = assigner.assign(proposal_list[i], gt, None, gl, inside_flags=real)      # rows behind the count take no part
             assigned_all = _hip.concat_gt_assign(ar.gt_inds, gt.size(0))
             dp, dn = draws['rcnn'][i] if 'rcnn' in draws else (None, None)
             pos, neg, cnt, _ = _hip.random_sample(assigned_all, cap, sampler.pos_fraction, sampler.neg_pos_ub, dp, dn)
@@ -267,15 +273,16 @@ class TwoStageDetector3D(nn.Module):
         cfg = self.test_cfg
         x = self.extract_feat(imgs, train=False)
         if proposals is None:
-            proposal_list = self.rpn_head.get_bboxes(*self.rpn_head(x), img_metas, SimpleNamespace(**cfg['rpn']))
+            proposal_list, counts = self.rpn_head.get_bboxes(*self.rpn_head(x), img_metas, SimpleNamespace(**cfg['rpn']), with_counts=True)
         else:
-            proposal_list = proposals
+            proposal_list, counts = proposals, [None]
         rois = bbox2roi3D(proposal_list)
         roi_feats = self.bbox_roi_extractor(x[:self.bbox_roi_extractor.num_inputs], rois)
         cls_score, bbox_pred = self.bbox_head(roi_feats)
         meta = img_metas[0]
         det_bboxes, det_labels = self.bbox_head.get_det_bboxes(rois, cls_score, bbox_pred, meta['img_shape'],
-                                                               meta.get('scale_factor', 1.0), rescale=rescale, cfg=cfg['rcnn'])
+                                                               meta.get('scale_factor', 1.0), rescale=rescale, cfg=cfg['rcnn'],
+                                                               valid_rows=counts[0])
         bbox_results = bbox2result3D(det_bboxes, det_labels, self.bbox_head.num_classes)
         if not self.with_mask:
             return bbox_results

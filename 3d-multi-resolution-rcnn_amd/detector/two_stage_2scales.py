@@ -82,16 +82,21 @@ class TwoStageDetector3D2Scales(TwoStageDetector3D):
         losses.update(loss_rpn_cls_2=l2['loss_rpn_cls'], loss_rpn_reg_2=l2['loss_rpn_reg'])
         with torch.no_grad():
             if proposals is None:
+                # fixed-capacity blocks + device-side row counts: no host round trip (detector/rpn_proposals.py)
                 pcfg = SimpleNamespace(**cfg['rpn_proposal'])
-                proposal_list = self.rpn_head.get_bboxes(*rpn_outs, img_meta, pcfg, use_pos_indices=True)
-                proposal_list_2 = self.rpn_head_2.get_bboxes(*rpn_outs_2, img_meta_2, pcfg, use_pos_indices=True)
-            else:                       # (proposal lists of pathway 1, of pathway 2): the `else` branch of :176-177
-                proposal_list, proposal_list_2 = proposals
-        self.last_proposals = (proposal_list, proposal_list_2)
+                proposal_list, pc1 = self.rpn_head.get_bboxes(*rpn_outs, img_meta, pcfg, use_pos_indices=True, with_counts=True)
+                proposal_list_2, pc2 = self.rpn_head_2.get_bboxes(*rpn_outs_2, img_meta_2, pcfg, use_pos_indices=True, with_counts=True)
+            else:                       # (proposal lists of pathway 1, of pathway 2 [, their counts]): the `else` branch of :176-177
+                proposal_list, proposal_list_2 = proposals[:2]
+                pc1, pc2 = proposals[2:4] if len(proposals) >= 4 else ([None] * len(proposal_list), [None] * len(proposal_list_2))
+        self.last_proposals = (proposal_list, proposal_list_2, pc1, pc2)
+        real_of = lambda p, c: None if c is None else torch.arange(p.size(0), device=p.device) < c
 
         # ---- assign / sample both pathways (:182-226)
-        s1 = self._sample(proposal_list[0], gt_bboxes[0], gt_labels[0], draws.get('rcnn', [None])[0], 0, want_mask=True)
-        s2 = self._sample(proposal_list_2[0], gt_bboxes_2[0], gt_labels_2[0], draws.get('rcnn_2', [None])[0], 0)
+        s1 = self._sample(proposal_list[0], gt_bboxes[0], gt_labels[0], draws.get('rcnn', [None])[0], 0,
+                          inside=real_of(proposal_list[0], pc1[0]), want_mask=True)
+        s2 = self._sample(proposal_list_2[0], gt_bboxes_2[0], gt_labels_2[0], draws.get('rcnn_2', [None])[0], 0,
+                          inside=real_of(proposal_list_2[0], pc2[0]))
 
         # ---- shared bbox head over both roi batches (:229-257)
         feats = self.bbox_roi_extractor(x[:4], s1['rois'])
@@ -149,18 +154,19 @@ class TwoStageDetector3D2Scales(TwoStageDetector3D):
         x_2 = self.extract_feat(imgs_2, 1, train=False)
         rcfg = SimpleNamespace(**cfg['rpn'])
         if proposals is None:
-            proposal_list = self.rpn_head.get_bboxes(*self.rpn_head(x), img_metas, rcfg)
-            proposal_list_2 = self.rpn_head_2.get_bboxes(*self.rpn_head_2(x_2), img_metas_2, rcfg)
+            proposal_list, pc1 = self.rpn_head.get_bboxes(*self.rpn_head(x), img_metas, rcfg, with_counts=True)
+            proposal_list_2, pc2 = self.rpn_head_2.get_bboxes(*self.rpn_head_2(x_2), img_metas_2, rcfg, with_counts=True)
         else:
             proposal_list = proposal_list_2 = proposals
+            pc1 = pc2 = [None]
 
-        def bboxes_scores(feats, props, m):                                  # test_mixins_3d.py simple_test_bboxes, cfg=None
+        def bboxes_scores(feats, props, m, count):                           # test_mixins_3d.py simple_test_bboxes, cfg=None
             rois = bbox2roi3D(props)
             cls_score, bbox_pred = self.bbox_head(self.bbox_roi_extractor(feats[:4], rois))
             return self.bbox_head.get_det_bboxes(rois, cls_score, bbox_pred, m['img_shape'], m.get('scale_factor', 1.0),
-                                                 rescale=rescale, cfg=None)
-        bboxes, scores = bboxes_scores(x, proposal_list, meta)
-        bboxes_2, scores_2 = bboxes_scores(x_2, proposal_list_2, meta_2)
+                                                 rescale=rescale, cfg=None, valid_rows=count)
+        bboxes, scores = bboxes_scores(x, proposal_list, meta, pc1[0])
+        bboxes_2, scores_2 = bboxes_scores(x_2, proposal_list_2, meta_2, pc2[0])
         # refinement (test_mixins_3d.py:102-128): class-1 boxes of pathway 2 + their score -> RoIAlign on PATHWAY-1 features
         ref_in = [torch.cat((bboxes_2[:, 6:], scores_2[:, 1, None]), dim=1)]
         rois_r = bbox2roi3D(ref_in)

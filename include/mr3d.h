@@ -70,6 +70,13 @@ size_t mr3d_nms3d_batched_workspace_bytes(const int *seg_rows_host, int num_segm
 int mr3d_nms3d_batched(const float *dets, const int *seg_rows_host, int num_segments, int row_stride, float iou_threshold,
                        int64_t *keep_out, int32_t *num_keep_out, void *workspace, size_t workspace_bytes,
                        mr3d_stream_t stream);
+/* As mr3d_nms3d_batched, with the number of REAL rows of every set read from device memory: set s owns seg_rows_host[s] rows of
+ * `dets` (its capacity; workspace and keep_out are sized by it) of which only the first seg_rows_dev[s] take part (NULL: all).
+ * Lets a producer kernel decide how many boxes a set has (a top-k over fewer valid anchors than k) without a host round
+ * trip; num_keep_out stays on the device for the consumer kernel. */
+int mr3d_nms3d_batched_dev(const float *dets, const int *seg_rows_host, const int32_t *seg_rows_dev, int num_segments, int row_stride,
+                           float iou_threshold, int64_t *keep_out, int32_t *num_keep_out, void *workspace, size_t workspace_bytes,
+                           mr3d_stream_t stream);
 
 /* multiclass_nms_3d (mmdet/core/post_processing/bbox_nms.py:57-106) as ONE device op: per foreground class c = 1..C-1
  * keep rows with multi_scores[r][c] > score_thr, NMS3D them (boxes multi_bboxes[r][6c..6c+5], or [0..5] when
@@ -543,6 +550,33 @@ int mr3d_stem_conv_forward_bf16(const float *x_ncdhw, const void *w16, const flo
                                 int relu, mr3d_stream_t stream);
 int mr3d_stem_conv_wgrad_bf16(const float *x_ncdhw, const void *dy_bf16, float *dw_packed, float *dbias, int n, int d, int h, int w,
                               mr3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * RPN proposal selection without a host round trip -- RPNHead3D.get_bboxes_single
+ * (mmdet/models/anchor_heads/rpn_head_3d.py:72-149): per level sigmoid -> drop flagged-out anchors (:95-106) -> top nms_pre
+ * (:108-112) -> decode -> nms -> first nms_post (:133-135); then top max_num over all levels (:141-148).
+ *   mr3d_rpn_select_topk: for every level with more than nms_pre anchors, the nms_pre highest-scoring anchors among those
+ *     whose `valid` byte is non-zero (NULL: all) -- an exact radix select on the logits; levels with at most nms_pre anchors
+ *     contribute all of them (no flags, as the reference).  Level l owns rows [sum_{j<l} k_j, +k_l) of flat_out / scores_out,
+ *     k_l = min(anchors_l, nms_pre); its first counts_out[l] rows are real, in ascending anchor order: flat index
+ *     ((h*W + w)*D + d)*A + a (the reference's permute(2,3,1,0) order) and sigmoid(logit); the rest is filler.
+ *   The rows then go through mr3d_rpn_decode_level and mr3d_nms3d_batched_dev (seg_rows_dev = counts_out).
+ *   mr3d_rpn_merge_levels: the first min(num_keep[l], nms_post) kept rows of every level, concatenated in level order, then
+ *     the max_num best by (score descending, position ascending): proposals_out [max_num, 7], zero rows behind *count_out.
+ *     dets / keep are laid out as for mr3d_nms3d_batched (seg_rows_host = the sets' capacities).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  const float *logits;                 /* [A, D, H, W] objectness logits, element strides below (any memory format) */
+  const void *valid;                   /* uint8 per anchor in flat (h, w, d, a) order, or NULL */
+  long long stride_a, stride_d, stride_h, stride_w;
+  int anchors, depth, height, width;
+} mr3d_rpn_level;
+size_t mr3d_rpn_select_topk_workspace_bytes(const mr3d_rpn_level *levels_host, int num_levels, int nms_pre);
+int mr3d_rpn_select_topk(const mr3d_rpn_level *levels_host, int num_levels, int nms_pre, long long *flat_out, float *scores_out,
+                         int32_t *counts_out, void *workspace, size_t workspace_bytes, mr3d_stream_t stream);
+int mr3d_rpn_merge_levels(const float *dets, const int *seg_rows_host, int num_levels, const long long *keep,
+                          const int32_t *num_keep, int nms_post, int max_num, float *proposals_out, int32_t *count_out,
+                          mr3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Plan executor: runs a pre-built list of the operations above with ONE call (the host-side loop of

@@ -106,8 +106,9 @@ def _ref_get_bboxes_single(cls_scores, bbox_preds, gens, strides, dstrides, img_
     return props[top]
 
 
+@pytest.mark.parametrize('nms_post', [700, 1500])       # < nms_pre: the path with host-side counts; == nms_pre: the sync-free device path
 @pytest.mark.parametrize('channels_last', [False, True, 'flags', 'few_flags'])
-def test_rpn_get_bboxes_single_vs_restatement(dev, channels_last):
+def test_rpn_get_bboxes_single_vs_restatement(dev, channels_last, nms_post):
     from mr3d_amd.core import AnchorGenerator3D
     from mr3d_amd.detector import get_bboxes_single
     torch.manual_seed(11)
@@ -122,7 +123,7 @@ def test_rpn_get_bboxes_single_vs_restatement(dev, channels_last):
         if channels_last is True:    # what the conv engine hands over: [C, D, H, W] views of an NDHWC buffer
             r = r.permute(1, 2, 3, 0).contiguous().permute(3, 0, 1, 2)
         cls.append(c); reg.append(r)
-    cfg = dict(nms_across_levels=False, nms_pre=1500, nms_post=700, max_num=1000, nms_thr=0.7, min_bbox_size=0)
+    cfg = dict(nms_across_levels=False, nms_pre=1500, nms_post=nms_post, max_num=1000, nms_thr=0.7, min_bbox_size=0)
     flags = None
     if channels_last == 'flags':     # the reference's cached inside-flags (rpn_head_3d.py:97-101): random 70 % here
         flags = [(torch.rand(d * h * w, device=dev) < 0.7).to(torch.uint8) for (d, h, w) in sizes]
@@ -134,6 +135,14 @@ def test_rpn_get_bboxes_single_vs_restatement(dev, channels_last):
     got = get_bboxes_single(cls, reg, gens, strides, dstrides, img_shape, cfg, valid_flags=flags)
     exp = _ref_get_bboxes_single(cls, reg, gens, strides, dstrides, img_shape, cfg, pos_indices=flags)
     assert got.shape == exp.shape
+    if nms_post >= cfg['nms_pre']:
+        # the device path itself: a fixed [max_num, 7] block, zero rows behind the device-side count
+        from types import SimpleNamespace
+        from mr3d_amd.detector.rpn_proposals import get_bboxes_single_device, _device_path_ok
+        assert _device_path_ok(cls, SimpleNamespace(**cfg))
+        blk, cnt = get_bboxes_single_device(cls, reg, gens, strides, dstrides, img_shape, cfg, valid_flags=flags)
+        assert tuple(blk.shape) == (cfg['max_num'], 7) and cnt.dtype == torch.int32 and int(cnt) == got.size(0)
+        assert torch.equal(blk[:int(cnt)], got) and (blk[int(cnt):] == 0).all()
     # same proposals, score-descending; sigmoid saturates, so equal fp32 scores occur and torch.topk orders ties
     # differently on host and device: compare in a canonical order (score desc, then coordinates).  Coordinates
     # differ by device-vs-host expf ulps only.
@@ -213,3 +222,41 @@ def test_multiclass_nms_3d_several_classes(dev, max_num, shared_boxes):
     np.testing.assert_array_equal(got_l.cpu().numpy(), exp_l)
     with pytest.raises(NotImplementedError):
         multiclass_nms_3d(torch.from_numpy(cols).to(dev), torch.from_numpy(scores).to(dev), 0.3, dict(type='soft_nms', iou_thr=0.5), 10)
+
+
+@pytest.mark.parametrize('n,k,frac', [(655360, 2000, 0.7), (81920, 2000, 1.0), (10240, 2000, 0.05), (5000, 2000, 0.0), (8192, 4096, 0.9)])
+def test_rpn_select_topk_is_an_exact_topk(dev, n, k, frac):
+    """mr3d_rpn_select_topk (radix select on the logits): the selected set equals torch.topk's on the masked scores wherever
+    the k-th score is not tied, comes out in ascending anchor order, carries sigmoid(logit), and reports
+    min(k, #valid) rows; strided (channels-last) logit maps give the same selection."""
+    from mr3d_amd import _hip
+    g = torch.Generator(device='cpu').manual_seed(n + k)
+    A, D = 1, 8
+    W = 16
+    H = n // (A * D * W)
+    n = A * D * H * W
+    logits = (torch.randn(A, D, H, W, generator=g) * 3).to(dev)
+    flags = (torch.rand(n, generator=g) < frac).to(dev) if frac < 1.0 else None
+    small = torch.randn(1, 2, 4, 4, generator=g).to(dev)                  # a level with fewer anchors than k: all 32 taken
+    for maps in ([logits, small], [logits.permute(1, 2, 3, 0).contiguous().permute(3, 0, 1, 2), small]):
+        caps, flat, scores, counts = _hip.rpn_select_topk(maps, [flags, None], k)
+        assert caps == [min(n, k), 32]
+        c = counts.cpu().numpy()
+        s_flat = maps[0].permute(2, 3, 1, 0).reshape(-1).sigmoid()           # the reference's flat order
+        lg_flat = maps[0].permute(2, 3, 1, 0).reshape(-1)
+        nvalid = n if flags is None else int(flags.sum())
+        assert c[0] == min(k, nvalid) and c[1] == 32
+        sel = flat[:c[0]]
+        assert (sel[1:] > sel[:-1]).all()                                      # ascending anchor order, no duplicates
+        if flags is not None:
+            assert flags[sel].all()
+        np.testing.assert_allclose(scores[:c[0]].cpu().numpy(), s_flat[sel].cpu().numpy(), rtol=2e-6, atol=1e-7)
+        if c[0] == k:
+            masked = lg_flat if flags is None else torch.where(flags, lg_flat, lg_flat.new_full((), -1e30))
+            ref_v, ref_i = masked.topk(k)
+            kth = ref_v[-1]
+            assert (lg_flat[sel] >= kth).all()                                # nothing below the k-th logit
+            strict = set(ref_i[ref_v > kth].tolist())
+            assert strict <= set(sel.tolist())                                # everything strictly above it
+        assert torch.equal(flat[caps[0]:caps[0] + 32], torch.arange(32, device=dev))
+        np.testing.assert_allclose(scores[caps[0]:].cpu().numpy(), small.permute(2, 3, 1, 0).reshape(-1).sigmoid().cpu().numpy(), rtol=2e-6)
