@@ -600,6 +600,12 @@ def make_op(kind, ptrs=(), ints=(), alpha=0.0, side=False):
     return o
 
 
+def plan_stream_wait_mark(slot, stream):
+    """mr3d_plan_stream_wait_mark: torch stream `stream` waits for SYNC mark `slot` of the last plan run on its device"""
+    with torch.cuda.device(stream.device):
+        check(lib().mr3d_plan_stream_wait_mark(int(slot), ctypes.c_void_p(stream.cuda_stream)), 'mr3d_plan_stream_wait_mark')
+
+
 def split64(v):
     v = int(v)
     lo, hi = v & 0xFFFFFFFF, (v >> 32) & 0xFFFFFFFF

@@ -258,6 +258,17 @@ extern "C" int mr3d_plan_run_marked(const mr3d_op *ops, int num_ops, int *failed
   return plan_run_impl(ops, num_ops, failed_index, stream, marks, num_marks, pairs);
 }
 
+// Lets a stream of the CALLER (e.g. the communication stream of the gradient exchange) wait for a point of the side queue
+// that a SYNC(mark) record remembered during the last plan run on this device.
+extern "C" int mr3d_plan_stream_wait_mark(int slot, mr3d_stream_t stream) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices || slot < 0 || slot > 3) return MR3D_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(g_side_mu[dev]);
+  SideStream &g_side = g_sides[dev];
+  if (!g_side.ok) return MR3D_OK;               // no side stream was ever used: everything ran on the caller's stream
+  return hipStreamWaitEvent(mr3d_stream(stream), g_side.mark[slot], 0) == hipSuccess ? MR3D_OK : MR3D_ERR_LAUNCH;
+}
+
 extern "C" int mr3d_event_pair_elapsed_ms(const mr3d_event_pair *pair, float *ms) {
   if (!pair || !pair->start || !pair->stop || !ms) return MR3D_ERR_INVALID_ARG;
   return hipEventElapsedTime(ms, (hipEvent_t)pair->start, (hipEvent_t)pair->stop) == hipSuccess ? MR3D_OK : MR3D_ERR_LAUNCH;

@@ -58,6 +58,7 @@ class _ConvSpec:
 
 class ExtractFeat3D(nn.Module):
     STAGE_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
+    MARK_GRADS_BUT_STEM = 1          # SYNC slot of the backward plan (see dist_utils.allreduce_overlapped)
 
     def __init__(self, depth=50, fpn_out_channels=64, num_outs=5, zero_init_residual=True, device='cuda',
                  dtype=torch.float32, neck_dcn=False):
@@ -327,6 +328,12 @@ class ExtractFeat3D(nn.Module):
                     self.get_parameter(b['conv3'].bn + '.weight').zero_()
 
     @property
+    def stem_elems(self):
+        """length of the leading arena range that holds the stem's parameters (conv1 weight + its BN scale / shift): the only
+        gradients that are not final when the backward plan's MARK_GRADS_BUT_STEM point is reached"""
+        return self.rel_offsets[self.specs[1].name + '.weight']
+
+    @property
     def flat_params(self):
         """the TRAINABLE range of the arena (no BN running statistics): what an optimiser may step"""
         return self._flat_params_view
@@ -571,6 +578,8 @@ class ExtractFeat3D(nn.Module):
         # own 16 channels are finished after the join.
         bwd.append(_hip.make_op(_hip.OP_FINISH_GRADS, [self._table.data_ptr() + dsz, self._arena, self._scratch, self._grad_arena],
                                 [nL - 1, self.max_cout], side=True))
+        # slot 1: "every parameter gradient but the stem's is final" -- the point the overlapped gradient exchange waits for
+        bwd.append(_hip.make_op(_hip.OP_SYNC, [], [_hip.SYNC_MARK, self.MARK_GRADS_BUT_STEM]))
         g_stem = self._new(P.stem_out.shape)
         bwd.append(self._op(_hip.OP_MAXPOOL_BWD, [g, P.pool_idx, P.pool_out, g_stem], [N, sd, sh, sw, 16]))
         bwd.append(_hip.make_op(_hip.OP_SYNC, [], [_hip.SYNC_WAIT, 0]))

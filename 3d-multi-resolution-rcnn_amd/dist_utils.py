@@ -28,6 +28,43 @@ def allreduce_flat_grads(flat, world_size=None, group=None):
     return flat
 
 
+_COMM_STREAMS = {}
+
+
+def allreduce_overlapped(flat, stem_elems, world_size=None, group=None, mark_slot=1, force_single_rank=False):
+    """In-place mean of the flat gradient arena as TWO collectives so that the exchange starts before the backward pass has
+    finished.  The arena begins with the stem's parameters (`stem_elems` floats); everything behind them -- the rest of the
+    backbone, the neck, every head: 99.9 % of the message -- is final as soon as the backward plan's gradient finishing of
+    those layers has run on the plan's side stream, which happens UNDERNEATH the stem's weight-gradient kernel (1.8 ms, the
+    last kernel of the backward).  So: a communication stream waits for that point (mr3d_plan_stream_wait_mark) and carries
+    the all-reduce of flat[stem_elems:]; the caller's stream then reduces the 66 KB stem range and waits for the first.
+    Semantics are those of allreduce_flat_grads / the reference (SUM, then divide, before the gradient clip:
+    mmdet/core/utils/dist_utils.py:22-28,51-57).  CPU tensors (gloo tests): the same two collectives, one after the other.
+    Call it after loss.backward() has returned (everything is enqueued by then)."""
+    if world_size is None:
+        world_size = dist.get_world_size(group)
+    if world_size == 1 and not force_single_rank:      # force_single_rank: launch the collectives anyway (1-GPU check of the
+        return flat                                     # launch structure under a profiler)
+    head, tail = flat[:stem_elems], flat[stem_elems:]
+    if flat.is_cuda:
+        from . import _hip
+        dev = flat.device
+        comm = _COMM_STREAMS.get(dev)
+        if comm is None:
+            comm = _COMM_STREAMS[dev] = torch.cuda.Stream(device=dev)
+        _hip.plan_stream_wait_mark(mark_slot, comm)
+        with torch.cuda.stream(comm):
+            work = dist.all_reduce(tail, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        dist.all_reduce(head, op=dist.ReduceOp.SUM, group=group)
+        work.wait()                                 # the caller's stream waits for the communication stream's collective
+    else:
+        dist.all_reduce(tail, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(head, op=dist.ReduceOp.SUM, group=group)
+    if world_size > 1:
+        flat.div_(world_size)
+    return flat
+
+
 def broadcast_params(flat, src=0, group=None):
     """identical initial weights on every rank (what MMDistributedDataParallel.__init__ does with its
     coalesced state_dict broadcast, mmdet/apis/train.py:92)"""
@@ -116,7 +153,13 @@ class DetectorArena:
         if self.heads is not None:
             self.heads.zero_grad()
 
-    def allreduce(self, world_size=None, group=None):
+    def allreduce(self, world_size=None, group=None, overlap=True):
+        """the one gradient exchange of a step.  overlap (default): two collectives, the first one started underneath the
+        tail of the backward pass (allreduce_overlapped); False: ONE in-place all-reduce after the backward pass, as the
+        reference issues it"""
+        if overlap and self.engine is not None:
+            return allreduce_overlapped(self.flat_grads, self.engine.stem_elems, world_size, group,
+                                        mark_slot=self.engine.MARK_GRADS_BUT_STEM)
         return allreduce_flat_grads(self.flat_grads, world_size, group)
 
 
@@ -212,7 +255,7 @@ class DistOptimizerStep:
         self.optimizer.step()
 
 
-def train_step(detector, arena, optimizer, batch, world_size=1, grad_clip=35.0, group=None):
+def train_step(detector, arena, optimizer, batch, world_size=1, grad_clip=35.0, group=None, overlap=True):
     """One iteration of the reference's hot loop (mmdet/apis/train.py:37-48 batch_processor + dist_utils.py:51-57):
     zero -> forward_train -> sum of the losses -> backward -> ONE all-reduce of the detector's gradient arena -> L2 clip
     (configs/...py:236) -> optimizer.step().  `batch` = (args, kwargs) of detector.forward_train.  Returns
@@ -223,7 +266,7 @@ def train_step(detector, arena, optimizer, batch, world_size=1, grad_clip=35.0, 
     total = detector.total_loss(losses)
     total.backward()
     if world_size > 1:
-        arena.allreduce(world_size, group)
+        arena.allreduce(world_size, group, overlap=overlap)
     if grad_clip is not None:
         clip_grad_norm_flat([arena.flat_grads], grad_clip)
     optimizer.step()

@@ -51,6 +51,8 @@ def parse():
     ap.add_argument('--config', choices=['backbone', 'two_stage'], default='backbone',
                     help="backbone = BASELINE configs[1] (the headline metric); two_stage = configs[2]/[3]: the whole "
                          "single-pathway training step with ONE all-reduce of the detector's 26 M-element gradient arena")
+    ap.add_argument('--serial-allreduce', action='store_true',
+                    help='N > 1: ONE all-reduce after the backward pass (the reference order) instead of the overlapped exchange')
     ap.add_argument('--backbone-only-allreduce', action='store_true',
                     help='N > 1, --config backbone: exchange only the 13.7 MB backbone+FPN gradients instead of the whole '
                          "detector's arena")
@@ -395,7 +397,7 @@ def main():
     import mr3d_amd
     from mr3d_amd import _hip
     from mr3d_amd.detector import ExtractFeat3D
-    from mr3d_amd.dist_utils import allreduce_flat_grads, broadcast_params
+    from mr3d_amd.dist_utils import allreduce_flat_grads, allreduce_overlapped, broadcast_params
 
     torch.manual_seed(1234 + rank)
     D, H, W = a.vol
@@ -430,10 +432,13 @@ def main():
         ev = plan.fwd.run(dev, marks_f) if (split or not marks_f) else plan.fwd.run_marked(marks_f, dev)
         eng.bind_grads(plan, cots)               # channels-last P2..P4 gradients are read in place, P5/P6 copied
         evb = plan.bwd.run(dev, marks_b) if (split or not marks_b) else plan.bwd.run_marked(marks_b, dev)
-        if world > 1:
-            allreduce_flat_grads(reduce_buf, world)
-        elif force_dist:
-            dist.all_reduce(reduce_buf)                  # world 1: still launches RCCL's kernel on its own stream
+        # the exchange: everything behind the stem's parameters starts on a communication stream as soon as its gradient
+        # finishing is done, underneath the stem weight gradient; the stem's 66 KB follow (dist_utils.allreduce_overlapped)
+        if world > 1 or force_dist:
+            if a.serial_allreduce:
+                allreduce_flat_grads(reduce_buf, world) if world > 1 else dist.all_reduce(reduce_buf)
+            else:
+                allreduce_overlapped(reduce_buf, eng.stem_elems, world, force_single_rank=force_dist)
         return ev, evb
 
     # ---- warmup; the last warmup step is bracketed op by op to find the dominant kernel

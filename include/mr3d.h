@@ -641,6 +641,11 @@ void mr3d_plan_set_side_stream(int enable);
  * recorded on the stream each record really runs on -- the plan is NOT split, so the timed step is the production step.
  * pairs[j] receives two events the library creates; read them with mr3d_event_pair_elapsed_ms after synchronising the
  * device and release them with mr3d_event_pair_destroy. */
+/* `stream` waits for the point of the side queue that the last SYNC(mark, slot) record of a plan run on the current device
+ * remembered (a never-recorded slot is no wait).  The gradient exchange uses it: the all-reduce of everything but the
+ * stem's parameters starts on a communication stream as soon as their gradient finishing is done, underneath the stem's
+ * weight-gradient kernel. */
+int mr3d_plan_stream_wait_mark(int slot, mr3d_stream_t stream);
 typedef struct { void *start, *stop; } mr3d_event_pair;
 int mr3d_plan_run_marked(const mr3d_op *ops_host, int num_ops, int *failed_index_host, mr3d_stream_t stream, const int *marks,
                          int num_marks, mr3d_event_pair *pairs);

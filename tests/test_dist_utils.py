@@ -170,6 +170,62 @@ def test_train_step_world2_identical_parameters():
         assert all(r[1:]), r
 
 
+def _overlap_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import mr3d_amd  # noqa: F401
+        from mr3d_amd.dist_utils import DetectorArena, broadcast_params, allreduce_flat_grads, allreduce_overlapped, clip_grad_norm_flat
+        dets, arenas, opts = [], [], []
+        for _ in range(2):                               # [serial exchange, two-collective exchange], identical starts
+            torch.manual_seed(3)
+            d = _StubDetector()
+            a = DetectorArena(d, engine_attr=None)
+            broadcast_params(a.flat_params)
+            dets.append(d); arenas.append(a)
+            opts.append(torch.optim.SGD([a.flat_params], lr=0.05, momentum=0.9, weight_decay=1e-4))
+        gen = torch.Generator().manual_seed(500 + rank)
+        split = 37                                       # any split point: the leading range plays the stem's part
+        for it in range(3):
+            x = torch.randn(5, 6, generator=gen)
+            args = (x, (torch.rand(5, 1, generator=gen) > 0.5).float(), torch.randn(5, 6, generator=gen))
+            for k in range(2):
+                arenas[k].zero_grad()
+                dets[k].total_loss(dets[k].forward_train(*args)).backward()
+                if k == 0:
+                    allreduce_flat_grads(arenas[k].flat_grads, world)
+                else:
+                    allreduce_overlapped(arenas[k].flat_grads, split, world)
+                clip_grad_norm_flat([arenas[k].flat_grads], 35.0)
+                opts[k].step()
+        same_paths = torch.equal(arenas[0].flat_params, arenas[1].flat_params) and torch.equal(arenas[0].flat_grads, arenas[1].flat_grads)
+        ws = [torch.empty_like(arenas[1].flat_params) for _ in range(world)]
+        dist.all_gather(ws, arenas[1].flat_params)
+        q.put((rank, same_paths, all(torch.equal(ws[0], w) for w in ws)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_exchange_equals_serial_exchange_world2():
+    """allreduce_overlapped (two collectives: everything behind the stem's range first, on the GPU underneath the stem weight
+    gradient, then the stem's range) leaves bit-identical gradients and, after 3 SGD steps, bit-identical parameters to the
+    reference's single all-reduce (dist_utils.py:51-57) -- and identical parameters on both ranks"""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in res:
+        assert all(r[1:]), r
+
+
 def test_dist_optimizer_step_keeps_arena_grads_attached():
     """DistOptimizerStep must not orphan arena-backed gradients (torch 2.x zero_grad sets them to None)."""
     from mr3d_amd.dist_utils import DistOptimizerStep, FlatArena

@@ -72,7 +72,9 @@ def test_config2_forward_train_backward_at_512x512x80(dev):
     assert torch.isfinite(g).all()
     # every parameter's arena range carries gradient
     dead = [n for n, p in det.named_parameters() if p.requires_grad and not (p.grad is not None and p.grad.abs().sum() > 0)]
-    assert not dead, dead[:8]
+    # P5's output conv only receives gradient from anchors / rois that land on P5 or P6: with 12 lesion-sized gts and 256 RPN
+    # samples drawn from 748,992 anchors (1,472 of them on P5 + P6) none may fall there in a given step
+    assert set(dead) <= {'extract.neck.fpn_convs.3.conv.weight', 'extract.neck.fpn_convs.3.conv.bias'}, dead[:8]
     starts = sorted(p.data_ptr() for p in det.parameters() if p.requires_grad)
     assert starts[0] >= arena.flat_params.data_ptr() and starts[-1] < arena.flat_params.data_ptr() + 4 * arena.flat_params.numel()
     losses2, g2 = run()
