@@ -88,10 +88,16 @@ def test_config2_forward_train_backward_at_512x512x80(dev):
 
 # Bounds of the bf16 + DeformConv3d configuration against the fp32 arithmetic of the same model (configs[4] is build-defined:
 # the reference has no bf16 numbers).  A bf16 value carries 8 significant bits (relative rounding 2^-9 = 2e-3 per stored map);
-# the backbone stores ~55 maps per direction, so loss values move by ~1e-2 and the arena gradient, whose ReLU / arg-max pattern
-# flips wherever an fp32 pre-activation sits within bf16 rounding of zero, by ~1e-1 in L2.
-CFG4_LOSS_REL = 5e-2
-CFG4_GRAD_L2 = 0.35
+# the backbone stores ~55 maps per direction and its ReLU / arg-max pattern flips wherever an fp32 pre-activation sits within
+# bf16 rounding of zero.  Measured on this input (tools/diag/cfg4_grad_diag.py): losses within 2e-3, backbone gradient 2.9e-2
+# in L2 (cosine 0.9996) -- the same 8e-2 bound as the engine-only bf16 test (tests/test_gpu_bf16.py).  The comparison needs a
+# well-conditioned network: with all 16 residual branches at full scale and random weights the activations of this UNTRAINED
+# net grow by orders of magnitude with depth, the neck's sampling offsets reach several voxels and fp32 itself is chaotic
+# there (bf16 vs fp32 gradients then differ by 0.9 in L2 with losses still within 2 %); the reference's own initialisation
+# zeroes the residual scales, here they are set to 0.25 so that every convolution still receives gradient.
+CFG4_LOSS_REL = 2e-2
+CFG4_GRAD_L2 = 8e-2
+RESIDUAL_SCALE = 0.25
 
 
 def test_config4_dual_pathway_dcn_neck_bf16(dev):
@@ -118,6 +124,8 @@ def test_config4_dual_pathway_dcn_neck_bf16(dev):
         det.extract.zero_init_residual = False
         det.extract.init_weights()
         with torch.no_grad():
+            for b in det.extract.blocks:
+                det.extract.get_parameter(b['conv3'].bn + '.weight').fill_(RESIDUAL_SCALE)
             for off in det.dcn_neck.conv_offset:
                 off.weight.normal_(0, 0.01)                  # non-trivial sampling offsets
         return det
@@ -161,7 +169,7 @@ def test_config4_dual_pathway_dcn_neck_bf16(dev):
     rel = ((g - g_ref).norm() / g_ref.norm()).item()
     assert rel < CFG4_GRAD_L2, rel
     cos = torch.nn.functional.cosine_similarity(g, g_ref, dim=0).item()
-    assert cos > 0.93, cos
+    assert cos > 0.995, cos
     for n, p in det.named_parameters():
         if n.startswith('extract.'):
             continue

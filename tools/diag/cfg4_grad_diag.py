@@ -29,12 +29,16 @@ def main():
     draws.update({k: [(w(128), w(512))] for k in ('rcnn', 'rcnn_2', 'refine')})
     args = (img, [meta], img_2, [meta_2], [gt], [gt * 1.5], [gl], [gl])
     for dcn in (False, True):
-        for zir in (True, False):
+        for zir in (True, 0.25, False):
             def build(dtype):
                 torch.manual_seed(5)
                 det = TwoStageDetector3D2Scales(device=dev, dtype=dtype, neck_dcn=dcn)
-                det.extract.zero_init_residual = zir
+                det.extract.zero_init_residual = zir is True
                 det.extract.init_weights()
+                if zir not in (True, False):          # damped residual branches: every conv gets gradient, activations stay tame
+                    with torch.no_grad():
+                        for b in det.extract.blocks:
+                            det.extract.get_parameter(b['conv3'].bn + '.weight').fill_(float(zir))
                 if dcn:
                     with torch.no_grad():
                         for off in det.dcn_neck.conv_offset:
