@@ -25,7 +25,6 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr bool getenv_free_wpad() { return true; }     // compile-time switch of FwdCfg::WPAD (A/B: set to false and rebuild)
 
 // PAR_: the parity-decomposed data gradient of a stride-2 3x3x3 convolution (see conv3d_dgrad_s2k3 below); the
 // kernel extents are then the per-axis MAXIMUM (2) and the taps actually walked are chosen per parity class.
@@ -52,7 +51,7 @@ struct FwdCfg {
   // WPAD: one spare column per halo row in the F(4,3) form.  Their GEMM rows step 2 or 4 positions along W, and with the
   // natural 10-position rows the 32 lanes of a ds_read_b32 group fall 3-way onto the 32 banks; 11-position rows make it 2-way
   // (the best any row pitch reaches: SQ_LDS_BANK_CONFLICT was 66 % of the LDS-active cycles of the F(4,3) kernel).
-  static constexpr int WPAD = (WINO_ == 4 && getenv_free_wpad()) ? 1 : 0;        // F(4,3): 0.480 -> 0.477 ms on P2; the F(2,3) 4x8x8 instance would spill
+  static constexpr int WPAD = (WINO_ == 4) ? 1 : 0;        // F(4,3): 0.480 -> 0.477 ms on P2; the F(2,3) 4x8x8 instance would spill
   static constexpr int HD = (TD - 1) * LSD + KD, HH = (TH - 1) * LSH + KH, HW = (TW - 1) * LSW + KW + WPAD;
   static constexpr int HP = HD * HH * HW;       // halo positions
   static constexpr int ROW = CC + 1;            // LDS row stride in floats
@@ -458,16 +457,16 @@ int dispatch_tile(const Conv3dFwdArgs &a, hipStream_t stream) {
     // large roi batches (mask heads on >= ~52 rois): the two-dimensional Winograd kernel (2x8x8 tiles on a 10x14x14 volume use
     // 77 % of their rows, at 1/3 of the MFMA work) instead of the direct 5x7x7 tiles: 128-row step 26.3 -> 24.9 ms; on 16-row
     // batches the two are equal
-    static const int roi2d_min = getenv("MR3D_FWD_WINO2D_ROI_MIN") ? atoi(getenv("MR3D_FWD_WINO2D_ROI_MIN")) : 1024;
-    static const int wino_roi = getenv("MR3D_FWD_WINO") ? atoi(getenv("MR3D_FWD_WINO")) : 4;
+    constexpr int roi2d_min = 1024;
+    constexpr int wino_roi = 4;
     const bool skip577 = wino_roi >= 4 && NB == 64 && CC == 16 && a.N * t288 >= roi2d_min && mr3d_conv3d_wino2d_ok(a);
     if (!skip577 && c577 > 1.15 * (c488 > c288 ? c488 : c288) && a.N * t577 * (a.Cout / NB) >= 512)
       return launch_fwd<FwdCfg<3, 3, 3, 1, 1, 1, 5, 7, 7, CC, NB>>(a, stream);
   }
   if constexpr (K == 3 && SD == 1 && SH == 1 && SW == 1 && CC == 16 && (NB == 16 || NB == 32)) {
     // narrow Cout (layer1 16 -> 16, layer2 32 -> 32 on the large maps): F(4,3) x F(2,3) with the waves split over GEMM rows
-    static const int wino_r = getenv("MR3D_FWD_WINO") ? atoi(getenv("MR3D_FWD_WINO")) : 4;
-    static const int min2d_r = getenv("MR3D_FWD_WINO2D_ROWS_MIN") ? atoi(getenv("MR3D_FWD_WINO2D_ROWS_MIN")) : 256;   // backbone step 11.83 -> 11.69 (layer1) -> 11.64 ms (+ layer2)
+    constexpr int wino_r = 4;
+    constexpr int min2d_r = 256;   // backbone step 11.83 -> 11.69 (layer1) -> 11.64 ms (+ layer2)
     if (wino_r >= 4 && a.Cout == NB && wgs(NB == 16 ? 8 : 4, 8, 8) >= min2d_r && mr3d_conv3d_wino2d_rows_ok(a)) {
       if (g_variant_probe) {
         mr3d_conv3d_variant &v = *g_variant_probe;
@@ -486,13 +485,13 @@ int dispatch_tile(const Conv3dFwdArgs &a, hipStream_t stream) {
     // outputs = 64 pair rows keep the accumulators at 64 registers and two workgroups per CU (P2 3x3x3 64->64:
     // 1.19 -> 1.02 ms; the 4x8x8 form needs 128 accumulator registers, one workgroup per CU: 1.11 ms).
     // The 16-wide single-chunk kernel (layer1) gains nothing from it (96 vs 96 TFLOP/s: not MFMA-bound).
-    static const int wino = getenv("MR3D_FWD_WINO") ? atoi(getenv("MR3D_FWD_WINO")) : 4;     // 0: direct form only; 1: F(2,3) 2x8x8 only; 2: + F(2,3) 4x8x8; 3: F(4,3) 4x8x8; 4: + F(4,3) x F(2,3) on large maps
+    constexpr int wino = 4;     // 0: direct form only; 1: F(2,3) 2x8x8 only; 2: + F(2,3) 4x8x8; 3: F(4,3) 4x8x8; 4: + F(4,3) x F(2,3) on large maps
     // 4x8x8 outputs = 128 pair rows: 128 accumulator registers; without the next-chunk register prefetch it still fits
     // two workgroups per CU, which hide each other's staging: P2 0.91 ms (159 TFLOP/s of algorithmic work)
-    static const int min43 = getenv("MR3D_FWD_WINO43_MIN") ? atoi(getenv("MR3D_FWD_WINO43_MIN")) : 256;   // P3 (320 tiles): 0.164 -> 0.157 ms
+    constexpr int min43 = 256;   // P3 (320 tiles): 0.164 -> 0.157 ms
     // 4: F(4,3) along W x F(2,3) along H (conv3d_wino2d.hip) on maps with >= min2d tiles of 2x8x8: P2 64->64 834 -> 640-660 us,
     // backbone step 12.52 -> 11.8 ms (P3, 640 tiles, included)
-    static const int min2d = getenv("MR3D_FWD_WINO2D_MIN") ? atoi(getenv("MR3D_FWD_WINO2D_MIN")) : 256;
+    constexpr int min2d = 256;
     if (wino >= 4 && wgs(2, 8, 8) >= min2d && mr3d_conv3d_wino2d_ok(a)) {
       if (g_variant_probe) {
         mr3d_conv3d_variant &v = *g_variant_probe;
@@ -504,12 +503,12 @@ int dispatch_tile(const Conv3dFwdArgs &a, hipStream_t stream) {
     }
     if (wino >= 3 && wgs(4, 8, 8) >= min43) return launch_fwd<FwdCfg<3, 3, 3, 1, 1, 1, 4, 8, 8, CC, NB, false, false, 4>>(a, stream);
     if (wino >= 2 && wgs(4, 8, 8) >= 512) return launch_fwd<FwdCfg<3, 3, 3, 1, 1, 1, 4, 8, 8, CC, NB, false, false, 2>>(a, stream);
-    static const int wino_min = getenv("MR3D_FWD_WINO_MIN") ? atoi(getenv("MR3D_FWD_WINO_MIN")) : 256;   // 16-roi mask batches (320 tiles): 133 -> 109 us
+    constexpr int wino_min = 256;   // 16-roi mask batches (320 tiles): 133 -> 109 us
     if (wino && wgs(2, 8, 8) >= wino_min) return launch_fwd<FwdCfg<3, 3, 3, 1, 1, 1, 2, 8, 8, CC, NB, false, false, 2>>(a, stream);
   }
   if constexpr (K == 3 && SD == 1 && SH == 1 && SW == 1 && CC == 16 && NB == 32) {
     // 32-wide Cout tile (layer2 32->32 on 20x64x64): F(2,3) on 4x8x8 tiles, 128 pair rows: 67 -> 57 us
-    static const int wino32 = getenv("MR3D_FWD_WINO") ? atoi(getenv("MR3D_FWD_WINO")) : 3;
+    constexpr int wino32 = 3;
     if (wino32 && wgs(4, 8, 8) >= 256) return launch_fwd<FwdCfg<3, 3, 3, 1, 1, 1, 4, 8, 8, CC, NB, false, false, 2>>(a, stream);
   }
   if (wgs(4, 8, 8) >= 512) return launch_fwd<T0>(a, stream);
@@ -531,7 +530,7 @@ inline int narrow_nb(const Conv3dFwdArgs &a, int nb) {
     const int th = nb_ == 32 ? 8 : 4;      // smallest position tile of that Cout tile: (2,8,8) for 32, else (2,4,8)
     return (long long)a.N * ((a.Do + 1) / 2) * ((a.Ho + th - 1) / th) * ((a.Wo + 7) / 8) * (a.Cout / nb_);
   };
-  static const int min_wgs = getenv("MR3D_FWD_MIN_WGS") ? atoi(getenv("MR3D_FWD_MIN_WGS")) : 256;
+  constexpr int min_wgs = 256;
   while (nb > 16 && wgs(nb) < min_wgs) nb /= 2;
   return nb;
 }

@@ -408,7 +408,7 @@ int launch_wgrad(const Conv3dWgradArgs &a, hipStream_t stream) {
     attr_done = true;
   }
   const int chunks = a.Cin / C::CC, ntiles = a.Cout / C::NB;
-  static const int total_wgs = getenv("MR3D_WGRAD_WGS") ? atoi(getenv("MR3D_WGRAD_WGS")) : 512;   // tuning knob
+  constexpr int total_wgs = 512;   // tuning knob
   int gx = total_wgs / (chunks * ntiles);      // ~2 workgroups per CU in total
   if (gx < 1) gx = 1;
   if (gx > num_tiles) gx = num_tiles;
@@ -453,7 +453,6 @@ extern "C" int mr3d_conv3d_wgrad(const mr3d_conv3d_wgrad_desc *d, mr3d_stream_t 
   const int k = d->kd, s = d->sd * 100 + d->sh * 10 + d->sw;
   // 3x3x3, Cout % 64 == 0: the 32-wide Cout tile (two workgroups per CU, twice the workgroups) wins on maps with few
   // tiles (P3: 100 vs 79 TFLOP/s, layer4: 31 vs 25), the 64-wide one on the big maps (P2: 111 vs 106)
-  static const int nb3_env = getenv("MR3D_WGRAD_NB3") ? atoi(getenv("MR3D_WGRAD_NB3")) : 0;   // tuning knob
   if (k == 1 && s == 111) {
     if (a.pd == 0 && a.ph == 0 && a.pw == 0) {
       const int st = mr3d_pointwise_wgrad_try(a, stream);
@@ -477,13 +476,13 @@ extern "C" int mr3d_conv3d_wgrad(const mr3d_conv3d_wgrad_desc *d, mr3d_stream_t 
           case 64: return launch_wgrad<WgCfg<3, 3, 3, 1, 1, 1, 16, 64, false, 5, 7, 7>>(a, stream);
         }
       }
-      const int nb3 = nb3_env ? nb3_env : (a.N * t488 < 2048 ? 32 : 64);
+      const int nb3 = a.N * t488 < 2048 ? 32 : 64;
       // Winograd forms (a caller that lends a workspace wants the bit-reproducible two-stage reduction: direct form)
-      static const int wino_env = getenv("MR3D_WGRAD_WINO") ? atoi(getenv("MR3D_WGRAD_WINO")) : 4;    // 0: direct form only; 1/2/3: F(3,2) along W on 64- / +32- / +16-wide tiles; 4: + the two-dimensional form
+      constexpr int wino_env = 4;    // 0: direct form only; 1/2/3: F(3,2) along W on 64- / +32- / +16-wide tiles; 4: + the two-dimensional form
       const int wino = a.part ? 0 : wino_env;
       // 4: the two-dimensional form (conv3d_wgrad_wino2d.hip) on maps with >= min2d tiles of 2x8x8: P2 64->64 1096 -> 857 us
       // standalone, backbone step 11.68 -> 11.48 ms, configs[2] step 19.7 -> 19.3 ms
-      static const int min2d = getenv("MR3D_WGRAD_WINO2D_MIN") ? atoi(getenv("MR3D_WGRAD_WINO2D_MIN")) : 256;
+      constexpr int min2d = 256;
       if (wino >= 4 && nb == 64 && (long long)a.N * ((a.Do + 1) / 2) * ((a.Ho + 7) / 8) * ((a.Wo + 7) / 8) >= min2d &&
           mr3d_conv3d_wgrad_wino2d_ok(a))
         return mr3d_conv3d_wgrad_wino2d(a, stream);

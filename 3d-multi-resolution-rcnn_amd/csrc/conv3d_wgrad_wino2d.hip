@@ -224,9 +224,8 @@ int mr3d_conv3d_wgrad_wino2d(const Conv3dWgradArgs &a, hipStream_t stream) {
   }
   const int tiles_d = (a.Do + TD - 1) / TD, tiles_h = (a.Ho + TH - 1) / TH, tiles_w = (a.Wo + TW - 1) / TW;
   const int ntiles = a.N * tiles_d * tiles_h * tiles_w;
-  static const int chunks_env = getenv("MR3D_WGRAD_WINO2D_CHUNKS") ? atoi(getenv("MR3D_WGRAD_WINO2D_CHUNKS")) : 0;
   const int types = (a.Cin / CC) * 3 * (a.Cout / 64);
-  int chunks = chunks_env > 0 ? chunks_env : (512 * 3) / types;   // ~3 rounds of 512 resident workgroups (128 at 64 -> 64: 888 us; 170: 953)
+  int chunks = (512 * 3) / types;   // ~3 rounds of 512 resident workgroups (128 at 64 -> 64: 888 us; 170: 953)
   if (chunks > ntiles) chunks = ntiles;
   if (chunks < 1) chunks = 1;
   dim3 grid((unsigned)chunks, (unsigned)(a.Cin / CC), (unsigned)(3 * (a.Cout / 64)));

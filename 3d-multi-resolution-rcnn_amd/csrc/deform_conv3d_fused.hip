@@ -852,7 +852,6 @@ extern "C" int mr3d_deform_conv3d_dgrad_fused(const mr3d_deform_conv3d_desc *d, 
   const size_t lds_tiled = ((size_t)2 * t.rz * t.ry * t.rx * kCs + kTm * 16 + 2 * kTm * kEntT) * 4;
   t.wnorm = w_packed + 3 * wn;
   bool tiled = dx && lds_tiled <= kTiledLdsMax;
-  if (const char *e = getenv("MR3D_DCN_DGRAD")) tiled = tiled && strcmp(e, "direct") != 0;
   if (allow_lds(dcn_dgrad_kernel<true>, kDgLds) != MR3D_OK || allow_lds(dcn_dgrad_kernel<false>, kDgLds) != MR3D_OK) return MR3D_ERR_LAUNCH;
   const unsigned tiles = 8u * (unsigned)((g.ntiles + 7) / 8);
   if (tiled) {

@@ -460,7 +460,7 @@ int launch_pw_fwd_impl(const Conv3dFwdArgs &a, hipStream_t stream) {
   const long long ntiles = (rows + C::ROWS - 1) / C::ROWS;
   // about 8 waves per CU (as many as the four-wave form had), fewer when LDS does not allow it
   constexpr int lds_wgs = (160 * 1024) / C::LDS_BYTES < 1 ? 1 : (160 * 1024) / C::LDS_BYTES;
-  static const int waves_per_cu = getenv("MR3D_PW_WAVES") ? atoi(getenv("MR3D_PW_WAVES")) : 8;   // tuning knob
+  constexpr int waves_per_cu = 8;   // tuning knob
   const int want_wgs = waves_per_cu / C::WPW < 1 ? 1 : waves_per_cu / C::WPW;
   const int wg_per_cu = lds_wgs < want_wgs ? lds_wgs : want_wgs;
   long long grid = (long long)num_cus() * wg_per_cu;

@@ -185,8 +185,7 @@ int launch_pw(const PwBfArgs &a, hipStream_t stream) {
 int mr3d_pointwise_bf16_try(const void *x, const void *w, void *y, const float *shift, const void *add1, const void *add2,
                             const void *up, const void *mask, long long rows, int cin, int cout, int cout_pad, int D, int H, int W,
                             int Du, int Hu, int Wu, int relu, hipStream_t stream) {
-  static const int off = getenv("MR3D_PW_BF16_STREAM") ? !atoi(getenv("MR3D_PW_BF16_STREAM")) : 0;      // A/B switch
-  if (off || rows < 32768) return MR3D_ERR_UNSUPPORTED;
+  if (rows < 32768) return MR3D_ERR_UNSUPPORTED;
   PwBfArgs a;
   a.x = (const bf16_t *)x; a.w = (const bf16_t *)w; a.y = (bf16_t *)y; a.shift = shift;
   a.add1 = (const bf16_t *)add1; a.add2 = (const bf16_t *)add2; a.up = (const bf16_t *)up; a.mask = (const bf16_t *)mask;

@@ -315,8 +315,6 @@ __device__ __forceinline__ T pick4(int i, const T (&a)[kMaxLevels]) {
 constexpr int kClThreads = 256;          // 4 waves
 constexpr int kClBins = 64;              // bins per workgroup (one LDS tile)
 constexpr int kAxisCap = 256;            // table entries per axis (P * sample_num)
-constexpr int kBoxCh = 16;               // LDS-box backward: channels per workgroup
-__host__ __device__ inline bool box_shape_ok(int PD, int PH, int PW) { return PD <= 32 && PH <= 32 && PW <= 32 && PH * PW <= 256; }
 
 // table entry: lo/hi are ELEMENT offsets along the axis (index * stride), valid folded into weights:
 // an out-of-range sample gets l = h = 0 and offsets 0, so it adds exactly 0 like the reference's `return 0`.
@@ -344,7 +342,7 @@ template <bool kBackward>
 __global__ __launch_bounds__(kClThreads) void roi_align3d_cl(const float *feat_or_top_src, float *out_or_bottom,
                                                             const float *__restrict__ rois, float scale, float scale_d,
                                                             int ns, int C, int D, int H, int W, int PD, int PH, int PW,
-                                                            int bug_compat, const int *__restrict__ owned, LevelTable lt) {
+                                                            int bug_compat, LevelTable lt) {
   __shared__ TabEntry tabx[kAxisCap], taby[kAxisCap], tabz[kAxisCap];
   __shared__ float tile[kClBins][MR3D_WAVE + 1];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -370,7 +368,6 @@ __global__ __launch_bounds__(kClThreads) void roi_align3d_cl(const float *feat_o
   __syncthreads();
   if (kBackward) {
     // RoIs the separable sub-box kernel owns (decided once per call by roi_box_plan_kernel)
-    if (owned && owned[r]) return;
   }
   const float count = (float)(ns * ns * ns);
   const long long base_n = (long long)g.b * D * sD;
@@ -467,7 +464,7 @@ __device__ __forceinline__ void build_idx_table(IdxEntry *tab, float start, floa
 }
 
 // ------------------------------------------------------------------------------------------
-// channels-last FORWARD, footprint staged in LDS (the bf16-feature path; opt-in for fp32, see staged_ok).  The
+// channels-last FORWARD, footprint staged in LDS (the generic bf16-feature path; fp32 features never take it: measured slower than the wave-per-bin kernel, 141 vs 87 us on the bbox case).  The
 // wave-per-bin kernel above re-reads every trilinear tap from L2 -- 64 x 256 B per output bin, ~22x the bytes the op has
 // to move (the distinct voxels under a RoI's sample footprint once + the output once).  Here a workgroup owns
 // (RoI, 16 channels): it finds the voxel box the RoI's
@@ -615,15 +612,6 @@ int launch_fwd_staged(const T *feat, float *out, const float *rois, int num_rois
   return mr3d_launch_status();
 }
 
-inline bool staged_ok(int C, int ns, int PD, int PH, int PW) {
-  // Measured on the SURVEY 8(d) bench shapes (MI355X): staging LOSES for fp32 features -- bbox 141 vs 87 us, mask 326 vs 230 us
-  // with the wave-per-bin kernel, whose 256-B tap reads are L2 hits at ~14 TB/s while the staged form pays 4x the
-  // workgroups (16-channel groups), 64-byte global segments and 4-address LDS reads.  It stays the bf16-feature path and an
-  // opt-in (MR3D_ROIALIGN_STAGED=1) for fp32.
-  static const int on = getenv("MR3D_ROIALIGN_STAGED") ? atoi(getenv("MR3D_ROIALIGN_STAGED")) : 0;
-  return on && C % kStCh == 0 && ns > 0 && PD * ns <= kStAxis && PH * ns <= kStAxis && PW * ns <= kStAxis;
-}
-
 // ------------------------------------------------------------------------------------------
 // channels-last FORWARD, separable.  The pooled value of bin (pd, ph, pw) is a sum over ns^3 samples of a trilinear tap sum:
 // 64 loads per output element in the reference (and in the wave-per-bin kernel above).  But weights factor per axis
@@ -706,28 +694,42 @@ __global__ __launch_bounds__(kClThreads) void roi_align3d_fwd_sep(const T *feat,
     int buf = 0;
     for (int z = zmin; z <= zmax; ++z, buf ^= 1) {
       float *T1 = body + buf * (S::T1CAP * kSepCh);
-      // ---- stage 1: x-contraction of plane z, rows y0 .. y0+ny-1.  Four items per thread and batch, all 16 tap loads issued
-      // before the first is used (one item at a time costs an L2 round trip per item).
-      for (int it0 = 0; it0 < ny * PW; it0 += 64) {
-        float v[4][4], w[4][4];
+      // ---- stage 1: x-contraction of plane z, rows y0 .. y0+ny-1.  A thread = (channel quad, one of 64 workers): its four
+      // taps are 16-byte loads (4 lanes cover the 64 bytes of a position's 16 channels; one channel per lane was 4x the
+      // load instructions and 7 dependent L2 round trips per plane for a 28-row footprint, now 2).  Four items per thread and
+      // batch, all 16 tap loads issued before the first is used.
+      {
+        const int q4 = tid & 3, w64 = tid >> 2;
+        const T *fq = feat + (base_n - ch) + q4 * 4;
+        for (int it0 = 0; it0 < ny * PW; it0 += 256) {
+          float4 v[4][4];
+          float w[4][4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int item = it0 + worker + 16 * u;
-          const bool ok = item < ny * PW;
-          const int yy = ok ? item / PW : 0, pw = ok ? item - yy * PW : 0;
-          const T *row = feat + base_n + z * sD + (y0 + yy) * sH;
+          for (int u = 0; u < 4; ++u) {
+            const int item = it0 + w64 + 64 * u;
+            const bool ok = item < ny * PW;
+            const int yy = ok ? item / PW : 0, pw = ok ? item - yy * PW : 0;
+            const T *row = fq + z * sD + (y0 + yy) * sH;
 #pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            const IdxEntry tx = tabx[pw * 2 + i];                   // an out-of-range sample has l = h = 0 and lo = hi = 0
-            w[u][2 * i] = tx.h; w[u][2 * i + 1] = tx.l;
-            v[u][2 * i] = ld_feat1(row + (long long)tx.lo * C);
-            v[u][2 * i + 1] = ld_feat1(row + (long long)tx.hi * C);
+            for (int i = 0; i < 2; ++i) {
+              const IdxEntry tx = tabx[pw * 2 + i];                   // an out-of-range sample has l = h = 0 and lo = hi = 0
+              w[u][2 * i] = tx.h; w[u][2 * i + 1] = tx.l;
+              v[u][2 * i] = ld_feat4(row + (long long)tx.lo * C);
+              v[u][2 * i + 1] = ld_feat4(row + (long long)tx.hi * C);
+            }
           }
-        }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int item = it0 + worker + 16 * u;
-          if (item < ny * PW) T1[item * kSepCh + ch] = (w[u][0] * v[u][0] + w[u][1] * v[u][1]) + (w[u][2] * v[u][2] + w[u][3] * v[u][3]);
+          for (int u = 0; u < 4; ++u) {
+            const int item = it0 + w64 + 64 * u;
+            if (item < ny * PW) {
+              float4 o;
+              o.x = (w[u][0] * v[u][0].x + w[u][1] * v[u][1].x) + (w[u][2] * v[u][2].x + w[u][3] * v[u][3].x);
+              o.y = (w[u][0] * v[u][0].y + w[u][1] * v[u][1].y) + (w[u][2] * v[u][2].y + w[u][3] * v[u][3].y);
+              o.z = (w[u][0] * v[u][0].z + w[u][1] * v[u][1].z) + (w[u][2] * v[u][2].z + w[u][3] * v[u][3].z);
+              o.w = (w[u][0] * v[u][0].w + w[u][1] * v[u][1].w) + (w[u][2] * v[u][2].w + w[u][3] * v[u][3].w);
+              *reinterpret_cast<float4 *>(T1 + item * kSepCh + q4 * 4) = o;
+            }
+          }
         }
       }
       __syncthreads();
@@ -829,16 +831,14 @@ int launch_fwd_sep(const T *feat, float *out, const float *rois, int num_rois, f
 template <typename T>
 int try_fwd_sep(const T *feat, float *out, const float *rois, int num_rois, float scale, float scale_d, int ns, int C, int D, int H,
                 int W, int PD, int PH, int PW, const LevelTable &lt, hipStream_t stream) {
-  static const int off = getenv("MR3D_ROIALIGN_SEPARABLE") ? !atoi(getenv("MR3D_ROIALIGN_SEPARABLE")) : 0;     // A/B switch
-  if (off || C % kSepCh != 0 || ns != 2 || PD * ns > kStAxis || PH * ns > kStAxis || PW * ns > kStAxis || PW > 14) return MR3D_ERR_UNSUPPORTED;
+  if (C % kSepCh != 0 || ns != 2 || PD * ns > kStAxis || PH * ns > kStAxis || PW * ns > kStAxis || PW > 14) return MR3D_ERR_UNSUPPORTED;
   const int phw = PH * PW;
   // Measured on the SURVEY 8(d) bench inputs: the separable form wins where many bins share the planes of a RoI -- the mask
   // extractor (10,14,14): 137 vs 232 us -- and only ties on the bbox extractor (3,7,7): 88 vs 88 us (3 pooled depths over up
   // to 20 planes: as many stage-1 taps as the direct form has in total; a variant that walks only the touched planes / rows in
   // groups was slower still, 110 us).  bf16 features take it for both shapes (there is no bf16 wave-per-bin kernel).
-  static const int sep_bbox = getenv("MR3D_ROIALIGN_SEPARABLE_BBOX") ? atoi(getenv("MR3D_ROIALIGN_SEPARABLE_BBOX")) : 0;
   if (phw <= 64 && PD <= 4) {     // bbox extractor (3,7,7): every pooled depth in one workgroup
-    if (!sep_bbox && sizeof(T) == 4) return MR3D_ERR_UNSUPPORTED;
+    if (sizeof(T) == 4) return MR3D_ERR_UNSUPPORTED;          // fp32 features: the box-in-LDS kernel (try_fwd_box) is faster there
     return launch_fwd_sep<T, SepCfg<4, 4, 224>>(feat, out, rois, num_rois, scale, scale_d, ns, C, D, H, W, PD, PH, PW, lt, stream);
   }
   if (phw <= 208)                 // mask extractor (10,14,14): chunks of 5 pooled depths
@@ -1109,195 +1109,12 @@ int launch_fwd_box(const T *feat, float *out, const float *rois, int num_rois, f
 template <typename T>
 int try_fwd_box(const T *feat, float *out, const float *rois, int num_rois, float scale, float scale_d, int ns, int C, int D,
                 int H, int W, int PD, int PH, int PW, const LevelTable &lt, hipStream_t stream) {
-  static const int mode = getenv("MR3D_ROIALIGN_BOX") ? atoi(getenv("MR3D_ROIALIGN_BOX")) : 1;
-  static const int lds_env = getenv("MR3D_ROIALIGN_BOX_LDS") ? atoi(getenv("MR3D_ROIALIGN_BOX_LDS")) : 0;
-  static const int pdc_env = getenv("MR3D_ROIALIGN_BOX_PDC") ? atoi(getenv("MR3D_ROIALIGN_BOX_PDC")) : 0;
-  if (mode <= 0 || (mode == 1 && PD > 4)) return MR3D_ERR_UNSUPPORTED;
+  if (PD > 4) return MR3D_ERR_UNSUPPORTED;          // many pooled depths (mask extractor): the separable kernel wins (157 vs 138 us)
   if (C % 64 != 0 || ns <= 0 || PD * ns > kStAxis || PH * ns > kStAxis || PW * ns > kStAxis) return MR3D_ERR_UNSUPPORTED;
-  const int budget = lds_env > 0 ? lds_env : 80 * 1024;               // two workgroups per CU
-  const int pdc = pdc_env > 0 ? pdc_env : (PD <= 4 ? PD : 2);
+  const int budget = 80 * 1024;               // two workgroups per CU
+  const int pdc = PD;
   if (ns == 2) return launch_fwd_box<T, 2, 64>(feat, out, rois, num_rois, scale, scale_d, ns, C, D, H, W, PD, PH, PW, pdc, budget, lt, stream);
   return launch_fwd_box<T, 0, 64>(feat, out, rois, num_rois, scale, scale_d, ns, C, D, H, W, PD, PH, PW, pdc, budget, lt, stream);
-}
-
-// ------------------------------------------------------------------------------------------
-// channels-last backward, separable owner-computes variant.  The global-atomic kernel above issues 64 fp32 atomics
-// per output element and runs at the chip's atomic rate (measured 0.9-1.0 TB/s of added bytes: 3-5 ms for the mask
-// extractor).  But the scatter of one RoI is separable: with Wx[x][pw] = sum over the ns samples of bin pw of their
-// weight on voxel x (h if lo == x, l if hi == x), and Wy, Wz alike,
-//     dX[z][y][x] = 1/count * sum_pd Wz[z][pd] * sum_ph Wy[y][ph] * sum_pw Wx[x][pw] * G[pd][ph][pw]
-// i.e. three tiny dense 1-D contractions per channel.  The RoI's voxel footprint is cut into 8x8x8 sub-boxes; a
-// workgroup evaluates one (sub-box, 16 channels) item owner-computes -- the [8][8][8][16] result lives in REGISTERS
-// (each thread owns its (y, x, channel) entries for every z), the intermediates in ~50 KB of LDS -- and issues ONE
-// global atomic per touched voxel-channel.  A plan kernel lists the (RoI, sub-box) items of the call (RoIs with more
-// than kMaxSub sub-boxes, or unsupported pooled shapes, stay with the global-atomic kernel, which reads the same
-// per-RoI flag); persistent workgroups walk the list.  No LDS atomics: an earlier ds_add_f32 box was slower than
-// the global atomics it replaced.
-// ------------------------------------------------------------------------------------------
-
-constexpr int kBoxP = 32;         // max pooled size per axis handled by the box kernel (PH*PW <= 256 as well)
-constexpr int kSubV = 8;          // voxels per axis of one sub-box
-constexpr int kMaxSub = 64;       // sub-boxes per RoI the box kernel accepts
-
-// [lo, lo+n) of the voxels any valid sample of this axis touches (n = 0 if none), straight from the geometry
-__device__ __forceinline__ void axis_extent_geom(float start, float bin, int P, int ns, int dim, int &lo, int &n) {
-  int mn = 0x7fffffff, mx = -1;
-  for (int e = 0; e < P * ns; ++e) {
-    const int p = e / ns, i = e - p * ns;
-    AxisTap t;
-    if (axis_tap(sample_coord(start, p, bin, i, ns), dim, t)) { mn = min(mn, t.lo); mx = max(mx, t.hi); }
-  }
-  lo = mx < 0 ? 0 : mn;
-  n = mx < 0 ? 0 : mx - mn + 1;
-}
-
-// one thread per RoI: owned[r] + the list of its non-empty sub-boxes: item = r * kMaxSub + (sz*ny + sy)*nx + sx
-__global__ __launch_bounds__(256) void roi_box_plan_kernel(const float *__restrict__ rois, int num_rois, float scale,
-                                                           float scale_d, int ns, int D, int H, int W, int PD, int PH, int PW,
-                                                           int *__restrict__ counter, int *__restrict__ owned,
-                                                           int *__restrict__ items, LevelTable lt) {
-  const int r = blockIdx.x * 256 + threadIdx.x;
-  if (r >= num_rois) return;
-  if (lt.num) {
-    const int lvl = roi_level(rois + (size_t)r * 7, lt.finest_scale, lt.num);
-    D = pick4(lvl, lt.D); H = pick4(lvl, lt.H); W = pick4(lvl, lt.W);
-    scale = pick4(lvl, lt.scale); scale_d = pick4(lvl, lt.scale_d);
-  }
-  const RoiGeom g = roi_geom(rois + (size_t)r * 7, scale, scale_d, ns, PD, PH, PW);
-  int x0, xn, y0, yn, z0, zn;
-  axis_extent_geom(g.sw, g.bw, PW, ns, W, x0, xn);
-  axis_extent_geom(g.sh, g.bh, PH, ns, H, y0, yn);
-  axis_extent_geom(g.sd, g.bd, PD, ns, D, z0, zn);
-  const int nx = (xn + kSubV - 1) / kSubV, ny = (yn + kSubV - 1) / kSubV, nz = (zn + kSubV - 1) / kSubV;
-  const int nsub = nx * ny * nz;
-  const int own = nsub <= kMaxSub;          // nsub == 0: nothing to scatter at all, owned and done
-  owned[r] = own;
-  if (!own || nsub == 0) return;
-  const int base = atomicAdd(counter, nsub);
-  for (int k = 0; k < nsub; ++k) items[base + k] = r * kMaxSub + k;
-}
-
-__global__ __launch_bounds__(kClThreads) void roi_align3d_bwd_box(const float *__restrict__ top, float *bottom,
-                                                                 const float *__restrict__ rois, float scale, float scale_d,
-                                                                 int ns, int C, int D, int H, int W, int PD, int PH, int PW,
-                                                                 int bug_compat, const int *__restrict__ counter,
-                                                                 const int *__restrict__ items, LevelTable lt) {
-  __shared__ IdxEntry tx[kAxisCap], ty[kAxisCap], tz[kAxisCap];
-  __shared__ float Wx[kSubV][kBoxP], Wy[kSubV][kBoxP], Wz[kSubV][kBoxP];
-  __shared__ float Gp[256][kBoxCh];                                   // one pd plane of top_grad: [ph*PW + pw][ch]
-  __shared__ float T1[kBoxP * kSubV][kBoxCh];                         // [ph][x][ch]
-  __shared__ float T2[kSubV * kSubV][kBoxCh];                         // [y][x][ch]
-  __shared__ int ext[6];
-  const int tid = threadIdx.x;
-  const int c0 = blockIdx.y * kBoxCh;
-  const int B = PD * PH * PW;
-  const int count_items = *counter;
-  constexpr int kOwn = kSubV * kSubV * kBoxCh / kClThreads;            // (y, x, ch) entries per thread: 4
-  const float inv_count = 1.f / (float)(ns * ns * ns);
-
-  for (int it = blockIdx.x; it < count_items; it += gridDim.x) {
-    const int item = items[it];
-    const int r = item / kMaxSub, sub = item % kMaxSub;
-    if (lt.num) {
-      const int lvl = roi_level(rois + (size_t)r * 7, lt.finest_scale, lt.num);
-      D = pick4(lvl, lt.D); H = pick4(lvl, lt.H); W = pick4(lvl, lt.W);
-      scale = pick4(lvl, lt.scale); scale_d = pick4(lvl, lt.scale_d);
-      bottom = pick4(lvl, lt.grad);
-    }
-    const RoiGeom g = roi_geom(rois + (size_t)r * 7, scale, scale_d, ns, PD, PH, PW);
-    __syncthreads();                          // previous item fully flushed before the tables are rebuilt
-    build_idx_table(tx, g.sw, g.bw, PW, ns, W, tid, kClThreads);
-    build_idx_table(ty, g.sh, g.bh, PH, ns, H, tid, kClThreads);
-    build_idx_table(tz, g.sd, g.bd, PD, ns, D, tid, kClThreads);
-    if (tid < 3) {
-      const float st = tid == 0 ? g.sw : (tid == 1 ? g.sh : g.sd), bn = tid == 0 ? g.bw : (tid == 1 ? g.bh : g.bd);
-      const int P = tid == 0 ? PW : (tid == 1 ? PH : PD), dim = tid == 0 ? W : (tid == 1 ? H : D);
-      axis_extent_geom(st, bn, P, ns, dim, ext[2 * tid], ext[2 * tid + 1]);
-    }
-    __syncthreads();
-    const int nx = (ext[1] + kSubV - 1) / kSubV, ny = (ext[3] + kSubV - 1) / kSubV;
-    const int sx = sub % nx, sy = (sub / nx) % ny, sz = sub / (nx * ny);
-    const int x0 = ext[0] + sx * kSubV, y0 = ext[2] + sy * kSubV, z0 = ext[4] + sz * kSubV;
-    const int xn = min(kSubV, ext[0] + ext[1] - x0), yn = min(kSubV, ext[2] + ext[3] - y0), zn = min(kSubV, ext[4] + ext[5] - z0);
-    // per-axis weight matrices of this sub-box
-    auto build_w = [&](float (*Wm)[kBoxP], const IdxEntry *tab, int P, int v0, int vn) {
-      for (int e = tid; e < vn * P; e += kClThreads) {
-        const int v = e / P, p = e % P;
-        float a = 0.f;
-        for (int i = 0; i < ns; ++i) {
-          const IdxEntry t = tab[p * ns + i];
-          if (t.l + t.h == 0.f) continue;
-          if (t.lo - v0 == v) a += t.h;
-          if (t.hi - v0 == v) a += t.l;
-        }
-        Wm[v][p] = a;
-      }
-    };
-    build_w(Wx, tx, PW, x0, xn);
-    build_w(Wy, ty, PH, y0, yn);
-    build_w(Wz, tz, PD, z0, zn);
-    float t3[kOwn][kSubV];
-#pragma unroll
-    for (int j = 0; j < kOwn; ++j)
-#pragma unroll
-      for (int z = 0; z < kSubV; ++z) t3[j][z] = 0.f;
-
-    for (int pd = 0; pd < PD; ++pd) {
-      __syncthreads();
-      // skip planes that do not reach this sub-box in z (Wz column all zero): wave-uniform test on LDS
-      bool any = false;
-      for (int z = 0; z < zn; ++z) any = any || Wz[z][pd] != 0.f;
-      if (!any) continue;
-      // Gp[ph*PW+pw][ch] = top_grad[r, c0+ch, (bug-compatible) index] / count
-      const int plane0 = bug_compat ? pd * PD * PW : pd * PH * PW;
-      for (int e = tid; e < PH * PW * kBoxCh; e += kClThreads) {
-        const int cc = e / (PH * PW), q = e % (PH * PW);
-        Gp[q][cc] = (c0 + cc < C) ? top[((size_t)r * C + c0 + cc) * B + plane0 + q] * inv_count : 0.f;
-      }
-      __syncthreads();
-      // T1[ph][x][ch] = sum_pw Wx[x][pw] * Gp[ph][pw][ch]
-      for (int e = tid; e < PH * xn * kBoxCh; e += kClThreads) {
-        const int ch = e % kBoxCh, x = (e / kBoxCh) % xn, ph = e / (kBoxCh * xn);
-        float a = 0.f;
-        for (int pw = 0; pw < PW; ++pw) a += Wx[x][pw] * Gp[ph * PW + pw][ch];
-        T1[ph * xn + x][ch] = a;
-      }
-      __syncthreads();
-      // T2[y][x][ch] = sum_ph Wy[y][ph] * T1[ph][x][ch]
-      for (int e = tid; e < yn * xn * kBoxCh; e += kClThreads) {
-        const int ch = e % kBoxCh, x = (e / kBoxCh) % xn, y = e / (kBoxCh * xn);
-        float a = 0.f;
-        for (int ph = 0; ph < PH; ++ph) a += Wy[y][ph] * T1[ph * xn + x][ch];
-        T2[y * xn + x][ch] = a;
-      }
-      __syncthreads();
-      // t3[(y,x,ch) owned by this thread][z] += Wz[z][pd] * T2[y][x][ch]
-#pragma unroll
-      for (int j = 0; j < kOwn; ++j) {
-        const int e = tid + j * kClThreads;
-        if (e < yn * xn * kBoxCh) {
-          const float t2 = (&T2[0][0])[e];
-#pragma unroll
-          for (int z = 0; z < kSubV; ++z)
-            if (z < zn) t3[j][z] += Wz[z][pd] * t2;
-        }
-      }
-    }
-    // flush: 16 consecutive channels of one voxel per 16 lanes, one global atomic per touched voxel-channel
-#pragma unroll
-    for (int j = 0; j < kOwn; ++j) {
-      const int e = tid + j * kClThreads;
-      if (e < yn * xn * kBoxCh) {
-        const int cc = e % kBoxCh, x = (e / kBoxCh) % xn, y = e / (kBoxCh * xn);
-        if (c0 + cc < C) {
-#pragma unroll
-          for (int z = 0; z < kSubV; ++z)
-            if (z < zn && t3[j][z] != 0.f)
-              atomicAdd(bottom + ((((size_t)g.b * D + z0 + z) * H + y0 + y) * W + x0 + x) * C + c0 + cc, t3[j][z]);
-        }
-      }
-    }
-  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1463,10 +1280,8 @@ __global__ __launch_bounds__(kClThreads) void roi_align3d_bwd_vox(const float *_
 // the voxel-owner backward for a pooled shape: MR3D_ERR_UNSUPPORTED = not applicable (the caller takes the plan + sub-box path)
 int try_bwd_vox(const float *top, float *bottom, const float *rois, int num_rois, float scale, float scale_d, int ns, int C, int D,
                 int H, int W, int PD, int PH, int PW, int bug, const LevelTable &lt, hipStream_t stream) {
-  static const int off = getenv("MR3D_ROIALIGN_BWD_VOX") ? !atoi(getenv("MR3D_ROIALIGN_BWD_VOX")) : 0;
-  static const int lds_env = getenv("MR3D_ROIALIGN_BWD_VOX_LDS") ? atoi(getenv("MR3D_ROIALIGN_BWD_VOX_LDS")) : 0;
-  if (off || C % 64 != 0 || ns <= 0 || PD * ns > kStAxis || PH * ns > kStAxis || PW * ns > kStAxis) return MR3D_ERR_UNSUPPORTED;
-  const int budget = lds_env > 0 ? lds_env : 80 * 1024;               // two workgroups per CU
+  if (C % 64 != 0 || ns <= 0 || PD * ns > kStAxis || PH * ns > kStAxis || PW * ns > kStAxis) return MR3D_ERR_UNSUPPORTED;
+  const int budget = 80 * 1024;               // two workgroups per CU
   int pdc = PD;
   while (pdc > 1 && vox_lds_bytes(pdc, PH, PW) > budget) --pdc;
   const int lds = vox_lds_bytes(pdc, PH, PW);
@@ -1483,35 +1298,11 @@ int try_bwd_vox(const float *top, float *bottom, const float *rois, int num_rois
       attr_bytes = lds;
     }
   }
-  static const int parts_env = getenv("MR3D_ROIALIGN_BWD_VOX_PARTS") ? atoi(getenv("MR3D_ROIALIGN_BWD_VOX_PARTS")) : 0;
   const int chunks = (PD + pdc - 1) / pdc;
-  const int parts = parts_env > 0 ? parts_env : (chunks == 1 ? 3 : 1);   // bbox extractor: 105 (1 part) -> 84 -> 76 us; mask extractor (10 chunks): 1
+  const int parts = chunks == 1 ? 3 : 1;   // bbox extractor: 105 (1 part) -> 84 -> 76 us; mask extractor (10 chunks): 1
   dim3 grid(num_rois, C / 64, chunks * parts);
   roi_align3d_bwd_vox<<<grid, kClThreads, lds, stream>>>(top, bottom, rois, scale, scale_d, ns, C, D, H, W, PD, PH, PW, pdc, parts, bug, lt);
   return mr3d_launch_status();
-}
-
-// persistent scratch of the backward plan: [0] item counter, [1 .. 1+R) owned flags, then R*kMaxSub items
-// plan scratch of the separable backward: one buffer per (device, stream) -- calls on the same stream are ordered, so
-// they may share it; another stream or another GPU gets its own (a process-global buffer raced there).  Growing a buffer
-// frees the old one with hipFree, which waits for the device: rare (capacity doubles).
-struct BoxScratch { int *p = nullptr; size_t ints = 0; };
-std::mutex g_box_mu;
-std::map<std::pair<int, hipStream_t>, BoxScratch> g_box_scratch;
-int *box_scratch(int num_rois, hipStream_t stream) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  std::lock_guard<std::mutex> lock(g_box_mu);
-  BoxScratch &b = g_box_scratch[{dev, stream}];
-  const size_t need = 1 + (size_t)num_rois * (1 + kMaxSub);
-  if (need > b.ints) {
-    if (b.p) (void)hipFree(b.p);
-    b.p = nullptr;
-    const size_t cap = need < 65536 ? 65536 : need * 2;
-    if (hipMalloc(reinterpret_cast<void **>(&b.p), cap * sizeof(int)) != hipSuccess) { b.ints = 0; return nullptr; }
-    b.ints = cap;
-  }
-  return b.p;
 }
 
 int check_common(const void *a, const void *b, const void *c, int num_rois, int batch, int C, int D, int H, int W, int PD,
@@ -1559,15 +1350,11 @@ extern "C" int mr3d_roi_align3d_forward(const float *features, const float *rois
                                        height, width, pooled_depth, pooled_height, pooled_width, LevelTable{}, stream);
     if (st2 != MR3D_ERR_UNSUPPORTED) return st2;
   }
-  if (use_cl(layout, sample_num, pooled_depth, pooled_height, pooled_width) &&
-      staged_ok(channels, sample_num, pooled_depth, pooled_height, pooled_width))
-    return launch_fwd_staged<float>(features, output, rois, num_rois, spatial_scale, spatial_scale_depth, sample_num, channels, depth,
-                                    height, width, pooled_depth, pooled_height, pooled_width, LevelTable{}, stream);
   if (use_cl(layout, sample_num, pooled_depth, pooled_height, pooled_width)) {
     dim3 grid(num_rois, (B + kClBins - 1) / kClBins);
     roi_align3d_cl<false><<<grid, kClThreads, 0, stream>>>(features, output, rois, spatial_scale, spatial_scale_depth,
                                                           sample_num, channels, depth, height, width, pooled_depth,
-                                                          pooled_height, pooled_width, 0, nullptr, LevelTable{});
+                                                          pooled_height, pooled_width, 0, LevelTable{});
   } else {
     const long long total = (long long)num_rois * channels * B;
     const long long blocks = (total + 255) / 256;
@@ -1596,24 +1383,10 @@ extern "C" int mr3d_roi_align3d_backward(const float *top_grad, const float *roi
                                 height, width, pooled_depth, pooled_height, pooled_width, bug, LevelTable{}, stream);
     if (stv != MR3D_ERR_UNSUPPORTED) return stv;
     dim3 grid(num_rois, (B + kClBins - 1) / kClBins);
-    int *scratch = box_shape_ok(pooled_depth, pooled_height, pooled_width) ? box_scratch(num_rois, stream) : nullptr;
-    int *owned = nullptr;
-    if (scratch) {
-      // plan: which RoIs (and which 8x8x8 sub-boxes of their footprints) the separable kernel takes
-      owned = scratch + 1;
-      if (hipMemsetAsync(scratch, 0, sizeof(int), stream) != hipSuccess) return MR3D_ERR_LAUNCH;
-      roi_box_plan_kernel<<<(num_rois + 255) / 256, 256, 0, stream>>>(rois, num_rois, spatial_scale, spatial_scale_depth,
-                                                                      sample_num, depth, height, width, pooled_depth,
-                                                                      pooled_height, pooled_width, scratch, owned,
-                                                                      scratch + 1 + num_rois, LevelTable{});
-    }
+    // other channel counts: the wave-per-bin kernel scatters with 256-byte-contiguous fp32 atomics
     roi_align3d_cl<true><<<grid, kClThreads, 0, stream>>>(top_grad, bottom_grad, rois, spatial_scale,
                                                          spatial_scale_depth, sample_num, channels, depth, height, width,
-                                                         pooled_depth, pooled_height, pooled_width, bug, owned, LevelTable{});
-    if (scratch)
-      roi_align3d_bwd_box<<<dim3(1024, (channels + kBoxCh - 1) / kBoxCh), kClThreads, 0, stream>>>(
-        top_grad, bottom_grad, rois, spatial_scale, spatial_scale_depth, sample_num, channels, depth, height, width,
-        pooled_depth, pooled_height, pooled_width, bug, scratch, scratch + 1 + num_rois, LevelTable{});
+                                                         pooled_depth, pooled_height, pooled_width, bug, LevelTable{});
   } else {
     const long long total = (long long)num_rois * channels * B;
     const long long blocks = (total + 255) / 256;
@@ -1722,13 +1495,10 @@ extern "C" int mr3d_roi_align3d_forward_ml(const mr3d_roi_level *levels_host, in
                                        pooled_height, pooled_width, lt, mr3d_stream(stream_));
     if (st2 != MR3D_ERR_UNSUPPORTED) return st2;
   }
-  if (staged_ok(channels, sample_num, pooled_depth, pooled_height, pooled_width))
-    return launch_fwd_staged<float>(nullptr, output, rois, num_rois, 0.f, 0.f, sample_num, channels, 1, 1, 1, pooled_depth,
-                                    pooled_height, pooled_width, lt, mr3d_stream(stream_));
   const int B = pooled_depth * pooled_height * pooled_width;
   dim3 grid(num_rois, (B + kClBins - 1) / kClBins);
   roi_align3d_cl<false><<<grid, kClThreads, 0, mr3d_stream(stream_)>>>(nullptr, output, rois, 0.f, 0.f, sample_num, channels, 1, 1, 1,
-                                                                      pooled_depth, pooled_height, pooled_width, 0, nullptr, lt);
+                                                                      pooled_depth, pooled_height, pooled_width, 0, lt);
   return mr3d_launch_status();
 }
 
@@ -1751,22 +1521,9 @@ extern "C" int mr3d_roi_align3d_backward_ml(const mr3d_roi_level *levels_host, i
                                 pooled_width, bug, lt, stream);
     if (stv != MR3D_ERR_UNSUPPORTED) return stv;
   }
-  int *scratch = box_shape_ok(pooled_depth, pooled_height, pooled_width) ? box_scratch(num_rois, stream) : nullptr;
-  int *owned = nullptr;
-  if (scratch) {
-    owned = scratch + 1;
-    if (hipMemsetAsync(scratch, 0, sizeof(int), stream) != hipSuccess) return MR3D_ERR_LAUNCH;
-    roi_box_plan_kernel<<<(num_rois + 255) / 256, 256, 0, stream>>>(rois, num_rois, 0.f, 0.f, sample_num, 1, 1, 1, pooled_depth,
-                                                                    pooled_height, pooled_width, scratch, owned,
-                                                                    scratch + 1 + num_rois, lt);
-  }
   dim3 grid(num_rois, (B + kClBins - 1) / kClBins);
   roi_align3d_cl<true><<<grid, kClThreads, 0, stream>>>(top_grad, nullptr, rois, 0.f, 0.f, sample_num, channels, 1, 1, 1,
-                                                       pooled_depth, pooled_height, pooled_width, bug, owned, lt);
-  if (scratch)
-    roi_align3d_bwd_box<<<dim3(1024, (channels + kBoxCh - 1) / kBoxCh), kClThreads, 0, stream>>>(
-      top_grad, nullptr, rois, 0.f, 0.f, sample_num, channels, 1, 1, 1, pooled_depth, pooled_height, pooled_width, bug, scratch,
-      scratch + 1 + num_rois, lt);
+                                                       pooled_depth, pooled_height, pooled_width, bug, lt);
   return mr3d_launch_status();
 }
 

@@ -108,97 +108,6 @@ __device__ __forceinline__ void stem_stage_channel(float *slab, const float *__r
   }
 }
 
-template <int TD, int TW>
-__global__ __launch_bounds__(TD * 64) void stem_fwd_kernel(StemFwdArgs p, int tiles_d, int tiles_h, int tiles_w) {
-  constexpr int TH = 8, WB = TW / 16;
-  using G = StemGeo<TD, TH, TW, (TW == 32 ? 72 : 40)>;
-  constexpr int SW_ROW = G::SW_ROW;
-  extern __shared__ __attribute__((aligned(16))) float slab[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // = output depth inside the tile
-  const int li = lane & 15, lk = lane >> 4;
-  const StemTile st = stem_tile_xcd(blockIdx.x, p.N * tiles_h * tiles_w, tiles_d, tiles_h, tiles_w);
-  if (!st.valid) return;
-  const int n = st.n;
-  const int d0 = st.td * TD, h0 = st.th * TH, w0 = st.tw * TW;
-
-  f32x4 acc[TH][WB];
-#pragma unroll
-  for (int th = 0; th < TH; ++th)
-    for (int wb = 0; wb < WB; ++wb) acc[th][wb] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // lane's 8-byte word inside a row: x = wb*16 + li, word index = x + lk  (floats 2x + 2lk, 2x + 2lk + 1)
-  const int lane_off = 2 * li + 2 * lk;
-  const size_t vox = (size_t)p.D * p.H * p.W;
-
-  for (int ci = 0; ci < 3; ++ci) {
-    __syncthreads();
-    stem_stage_channel<TD * 64, G>(slab, p.x + ((size_t)n * 3 + ci) * vox, p.D, p.H, p.W, d0, h0, w0, tid);
-    __syncthreads();
-    // B for (kd, kh): step s uses kw = 2*lk + s; element wf[((kd*7+kh)*7 + kw)*64 + ci*16 + co]
-    auto load_b = [&](int kd, int kh, float &b0, float &b1) {
-      const float *wrow = p.wf + (size_t)((kd * 7 + kh) * 7) * 64 + ci * 16 + li;
-      // slab column 2x + 2k + s is input column 2(w0+x) - 3 + (2k + s - 1): step s of MFMA k index k is tap kw = 2k+s-1
-      b0 = (lk > 0) ? wrow[(2 * lk - 1) * 64] : 0.f;
-      b1 = wrow[(2 * lk) * 64];
-    };
-    // software pipeline over the 49 (kd, kh) rows: the A words (LDS) and B values (L2) of row r+1 are
-    // requested before the 32 MFMAs of row r issue, so neither latency is ever exposed
-    auto load_a = [&](int kd, int kh, float2 (&a)[TH][WB]) {
-      const float *rowbase = slab + ((wave + kd) * G::PH + kh) * SW_ROW + lane_off;
-#pragma unroll
-      for (int th = 0; th < TH; ++th)
-#pragma unroll
-        for (int wb = 0; wb < WB; ++wb) a[th][wb] = *reinterpret_cast<const float2 *>(rowbase + (2 * th) * SW_ROW + wb * 32);
-    };
-    auto mfma_row = [&](const float2 (&a)[TH][WB], float b0, float b1) {
-#pragma unroll
-      for (int th = 0; th < TH; ++th)
-#pragma unroll
-        for (int wb = 0; wb < WB; ++wb) {
-          acc[th][wb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[th][wb].x, b0, acc[th][wb], 0, 0, 0);
-          acc[th][wb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[th][wb].y, b1, acc[th][wb], 0, 0, 0);
-        }
-    };
-    float2 a0[TH][WB], a1[TH][WB];
-    float b00, b01, b10 = 0.f, b11 = 0.f;
-    load_b(0, 0, b00, b01);
-    load_a(0, 0, a0);
-    // rows r = kd*7 + kh, processed two at a time (49 = 24 pairs + 1)
-    for (int r = 0; r < 48; r += 2) {
-      const int r1 = r + 1, r2 = r + 2;
-      load_b(r1 / 7, r1 % 7, b10, b11);
-      load_a(r1 / 7, r1 % 7, a1);
-      mfma_row(a0, b00, b01);
-      load_b(r2 / 7, r2 % 7, b00, b01);
-      load_a(r2 / 7, r2 % 7, a0);
-      mfma_row(a1, b10, b11);
-    }
-    mfma_row(a0, b00, b01);
-  }
-
-  // epilogue: + shift, ReLU, NDHWC store (lane: co = li, rows x = wb*16 + lk*4 + r)
-  const int od = d0 + wave;
-  if (od >= p.D) return;
-  const float sh = p.shift ? p.shift[li] : 0.f;
-#pragma unroll
-  for (int th = 0; th < TH; ++th) {
-    const int oh = h0 + th;
-    if (oh >= p.Ho) continue;
-#pragma unroll
-    for (int wb = 0; wb < WB; ++wb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ow = w0 + wb * 16 + lk * 4 + r;
-        if (ow < p.Wo) {
-          float v = acc[th][wb][r] + sh;
-          if (p.relu) v = fmaxf(v, 0.f);
-          stem_store(p, ((((size_t)n * p.D + od) * p.Ho + oh) * p.Wo + ow) * 16 + li, v);
-        }
-      }
-  }
-}
-
 // ------------------------------------------------------------------------------------------------ forward, Winograd along D
 // The stem has stride 1 along depth, so its seven depth taps split as 3 + 3 + 1 and each 3-tap group takes the
 // F(2,3) form over a PAIR of output depths (d, d+1):  with slab planes P_j = plane(d + j),
@@ -206,7 +115,9 @@ __global__ __launch_bounds__(TD * 64) void stem_fwd_kernel(StemFwdArgs p, int ti
 //   tap kd 6: P6*g6 belongs to y[d] only and P7*g6 to y[d+1] only, i.e. to M0 and (negated) M3 of
 //   y[d] = M0+M1+M2, y[d+1] = M1-M2-M3 -- no extra accumulators.
 // 10 MFMA groups per (kh, kw step) and depth pair instead of 14.  A wave owns a depth pair and four of the tile's
-// eight output rows; everything else (slab, kw split, B from L2) is as in stem_fwd_kernel.
+// eight output rows.  Operands: the planar input slab of one channel at a time in LDS (stem_stage_channel), the kw taps split
+// as kw = 2k + s - 1 so that a stride-2 output row reads two contiguous LDS words (ds_read_b64), B fragments from L2.
+// (The direct form this replaced -- one wave per output depth, 14 MFMA groups -- ran at 1.79 ms on the 512 volume.)
 template <int TW>
 __global__ __launch_bounds__(256, 3) void stem_fwd_wino_kernel(StemFwdArgs p, int tiles_d, int tiles_h, int tiles_w) {
   constexpr int TD = 4, TH = 8, THW = 4;                       // THW: output rows per wave
@@ -506,11 +417,9 @@ static int stem_forward_impl(const float *x_ncdhw, const float *w_packed, const 
   using G = StemGeo<TD, 8, TW, 40>;
   constexpr int lds_bytes = G::SLAB * 4;
   const int td = (d + TD - 1) / TD, th = (a.Ho + 7) / 8, tw = (a.Wo + TW - 1) / TW;
-  // Winograd-along-depth form by default (1.79 -> 1.43 ms on the 512 volume); MR3D_STEM_WINO=0: direct form
-  static const int wino = getenv("MR3D_STEM_WINO") ? atoi(getenv("MR3D_STEM_WINO")) : 1;
+  // Winograd along depth (1.79 -> 1.43 ms on the 512 volume)
   const unsigned grid = 8u * (unsigned)((n * th * tw + 7) / 8) * (unsigned)td;           // stem_tile_xcd
-  if (wino) stem_fwd_wino_kernel<TW><<<grid, 256, lds_bytes, mr3d_stream(stream_)>>>(a, td, th, tw);
-  else stem_fwd_kernel<TD, TW><<<grid, TD * 64, lds_bytes, mr3d_stream(stream_)>>>(a, td, th, tw);
+  stem_fwd_wino_kernel<TW><<<grid, 256, lds_bytes, mr3d_stream(stream_)>>>(a, td, th, tw);
   return mr3d_launch_status();
 }
 

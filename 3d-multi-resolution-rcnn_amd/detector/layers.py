@@ -12,12 +12,8 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 import ctypes
-import os
 
 from .. import _hip
-
-_LINEAR_IMPL = os.environ.get('MR3D_LINEAR', 'hip')
-
 
 def _ndhwc(x):
     """[N,C,D,H,W] (any strides) -> contiguous [N,D,H,W,C] (zero-copy when x is channels_last_3d)"""
@@ -212,13 +208,8 @@ class _LinearFn(Function):
 def linear(x, weight, bias=None, relu=False, impl=None):
     """y = x @ weight.T + bias for x [R, K] -- torch.nn.Linear of the reference's bbox heads
     (convfc_bbox_head_3d.py:104-140).  Default: the hand-written fp32 MFMA GEMM of csrc/linear.hip (forward / dgrad / wgrad,
-    split-K where the output has few tiles).  impl='blas' (or MR3D_LINEAR=blas): torch.addmm (hipBLASLt), kept for A/B
-    timing; impl='conv' (MR3D_LINEAR=conv): the pointwise-conv route of the first round."""
-    mode = impl or _LINEAR_IMPL
-    if mode == 'blas':
-        y = torch.addmm(bias, x, weight.t()) if bias is not None else x @ weight.t()
-        return torch.relu(y) if relu else y
-    if mode != 'conv':
+    split-K where the output has few tiles).  impl='conv': the same product through the pointwise-conv kernels (tested)."""
+    if impl != 'conv':
         return _LinearFn.apply(x, weight, bias, bool(relu))
     R, K = x.shape
     rp = _pad_to(max(R, 1), 64)

@@ -11,7 +11,6 @@ autograd: backward returns (grad_input, grad_offset, grad_weight[, grad_mask, gr
 (functions/deform_conv.py:88-89).  `groups > 1` is not built (the reference's 3D path never instantiates it)."""
 import ctypes
 import math
-import os
 
 import torch
 import torch.nn as nn
@@ -52,7 +51,7 @@ def _cl(t):
 
 def _fused_desc(xc_shape, k, stride, pad, dil, dg, co, has_mask, has_bias):
     """the descriptor of the fused (column-free) kernels if they take this shape (csrc/deform_conv3d_fused.hip), else None"""
-    if has_mask or has_bias or os.environ.get('MR3D_DCN_FUSED', '1') == '0':
+    if has_mask or has_bias:
         return None
     d = _desc(xc_shape, k, stride, pad, dil, dg, 0, 1)
     return d if _hip.lib().mr3d_deform_conv3d_fused_supported(ctypes.byref(d), int(co)) == 1 else None

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """RoIAlign3D forward through SingleRoIExtractor over P2..P5 on the SURVEY 8(d) inputs (bench.py's roi cases): time and
-fraction of the HBM roof of the LB bytes.  Kernel choice follows the MR3D_ROIALIGN_* environment (read once per process).
+fraction of the HBM roof of the LB bytes.  
 usage: python tools/roi_fwd_bench.py [--bf16]"""
 import argparse
 import importlib.util
