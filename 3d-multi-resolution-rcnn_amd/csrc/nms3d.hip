@@ -413,6 +413,13 @@ __global__ __launch_bounds__(kRegThreads) void nms3d_sweep_reg_kernel(const uint
       else rows[s_][q] = v;
     }
   }
+  int blk_lo[kRegSlots], blk_hi[kRegSlots];            // wave-uniform block range of each slot (an idle lane has meta = -1)
+#pragma unroll
+  for (int s_ = 0; s_ < kRegSlots; ++s_) {
+    const int first = __builtin_amdgcn_readfirstlane(meta[s_]), last = __builtin_amdgcn_readlane(meta[s_], 63);
+    blk_lo[s_] = first < 0 ? 0x7fffffff : (first >> 16);
+    blk_hi[s_] = first < 0 ? -1 : (last < 0 ? cb : (last >> 16));
+  }
   __syncthreads();
   for (int b = 0; b < cb; ++b) {
     if (wave == 0) {
@@ -432,9 +439,12 @@ __global__ __launch_bounds__(kRegThreads) void nms3d_sweep_reg_kernel(const uint
     }
     __syncthreads();
     const uint64_t kept = keptb[b];
+    // a wave's 64 items of one slot are consecutive ids, i.e. they belong to one block or two neighbouring ones: the test
+    // whether ANY of them is due is two scalar compares (16 waves evaluating four per-lane tests per block was the largest
+    // share of the loop)
 #pragma unroll
     for (int s_ = 0; s_ < kRegSlots; ++s_)
-      if ((meta[s_] >> 16) == b) {
+      if (b >= blk_lo[s_] && b <= blk_hi[s_] && (meta[s_] >> 16) == b) {
         const int w = (meta[s_] >> 8) & 255, g = meta[s_] & 255;
         const unsigned kb = (unsigned)(kept >> (g * kRowsPerItem)) & 255u;
         uint64_t acc = 0;

@@ -691,6 +691,26 @@ __global__ __launch_bounds__(kClThreads) void roi_align3d_fwd_sep(const T *feat,
 
   const bool separable = ns == 2 && ny * PW <= S::T1CAP && PHW <= 16 * S::J;
   if (separable) {
+    // everything about a thread's items that does not depend on the plane is worked out once: the kernel is issue-bound, and an
+    // integer division by the (runtime) PW per item and plane was a large share of its instructions
+    const int q4 = tid & 3, w64 = tid >> 2;
+    const int yy_w = w64 / PW, pw_w = w64 - yy_w * PW, q64 = 64 / PW, r64 = 64 - q64 * PW;
+    int t1lo[S::J][2], t1hi[S::J][2];                            // T1 element offsets of item j's two y-samples (-1: sample out of range)
+    float wyh[S::J][2], wyl[S::J][2];
+#pragma unroll
+    for (int j = 0; j < S::J; ++j) {
+      const int item = worker + 16 * j;
+      const int ph = item < PHW ? item / PW : 0, pw = item < PHW ? item - ph * PW : 0;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const IdxEntry ty = taby[ph * 2 + i];
+        const bool on = item < PHW && ty.l + ty.h != 0.f;
+        t1lo[j][i] = on ? ((ty.lo - y0) * PW + pw) * kSepCh + ch : 0;
+        t1hi[j][i] = on ? ((ty.hi - y0) * PW + pw) * kSepCh + ch : 0;
+        wyh[j][i] = on ? ty.h : 0.f;
+        wyl[j][i] = on ? ty.l : 0.f;
+      }
+    }
     int buf = 0;
     for (int z = zmin; z <= zmax; ++z, buf ^= 1) {
       float *T1 = body + buf * (S::T1CAP * kSepCh);
@@ -699,20 +719,23 @@ __global__ __launch_bounds__(kClThreads) void roi_align3d_fwd_sep(const T *feat,
       // load instructions and 7 dependent L2 round trips per plane for a 28-row footprint, now 2).  Four items per thread and
       // batch, all 16 tap loads issued before the first is used.
       {
-        const int q4 = tid & 3, w64 = tid >> 2;
         const T *fq = feat + (base_n - ch) + q4 * 4;
+        int yy_u = yy_w, pw_u = pw_w;                            // (row, bin) of item w64; + 64 per step without a division
         for (int it0 = 0; it0 < ny * PW; it0 += 256) {
           float4 v[4][4];
           float w[4][4];
+          int yy4[4], pw4[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const int item = it0 + w64 + 64 * u;
             const bool ok = item < ny * PW;
-            const int yy = ok ? item / PW : 0, pw = ok ? item - yy * PW : 0;
-            const T *row = fq + z * sD + (y0 + yy) * sH;
+            yy4[u] = ok ? yy_u : 0; pw4[u] = ok ? pw_u : 0;
+            pw_u += r64; yy_u += q64;
+            if (pw_u >= PW) { pw_u -= PW; ++yy_u; }
+            const T *row = fq + z * sD + (y0 + yy4[u]) * sH;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-              const IdxEntry tx = tabx[pw * 2 + i];                   // an out-of-range sample has l = h = 0 and lo = hi = 0
+              const IdxEntry tx = tabx[pw4[u] * 2 + i];               // an out-of-range sample has l = h = 0 and lo = hi = 0
               w[u][2 * i] = tx.h; w[u][2 * i + 1] = tx.l;
               v[u][2 * i] = ld_feat4(row + (long long)tx.lo * C);
               v[u][2 * i + 1] = ld_feat4(row + (long long)tx.hi * C);
@@ -747,18 +770,10 @@ __global__ __launch_bounds__(kClThreads) void roi_align3d_fwd_sep(const T *feat,
       }
 #pragma unroll
       for (int j = 0; j < S::J; ++j) {
-        const int item = worker + 16 * j;
-        if (item < PHW) {
-          const int ph = item / PW, pw = item - ph * PW;
-          float t2 = 0.f;
-          for (int i = 0; i < ns; ++i) {
-            const IdxEntry ty = taby[ph * ns + i];
-            if (ty.l + ty.h != 0.f)
-              t2 += ty.h * T1[((ty.lo - y0) * PW + pw) * kSepCh + ch] + ty.l * T1[((ty.hi - y0) * PW + pw) * kSepCh + ch];
-          }
+        // (a sample that is out of range, or an item beyond PHW, carries zero weights and reads T1 element 0)
+        const float t2 = (wyh[j][0] * T1[t1lo[j][0]] + wyl[j][0] * T1[t1hi[j][0]]) + (wyh[j][1] * T1[t1lo[j][1]] + wyl[j][1] * T1[t1hi[j][1]]);
 #pragma unroll
-          for (int a = 0; a < S::PDC; ++a) acc[a][j] += wz[a] * t2;
-        }
+        for (int a = 0; a < S::PDC; ++a) acc[a][j] += wz[a] * t2;
       }
       // the other T1 buffer is written next: one barrier per plane is enough (its readers passed the barrier above)
     }
