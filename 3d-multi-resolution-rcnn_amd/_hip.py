@@ -569,7 +569,7 @@ def conv3d_wgrad(x, dy, dw_packed, k, stride, pad, dbias=None, workspace=None):
 # plan records (mr3d_op / mr3d_layer_desc in include/mr3d.h)
 OP_CONV_FWD, OP_CONV_WGRAD, OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_ZERO_STUFF2, OP_UPSAMPLE_ADJ = 1, 2, 3, 4, 5, 6
 OP_SUBSAMPLE_FWD, OP_SUBSAMPLE_BWD, OP_VOLUME_PACK, OP_MEMSET0, OP_AXPY, OP_PREP_WEIGHTS, OP_FINISH_GRADS = 7, 8, 9, 10, 11, 12, 13
-OP_STEM_FWD, OP_STEM_WGRAD, OP_CONV_DGRAD_S2, OP_PREP_WEIGHTS_BF16, OP_STEM_PACK_BF16, OP_SYNC, OP_WINO2D_PREP = 14, 15, 16, 17, 18, 19, 20
+OP_STEM_FWD, OP_STEM_WGRAD, OP_CONV_DGRAD_S2, OP_PREP_WEIGHTS_BF16, OP_STEM_PACK_BF16, OP_SYNC, OP_WINO2D_PREP, OP_PW_PAIR = 14, 15, 16, 17, 18, 19, 20, 21
 SYNC_JOIN, SYNC_MARK, SYNC_WAIT = 0, 1, 2      # mr3d_op.i[0] of an OP_SYNC record
 DTYPE_BF16 = 1          # mr3d_op.i[25]: MR3D_DTYPE_BF16
 CONV_RELU, CONV_UP_EVEN = 1, 2      # mr3d_conv3d_desc.relu flags (i[18] of a CONV_FWD record)
@@ -598,6 +598,19 @@ def make_op(kind, ptrs=(), ints=(), alpha=0.0, side=False):
         o.i[k] = int(v)
     o.f[0] = float(alpha)
     return o
+
+
+def pw_pair_supported(c0, c1, c2, positions):
+    fn = lib().mr3d_pointwise_pair_supported
+    fn.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_longlong]
+    return fn(int(c0), int(c1), int(c2), int(positions)) == 1
+
+
+def make_pw_pair_op(x, w1, shift1, add1, mask1, y1, w2, shift2, mask2, y2, c0, c1, c2, relu1, relu2, positions):
+    """PW_PAIR plan record (mr3d_pointwise_pair): tensors or raw addresses; the shift pointers travel in the integer block"""
+    addr = lambda v: 0 if v is None else (v.data_ptr() if hasattr(v, 'data_ptr') else int(v))
+    ints = [c0, c1, c2, int(bool(relu1)), int(bool(relu2)), *split64(positions), *split64(addr(shift1)), *split64(addr(shift2))]
+    return make_op(OP_PW_PAIR, [x, w1, add1, mask1, y1, w2, mask2, y2], ints)
 
 
 def plan_stream_wait_mark(slot, stream):
@@ -811,6 +824,10 @@ def op_kernel_key(op):
         if i[25] == DTYPE_BF16:
             return f'{name}_bf16<k{k},s{sd}{sh}{sw},cin{cin},cout{cout}>', flops
         return f'{name}<k{k},s{sd}{sh}{sw},cc{cc},nb{nb}>', flops
+    if op.kind == OP_PW_PAIR:
+        c0, c1, c2 = i[0], i[1], i[2]
+        pos = (i[5] & 0xFFFFFFFF) | (i[6] << 32)
+        return f'pw_pair<{c0},{c1},{c2}>', 2.0 * pos * (c0 * c1 + c1 * c2)
     if op.kind == OP_CONV_DGRAD_S2:      # i[1:4] = dy's (coarse) grid; every dy element meets each of the 27 taps once
         n, d, h, w, cin, cout = i[0], i[1], i[2], i[3], i[4], i[5]
         nb = _narrow_nb(n, d, h, w, cout, 64 if cout % 64 == 0 else (32 if cout % 32 == 0 else 16))

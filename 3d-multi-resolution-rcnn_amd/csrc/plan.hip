@@ -42,6 +42,16 @@ int run_one(const mr3d_op &o, mr3d_stream_t s, bool shared_ws = true) {
       d.workspace = shared_ws ? (float *)p[4] : nullptr; d.workspace_bytes = d.workspace ? i64_of(i + 15) : 0;
       return bf16 ? mr3d_conv3d_wgrad_bf16(&d, s) : mr3d_conv3d_wgrad(&d, s);
     }
+    case MR3D_OP_PW_PAIR: {
+      mr3d_pw_pair_desc d;
+      d.x = (const float *)p[0]; d.w1 = (const float *)p[1]; d.add1 = (const float *)p[2]; d.mask1 = (const float *)p[3];
+      d.y1 = (float *)p[4]; d.w2 = (const float *)p[5]; d.mask2 = (const float *)p[6]; d.y2 = (float *)p[7];
+      d.c0 = i[0]; d.c1 = i[1]; d.c2 = i[2]; d.relu1 = i[3]; d.relu2 = i[4];
+      d.positions = i64_of(i + 5);
+      d.shift1 = (const float *)(uintptr_t)i64_of(i + 7);
+      d.shift2 = (const float *)(uintptr_t)i64_of(i + 9);
+      return mr3d_pointwise_pair(&d, s);
+    }
     case MR3D_OP_MAXPOOL_FWD:
       if (bf16) return mr3d_maxpool3d_forward_bf16(p[0], p[1], (uint32_t *)p[2], i[0], i[1], i[2], i[3], i[4], s);
       return mr3d_maxpool3d_forward((const float *)p[0], (float *)p[1], (uint32_t *)p[2], i[0], i[1], i[2], i[3], i[4], s);

@@ -1,0 +1,211 @@
+// Two chained pointwise (1x1x1, stride 1) convolutions in ONE launch, for the small feature maps of layer3 / layer4.
+//
+// Between two bottleneck blocks of a ResNet3D stage (mmdet/models/backbones/resnet3d.py:198-233) the forward pass runs
+//     out = relu(bn3(conv3(a2)) + identity)            C0 -> C1   (64 -> 256 / 128 -> 512)
+//     a1' = relu(bn1'(conv1'(out)))                    C1 -> C2   (256 -> 64 / 512 -> 128)
+// and the backward pass the mirror image (conv1'^T with the residual gradient added and the ReLU mask of `out`, then conv3^T
+// with the mask of a2).  Neither convolution needs a halo, so a workgroup that owns 32 positions can run both: the C1-wide
+// intermediate goes to global memory once (the next block's residual / the weight gradients need it) and stays in LDS for
+// the second product instead of being read back by another launch.  On the 10x32x32 / 5x16x16 maps these launches are
+// latency-bound (10-20 us for < 3 us of matrix work: global load -> LDS -> a short MFMA loop -> epilogue, with nothing to
+// overlap), and each one saved is a launch, a cold start and a round trip of the intermediate.
+//
+// Workgroup = 32 positions, 4 waves.
+//   stage 1  [32 x C0] x [C0 x C1]: v_mfma_f32_32x32x2_f32, A from the x tile in LDS (row stride C0 + 1), a wave owns
+//            C1 / 128 column tiles of 32; B fragments straight from L2 (rows of C1 are contiguous), a chunk of 8 k-steps ahead;
+//            epilogue: + shift, + residual, ReLU / mask -> y1 (global) and the y1 tile in LDS (row stride C1 + 4).
+//   stage 2  [32 x C1] x [C1 x C2]: v_mfma_f32_16x16x4_f32 (C2 / 64 column tiles of 16 per wave, both row tiles), A from the
+//            y1 tile, B from L2 a chunk ahead; epilogue: + shift, ReLU / mask -> y2.
+#include "mr3d_common.h"
+#include "conv3d.h"
+
+namespace {
+
+constexpr int kPairThreads = 256;
+
+struct PwPairArgs {
+  const float *x, *w1, *shift1, *add1, *mask1;
+  float *y1;
+  const float *w2, *shift2, *mask2;
+  float *y2;
+  long long P;
+  int relu1, relu2;
+};
+
+template <int C0_, int C1_, int C2_>
+struct PairCfg {
+  static constexpr int C0 = C0_, C1 = C1_, C2 = C2_;
+  static constexpr int MP = 32;
+  static constexpr int XS = C0 + 1, YS = C1 + 4;
+  static constexpr int T1 = C1 / 32 / 4;          // 32-wide stage-1 column tiles per wave
+  static constexpr int T2 = C2 / 16 / 4;          // 16-wide stage-2 column tiles per wave
+  static constexpr int KS1 = C0 / 2, KS2 = C1 / 4;
+  static constexpr int KC = 8;                    // k-steps per B-fragment chunk
+  static constexpr int LDS_BYTES = (MP * XS + MP * YS) * 4;
+  static_assert(C1 % 128 == 0 && C2 % 64 == 0 && C0 % 16 == 0 && KS1 % KC == 0 && KS2 % KC == 0, "shape");
+};
+
+template <class C>
+__global__ __launch_bounds__(kPairThreads) void pw_pair_kernel(PwPairArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *xs = lds, *ys = lds + C::MP * C::XS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long long p0 = (long long)blockIdx.x * C::MP;
+
+  // ---- x tile -> LDS
+  {
+    constexpr int Q = C::C0 / 4;
+    for (int e = tid; e < C::MP * Q; e += kPairThreads) {
+      const int row = e / Q, q = e - row * Q;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p0 + row < p.P) v = *reinterpret_cast<const float4 *>(p.x + (size_t)(p0 + row) * C::C0 + q * 4);
+      float *d = xs + row * C::XS + q * 4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+  }
+  // ---- stage 1
+  const int li = lane & 31, lk = lane >> 5;
+  const int n1 = wave * C::T1 * 32;                                  // this wave's first stage-1 column
+  f32x16 acc1[C::T1];
+#pragma unroll
+  for (int t = 0; t < C::T1; ++t)
+    for (int r = 0; r < 16; ++r) acc1[t][r] = 0.f;
+  const float *w1l = p.w1 + (size_t)lk * C::C1 + n1 + li;
+  float b0[C::KC][C::T1], b1[C::KC][C::T1];
+  auto load_b1 = [&](float (&b)[C::KC][C::T1], int k0) {
+#pragma unroll
+    for (int kk = 0; kk < C::KC; ++kk)
+#pragma unroll
+      for (int t = 0; t < C::T1; ++t) b[kk][t] = w1l[(size_t)(k0 + kk) * 2 * C::C1 + t * 32];
+  };
+  auto mma1 = [&](const float (&b)[C::KC][C::T1], int k0) {
+#pragma unroll
+    for (int kk = 0; kk < C::KC; ++kk) {
+      const float a = xs[li * C::XS + (k0 + kk) * 2 + lk];
+#pragma unroll
+      for (int t = 0; t < C::T1; ++t) acc1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[kk][t], acc1[t], 0, 0, 0);
+    }
+  };
+  load_b1(b0, 0);
+  __syncthreads();
+  for (int k0 = 0; k0 < C::KS1; k0 += 2 * C::KC) {
+    if (k0 + C::KC < C::KS1) load_b1(b1, k0 + C::KC);
+    mma1(b0, k0);
+    if (k0 + 2 * C::KC < C::KS1) load_b1(b0, k0 + 2 * C::KC);
+    if (k0 + C::KC < C::KS1) mma1(b1, k0 + C::KC);
+  }
+  // first B chunk of stage 2: in flight across the epilogue
+  const int li2 = lane & 15, lk2 = lane >> 4;
+  const int n2 = wave * C::T2 * 16;
+  const float *w2l = p.w2 + (size_t)lk2 * C::C2 + n2 + li2;
+  float c0[C::KC][C::T2], c1[C::KC][C::T2];
+  auto load_b2 = [&](float (&b)[C::KC][C::T2], int k0) {
+#pragma unroll
+    for (int kk = 0; kk < C::KC; ++kk)
+#pragma unroll
+      for (int t = 0; t < C::T2; ++t) b[kk][t] = w2l[(size_t)(k0 + kk) * 4 * C::C2 + t * 16];
+  };
+  load_b2(c0, 0);
+  // ---- epilogue 1: y1 = act(acc + shift + residual) -> global and LDS
+#pragma unroll
+  for (int t = 0; t < C::T1; ++t) {
+    const int col = n1 + t * 32 + li;
+    const float sh = p.shift1 ? p.shift1[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
+      const long long pos = p0 + row;
+      float v = acc1[t][r] + sh;
+      if (pos < p.P) {
+        const size_t idx = (size_t)pos * C::C1 + col;
+        if (p.add1) v += p.add1[idx];
+        if (p.relu1) v = fmaxf(v, 0.f);
+        if (p.mask1) v = p.mask1[idx] > 0.f ? v : 0.f;
+        p.y1[idx] = v;
+      } else {
+        v = 0.f;
+      }
+      ys[row * C::YS + col] = v;
+    }
+  }
+  __syncthreads();
+  // ---- stage 2
+  f32x4 acc2[C::T2][2];
+#pragma unroll
+  for (int t = 0; t < C::T2; ++t)
+    for (int m = 0; m < 2; ++m) acc2[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto mma2 = [&](const float (&b)[C::KC][C::T2], int k0) {
+#pragma unroll
+    for (int kk = 0; kk < C::KC; ++kk) {
+      const int k = (k0 + kk) * 4 + lk2;
+      const float a0 = ys[li2 * C::YS + k], a1 = ys[(16 + li2) * C::YS + k];
+#pragma unroll
+      for (int t = 0; t < C::T2; ++t) {
+        acc2[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b[kk][t], acc2[t][0], 0, 0, 0);
+        acc2[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[kk][t], acc2[t][1], 0, 0, 0);
+      }
+    }
+  };
+  for (int k0 = 0; k0 < C::KS2; k0 += 2 * C::KC) {
+    if (k0 + C::KC < C::KS2) load_b2(c1, k0 + C::KC);
+    mma2(c0, k0);
+    if (k0 + 2 * C::KC < C::KS2) load_b2(c0, k0 + 2 * C::KC);
+    if (k0 + C::KC < C::KS2) mma2(c1, k0 + C::KC);
+  }
+  // ---- epilogue 2
+#pragma unroll
+  for (int t = 0; t < C::T2; ++t) {
+    const int col = n2 + t * 16 + li2;
+    const float sh = p.shift2 ? p.shift2[col] : 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long long pos = p0 + m * 16 + lk2 * 4 + r;
+        if (pos < p.P) {
+          const size_t idx = (size_t)pos * C::C2 + col;
+          float v = acc2[t][m][r] + sh;
+          if (p.relu2) v = fmaxf(v, 0.f);
+          if (p.mask2) v = p.mask2[idx] > 0.f ? v : 0.f;
+          p.y2[idx] = v;
+        }
+      }
+  }
+}
+
+template <class C>
+int launch_pair(const PwPairArgs &a, hipStream_t stream) {
+  static bool attr_done = false;
+  if (!attr_done && C::LDS_BYTES > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(pw_pair_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            C::LDS_BYTES) != hipSuccess) {
+      (void)hipGetLastError();
+      return MR3D_ERR_LAUNCH;
+    }
+    attr_done = true;
+  }
+  const long long wgs = (a.P + C::MP - 1) / C::MP;
+  pw_pair_kernel<C><<<(unsigned)wgs, kPairThreads, C::LDS_BYTES, stream>>>(a);
+  return mr3d_launch_status();
+}
+
+}  // namespace
+
+extern "C" int mr3d_pointwise_pair_supported(int c0, int c1, int c2, long long positions) {
+  // the small maps only: from 32k positions on the streaming kernels of pointwise.hip are HBM-bound and better served
+  if (positions <= 0 || positions >= 32768) return 0;
+  return (c0 == 64 && c1 == 256 && c2 == 64) || (c0 == 128 && c1 == 512 && c2 == 128);
+}
+
+extern "C" int mr3d_pointwise_pair(const mr3d_pw_pair_desc *d, mr3d_stream_t stream_) {
+  if (!d || !d->x || !d->w1 || !d->y1 || !d->w2 || !d->y2 || d->positions <= 0) return MR3D_ERR_INVALID_ARG;
+  if (!mr3d_pointwise_pair_supported(d->c0, d->c1, d->c2, d->positions)) return MR3D_ERR_UNSUPPORTED;
+  PwPairArgs a;
+  a.x = d->x; a.w1 = d->w1; a.shift1 = d->shift1; a.add1 = d->add1; a.mask1 = d->mask1; a.y1 = d->y1;
+  a.w2 = d->w2; a.shift2 = d->shift2; a.mask2 = d->mask2; a.y2 = d->y2;
+  a.P = d->positions; a.relu1 = d->relu1; a.relu2 = d->relu2;
+  hipStream_t stream = mr3d_stream(stream_);
+  if (d->c0 == 64) return launch_pair<PairCfg<64, 256, 64>>(a, stream);
+  return launch_pair<PairCfg<128, 512, 128>>(a, stream);
+}

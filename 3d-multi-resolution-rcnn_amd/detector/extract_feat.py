@@ -454,10 +454,22 @@ class ExtractFeat3D(nn.Module):
         x = P.pool_out
         P.blk = []
         stage_outs = []
-        for b in self.blocks:
+        # Small maps (layer3 / layer4; fp32): a block's conv3 (+ identity + ReLU) and the NEXT block's conv1 (+ ReLU) are one
+        # launch (csrc/pw_pair.hip) -- neither needs a halo, the 4x-wide block output stays in LDS for the second product.
+        def pair_ok(b, nb):
+            if self.bf16 or nb is None or nb['stage'] != b['stage'] or nb['ds']:
+                return False
+            pos = int(np.prod(self._out_shape(self._out_shape(x.shape, b['conv1']), b['conv2'])[:4]))
+            return _hip.pw_pair_supported(b['planes'], b['planes'] * 4, nb['planes'], pos)
+        pending_a1 = None
+        for bi, b in enumerate(self.blocks):
+            nb = self.blocks[bi + 1] if bi + 1 < len(self.blocks) else None
             st = dict(x=x)
-            st['a1'] = self._new(self._out_shape(x.shape, b['conv1']))
-            fwd.append(self._conv_fwd(x, b['conv1'], st['a1'], relu=True))
+            if pending_a1 is not None:
+                st['a1'] = pending_a1                    # already produced by the previous block's pair launch
+            else:
+                st['a1'] = self._new(self._out_shape(x.shape, b['conv1']))
+                fwd.append(self._conv_fwd(x, b['conv1'], st['a1'], relu=True))
             st['a2'] = self._new(self._out_shape(st['a1'].shape, b['conv2']))
             fwd.append(self._conv_fwd(st['a1'], b['conv2'], st['a2'], relu=True))
             oshape = self._out_shape(st['a2'].shape, b['conv3'])
@@ -468,7 +480,15 @@ class ExtractFeat3D(nn.Module):
             else:
                 idn = x
             st['out'] = self._new(oshape)
-            fwd.append(self._conv_fwd(st['a2'], b['conv3'], st['out'], add1=idn, relu=True))
+            st['pair_next'] = pair_ok(b, nb)
+            if st['pair_next']:
+                pending_a1 = self._new(self._out_shape(oshape, nb['conv1']))
+                fwd.append(_hip.make_pw_pair_op(st['a2'], self._w(b['conv3'], 'wf'), self._w(b['conv3'], 'shift'), idn, None, st['out'],
+                                                self._w(nb['conv1'], 'wf'), self._w(nb['conv1'], 'shift'), None, pending_a1,
+                                                b['planes'], b['planes'] * 4, nb['planes'], True, True, int(np.prod(oshape[:4]))))
+            else:
+                pending_a1 = None
+                fwd.append(self._conv_fwd(st['a2'], b['conv3'], st['out'], add1=idn, relu=True))
             P.blk.append(st)
             x = st['out']
             last_of_stage = b['block'] == self.STAGE_BLOCKS[self.depth][b['stage']] - 1
@@ -518,12 +538,17 @@ class ExtractFeat3D(nn.Module):
             # the gradient of the LAST stage output only comes through its lateral conv: apply its ReLU mask here
             bwd.append(self._conv_dgrad(glat[i], self.lateral[i], gC_lat[i], mask=P.C[3] if i == 3 else None))
         g = gC_lat[3]                     # grad w.r.t. the current block's output, ReLU-masked
+        pending_g_a2 = None
         for bi in range(len(self.blocks) - 1, -1, -1):
             b, st = self.blocks[bi], P.blk[bi]
             x = st['x']
             bwd.append(self._conv_wgrad(st['a2'], g, b['conv3']))
-            g_a2 = self._new(st['a2'].shape)
-            bwd.append(self._conv_dgrad(g, b['conv3'], g_a2, mask=st['a2']))
+            if pending_g_a2 is not None:
+                g_a2 = pending_g_a2                      # produced by the pair launch that closed the block behind this one
+            else:
+                g_a2 = self._new(st['a2'].shape)
+                bwd.append(self._conv_dgrad(g, b['conv3'], g_a2, mask=st['a2']))
+            pending_g_a2 = None
             bwd.append(self._conv_wgrad(st['a1'], g_a2, b['conv2']))
             g_a1 = self._new(st['a1'].shape)
             if b['stride'] == 1:
@@ -569,7 +594,17 @@ class ExtractFeat3D(nn.Module):
                     bwd.append(op)
             else:
                 assert lat_part is None
-                bwd.append(self._conv_dgrad(g_a1, b['conv1'], gx, add1=g, mask=mask))
+                pst = P.blk[bi - 1]
+                if pst['pair_next']:
+                    # mirror of the forward pair: gx = mask_x(conv1^T(g_a1) + g), then the previous block's
+                    # g_a2 = mask_a2(conv3^T(gx)), in one launch
+                    pb = self.blocks[bi - 1]
+                    pending_g_a2 = self._new(pst['a2'].shape)
+                    bwd.append(_hip.make_pw_pair_op(g_a1, self._w(b['conv1'], 'wb'), None, g, mask, gx,
+                                                    self._w(pb['conv3'], 'wb'), None, pst['a2'], pending_g_a2,
+                                                    b['planes'], b['planes'] * 4, pb['planes'], False, False, int(np.prod(gx.shape[:4]))))
+                else:
+                    bwd.append(self._conv_dgrad(g_a1, b['conv1'], gx, add1=g, mask=mask))
             g = gx
         # Gradient finishing (dW = s dW', BN gamma / beta from the raw sums, ~0.11 ms) of every layer but the stem: queued on
         # the side stream behind the last conv weight gradient -- a side record waits for the main chain only up to the point

@@ -552,6 +552,25 @@ int mr3d_stem_conv_wgrad_bf16(const float *x_ncdhw, const void *dy_bf16, float *
                               mr3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Two chained pointwise (1x1x1, stride 1) convolutions in one launch (csrc/pw_pair.hip), for the small maps of layer3 / layer4
+ * where every separate launch is latency-bound: between two bottleneck blocks (resnet3d.py:198-233)
+ *     y1 = act1(x  * w1 + shift1 + add1)      [P, c0] -> [P, c1]     e.g. conv3 + bn3 + identity + ReLU
+ *     y2 = act2(y1 * w2 + shift2)             [P, c1] -> [P, c2]     e.g. the next block's conv1 + bn1 + ReLU
+ * act = ReLU if relu, then, if mask != NULL, y = mask > 0 ? y : 0 (the backward pass: conv1'^T + residual gradient with the
+ * mask of the block input, then conv3^T with the mask of a2).  y1 is written to global memory and kept in LDS for the second
+ * product.  Weights packed [cin][cout] as for mr3d_conv3d_forward.  Shapes: (64, 256, 64) and (128, 512, 128), fewer than
+ * 32,768 positions; anything else: MR3D_ERR_UNSUPPORTED (mr3d_pointwise_pair_supported answers without a launch).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  const float *x; const float *w1; const float *shift1; const float *add1; const float *mask1; float *y1;
+  const float *w2; const float *shift2; const float *mask2; float *y2;
+  long long positions;
+  int c0, c1, c2, relu1, relu2;
+} mr3d_pw_pair_desc;
+int mr3d_pointwise_pair_supported(int c0, int c1, int c2, long long positions);
+int mr3d_pointwise_pair(const mr3d_pw_pair_desc *desc, mr3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * RPN proposal selection without a host round trip -- RPNHead3D.get_bboxes_single
  * (mmdet/models/anchor_heads/rpn_head_3d.py:72-149): per level sigmoid -> drop flagged-out anchors (:95-106) -> top nms_pre
  * (:108-112) -> decode -> nms -> first nms_post (:133-135); then top max_num over all levels (:141-148).
@@ -599,6 +618,8 @@ int mr3d_rpn_merge_levels(const float *dets, const int *seg_rows_host, int num_l
  *   STEM_FWD      p = {x_ncdhw,w_packed,shift,y}        i = {n,d,h,w,relu}
  *   STEM_WGRAD    p = {x_ncdhw,dy,dw_packed,dbias,workspace}  i = {n,d,h,w, workspace bytes lo, hi}
  *   CONV_DGRAD_S2 p / i as CONV_FWD (mr3d_conv3d_dgrad_s2k3: x = dy, w = wb, y = dx; y_d/y_h/y_w = dx's grid)
+ *   PW_PAIR       p = {x,w1,add1,mask1,y1,w2,mask2,y2}  i = {c0,c1,c2,relu1,relu2, positions lo,hi, shift1 lo,hi, shift2 lo,hi}
+ *                 (mr3d_pointwise_pair; the two shift pointers travel as 64-bit integers)
  *   SYNC          i = {mode, slot}: ordering between the caller's stream and the internal side stream (see below)
  *   WINO2D_PREP   p = {workspace}  i = {bytes_lo, bytes_hi}: transforms, in ONE launch, the weights of every fp32 CONV_FWD
  *                 record between here and the next PREP_WEIGHTS record that qualifies for the two-dimensional Winograd
@@ -616,6 +637,7 @@ typedef enum {
   MR3D_OP_PREP_WEIGHTS_BF16 = 17,     /* p = {table16, params, packed16}   i = {num_layers} */
   MR3D_OP_STEM_PACK_BF16 = 18,        /* p = {w_packed (fp32 [343][4][16]), w16} */
   MR3D_OP_WINO2D_PREP = 20,
+  MR3D_OP_PW_PAIR = 21,
   MR3D_OP_SYNC = 19,                  /* i[0] = 0: the caller's stream waits for everything queued on the side stream;
                                          1: remember this point of the side queue in slot i[1] (0..3);
                                          2: the caller's stream waits for the point remembered in slot i[1] */

@@ -457,3 +457,38 @@ def test_conv3d_wgrad_winograd_path_ragged_volume(dev):
     assert rel(db, dy.sum((0, 2, 3, 4))) <= 1e-4
     _hip.conv3d_wgrad(xc, dyc, dw, (3,) * 3, (1,) * 3, (1,) * 3)            # accumulates
     assert rel(dw, 2 * ref) <= RTOL
+
+
+@pytest.mark.parametrize('c0,c1,c2,P', [(64, 256, 64, 10240), (64, 256, 64, 77), (128, 512, 128, 1280), (128, 512, 128, 33)])
+@pytest.mark.parametrize('mode', ['forward', 'backward'])
+def test_pointwise_pair_vs_fp64(dev, c0, c1, c2, P, mode):
+    """mr3d_pointwise_pair (csrc/pw_pair.hip): conv3 + identity + ReLU -> next conv1 + ReLU (forward) and conv1^T + residual
+    gradient + mask -> conv3^T + mask (backward) in one launch, against float64; ragged position counts included"""
+    import ctypes
+    from mr3d_amd import _hip
+    g = torch.Generator().manual_seed(c0 + P)
+    x = torch.randn(P, c0, generator=g)
+    w1 = torch.randn(c0, c1, generator=g) / c0 ** 0.5
+    w2 = torch.randn(c1, c2, generator=g) / c1 ** 0.5
+    add1 = torch.randn(P, c1, generator=g)
+    if mode == 'forward':
+        sh1, sh2 = torch.randn(c1, generator=g), torch.randn(c2, generator=g)
+        y1 = torch.relu(x.double() @ w1.double() + sh1.double() + add1.double())
+        y2 = torch.relu(y1 @ w2.double() + sh2.double())
+        m1 = m2 = None
+    else:
+        sh1 = sh2 = None
+        m1, m2 = torch.randn(P, c1, generator=g), torch.randn(P, c2, generator=g)
+        y1 = (x.double() @ w1.double() + add1.double()) * (m1 > 0)
+        y2 = (y1 @ w2.double()) * (m2 > 0)
+    d = lambda t: None if t is None else t.to(dev).contiguous()
+    xd, w1d, w2d, ad, s1, s2, m1d, m2d = d(x), d(w1), d(w2), d(add1), d(sh1), d(sh2), d(m1), d(m2)
+    o1 = torch.full((P, c1), 7.0, device=dev)
+    o2 = torch.full((P, c2), 7.0, device=dev)
+    assert _hip.pw_pair_supported(c0, c1, c2, P) and not _hip.pw_pair_supported(c0, c1, c2, 40000) and not _hip.pw_pair_supported(16, 64, 16, P)
+    op = _hip.make_pw_pair_op(xd, w1d, s1, ad, m1d, o1, w2d, s2, m2d, o2, c0, c1, c2, mode == 'forward', mode == 'forward', P)
+    _hip.Plan([op]).run(dev)
+    torch.cuda.synchronize()
+    for got, exp in ((o1, y1), (o2, y2)):
+        err = (got.double().cpu() - exp).abs().max().item()
+        assert err <= 1e-4 * exp.abs().max().item(), (mode, err)
