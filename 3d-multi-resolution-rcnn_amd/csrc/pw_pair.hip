@@ -12,10 +12,11 @@
 //
 // Workgroup = 32 positions, 4 waves.
 //   stage 1  [32 x C0] x [C0 x C1]: v_mfma_f32_32x32x2_f32, A from the x tile in LDS (row stride C0 + 1), a wave owns
-//            C1 / 128 column tiles of 32; B fragments straight from L2 (rows of C1 are contiguous), a chunk of 8 k-steps ahead;
+//            C1 / 128 column tiles of 32; B fragments straight from L2 (rows of C1 are contiguous), ALL of them (both
+//            products) requested at the top of the kernel;
 //            epilogue: + shift, + residual, ReLU / mask -> y1 (global) and the y1 tile in LDS (row stride C1 + 4).
 //   stage 2  [32 x C1] x [C1 x C2]: v_mfma_f32_16x16x4_f32 (C2 / 64 column tiles of 16 per wave, both row tiles), A from the
-//            y1 tile, B from L2 a chunk ahead; epilogue: + shift, ReLU / mask -> y2.
+//            y1 tile; epilogue: + shift, ReLU / mask -> y2.
 #include "mr3d_common.h"
 #include "conv3d.h"
 
@@ -40,9 +41,12 @@ struct PairCfg {
   static constexpr int T1 = C1 / 32 / 4;          // 32-wide stage-1 column tiles per wave
   static constexpr int T2 = C2 / 16 / 4;          // 16-wide stage-2 column tiles per wave
   static constexpr int KS1 = C0 / 2, KS2 = C1 / 4;
-  static constexpr int KC = 8;                    // k-steps per B-fragment chunk
   static constexpr int LDS_BYTES = (MP * XS + MP * YS) * 4;
-  static_assert(C1 % 128 == 0 && C2 % 64 == 0 && C0 % 16 == 0 && KS1 % KC == 0 && KS2 % KC == 0, "shape");
+  // ALL B fragments of a product are requested at once (64 registers per product at 64 / 256 / 64), the first product's at
+  // the top of the kernel, the second's right behind the first product's MFMAs: fetching them a chunk ahead of their MFMAs
+  // stalled every chunk for an L2 round trip (a chunk of 8 k-steps is 0.25-0.5 us of matrix work) and made the fused launch
+  // slower than the two it replaces (39 vs 35 us)
+  static_assert(C1 % 128 == 0 && C2 % 64 == 0 && C0 % 16 == 0 && KS1 * T1 <= 64 && KS2 * T2 <= 64, "shape");
 };
 
 template <class C>
@@ -53,6 +57,19 @@ __global__ __launch_bounds__(kPairThreads) void pw_pair_kernel(PwPairArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long long p0 = (long long)blockIdx.x * C::MP;
 
+  // ---- all weight fragments of this wave, both products: in flight from here on
+  const int li = lane & 31, lk = lane >> 5;
+  const int n1 = wave * C::T1 * 32;                                  // this wave's first stage-1 column
+  const int li2 = lane & 15, lk2 = lane >> 4;
+  const int n2 = wave * C::T2 * 16;
+  float b1[C::KS1][C::T1], b2[C::KS2][C::T2];
+  {
+    const float *w1l = p.w1 + (size_t)lk * C::C1 + n1 + li;
+#pragma unroll
+    for (int kk = 0; kk < C::KS1; ++kk)
+#pragma unroll
+      for (int t = 0; t < C::T1; ++t) b1[kk][t] = w1l[(size_t)kk * 2 * C::C1 + t * 32];
+  }
   // ---- x tile -> LDS
   {
     constexpr int Q = C::C0 / 4;
@@ -64,49 +81,38 @@ __global__ __launch_bounds__(kPairThreads) void pw_pair_kernel(PwPairArgs p) {
       d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
   }
+  // ---- residual / mask values of this lane's stage-1 outputs: requested before the products, used after them
+  float r1[C::T1][16], m1[C::T1][16];
+#pragma unroll
+  for (int t = 0; t < C::T1; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const long long pos = p0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+      const size_t idx = (size_t)(pos < p.P ? pos : 0) * C::C1 + n1 + t * 32 + li;
+      r1[t][r] = p.add1 ? p.add1[idx] : 0.f;
+      m1[t][r] = p.mask1 ? p.mask1[idx] : 1.f;
+    }
   // ---- stage 1
-  const int li = lane & 31, lk = lane >> 5;
-  const int n1 = wave * C::T1 * 32;                                  // this wave's first stage-1 column
   f32x16 acc1[C::T1];
 #pragma unroll
   for (int t = 0; t < C::T1; ++t)
     for (int r = 0; r < 16; ++r) acc1[t][r] = 0.f;
-  const float *w1l = p.w1 + (size_t)lk * C::C1 + n1 + li;
-  float b0[C::KC][C::T1], b1[C::KC][C::T1];
-  auto load_b1 = [&](float (&b)[C::KC][C::T1], int k0) {
-#pragma unroll
-    for (int kk = 0; kk < C::KC; ++kk)
-#pragma unroll
-      for (int t = 0; t < C::T1; ++t) b[kk][t] = w1l[(size_t)(k0 + kk) * 2 * C::C1 + t * 32];
-  };
-  auto mma1 = [&](const float (&b)[C::KC][C::T1], int k0) {
-#pragma unroll
-    for (int kk = 0; kk < C::KC; ++kk) {
-      const float a = xs[li * C::XS + (k0 + kk) * 2 + lk];
-#pragma unroll
-      for (int t = 0; t < C::T1; ++t) acc1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[kk][t], acc1[t], 0, 0, 0);
-    }
-  };
-  load_b1(b0, 0);
   __syncthreads();
-  for (int k0 = 0; k0 < C::KS1; k0 += 2 * C::KC) {
-    if (k0 + C::KC < C::KS1) load_b1(b1, k0 + C::KC);
-    mma1(b0, k0);
-    if (k0 + 2 * C::KC < C::KS1) load_b1(b0, k0 + 2 * C::KC);
-    if (k0 + C::KC < C::KS1) mma1(b1, k0 + C::KC);
+#pragma unroll
+  for (int kk = 0; kk < C::KS1; ++kk) {
+    const float a = xs[li * C::XS + kk * 2 + lk];
+#pragma unroll
+    for (int t = 0; t < C::T1; ++t) acc1[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1[kk][t], acc1[t], 0, 0, 0);
   }
-  // first B chunk of stage 2: in flight across the epilogue
-  const int li2 = lane & 15, lk2 = lane >> 4;
-  const int n2 = wave * C::T2 * 16;
-  const float *w2l = p.w2 + (size_t)lk2 * C::C2 + n2 + li2;
-  float c0[C::KC][C::T2], c1[C::KC][C::T2];
-  auto load_b2 = [&](float (&b)[C::KC][C::T2], int k0) {
+  // the second product's fragments: requested as soon as the first product has issued (they take over its registers --
+  // holding both sets at once left one workgroup per CU) and land during the epilogue and the barrier behind it
+  {
+    const float *w2l = p.w2 + (size_t)lk2 * C::C2 + n2 + li2;
 #pragma unroll
-    for (int kk = 0; kk < C::KC; ++kk)
+    for (int kk = 0; kk < C::KS2; ++kk)
 #pragma unroll
-      for (int t = 0; t < C::T2; ++t) b[kk][t] = w2l[(size_t)(k0 + kk) * 4 * C::C2 + t * 16];
-  };
-  load_b2(c0, 0);
+      for (int t = 0; t < C::T2; ++t) b2[kk][t] = w2l[(size_t)kk * 4 * C::C2 + t * 16];
+  }
   // ---- epilogue 1: y1 = act(acc + shift + residual) -> global and LDS
 #pragma unroll
   for (int t = 0; t < C::T1; ++t) {
@@ -116,16 +122,11 @@ __global__ __launch_bounds__(kPairThreads) void pw_pair_kernel(PwPairArgs p) {
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
       const long long pos = p0 + row;
-      float v = acc1[t][r] + sh;
-      if (pos < p.P) {
-        const size_t idx = (size_t)pos * C::C1 + col;
-        if (p.add1) v += p.add1[idx];
-        if (p.relu1) v = fmaxf(v, 0.f);
-        if (p.mask1) v = p.mask1[idx] > 0.f ? v : 0.f;
-        p.y1[idx] = v;
-      } else {
-        v = 0.f;
-      }
+      float v = acc1[t][r] + sh + r1[t][r];
+      if (p.relu1) v = fmaxf(v, 0.f);
+      v = m1[t][r] > 0.f ? v : 0.f;
+      if (pos < p.P) p.y1[(size_t)pos * C::C1 + col] = v;
+      else v = 0.f;
       ys[row * C::YS + col] = v;
     }
   }
@@ -135,23 +136,15 @@ __global__ __launch_bounds__(kPairThreads) void pw_pair_kernel(PwPairArgs p) {
 #pragma unroll
   for (int t = 0; t < C::T2; ++t)
     for (int m = 0; m < 2; ++m) acc2[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto mma2 = [&](const float (&b)[C::KC][C::T2], int k0) {
 #pragma unroll
-    for (int kk = 0; kk < C::KC; ++kk) {
-      const int k = (k0 + kk) * 4 + lk2;
-      const float a0 = ys[li2 * C::YS + k], a1 = ys[(16 + li2) * C::YS + k];
+  for (int kk = 0; kk < C::KS2; ++kk) {
+    const int k = kk * 4 + lk2;
+    const float a0 = ys[li2 * C::YS + k], a1 = ys[(16 + li2) * C::YS + k];
 #pragma unroll
-      for (int t = 0; t < C::T2; ++t) {
-        acc2[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b[kk][t], acc2[t][0], 0, 0, 0);
-        acc2[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b[kk][t], acc2[t][1], 0, 0, 0);
-      }
+    for (int t = 0; t < C::T2; ++t) {
+      acc2[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b2[kk][t], acc2[t][0], 0, 0, 0);
+      acc2[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b2[kk][t], acc2[t][1], 0, 0, 0);
     }
-  };
-  for (int k0 = 0; k0 < C::KS2; k0 += 2 * C::KC) {
-    if (k0 + C::KC < C::KS2) load_b2(c1, k0 + C::KC);
-    mma2(c0, k0);
-    if (k0 + 2 * C::KC < C::KS2) load_b2(c0, k0 + 2 * C::KC);
-    if (k0 + C::KC < C::KS2) mma2(c1, k0 + C::KC);
   }
   // ---- epilogue 2
 #pragma unroll
@@ -195,7 +188,9 @@ int launch_pair(const PwPairArgs &a, hipStream_t stream) {
 extern "C" int mr3d_pointwise_pair_supported(int c0, int c1, int c2, long long positions) {
   // the small maps only: from 32k positions on the streaming kernels of pointwise.hip are HBM-bound and better served
   if (positions <= 0 || positions >= 32768) return 0;
-  return (c0 == 64 && c1 == 256 && c2 == 64) || (c0 == 128 && c1 == 512 && c2 == 128);
+  // layer3 only: at 128 / 512 / 128 (layer4: 40 workgroups of 32 positions) a wave cannot hold its weight fragments and
+  // streaming 512 KB of weights per workgroup chunk by chunk measured 70 us against 22 us for the two separate launches
+  return c0 == 64 && c1 == 256 && c2 == 64;
 }
 
 extern "C" int mr3d_pointwise_pair(const mr3d_pw_pair_desc *d, mr3d_stream_t stream_) {
@@ -206,6 +201,5 @@ extern "C" int mr3d_pointwise_pair(const mr3d_pw_pair_desc *d, mr3d_stream_t str
   a.w2 = d->w2; a.shift2 = d->shift2; a.mask2 = d->mask2; a.y2 = d->y2;
   a.P = d->positions; a.relu1 = d->relu1; a.relu2 = d->relu2;
   hipStream_t stream = mr3d_stream(stream_);
-  if (d->c0 == 64) return launch_pair<PairCfg<64, 256, 64>>(a, stream);
-  return launch_pair<PairCfg<128, 512, 128>>(a, stream);
+  return launch_pair<PairCfg<64, 256, 64>>(a, stream);
 }

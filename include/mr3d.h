@@ -552,14 +552,14 @@ int mr3d_stem_conv_wgrad_bf16(const float *x_ncdhw, const void *dy_bf16, float *
                               mr3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Two chained pointwise (1x1x1, stride 1) convolutions in one launch (csrc/pw_pair.hip), for the small maps of layer3 / layer4
+ * Two chained pointwise (1x1x1, stride 1) convolutions in one launch (csrc/pw_pair.hip), for the small maps of layer3
  * where every separate launch is latency-bound: between two bottleneck blocks (resnet3d.py:198-233)
  *     y1 = act1(x  * w1 + shift1 + add1)      [P, c0] -> [P, c1]     e.g. conv3 + bn3 + identity + ReLU
  *     y2 = act2(y1 * w2 + shift2)             [P, c1] -> [P, c2]     e.g. the next block's conv1 + bn1 + ReLU
  * act = ReLU if relu, then, if mask != NULL, y = mask > 0 ? y : 0 (the backward pass: conv1'^T + residual gradient with the
  * mask of the block input, then conv3^T with the mask of a2).  y1 is written to global memory and kept in LDS for the second
- * product.  Weights packed [cin][cout] as for mr3d_conv3d_forward.  Shapes: (64, 256, 64) and (128, 512, 128), fewer than
- * 32,768 positions; anything else: MR3D_ERR_UNSUPPORTED (mr3d_pointwise_pair_supported answers without a launch).
+ * product.  Weights packed [cin][cout] as for mr3d_conv3d_forward.  Shape: (64, 256, 64) with fewer than
+ * 32,768 positions (layer3); anything else: MR3D_ERR_UNSUPPORTED (mr3d_pointwise_pair_supported answers without a launch).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
   const float *x; const float *w1; const float *shift1; const float *add1; const float *mask1; float *y1;

@@ -459,7 +459,7 @@ def test_conv3d_wgrad_winograd_path_ragged_volume(dev):
     assert rel(dw, 2 * ref) <= RTOL
 
 
-@pytest.mark.parametrize('c0,c1,c2,P', [(64, 256, 64, 10240), (64, 256, 64, 77), (128, 512, 128, 1280), (128, 512, 128, 33)])
+@pytest.mark.parametrize('c0,c1,c2,P', [(64, 256, 64, 10240), (64, 256, 64, 77), (64, 256, 64, 32)])
 @pytest.mark.parametrize('mode', ['forward', 'backward'])
 def test_pointwise_pair_vs_fp64(dev, c0, c1, c2, P, mode):
     """mr3d_pointwise_pair (csrc/pw_pair.hip): conv3 + identity + ReLU -> next conv1 + ReLU (forward) and conv1^T + residual
