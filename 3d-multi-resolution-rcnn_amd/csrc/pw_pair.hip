@@ -41,7 +41,7 @@ struct PairCfg {
   static constexpr int T1 = C1 / 32 / 4;          // 32-wide stage-1 column tiles per wave
   static constexpr int T2 = C2 / 16 / 4;          // 16-wide stage-2 column tiles per wave
   static constexpr int KS1 = C0 / 2, KS2 = C1 / 4;
-  static constexpr int LDS_BYTES = (MP * XS + MP * YS) * 4;
+  static constexpr int LDS_BYTES = (MP * XS + 2 * MP * YS) * 4;      // x tile, y1 tile (first holds the residual), mask tile
   // ALL B fragments of a product are requested at once (64 registers per product at 64 / 256 / 64), the first product's at
   // the top of the kernel, the second's right behind the first product's MFMAs: fetching them a chunk ahead of their MFMAs
   // stalled every chunk for an L2 round trip (a chunk of 8 k-steps is 0.25-0.5 us of matrix work) and made the fused launch
@@ -81,17 +81,22 @@ __global__ __launch_bounds__(kPairThreads) void pw_pair_kernel(PwPairArgs p) {
       d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
   }
-  // ---- residual / mask values of this lane's stage-1 outputs: requested before the products, used after them
-  float r1[C::T1][16], m1[C::T1][16];
-#pragma unroll
-  for (int t = 0; t < C::T1; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const long long pos = p0 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-      const size_t idx = (size_t)(pos < p.P ? pos : 0) * C::C1 + n1 + t * 32 + li;
-      r1[t][r] = p.add1 ? p.add1[idx] : 0.f;
-      m1[t][r] = p.mask1 ? p.mask1[idx] : 1.f;
+  // ---- residual and mask tiles of the stage-1 outputs -> LDS with 16-byte coalesced loads (the accumulator layout of the
+  // 32x32 MFMA would make them 32 + 32 four-byte loads per lane); the residual lands in the y1 tile, where the epilogue
+  // replaces it value by value
+  float *ms = ys + C::MP * C::YS;
+  {
+    constexpr int Q1 = C::C1 / 4;
+    for (int e = tid; e < C::MP * Q1; e += kPairThreads) {
+      const int row = e / Q1, q = e - row * Q1;
+      const bool in = p0 + row < p.P;
+      const size_t g = (size_t)(p0 + row) * C::C1 + q * 4;
+      const float4 a = (in && p.add1) ? *reinterpret_cast<const float4 *>(p.add1 + g) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 m = (in && p.mask1) ? *reinterpret_cast<const float4 *>(p.mask1 + g) : make_float4(1.f, 1.f, 1.f, 1.f);
+      *reinterpret_cast<float4 *>(ys + row * C::YS + q * 4) = a;
+      *reinterpret_cast<float4 *>(ms + row * C::YS + q * 4) = m;
     }
+  }
   // ---- stage 1
   f32x16 acc1[C::T1];
 #pragma unroll
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(kPairThreads) void pw_pair_kernel(PwPairArgs p) {
 #pragma unroll
       for (int t = 0; t < C::T2; ++t) b2[kk][t] = w2l[(size_t)kk * 4 * C::C2 + t * 16];
   }
-  // ---- epilogue 1: y1 = act(acc + shift + residual) -> global and LDS
+  // ---- epilogue 1: y1 = act(acc + shift + residual) into the LDS tile, then the tile -> global with 16-byte stores
 #pragma unroll
   for (int t = 0; t < C::T1; ++t) {
     const int col = n1 + t * 32 + li;
@@ -121,16 +126,21 @@ __global__ __launch_bounds__(kPairThreads) void pw_pair_kernel(PwPairArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * lk;
-      const long long pos = p0 + row;
-      float v = acc1[t][r] + sh + r1[t][r];
+      float v = acc1[t][r] + sh + ys[row * C::YS + col];
       if (p.relu1) v = fmaxf(v, 0.f);
-      v = m1[t][r] > 0.f ? v : 0.f;
-      if (pos < p.P) p.y1[(size_t)pos * C::C1 + col] = v;
-      else v = 0.f;
-      ys[row * C::YS + col] = v;
+      v = ms[row * C::YS + col] > 0.f ? v : 0.f;
+      ys[row * C::YS + col] = p0 + row < p.P ? v : 0.f;
     }
   }
   __syncthreads();
+  {
+    constexpr int Q1 = C::C1 / 4;
+    for (int e = tid; e < C::MP * Q1; e += kPairThreads) {
+      const int row = e / Q1, q = e - row * Q1;
+      if (p0 + row < p.P)
+        *reinterpret_cast<float4 *>(p.y1 + (size_t)(p0 + row) * C::C1 + q * 4) = *reinterpret_cast<const float4 *>(ys + row * C::YS + q * 4);
+    }
+  }
   // ---- stage 2
   f32x4 acc2[C::T2][2];
 #pragma unroll
