@@ -68,7 +68,11 @@ class TwoStageDetector3D2Scales(TwoStageDetector3D):
     def forward_train(self, imgs, img_meta, imgs_2, img_meta_2, gt_bboxes, gt_bboxes_2, gt_labels, gt_labels_2,
                       gt_bboxes_ignore=None, gt_masks=None, gt_masks_2=None, proposals=None, draws=None):
         assert imgs.shape[1] == 3 and imgs_2.shape[1] == 3                     # :148
-        assert imgs.size(0) == 1, 'imgs_per_gpu = 1 (configs/...py:191)'
+        # One volume per GPU, like the reference's own dual-pathway model: its refinement stage wraps ALL pathway-2 predictions
+        # in a one-element list (`pred_bboxes_2 = [torch.from_numpy(pred_bboxes_2).cuda()]`, two_stage_3d_2scales.py:263-267)
+        # and then indexes it per image (:275-283), which raises for a second image; the shipped config sets imgs_per_gpu = 1
+        # (configs/...py:191).  The single-pathway detector (two_stage.py) is batch-agnostic.
+        assert imgs.size(0) == 1, 'TwoStageDetector3D2Scales trains one volume per GPU (reference: two_stage_3d_2scales.py:263-283)'
         draws = draws or {}
         cfg = self.train_cfg
         x = self.extract_feat(imgs, 0)
