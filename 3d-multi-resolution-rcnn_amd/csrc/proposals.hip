@@ -363,15 +363,24 @@ namespace {
 constexpr int kMergeThreads = 1024;
 constexpr int kMergeE = 16;                      // 16,384 candidates at most
 constexpr int kMergeMax = kMergeThreads * kMergeE;
+constexpr int kMergeSel = 2 * kMergeThreads;     // the sorted part: max_num <= 2048
 
 struct MergeTab { int num; int row0[kMaxLevels * 2]; };
 
+// Candidates = the first min(num_keep, nms_post) kept rows of every level, position = running index in level order.  Their
+// keys (~score bits, position) are held 16 per thread.  Sorting all of them in one workgroup cost 220 us (91 compare-exchange
+// rounds over 8,192 keys); only the max_num best are wanted, so: an 8-bit-per-pass radix select of the max_num-th key over
+// LDS histograms (4 passes), a compaction of the keys below it (+ the first few ON it, in position order) into 2,048 slots,
+// and the register bitonic sort of those.
 __global__ __launch_bounds__(kMergeThreads) void rpn_merge_kernel(const float *__restrict__ dets, MergeTab mt,
                                                                  const long long *__restrict__ keep, const int32_t *__restrict__ num_keep,
                                                                  int nms_post, int max_num, float *__restrict__ out,
                                                                  int32_t *__restrict__ count_out) {
-  extern __shared__ __attribute__((aligned(16))) uint64_t sm[];
+  __shared__ uint64_t sel[kMergeSel];
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t scan[kMergeThreads];
   __shared__ int s_start[kMaxLevels * 2 + 1];
+  __shared__ uint32_t s_bin, s_below, s_slot;
   const int tid = threadIdx.x;
   if (tid == 0) {
     int run = 0;
@@ -382,40 +391,108 @@ __global__ __launch_bounds__(kMergeThreads) void rpn_merge_kernel(const float *_
       run += k;
     }
     s_start[mt.num] = run > kMergeMax ? kMergeMax : run;
+    s_slot = 0;
   }
+  for (int i = tid; i < kMergeSel; i += kMergeThreads) sel[i] = ~0ull;
   __syncthreads();
   const int total = s_start[mt.num];
-  int np2 = 2;
-  while (np2 < total) np2 <<= 1;
-  // candidate c of level l = row keep[row0[l] + (c - start[l])] of that level's dets block; key = (score desc, c asc)
-  uint64_t v[kMergeE];
+  auto row_of = [&](int c) {
+    int l = 0;
+    for (int j = 1; j < mt.num; ++j)
+      if (c >= s_start[j]) l = j;
+    return (long long)mt.row0[l] + keep[mt.row0[l] + (c - s_start[l])];
+  };
+  uint32_t k32[kMergeE];                       // ~(order-preserving score bits): smaller = better; 0xffffffff = no candidate
 #pragma unroll
   for (int e = 0; e < kMergeE; ++e) {
     const int c = tid * kMergeE + e;
-    uint64_t key = ~0ull;
+    uint32_t key = 0xffffffffu;
     if (c < total) {
-      int l = 0;
-      for (int j = 1; j < mt.num; ++j)
-        if (c >= s_start[j]) l = j;
-      const long long row = mt.row0[l] + keep[mt.row0[l] + (c - s_start[l])];
-      uint32_t u = __float_as_uint(dets[row * 7 + 6]);
+      uint32_t u = __float_as_uint(dets[row_of(c) * 7 + 6]);
       if (u == 0x80000000u) u = 0u;
       u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-      key = ((uint64_t)(~u) << 32) | (uint32_t)c;
+      key = ~u;
+      if (key == 0xffffffffu) key = 0xfffffffeu;
     }
-    v[e] = key;
+    k32[e] = key;
   }
-  bitonic_sort_regs<kMergeE>(v, tid, np2, sm);
   const int take = total < max_num ? total : max_num;
+  uint32_t T = 0xffffffffu, eq_take = 0;       // selected: key < T, or key == T and fewer than eq_take equal keys in front
+  if (total > max_num) {
+    uint32_t prefix = 0, krem = (uint32_t)max_num;
+#pragma unroll 1
+    for (int pass = 0; pass < 4; ++pass) {
+      const int shift = 24 - 8 * pass;
+      if (tid < 256) hist[tid] = 0;
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < kMergeE; ++e) {
+        const uint32_t key = k32[e];
+        if (key != 0xffffffffu && (pass == 0 || (key >> (shift + 8)) == prefix)) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+      }
+      __syncthreads();
+      if (tid < 64) {                          // one wave: 4 bins per lane, ascending
+        uint32_t h[4], sum = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { h[j] = hist[tid * 4 + j]; sum += h[j]; }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const uint32_t v = (uint32_t)__shfl_up((int)incl, o);
+          if (tid >= o) incl += v;
+        }
+        uint32_t run = incl - sum;
+        if (run < krem && incl >= krem) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (run + h[j] >= krem) { s_bin = (uint32_t)(tid * 4 + j); s_below = run; break; }
+            run += h[j];
+          }
+        }
+      }
+      __syncthreads();
+      prefix = (prefix << 8) | s_bin;
+      krem -= s_below;
+      __syncthreads();
+    }
+    T = prefix; eq_take = krem;
+  }
+  // rank of this thread's keys ON the pivot among all such keys, in position order
+  uint32_t neq = 0;
+#pragma unroll
+  for (int e = 0; e < kMergeE; ++e) neq += k32[e] == T && T != 0xffffffffu;
+  scan[tid] = neq;
+  __syncthreads();
+  for (int o = 1; o < kMergeThreads; o <<= 1) {
+    const uint32_t v = tid >= o ? scan[tid - o] : 0u;
+    __syncthreads();
+    scan[tid] += v;
+    __syncthreads();
+  }
+  uint32_t eq_before = scan[tid] - neq;
 #pragma unroll
   for (int e = 0; e < kMergeE; ++e) {
-    const int i = tid * kMergeE + e;
+    const uint32_t key = k32[e];
+    const bool is_eq = key == T && T != 0xffffffffu;
+    if (key < T || (is_eq && eq_before < eq_take)) {
+      const uint32_t slot = atomicAdd(&s_slot, 1u);
+      if (slot < (uint32_t)kMergeSel) sel[slot] = ((uint64_t)key << 32) | (uint32_t)(tid * kMergeE + e);
+    }
+    eq_before += is_eq;
+  }
+  __syncthreads();
+  // the selected keys (<= max_num of them, unordered) -> (score desc, position asc)
+  extern __shared__ __attribute__((aligned(16))) uint64_t sm[];
+  uint64_t v[2] = {sel[tid * 2], sel[tid * 2 + 1]};
+  __syncthreads();
+  int np2 = 2;
+  while (np2 < take) np2 <<= 1;
+  bitonic_sort_regs<2>(v, tid, np2 > kMergeSel ? kMergeSel : np2, sm);
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int i = tid * 2 + e;
     if (i < take) {
-      const int c = (int)(uint32_t)v[e];
-      int l = 0;
-      for (int j = 1; j < mt.num; ++j)
-        if (c >= s_start[j]) l = j;
-      const long long row = mt.row0[l] + keep[mt.row0[l] + (c - s_start[l])];
+      const long long row = row_of((int)(uint32_t)v[e]);
 #pragma unroll
       for (int q = 0; q < 7; ++q) out[(size_t)i * 7 + q] = dets[row * 7 + q];
     }
@@ -446,8 +523,8 @@ extern "C" int mr3d_rpn_merge_levels(const float *dets, const int *seg_rows_host
       cand += seg_rows_host[l] < nms_post ? seg_rows_host[l] : nms_post;
     }
   }
-  if (cand > kMergeMax) return MR3D_ERR_UNSUPPORTED;
-  constexpr int lds = kMergeMax * 8;
+  if (cand > kMergeMax || max_num > kMergeSel) return MR3D_ERR_UNSUPPORTED;
+  constexpr int lds = kMergeSel * 8;
   static bool attr_done = false;
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(rpn_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {

@@ -24,7 +24,7 @@ def _device_path_ok(cls_scores, cfg):
     shipped train and test configs have both at 2000) -- the cut keeps rows in the order the NMS saw them, which the
     reference makes score order or anchor order depending on a data-dependent branch (:103-112)."""
     return (not getattr(cfg, 'nms_across_levels', False) and 0 < cfg.nms_pre <= cfg.nms_post and cfg.nms_pre <= 4096 and
-            len(cls_scores) <= 8 and 0 < cfg.max_num and len(cls_scores) * min(cfg.nms_pre, cfg.nms_post) <= 16384 and
+            len(cls_scores) <= 8 and 0 < cfg.max_num <= 2048 and len(cls_scores) * min(cfg.nms_pre, cfg.nms_post) <= 16384 and
             all(c.dtype == torch.float32 for c in cls_scores))
 
 
