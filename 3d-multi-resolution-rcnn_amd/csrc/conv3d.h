@@ -28,6 +28,11 @@ struct Conv3dFwdArgs {
   // that assumes it
   float *ws = nullptr;
   long long ws_bytes = 0;
+  // streaming pointwise PAIR (pointwise.hip): a second 1x1x1 product on the activated tile while it still sits in LDS,
+  // y2 = act2(y * w2 + shift2); w2 packed [Cout][C2]
+  const float *w2 = nullptr, *shift2 = nullptr, *mask2 = nullptr;
+  float *y2 = nullptr;
+  int relu2 = 0;
 };
 
 struct Conv3dWgradArgs {
@@ -68,6 +73,8 @@ int mr3d_conv3d_wgrad_wino2d(const Conv3dWgradArgs &a, hipStream_t stream);
 
 // streaming pointwise instances (pointwise.hip); MR3D_ERR_UNSUPPORTED = use the generic kernels
 int mr3d_pointwise_fwd_try(const Conv3dFwdArgs &a, hipStream_t stream, bool probe_only = false);
+// the PAIR form (a.w2 / a.y2 set): 16 -> 64 -> 16 on whole 32-row tiles; MR3D_ERR_UNSUPPORTED otherwise
+int mr3d_pointwise_pair_stream_try(const Conv3dFwdArgs &a, int c2, hipStream_t stream, bool probe_only = false);
 int mr3d_pointwise_wgrad_try(const Conv3dWgradArgs &a, hipStream_t stream);
 
 // streaming bf16 pointwise instances (pointwise_bf16.hip); MR3D_ERR_UNSUPPORTED = use the generic bf16 kernel

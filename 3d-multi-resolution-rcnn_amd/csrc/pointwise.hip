@@ -31,10 +31,16 @@ __device__ __forceinline__ int pw_nearest_src(int dst, int in, int out) {
 // EXTRA = the call carries residual / mask streams (add1, add2, mask): 32-row tiles, and the add1 / mask tiles of
 // the CURRENT tile are requested at the top of the iteration so that their HBM latency hides behind the LDS
 // round trip and the MFMAs instead of being exposed in the epilogue.
-template <int CI_, int CO_, bool EXTRA_ = false>
+// C2_ > 0: the PAIR form -- a second pointwise product CO -> C2 on the activated output tile while it still sits in the wave's
+// LDS slab (a bottleneck block's conv3 + identity + ReLU followed by the next block's conv1 + ReLU, and the mirror image in the
+// backward pass): the 4x-wide block output is written once and not read back by another launch.
+template <int CI_, int CO_, bool EXTRA_ = false, int C2_ = 0>
 struct PwCfg {
-  static constexpr int CI = CI_, CO = CO_;
-  static constexpr bool EXTRA = EXTRA_;
+  static constexpr int CI = CI_, CO = CO_, C2 = C2_;
+  static constexpr bool EXTRA = EXTRA_, PAIR = C2_ > 0;
+  static constexpr int KK2 = CO_ / 4, MT2 = 2, OS2 = C2_ + 4;            // stage 2: 16x16x4, both 16-row tiles of the 32-row tile
+  static constexpr int NOUT2 = C2_ > 0 ? 32 * C2_ / 4 / 64 : 1;
+  static_assert(C2_ == 0 || (C2_ == 16 && EXTRA_ && CO_ % 4 == 0), "pair: 16-wide second product on 32-row tiles");
   static constexpr bool k16 = (CO == 16);
   static constexpr int TM = k16 ? 16 : 32;
   static constexpr int KSTEP = k16 ? 4 : 2;
@@ -79,6 +85,12 @@ __global__ __launch_bounds__(64 * C::WPW) void pointwise_fwd_kernel(Conv3dFwdArg
     for (int e = tid; e < C::CI * C::CO / 4; e += 64 * C::WPW)
       *reinterpret_cast<float4 *>(lds + e * 4) = *reinterpret_cast<const float4 *>(p.w + (size_t)e * 4);
     __syncthreads();
+  }
+
+  float breg2[C::PAIR ? C::KK2 : 1];
+  if constexpr (C::PAIR) {
+#pragma unroll
+    for (int kk = 0; kk < C::KK2; ++kk) breg2[kk] = p.w2[(size_t)(kk * 4 + (lane >> 4)) * C::C2 + (lane & 15)];
   }
 
   const long long ntiles = (rows_total + C::ROWS - 1) / C::ROWS;
@@ -263,6 +275,43 @@ __global__ __launch_bounds__(64 * C::WPW) void pointwise_fwd_kernel(Conv3dFwdArg
         float4 *y4 = reinterpret_cast<float4 *>(p.y) + t4;
 #pragma unroll
         for (int q = 0; q < C::NOUT; ++q) y4[q * 64 + lane] = v[q];
+      }
+      if constexpr (C::PAIR) {
+        // the activated tile back into the slab, second product from there
+#pragma unroll
+        for (int q = 0; q < C::NOUT; ++q) {
+          const int f = q * 64 + lane;
+          *reinterpret_cast<float4 *>(slab + (f / (C::CO / 4)) * C::OS + (f % (C::CO / 4)) * 4) = v[q];
+        }
+        f32x4 acc2[C::MT2];
+#pragma unroll
+        for (int m = 0; m < C::MT2; ++m) acc2[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int li2 = lane & 15, lk2 = lane >> 4;
+#pragma unroll
+        for (int kk = 0; kk < C::KK2; ++kk) {
+          float a2[C::MT2];
+#pragma unroll
+          for (int m = 0; m < C::MT2; ++m) a2[m] = slab[(m * 16 + li2) * C::OS + kk * 4 + lk2];
+#pragma unroll
+          for (int m = 0; m < C::MT2; ++m) acc2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[m], breg2[kk], acc2[m], 0, 0, 0);
+        }
+        const float sh2 = p.shift2 ? p.shift2[li2] : 0.f;
+#pragma unroll
+        for (int m = 0; m < C::MT2; ++m)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) slab[(m * 16 + lk2 * 4 + r) * C::OS2 + li2] = acc2[m][r] + sh2;
+        const size_t t42 = (size_t)row0 * (C::C2 / 4);
+#pragma unroll
+        for (int q = 0; q < C::NOUT2; ++q) {
+          const int f = q * 64 + lane;
+          float4 o = *reinterpret_cast<const float4 *>(slab + (f / (C::C2 / 4)) * C::OS2 + (f % (C::C2 / 4)) * 4);
+          if (p.relu2) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+          if (p.mask2) {
+            const float4 m = (reinterpret_cast<const float4 *>(p.mask2) + t42)[f];
+            o.x = m.x > 0.f ? o.x : 0.f; o.y = m.y > 0.f ? o.y : 0.f; o.z = m.z > 0.f ? o.z : 0.f; o.w = m.w > 0.f ? o.w : 0.f;
+          }
+          (reinterpret_cast<float4 *>(p.y2) + t42)[f] = o;
+        }
       }
     } else {
       // ragged last tile: per-element predicates (at most one tile per launch)
@@ -470,6 +519,20 @@ int launch_pw_fwd_impl(const Conv3dFwdArgs &a, hipStream_t stream) {
   return mr3d_launch_status();
 }
 
+template <int CI, int CO, int C2>
+int launch_pw_pair(const Conv3dFwdArgs &a, hipStream_t stream) {
+  using C = PwCfg<CI, CO, true, C2>;
+  if (set_lds_attr<C>(pointwise_fwd_kernel<C>) != MR3D_OK) return MR3D_ERR_LAUNCH;
+  const long long rows = (long long)a.N * a.Do * a.Ho * a.Wo;
+  const long long ntiles = rows / C::ROWS;
+  constexpr int lds_wgs = (160 * 1024) / C::LDS_BYTES < 1 ? 1 : (160 * 1024) / C::LDS_BYTES;
+  const int wg_per_cu = lds_wgs < 8 ? lds_wgs : 8;
+  long long grid = (long long)num_cus() * wg_per_cu;
+  if (grid > ntiles) grid = ntiles;
+  pointwise_fwd_kernel<C><<<(unsigned)grid, 64 * C::WPW, C::LDS_BYTES, stream>>>(a, rows);
+  return mr3d_launch_status();
+}
+
 template <int CI, int CO>
 int launch_pw_fwd(const Conv3dFwdArgs &a, hipStream_t stream) {
   if (a.add1 || a.add2 || a.mask || a.up) return launch_pw_fwd_impl<CI, CO, true>(a, stream);
@@ -526,6 +589,15 @@ int mr3d_pointwise_fwd_try(const Conv3dFwdArgs &a, hipStream_t stream, bool prob
     case 128064: return launch_pw_fwd<128, 64>(a, stream);
   }
   return MR3D_ERR_UNSUPPORTED;
+}
+
+int mr3d_pointwise_pair_stream_try(const Conv3dFwdArgs &a, int c2, hipStream_t stream, bool probe_only) {
+  const long long rows = (long long)a.N * a.Do * a.Ho * a.Wo;
+  // whole 32-row tiles only (the ragged-tile path of the kernel has no second product); the HBM-bound layer1 shape
+  if (a.Cin != 16 || a.Cout != 64 || c2 != 16 || rows < 32768 || rows > 0x7fffffffLL || rows % 32 != 0) return MR3D_ERR_UNSUPPORTED;
+  if (a.up || a.add2 || a.D != a.Do || a.H != a.Ho || a.W != a.Wo) return MR3D_ERR_UNSUPPORTED;
+  if (probe_only) return MR3D_OK;
+  return launch_pw_pair<16, 64, 16>(a, stream);
 }
 
 int mr3d_pointwise_wgrad_try(const Conv3dWgradArgs &a, hipStream_t stream) {

@@ -195,9 +195,27 @@ int launch_pair(const PwPairArgs &a, hipStream_t stream) {
 
 }  // namespace
 
+namespace {
+// the HBM-bound regime (>= 32k positions): the streaming kernel of pointwise.hip with its second product (16 -> 64 -> 16, layer1)
+Conv3dFwdArgs stream_args(const mr3d_pw_pair_desc *d) {
+  Conv3dFwdArgs a{};
+  a.x = d->x; a.w = d->w1; a.y = d->y1; a.shift = d->shift1; a.add1 = d->add1; a.add2 = nullptr; a.up = nullptr; a.mask = d->mask1;
+  a.N = 1; a.D = 1; a.H = 1; a.W = (int)d->positions; a.Cin = d->c0; a.Do = 1; a.Ho = 1; a.Wo = (int)d->positions; a.Cout = d->c1;
+  a.pd = a.ph = a.pw = 0; a.Du = a.Hu = a.Wu = 0; a.relu = d->relu1; a.up_even = 0;
+  a.ysd = a.ysh = a.ysw = 1; a.yD = 1; a.yH = 1; a.yW = (int)d->positions;
+  a.w2 = d->w2; a.shift2 = d->shift2; a.mask2 = d->mask2; a.y2 = d->y2; a.relu2 = d->relu2;
+  return a;
+}
+}  // namespace
+
 extern "C" int mr3d_pointwise_pair_supported(int c0, int c1, int c2, long long positions) {
-  // the small maps only: from 32k positions on the streaming kernels of pointwise.hip are HBM-bound and better served
-  if (positions <= 0 || positions >= 32768) return 0;
+  if (positions <= 0 || positions > 0x7fffffffLL) return 0;
+  if (positions >= 32768) {
+    Conv3dFwdArgs a{};
+    a.N = 1; a.D = a.H = a.Do = a.Ho = 1; a.W = a.Wo = (int)positions; a.Cin = c0; a.Cout = c1;
+    return mr3d_pointwise_pair_stream_try(a, c2, nullptr, true) == MR3D_OK;
+  }
+  // the small maps: the workgroup-tile kernel below
   // layer3 only: at 128 / 512 / 128 (layer4: 40 workgroups of 32 positions) a wave cannot hold its weight fragments and
   // streaming 512 KB of weights per workgroup chunk by chunk measured 70 us against 22 us for the two separate launches
   return c0 == 64 && c1 == 256 && c2 == 64;
@@ -206,6 +224,7 @@ extern "C" int mr3d_pointwise_pair_supported(int c0, int c1, int c2, long long p
 extern "C" int mr3d_pointwise_pair(const mr3d_pw_pair_desc *d, mr3d_stream_t stream_) {
   if (!d || !d->x || !d->w1 || !d->y1 || !d->w2 || !d->y2 || d->positions <= 0) return MR3D_ERR_INVALID_ARG;
   if (!mr3d_pointwise_pair_supported(d->c0, d->c1, d->c2, d->positions)) return MR3D_ERR_UNSUPPORTED;
+  if (d->positions >= 32768) return mr3d_pointwise_pair_stream_try(stream_args(d), d->c2, mr3d_stream(stream_));
   PwPairArgs a;
   a.x = d->x; a.w1 = d->w1; a.shift1 = d->shift1; a.add1 = d->add1; a.mask1 = d->mask1; a.y1 = d->y1;
   a.w2 = d->w2; a.shift2 = d->shift2; a.mask2 = d->mask2; a.y2 = d->y2;

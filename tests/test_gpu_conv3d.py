@@ -459,7 +459,7 @@ def test_conv3d_wgrad_winograd_path_ragged_volume(dev):
     assert rel(dw, 2 * ref) <= RTOL
 
 
-@pytest.mark.parametrize('c0,c1,c2,P', [(64, 256, 64, 10240), (64, 256, 64, 77), (64, 256, 64, 32)])
+@pytest.mark.parametrize('c0,c1,c2,P', [(64, 256, 64, 10240), (64, 256, 64, 77), (64, 256, 64, 32), (16, 64, 16, 65536), (16, 64, 16, 32768 + 32 * 7)])
 @pytest.mark.parametrize('mode', ['forward', 'backward'])
 def test_pointwise_pair_vs_fp64(dev, c0, c1, c2, P, mode):
     """mr3d_pointwise_pair (csrc/pw_pair.hip): conv3 + identity + ReLU -> next conv1 + ReLU (forward) and conv1^T + residual
@@ -485,7 +485,9 @@ def test_pointwise_pair_vs_fp64(dev, c0, c1, c2, P, mode):
     xd, w1d, w2d, ad, s1, s2, m1d, m2d = d(x), d(w1), d(w2), d(add1), d(sh1), d(sh2), d(m1), d(m2)
     o1 = torch.full((P, c1), 7.0, device=dev)
     o2 = torch.full((P, c2), 7.0, device=dev)
-    assert _hip.pw_pair_supported(c0, c1, c2, P) and not _hip.pw_pair_supported(c0, c1, c2, 40000) and not _hip.pw_pair_supported(16, 64, 16, P)
+    # small maps: the workgroup-tile kernel (64 / 256 / 64); >= 32k positions in whole 32-row tiles: the streaming kernel (16 / 64 / 16)
+    assert _hip.pw_pair_supported(c0, c1, c2, P) and not _hip.pw_pair_supported(64, 256, 64, 40000) and not _hip.pw_pair_supported(16, 64, 16, 1024)
+    assert not _hip.pw_pair_supported(16, 64, 16, 32768 + 5)
     op = _hip.make_pw_pair_op(xd, w1d, s1, ad, m1d, o1, w2d, s2, m2d, o2, c0, c1, c2, mode == 'forward', mode == 'forward', P)
     _hip.Plan([op]).run(dev)
     torch.cuda.synchronize()
