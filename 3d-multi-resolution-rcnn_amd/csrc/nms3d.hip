@@ -380,10 +380,23 @@ constexpr int kRegSlots = 4;        // ceil(30 * 31 / 2 * 8 items / 960 threads)
 constexpr int kRegSlotsR = 2;       // slots held in registers; the rest in LDS as [slot][row][thread]
 constexpr size_t kRegLdsBytes = sizeof(uint64_t) * (3 * kRegMaxCb + kRegMaxCb * 64 + (kRegSlots - kRegSlotsR) * kRowsPerItem * kRegThreads);
 
-__device__ __forceinline__ uint64_t wave_or64(uint64_t v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v |= shfl_xor64(v, o);
+// OR over the 64 lanes (wave-uniform result): four DPP row rotations leave every lane with the OR of its row of 16 (OR is
+// idempotent, so rotations instead of a scan), four v_readlane per half combine the rows.  A butterfly of 12 dependent
+// ds_bpermute round trips made the resolver's chain longer than the barrier it saved.
+__device__ __forceinline__ uint32_t row_or32(uint32_t v) {
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xf, 0xf, false);      // row_ror:1
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xf, 0xf, false);      // row_ror:2
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false);      // row_ror:4
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);      // row_ror:8
   return v;
+}
+__device__ __forceinline__ uint64_t wave_or64(uint64_t v) {
+  const uint32_t lo = row_or32((uint32_t)v), hi = row_or32((uint32_t)(v >> 32));
+  const uint32_t l = (uint32_t)(__builtin_amdgcn_readlane((int)lo, 0) | __builtin_amdgcn_readlane((int)lo, 16) |
+                                __builtin_amdgcn_readlane((int)lo, 32) | __builtin_amdgcn_readlane((int)lo, 48));
+  const uint32_t h = (uint32_t)(__builtin_amdgcn_readlane((int)hi, 0) | __builtin_amdgcn_readlane((int)hi, 16) |
+                                __builtin_amdgcn_readlane((int)hi, 32) | __builtin_amdgcn_readlane((int)hi, 48));
+  return ((uint64_t)h << 32) | l;
 }
 
 __global__ __launch_bounds__(kRegThreads) void nms3d_sweep_reg_kernel(const uint64_t *__restrict__ mask_all,
@@ -447,7 +460,10 @@ __global__ __launch_bounds__(kRegThreads) void nms3d_sweep_reg_kernel(const uint
   }
   __syncthreads();
   uint64_t crit = 0;                                   // resolver: block b-1's suppression of block b (wave-uniform)
-  for (int b = 0; b <= cb; ++b) {
+  // fully unrolled over the (at most 33) steps: the resolver's crit_col[b] is then a plain register, not a 31-way select
+#pragma unroll
+  for (int b = 0; b <= kRegMaxCb; ++b) {
+    if (b > cb) break;
     if (wave == 0) {
       if (b < cb) {
         const uint64_t d = diag[b * 64 + lane];
@@ -464,11 +480,8 @@ __global__ __launch_bounds__(kRegThreads) void nms3d_sweep_reg_kernel(const uint
         }
         const uint64_t kept = ~cur & valid;
         if (lane == 0) keptb[b] = kept;
-        uint64_t mine = 0;
-#pragma unroll
-        for (int j = 0; j < kRegMaxCb - 1; ++j)
-          if (j == b) mine = crit_col[j];
-        crit = mr3d_uniform64(wave_or64(((kept >> lane) & 1ull) ? mine : 0ull));
+        const uint64_t mine = b < kRegMaxCb - 1 ? crit_col[b < kRegMaxCb - 1 ? b : 0] : 0ull;
+        crit = wave_or64(((kept >> lane) & 1ull) ? mine : 0ull);
       }
     } else if (b >= 1) {
       const int pb = b - 1;                            // the block whose kept rows are applied now
