@@ -363,42 +363,15 @@ __global__ __launch_bounds__(kSweepThreads) void nms3d_sweep_fast_kernel(const u
 
 // ---- greedy sweep, cb <= 32 blocks (n <= 2048: the RPN's nms_pre = 2000 sets): the whole upper triangle on chip -----------
 // Prefetching one block ahead still waits ~1 us per block for the mask rows (44 us for 32 blocks).  Here the chain never
-// touches global memory, and resolving a block overlaps applying the block before it:
-//   * wave 0 (the resolver) keeps, for every block b, the word b+1 of its 64 rows in registers (the "critical column": the only
-//     part of block b's suppression that block b+1 needs immediately).  Per block: suppressed bits = remv[b] (LDS: blocks
-//     <= b-2, complete since the last barrier) | the critical column of block b-1 (an SGPR pair); greedy resolution on the
-//     diagonal words (LDS); kept bits -> LDS; OR-reduction of the kept rows' word b+1 across the wave -> next critical column.
-//   * waves 1..15 (the appliers) own the words w >= b+2 of every block b: an item = 8 mask rows x 1 word, <= 4 items per
-//     thread, two kept in registers and two in LDS (all four in registers spilled), every load issued at the start.  While
-//     the resolver works on block b they OR block b-1's kept rows into remv[w >= b+1].
-//   * ONE barrier per block (the round-2 sweep: two dependent global round trips per block; the first on-chip version: resolve,
-//     barrier, apply, barrier -- 37 us).
+// touches global memory: 1024 threads fetch ALL words above the diagonal once -- an item = 8 mask rows x 1 word, <= 4 items
+// per thread, two of them kept in registers and two in LDS (128 KB; all four in registers spill) -- with every load in
+// flight at the same time; then per block: wave 0 resolves the diagonal from LDS, one barrier, the threads that own items
+// of this block OR their kept rows into the later blocks' suppression words in LDS, one barrier.
 constexpr int kRegThreads = 1024;
-constexpr int kRegAppliers = kRegThreads - 64;
 constexpr int kRegMaxCb = 32;
-constexpr int kRegSlots = 4;        // ceil(30 * 31 / 2 * 8 items / 960 threads)
+constexpr int kRegSlots = 4;        // ceil(31 * 32 / 2 * 8 items / 1024 threads)
 constexpr int kRegSlotsR = 2;       // slots held in registers; the rest in LDS as [slot][row][thread]
 constexpr size_t kRegLdsBytes = sizeof(uint64_t) * (3 * kRegMaxCb + kRegMaxCb * 64 + (kRegSlots - kRegSlotsR) * kRowsPerItem * kRegThreads);
-
-// OR over the 64 lanes (wave-uniform result): four DPP row rotations leave every lane with the OR of its row of 16 (OR is
-// idempotent, so rotations instead of a scan), four v_readlane per half combine the rows.  A butterfly of 12 dependent
-// ds_bpermute round trips made the resolver's chain longer than the barrier it saved.
-__device__ __forceinline__ uint32_t row_or32(uint32_t v) {
-  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xf, 0xf, false);      // row_ror:1
-  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xf, 0xf, false);      // row_ror:2
-  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false);      // row_ror:4
-  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);      // row_ror:8
-  return v;
-}
-__device__ __forceinline__ uint64_t wave_or64(uint64_t v) {
-  const uint32_t lo = row_or32((uint32_t)v), hi = row_or32((uint32_t)(v >> 32));
-  const uint32_t l = (uint32_t)(__builtin_amdgcn_readlane((int)lo, 0) | __builtin_amdgcn_readlane((int)lo, 16) |
-                                __builtin_amdgcn_readlane((int)lo, 32) | __builtin_amdgcn_readlane((int)lo, 48));
-  const uint32_t h = (uint32_t)(__builtin_amdgcn_readlane((int)hi, 0) | __builtin_amdgcn_readlane((int)hi, 16) |
-                                __builtin_amdgcn_readlane((int)hi, 32) | __builtin_amdgcn_readlane((int)hi, 48));
-  return ((uint64_t)h << 32) | l;
-}
-
 __global__ __launch_bounds__(kRegThreads) void nms3d_sweep_reg_kernel(const uint64_t *__restrict__ mask_all,
                                                                      const int *__restrict__ order_all, SegTable seg,
                                                                      int64_t *__restrict__ keep_all,
@@ -419,36 +392,25 @@ __global__ __launch_bounds__(kRegThreads) void nms3d_sweep_reg_kernel(const uint
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid < 3 * kRegMaxCb) sm[tid] = 0;
   for (int r = tid; r < cb * 64; r += kRegThreads) diag[r] = r < n ? mask[(size_t)r * cb + (r >> 6)] : 0ull;
+  // item id -> (block b, word w > b, row group g): ids run block by block; block b has (cb - 1 - b) * 8 items
   constexpr int G = 64 / kRowsPerItem;
   uint64_t rows[kRegSlotsR][kRowsPerItem];
-  uint64_t crit_col[kRegMaxCb - 1];    // resolver: word b+1 of row (b*64 + lane)
-  int meta[kRegSlots];                 // appliers: b << 16 | w << 8 | g, or -1
+  int meta[kRegSlots];                 // b << 16 | w << 8 | g, or -1
 #pragma unroll
-  for (int s_ = 0; s_ < kRegSlots; ++s_) meta[s_] = -1;
-  if (wave == 0) {
+  for (int s_ = kRegSlots - 1; s_ >= 0; --s_) {      // the LDS-resident slots first: their data passes through registers
+    int id = s_ * kRegThreads + tid, b = 0;
+    while (b < cb && id >= (cb - 1 - b) * G) { id -= (cb - 1 - b) * G; ++b; }
+    const bool on = b < cb - 1;
+    const int later = cb - 1 - b;
+    const int w = on ? b + 1 + id % later : 0, g = on ? id / later : 0;
+    meta[s_] = on ? (b << 16 | w << 8 | g) : -1;
+    const unsigned off = (unsigned)((b * 64 + g * kRowsPerItem) * cb + w);
 #pragma unroll
-    for (int b = 0; b < kRegMaxCb - 1; ++b) {
-      const int row = b * 64 + lane;
-      crit_col[b] = (b + 1 < cb && row < n) ? mask[(size_t)row * cb + b + 1] : 0ull;
-    }
-  } else {
-    // item id -> (block b, word w >= b+2, row group g): ids run block by block; block b has (cb - 2 - b) * 8 items
-#pragma unroll
-    for (int s_ = kRegSlots - 1; s_ >= 0; --s_) {      // the LDS-resident slots first: their data passes through registers
-      int id = s_ * kRegAppliers + (tid - 64), b = 0;
-      while (b < cb && id >= (cb - 2 - b) * G) { id -= (cb - 2 - b) * G > 0 ? (cb - 2 - b) * G : 0; ++b; }
-      const bool on = b < cb - 2;
-      const int later = cb - 2 - b;
-      const int w = on ? b + 2 + id % later : 0, g = on ? id / later : 0;
-      meta[s_] = on ? (b << 16 | w << 8 | g) : -1;
-      const unsigned off = (unsigned)((b * 64 + g * kRowsPerItem) * cb + w);
-#pragma unroll
-      for (int q = 0; q < kRowsPerItem; ++q) {
-        const int row = b * 64 + g * kRowsPerItem + q;
-        const uint64_t v = (on && row < n) ? mask[off + (unsigned)(q * cb)] : 0ull;
-        if (s_ >= kRegSlotsR) lrows[((s_ - kRegSlotsR) * kRowsPerItem + q) * kRegThreads + tid] = v;
-        else rows[s_][q] = v;
-      }
+    for (int q = 0; q < kRowsPerItem; ++q) {
+      const int row = b * 64 + g * kRowsPerItem + q;
+      const uint64_t v = (on && row < n) ? mask[off + (unsigned)(q * cb)] : 0ull;
+      if (s_ >= kRegSlotsR) lrows[((s_ - kRegSlotsR) * kRowsPerItem + q) * kRegThreads + tid] = v;
+      else rows[s_][q] = v;
     }
   }
   int blk_lo[kRegSlots], blk_hi[kRegSlots];            // wave-uniform block range of each slot (an idle lane has meta = -1)
@@ -459,47 +421,40 @@ __global__ __launch_bounds__(kRegThreads) void nms3d_sweep_reg_kernel(const uint
     blk_hi[s_] = first < 0 ? -1 : (last < 0 ? cb : (last >> 16));
   }
   __syncthreads();
-  uint64_t crit = 0;                                   // resolver: block b-1's suppression of block b (wave-uniform)
-  // fully unrolled over the (at most 33) steps: the resolver's crit_col[b] is then a plain register, not a 31-way select
-#pragma unroll
-  for (int b = 0; b <= kRegMaxCb; ++b) {
-    if (b > cb) break;
+  for (int b = 0; b < cb; ++b) {
     if (wave == 0) {
-      if (b < cb) {
-        const uint64_t d = diag[b * 64 + lane];
-        const int nr = min(64, n - b * 64);
-        const uint64_t valid = (nr == 64) ? ~0ull : ((1ull << nr) - 1ull);
-        uint64_t cur = mr3d_uniform64(remv[b]) | crit;
-        uint64_t cand = (uint64_t)__ballot(d != 0ull) & ~cur & valid;
-        while (cand) {
-          const int t = __builtin_ctzll(cand);
-          const uint64_t dd = mr3d_readlane64(d, t);
-          cur |= dd;
-          cand &= ~dd;
-          cand &= ~(1ull << t);
-        }
-        const uint64_t kept = ~cur & valid;
-        if (lane == 0) keptb[b] = kept;
-        const uint64_t mine = b < kRegMaxCb - 1 ? crit_col[b < kRegMaxCb - 1 ? b : 0] : 0ull;
-        crit = wave_or64(((kept >> lane) & 1ull) ? mine : 0ull);
+      const uint64_t d = diag[b * 64 + lane];
+      const int nr = min(64, n - b * 64);
+      const uint64_t valid = (nr == 64) ? ~0ull : ((1ull << nr) - 1ull);
+      uint64_t cur = mr3d_uniform64(remv[b]);
+      uint64_t cand = (uint64_t)__ballot(d != 0ull) & ~cur & valid;
+      while (cand) {
+        const int t = __builtin_ctzll(cand);
+        const uint64_t dd = mr3d_readlane64(d, t);
+        cur |= dd;
+        cand &= ~dd;
+        cand &= ~(1ull << t);
       }
-    } else if (b >= 1) {
-      const int pb = b - 1;                            // the block whose kept rows are applied now
-      const uint64_t kept = keptb[pb];
-#pragma unroll
-      for (int s_ = 0; s_ < kRegSlots; ++s_)
-        if (pb >= blk_lo[s_] && pb <= blk_hi[s_] && (meta[s_] >> 16) == pb) {
-          const int w = (meta[s_] >> 8) & 255, g = meta[s_] & 255;
-          const unsigned kb = (unsigned)(kept >> (g * kRowsPerItem)) & 255u;
-          uint64_t acc = 0;
-#pragma unroll
-          for (int q = 0; q < kRowsPerItem; ++q) {
-            const uint64_t v = s_ >= kRegSlotsR ? lrows[((s_ - kRegSlotsR) * kRowsPerItem + q) * kRegThreads + tid] : rows[s_ < kRegSlotsR ? s_ : 0][q];
-            acc |= ((kb >> q) & 1u) ? v : 0ull;
-          }
-          if (acc) atomicOr((unsigned long long *)&remv[w], (unsigned long long)acc);
-        }
+      if (lane == 0) keptb[b] = ~cur & valid;
     }
+    __syncthreads();
+    const uint64_t kept = keptb[b];
+    // a wave's 64 items of one slot are consecutive ids, i.e. they belong to one block or two neighbouring ones: the test
+    // whether ANY of them is due is two scalar compares (16 waves evaluating four per-lane tests per block was the largest
+    // share of the loop)
+#pragma unroll
+    for (int s_ = 0; s_ < kRegSlots; ++s_)
+      if (b >= blk_lo[s_] && b <= blk_hi[s_] && (meta[s_] >> 16) == b) {
+        const int w = (meta[s_] >> 8) & 255, g = meta[s_] & 255;
+        const unsigned kb = (unsigned)(kept >> (g * kRowsPerItem)) & 255u;
+        uint64_t acc = 0;
+#pragma unroll
+        for (int q = 0; q < kRowsPerItem; ++q) {
+          const uint64_t v = s_ >= kRegSlotsR ? lrows[((s_ - kRegSlotsR) * kRowsPerItem + q) * kRegThreads + tid] : rows[s_ < kRegSlotsR ? s_ : 0][q];
+          acc |= ((kb >> q) & 1u) ? v : 0ull;
+        }
+        if (acc) atomicOr((unsigned long long *)&remv[w], (unsigned long long)acc);
+      }
     __syncthreads();
   }
   for (int r = tid; r < n; r += kRegThreads)
