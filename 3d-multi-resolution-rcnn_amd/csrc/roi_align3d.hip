@@ -640,7 +640,7 @@ struct SepCfg {
 };
 
 template <typename T, class S>
-__global__ __launch_bounds__(kClThreads) void roi_align3d_fwd_sep(const T *feat, float *__restrict__ out, const float *__restrict__ rois,
+__global__ __launch_bounds__(kClThreads, 2) void roi_align3d_fwd_sep(const T *feat, float *__restrict__ out, const float *__restrict__ rois,
                                                                  float scale, float scale_d, int ns, int C, int D, int H, int W,
                                                                  int PD, int PH, int PW, LevelTable lt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sp_lds[];
@@ -694,8 +694,12 @@ __global__ __launch_bounds__(kClThreads) void roi_align3d_fwd_sep(const T *feat,
     // everything about a thread's items that does not depend on the plane is worked out once: the kernel is issue-bound, and an
     // integer division by the (runtime) PW per item and plane was a large share of its instructions
     const int q4 = tid & 3, w64 = tid >> 2;
+    constexpr int U = sizeof(T) == 4 ? 2 : 4;                    // stage-1 items per thread and batch (fp32: 2, for two waves per SIMD)
     const int yy_w = w64 / PW, pw_w = w64 - yy_w * PW, q64 = 64 / PW, r64 = 64 - q64 * PW;
-    int t1lo[S::J][2], t1hi[S::J][2];                            // T1 element offsets of item j's two y-samples (-1: sample out of range)
+    // T1 element offsets of the two rows of item j's two y-samples, (hi << 16) | lo: every register counts here -- 281 of them
+    // meant one wave per SIMD, and the kernel lives on hiding its plane-by-plane round trips behind other waves
+    unsigned t1[S::J][2];
+    static_assert(S::T1CAP * kSepCh <= 0xffff, "T1 offsets are packed in 16 bits");
     float wyh[S::J][2], wyl[S::J][2];
 #pragma unroll
     for (int j = 0; j < S::J; ++j) {
@@ -705,8 +709,7 @@ __global__ __launch_bounds__(kClThreads) void roi_align3d_fwd_sep(const T *feat,
       for (int i = 0; i < 2; ++i) {
         const IdxEntry ty = taby[ph * 2 + i];
         const bool on = item < PHW && ty.l + ty.h != 0.f;
-        t1lo[j][i] = on ? ((ty.lo - y0) * PW + pw) * kSepCh + ch : 0;
-        t1hi[j][i] = on ? ((ty.hi - y0) * PW + pw) * kSepCh + ch : 0;
+        t1[j][i] = on ? (unsigned)(((ty.lo - y0) * PW + pw) * kSepCh + ch) | ((unsigned)(((ty.hi - y0) * PW + pw) * kSepCh + ch) << 16) : 0u;
         wyh[j][i] = on ? ty.h : 0.f;
         wyl[j][i] = on ? ty.l : 0.f;
       }
@@ -716,17 +719,17 @@ __global__ __launch_bounds__(kClThreads) void roi_align3d_fwd_sep(const T *feat,
       float *T1 = body + buf * (S::T1CAP * kSepCh);
       // ---- stage 1: x-contraction of plane z, rows y0 .. y0+ny-1.  A thread = (channel quad, one of 64 workers): its four
       // taps are 16-byte loads (4 lanes cover the 64 bytes of a position's 16 channels; one channel per lane was 4x the
-      // load instructions and 7 dependent L2 round trips per plane for a 28-row footprint, now 2).  Four items per thread and
+      // load instructions and 7 dependent L2 round trips per plane for a 28-row footprint, now 2).  U items per thread and
       // batch, all 16 tap loads issued before the first is used.
       {
         const T *fq = feat + (base_n - ch) + q4 * 4;
         int yy_u = yy_w, pw_u = pw_w;                            // (row, bin) of item w64; + 64 per step without a division
-        for (int it0 = 0; it0 < ny * PW; it0 += 256) {
-          float4 v[4][4];
-          float w[4][4];
-          int yy4[4], pw4[4];
+        for (int it0 = 0; it0 < ny * PW; it0 += 64 * U) {
+          float4 v[U][4];
+          float w[U][4];
+          int yy4[U], pw4[U];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
+          for (int u = 0; u < U; ++u) {
             const int item = it0 + w64 + 64 * u;
             const bool ok = item < ny * PW;
             yy4[u] = ok ? yy_u : 0; pw4[u] = ok ? pw_u : 0;
@@ -742,7 +745,7 @@ __global__ __launch_bounds__(kClThreads) void roi_align3d_fwd_sep(const T *feat,
             }
           }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
+          for (int u = 0; u < U; ++u) {
             const int item = it0 + w64 + 64 * u;
             if (item < ny * PW) {
               float4 o;
@@ -771,7 +774,8 @@ __global__ __launch_bounds__(kClThreads) void roi_align3d_fwd_sep(const T *feat,
 #pragma unroll
       for (int j = 0; j < S::J; ++j) {
         // (a sample that is out of range, or an item beyond PHW, carries zero weights and reads T1 element 0)
-        const float t2 = (wyh[j][0] * T1[t1lo[j][0]] + wyl[j][0] * T1[t1hi[j][0]]) + (wyh[j][1] * T1[t1lo[j][1]] + wyl[j][1] * T1[t1hi[j][1]]);
+        const float t2 = (wyh[j][0] * T1[t1[j][0] & 0xffffu] + wyl[j][0] * T1[t1[j][0] >> 16]) +
+                         (wyh[j][1] * T1[t1[j][1] & 0xffffu] + wyl[j][1] * T1[t1[j][1] >> 16]);
 #pragma unroll
         for (int a = 0; a < S::PDC; ++a) acc[a][j] += wz[a] * t2;
       }
