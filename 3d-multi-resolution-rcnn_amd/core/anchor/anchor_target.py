@@ -27,12 +27,14 @@ def _get(cfg, k):
 
 
 def anchor_target_single(flat_anchors, valid_flags, gt_bboxes, gt_bboxes_ignore, gt_labels, img_meta, target_means, target_stds,
-                         cfg, label_channels=1, sampling=True, unmap_outputs=True, draws=None):
-    """-> labels, label_weights, bbox_targets, bbox_weights (full anchor set), counts (i32 [4] device), inside_flags"""
+                         cfg, label_channels=1, sampling=True, unmap_outputs=True, draws=None, inside_flags=None):
+    """-> labels, label_weights, bbox_targets, bbox_weights (full anchor set), counts (i32 [4] device), inside_flags.
+    inside_flags: precomputed anchor_inside_flags of this geometry (they depend on shapes only; RPNHead3D caches them)."""
     if not sampling:
         raise NotImplementedError('sampling=False (focal loss) is not on the shipped path (use_focal_loss=False)')
     assert unmap_outputs, 'targets are produced for the full anchor set'
-    inside_flags = anchor_inside_flags(flat_anchors, valid_flags, img_meta['img_shape'], _get(cfg, 'allowed_border'))
+    if inside_flags is None:
+        inside_flags = anchor_inside_flags(flat_anchors, valid_flags, img_meta['img_shape'], _get(cfg, 'allowed_border'))
     assigner, sampler = build_assigner(_get(cfg, 'assigner')), build_sampler(_get(cfg, 'sampler'))
     assert not sampler.add_gt_as_proposals, 'RPN sampling never adds the gts (configs/...py:100)'
     gt = gt_bboxes.float()
@@ -47,7 +49,7 @@ def anchor_target_single(flat_anchors, valid_flags, gt_bboxes, gt_bboxes_ignore,
 
 def images_to_levels(target, num_level_anchors):
     """anchor_target.py:98-111"""
-    target = torch.stack(target, 0)
+    target = torch.stack(target, 0) if len(target) > 1 else target[0].unsqueeze(0)      # one image: a view, no copy
     level_targets, start = [], 0
     for n in num_level_anchors:
         level_targets.append(target[:, start:start + n].squeeze(0))
@@ -57,10 +59,14 @@ def images_to_levels(target, num_level_anchors):
 
 def anchor_target(anchor_list, valid_flag_list, gt_bboxes_list, img_metas, target_means, target_stds, cfg,
                   gt_bboxes_ignore_list=None, gt_labels_list=None, label_channels=1, sampling=True, unmap_outputs=True,
-                  iteration=None, draws_list=None):
+                  iteration=None, draws_list=None, inside_flags_list=None, num_level_anchors=None):
+    """anchor_list[i]: the per-level anchors of image i, or their concatenation (then pass num_level_anchors)"""
     num_imgs = len(img_metas)
     assert len(anchor_list) == len(valid_flag_list) == num_imgs
-    num_level_anchors = [a.size(0) for a in anchor_list[0]]
+    if num_level_anchors is None:
+        num_level_anchors = [a.size(0) for a in anchor_list[0]]
+    if inside_flags_list is None:
+        inside_flags_list = [None] * num_imgs
     flat_anchors = [torch.cat(a) if isinstance(a, (list, tuple)) else a for a in anchor_list]
     flat_flags = [torch.cat(v) if isinstance(v, (list, tuple)) else v for v in valid_flag_list]
     if gt_bboxes_ignore_list is None:
@@ -71,7 +77,7 @@ def anchor_target(anchor_list, valid_flag_list, gt_bboxes_list, img_metas, targe
         draws_list = [None] * num_imgs
     res = [anchor_target_single(flat_anchors[i], flat_flags[i], gt_bboxes_list[i], gt_bboxes_ignore_list[i], gt_labels_list[i],
                                 img_metas[i], target_means, target_stds, cfg, label_channels, sampling, unmap_outputs,
-                                draws=draws_list[i]) for i in range(num_imgs)]
+                                draws=draws_list[i], inside_flags=inside_flags_list[i]) for i in range(num_imgs)]
     all_labels, all_label_weights, all_bbox_targets, all_bbox_weights, counts, inside, _, _ = (list(x) for x in zip(*res))
     counts = torch.stack(counts)                                              # [num_imgs, 4] on the device
     one = counts.new_ones(())

@@ -161,22 +161,46 @@ class RPNHead3D(nn.Module):
 
     # ------------------------------------------------------------------ training (anchor_head_3d.py:83-230)
     def get_anchors(self, featmap_sizes, img_metas, device='cuda'):
-        """anchor_head_3d.py:83-123; the multi-level anchors of a pyramid shape are generated once and cached"""
+        """anchor_head_3d.py:83-123.  Anchors and valid flags are functions of the pyramid shape and of the images' padded
+        shapes only, so both are generated once per such geometry and cached (the reference rebuilds them every step:
+        ~45 tiny launches for the flags of five levels)."""
         key = (tuple(tuple(int(v) for v in fs) for fs in featmap_sizes), str(device))
         if getattr(self, '_anchor_cache_key', None) != key:
             self._anchor_cache = [g.grid_anchors(fs, s, d, device=device) for g, fs, s, d in
                                   zip(self.anchor_generators, featmap_sizes, self.anchor_strides, self.anchor_strides_depth)]
             self._anchor_cache_key = key
+            self._flag_cache = {}
         anchor_list = [list(self._anchor_cache) for _ in img_metas]
         valid_flag_list = []
         for meta in img_metas:
-            flags = []
-            for g, (fz, fh, fw), s, ds in zip(self.anchor_generators, featmap_sizes, self.anchor_strides, self.anchor_strides_depth):
-                h, w, _, z = meta['pad_shape']
-                valid = (min(int(np.ceil(z / ds)), fz), min(int(np.ceil(h / s)), fh), min(int(np.ceil(w / s)), fw))
-                flags.append(g.valid_flags((fz, fh, fw), valid, device=device))
-            valid_flag_list.append(flags)
+            pad = tuple(int(v) for v in meta['pad_shape'])
+            if pad not in self._flag_cache:
+                flags = []
+                for g, (fz, fh, fw), s, ds in zip(self.anchor_generators, featmap_sizes, self.anchor_strides, self.anchor_strides_depth):
+                    h, w, _, z = pad
+                    valid = (min(int(np.ceil(z / ds)), fz), min(int(np.ceil(h / s)), fh), min(int(np.ceil(w / s)), fw))
+                    flags.append(g.valid_flags((fz, fh, fw), valid, device=device))
+                self._flag_cache[pad] = flags
+            valid_flag_list.append(list(self._flag_cache[pad]))
         return anchor_list, valid_flag_list
+
+    def anchor_geometry(self, featmap_sizes, img_metas, cfg, device='cuda'):
+        """Everything about the anchors that depends on shapes alone, cached per geometry: per image the flat anchors, the
+        flat valid flags and the inside flags (anchor_target.py:193-216), and the per-level inside flags in the layout
+        anchor_target returns them (what the reference caches as `self.pos_indices`, anchor_head_3d.py:212)."""
+        from ..core.anchor.anchor_target import anchor_inside_flags, images_to_levels
+        border = cfg['allowed_border'] if isinstance(cfg, dict) else cfg.allowed_border
+        key = (tuple(tuple(int(v) for v in fs) for fs in featmap_sizes), str(device), int(border),
+               tuple((tuple(int(v) for v in m['pad_shape']), tuple(int(v) for v in m['img_shape'])) for m in img_metas))
+        if getattr(self, '_geom_key', None) != key:
+            anchor_list, valid_flag_list = self.get_anchors(featmap_sizes, img_metas, device=device)
+            flat_anchors = [torch.cat(a) for a in anchor_list[:1]] * len(img_metas)        # the same tensor for every image
+            flat_flags = [torch.cat(v) for v in valid_flag_list]
+            inside = [anchor_inside_flags(a, f, m['img_shape'], border) for a, f, m in zip(flat_anchors, flat_flags, img_metas)]
+            levels = images_to_levels(inside, [a.size(0) for a in anchor_list[0]])
+            self._geom = (flat_anchors, flat_flags, inside, levels)
+            self._geom_key = key
+        return self._geom
 
     def loss_single(self, cls_score, bbox_pred, labels, label_weights, bbox_targets, bbox_weights, num_total_samples, cfg):
         """anchor_head_3d.py:125-177 (sigmoid classification, no focal loss)"""
@@ -193,12 +217,13 @@ class RPNHead3D(nn.Module):
         """rpn_head_3d.py:36-70 -> anchor_head_3d.py:179-230.  `draws_list`: per image (pos_words, neg_words) for a
         reproducible sampler; default = the device generator."""
         featmap_sizes = [tuple(f.shape[-3:]) for f in cls_scores]
-        anchor_list, valid_flag_list = self.get_anchors(featmap_sizes, img_metas, device=cls_scores[0].device)
-        (labels_list, label_weights_list, bbox_targets_list, bbox_weights_list, num_total_pos, num_total_neg, _,
-         inside_flags) = anchor_target(anchor_list, valid_flag_list, gt_bboxes, img_metas, self.target_means, self.target_stds,
-                                       cfg, gt_bboxes_ignore_list=gt_bboxes_ignore, gt_labels_list=None, label_channels=1,
-                                       sampling=True, draws_list=draws_list)
-        self.pos_indices = inside_flags                                          # anchor_head_3d.py:212
+        flat_anchors, flat_flags, inside, inside_levels = self.anchor_geometry(featmap_sizes, img_metas, cfg, cls_scores[0].device)
+        (labels_list, label_weights_list, bbox_targets_list, bbox_weights_list, num_total_pos, num_total_neg, _, _) = \
+            anchor_target(flat_anchors, flat_flags, gt_bboxes, img_metas, self.target_means, self.target_stds,
+                          cfg, gt_bboxes_ignore_list=gt_bboxes_ignore, gt_labels_list=None, label_channels=1,
+                          sampling=True, draws_list=draws_list, inside_flags_list=inside,
+                          num_level_anchors=[int(np.prod(fs)) * self.num_anchors for fs in featmap_sizes])
+        self.pos_indices = inside_levels                                         # anchor_head_3d.py:212
         num_total_samples = (num_total_pos + num_total_neg).float()             # device scalar: no read-back
         losses_cls, losses_reg = [], []
         for lvl in range(len(cls_scores)):

@@ -177,22 +177,63 @@ class TwoStageDetector3D(nn.Module):
             outs = tuple(o.to(torch.bfloat16) for o in outs)
         return outs
 
+    def forward_backward(self, *args, **kwargs):
+        """forward_train + the backward pass of the summed losses (base.py `_parse_losses` + `loss.backward()`), issued in
+        the order that keeps the device fed.  The step has ONE host wait -- the positive count that sizes the mask head's
+        batch (PosCountReadback) -- and everything enqueued behind it meets an idle device, so its launch cost is step
+        time.  `total.backward()` after forward_train puts the whole head backward (≈ 200 small launches) there.  Here
+        the RPN and bbox-head losses are differentiated down to the pyramid BEFORE the wait (their launches hide under the
+        backbone forward the device is still running), and only the mask branch and the backbone backward follow it.
+        Same gradients: every loss enters the sum with coefficient 1, and a sum's gradient is the sum of the gradients.
+        Returns the loss dict with detached values; parameter gradients are accumulated as by backward()."""
+        return self.forward_train(*args, _eager_backward=True, **kwargs)
+
     def forward_train(self, imgs, img_meta, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_masks=None, proposals=None,
-                      draws=None):
+                      draws=None, _eager_backward=False):
         """Returns the reference's loss dict (loss_rpn_cls / loss_rpn_reg lists per level, loss_cls, acc, loss_reg,
         loss_mask).  draws: optional dict(rpn=[(pos, neg) per image], rcnn=[(pos, neg) per image]) of sampler words."""
         assert imgs.shape[1] == 3                                           # two_stage_3d.py:124
         draws = draws or {}
         self._mark('start')
         x = self.extract_feat(imgs)
-        self._mark('backbone+fpn fwd')
         losses = dict()
         cfg = self.train_cfg
-        rpn_outs = self.rpn_head(x)
-        self._mark('rpn head fwd')
-        losses.update(self.rpn_head.loss(*rpn_outs, gt_bboxes, img_meta, cfg['rpn'], gt_bboxes_ignore=gt_bboxes_ignore,
-                                         draws_list=draws.get('rpn')))
-        self._mark('rpn targets+loss')
+        if _eager_backward:
+            # The RPN branch -- head, targets, losses and their whole backward pass (two 3x3x3 convolutions' worth of data and
+            # weight gradients on P2: ~2 ms of dense work) -- runs on a second stream next to the proposal / roi-head chain,
+            # which is ~300 small launches with an idle device between them.  Each branch differentiates down to its own
+            # detached copy of the pyramid; the two gradients are added in front of the backbone backward.
+            x_graph = x
+            x = tuple(t.detach().requires_grad_(True) for t in x_graph)
+            x_rpn = tuple(t.detach().requires_grad_(True) for t in x_graph)
+            self._mark('backbone+fpn fwd')
+            main = torch.cuda.current_stream()
+            if getattr(self, '_rpn_stream', None) is None:
+                self._rpn_stream = torch.cuda.Stream(device=self.device)
+            side = self._rpn_stream
+            # the inside flags the proposal stage filters with (anchor_head_3d.py:212) depend on shapes only
+            self.rpn_head.pos_indices = self.rpn_head.anchor_geometry([tuple(t.shape[-3:]) for t in x], img_meta, cfg['rpn'],
+                                                                      x[0].device)[3]
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                rpn_outs = self.rpn_head(x_rpn)
+                head_done = torch.cuda.Event()
+                head_done.record(side)
+                rpn_losses = self.rpn_head.loss(*rpn_outs, gt_bboxes, img_meta, cfg['rpn'], gt_bboxes_ignore=gt_bboxes_ignore,
+                                                draws_list=draws.get('rpn'))
+                torch.autograd.backward(self.total_loss(rpn_losses))
+            losses.update(rpn_losses)
+            main.wait_event(head_done)
+            for t in list(rpn_outs[0]) + list(rpn_outs[1]):
+                t.record_stream(main)
+            self._mark('rpn head fwd (second stream: + loss + backward)')
+        else:
+            self._mark('backbone+fpn fwd')
+            rpn_outs = self.rpn_head(x)
+            self._mark('rpn head fwd')
+            losses.update(self.rpn_head.loss(*rpn_outs, gt_bboxes, img_meta, cfg['rpn'], gt_bboxes_ignore=gt_bboxes_ignore,
+                                             draws_list=draws.get('rpn')))
+            self._mark('rpn targets+loss')
         with torch.no_grad():
             # fixed-capacity proposal blocks + device-side row counts: no host round trip (detector/rpn_proposals.py)
             if proposals is None:
@@ -243,6 +284,9 @@ class TwoStageDetector3D(nn.Module):
         valid_rows = (counts[:, 0] + counts[:, 1]).sum().reshape(1).to(torch.int32)
         losses.update(self.bbox_head.loss(cls_score, bbox_pred, lab, lw, bt, bw, valid_rows=valid_rows, num_rois=num_rois))
         self._mark('bbox roialign+head+loss')
+        if _eager_backward:
+            torch.autograd.backward(losses['loss_cls'].sum() + losses['loss_reg'].sum())
+            self._mark('bbox head backward')
 
         # ---- mask head on the positives (two_stage_3d.py:194-218): rows [0, cap_pos) of every image's roi batch, the
         # first #pos of them real; targets are cropped per image (each has its own gt masks), then packed like the rois
@@ -262,6 +306,13 @@ class TwoStageDetector3D(nn.Module):
             mask_pred = self.mask_head(mask_feats)
             losses.update(self.mask_head.loss(mask_pred, mask_targets, pos_labels, valid_rows=n_pos_total))
             self._mark('mask roialign+head+targets+loss')
+        if _eager_backward:
+            if self.with_mask:
+                torch.autograd.backward(losses['loss_mask'].sum())
+            main.wait_stream(side)
+            torch.autograd.backward(x_graph, [b.grad if a.grad is None else a.grad + b.grad for a, b in zip(x, x_rpn)])
+            losses = {k: ([t.detach() for t in v] if isinstance(v, (list, tuple)) else v.detach()) for k, v in losses.items()}
+            self._mark('mask branch + backbone backward')
         self.iteration += 1
         return losses
 
@@ -301,8 +352,8 @@ class TwoStageDetector3D(nn.Module):
     @staticmethod
     def total_loss(losses):
         """mmdet/models/detectors/base.py `_parse_losses`: sum of every entry whose key contains 'loss'"""
-        tot = 0
+        terms = []
         for k, v in losses.items():
             if 'loss' in k:
-                tot = tot + (sum(t.sum() for t in v) if isinstance(v, (list, tuple)) else v.sum())
-        return tot
+                terms += [t.reshape(-1) for t in (v if isinstance(v, (list, tuple)) else [v])]
+        return torch.cat(terms).sum()                 # one gather + one reduction instead of a sum and an add per entry

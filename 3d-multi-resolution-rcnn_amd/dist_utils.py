@@ -262,9 +262,13 @@ def train_step(detector, arena, optimizer, batch, world_size=1, grad_clip=35.0, 
     (total loss, loss dict) as device tensors: nothing is synchronised here."""
     arena.zero_grad()
     args, kwargs = batch
-    losses = detector.forward_train(*args, **kwargs)
-    total = detector.total_loss(losses)
-    total.backward()
+    if hasattr(detector, 'forward_backward'):     # same gradients, head backward issued ahead of the step's one host wait
+        losses = detector.forward_backward(*args, **kwargs)
+        total = detector.total_loss(losses)
+    else:
+        losses = detector.forward_train(*args, **kwargs)
+        total = detector.total_loss(losses)
+        total.backward()
     if world_size > 1:
         arena.allreduce(world_size, group, overlap=overlap)
     if grad_clip is not None:

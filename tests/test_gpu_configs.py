@@ -84,6 +84,19 @@ def test_config2_forward_train_backward_at_512x512x80(dev):
     # parameter gradients: the atomics of the weight-gradient kernels commute only up to rounding
     rel = ((g2 - g).norm() / g.norm()).item()
     assert rel < 1e-5, rel
+    # forward_backward (head backward issued in front of the step's host wait): the same losses and the same gradients --
+    # of the backbone arena and of every head parameter
+    head_grads = lambda: torch.cat([p.grad.reshape(-1) for n, p in det.named_parameters() if not n.startswith('extract.')])
+    h_ref = head_grads().clone()
+    arena.zero_grad()
+    losses3 = det.forward_backward(img, meta, [gt], [gl], gt_masks=[masks], draws=draws)
+    torch.cuda.synchronize()
+    for k in losses:
+        a, b = losses[k], losses3[k]
+        assert all(torch.equal(u, v) for u, v in zip(a, b)) if isinstance(a, (list, tuple)) else torch.equal(a, b), k
+        assert not any(t.requires_grad for t in (b if isinstance(b, (list, tuple)) else [b]))
+    assert ((arena.flat_grads - g).norm() / g.norm()).item() < 1e-5
+    assert ((head_grads() - h_ref).norm() / h_ref.norm()).item() < 1e-5
 
 
 # Bounds of the bf16 + DeformConv3d configuration against the fp32 arithmetic of the same model (configs[4] is build-defined:

@@ -60,6 +60,14 @@ def main():
     print('exclusive time (only this kernel name running) / overlapped time, top 25:')
     for n, v in sorted(excl.items(), key=lambda kv: -kv[1])[:25]:
         print(f'  {1e-3 * v:9.1f} us excl  {1e-3 * shared.get(n, 0):9.1f} us overlapped  {n}')
+    if len(sys.argv) > 3 and sys.argv[3] == 'dump':
+        # every kernel of the step in start order with the device-idle gap in front of it (for the launch-bound head phases)
+        end = t0
+        for s_, e_, n, q in step:
+            gap = s_ - end
+            print(f'  {1e-3 * (s_ - t0):9.1f} +{1e-3 * (e_ - s_):7.1f} us  gap {1e-3 * max(gap, 0):6.1f}  q{q}  {n}')
+            end = max(end, e_)
+        return
     # phases: where the main queue sits at a few milestones
     marks = ('stem_fwd', 'maxpool_fwd', 'subsample2', 'maxpool_bwd', 'stem_wgrad', 'finish_affine')
     for s, e, n, q in step:

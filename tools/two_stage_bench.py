@@ -40,6 +40,8 @@ def main():
     ap.add_argument('--static-mask-batch', action='store_true',
                     help='mask heads always on the full 128-row batch (no positive-count read-back, no host sync)')
     ap.add_argument('--profile', action='store_true', help='torch profiler table of one step')
+    ap.add_argument('--split-backward', action='store_true', help='forward_train + total.backward() instead of forward_backward')
+    ap.add_argument('--host-profile', action='store_true', help='cProfile of the host side of 5 steps + enqueue time per step')
     ap.add_argument('--bf16', action='store_true', help='BASELINE configs[4]: bf16 activation storage in backbone + FPN')
     ap.add_argument('--dcn-neck', action='store_true', help='BASELINE configs[4]: DeformConv3d in place of the FPN output convs')
     a = ap.parse_args()
@@ -70,6 +72,8 @@ def main():
                 m.zero_grad(set_to_none=True)
         if a.two_scales:
             losses = det.forward_train(img, meta, img_2, meta_2, [gt], [gt * 1.5], [gl], [gl], gt_masks=[masks])
+        elif not a.split_backward:
+            return det.forward_backward(img, meta, [gt], [gl], gt_masks=[masks])
         else:
             losses = det.forward_train(img, meta, [gt], [gl], gt_masks=[masks])
         tot = det.total_loss(losses)
@@ -82,11 +86,14 @@ def main():
     if a.phases and not a.two_scales:
         det._phase_events = []
         det.extract.zero_grad()
-        losses = det.forward_train(img, meta, [gt], [gl], gt_masks=[masks])
-        tot = det.total_loss(losses)
-        det._mark('sum losses')
-        tot.backward()
-        det._mark('backward (heads + backbone)')
+        if a.split_backward:
+            losses = det.forward_train(img, meta, [gt], [gl], gt_masks=[masks])
+            tot = det.total_loss(losses)
+            det._mark('sum losses')
+            tot.backward()
+            det._mark('backward (heads + backbone)')
+        else:
+            losses = det.forward_backward(img, meta, [gt], [gl], gt_masks=[masks])
         torch.cuda.synchronize()
         ev = det._phase_events
         det._phase_events = None
@@ -104,6 +111,26 @@ def main():
         print(f'device time total {tot:.2f} ms')
         for k, ms, cnt in rows[:60]:
             print(f'{ms:8.3f} ms {100 * ms / tot:5.1f}% n={cnt:4d}  {k[:150]}')
+    if a.host_profile:
+        import cProfile
+        import pstats
+        enq = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            step()
+            t1 = time.perf_counter()
+            torch.cuda.synchronize()
+            enq.append((round((t1 - t0) * 1e3, 2), round((time.perf_counter() - t0) * 1e3, 2)))
+        print('host enqueue ms / step wall ms (GPU idle at start):', enq)
+        pr = cProfile.Profile()
+        pr.enable()
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        pr.disable()
+        pstats.Stats(pr).sort_stats('cumulative').print_stats(70)
+        pstats.Stats(pr).sort_stats('tottime').print_stats(35)
     for rep in range(a.repeats):
         t0 = time.perf_counter()
         for _ in range(a.steps):
