@@ -65,8 +65,14 @@ class TwoStageDetector3D2Scales(TwoStageDetector3D):
         return {key: loss['loss_mask']}
 
     # ------------------------------------------------------------------ forward_train
+    def forward_backward(self, *args, **kwargs):
+        """forward_train + backward of the summed losses with both RPN branches (heads, targets, losses, backward) on a second
+        stream beside the roi-head chain, and the bbox / refinement heads differentiated in front of the mask heads' host
+        waits -- see TwoStageDetector3D.forward_backward.  Returns the loss dict with detached values."""
+        return self.forward_train(*args, _eager_backward=True, **kwargs)
+
     def forward_train(self, imgs, img_meta, imgs_2, img_meta_2, gt_bboxes, gt_bboxes_2, gt_labels, gt_labels_2,
-                      gt_bboxes_ignore=None, gt_masks=None, gt_masks_2=None, proposals=None, draws=None):
+                      gt_bboxes_ignore=None, gt_masks=None, gt_masks_2=None, proposals=None, draws=None, _eager_backward=False):
         assert imgs.shape[1] == 3 and imgs_2.shape[1] == 3                     # :148
         # One volume per GPU, like the reference's own dual-pathway model: its refinement stage wraps ALL pathway-2 predictions
         # in a one-element list (`pred_bboxes_2 = [torch.from_numpy(pred_bboxes_2).cuda()]`, two_stage_3d_2scales.py:263-267)
@@ -80,9 +86,34 @@ class TwoStageDetector3D2Scales(TwoStageDetector3D):
         losses = dict()
 
         # ---- RPN forward, losses, proposals (:155-176); the second head's loss keys carry the _2 suffix (rpn_head_3d.py:63-65)
-        rpn_outs, rpn_outs_2 = self.rpn_head(x), self.rpn_head_2(x_2)
-        losses.update(self.rpn_head.loss(*rpn_outs, gt_bboxes, img_meta, cfg['rpn'], draws_list=draws.get('rpn')))
-        l2 = self.rpn_head_2.loss(*rpn_outs_2, gt_bboxes_2, img_meta_2, cfg['rpn'], draws_list=draws.get('rpn_2'))
+        if _eager_backward:
+            graph = tuple(x) + tuple(x_2)
+            leaf = lambda ts: tuple(t.detach().requires_grad_(True) for t in ts)
+            x, x_2 = leaf(x), leaf(x_2)                                        # roi heads
+            xr, xr_2 = leaf(x), leaf(x_2)                                      # RPN branches
+            main = torch.cuda.current_stream()
+            if getattr(self, '_rpn_stream', None) is None:
+                self._rpn_stream = torch.cuda.Stream(device=imgs.device)
+            side = self._rpn_stream
+            sizes = lambda ts: [tuple(t.shape[-3:]) for t in ts]
+            self.rpn_head.pos_indices = self.rpn_head.anchor_geometry(sizes(x), img_meta, cfg['rpn'], x[0].device)[3]
+            self.rpn_head_2.pos_indices = self.rpn_head_2.anchor_geometry(sizes(x_2), img_meta_2, cfg['rpn'], x_2[0].device)[3]
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                rpn_outs, rpn_outs_2 = self.rpn_head(xr), self.rpn_head_2(xr_2)
+                heads_done = torch.cuda.Event()
+                heads_done.record(side)
+                l1 = self.rpn_head.loss(*rpn_outs, gt_bboxes, img_meta, cfg['rpn'], draws_list=draws.get('rpn'))
+                l2 = self.rpn_head_2.loss(*rpn_outs_2, gt_bboxes_2, img_meta_2, cfg['rpn'], draws_list=draws.get('rpn_2'))
+                torch.autograd.backward(self.total_loss(l1) + self.total_loss(l2))
+            main.wait_event(heads_done)
+            for t in list(rpn_outs[0]) + list(rpn_outs[1]) + list(rpn_outs_2[0]) + list(rpn_outs_2[1]):
+                t.record_stream(main)
+        else:
+            rpn_outs, rpn_outs_2 = self.rpn_head(x), self.rpn_head_2(x_2)
+            l1 = self.rpn_head.loss(*rpn_outs, gt_bboxes, img_meta, cfg['rpn'], draws_list=draws.get('rpn'))
+            l2 = self.rpn_head_2.loss(*rpn_outs_2, gt_bboxes_2, img_meta_2, cfg['rpn'], draws_list=draws.get('rpn_2'))
+        losses.update(l1)
         losses.update(loss_rpn_cls_2=l2['loss_rpn_cls'], loss_rpn_reg_2=l2['loss_rpn_reg'])
         with torch.no_grad():
             if proposals is None:
@@ -135,12 +166,20 @@ class TwoStageDetector3D2Scales(TwoStageDetector3D):
         lr = self.refinement_head.loss(None, refined_pred, sr['labels'], sr['label_weights'], sr['bbox_targets'],
                                        sr['bbox_weights'], num_rois=_hip.avg_factor_from_counts(sr['counts'].reshape(1, -1), 1))
         losses['loss_refinement_reg'] = lr['loss_reg']                                 # bbox_head_3d_refinement.py:113-118
+        if _eager_backward:
+            torch.autograd.backward(losses['loss_cls'].sum() + losses['loss_reg'].sum() + losses['loss_refinement_reg'].sum())
 
         # ---- mask heads on the positives of pathway 1 and of the refinement samples (:301-327)
         losses.update(self._mask_loss(self.mask_roi_extractor, self.mask_head, x, s1, gt_masks[0], 'loss_mask'))
         losses.update(self._mask_loss(self.refinement_mask_roi_extractor, self.refinement_mask_head, x, sr, gt_masks[0],
                                       'loss_mask_refinement'))
         self.last_sample_counts = torch.stack((s1['counts'], s2['counts'], sr['counts']))
+        if _eager_backward:
+            torch.autograd.backward(losses['loss_mask'].sum() + losses['loss_mask_refinement'].sum())
+            main.wait_stream(side)
+            torch.autograd.backward(graph, [b.grad if a.grad is None else a.grad + b.grad
+                                            for a, b in zip(tuple(x) + tuple(x_2), tuple(xr) + tuple(xr_2))])
+            losses = {k: ([t.detach() for t in v] if isinstance(v, (list, tuple)) else v.detach()) for k, v in losses.items()}
         self.iteration += 1
         return losses
 

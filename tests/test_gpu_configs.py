@@ -190,5 +190,19 @@ def test_config4_dual_pathway_dcn_neck_bf16(dev):
         if n.startswith(('rpn_head', 'bbox_head', 'mask_head', 'dcn_neck.conv.')) and gh_ref[n].norm() > 0:
             r = ((p.grad - gh_ref[n]).norm() / gh_ref[n].norm()).item()
             assert r < CFG4_GRAD_L2, (n, r)
+    # forward_backward of the dual-pathway model (RPN branches on a second stream, head backward ahead of the host waits):
+    # the fp32 model's own losses and gradients again
+    for p_ in ref.parameters():
+        if p_.grad is not None:
+            p_.grad.zero_()
+    ref.extract.zero_grad()
+    l_fb = ref.forward_backward(*args, gt_masks=[masks], draws=draws, proposals=proposals)
+    torch.cuda.synchronize()
+    for k in l_ref:
+        assert abs(val(l_fb[k]) - val(l_ref[k])) <= 1e-6 * max(abs(val(l_ref[k])), 1e-3), k
+    assert ((ref.extract.flat_grads - g_ref).norm() / g_ref.norm()).item() < 1e-4
+    for n, p_ in ref.named_parameters():
+        if not n.startswith('extract.') and gh_ref[n].norm() > 0:
+            assert ((p_.grad - gh_ref[n]).norm() / gh_ref[n].norm()).item() < 1e-4, n
     print(f'configs[4] bf16+dcn vs fp32: backbone gradient L2 {rel:.3e}, cosine {cos:.5f}; ' +
           ', '.join(f'{k} {val(l_bf[k]):.5f}/{val(l_ref[k]):.5f}' for k in l_ref if k != 'acc'))

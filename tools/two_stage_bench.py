@@ -70,7 +70,9 @@ def main():
         if a.none_grads:
             for m in [c for n_, c in det.named_children() if n_ != 'extract']:
                 m.zero_grad(set_to_none=True)
-        if a.two_scales:
+        if a.two_scales and not a.split_backward:
+            return det.forward_backward(img, meta, img_2, meta_2, [gt], [gt * 1.5], [gl], [gl], gt_masks=[masks])
+        elif a.two_scales:
             losses = det.forward_train(img, meta, img_2, meta_2, [gt], [gt * 1.5], [gl], [gl], gt_masks=[masks])
         elif not a.split_backward:
             return det.forward_backward(img, meta, [gt], [gl], gt_masks=[masks])
