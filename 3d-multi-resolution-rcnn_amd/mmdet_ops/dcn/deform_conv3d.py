@@ -180,6 +180,72 @@ class DeformConvFunction3D(Function):
                 None, None, None, None, None)
 
 
+class DeformConvBf16Function3D(Function):
+    """DeformConv3d on bf16 maps (BASELINE configs[4]; csrc/deform_conv3d_bf16.hip): x16 [N,D,H,W,64] and off16 [N,Do,Ho,Wo,S]
+    (bf16, NDHWC; the first 3 * taps entries of an offset row are the taps' (dd, dh, dw), S >= 3 * taps -- the offset conv's
+    padded output is taken as it is), weight [64, 64, kd, kh, kw] fp32 -> y16 [N,Do,Ho,Wo,64] bf16.  backward returns
+    (grad x bf16, grad offsets bf16 with the same row stride and zero padding, grad weight fp32)."""
+
+    @staticmethod
+    def forward(ctx, x16, off16, weight, stride, padding, dilation):
+        assert x16.is_cuda and x16.dtype == torch.bfloat16 and off16.dtype == torch.bfloat16 and x16.is_contiguous() and off16.is_contiguous()
+        stride, padding, dilation = _triple(stride), _triple(padding), _triple(dilation)
+        co, ci = weight.shape[:2]
+        k = tuple(weight.shape[2:])
+        K = k[0] * k[1] * k[2]
+        N = x16.size(0)
+        osz = _out_size(x16.shape, k, stride, padding, dilation)
+        assert tuple(off16.shape[:4]) == (N,) + osz and off16.size(4) >= 3 * K, 'offset shape'
+        d = _desc(x16.shape, k, stride, padding, dilation, 1, 0, 1)
+        L = _hip.lib()
+        if L.mr3d_dcn_bf16_supported(ctypes.byref(d), int(co)) != 1:
+            raise NotImplementedError('the bf16 DeformConv3d kernels take Cin = Cout = 64 and a sample box of <= 768 voxels')
+        w = weight.detach()
+        y16 = torch.empty((N,) + osz + (co,), dtype=torch.bfloat16, device=x16.device)
+        wp = _hip.pack_conv_weight_bf16(w)
+        with torch.cuda.device(x16.device):
+            _hip.check(L.mr3d_dcn_bf16_forward(ctypes.byref(d), co, _hip.ptr(x16), _hip.ptr(off16), int(off16.size(4)), _hip.ptr(wp),
+                                               _hip.ptr(y16), _hip.stream_ptr(x16.device)), 'mr3d_dcn_bf16_forward')
+        ctx.save_for_backward(x16, off16, w)
+        ctx.meta = (k, stride, padding, dilation)
+        return y16
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x16, off16, w = ctx.saved_tensors
+        k, stride, padding, dilation = ctx.meta
+        co, ci = w.shape[:2]
+        K = k[0] * k[1] * k[2]
+        g16 = gy.contiguous()
+        assert g16.dtype == torch.bfloat16
+        d = _desc(x16.shape, k, stride, padding, dilation, 1, 0, 1)
+        S = int(off16.size(4))
+        L = _hip.lib()
+        dev = x16.device
+        dwp = torch.zeros((K, ci, co), dtype=torch.float32, device=dev)
+        goff = torch.zeros_like(off16)
+        gx = torch.zeros(x16.shape, dtype=torch.float32, device=dev)
+        wt = _hip.pack_conv_weight_bf16(w.transpose(0, 1))
+        packed = torch.empty((3 * K * ci * co + 1,), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            st = _hip.stream_ptr(dev)
+            _hip.check(L.mr3d_dcn_bf16_wgrad(ctypes.byref(d), co, _hip.ptr(x16), _hip.ptr(off16), S, _hip.ptr(g16), _hip.ptr(dwp), st),
+                       'mr3d_dcn_bf16_wgrad')
+            _hip.check(L.mr3d_dcn_bf16_doffset(ctypes.byref(d), co, _hip.ptr(x16), _hip.ptr(off16), S, _hip.ptr(g16), _hip.ptr(wt),
+                                               _hip.ptr(goff), S, st), 'mr3d_dcn_bf16_doffset')
+            _hip.check(L.mr3d_deform_conv3d_pack_weights(_hip.ptr(w.contiguous()), co, ci, K, _hip.ptr(packed), st),
+                       'mr3d_deform_conv3d_pack_weights')
+            _hip.check(L.mr3d_dcn_bf16_dx(ctypes.byref(d), co, _hip.ptr(off16), S, _hip.ptr(g16), _hip.ptr(packed), _hip.ptr(gx), st),
+                       'mr3d_dcn_bf16_dx')
+        gw = dwp.permute(2, 1, 0).reshape(co, ci, *k).contiguous()
+        return gx.to(torch.bfloat16), goff, gw, None, None, None
+
+
+def deform_conv3d_bf16(x16, off16, weight, stride=1, padding=0, dilation=1):
+    return DeformConvBf16Function3D.apply(x16, off16, weight, stride, padding, dilation)
+
+
 def deform_conv3d(x, offset, weight, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1):
     return DeformConvFunction3D.apply(x, offset, weight, None, None, stride, padding, dilation, groups, deformable_groups)
 

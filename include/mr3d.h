@@ -496,6 +496,27 @@ int mr3d_deform_conv3d_wgrad_fused(const mr3d_deform_conv3d_desc *d, int cout, c
 int mr3d_deform_conv3d_dgrad_fused(const mr3d_deform_conv3d_desc *d, int cout, const float *x, const float *offset,
                                    const float *dy, const float *w_packed, float *dx, float *doffset, mr3d_stream_t s);
 
+/* bf16 form of the same operator (BASELINE configs[4]: bf16 storage + DeformConv3d neck; csrc/deform_conv3d_bf16.hip): x, the
+ * offsets, y / dy and the offset gradient are bf16 (NDHWC; the offsets [position][off_stride] with the taps' (dd, dh, dw) in the
+ * first taps*3 entries of a row -- the offset conv's output padded to its N tile), sums are fp32.  A workgroup copies the voxel
+ * box a 4x4x8 block of positions can reach with |offset| < 1 into LDS once for all taps and samples from there; samples that leave
+ * the box read global memory.  c == cout == 64, dg == 1, the box must fit 768 voxels (the neck's 3x3x3 / stride 1: 8x8x12).
+ *   w_packed / wt_packed: bf16 [taps][k / 8][n = 64][8], the B-operand layout of mr3d_conv3d_forward_bf16, of W (k = ci, n = co)
+ *            resp. of its transpose (k = co, n = ci).
+ *   wgrad:   dw [taps][cin][cout] fp32 += (atomics, PRE-ZEROED).
+ *   doffset: [position][doff_stride] bf16, entries 0 .. taps*3-1 of every row written.
+ *   dx:      fp32 [N,D,H,W,64] += (PRE-ZEROED), the tiled LDS accumulator of the fp32 form; w_packed_f32 =
+ *            mr3d_deform_conv3d_pack_weights. */
+int mr3d_dcn_bf16_supported(const mr3d_deform_conv3d_desc *d, int cout);
+int mr3d_dcn_bf16_forward(const mr3d_deform_conv3d_desc *d, int cout, const uint16_t *x, const uint16_t *offset, int off_stride,
+                          const uint16_t *w_packed, uint16_t *y, mr3d_stream_t s);
+int mr3d_dcn_bf16_wgrad(const mr3d_deform_conv3d_desc *d, int cout, const uint16_t *x, const uint16_t *offset, int off_stride,
+                        const uint16_t *dy, float *dw, mr3d_stream_t s);
+int mr3d_dcn_bf16_doffset(const mr3d_deform_conv3d_desc *d, int cout, const uint16_t *x, const uint16_t *offset, int off_stride,
+                          const uint16_t *dy, const uint16_t *wt_packed, uint16_t *doffset, int doff_stride, mr3d_stream_t s);
+int mr3d_dcn_bf16_dx(const mr3d_deform_conv3d_desc *d, int cout, const uint16_t *offset, int off_stride, const uint16_t *dy,
+                     const float *w_packed_f32, float *dx, mr3d_stream_t s);
+
 /* ------------------------------------------------------------------------------------------------
  * ResNet3D stem -- Conv3d(3, 16, kernel 7, stride (1,2,2), padding 3) + folded BN + ReLU, forward and weight
  * gradient (mmdet/models/backbones/resnet3d.py:397-409,467-469), specialised: reads the volume in the

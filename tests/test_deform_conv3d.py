@@ -231,3 +231,53 @@ def test_detector_with_dcn_neck_trains(bf16):
     det2 = TwoStageDetector3D(device=dev, dtype=torch.bfloat16 if bf16 else torch.float32, neck_dcn=True)
     missing, unexpected = det2.load_state_dict(sd, strict=True)
     assert torch.equal(det2.dcn_neck.conv[2].weight, det.dcn_neck.conv[2].weight)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape,scale', [
+    ((2, 5, 9, 8), 0.4),          # every sample inside the LDS box; tiles cut by the volume on every axis
+    ((1, 9, 13, 19), 1.3),        # offsets beyond +-1: samples outside the box (global-memory corners) and outside the volume
+    ((1, 4, 8, 16), 0.0),         # zero offsets: the plain convolution
+])
+def test_deform_conv3d_bf16_box_kernels(shape, scale):
+    """The bf16 form of the neck's DeformConv3d (csrc/deform_conv3d_bf16.hip: samples from a voxel box in LDS, bf16 MFMA) --
+    forward and the three gradients against the float64 restatement evaluated on the SAME bf16-rounded inputs, offsets and
+    weights.  What is left is the kernels' own rounding: columns / dcol to bf16 (2^-9 relative per entry, averaged over 1728
+    resp. 64 products) and the bf16 results."""
+    from mr3d_amd.mmdet_ops.dcn import deform_conv3d_bf16
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(7)
+    N, D, H, W = shape
+    C, K, S = 64, 27, 96
+    rb = lambda t: t.to(torch.bfloat16).double()
+    x = rb(torch.randn(N, C, D, H, W, generator=g)).requires_grad_(True)
+    off = rb(torch.randn(N, 3 * K, D, H, W, generator=g) * scale).requires_grad_(True)
+    w = rb(torch.randn(C, C, 3, 3, 3, generator=g) * 0.05).requires_grad_(True)
+    ref = dr.deform_conv3d_torch(x, off, w, None, None, (1, 1, 1), (1, 1, 1), (1, 1, 1), 1)
+    cot = rb(torch.randn(ref.shape, generator=g))
+    ref.backward(cot)
+    x16 = x.detach().permute(0, 2, 3, 4, 1).contiguous().to(dev, torch.bfloat16).requires_grad_(True)
+    off16 = torch.zeros(N, D, H, W, S, dtype=torch.bfloat16, device=dev)
+    off16[..., :3 * K] = off.detach().permute(0, 2, 3, 4, 1).to(dev, torch.bfloat16)
+    off16.requires_grad_(True)
+    wd = w.detach().float().to(dev).requires_grad_(True)
+    y16 = deform_conv3d_bf16(x16, off16, wd, 1, 1, 1)
+    assert y16.dtype == torch.bfloat16 and tuple(y16.shape) == (N, D, H, W, C)
+
+    def l2(a, b):
+        return float((a.cpu().double() - b).norm() / b.norm())
+
+    def mx(a, b):
+        return float((a.cpu().double() - b).abs().max() / b.abs().max())
+    y_ref = ref.detach().permute(0, 2, 3, 4, 1)
+    assert l2(y16, y_ref) <= 4e-3 and mx(y16, y_ref) <= 1.5e-2, (l2(y16, y_ref), mx(y16, y_ref))
+    y16.backward(cot.permute(0, 2, 3, 4, 1).contiguous().to(dev, torch.bfloat16))
+    gx_ref = x.grad.permute(0, 2, 3, 4, 1)
+    assert l2(x16.grad, gx_ref) <= 4e-3 and mx(x16.grad, gx_ref) <= 1.5e-2, (l2(x16.grad, gx_ref), mx(x16.grad, gx_ref))
+    assert l2(wd.grad, w.grad) <= 4e-3 and mx(wd.grad, w.grad) <= 1.5e-2, (l2(wd.grad, w.grad), mx(wd.grad, w.grad))
+    go = off16.grad
+    assert go.dtype == torch.bfloat16 and float(go[..., 3 * K:].abs().max()) == 0.0          # the padding stays zero
+    if scale > 0:
+        go_ref = off.grad.permute(0, 2, 3, 4, 1)
+        # offset gradients are discontinuous where a sample sits within rounding of an integer coordinate or of the validity box
+        assert l2(go[..., :3 * K], go_ref) <= 1e-2, l2(go[..., :3 * K], go_ref)
