@@ -300,14 +300,25 @@ __global__ __launch_bounds__(kBT) void dcn_bf16_wgrad_kernel(const bf16_t *__res
   for (int tile_id = t_begin; tile_id < t_end; ++tile_id) {
     const TileOrg org = tile_origin(g, tile_id);
     const BoxOrg bo = box_origin(g, org);
-    __syncthreads();                                // the previous tile's box, dy tile and columns are done with
+    uint4 dyv[2];
+    uint32_t live = 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int it = tid + j * kBT, row = it >> 3, piece = it & 7;
+      const Coord c = tile_pos(g, org, row);
+      dyv[j] = make_uint4(0u, 0u, 0u, 0u);
+      if (c.in) dyv[j] = *reinterpret_cast<const uint4 *>(dy + (size_t)c.pos * kC + piece * 8);
+      live |= (dyv[j].x | dyv[j].y | dyv[j].z | dyv[j].w) & 0x7fff7fffu;
+    }
+    // (a barrier: the previous tile's box, dy tile and columns are done with.)  dy == 0 on the whole tile -- the usual case in
+    // detector training, where the gradient of a pyramid level comes from 256 sampled anchors and the sampled rois' footprints --
+    // adds nothing to dW: skip the box and the gather passes
+    if (!__syncthreads_or((int)live)) continue;
     load_box(x, g, b, bo, box, tid);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {                   // dy tile [pos][co] -> dyT[co row][pos]
       const int it = tid + j * kBT, row = it >> 3, piece = it & 7;
-      const Coord c = tile_pos(g, org, row);
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (c.in) v = *reinterpret_cast<const uint4 *>(dy + (size_t)c.pos * kC + piece * 8);
+      const uint4 v = dyv[j];
       const uint32_t d[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int q = 0; q < 8; ++q)
@@ -412,19 +423,24 @@ __global__ __launch_bounds__(kBT) void dcn_bf16_doffset_kernel(const bf16_t *__r
   if (tile_id < 0) return;
   const TileOrg org = tile_origin(g, tile_id);
   const BoxOrg bo = box_origin(g, org);
-  load_box(x, g, b, bo, box, tid);
 
   // A operand: dy rows 32 mt + r, k = co: registers for the whole tap loop
   bf16x8 afr[4];
   {
     const Coord c = tile_pos(g, org, mt * 32 + r);
+    uint32_t live = 0;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
       if (c.in) v = *reinterpret_cast<const uint4 *>(dy + (size_t)c.pos * kC + kk * 16 + 8 * h);
+      live |= (v.x | v.y | v.z | v.w) & 0x7fff7fffu;
       afr[kk] = __builtin_bit_cast(bf16x8, v);
     }
+    // dy == 0 on the whole tile (the usual case in detector training, see the weight gradient): the offset gradient keeps the
+    // zeros the caller put there
+    if (!__syncthreads_or((int)live)) return;
   }
+  load_box(x, g, b, bo, box, tid);
   // B fragments of a tap: W[tap]^T, B[k = co][n = ci = 32 nt + r], packed [tap][co / 8][ci][8]
   const bf16x8 *wlane = reinterpret_cast<const bf16x8 *>(wb) + (size_t)h * kC + nt * 32 + r;
   auto load_b = [&](bf16x8 (&dst)[4], int tap) {

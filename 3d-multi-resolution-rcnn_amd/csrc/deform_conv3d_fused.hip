@@ -197,11 +197,16 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
     TapIdx tx;
     tx.set(g, tap0);
     float bfr[kM / 2];                                 // B[k = position 2j + h][n = co]
+    int live = 0;
 #pragma unroll
     for (int j = 0; j < kM / 2; ++j) {
       const Coord c = tile_pos(g, org, 2 * j + h);
       bfr[j] = c.in ? dy[(size_t)c.pos * kC + nb * 32 + l31] : 0.f;
+      live |= bfr[j] != 0.f;
     }
+    // The gradient that reaches a pyramid level in detector training is sparse -- it comes from 256 sampled anchors and from the
+    // RoIAlign footprints of the sampled rois -- so most tiles carry dy == 0 and add nothing to dW: skip their 27 gather passes
+    if (!__syncthreads_or(live)) continue;
 #pragma unroll
     for (int t = 0; t < kTapsPerWg; ++t) {
       const int tap = tap0 + t;
@@ -278,9 +283,15 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
   float4 afr[8];
   {
     const Coord c = tile_pos(g, org, wave * 32 + l31);
+    int live = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 8; ++i) {
       afr[i] = c.in ? *reinterpret_cast<const float4 *>(dy + (size_t)c.pos * kC + 8 * i + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+      live |= (afr[i].x != 0.f) | (afr[i].y != 0.f) | (afr[i].z != 0.f) | (afr[i].w != 0.f);
+    }
+    // dy == 0 on the whole tile (the usual case in detector training, see the weight gradient): dx gets nothing and doffset keeps
+    // the zeros the caller put there
+    if (!__syncthreads_or(live)) return;
   }
 
   const Coord me = tile_pos(g, org, tid & (kM - 1));

@@ -504,7 +504,8 @@ int mr3d_deform_conv3d_dgrad_fused(const mr3d_deform_conv3d_desc *d, int cout, c
  *   w_packed / wt_packed: bf16 [taps][k / 8][n = 64][8], the B-operand layout of mr3d_conv3d_forward_bf16, of W (k = ci, n = co)
  *            resp. of its transpose (k = co, n = ci).
  *   wgrad:   dw [taps][cin][cout] fp32 += (atomics, PRE-ZEROED).
- *   doffset: [position][doff_stride] bf16, entries 0 .. taps*3-1 of every row written.
+ *   doffset: [position][doff_stride] bf16, PRE-ZEROED: tiles of 4x4x8 positions whose dy is zero are skipped (so are they in wgrad and
+ *            in the fp32 form: the gradient of a pyramid level in detector training is sparse).
  *   dx:      fp32 [N,D,H,W,64] += (PRE-ZEROED), the tiled LDS accumulator of the fp32 form; w_packed_f32 =
  *            mr3d_deform_conv3d_pack_weights. */
 int mr3d_dcn_bf16_supported(const mr3d_deform_conv3d_desc *d, int cout);
