@@ -105,8 +105,10 @@ class TwoStageDetector3D(nn.Module):
         self.test_cfg = test_cfg or DEFAULT_TEST_CFG
         self.extract = ExtractFeat3D(device=device, dtype=dtype, neck_dcn=neck_dcn)   # backbone + neck (module names as the reference)
         self.neck_dcn = bool(neck_dcn)
-        if dtype == torch.bfloat16 and not neck_dcn:
-            self.extract.pyramid_dtype = torch.bfloat16          # RPN head and RoIAlign3D read the bf16 pyramid directly
+        if dtype == torch.bfloat16:
+            # RPN head and RoIAlign3D read the bf16 pyramid directly; with the deformable neck the lateral sums leave the engine
+            # in bf16 and the neck's bf16 kernels take them as they are (detector/dcn_neck.py)
+            self.extract.pyramid_dtype = torch.bfloat16
         if neck_dcn:
             from .dcn_neck import DCNNeck3D
             self.dcn_neck = DCNNeck3D(offset_bf16=(dtype == torch.bfloat16)).to(self.device)
