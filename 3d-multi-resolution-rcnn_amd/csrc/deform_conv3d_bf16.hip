@@ -41,7 +41,7 @@ constexpr int kColB = 144;                     // bytes per row of a [128 pos][6
 constexpr int kColBytes = kM * kColB;          //   of 16 rows hit 16 different 16-byte slots of the 256-B bank row
 constexpr int kTrB = 272;                      // bytes per row of a transposed [64 ch][128 pos] bf16 tile (+16 B, same reason)
 constexpr int kTrBytes = kC * kTrB;
-constexpr int kTabBytes = kBW * 2 * 16 * 16;   // per wave, double-buffered: 16 entries of 16 B
+constexpr int kTabBytes = kBW * 2 * 64 * 16;   // per wave, double-buffered: 4 taps x 16 positions, 16 B each
 constexpr int kDead = -1, kFar = -2;           // entry codes: sample outside the validity box / outside the LDS box
 
 struct BoxGeo { int rz, ry, rx, nbox; };       // rx even
@@ -125,6 +125,35 @@ __device__ __forceinline__ void make_entry(const FGeo &g, const BoxGeo &b, const
   *dst = make_int4(code, __float_as_int(fz), __float_as_int(fy), __float_as_int(fx));
 }
 
+// Table entries are made four taps at a time by all 64 lanes of a wave (lane = 16 * (tap & 3) + position: one lane per entry;
+// 16 active lanes per tap cost the same instructions), into the wave's own table (batch & 1): no barrier involved.  The three
+// offsets of the NEXT batch are requested right after a batch is made, four taps before they are needed.
+struct EntryBatches {
+  const bf16_t *p;                // this lane's position row of the offsets
+  Coord c;
+  float nx[3];
+  int tap0, ntap, sub;            // taps [tap0, tap0 + ntap) are walked; sub = lane >> 4
+  __device__ __forceinline__ void fetch(int t) {            // t = tap - tap0 of this lane's next entry
+    nx[0] = nx[1] = nx[2] = 0.f;
+    if (c.in && t < ntap) { const int k = 3 * (tap0 + t); nx[0] = bf2f(p[k]); nx[1] = bf2f(p[k + 1]); nx[2] = bf2f(p[k + 2]); }
+  }
+  __device__ __forceinline__ void start(const bf16_t *__restrict__ offset, int stride, const Coord &me, int lane, int tap0_, int ntap_) {
+    c = me; tap0 = tap0_; ntap = ntap_; sub = lane >> 4;
+    p = offset + (size_t)me.pos * stride;
+    fetch(sub);
+  }
+  // entries of taps tap0 + 4 * batch .. + 3 -> tab[(batch & 1) * 64 + lane]
+  __device__ __forceinline__ void make(const FGeo &g, const BoxGeo &b, const BoxOrg &o, int batch, int4 *tab, int lane) {
+    const int t = 4 * batch + sub;
+    TapIdx ti;
+    ti.set(g, min(tap0 + t, g.K - 1));
+    Coord cc = c;
+    cc.in = c.in && t < ntap;
+    make_entry(g, b, o, cc, ti, nx[0], nx[1], nx[2], tab + (batch & 1) * 64 + lane);
+    fetch(t + 4);
+  }
+};
+
 // the 8 corner values (this lane's 8 channels) of an in-box sample, x-corners in the lane's conflict-free order:
 // v[(a * 2 + b) * 2 + i] = corner (z0 + a, y0 + b, x0 + (i ? 1 - cf : cf))
 __device__ __forceinline__ void box_corners(const uint4 *box, const BoxGeo &b, int code, int cf, int piece, uint4 (&v)[8]) {
@@ -135,8 +164,9 @@ __device__ __forceinline__ void box_corners(const uint4 *box, const BoxGeo &b, i
 }
 
 // a sample outside the LDS box: the same sum from global memory, corner by corner
-__device__ __noinline__ void far_columns(const bf16_t *__restrict__ x, const FGeo &g, int n, float pz, float py, float px, int piece,
-                                         v2f (&acc)[4]) {
+struct Acc8 { v2f a[4]; };
+__device__ __noinline__ Acc8 far_columns_nv(const bf16_t *__restrict__ x, int D, int H, int W, int n, float pz, float py, float px, int piece) {
+  v2f acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
   const int z0 = (int)floorf(pz), y0 = (int)floorf(py), x0 = (int)floorf(px);
   const float lz = pz - (float)z0, ly = py - (float)y0, lx = px - (float)x0;
   const float wz[2] = {1.f - lz, lz}, wy[2] = {1.f - ly, ly}, wx[2] = {1.f - lx, lx};
@@ -144,41 +174,59 @@ __device__ __noinline__ void far_columns(const bf16_t *__restrict__ x, const FGe
     for (int bb = 0; bb < 2; ++bb)
       for (int c = 0; c < 2; ++c) {
         const int z = z0 + a, y = y0 + bb, xx = x0 + c;
-        if ((unsigned)z < (unsigned)g.D && (unsigned)y < (unsigned)g.H && (unsigned)xx < (unsigned)g.W)
-          fma8(acc, wz[a] * wy[bb] * wx[c], *reinterpret_cast<const uint4 *>(x + ((((size_t)n * g.D + z) * g.H + y) * g.W + xx) * kC + piece * 8));
+        if ((unsigned)z < (unsigned)D && (unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W)
+          fma8(acc, wz[a] * wy[bb] * wx[c], *reinterpret_cast<const uint4 *>(x + ((((size_t)n * D + z) * H + y) * W + xx) * kC + piece * 8));
       }
+  Acc8 r;
+  r.a[0] = acc[0]; r.a[1] = acc[1]; r.a[2] = acc[2]; r.a[3] = acc[3];
+  return r;
+}
+__device__ __forceinline__ void far_columns(const bf16_t *__restrict__ x, const FGeo &g, int n, float pz, float py, float px, int piece,
+                                            v2f (&acc)[4]) {
+  const Acc8 r = far_columns_nv(x, g.D, g.H, g.W, n, pz, py, px, piece);
+  acc[0] = r.a[0]; acc[1] = r.a[1]; acc[2] = r.a[2]; acc[3] = r.a[3];
 }
 
-// The weighted corner sums of this wave's 16 positions for one tap: two passes of 8 samples (slot = lane >> 3), 8 channels per
-// lane (piece = lane & 7).  sink(local row 0..15, piece, sums of the 8 channels).
-template <class Sink>
+// The weighted corner sums of this wave's 16 positions for one tap: two groups of 8 samples (slot = lane >> 3), 8 channels per
+// lane (piece = lane & 7); the 16 corner reads of both groups are issued before the first is used.
+// sink(local row 0..15, piece, sums of the 8 channels).
+template <bool BOTH, class Sink>
 __device__ __forceinline__ void gather_columns(const uint4 *box, const BoxGeo &b, const int4 *tab, int lane, const bf16_t *__restrict__ x,
                                                const FGeo &g, int n, Sink &&sink) {
   const int s = lane >> 3, piece = lane & 7, pol = (s >> 1) & 1;
+  constexpr int NG = BOTH ? 2 : 1;                  // groups whose reads are in flight together (registers: 32 per group)
 #pragma unroll
-  for (int gi = 0; gi < 2; ++gi) {
-    const int rl = gi * 8 + s;
-    const int4 e = tab[rl];
-    v2f acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-    if (e.x >= 0) {
-      const float lz = __int_as_float(e.y), ly = __int_as_float(e.z), lx = __int_as_float(e.w);
-      const int cf = (e.x & 1) ^ pol;
-      uint4 v[8];
-      box_corners(box, b, e.x, cf, piece, v);
-      const float wx0 = cf ? lx : 1.f - lx, wx1 = cf ? 1.f - lx : lx;
-      const float wz[2] = {1.f - lz, lz}, wy[2] = {1.f - ly, ly};
+  for (int g0 = 0; g0 < 2; g0 += NG) {
+    int4 e[NG];
+    uint4 v[NG][8];
+    int cf[NG];
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+    for (int u = 0; u < NG; ++u) e[u] = tab[(g0 + u) * 8 + s];
 #pragma unroll
-        for (int bb = 0; bb < 2; ++bb) {
-          const float wab = wz[a] * wy[bb];
-          fma8(acc, wab * wx0, v[(a * 2 + bb) * 2]);
-          fma8(acc, wab * wx1, v[(a * 2 + bb) * 2 + 1]);
-        }
-    } else if (e.x == kFar) {
-      far_columns(x, g, n, __int_as_float(e.y), __int_as_float(e.z), __int_as_float(e.w), piece, acc);
+    for (int u = 0; u < NG; ++u) {
+      cf[u] = (e[u].x & 1) ^ pol;
+      box_corners(box, b, max(e[u].x, 0), cf[u], piece, v[u]);        // a dead / far sample reads voxel 0 and drops it
     }
-    sink(rl, piece, acc);
+#pragma unroll
+    for (int u = 0; u < NG; ++u) {
+      v2f acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+      const float lz = __int_as_float(e[u].y), ly = __int_as_float(e[u].z), lx = __int_as_float(e[u].w);
+      if (e[u].x >= 0) {
+        const float wx0 = cf[u] ? lx : 1.f - lx, wx1 = cf[u] ? 1.f - lx : lx;
+        const float wz[2] = {1.f - lz, lz}, wy[2] = {1.f - ly, ly};
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int bb = 0; bb < 2; ++bb) {
+            const float wab = wz[a] * wy[bb];
+            fma8(acc, wab * wx0, v[u][(a * 2 + bb) * 2]);
+            fma8(acc, wab * wx1, v[u][(a * 2 + bb) * 2 + 1]);
+          }
+      } else if (e[u].x == kFar) {
+        far_columns(x, g, n, lz, ly, lx, piece, acc);
+      }
+      sink((g0 + u) * 8 + s, piece, acc);
+    }
   }
 }
 
@@ -203,22 +251,11 @@ __global__ __launch_bounds__(kBT) void dcn_bf16_fwd_kernel(const bf16_t *__restr
   const BoxOrg bo = box_origin(g, org);
   load_box(x, g, b, bo, box, tid);
 
-  const Coord me = tile_pos(g, org, wave * 16 + (lane & 15));
-  OffStream os;
-  os.start(offset, off_stride, me, lane < 16, 0);
-  TapIdx ti;
-  ti.set(g, 0);
-  int4 *mytab = tab + wave * 32;
-  auto entries = [&](int tap, int buf) {           // taps in increasing order
-    if (lane < 16) {
-      float oz, oy, ox;
-      os.take(oz, oy, ox, tap + 1, g.K);
-      make_entry(g, b, bo, me, ti, oz, oy, ox, mytab + buf * 16 + lane);
-    }
-    ti.next(g);
-  };
-  auto gather = [&](int buf, unsigned char *dst) {
-    gather_columns(box, b, mytab + buf * 16, lane, x, g, org.n, [&](int rl, int piece, const v2f (&acc)[4]) {
+  EntryBatches eb;
+  eb.start(offset, off_stride, tile_pos(g, org, wave * 16 + (lane & 15)), lane, 0, g.K);
+  int4 *mytab = tab + wave * 128;
+  auto gather = [&](int tap, unsigned char *dst) {
+    gather_columns<true>(box, b, mytab + ((tap >> 2) & 1) * 64 + (tap & 3) * 16, lane, x, g, org.n, [&](int rl, int piece, const v2f (&acc)[4]) {
       *reinterpret_cast<uint4 *>(dst + (wave * 16 + rl) * kColB + piece * 16) = pack8(acc);
     });
   };
@@ -233,19 +270,18 @@ __global__ __launch_bounds__(kBT) void dcn_bf16_fwd_kernel(const bf16_t *__restr
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
   bf16x8 bcur[4], bnxt[4];
   load_b(bcur, 0);
-  entries(0, 0);
+  eb.make(g, b, bo, 0, mytab, lane);
   __syncthreads();                                  // the box is complete
   gather(0, col);
-  if (g.K > 1) entries(1, 1);
   __syncthreads();
   for (int tap = 0; tap < g.K; ++tap) {
     if (tap + 1 < g.K) load_b(bnxt, tap + 1);
+    if ((tap & 3) == 1 && 4 * ((tap >> 2) + 1) < g.K) eb.make(g, b, bo, (tap >> 2) + 1, mytab, lane);
     const unsigned char *arow = col + (tap & 1) * kColBytes + (mt * 32 + r) * kColB + 16 * h;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(arow + kk * 32), bcur[kk], acc, 0, 0, 0);
-    if (tap + 1 < g.K) gather((tap + 1) & 1, col + ((tap + 1) & 1) * kColBytes);
-    if (tap + 2 < g.K) entries(tap + 2, tap & 1);
+    if (tap + 1 < g.K) gather(tap + 1, col + ((tap + 1) & 1) * kColBytes);
     __syncthreads();
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) bcur[kk] = bnxt[kk];
@@ -275,8 +311,9 @@ __global__ __launch_bounds__(kBT) void dcn_bf16_wgrad_kernel(const bf16_t *__res
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   uint4 *box = reinterpret_cast<uint4 *>(lds);
   unsigned char *colT = lds + kBoxBytes;                                 // 2 x [64 ci rows][kTrB]
-  unsigned char *dyT = colT + 2 * kTrBytes;                              // [64 co rows][kTrB]
-  int4 *tab = reinterpret_cast<int4 *>(dyT + kTrBytes);
+  unsigned char *dyT = colT + 2 * kTrBytes;                              // [64 co rows][kTrB]; once its fragments sit in registers
+  int4 *tab = reinterpret_cast<int4 *>(dyT);                             //   the region holds the waves' sample tables
+  static_assert(kTabBytes <= kTrBytes, "the tables live in the dy tile's LDS");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
@@ -295,7 +332,7 @@ __global__ __launch_bounds__(kBT) void dcn_bf16_wgrad_kernel(const bf16_t *__res
   for (int t = 0; t < NA; ++t)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-  int4 *mytab = tab + wave * 32;
+  int4 *mytab = tab + wave * 128;
 
   for (int tile_id = t_begin; tile_id < t_end; ++tile_id) {
     const TileOrg org = tile_origin(g, tile_id);
@@ -324,21 +361,10 @@ __global__ __launch_bounds__(kBT) void dcn_bf16_wgrad_kernel(const bf16_t *__res
       for (int q = 0; q < 8; ++q)
         *reinterpret_cast<bf16_t *>(dyT + (q * 8 + piece) * kTrB + row * 2) = (bf16_t)(d[q >> 1] >> (16 * (q & 1)));
     }
-    const Coord me = tile_pos(g, org, wave * 16 + (lane & 15));
-    OffStream os;
-    os.start(offset, off_stride, me, lane < 16, tap0);
-    TapIdx ti;
-    ti.set(g, tap0);
-    auto entries = [&](int t, int buf) {            // t = tap - tap0, increasing
-      if (lane < 16) {
-        float oz, oy, ox;
-        os.take(oz, oy, ox, t + 1 < ntap ? tap0 + t + 1 : g.K, g.K);
-        make_entry(g, b, bo, me, ti, oz, oy, ox, mytab + buf * 16 + lane);
-      }
-      ti.next(g);
-    };
-    auto gather = [&](int buf, unsigned char *dst) {
-      gather_columns(box, b, mytab + buf * 16, lane, x, g, org.n, [&](int rl, int piece, const v2f (&a)[4]) {
+    EntryBatches eb;
+    eb.start(offset, off_stride, tile_pos(g, org, wave * 16 + (lane & 15)), lane, tap0, ntap);
+    auto gather = [&](int t, unsigned char *dst) {        // t = tap - tap0
+      gather_columns<false>(box, b, mytab + ((t >> 2) & 1) * 64 + (t & 3) * 16, lane, x, g, org.n, [&](int rl, int piece, const v2f (&a)[4]) {
         const int pos = wave * 16 + rl;
         const float f[8] = {a[0].x, a[0].y, a[1].x, a[1].y, a[2].x, a[2].y, a[3].x, a[3].y};
 #pragma unroll
@@ -346,25 +372,25 @@ __global__ __launch_bounds__(kBT) void dcn_bf16_wgrad_kernel(const bf16_t *__res
           *reinterpret_cast<bf16_t *>(dst + (q * 8 + piece) * kTrB + pos * 2) = __builtin_bit_cast(bf16_t, (__bf16)f[q]);
       });
     };
-    entries(0, 0);
     __syncthreads();                                // box and dy tile complete
     bf16x8 bfr[8];                                  // B[k = position 16 kk + 8 h ..][n = co row 32 nb + r]
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) bfr[kk] = *reinterpret_cast<const bf16x8 *>(dyT + (nb * 32 + r) * kTrB + kk * 32 + 16 * h);
+    __syncthreads();                                // every wave has its dy fragments: the region becomes the tables
+    eb.make(g, b, bo, 0, mytab, lane);
     gather(0, colT);
-    if (ntap > 1) entries(1, 1);
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < kWgTaps; ++t) {
       if (t < ntap) {
+        if ((t & 3) == 1 && 4 * ((t >> 2) + 1) < ntap) eb.make(g, b, bo, (t >> 2) + 1, mytab, lane);
         if ((t & 1) == par) {
           const unsigned char *arow = colT + (t & 1) * kTrBytes + (mb * 32 + r) * kTrB + 16 * h;
 #pragma unroll
           for (int kk = 0; kk < 8; ++kk)
             acc[t >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8 *>(arow + kk * 32), bfr[kk], acc[t >> 1], 0, 0, 0);
         }
-        if (t + 1 < ntap) gather((t + 1) & 1, colT + ((t + 1) & 1) * kTrBytes);
-        if (t + 2 < ntap) entries(t + 2, t & 1);
+        if (t + 1 < ntap) gather(t + 1, colT + ((t + 1) & 1) * kTrBytes);
         __syncthreads();
       }
     }
@@ -390,8 +416,12 @@ __device__ __forceinline__ float sum8(float t) {       // over the 8 lanes of a 
   return t;
 }
 
-__device__ __noinline__ void far_doffset(const bf16_t *__restrict__ x, const FGeo &g, int n, float pz, float py, float px, int piece,
-                                         const v2f (&dc)[4], float &gz, float &gy, float &gx) {
+struct Grad3 { float z, y, x; };
+__device__ __noinline__ Grad3 far_doffset_nv(const bf16_t *__restrict__ x, int D, int H, int W, int n, float pz, float py, float px, int piece,
+                                            v2f dc0, v2f dc1, v2f dc2, v2f dc3) {
+  const v2f dc[4] = {dc0, dc1, dc2, dc3};
+  float gz = 0.f, gy = 0.f, gx = 0.f;
+  struct { int D, H, W; } g = {D, H, W};
   const int z0 = (int)floorf(pz), y0 = (int)floorf(py), x0 = (int)floorf(px);
   const float lz = pz - (float)z0, ly = py - (float)y0, lx = px - (float)x0;
   const float wz[2] = {1.f - lz, lz}, wy[2] = {1.f - ly, ly}, wx[2] = {1.f - lx, lx}, sg[2] = {-1.f, 1.f};
@@ -406,6 +436,13 @@ __device__ __noinline__ void far_doffset(const bf16_t *__restrict__ x, const FGe
           gx = fmaf(wz[a] * wy[bb] * sg[c], dot, gx);
         }
       }
+  Grad3 r = {gz, gy, gx};
+  return r;
+}
+__device__ __forceinline__ void far_doffset(const bf16_t *__restrict__ x, const FGeo &g, int n, float pz, float py, float px, int piece,
+                                            const v2f (&dc)[4], float &gz, float &gy, float &gx) {
+  const Grad3 r = far_doffset_nv(x, g.D, g.H, g.W, n, pz, py, px, piece, dc[0], dc[1], dc[2], dc[3]);
+  gz = r.z; gy = r.y; gx = r.x;
 }
 
 __global__ __launch_bounds__(kBT) void dcn_bf16_doffset_kernel(const bf16_t *__restrict__ x, const bf16_t *__restrict__ offset, int off_stride,
@@ -459,45 +496,45 @@ __global__ __launch_bounds__(kBT) void dcn_bf16_doffset_kernel(const bf16_t *__r
       *reinterpret_cast<bf16_t *>(dst + row * kColB + (nt * 32 + r) * 2) = __builtin_bit_cast(bf16_t, (__bf16)acc[e]);
     }
   };
-  const Coord me = tile_pos(g, org, wave * 16 + (lane & 15));
-  OffStream os;
-  os.start(offset, off_stride, me, lane < 16, 0);
-  TapIdx ti;
-  ti.set(g, 0);
-  int4 *mytab = tab + wave * 32;
-  auto entries = [&](int tap, int buf) {
-    if (lane < 16) {
-      float oz, oy, ox;
-      os.take(oz, oy, ox, tap + 1, g.K);
-      make_entry(g, b, bo, me, ti, oz, oy, ox, mytab + buf * 16 + lane);
-    }
-    ti.next(g);
-  };
+  EntryBatches eb;
+  eb.start(offset, off_stride, tile_pos(g, org, wave * 16 + (lane & 15)), lane, 0, g.K);
+  int4 *mytab = tab + wave * 128;
   const int s = lane >> 3, piece = lane & 7, pol = (s >> 1) & 1;
   bf16x8 bcur[4], bnxt[4];
   load_b(bcur, 0);
-  entries(0, 0);
+  eb.make(g, b, bo, 0, mytab, lane);
   mma(bcur, dcol);
   __syncthreads();                                  // box, dcol of tap 0
   for (int tap = 0; tap < g.K; ++tap) {
-    if (tap + 1 < g.K) {
-      load_b(bnxt, tap + 1);
-      entries(tap + 1, (tap + 1) & 1);
-    }
+    if (tap + 1 < g.K) load_b(bnxt, tap + 1);
+    if ((tap & 3) == 1 && 4 * ((tap >> 2) + 1) < g.K) eb.make(g, b, bo, (tap >> 2) + 1, mytab, lane);
     const unsigned char *dc_tile = dcol + (tap & 1) * kColBytes;
-    const int4 *tb = mytab + (tap & 1) * 16;
+    const int4 *tb = mytab + ((tap >> 2) & 1) * 64 + (tap & 3) * 16;
+    // both groups' table entries, dcol rows and 16 corner reads are requested before the first is used
+    int4 e2[2];
+    uint4 dcv2[2], v2[2][8];
+    int cf2[2];
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi) {
+      e2[gi] = tb[gi * 8 + s];
+      dcv2[gi] = *reinterpret_cast<const uint4 *>(dc_tile + (wave * 16 + gi * 8 + s) * kColB + piece * 16);
+    }
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi) {
+      cf2[gi] = (e2[gi].x & 1) ^ pol;
+      box_corners(box, b, max(e2[gi].x, 0), cf2[gi], piece, v2[gi]);
+    }
 #pragma unroll
     for (int gi = 0; gi < 2; ++gi) {
       const int rl = gi * 8 + s, row = wave * 16 + rl;
-      const int4 e = tb[rl];
-      const uint4 dcv = *reinterpret_cast<const uint4 *>(dc_tile + row * kColB + piece * 16);
+      const int4 e = e2[gi];
+      const uint4 dcv = dcv2[gi];
       const v2f dc[4] = {unpack2(dcv.x), unpack2(dcv.y), unpack2(dcv.z), unpack2(dcv.w)};
       float gz = 0.f, gy = 0.f, gx = 0.f;
       if (e.x >= 0) {
         const float lz = __int_as_float(e.y), ly = __int_as_float(e.z), lx = __int_as_float(e.w);
-        const int cf = (e.x & 1) ^ pol;
-        uint4 v[8];
-        box_corners(box, b, e.x, cf, piece, v);
+        const int cf = cf2[gi];
+        const uint4 (&v)[8] = v2[gi];
         const float wx0 = cf ? lx : 1.f - lx, wx1 = cf ? 1.f - lx : lx;       // weight of the first / second x-corner read
         const float sx0 = cf ? 1.f : -1.f;                                    // d(weight of the first) / d(lx); the second: -sx0
         const float wz[2] = {1.f - lz, lz}, wy[2] = {1.f - ly, ly}, sg[2] = {-1.f, 1.f};
@@ -540,7 +577,7 @@ int box_geo(const FGeo &g, BoxGeo &b) {
 }
 
 constexpr size_t kFwdLdsB = (size_t)kBoxBytes + 2 * kColBytes + kTabBytes;
-constexpr size_t kWgLdsB = (size_t)kBoxBytes + 3 * kTrBytes + kTabBytes;
+constexpr size_t kWgLdsB = (size_t)kBoxBytes + 3 * kTrBytes;
 static_assert(kFwdLdsB <= 160 * 1024 && kWgLdsB <= 160 * 1024, "LDS");
 
 }  // namespace
