@@ -526,7 +526,7 @@ class Conv3dWgradDesc(ctypes.Structure):
     """mr3d_conv3d_wgrad_desc (include/mr3d.h)"""
     _fields_ = [(n, ctypes.c_void_p) for n in ('x', 'dy', 'dw', 'dbias')] + \
                [(n, ctypes.c_int) for n in ('n', 'd', 'h', 'w_in', 'cin', 'cout', 'kd', 'kh', 'kw', 'sd', 'sh', 'sw',
-                                            'pd', 'ph', 'pw', 'reserved')] + \
+                                            'pd', 'ph', 'pw', 'flags')] + \
                [('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_longlong)]
 
 
@@ -544,9 +544,13 @@ def wgrad_workspace(device):
     return _wgrad_ws[key]
 
 
-def conv3d_wgrad(x, dy, dw_packed, k, stride, pad, dbias=None, workspace=None):
+WGRAD_SPARSE_DY = 1      # mr3d_conv3d_wgrad_desc.flags / i[17] of a CONV_WGRAD record: MR3D_WGRAD_SPARSE_DY
+
+
+def conv3d_wgrad(x, dy, dw_packed, k, stride, pad, dbias=None, workspace=None, sparse_dy=False):
     """dw_packed [taps,Cin,Cout] += wgrad(x [N,D,H,W,Cin], dy [N,Do,Ho,Wo,Cout]); dw must be pre-zeroed.
-    workspace: optional fp32 tensor (>= WGRAD_WORKSPACE_BYTES) for the two-stage reduction; None = atomics."""
+    workspace: optional fp32 tensor (>= WGRAD_WORKSPACE_BYTES) for the two-stage reduction; None = atomics.
+    sparse_dy: dy is expected to be zero on most position tiles (tested and skipped by the large-map kernels)."""
     assert x.is_cuda and x.is_contiguous() and dy.is_contiguous() and dw_packed.is_contiguous()
     cout = dw_packed.size(2)
     assert tuple(dy.shape) == tuple(conv3d_out_shape(x.shape, cout, k, stride, pad))
@@ -557,6 +561,7 @@ def conv3d_wgrad(x, dy, dw_packed, k, stride, pad, dbias=None, workspace=None):
     d.kd, d.kh, d.kw = k
     d.sd, d.sh, d.sw = stride
     d.pd, d.ph, d.pw = pad
+    d.flags = WGRAD_SPARSE_DY if sparse_dy else 0
     if workspace is not None:
         d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * 4
     with torch.cuda.device(x.device):

@@ -47,6 +47,7 @@ struct Conv3dWgradArgs {
   // stores and a second kernel adds the blocks into dw (null or too small: fp32 atomics straight into dw)
   float *part;
   long long part_bytes;
+  int sparse_dy;        // MR3D_WGRAD_SPARSE_DY: test the dy tiles and skip the zero ones
 };
 
 // adds `nparts` partial blocks per (chunk y, Cout tile z) into dw: block element e = (g*R + row)*NBc + col goes to

@@ -441,6 +441,7 @@ extern "C" int mr3d_conv3d_wgrad(const mr3d_conv3d_wgrad_desc *d, mr3d_stream_t 
   Conv3dWgradArgs a;
   a.x = d->x; a.dy = d->dy; a.dw = d->dw; a.dbias = d->dbias;
   a.part = d->workspace; a.part_bytes = d->workspace ? d->workspace_bytes : 0;
+  a.sparse_dy = d->flags & MR3D_WGRAD_SPARSE_DY;
   a.N = d->n; a.D = d->d; a.H = d->h; a.W = d->w_in; a.Cin = d->cin; a.Cout = d->cout;
   a.pd = d->pd; a.ph = d->ph; a.pw = d->pw;
   a.Do = (d->d + 2 * d->pd - d->kd) / d->sd + 1;

@@ -34,6 +34,8 @@ constexpr int VP = NF * CC + 16;                       // V pitch per patch: lan
 constexpr int VL = 16 * VP;
 constexpr int LDS_BYTES = (HALO + DYL + VL) * 4;
 
+// SPARSE (MR3D_WGRAD_SPARSE_DY): dy tiles are tested and zero tiles skipped; the dense instance carries no test
+template <bool SPARSE>
 __global__ __launch_bounds__(kThreads, 2) void conv3d_wgrad_wino2d_kernel(Conv3dWgradArgs p, int tiles_d, int tiles_h, int tiles_w) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *halo = lds, *dyl = lds + HALO, *vl = dyl + DYL;
@@ -102,11 +104,26 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wgrad_wino2d_kernel(Conv3d
       *reinterpret_cast<float4 *>(dyl + (it >> 4) * DYP + (it & 15) * 4) = ys[j];
     }
   };
+  // A tile whose dy is zero adds nothing: in detector training the gradient that reaches the RPN conv and the FPN output convs is
+  // sparse (256 sampled anchors, the RoIAlign footprints of the sampled rois), so most tiles are.  live[] is a workgroup flag per
+  // tile parity: raised by any thread that fetched a non-zero dy value, read after the barrier every tile passes anyway.
+  __shared__ int live[2];
+  if (tid == 0) live[0] = 0;
+  int tile_par = 0;
   if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
-  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x, tile_par ^= 1) {
     __syncthreads();                                     // the previous tile's k-steps are done with dyl and V
+    if constexpr (SPARSE) {
+      bool nz = false;
+#pragma unroll
+      for (int j = 0; j < NY; ++j) nz |= (ys[j].x != 0.f) | (ys[j].y != 0.f) | (ys[j].z != 0.f) | (ys[j].w != 0.f);
+      if (nz) live[tile_par] = 1;
+      if (tid == 0) live[tile_par ^ 1] = 0;
+    }
     commit();
     __syncthreads();
+    const bool tile_live = !SPARSE || live[tile_par] != 0;          // (workgroup-uniform)
+    if (tile_live)
     // ---- V = Bh^T d Bw of (patch, ci): 16 x 16 items, one per thread -> vl[patch][f][ci]
     {
       const int ci = tid & 15, patch = tid >> 4;          // patch = plane * 8 + th2 * 2 + tw4
@@ -132,11 +149,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wgrad_wino2d_kernel(Conv3d
         dst[(fh * 6 + 5) * CC] = 4.f * tt[1] - 5.f * tt[3] + tt[5];
       }
     }
-    __syncthreads();
+    if (tile_live) __syncthreads();
     if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);
     // ---- 4 k-steps of 4 patches: A = V[patch][f][ci = li] from LDS, B = E(co = li, patch) formed in registers
 #pragma unroll 1
-    for (int ks = 0; ks < 4; ++ks) {                      // not unrolled: four k-steps in flight at once spill
+    for (int ks = 0; ks < (tile_live ? 4 : 0); ++ks) {    // not unrolled: four k-steps in flight at once spill
       const int patch = ks * 4 + lk;
       const float *va = vl + patch * VP + li;          // A fragments: one column of products (4 values) at a time, a column ahead
       // dy patch g[2][4] of (co, patch)
@@ -215,7 +232,9 @@ bool mr3d_conv3d_wgrad_wino2d_ok(const Conv3dWgradArgs &a) {
 int mr3d_conv3d_wgrad_wino2d(const Conv3dWgradArgs &a, hipStream_t stream) {
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3d_wgrad_wino2d_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3d_wgrad_wino2d_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(conv3d_wgrad_wino2d_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             LDS_BYTES) != hipSuccess) {
       (void)hipGetLastError();
       return MR3D_ERR_LAUNCH;
@@ -229,6 +248,7 @@ int mr3d_conv3d_wgrad_wino2d(const Conv3dWgradArgs &a, hipStream_t stream) {
   if (chunks > ntiles) chunks = ntiles;
   if (chunks < 1) chunks = 1;
   dim3 grid((unsigned)chunks, (unsigned)(a.Cin / CC), (unsigned)(3 * (a.Cout / 64)));
-  conv3d_wgrad_wino2d_kernel<<<grid, kThreads, LDS_BYTES, stream>>>(a, tiles_d, tiles_h, tiles_w);
+  if (a.sparse_dy) conv3d_wgrad_wino2d_kernel<true><<<grid, kThreads, LDS_BYTES, stream>>>(a, tiles_d, tiles_h, tiles_w);
+  else conv3d_wgrad_wino2d_kernel<false><<<grid, kThreads, LDS_BYTES, stream>>>(a, tiles_d, tiles_h, tiles_w);
   return mr3d_launch_status();
 }

@@ -38,7 +38,7 @@ int run_one(const mr3d_op &o, mr3d_stream_t s, bool shared_ws = true) {
       mr3d_conv3d_wgrad_desc d;
       d.x = (const float *)p[0]; d.dy = (const float *)p[1]; d.dw = (float *)p[2]; d.dbias = (float *)p[3];
       memcpy(&d.n, i, sizeof(int) * 15);
-      d.reserved = 0;
+      d.flags = i[17];
       d.workspace = shared_ws ? (float *)p[4] : nullptr; d.workspace_bytes = d.workspace ? i64_of(i + 15) : 0;
       return bf16 ? mr3d_conv3d_wgrad_bf16(&d, s) : mr3d_conv3d_wgrad(&d, s);
     }

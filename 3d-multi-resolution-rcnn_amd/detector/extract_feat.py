@@ -76,6 +76,9 @@ class ExtractFeat3D(nn.Module):
         # dtype of the pyramid handed out: fp32 (any consumer), or bf16 for consumers that read bf16 maps directly (the RPN
         # head's bf16 plan, RoIAlign3D's bf16-feature kernel): no fp32 copy of the five maps, bf16 gradients come straight back
         self.pyramid_dtype = torch.float32
+        # set by the detectors BEFORE the first forward pass: the gradients arriving at the pyramid are zero on most position
+        # tiles (256 sampled anchors + the sampled rois' footprints), and the FPN output convs' weight gradients test for that
+        self.sparse_pyramid_grads = False
         self.neck_dcn = bool(neck_dcn)
         if depth not in self.STAGE_BLOCKS:
             raise KeyError(f'invalid depth {depth} for the bottleneck ResNet3D engine')
@@ -404,10 +407,12 @@ class ExtractFeat3D(nn.Module):
             ints = self._conv_ints(dy.shape, spec.cout, spec.cin_pad, k, (1, 1, 1), pad)
         return self._op(_hip.OP_CONV_FWD, [dy, self._w(spec, 'wb'), dx, None, add1, add2, None, mask], ints)
 
-    def _conv_wgrad(self, x, dy, spec):
+    def _conv_wgrad(self, x, dy, spec, sparse_dy=False):
         n, d, h, w, _ = x.shape
         ints = [n, d, h, w, spec.cin_pad, spec.cout, spec.k, spec.k, spec.k, *spec.stride, spec.pad, spec.pad, spec.pad]
         ints = ints + [0] * (26 - len(ints)) + [1]          # i[26] = 1: may run on the plan's side stream
+        if sparse_dy:
+            ints[17] = _hip.WGRAD_SPARSE_DY                  # zero dy tiles are tested for and skipped
         return self._op(_hip.OP_CONV_WGRAD, [x, dy, self._s(spec, 'dwraw'), self._s(spec, 'dbias')], ints)
 
     def _new(self, shape, dtype=None):
@@ -528,7 +533,7 @@ class ExtractFeat3D(nn.Module):
         gC_lat = [self._new(c.shape) for c in P.C]
         for i in range(4):
             if not self.neck_dcn:
-                bwd.append(self._conv_wgrad(P.lat[i], P.gouts[i], self.fpnconv[i]))
+                bwd.append(self._conv_wgrad(P.lat[i], P.gouts[i], self.fpnconv[i], sparse_dy=self.sparse_pyramid_grads))
                 bwd.append(self._conv_dgrad(P.gouts[i], self.fpnconv[i], glat[i]))
             if i > 0:
                 nf, df, hf, wf, c = glat[i - 1].shape

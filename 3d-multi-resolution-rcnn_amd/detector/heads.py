@@ -100,6 +100,7 @@ class _RPNHeadPlanFn(torch.autograd.Function):
             gx = torch.empty(x.shape, dtype=adt, device=dev)
             keep += [g16, gh]
             side = [0] * 11 + [1]                                                        # i[26] = 1: side stream
+            side[2] = _hip.WGRAD_SPARSE_DY          # i[17]: the loss gradient is non-zero at the sampled anchors only
             ops.append(_hip.make_op(_hip.OP_CONV_WGRAD, [h, g16, dw1, db1], [n, d, hh, w, c, cop, 1, 1, 1, 1, 1, 1, 0, 0, 0] + side))
             ops.append(_hip.make_op(_hip.OP_CONV_FWD, [g16, wb1, gh, None, None, None, None, h],
                                     [n, d, hh, w, cop, c, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0]))      # dgrad 1x1, mask = h (ReLU)

@@ -236,12 +236,16 @@ int mr3d_conv3d_dgrad_s2k3(const mr3d_conv3d_desc *desc, mr3d_stream_t stream);
  * Same kernel-size / stride / channel support as mr3d_conv3d_forward.
  * ---------------------------------------------------------------------------------------------- */
 #define MR3D_WGRAD_WORKSPACE_BYTES (64ll << 20)
+/* flags: the caller expects dy to be zero on most position tiles -- the gradient that reaches the RPN conv and the FPN output convs
+ * in detector training is non-zero around the 256 sampled anchors and under the sampled rois only -- and the large-map kernels
+ * then test every dy tile and skip the zero ones (same sums: a zero tile adds zero).  Without it no test is made. */
+#define MR3D_WGRAD_SPARSE_DY 1
 typedef struct {
   const float *x; const float *dy; float *dw;
   float *dbias;   /* [cout] += sum_p dy[p][co] (bias / BN-beta gradient); pre-zeroed; may be NULL */
   int n, d, h, w_in, cin, cout;
   int kd, kh, kw, sd, sh, sw, pd, ph, pw;
-  int reserved;
+  int flags;                    /* MR3D_WGRAD_SPARSE_DY or 0 */
   float *workspace;             /* NULL: atomics */
   long long workspace_bytes;
 } mr3d_conv3d_wgrad_desc;
@@ -626,7 +630,7 @@ int mr3d_rpn_merge_levels(const float *dets, const int *seg_rows_host, int num_l
  * (resnet3d.py:467-478, fpn3d.py:95-134) and of autograd's backward over them.
  * Field use per kind (unused = 0):
  *   CONV_FWD      p = {x,w,y,shift,add1,add2,up,mask}   i = the 25 ints of mr3d_conv3d_desc in order
- *   CONV_WGRAD    p = {x,dy,dw,dbias,workspace}         i = the 15 ints of mr3d_conv3d_wgrad_desc, i[15..16] = workspace bytes (lo, hi)
+ *   CONV_WGRAD    p = {x,dy,dw,dbias,workspace}         i = the 15 ints of mr3d_conv3d_wgrad_desc, i[15..16] = workspace bytes (lo, hi), i[17] = flags
  *   MAXPOOL_FWD   p = {x,y,argmax}                      i = {n,d,h,w,c}
  *   MAXPOOL_BWD   p = {dy,argmax,pooled,dx}             i = {n,d,h,w,c}
  *   ZERO_STUFF2   p = {src,dst}                         i = {n,do,ho,wo,d,h,w,c}

@@ -459,6 +459,29 @@ def test_conv3d_wgrad_winograd_path_ragged_volume(dev):
     assert rel(dw, 2 * ref) <= RTOL
 
 
+def test_conv3d_wgrad_sparse_dy_flag_skips_zero_tiles_only(dev):
+    """MR3D_WGRAD_SPARSE_DY (detector training: the gradient at the RPN conv / FPN output convs is zero on most position tiles):
+    with a dy that is non-zero in a few scattered boxes -- some cut by tile borders, one single voxel -- the tile-skipping
+    instance returns the dense instance's sums (and bias gradient); with a dense dy likewise"""
+    from mr3d_amd import _hip
+    g = torch.Generator(device='cpu').manual_seed(5)
+    shape = (1, 41, 127, 125, 64)
+    xc = torch.randn(shape, generator=g).to(dev)
+    dense = torch.randn(shape, generator=g).to(dev)
+    sparse = torch.zeros_like(dense)
+    for (d0, d1, h0, h1, w0, w1) in ((3, 9, 10, 31, 7, 22), (20, 21, 64, 65, 64, 65), (38, 41, 120, 127, 118, 125), (15, 17, 7, 9, 90, 100)):
+        sparse[:, d0:d1, h0:h1, w0:w1] = dense[:, d0:d1, h0:h1, w0:w1]
+    for dy in (sparse, dense):
+        out = []
+        for flag in (False, True):
+            dw, db = torch.zeros((27, 64, 64), device=dev), torch.zeros(64, device=dev)
+            _hip.conv3d_wgrad(xc, dy, dw, (3,) * 3, (1,) * 3, (1,) * 3, dbias=db, sparse_dy=flag)
+            out.append((dw, db))
+        assert out[0][0].abs().max() > 0
+        assert ((out[1][0] - out[0][0]).abs().max() / out[0][0].abs().max()).item() <= 1e-5          # atomics: order only
+        assert ((out[1][1] - out[0][1]).abs().max() / out[0][1].abs().max()).item() <= 1e-5
+
+
 @pytest.mark.parametrize('c0,c1,c2,P', [(64, 256, 64, 10240), (64, 256, 64, 77), (64, 256, 64, 32), (16, 64, 16, 65536), (16, 64, 16, 32768 + 32 * 7)])
 @pytest.mark.parametrize('mode', ['forward', 'backward'])
 def test_pointwise_pair_vs_fp64(dev, c0, c1, c2, P, mode):
