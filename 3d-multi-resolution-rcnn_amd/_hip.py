@@ -481,8 +481,9 @@ def conv3d_forward_bf16(x, w16, cout, k, stride, pad, shift=None, add1=None, add
     return y
 
 
-def conv3d_wgrad_bf16(x, dy, dw_packed, k, stride, pad, dbias=None):
-    """dw_packed fp32 [taps,Cin,Cout] += wgrad(x bf16 [N,D,H,W,Cin], dy bf16 [N,Do,Ho,Wo,Cout]); dw pre-zeroed"""
+def conv3d_wgrad_bf16(x, dy, dw_packed, k, stride, pad, dbias=None, sparse_dy=False):
+    """dw_packed fp32 [taps,Cin,Cout] += wgrad(x bf16 [N,D,H,W,Cin], dy bf16 [N,Do,Ho,Wo,Cout]); dw pre-zeroed.
+    sparse_dy: dy is expected to be zero on most position tiles (stride-1 kernels test and skip them)."""
     assert x.is_cuda and x.is_contiguous() and dy.is_contiguous() and x.dtype == dy.dtype == torch.bfloat16
     assert dw_packed.dtype == torch.float32 and dw_packed.is_contiguous()
     cout = dw_packed.size(2)
@@ -493,6 +494,7 @@ def conv3d_wgrad_bf16(x, dy, dw_packed, k, stride, pad, dbias=None):
     d.kd, d.kh, d.kw = k
     d.sd, d.sh, d.sw = stride
     d.pd, d.ph, d.pw = pad
+    d.flags = 1 if sparse_dy else 0                      # MR3D_WGRAD_SPARSE_DY
     with torch.cuda.device(x.device):
         st = lib().mr3d_conv3d_wgrad_bf16(ctypes.byref(d), stream_ptr(x.device))
     check(st, 'mr3d_conv3d_wgrad_bf16')

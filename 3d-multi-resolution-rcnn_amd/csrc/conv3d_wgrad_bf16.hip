@@ -57,7 +57,9 @@ __device__ __forceinline__ bf16x8 tr_frag(unsigned char *lds, int off0, int off1
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <class C>
+// SPARSE (MR3D_WGRAD_SPARSE_DY; stride-1 instances): every dy tile is tested while it is staged and the MFMA loop of a zero tile is
+// skipped -- in detector training the gradient at the RPN convs, the FPN output / offset convs is zero on most position tiles
+template <class C, bool SPARSE>
 __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_wgrad_bf16_kernel(WgArgs p, int tiles_d, int tiles_h, int tiles_w, int ntiles) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char *xs = lds, *ys = lds + C::XBYTES;
@@ -180,11 +182,22 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_wgrad_bf16_kernel(W
     }
   };
 
+  static_assert(!SPARSE || PFX, "the tile test sits in the register-staged path");
+  __shared__ int live_flag[2];                          // per tile parity: some thread staged a non-zero dy value
+  if (SPARSE && tid == 0) live_flag[0] = 0;
+  int par = 0;
   if constexpr (PFX) fetch_part(blockIdx.x, PFX, PFY);
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, par ^= 1) {
     __syncthreads();                                    // the previous tile's fragments have been read
     if constexpr (PFX) {
       fetch_part(tile, false, !PFY);                    // the dy tile where it is not prefetched
+      if constexpr (SPARSE) {
+        unsigned nz = 0;
+#pragma unroll
+        for (int j = 0; j < NYR; ++j) nz |= (yr[j].x | yr[j].y | yr[j].z | yr[j].w) & 0x7fff7fffu;
+        if (nz) live_flag[par] = 1;
+        if (tid == 0) live_flag[par ^ 1] = 0;
+      }
       commit();
       __syncthreads();
       fetch_part(tile + gridDim.x, PFX, PFY);           // in flight during the MFMA loop
@@ -192,6 +205,7 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_wgrad_bf16_kernel(W
       stage_direct(tile);
       __syncthreads();
     }
+    if (SPARSE && !live_flag[par]) continue;            // (workgroup-uniform)
 
     if constexpr (C::PW1) {
       for (int ks = wave; ks < C::KS; ks += 4) {        // waves split the k-steps
@@ -288,12 +302,12 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_wgrad_bf16_kernel(W
   }
 }
 
-template <class C>
+template <class C, bool SPARSE = false>
 int launch_wg(const WgArgs &a, hipStream_t stream) {
   const int tiles_d = (a.Do + C::TD - 1) / C::TD, tiles_h = (a.Ho + C::TH - 1) / C::TH, tiles_w = (a.Wo + C::TW - 1) / C::TW;
   static bool attr_done = false;
   if (!attr_done && C::LDS_BYTES > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3d_wgrad_bf16_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3d_wgrad_bf16_kernel<C, SPARSE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             C::LDS_BYTES) != hipSuccess) {
       (void)hipGetLastError();
       return MR3D_ERR_LAUNCH;
@@ -308,7 +322,7 @@ int launch_wg(const WgArgs &a, hipStream_t stream) {
   if (gx < 1) gx = 1;
   if (gx > ntiles) gx = ntiles;
   dim3 grid((unsigned)gx, (unsigned)by, (unsigned)bz);
-  conv3d_wgrad_bf16_kernel<C><<<grid, kThreads, C::LDS_BYTES, stream>>>(a, tiles_d, tiles_h, tiles_w, (int)ntiles);
+  conv3d_wgrad_bf16_kernel<C, SPARSE><<<grid, kThreads, C::LDS_BYTES, stream>>>(a, tiles_d, tiles_h, tiles_w, (int)ntiles);
   return mr3d_launch_status();
 }
 
@@ -328,6 +342,9 @@ extern "C" int mr3d_conv3d_wgrad_bf16(const mr3d_conv3d_wgrad_desc *d, mr3d_stre
   if (a.Cin % 8 != 0 || a.Cout % 8 != 0) return MR3D_ERR_UNSUPPORTED;
   hipStream_t stream = mr3d_stream(stream_);
   const int k = d->kd, s = d->sd;
+  const bool sparse = (d->flags & MR3D_WGRAD_SPARSE_DY) != 0;
+  if (k == 3 && s == 1 && sparse) return launch_wg<WgCfg<3, 1, 2, 8>, true>(a, stream);
+  if (k == 1 && s == 1 && sparse) return launch_wg<WgCfg<1, 1, 2, 8>, true>(a, stream);
   if (k == 3 && s == 1) return launch_wg<WgCfg<3, 1, 2, 8>>(a, stream);
   if (k == 3 && s == 2) return launch_wg<WgCfg<3, 2, 1, 4>>(a, stream);
   if (k == 1 && s == 1) return launch_wg<WgCfg<1, 1, 2, 8>>(a, stream);

@@ -82,7 +82,7 @@ class _DcnLevelBf16Fn(Function):
         # offset conv backward on the padded bf16 offset gradient
         dwo = torch.zeros((27, 64, cop), dtype=torch.float32, device=dev)
         dbo = torch.zeros((cop,), dtype=torch.float32, device=dev)
-        _hip.conv3d_wgrad_bf16(x16, goff, dwo, (3, 3, 3), (1, 1, 1), (1, 1, 1), dbias=dbo)
+        _hip.conv3d_wgrad_bf16(x16, goff, dwo, (3, 3, 3), (1, 1, 1), (1, 1, 1), dbias=dbo, sparse_dy=True)    # zero where dy was
         gw_off = dwo.permute(2, 1, 0).reshape(cop, 64, 3, 3, 3)[:co_off].contiguous()
         gb_off = dbo[:co_off].contiguous()
         wb = _hip.pack_conv_weight_bf16(wo.flip(2, 3, 4).transpose(0, 1))                # [ci = 64][cop][3,3,3]: data-gradient operand

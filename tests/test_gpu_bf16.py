@@ -389,3 +389,27 @@ def test_mask_head_bf16_plan_vs_fp32_plan(dev):
     for n in res['f32'][2]:
         _close(res['bf16'][2][n], res['f32'][2][n], f'mask grad {n}', 5e-2, 3e-2)
 
+
+
+@pytest.mark.parametrize('k', [3, 1])
+def test_conv3d_wgrad_bf16_sparse_dy_flag(dev, k):
+    """MR3D_WGRAD_SPARSE_DY on the bf16 weight-gradient kernels: with a dy that is non-zero in a few boxes (and with a dense one)
+    the tile-skipping instance returns the sums of the plain instance"""
+    from mr3d_amd import _hip
+    g = torch.Generator(device='cpu').manual_seed(9)
+    shape = (1, 20, 63, 70, 64)
+    x = torch.randn(shape, generator=g).to(dev, torch.bfloat16)
+    dense = torch.randn(shape, generator=g).to(dev, torch.bfloat16)
+    sparse = torch.zeros_like(dense)
+    for (d0, d1, h0, h1, w0, w1) in ((1, 5, 10, 31, 7, 22), (10, 11, 32, 33, 48, 49), (17, 20, 57, 63, 60, 70)):
+        sparse[:, d0:d1, h0:h1, w0:w1] = dense[:, d0:d1, h0:h1, w0:w1]
+    pad = (k // 2,) * 3
+    for dy in (sparse, dense):
+        out = []
+        for flag in (False, True):
+            dw, db = torch.zeros((k ** 3, 64, 64), device=dev), torch.zeros(64, device=dev)
+            _hip.conv3d_wgrad_bf16(x, dy, dw, (k,) * 3, (1,) * 3, pad, dbias=db, sparse_dy=flag)
+            out.append((dw, db))
+        assert out[0][0].abs().max() > 0
+        assert ((out[1][0] - out[0][0]).abs().max() / out[0][0].abs().max()).item() <= 1e-5
+        assert ((out[1][1] - out[0][1]).abs().max() / out[0][1].abs().max()).item() <= 1e-5
