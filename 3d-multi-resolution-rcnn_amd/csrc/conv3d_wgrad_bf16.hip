@@ -186,18 +186,27 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_wgrad_bf16_kernel(W
   __shared__ int live_flag[2];                          // per tile parity: some thread staged a non-zero dy value
   if (SPARSE && tid == 0) live_flag[0] = 0;
   int par = 0;
-  if constexpr (PFX) fetch_part(blockIdx.x, PFX, PFY);
+  if constexpr (SPARSE) fetch_part(blockIdx.x, false, true);          // sparse: only dy travels ahead; x is fetched for live tiles
+  else if constexpr (PFX) fetch_part(blockIdx.x, PFX, PFY);
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, par ^= 1) {
     __syncthreads();                                    // the previous tile's fragments have been read
-    if constexpr (PFX) {
-      fetch_part(tile, false, !PFY);                    // the dy tile where it is not prefetched
-      if constexpr (SPARSE) {
-        unsigned nz = 0;
+    if constexpr (SPARSE) {
+      unsigned nz = 0;
 #pragma unroll
-        for (int j = 0; j < NYR; ++j) nz |= (yr[j].x | yr[j].y | yr[j].z | yr[j].w) & 0x7fff7fffu;
-        if (nz) live_flag[par] = 1;
-        if (tid == 0) live_flag[par ^ 1] = 0;
+      for (int j = 0; j < NYR; ++j) nz |= (yr[j].x | yr[j].y | yr[j].z | yr[j].w) & 0x7fff7fffu;
+      if (nz) live_flag[par] = 1;
+      if (tid == 0) live_flag[par ^ 1] = 0;
+      __syncthreads();
+      const bool lv = live_flag[par] != 0;              // (workgroup-uniform)
+      if (lv) {
+        fetch_part(tile, true, false);                  // a dead tile's x halo is never read: that was most of a skipped tile's time
+        commit();
       }
+      fetch_part(tile + gridDim.x, false, true);
+      if (!lv) continue;
+      __syncthreads();
+    } else if constexpr (PFX) {
+      fetch_part(tile, false, !PFY);                    // the dy tile where it is not prefetched
       commit();
       __syncthreads();
       fetch_part(tile + gridDim.x, PFX, PFY);           // in flight during the MFMA loop
@@ -205,7 +214,6 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_wgrad_bf16_kernel(W
       stage_direct(tile);
       __syncthreads();
     }
-    if (SPARSE && !live_flag[par]) continue;            // (workgroup-uniform)
 
     if constexpr (C::PW1) {
       for (int ks = wave; ks < C::KS; ks += 4) {        // waves split the k-steps

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wgrad_wino2d_kernel(Conv3d
   // current tile's k-steps (their latency rides under 96 MFMAs per wave) and committed to LDS after them.
   constexpr int NX = (TD * HH * HW * (CC / 4) + kThreads - 1) / kThreads, NY = TD * TH * TW * 16 / kThreads;
   float4 xs[NX], ys[NY];
-  auto fetch = [&](int t) {
+  auto fetch = [&](int t, bool do_x, bool do_y) {
     int b = t;
     const int tw_i = b % tiles_w; b /= tiles_w;
     const int th_i = b % tiles_h; b /= tiles_h;
@@ -67,6 +67,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wgrad_wino2d_kernel(Conv3d
     const int n = b;
     const int od0 = td_i * TD, oh0 = th_i * TH, ow0 = tw_i * TW;
     const int id0 = od0 + kd - p.pd, ih0 = oh0 - p.ph, iw0 = ow0 - p.pw;
+    if (do_x)
 #pragma unroll
     for (int j = 0; j < NX; ++j) {
       const int it = tid + j * kThreads;
@@ -78,6 +79,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wgrad_wino2d_kernel(Conv3d
         v = *reinterpret_cast<const float4 *>(p.x + ((((size_t)n * p.D + id) * p.H + ih) * p.W + iw) * p.Cin + c0 + q * 4);
       xs[j] = v;
     }
+    if (do_y)
 #pragma unroll
     for (int j = 0; j < NY; ++j) {
       const int it = tid + j * kThreads;
@@ -110,19 +112,22 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wgrad_wino2d_kernel(Conv3d
   __shared__ int live[2];
   if (tid == 0) live[0] = 0;
   int tile_par = 0;
-  if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+  if ((int)blockIdx.x < ntiles) fetch(blockIdx.x, !SPARSE, true);      // sparse: only dy travels ahead; x is fetched for live tiles
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x, tile_par ^= 1) {
     __syncthreads();                                     // the previous tile's k-steps are done with dyl and V
+    bool tile_live = true;                               // (workgroup-uniform)
     if constexpr (SPARSE) {
       bool nz = false;
 #pragma unroll
       for (int j = 0; j < NY; ++j) nz |= (ys[j].x != 0.f) | (ys[j].y != 0.f) | (ys[j].z != 0.f) | (ys[j].w != 0.f);
       if (nz) live[tile_par] = 1;
       if (tid == 0) live[tile_par ^ 1] = 0;
+      __syncthreads();
+      tile_live = live[tile_par] != 0;
+      if (tile_live) fetch(t, true, false);              // a dead tile's x halo is never read
     }
-    commit();
+    if (tile_live) commit();
     __syncthreads();
-    const bool tile_live = !SPARSE || live[tile_par] != 0;          // (workgroup-uniform)
     if (tile_live)
     // ---- V = Bh^T d Bw of (patch, ci): 16 x 16 items, one per thread -> vl[patch][f][ci]
     {
@@ -150,7 +155,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wgrad_wino2d_kernel(Conv3d
       }
     }
     if (tile_live) __syncthreads();
-    if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);
+    if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x, !SPARSE, true);
     // ---- 4 k-steps of 4 patches: A = V[patch][f][ci = li] from LDS, B = E(co = li, patch) formed in registers
 #pragma unroll 1
     for (int ks = 0; ks < (tile_live ? 4 : 0); ++ks) {    // not unrolled: four k-steps in flight at once spill
