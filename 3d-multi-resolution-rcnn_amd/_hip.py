@@ -372,7 +372,7 @@ class Conv3dDesc(ctypes.Structure):
                [(n, ctypes.c_int) for n in ('n', 'd', 'h', 'w_in', 'cin', 'cout', 'kd', 'kh', 'kw', 'sd', 'sh', 'sw',
                                             'pd', 'ph', 'pw', 'up_d', 'up_h', 'up_w', 'relu',
                                             'ys_d', 'ys_h', 'ys_w', 'y_d', 'y_h', 'y_w')] + \
-               [('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_longlong)]
+               [('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_longlong), ('x_live', ctypes.c_void_p)]
 
 
 def _aligned_bytes(nbytes, device):
@@ -403,9 +403,31 @@ def conv3d_out_shape(x_shape, cout, k, stride, pad):
             (w + 2 * pad[2] - k[2]) // stride[2] + 1, cout)
 
 
+def voxel_liveness_words(positions):
+    fn = lib().mr3d_voxel_liveness_words
+    fn.restype = ctypes.c_longlong
+    fn.argtypes = [ctypes.c_longlong]
+    return int(fn(int(positions)))
+
+
+def voxel_liveness(x, out=None):
+    """int32 words of the liveness bitmap of the NDHWC map x (fp32 / bf16): bit p & 31 of word p >> 5 is set iff position p has a
+    non-zero channel (mr3d_voxel_liveness) -- the `x_live` argument of conv3d_forward for data gradients of sparse maps"""
+    assert x.is_cuda and x.is_contiguous() and x.dim() == 5 and x.dtype in (torch.float32, torch.bfloat16)
+    n, d, h, w, c = x.shape
+    words = voxel_liveness_words(n * d * h * w)
+    bits = out if out is not None else torch.empty((words,), dtype=torch.int32, device=x.device)
+    assert bits.numel() >= words and bits.dtype == torch.int32
+    with torch.cuda.device(x.device):
+        check(lib().mr3d_voxel_liveness(ptr(x), int(x.dtype == torch.bfloat16), n, d, h, w, c, ptr(bits), stream_ptr(x.device)),
+              'mr3d_voxel_liveness')
+    return bits
+
+
 def conv3d_forward(x, w_packed, k, stride, pad, shift=None, add1=None, add2=None, up=None, mask=None, relu=False,
-                   out=None, out_stride=None, out_offset=0):
-    """x: [N,D,H,W,Cin] contiguous (NDHWC); w_packed: [taps,Cin,Cout]; returns y [N,Do,Ho,Wo,Cout]."""
+                   out=None, out_stride=None, out_offset=0, x_live=None):
+    """x: [N,D,H,W,Cin] contiguous (NDHWC); w_packed: [taps,Cin,Cout]; returns y [N,Do,Ho,Wo,Cout].
+    x_live: voxel_liveness(x) -- tiles whose input halo holds no live voxel are written from the epilogue alone."""
     assert x.is_cuda and x.is_contiguous() and x.dtype == torch.float32 and x.dim() == 5
     assert w_packed.is_contiguous() and w_packed.dim() == 3 and w_packed.size(1) == x.size(4)
     cout = w_packed.size(2)
@@ -438,6 +460,9 @@ def conv3d_forward(x, w_packed, k, stride, pad, shift=None, add1=None, add2=None
         nbytes = wino2d_workspace_bytes(d.cin, d.cout)
         keep, d.workspace = _aligned_bytes(nbytes, x.device)
         d.workspace_bytes = nbytes
+    if x_live is not None:
+        assert x_live.dtype == torch.int32 and x_live.is_contiguous() and x_live.numel() >= voxel_liveness_words(x.numel() // x.size(4))
+        d.x_live = x_live.data_ptr()
     with torch.cuda.device(x.device):
         st = lib().mr3d_conv3d_forward(ctypes.byref(d), stream_ptr(x.device))
     check(st, 'mr3d_conv3d_forward')
@@ -577,6 +602,7 @@ def conv3d_wgrad(x, dy, dw_packed, k, stride, pad, dbias=None, workspace=None, s
 OP_CONV_FWD, OP_CONV_WGRAD, OP_MAXPOOL_FWD, OP_MAXPOOL_BWD, OP_ZERO_STUFF2, OP_UPSAMPLE_ADJ = 1, 2, 3, 4, 5, 6
 OP_SUBSAMPLE_FWD, OP_SUBSAMPLE_BWD, OP_VOLUME_PACK, OP_MEMSET0, OP_AXPY, OP_PREP_WEIGHTS, OP_FINISH_GRADS = 7, 8, 9, 10, 11, 12, 13
 OP_STEM_FWD, OP_STEM_WGRAD, OP_CONV_DGRAD_S2, OP_PREP_WEIGHTS_BF16, OP_STEM_PACK_BF16, OP_SYNC, OP_WINO2D_PREP, OP_PW_PAIR = 14, 15, 16, 17, 18, 19, 20, 21
+OP_VOXEL_LIVENESS = 22      # p = {x, bits}, i = {n,d,h,w,c, arm}: arm = 1 hands the bitmap to the next CONV_FWD record as its x_live
 SYNC_JOIN, SYNC_MARK, SYNC_WAIT = 0, 1, 2      # mr3d_op.i[0] of an OP_SYNC record
 DTYPE_BF16 = 1          # mr3d_op.i[25]: MR3D_DTYPE_BF16
 CONV_RELU, CONV_UP_EVEN = 1, 2      # mr3d_conv3d_desc.relu flags (i[18] of a CONV_FWD record)

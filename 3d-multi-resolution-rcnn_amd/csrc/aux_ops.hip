@@ -523,3 +523,53 @@ extern "C" int mr3d_prepare_weights_bf16(const mr3d_layer_desc *table, int num_l
   prep_weights_bf16_kernel<<<dim3(64, num_layers), kT, 0, mr3d_stream(s)>>>(table, params, (bf16_t *)packed16);
   return mr3d_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------
+// Voxel liveness of an NDHWC map: ONE BIT per position (bit p & 31 of word p >> 5, p = ((n*D + d)*H + h)*W + w), set iff one of the
+// position's channels is non-zero (NaN counts, -0 does not).  The large-map data-gradient convolution reads it
+// (mr3d_conv3d_desc.x_live): the gradient that reaches the RPN conv / the FPN output convs in detector training is zero outside the
+// sampled anchors' / rois' neighbourhoods, and a tile whose halo holds no live voxel is its epilogue.  A wave owns 64 positions: the
+// 16-byte pieces of 64 / P positions per load instruction (P = pieces per position: fully coalesced), a ballot per instruction.
+// HBM-bound: one pass over the map.
+// ------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void voxel_liveness_kernel(const unsigned char *__restrict__ x, long long total, int row_bytes, int P,
+                                                            unsigned keep, unsigned *__restrict__ bits) {
+  const int lane = threadIdx.x & 63;
+  const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long long base = wave * 64;
+  if (base >= total) return;
+  const int PP = 64 / P;                            // positions per load instruction
+  const int g = lane / P, piece = lane - g * P;
+  const unsigned long long gmask = P == 64 ? ~0ull : ((1ull << P) - 1ull);
+  unsigned long long acc = 0;
+  for (int it = 0; it < P; ++it) {
+    const long long pos = base + (long long)it * PP + g;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (pos < total) v = *reinterpret_cast<const uint4 *>(x + pos * row_bytes + piece * 16);
+    const unsigned long long m = __ballot(((v.x | v.y | v.z | v.w) & keep) != 0);
+    for (int q = 0; q < PP; ++q)
+      if ((m >> (q * P)) & gmask) acc |= 1ull << (it * PP + q);
+  }
+  if (lane == 0) {
+    bits[wave * 2] = (unsigned)acc;
+    bits[wave * 2 + 1] = (unsigned)(acc >> 32);
+  }
+}
+}  // namespace
+
+extern "C" long long mr3d_voxel_liveness_words(long long positions) { return positions <= 0 ? 0 : ((positions + 63) / 64) * 2 + 2; }
+
+extern "C" int mr3d_voxel_liveness(const void *x, int bf16, int n, int d, int h, int w, int c, unsigned *bits, mr3d_stream_t s) {
+  if (!x || !bits || n <= 0 || d <= 0 || h <= 0 || w <= 0 || c <= 0 || ((uintptr_t)x & 15)) return MR3D_ERR_INVALID_ARG;
+  const int row_bytes = c * (bf16 ? 2 : 4);
+  const int P = row_bytes / 16;
+  if (row_bytes % 16 != 0 || P < 1 || P > 64 || (64 % P) != 0) return MR3D_ERR_UNSUPPORTED;
+  const long long total = (long long)n * d * h * w;
+  const long long waves = (total + 63) / 64;
+  if ((waves + 3) / 4 > 0x7fffffffLL) return MR3D_ERR_UNSUPPORTED;
+  if (hipMemsetAsync(bits + waves * 2, 0, 8, mr3d_stream(s)) != hipSuccess) return MR3D_ERR_LAUNCH;      // the two words of padding
+  voxel_liveness_kernel<<<(unsigned)((waves + 3) / 4), 256, 0, mr3d_stream(s)>>>((const unsigned char *)x, total, row_bytes, P,
+                                                                                 bf16 ? 0x7fff7fffu : 0x7fffffffu, bits);
+  return mr3d_launch_status();
+}

@@ -33,6 +33,9 @@ struct Conv3dFwdArgs {
   const float *w2 = nullptr, *shift2 = nullptr, *mask2 = nullptr;
   float *y2 = nullptr;
   int relu2 = 0;
+  // optional liveness bitmap of x (mr3d_voxel_liveness: one bit per position): a 3x3x3 / stride-1 tile whose halo holds no live
+  // voxel is its epilogue only (conv3d_wino2d_kernel<true>)
+  const unsigned char *x_live = nullptr;
 };
 
 struct Conv3dWgradArgs {

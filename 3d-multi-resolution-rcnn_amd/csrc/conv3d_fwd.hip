@@ -599,6 +599,7 @@ extern "C" int mr3d_conv3d_forward(const mr3d_conv3d_desc *d, mr3d_stream_t stre
   a.ysd = d->ys_d > 0 ? d->ys_d : 1; a.ysh = d->ys_h > 0 ? d->ys_h : 1; a.ysw = d->ys_w > 0 ? d->ys_w : 1;
   a.yD = d->y_d > 0 ? d->y_d : a.Do; a.yH = d->y_h > 0 ? d->y_h : a.Ho; a.yW = d->y_w > 0 ? d->y_w : a.Wo;
   a.ws = (float *)d->workspace; a.ws_bytes = d->workspace_bytes;
+  a.x_live = d->x_live;
   if (a.ws && ((uintptr_t)a.ws & 255)) return MR3D_ERR_WORKSPACE;
   if ((a.Do - 1) * a.ysd >= a.yD || (a.Ho - 1) * a.ysh >= a.yH || (a.Wo - 1) * a.ysw >= a.yW) return MR3D_ERR_INVALID_ARG;
   if (a.N <= 0 || a.Do <= 0 || a.Ho <= 0 || a.Wo <= 0) return MR3D_ERR_INVALID_ARG;

@@ -76,6 +76,9 @@ __global__ __launch_bounds__(256) void wino2d_weights_kernel(const float *__rest
   }
 }
 
+// LIVE: the caller lent a voxel liveness bitmap of x (mr3d_voxel_liveness): a tile whose halo holds no live voxel is written from its
+// epilogue alone.  The plain instance carries no test (the kernel sits at 251 registers; the test costs the dense case 1.4 %).
+template <bool LIVE>
 __global__ __launch_bounds__(kThreads, 2) void conv3d_wino2d_kernel(Conv3dFwdArgs p, const float *__restrict__ U, int tiles_d,
                                                                    int tiles_h, int tiles_w) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -158,9 +161,28 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wino2d_kernel(Conv3dFwdArg
         acc[h * (NF / 2) + f] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[h][f], bq[s % 3][h * (NF / 2) + f], acc[h * (NF / 2) + f], 0, 0, 0);
     }
   };
+  // sparse input (the data gradient of the RPN conv / an FPN output conv in detector training): one bit per voxel of x; lane r < 40
+  // tests the 10 voxels of halo row (plane r / 10, row r % 10); all clear = nothing to multiply (wave-uniform)
+  bool dead = false;
+  if constexpr (LIVE) {
+    const int hd = lane / HH, hh = lane - hd * HH;
+    const int id = id0 + hd, ih = ih0 + hh;
+    unsigned bits = 0;
+    if (lane < HD * HH && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H) {
+      const int w_lo = max(iw0, 0), w_hi = min(iw0 + HW, p.W);                  // [w_lo, w_hi) of this row
+      const long long b0 = (((long long)n * p.D + id) * p.H + ih) * p.W + w_lo;
+      const unsigned *wd = reinterpret_cast<const unsigned *>(p.x_live) + (b0 >> 5);
+      const int sh = (int)(b0 & 31), cnt = w_hi - w_lo;                          // cnt <= 10: at most two words
+      const unsigned long long two = (unsigned long long)wd[0] | ((unsigned long long)(sh + cnt > 32 ? wd[1] : 0u) << 32);
+      bits = (unsigned)(two >> sh) & ((1u << cnt) - 1u);
+    }
+    dead = __ballot(bits != 0) == 0;
+  }
+  if (!dead) {
   load_b(bq[0], 0, 0, 0);
   load_b(bq[1], 0, 0, 1);
-  for (int c0 = 0; c0 < p.Cin; c0 += CC) {
+  }
+  for (int c0 = 0; c0 < (dead ? 0 : p.Cin); c0 += CC) {
     __syncthreads();                                     // the previous chunk's steps are done with V (and its V phase with the halo)
     {
       float4 stage[NIT];
@@ -563,12 +585,15 @@ int mr3d_conv3d_wino2d(const Conv3dFwdArgs &a, hipStream_t stream) {
   static std::once_flag attr_once;                       // LDS above 64 KiB needs the opt-in attribute (one CU has 160 KiB)
   static bool attr_ok = false;
   std::call_once(attr_once, [] {
-    attr_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(conv3d_wino2d_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    attr_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(conv3d_wino2d_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  LDS_BYTES) == hipSuccess &&
+              hipFuncSetAttribute(reinterpret_cast<const void *>(conv3d_wino2d_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   LDS_BYTES) == hipSuccess;
     if (!attr_ok) (void)hipGetLastError();
   });
   if (!attr_ok) return MR3D_ERR_LAUNCH;
   dim3 grid((unsigned)(a.N * tiles_d * tiles_h * tiles_w), (unsigned)(a.Cout / 64));
-  conv3d_wino2d_kernel<<<grid, kThreads, LDS_BYTES, stream>>>(a, U, tiles_d, tiles_h, tiles_w);
+  if (a.x_live) conv3d_wino2d_kernel<true><<<grid, kThreads, LDS_BYTES, stream>>>(a, U, tiles_d, tiles_h, tiles_w);
+  else conv3d_wino2d_kernel<false><<<grid, kThreads, LDS_BYTES, stream>>>(a, U, tiles_d, tiles_h, tiles_w);
   return mr3d_launch_status();
 }

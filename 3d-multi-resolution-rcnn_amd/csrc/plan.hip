@@ -13,7 +13,7 @@ long long i64_of(const int32_t *lo_hi) {
 
 // shared_ws: the partial-sum workspace of weight-gradient records may be used (records that can run concurrently on
 // DIFFERENT streams must not share it: see mr3d_plan_run)
-int run_one(const mr3d_op &o, mr3d_stream_t s, bool shared_ws = true) {
+int run_one(const mr3d_op &o, mr3d_stream_t s, bool shared_ws = true, const unsigned char *x_live = nullptr) {
   const int32_t *i = o.i;
   void *const *p = o.p;
   const bool bf16 = i[25] == MR3D_DTYPE_BF16;        // storage type of the activations the record touches
@@ -24,6 +24,7 @@ int run_one(const mr3d_op &o, mr3d_stream_t s, bool shared_ws = true) {
       d.add1 = (const float *)p[4]; d.add2 = (const float *)p[5]; d.up = (const float *)p[6]; d.mask = (const float *)p[7];
       memcpy(&d.n, i, sizeof(int) * 25);
       d.workspace = nullptr; d.workspace_bytes = 0;      // transformed weights come from the plan's WINO2D_PREP record, if any
+      d.x_live = x_live;                                 // armed by the VOXEL_LIVENESS record in front of this one, if any
       return bf16 ? mr3d_conv3d_forward_bf16(&d, s) : mr3d_conv3d_forward(&d, s);
     }
     case MR3D_OP_CONV_DGRAD_S2: {
@@ -32,6 +33,7 @@ int run_one(const mr3d_op &o, mr3d_stream_t s, bool shared_ws = true) {
       d.add1 = (const float *)p[4]; d.add2 = (const float *)p[5]; d.up = nullptr; d.mask = (const float *)p[7];
       memcpy(&d.n, i, sizeof(int) * 25);
       d.workspace = nullptr; d.workspace_bytes = 0;
+      d.x_live = nullptr;
       return mr3d_conv3d_dgrad_s2k3(&d, s);
     }
     case MR3D_OP_CONV_WGRAD: {
@@ -42,6 +44,8 @@ int run_one(const mr3d_op &o, mr3d_stream_t s, bool shared_ws = true) {
       d.workspace = shared_ws ? (float *)p[4] : nullptr; d.workspace_bytes = d.workspace ? i64_of(i + 15) : 0;
       return bf16 ? mr3d_conv3d_wgrad_bf16(&d, s) : mr3d_conv3d_wgrad(&d, s);
     }
+    case MR3D_OP_VOXEL_LIVENESS:
+      return mr3d_voxel_liveness(p[0], bf16 ? 1 : 0, i[0], i[1], i[2], i[3], i[4], (unsigned *)p[1], s);
     case MR3D_OP_PW_PAIR: {
       mr3d_pw_pair_desc d;
       d.x = (const float *)p[0]; d.w1 = (const float *)p[1]; d.add1 = (const float *)p[2]; d.mask1 = (const float *)p[3];
@@ -202,6 +206,7 @@ int plan_run_impl(const mr3d_op *ops, int num_ops, int *failed_index, mr3d_strea
     join();
     return st;
   };
+  const unsigned char *armed_live = nullptr;          // set by a VOXEL_LIVENESS record with arm = 1, taken by the next CONV_FWD
   for (int k = 0; k < num_ops; ++k) {
     int st = MR3D_OK;
     if (ops[k].kind == MR3D_OP_SYNC) {
@@ -240,7 +245,10 @@ int plan_run_impl(const mr3d_op *ops, int num_ops, int *failed_index, mr3d_strea
       pairs[next_mark].start = a; pairs[next_mark].stop = b;
       if (hipEventRecord(a, run_s) != hipSuccess) return fail(k, MR3D_ERR_LAUNCH);
     }
-    st = run_one(ops[k], (mr3d_stream_t)run_s);
+    const unsigned char *x_live = nullptr;
+    if (ops[k].kind == MR3D_OP_CONV_FWD) { x_live = armed_live; armed_live = nullptr; }
+    st = run_one(ops[k], (mr3d_stream_t)run_s, true, x_live);
+    if (ops[k].kind == MR3D_OP_VOXEL_LIVENESS && ops[k].i[5] == 1) armed_live = (const unsigned char *)ops[k].p[1];
     if (marked) {
       if (hipEventRecord((hipEvent_t)pairs[next_mark].stop, run_s) != hipSuccess && st == MR3D_OK) st = MR3D_ERR_LAUNCH;
       ++next_mark;

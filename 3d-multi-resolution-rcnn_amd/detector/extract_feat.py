@@ -534,6 +534,13 @@ class ExtractFeat3D(nn.Module):
         for i in range(4):
             if not self.neck_dcn:
                 bwd.append(self._conv_wgrad(P.lat[i], P.gouts[i], self.fpnconv[i], sparse_dy=self.sparse_pyramid_grads))
+                if self.sparse_pyramid_grads and not self.bf16 and P.gouts[i].shape[1] * P.gouts[i].shape[2] * P.gouts[i].shape[3] >= 65536:
+                    # voxel liveness of the incoming gradient, handed to the data-gradient record behind it (large maps: the
+                    # two-dimensional Winograd kernel writes tiles whose halo holds no live voxel from its epilogue alone)
+                    n_, d_, h_, w_, c_ = P.gouts[i].shape
+                    lbits = torch.empty((_hip.voxel_liveness_words(n_ * d_ * h_ * w_),), dtype=torch.int32, device=self.device)
+                    P.keep = getattr(P, 'keep', []) + [lbits]
+                    bwd.append(_hip.make_op(_hip.OP_VOXEL_LIVENESS, [P.gouts[i], lbits], [n_, d_, h_, w_, c_, 1]))
                 bwd.append(self._conv_dgrad(P.gouts[i], self.fpnconv[i], glat[i]))
             if i > 0:
                 nf, df, hf, wf, c = glat[i - 1].shape

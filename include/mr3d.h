@@ -199,8 +199,17 @@ typedef struct {
    * workspace_bytes = -1 in a mr3d_conv3d_forward_variant query means "assume the scratch is there". */
   void *workspace;
   long long workspace_bytes;
+  /* Optional liveness bitmap of x (mr3d_voxel_liveness: one bit per position): the large-map 3x3x3 / stride-1 fp32 kernel writes a
+   * tile whose input halo holds no live voxel from its epilogue alone.  For data-gradient calls on the sparse gradients of detector
+   * training (RPN conv, FPN output convs).  NULL: no test.  Other kernel instances ignore it. */
+  const unsigned char *x_live;
 } mr3d_conv3d_desc;
 int mr3d_conv3d_forward(const mr3d_conv3d_desc *desc, mr3d_stream_t stream);
+/* bits: one bit per position p = ((n*D + d)*H + h)*W + w of the NDHWC map x (fp32, or bf16 if `bf16`; a position's channels must be
+ * 16 * 2^k bytes, k <= 6) -- bit (p & 31) of word p >> 5 is set iff a channel of p is non-zero.  The buffer holds
+ * mr3d_voxel_liveness_words(n*d*h*w) 32-bit words (two of them padding, zeroed). */
+long long mr3d_voxel_liveness_words(long long positions);
+int mr3d_voxel_liveness(const void *x, int bf16, int n, int d, int h, int w, int c, unsigned *bits, mr3d_stream_t s);
 /* bytes of transformed weights U = Gh g Gw^T of one cin -> cout 3x3x3 convolution (72 floats per (ci, co), rounded up to 256 B) */
 size_t mr3d_conv3d_wino2d_workspace_bytes(int cin, int cout);
 
@@ -646,6 +655,8 @@ int mr3d_rpn_merge_levels(const float *dets, const int *seg_rows_host, int num_l
  *   CONV_DGRAD_S2 p / i as CONV_FWD (mr3d_conv3d_dgrad_s2k3: x = dy, w = wb, y = dx; y_d/y_h/y_w = dx's grid)
  *   PW_PAIR       p = {x,w1,add1,mask1,y1,w2,mask2,y2}  i = {c0,c1,c2,relu1,relu2, positions lo,hi, shift1 lo,hi, shift2 lo,hi}
  *                 (mr3d_pointwise_pair; the two shift pointers travel as 64-bit integers)
+ *   VOXEL_LIVENESS p = {x, bits}  i = {n,d,h,w,c, arm}: mr3d_voxel_liveness of x (storage type i[25]); arm = 1: the NEXT CONV_FWD
+ *                 record of the run takes the bitmap as its mr3d_conv3d_desc.x_live (a record has no pointer slot left for it)
  *   SYNC          i = {mode, slot}: ordering between the caller's stream and the internal side stream (see below)
  *   WINO2D_PREP   p = {workspace}  i = {bytes_lo, bytes_hi}: transforms, in ONE launch, the weights of every fp32 CONV_FWD
  *                 record between here and the next PREP_WEIGHTS record that qualifies for the two-dimensional Winograd
@@ -664,6 +675,7 @@ typedef enum {
   MR3D_OP_STEM_PACK_BF16 = 18,        /* p = {w_packed (fp32 [343][4][16]), w16} */
   MR3D_OP_WINO2D_PREP = 20,
   MR3D_OP_PW_PAIR = 21,
+  MR3D_OP_VOXEL_LIVENESS = 22,
   MR3D_OP_SYNC = 19,                  /* i[0] = 0: the caller's stream waits for everything queued on the side stream;
                                          1: remember this point of the side queue in slot i[1] (0..3);
                                          2: the caller's stream waits for the point remembered in slot i[1] */

@@ -459,6 +459,65 @@ def test_conv3d_wgrad_winograd_path_ragged_volume(dev):
     assert rel(dw, 2 * ref) <= RTOL
 
 
+def test_conv3d_forward_liveness_bitmap_writes_dead_tiles_from_the_epilogue(dev):
+    """mr3d_voxel_liveness + mr3d_conv3d_desc.x_live (data gradients of sparse maps in detector training): the bitmap holds exactly
+    the positions with a non-zero channel, and the large-map 3x3x3 kernel given the bitmap returns what it returns without it -- on a
+    map with a few non-zero boxes and single voxels (on tile corners, on the volume's faces, a lone -0.0 that does not count), with
+    shift / add / ReLU in the epilogue (dead tiles are NOT zero then), for 64 fp32 / 16 fp32 / 64 bf16 channels, and on a dense map"""
+    from mr3d_amd import _hip
+    g = torch.Generator(device='cpu').manual_seed(21)
+    shape = (1, 40, 128, 125, 64)                   # W not a multiple of 8 or 32: rows straddle bitmap words
+    dense = torch.randn(shape, generator=g).to(dev)
+    sparse = torch.zeros_like(dense)
+    boxes = ((3, 9, 10, 31, 7, 22), (20, 21, 64, 65, 64, 65), (38, 40, 120, 128, 118, 125), (15, 17, 7, 9, 90, 100),
+             (0, 1, 0, 1, 0, 1), (39, 40, 127, 128, 124, 125), (8, 9, 8, 9, 8, 9), (7, 8, 7, 8, 7, 8))
+    for (d0, d1, h0, h1, w0, w1) in boxes:
+        sparse[:, d0:d1, h0:h1, w0:w1] = dense[:, d0:d1, h0:h1, w0:w1]
+    sparse[0, 30, 30, 30, 5] = -0.0
+    sparse[0, 12, 100, 3, 63] = 1e-30               # one tiny channel is enough
+
+    def unpack(bits, npos):
+        b = bits[: (npos + 31) // 32].view(torch.int32).cpu().numpy().astype(np.uint32)
+        return torch.from_numpy(((b[:, None] >> np.arange(32, dtype=np.uint32)[None, :]) & 1).reshape(-1)[:npos].astype(bool))
+    npos = sparse.numel() // 64
+    for x in (sparse, sparse[..., :16].contiguous(), sparse.to(torch.bfloat16)):
+        got = unpack(_hip.voxel_liveness(x), npos)
+        assert torch.equal(got, (x.float() != 0).any(dim=4).reshape(-1).cpu())
+    assert bool(unpack(_hip.voxel_liveness(dense), npos).all())
+    w = (torch.randn((27, 64, 64), generator=g) * 0.05).to(dev)
+    shift = torch.randn(64, generator=g).to(dev)
+    add = torch.randn(shape, generator=g).to(dev)
+    for x in (sparse, dense):
+        live = _hip.voxel_liveness(x)
+        for kw in (dict(), dict(shift=shift, add1=add, relu=True)):
+            y0 = _hip.conv3d_forward(x, w, (3,) * 3, (1,) * 3, (1,) * 3, **kw)
+            y1 = _hip.conv3d_forward(x, w, (3,) * 3, (1,) * 3, (1,) * 3, x_live=live, **kw)
+            assert torch.equal(y0, y1)
+    # timing: the sparse map's launch is several times shorter than the same launch without the bitmap
+    m = _hip.voxel_liveness(sparse)
+
+    def timed(**kw):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        _hip.conv3d_forward(sparse, w, (3,) * 3, (1,) * 3, (1,) * 3, **kw)
+        ev[0].record()
+        for _ in range(5):
+            _hip.conv3d_forward(sparse, w, (3,) * 3, (1,) * 3, (1,) * 3, **kw)
+        ev[1].record()
+        torch.cuda.synchronize()
+        return ev[0].elapsed_time(ev[1]) / 5
+    t_dense, t_map = timed(), timed(x_live=m)
+    print(f'3x3x3 64->64 on 40x128x125, a few live boxes: {t_dense:.3f} ms without the bitmap, {t_map:.3f} ms with it')
+    assert t_map < 0.6 * t_dense
+    # and through a plan: the VOXEL_LIVENESS record arms the CONV_FWD record behind it
+    y2 = torch.empty_like(sparse)
+    lbits = torch.empty_like(m)
+    ops = [_hip.make_op(_hip.OP_VOXEL_LIVENESS, [sparse, lbits], [1, 40, 128, 125, 64, 1]),
+           _hip.make_op(_hip.OP_CONV_FWD, [sparse, w, y2, None, None, None, None, None],
+                        [1, 40, 128, 125, 64, 64, 3, 3, 3, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0])]
+    _hip.Plan(ops).run(dev)
+    assert torch.equal(lbits, m) and torch.equal(y2, _hip.conv3d_forward(sparse, w, (3,) * 3, (1,) * 3, (1,) * 3))
+
+
 def test_conv3d_wgrad_sparse_dy_flag_skips_zero_tiles_only(dev):
     """MR3D_WGRAD_SPARSE_DY (detector training: the gradient at the RPN conv / FPN output convs is zero on most position tiles):
     with a dy that is non-zero in a few scattered boxes -- some cut by tile borders, one single voxel -- the tile-skipping
