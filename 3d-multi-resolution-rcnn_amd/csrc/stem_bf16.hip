@@ -216,15 +216,21 @@ __global__ __launch_bounds__(512, 1) void stem_fwd_bf16_kernel(StemBfArgs p, int
 struct WgGeo {
   static constexpr int TD = 4, TH = 4, TW = 32, NT = 512;
   static constexpr int HD = TD + 6, HH = 2 * (TH - 1) + 7;                    // 10 x 13 rows
-  static constexpr int HALF = 40;                                             // columns per parity plane (35 used + slack)
+  static constexpr int HALF = 38;                                             // columns per parity plane (36 used; 38 and the plane pad below
+                                                                              //   spread a fragment dword's 32 lanes over the banks: see PLANE)
   // A row holds FOUR images: even columns, even columns shifted by one, odd columns, odd columns shifted by one.  A fragment
   // starts at plane index ow + (kw >> 1): with the shifted copy every start is an EVEN element = 4-byte aligned.  (2-byte
   // aligned 16-byte LDS reads work on gfx950 but were measured ~10x slower than dword-aligned ones: 1.68 ms for this kernel.)
   static constexpr int ROW = 4 * HALF;
-  static constexpr int PLANE = HD * HH * ROW;
+  // A fragment is four dword reads (4-byte aligned starts), 32 lanes per LDS pass: 16 GEMM rows (8 kw x 2 channels, or 2 (kd, kh)
+  // rows) x 2 k-groups.  With HALF = 40 and planes of 10400 dwords the rows r and r + 8 -- the same tap of channels c and c + 1 -- sat
+  // on the SAME bank and the (kw, q) pattern {0,8,20,28,1,9,21,29} + {0,4} collided with itself: 4-way on average, 71 % of this
+  // kernel's LDS-active cycles were conflict cycles.  HALF = 38 with a 2-element plane pad (searched over HALF, plane and row pads
+  // with the kernel's own address map) leaves 2-way: 1.03 -> 0.8 ms.
+  static constexpr int PLANE = HD * HH * ROW + 2;
   static constexpr int DYROW = 24;                                            // bf16 per dy row: 16 + 8 of padding (48 B)
   static constexpr int M = TD * TH * TW, KS = TD * TH;
-  static constexpr int SLAB_BYTES = 3 * PLANE * 2, DY_BYTES = M * DYROW * 2;
+  static constexpr int SLAB_BYTES = (3 * PLANE * 2 + 15) / 16 * 16, DY_BYTES = M * DYROW * 2;
   static constexpr int LDS_BYTES = SLAB_BYTES + DY_BYTES + 64;
   static constexpr int ROWS = 49 * 24, MT = (ROWS + 15) / 16;                 // 1176 GEMM rows -> 74 tiles (+ 1 of ones)
   static constexpr int MTW = 10;                                              // row tiles per wave (8 waves x 10 >= 75)
@@ -260,9 +266,11 @@ __global__ __launch_bounds__(512, 1) void stem_wgrad_bf16_kernel(StemBfWgArgs p,
     ones[i] = (m == G::MT);                              // the extra tile: a fragment of ones -> sum_p dy
     live[i] = (m < G::MT) && R < G::ROWS && kw < 7;
     // input column 2*ow + kw (relative to the slab origin): parity plane kw & 1, index ow + (kw >> 1)
-    const int cc = live[i] ? c : 0, kk = live[i] ? kw : 0, dd = live[i] ? kd : 0, hh_ = live[i] ? kh : 0;
+    // (a dead kw = 7 lane reads its kw = 6 neighbour's fragment -- the same dwords: a broadcast, not a conflict -- and drops it)
+    const bool in_rows = (m < G::MT) && R < G::ROWS;
+    const int cc = in_rows ? c : 0, kk = in_rows ? min(kw, 6) : 0, dd = in_rows ? kd : 0, hh_ = in_rows ? kh : 0;
     const int sft = kk >> 1;                             // odd start -> the copy shifted by one, one element earlier
-    aoff[i] = (((cc * G::HD + dd) * G::HH + hh_) * G::ROW + (kk & 1) * 2 * G::HALF + (sft & 1) * G::HALF + (sft & ~1) + 8 * q) * 2;
+    aoff[i] = (cc * G::PLANE + (dd * G::HH + hh_) * G::ROW + (kk & 1) * 2 * G::HALF + (sft & 1) * G::HALF + (sft & ~1) + 8 * q) * 2;
   }
   // transposing read of dy [position][16]: group q reads positions 8q..8q+7; inside the group lane 4a+b gives row a, columns 4b..4b+3
   const int i16 = lane & 15, ra = i16 >> 2, cb = i16 & 3;
@@ -324,7 +332,7 @@ __global__ __launch_bounds__(512, 1) void stem_wgrad_bf16_kernel(StemBfWgArgs p,
       bf16_t *dst = slab + s_hh * G::ROW;
 #pragma unroll
       for (int u = 0; u < NPL; ++u) {
-        bf16_t *d = dst + u * G::HH * G::ROW;
+        bf16_t *d = dst + (u / G::HD) * G::PLANE + (u % G::HD) * G::HH * G::ROW;
         const bf16_t vo = f2bf(st[u].x), ve = f2bf(st[u].y);          // odd-plane index pr - 1, even-plane index pr
         if (s_pr >= 1) d[2 * G::HALF + s_pr - 1] = vo;
         if (s_pr >= 2) d[3 * G::HALF + s_pr - 2] = vo;                // shifted copy: X1[i] = X0[i + 1]

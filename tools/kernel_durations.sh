@@ -1,6 +1,6 @@
 #!/bin/bash
 # per-launch durations of the kernels whose name contains $2 over a bench.py run (rocprofv3 kernel trace)
-# usage: tools/kernel_durations.sh <out-name> <name-substring> [steps]      (through gpurun)
+# usage: tools/kernel_durations.sh <out-name> <name-substring> [steps] ["extra bench flags"]      (through gpurun)
 set -u
 REPO=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$REPO/gpurun_out/${1:-kd}
@@ -8,7 +8,7 @@ PAT=${2:-stem_wgrad}
 STEPS=${3:-30}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --output-format csv --kernel-trace -d "$OUT/tr" -o kd -- python3 "$REPO/bench.py" --steps "$STEPS" --warmup 3 --no-aux --no-cpu-baseline > "$OUT/bench.json" 2> "$OUT/err.txt"
+rocprofv3 --output-format csv --kernel-trace -d "$OUT/tr" -o kd -- python3 "$REPO/bench.py" --steps "$STEPS" --warmup 3 --no-aux --no-cpu-baseline ${4:-} > "$OUT/bench.json" 2> "$OUT/err.txt"
 cd "$REPO"
 KT=$(find "$OUT/tr" -name '*kernel_trace.csv' | head -1)
 python3 - "$KT" "$PAT" > "$OUT/durations.txt" <<'PY'
