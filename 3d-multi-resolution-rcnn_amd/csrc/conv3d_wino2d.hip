@@ -45,6 +45,12 @@ constexpr int VPITCH = NFC * CC + 2;                    // floats per (plane, pa
 constexpr int VFLOATS = HD * 8 * VPITCH;
 constexpr int LDS_BYTES = (VFLOATS > HP * ROW ? VFLOATS : HP * ROW) * 4;      // V overlays the halo
 constexpr int NF = 24;                                 // products per patch and kd tap
+// conv3d_wino2d_rows_kernel reads its 4 x 6 windows straight from the halo: a lane's address is (plane, row pair, column quad, k)
+// of its patch, and with the plain geometry (row pitch 10, planes of 1700 floats) the plane and the column quad both moved a lane by
+// 4 banks: 3-way conflicts, 65 % of the kernel's LDS-active cycles.  A row pitch of 12 positions and 2 floats between planes make the
+// 32 lanes of a read hit 32 banks (searched over row / plane pitches with the kernel's own address map).
+constexpr int HWR = 12, RPAD = 2;
+constexpr int rows_plane(int hh) { return hh * HWR * ROW + RPAD; }
 
 // U(kd, f = fh*6+fw, ci, co) = sum_kh sum_kw Gh[fh][kh] Gw[fw][kw] w[(kd*3+kh)*3+kw][ci][co]
 __global__ __launch_bounds__(256) void wino2d_weights_kernel(const float *__restrict__ w, float *__restrict__ U, int cin, int cout) {
@@ -296,7 +302,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wino2d_rows_kernel(Conv3dF
   const int wave_m = wave / WN, wave_n = wave % WN;
   const int co = blockIdx.y * (16 * WN) + wave_n * 16 + li;
   // A operand: this lane's GEMM row (li) = patch (td, th2, tw4) and its k index inside the k-step (lk)
-  const int abase = ((((2 * wave_m + (li >> 3)) * HHr) + ((li >> 1) & 3) * 2) * HW + (li & 1) * 4) * ROW + lk;
+  constexpr int PL = rows_plane(HHr);
+  const int abase = (2 * wave_m + (li >> 3)) * PL + (((li >> 1) & 3) * 2 * HWR + (li & 1) * 4) * ROW + lk;
   const float *ul = U + ((size_t)lk * (NF / 4) * p.Cout + co) * 4;
 
   constexpr int MT = 1;
@@ -316,11 +323,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wino2d_rows_kernel(Conv3dF
   auto read_d = [&](int kd, int kk) {                    // the 4 x 6 input window of this lane's patch and channel
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const float *src = lds + abase + ((kd + 2 * mt) * HHr * HW) * ROW + kk * 4;
+      const float *src = lds + abase + (kd + 2 * mt) * PL + kk * 4;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 6; ++j) d[mt][i][j] = src[(i * HW + j) * ROW];
+        for (int j = 0; j < 6; ++j) d[mt][i][j] = src[(i * HWR + j) * ROW];
     }
   };
   auto xform = [&](int mt, int fh, float (&dst)[NF]) {   // row fh of V = Bh^T d Bw
@@ -388,7 +395,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wino2d_rows_kernel(Conv3dF
           if (it < HDr * HH * HW * Q) {
             const int pos = it / Q, q = it - pos * Q;
             const int hw = pos % HW, hh = (pos / HW) % HH, hd = pos / (HW * HH);
-            float *dd = lds + ((hd * HHr + hh) * HW + hw) * ROW + q * 4;
+            float *dd = lds + hd * PL + (hh * HWR + hw) * ROW + q * 4;
             dd[0] = stage[jj].x; dd[1] = stage[jj].y; dd[2] = stage[jj].z; dd[3] = stage[jj].w;
           }
         }
@@ -510,7 +517,7 @@ bool mr3d_conv3d_wino2d_rows_ok(const Conv3dFwdArgs &a) {
 
 template <int WN>
 static int launch_rows(const Conv3dFwdArgs &a, const float *U, hipStream_t stream) {
-  constexpr int TDr = 2 * (4 / WN), lds = (TDr + 2) * HH * HW * ROW * 4;
+  constexpr int TDr = 2 * (4 / WN), lds = (TDr + 2) * rows_plane(HH) * 4;
   static std::once_flag once;
   static bool ok = false;
   std::call_once(once, [] {
