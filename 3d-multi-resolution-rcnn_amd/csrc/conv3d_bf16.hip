@@ -51,13 +51,18 @@ struct BfCfg {
   static constexpr int LS = PW1 ? 1 : S_;          // LDS step per output position
   static constexpr int GS = PW1 ? S_ : 1;          // global step per halo position (a strided 1x1x1 reads every S-th voxel)
   static constexpr int HD = (TD - 1) * LS + K, HH = (TH - 1) * LS + K, HW = (TW - 1) * LS + K, HP = HD * HH * HW;
+  // halo row pitch in LDS: the 16 lanes of a ds_read_b128 group hold positions of four tile rows, and with the plain pitch (10 for
+  // the 3x3x3 / stride-1 tiles) three of them land on one 16-byte slot of the bank row (62 % of the LDS-active cycles were
+  // conflicts); two spare positions per row leave 2-way (searched with the kernel's own address map)
+  static constexpr int HWP = (K == 3 && S == 1 && TW == 8) ? HW + 2 : HW;
+  static constexpr int HPP = HD * HH * HWP;
   static constexpr int ROWB = CC * 2 + 16;         // bytes per halo position (16 B of padding staggers the banks)
   static constexpr int M = TD * TH * TW;
   static constexpr int MTW = M / 128;              // 32-row MFMA tiles per wave
   static constexpr int KK = CC / 16;               // MFMA k-steps per tap and chunk
   static constexpr int TAPS = K * K * K;
   static constexpr int NB = 32 * NT;
-  static constexpr int LDS_BYTES = (HP * ROWB > M * 36 * 4) ? HP * ROWB : M * 36 * 4;    // halo, later the epilogue's rows
+  static constexpr int LDS_BYTES = (HPP * ROWB > M * 36 * 4) ? HPP * ROWB : M * 36 * 4;    // halo, later the epilogue's rows
   static constexpr int PIECES = HP * (CC / 8);     // 16-byte pieces of a halo chunk
   static constexpr int NIT = (PIECES + kThreads - 1) / kThreads;
   static_assert(M % 128 == 0 && CC % 16 == 0, "tile");
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_bf16_kernel(BfArgs p, int 
   for (int mt = 0; mt < C::MTW; ++mt) {
     const int m = (wave * C::MTW + mt) * 32 + r;
     const int tw = m % C::TW, th = (m / C::TW) % C::TH, td = m / (C::TW * C::TH);
-    abase[mt] = (((td * C::LS) * C::HH + th * C::LS) * C::HW + tw * C::LS) * C::ROWB + 16 * h;
+    abase[mt] = (((td * C::LS) * C::HH + th * C::LS) * C::HWP + tw * C::LS) * C::ROWB + 16 * h;
   }
   // this lane's B fragment: rows of 8 input channels (k = 8h .. 8h+7 of a 16-wide k-step), column n0 + nt*32 + r
   const int cin8 = p.Cin >> 3;
@@ -122,7 +127,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_bf16_kernel(BfArgs p, int 
       constexpr int Q = C::CC / 8;
       if (it < C::PIECES) {
         const int pos = it / Q, q = it - pos * Q;
-        *reinterpret_cast<uint4 *>(lds + pos * C::ROWB + q * 16) = stage[j];
+        const int row = pos / C::HW, hw = pos - row * C::HW;
+        *reinterpret_cast<uint4 *>(lds + (row * C::HWP + hw) * C::ROWB + q * 16) = stage[j];
       }
     }
   };
@@ -136,7 +142,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_bf16_kernel(BfArgs p, int 
   };
   auto mma_tap = [&](const bf16x8 (&bw)[C::KK][C::NT], int tap) {
     const int kw = tap % C::K, kh = (tap / C::K) % C::K, kd = tap / (C::K * C::K);
-    const int tapoff = ((kd * C::HH + kh) * C::HW + kw) * C::ROWB;
+    const int tapoff = ((kd * C::HH + kh) * C::HWP + kw) * C::ROWB;
 #pragma unroll
     for (int kk = 0; kk < C::KK; ++kk) {
       bf16x8 a[C::MTW];
