@@ -23,7 +23,6 @@ using bf16_t = uint16_t;
 typedef __attribute__((address_space(3))) s16x4 *lds_s16x4_ptr;
 
 constexpr int kThreads = 256;
-constexpr int ROWB = 80;             // 32 channels x 2 B + 16 B of padding per staged position
 
 struct WgArgs {
   const bf16_t *x; const bf16_t *dy; float *dw; float *dbias;
@@ -41,7 +40,11 @@ struct WgCfg {
   static constexpr int M = TD * TH * TW, KS = TD * TH;          // positions, k-steps per tile
   static constexpr int TAPS = K * K * K;
   static constexpr int NTW = PW1 ? 1 : (TAPS + 3) / 4;          // accumulator slots per wave (taps, + the ones slot)
-  static constexpr int XBYTES = HP * ROWB, YBYTES = M * ROWB;
+  // bytes per staged position.  A transposing read (ds_read_b64_tr_b16, 32 lanes per LDS pass) takes 4 positions x 64 B: unpadded
+  // 64-byte rows put them on four disjoint 16-bank blocks of the 64-bank row (80-byte rows overlapped two of them: 2-way, 50 % of
+  // the LDS-active cycles); a stride-2 halo (every second position) needs 96.
+  static constexpr int XROWB = (LS == 2) ? 96 : 64, YROWB = 64;
+  static constexpr int XBYTES = HP * XROWB, YBYTES = M * YROWB;
   static constexpr int RED_BYTES = PW1 ? 4 * 2 * 32 * 33 * 4 : 0;   // 1x1x1: the four waves' (dw, sum dy) tiles meet here
   static constexpr int LDS_BYTES = (XBYTES + YBYTES > RED_BYTES) ? XBYTES + YBYTES : RED_BYTES;
   // 3x3x3 stride 1: ONE workgroup per CU with the whole 512-register budget -- both operands of the next tile prefetched and the
@@ -69,8 +72,8 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_wgrad_bf16_kernel(W
   // inside the group lane 4q+pp supplies the address of row q (a position), channels 4pp..4pp+3
   const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pp = i16 & 3, cb = g & 1, hh = g >> 1;
   const int ci0 = blockIdx.y * 32, co0 = blockIdx.z * 32;
-  const int a_lane = ((8 * hh + q) * C::LS) * ROWB + (16 * cb + 4 * pp) * 2;     // x halo: k-th position of a row is LS apart
-  const int b_lane = (8 * hh + q) * ROWB + (16 * cb + 4 * pp) * 2;
+  const int a_lane = ((8 * hh + q) * C::LS) * C::XROWB + (16 * cb + 4 * pp) * 2;     // x halo: k-th position of a row is LS apart
+  const int b_lane = (8 * hh + q) * C::YROWB + (16 * cb + 4 * pp) * 2;
   const bool want_bias = p.dbias != nullptr && blockIdx.y == 0;
 
   f32x16_t acc[C::NTW + (C::PW1 ? 1 : 0)];
@@ -142,12 +145,12 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_wgrad_bf16_kernel(W
 #pragma unroll
     for (int j = 0; j < NXR; ++j) {
       const int it = tid + j * kThreads;
-      if (it < C::HP * 4) *reinterpret_cast<uint4 *>(xs + (it >> 2) * ROWB + (it & 3) * 16) = xr[j];
+      if (it < C::HP * 4) *reinterpret_cast<uint4 *>(xs + (it >> 2) * C::XROWB + (it & 3) * 16) = xr[j];
     }
 #pragma unroll
     for (int j = 0; j < NYR; ++j) {
       const int it = tid + j * kThreads;
-      if (it < C::M * 4) *reinterpret_cast<uint4 *>(ys + (it >> 2) * ROWB + (it & 3) * 16) = yr[j];
+      if (it < C::M * 4) *reinterpret_cast<uint4 *>(ys + (it >> 2) * C::YROWB + (it & 3) * 16) = yr[j];
     }
   };
 
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_wgrad_bf16_kernel(W
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
       if (ci < p.Cin && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
         v = *reinterpret_cast<const uint4 *>(p.x + ((((size_t)n * p.D + id) * p.H + ih) * p.W + iw) * p.Cin + ci);
-      *reinterpret_cast<uint4 *>(xs + pos * ROWB + qq * 16) = v;
+      *reinterpret_cast<uint4 *>(xs + pos * C::XROWB + qq * 16) = v;
     }
     for (int it = tid; it < C::M * 4; it += kThreads) {
       const int m = it >> 2, qq = it & 3;
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_wgrad_bf16_kernel(W
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
       if (co < p.Cout && od < p.Do && oh < p.Ho && ow < p.Wo)
         v = *reinterpret_cast<const uint4 *>(p.dy + ((((size_t)n * p.Do + od) * p.Ho + oh) * p.Wo + ow) * p.Cout + co);
-      *reinterpret_cast<uint4 *>(ys + m * ROWB + qq * 16) = v;
+      *reinterpret_cast<uint4 *>(ys + m * C::YROWB + qq * 16) = v;
     }
   };
 
@@ -217,8 +220,8 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_wgrad_bf16_kernel(W
 
     if constexpr (C::PW1) {
       for (int ks = wave; ks < C::KS; ks += 4) {        // waves split the k-steps
-        const bf16x8 bf = tr_frag(ys, b_lane + ks * 16 * ROWB, b_lane + (ks * 16 + 4) * ROWB);
-        const bf16x8 af = tr_frag(xs, a_lane + ks * 16 * ROWB, a_lane + (ks * 16 + 4) * ROWB);
+        const bf16x8 bf = tr_frag(ys, b_lane + ks * 16 * C::YROWB, b_lane + (ks * 16 + 4) * C::YROWB);
+        const bf16x8 af = tr_frag(xs, a_lane + ks * 16 * C::XROWB, a_lane + (ks * 16 + 4) * C::XROWB);
         acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[0], 0, 0, 0);
         if (want_bias) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bf, acc[1], 0, 0, 0);
       }
@@ -235,16 +238,16 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_wgrad_bf16_kernel(W
         int tap = wave + 4 * ti;
         if (tap >= C::TAPS) tap = C::TAPS - 1;
         const int kw = tap % C::K, kh = (tap / C::K) % C::K, kd = tap / (C::K * C::K);
-        tapoff[ti] = ((kd * C::HH + kh) * C::HW + kw) * ROWB;
+        tapoff[ti] = ((kd * C::HH + kh) * C::HW + kw) * C::XROWB;
       }
       auto load_frags = [&](int ks, bf16x8 (&af)[C::NTW], bf16x8 &bf) {
         const int th = ks % C::TH, td = ks / C::TH;
-        bf = tr_frag(ys, b_lane + ks * 16 * ROWB, b_lane + (ks * 16 + 4) * ROWB);
-        const int rowbase = a_lane + (((td * C::LS) * C::HH + th * C::LS) * C::HW) * ROWB;
+        bf = tr_frag(ys, b_lane + ks * 16 * C::YROWB, b_lane + (ks * 16 + 4) * C::YROWB);
+        const int rowbase = a_lane + (((td * C::LS) * C::HH + th * C::LS) * C::HW) * C::XROWB;
 #pragma unroll
         for (int ti = 0; ti < C::NTW; ++ti) {
           const int off = rowbase + tapoff[ti];
-          af[ti] = tr_frag(xs, off, off + 4 * C::LS * ROWB);
+          af[ti] = tr_frag(xs, off, off + 4 * C::LS * C::XROWB);
         }
         if (spare) af[LAST] = ones;                      // sum_p dy on the matrix pipe (wave-uniform select)
       };
