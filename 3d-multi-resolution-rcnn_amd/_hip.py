@@ -286,6 +286,11 @@ def rpn_merge_levels(dets, caps, keep, num_keep, nms_post, max_num):
     return out, count
 
 
+def multiclass_nms3d_fits(n, num_classes):
+    """whether mr3d_multiclass_nms3d takes n rows x num_classes columns (its LDS-resident ranking: <= 4096 rows, <= 16 classes)"""
+    return num_classes < 2 or _sz(lib().mr3d_multiclass_nms3d_workspace_bytes, int(n), int(num_classes)) != 0
+
+
 def multiclass_nms3d(multi_bboxes, multi_scores, score_thr, iou_thr, max_num):
     """mr3d_multiclass_nms3d -> (dets [k,7], labels int64 [k]); one 4-byte read-back (the output's row count)"""
     for t, what in ((multi_bboxes, 'multi_bboxes'), (multi_scores, 'multi_scores')):

@@ -224,6 +224,27 @@ def test_multiclass_nms_3d_several_classes(dev, max_num, shared_boxes):
         multiclass_nms_3d(torch.from_numpy(cols).to(dev), torch.from_numpy(scores).to(dev), 0.3, dict(type='soft_nms', iou_thr=0.5), 10)
 
 
+def test_multiclass_nms_3d_beyond_the_fused_ops_limits(dev):
+    """more rows than the one-launch op ranks in LDS (4096): the class-by-class walk over the device NMS3D gives the restated
+    reference flow's result too (e.g. a test_cfg whose two pathways bring 2 x 2500 rows)"""
+    from mr3d_amd.core import multiclass_nms_3d
+    from mr3d_amd import _hip
+    rng = np.random.default_rng(4)
+    n, C = 5000, 3
+    assert not _hip.multiclass_nms3d_fits(n, C) and _hip.multiclass_nms3d_fits(4000, 2)
+    ctr = rng.uniform([10, 10, 4], [400, 400, 70], (200, 3))[rng.integers(0, 200, n)] + rng.normal(0, 2, (n, 3))
+    half = rng.uniform([4, 4, 2], [14, 14, 6], (n, 3))
+    b = np.stack([ctr[:, 0] - half[:, 0], ctr[:, 1] - half[:, 1], ctr[:, 0] + half[:, 0], ctr[:, 1] + half[:, 1],
+                  ctr[:, 2] - half[:, 2], ctr[:, 2] + half[:, 2]], 1).astype(np.float32)
+    scores = rng.permutation(n * C).reshape(n, C).astype(np.float32) / (n * C)
+    for max_num in (10000, 300):
+        got_b, got_l = multiclass_nms_3d(torch.from_numpy(b).to(dev), torch.from_numpy(scores).to(dev), 0.5,
+                                         dict(type='nms', iou_thr=0.5), max_num)
+        exp_b, exp_l = _ref_multiclass(b, scores, 0.5, 0.5, max_num)
+        np.testing.assert_array_equal(got_b.cpu().numpy(), exp_b)
+        np.testing.assert_array_equal(got_l.cpu().numpy(), exp_l)
+
+
 @pytest.mark.parametrize('n,k,frac', [(655360, 2000, 0.7), (81920, 2000, 1.0), (10240, 2000, 0.05), (5000, 2000, 0.0), (8192, 4096, 0.9)])
 def test_rpn_select_topk_is_an_exact_topk(dev, n, k, frac):
     """mr3d_rpn_select_topk (radix select on the logits): the selected set equals torch.topk's on the masked scores wherever
