@@ -156,15 +156,21 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_bf16_kernel(BfArgs p, int 
     }
   };
 
-  bf16x8 b0[C::KK][C::NT], b1[C::KK][C::NT];
+  // The weight fragments of the next RD - 1 (chunk, tap) steps are in flight while a step is multiplied.  One step ahead was enough
+  // on the large maps (many MFMAs per tap) but on the small ones (one 32-row tile per wave: layer3 / layer4, P4 / P5) every tap
+  // waited for an L2 round trip -- 27 taps x Cin / 32 chunks x ~0.7 us = the whole 40 us of a launch with 2-6 us of matrix work.
+  constexpr int RD = C::MTW == 1 ? 4 : 2;
+  bf16x8 bq[RD][C::KK][C::NT];
   const int nchunks = p.Cin / C::CC;
-  const int total = nchunks * C::TAPS;          // flattened (chunk, tap) walk; the B registers ping-pong across it
+  const int total = nchunks * C::TAPS;          // flattened (chunk, tap) walk; the B registers rotate across it
   fetch(0);
-  load_b(b0, 0, 0);
-  for (int it = 0; it < total; it += 2) {
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const int cur = it + half;
+  for (int u = 0; u < RD - 1; ++u)
+    if (u < total) load_b(bq[u], (u / C::TAPS) * C::CC, u % C::TAPS);
+  for (int it = 0; it < total; it += RD) {
+#pragma unroll
+    for (int u = 0; u < RD; ++u) {
+      const int cur = it + u;
       if (cur >= total) break;
       const int chunk = cur / C::TAPS, tap = cur - chunk * C::TAPS;
       if (tap == 0) {
@@ -173,12 +179,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_bf16_kernel(BfArgs p, int 
         __syncthreads();
         if (chunk + 1 < nchunks) fetch((chunk + 1) * C::CC);
       }
-      const int nxt = cur + 1;
+      const int nxt = cur + RD - 1;
       if (nxt < total) {
         const int nchunk = nxt / C::TAPS, ntap = nxt - nchunk * C::TAPS;
-        if (half == 0) load_b(b1, nchunk * C::CC, ntap); else load_b(b0, nchunk * C::CC, ntap);
+        load_b(bq[(u + RD - 1) % RD], nchunk * C::CC, ntap);
       }
-      if (half == 0) mma_tap(b0, tap); else mma_tap(b1, tap);
+      mma_tap(bq[u], tap);
     }
   }
 
