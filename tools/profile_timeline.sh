@@ -6,7 +6,7 @@ REPO=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$REPO/gpurun_out/${1:-tl}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --output-format csv --kernel-trace -d "$OUT/tr" -o tl -- python3 "$REPO/bench.py" --steps 6 --warmup 3 --no-aux --no-cpu-baseline > "$OUT/bench.json" 2> "$OUT/err.txt"
+rocprofv3 --output-format csv --kernel-trace -d "$OUT/tr" -o tl -- python3 "$REPO/bench.py" --steps 6 --warmup 3 --no-aux --no-cpu-baseline ${2:-} ${3:-} > "$OUT/bench.json" 2> "$OUT/err.txt"
 cd "$REPO"
 KT=$(find "$OUT/tr" -name '*kernel_trace.csv' | head -1)
 python3 tools/timeline.py "$KT" -2 > "$OUT/timeline.txt"
