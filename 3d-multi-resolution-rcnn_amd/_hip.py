@@ -487,8 +487,9 @@ def pack_conv_weight_bf16(w):
     return buf.view(taps, ci16 // 8, 8, co32).permute(0, 1, 3, 2).contiguous().to(torch.bfloat16)
 
 
-def conv3d_forward_bf16(x, w16, cout, k, stride, pad, shift=None, add1=None, add2=None, up=None, mask=None, relu=False):
-    """x: [N,D,H,W,Cin] bf16 (NDHWC); w16: pack_conv_weight_bf16 layout; returns y [N,Do,Ho,Wo,cout] bf16."""
+def conv3d_forward_bf16(x, w16, cout, k, stride, pad, shift=None, add1=None, add2=None, up=None, mask=None, relu=False, x_live=None):
+    """x: [N,D,H,W,Cin] bf16 (NDHWC); w16: pack_conv_weight_bf16 layout; returns y [N,Do,Ho,Wo,cout] bf16.
+    x_live: a voxel_liveness bitmap that covers x's non-zero positions (3x3x3 / stride 1 / pad 1: dead tiles are their epilogue)."""
     assert x.is_cuda and x.is_contiguous() and x.dtype == torch.bfloat16 and x.dim() == 5 and w16.dtype == torch.bfloat16
     oshape = conv3d_out_shape(x.shape, cout, k, stride, pad)
     y = torch.empty(oshape, dtype=torch.bfloat16, device=x.device)
@@ -505,6 +506,9 @@ def conv3d_forward_bf16(x, w16, cout, k, stride, pad, shift=None, add1=None, add
         assert up.is_contiguous() and up.size(4) == cout and up.dtype == torch.bfloat16
         d.up_d, d.up_h, d.up_w = up.size(1), up.size(2), up.size(3)
     d.relu = int(bool(relu))
+    if x_live is not None:
+        assert x_live.dtype == torch.int32 and x_live.is_contiguous() and x_live.numel() >= voxel_liveness_words(x.numel() // x.size(4))
+        d.x_live = x_live.data_ptr()
     with torch.cuda.device(x.device):
         st = lib().mr3d_conv3d_forward_bf16(ctypes.byref(d), stream_ptr(x.device))
     check(st, 'mr3d_conv3d_forward_bf16')

@@ -32,6 +32,7 @@ struct BfArgs {
   int Du, Hu, Wu;
   int relu;
   int ysd, ysh, ysw, yD, yH, yW;
+  const unsigned char *x_live = nullptr;      // mr3d_voxel_liveness bitmap of x, or null
 };
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float((uint32_t)v << 16); }
@@ -69,7 +70,9 @@ struct BfCfg {
   static_assert(LDS_BYTES <= 160 * 1024, "halo exceeds LDS");
 };
 
-template <class C>
+// LIVE (3x3x3 / stride 1): the caller lent a voxel liveness bitmap of x (mr3d_voxel_liveness) -- a tile whose halo holds no live voxel
+// is written from its epilogue alone (data gradients of the sparse maps of detector training, cf. conv3d_wino2d_kernel<true>)
+template <class C, bool LIVE = false>
 __global__ __launch_bounds__(kThreads, 2) void conv3d_bf16_kernel(BfArgs p, int tiles_d, int tiles_h, int tiles_w) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -84,6 +87,22 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_bf16_kernel(BfArgs p, int 
   const int od0 = td_i * C::TD, oh0 = th_i * C::TH, ow0 = tw_i * C::TW;
   const int id0 = od0 * C::S - p.pd, ih0 = oh0 * C::S - p.ph, iw0 = ow0 * C::S - p.pw;
   const int n0 = blockIdx.y * C::NB;
+  bool dead = false;                                 // (workgroup-uniform: every wave tests the same halo rows)
+  if constexpr (LIVE) {
+    static_assert(C::HD * C::HH <= 64, "one lane per halo row");
+    const int hd = lane / C::HH, hh = lane - hd * C::HH;
+    const int id = id0 + hd, ih = ih0 + hh;
+    unsigned bits = 0;
+    if (lane < C::HD * C::HH && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H) {
+      const int w_lo = max(iw0, 0), w_hi = min(iw0 + C::HW, p.W);
+      const long long b0 = (((long long)n * p.D + id) * p.H + ih) * p.W + w_lo;
+      const unsigned *wd = reinterpret_cast<const unsigned *>(p.x_live) + (b0 >> 5);
+      const int sh = (int)(b0 & 31), cnt = w_hi - w_lo;                        // cnt <= 10: at most two words
+      const unsigned long long two = (unsigned long long)wd[0] | ((unsigned long long)(sh + cnt > 32 ? wd[1] : 0u) << 32);
+      bits = (unsigned)(two >> sh) & ((1u << cnt) - 1u);
+    }
+    dead = __builtin_amdgcn_ballot_w64(bits != 0) == 0;
+  }
 
   int abase[C::MTW];
 #pragma unroll
@@ -162,8 +181,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_bf16_kernel(BfArgs p, int 
   constexpr int RD = C::MTW == 1 ? 4 : 2;
   bf16x8 bq[RD][C::KK][C::NT];
   const int nchunks = p.Cin / C::CC;
-  const int total = nchunks * C::TAPS;          // flattened (chunk, tap) walk; the B registers rotate across it
-  fetch(0);
+  const int total = dead ? 0 : nchunks * C::TAPS;          // flattened (chunk, tap) walk; the B registers rotate across it
+  if (!dead) fetch(0);
 #pragma unroll
   for (int u = 0; u < RD - 1; ++u)
     if (u < total) load_b(bq[u], (u / C::TAPS) * C::CC, u % C::TAPS);
@@ -257,12 +276,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_bf16_kernel(BfArgs p, int 
   }
 }
 
-template <class C>
+template <class C, bool LIVE = false>
 int launch_bf(const BfArgs &a, hipStream_t stream) {
   const int tiles_d = (a.Do + C::TD - 1) / C::TD, tiles_h = (a.Ho + C::TH - 1) / C::TH, tiles_w = (a.Wo + C::TW - 1) / C::TW;
   static bool attr_done = false;
   if (!attr_done && C::LDS_BYTES > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3d_bf16_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3d_bf16_kernel<C, LIVE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             C::LDS_BYTES) != hipSuccess) {
       (void)hipGetLastError();
       return MR3D_ERR_LAUNCH;
@@ -270,7 +289,7 @@ int launch_bf(const BfArgs &a, hipStream_t stream) {
     attr_done = true;
   }
   dim3 grid((unsigned)(a.N * tiles_d * tiles_h * tiles_w), (unsigned)(a.CoutPad / C::NB));
-  conv3d_bf16_kernel<C><<<grid, kThreads, C::LDS_BYTES, stream>>>(a, tiles_d, tiles_h, tiles_w);
+  conv3d_bf16_kernel<C, LIVE><<<grid, kThreads, C::LDS_BYTES, stream>>>(a, tiles_d, tiles_h, tiles_w);
   return mr3d_launch_status();
 }
 
@@ -280,6 +299,12 @@ int dispatch_tile(const BfArgs &a, hipStream_t stream) {
   if constexpr (K == 3 && S == 2) {
     return launch_bf<BfCfg<K, S, 2, 8, 8, CC, NT>>(a, stream);       // the 4x8x8 halo of a stride-2 3x3x3 does not fit LDS
   } else {
+    if constexpr (K == 3 && S == 1) {
+      if (a.x_live && a.pd == 1 && a.ph == 1 && a.pw == 1) {
+        if (wg488 >= 512) return launch_bf<BfCfg<K, S, 4, 8, 8, CC, NT>, true>(a, stream);
+        return launch_bf<BfCfg<K, S, 2, 8, 8, CC, NT>, true>(a, stream);
+      }
+    }
     if (wg488 >= 512) return launch_bf<BfCfg<K, S, 4, 8, 8, CC, NT>>(a, stream);
     return launch_bf<BfCfg<K, S, 2, 8, 8, CC, NT>>(a, stream);
   }
@@ -316,6 +341,7 @@ extern "C" int mr3d_conv3d_forward_bf16(const mr3d_conv3d_desc *d, mr3d_stream_t
   a.Wo = (d->w_in + 2 * d->pw - d->kw) / d->sw + 1;
   a.Du = d->up_d; a.Hu = d->up_h; a.Wu = d->up_w;
   a.relu = d->relu;
+  a.x_live = d->x_live;
   a.ysd = d->ys_d > 0 ? d->ys_d : 1; a.ysh = d->ys_h > 0 ? d->ys_h : 1; a.ysw = d->ys_w > 0 ? d->ys_w : 1;
   a.yD = d->y_d > 0 ? d->y_d : a.Do; a.yH = d->y_h > 0 ? d->y_h : a.Ho; a.yW = d->y_w > 0 ? d->y_w : a.Wo;
   if ((a.Do - 1) * a.ysd >= a.yD || (a.Ho - 1) * a.ysh >= a.yH || (a.Wo - 1) * a.ysw >= a.yW) return MR3D_ERR_INVALID_ARG;

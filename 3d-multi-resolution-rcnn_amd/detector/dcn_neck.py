@@ -86,7 +86,10 @@ class _DcnLevelBf16Fn(Function):
         gw_off = dwo.permute(2, 1, 0).reshape(cop, 64, 3, 3, 3)[:co_off].contiguous()
         gb_off = dbo[:co_off].contiguous()
         wb = _hip.pack_conv_weight_bf16(wo.flip(2, 3, 4).transpose(0, 1))                # [ci = 64][cop][3,3,3]: data-gradient operand
-        gx16 = _hip.conv3d_forward_bf16(goff, wb, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), add1=dx.to(torch.bfloat16))
+        # the offset gradient is non-zero only where dy is (position-wise): dy's liveness bitmap lets the data-gradient kernel write
+        # the tiles whose halo is dead from the epilogue alone
+        live = _hip.voxel_liveness(g16) if x16.shape[1] * x16.shape[2] * x16.shape[3] >= 65536 else None
+        gx16 = _hip.conv3d_forward_bf16(goff, wb, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), add1=dx.to(torch.bfloat16), x_live=live)
         return gx16.permute(0, 4, 1, 2, 3), gw_off, gb_off, gw_dcn
 
 

@@ -105,7 +105,7 @@ class _RPNHeadPlanFn(torch.autograd.Function):
             ops.append(_hip.make_op(_hip.OP_CONV_FWD, [g16, wb1, gh, None, None, None, None, h],
                                     [n, d, hh, w, cop, c, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0]))      # dgrad 1x1, mask = h (ReLU)
             ops.append(_hip.make_op(_hip.OP_CONV_WGRAD, [x, gh, dw3, db3], [n, d, hh, w, c, c, 3, 3, 3, 1, 1, 1, 1, 1, 1] + side))
-            if not bf and d * hh * w >= 65536:
+            if d * hh * w >= 65536:
                 # gh is non-zero where the loss gradient g16 is (a 1x1x1 conv + mask): its voxel liveness, from the 16-channel
                 # map, lets the large-map data-gradient kernel write the tiles whose halo is dead from its epilogue
                 lbits = torch.empty((_hip.voxel_liveness_words(n * d * hh * w),), dtype=torch.int32, device=dev)

@@ -413,3 +413,26 @@ def test_conv3d_wgrad_bf16_sparse_dy_flag(dev, k):
         assert out[0][0].abs().max() > 0
         assert ((out[1][0] - out[0][0]).abs().max() / out[0][0].abs().max()).item() <= 1e-5
         assert ((out[1][1] - out[0][1]).abs().max() / out[0][1].abs().max()).item() <= 1e-5
+
+
+def test_conv3d_bf16_liveness_bitmap_writes_dead_tiles_from_the_epilogue(dev):
+    """mr3d_conv3d_desc.x_live on the bf16 3x3x3 / stride-1 kernel: identical results with and without the bitmap on a map with a few
+    non-zero boxes (with a residual add + ReLU epilogue: dead tiles are not zero), on a dense map, and with a bitmap that covers
+    MORE than the non-zero positions (a superset is allowed: the offset conv's data gradient uses dy's bitmap)"""
+    from mr3d_amd import _hip
+    g = torch.Generator(device='cpu').manual_seed(23)
+    shape = (1, 20, 64, 61, 64)
+    dense = torch.randn(shape, generator=g).to(dev, torch.bfloat16)
+    sparse = torch.zeros_like(dense)
+    for (d0, d1, h0, h1, w0, w1) in ((3, 9, 10, 31, 7, 22), (12, 13, 32, 33, 40, 41), (18, 20, 56, 64, 55, 61), (0, 1, 0, 1, 0, 1)):
+        sparse[:, d0:d1, h0:h1, w0:w1] = dense[:, d0:d1, h0:h1, w0:w1]
+    w16 = _hip.pack_conv_weight_bf16((torch.randn((64, 64, 3, 3, 3), generator=g) * 0.05).to(dev))
+    add = torch.randn(shape, generator=g).to(dev, torch.bfloat16)
+    wider = sparse.clone()
+    wider[:, 5:8, 40:50, 30:40] = 1.0                     # live in the bitmap, zero in the map that is convolved
+    for x, live_src in ((sparse, sparse), (dense, dense), (sparse, wider)):
+        live = _hip.voxel_liveness(live_src)
+        for kw in (dict(), dict(add1=add, relu=True)):
+            y0 = _hip.conv3d_forward_bf16(x, w16, 64, (3,) * 3, (1,) * 3, (1,) * 3, **kw)
+            y1 = _hip.conv3d_forward_bf16(x, w16, 64, (3,) * 3, (1,) * 3, (1,) * 3, x_live=live, **kw)
+            assert torch.equal(y0, y1)
