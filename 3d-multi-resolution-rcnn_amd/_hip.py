@@ -933,6 +933,25 @@ def stem_conv_wgrad(x_ncdhw, dy, dw_packed, dbias=None, workspace=None):
     return dw_packed
 
 
+def stem_conv_wgrad_pooled(x_ncdhw, g_pooled, argmax, pooled, dw_packed, dbias=None, workspace=None):
+    """stem weight gradient straight from the gradient of the max-pooled map (mr3d_stem_conv_wgrad_pooled): the max-pool
+    backward (resnet3d.py:471) and the stem's ReLU mask (pooled > 0; None: no mask) happen in the kernel's dy staging"""
+    n, _, d, h, w = x_ncdhw.shape
+    assert g_pooled.is_contiguous() and g_pooled.dtype == torch.float32 and tuple(dw_packed.shape) == (343, 4, 16)
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    assert tuple(g_pooled.shape) == (n, (d - 1) // 2 + 1, (ho - 1) // 2 + 1, (wo - 1) // 2 + 1, 16)
+    assert argmax.is_contiguous() and argmax.numel() * 4 == g_pooled.numel()
+    assert pooled is None or (pooled.is_contiguous() and pooled.shape == g_pooled.shape and pooled.dtype == torch.float32)
+    with torch.cuda.device(x_ncdhw.device):
+        st = lib().mr3d_stem_conv_wgrad_pooled(ptr(x_ncdhw), ptr(g_pooled), ptr(argmax), ctypes.c_void_p(_opt(pooled)),
+                                               ptr(dw_packed), ctypes.c_void_p(_opt(dbias)), n, d, h, w,
+                                               ctypes.c_void_p(_opt(workspace)),
+                                               ctypes.c_longlong(0 if workspace is None else workspace.numel() * 4),
+                                               stream_ptr(x_ncdhw.device))
+    check(st, 'mr3d_stem_conv_wgrad_pooled')
+    return dw_packed
+
+
 # --------------------------------------------------------------------------------------------
 def _f6(v, default):
     v = list(default if v is None else v)

@@ -100,6 +100,10 @@ int run_one(const mr3d_op &o, mr3d_stream_t s, bool shared_ws = true, const unsi
     case MR3D_OP_STEM_WGRAD:
       if (bf16 && i[6] == 1) return mr3d_stem_conv_wgrad_bf16((const float *)p[0], p[1], (float *)p[2], (float *)p[3], i[0], i[1], i[2], i[3], s);
       if (bf16) return mr3d_stem_conv_wgrad_bf16dy((const float *)p[0], p[1], (float *)p[2], (float *)p[3], i[0], i[1], i[2], i[3], s);
+      if (i[7] == 1)
+        return mr3d_stem_conv_wgrad_pooled((const float *)p[0], (const float *)p[1], (const uint32_t *)p[5], (const float *)p[6],
+                                           (float *)p[2], (float *)p[3], i[0], i[1], i[2], i[3], shared_ws ? (float *)p[4] : nullptr,
+                                           (shared_ws && p[4]) ? i64_of(i + 4) : 0, s);
       return mr3d_stem_conv_wgrad_ws((const float *)p[0], (const float *)p[1], (float *)p[2], (float *)p[3], i[0], i[1], i[2], i[3],
                                      shared_ws ? (float *)p[4] : nullptr, (shared_ws && p[4]) ? i64_of(i + 4) : 0, s);
   }
@@ -130,6 +134,8 @@ struct SideStream {
     // default-priority stream can be folded onto the same hardware queue as the caller's stream once other
     // libraries hold streams too -- measured with an RCCL communicator alive: 17.4 instead of 15.6 ms/step, all of
     // the weight-gradient overlap gone (kernel durations unchanged).
+    // (Round 3, headline step: high 11.10 ms, normal 11.23, low 11.24 -- the weight gradients finishing early matters more
+    // than the main chain's kernels keeping every CU.)
     if (hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, hi) != hipSuccess) return false;
     if (hipEventCreateWithFlags(&join_ev, hipEventDisableTiming) != hipSuccess) return false;
     for (auto &e : fork)

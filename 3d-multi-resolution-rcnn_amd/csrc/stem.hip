@@ -14,6 +14,7 @@
 //     the 3 x 24 (ci, tap group) accumulator tiles are split over the 8 waves (3 groups each) and live in
 //     registers across a persistent loop over tiles; one atomic pass at the end.
 // One input channel of the halo block ((TD+6) x (2*TH+5) x 72 floats) is resident in LDS at a time.
+#include <atomic>
 #include "conv3d.h"
 #include <stdlib.h>
 
@@ -233,6 +234,12 @@ struct StemWgradArgs {
   int N, D, H, W, Ho, Wo;
   float *part;         // per-workgroup partial blocks [343][3][16] (two-stage reduction) or null (atomics)
   int dy_bf16;         // configs[4]: dy is a bf16 buffer
+  // max-pool backward folded into the dy staging (mr3d_stem_conv_wgrad_pooled): dy is then the gradient of the POOLED map
+  // [N, Dp, Hp, Wp, 16], scattered to its arg-max positions inside the tile
+  const uint32_t *pool_idx;   // [N, Dp, Hp, Wp, 4] tap ids of the 3x3x3 / stride 2 / pad 1 pool, or null
+  const float *pooled;        // pooled activation (its sign is the ReLU mask) or null
+  int Dp, Hp, Wp;
+  int queue_slot;             // which g_stem_wgrad_queues slot this launch pulls its tiles from
 };
 
 // LDS geometry of the weight-gradient slab.  Row stride 39 (== 7 mod 32) and plane stride 849 (== 17 == 49 - 32 mod 32)
@@ -273,6 +280,9 @@ __device__ __forceinline__ void stem_wgrad_stage_channel(float *slab, const floa
   }
 }
 
+// per slot: 8 tile-queue heads + 1 finished-workgroup count, all 0 between launches
+__device__ unsigned g_stem_wgrad_queues[64 * 16];
+
 __global__ __launch_bounds__(kStemThreads) void stem_wgrad_kernel(StemWgradArgs p, int tiles_d, int tiles_h, int tiles_w) {
   using G = StemWgGeo;
   constexpr int TD = G::TD, TH = G::TH, TW = G::TW;
@@ -307,43 +317,87 @@ __global__ __launch_bounds__(kStemThreads) void stem_wgrad_kernel(StemWgradArgs 
   const int lane_col = (lk >> 1) + 8 * (lk & 1);
   float bsum = 0.f;
 
-  // a workgroup walks a contiguous run of the depth-fastest tile order (a column, or part of one); the runs of one
-  // XCD's workgroups are adjacent (gridDim.x is a multiple of 8 whenever it is >= 8)
-  int t_begin, t_end;
-  if ((gridDim.x & 7) == 0) {
-    const int per_xcd = (num_tiles + 7) >> 3, wgs = gridDim.x >> 3;
-    const int per_wg = (per_xcd + wgs - 1) / wgs;
-    const int x0 = (blockIdx.x & 7) * per_xcd;
-    t_begin = x0 + (int)(blockIdx.x >> 3) * per_wg;
-    t_end = min(min(t_begin + per_wg, x0 + per_xcd), num_tiles);
-  } else {
-    const int per_wg = (num_tiles + gridDim.x - 1) / gridDim.x;
-    t_begin = blockIdx.x * per_wg;
-    t_end = min(t_begin + per_wg, num_tiles);
-  }
-  for (int tile = t_begin; tile < t_end; ++tile) {
+  // Tiles are PULLED, one at a time, from eight queues -- the depth-fastest tile order cut into one contiguous range per XCD; a
+  // workgroup drains its own XCD's range first (neighbouring tiles share halo planes in that XCD's L2), then the others'.
+  // A fixed run of tiles per workgroup made the whole launch as late as its latest workgroup: in the training step the
+  // last weight gradients and the gradient finishing of the other layers run beside this kernel, and the workgroups that
+  // shared their CU with those finished 0.3 ms after the rest (1.83 ms alone, 2.14 ms in the step).
+  __shared__ int s_tile;
+  unsigned *queue = g_stem_wgrad_queues + 16 * p.queue_slot;
+  const int per_xcd = (num_tiles + 7) >> 3;
+  const int home = blockIdx.x & 7;
+  auto range = [&](int x, int &lo) { lo = x * per_xcd; return max(min(lo + per_xcd, num_tiles) - lo, 0); };
+  auto take = [&](unsigned ticket) {          // thread 0: the home queue's ticket, else the other queues in turn
+    int lo, cnt = range(home, lo);
+    if (ticket < (unsigned)cnt) return lo + (int)ticket;
+    for (int a = 1; a < 8; ++a) {
+      cnt = range((home + a) & 7, lo);
+      if (cnt > 0) {
+        const unsigned v = atomicAdd(queue + ((home + a) & 7), 1u);
+        if (v < (unsigned)cnt) return lo + (int)v;
+      }
+    }
+    return -1;
+  };
+  unsigned ticket = 0;
+  if (tid == 0) s_tile = take(atomicAdd(queue + home, 1u));
+  __syncthreads();
+  int tile = s_tile;
+  while (tile >= 0) {
     const StemTile st = stem_tile_of(tile, tiles_d, tiles_h, tiles_w);
     const int n = st.n;
     const int d0 = st.td * TD, h0 = st.th * TH, w0 = st.tw * TW;
-    __syncthreads();
-    // dy tile [m'][16], m' = ks*4 + k in GEMM-k order, zeros outside
-    for (int it = tid; it < M * 4; it += kStemThreads) {
-      const int m = it >> 2, q4 = it & 3;
-      const int k = m & 3, j = (m >> 2) & 3, th = (m >> 4) & 7, td = m >> 7;
-      const int tw = 2 * j + (k >> 1) + 8 * (k & 1);
-      const int od = d0 + td, oh = h0 + th, ow = w0 + tw;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (od < p.D && oh < p.Ho && ow < p.Wo) {
-        const size_t at = ((((size_t)n * p.D + od) * p.Ho + oh) * p.Wo + ow) * 16 + q4 * 4;
-        if (p.dy_bf16) {
-          const uint2 q = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(p.dy) + at);
-          v = make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16),
-                          __uint_as_float(q.y & 0xffff0000u));
-        } else {
-          v = *reinterpret_cast<const float4 *>(p.dy + at);
+    if (tid == 0) ticket = atomicAdd(queue + home, 1u);      // the next tile's ticket: looked at after this tile's MFMAs
+    if (p.pool_idx) {
+      // dy = the max-pool backward of the pooled gradient, built in place: the tile's 4 x 8 x 16 positions are reached by
+      // 3 x 5 x 9 windows; each window adds relu'(pooled) * g at its arg-max when that lies inside the tile (a window on the
+      // tile border belongs to up to eight tiles, each keeps its own positions) -- the 335 MB un-pooled gradient of the
+      // 512 volume is neither written nor read
+      for (int it = tid; it < M * 4; it += kStemThreads) reinterpret_cast<float4 *>(dyt)[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      __syncthreads();
+      for (int it = tid; it < 3 * 5 * 9 * 4; it += kStemThreads) {
+        const int q4 = it & 3, pp = it >> 2;
+        const int pw = pp % 9, ph = (pp / 9) % 5, pd = pp / 45;
+        const int od = (d0 >> 1) + pd, oh = (h0 >> 1) + ph, ow = (w0 >> 1) + pw;
+        if (od < p.Dp && oh < p.Hp && ow < p.Wp) {
+          const size_t o = ((((size_t)n * p.Dp + od) * p.Hp + oh) * p.Wp + ow) * 4 + q4;
+          const uint32_t ix = p.pool_idx[o];
+          const float4 g = *reinterpret_cast<const float4 *>(p.dy + o * 4);
+          float4 pa = make_float4(1.f, 1.f, 1.f, 1.f);
+          if (p.pooled) pa = *reinterpret_cast<const float4 *>(p.pooled + o * 4);
+          const float gv[4] = {g.x, g.y, g.z, g.w}, pv[4] = {pa.x, pa.y, pa.z, pa.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int tap = (ix >> (8 * r)) & 255;
+            const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+            const int td = 2 * od - 1 + kd - d0, th = 2 * oh - 1 + kh - h0, tw = 2 * ow - 1 + kw - w0;
+            if (pv[r] > 0.f && gv[r] != 0.f && (unsigned)td < (unsigned)TD && (unsigned)th < (unsigned)TH && (unsigned)tw < (unsigned)TW) {
+              const int m = (td << 7) | (th << 4) | (((tw & 7) >> 1) << 2) | ((tw & 1) << 1) | (tw >> 3);
+              atomicAdd(dyt + m * DYROW + q4 * 4 + r, gv[r]);
+            }
+          }
         }
       }
-      *reinterpret_cast<float4 *>(dyt + m * DYROW + q4 * 4) = v;
+    } else {
+      // dy tile [m'][16], m' = ks*4 + k in GEMM-k order, zeros outside
+      for (int it = tid; it < M * 4; it += kStemThreads) {
+        const int m = it >> 2, q4 = it & 3;
+        const int k = m & 3, j = (m >> 2) & 3, th = (m >> 4) & 7, td = m >> 7;
+        const int tw = 2 * j + (k >> 1) + 8 * (k & 1);
+        const int od = d0 + td, oh = h0 + th, ow = w0 + tw;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (od < p.D && oh < p.Ho && ow < p.Wo) {
+          const size_t at = ((((size_t)n * p.D + od) * p.Ho + oh) * p.Wo + ow) * 16 + q4 * 4;
+          if (p.dy_bf16) {
+            const uint2 q = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(p.dy) + at);
+            v = make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xffff0000u), __uint_as_float(q.y << 16),
+                            __uint_as_float(q.y & 0xffff0000u));
+          } else {
+            v = *reinterpret_cast<const float4 *>(p.dy + at);
+          }
+        }
+        *reinterpret_cast<float4 *>(dyt + m * DYROW + q4 * 4) = v;
+      }
     }
     for (int ci = 0; ci < 3; ++ci) {
       if (ci) __syncthreads();
@@ -372,6 +426,16 @@ __global__ __launch_bounds__(kStemThreads) void stem_wgrad_kernel(StemWgradArgs 
       if (ci == 0) run(acc[0], wave == 0);
       else if (ci == 1) run(acc[1], false);
       else run(acc[2], false);
+    }
+    if (tid == 0) s_tile = take(ticket);
+    __syncthreads();                       // also: every wave is done with this tile's dy rows and slab
+    tile = s_tile;
+  }
+  if (tid == 0) {                          // the last workgroup to run dry re-arms the queues for the next launch
+    const unsigned done = atomicAdd(queue + 8, 1u);
+    if (done == gridDim.x - 1) {
+#pragma unroll
+      for (int x = 0; x < 9; ++x) atomicExch(queue + x, 0u);
     }
   }
 
@@ -434,7 +498,15 @@ extern "C" int mr3d_stem_conv_forward_bf16out(const float *x_ncdhw, const float 
 }
 
 static int stem_wgrad_impl(const float *x_ncdhw, const float *dy, int dy_bf16, float *dw_packed, float *dbias, int n, int d, int h,
-                           int w, float *workspace, long long workspace_bytes, mr3d_stream_t stream_);
+                           int w, float *workspace, long long workspace_bytes, mr3d_stream_t stream_,
+                           const uint32_t *pool_idx = nullptr, const float *pooled = nullptr);
+
+extern "C" int mr3d_stem_conv_wgrad_pooled(const float *x_ncdhw, const float *g_pooled, const uint32_t *argmax, const float *pooled,
+                                           float *dw_packed, float *dbias, int n, int d, int h, int w, float *workspace,
+                                           long long workspace_bytes, mr3d_stream_t stream_) {
+  if (!argmax) return MR3D_ERR_INVALID_ARG;
+  return stem_wgrad_impl(x_ncdhw, g_pooled, 0, dw_packed, dbias, n, d, h, w, workspace, workspace_bytes, stream_, argmax, pooled);
+}
 
 extern "C" int mr3d_stem_conv_wgrad_bf16dy(const float *x_ncdhw, const void *dy_bf16, float *dw_packed, float *dbias, int n, int d,
                                            int h, int w, mr3d_stream_t stream_) {
@@ -452,12 +524,15 @@ extern "C" int mr3d_stem_conv_wgrad_ws(const float *x_ncdhw, const float *dy, fl
 }
 
 static int stem_wgrad_impl(const float *x_ncdhw, const float *dy, int dy_bf16, float *dw_packed, float *dbias, int n, int d, int h,
-                           int w, float *workspace, long long workspace_bytes, mr3d_stream_t stream_) {
+                           int w, float *workspace, long long workspace_bytes, mr3d_stream_t stream_, const uint32_t *pool_idx,
+                           const float *pooled) {
   if (!x_ncdhw || !dy || !dw_packed || n <= 0 || d <= 0 || h <= 0 || w <= 0) return MR3D_ERR_INVALID_ARG;
   StemWgradArgs a;
   a.x = x_ncdhw; a.dy = dy; a.dw = dw_packed; a.dbias = dbias; a.dy_bf16 = dy_bf16;
   a.N = n; a.D = d; a.H = h; a.W = w;
   a.Ho = (h + 6 - 7) / 2 + 1; a.Wo = (w + 6 - 7) / 2 + 1;
+  a.pool_idx = pool_idx; a.pooled = pooled;
+  a.Dp = (d - 1) / 2 + 1; a.Hp = (a.Ho - 1) / 2 + 1; a.Wp = (a.Wo - 1) / 2 + 1;
   constexpr int lds_bytes = (StemWgGeo::SLAB + 4 * 8 * 16 * 16) * 4;       // 66.0 KiB: two workgroups per CU
   static bool attr = false;
   if (!attr) {
@@ -479,7 +554,11 @@ static int stem_wgrad_impl(const float *x_ncdhw, const float *dy, int dy_bf16, f
       cus = prop.multiProcessorCount;
   }
   int grid = tiles < 2 * cus ? tiles : 2 * cus;
-  if (grid >= 8) grid &= ~7;                                 // XCD-contiguous tile runs need a multiple of 8
+  if (grid >= 8) grid &= ~7;
+  // tile queues: a ring of 64 slots in a zero-initialised device global; a launch leaves its slot zeroed again, so only
+  // launches that are in flight at the same time need different slots
+  static std::atomic<unsigned> next_slot{0};
+  a.queue_slot = (int)(next_slot.fetch_add(1) & 63u);
   // two-stage reduction when the caller lends a workspace: 512 workgroups x 16,464 same-address atomics are ~0.13 ms
   a.part = (workspace && workspace_bytes >= (long long)grid * 343 * 3 * 16 * 4) ? workspace : nullptr;
   stem_wgrad_kernel<<<(unsigned)grid, kStemThreads, lds_bytes, mr3d_stream(stream_)>>>(a, td, th, tw);

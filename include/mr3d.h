@@ -545,6 +545,14 @@ int mr3d_stem_conv_wgrad(const float *x_ncdhw, const float *dy, float *dw_packed
 /* same, with the optional partial-sum workspace of mr3d_conv3d_wgrad_desc (NULL / too small: atomics) */
 int mr3d_stem_conv_wgrad_ws(const float *x_ncdhw, const float *dy, float *dw_packed, float *dbias,
                             int n, int d, int h, int w, float *workspace, long long workspace_bytes, mr3d_stream_t stream);
+/* the stem's weight gradient with the max-pool backward (resnet3d.py:471, nn.MaxPool3d(3, 2, 1)) and the stem's ReLU mask
+ * folded into its dy staging: g_pooled [N, Dp, Hp, Wp, 16] is the gradient of the POOLED map, argmax / pooled are
+ * mr3d_maxpool3d_forward's outputs (pooled = NULL: no ReLU mask).  Equals mr3d_maxpool3d_backward followed by
+ * mr3d_stem_conv_wgrad_ws up to the summation order of windows that share an arg-max; the un-pooled gradient
+ * (335 MB on a 512x512x80 volume) is never materialised. */
+int mr3d_stem_conv_wgrad_pooled(const float *x_ncdhw, const float *g_pooled, const uint32_t *argmax, const float *pooled,
+                                float *dw_packed, float *dbias, int n, int d, int h, int w, float *workspace,
+                                long long workspace_bytes, mr3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * bf16 storage path (BASELINE.json configs[4]): the same layers with activations and activation gradients stored as bf16
@@ -652,6 +660,7 @@ int mr3d_rpn_merge_levels(const float *dets, const int *seg_rows_host, int num_l
  *   FINISH_GRADS  p = {table,params,scratch,grads}      i = {num_layers,max_cout}
  *   STEM_FWD      p = {x_ncdhw,w_packed,shift,y}        i = {n,d,h,w,relu}
  *   STEM_WGRAD    p = {x_ncdhw,dy,dw_packed,dbias,workspace}  i = {n,d,h,w, workspace bytes lo, hi}
+ *                 i[7] = 1: mr3d_stem_conv_wgrad_pooled with p[1] = g_pooled, p[5] = argmax, p[6] = pooled (fp32 plans)
  *   CONV_DGRAD_S2 p / i as CONV_FWD (mr3d_conv3d_dgrad_s2k3: x = dy, w = wb, y = dx; y_d/y_h/y_w = dx's grid)
  *   PW_PAIR       p = {x,w1,add1,mask1,y1,w2,mask2,y2}  i = {c0,c1,c2,relu1,relu2, positions lo,hi, shift1 lo,hi, shift2 lo,hi}
  *                 (mr3d_pointwise_pair; the two shift pointers travel as 64-bit integers)

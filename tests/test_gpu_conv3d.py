@@ -249,6 +249,48 @@ def test_stem_kernels_forward_and_wgrad(dev, n, dhw):
     assert errw <= 2e-5 and errb <= 1e-4, f'stem wgrad rel err {errw:.3e}, dbias {errb:.3e}'
 
 
+@pytest.mark.parametrize('n,dhw,relu', [(1, (8, 32, 32), True), (2, (10, 40, 36), True), (1, (5, 70, 130), False), (1, (9, 17, 23), True),
+                                        (1, (16, 64, 64), True)])
+def test_stem_wgrad_from_the_pooled_gradient(dev, n, dhw, relu):
+    """mr3d_stem_conv_wgrad_pooled: conv -> (ReLU) -> MaxPool3d(3, 2, 1) differentiated by torch in fp64 (resnet3d.py:467-471)
+    against the kernel that scatters the pooled gradient to its arg-max positions inside its dy staging; the pooled
+    gradient is sparse in one case (most windows 0) like the detector's"""
+    from mr3d_amd import _hip
+    g = torch.Generator().manual_seed(sum(dhw) + 3 * n)
+    x = torch.randn((n, 3) + dhw, generator=g)
+    w = (torch.randn((16, 3, 7, 7, 7), generator=g) / np.sqrt(1029)).requires_grad_(True)
+    shift = (0.3 * torch.randn(16, generator=g)).requires_grad_(True)
+    w4 = torch.zeros(16, 4, 7, 7, 7); w4[:, :3] = w.detach()
+    wp = _hip.pack_conv_weight(w4).to(dev)
+    y = _hip.stem_conv_forward(x.to(dev), wp, shift.detach().to(dev), relu=relu)            # NDHWC fp32
+    nn, d, ho, wo, _ = y.shape
+    pooled = torch.empty((nn, (d - 1) // 2 + 1, (ho - 1) // 2 + 1, (wo - 1) // 2 + 1, 16), device=dev)
+    am = torch.empty(pooled.shape[:4] + (4,), dtype=torch.int32, device=dev)
+    _hip.Plan([_hip.make_op(_hip.OP_MAXPOOL_FWD, [y, pooled, am], [nn, d, ho, wo, 16])]).run(dev)
+    gp = torch.randn(pooled.shape, generator=g)
+    if dhw[0] == 10:
+        gp = gp * (torch.rand(gp.shape[:4] + (1,), generator=g) < 0.1)
+    # torch reference on the device's own activation (ties / arg-max then agree): pool the kernel's y, route gp through
+    # the pool, mask by y > 0, differentiate the conv in fp64
+    yk = y.permute(0, 4, 1, 2, 3).cpu().double().requires_grad_(True)
+    F.max_pool3d(yk, 3, 2, 1).backward(gp.permute(0, 4, 1, 2, 3).double())
+    dy = yk.grad * (yk.detach() > 0) if relu else yk.grad
+    F.conv3d(x.double(), w.double(), shift.double(), (1, 2, 2), 3).backward(dy)
+    for ws in (None, _hip.wgrad_workspace(dev)):
+        dw = torch.zeros((343, 4, 16), device=dev); db = torch.zeros(16, device=dev)
+        _hip.stem_conv_wgrad_pooled(x.to(dev), gp.to(dev), am, pooled if relu else None, dw, db, workspace=ws)
+        refp = _hip.pack_conv_weight(torch.cat([w.grad, torch.zeros(16, 1, 7, 7, 7)], 1))
+        errw = (dw.cpu() - refp).abs().max().item() / refp.abs().max().item()
+        errb = (db.cpu() - shift.grad).abs().max().item() / shift.grad.abs().max().item()
+        assert errw <= 2e-5 and errb <= 1e-4, f'stem wgrad (pooled) rel err {errw:.3e}, dbias {errb:.3e}'
+    # and against the two-launch form it replaces
+    gs = torch.empty_like(y)
+    _hip.Plan([_hip.make_op(_hip.OP_MAXPOOL_BWD, [gp.to(dev), am, pooled if relu else None, gs], [nn, d, ho, wo, 16])]).run(dev)
+    dw2 = torch.zeros_like(dw)
+    _hip.stem_conv_wgrad(x.to(dev), gs, dw2, None)
+    assert (dw2 - dw).abs().max().item() <= 2e-5 * dw2.abs().max().item()
+
+
 # the streaming pointwise kernels (csrc/pointwise.hip) only engage above 32768 positions
 PW_CASES = [(16, 16), (16, 64), (64, 16), (64, 32), (32, 64), (64, 64), (32, 128), (128, 32), (64, 128), (128, 64)]
 

@@ -10,4 +10,5 @@ rocprofv3 --output-format csv --kernel-trace -d "$OUT/tr" -o tl -- python3 "$REP
 cd "$REPO"
 KT=$(find "$OUT/tr" -name '*kernel_trace.csv' | head -1)
 python3 tools/timeline.py "$KT" -2 > "$OUT/timeline.txt"
+python3 tools/timeline.py "$KT" -2 dump > "$OUT/timeline_dump.txt"
 rm -rf "$OUT/tr"

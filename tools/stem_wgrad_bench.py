@@ -1,0 +1,59 @@
+"""stem weight gradient on the 512x512x80 volume: max-pool backward + dense-dy kernel against the pooled-gradient kernel
+(mr3d_stem_conv_wgrad_pooled).  usage: python tools/stem_wgrad_bench.py [--density 1.0]      (through gpurun)"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import mr3d_amd  # noqa: E402,F401
+from mr3d_amd import _hip  # noqa: E402
+
+
+def timed(fn, reps=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps * 1e3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--density', type=float, default=1.0, help='fraction of pooled positions with a non-zero gradient')
+    ap.add_argument('--shape', type=int, nargs=3, default=(80, 512, 512))
+    a = ap.parse_args()
+    dev = torch.device('cuda:0')
+    d, h, w = a.shape
+    g = torch.Generator(device=dev).manual_seed(0)
+    x = torch.randn((1, 3, d, h, w), device=dev, generator=g)
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    y = torch.randn((1, d, ho, wo, 16), device=dev, generator=g).relu_()
+    pooled = torch.empty((1, (d - 1) // 2 + 1, (ho - 1) // 2 + 1, (wo - 1) // 2 + 1, 16), device=dev)
+    am = torch.empty(pooled.shape[:4] + (4,), dtype=torch.int32, device=dev)
+    _hip.Plan([_hip.make_op(_hip.OP_MAXPOOL_FWD, [y, pooled, am], [1, d, ho, wo, 16])]).run(dev)
+    gp = torch.randn(pooled.shape, device=dev, generator=g)
+    if a.density < 1.0:
+        gp = gp * (torch.rand(gp.shape[:4] + (1,), device=dev, generator=g) < a.density)
+    gs = torch.empty_like(y)
+    dw = torch.zeros((343, 4, 16), device=dev)
+    db = torch.zeros(16, device=dev)
+    bwd = _hip.Plan([_hip.make_op(_hip.OP_MAXPOOL_BWD, [gp, am, pooled, gs], [1, d, ho, wo, 16])])
+    t_pool = timed(lambda: bwd.run(dev))
+    t_dense = timed(lambda: _hip.stem_conv_wgrad(x, gs, dw, db))
+    dw1 = torch.zeros_like(dw); _hip.stem_conv_wgrad(x, gs, dw1, None)
+    t_fused = timed(lambda: _hip.stem_conv_wgrad_pooled(x, gp, am, pooled, dw, db))
+    dw2 = torch.zeros_like(dw); _hip.stem_conv_wgrad_pooled(x, gp, am, pooled, dw2, None)
+    err = (dw1 - dw2).abs().max().item() / dw1.abs().max().item()
+    print(f'density {a.density}: maxpool_bwd {t_pool:.0f} us + stem_wgrad {t_dense:.0f} us = {t_pool + t_dense:.0f} us; '
+          f'pooled-gradient kernel {t_fused:.0f} us; rel diff {err:.1e}')
+
+
+if __name__ == '__main__':
+    main()
