@@ -921,6 +921,22 @@ def stem_conv_wgrad_bf16(x_ncdhw, dy, dw_packed, dbias=None):
     return dw_packed
 
 
+def stem_conv_wgrad_bf16_pooled(x_ncdhw, g_pooled, argmax, pooled, dw_packed, dbias=None):
+    """bf16 form of stem_conv_wgrad_pooled (mr3d_stem_conv_wgrad_bf16_pooled)"""
+    n, _, d, h, w = x_ncdhw.shape
+    assert g_pooled.is_contiguous() and g_pooled.dtype == torch.bfloat16 and tuple(dw_packed.shape) == (343, 4, 16)
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    assert tuple(g_pooled.shape) == (n, (d - 1) // 2 + 1, (ho - 1) // 2 + 1, (wo - 1) // 2 + 1, 16)
+    assert argmax.is_contiguous() and argmax.numel() * 4 == g_pooled.numel()
+    assert pooled is None or (pooled.is_contiguous() and pooled.shape == g_pooled.shape and pooled.dtype == torch.bfloat16)
+    with torch.cuda.device(x_ncdhw.device):
+        st = lib().mr3d_stem_conv_wgrad_bf16_pooled(ptr(x_ncdhw), ptr(g_pooled), ptr(argmax), ctypes.c_void_p(_opt(pooled)),
+                                                    ptr(dw_packed), ctypes.c_void_p(_opt(dbias)), n, d, h, w,
+                                                    stream_ptr(x_ncdhw.device))
+    check(st, 'mr3d_stem_conv_wgrad_bf16_pooled')
+    return dw_packed
+
+
 def stem_conv_wgrad(x_ncdhw, dy, dw_packed, dbias=None, workspace=None):
     n, _, d, h, w = x_ncdhw.shape
     assert dy.is_contiguous() and tuple(dw_packed.shape) == (343, 4, 16)

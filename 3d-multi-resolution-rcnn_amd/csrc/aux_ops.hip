@@ -32,31 +32,37 @@ __device__ __forceinline__ void st4(bf16_t *p, float4 v) {
 
 // ---------------------------------------------------------------- maxpool k3 s2 p1
 // scan order (kd, kh, kw); the FIRST maximum wins (torch: `val > maxval`), its tap id is stored.
+// A workgroup owns one pooled row (n, od, oh): the (<= 3 x 3) input rows it reads are scalars, a thread walks the row's
+// (ow, channel quad) items with 32-bit indices (the element-per-thread form with 64-bit div / mod chains per element took
+// 137 us for the stem's 335 MB map).
 template <typename T>
 __global__ __launch_bounds__(kT) void maxpool_fwd_kernel(const T *__restrict__ x, T *__restrict__ y,
                                                         uint32_t *__restrict__ idx, int N, int D, int H, int W, int C,
                                                         int Do, int Ho, int Wo) {
   const int C4 = C / 4;
-  const long long total = (long long)N * Do * Ho * Wo * C4;
-  for (long long t = (long long)blockIdx.x * kT + threadIdx.x; t < total; t += (long long)gridDim.x * kT) {
-    const int c4 = (int)(t % C4);
-    long long r = t / C4;
-    const int ow = (int)(r % Wo); r /= Wo;
-    const int oh = (int)(r % Ho); r /= Ho;
-    const int od = (int)(r % Do);
-    const int n = (int)(r / Do);
+  int row = blockIdx.x;                                  // (n, od, oh)
+  const int oh = row % Ho; row /= Ho;
+  const int od = row % Do;
+  const int n = row / Do;
+  const size_t orow = ((size_t)(n * Do + od) * Ho + oh) * (size_t)Wo * C4;
+  for (int e = threadIdx.x; e < Wo * C4; e += kT) {
+    const int ow = e / C4, c4 = e - ow * C4;
     float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
     uint32_t bi0 = 0, bi1 = 0, bi2 = 0, bi3 = 0;
+#pragma unroll
     for (int kd = 0; kd < 3; ++kd) {
       const int id = od * 2 - 1 + kd;
       if ((unsigned)id >= (unsigned)D) continue;
+#pragma unroll
       for (int kh = 0; kh < 3; ++kh) {
         const int ih = oh * 2 - 1 + kh;
         if ((unsigned)ih >= (unsigned)H) continue;
+        const T *src = x + ((size_t)(n * D + id) * H + ih) * (size_t)W * C + c4 * 4;
+#pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
           const int iw = ow * 2 - 1 + kw;
           if ((unsigned)iw >= (unsigned)W) continue;
-          const float4 v = ld4(x + ((((size_t)n * D + id) * H + ih) * W + iw) * C + c4 * 4);
+          const float4 v = ld4(src + iw * C);
           const uint32_t tap = (kd * 3 + kh) * 3 + kw;
           if (v.x > best.x) { best.x = v.x; bi0 = tap; }
           if (v.y > best.y) { best.y = v.y; bi1 = tap; }
@@ -65,8 +71,8 @@ __global__ __launch_bounds__(kT) void maxpool_fwd_kernel(const T *__restrict__ x
         }
       }
     }
-    st4(y + (size_t)t * 4, best);
-    idx[t] = bi0 | (bi1 << 8) | (bi2 << 16) | (bi3 << 24);
+    st4(y + (orow + e) * 4, best);
+    idx[orow + e] = bi0 | (bi1 << 8) | (bi2 << 16) | (bi3 << 24);
   }
 }
 
@@ -346,7 +352,7 @@ extern "C" int mr3d_maxpool3d_forward(const float *x, float *y, uint32_t *argmax
                                       mr3d_stream_t s) {
   if (!x || !y || !argmax || c % 4) return MR3D_ERR_INVALID_ARG;
   const int Do = (d - 1) / 2 + 1, Ho = (h - 1) / 2 + 1, Wo = (w - 1) / 2 + 1;
-  maxpool_fwd_kernel<<<grid_for((long long)n * Do * Ho * Wo * c / 4), kT, 0, mr3d_stream(s)>>>(x, y, argmax, n, d, h, w, c, Do,
+  maxpool_fwd_kernel<<<(unsigned)(n * Do * Ho), kT, 0, mr3d_stream(s)>>>(x, y, argmax, n, d, h, w, c, Do,
                                                                                           Ho, Wo);
   return mr3d_launch_status();
 }
@@ -479,7 +485,7 @@ extern "C" int mr3d_maxpool3d_forward_bf16(const void *x, void *y, uint32_t *arg
                                            mr3d_stream_t s) {
   if (!x || !y || !argmax || c % 4) return MR3D_ERR_INVALID_ARG;
   const int Do = (d - 1) / 2 + 1, Ho = (h - 1) / 2 + 1, Wo = (w - 1) / 2 + 1;
-  maxpool_fwd_kernel<<<grid_for((long long)n * Do * Ho * Wo * c / 4), kT, 0, mr3d_stream(s)>>>((const bf16_t *)x, (bf16_t *)y, argmax,
+  maxpool_fwd_kernel<<<(unsigned)(n * Do * Ho), kT, 0, mr3d_stream(s)>>>((const bf16_t *)x, (bf16_t *)y, argmax,
                                                                                           n, d, h, w, c, Do, Ho, Wo);
   return mr3d_launch_status();
 }

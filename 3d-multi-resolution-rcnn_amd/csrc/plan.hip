@@ -98,6 +98,9 @@ int run_one(const mr3d_op &o, mr3d_stream_t s, bool shared_ws = true, const unsi
       return mr3d_stem_conv_forward((const float *)p[0], (const float *)p[1], (const float *)p[2], (float *)p[3], i[0], i[1], i[2],
                                     i[3], i[4], s);
     case MR3D_OP_STEM_WGRAD:
+      if (bf16 && i[6] == 1 && i[7] == 1)
+        return mr3d_stem_conv_wgrad_bf16_pooled((const float *)p[0], p[1], (const uint32_t *)p[5], p[6], (float *)p[2], (float *)p[3],
+                                                i[0], i[1], i[2], i[3], s);
       if (bf16 && i[6] == 1) return mr3d_stem_conv_wgrad_bf16((const float *)p[0], p[1], (float *)p[2], (float *)p[3], i[0], i[1], i[2], i[3], s);
       if (bf16) return mr3d_stem_conv_wgrad_bf16dy((const float *)p[0], p[1], (float *)p[2], (float *)p[3], i[0], i[1], i[2], i[3], s);
       if (i[7] == 1)

@@ -15,6 +15,7 @@
 // unaligned 16-byte read.  B = dy [position][16] read with the transposing LDS read (ds_read_b64_tr_b16).  8 waves split the
 // 74 row tiles (+ one tile of ones: sum_p dy); persistent workgroups, fp32 atomics at the end into the generic packed
 // layout [343][4][16] that mr3d_finish_grads consumes.
+#include <atomic>
 #include "mr3d_common.h"
 
 namespace {
@@ -232,6 +233,8 @@ struct WgGeo {
   static constexpr int M = TD * TH * TW, KS = TD * TH;
   static constexpr int SLAB_BYTES = (3 * PLANE * 2 + 15) / 16 * 16, DY_BYTES = M * DYROW * 2;
   static constexpr int LDS_BYTES = SLAB_BYTES + DY_BYTES + 64;
+  static constexpr int SCATTER_BYTES = M * 8 * 4;                            // POOLED: fp32 [position][8] the windows add into, one channel half at a time
+  static constexpr int WINDOWS = 3 * 3 * 17;                                  // pooled windows that reach a 4 x 4 x 32 tile
   static constexpr int ROWS = 49 * 24, MT = (ROWS + 15) / 16;                 // 1176 GEMM rows -> 74 tiles (+ 1 of ones)
   static constexpr int MTW = 10;                                              // row tiles per wave (8 waves x 10 >= 75)
   static constexpr int PAIRS = 36;                                            // columns -1 .. 70; 13 rows x 36 pairs = 468 threads per plane
@@ -241,13 +244,26 @@ struct WgGeo {
 struct StemBfWgArgs {
   const float *x; const bf16_t *dy; float *dw; float *dbias;
   int N, D, H, W, Ho, Wo;
+  // POOLED (mr3d_stem_conv_wgrad_bf16_pooled): dy is the gradient of the max-pooled map [N, Dp, Hp, Wp, 16]
+  const uint32_t *pool_idx; const bf16_t *pooled;
+  int Dp, Hp, Wp;
+  int queue_slot;                      // g_stem_bf16_queues slot of this launch
 };
 
+// tile queues of the weight-gradient kernel, as in csrc/stem.hip: per slot 8 queue heads + 1 finished-workgroup count,
+// all 0 between launches
+__device__ unsigned g_stem_bf16_queues[64 * 16];
+
+// POOLED: the max-pool backward (3x3x3 / stride 2 / pad 1) and the stem's ReLU mask are folded into the dy staging: the
+// windows that reach the tile add relu'(pooled) * g at their arg-max into an fp32 tile in LDS, which is rounded to the bf16 dy
+// rows once (the un-pooled bf16 gradient -- 168 MB on the 512 volume -- is neither written nor read).
+template <bool POOLED>
 __global__ __launch_bounds__(512, 1) void stem_wgrad_bf16_kernel(StemBfWgArgs p, int tiles_d, int tiles_h, int tiles_w, int ntiles) {
   using G = WgGeo;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   bf16_t *slab = reinterpret_cast<bf16_t *>(lds);
   unsigned char *dyt = lds + G::SLAB_BYTES;
+  float *scat = reinterpret_cast<float *>(lds + G::LDS_BYTES);       // POOLED only
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
@@ -314,7 +330,7 @@ __global__ __launch_bounds__(512, 1) void stem_wgrad_bf16_kernel(StemBfWgArgs p,
         }
       }
     }
-    {
+    if constexpr (!POOLED) {
       const int m = tid;                                 // 512 positions, one per thread
       const int tw = m & 31, th = (m >> 5) % G::TH, td = m / (32 * G::TH);
       const int od = d0 + td, oh = h0 + th, ow = w0 + tw;
@@ -322,6 +338,26 @@ __global__ __launch_bounds__(512, 1) void stem_wgrad_bf16_kernel(StemBfWgArgs p,
       if (tile_ok && od < p.D && oh < p.Ho && ow < p.Wo) {
         const uint4 *src = reinterpret_cast<const uint4 *>(p.dy + ((((size_t)n * p.D + od) * p.Ho + oh) * p.Wo + ow) * 16);
         sdy[0] = src[0]; sdy[1] = src[1];
+      }
+    } else {
+      // (window, channel quad) items: 3 x 3 x 17 windows x 4 = 612 for 512 threads; sdy[j] = {tap ids, g (2 dwords), ReLU bits}
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int it = tid + j * G::NT, q4 = it & 3, pp = it >> 2;
+        const int pw = pp % 17, ph = (pp / 17) % 3, pd = pp / 51;
+        const int od = (d0 >> 1) + pd, oh = (h0 >> 1) + ph, ow = (w0 >> 1) + pw;
+        sdy[j] = make_uint4(0u, 0u, 0u, 0u);
+        if (tile_ok && it < G::WINDOWS * 4 && od < p.Dp && oh < p.Hp && ow < p.Wp) {
+          const size_t o = ((((size_t)n * p.Dp + od) * p.Hp + oh) * p.Wp + ow) * 4 + q4;
+          const uint2 g = *reinterpret_cast<const uint2 *>(p.dy + o * 4);
+          uint32_t pos = 0xfu;                           // bit r: pooled value of channel r is > 0
+          if (p.pooled) {
+            const uint2 a = *reinterpret_cast<const uint2 *>(p.pooled + o * 4);
+            auto gt0 = [](uint32_t h) { return (h & 0x7fffu) != 0u && (h & 0x8000u) == 0u && (h & 0x7fffu) <= 0x7f80u; };
+            pos = (gt0(a.x & 0xffffu) ? 1u : 0u) | (gt0(a.x >> 16) ? 2u : 0u) | (gt0(a.y & 0xffffu) ? 4u : 0u) | (gt0(a.y >> 16) ? 8u : 0u);
+          }
+          sdy[j] = make_uint4(p.pool_idx[o], g.x, g.y, pos);
+        }
       }
     }
   };
@@ -340,18 +376,87 @@ __global__ __launch_bounds__(512, 1) void stem_wgrad_bf16_kernel(StemBfWgArgs p,
         if (s_pr >= 1) d[G::HALF + s_pr - 1] = ve;
       }
     }
-    *reinterpret_cast<uint4 *>(dyt + tid * (G::DYROW * 2)) = sdy[0];
-    *reinterpret_cast<uint4 *>(dyt + tid * (G::DYROW * 2) + 16) = sdy[1];
+    if constexpr (!POOLED) {
+      *reinterpret_cast<uint4 *>(dyt + tid * (G::DYROW * 2)) = sdy[0];
+      *reinterpret_cast<uint4 *>(dyt + tid * (G::DYROW * 2) + 16) = sdy[1];
+    }
   };
-
-  int t_begin, t_end;
-  bf_tile_run((int)blockIdx.x, (int)gridDim.x, ntiles, t_begin, t_end);
-  fetch(t_begin < t_end ? t_begin : ntiles);
-  for (int tile = t_begin; tile < t_end; ++tile) {
+  // POOLED: the windows of channel quads 2*half, 2*half + 1 add their gradient at their arg-max (143 KB of slab + dy rows leave
+  // room for 8 of the 16 channels in fp32: two rounds per tile)
+  auto scatter = [&](int half) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int it = tid + j * G::NT, q4 = it & 3, pp = it >> 2;
+      if ((q4 >> 1) != half) continue;
+      const int pw = pp % 17, ph = (pp / 17) % 3, pd = pp / 51;
+      const uint32_t gq[2] = {sdy[j].y, sdy[j].z};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const uint32_t gb = (r & 1) ? (gq[r >> 1] & 0xffff0000u) : (gq[r >> 1] << 16);
+        const int tap = (sdy[j].x >> (8 * r)) & 255;
+        const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+        // window (pd, ph, pw) of the tile's window block covers tile positions 2 p - 1 + k
+        const int td = 2 * pd - 1 + kd, th = 2 * ph - 1 + kh, tw = 2 * pw - 1 + kw;
+        if (((sdy[j].w >> r) & 1u) && (gb & 0x7fffffffu) != 0u && (unsigned)td < (unsigned)G::TD && (unsigned)th < (unsigned)G::TH &&
+            (unsigned)tw < (unsigned)G::TW)
+          atomicAdd(scat + ((td * G::TH + th) * G::TW + tw) * 8 + (q4 & 1) * 4 + r, __uint_as_float(gb));
+      }
+    }
+  };
+  // after the barrier behind scatter(half): a thread rounds its position's 8 sums into its bf16 dy row and clears them
+  auto round_rows = [&](int half) {
+    float4 *src = reinterpret_cast<float4 *>(scat + tid * 8);
+    const float4 a = src[0], b = src[1];
+    src[0] = src[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<uint4 *>(dyt + tid * (G::DYROW * 2) + half * 16) =
+        make_uint4((uint32_t)f2bf(a.x) | ((uint32_t)f2bf(a.y) << 16), (uint32_t)f2bf(a.z) | ((uint32_t)f2bf(a.w) << 16),
+                   (uint32_t)f2bf(b.x) | ((uint32_t)f2bf(b.y) << 16), (uint32_t)f2bf(b.z) | ((uint32_t)f2bf(b.w) << 16));
+  };
+  // Tiles are pulled from eight queues (one contiguous range of the depth-fastest order per XCD, the workgroup's own XCD first):
+  // with a fixed run per workgroup the launch ended with its latest workgroup, and in the training step the other layers'
+  // last weight gradients and their finishing run beside this kernel (see stem_wgrad_kernel in csrc/stem.hip).
+  __shared__ int s_tile;
+  unsigned *queue = g_stem_bf16_queues + 16 * p.queue_slot;
+  const int per_xcd = (ntiles + 7) >> 3, home = blockIdx.x & 7;
+  auto range = [&](int x, int &lo) { lo = x * per_xcd; return max(min(lo + per_xcd, ntiles) - lo, 0); };
+  auto take = [&](unsigned ticket) {                     // thread 0
+    int lo, cnt = range(home, lo);
+    if (ticket < (unsigned)cnt) return lo + (int)ticket;
+    for (int a = 1; a < 8; ++a) {
+      cnt = range((home + a) & 7, lo);
+      if (cnt > 0) {
+        const unsigned v = atomicAdd(queue + ((home + a) & 7), 1u);
+        if (v < (unsigned)cnt) return lo + (int)v;
+      }
+    }
+    return -1;
+  };
+  if constexpr (POOLED) {
+    for (int e = tid; e < G::M * 2; e += G::NT) reinterpret_cast<float4 *>(scat)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  unsigned ticket = 0;
+  if (tid == 0) s_tile = take(atomicAdd(queue + home, 1u));
+  __syncthreads();
+  int tile = s_tile;
+  fetch(tile >= 0 ? tile : ntiles);
+  if (tid == 0) ticket = atomicAdd(queue + home, 1u);
+  while (tile >= 0) {
     __syncthreads();
     commit();
+    if constexpr (POOLED) scatter(0);
+    if (tid == 0) s_tile = take(ticket);                 // issued a tile ago
     __syncthreads();
-    fetch(tile + 1 < t_end ? tile + 1 : ntiles);         // in flight during the MFMA phase
+    if constexpr (POOLED) {
+      round_rows(0);
+      __syncthreads();
+      scatter(1);
+      __syncthreads();
+      round_rows(1);
+      __syncthreads();
+    }
+    const int next = s_tile;
+    if (tid == 0 && next >= 0) ticket = atomicAdd(queue + home, 1u);
+    fetch(next >= 0 ? next : ntiles);                    // in flight during the MFMA phase
     // the ten row-tile fragments and the dy fragment of a k-step are requested together, before its first MFMA
     // (read-then-multiply per tile left every 16-cycle MFMA waiting for an LDS round trip; double-buffering them across
     // k-steps as well needs 80 more registers and spills); tiles past the end of a wave's list multiply a valid but unused
@@ -378,6 +483,14 @@ __global__ __launch_bounds__(512, 1) void stem_wgrad_bf16_kernel(StemBfWgArgs p,
       load_step(ks, aA, bA);
       __builtin_amdgcn_sched_barrier(0);
       mma_step(aA, bA);
+    }
+    tile = next;
+  }
+  if (tid == 0) {                                        // the last workgroup to run dry re-arms the queues
+    const unsigned done = atomicAdd(queue + 8, 1u);
+    if (done == gridDim.x - 1) {
+#pragma unroll
+      for (int x = 0; x < 9; ++x) atomicExch(queue + x, 0u);
     }
   }
   // ---- write-out: column (cout) = lane & 15, GEMM row = 16*m + 4*(lane>>4) + reg
@@ -437,18 +550,22 @@ extern "C" int mr3d_stem_conv_forward_bf16(const float *x_ncdhw, const void *w16
   return mr3d_launch_status();
 }
 
-extern "C" int mr3d_stem_conv_wgrad_bf16(const float *x_ncdhw, const void *dy_bf16, float *dw_packed, float *dbias, int n, int d, int h,
-                                         int w, mr3d_stream_t stream_) {
+static int stem_wgrad_bf16_impl(const float *x_ncdhw, const void *dy_bf16, const uint32_t *pool_idx, const void *pooled, float *dw_packed,
+                                float *dbias, int n, int d, int h, int w, mr3d_stream_t stream_) {
   if (!x_ncdhw || !dy_bf16 || !dw_packed || n <= 0 || d <= 0 || h <= 0 || w <= 0) return MR3D_ERR_INVALID_ARG;
   StemBfWgArgs a;
   a.x = x_ncdhw; a.dy = (const bf16_t *)dy_bf16; a.dw = dw_packed; a.dbias = dbias;
   a.N = n; a.D = d; a.H = h; a.W = w; a.Ho = (h - 1) / 2 + 1; a.Wo = (w - 1) / 2 + 1;
+  a.pool_idx = pool_idx; a.pooled = (const bf16_t *)pooled;
+  a.Dp = (d - 1) / 2 + 1; a.Hp = (a.Ho - 1) / 2 + 1; a.Wp = (a.Wo - 1) / 2 + 1;
   using G = WgGeo;
   static bool attr = false;
   static int cus = 0;
   if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(stem_wgrad_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            G::LDS_BYTES) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(stem_wgrad_bf16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            G::LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(stem_wgrad_bf16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            G::LDS_BYTES + G::SCATTER_BYTES) != hipSuccess) {
       (void)hipGetLastError();
       return MR3D_ERR_LAUNCH;
     }
@@ -462,8 +579,25 @@ extern "C" int mr3d_stem_conv_wgrad_bf16(const float *x_ncdhw, const void *dy_bf
   const int td = (d + G::TD - 1) / G::TD, th = (a.Ho + G::TH - 1) / G::TH, tw = (a.Wo + G::TW - 1) / G::TW;
   const long long ntiles = (long long)n * td * th * tw;
   if (ntiles > 0x7fffffffLL) return MR3D_ERR_UNSUPPORTED;
-  int grid = ntiles < cus ? (int)ntiles : cus;               // one persistent workgroup per CU (87 KB of LDS)
+  int grid = ntiles < cus ? (int)ntiles : cus;               // one persistent workgroup per CU (140 / 156 KB of LDS)
   if (grid >= 8) grid &= ~7;
-  stem_wgrad_bf16_kernel<<<(unsigned)grid, 512, G::LDS_BYTES, mr3d_stream(stream_)>>>(a, td, th, tw, (int)ntiles);
+  static std::atomic<unsigned> next_slot{0};                 // ring of queue slots: see stem_wgrad_impl in csrc/stem.hip
+  a.queue_slot = (int)(next_slot.fetch_add(1) & 63u);
+  if (pool_idx)
+    stem_wgrad_bf16_kernel<true><<<(unsigned)grid, 512, G::LDS_BYTES + G::SCATTER_BYTES, mr3d_stream(stream_)>>>(a, td, th, tw, (int)ntiles);
+  else
+    stem_wgrad_bf16_kernel<false><<<(unsigned)grid, 512, G::LDS_BYTES, mr3d_stream(stream_)>>>(a, td, th, tw, (int)ntiles);
   return mr3d_launch_status();
+}
+
+extern "C" int mr3d_stem_conv_wgrad_bf16(const float *x_ncdhw, const void *dy_bf16, float *dw_packed, float *dbias, int n, int d, int h,
+                                         int w, mr3d_stream_t stream_) {
+  return stem_wgrad_bf16_impl(x_ncdhw, dy_bf16, nullptr, nullptr, dw_packed, dbias, n, d, h, w, stream_);
+}
+
+extern "C" int mr3d_stem_conv_wgrad_bf16_pooled(const float *x_ncdhw, const void *g_pooled_bf16, const uint32_t *argmax,
+                                                const void *pooled_bf16, float *dw_packed, float *dbias, int n, int d, int h, int w,
+                                                mr3d_stream_t stream_) {
+  if (!argmax) return MR3D_ERR_INVALID_ARG;
+  return stem_wgrad_bf16_impl(x_ncdhw, g_pooled_bf16, argmax, pooled_bf16, dw_packed, dbias, n, d, h, w, stream_);
 }

@@ -627,18 +627,12 @@ class ExtractFeat3D(nn.Module):
                                 [nL - 1, self.max_cout], side=True))
         # slot 1: "every parameter gradient but the stem's is final" -- the point the overlapped gradient exchange waits for
         bwd.append(_hip.make_op(_hip.OP_SYNC, [], [_hip.SYNC_MARK, self.MARK_GRADS_BUT_STEM]))
-        if self.bf16:
-            g_stem = self._new(P.stem_out.shape)
-            bwd.append(self._op(_hip.OP_MAXPOOL_BWD, [g, P.pool_idx, P.pool_out, g_stem], [N, sd, sh, sw, 16]))
-            bwd.append(_hip.make_op(_hip.OP_SYNC, [], [_hip.SYNC_WAIT, 0]))
-            bwd.append(self._op(_hip.OP_STEM_WGRAD, [P.x_in, g_stem, self._s(stem, 'dwraw'), self._s(stem, 'dbias')],
-                                [N, D, H, W, 0, 0, 1]))
-        else:
-            # fp32: the max-pool backward and the stem's ReLU mask happen inside the weight gradient's dy staging
-            # (mr3d_stem_conv_wgrad_pooled) -- no un-pooled gradient buffer (335 MB on the 512 volume), one launch less
-            bwd.append(_hip.make_op(_hip.OP_SYNC, [], [_hip.SYNC_WAIT, 0]))
-            bwd.append(self._op(_hip.OP_STEM_WGRAD, [P.x_in, g, self._s(stem, 'dwraw'), self._s(stem, 'dbias'), None, P.pool_idx,
-                                                     P.pool_out], [N, D, H, W, 0, 0, 0, 1]))
+        # the max-pool backward and the stem's ReLU mask happen inside the weight gradient's dy staging
+        # (mr3d_stem_conv_wgrad_pooled / _bf16_pooled) -- no un-pooled gradient buffer (335 MB fp32 on the 512 volume), one
+        # launch less on the main chain
+        bwd.append(_hip.make_op(_hip.OP_SYNC, [], [_hip.SYNC_WAIT, 0]))
+        bwd.append(self._op(_hip.OP_STEM_WGRAD, [P.x_in, g, self._s(stem, 'dwraw'), self._s(stem, 'dbias'), None, P.pool_idx,
+                                                 P.pool_out], [N, D, H, W, 0, 0, 1 if P.stem_bf16 else 0, 1]))
         bwd.append(_hip.make_op(_hip.OP_SYNC, [], [_hip.SYNC_JOIN]))
         bwd.append(_hip.make_op(_hip.OP_FINISH_GRADS, [self._table, self._arena, self._scratch, self._grad_arena], [1, stem.cout]))
         P.fwd_ops, P.bwd_ops = fwd, bwd

@@ -593,6 +593,11 @@ int mr3d_stem_conv_forward_bf16(const float *x_ncdhw, const void *w16, const flo
                                 int relu, mr3d_stream_t stream);
 int mr3d_stem_conv_wgrad_bf16(const float *x_ncdhw, const void *dy_bf16, float *dw_packed, float *dbias, int n, int d, int h, int w,
                               mr3d_stream_t stream);
+/* bf16 form of mr3d_stem_conv_wgrad_pooled: g_pooled / pooled are bf16 [N, Dp, Hp, Wp, 16] (mr3d_maxpool3d_forward_bf16's
+ * outputs); window sums are formed in fp32 and rounded to bf16 once, like mr3d_maxpool3d_backward_bf16 does.
+ * Plan record: STEM_WGRAD with i[25] = bf16, i[6] = 1, i[7] = 1, p[1] = g_pooled, p[5] = argmax, p[6] = pooled. */
+int mr3d_stem_conv_wgrad_bf16_pooled(const float *x_ncdhw, const void *g_pooled_bf16, const uint32_t *argmax, const void *pooled_bf16,
+                                     float *dw_packed, float *dbias, int n, int d, int h, int w, mr3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Two chained pointwise (1x1x1, stride 1) convolutions in one launch (csrc/pw_pair.hip), for the small maps of layer3

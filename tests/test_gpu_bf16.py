@@ -236,6 +236,43 @@ def test_stem_bf16_forward_and_wgrad(dev, dhw):
     _close(db.cpu(), dy.double().sum(dim=(0, 2, 3, 4)), 'stem dbias', 1e-4, 1e-4)
 
 
+@pytest.mark.parametrize('n,dhw,relu', [(2, (6, 20, 24), True), (1, (9, 34, 70), True), (1, (5, 17, 33), False), (1, (12, 40, 136), True)])
+def test_stem_bf16_wgrad_from_the_pooled_gradient(dev, n, dhw, relu):
+    """mr3d_stem_conv_wgrad_bf16_pooled against the two launches it replaces (bf16 max-pool backward with the ReLU mask, then
+    the bf16 weight gradient) and against float64 on the same bf16 dy; several tiles per queue and a sparse gradient in
+    the last case"""
+    from mr3d_amd import _hip
+    g = torch.Generator().manual_seed(sum(dhw) + n)
+    x = torch.randn((n, 3) + dhw, generator=g)
+    d, ho, wo = dhw[0], (dhw[1] - 1) // 2 + 1, (dhw[2] - 1) // 2 + 1
+    y = _bf(torch.randn((n, d, ho, wo, 16), generator=g))
+    if relu:
+        y = torch.relu(y)
+    y = y.to(dev).bfloat16()
+    pooled = torch.empty((n, (d - 1) // 2 + 1, (ho - 1) // 2 + 1, (wo - 1) // 2 + 1, 16), device=dev, dtype=torch.bfloat16)
+    am = torch.empty(pooled.shape[:4] + (4,), dtype=torch.int32, device=dev)
+    op = _hip.make_op(_hip.OP_MAXPOOL_FWD, [y, pooled, am], [n, d, ho, wo, 16]); op.i[25] = _hip.DTYPE_BF16
+    _hip.Plan([op]).run(dev)
+    gp = _bf(torch.randn(pooled.shape, generator=g))
+    if dhw[0] == 12:
+        gp = gp * (torch.rand(gp.shape[:4] + (1,), generator=g) < 0.1)
+    gp = gp.to(dev).bfloat16()
+    gs = torch.empty_like(y)
+    op = _hip.make_op(_hip.OP_MAXPOOL_BWD, [gp, am, pooled if relu else None, gs], [n, d, ho, wo, 16]); op.i[25] = _hip.DTYPE_BF16
+    _hip.Plan([op]).run(dev)
+    dw2 = torch.zeros(343, 4, 16, device=dev); db2 = torch.zeros(16, device=dev)
+    _hip.stem_conv_wgrad_bf16(x.to(dev), gs, dw2, dbias=db2)
+    for rep in (1, 2):                                   # the second launch finds the tile queues re-armed by the first
+        dw = torch.zeros(343, 4, 16, device=dev); db = torch.zeros(16, device=dev)
+        _hip.stem_conv_wgrad_bf16_pooled(x.to(dev), gp, am, pooled if relu else None, dw, dbias=db)
+        # same bf16 products; the window sums may round differently where two windows share an arg-max (fp32 order)
+        _close(dw.cpu(), dw2.cpu().double(), 'pooled vs two launches', 2e-3, 2e-3)
+        _close(db.cpu(), db2.cpu().double(), 'pooled vs two launches, dbias', 2e-3, 2e-3)
+    refw = torch.nn.grad.conv3d_weight(_bf(x).double(), (16, 3, 7, 7, 7), gs.float().permute(0, 4, 1, 2, 3).cpu().double(), (1, 2, 2), 3)
+    got = dw[:, :3, :].permute(2, 1, 0).reshape(16, 3, 7, 7, 7).cpu()
+    _close(got, refw, 'stem wgrad (pooled)', 2e-3, 2e-3)
+
+
 @pytest.mark.parametrize('cin,cout', [(16, 64), (64, 16), (64, 64), (32, 128), (128, 64), (16, 16)])
 def test_pointwise_bf16_streaming(dev, cin, cout):
     """>= 32768 positions: the barrier-free streaming kernel (csrc/pointwise_bf16.hip, transposed GEMM, weights in registers)

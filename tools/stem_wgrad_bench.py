@@ -28,30 +28,44 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--density', type=float, default=1.0, help='fraction of pooled positions with a non-zero gradient')
     ap.add_argument('--shape', type=int, nargs=3, default=(80, 512, 512))
+    ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32', help='storage type of the activations / gradients')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     d, h, w = a.shape
     g = torch.Generator(device=dev).manual_seed(0)
     x = torch.randn((1, 3, d, h, w), device=dev, generator=g)
     ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
-    y = torch.randn((1, d, ho, wo, 16), device=dev, generator=g).relu_()
-    pooled = torch.empty((1, (d - 1) // 2 + 1, (ho - 1) // 2 + 1, (wo - 1) // 2 + 1, 16), device=dev)
+    bf = a.dtype == 'bf16'
+    dt = torch.bfloat16 if bf else torch.float32
+
+    def op(kind, ptrs, ints):
+        o = _hip.make_op(kind, ptrs, ints)
+        if bf:
+            o.i[25] = _hip.DTYPE_BF16
+        return o
+
+    y = torch.randn((1, d, ho, wo, 16), device=dev, generator=g).relu_().to(dt)
+    pooled = torch.empty((1, (d - 1) // 2 + 1, (ho - 1) // 2 + 1, (wo - 1) // 2 + 1, 16), device=dev, dtype=dt)
     am = torch.empty(pooled.shape[:4] + (4,), dtype=torch.int32, device=dev)
-    _hip.Plan([_hip.make_op(_hip.OP_MAXPOOL_FWD, [y, pooled, am], [1, d, ho, wo, 16])]).run(dev)
+    _hip.Plan([op(_hip.OP_MAXPOOL_FWD, [y, pooled, am], [1, d, ho, wo, 16])]).run(dev)
     gp = torch.randn(pooled.shape, device=dev, generator=g)
     if a.density < 1.0:
         gp = gp * (torch.rand(gp.shape[:4] + (1,), device=dev, generator=g) < a.density)
+    gp = gp.to(dt)
     gs = torch.empty_like(y)
     dw = torch.zeros((343, 4, 16), device=dev)
     db = torch.zeros(16, device=dev)
-    bwd = _hip.Plan([_hip.make_op(_hip.OP_MAXPOOL_BWD, [gp, am, pooled, gs], [1, d, ho, wo, 16])])
+    bwd = _hip.Plan([op(_hip.OP_MAXPOOL_BWD, [gp, am, pooled, gs], [1, d, ho, wo, 16])])
+    dense = (lambda w_, b_: _hip.stem_conv_wgrad_bf16(x, gs, w_, b_)) if bf else (lambda w_, b_: _hip.stem_conv_wgrad(x, gs, w_, b_))
+    fused = ((lambda w_, b_: _hip.stem_conv_wgrad_bf16_pooled(x, gp, am, pooled, w_, b_)) if bf else
+             (lambda w_, b_: _hip.stem_conv_wgrad_pooled(x, gp, am, pooled, w_, b_)))
     t_pool = timed(lambda: bwd.run(dev))
-    t_dense = timed(lambda: _hip.stem_conv_wgrad(x, gs, dw, db))
-    dw1 = torch.zeros_like(dw); _hip.stem_conv_wgrad(x, gs, dw1, None)
-    t_fused = timed(lambda: _hip.stem_conv_wgrad_pooled(x, gp, am, pooled, dw, db))
-    dw2 = torch.zeros_like(dw); _hip.stem_conv_wgrad_pooled(x, gp, am, pooled, dw2, None)
+    t_dense = timed(lambda: dense(dw, db))
+    dw1 = torch.zeros_like(dw); dense(dw1, None)
+    t_fused = timed(lambda: fused(dw, db))
+    dw2 = torch.zeros_like(dw); fused(dw2, None)
     err = (dw1 - dw2).abs().max().item() / dw1.abs().max().item()
-    print(f'density {a.density}: maxpool_bwd {t_pool:.0f} us + stem_wgrad {t_dense:.0f} us = {t_pool + t_dense:.0f} us; '
+    print(f'{a.dtype} density {a.density}: maxpool_bwd {t_pool:.0f} us + stem_wgrad {t_dense:.0f} us = {t_pool + t_dense:.0f} us; '
           f'pooled-gradient kernel {t_fused:.0f} us; rel diff {err:.1e}')
 
 
