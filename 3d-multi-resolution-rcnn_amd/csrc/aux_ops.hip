@@ -272,39 +272,71 @@ __global__ __launch_bounds__(kT) void prep_weights_kernel(const mr3d_layer_desc 
 }
 
 // grads[w] += s[co] * dwraw[tap][ci][co]   (dwraw = gradient w.r.t. the FOLDED weights)
+// Both finishing kernels are latency chains, not bandwidth (3.5 M parameters in all): a thread's gathers from the
+// [tap][ci][co] scratch depend on nothing but its index, so they are issued four at a time, and the grid is wide enough that
+// the largest layer (128 x 128 x 27) takes 7 rounds instead of 27 (64 blocks per layer: 100 us beside the stem weight gradient).
 __global__ __launch_bounds__(kT) void finish_wgrads_kernel(const mr3d_layer_desc *__restrict__ table,
                                                           const float *__restrict__ params,
                                                           const float *__restrict__ scratch, float *__restrict__ grads) {
   const mr3d_layer_desc L = table[blockIdx.y];
   const int total = L.co * L.ci * L.taps;
-  for (int e = blockIdx.x * kT + threadIdx.x; e < total; e += gridDim.x * kT) {
-    const int tap = e % L.taps, ci = (e / L.taps) % L.ci, co = e / (L.taps * L.ci);
-    grads[L.w_off + e] += layer_scale(L, params, co) * scratch[L.dwraw_off + ((long long)tap * L.ci_pad + ci) * L.co + co];
+  const int stride = gridDim.x * kT;
+  for (int e0 = blockIdx.x * kT + threadIdx.x; e0 < total; e0 += 4 * stride) {
+    float v[4], sc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u * stride;
+      v[u] = 0.f; sc[u] = 0.f;
+      if (e < total) {
+        const int tap = e % L.taps, ci = (e / L.taps) % L.ci, co = e / (L.taps * L.ci);
+        v[u] = scratch[L.dwraw_off + ((long long)tap * L.ci_pad + ci) * L.co + co];
+        sc[u] = layer_scale(L, params, co);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u * stride;
+      if (e < total) grads[L.w_off + e] += sc[u] * v[u];
+    }
   }
 }
 
-// per output channel c (one wave each):  dot = sum_k W[c][k] * dwraw[k][c]  ( = sum_p dy*z )
+// per output channel c (one workgroup each):  dot = sum_k W[c][k] * dwraw[k][c]  ( = sum_p dy*z )
 //   BN:   dgamma += invstd*(dot - mean*sumdy),  dbeta += sumdy        conv bias: dbias += sumdy
 __global__ __launch_bounds__(kT) void finish_affine_kernel(const mr3d_layer_desc *__restrict__ table,
                                                           const float *__restrict__ params,
                                                           const float *__restrict__ scratch, float *__restrict__ grads) {
   const mr3d_layer_desc L = table[blockIdx.y];
-  const int lane = threadIdx.x & 63;
-  const int c = blockIdx.x * (kT / 64) + (threadIdx.x >> 6);
+  const int c = blockIdx.x;
   if (c >= L.co) return;
   const float sumdy = scratch[L.dbias_off + c];
   if (L.gamma_off < 0) {
-    if (L.bias_off >= 0 && lane == 0) grads[L.bias_off + c] += sumdy;
+    if (L.bias_off >= 0 && threadIdx.x == 0) grads[L.bias_off + c] += sumdy;
     return;
   }
   float dot = 0.f;
   const int K = L.ci * L.taps;
-  for (int k = lane; k < K; k += 64) {
-    const int tap = k % L.taps, ci = k / L.taps;
-    dot += params[L.w_off + (long long)c * K + k] * scratch[L.dwraw_off + ((long long)tap * L.ci_pad + ci) * L.co + c];
+  for (int k0 = threadIdx.x; k0 < K; k0 += 4 * kT) {
+    float w[4], g[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = k0 + u * kT;
+      w[u] = 0.f; g[u] = 0.f;
+      if (k < K) {
+        const int tap = k % L.taps, ci = k / L.taps;
+        w[u] = params[L.w_off + (long long)c * K + k];
+        g[u] = scratch[L.dwraw_off + ((long long)tap * L.ci_pad + ci) * L.co + c];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) dot += w[u] * g[u];
   }
   for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
-  if (lane == 0) {
+  __shared__ float part[kT / 64];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = dot;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    dot = (part[0] + part[1]) + (part[2] + part[3]);
     const float invstd = 1.f / sqrtf(params[L.var_off + c] + L.eps);
     grads[L.gamma_off + c] += invstd * (dot - params[L.mean_off + c] * sumdy);
     grads[L.beta_off + c] += sumdy;
@@ -474,8 +506,8 @@ extern "C" int mr3d_prepare_weights(const mr3d_layer_desc *table, int num_layers
 extern "C" int mr3d_finish_grads(const mr3d_layer_desc *table, int num_layers, int max_cout, const float *params,
                                  const float *scratch, float *grads, mr3d_stream_t s) {
   if (!table || !params || !scratch || !grads || num_layers <= 0 || max_cout <= 0) return MR3D_ERR_INVALID_ARG;
-  finish_wgrads_kernel<<<dim3(64, num_layers), kT, 0, mr3d_stream(s)>>>(table, params, scratch, grads);
-  finish_affine_kernel<<<dim3((max_cout + 3) / 4, num_layers), kT, 0, mr3d_stream(s)>>>(table, params, scratch, grads);
+  finish_wgrads_kernel<<<dim3(256, num_layers), kT, 0, mr3d_stream(s)>>>(table, params, scratch, grads);
+  finish_affine_kernel<<<dim3(max_cout, num_layers), kT, 0, mr3d_stream(s)>>>(table, params, scratch, grads);
   return mr3d_launch_status();
 }
 
