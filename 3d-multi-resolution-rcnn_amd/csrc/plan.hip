@@ -160,8 +160,11 @@ int g_side_enabled = 1;
 // touches before the next join / wait (weight gradients, the table-driven weight preparation and gradient finishing, the
 // zero-fill of the weight-gradient scratch)
 bool wants_side(const mr3d_op &o) {
+  // ... and, since round 3, convolutions / subsampling / liveness bitmaps of pyramid levels whose results the main chain
+  // only needs behind a SYNC record: the P3..P5 output convolutions (and their data gradients) run beside the P2 one
   return o.i[26] == 1 && (o.kind == MR3D_OP_CONV_WGRAD || o.kind == MR3D_OP_STEM_WGRAD || o.kind == MR3D_OP_PREP_WEIGHTS ||
-                          o.kind == MR3D_OP_PREP_WEIGHTS_BF16 || o.kind == MR3D_OP_MEMSET0 || o.kind == MR3D_OP_FINISH_GRADS);
+                          o.kind == MR3D_OP_PREP_WEIGHTS_BF16 || o.kind == MR3D_OP_MEMSET0 || o.kind == MR3D_OP_FINISH_GRADS ||
+                          o.kind == MR3D_OP_CONV_FWD || o.kind == MR3D_OP_SUBSAMPLE_FWD || o.kind == MR3D_OP_VOXEL_LIVENESS);
 }
 
 }  // namespace

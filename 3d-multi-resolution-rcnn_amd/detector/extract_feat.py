@@ -59,6 +59,7 @@ class _ConvSpec:
 class ExtractFeat3D(nn.Module):
     STAGE_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
     MARK_GRADS_BUT_STEM = 1          # SYNC slot of the backward plan (see dist_utils.allreduce_overlapped)
+    MARK_COARSE_DGRADS = 2           # SYNC slot: the P3..P5 output-conv data gradients (side stream) are done
 
     def __init__(self, depth=50, fpn_out_channels=64, num_outs=5, zero_init_residual=True, device='cuda',
                  dtype=torch.float32, neck_dcn=False):
@@ -378,6 +379,12 @@ class ExtractFeat3D(nn.Module):
             o.i[25] = _hip.DTYPE_BF16
         return o
 
+    @staticmethod
+    def _side(op):
+        """the record may run on the plan's side stream (mr3d_op.i[26]); its readers sit behind a SYNC record"""
+        op.i[26] = 1
+        return op
+
     def _s(self, spec, kind):
         return self._scratch.data_ptr() + 4 * getattr(self._table_host[spec.index], kind + '_off')
 
@@ -508,13 +515,17 @@ class ExtractFeat3D(nn.Module):
         if self.neck_dcn:
             P.outs = list(P.lat)                    # the deformable neck (detector/dcn_neck.py) takes over from here
         else:
-            for i in range(4):
-                o = self._new(self._out_shape(P.lat[i].shape, self.fpnconv[i]))
-                fwd.append(self._conv_fwd(P.lat[i], self.fpnconv[i], o))
-                P.outs.append(o)
-            _, d5, h5, w5, _ = P.outs[3].shape
-            p6 = self._new((N, (d5 - 1) // 2 + 1, (h5 - 1) // 2 + 1, (w5 - 1) // 2 + 1, self.fpn_out))
-            fwd.append(self._op(_hip.OP_SUBSAMPLE_FWD, [P.outs[3], p6], [N, d5, h5, w5, self.fpn_out]))
+            # The P3..P5 output convolutions and P6 (small maps: tens of workgroups each) are queued on the side stream IN FRONT of
+            # the P2 one, which fills the chip for 0.6 ms on the main stream; nothing reads them before the plan's final join
+            # (headline step, 300 steps each: 11.05 -> 11.01 ms).
+            P.outs = [self._new(self._out_shape(P.lat[i].shape, self.fpnconv[i])) for i in range(4)]
+            for i in (3, 2, 1):
+                fwd.append(self._side(self._conv_fwd(P.lat[i], self.fpnconv[i], P.outs[i])))
+                if i == 3:
+                    _, d5, h5, w5, _ = P.outs[3].shape
+                    p6 = self._new((N, (d5 - 1) // 2 + 1, (h5 - 1) // 2 + 1, (w5 - 1) // 2 + 1, self.fpn_out))
+                    fwd.append(self._side(self._op(_hip.OP_SUBSAMPLE_FWD, [P.outs[3], p6], [N, d5, h5, w5, self.fpn_out])))
+            fwd.append(self._conv_fwd(P.lat[0], self.fpnconv[0], P.outs[0]))
             P.outs.append(p6)
 
         # ---------------- backward
@@ -531,17 +542,37 @@ class ExtractFeat3D(nn.Module):
             glat = [self._new(l.shape) for l in P.lat]
             P.n_direct = 3                          # P2..P4 gradients are only read; the P5 buffer also takes P6's
         gC_lat = [self._new(c.shape) for c in P.C]
+
+        def fpn_dgrad(i, side):
+            ops = []
+            if self.sparse_pyramid_grads and not self.bf16 and P.gouts[i].shape[1] * P.gouts[i].shape[2] * P.gouts[i].shape[3] >= 65536:
+                # voxel liveness of the incoming gradient, handed to the data-gradient record behind it (large maps: the
+                # two-dimensional Winograd kernel writes tiles whose halo holds no live voxel from its epilogue alone)
+                n_, d_, h_, w_, c_ = P.gouts[i].shape
+                lbits = torch.empty((_hip.voxel_liveness_words(n_ * d_ * h_ * w_),), dtype=torch.int32, device=self.device)
+                P.keep = getattr(P, 'keep', []) + [lbits]
+                ops.append(_hip.make_op(_hip.OP_VOXEL_LIVENESS, [P.gouts[i], lbits], [n_, d_, h_, w_, c_, 1]))
+            ops.append(self._conv_dgrad(P.gouts[i], self.fpnconv[i], glat[i]))
+            return [self._side(o) for o in ops] if side else ops
+
+        # bf16 only: in the fp32 step the side queue (every weight gradient) has no slack -- whatever it still holds when the
+        # stem weight gradient starts runs after it (the stem's persistent workgroups leave no room for an LDS-heavy kernel):
+        # measured 11.07 -> 11.18 ms with these 0.17 ms moved over, 5.61 -> 5.51 ms in the bf16 step
+        coarse_on_side = self.bf16
+        if not self.neck_dcn:
+            # the data gradients of the P3..P5 output convolutions only meet the main chain at the upsample adjoints: they are
+            # queued on the side stream in front of the weight gradients, beside the P2 one
+            if coarse_on_side:
+                for i in (3, 2, 1):
+                    bwd += fpn_dgrad(i, True)
+                bwd.append(_hip.make_op(_hip.OP_SYNC, [], [_hip.SYNC_MARK, self.MARK_COARSE_DGRADS]))
         for i in range(4):
             if not self.neck_dcn:
                 bwd.append(self._conv_wgrad(P.lat[i], P.gouts[i], self.fpnconv[i], sparse_dy=self.sparse_pyramid_grads))
-                if self.sparse_pyramid_grads and not self.bf16 and P.gouts[i].shape[1] * P.gouts[i].shape[2] * P.gouts[i].shape[3] >= 65536:
-                    # voxel liveness of the incoming gradient, handed to the data-gradient record behind it (large maps: the
-                    # two-dimensional Winograd kernel writes tiles whose halo holds no live voxel from its epilogue alone)
-                    n_, d_, h_, w_, c_ = P.gouts[i].shape
-                    lbits = torch.empty((_hip.voxel_liveness_words(n_ * d_ * h_ * w_),), dtype=torch.int32, device=self.device)
-                    P.keep = getattr(P, 'keep', []) + [lbits]
-                    bwd.append(_hip.make_op(_hip.OP_VOXEL_LIVENESS, [P.gouts[i], lbits], [n_, d_, h_, w_, c_, 1]))
-                bwd.append(self._conv_dgrad(P.gouts[i], self.fpnconv[i], glat[i]))
+                if i == 0 or not coarse_on_side:
+                    bwd += fpn_dgrad(i, False)
+                elif i == 1:
+                    bwd.append(_hip.make_op(_hip.OP_SYNC, [], [_hip.SYNC_WAIT, self.MARK_COARSE_DGRADS]))
             if i > 0:
                 nf, df, hf, wf, c = glat[i - 1].shape
                 bwd.append(self._op(_hip.OP_UPSAMPLE_ADJ, [glat[i - 1], glat[i]],

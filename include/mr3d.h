@@ -706,8 +706,9 @@ typedef struct {
   void *p[8];
 } mr3d_op;
 int mr3d_plan_run(const mr3d_op *ops_host, int num_ops, int *failed_index_host, mr3d_stream_t stream);
-/* CONV_WGRAD / STEM_WGRAD / PREP_WEIGHTS(_BF16) / MEMSET0 / FINISH_GRADS records with i[26] == 1 run on an internal side
- * stream beside the caller's chain (fork by event before the op; the side stream is one in-order queue).  The caller's
+/* CONV_WGRAD / STEM_WGRAD / PREP_WEIGHTS(_BF16) / MEMSET0 / FINISH_GRADS / CONV_FWD / SUBSAMPLE_FWD / VOXEL_LIVENESS records
+ * with i[26] == 1 run on an internal side stream beside the caller's chain (fork by event before the op; the side stream is
+ * one in-order queue; a record on the caller's stream that reads a side record's output must sit behind a SYNC).  The caller's
  * stream re-joins it at SYNC records, before a FINISH_GRADS record that runs on the caller's stream, and at the end of
  * the call.  0 disables the side stream (everything on `stream`, in list order); default 1. */
 void mr3d_plan_set_side_stream(int enable);
