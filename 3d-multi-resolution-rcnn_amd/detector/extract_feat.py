@@ -477,6 +477,11 @@ class ExtractFeat3D(nn.Module):
         for bi, b in enumerate(self.blocks):
             nb = self.blocks[bi + 1] if bi + 1 < len(self.blocks) else None
             st = dict(x=x)
+            if b['ds']:
+                # the projection shortcut only meets the chain at conv3's residual add: it runs on the side stream beside
+                # conv1 / conv2 (a streaming pointwise kernel next to the 3x3x3 matrix work; 147 us of the forward chain)
+                st['idn'] = self._new(self._out_shape(x.shape, b['dsconv']))
+                fwd.append(self._side(self._conv_fwd(x, b['dsconv'], st['idn'])))
             if pending_a1 is not None:
                 st['a1'] = pending_a1                    # already produced by the previous block's pair launch
             else:
@@ -486,8 +491,8 @@ class ExtractFeat3D(nn.Module):
             fwd.append(self._conv_fwd(st['a1'], b['conv2'], st['a2'], relu=True))
             oshape = self._out_shape(st['a2'].shape, b['conv3'])
             if b['ds']:
-                st['idn'] = self._new(oshape)
-                fwd.append(self._conv_fwd(x, b['dsconv'], st['idn']))
+                assert tuple(st['idn'].shape) == tuple(oshape)
+                fwd.append(_hip.make_op(_hip.OP_SYNC, [], [_hip.SYNC_JOIN]))
                 idn = st['idn']
             else:
                 idn = x
