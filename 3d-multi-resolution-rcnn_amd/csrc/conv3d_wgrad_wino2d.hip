@@ -59,6 +59,18 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wgrad_wino2d_kernel(Conv3d
   // current tile's k-steps (their latency rides under 96 MFMAs per wave) and committed to LDS after them.
   constexpr int NX = (TD * HH * HW * (CC / 4) + kThreads - 1) / kThreads, NY = TD * TH * TW * 16 / kThreads;
   float4 xs[NX], ys[NY];
+  // Addresses: this kernel is VALU-issue bound (two waves per SIMD, ~1200 vector instructions per tile and wave against 96
+  // MFMAs), and a third of those were the 64-bit multiply chains of these 12 loads.  A load is now a per-tile SCALAR 64-bit
+  // base plus a 32-bit lane offset that does not depend on the tile (x: one register per piece, hoisted; dy: one register, the
+  // pieces differ by scalars), and tiles whose halo lies inside the volume (most) carry no per-lane bounds tests.
+  int xrel[NX];
+#pragma unroll
+  for (int j = 0; j < NX; ++j) {
+    const int it = tid + j * kThreads, pos = it >> 2, q = it & 3;
+    const int hw = pos % HW, hh = (pos / HW) % HH, hd = pos / (HW * HH);
+    xrel[j] = ((hd * p.H + hh) * p.W + hw) * p.Cin + q * 4;
+  }
+  const int yrel0 = ((tid >> 7) * p.Wo + ((tid >> 4) & 7)) * p.Cout + (tid & 15) * 4;      // piece 0: od 0, oh tid >> 7, ow
   auto fetch = [&](int t, bool do_x, bool do_y) {
     int b = t;
     const int tw_i = b % tiles_w; b /= tiles_w;
@@ -67,28 +79,41 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wgrad_wino2d_kernel(Conv3d
     const int n = b;
     const int od0 = td_i * TD, oh0 = th_i * TH, ow0 = tw_i * TW;
     const int id0 = od0 + kd - p.pd, ih0 = oh0 - p.ph, iw0 = ow0 - p.pw;
-    if (do_x)
+    if (do_x) {
+      const float *xb = p.x + ((((long long)n * p.D + id0) * p.H + ih0) * p.W + iw0) * p.Cin + c0;      // may point in front of x: masked
+      const bool inside = id0 >= 0 && id0 + TD <= p.D && ih0 >= 0 && ih0 + HH <= p.H && iw0 >= 0 && iw0 + HW <= p.W;   // (scalar)
+      if (inside) {
 #pragma unroll
-    for (int j = 0; j < NX; ++j) {
-      const int it = tid + j * kThreads;
-      const int pos = it >> 2, q = it & 3;
-      const int hw = pos % HW, hh = (pos / HW) % HH, hd = pos / (HW * HH);
-      const int id = id0 + hd, ih = ih0 + hh, iw = iw0 + hw;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (it < TD * HH * HW * (CC / 4) && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
-        v = *reinterpret_cast<const float4 *>(p.x + ((((size_t)n * p.D + id) * p.H + ih) * p.W + iw) * p.Cin + c0 + q * 4);
-      xs[j] = v;
+        for (int j = 0; j < NX; ++j) {
+          xs[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if ((j + 1) * kThreads <= TD * HH * HW * (CC / 4) || tid + j * kThreads < TD * HH * HW * (CC / 4))
+            xs[j] = *reinterpret_cast<const float4 *>(xb + xrel[j]);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+          const int it = tid + j * kThreads, pos = it >> 2;
+          const int hw = pos % HW, hh = (pos / HW) % HH, hd = pos / (HW * HH);
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (it < TD * HH * HW * (CC / 4) && (unsigned)(id0 + hd) < (unsigned)p.D && (unsigned)(ih0 + hh) < (unsigned)p.H &&
+              (unsigned)(iw0 + hw) < (unsigned)p.W)
+            v = *reinterpret_cast<const float4 *>(xb + xrel[j]);
+          xs[j] = v;
+        }
+      }
     }
-    if (do_y)
+    if (do_y) {
+      const float *yb = p.dy + ((((long long)n * p.Do + od0) * p.Ho + oh0) * p.Wo + ow0) * p.Cout + n0;
+      const bool inside = od0 + TD <= p.Do && oh0 + TH <= p.Ho && ow0 + TW <= p.Wo;
+      const int row2 = 2 * p.Wo * p.Cout, plane = p.Ho * p.Wo * p.Cout;                 // pieces: oh += 2 per j, od = j >> 2
 #pragma unroll
-    for (int j = 0; j < NY; ++j) {
-      const int it = tid + j * kThreads;
-      const int pos = it >> 4, q = it & 15;
-      const int ow = pos % TW, oh = (pos / TW) % TH, od = pos / (TW * TH);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (od0 + od < p.Do && oh0 + oh < p.Ho && ow0 + ow < p.Wo)
-        v = *reinterpret_cast<const float4 *>(p.dy + ((((size_t)n * p.Do + od0 + od) * p.Ho + oh0 + oh) * p.Wo + ow0 + ow) * p.Cout + n0 + q * 4);
-      ys[j] = v;
+      for (int j = 0; j < NY; ++j) {
+        const int rel = yrel0 + (j & 3) * row2 + (j >> 2) * plane;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (inside || (od0 + (j >> 2) < p.Do && oh0 + (tid >> 7) + 2 * (j & 3) < p.Ho && ow0 + ((tid >> 4) & 7) < p.Wo))
+          v = *reinterpret_cast<const float4 *>(yb + rel);
+        ys[j] = v;
+      }
     }
   };
   auto commit = [&]() {

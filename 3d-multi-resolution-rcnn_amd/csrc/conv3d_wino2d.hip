@@ -98,6 +98,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wino2d_kernel(Conv3dFwdArg
   const int n = b;
   const int od0 = td_i * TD, oh0 = th_i * TH, ow0 = tw_i * TW;
   const int id0 = od0 - p.pd, ih0 = oh0 - p.ph, iw0 = ow0 - p.pw;
+  // halo origin (may lie in front of x: only addresses inside the volume are dereferenced) and "no bounds tests needed" (scalars)
+  const float *xtile = p.x + ((((long long)n * p.D + id0) * p.H + ih0) * p.W + iw0) * p.Cin;
+  const bool halo_inside = id0 >= 0 && id0 + HD <= p.D && ih0 >= 0 && ih0 + HH <= p.H && iw0 >= 0 && iw0 + HW <= p.W;
   const int li = lane & 15, lk = lane >> 4;
   const int co = blockIdx.y * 64 + wave * 16 + li;
   // A operand: this lane's GEMM row li = (output plane li >> 3, patch li & 7) and its k index inside the k-step (lk)
@@ -134,10 +137,13 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wino2d_kernel(Conv3dFwdArg
     const int it = tv + j * kThreads;
     const int pos = it / Q, q = it - pos * Q;
     const int hw = pos % HW, hh = (pos / HW) % HH, hd = pos / (HW * HH);
-    const int id = id0 + hd, ih = ih0 + hh, iw = iw0 + hw;
+    // scalar 64-bit tile base + 32-bit lane offset (24-bit multiplies): the size_t chain per load was ~20 slow vector
+    // instructions, and this kernel's staging competes with its MFMAs for the SIMD's vector issue
+    const int rel = (int)__umul24(__umul24(__umul24(hd, p.H) + hh, p.W) + hw, p.Cin) + c0 + q * 4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (it < HD * HH * HW * Q && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
-      v = *reinterpret_cast<const float4 *>(p.x + ((((size_t)n * p.D + id) * p.H + ih) * p.W + iw) * p.Cin + c0 + q * 4);
+    if (it < HD * HH * HW * Q &&
+        (halo_inside || ((unsigned)(id0 + hd) < (unsigned)p.D && (unsigned)(ih0 + hh) < (unsigned)p.H && (unsigned)(iw0 + hw) < (unsigned)p.W)))
+      v = *reinterpret_cast<const float4 *>(xtile + rel);
     return v;
   };
   auto commit = [&](int j, const float4 &v) {
@@ -298,6 +304,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wino2d_rows_kernel(Conv3dF
   const int n = b;
   const int od0 = td_i * TDr, oh0 = th_i * TH, ow0 = tw_i * TW;
   const int id0 = od0 - p.pd, ih0 = oh0 - p.ph, iw0 = ow0 - p.pw;
+  const float *xtile = p.x + ((((long long)n * p.D + id0) * p.H + ih0) * p.W + iw0) * p.Cin;       // see conv3d_wino2d_kernel
+  const bool halo_inside = id0 >= 0 && id0 + HDr <= p.D && ih0 >= 0 && ih0 + HH <= p.H && iw0 >= 0 && iw0 + HW <= p.W;
   const int li = lane & 15, lk = lane >> 4;
   const int wave_m = wave / WN, wave_n = wave % WN;
   const int co = blockIdx.y * (16 * WN) + wave_n * 16 + li;
@@ -383,10 +391,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wino2d_rows_kernel(Conv3dF
           const int it = tv + (j0 + jj) * kThreads;
           const int pos = it / Q, q = it - pos * Q;
           const int hw = pos % HW, hh = (pos / HW) % HH, hd = pos / (HW * HH);
-          const int id = id0 + hd, ih = ih0 + hh, iw = iw0 + hw;
+          const int rel = (int)__umul24(__umul24(__umul24(hd, p.H) + hh, p.W) + hw, p.Cin) + c0 + q * 4;
           float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (it < HDr * HH * HW * Q && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
-            v = *reinterpret_cast<const float4 *>(p.x + ((((size_t)n * p.D + id) * p.H + ih) * p.W + iw) * p.Cin + c0 + q * 4);
+          if (it < HDr * HH * HW * Q &&
+              (halo_inside || ((unsigned)(id0 + hd) < (unsigned)p.D && (unsigned)(ih0 + hh) < (unsigned)p.H && (unsigned)(iw0 + hw) < (unsigned)p.W)))
+            v = *reinterpret_cast<const float4 *>(xtile + rel);
           stage[jj] = v;
         }
 #pragma unroll
