@@ -399,33 +399,49 @@ __global__ __launch_bounds__(kStemThreads) void stem_wgrad_kernel(StemWgradArgs 
         *reinterpret_cast<float4 *>(dyt + m * DYROW + q4 * 4) = v;
       }
     }
+    // The k-steps of a channel are FULLY unrolled: every LDS address is then a per-lane base register (one for the dy column, one
+    // per tap-column group) plus an immediate offset, and the loop carries no vector instruction besides its MFMAs -- on this
+    // chip a vector ALU instruction does not hide under an fp32 MFMA (tools/micro/mfma_clock.hip: 14.7 ns per MFMA and SIMD bare,
+    // 17.4 with ten integer adds per six MFMAs), and the four address adds per k-step cost this kernel 0.15 ms.  The three
+    // channels share the one unrolled body: it always accumulates into acc[0], and the accumulator groups rotate after it.
+    const float *abase = dyt + lk * DYROW + li;
+    const float *bbase[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) bbase[q] = slab + goff[q] + 2 * lane_col;
+#pragma unroll 1
     for (int ci = 0; ci < 3; ++ci) {
       if (ci) __syncthreads();
       stem_wgrad_stage_channel(slab, p.x + ((size_t)n * 3 + ci) * vox, p.D, p.H, p.W, d0, h0, w0, tid);
       __syncthreads();
+      if (ci == 0 && wave == 0) {                       // bias gradient: this wave's column sums of the dy tile
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll 8
+        for (int ks = 0; ks < M / 4; ks += 2) { s0 += abase[ks * 4 * DYROW]; s1 += abase[(ks + 1) * 4 * DYROW]; }
+        bsum += s0 + s1;
+      }
       auto ld = [&](int ks, float &a, float (&bv)[NQ]) {
         const int j = ks & 3, th = (ks >> 2) & 7, td = ks >> 5;
-        a = dyt[(ks * 4 + lk) * DYROW + li];                        // A[i = co][k]
-        const int pos = td * G::PLANE + 2 * th * G::ROW + 2 * (2 * j + lane_col);   // halo origin of that position
+        a = abase[ks * 4 * DYROW];                                      // A[i = co][k]
+        const int pos = td * G::PLANE + 2 * th * G::ROW + 4 * j;        // halo origin of that k-step's positions (immediate)
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) bv[q] = slab[pos + goff[q]];
+        for (int q = 0; q < NQ; ++q) bv[q] = bbase[q][pos];
       };
-      auto run = [&](f32x4 (&ac)[NQ], bool count_bias) {
-        float a0, a1, b0[NQ], b1[NQ];
-        ld(0, a0, b0);
-        for (int ks = 0; ks < M / 4; ks += 2) {
-          ld(ks + 1, a1, b1);
+      float a0, a1, b0[NQ], b1[NQ];
+      ld(0, a0, b0);
 #pragma unroll
-          for (int q = 0; q < NQ; ++q) ac[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[q], ac[q], 0, 0, 0);
-          if (count_bias) bsum += a0 + a1;
-          if (ks + 2 < M / 4) ld(ks + 2, a0, b0);
+      for (int ks = 0; ks < M / 4; ks += 2) {
+        ld(ks + 1, a1, b1);
 #pragma unroll
-          for (int q = 0; q < NQ; ++q) ac[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[q], ac[q], 0, 0, 0);
-        }
-      };
-      if (ci == 0) run(acc[0], wave == 0);
-      else if (ci == 1) run(acc[1], false);
-      else run(acc[2], false);
+        for (int q = 0; q < NQ; ++q) acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[q], acc[0][q], 0, 0, 0);
+        if (ks + 2 < M / 4) ld(ks + 2, a0, b0);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[0][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[q], acc[0][q], 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {                    // rotate: after the third channel the groups are back in place
+        const f32x4 t = acc[0][q];
+        acc[0][q] = acc[1][q]; acc[1][q] = acc[2][q]; acc[2][q] = t;
+      }
     }
     if (tid == 0) s_tile = take(ticket);
     __syncthreads();                       // also: every wave is done with this tile's dy rows and slab

@@ -28,6 +28,46 @@ __global__ __launch_bounds__(256) void mfma_loop(float *out, long long *ticks, i
   if (threadIdx.x == 0) { ticks[2 * blockIdx.x] = t1 - t0; ticks[2 * blockIdx.x + 1] = w1 - w0; }
 }
 
+// the shape of stem_wgrad_kernel's inner loop without its LDS reads: 3 accumulators, the A / B operands of every k-step formed by
+// a few vector and scalar instructions, a barrier every `per_barrier` k-steps (0 = none)
+__global__ __launch_bounds__(512) void stem_like_loop(float *out, long long *ticks, int iters, int per_barrier) {
+  f32x4 acc[3] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+  const int lk = threadIdx.x >> 4 & 3;
+  const long long t0 = __builtin_readcyclecounter(), w0 = wall_clock64();
+  for (int it = 0; it < iters; ++it) {
+    for (int ks = 0; ks < 128; ks += 2) {
+      const float a0 = __int_as_float(ks + lk), a1 = __int_as_float(ks + 1 + lk);
+      float b0[3], b1[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { b0[q] = __int_as_float(ks * 3 + q + it); b1[q] = __int_as_float(ks * 3 + 3 + q + it); }
+#pragma unroll
+      for (int q = 0; q < 3; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[q], acc[q], 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[q], acc[q], 0, 0, 0);
+    }
+    if (per_barrier && (it % per_barrier) == per_barrier - 1) __syncthreads();
+  }
+  const long long t1 = __builtin_readcyclecounter(), w1 = wall_clock64();
+  out[blockIdx.x * 512 + threadIdx.x] = acc[0][0] + acc[1][0] + acc[2][0];
+  if (threadIdx.x == 0) { ticks[2 * blockIdx.x] = t1 - t0; ticks[2 * blockIdx.x + 1] = w1 - w0; }
+}
+
+void run_stem_like(int cus, int per_barrier) {
+  const int grid = 2 * cus, iters = 60;                // 2 workgroups of 8 waves per CU = 4 waves per SIMD, 384 MFMAs per iteration
+  float *out; long long *ticks;
+  hipMalloc(&out, grid * 512 * 4); hipMalloc(&ticks, grid * 16);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  stem_like_loop<<<grid, 512>>>(out, ticks, 2, per_barrier);
+  hipEventRecord(e0);
+  stem_like_loop<<<grid, 512>>>(out, ticks, iters, per_barrier);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  const double mfmas_per_simd = 384.0 * iters * 4;
+  printf("stem-like loop, 4 waves/SIMD, barrier every %d x 384 MFMAs: %.3f ms, ns per MFMA and SIMD %.2f\n", per_barrier, ms,
+         ms * 1e6 / mfmas_per_simd);
+  hipFree(out); hipFree(ticks);
+}
+
 template <int KIND, int NACC>
 void run(const char *name, int wgs_per_cu, int cus) {
   const int grid = cus * wgs_per_cu, iters = 20000;
@@ -62,5 +102,7 @@ int main() {
   run<1, 2>("32x32x2 f32, 2 accumulators", 1, cus);
   run<1, 2>("32x32x2 f32, 2 accumulators", 2, cus);
   run<0, 3>("16x16x4 f32, 3 acc, 32 CUs", 1, 32);
+  run_stem_like(cus, 0);
+  run_stem_like(cus, 1);
   return 0;
 }
