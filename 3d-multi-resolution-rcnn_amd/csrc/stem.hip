@@ -160,13 +160,13 @@ __global__ __launch_bounds__(256, 3) void stem_fwd_wino_kernel(StemFwdArgs p, in
     load_g(0, g0);
     auto row = [&](int kh, const float (&g)[7][2]) {
       // B values: [group][f][step]
-      float u1[4][2], u2[4][2], u6[2];
+      float u1[4][2], u2[4][2], u6[2], u6n[2];
 #pragma unroll
       for (int s_ = 0; s_ < 2; ++s_) {
         const float a0 = g[0][s_], a1 = g[1][s_], a2 = g[2][s_], b0 = g[3][s_], b1 = g[4][s_], b2 = g[5][s_];
         u1[0][s_] = a0; u1[1][s_] = 0.5f * ((a0 + a2) + a1); u1[2][s_] = 0.5f * ((a0 + a2) - a1); u1[3][s_] = a2;
         u2[0][s_] = b0; u2[1][s_] = 0.5f * ((b0 + b2) + b1); u2[2][s_] = 0.5f * ((b0 + b2) - b1); u2[3][s_] = b2;
-        u6[s_] = g[6][s_];
+        u6[s_] = g[6][s_]; u6n[s_] = -g[6][s_];
       }
 #pragma unroll
       for (int t = 0; t < THW; ++t) {
@@ -174,22 +174,31 @@ __global__ __launch_bounds__(256, 3) void stem_fwd_wino_kernel(StemFwdArgs p, in
         float2 P[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) P[j] = *reinterpret_cast<const float2 *>(base + j * G::PH * SW_ROW);
+        // The ten transformed operand pairs of the row are formed FIRST, in one batch, and the 20 MFMAs follow behind a
+        // scheduling barrier: issued pairwise (v_sub -> v_mfma) every MFMA waited two `s_nop` wait states for its freshly written
+        // operand register (62 s_nop per 80 MFMAs), and vector ALU instructions do not hide under fp32 MFMAs on this chip anyway.
+        auto sub = [](float2 a, float2 b_) { return make_float2(a.x - b_.x, a.y - b_.y); };
+        auto add = [](float2 a, float2 b_) { return make_float2(a.x + b_.x, a.y + b_.y); };
+        float2 T[10];
+        T[0] = sub(P[0], P[2]); T[1] = add(P[1], P[2]); T[2] = sub(P[2], P[1]); T[3] = sub(P[1], P[3]);
+        T[4] = sub(P[3], P[5]); T[5] = add(P[4], P[5]); T[6] = sub(P[5], P[4]); T[7] = sub(P[4], P[6]);
+        T[8] = P[6]; T[9] = P[7];
+        __builtin_amdgcn_sched_barrier(0);
         auto mm = [&](f32x4 &c, float2 a, const float (&bb)[2]) {
           c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bb[0], c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bb[1], c, 0, 0, 0);
         };
-        auto sub = [](float2 a, float2 b_) { return make_float2(a.x - b_.x, a.y - b_.y); };
-        auto add = [](float2 a, float2 b_) { return make_float2(a.x + b_.x, a.y + b_.y); };
-        mm(acc[0][t], sub(P[0], P[2]), u1[0]);
-        mm(acc[1][t], add(P[1], P[2]), u1[1]);
-        mm(acc[2][t], sub(P[2], P[1]), u1[2]);
-        mm(acc[3][t], sub(P[1], P[3]), u1[3]);
-        mm(acc[0][t], sub(P[3], P[5]), u2[0]);
-        mm(acc[1][t], add(P[4], P[5]), u2[1]);
-        mm(acc[2][t], sub(P[5], P[4]), u2[2]);
-        mm(acc[3][t], sub(P[4], P[6]), u2[3]);
-        mm(acc[0][t], P[6], u6);
-        mm(acc[3][t], make_float2(-P[7].x, -P[7].y), u6);
+        mm(acc[0][t], T[0], u1[0]);
+        mm(acc[1][t], T[1], u1[1]);
+        mm(acc[2][t], T[2], u1[2]);
+        mm(acc[3][t], T[3], u1[3]);
+        mm(acc[0][t], T[4], u2[0]);
+        mm(acc[1][t], T[5], u2[1]);
+        mm(acc[2][t], T[6], u2[2]);
+        mm(acc[3][t], T[7], u2[3]);
+        mm(acc[0][t], T[8], u6);
+        mm(acc[3][t], T[9], u6n);                      // m3 -= P7 * g6: the sign sits on the weight
+        __builtin_amdgcn_sched_barrier(0);
       }
     };
     // kh rows two at a time, the next row's weights requested before the current row's MFMAs
