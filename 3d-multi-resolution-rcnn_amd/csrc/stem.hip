@@ -88,14 +88,28 @@ __device__ __forceinline__ void stem_stage_channel(float *slab, const float *__r
   constexpr int SW_ROW = G::SW_ROW;
   static_assert(SW_ROW % 4 == 0, "row stride in whole float4");
   if ((W & 3) == 0) {
+    // A thread owns one float4 column group (r, q) of EVERY plane: its row / column tests and its 32-bit offset inside a plane are
+    // formed once, a plane's pointer and its depth test are scalars, the LDS address is the thread's base plus an immediate -- no
+    // vector ALU work per element.  (One item per loop trip with div / mod chains, three bounds tests and a 64-bit multiply
+    // chain each was 0.9 vector instructions per MFMA of this kernel, and those do not hide under fp32 MFMAs.)
     constexpr int Q = SW_ROW / 4;
-    for (int e = tid; e < G::PD * G::PH * Q; e += NTHREADS) {
-      const int q = e % Q, r = (e / Q) % G::PH, pl = e / (Q * G::PH);
-      const int id = d0 - 3 + pl, ih = 2 * h0 - 3 + r, iw = 2 * w0 - 4 + 4 * q;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((unsigned)id < (unsigned)D && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
-        v = *reinterpret_cast<const float4 *>(xc + ((size_t)id * H + ih) * W + iw);
-      *reinterpret_cast<float4 *>(slab + (pl * G::PH + r) * SW_ROW + 4 * q) = v;
+    static_assert(G::PH * Q <= NTHREADS, "one plane per pass");
+    const int r = tid / Q, q = tid - r * Q;
+    const int ih = 2 * h0 - 3 + r, iw = 2 * w0 - 4 + 4 * q;
+    const bool mine = tid < G::PH * Q && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+    const unsigned voff = mine ? (unsigned)(ih * W + iw) : 0u;
+    const size_t plane = (size_t)H * W;
+    float4 v[G::PD];
+#pragma unroll
+    for (int pl = 0; pl < G::PD; ++pl) {
+      const int id = d0 - 3 + pl;                                   // (scalar)
+      v[pl] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((unsigned)id < (unsigned)D && mine) v[pl] = *reinterpret_cast<const float4 *>(xc + (size_t)id * plane + voff);
+    }
+    if (tid < G::PH * Q) {
+      float *dst = slab + r * SW_ROW + 4 * q;
+#pragma unroll
+      for (int pl = 0; pl < G::PD; ++pl) *reinterpret_cast<float4 *>(dst + pl * G::PH * SW_ROW) = v[pl];
     }
   } else {
     for (int e = tid; e < G::PD * G::PH * SW_ROW; e += NTHREADS) {
@@ -267,21 +281,46 @@ __device__ __forceinline__ void stem_wgrad_stage_channel(float *slab, const floa
                                                          int h0, int w0, int tid) {
   using G = StemWgGeo;
   constexpr int Q = 10;                                  // float4 per row: slab columns 0..39, column 39 is not stored
-  const bool vec = (W & 3) == 0;
+  if ((W & 3) == 0) {
+    // as in stem_stage_channel: a thread owns the column group (r, q) of every second plane (two planes per pass of the 512
+    // threads); per element there is one load with a scalar plane pointer and four LDS stores at immediate offsets
+    constexpr int PER = G::PH * Q;                       // 210 column groups per plane
+    static_assert(2 * PER <= kStemThreads && G::PD % 2 == 0, "two planes per pass");
+    const int half = tid >= PER ? 1 : 0, t = tid - half * PER;
+    const int r = t / Q, q = t - r * Q;
+    const int ih = 2 * h0 - 3 + r, iw = 2 * w0 - 4 + 4 * q;
+    const bool lane_ok = tid < 2 * PER;
+    const bool mine = lane_ok && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+    const unsigned voff = mine ? (unsigned)(ih * W + iw) : 0u;
+    const size_t plane = (size_t)H * W;
+    float4 v[G::PD / 2];
+#pragma unroll
+    for (int k = 0; k < G::PD / 2; ++k) {
+      const int id = d0 - 3 + 2 * k + half;
+      v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((unsigned)id < (unsigned)D && mine) v[k] = *reinterpret_cast<const float4 *>(xc + (size_t)id * plane + voff);
+    }
+    if (lane_ok) {
+      float *d = slab + half * G::PLANE + r * G::ROW + 4 * q;
+#pragma unroll
+      for (int k = 0; k < G::PD / 2; ++k) {
+        float *dd = d + 2 * k * G::PLANE;
+        dd[0] = v[k].x; dd[1] = v[k].y; dd[2] = v[k].z;
+        if (q < Q - 1) dd[3] = v[k].w;
+      }
+    }
+    return;
+  }
   for (int e = tid; e < G::PD * G::PH * Q; e += kStemThreads) {
     const int q = e % Q, r = (e / Q) % G::PH, pl = e / (Q * G::PH);
     const int id = d0 - 3 + pl, ih = 2 * h0 - 3 + r, iw = 2 * w0 - 4 + 4 * q;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if ((unsigned)id < (unsigned)D && (unsigned)ih < (unsigned)H) {
       const float *src = xc + ((size_t)id * H + ih) * W;
-      if (vec) {
-        if ((unsigned)iw < (unsigned)W) v = *reinterpret_cast<const float4 *>(src + iw);
-      } else {
-        if ((unsigned)iw < (unsigned)W) v.x = src[iw];
-        if ((unsigned)(iw + 1) < (unsigned)W) v.y = src[iw + 1];
-        if ((unsigned)(iw + 2) < (unsigned)W) v.z = src[iw + 2];
-        if ((unsigned)(iw + 3) < (unsigned)W) v.w = src[iw + 3];
-      }
+      if ((unsigned)iw < (unsigned)W) v.x = src[iw];
+      if ((unsigned)(iw + 1) < (unsigned)W) v.y = src[iw + 1];
+      if ((unsigned)(iw + 2) < (unsigned)W) v.z = src[iw + 2];
+      if ((unsigned)(iw + 3) < (unsigned)W) v.w = src[iw + 3];
     }
     float *d = slab + pl * G::PLANE + r * G::ROW + 4 * q;
     d[0] = v.x; d[1] = v.y; d[2] = v.z;
