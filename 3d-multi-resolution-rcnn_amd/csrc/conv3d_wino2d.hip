@@ -98,14 +98,15 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wino2d_kernel(Conv3dFwdArg
   const int n = b;
   const int od0 = td_i * TD, oh0 = th_i * TH, ow0 = tw_i * TW;
   const int id0 = od0 - p.pd, ih0 = oh0 - p.ph, iw0 = ow0 - p.pw;
-  // halo origin (may lie in front of x: only addresses inside the volume are dereferenced) and "no bounds tests needed" (scalars)
+  // halo origin (may lie in front of x: only addresses inside the volume are dereferenced)
   const float *xtile = p.x + ((((long long)n * p.D + id0) * p.H + ih0) * p.W + iw0) * p.Cin;
-  const bool halo_inside = id0 >= 0 && id0 + HD <= p.D && ih0 >= 0 && ih0 + HH <= p.H && iw0 >= 0 && iw0 + HW <= p.W;
   const int li = lane & 15, lk = lane >> 4;
   const int co = blockIdx.y * 64 + wave * 16 + li;
   // A operand: this lane's GEMM row li = (output plane li >> 3, patch li & 7) and its k index inside the k-step (lk)
   const float *vlane = vl + li * VPITCH + lk;
-  const float *ul = U + ((size_t)lk * (NF / 4) * p.Cout + co) * 4;
+  // U fragments: scalar 64-bit base of the (kd, k-step) + this lane's 32-bit offset (vector ALU instructions do not hide under
+  // fp32 MFMAs on this chip: no 64-bit address arithmetic per load)
+  const unsigned ul_off = (unsigned)((lk * (NF / 4) * p.Cout + co) * 4);
 
   f32x4 acc[NF];
 #pragma unroll
@@ -113,10 +114,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wino2d_kernel(Conv3dFwdArg
 
   float bq[3][NF], aq[2][NF / 2];
   auto load_b = [&](float (&dst)[NF], int c0, int kd, int kk) {
-    const float *src = ul + ((size_t)kd * p.Cin + c0 + kk * 4) * (NF / 4) * p.Cout * 4;
+    const float *src = U + ((size_t)kd * p.Cin + c0 + kk * 4) * (NF / 4) * p.Cout * 4;          // (scalar)
 #pragma unroll
     for (int f4 = 0; f4 < NF / 4; ++f4) {
-      const float4 v = *reinterpret_cast<const float4 *>(src + (size_t)f4 * p.Cout * 4);
+      const float4 v = *reinterpret_cast<const float4 *>(src + (size_t)f4 * p.Cout * 4 + ul_off);
       dst[f4 * 4] = v.x; dst[f4 * 4 + 1] = v.y; dst[f4 * 4 + 2] = v.z; dst[f4 * 4 + 3] = v.w;
     }
   };
@@ -127,33 +128,51 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wino2d_kernel(Conv3dFwdArg
     for (int f = 0; f < NF / 2; ++f) dst[f] = src[f * CC];
   };
   constexpr int Q = CC / 4;
-  constexpr int NIT = (HD * HH * HW * Q + kThreads - 1) / kThreads;
-  // halo staging, piece j of NIT (one float4 per thread): fetch into a register, commit to LDS.  The addresses are
-  // recomputed per use: hoisted out of the chunk loop they sit in 20 registers across the MFMA steps and the kernel spills (a
-  // kernel that touches scratch stalls the queue at its dispatch).
-  auto fetch = [&](int j, int c0) {
+  // Halo staging.  A thread owns ONE (column, channel quad) of the halo rows rg, rg + 6, rg + 12, ... (40 lanes per row of
+  // 10 columns x 4 quads, 6 row groups: 240 of the 256 threads, 7 pieces): the validity bits of its seven pieces are formed
+  // ONCE, in front of the chunk loop; a piece's offset is three 24-bit multiply-adds from scalars.  The piece-per-thread map this replaced recomputed three divisions, three bounds
+  // tests and a product chain per piece and chunk, twice (fetch and commit): 540 vector instructions, a fifth of them 16-cycle
+  // integer multiplies, per 288 MFMAs -- and vector ALU work does not hide under fp32 MFMAs on this chip.
+  constexpr int NIT = (HD * HH + 5) / 6;                 // 7
+  unsigned s_ok = 0;                                     // bit j: piece j of this thread lies inside the volume
+  {
+    const int lane40 = tid % (HW * Q), rg = tid / (HW * Q), hw = lane40 / Q;
+    const bool col_ok = rg < 6 && (unsigned)(iw0 + hw) < (unsigned)p.W;
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+      const int row = rg + 6 * j, hd = row / HH, hh = row - hd * HH;
+      const bool ok = col_ok && row < HD * HH && (unsigned)(id0 + hd) < (unsigned)p.D && (unsigned)(ih0 + hh) < (unsigned)p.H;
+      s_ok |= ok ? (1u << j) : 0u;
+    }
+  }
+  const int s_plane = p.H * p.W * p.Cin, s_rowp = p.W * p.Cin;               // (scalars; the halo spans < 2^24 elements)
+  // the thread's own coordinates are re-derived per chunk from an opaque copy of tid: kept across the MFMA steps they cost
+  // registers this kernel does not have (it spilled 64 bytes per lane with them hoisted)
+  struct Own { int rg, hw, q; };
+  auto own = [&]() {
     int tv = tid;
     asm volatile("" : "+v"(tv));
-    const int it = tv + j * kThreads;
-    const int pos = it / Q, q = it - pos * Q;
-    const int hw = pos % HW, hh = (pos / HW) % HH, hd = pos / (HW * HH);
-    // scalar 64-bit tile base + 32-bit lane offset (24-bit multiplies): the size_t chain per load was ~20 slow vector
-    // instructions, and this kernel's staging competes with its MFMAs for the SIMD's vector issue
-    const int rel = (int)__umul24(__umul24(__umul24(hd, p.H) + hh, p.W) + hw, p.Cin) + c0 + q * 4;
+    Own o;
+    o.rg = tv / (HW * Q);
+    const int lane40 = tv - o.rg * (HW * Q);
+    o.hw = lane40 / Q; o.q = lane40 - o.hw * Q;
+    return o;
+  };
+  auto fetch = [&](const Own &o, int j, int c0) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (it < HD * HH * HW * Q &&
-        (halo_inside || ((unsigned)(id0 + hd) < (unsigned)p.D && (unsigned)(ih0 + hh) < (unsigned)p.H && (unsigned)(iw0 + hw) < (unsigned)p.W)))
-      v = *reinterpret_cast<const float4 *>(xtile + rel);
+    if ((s_ok >> j) & 1u) {
+      const int row = o.rg + 6 * j;
+      const int hd = (row >= HH) + (row >= 2 * HH) + (row >= 3 * HH), hh = row - hd * HH;
+      const int rel = (int)__umul24(hd, s_plane) + (int)__umul24(hh, s_rowp) + (int)__umul24(o.hw, p.Cin) + o.q * 4;   // full-rate multiplies
+      v = *reinterpret_cast<const float4 *>(xtile + c0 + rel);
+    }
     return v;
   };
-  auto commit = [&](int j, const float4 &v) {
-    int tv = tid;
-    asm volatile("" : "+v"(tv));
-    const int it = tv + j * kThreads;
-    if (it < HD * HH * HW * Q) {
-      const int pos = it / Q, q = it - pos * Q;
-      const int hw = pos % HW, hh = (pos / HW) % HH, hd = pos / (HW * HH);
-      float *dd = lds + ((hd * HHP + hh) * HW + hw) * ROW + q * 4;
+  auto commit = [&](const Own &o, int j, const float4 &v) {
+    const int row = o.rg + 6 * j;                        // (hd * HHP + hh) = row + hd: one spare row per plane
+    if (o.rg < 6 && row < HD * HH) {
+      const int hd = (row >= HH) + (row >= 2 * HH) + (row >= 3 * HH);
+      float *dd = lds + ((row + hd) * HW + o.hw) * ROW + o.q * 4;
       dd[0] = v.x; dd[1] = v.y; dd[2] = v.z; dd[3] = v.w;
     }
   };
@@ -198,10 +217,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wino2d_kernel(Conv3dFwdArg
     __syncthreads();                                     // the previous chunk's steps are done with V (and its V phase with the halo)
     {
       float4 stage[NIT];
+      const Own o = own();
 #pragma unroll
-      for (int j = 0; j < NIT; ++j) stage[j] = fetch(j, c0);
+      for (int j = 0; j < NIT; ++j) stage[j] = fetch(o, j, c0);
 #pragma unroll
-      for (int j = 0; j < NIT; ++j) commit(j, stage[j]);
+      for (int j = 0; j < NIT; ++j) commit(o, j, stage[j]);
     }
     __syncthreads();
     // ---- V = Bh^T d Bw of every (plane, patch, channel) of the chunk: 4 * 8 * 16 = 512 items, two per thread.  V is written
@@ -247,9 +267,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wino2d_kernel(Conv3dFwdArg
 
   // ---- epilogue: Y = Ah^T M Aw per accumulator element, then shift / adds / upsample add / ReLU / mask; NDHWC store
   const float sh = p.shift ? p.shift[co] : 0.f;
-  auto emit = [&](int od, int oh, int ow, float val) {
+  auto emit = [&](size_t idx, int od, int oh, int ow, float val) {
     if (od < p.Do && oh < p.Ho && ow < p.Wo) {
-      const size_t idx = ((((size_t)n * p.yD + od * p.ysd) * p.yH + oh * p.ysh) * p.yW + ow * p.ysw) * p.Cout + co;
       float v = val + sh;
       if (p.add1) v += p.add1[idx];
       if (p.add2) v += p.add2[idx];
@@ -266,6 +285,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wino2d_kernel(Conv3dFwdArg
       p.y[idx] = v;
     }
   };
+  const size_t xstep = (size_t)p.ysw * p.Cout, rowstep = (size_t)p.ysh * p.yW * p.Cout;      // (scalars)
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = lk * 4 + r;
@@ -278,10 +298,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wino2d_kernel(Conv3dFwdArg
       const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
       z[fh][0] = (m0 + s12) + s34; z[fh][1] = d12 + 2.f * d34; z[fh][2] = s12 + 4.f * s34; z[fh][3] = (d12 + 8.f * d34) + m5;
     }
+    // one 64-bit output index per accumulator row; its eight outputs are scalar steps away
+    const size_t idx0 = ((((size_t)n * p.yD + od * p.ysd) * p.yH + oh * p.ysh) * p.yW + ow * p.ysw) * p.Cout + co;
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
-      emit(od, oh, ow + x, (z[0][x] + z[1][x]) + z[2][x]);
-      emit(od, oh + 1, ow + x, (z[1][x] - z[2][x]) - z[3][x]);
+      emit(idx0 + x * xstep, od, oh, ow + x, (z[0][x] + z[1][x]) + z[2][x]);
+      emit(idx0 + x * xstep + rowstep, od, oh + 1, ow + x, (z[1][x] - z[2][x]) - z[3][x]);
     }
   }
 }
