@@ -267,11 +267,17 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wino2d_kernel(Conv3dFwdArg
 
   // ---- epilogue: Y = Ah^T M Aw per accumulator element, then shift / adds / upsample add / ReLU / mask; NDHWC store
   const float sh = p.shift ? p.shift[co] : 0.f;
-  auto emit = [&](size_t idx, int od, int oh, int ow, float val) {
+  // Output addressing: a SCALAR 64-bit index of the tile's first output + 32-bit lane offsets (one per accumulator row, the row's
+  // eight outputs are scalar steps away).  (One size_t product chain per output was ~1,600 vector instructions per tile, 300 of them 16-cycle multiplies.)
+  const size_t ybase = ((((size_t)n * p.yD + (size_t)od0 * p.ysd) * p.yH + (size_t)oh0 * p.ysh) * p.yW + (size_t)ow0 * p.ysw) * p.Cout;
+  const float *add1b = p.add1 ? p.add1 + ybase : nullptr, *add2b = p.add2 ? p.add2 + ybase : nullptr, *maskb = p.mask ? p.mask + ybase : nullptr;
+  float *yb = p.y + ybase;
+  const int xstep = p.ysw * p.Cout * 4, rowstep = p.ysh * p.yW * p.Cout * 4, planestep = p.ysd * p.yH * p.yW * p.Cout * 4;   // bytes
+  auto emit = [&](unsigned rel, int od, int oh, int ow, float val) {
     if (od < p.Do && oh < p.Ho && ow < p.Wo) {
       float v = val + sh;
-      if (p.add1) v += p.add1[idx];
-      if (p.add2) v += p.add2[idx];
+      if (add1b) v += *reinterpret_cast<const float *>(reinterpret_cast<const char *>(add1b) + rel);
+      if (add2b) v += *reinterpret_cast<const float *>(reinterpret_cast<const char *>(add2b) + rel);
       if (p.up) {
         auto nearest = [](int dst, int in, int out) {          // torch nearest: min(floor(dst * (in/out)), in-1)
           const int s_ = (int)floorf((float)dst * ((float)in / (float)out));
@@ -281,15 +287,15 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wino2d_kernel(Conv3dFwdArg
         v += p.up[((((size_t)n * p.Du + ud) * p.Hu + uh) * p.Wu + uw) * p.Cout + co];
       }
       if (p.relu) v = fmaxf(v, 0.f);
-      if (p.mask) v = p.mask[idx] > 0.f ? v : 0.f;
-      p.y[idx] = v;
+      if (maskb) v = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(maskb) + rel) > 0.f ? v : 0.f;
+      *reinterpret_cast<float *>(reinterpret_cast<char *>(yb) + rel) = v;
     }
   };
-  const size_t xstep = (size_t)p.ysw * p.Cout, rowstep = (size_t)p.ysh * p.yW * p.Cout;      // (scalars)
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = lk * 4 + r;
-    const int od = od0 + (row >> 3), oh = oh0 + ((row >> 1) & 3) * 2, ow = ow0 + (row & 1) * 4;
+    const int dz = row >> 3, dh = ((row >> 1) & 3) * 2, dw = (row & 1) * 4;
+    const int od = od0 + dz, oh = oh0 + dh, ow = ow0 + dw;
     float z[4][4];                                       // along W: z[fh][x]
 #pragma unroll
     for (int fh = 0; fh < 4; ++fh) {
@@ -298,12 +304,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wino2d_kernel(Conv3dFwdArg
       const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
       z[fh][0] = (m0 + s12) + s34; z[fh][1] = d12 + 2.f * d34; z[fh][2] = s12 + 4.f * s34; z[fh][3] = (d12 + 8.f * d34) + m5;
     }
-    // one 64-bit output index per accumulator row; its eight outputs are scalar steps away
-    const size_t idx0 = ((((size_t)n * p.yD + od * p.ysd) * p.yH + oh * p.ysh) * p.yW + ow * p.ysw) * p.Cout + co;
+    const unsigned rel0 = (unsigned)(dz * planestep + dh * rowstep + dw * xstep + co * 4);        // byte offset inside the tile
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
-      emit(idx0 + x * xstep, od, oh, ow + x, (z[0][x] + z[1][x]) + z[2][x]);
-      emit(idx0 + x * xstep + rowstep, od, oh + 1, ow + x, (z[1][x] - z[2][x]) - z[3][x]);
+      emit(rel0 + x * xstep, od, oh, ow + x, (z[0][x] + z[1][x]) + z[2][x]);
+      emit(rel0 + x * xstep + rowstep, od, oh + 1, ow + x, (z[1][x] - z[2][x]) - z[3][x]);
     }
   }
 }
@@ -448,12 +453,17 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wino2d_rows_kernel(Conv3dF
 
   // ---- epilogue: Y = Ah^T M Aw per accumulator element, then shift / adds / upsample add / ReLU / mask; NDHWC store
   const float sh = p.shift ? p.shift[co] : 0.f;
-  auto emit = [&](int od, int oh, int ow, float val) {
+  // Output addressing: a SCALAR 64-bit index of the tile's first output + 32-bit lane offsets (one per accumulator row, the row's
+  // eight outputs are scalar steps away).  (One size_t product chain per output was ~1,600 vector instructions per tile, 300 of them 16-cycle multiplies.)
+  const size_t ybase = ((((size_t)n * p.yD + (size_t)od0 * p.ysd) * p.yH + (size_t)oh0 * p.ysh) * p.yW + (size_t)ow0 * p.ysw) * p.Cout;
+  const float *add1b = p.add1 ? p.add1 + ybase : nullptr, *add2b = p.add2 ? p.add2 + ybase : nullptr, *maskb = p.mask ? p.mask + ybase : nullptr;
+  float *yb = p.y + ybase;
+  const int xstep = p.ysw * p.Cout * 4, rowstep = p.ysh * p.yW * p.Cout * 4, planestep = p.ysd * p.yH * p.yW * p.Cout * 4;   // bytes
+  auto emit = [&](unsigned rel, int od, int oh, int ow, float val) {
     if (od < p.Do && oh < p.Ho && ow < p.Wo) {
-      const size_t idx = ((((size_t)n * p.yD + od * p.ysd) * p.yH + oh * p.ysh) * p.yW + ow * p.ysw) * p.Cout + co;
       float v = val + sh;
-      if (p.add1) v += p.add1[idx];
-      if (p.add2) v += p.add2[idx];
+      if (add1b) v += *reinterpret_cast<const float *>(reinterpret_cast<const char *>(add1b) + rel);
+      if (add2b) v += *reinterpret_cast<const float *>(reinterpret_cast<const char *>(add2b) + rel);
       if (p.up) {
         auto nearest = [](int dst, int in, int out) {          // torch nearest: min(floor(dst * (in/out)), in-1)
           const int s_ = (int)floorf((float)dst * ((float)in / (float)out));
@@ -463,8 +473,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wino2d_rows_kernel(Conv3dF
         v += p.up[((((size_t)n * p.Du + ud) * p.Hu + uh) * p.Wu + uw) * p.Cout + co];
       }
       if (p.relu) v = fmaxf(v, 0.f);
-      if (p.mask) v = p.mask[idx] > 0.f ? v : 0.f;
-      p.y[idx] = v;
+      if (maskb) v = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(maskb) + rel) > 0.f ? v : 0.f;
+      *reinterpret_cast<float *>(reinterpret_cast<char *>(yb) + rel) = v;
     }
   };
 #pragma unroll
@@ -472,7 +482,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wino2d_rows_kernel(Conv3dF
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = lk * 4 + r;
-    const int od = od0 + 2 * wave_m + (row >> 3), oh = oh0 + ((row >> 1) & 3) * 2, ow = ow0 + (row & 1) * 4;
+    const int dz = 2 * wave_m + (row >> 3), dh = ((row >> 1) & 3) * 2, dw = (row & 1) * 4;
+    const int od = od0 + dz, oh = oh0 + dh, ow = ow0 + dw;
     float z[4][4];                                       // along W: z[fh][x]
 #pragma unroll
     for (int fh = 0; fh < 4; ++fh) {
@@ -481,10 +492,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wino2d_rows_kernel(Conv3dF
       const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
       z[fh][0] = (m0 + s12) + s34; z[fh][1] = d12 + 2.f * d34; z[fh][2] = s12 + 4.f * s34; z[fh][3] = (d12 + 8.f * d34) + m5;
     }
+    const unsigned rel0 = (unsigned)(dz * planestep + dh * rowstep + dw * xstep + co * 4);        // byte offset inside the tile
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
-      emit(od, oh, ow + x, (z[0][x] + z[1][x]) + z[2][x]);
-      emit(od, oh + 1, ow + x, (z[1][x] - z[2][x]) - z[3][x]);
+      emit(rel0 + x * xstep, od, oh, ow + x, (z[0][x] + z[1][x]) + z[2][x]);
+      emit(rel0 + x * xstep + rowstep, od, oh + 1, ow + x, (z[1][x] - z[2][x]) - z[3][x]);
     }
   }
 }
