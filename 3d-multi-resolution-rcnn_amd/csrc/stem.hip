@@ -156,18 +156,24 @@ __global__ __launch_bounds__(256, 3) void stem_fwd_wino_kernel(StemFwdArgs p, in
     for (int t = 0; t < THW; ++t) acc[f][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int lane_off = 2 * li + 2 * lk;
   const size_t vox = (size_t)p.D * p.H * p.W;
+  // weight taps of this lane: kw = 2 lk - 1 (none for lk = 0: the product is masked) and kw = 2 lk
+  const unsigned goff0 = (unsigned)(((lk > 0 ? 2 * lk - 1 : 0) * 64 + li) * 4), goff1 = (unsigned)((2 * lk * 64 + li) * 4);
+  const float gmask0 = lk > 0 ? 1.f : 0.f;
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.wf), 0, 343 * 4 * 16 * 4, 0x00020000);
 
   for (int ci = 0; ci < 3; ++ci) {
     __syncthreads();
     stem_stage_channel<256, G>(slab, p.x + ((size_t)n * 3 + ci) * vox, p.D, p.H, p.W, d0, h0, w0, tid);
     __syncthreads();
     // raw weights of one kh row: g[kd][step]; step s of MFMA k index lk is tap kw = 2*lk + s - 1 (kw = -1: weight 0)
+    // buffer loads: the (kd, kh, ci) row is a SCALAR byte offset, the lane's two taps are constant vector offsets -- no vector
+    // address arithmetic per load (flat loads rebuilt a 64-bit pointer per kd: ~4 vector instructions per tap pair)
     auto load_g = [&](int kh, float (&g)[7][2]) {
 #pragma unroll
       for (int kd = 0; kd < 7; ++kd) {
-        const float *wrow = p.wf + (size_t)((kd * 7 + kh) * 7) * 64 + ci * 16 + li;
-        g[kd][0] = (lk > 0) ? wrow[(2 * lk - 1) * 64] : 0.f;
-        g[kd][1] = wrow[(2 * lk) * 64];
+        const int srow = (((kd * 7 + kh) * 7) * 64 + ci * 16) * 4;
+        g[kd][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrsrc, goff0, srow, 0)) * gmask0;
+        g[kd][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrsrc, goff1, srow, 0));
       }
     };
     float g0[7][2], g1[7][2];
