@@ -35,6 +35,18 @@
 namespace {
 
 constexpr int kThreads = 256;
+
+// 16 bytes through a raw buffer descriptor: address = descriptor base + vector byte offset + SCALAR byte offset.  What differs
+// between the loads of a loop is folded into the scalar operand, so a load costs no vector ALU instruction (flat loads rebuild a
+// 64-bit pointer per load, and vector ALU work does not hide under fp32 MFMAs on this chip).
+typedef float buf_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_of(const float *base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ float4 buffer_load4(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
+  const buf_f32x4 v = __builtin_bit_cast(buf_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff_bytes, (int)soff_bytes, 0));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
 constexpr int TD = 2, TH = 8, TW = 8;                  // output tile: 16 GEMM rows (patches of 2 x 4 outputs)
 constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;   // halo
 constexpr int HHP = HH + 1;                            // one spare row per halo plane: 2-way instead of 3-way LDS bank conflicts in the V phase
@@ -106,7 +118,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wino2d_kernel(Conv3dFwdArg
   const float *vlane = vl + li * VPITCH + lk;
   // U fragments: scalar 64-bit base of the (kd, k-step) + this lane's 32-bit offset (vector ALU instructions do not hide under
   // fp32 MFMAs on this chip: no 64-bit address arithmetic per load)
-  const unsigned ul_off = (unsigned)((lk * (NF / 4) * p.Cout + co) * 4);
+  const unsigned ul_off = (unsigned)((lk * (NF / 4) * p.Cout + co) * 4 * 4);             // bytes
+  const __amdgpu_buffer_rsrc_t ursrc = buffer_of(U), xrsrc = buffer_of(xtile);
 
   f32x4 acc[NF];
 #pragma unroll
@@ -114,10 +127,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wino2d_kernel(Conv3dFwdArg
 
   float bq[3][NF], aq[2][NF / 2];
   auto load_b = [&](float (&dst)[NF], int c0, int kd, int kk) {
-    const float *src = U + ((size_t)kd * p.Cin + c0 + kk * 4) * (NF / 4) * p.Cout * 4;          // (scalar)
+    const unsigned src = (unsigned)(((kd * p.Cin + c0 + kk * 4) * (NF / 4) * p.Cout * 4) * 4);      // (scalar byte offset: U is < 2 GiB)
 #pragma unroll
     for (int f4 = 0; f4 < NF / 4; ++f4) {
-      const float4 v = *reinterpret_cast<const float4 *>(src + (size_t)f4 * p.Cout * 4 + ul_off);
+      const float4 v = buffer_load4(ursrc, ul_off, src + (unsigned)(f4 * p.Cout * 4 * 4));
       dst[f4 * 4] = v.x; dst[f4 * 4 + 1] = v.y; dst[f4 * 4 + 2] = v.z; dst[f4 * 4 + 3] = v.w;
     }
   };
@@ -164,7 +177,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wino2d_kernel(Conv3dFwdArg
       const int row = o.rg + 6 * j;
       const int hd = (row >= HH) + (row >= 2 * HH) + (row >= 3 * HH), hh = row - hd * HH;
       const int rel = (int)__umul24(hd, s_plane) + (int)__umul24(hh, s_rowp) + (int)__umul24(o.hw, p.Cin) + o.q * 4;   // full-rate multiplies
-      v = *reinterpret_cast<const float4 *>(xtile + c0 + rel);
+      v = buffer_load4(xrsrc, (unsigned)rel * 4u, (unsigned)c0 * 4u);
     }
     return v;
   };
@@ -339,7 +352,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wino2d_rows_kernel(Conv3dF
   // A operand: this lane's GEMM row (li) = patch (td, th2, tw4) and its k index inside the k-step (lk)
   constexpr int PL = rows_plane(HHr);
   const int abase = (2 * wave_m + (li >> 3)) * PL + (((li >> 1) & 3) * 2 * HWR + (li & 1) * 4) * ROW + lk;
-  const float *ul = U + ((size_t)lk * (NF / 4) * p.Cout + co) * 4;
+  const unsigned ul_off = (unsigned)((lk * (NF / 4) * p.Cout + co) * 4 * 4);             // bytes
+  const __amdgpu_buffer_rsrc_t ursrc = buffer_of(U), xrsrc = buffer_of(xtile);
 
   constexpr int MT = 1;
   f32x4 acc[MT][NF];
@@ -348,10 +362,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wino2d_rows_kernel(Conv3dF
 
   float b0[NF], b1[NF], a0[MT][NF], a1[MT][NF], d[MT][4][6];
   auto load_b = [&](float (&dst)[NF], int c0, int kd, int kk) {
-    const float *src = ul + ((size_t)kd * p.Cin + c0 + kk * 4) * (NF / 4) * p.Cout * 4;
+    const unsigned src = (unsigned)(((kd * p.Cin + c0 + kk * 4) * (NF / 4) * p.Cout * 4) * 4);      // (scalar byte offset)
 #pragma unroll
     for (int f4 = 0; f4 < NF / 4; ++f4) {
-      const float4 v = *reinterpret_cast<const float4 *>(src + (size_t)f4 * p.Cout * 4);
+      const float4 v = buffer_load4(ursrc, ul_off, src + (unsigned)(f4 * p.Cout * 4 * 4));
       dst[f4 * 4] = v.x; dst[f4 * 4 + 1] = v.y; dst[f4 * 4 + 2] = v.z; dst[f4 * 4 + 3] = v.w;
     }
   };
@@ -418,11 +432,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wino2d_rows_kernel(Conv3dF
           const int it = tv + (j0 + jj) * kThreads;
           const int pos = it / Q, q = it - pos * Q;
           const int hw = pos % HW, hh = (pos / HW) % HH, hd = pos / (HW * HH);
-          const int rel = (int)__umul24(__umul24(__umul24(hd, p.H) + hh, p.W) + hw, p.Cin) + c0 + q * 4;
+          const int rel = (int)__umul24(__umul24(__umul24(hd, p.H) + hh, p.W) + hw, p.Cin) + q * 4;
           float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
           if (it < HDr * HH * HW * Q &&
               (halo_inside || ((unsigned)(id0 + hd) < (unsigned)p.D && (unsigned)(ih0 + hh) < (unsigned)p.H && (unsigned)(iw0 + hw) < (unsigned)p.W)))
-            v = *reinterpret_cast<const float4 *>(xtile + rel);
+            v = buffer_load4(xrsrc, (unsigned)rel * 4u, (unsigned)c0 * 4u);
           stage[jj] = v;
         }
 #pragma unroll
