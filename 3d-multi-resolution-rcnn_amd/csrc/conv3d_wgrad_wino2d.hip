@@ -81,13 +81,14 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wgrad_wino2d_kernel(Conv3d
     const int id0 = od0 + kd - p.pd, ih0 = oh0 - p.ph, iw0 = ow0 - p.pw;
     if (do_x) {
       const float *xb = p.x + ((((long long)n * p.D + id0) * p.H + ih0) * p.W + iw0) * p.Cin + c0;      // may point in front of x: masked
+      const __amdgpu_buffer_rsrc_t xr = buffer_of(xb);   // (scalar descriptor: the loads below carry no vector address arithmetic)
       const bool inside = id0 >= 0 && id0 + TD <= p.D && ih0 >= 0 && ih0 + HH <= p.H && iw0 >= 0 && iw0 + HW <= p.W;   // (scalar)
       if (inside) {
 #pragma unroll
         for (int j = 0; j < NX; ++j) {
           xs[j] = make_float4(0.f, 0.f, 0.f, 0.f);
           if ((j + 1) * kThreads <= TD * HH * HW * (CC / 4) || tid + j * kThreads < TD * HH * HW * (CC / 4))
-            xs[j] = *reinterpret_cast<const float4 *>(xb + xrel[j]);
+            xs[j] = buffer_load4(xr, (unsigned)xrel[j] * 4u, 0u);
         }
       } else {
 #pragma unroll
@@ -97,21 +98,21 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wgrad_wino2d_kernel(Conv3d
           float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
           if (it < TD * HH * HW * (CC / 4) && (unsigned)(id0 + hd) < (unsigned)p.D && (unsigned)(ih0 + hh) < (unsigned)p.H &&
               (unsigned)(iw0 + hw) < (unsigned)p.W)
-            v = *reinterpret_cast<const float4 *>(xb + xrel[j]);
+            v = buffer_load4(xr, (unsigned)xrel[j] * 4u, 0u);
           xs[j] = v;
         }
       }
     }
     if (do_y) {
       const float *yb = p.dy + ((((long long)n * p.Do + od0) * p.Ho + oh0) * p.Wo + ow0) * p.Cout + n0;
+      const __amdgpu_buffer_rsrc_t yr = buffer_of(yb);
       const bool inside = od0 + TD <= p.Do && oh0 + TH <= p.Ho && ow0 + TW <= p.Wo;
       const int row2 = 2 * p.Wo * p.Cout, plane = p.Ho * p.Wo * p.Cout;                 // pieces: oh += 2 per j, od = j >> 2
 #pragma unroll
       for (int j = 0; j < NY; ++j) {
-        const int rel = yrel0 + (j & 3) * row2 + (j >> 2) * plane;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (inside || (od0 + (j >> 2) < p.Do && oh0 + (tid >> 7) + 2 * (j & 3) < p.Ho && ow0 + ((tid >> 4) & 7) < p.Wo))
-          v = *reinterpret_cast<const float4 *>(yb + rel);
+          v = buffer_load4(yr, (unsigned)yrel0 * 4u, (unsigned)(((j & 3) * row2 + (j >> 2) * plane) * 4));      // the piece is a scalar offset
         ys[j] = v;
       }
     }

@@ -36,17 +36,6 @@ namespace {
 
 constexpr int kThreads = 256;
 
-// 16 bytes through a raw buffer descriptor: address = descriptor base + vector byte offset + SCALAR byte offset.  What differs
-// between the loads of a loop is folded into the scalar operand, so a load costs no vector ALU instruction (flat loads rebuild a
-// 64-bit pointer per load, and vector ALU work does not hide under fp32 MFMAs on this chip).
-typedef float buf_f32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_of(const float *base) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, 0x7fffffff, 0x00020000);
-}
-__device__ __forceinline__ float4 buffer_load4(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
-  const buf_f32x4 v = __builtin_bit_cast(buf_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff_bytes, (int)soff_bytes, 0));
-  return make_float4(v.x, v.y, v.z, v.w);
-}
 constexpr int TD = 2, TH = 8, TW = 8;                  // output tile: 16 GEMM rows (patches of 2 x 4 outputs)
 constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;   // halo
 constexpr int HHP = HH + 1;                            // one spare row per halo plane: 2-way instead of 3-way LDS bank conflicts in the V phase

@@ -98,13 +98,14 @@ __device__ __forceinline__ void stem_stage_channel(float *slab, const float *__r
     const int ih = 2 * h0 - 3 + r, iw = 2 * w0 - 4 + 4 * q;
     const bool mine = tid < G::PH * Q && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
     const unsigned voff = mine ? (unsigned)(ih * W + iw) : 0u;
-    const size_t plane = (size_t)H * W;
+    const int plane = H * W;                             // a channel volume is < 2^29 elements (checked by the launcher)
+    const __amdgpu_buffer_rsrc_t xr = buffer_of(xc);
     float4 v[G::PD];
 #pragma unroll
     for (int pl = 0; pl < G::PD; ++pl) {
       const int id = d0 - 3 + pl;                                   // (scalar)
       v[pl] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((unsigned)id < (unsigned)D && mine) v[pl] = *reinterpret_cast<const float4 *>(xc + (size_t)id * plane + voff);
+      if ((unsigned)id < (unsigned)D && mine) v[pl] = buffer_load4(xr, voff * 4u, (unsigned)(id * plane) * 4u);       // scalar plane offset
     }
     if (tid < G::PH * Q) {
       float *dst = slab + r * SW_ROW + 4 * q;
@@ -298,13 +299,14 @@ __device__ __forceinline__ void stem_wgrad_stage_channel(float *slab, const floa
     const bool lane_ok = tid < 2 * PER;
     const bool mine = lane_ok && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
     const unsigned voff = mine ? (unsigned)(ih * W + iw) : 0u;
-    const size_t plane = (size_t)H * W;
+    const int plane = H * W;
+    const __amdgpu_buffer_rsrc_t xr = buffer_of(xc);
     float4 v[G::PD / 2];
 #pragma unroll
     for (int k = 0; k < G::PD / 2; ++k) {
       const int id = d0 - 3 + 2 * k + half;
       v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((unsigned)id < (unsigned)D && mine) v[k] = *reinterpret_cast<const float4 *>(xc + (size_t)id * plane + voff);
+      if ((unsigned)id < (unsigned)D && mine) v[k] = buffer_load4(xr, (voff + (unsigned)(id * plane)) * 4u, 0u);
     }
     if (lane_ok) {
       float *d = slab + half * G::PLANE + r * G::ROW + 4 * q;
@@ -539,6 +541,7 @@ __global__ __launch_bounds__(kStemThreads) void stem_wgrad_kernel(StemWgradArgs 
 static int stem_forward_impl(const float *x_ncdhw, const float *w_packed, const float *shift, float *y, int y_bf16, int n, int d,
                              int h, int w, int relu, mr3d_stream_t stream_) {
   if (!x_ncdhw || !w_packed || !y || n <= 0 || d <= 0 || h <= 0 || w <= 0) return MR3D_ERR_INVALID_ARG;
+  if ((long long)d * h * w >= (1LL << 29)) return MR3D_ERR_UNSUPPORTED;       // 32-bit byte offsets inside a channel volume
   StemFwdArgs a;
   a.x = x_ncdhw; a.wf = w_packed; a.shift = shift; a.y = y; a.y_bf16 = y_bf16;
   a.N = n; a.D = d; a.H = h; a.W = w;
@@ -597,6 +600,7 @@ static int stem_wgrad_impl(const float *x_ncdhw, const float *dy, int dy_bf16, f
                            int w, float *workspace, long long workspace_bytes, mr3d_stream_t stream_, const uint32_t *pool_idx,
                            const float *pooled) {
   if (!x_ncdhw || !dy || !dw_packed || n <= 0 || d <= 0 || h <= 0 || w <= 0) return MR3D_ERR_INVALID_ARG;
+  if ((long long)d * h * w >= (1LL << 29)) return MR3D_ERR_UNSUPPORTED;       // 32-bit byte offsets inside a channel volume
   StemWgradArgs a;
   a.x = x_ncdhw; a.dy = dy; a.dw = dw_packed; a.dbias = dbias; a.dy_bf16 = dy_bf16;
   a.N = n; a.D = d; a.H = h; a.W = w;
