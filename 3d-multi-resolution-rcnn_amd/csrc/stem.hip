@@ -398,7 +398,7 @@ __global__ __launch_bounds__(kStemThreads) void stem_wgrad_kernel(StemWgradArgs 
   unsigned ticket = 0;
   if (tid == 0) s_tile = take(atomicAdd(queue + home, 1u));
   __syncthreads();
-  int tile = s_tile;
+  int tile = __builtin_amdgcn_readfirstlane(s_tile);      // wave-uniform: the tile arithmetic below stays on the scalar unit
   while (tile >= 0) {
     const StemTile st = stem_tile_of(tile, tiles_d, tiles_h, tiles_w);
     const int n = st.n;
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(kStemThreads) void stem_wgrad_kernel(StemWgradArgs 
     }
     if (tid == 0) s_tile = take(ticket);
     __syncthreads();                       // also: every wave is done with this tile's dy rows and slab
-    tile = s_tile;
+    tile = __builtin_amdgcn_readfirstlane(s_tile);
   }
   if (tid == 0) {                          // the last workgroup to run dry re-arms the queues for the next launch
     const unsigned done = atomicAdd(queue + 8, 1u);

@@ -437,7 +437,7 @@ __global__ __launch_bounds__(512, 1) void stem_wgrad_bf16_kernel(StemBfWgArgs p,
   unsigned ticket = 0;
   if (tid == 0) s_tile = take(atomicAdd(queue + home, 1u));
   __syncthreads();
-  int tile = s_tile;
+  int tile = __builtin_amdgcn_readfirstlane(s_tile);      // wave-uniform: the tile arithmetic below stays on the scalar unit
   fetch(tile >= 0 ? tile : ntiles);
   if (tid == 0) ticket = atomicAdd(queue + home, 1u);
   while (tile >= 0) {
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(512, 1) void stem_wgrad_bf16_kernel(StemBfWgArgs p,
       round_rows(1);
       __syncthreads();
     }
-    const int next = s_tile;
+    const int next = __builtin_amdgcn_readfirstlane(s_tile);
     if (tid == 0 && next >= 0) ticket = atomicAdd(queue + home, 1u);
     fetch(next >= 0 ? next : ntiles);                    // in flight during the MFMA phase
     // the ten row-tile fragments and the dy fragment of a k-step are requested together, before its first MFMA
