@@ -195,16 +195,19 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wgrad_wino2d_kernel(Conv3d
 #pragma unroll
         for (int j = 0; j < 4; ++j) g[i][j] = gsrc[(i * TW + j) * DYP];
       if (want_bias) bias_sum += ((g[0][0] + g[0][1]) + (g[0][2] + g[0][3])) + ((g[1][0] + g[1][1]) + (g[1][2] + g[1][3]));
-      float r[2][6];                                     // along W: Gw g (rows)
+      // along W: Gw g WITHOUT its constants -- the column factors c_f = (1/4, -1/6, -1/6, 1/24, 1/24, 1) and the 1/2 of the two middle
+      // rows of Gh are applied once, to the 24 accumulators, in front of the inverse transform (22 of the 52 vector instructions of
+      // this transform per k-step were those multiplies, and they do not hide under the MFMAs)
+      float r[2][6];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const float g0 = g[i][0], g1 = g[i][1], g2 = g[i][2], g3 = g[i][3];
         const float s02 = g0 + g2, s13 = g1 + g3, a = g0 + 4.f * g2, bq = 2.f * g1 + 8.f * g3;
-        r[i][0] = 0.25f * g0;
-        r[i][1] = (s02 + s13) * (-1.f / 6.f);
-        r[i][2] = (s02 - s13) * (-1.f / 6.f);
-        r[i][3] = (a + bq) * (1.f / 24.f);
-        r[i][4] = (a - bq) * (1.f / 24.f);
+        r[i][0] = g0;
+        r[i][1] = s02 + s13;
+        r[i][2] = s02 - s13;
+        r[i][3] = a + bq;
+        r[i][4] = a - bq;
         r[i][5] = g3;
       }
       float ac[2][4];
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wgrad_wino2d_kernel(Conv3d
 #pragma unroll
           for (int fh = 0; fh < 4; ++fh) ac[(fw + 1) & 1][fh] = va[(fh * 6 + fw + 1) * CC];
         }
-        const float e0 = r[0][fw], e3 = r[1][fw], e1 = 0.5f * (e0 + e3), e2 = 0.5f * (e0 - e3);
+        const float e0 = r[0][fw], e3 = r[1][fw], e1 = e0 + e3, e2 = e0 - e3;
         acc[0 * 6 + fw] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[fw & 1][0], e0, acc[0 * 6 + fw], 0, 0, 0);
         acc[1 * 6 + fw] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[fw & 1][1], e1, acc[1 * 6 + fw], 0, 0, 0);
         acc[2 * 6 + fw] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[fw & 1][2], e2, acc[2 * 6 + fw], 0, 0, 0);
@@ -225,6 +228,18 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wgrad_wino2d_kernel(Conv3d
     }
   }
 
+  // ---- the constants of G that the k-steps left out
+  {
+    const float cw[6] = {0.25f, -1.f / 6.f, -1.f / 6.f, 1.f / 24.f, 1.f / 24.f, 1.f};
+#pragma unroll
+    for (int fh = 0; fh < 4; ++fh)
+#pragma unroll
+      for (int fw = 0; fw < 6; ++fw) {
+        const float c = cw[fw] * ((fh == 1 || fh == 2) ? 0.5f : 1.f);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[fh * 6 + fw][r] *= c;
+      }
+  }
   // ---- dw[kd][kh][kw][ci][co] += Ah^T M Aw: accumulator element r of lane (li, lk) is (ci = 4 lk + r, co = li)
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
