@@ -124,6 +124,12 @@ namespace {
 // Join: before FINISH_GRADS and at the end of every call.
 struct SideStream {
   hipStream_t stream = nullptr;
+  // second side queue: CONV_WGRAD records alternate between the two (they only read finished tensors and add into their own
+  // scratch slices), every other side record stays on `stream`.  One in-order queue ran the many small weight gradients of the
+  // large maps one at a time -- 25-85 us kernels that fill a fraction of the chip -- and fell behind the main chain once that got
+  // faster: 0.5 ms of them ran alone, with 6 us launch gaps, after the stem weight gradient (profiles/r03).
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev12 = nullptr, ev21 = nullptr;
   hipEvent_t join_ev = nullptr;
   hipEvent_t fork[16] = {};
   hipEvent_t mark[4] = {};          // MR3D_OP_SYNC slots: a point of the side queue the caller's stream can wait for
@@ -140,7 +146,10 @@ struct SideStream {
     // (Round 3, headline step: high 11.10 ms, normal 11.23, low 11.24 -- the weight gradients finishing early matters more
     // than the main chain's kernels keeping every CU.)
     if (hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, hi) != hipSuccess) return false;
+    if (hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, hi) != hipSuccess) return false;
     if (hipEventCreateWithFlags(&join_ev, hipEventDisableTiming) != hipSuccess) return false;
+    if (hipEventCreateWithFlags(&ev12, hipEventDisableTiming) != hipSuccess) return false;
+    if (hipEventCreateWithFlags(&ev21, hipEventDisableTiming) != hipSuccess) return false;
     for (auto &e : fork)
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
     for (auto &e : mark)
@@ -184,10 +193,23 @@ int plan_run_impl(const mr3d_op *ops, int num_ops, int *failed_index, mr3d_strea
   // a single-op call (used to time one kernel) always runs on the caller's stream
   const bool use_side = g_side_enabled && num_ops > 1 && g_side.init();
   bool side_busy = false;
+  bool s2_busy = false;          // the second side queue holds work the first has not waited for
+  bool s1_ahead = false;         // the first side queue holds a non-wgrad record (scratch zero-fill, ...) the second has not waited for
+  bool use2 = false;             // which side queue the next CONV_WGRAD record takes
+  // a plan that is being captured into a hipGraph keeps to ONE side queue (mr3d_plan_capture: the capture of a second forked
+  // stream that is folded back through the first crashed inside the runtime of this image)
+  hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+  const bool two_side_queues = hipStreamIsCapturing(main_s, &cap_status) == hipSuccess && cap_status == hipStreamCaptureStatusNone;
+  auto fold2 = [&]() {           // the first side queue waits for everything queued on the second
+    if (!s2_busy) return true;
+    s2_busy = false;
+    return hipEventRecord(g_side.ev21, g_side.stream2) == hipSuccess && hipStreamWaitEvent(g_side.stream, g_side.ev21, 0) == hipSuccess;
+  };
   auto join = [&]() {
     if (!side_busy) return true;
     side_busy = false;
-    return hipEventRecord(g_side.join_ev, g_side.stream) == hipSuccess && hipStreamWaitEvent(main_s, g_side.join_ev, 0) == hipSuccess;
+    return fold2() && hipEventRecord(g_side.join_ev, g_side.stream) == hipSuccess &&
+           hipStreamWaitEvent(main_s, g_side.join_ev, 0) == hipSuccess;
   };
   // WINO2D_PREP record at k0: the weight transforms of the two-dimensional Winograd convolutions (conv3d_wino2d.hip) of the
   // records behind it, up to the next weight-writing record, in ONE launch into the plan-owned workspace (one launch in
@@ -228,7 +250,7 @@ int plan_run_impl(const mr3d_op *ops, int num_ops, int *failed_index, mr3d_strea
       if (use_side) {
         bool ok = true;
         if (mode == 0) ok = join();
-        else if (mode == 1) ok = hipEventRecord(g_side.mark[slot], g_side.stream) == hipSuccess;
+        else if (mode == 1) ok = fold2() && hipEventRecord(g_side.mark[slot], g_side.stream) == hipSuccess;
         else if (mode == 2) ok = hipStreamWaitEvent(main_s, g_side.mark[slot], 0) == hipSuccess;
         if (!ok) return fail(k, MR3D_ERR_LAUNCH);
       }
@@ -241,12 +263,29 @@ int plan_run_impl(const mr3d_op *ops, int num_ops, int *failed_index, mr3d_strea
       continue;
     }
     const bool on_side = use_side && wants_side(ops[k]);
-    hipStream_t run_s = on_side ? g_side.stream : main_s;
+    bool on_second = false;
+    // (fp32 records only: the bf16 backbone step measured 5.50 ms on one side queue, 5.57 on two -- its queue has slack)
+    if (on_side && two_side_queues && ops[k].kind == MR3D_OP_CONV_WGRAD && ops[k].i[25] != MR3D_DTYPE_BF16) {
+      on_second = use2;
+      use2 = !use2;
+    }
+    hipStream_t run_s = on_side ? (on_second ? g_side.stream2 : g_side.stream) : main_s;
     const bool marked = marks && next_mark < num_marks && marks[next_mark] == k;
     if (on_side) {
       hipEvent_t ev = g_side.fork[g_side.next++ & 15];
-      if (hipEventRecord(ev, main_s) != hipSuccess || hipStreamWaitEvent(g_side.stream, ev, 0) != hipSuccess)
+      if (hipEventRecord(ev, main_s) != hipSuccess || hipStreamWaitEvent(run_s, ev, 0) != hipSuccess)
         return fail(k, MR3D_ERR_LAUNCH);
+      if (on_second) {
+        if (s1_ahead) {          // e.g. the zero-fill of the weight-gradient scratch
+          s1_ahead = false;
+          if (hipEventRecord(g_side.ev12, g_side.stream) != hipSuccess || hipStreamWaitEvent(g_side.stream2, g_side.ev12, 0) != hipSuccess)
+            return fail(k, MR3D_ERR_LAUNCH);
+        }
+        s2_busy = true;
+      } else if (ops[k].kind != MR3D_OP_CONV_WGRAD) {
+        if (!fold2()) return fail(k, MR3D_ERR_LAUNCH);          // finishing / zero-fill / ... behind every weight gradient
+        s1_ahead = true;
+      }
       side_busy = true;
     } else if (ops[k].kind == MR3D_OP_FINISH_GRADS && !join()) {
       return fail(k, MR3D_ERR_LAUNCH);
@@ -259,7 +298,7 @@ int plan_run_impl(const mr3d_op *ops, int num_ops, int *failed_index, mr3d_strea
     }
     const unsigned char *x_live = nullptr;
     if (ops[k].kind == MR3D_OP_CONV_FWD) { x_live = armed_live; armed_live = nullptr; }
-    st = run_one(ops[k], (mr3d_stream_t)run_s, true, x_live);
+    st = run_one(ops[k], (mr3d_stream_t)run_s, !on_second, x_live);      // the lent partial-sum workspace belongs to the first side queue
     if (ops[k].kind == MR3D_OP_VOXEL_LIVENESS && ops[k].i[5] == 1) armed_live = (const unsigned char *)ops[k].p[1];
     if (marked) {
       if (hipEventRecord((hipEvent_t)pairs[next_mark].stop, run_s) != hipSuccess && st == MR3D_OK) st = MR3D_ERR_LAUNCH;
