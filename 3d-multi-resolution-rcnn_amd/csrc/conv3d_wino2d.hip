@@ -334,7 +334,6 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wino2d_rows_kernel(Conv3dF
   const int od0 = td_i * TDr, oh0 = th_i * TH, ow0 = tw_i * TW;
   const int id0 = od0 - p.pd, ih0 = oh0 - p.ph, iw0 = ow0 - p.pw;
   const float *xtile = p.x + ((((long long)n * p.D + id0) * p.H + ih0) * p.W + iw0) * p.Cin;       // see conv3d_wino2d_kernel
-  const bool halo_inside = id0 >= 0 && id0 + HDr <= p.D && ih0 >= 0 && ih0 + HH <= p.H && iw0 >= 0 && iw0 + HW <= p.W;
   const int li = lane & 15, lk = lane >> 4;
   const int wave_m = wave / WN, wave_n = wave % WN;
   const int co = blockIdx.y * (16 * WN) + wave_n * 16 + li;
@@ -405,36 +404,53 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wino2d_rows_kernel(Conv3dF
   };
 
   constexpr int Q = CC / 4;
-  constexpr int NIT = (HDr * HH * HW * Q + kThreads - 1) / kThreads;
+  // Halo staging by ownership, as in conv3d_wino2d_kernel: a thread owns one (column, channel quad) of the halo rows rg, rg + 6, ...
+  // (HDr * HH rows of HW * Q = 40 lanes; 240 of the 256 threads).  The validity bits of its pieces are formed once per tile; a
+  // piece's offsets are 24-bit multiply-adds from scalars.  (A flat piece index with three divisions, three bounds tests and two
+  // product chains per piece, once for the load and once for the LDS store, was ~880 of this kernel's ~3,000 vector
+  // instructions per tile and wave.)
+  constexpr int ROWS_H = HDr * HH, NIT = (ROWS_H + 5) / 6;
+  static_assert(NIT <= 32, "one validity bit per piece");
+  unsigned s_ok = 0;
+  {
+    const int lane40 = tid % (HW * Q), rg = tid / (HW * Q), hw = lane40 / Q;
+    const bool col_ok = rg < 6 && (unsigned)(iw0 + hw) < (unsigned)p.W;
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+      const int row = rg + 6 * j, hd = row / HH, hh = row - hd * HH;
+      const bool ok = col_ok && row < ROWS_H && (unsigned)(id0 + hd) < (unsigned)p.D && (unsigned)(ih0 + hh) < (unsigned)p.H;
+      s_ok |= ok ? (1u << j) : 0u;
+    }
+  }
+  const int s_plane = p.H * p.W * p.Cin, s_rowp = p.W * p.Cin;               // (scalars; the halo spans < 2^24 elements)
   load_b(b0, 0, 0, 0);
   for (int c0 = 0; c0 < p.Cin; c0 += CC) {
     __syncthreads();
     {
-      // four pieces at a time (16 in flight would spill), addresses recomputed per chunk (hoisted they spill too)
+      // four pieces at a time (16 in flight would spill); the thread's coordinates are re-derived from an opaque copy of tid (kept
+      // across the MFMA steps they would cost registers this kernel does not have)
       int tv = tid;
       asm volatile("" : "+v"(tv));
+      const int rg = tv / (HW * Q), lane40 = tv - rg * (HW * Q), hw = lane40 / Q, q = lane40 - hw * Q;
+      const unsigned col = __umul24(hw, p.Cin) + q * 4;
+      float *lcol = lds + hw * ROW + q * 4;
 #pragma unroll 1
       for (int j0 = 0; j0 < NIT; j0 += 4) {
         float4 stage[4];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
-          const int it = tv + (j0 + jj) * kThreads;
-          const int pos = it / Q, q = it - pos * Q;
-          const int hw = pos % HW, hh = (pos / HW) % HH, hd = pos / (HW * HH);
-          const int rel = (int)__umul24(__umul24(__umul24(hd, p.H) + hh, p.W) + hw, p.Cin) + q * 4;
+          const int row = rg + 6 * (j0 + jj);
+          const int hd = (int)(__umul24(row, 205) >> 11), hh = row - hd * HH;          // row / 10 for row < 1029
           float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (it < HDr * HH * HW * Q &&
-              (halo_inside || ((unsigned)(id0 + hd) < (unsigned)p.D && (unsigned)(ih0 + hh) < (unsigned)p.H && (unsigned)(iw0 + hw) < (unsigned)p.W)))
-            v = buffer_load4(xrsrc, (unsigned)rel * 4u, (unsigned)c0 * 4u);
+          if ((s_ok >> (j0 + jj)) & 1u) v = buffer_load4(xrsrc, (__umul24(hd, s_plane) + __umul24(hh, s_rowp) + col) * 4u, (unsigned)c0 * 4u);
           stage[jj] = v;
         }
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
-          const int it = tv + (j0 + jj) * kThreads;
-          if (it < HDr * HH * HW * Q) {
-            const int pos = it / Q, q = it - pos * Q;
-            const int hw = pos % HW, hh = (pos / HW) % HH, hd = pos / (HW * HH);
-            float *dd = lds + hd * PL + (hh * HWR + hw) * ROW + q * 4;
+          const int row = rg + 6 * (j0 + jj);
+          if (rg < 6 && row < ROWS_H) {
+            const int hd = (int)(__umul24(row, 205) >> 11), hh = row - hd * HH;
+            float *dd = lcol + hd * PL + hh * (HWR * ROW);
             dd[0] = stage[jj].x; dd[1] = stage[jj].y; dd[2] = stage[jj].z; dd[3] = stage[jj].w;
           }
         }
