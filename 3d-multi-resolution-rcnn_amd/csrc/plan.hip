@@ -196,6 +196,8 @@ int plan_run_impl(const mr3d_op *ops, int num_ops, int *failed_index, mr3d_strea
   bool s2_busy = false;          // the second side queue holds work the first has not waited for
   bool s1_ahead = false;         // the first side queue holds a non-wgrad record (scratch zero-fill, ...) the second has not waited for
   bool use2 = false;             // which side queue the next CONV_WGRAD record takes
+  bool main_dirty = true;        // the caller's stream got work since the last fork event
+  hipEvent_t last_fork = nullptr;
   // a plan that is being captured into a hipGraph keeps to ONE side queue (mr3d_plan_capture: the capture of a second forked
   // stream that is folded back through the first crashed inside the runtime of this image)
   hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
@@ -249,6 +251,7 @@ int plan_run_impl(const mr3d_op *ops, int num_ops, int *failed_index, mr3d_strea
       const int mode = ops[k].i[0], slot = ops[k].i[1] & 3;
       if (use_side) {
         bool ok = true;
+        if (mode != 1) main_dirty = true;          // the caller's stream took on a dependency: later forks must carry it
         if (mode == 0) ok = join();
         else if (mode == 1) ok = fold2() && hipEventRecord(g_side.mark[slot], g_side.stream) == hipSuccess;
         else if (mode == 2) ok = hipStreamWaitEvent(main_s, g_side.mark[slot], 0) == hipSuccess;
@@ -258,6 +261,7 @@ int plan_run_impl(const mr3d_op *ops, int num_ops, int *failed_index, mr3d_strea
     }
     if (ops[k].kind == MR3D_OP_WINO2D_PREP) {
       mr3d_conv3d_wino2d_prepare_end();
+      main_dirty = true;
       st = prepare_wino2d(k, (float *)ops[k].p[0], i64_of(ops[k].i));
       if (st != MR3D_OK) return fail(k, st);
       continue;
@@ -272,9 +276,15 @@ int plan_run_impl(const mr3d_op *ops, int num_ops, int *failed_index, mr3d_strea
     hipStream_t run_s = on_side ? (on_second ? g_side.stream2 : g_side.stream) : main_s;
     const bool marked = marks && next_mark < num_marks && marks[next_mark] == k;
     if (on_side) {
-      hipEvent_t ev = g_side.fork[g_side.next++ & 15];
-      if (hipEventRecord(ev, main_s) != hipSuccess || hipStreamWaitEvent(run_s, ev, 0) != hipSuccess)
-        return fail(k, MR3D_ERR_LAUNCH);
+      // Fork: the side queue waits for the caller's stream as of NOW.  Consecutive side records share one event: an event record
+      // is a packet in the caller's queue, and the kernel behind it starts ~6 us later than it would back to back (visible as
+      // device-idle gaps in front of main-chain kernels once the side queues had slack: profiles/r03).
+      if (main_dirty || !last_fork) {
+        last_fork = g_side.fork[g_side.next++ & 15];
+        if (hipEventRecord(last_fork, main_s) != hipSuccess) return fail(k, MR3D_ERR_LAUNCH);
+        main_dirty = false;
+      }
+      if (hipStreamWaitEvent(run_s, last_fork, 0) != hipSuccess) return fail(k, MR3D_ERR_LAUNCH);
       if (on_second) {
         if (s1_ahead) {          // e.g. the zero-fill of the weight-gradient scratch
           s1_ahead = false;
@@ -298,6 +308,7 @@ int plan_run_impl(const mr3d_op *ops, int num_ops, int *failed_index, mr3d_strea
     }
     const unsigned char *x_live = nullptr;
     if (ops[k].kind == MR3D_OP_CONV_FWD) { x_live = armed_live; armed_live = nullptr; }
+    if (!on_side) main_dirty = true;
     st = run_one(ops[k], (mr3d_stream_t)run_s, !on_second, x_live);      // the lent partial-sum workspace belongs to the first side queue
     if (ops[k].kind == MR3D_OP_VOXEL_LIVENESS && ops[k].i[5] == 1) armed_live = (const unsigned char *)ops[k].p[1];
     if (marked) {
