@@ -590,13 +590,15 @@ class ExtractFeat3D(nn.Module):
         for bi in range(len(self.blocks) - 1, -1, -1):
             b, st = self.blocks[bi], P.blk[bi]
             x = st['x']
-            bwd.append(self._conv_wgrad(st['a2'], g, b['conv3']))
             if pending_g_a2 is not None:
                 g_a2 = pending_g_a2                      # produced by the pair launch that closed the block behind this one
             else:
                 g_a2 = self._new(st['a2'].shape)
                 bwd.append(self._conv_dgrad(g, b['conv3'], g_a2, mask=st['a2']))
             pending_g_a2 = None
+            # conv3's and conv2's weight gradients behind conv3's data gradient: the two side records share ONE fork event of
+            # the caller's stream (plan.hip) -- an event record delays the kernel behind it in that queue by ~6 us
+            bwd.append(self._conv_wgrad(st['a2'], g, b['conv3']))
             bwd.append(self._conv_wgrad(st['a1'], g_a2, b['conv2']))
             g_a1 = self._new(st['a1'].shape)
             if b['stride'] == 1:
