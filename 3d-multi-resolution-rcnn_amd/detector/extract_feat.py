@@ -59,7 +59,8 @@ class _ConvSpec:
 class ExtractFeat3D(nn.Module):
     STAGE_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
     MARK_GRADS_BUT_STEM = 1          # SYNC slot of the backward plan (see dist_utils.allreduce_overlapped)
-    MARK_COARSE_DGRADS = 2           # SYNC slot: the P3..P5 output-conv data gradients (side stream) are done
+    MARK_COARSE_DGRADS = 2           # SYNC slot: the P3..P5 output-conv data gradients (side stream) are done (bf16 plans);
+                                     # fp32 plans: slots 2 / 3 = the P2 / P3 lateral data gradients are done
 
     def __init__(self, depth=50, fpn_out_channels=64, num_outs=5, zero_init_residual=True, device='cuda',
                  dtype=torch.float32, neck_dcn=False):
@@ -547,6 +548,7 @@ class ExtractFeat3D(nn.Module):
             glat = [self._new(l.shape) for l in P.lat]
             P.n_direct = 3                          # P2..P4 gradients are only read; the P5 buffer also takes P6's
         gC_lat = [self._new(c.shape) for c in P.C]
+        lat_on_side = not self.bf16          # fp32, 300 steps each way: 10.146 -> 10.066 ms
 
         def fpn_dgrad(i, side):
             ops = []
@@ -584,7 +586,14 @@ class ExtractFeat3D(nn.Module):
                                     [N, df, hf, wf, glat[i].shape[1], glat[i].shape[2], glat[i].shape[3], c]))
             bwd.append(self._conv_wgrad(P.C[i], glat[i], self.lateral[i]))
             # the gradient of the LAST stage output only comes through its lateral conv: apply its ReLU mask here
-            bwd.append(self._conv_dgrad(glat[i], self.lateral[i], gC_lat[i], mask=P.C[3] if i == 3 else None))
+            # gC_lat[i] is read where the backbone backward reaches the end of stage i: the P2 / P3 lateral data gradients (0.6 ms of
+            # streaming pointwise work while the chain behind them is matrix-bound) leave the main chain for the side queue
+            op = self._conv_dgrad(glat[i], self.lateral[i], gC_lat[i], mask=P.C[3] if i == 3 else None)
+            if lat_on_side and i < 2 and not self.neck_dcn:
+                bwd.append(self._side(op))
+                bwd.append(_hip.make_op(_hip.OP_SYNC, [], [_hip.SYNC_MARK, self.MARK_COARSE_DGRADS if i == 0 else 3]))
+            else:
+                bwd.append(op)
         g = gC_lat[3]                     # grad w.r.t. the current block's output, ReLU-masked
         pending_g_a2 = None
         for bi in range(len(self.blocks) - 1, -1, -1):
@@ -617,6 +626,8 @@ class ExtractFeat3D(nn.Module):
             bwd.append(self._conv_wgrad(x, g_a1, b['conv1']))
             first_of_stage = b['block'] == 0
             lat_part = gC_lat[b['stage'] - 1] if (first_of_stage and b['stage'] > 0) else None
+            if lat_part is not None and lat_on_side and b['stage'] - 1 < 2 and not self.neck_dcn:
+                bwd.append(_hip.make_op(_hip.OP_SYNC, [], [_hip.SYNC_WAIT, self.MARK_COARSE_DGRADS if b['stage'] - 1 == 0 else 3]))
             mask = x if bi > 0 else None          # x of the very first block is the max-pool output (no ReLU after it)
             gx = self._new(x.shape)
             if b['ds']:
