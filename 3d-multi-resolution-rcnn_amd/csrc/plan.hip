@@ -132,7 +132,7 @@ struct SideStream {
   hipEvent_t ev12 = nullptr, ev21 = nullptr;
   hipEvent_t join_ev = nullptr;
   hipEvent_t fork[16] = {};
-  hipEvent_t mark[4] = {};          // MR3D_OP_SYNC slots: a point of the side queue the caller's stream can wait for
+  hipEvent_t mark[8] = {};          // MR3D_OP_SYNC slots: a point of the side queue the caller's stream can wait for
   int next = 0;
   bool ok = false;
   bool init() {
@@ -248,12 +248,14 @@ int plan_run_impl(const mr3d_op *ops, int num_ops, int *failed_index, mr3d_strea
     if (ops[k].kind == MR3D_OP_SYNC) {
       // 0: the caller's stream waits for everything queued on the side stream so far; 1: remember this point of the side
       // queue in slot i[1]; 2: the caller's stream waits for the point remembered in slot i[1]
-      const int mode = ops[k].i[0], slot = ops[k].i[1] & 3;
+      const int mode = ops[k].i[0], slot = ops[k].i[1] & 7;
       if (use_side) {
         bool ok = true;
         if (mode != 1) main_dirty = true;          // the caller's stream took on a dependency: later forks must carry it
         if (mode == 0) ok = join();
-        else if (mode == 1) ok = fold2() && hipEventRecord(g_side.mark[slot], g_side.stream) == hipSuccess;
+        // (a mark is a point of the FIRST side queue: the records it stands for -- zero-fill, finishing, CONV_FWD -- run there, and a
+        // finishing record has already waited for the second queue's weight gradients)
+        else if (mode == 1) ok = hipEventRecord(g_side.mark[slot], g_side.stream) == hipSuccess;
         else if (mode == 2) ok = hipStreamWaitEvent(main_s, g_side.mark[slot], 0) == hipSuccess;
         if (!ok) return fail(k, MR3D_ERR_LAUNCH);
       }
@@ -342,7 +344,7 @@ extern "C" int mr3d_plan_run_marked(const mr3d_op *ops, int num_ops, int *failed
 // that a SYNC(mark) record remembered during the last plan run on this device.
 extern "C" int mr3d_plan_stream_wait_mark(int slot, mr3d_stream_t stream) {
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices || slot < 0 || slot > 3) return MR3D_ERR_INVALID_ARG;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices || slot < 0 || slot > 7) return MR3D_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> lock(g_side_mu[dev]);
   SideStream &g_side = g_sides[dev];
   if (!g_side.ok) return MR3D_OK;               // no side stream was ever used: everything ran on the caller's stream

@@ -59,8 +59,8 @@ class _ConvSpec:
 class ExtractFeat3D(nn.Module):
     STAGE_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
     MARK_GRADS_BUT_STEM = 1          # SYNC slot of the backward plan (see dist_utils.allreduce_overlapped)
-    MARK_COARSE_DGRADS = 2           # SYNC slot: the P3..P5 output-conv data gradients (side stream) are done (bf16 plans);
-                                     # fp32 plans: slots 2 / 3 = the P2 / P3 lateral data gradients are done
+    MARK_COARSE_DGRADS = 2           # SYNC slot: the P3..P5 output-conv data gradients (side stream) are done
+    MARK_LATERAL_DGRAD = 4           # SYNC slots 4 / 5: the P2 / P3 lateral data gradients (side stream, fp32 plans) are done
 
     def __init__(self, depth=50, fpn_out_channels=64, num_outs=5, zero_init_residual=True, device='cuda',
                  dtype=torch.float32, neck_dcn=False):
@@ -565,7 +565,7 @@ class ExtractFeat3D(nn.Module):
         # bf16 only: in the fp32 step the side queue (every weight gradient) has no slack -- whatever it still holds when the
         # stem weight gradient starts runs after it (the stem's persistent workgroups leave no room for an LDS-heavy kernel):
         # measured 11.07 -> 11.18 ms with these 0.17 ms moved over; bf16 step, 300 steps each way: 5.57 -> 5.51 ms
-        coarse_on_side = self.bf16
+        coarse_on_side = self.bf16           # (fp32 re-measured with two side queues: 9.98 -> 10.01 ms)
         if not self.neck_dcn:
             # the data gradients of the P3..P5 output convolutions only meet the main chain at the upsample adjoints: they are
             # queued on the side stream in front of the weight gradients, beside the P2 one
@@ -598,7 +598,7 @@ class ExtractFeat3D(nn.Module):
             op = self._conv_dgrad(glat[i], self.lateral[i], gC_lat[i], mask=P.C[3] if i == 3 else None)
             if lat_on_side and i < 2 and not self.neck_dcn:
                 bwd.append(self._side(op))
-                bwd.append(_hip.make_op(_hip.OP_SYNC, [], [_hip.SYNC_MARK, self.MARK_COARSE_DGRADS if i == 0 else 3]))
+                bwd.append(_hip.make_op(_hip.OP_SYNC, [], [_hip.SYNC_MARK, self.MARK_LATERAL_DGRAD + i]))
             else:
                 bwd.append(op)
         g = gC_lat[3]                     # grad w.r.t. the current block's output, ReLU-masked
@@ -634,7 +634,7 @@ class ExtractFeat3D(nn.Module):
             first_of_stage = b['block'] == 0
             lat_part = gC_lat[b['stage'] - 1] if (first_of_stage and b['stage'] > 0) else None
             if lat_part is not None and lat_on_side and b['stage'] - 1 < 2 and not self.neck_dcn:
-                bwd.append(_hip.make_op(_hip.OP_SYNC, [], [_hip.SYNC_WAIT, self.MARK_COARSE_DGRADS if b['stage'] - 1 == 0 else 3]))
+                bwd.append(_hip.make_op(_hip.OP_SYNC, [], [_hip.SYNC_WAIT, self.MARK_LATERAL_DGRAD + b['stage'] - 1]))
             mask = x if bi > 0 else None          # x of the very first block is the max-pool output (no ReLU after it)
             gx = self._new(x.shape)
             if b['ds']:

@@ -691,7 +691,7 @@ typedef enum {
   MR3D_OP_PW_PAIR = 21,
   MR3D_OP_VOXEL_LIVENESS = 22,
   MR3D_OP_SYNC = 19,                  /* i[0] = 0: the caller's stream waits for everything queued on the side stream;
-                                         1: remember this point of the side queue in slot i[1] (0..3);
+                                         1: remember this point of the side queue in slot i[1] (0..7);
                                          2: the caller's stream waits for the point remembered in slot i[1] */
   MR3D_OP_KIND_END
 } mr3d_op_kind;
