@@ -136,6 +136,10 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_fwd_kernel(Conv3dFw
     abase[mt] = (((td * C::LSD) * C::HH + th * C::LSH) * C::HW + tw * C::LSW) * C::ROW + lk;
   }
   const float *wlane = p.w + (size_t)lk * p.Cout + n0 + wave_n * C::TM + li;
+  // halo origin of the tile (may lie in front of x: only addresses inside the volume are dereferenced); the halo spans < 2^24
+  // elements, the packed weights < 2^31 bytes
+  const __amdgpu_buffer_rsrc_t xrsrc = buffer_of(p.x + ((((long long)n * p.D + id0) * p.H + ih0) * p.W + iw0) * p.Cin),
+                               wrsrc = buffer_of(p.w);
 
   using acc_t = typename std::conditional<C::k16, f32x4, f32x16>::type;
   acc_t acc[C::NF * C::MT];                    // WINO: [f][mt]
@@ -160,7 +164,10 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_fwd_kernel(Conv3dFw
         constexpr int PER_TAP = C::CC * C::NB / 4, PER_ROW = C::NB / 4;
         const int tap = e / PER_TAP, rem = e - tap * PER_TAP;
         const int ci = rem / PER_ROW, q = rem - ci * PER_ROW;
-        wstage[j] = (e < WQ) ? *reinterpret_cast<const float4 *>(p.w + ((size_t)tap * p.Cin + c0 + ci) * p.Cout + n0 + q * 4)
+        // buffer load: 32-bit lane offset (24-bit multiplies) + the chunk as a SCALAR offset -- a size_t product chain per load is
+        // 4-5 quarter-rate integer multiplies, and on the small maps this staging sits in the kernel's latency chain
+        wstage[j] = (e < WQ) ? buffer_load4(wrsrc, (__umul24(__umul24(tap, p.Cin) + ci, p.Cout) + (unsigned)(n0 + q * 4)) * 4u,
+                                            (unsigned)(c0 * p.Cout) * 4u)
                              : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
@@ -172,7 +179,8 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_fwd_kernel(Conv3dFw
       const int id = id0 + hd * C::GSD, ih = ih0 + hh * C::GSH, iw = iw0 + hw * C::GSW;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (it < C::HP * Q && hw < C::HW - C::WPAD && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
-        v = *reinterpret_cast<const float4 *>(p.x + ((((size_t)n * p.D + id) * p.H + ih) * p.W + iw) * p.Cin + c0 + q * 4);
+        v = buffer_load4(xrsrc, (__umul24(__umul24(__umul24(hd * C::GSD, p.H) + hh * C::GSH, p.W) + hw * C::GSW, p.Cin) + (unsigned)(q * 4)) * 4u,
+                         (unsigned)c0 * 4u);                     // relative to the tile's halo origin (scalar 64-bit, in the descriptor)
       stage[j] = v;
     }
   };
@@ -350,19 +358,26 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_fwd_kernel(Conv3dFw
   // ---- epilogue: shift, residual adds, nearest-upsample add, ReLU / ReLU-mask; NDHWC store
   const int co = n0 + wave_n * C::TM + li;
   const float sh = p.shift ? p.shift[co] : 0.f;
-  auto emit = [&](int od, int oh, int ow, bool inside, float val) {
-    size_t idx;
-    if constexpr (C::PAR) {
-      const int fd = 2 * od + ad, fh = 2 * oh + ah, fw = 2 * ow + aw;
-      inside = inside && fd < p.yD && fh < p.yH && fw < p.yW;
-      idx = ((((size_t)n * p.yD + fd) * p.yH + fh) * p.yW + fw) * p.Cout + co;
-    } else {
-      idx = ((((size_t)n * p.yD + od * p.ysd) * p.yH + oh * p.ysh) * p.yW + ow * p.ysw) * p.Cout + co;
-    }
+  // Output addressing: a SCALAR 64-bit index of the tile's first output + a 32-bit byte offset per element (three 32-bit products of
+  // tile-local coordinates with scalar steps).  One size_t product chain per element was 25 vector instructions, five of them
+  // quarter-rate multiplies -- 3,000 per wave in the strided / parity instances, and vector ALU work does not hide under fp32 MFMAs.
+  const int sd_ = C::PAR ? 2 : p.ysd, sh_ = C::PAR ? 2 : p.ysh, sw_ = C::PAR ? 2 : p.ysw;
+  const size_t ybase = ((((size_t)n * p.yD + (size_t)(od0 * sd_ + (C::PAR ? ad : 0))) * p.yH + (size_t)(oh0 * sh_ + (C::PAR ? ah : 0))) * p.yW +
+                        (size_t)(ow0 * sw_ + (C::PAR ? aw : 0))) * p.Cout;
+  const int xstep = sw_ * p.Cout * 4, rstep = sh_ * p.yW * p.Cout * 4, pstep = sd_ * p.yH * p.yW * p.Cout * 4;       // bytes (a tile spans < 2^31)
+  const char *add1b = p.add1 ? reinterpret_cast<const char *>(p.add1 + ybase) : nullptr;
+  const char *add2b = p.add2 ? reinterpret_cast<const char *>(p.add2 + ybase) : nullptr;
+  const char *maskb = p.mask ? reinterpret_cast<const char *>(p.mask + ybase) : nullptr;
+  char *yb = reinterpret_cast<char *>(p.y + ybase);
+  // rel_of: byte offset of tile-local output (td, th, tw).  Accumulator elements come in groups of four consecutive GEMM rows that
+  // share (td, th) whenever a tile row holds a multiple of four GEMM rows: their offsets are one product set + scalar steps.
+  auto rel_of = [&](int td, int th, int tw) { return (unsigned)(td * pstep + th * rstep + tw * xstep + co * 4); };
+  auto emit = [&](unsigned rel, int od, int oh, int ow, bool inside, float val) {
+    if constexpr (C::PAR) inside = inside && 2 * od + ad < p.yD && 2 * oh + ah < p.yH && 2 * ow + aw < p.yW;
     if (inside) {
       float v = val + sh;
-      if (p.add1) v += p.add1[idx];
-      if (p.add2) v += p.add2[idx];
+      if (add1b) v += *reinterpret_cast<const float *>(add1b + rel);
+      if (add2b) v += *reinterpret_cast<const float *>(add2b + rel);
       if (p.up) {
         if (p.up_even) {
           if (!((od | oh | ow) & 1)) v += p.up[((((size_t)n * p.Du + (od >> 1)) * p.Hu + (oh >> 1)) * p.Wu + (ow >> 1)) * p.Cout + co];
@@ -372,12 +387,13 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_fwd_kernel(Conv3dFw
         }
       }
       if (p.relu) v = fmaxf(v, 0.f);
-      if (p.mask) v = p.mask[idx] > 0.f ? v : 0.f;
-      p.y[idx] = v;
+      if (maskb) v = *reinterpret_cast<const float *>(maskb + rel) > 0.f ? v : 0.f;
+      *reinterpret_cast<float *>(yb + rel) = v;
     }
   };
 #pragma unroll
   for (int mt = 0; mt < C::MT; ++mt) {
+    unsigned rel_g = 0;
 #pragma unroll
     for (int r = 0; r < (C::k16 ? 4 : 16); ++r) {
       const int row = C::k16 ? (lk * 4 + r) : ((r & 3) + 8 * (r >> 2) + 4 * lk);
@@ -386,20 +402,27 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_fwd_kernel(Conv3dFw
       const int tw = (m % RW) * C::OPR, th = (m / RW) % C::TH, td = m / (RW * C::TH);
       const int od = od0 + td, oh = oh0 + th, ow = ow0 + tw;
       const bool inside = od < p.Do && oh < p.Ho && ow < p.Wo && (C::MV == C::M || m < C::MV);
+      unsigned rel;
+      if constexpr (RW % 4 == 0) {
+        if ((r & 3) == 0) rel_g = rel_of(td, th, tw);
+        rel = rel_g + (unsigned)((r & 3) * C::OPR * xstep);
+      } else {
+        rel = rel_of(td, th, tw);
+      }
       if constexpr (C::WINO == 4) {
         const float m0 = acc[mt][r], m1 = acc[C::MT + mt][r], m2 = acc[2 * C::MT + mt][r], m3 = acc[3 * C::MT + mt][r],
                     m4 = acc[4 * C::MT + mt][r], m5 = acc[5 * C::MT + mt][r];
         const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
-        emit(od, oh, ow, inside, (m0 + s12) + s34);
-        emit(od, oh, ow + 1, inside && ow + 1 < p.Wo, d12 + 2.f * d34);
-        emit(od, oh, ow + 2, inside && ow + 2 < p.Wo, s12 + 4.f * s34);
-        emit(od, oh, ow + 3, inside && ow + 3 < p.Wo, (d12 + 8.f * d34) + m5);
+        emit(rel, od, oh, ow, inside, (m0 + s12) + s34);
+        emit(rel + xstep, od, oh, ow + 1, inside && ow + 1 < p.Wo, d12 + 2.f * d34);
+        emit(rel + 2 * xstep, od, oh, ow + 2, inside && ow + 2 < p.Wo, s12 + 4.f * s34);
+        emit(rel + 3 * xstep, od, oh, ow + 3, inside && ow + 3 < p.Wo, (d12 + 8.f * d34) + m5);
       } else if constexpr (C::WINO == 2) {
         const float m0 = acc[mt][r], m1 = acc[C::MT + mt][r], m2 = acc[2 * C::MT + mt][r], m3 = acc[3 * C::MT + mt][r];
-        emit(od, oh, ow, inside, (m0 + m1) + m2);
-        emit(od, oh, ow + 1, inside && ow + 1 < p.Wo, (m1 - m2) - m3);
+        emit(rel, od, oh, ow, inside, (m0 + m1) + m2);
+        emit(rel + xstep, od, oh, ow + 1, inside && ow + 1 < p.Wo, (m1 - m2) - m3);
       } else {
-        emit(od, oh, ow, inside, acc[mt][r]);
+        emit(rel, od, oh, ow, inside, acc[mt][r]);
       }
     }
   }
