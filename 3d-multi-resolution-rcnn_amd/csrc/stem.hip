@@ -232,7 +232,12 @@ __global__ __launch_bounds__(256, 3) void stem_fwd_wino_kernel(StemFwdArgs p, in
     row(6, g0);
   }
 
+  // Stores through a buffer descriptor: the output row (n, od, oh) is a SCALAR byte offset (the depth pair and row half of a wave
+  // are wave-uniform), a lane's four columns are constant offsets -- no 64-bit index arithmetic per element (32 stores per lane).
   const float sh = p.shift ? p.shift[li] : 0.f;
+  const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, 0x7fffffff, 0x00020000);
+  const int esz = p.y_bf16 ? 2 : 4;                                  // (the launcher bounds the output below 2^31 bytes)
+  const int lane_b = ((w0 + lk * 4) * 16 + li) * esz;
 #pragma unroll
   for (int t = 0; t < THW; ++t) {
     const int oh = h0 + hh * THW + t;
@@ -241,6 +246,7 @@ __global__ __launch_bounds__(256, 3) void stem_fwd_wino_kernel(StemFwdArgs p, in
     for (int e = 0; e < 2; ++e) {
       const int od = d0 + 2 * dp + e;
       if (od >= p.D) continue;
+      const int row_b = (((n * p.D + od) * p.Ho + oh) * p.Wo) * 16 * esz;          // (scalar)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ow = w0 + lk * 4 + r;
@@ -248,7 +254,8 @@ __global__ __launch_bounds__(256, 3) void stem_fwd_wino_kernel(StemFwdArgs p, in
           const float m0 = acc[0][t][r], m1 = acc[1][t][r], m2 = acc[2][t][r], m3 = acc[3][t][r];
           float v = (e == 0 ? (m0 + m1) + m2 : (m1 - m2) - m3) + sh;
           if (p.relu) v = fmaxf(v, 0.f);
-          stem_store(p, ((((size_t)n * p.D + od) * p.Ho + oh) * p.Wo + ow) * 16 + li, v);
+          if (p.y_bf16) __builtin_amdgcn_raw_buffer_store_b16(stem_f2bf(v), yr, lane_b + r * 16 * esz, row_b, 0);
+          else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yr, lane_b + r * 16 * esz, row_b, 0);
         }
       }
     }
@@ -542,6 +549,7 @@ static int stem_forward_impl(const float *x_ncdhw, const float *w_packed, const 
                              int h, int w, int relu, mr3d_stream_t stream_) {
   if (!x_ncdhw || !w_packed || !y || n <= 0 || d <= 0 || h <= 0 || w <= 0) return MR3D_ERR_INVALID_ARG;
   if ((long long)d * h * w >= (1LL << 29)) return MR3D_ERR_UNSUPPORTED;       // 32-bit byte offsets inside a channel volume
+  if ((long long)n * d * ((h - 1) / 2 + 1) * ((w - 1) / 2 + 1) * 64 >= (1LL << 31)) return MR3D_ERR_UNSUPPORTED;   // ... and in the output
   StemFwdArgs a;
   a.x = x_ncdhw; a.wf = w_packed; a.shift = shift; a.y = y; a.y_bf16 = y_bf16;
   a.N = n; a.D = d; a.H = h; a.W = w;

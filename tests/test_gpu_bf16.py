@@ -236,6 +236,26 @@ def test_stem_bf16_forward_and_wgrad(dev, dhw):
     _close(db.cpu(), dy.double().sum(dim=(0, 2, 3, 4)), 'stem dbias', 1e-4, 1e-4)
 
 
+@pytest.mark.parametrize('dhw', [(6, 20, 24), (5, 34, 70)])
+def test_stem_fp32_arithmetic_with_bf16_output(dev, dhw):
+    """STEM_FWD record with bf16 storage and fp32 arithmetic (mr3d_stem_conv_forward_bf16out: 2-byte buffer stores) = the fp32
+    stem's output rounded to bf16 once"""
+    from mr3d_amd import _hip
+    g = torch.Generator().manual_seed(sum(dhw) + 5)
+    x = torch.randn((2, 3) + dhw, generator=g).to(dev)
+    w = torch.randn((16, 3, 7, 7, 7), generator=g) / np.sqrt(3 * 343)
+    shift = torch.randn(16, generator=g).to(dev)
+    w4 = torch.zeros(16, 4, 7, 7, 7); w4[:, :3] = w
+    wp = _hip.pack_conv_weight(w4).to(dev)
+    y32 = _hip.stem_conv_forward(x, wp, shift, relu=True)
+    y16 = torch.empty(y32.shape, dtype=torch.bfloat16, device=dev)
+    op = _hip.make_op(_hip.OP_STEM_FWD, [x, wp, shift, y16], [2, dhw[0], dhw[1], dhw[2], 1])
+    op.i[25] = _hip.DTYPE_BF16
+    _hip.Plan([op]).run(dev)
+    torch.cuda.synchronize()
+    assert torch.equal(y16, y32.bfloat16())
+
+
 @pytest.mark.parametrize('n,dhw,relu', [(2, (6, 20, 24), True), (1, (9, 34, 70), True), (1, (5, 17, 33), False), (1, (12, 40, 136), True)])
 def test_stem_bf16_wgrad_from_the_pooled_gradient(dev, n, dhw, relu):
     """mr3d_stem_conv_wgrad_bf16_pooled against the two launches it replaces (bf16 max-pool backward with the ReLU mask, then
