@@ -629,6 +629,12 @@ extern "C" int mr3d_conv3d_forward(const mr3d_conv3d_desc *d, mr3d_stream_t stre
   if (a.up && (a.Du <= 0 || a.Hu <= 0 || a.Wu <= 0)) return MR3D_ERR_INVALID_ARG;
   if (a.up && a.up_even && (a.Du != (a.Do + 1) / 2 || a.Hu != (a.Ho + 1) / 2 || a.Wu != (a.Wo + 1) / 2 || a.ysd != 1 || a.ysh != 1 || a.ysw != 1))
     return MR3D_ERR_INVALID_ARG;
+  // Ranges of the 32-bit / 24-bit offset arithmetic inside the kernels (halo staging through buffer loads, tile-relative output
+  // offsets): an input plane below 2^20 positions and 2^24 elements, an output plane (times its scatter stride) below 2^25
+  // elements, weights below 2^29 elements.  Far above anything a 512 x 512 x 80 volume produces behind the stem.
+  if ((long long)a.H * a.W >= (1LL << 20) || (long long)a.H * a.W * a.Cin >= (1LL << 24) ||
+      (long long)a.yH * a.yW * a.Cout * a.ysd >= (1LL << 25) || (long long)d->kd * d->kh * d->kw * a.Cin * a.Cout >= (1LL << 29))
+    return MR3D_ERR_UNSUPPORTED;
   const int nb = pick_nb(a.Cout);
   if (!nb) return MR3D_ERR_UNSUPPORTED;
   hipStream_t stream = mr3d_stream(stream_);
@@ -694,6 +700,9 @@ extern "C" int mr3d_conv3d_dgrad_s2k3(const mr3d_conv3d_desc *d, mr3d_stream_t s
   a.Do = d->d; a.Ho = d->h; a.Wo = d->w_in;          // class grid = dy's grid
   a.Du = a.Hu = a.Wu = 0; a.relu = 0;
   a.ysd = a.ysh = a.ysw = 2; a.yD = d->y_d; a.yH = d->y_h; a.yW = d->y_w;
+  if ((long long)a.H * a.W >= (1LL << 20) || (long long)a.H * a.W * a.Cin >= (1LL << 24) ||
+      (long long)a.yH * a.yW * a.Cout * 2 >= (1LL << 25) || 27LL * a.Cin * a.Cout >= (1LL << 29))
+    return MR3D_ERR_UNSUPPORTED;                       // ranges of the kernels' 32-bit / 24-bit offset arithmetic (mr3d_conv3d_forward)
   hipStream_t stream = mr3d_stream(stream_);
   switch (narrow_nb(a, pick_nb(a.Cout))) {
     case 16: return dispatch_par<16>(a, stream);

@@ -644,7 +644,7 @@ extern "C" size_t mr3d_conv3d_wino2d_workspace_bytes(int cin, int cout) {
 
 bool mr3d_conv3d_wino2d_ok(const Conv3dFwdArgs &a) {
   return a.Cin % CC == 0 && a.Cout % 64 == 0 && a.Do == a.D + 2 * a.pd - 2 && a.Ho == a.H + 2 * a.ph - 2 && a.Wo == a.W + 2 * a.pw - 2 &&
-         u_available(a);
+         u_available(a) && (long long)a.H * a.W * a.Cin < (1LL << 24);      // 24-bit offset products in the halo staging
 }
 
 int mr3d_conv3d_wino2d(const Conv3dFwdArgs &a, hipStream_t stream) {

@@ -204,6 +204,9 @@ typedef struct {
    * training (RPN conv, FPN output convs).  NULL: no test.  Other kernel instances ignore it. */
   const unsigned char *x_live;
 } mr3d_conv3d_desc;
+/* Size limits (MR3D_ERR_UNSUPPORTED beyond them; the kernels address a tile with 32-bit byte offsets and 24-bit products):
+ * an input plane h * w below 2^20 positions and h * w * cin below 2^24 elements, an output plane y_h * y_w * cout * ys_d below
+ * 2^25 elements, the weights below 2^29 elements. */
 int mr3d_conv3d_forward(const mr3d_conv3d_desc *desc, mr3d_stream_t stream);
 /* bits: one bit per position p = ((n*D + d)*H + h)*W + w of the NDHWC map x (fp32, or bf16 if `bf16`; a position's channels must be
  * 16 * 2^k bytes, k <= 6) -- bit (p & 31) of word p >> 5 is set iff a channel of p is non-zero.  The buffer holds
