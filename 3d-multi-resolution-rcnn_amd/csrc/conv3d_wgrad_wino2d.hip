@@ -273,7 +273,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wgrad_wino2d_kernel(Conv3d
 bool mr3d_conv3d_wgrad_wino2d_ok(const Conv3dWgradArgs &a) {
   return a.Cin % CC == 0 && a.Cout % 64 == 0 && !a.part && a.Do == a.D + 2 * a.pd - 2 && a.Ho == a.H + 2 * a.ph - 2 &&
          a.Wo == a.W + 2 * a.pw - 2 &&
-         (long long)a.H * a.W * a.Cin < (1LL << 28) && (long long)a.Ho * a.Wo * a.Cout < (1LL << 28);      // 32-bit byte offsets inside a tile's planes
+         (long long)a.H * a.W * a.Cin < (1LL << 27) && (long long)a.Ho * a.Wo * a.Cout < (1LL << 27);      // byte offsets of a tile (two planes) below 2^31
 }
 
 int mr3d_conv3d_wgrad_wino2d(const Conv3dWgradArgs &a, hipStream_t stream) {
