@@ -98,7 +98,7 @@ __device__ __forceinline__ void stem_stage_channel(float *slab, const float *__r
     const int ih = 2 * h0 - 3 + r, iw = 2 * w0 - 4 + 4 * q;
     const bool mine = tid < G::PH * Q && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
     const unsigned voff = mine ? (unsigned)(ih * W + iw) : 0u;
-    const int plane = H * W;                             // a channel volume is < 2^29 elements (checked by the launcher)
+    const int plane = H * W;                             // a channel volume is < 2^28 elements (checked by the launcher)
     const __amdgpu_buffer_rsrc_t xr = buffer_of(xc);
     float4 v[G::PD];
 #pragma unroll
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(kStemThreads) void stem_wgrad_kernel(StemWgradArgs 
 static int stem_forward_impl(const float *x_ncdhw, const float *w_packed, const float *shift, float *y, int y_bf16, int n, int d,
                              int h, int w, int relu, mr3d_stream_t stream_) {
   if (!x_ncdhw || !w_packed || !y || n <= 0 || d <= 0 || h <= 0 || w <= 0) return MR3D_ERR_INVALID_ARG;
-  if ((long long)d * h * w >= (1LL << 29)) return MR3D_ERR_UNSUPPORTED;       // 32-bit byte offsets inside a channel volume
+  if ((long long)d * h * w >= (1LL << 28)) return MR3D_ERR_UNSUPPORTED;       // byte offsets inside a channel volume below 2^30
   if ((long long)n * d * ((h - 1) / 2 + 1) * ((w - 1) / 2 + 1) * 64 >= (1LL << 31)) return MR3D_ERR_UNSUPPORTED;   // ... and in the output
   StemFwdArgs a;
   a.x = x_ncdhw; a.wf = w_packed; a.shift = shift; a.y = y; a.y_bf16 = y_bf16;
@@ -608,7 +608,7 @@ static int stem_wgrad_impl(const float *x_ncdhw, const float *dy, int dy_bf16, f
                            int w, float *workspace, long long workspace_bytes, mr3d_stream_t stream_, const uint32_t *pool_idx,
                            const float *pooled) {
   if (!x_ncdhw || !dy || !dw_packed || n <= 0 || d <= 0 || h <= 0 || w <= 0) return MR3D_ERR_INVALID_ARG;
-  if ((long long)d * h * w >= (1LL << 29)) return MR3D_ERR_UNSUPPORTED;       // 32-bit byte offsets inside a channel volume
+  if ((long long)d * h * w >= (1LL << 28)) return MR3D_ERR_UNSUPPORTED;       // byte offsets inside a channel volume below 2^30
   StemWgradArgs a;
   a.x = x_ncdhw; a.dy = dy; a.dw = dw_packed; a.dbias = dbias; a.dy_bf16 = dy_bf16;
   a.N = n; a.D = d; a.H = h; a.W = w;
