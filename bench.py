@@ -287,6 +287,17 @@ def ops_microbench(dev):
 
 
 
+def rank_census(dev, world):
+    """{'dist_world_size', 'rccl_ranks'}: what torch.distributed reports and the number of ranks a SUM all-reduce of ones
+    over RCCL really counted (every rank calls this)"""
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return {'dist_world_size': 1, 'rccl_ranks': 1}
+    one = torch.ones(1, device=dev, dtype=torch.float32)
+    dist.all_reduce(one)
+    return {'dist_world_size': dist.get_world_size(), 'rccl_ranks': int(round(float(one.item())))}
+
+
 def emit_json_line(obj):
     """the ONE JSON line, as the LAST line of stdout: RCCL writes its version banner through C stdio (block-buffered on a pipe,
     flushed at exit -- after Python's own line); flush C stdio first, then print"""
@@ -354,6 +365,7 @@ def two_stage_main(a, rank, world, dev):
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
+    census = rank_census(dev, world)
     if rank == 0:
         ms = el * 1e3 / a.steps
         # algorithmic FLOPs of the step: backbone+FPN fwd+bwd 1124.38 + RPN head 3 x 165.8; roi heads depend on
@@ -372,18 +384,74 @@ def two_stage_main(a, rank, world, dev):
             'roofline': {'bound': 'mfma', 'kernel': 'whole step (backbone+FPN+RPN convolutions)', 'achieved': flops / (ms * 1e-3) / 1e12,
                          'peak': (PEAK_BF16_MATRIX if bf else PEAK_FP32_MATRIX) / 1e12, 'unit': 'TFLOP/s',
                          'frac': flops / (ms * 1e-3) / (PEAK_BF16_MATRIX if bf else PEAK_FP32_MATRIX), 'traffic': None},
-            'arena_mbytes': arena.flat_grads.numel() * 4 / 1e6})
+            'arena_mbytes': arena.flat_grads.numel() * 4 / 1e6, **census})
     if dist.is_initialized():
         dist.destroy_process_group()
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def rank_env(rank, world, port, base=None):
+    """environment of one rank of a single-node job: what `python -m torch.distributed.launch --nproc_per_node=N`
+    (tools/dist_train.sh:5 of the reference) hands each child"""
+    env = dict(os.environ if base is None else base)
+    env.update({'RANK': str(rank), 'LOCAL_RANK': str(rank), 'WORLD_SIZE': str(world), 'LOCAL_WORLD_SIZE': str(world),
+                'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': str(port), 'HSA_ENABLE_IPC_MODE_LEGACY': '0',
+                'MR3D_BENCH_SPAWNED': '1'})
+    return env
+
+
+def launch_ranks(n, argv=None, device_count=None, script=None):
+    """`bench.py --gpus N` outside a launcher: start N ranks of this script, one per GPU (the reference's
+    tools/dist_train.sh:5 / mmdet/apis/train.py:85-100 shape).  The parent never touches a GPU: it only counts devices
+    (torch.cuda.device_count() does not initialise HIP), starts the children, forwards their output and returns the worst
+    exit code.  Fewer than N devices is an error, never a silent N=1 run."""
+    import subprocess
+    have = torch.cuda.device_count() if device_count is None else device_count
+    if have < n:
+        print(f'bench.py: --gpus {n} asked for {n} ranks but this node shows {have} GPU(s); refusing to run a smaller job '
+              f'under the name of a {n}-GPU one', file=sys.stderr)
+        return 2
+    port = _free_port()
+    argv = sys.argv[1:] if argv is None else argv
+    procs = [subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=rank_env(r, n, port))
+             for r in range(n)]
+    worst = 0
+    try:
+        for p in procs:
+            rc = p.wait()
+            if rc != 0:
+                worst = worst or (rc if rc > 0 else 1)
+                for q in procs:              # a dead rank leaves the others in a collective: end exactly the PIDs started here
+                    if q.poll() is None:
+                        q.terminate()
+    except KeyboardInterrupt:
+        for q in procs:
+            if q.poll() is None:
+                q.terminate()
+        worst = 130
+    return worst
+
+
 def main():
     a = parse()
+    if 'WORLD_SIZE' not in os.environ and a.gpus > 1:
+        raise SystemExit(launch_ranks(a.gpus))
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != a.gpus:
+        raise SystemExit(f'bench.py: --gpus {a.gpus} disagrees with WORLD_SIZE={world} of the launcher; the JSON line must '
+                         'name the rank count that really ran')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the HIP hot path has no CPU fallback')
+    if torch.cuda.device_count() <= local:
+        raise SystemExit(f'bench.py: rank {rank} has LOCAL_RANK={local} but only {torch.cuda.device_count()} GPU(s) are visible')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     import torch.distributed as dist
@@ -490,6 +558,7 @@ def main():
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
+    census = rank_census(dev, world)
 
     def committed_traffic(kernel_key):
         """HBM bytes per launch of `kernel_key` from the committed rocprofv3 PMC passes of this same command
@@ -536,7 +605,7 @@ def main():
             'metric': f'train iters/sec on 512x512x80 vols (ResNet3D-50+FPN3D forward+backward, {"fp32" if a.dtype == "f32" else "bf16 storage / fp32 accumulate"})',
             'value': world * a.steps / el, 'unit': 'iters/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype,
-            'data': 'synthetic',
+            'data': 'synthetic', **census,
             'config': {'workload': f'BASELINE configs[{1 if a.dtype == "f32" else 4}] backbone: 1x3x{D}x{H}x{W} fp32 volume per GPU, ResNet3D-50 + FPN3D '
                                    'forward+backward (eval-mode BN, random-init weights' + ('' if a.dtype == 'f32' else '; bf16 activations') + ')' +
                                    ('' if world == 1 else f' + one SUM all-reduce of a {msg:.1f} MB flat fp32 gradient arena over RCCL' +
