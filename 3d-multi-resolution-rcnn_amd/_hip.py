@@ -661,6 +661,16 @@ def plan_stream_wait_mark(slot, stream):
         check(lib().mr3d_plan_stream_wait_mark(int(slot), ctypes.c_void_p(stream.cuda_stream)), 'mr3d_plan_stream_wait_mark')
 
 
+def plan_stream_wait_mark_checked(slot, stream):
+    """mr3d_plan_stream_wait_mark_checked: True when `stream` now waits for SYNC mark `slot` as recorded by a live plan run since
+    the last checked wait; False (no wait was issued) when the mark was not recorded -- side stream off, captured plan, no run"""
+    waited = ctypes.c_int(0)
+    with torch.cuda.device(stream.device):
+        check(lib().mr3d_plan_stream_wait_mark_checked(int(slot), ctypes.c_void_p(stream.cuda_stream), ctypes.byref(waited)),
+              'mr3d_plan_stream_wait_mark_checked')
+    return bool(waited.value)
+
+
 def split64(v):
     v = int(v)
     lo, hi = v & 0xFFFFFFFF, (v >> 32) & 0xFFFFFFFF

@@ -348,6 +348,7 @@ extern "C" int mr3d_conv3d_forward_bf16(const mr3d_conv3d_desc *d, mr3d_stream_t
   if (a.N <= 0 || a.Do <= 0 || a.Ho <= 0 || a.Wo <= 0) return MR3D_ERR_INVALID_ARG;
   if (a.up && (a.Du <= 0 || a.Hu <= 0 || a.Wu <= 0)) return MR3D_ERR_INVALID_ARG;
   if (a.Cin % 16 != 0 || a.Cout % 8 != 0) return MR3D_ERR_UNSUPPORTED;
+  if (d->relu & ~MR3D_CONV_RELU) return MR3D_ERR_UNSUPPORTED;          // MR3D_CONV_UP_EVEN: fp32 kernels only (mr3d.h)
   hipStream_t stream = mr3d_stream(stream_);
   const int k = d->kd, s = d->sd;
   if (k == 1 && s == 1) {

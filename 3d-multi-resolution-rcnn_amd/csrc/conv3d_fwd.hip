@@ -632,9 +632,10 @@ extern "C" int mr3d_conv3d_forward(const mr3d_conv3d_desc *d, mr3d_stream_t stre
   // Ranges of the 32-bit / 24-bit offset arithmetic inside the kernels (halo staging through buffer loads, tile-relative output
   // offsets): an input plane below 2^20 positions and 2^24 elements, an output plane (times its scatter stride) below 2^25
   // elements, weights below 2^29 elements.  Far above anything a 512 x 512 x 80 volume produces behind the stem.
-  if ((long long)a.H * a.W >= (1LL << 20) || (long long)a.H * a.W * a.Cin >= (1LL << 24) ||
-      (long long)a.yH * a.yW * a.Cout * a.ysd >= (1LL << 25) || (long long)d->kd * d->kh * d->kw * a.Cin * a.Cout >= (1LL << 29))
-    return MR3D_ERR_UNSUPPORTED;
+  // (the streaming pointwise kernels index with 64 bits: they are tried first, in front of the guard)
+  const bool offsets_fit = !((long long)a.H * a.W >= (1LL << 20) || (long long)a.H * a.W * a.Cin >= (1LL << 24) ||
+                             (long long)a.yH * a.yW * a.Cout * a.ysd >= (1LL << 25) ||
+                             (long long)d->kd * d->kh * d->kw * a.Cin * a.Cout >= (1LL << 29));
   const int nb = pick_nb(a.Cout);
   if (!nb) return MR3D_ERR_UNSUPPORTED;
   hipStream_t stream = mr3d_stream(stream_);
@@ -651,9 +652,12 @@ extern "C" int mr3d_conv3d_forward(const mr3d_conv3d_desc *d, mr3d_stream_t stre
         return st;
       }
     }
+    if (!offsets_fit) return MR3D_ERR_UNSUPPORTED;
     if (a.Cin % 64 == 0) return dispatch_nb<1, 1, 1, 1, 64>(a, nb, stream);
     if (a.Cin % 32 == 0) return dispatch_nb<1, 1, 1, 1, 32>(a, nb, stream);
     if (a.Cin % 16 == 0) return dispatch_nb<1, 1, 1, 1, 16>(a, nb, stream);
+  } else if (!offsets_fit) {
+    return MR3D_ERR_UNSUPPORTED;
   } else if (k == 1 && s == 222) {
     if (a.Cin % 64 == 0) return dispatch_nb<1, 2, 2, 2, 64>(a, nb, stream);
     if (a.Cin % 16 == 0) return dispatch_nb<1, 2, 2, 2, 16>(a, nb, stream);

@@ -573,7 +573,8 @@ bool u_available(const Conv3dFwdArgs &a) {
 
 // narrow Cout tiles: Cout 16 or 32 exactly (a wider Cout takes the 64-wide kernel or the one-dimensional forms)
 bool mr3d_conv3d_wino2d_rows_ok(const Conv3dFwdArgs &a) {
-  return a.Cin % CC == 0 && (a.Cout == 16 || a.Cout == 32) && a.Do == a.D + 2 * a.pd - 2 && a.Ho == a.H + 2 * a.ph - 2 &&
+  // (the even-position add of MR3D_CONV_UP_EVEN exists in the generic and the streaming pointwise kernels only)
+  return !a.up_even && a.Cin % CC == 0 && (a.Cout == 16 || a.Cout == 32) && a.Do == a.D + 2 * a.pd - 2 && a.Ho == a.H + 2 * a.ph - 2 &&
          a.Wo == a.W + 2 * a.pw - 2 && u_available(a);
 }
 
@@ -643,8 +644,8 @@ extern "C" size_t mr3d_conv3d_wino2d_workspace_bytes(int cin, int cout) {
 }
 
 bool mr3d_conv3d_wino2d_ok(const Conv3dFwdArgs &a) {
-  return a.Cin % CC == 0 && a.Cout % 64 == 0 && a.Do == a.D + 2 * a.pd - 2 && a.Ho == a.H + 2 * a.ph - 2 && a.Wo == a.W + 2 * a.pw - 2 &&
-         u_available(a) && (long long)a.H * a.W * a.Cin < (1LL << 24);      // 24-bit offset products in the halo staging
+  return !a.up_even && a.Cin % CC == 0 && a.Cout % 64 == 0 && a.Do == a.D + 2 * a.pd - 2 && a.Ho == a.H + 2 * a.ph - 2 &&
+         a.Wo == a.W + 2 * a.pw - 2 && u_available(a) && (long long)a.H * a.W * a.Cin < (1LL << 24);      // 24-bit offset products in the halo staging
 }
 
 int mr3d_conv3d_wino2d(const Conv3dFwdArgs &a, hipStream_t stream) {

@@ -133,6 +133,9 @@ struct SideStream {
   hipEvent_t join_ev = nullptr;
   hipEvent_t fork[16] = {};
   hipEvent_t mark[8] = {};          // MR3D_OP_SYNC slots: a point of the side queue the caller's stream can wait for
+  // a slot is ARMED while its event stands for a point of a real (not captured) run that nobody outside the plan has consumed
+  // yet: mr3d_plan_stream_wait_mark_checked only waits on an armed slot and tells its caller when it did not
+  bool mark_armed[8] = {};
   int next = 0;
   bool ok = false;
   bool init() {
@@ -202,6 +205,7 @@ int plan_run_impl(const mr3d_op *ops, int num_ops, int *failed_index, mr3d_strea
   // stream that is folded back through the first crashed inside the runtime of this image)
   hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
   const bool two_side_queues = hipStreamIsCapturing(main_s, &cap_status) == hipSuccess && cap_status == hipStreamCaptureStatusNone;
+  const bool capturing = !two_side_queues;
   auto fold2 = [&]() {           // the first side queue waits for everything queued on the second
     if (!s2_busy) return true;
     s2_busy = false;
@@ -242,6 +246,10 @@ int plan_run_impl(const mr3d_op *ops, int num_ops, int *failed_index, mr3d_strea
     join();
     return st;
   };
+  constexpr int kMaxDwSeen = 256;
+  const void *dw_seen[kMaxDwSeen];
+  bool dw_queue[kMaxDwSeen];
+  int n_dw_seen = 0;
   const unsigned char *armed_live = nullptr;          // set by a VOXEL_LIVENESS record with arm = 1, taken by the next CONV_FWD
   for (int k = 0; k < num_ops; ++k) {
     int st = MR3D_OK;
@@ -249,6 +257,9 @@ int plan_run_impl(const mr3d_op *ops, int num_ops, int *failed_index, mr3d_strea
       // 0: the caller's stream waits for everything queued on the side stream so far; 1: remember this point of the side
       // queue in slot i[1]; 2: the caller's stream waits for the point remembered in slot i[1]
       const int mode = ops[k].i[0], slot = ops[k].i[1] & 7;
+      // a mark of this run is only worth waiting for if the event is really recorded NOW: not with the side stream off (the
+      // record is skipped) and not under capture (the record becomes a graph node; a replay does not touch the event)
+      if (mode == 1) g_side.mark_armed[slot] = use_side && !capturing;
       if (use_side) {
         bool ok = true;
         if (mode != 1) main_dirty = true;          // the caller's stream took on a dependency: later forks must carry it
@@ -272,8 +283,21 @@ int plan_run_impl(const mr3d_op *ops, int num_ops, int *failed_index, mr3d_strea
     bool on_second = false;
     // (fp32 records only: the bf16 backbone step measured 5.50 ms on one side queue, 5.57 on two -- its queue has slack)
     if (on_side && two_side_queues && ops[k].kind == MR3D_OP_CONV_WGRAD && ops[k].i[25] != MR3D_DTYPE_BF16) {
-      on_second = use2;
-      use2 = !use2;
+      // records that accumulate into the SAME dw must stay on one queue (the first queue may reduce a lent partial-sum workspace
+      // into dw without atomics, the second adds atomically: two queues on one dw would race) -- e.g. the RPN head's five
+      // levels share dw1 / dw3.  A new dw takes the queues in turn.
+      const void *dw = ops[k].p[2];
+      int seen = -1;
+      for (int j = 0; j < n_dw_seen; ++j)
+        if (dw_seen[j] == dw) { seen = j; break; }
+      if (seen >= 0) {
+        on_second = dw_queue[seen];
+      } else {
+        on_second = use2;
+        use2 = !use2;
+        if (n_dw_seen < kMaxDwSeen) { dw_seen[n_dw_seen] = dw; dw_queue[n_dw_seen++] = on_second; }
+        else on_second = false;          // table full (never with the shipped plans): the first queue is always safe
+      }
     }
     hipStream_t run_s = on_side ? (on_second ? g_side.stream2 : g_side.stream) : main_s;
     const bool marked = marks && next_mark < num_marks && marks[next_mark] == k;
@@ -349,6 +373,19 @@ extern "C" int mr3d_plan_stream_wait_mark(int slot, mr3d_stream_t stream) {
   SideStream &g_side = g_sides[dev];
   if (!g_side.ok) return MR3D_OK;               // no side stream was ever used: everything ran on the caller's stream
   return hipStreamWaitEvent(mr3d_stream(stream), g_side.mark[slot], 0) == hipSuccess ? MR3D_OK : MR3D_ERR_LAUNCH;
+}
+
+extern "C" int mr3d_plan_stream_wait_mark_checked(int slot, mr3d_stream_t stream, int *waited) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices || slot < 0 || slot > 7 || !waited) return MR3D_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(g_side_mu[dev]);
+  SideStream &g_side = g_sides[dev];
+  *waited = 0;
+  if (!g_side.ok || !g_side.mark_armed[slot]) return MR3D_OK;
+  if (hipStreamWaitEvent(mr3d_stream(stream), g_side.mark[slot], 0) != hipSuccess) return MR3D_ERR_LAUNCH;
+  g_side.mark_armed[slot] = false;          // one consumer per recorded mark: the next run has to record it again
+  *waited = 1;
+  return MR3D_OK;
 }
 
 extern "C" int mr3d_event_pair_elapsed_ms(const mr3d_event_pair *pair, float *ms) {

@@ -93,6 +93,7 @@ class ExtractFeat3D(nn.Module):
         self._build_specs()
         self._build_arena()
         self._plans = {}
+        self.grads_touched = False
         self.init_weights()
 
     # ------------------------------------------------------------------ structure
@@ -791,6 +792,7 @@ class ExtractFeat3D(nn.Module):
             self.flat_grads.zero_()
         with torch.cuda.device(self.device):
             P.bwd.run(self.device)
+        self.grads_touched = True           # every engine parameter has had a gradient (dist_utils.ArenaSGD / DetectorArena)
 
     def forward(self, img, slot=0):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):

@@ -52,7 +52,11 @@ def allreduce_overlapped(flat, stem_elems, world_size=None, group=None, mark_slo
         comm = _COMM_STREAMS.get(dev)
         if comm is None:
             comm = _COMM_STREAMS[dev] = torch.cuda.Stream(device=dev)
-        _hip.plan_stream_wait_mark(mark_slot, comm)
+        # the communication stream starts behind the plan's mark -- IF this step's backward pass recorded it.  It did not when
+        # the side stream is off, when the plan is replayed from a hipGraph, or when no plan ran: the collective then waits for
+        # everything the caller's stream holds (no overlap, same result).
+        if not _hip.plan_stream_wait_mark_checked(mark_slot, comm):
+            comm.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(comm):
             work = dist.all_reduce(tail, op=dist.ReduceOp.SUM, group=group, async_op=True)
         dist.all_reduce(head, op=dist.ReduceOp.SUM, group=group)
@@ -73,13 +77,16 @@ def broadcast_params(flat, src=0, group=None):
     return flat
 
 
-def _keep_grad_in_arena(p, gview):
+def _keep_grad_in_arena(p, gview, on_touch=None):
     """torch's zero_grad (set_to_none=True by default on 2.x) detaches a parameter from its arena slot and autograd then
-    allocates a fresh gradient.  This hook moves such a gradient back: `None` meant zero, so the slot is overwritten."""
+    allocates a fresh gradient.  This hook moves such a gradient back: `None` meant zero, so the slot is overwritten.
+    on_touch(): called every time autograd has accumulated a gradient into the parameter (see FlatArena.touched)."""
     def hook(param):
         if param.grad is not None and param.grad.data_ptr() != gview.data_ptr():
             gview.copy_(param.grad)
             param.grad = gview
+        if on_touch is not None:
+            on_touch()
     p.register_post_accumulate_grad_hook(hook)
 
 
@@ -100,17 +107,30 @@ class FlatArena:
             fp, fg, at = storage
             self.flat_params, self.flat_grads = fp[at:at + n], fg[at:at + n]
         off = 0
+        # touched[i]: parameter i has received a gradient at least once.  In the reference a parameter whose .grad is still None
+        # is neither exchanged nor stepped (mmdet/core/utils/dist_utils.py:32-35; torch.optim.SGD skips `p.grad is None`), so
+        # weight decay does not reach e.g. the mask head before its first positive roi.  Here every .grad is an arena view
+        # from the start; the flags carry the difference (ArenaSGD reads them).
+        self.touched = [False] * len(params)
+        self.ranges = []
+        self.version = 0                     # bumped whenever a flag flips (ArenaSGD caches its mask per version)
         with torch.no_grad():
-            for p in params:
+            for i, p in enumerate(params):
                 k = p.numel()
                 self.flat_params[off:off + k].copy_(p.detach().reshape(-1))
                 p.data = self.flat_params[off:off + k].view(p.shape)
                 gview = self.flat_grads[off:off + k].view(p.shape)
                 p.grad = gview
-                _keep_grad_in_arena(p, gview)
+                _keep_grad_in_arena(p, gview, on_touch=lambda i=i: self._touch(i))
+                self.ranges.append((off, off + k))
                 off += k
         self.params = params
         self.numel = n
+
+    def _touch(self, i):
+        if not self.touched[i]:
+            self.touched[i] = True
+            self.version += 1
 
     def zero_grad(self):
         self.flat_grads.zero_()
@@ -153,6 +173,21 @@ class DetectorArena:
         if self.heads is not None:
             self.heads.zero_grad()
 
+    def untouched_ranges(self):
+        """[(lo, hi)] element ranges of flat_params whose parameters have never received a gradient (none, after the first
+        iteration that produced every loss): the reference does not step those (see FlatArena.touched)"""
+        out = []
+        if self.engine is not None and not getattr(self.engine, 'grads_touched', True):
+            out.append((0, self.engine.num_trainable))
+        if self.heads is not None:
+            base = self.engine.num_trainable if self.engine is not None else 0
+            out += [(base + lo, base + hi) for (lo, hi), t in zip(self.heads.ranges, self.heads.touched) if not t]
+        return out
+
+    def touch_version(self):
+        return (self.heads.version if self.heads is not None else 0,
+                bool(getattr(self.engine, 'grads_touched', True)) if self.engine is not None else True)
+
     def allreduce(self, world_size=None, group=None, overlap=True):
         """the one gradient exchange of a step.  overlap (default): two collectives, the first one started underneath the
         tail of the backward pass (allreduce_overlapped); False: ONE in-place all-reduce after the backward pass, as the
@@ -161,6 +196,60 @@ class DetectorArena:
             return allreduce_overlapped(self.flat_grads, self.engine.stem_elems, world_size, group,
                                         mark_slot=self.engine.MARK_GRADS_BUT_STEM)
         return allreduce_flat_grads(self.flat_grads, world_size, group)
+
+
+class ArenaSGD:
+    """torch.optim.SGD (momentum, weight decay, no dampening / Nesterov: configs/3d-multi-resolution-rcnn.py:235) over a
+    DetectorArena as ONE fused update of the flat buffer -- with the reference's treatment of parameters that have never
+    received a gradient: torch.optim.SGD skips `p.grad is None` (no weight decay, no momentum buffer), and the reference's
+    zero_grad (torch 1.0: in-place zero) keeps a gradient non-None for good once it has existed.  So a slice is stepped from
+    its first gradient onwards, exactly like the per-parameter optimiser; until then it stays at its initial value.
+    Interface: step(), zero_grad(), param_groups[0]['lr'] (the lr schedule hooks of the runner write it)."""
+
+    def __init__(self, arena, lr, momentum=0.0, weight_decay=0.0):
+        self.arena = arena
+        self.param_groups = [dict(params=[arena.flat_params], lr=lr, momentum=momentum, weight_decay=weight_decay)]
+        self.momentum_buffer = torch.zeros_like(arena.flat_params)
+        self._d = torch.empty_like(arena.flat_params)
+        self._mask, self._mask_version = None, None
+
+    def _active_mask(self):
+        """None when every slice is live, else a 0/1 float tensor over the arena (rebuilt only when a flag flips)"""
+        version = self.arena.touch_version()
+        if version != self._mask_version:
+            ranges = self.arena.untouched_ranges()
+            if not ranges:
+                self._mask = None
+            else:
+                self._mask = torch.ones_like(self.arena.flat_params)
+                for lo, hi in ranges:
+                    self._mask[lo:hi] = 0
+            self._mask_version = version
+        return self._mask
+
+    @torch.no_grad()
+    def step(self):
+        g = self.param_groups[0]
+        p, grad, buf, d = self.arena.flat_params, self.arena.flat_grads, self.momentum_buffer, self._d
+        torch.add(grad, p, alpha=g['weight_decay'], out=d)          # d = grad + wd * p
+        mask = self._active_mask()
+        if mask is not None:
+            d.mul_(mask)                                            # a never-touched slice: no decay, buffer stays zero
+        if g['momentum'] != 0:
+            buf.mul_(g['momentum']).add_(d)                         # first live step: buf = d (torch clones d there)
+            p.add_(buf, alpha=-g['lr'])
+        else:
+            p.add_(d, alpha=-g['lr'])
+
+    def zero_grad(self, set_to_none=False):
+        self.arena.zero_grad()
+
+    def state_dict(self):
+        return {'momentum_buffer': self.momentum_buffer, 'param_groups': [{k: v for k, v in self.param_groups[0].items() if k != 'params'}]}
+
+    def load_state_dict(self, sd):
+        self.momentum_buffer.copy_(sd['momentum_buffer'])
+        self.param_groups[0].update(sd['param_groups'][0])
 
 
 def _allreduce_coalesced(tensors, world_size, bucket_size_mb=-1, group=None):

@@ -333,7 +333,7 @@ def two_stage_main(a, rank, world, dev):
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
     from two_stage_bench import synthetic_gt
     from mr3d_amd.detector import TwoStageDetector3D
-    from mr3d_amd.dist_utils import DetectorArena, broadcast_params, train_step
+    from mr3d_amd.dist_utils import ArenaSGD, DetectorArena, broadcast_params, train_step
     D, H, W = a.vol
     torch.manual_seed(0)
     bf = getattr(a, 'dtype', 'f32') == 'bf16'           # BASELINE configs[4] storage type on the configs[2] / [3] step
@@ -342,7 +342,7 @@ def two_stage_main(a, rank, world, dev):
     arena = DetectorArena(det)
     if world > 1:
         broadcast_params(arena.flat_params)
-    opt = torch.optim.SGD([arena.flat_params], lr=0.001, momentum=0.9, weight_decay=1e-4)     # configs/...py:235
+    opt = ArenaSGD(arena, lr=0.001, momentum=0.9, weight_decay=1e-4)     # configs/...py:235
     rng = np.random.default_rng(100 + rank)
     img = torch.randn(1, 3, D, H, W, device=dev)
     gt, masks = synthetic_gt(rng, 12, D, H, W, dev)

@@ -724,6 +724,12 @@ void mr3d_plan_set_side_stream(int enable);
  * stem's parameters starts on a communication stream as soon as their gradient finishing is done, underneath the stem's
  * weight-gradient kernel. */
 int mr3d_plan_stream_wait_mark(int slot, mr3d_stream_t stream);
+/* The same wait for a consumer that must KNOW whether it is ordered: *waited = 1 when `stream` now waits for the point a
+ * SYNC(mark, slot) record really recorded since the last checked wait on that slot; *waited = 0 (and no wait) when the slot
+ * was not recorded by a live run -- side stream disabled (mr3d_plan_set_side_stream(0): SYNC records are skipped), the plan
+ * was captured into a hipGraph (a replay never re-records the event), or no plan has run.  The caller then orders itself
+ * behind the stream the plan ran on.  A recorded mark is consumed by one checked wait. */
+int mr3d_plan_stream_wait_mark_checked(int slot, mr3d_stream_t stream, int *waited);
 typedef struct { void *start, *stop; } mr3d_event_pair;
 int mr3d_plan_run_marked(const mr3d_op *ops_host, int num_ops, int *failed_index_host, mr3d_stream_t stream, const int *marks,
                          int num_marks, mr3d_event_pair *pairs);

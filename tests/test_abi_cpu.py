@@ -84,3 +84,84 @@ def test_compiled_extension_modules_export_the_reference_entry_points():
         roi_align_cuda.forward3d(torch.zeros(1, 4, 2, 4, 4), torch.zeros(1, 7), 1, 2, 2, 1.0, 1.0, 2, torch.zeros(1, 4, 1, 2, 2))
     with pytest.raises(NotImplementedError):
         nms_cuda.nms(torch.zeros((3, 5)), 0.5)
+
+
+def _conv_desc(k, s, h, w, cin, cout, d=4, relu=0, up=False):
+    from mr3d_amd import _hip
+    c = _hip.Conv3dDesc()
+    c.n, c.d, c.h, c.w_in, c.cin, c.cout = 1, d, h, w, cin, cout
+    c.kd = c.kh = c.kw = k
+    c.sd = c.sh = c.sw = s
+    c.pd = c.ph = c.pw = k // 2
+    c.relu = relu
+    c.workspace_bytes = -1
+    if up:
+        c.up = 64
+        c.up_d, c.up_h, c.up_w = (d + 1) // 2, (h + 1) // 2, (w + 1) // 2
+    return c
+
+
+def test_conv3d_size_guards_sit_exactly_at_the_documented_limits():
+    """include/mr3d.h 'Size limits': the fp32 conv kernels use 24-bit products / 32-bit byte offsets inside a tile.  Above a
+    limit: MR3D_ERR_UNSUPPORTED before anything is launched; just below: a kernel instance is chosen
+    (mr3d_conv3d_forward_variant launches nothing).  The streaming pointwise kernels index with 64 bits and stay available."""
+    import ctypes
+    from mr3d_amd import _hip
+    L = _hip.lib()
+    OK, UNSUPPORTED = 0, 4
+    v = _hip.Conv3dVariant()
+    probe = lambda c: L.mr3d_conv3d_forward_variant(ctypes.byref(c), ctypes.byref(v))
+    # h * w * cin: 2^24 elements is out, one column less is in
+    assert probe(_conv_desc(3, 1, 512, 512, 64, 64)) == UNSUPPORTED
+    assert probe(_conv_desc(3, 1, 512, 511, 64, 64)) == OK
+    # the real entry point with non-null operands: refused by the guard, nothing launched (no GPU needed)
+    c = _conv_desc(3, 1, 512, 512, 64, 64)
+    c.x = c.w = c.y = 64
+    assert L.mr3d_conv3d_forward(ctypes.byref(c), None) == UNSUPPORTED
+    # h * w: 2^20 positions is out
+    # (stride-2 instance: the only fp32 3x3x3 form that takes 8 input channels, so h * w * cin = 2^23 stays inside its own limit)
+    assert probe(_conv_desc(3, 2, 1024, 1024, 8, 16, d=2)) == UNSUPPORTED
+    assert probe(_conv_desc(3, 2, 1024, 1023, 8, 16, d=2)) == OK
+    # output plane y_h * y_w * cout * ys_d below 2^25 elements
+    assert probe(_conv_desc(3, 1, 256, 256, 16, 512)) == UNSUPPORTED        # 2^16 * 2^9 = 2^25
+    assert probe(_conv_desc(3, 1, 256, 255, 16, 512)) == OK
+    # weights below 2^29 elements: 27 * 4096 * 8192 > 2^29
+    assert probe(_conv_desc(3, 1, 8, 8, 4096, 8192)) == UNSUPPORTED
+    assert probe(_conv_desc(3, 1, 8, 8, 2048, 4096)) == OK                  # 27 * 2^23 < 2^29
+    # a 1x1x1 convolution on a 512 x 512 x 64 plane takes the streaming kernel (64-bit indexing), guard or not
+    assert probe(_conv_desc(1, 1, 512, 512, 64, 64, d=2)) == OK and v.streaming_pointwise == 1
+    # strided 3x3x3 data gradient (parity-decomposed): same ranges on the dy plane
+    d = _conv_desc(3, 1, 512, 512, 64, 64)
+    d.x = d.w = d.y = 64
+    d.pd = d.ph = d.pw = 0
+    d.y_d, d.y_h, d.y_w = 2 * 4 - 1, 2 * 512 - 1, 2 * 512 - 1
+    assert L.mr3d_conv3d_dgrad_s2k3(ctypes.byref(d), None) == UNSUPPORTED
+
+
+def test_stem_size_guard():
+    """stem kernels: byte offsets inside one channel volume stay below 2^30 (d * h * w < 2^28), output below 2^31 elements"""
+    import ctypes
+    from mr3d_amd import _hip
+    L = _hip.lib()
+    p = ctypes.c_void_p(64)
+    assert L.mr3d_stem_conv_forward(p, p, p, p, 1, 1024, 512, 512, 1, None) == 4         # 2^28 voxels
+    assert L.mr3d_stem_conv_wgrad_ws(p, p, p, p, 1, 1024, 512, 512, None, ctypes.c_longlong(0), None) == 4
+    assert L.mr3d_stem_conv_forward(p, p, p, p, 9, 1000, 512, 512, 1, None) == 4         # volume fits, output 9 * 1000 * 256 * 256 * 64 B >= 2^31
+
+
+def test_up_even_flag_is_refused_where_no_kernel_implements_it():
+    """MR3D_CONV_UP_EVEN (the even-position add of a stride-2 adjoint) exists in the generic fp32 kernel and the streaming
+    pointwise kernels.  The two-dimensional Winograd instances must not be chosen for it, and the bf16 entry point refuses it."""
+    import ctypes
+    from mr3d_amd import _hip
+    L = _hip.lib()
+    v = _hip.Conv3dVariant()
+    plain = _conv_desc(3, 1, 128, 128, 64, 64, d=40)
+    assert L.mr3d_conv3d_forward_variant(ctypes.byref(plain), ctypes.byref(v)) == 0 and v.winograd == 8
+    flagged = _conv_desc(3, 1, 128, 128, 64, 64, d=40, relu=_hip.CONV_UP_EVEN, up=True)
+    assert L.mr3d_conv3d_forward_variant(ctypes.byref(flagged), ctypes.byref(v)) == 0 and v.winograd != 8
+    narrow = _conv_desc(3, 1, 128, 128, 16, 16, d=40, relu=_hip.CONV_UP_EVEN, up=True)
+    assert L.mr3d_conv3d_forward_variant(ctypes.byref(narrow), ctypes.byref(v)) == 0 and v.winograd != 8
+    b = _conv_desc(3, 1, 32, 32, 64, 64, relu=_hip.CONV_UP_EVEN, up=True)
+    b.x = b.w = b.y = 64
+    assert L.mr3d_conv3d_forward_bf16(ctypes.byref(b), None) == 4

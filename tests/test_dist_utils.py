@@ -245,3 +245,65 @@ def test_dist_optimizer_step_keeps_arena_grads_attached():
     model(torch.randn(8, 4)).pow(2).sum().backward()
     assert all(p.grad.untyped_storage().data_ptr() == base for p in model.parameters())
     assert arena.flat_grads.abs().sum() > 0
+
+
+class _LateHeadDetector(torch.nn.Module):
+    """a detector whose mask head receives no gradient before iteration `first_mask_iter` (no positive roi yet): the
+    reference neither exchanges nor steps a parameter whose .grad is None (mmdet/core/utils/dist_utils.py:32-35)"""
+
+    def __init__(self):
+        super().__init__()
+        self.backbone = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 8))
+        self.bbox_head = torch.nn.Linear(8, 6)
+        self.mask_head = torch.nn.Linear(8, 4)
+        self.never_used = torch.nn.Linear(3, 3)
+        self.with_mask = False
+
+    def forward_train(self, x, reg_t, mask_t):
+        f = self.backbone(x)
+        losses = dict(loss_reg=torch.nn.functional.smooth_l1_loss(self.bbox_head(f), reg_t))
+        if self.with_mask:
+            losses['loss_mask'] = torch.nn.functional.mse_loss(self.mask_head(f), mask_t)
+        return losses
+
+    @staticmethod
+    def total_loss(losses):
+        return sum(v for k, v in losses.items() if 'loss' in k)
+
+
+def test_arena_sgd_equals_per_parameter_sgd_with_grads_none():
+    """ArenaSGD over the flat arena == torch.optim.SGD over the separate parameters, where parameters that have not yet received a
+    gradient have .grad None (skipped: no weight decay, no momentum) and, once they have had one, keep being stepped after an
+    in-place zero (torch 1.0's zero_grad, which the reference runs under)."""
+    import copy
+    import mr3d_amd  # noqa: F401
+    from mr3d_amd.dist_utils import ArenaSGD, DetectorArena, train_step
+    torch.manual_seed(3)
+    ref = _LateHeadDetector()
+    det = copy.deepcopy(ref)
+    arena = DetectorArena(det, engine_attr=None)
+    opt = ArenaSGD(arena, lr=0.05, momentum=0.9, weight_decay=0.01)
+    ref_opt = torch.optim.SGD(ref.parameters(), lr=0.05, momentum=0.9, weight_decay=0.01)
+    gen = torch.Generator().manual_seed(9)
+    for it in range(6):
+        ref.with_mask = det.with_mask = it in (2, 3)           # the mask loss exists in iterations 2 and 3 only
+        x, reg_t, mask_t = torch.randn(5, 6, generator=gen), torch.randn(5, 6, generator=gen), torch.randn(5, 4, generator=gen)
+        # reference order: zero (in place: .grad stays a tensor once it exists), backward, step
+        for p in ref.parameters():
+            if p.grad is not None:
+                p.grad.zero_()
+        ref.total_loss(ref.forward_train(x, reg_t, mask_t)).backward()
+        ref_opt.step()
+        train_step(det, arena, opt, ((x, reg_t, mask_t), {}), world_size=1, grad_clip=None)
+        for (n, a), b in zip(ref.named_parameters(), det.parameters()):
+            assert torch.allclose(a, b, rtol=1e-6, atol=1e-7), (it, n)
+        if it < 2:
+            assert len(arena.untouched_ranges()) == 4           # mask head + the unused layer: weight and bias each
+    # the never-used layer was never decayed; the mask head was decayed from iteration 2 on, also in 4 and 5 (zero gradient)
+    assert torch.equal(ref.never_used.weight, det.never_used.weight)
+    init = _LateHeadDetector
+    torch.manual_seed(3)
+    fresh = init()
+    assert torch.equal(fresh.never_used.weight, det.never_used.weight)
+    assert not torch.equal(fresh.mask_head.weight, det.mask_head.weight)
+    assert len(arena.untouched_ranges()) == 2

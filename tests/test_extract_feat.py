@@ -347,3 +347,47 @@ def test_engine_gradients_at_its_own_activation_pattern(shape):
           f'worst L2 rel {worst_l2[1]:.2e} ({worst_l2[0]})')
     assert worst_max[1] <= 1e-3, worst_max
     assert worst_l2[1] <= 2e-4, worst_l2
+
+
+@pytest.mark.gpu
+def test_overlapped_exchange_is_ordered_when_the_mark_was_not_recorded():
+    """dist_utils.allreduce_overlapped starts its big collective behind the backward plan's MARK_GRADS_BUT_STEM point.  The
+    checked wait (mr3d_plan_stream_wait_mark_checked) must say when that point does not exist for this step -- side stream
+    off, plan replayed from a hipGraph -- so that the communication stream falls back to waiting for the caller's stream."""
+    import mr3d_amd  # noqa: F401
+    from mr3d_amd import _hip
+    from mr3d_amd.detector import ExtractFeat3D
+    dev = torch.device('cuda:0')
+    torch.manual_seed(5)
+    eng = ExtractFeat3D(device=dev)
+    x = torch.randn(1, 3, 16, 64, 64, device=dev)
+    cots = [torch.randn_like(o) for o in eng.forward_features(x)]
+    comm = torch.cuda.Stream(device=dev)
+    slot = eng.MARK_GRADS_BUT_STEM
+
+    def fwd_bwd():
+        eng.zero_grad()
+        eng.forward_features(x)
+        eng.backward_features(cots)
+
+    fwd_bwd()
+    assert _hip.plan_stream_wait_mark_checked(slot, comm) is True          # live run: recorded
+    assert _hip.plan_stream_wait_mark_checked(slot, comm) is False         # consumed: one wait per recorded mark
+    fwd_bwd()
+    assert _hip.plan_stream_wait_mark_checked(slot, comm) is True
+    g_ref = eng.flat_grads.clone()
+    try:
+        _hip.lib().mr3d_plan_set_side_stream(0)
+        fwd_bwd()
+        assert _hip.plan_stream_wait_mark_checked(slot, comm) is False     # SYNC records were skipped
+    finally:
+        _hip.lib().mr3d_plan_set_side_stream(1)
+    fwd_bwd()
+    assert _hip.plan_stream_wait_mark_checked(slot, comm) is True
+    eng.capture(eng._plan_for(x.shape))                                    # capture "records" the mark as a graph node only
+    assert _hip.plan_stream_wait_mark_checked(slot, comm) is False
+    fwd_bwd()                                                              # graph replay: the event is not re-recorded
+    assert _hip.plan_stream_wait_mark_checked(slot, comm) is False
+    torch.cuda.synchronize()
+    scale = g_ref.abs().max().item()
+    assert (eng.flat_grads - g_ref).abs().max().item() <= 1e-5 * scale

@@ -23,7 +23,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mr3d_amd  # noqa: E402
 from mr3d_amd.datasets import prepare_volume  # noqa: E402
 from mr3d_amd.detector import TwoStageDetector3D2Scales  # noqa: E402
-from mr3d_amd.dist_utils import DetectorArena, broadcast_params, train_step  # noqa: E402
+from mr3d_amd.dist_utils import ArenaSGD, DetectorArena, broadcast_params, train_step  # noqa: E402
 
 
 def synthetic_sample(rng, D, H, W, dev, n_gt=6):
@@ -62,7 +62,7 @@ def main():
     det.extract.init_weights()
     arena = DetectorArena(det)
     broadcast_params(arena.flat_params)                          # identical initial weights (mmcv DDP init)
-    opt = torch.optim.SGD([arena.flat_params], lr=a.lr, momentum=0.9, weight_decay=1e-4)
+    opt = ArenaSGD(arena, lr=a.lr, momentum=0.9, weight_decay=1e-4)
     rng = np.random.default_rng(100 + rank)                      # every rank draws its own volumes (DistributedSampler)
     t0 = time.perf_counter()
     for it in range(a.iters):
