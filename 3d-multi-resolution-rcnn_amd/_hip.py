@@ -211,7 +211,7 @@ class RpnLevel(ctypes.Structure):
                [(n, ctypes.c_int) for n in ('anchors', 'depth', 'height', 'width')]
 
 
-def rpn_select_topk(cls_maps, valid_flags, nms_pre):
+def rpn_select_topk(cls_maps, valid_flags, nms_pre, counts_out=None):
     """mr3d_rpn_select_topk over all pyramid levels at once.  cls_maps[l]: [A, D, H, W] fp32 device logits (any strides);
     valid_flags[l]: uint8 / bool [A*D*H*W] in flat (h, w, d, a) order or None.  Returns (caps, flat int64 [sum caps], scores
     fp32 [sum caps], counts int32 [L] ON THE DEVICE): level l owns rows [sum caps[:l], +caps[l]), the first counts[l] real."""
@@ -235,7 +235,9 @@ def rpn_select_topk(cls_maps, valid_flags, nms_pre):
     K = sum(caps)
     flat = torch.empty(K, dtype=torch.long, device=dev)
     scores = torch.empty(K, dtype=torch.float32, device=dev)
-    counts = torch.empty(L, dtype=torch.int32, device=dev)
+    # counts_out: a caller-owned int32 [L] slice (the dual-pathway detector keeps both pathways' counts in one tensor)
+    counts = torch.empty(L, dtype=torch.int32, device=dev) if counts_out is None else counts_out
+    assert counts.dtype == torch.int32 and counts.numel() == L and counts.is_contiguous()
     lib_ = lib()
     wsb = _sz(lib_.mr3d_rpn_select_topk_workspace_bytes, lv, L, int(nms_pre))
     if wsb == 0:

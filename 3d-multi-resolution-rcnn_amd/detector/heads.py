@@ -356,6 +356,28 @@ class SharedFCBBoxHead3D(nn.Module):
         return losses
 
 
+def rpn_get_bboxes_pair(head_a, outs_a, metas_a, head_b, outs_b, metas_b, cfg, use_pos_indices=False):
+    """`head_a.get_bboxes(*outs_a, metas_a, cfg, with_counts=True)` and the same for the second pathway's head
+    (two_stage_3d_2scales.py:170-176) -- with ONE NMS3D launch sequence over both pathways' level sets when each pathway holds
+    one image and the sync-free path applies (rpn_proposals.get_bboxes_pair_device); otherwise the two separate calls.
+    Returns ((proposal list, counts), (proposal list 2, counts 2))."""
+    from .rpn_proposals import get_bboxes_pair_device, _device_path_ok, _as_cfg
+    c = _as_cfg(cfg)
+    if len(metas_a) == 1 and len(metas_b) == 1 and _device_path_ok([t[0] for t in outs_a[0]], c) and \
+            _device_path_ok([t[0] for t in outs_b[0]], c):
+        def pack(head, outs, meta):
+            flags = getattr(head, 'pos_indices', None) if use_pos_indices else None
+            vf = None if flags is None else [f if f.dim() == 1 else f[0] for f in flags]
+            return ([t[0] for t in outs[0]], [t[0] for t in outs[1]], head.anchor_generators, head.anchor_strides,
+                    head.anchor_strides_depth, meta['img_shape'], head.target_means, head.target_stds), vf
+        args_a, vf_a = pack(head_a, outs_a, metas_a[0])
+        args_b, vf_b = pack(head_b, outs_b, metas_b[0])
+        (pa, ca), (pb, cb_) = get_bboxes_pair_device(args_a, args_b, c, vf_a, vf_b)
+        return ([pa], [ca]), ([pb], [cb_])
+    return (head_a.get_bboxes(*outs_a, metas_a, cfg, use_pos_indices=use_pos_indices, with_counts=True),
+            head_b.get_bboxes(*outs_b, metas_b, cfg, use_pos_indices=use_pos_indices, with_counts=True))
+
+
 class _ConvModule(nn.Module):
     """parameter container named like ConvModule3D (`convs.0.conv.weight`, conv_module3d.py:34)"""
 

@@ -34,8 +34,23 @@ def get_bboxes_single_device(cls_scores, bbox_preds, anchor_generators, anchor_s
     the device).  Launch sequence: radix select of the nms_pre best valid anchors of all levels (mr3d_rpn_select_topk), one
     decode per level, batched NMS3D with device-side row counts, merge of the levels' kept rows into the max_num best."""
     cfg = _as_cfg(cfg)
-    caps, flat, scores, counts = _hip.rpn_select_topk(cls_scores, valid_flags, cfg.nms_pre)
-    dets = torch.empty((sum(caps), 7), dtype=torch.float32, device=flat.device)
+    caps = _level_caps(cls_scores, cfg)
+    dets = torch.empty((sum(caps), 7), dtype=torch.float32, device=cls_scores[0].device)
+    counts = torch.empty(len(caps), dtype=torch.int32, device=dets.device)
+    _select_and_decode(cls_scores, bbox_preds, anchor_generators, anchor_strides, anchor_strides_depth, img_shape, cfg,
+                       target_means, target_stds, valid_flags, dets, counts)
+    keep, num_keep = _hip.nms3d_batched_dev(dets, caps, counts, cfg.nms_thr)
+    return _hip.rpn_merge_levels(dets, caps, keep, num_keep, cfg.nms_post, cfg.max_num)
+
+
+def _level_caps(cls_scores, cfg):
+    return [min(int(c.numel()), int(cfg.nms_pre)) for c in cls_scores]
+
+
+def _select_and_decode(cls_scores, bbox_preds, anchor_generators, anchor_strides, anchor_strides_depth, img_shape, cfg,
+                       target_means, target_stds, valid_flags, dets, counts):
+    """top-`nms_pre` selection of every level + decode into the caller's `dets` rows / `counts` slots"""
+    caps, flat, scores, _ = _hip.rpn_select_topk(cls_scores, valid_flags, cfg.nms_pre, counts_out=counts)
     row = 0
     for lvl, (cls, reg) in enumerate(zip(cls_scores, bbox_preds)):
         A, D, H, W = cls.shape
@@ -48,8 +63,29 @@ def get_bboxes_single_device(cls_scores, bbox_preds, anchor_generators, anchor_s
                               (D, H, W), anchor_strides[lvl], anchor_strides_depth[lvl], target_means, target_stds, img_shape,
                               out=dets[row:row + k])
         row += k
-    keep, num_keep = _hip.nms3d_batched_dev(dets, caps, counts, cfg.nms_thr)
-    return _hip.rpn_merge_levels(dets, caps, keep, num_keep, cfg.nms_post, cfg.max_num)
+    return caps
+
+
+def get_bboxes_pair_device(args_a, args_b, cfg, valid_flags_a=None, valid_flags_b=None):
+    """The two pathways of the dual-pathway detector (two_stage_3d_2scales.py:170-176: `proposal_list`, `proposal_list_2`) with
+    ONE NMS3D launch sequence over both pathways' level sets (10 independent sets; the reference issues 10 nms() calls).
+    args_*: (cls_scores, bbox_preds, anchor_generators, anchor_strides, anchor_strides_depth, img_shape, target_means,
+    target_stds) of one image of a pathway.  Returns ((proposals, count), (proposals_2, count_2)) as get_bboxes_single_device
+    does per pathway -- same rows, bit for bit (the sets are independent problems)."""
+    cfg = _as_cfg(cfg)
+    caps_a, caps_b = _level_caps(args_a[0], cfg), _level_caps(args_b[0], cfg)
+    dev = args_a[0][0].device
+    ra = sum(caps_a)
+    dets = torch.empty((ra + sum(caps_b), 7), dtype=torch.float32, device=dev)
+    counts = torch.empty(len(caps_a) + len(caps_b), dtype=torch.int32, device=dev)
+    for args, vf, d, c in ((args_a, valid_flags_a, dets[:ra], counts[:len(caps_a)]),
+                           (args_b, valid_flags_b, dets[ra:], counts[len(caps_a):])):
+        cls, reg, gens, st, std, shape, means, stds = args
+        _select_and_decode(cls, reg, gens, st, std, shape, cfg, means, stds, vf, d, c)
+    keep, num_keep = _hip.nms3d_batched_dev(dets, caps_a + caps_b, counts, cfg.nms_thr)
+    out_a = _hip.rpn_merge_levels(dets[:ra], caps_a, keep[:ra], num_keep[:len(caps_a)], cfg.nms_post, cfg.max_num)
+    out_b = _hip.rpn_merge_levels(dets[ra:], caps_b, keep[ra:], num_keep[len(caps_a):], cfg.nms_post, cfg.max_num)
+    return out_a, out_b
 
 
 def get_bboxes_single(cls_scores, bbox_preds, anchor_generators, anchor_strides, anchor_strides_depth, img_shape, cfg,

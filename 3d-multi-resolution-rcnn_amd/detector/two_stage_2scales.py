@@ -15,7 +15,7 @@ from .. import _hip
 from ..core.bbox import build_assigner, build_sampler, delta2bbox3D, bbox2roi3D
 from ..core.post_processing import multiclass_nms_3d
 from ..core.mask import mask_target_single
-from .heads import RPNHead3D, SharedFCBBoxHead3D, FCNMaskHead3D
+from .heads import RPNHead3D, SharedFCBBoxHead3D, FCNMaskHead3D, rpn_get_bboxes_pair
 from .roi_extractor import SingleRoIExtractor
 from .two_stage import TwoStageDetector3D, bbox2result3D, PosCountReadback, MASK_BATCH_BUCKETS
 
@@ -119,8 +119,9 @@ class TwoStageDetector3D2Scales(TwoStageDetector3D):
             if proposals is None:
                 # fixed-capacity blocks + device-side row counts: no host round trip (detector/rpn_proposals.py)
                 pcfg = SimpleNamespace(**cfg['rpn_proposal'])
-                proposal_list, pc1 = self.rpn_head.get_bboxes(*rpn_outs, img_meta, pcfg, use_pos_indices=True, with_counts=True)
-                proposal_list_2, pc2 = self.rpn_head_2.get_bboxes(*rpn_outs_2, img_meta_2, pcfg, use_pos_indices=True, with_counts=True)
+                # both pathways' 10 level sets share ONE NMS3D launch sequence (detector/heads.rpn_get_bboxes_pair)
+                (proposal_list, pc1), (proposal_list_2, pc2) = rpn_get_bboxes_pair(
+                    self.rpn_head, rpn_outs, img_meta, self.rpn_head_2, rpn_outs_2, img_meta_2, pcfg, use_pos_indices=True)
             else:                       # (proposal lists of pathway 1, of pathway 2 [, their counts]): the `else` branch of :176-177
                 proposal_list, proposal_list_2 = proposals[:2]
                 pc1, pc2 = proposals[2:4] if len(proposals) >= 4 else ([None] * len(proposal_list), [None] * len(proposal_list_2))
@@ -197,8 +198,8 @@ class TwoStageDetector3D2Scales(TwoStageDetector3D):
         x_2 = self.extract_feat(imgs_2, 1, train=False)
         rcfg = SimpleNamespace(**cfg['rpn'])
         if proposals is None:
-            proposal_list, pc1 = self.rpn_head.get_bboxes(*self.rpn_head(x), img_metas, rcfg, with_counts=True)
-            proposal_list_2, pc2 = self.rpn_head_2.get_bboxes(*self.rpn_head_2(x_2), img_metas_2, rcfg, with_counts=True)
+            (proposal_list, pc1), (proposal_list_2, pc2) = rpn_get_bboxes_pair(
+                self.rpn_head, self.rpn_head(x), img_metas, self.rpn_head_2, self.rpn_head_2(x_2), img_metas_2, rcfg)
         else:
             proposal_list = proposal_list_2 = proposals
             pc1 = pc2 = [None]

@@ -88,10 +88,61 @@ def cpu_baseline(seconds):
             break
     per_small = el / n
     scale = 432.34 / 10.81
-    return {'value': 1.0 / (per_small * scale), 'unit': 'iters/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'host_cpus': avail,
-            'sample': f'{n} fwd+bwd iterations of the PyTorch-CPU (oneDNN) restatement on 1x3x32x128x128 '
-                      f'({per_small * 1e3:.1f} ms each), scaled x{scale:.1f} by algorithmic FLOPs to 512x512x80'}
+    res = {'value': 1.0 / (per_small * scale), 'unit': 'iters/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+           'host_cpus': avail,
+           'sample': f'{n} fwd+bwd iterations of the PyTorch-CPU (oneDNN) restatement on 1x3x32x128x128 '
+                     f'({per_small * 1e3:.1f} ms each), scaled x{scale:.1f} by algorithmic FLOPs to 512x512x80'}
+    # BASELINE.md section 3, C1 "optionally 1x3x80x512x512 (one iteration)": the metric's own size, measured, next to the
+    # scaled figure -- skipped when the scaled estimate says it would not fit the budget (one warm-up + one timed iteration)
+    if per_small * scale * 2 <= max(seconds, 20.0):
+        try:
+            xl = torch.randn(1, 3, 80, 512, 512)
+
+            def big():
+                m.zero_grad()
+                sum(o.sum() for o in m(xl)).backward()
+            big()
+            t0 = time.perf_counter()
+            big()
+            t_big = time.perf_counter() - t0
+            res['full_size'] = {'value': 1.0 / t_big, 'unit': 'iters/s', 'seconds_per_iter': t_big,
+                                'sample': 'ONE timed fwd+bwd iteration (after one warm-up) of the same restatement on 1x3x80x512x512'}
+        except Exception as exc:          # host memory: the activations of the full-size graph need several GB
+            res['full_size'] = {'error': repr(exc)}
+    return res
+
+
+def cpu_baseline_allreduce(seconds):
+    """the reference's gradient exchange (SUM all-reduce + 1/world of ONE flat 25.98 M-element fp32
+    buffer, mmdet/core/utils/dist_utils.py:22-28) over gloo between 2 / 4 / 8 local CPU ranks: tools/gloo_mean_bench.py started
+    once per rank as a child process (the parent only waits).  A sanity baseline for the RCCL curve, not a target."""
+    import subprocess
+    numel = 25_980_000
+    out = {'unit': 'ms per exchange', 'mbytes': numel * 4 / 1e6, 'kind': 'port', 'host_cpus': _host_cores(),
+           'sample': 'gloo all_reduce(SUM) + div_(world) of a 103.9 MB fp32 buffer between local CPU ranks (one thread each), '
+                     'mean of 3 timed repetitions after a warm-up'}
+    script = os.path.join(ROOT, 'tools', 'gloo_mean_bench.py')
+    t_start = time.perf_counter()
+    for world in (2, 4, 8):
+        if time.perf_counter() - t_start > 2 * seconds:
+            out[f'ranks_{world}'] = None
+            continue
+        port = _free_port()
+        procs = [subprocess.Popen([sys.executable, script, str(numel), '3'], env=rank_env(r, world, port), stdout=subprocess.PIPE,
+                                  stderr=subprocess.DEVNULL, text=True) for r in range(world)]
+        val = None
+        for r, p in enumerate(procs):
+            try:
+                so, _ = p.communicate(timeout=180)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                so = ''
+            if r == 0:
+                for line in so.splitlines():
+                    if line.startswith('ms_per_exchange'):
+                        val = round(float(line.split()[1]), 2)
+        out[f'ranks_{world}'] = val
+    return out
 
 
 def _host_cores():
@@ -242,13 +293,19 @@ def ops_microbench(dev):
     # device for the merge kernel -- nothing is read back, so back-to-back calls measure the device time of the three kernels
     caps = [int(d.size(0)) for d in level_dets]
     cat = torch.cat(level_dets, 0).contiguous()
-    out['nms3d_us_per_vol'] = 2 * timed(lambda: _h.nms3d_batched_dev(cat, caps, None, 0.7), iters=50)
+    out['nms3d_one_pathway_us'] = timed(lambda: _h.nms3d_batched_dev(cat, caps, None, 0.7), iters=50)
+    # a volume = 2 pathways x 5 levels = 10 independent sets; the dual-pathway detector hands all ten to ONE launch sequence
+    # (detector/heads.rpn_get_bboxes_pair -> rpn_proposals.get_bboxes_pair_device); the second pathway's sets are a second draw
+    level_dets_2 = [d.to(dev) for d in nms_bench_inputs(g)]
+    cat10 = torch.cat(level_dets + level_dets_2, 0).contiguous()
+    caps10 = caps + [int(d.size(0)) for d in level_dets_2]
+    out['nms3d_us_per_vol'] = timed(lambda: _h.nms3d_batched_dev(cat10, caps10, None, 0.7), iters=50)
     # the same call followed by a read-back of the kept counts (what mmdet's nms() wrapper needs to size its result)
     out['nms3d_with_readback_us_per_vol'] = 2 * timed(lambda: _h.nms3d_batched(level_dets, 0.7))
     # algorithmic work: N(N-1)/2 IoU evaluations per level; latency-bound, so pairs/s is the figure of merit
-    pairs = sum(d.size(0) * (d.size(0) - 1) // 2 for d in level_dets)
-    out['nms3d_pairs_per_vol'] = 2 * pairs
-    out['nms3d_gpairs_per_s'] = 2 * pairs / out['nms3d_us_per_vol'] * 1e-3
+    pairs = sum(d.size(0) * (d.size(0) - 1) // 2 for d in level_dets + level_dets_2)
+    out['nms3d_pairs_per_vol'] = pairs
+    out['nms3d_gpairs_per_s'] = pairs / out['nms3d_us_per_vol'] * 1e-3
     # RoIAlign3D through SingleRoIExtractor over P2..P5: 512 rois x 64 ch x (3,7,7) and 128 rois x
     # (10,14,14); roi sizes log-uniform [4,128] px in xy and [2,40] in z, mapped to levels by the reference's rule
     from mr3d_amd.detector import SingleRoIExtractor
@@ -658,6 +715,10 @@ def main():
                 res['cpu_baseline']['ops'] = cpu_baseline_ops(min(a.cpu_seconds, 12.0))
             except Exception as exc:
                 res['cpu_baseline']['ops'] = {'error': repr(exc)}
+            try:        # C4: gloo mean of the 103.9 MB gradient buffer at 2 / 4 / 8 local ranks
+                res['cpu_baseline'].setdefault('ops', {})['allreduce_gloo'] = cpu_baseline_allreduce(min(a.cpu_seconds, 12.0))
+            except Exception as exc:
+                res['cpu_baseline'].setdefault('ops', {})['allreduce_gloo'] = {'error': repr(exc)}
         emit_json_line(res)
     if world > 1 or force_dist:
         dist.destroy_process_group()

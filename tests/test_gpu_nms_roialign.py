@@ -347,3 +347,26 @@ def test_compiled_extension_and_ctypes_forms_agree(dev):
         roi_align_cuda.forward3d(f, torch.zeros((2, 5), device=dev, dtype=f.dtype), 3, 7, 7, 0.25, 0.5, 2, o1)       # wrong roi size
     with pytest.raises(RuntimeError):
         roi_align_cuda.forward3d(f.permute(0, 1, 3, 2, 4), r, 3, 7, 7, 0.25, 0.5, 2, o1)                             # not contiguous
+
+
+def test_nms3d_long_dependency_chains_and_negative_threshold(dev):
+    """The chain sweep resolves block after block through published kept words: a set in which every box's fate depends on its
+    predecessor's (a row of boxes, each overlapping only its neighbours above the threshold) exercises every hand-over, and a
+    negative threshold (every pair with IoU >= 0 'overlaps', nms_kernel.cu:122 is a plain `>`) the no-skip instance."""
+    from mr3d_amd.mmdet_ops.nms import nms_cuda
+    for n in (64, 65, 1000, 2048):
+        x0 = np.arange(n, dtype=np.float32) * 2.0
+        dets = np.stack([x0, np.zeros(n), x0 + 9, np.full(n, 9.0), np.zeros(n), np.full(n, 9.0), np.linspace(0.9, 0.1, n)], 1).astype(np.float32)
+        for thr in (0.5, 0.6, 0.25):
+            exp = orc.nms3d(dets, thr)
+            got = nms_cuda.nms_3d(torch.from_numpy(dets).to(dev), thr)
+            np.testing.assert_array_equal(got.cpu().numpy(), exp)
+        # the same row in reverse score order: the chain runs from the last box to the first
+        dets[:, 6] = np.linspace(0.1, 0.9, n)
+        np.testing.assert_array_equal(nms_cuda.nms_3d(torch.from_numpy(dets).to(dev), 0.5).cpu().numpy(), orc.nms3d(dets, 0.5))
+    rng = np.random.default_rng(3)
+    d = np.concatenate([rng.uniform(0, 100, (300, 3)), rng.uniform(0, 1, (300, 4))], 1)
+    d = np.stack([d[:, 0], d[:, 1], d[:, 0] + 10 * d[:, 3] + 2, d[:, 1] + 10 * d[:, 4] + 2, d[:, 2], d[:, 2] + 5 * d[:, 5] + 1, d[:, 6]], 1).astype(np.float32)
+    got = nms_cuda.nms_3d(torch.from_numpy(d).to(dev), -0.5)
+    np.testing.assert_array_equal(got.cpu().numpy(), orc.nms3d(d, -0.5))
+    assert got.numel() == 1                                              # IoU >= 0 > -0.5 for every pair: only the best survives

@@ -154,6 +154,32 @@ def test_rpn_get_bboxes_single_vs_restatement(dev, channels_last, nms_post):
     np.testing.assert_allclose(canon(g), canon(e), rtol=2e-6, atol=2e-4)
 
 
+def test_pair_proposals_one_nms_call_equals_two_separate_calls(dev):
+    """rpn_proposals.get_bboxes_pair_device: both pathways of the dual-pathway detector (two_stage_3d_2scales.py:170-176) through
+    ONE NMS3D launch sequence over their 2 x L level sets -- every row and both counts equal the per-pathway calls exactly."""
+    from mr3d_amd.core import AnchorGenerator3D
+    from mr3d_amd.detector.rpn_proposals import get_bboxes_pair_device, get_bboxes_single_device
+    torch.manual_seed(5)
+    strides, dstrides = [4, 8, 16], [2, 4, 8]
+    gens = [AnchorGenerator3D(s, [2], [2], [1.0], ds) for s, ds in zip(strides, dstrides)]
+    cfg = dict(nms_across_levels=False, nms_pre=1500, nms_post=1500, max_num=1000, nms_thr=0.7, min_bbox_size=0)
+    means, stds = (0.,) * 6, (1.,) * 6
+
+    def pathway(sizes, img_shape, flag_p):
+        cls = [torch.randn(1, d, h, w, device=dev) * 2 for d, h, w in sizes]
+        reg = [(torch.randn(6, d, h, w, device=dev) * 0.4).permute(1, 2, 3, 0).contiguous().permute(3, 0, 1, 2) for d, h, w in sizes]
+        flags = None if flag_p is None else [(torch.rand(d * h * w, device=dev) < flag_p).to(torch.uint8) for d, h, w in sizes]
+        return (cls, reg, gens, strides, dstrides, img_shape, means, stds), flags
+
+    a, fa = pathway([(10, 32, 32), (5, 16, 16), (3, 8, 8)], (128, 128, 3, 20), 0.7)
+    b, fb = pathway([(15, 48, 48), (8, 24, 24), (4, 12, 12)], (192, 192, 3, 30), None)      # the 1.5x pathway
+    (pa, ca), (pb, cb) = get_bboxes_pair_device(a, b, cfg, fa, fb)
+    for args, flags, p, c in ((a, fa, pa, ca), (b, fb, pb, cb)):
+        ep, ec = get_bboxes_single_device(*args[:6], cfg, args[6], args[7], valid_flags=flags)
+        assert int(c) == int(ec) and int(c) > 0
+        assert torch.equal(p, ep)
+
+
 def test_multiclass_nms_3d_vs_restatement(dev):
     from mr3d_amd.core import multiclass_nms_3d
     rng = np.random.default_rng(4)
