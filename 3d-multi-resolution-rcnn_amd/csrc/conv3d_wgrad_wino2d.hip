@@ -268,6 +268,13 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wgrad_wino2d_kernel(Conv3d
   }
 }
 
+
+// Round 4, measured and rejected: ALL THREE kd per workgroup (one staging of the dy tile and one E transform for the 72 products of
+// the three kd, the four input planes of a tile transformed once): 2.0 instead of 4.8 vector instructions per MFMA, but the 3 x 24
+// product matrices of a 16 x 64 block are 288 accumulator registers per lane with four waves (the compiler swapped them between
+// the two register files around every MFMA) or 144 with eight waves and 113 KB of LDS -- either way ONE workgroup per CU, whose
+// staging / transform / MFMA phases then have nothing to overlap with: P2 map 1170 us against 729 us for this kernel (two
+// workgroups per CU), P3 191 against 127.  The CU's register file cannot hold two such blocks, so the form above stays.
 }  // namespace
 
 bool mr3d_conv3d_wgrad_wino2d_ok(const Conv3dWgradArgs &a) {

@@ -22,3 +22,8 @@ extern "C" int mr3d_device_ok(void) {
   if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
   return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
 }
+
+// measurement knobs (include/mr3d.h): plain ints read by the dispatch code, 0 = shipped default
+int g_mr3d_tuning[MR3D_TUNE_NUM_KEYS] = {};
+extern "C" void mr3d_tuning_set(int key, int value) { if (key >= 0 && key < MR3D_TUNE_NUM_KEYS) g_mr3d_tuning[key] = value; }
+extern "C" int mr3d_tuning_get(int key) { return key >= 0 && key < MR3D_TUNE_NUM_KEYS ? g_mr3d_tuning[key] : 0; }

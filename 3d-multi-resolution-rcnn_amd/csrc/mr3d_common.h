@@ -8,6 +8,8 @@
 
 #define MR3D_WAVE 64
 
+extern int g_mr3d_tuning[MR3D_TUNE_NUM_KEYS];          // mr3d_tuning_set (mr3d_api.hip)
+
 static inline hipStream_t mr3d_stream(mr3d_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 // hipGetLastError() also clears the sticky error, so a failed call does not poison the next one

@@ -250,6 +250,7 @@ int plan_run_impl(const mr3d_op *ops, int num_ops, int *failed_index, mr3d_strea
   const void *dw_seen[kMaxDwSeen];
   bool dw_queue[kMaxDwSeen];
   int n_dw_seen = 0;
+  const int skip_mask = g_mr3d_tuning[MR3D_TUNE_PLAN_SKIP];
   const unsigned char *armed_live = nullptr;          // set by a VOXEL_LIVENESS record with arm = 1, taken by the next CONV_FWD
   for (int k = 0; k < num_ops; ++k) {
     int st = MR3D_OK;
@@ -278,6 +279,19 @@ int plan_run_impl(const mr3d_op *ops, int num_ops, int *failed_index, mr3d_strea
       st = prepare_wino2d(k, (float *)ops[k].p[0], i64_of(ops[k].i));
       if (st != MR3D_OK) return fail(k, st);
       continue;
+    }
+    if (skip_mask) {          // MR3D_TUNE_PLAN_SKIP: sensitivity runs (what would the step cost without this class of records?)
+      const mr3d_op &o = ops[k];
+      const int32_t *i = o.i;
+      bool skip = false;
+      if (o.kind == MR3D_OP_CONV_WGRAD) {
+        skip = (skip_mask & 4) || ((skip_mask & 1) && i[6] == 3 && i[4] == 16 && i[5] == 16) ||
+               ((skip_mask & 2) && i[6] == 3 && i[4] == 64 && i[5] == 64) || ((skip_mask & 64) && i[6] == 1);
+      } else if (o.kind == MR3D_OP_MAXPOOL_FWD) skip = skip_mask & 8;
+      else if (o.kind == MR3D_OP_FINISH_GRADS) skip = skip_mask & 16;
+      else if (o.kind == MR3D_OP_STEM_WGRAD) skip = skip_mask & 32;
+      else if (o.kind == MR3D_OP_CONV_FWD) skip = (skip_mask & 128) && i[6] == 3 && i[4] >= 64 && (long long)i[0] * i[1] * i[2] * i[3] < 32768;
+      if (skip) continue;
     }
     const bool on_side = use_side && wants_side(ops[k]);
     bool on_second = false;

@@ -1094,7 +1094,7 @@ template <typename T, int NS, int CH>
 int launch_fwd_box(const T *feat, float *out, const float *rois, int num_rois, float scale, float scale_d, int ns, int C, int D,
                    int H, int W, int PD, int PH, int PW, int pdc, int lds_budget, const LevelTable &lt, hipStream_t stream) {
   // results tile: 32 bins (two passes of the 16 bin slots at CH = 64); the box gets what is left of the LDS budget
-  const int tbins = 32;
+  const int tbins = (kClThreads / (CH / 4)) > 32 ? (kClThreads / (CH / 4)) : 32;          // at least one pass of the bin slots
   const int tile_bytes = CH * (tbins + 1) * 4;
   const int cap = (lds_budget - kBxTabBytes - tile_bytes) / (CH * 4);
   if (cap < 16) return MR3D_ERR_UNSUPPORTED;
@@ -1130,8 +1130,10 @@ int try_fwd_box(const T *feat, float *out, const float *rois, int num_rois, floa
                 int H, int W, int PD, int PH, int PW, const LevelTable &lt, hipStream_t stream) {
   if (PD > 4) return MR3D_ERR_UNSUPPORTED;          // many pooled depths (mask extractor): the separable kernel wins (157 vs 138 us)
   if (C % 64 != 0 || ns <= 0 || PD * ns > kStAxis || PH * ns > kStAxis || PW * ns > kStAxis) return MR3D_ERR_UNSUPPORTED;
-  const int budget = 80 * 1024;               // two workgroups per CU
   const int pdc = PD;
+  if (g_mr3d_tuning[MR3D_TUNE_ROI_FWD_BOX_CH] == 16 && ns == 2)          // A/B: 16 channels per workgroup, 4x the workgroups, six per CU
+    return launch_fwd_box<T, 2, 16>(feat, out, rois, num_rois, scale, scale_d, ns, C, D, H, W, PD, PH, PW, pdc, 26 * 1024, lt, stream);
+  const int budget = 80 * 1024;               // two workgroups per CU
   if (ns == 2) return launch_fwd_box<T, 2, 64>(feat, out, rois, num_rois, scale, scale_d, ns, C, D, H, W, PD, PH, PW, pdc, budget, lt, stream);
   return launch_fwd_box<T, 0, 64>(feat, out, rois, num_rois, scale, scale_d, ns, C, D, H, W, PD, PH, PW, pdc, budget, lt, stream);
 }
