@@ -40,34 +40,53 @@ __global__ __launch_bounds__(kT) void maxpool_fwd_kernel(const T *__restrict__ x
                                                         uint32_t *__restrict__ idx, int N, int D, int H, int W, int C,
                                                         int Do, int Ho, int Wo) {
   const int C4 = C / 4;
-  int row = blockIdx.x;                                  // (n, od, oh)
+  // Output rows are dealt to the XCDs in contiguous runs (workgroup b runs on XCD b & 7): rows (od, oh) and (od, oh + 1) share a
+  // third of their nine input rows, and dealt round-robin they sat on different XCDs -- every input row was fetched by up to four
+  // L2s (694 MiB of HBM reads per launch for a 320 MiB map, profiles/r03/summary.md).
+  const int nrows = N * Do * Ho, per_xcd = (int)gridDim.x >> 3;              // grid = 8 * ceil(nrows / 8)
+  int row = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);       // (n, od, oh)
+  if (row >= nrows) return;
   const int oh = row % Ho; row /= Ho;
   const int od = row % Do;
   const int n = row / Do;
   const size_t orow = ((size_t)(n * Do + od) * Ho + oh) * (size_t)Wo * C4;
   for (int e = threadIdx.x; e < Wo * C4; e += kT) {
     const int ow = e / C4, c4 = e - ow * C4;
+    // All 27 taps are requested before the first comparison (clamped addresses; a tap outside the map is discarded afterwards):
+    // with the loads inside the bounds tests a thread went through nine dependent round trips per output (3 TB/s on a kernel that
+    // only moves bytes).
+    float4 v[27];
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) {
+      const int id = min(max(od * 2 - 1 + kd, 0), D - 1);
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int ih = min(max(oh * 2 - 1 + kh, 0), H - 1);
+        const T *src = x + ((size_t)(n * D + id) * H + ih) * (size_t)W * C + c4 * 4;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int iw = min(max(ow * 2 - 1 + kw, 0), W - 1);
+          v[(kd * 3 + kh) * 3 + kw] = ld4(src + iw * C);
+        }
+      }
+    }
     float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
     uint32_t bi0 = 0, bi1 = 0, bi2 = 0, bi3 = 0;
 #pragma unroll
     for (int kd = 0; kd < 3; ++kd) {
-      const int id = od * 2 - 1 + kd;
-      if ((unsigned)id >= (unsigned)D) continue;
+      const bool okd = (unsigned)(od * 2 - 1 + kd) < (unsigned)D;
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh) {
-        const int ih = oh * 2 - 1 + kh;
-        if ((unsigned)ih >= (unsigned)H) continue;
-        const T *src = x + ((size_t)(n * D + id) * H + ih) * (size_t)W * C + c4 * 4;
+        const bool okh = okd && (unsigned)(oh * 2 - 1 + kh) < (unsigned)H;
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
-          const int iw = ow * 2 - 1 + kw;
-          if ((unsigned)iw >= (unsigned)W) continue;
-          const float4 v = ld4(src + iw * C);
+          const bool ok = okh && (unsigned)(ow * 2 - 1 + kw) < (unsigned)W;
           const uint32_t tap = (kd * 3 + kh) * 3 + kw;
-          if (v.x > best.x) { best.x = v.x; bi0 = tap; }
-          if (v.y > best.y) { best.y = v.y; bi1 = tap; }
-          if (v.z > best.z) { best.z = v.z; bi2 = tap; }
-          if (v.w > best.w) { best.w = v.w; bi3 = tap; }
+          const float4 t = v[tap];
+          if (ok && t.x > best.x) { best.x = t.x; bi0 = tap; }
+          if (ok && t.y > best.y) { best.y = t.y; bi1 = tap; }
+          if (ok && t.z > best.z) { best.z = t.z; bi2 = tap; }
+          if (ok && t.w > best.w) { best.w = t.w; bi3 = tap; }
         }
       }
     }
@@ -384,8 +403,7 @@ extern "C" int mr3d_maxpool3d_forward(const float *x, float *y, uint32_t *argmax
                                       mr3d_stream_t s) {
   if (!x || !y || !argmax || c % 4) return MR3D_ERR_INVALID_ARG;
   const int Do = (d - 1) / 2 + 1, Ho = (h - 1) / 2 + 1, Wo = (w - 1) / 2 + 1;
-  maxpool_fwd_kernel<<<(unsigned)(n * Do * Ho), kT, 0, mr3d_stream(s)>>>(x, y, argmax, n, d, h, w, c, Do,
-                                                                                          Ho, Wo);
+  maxpool_fwd_kernel<<<(unsigned)((n * Do * Ho + 7) / 8 * 8), kT, 0, mr3d_stream(s)>>>(x, y, argmax, n, d, h, w, c, Do, Ho, Wo);
   return mr3d_launch_status();
 }
 
@@ -517,8 +535,8 @@ extern "C" int mr3d_maxpool3d_forward_bf16(const void *x, void *y, uint32_t *arg
                                            mr3d_stream_t s) {
   if (!x || !y || !argmax || c % 4) return MR3D_ERR_INVALID_ARG;
   const int Do = (d - 1) / 2 + 1, Ho = (h - 1) / 2 + 1, Wo = (w - 1) / 2 + 1;
-  maxpool_fwd_kernel<<<(unsigned)(n * Do * Ho), kT, 0, mr3d_stream(s)>>>((const bf16_t *)x, (bf16_t *)y, argmax,
-                                                                                          n, d, h, w, c, Do, Ho, Wo);
+  maxpool_fwd_kernel<<<(unsigned)((n * Do * Ho + 7) / 8 * 8), kT, 0, mr3d_stream(s)>>>((const bf16_t *)x, (bf16_t *)y, argmax, n, d, h, w, c,
+                                                                                        Do, Ho, Wo);
   return mr3d_launch_status();
 }
 

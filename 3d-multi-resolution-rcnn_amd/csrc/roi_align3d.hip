@@ -1131,8 +1131,8 @@ int try_fwd_box(const T *feat, float *out, const float *rois, int num_rois, floa
   if (PD > 4) return MR3D_ERR_UNSUPPORTED;          // many pooled depths (mask extractor): the separable kernel wins (157 vs 138 us)
   if (C % 64 != 0 || ns <= 0 || PD * ns > kStAxis || PH * ns > kStAxis || PW * ns > kStAxis) return MR3D_ERR_UNSUPPORTED;
   const int pdc = PD;
-  if (g_mr3d_tuning[MR3D_TUNE_ROI_FWD_BOX_CH] == 16 && ns == 2)          // A/B: 16 channels per workgroup, 4x the workgroups, six per CU
-    return launch_fwd_box<T, 2, 16>(feat, out, rois, num_rois, scale, scale_d, ns, C, D, H, W, PD, PH, PW, pdc, 26 * 1024, lt, stream);
+  // (round 4: 16 channels per workgroup -- 4x the workgroups, six per CU, 26 KB boxes -- measured 84 us against 52 us on the bbox case:
+  //  the per-workgroup geometry / table phases are paid four times and the 64-byte voxel rows conflict in LDS)
   const int budget = 80 * 1024;               // two workgroups per CU
   if (ns == 2) return launch_fwd_box<T, 2, 64>(feat, out, rois, num_rois, scale, scale_d, ns, C, D, H, W, PD, PH, PW, pdc, budget, lt, stream);
   return launch_fwd_box<T, 0, 64>(feat, out, rois, num_rois, scale, scale_d, ns, C, D, H, W, PD, PH, PW, pdc, budget, lt, stream);

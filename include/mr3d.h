@@ -46,7 +46,7 @@ int mr3d_device_ok(void);
 /* Measurement knobs (A/B runs of kernel variants from the benchmark tools; 0 = the shipped default everywhere).  Not part of the
  * reference's interface: the drop-in entry points never need them.  Keys: */
 enum {
-  MR3D_TUNE_ROI_FWD_BOX_CH = 0,   /* channels per workgroup of the box-in-LDS RoIAlign3D forward: 0 (default) / 16 / 64 */
+  MR3D_TUNE_RESERVED_0 = 0,
   MR3D_TUNE_PLAN_SKIP = 1,        /* sensitivity runs ONLY (results are wrong): bit mask of plan records mr3d_plan_run leaves out --
                                      1: CONV_WGRAD 3x3x3 16->16, 2: CONV_WGRAD 3x3x3 64->64, 4: every CONV_WGRAD, 8: MAXPOOL_FWD,
                                      16: FINISH_GRADS, 32: STEM_WGRAD, 64: CONV_WGRAD 1x1x1, 128: CONV_FWD 3x3x3 with cin >= 64 on

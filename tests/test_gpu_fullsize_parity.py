@@ -227,6 +227,95 @@ def test_full_size_backward_kernels_windows():
     assert dws[:, 3, :].abs().max().item() == 0.0                      # the padding channel stays zero
 
 
+def _dgrad_s2_window(dy, w, win, dx_dims):
+    """fp64 data gradient of a kernel-3 / stride-2 / pad-1 conv restricted to the dx window `win`: the coarse gradient rows that
+    reach the window are cropped and run through conv_transpose3d (dx[i] = sum_o dy[o] w[i - 2 o + 1])"""
+    sl, off = [], []
+    for ax, (i0, i1) in enumerate(win):
+        o_lo, o_hi = max((i0 - 1) // 2, 0), min(i1 // 2, dy.shape[2 + ax] - 1)
+        sl.append(slice(o_lo, o_hi + 1))
+        off.append(i0 - 2 * o_lo + 1)                       # index of dx[i0] inside the transposed conv's output
+    full = F.conv_transpose3d(dy[:, :, sl[0], sl[1], sl[2]].double(), w.double(), None, 2, 0)
+    return full[:, :, off[0]:off[0] + win[0][1] - win[0][0], off[1]:off[1] + win[1][1] - win[1][0], off[2]:off[2] + win[2][1] - win[2][0]]
+
+
+@pytest.mark.parametrize('vol', [(80, 512, 512), (120, 768, 768)])
+def test_full_size_more_kernel_instances_windows(vol):
+    """One instance each of the kernels the dominant-layer tests above do not reach, at the extents of a 1x3x80x512x512 volume and of
+    the second pathway's 1x3x120x768x768 (VERDICT r3 #6a): the row-split two-dimensional Winograd kernels (16 -> 16 on the layer1
+    map, 32 -> 32 on the layer2 map), the generic halo-tile kernel with its 24-bit offset arithmetic (3x3x3 stride 2, and a strided
+    1x1x1), the parity-decomposed stride-2 data gradient (mr3d_conv3d_dgrad_s2k3, layer2.0) and the streaming pointwise pair at the
+    layer1 position count -- each against fp64 on corner / border / interior windows."""
+    import mr3d_amd  # noqa: F401
+    from mr3d_amd import _hip
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(vol[0])
+    D1, H1, W1 = (vol[0] - 1) // 2 + 1, (vol[1] // 2 - 1) // 2 + 1, (vol[2] // 2 - 1) // 2 + 1      # layer1 map (stem + max-pool)
+    D2, H2, W2 = (D1 - 1) // 2 + 1, (H1 - 1) // 2 + 1, (W1 - 1) // 2 + 1                             # layer2 map
+    cl = lambda t: t.permute(0, 2, 3, 4, 1).contiguous().to(dev)
+    worst = {}
+
+    def conv_case(tag, cin, cout, k, stride, dims, want_variant=None):
+        x = torch.randn(1, cin, *dims, generator=g)
+        w = torch.randn(cout, cin, k, k, k, generator=g) / np.sqrt(cin * k ** 3)
+        b = torch.randn(cout, generator=g)
+        y = _hip.conv3d_forward(cl(x), _hip.pack_conv_weight(w).to(dev), (k,) * 3, (stride,) * 3, (k // 2,) * 3, shift=b.to(dev), relu=True)
+        if want_variant is not None:
+            c = _hip.Conv3dDesc()
+            c.n, c.d, c.h, c.w_in, c.cin, c.cout = 1, dims[0], dims[1], dims[2], cin, cout
+            c.kd = c.kh = c.kw = k
+            c.sd = c.sh = c.sw = stride
+            c.pd = c.ph = c.pw = k // 2
+            c.workspace_bytes = -1
+            v = _hip.Conv3dVariant()
+            import ctypes
+            _hip.check(_hip.lib().mr3d_conv3d_forward_variant(ctypes.byref(c), ctypes.byref(v)), 'variant')
+            assert want_variant(v), (tag, v.winograd, v.tile_d, v.tile_h, v.tile_w, v.cout_tile, v.streaming_pointwise)
+        for win in _windows(y.shape[1:4], (5, 9, 13)):
+            _, exp = _crop_conv(x, w, b, (stride,) * 3, (k // 2,) * 3, win)
+            worst[tag] = max(worst.get(tag, 0), _assert_close(_win(y, win), F.relu(exp), f'{tag} {win}')[0])
+        del x, y
+
+    conv_case('rows 16->16 (layer1 conv2)', 16, 16, 3, 1, (D1, H1, W1), lambda v: v.winograd == 8 and v.cout_tile == 16)
+    conv_case('rows 32->32 (layer2 conv2)', 32, 32, 3, 1, (D2, H2, W2), lambda v: v.winograd == 8 and v.cout_tile == 32)
+    conv_case('generic 3x3x3 s2 32->32 (layer2.0 conv2)', 32, 32, 3, 2, (D1, H1, W1), lambda v: v.winograd == 0 and not v.streaming_pointwise)
+    conv_case('generic 1x1x1 s2 64->128 (layer2.0 downsample)', 64, 128, 1, 2, (D1, H1, W1), lambda v: not v.streaming_pointwise)
+
+    # ---- stride-2 data gradient of layer2.0's conv2: dy on the layer2 grid, dx on the layer1 grid
+    w = torch.randn(32, 32, 3, 3, 3, generator=g) / np.sqrt(32 * 27)                 # forward weight [cout, cin, ...]
+    dy = torch.randn(1, 32, D2, H2, W2, generator=g)
+    wb = _hip.pack_conv_weight(w.flip(2, 3, 4).transpose(0, 1).contiguous())        # [27, cout_fwd, cin_fwd]
+    mask = torch.randn(1, 32, D1, H1, W1, generator=g)
+    dx = _hip.conv3d_dgrad_s2k3(cl(dy), wb.to(dev), (1, D1, H1, W1, 32), mask=cl(mask))
+    for win in _windows((D1, H1, W1), (6, 10, 14)):
+        exp = _dgrad_s2_window(dy, w, win, (D1, H1, W1))
+        (d0, d1), (h0, h1), (w0, w1) = win
+        exp = exp * (mask[:, :, d0:d1, h0:h1, w0:w1] > 0)
+        worst['dgrad_s2k3'] = max(worst.get('dgrad_s2k3', 0), _assert_close(_win(dx, win), exp, f'dgrad_s2k3 {win}')[0])
+    del dx, dy, mask
+
+    # ---- streaming pointwise pair (layer1: conv3 16 -> 64 + identity + ReLU, next conv1 64 -> 16 + ReLU) over every position
+    P = D1 * H1 * W1
+    x = torch.randn(P, 16, generator=g)
+    w1 = torch.randn(16, 64, generator=g) / 4
+    w2 = torch.randn(64, 16, generator=g) / 8
+    add1 = torch.randn(P, 64, generator=g)
+    sh1, sh2 = torch.randn(64, generator=g), torch.randn(16, generator=g)
+    if _hip.pw_pair_supported(16, 64, 16, P):
+        o1 = torch.empty((P, 64), device=dev)
+        o2 = torch.empty((P, 16), device=dev)
+        op = _hip.make_pw_pair_op(x.to(dev), w1.to(dev), sh1.to(dev), add1.to(dev), None, o1, w2.to(dev), sh2.to(dev), None, o2, 16, 64, 16, True, True, P)
+        _hip.Plan([op]).run(dev)
+        rows = torch.cat([torch.arange(0, 4096), torch.arange(P // 2 - 2048, P // 2 + 2048), torch.arange(P - 4096, P)])
+        y1 = torch.relu(x[rows].double() @ w1.double() + sh1.double() + add1[rows].double())
+        y2 = torch.relu(y1 @ w2.double() + sh2.double())
+        worst['pw_pair'] = max(_assert_close(o1[rows.to(dev)].cpu().double(), y1, 'pw_pair y1')[0], _assert_close(o2[rows.to(dev)].cpu().double(), y2, 'pw_pair y2')[0])
+        # every row, against the fp32 product on the device (catches a tile that is skipped or written twice anywhere in the map)
+        ref1 = torch.relu(x.to(dev) @ w1.to(dev) + sh1.to(dev) + add1.to(dev))
+        assert (o1 - ref1).abs().max().item() <= 1e-4 * ref1.abs().max().item()
+    print(f'full-size windowed parity at {vol} (max-norm rel):', {k: f'{v:.1e}' for k, v in worst.items()})
+
+
 @pytest.mark.parametrize('case', ['bbox', 'mask'])
 def test_full_size_roialign_forward_backward_vs_oracle(case):
     """the RoIAlign3D bench shapes (512 rois x 64 ch x (3,7,7); 128 rois x (10,14,14)) over P2..P5 of a 512x512x80 volume

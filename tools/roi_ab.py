@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of RoIAlign3D kernel variants through the measurement knobs (mr3d_tuning_set) on bench.py's own inputs.
-usage: python3 tools/roi_ab.py [key=value,...]  e.g.  tools/roi_ab.py 0=0 0=16"""
+usage: python3 tools/roi_ab.py [key=value,...]  e.g.  tools/roi_ab.py 1=0"""
 import importlib.util
 import os
 import sys
