@@ -17,6 +17,7 @@
 //               top_grad side is accessed in 256-B runs as well.
 #include "mr3d_common.h"
 #include <hip/hip_fp16.h>
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -75,8 +76,10 @@ __device__ __forceinline__ bool axis_tap(float v, int dim, AxisTap &t) {
   return true;
 }
 
+// roi_align_kernel.cu:271-281, op by op WITHOUT fused multiply-adds: a contracted `start + p * bin` moves a coordinate near 100
+// by one ulp (8e-6), i.e. a tap weight by 1e-5 -- every kernel of this file then agrees with the unfused restatement to rounding
 __device__ __forceinline__ float sample_coord(float start, int p, float bin, int i, int ns) {
-  return start + p * bin + (float)(i + .5f) * bin / (float)ns;
+  return __fadd_rn(__fadd_rn(start, __fmul_rn((float)p, bin)), __fdiv_rn(__fmul_rn((float)(i + .5f), bin), (float)ns));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1139,6 +1142,268 @@ int try_fwd_box(const T *feat, float *out, const float *rois, int num_rois, floa
 }
 
 // ------------------------------------------------------------------------------------------
+// channels-last FORWARD, one WAVE per (RoI, 64 channels, chunk of bins) (round 4).
+// The box kernel above is a chain of workgroup phases -- tables, extents, staging, bins, tile flush, each behind a barrier -- and a
+// launch lasts as long as its slowest workgroup (rois whose box does not fit LDS read their taps from global memory: 45 of the
+// 52 us).  RoIAlign3D's samples are separable: with the per-axis tap weights,
+//     out[pd][ph][pw] = 1/count * sum_z Wz[pd][z] sum_y Wy[ph][y] sum_x Wx[pw][x] F[z][y][x].
+// A lane owns ONE channel, so every weight, index and loop bound is wave-uniform (scalar registers, scalar branches).  The voxel
+// rows of the footprint travel global -> LDS directly (`buffer_load_dword ... lds`: one 256-byte row of 64 channels per load, no
+// vector registers, no vector address arithmetic), 64 voxels per batch, every DISTINCT voxel once; per voxel row (z, y) the wave
+// forms T1[pw] = the row's x-contraction (2 taps per x-sample, read back from LDS) and adds wz * wy * T1 into the bins (pd, ph)
+// whose samples touch plane z and row y.  No workgroup barrier inside the loop (the LDS rows are the wave's own).  The bin
+// accumulators stay in registers and leave through an LDS tile [bin][channel] (it shares the row buffer's space), so that
+// [R,C,PD,PH,PW] rows are written in runs of consecutive bins.  Same samples, taps and weights as the reference (axis_tap /
+// sample_coord); the fp32 sums are associated per axis instead of per sample (<= 5e-7 against the box kernel on the bench rois).
+// Measured on the way (bbox extractor, bench rois): one row of per-sample loads at a time 194 us; four rows of per-sample loads in
+// flight 78 us (176 MB of load requests for 37 MB of distinct voxels: request-bound); this form: see try_fwd_wave.
+// ------------------------------------------------------------------------------------------
+constexpr int kWvSlots = 64;               // voxel rows (256 B each) of the wave's LDS row buffer: 16 KB
+
+template <int PDC, int PHC, int PWT, int NS>
+__global__ __launch_bounds__(MR3D_WAVE) void roi_align3d_fwd_wave(const float *feat, float *__restrict__ out, const float *__restrict__ rois,
+                                                                  float scale, float scale_d, int C, int D, int H, int W, int PD, int PH,
+                                                                  LevelTable lt) {
+  constexpr int NXS = PWT * NS, NYS = PHC * NS, NZS = PDC * NS;
+  constexpr int TILE = PHC * PWT * (MR3D_WAVE + 1), BUF = kWvSlots * MR3D_WAVE;
+  __shared__ IdxEntry tabx[NXS], taby[NYS], tabz[NZS];
+  __shared__ __attribute__((aligned(16))) float buf[TILE > BUF ? TILE : BUF];       // row buffer, then the output tile
+  const int lane = threadIdx.x;
+  const int r = blockIdx.x, c0 = blockIdx.y * MR3D_WAVE;
+  const int phchunks = (PH + PHC - 1) / PHC;
+  const int pd0 = ((int)blockIdx.z / phchunks) * PDC, ph0 = ((int)blockIdx.z % phchunks) * PHC;
+  const int npd = min(PDC, PD - pd0), nph = min(PHC, PH - ph0);          // (scalar)
+  if (lt.num) {
+    const int lvl = roi_level(rois + (size_t)r * 7, lt.finest_scale, lt.num);
+    D = pick4(lvl, lt.D); H = pick4(lvl, lt.H); W = pick4(lvl, lt.W);
+    scale = pick4(lvl, lt.scale); scale_d = pick4(lvl, lt.scale_d);
+    feat = pick4(lvl, lt.feat);
+  }
+  const RoiGeom g = roi_geom(rois + (size_t)r * 7, scale, scale_d, NS, PD, PH, PWT);
+  // tap tables of the chunk's samples (lanes 0 .. NXS + NYS + NZS - 1, one sample each); an out-of-range sample has zero weights
+  // and index -1 (it never matches a voxel)
+  {
+    const int e = lane;
+    AxisTap t;
+    IdxEntry te;
+    te.lo = -1; te.hi = -1; te.l = 0.f; te.h = 0.f;
+    if (e < NXS) {
+      if (axis_tap(sample_coord(g.sw, e / NS, g.bw, e % NS, NS), W, t)) { te.lo = t.lo; te.hi = t.hi; te.l = t.l; te.h = t.h; }
+      tabx[e] = te;
+    } else if (e < NXS + NYS) {
+      const int k = e - NXS;
+      if (k / NS < nph && axis_tap(sample_coord(g.sh, ph0 + k / NS, g.bh, k % NS, NS), H, t)) { te.lo = t.lo; te.hi = t.hi; te.l = t.l; te.h = t.h; }
+      taby[k] = te;
+    } else if (e < NXS + NYS + NZS) {
+      const int k = e - NXS - NYS;
+      if (k / NS < npd && axis_tap(sample_coord(g.sd, pd0 + k / NS, g.bd, k % NS, NS), D, t)) { te.lo = t.lo; te.hi = t.hi; te.l = t.l; te.h = t.h; }
+      tabz[k] = te;
+    }
+  }
+  static_assert(NXS + NYS + NZS <= MR3D_WAVE, "one sample per lane");
+  __syncthreads();
+  auto sf = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+  // footprint extents (scalar)
+  int x0 = 0x7fffffff, x1 = -1, y0 = 0x7fffffff, y1 = -1, z0 = 0x7fffffff, z1 = -1;
+#pragma unroll
+  for (int e = 0; e < NXS; ++e) {
+    const int lo = __builtin_amdgcn_readfirstlane(tabx[e].lo), hi = __builtin_amdgcn_readfirstlane(tabx[e].hi);
+    if (lo >= 0) { x0 = min(x0, lo); x1 = max(x1, hi); }
+  }
+#pragma unroll
+  for (int e = 0; e < NYS; ++e) {
+    const int lo = __builtin_amdgcn_readfirstlane(taby[e].lo), hi = __builtin_amdgcn_readfirstlane(taby[e].hi);
+    if (lo >= 0) { y0 = min(y0, lo); y1 = max(y1, hi); }
+  }
+#pragma unroll
+  for (int e = 0; e < NZS; ++e) {
+    const int lo = __builtin_amdgcn_readfirstlane(tabz[e].lo), hi = __builtin_amdgcn_readfirstlane(tabz[e].hi);
+    if (lo >= 0) { z0 = min(z0, lo); z1 = max(z1, hi); }
+  }
+  const int nx = x1 - x0 + 1, ny = y1 - y0 + 1;
+  // x taps as LDS byte offsets relative to the row's first voxel (lane's channel included) + the two weights
+  int alo[NXS], ahi[NXS];
+  float xwl[NXS], xwh[NXS];
+#pragma unroll
+  for (int e = 0; e < NXS; ++e) {
+    const IdxEntry t = tabx[e];
+    const bool ok = t.lo >= 0;
+    alo[e] = ((ok ? t.lo - x0 : 0) * MR3D_WAVE + lane) * 4;
+    ahi[e] = ((ok ? t.hi - x0 : 0) * MR3D_WAVE + lane) * 4;
+    xwl[e] = sf(t.h);
+    xwh[e] = sf(t.l);
+  }
+  // dense per-row y weights Wy[row][ph] in LDS (a clamped sample has lo == hi: both taps count)
+  constexpr int YT = 64, PHP = 8;
+  static_assert(PHC <= PHP, "row weights");
+  __shared__ __attribute__((aligned(16))) float wyt[YT][PHP];
+  auto row_weight = [&](int y, int a) {
+    float w = 0.f;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      const IdxEntry t = taby[a * NS + i];
+      if (t.lo == y) w += t.h;
+      if (t.hi == y) w += t.l;
+    }
+    return w;
+  };
+  for (int idx = lane; idx < min(ny, YT) * PHP; idx += MR3D_WAVE) {
+    const int row = idx / PHP, a = idx - row * PHP;
+    wyt[row][a] = a < PHC ? row_weight(y0 + row, a) : 0.f;
+  }
+  __syncthreads();
+
+  float acc[PDC][PHC * PWT];
+#pragma unroll
+  for (int a = 0; a < PDC; ++a)
+#pragma unroll
+    for (int b = 0; b < PHC * PWT; ++b) acc[a][b] = 0.f;
+
+  const int row_bytes = W * C * 4;                       // (a feature plane stays below 2^31 bytes: checked by the launcher)
+  const int xstride = C * 4;
+  // rows per batch: as many whole voxel rows as the buffer holds (a row wider than the buffer is walked in 64-voxel pieces by the
+  // per-sample path below)
+  const bool wide = nx > kWvSlots;
+  const int rpb = wide ? 1 : max(1, kWvSlots / max(nx, 1));
+  for (int z = z0; z <= z1; ++z) {
+    float wz[PDC];
+    bool zany = false;
+#pragma unroll
+    for (int a = 0; a < PDC; ++a) {
+      float w = 0.f;
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        const IdxEntry t = tabz[a * NS + i];
+        if (t.lo == z) w += t.h;
+        if (t.hi == z) w += t.l;
+      }
+      wz[a] = sf(w);
+      zany = zany || wz[a] != 0.f;
+    }
+    if (!zany) continue;
+    const float *plane = feat + (((size_t)g.b * D + z) * H) * (size_t)W * C + c0;
+    const __amdgpu_buffer_rsrc_t pr = buffer_of(plane);
+    for (int yb = y0; yb <= y1; yb += rpb) {
+      const int rows = min(rpb, y1 - yb + 1);
+      if (!wide) {
+        // every distinct voxel of the batch's rows: global -> LDS, one 256-byte row of 64 channels per load
+        for (int k = 0; k < rows; ++k) {
+          const int gb = (yb + k) * row_bytes + x0 * xstride;
+          for (int i = 0; i < nx; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(pr, (__attribute__((address_space(3))) void *)(buf + (k * nx + i) * MR3D_WAVE), 4,
+                                                     lane * 4, gb + i * xstride, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0070);              // vmcnt(0): the rows are in LDS (lgkmcnt / expcnt untouched)
+      }
+      for (int k = 0; k < rows; ++k) {
+        const int y = yb + k;
+        float wy[PHC];
+        if (y - y0 < YT) {
+          const float4 q0 = *reinterpret_cast<const float4 *>(&wyt[y - y0][0]), q1 = *reinterpret_cast<const float4 *>(&wyt[y - y0][4]);
+          const float q[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+          for (int a = 0; a < PHC; ++a) wy[a] = sf(q[a]);
+        } else {
+#pragma unroll
+          for (int a = 0; a < PHC; ++a) wy[a] = sf(row_weight(y, a));
+        }
+        bool any = false;
+#pragma unroll
+        for (int a = 0; a < PHC; ++a) any = any || wy[a] != 0.f;
+        if (!any) continue;
+        // T1[pw] = sum over the bin's x-samples of (w_lo F[lo] + w_hi F[hi])
+        float t1[PWT];
+        if (!wide) {
+          const char *rowp = reinterpret_cast<const char *>(buf) + k * nx * (MR3D_WAVE * 4);
+#pragma unroll
+          for (int pw = 0; pw < PWT; ++pw) {
+            float s_ = 0.f;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+              const int e = pw * NS + i;
+              s_ += xwl[e] * *reinterpret_cast<const float *>(rowp + alo[e]) + xwh[e] * *reinterpret_cast<const float *>(rowp + ahi[e]);
+            }
+            t1[pw] = s_;
+          }
+        } else {
+          const int rb = y * row_bytes + x0 * xstride;
+#pragma unroll
+          for (int pw = 0; pw < PWT; ++pw) {
+            float s_ = 0.f;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+              const int e = pw * NS + i;
+              const int lo = __builtin_amdgcn_readfirstlane(alo[e] >> 8), hi = __builtin_amdgcn_readfirstlane(ahi[e] >> 8);     // voxel index relative to x0
+              s_ += xwl[e] * buffer_load1(pr, (unsigned)lane * 4u, (unsigned)(rb + lo * xstride)) +
+                    xwh[e] * buffer_load1(pr, (unsigned)lane * 4u, (unsigned)(rb + hi * xstride));
+            }
+            t1[pw] = s_;
+          }
+        }
+#pragma unroll
+        for (int a = 0; a < PDC; ++a) {
+          if (wz[a] == 0.f) continue;
+#pragma unroll
+          for (int b = 0; b < PHC; ++b) {
+            if (wy[b] == 0.f) continue;
+            const float w = wz[a] * wy[b];
+#pragma unroll
+            for (int pw = 0; pw < PWT; ++pw) acc[a][b * PWT + pw] += w * t1[pw];
+          }
+        }
+      }
+    }
+  }
+
+  // ---- out[r][c0 + lane][pd][ph][pw]: per pooled depth through the LDS tile [bin][channel], then one run of the chunk's bins per
+  // channel (the chunk's bins of one depth are contiguous in a channel's row)
+  const float inv_count = 1.f / (float)(NS * NS * NS);
+  const int B = PD * PH * PWT;
+  float *orow = out + ((size_t)r * C + c0) * B;
+  float (*tile)[MR3D_WAVE + 1] = reinterpret_cast<float (*)[MR3D_WAVE + 1]>(buf);
+#pragma unroll
+  for (int a = 0; a < PDC; ++a) {
+    if (a >= npd) break;
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < PHC * PWT; ++b) tile[b][lane] = acc[a][b] * inv_count;
+    __syncthreads();
+    const int nb = nph * PWT, first = ((pd0 + a) * PH + ph0) * PWT;
+    if (lane < nb) {
+      float *dst = orow + first + lane;
+#pragma unroll 8
+      for (int ch = 0; ch < MR3D_WAVE; ++ch) dst[(size_t)ch * B] = tile[lane][ch];
+    }
+  }
+}
+
+template <int PDC, int PHC, int PWT, int NS>
+int launch_fwd_wave(const float *feat, float *out, const float *rois, int num_rois, float scale, float scale_d, int C, int D, int H, int W,
+                    int PD, int PH, const LevelTable &lt, hipStream_t stream) {
+  const dim3 grid(num_rois, C / MR3D_WAVE, ((PD + PDC - 1) / PDC) * ((PH + PHC - 1) / PHC));
+  roi_align3d_fwd_wave<PDC, PHC, PWT, NS><<<grid, MR3D_WAVE, 0, stream>>>(feat, out, rois, scale, scale_d, C, D, H, W, PD, PH, lt);
+  return mr3d_launch_status();
+}
+
+// fp32 channels-last features, C % 64 == 0, sample_num 2, the two extractor shapes of the shipped model; anything else: the kernels above
+int try_fwd_wave(const float *feat, float *out, const float *rois, int num_rois, float scale, float scale_d, int ns, int C, int D, int H,
+                 int W, int PD, int PH, int PW, const LevelTable &lt, hipStream_t stream) {
+  if (C % MR3D_WAVE != 0 || ns != 2) return MR3D_ERR_UNSUPPORTED;
+  // byte offsets inside one feature plane travel as 32-bit scalars
+  long long plane = (long long)H * W * C * 4;
+  for (int i = 0; i < lt.num; ++i) plane = std::max(plane, (long long)lt.H[i] * lt.W[i] * C * 4);
+  if (plane >= (1LL << 31)) return MR3D_ERR_UNSUPPORTED;
+  // Kernel times on the SURVEY 8(d) rois and on size classes of 512 / 128 rois (rocprofv3, us; box / sep = the kernels above):
+  //   (3,7,7):    mixed 51 box, 74 wave | 8-16 px 36 / 28 | 8-32 px 47 / 39 | 48-128 px 39 / 32 | flat 64-128 x 2-4 px 54 / 68
+  //   (10,14,14): mixed 72 sep, 63 wave (4 pooled rows per wave; 7 rows: 93) | 8-16 px 48 / 47 | 48-128 px 49 / 50 | flat 50 / 72
+  // A wave is a serial chain (tables 5 us, one memory round trip per 64-voxel batch, tile flush 5-8 us), so rois with thousands of
+  // footprint voxels (the log-uniform bench sizes produce 128 x 4 x 2 px slabs) take 37 batches: the box kernel keeps the (3,7,7)
+  // extractor, this one takes the mask extractor's shape, where the footprint per (pooled depth, 4 pooled rows) chunk is small.
+  if (PW == 14 && PH == 14) return launch_fwd_wave<1, 4, 14, 2>(feat, out, rois, num_rois, scale, scale_d, C, D, H, W, PD, PH, lt, stream);
+  return MR3D_ERR_UNSUPPORTED;
+}
+
+// ------------------------------------------------------------------------------------------
 // channels-last backward, voxel-owner form (C % 64 == 0).  A workgroup owns (RoI, 64 channels, a chunk of pooled depths): the
 // chunk's top-gradient planes are staged once as G[bin][64 ch] in LDS, the per-axis weight matrices Wx[x][pw] (Wy, Wz alike:
 // the summed tap weights of bin pw on voxel x) are built once together with the range of bins that reach each voxel (the
@@ -1364,6 +1629,9 @@ extern "C" int mr3d_roi_align3d_forward(const float *features, const float *rois
   hipStream_t stream = mr3d_stream(stream_);
   const int B = pooled_depth * pooled_height * pooled_width;
   if (use_cl(layout, sample_num, pooled_depth, pooled_height, pooled_width)) {
+    const int st0 = try_fwd_wave(features, output, rois, num_rois, spatial_scale, spatial_scale_depth, sample_num, channels, depth, height,
+                                 width, pooled_depth, pooled_height, pooled_width, LevelTable{}, stream);
+    if (st0 != MR3D_ERR_UNSUPPORTED) return st0;
     const int st1 = try_fwd_box<float>(features, output, rois, num_rois, spatial_scale, spatial_scale_depth, sample_num, channels, depth,
                                          height, width, pooled_depth, pooled_height, pooled_width, LevelTable{}, stream);
     if (st1 != MR3D_ERR_UNSUPPORTED) return st1;
@@ -1509,6 +1777,9 @@ extern "C" int mr3d_roi_align3d_forward_ml(const mr3d_roi_level *levels_host, in
   if (!rois || !output) return MR3D_ERR_INVALID_ARG;
   if (!use_cl(MR3D_LAYOUT_NDHWC, sample_num, pooled_depth, pooled_height, pooled_width)) return MR3D_ERR_UNSUPPORTED;
   {
+    const int st0 = try_fwd_wave(nullptr, output, rois, num_rois, 0.f, 0.f, sample_num, channels, 1, 1, 1, pooled_depth, pooled_height,
+                                 pooled_width, lt, mr3d_stream(stream_));
+    if (st0 != MR3D_ERR_UNSUPPORTED) return st0;
     const int st1 = try_fwd_box<float>(nullptr, output, rois, num_rois, 0.f, 0.f, sample_num, channels, 1, 1, 1, pooled_depth,
                                          pooled_height, pooled_width, lt, mr3d_stream(stream_));
     if (st1 != MR3D_ERR_UNSUPPORTED) return st1;

@@ -106,6 +106,7 @@ class TwoStageDetector3D(nn.Module):
         self.extract = ExtractFeat3D(device=device, dtype=dtype, neck_dcn=neck_dcn)   # backbone + neck (module names as the reference)
         self.neck_dcn = bool(neck_dcn)
         self.extract.sparse_pyramid_grads = True          # detector training: see ExtractFeat3D.sparse_pyramid_grads
+        self.extract.clone_outputs = False                # a training / test step consumes the pyramid before the engine runs again
         if dtype == torch.bfloat16:
             # RPN head and RoIAlign3D read the bf16 pyramid directly; with the deformable neck the lateral sums leave the engine
             # in bf16 and the neck's bf16 kernels take them as they are (detector/dcn_neck.py)

@@ -3,11 +3,11 @@ float64 torch on the host, evaluated on WINDOWS (corners, borders, interior) -- 
 on its input halo, so the fp64 reference runs on crops in milliseconds while the device kernels run at production extents
 (32-bit index overflow, tile edges, grid-size limits are what small shapes cannot catch); weight gradients are made local
 by a cotangent that is zero outside the windows.  RoIAlign3D forward + backward at the bench size against the OpenMP
-oracle, every roi, both index modes.  Opt-in (MR3D_FULLSIZE=1): end to end: the engine's ResNet3D-50+FPN3D forward and backward on a 1x3x80x512x512 volume
+oracle, every roi, both index modes.  Default-on since round 4 (MR3D_FULLSIZE=0 skips it): end to end: the engine's ResNet3D-50+FPN3D forward and backward on a 1x3x80x512x512 volume
 against the plain-PyTorch restatement (oracle/torch_ref_model.py, pinned to the reference by the goldens) run on the
 SAME GPU through PyTorch-ROCm/MIOpen, with identical random weights.  It catches what small shapes cannot (32-bit
-index overflow, tile-edge handling at production extents).  MIOpen needs minutes to pick its 3D kernels, so the test
-only runs when MR3D_FULLSIZE=1 (run once per round; result recorded in DESIGN.md section 6)."""
+index overflow, tile-edge handling at production extents).  MIOpen needs about two minutes to pick its 3D kernels (145 s for
+the whole test on a fresh box, round 4); the measured errors are recorded in DESIGN.md section 6."""
 import os
 
 import pytest
@@ -18,7 +18,7 @@ from oracle.torch_ref_model import RefExtractFeat
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.skipif(os.environ.get('MR3D_FULLSIZE') != '1', reason='set MR3D_FULLSIZE=1 (takes minutes: MIOpen kernel search)')
+@pytest.mark.skipif(os.environ.get('MR3D_FULLSIZE') == '0', reason='MR3D_FULLSIZE=0: end-to-end run against PyTorch-ROCm/MIOpen skipped (2.5 minutes)')
 def test_engine_full_size_vs_torch_on_gpu():
     import mr3d_amd  # noqa: F401
     from mr3d_amd.detector import ExtractFeat3D
