@@ -1563,6 +1563,219 @@ __global__ __launch_bounds__(kClThreads) void roi_align3d_bwd_vox(const float *_
       }
 }
 
+// ------------------------------------------------------------------------------------------
+// channels-last BACKWARD, one WAVE per (RoI, 64 channels, pooled depth, chunk of pooled rows) (round 4): the transposed form of
+// roi_align3d_fwd_wave.  The chunk's top gradients G[ph][pw] sit in the lane's registers (lane = channel; read through an LDS tile
+// so that [R,C,PD,PH,PW] rows are fetched in runs of consecutive bins); per voxel row (z, y) of the footprint
+//     T1[pw] = wz * sum_ph Wy[ph][y] G[ph][pw],      dF[z][y][x] += sum over the x-samples' taps on x of their weight * T1[bin]
+// is accumulated in a wave-private LDS row [x][channel] and flushed with ONE 256-byte-contiguous atomic per touched voxel (the
+// full-rate atomic shape).  No workgroup barrier after the set-up, no memory round trip inside the loop; weights, indices and loop
+// bounds are wave-uniform.  Same taps and weights as the scatter form (l / h of axis_tap, dropped samples contribute nothing);
+// the reference's top-gradient index bug (:554-555) behind `bug_compat` as everywhere.
+// ------------------------------------------------------------------------------------------
+template <int PDC, int PHC, int PWT, int NS>
+__global__ __launch_bounds__(MR3D_WAVE) void roi_align3d_bwd_wave(const float *__restrict__ top, float *bottom, const float *__restrict__ rois,
+                                                                  float scale, float scale_d, int C, int D, int H, int W, int PD, int PH,
+                                                                  int bug_compat, LevelTable lt) {
+  constexpr int NXS = PWT * NS, NYS = PHC * NS, NZS = PDC * NS;
+  constexpr int TILE = PHC * PWT * (MR3D_WAVE + 1), BUF = kWvSlots * MR3D_WAVE;
+  __shared__ IdxEntry tabx[NXS], taby[NYS], tabz[NZS];
+  __shared__ __attribute__((aligned(16))) float buf[TILE > BUF ? TILE : BUF];       // the G tile, then the voxel row
+  const int lane = threadIdx.x;
+  const int r = blockIdx.x, c0 = blockIdx.y * MR3D_WAVE;
+  const int phchunks = (PH + PHC - 1) / PHC;
+  const int pd0 = ((int)blockIdx.z / phchunks) * PDC, ph0 = ((int)blockIdx.z % phchunks) * PHC;
+  const int npd = min(PDC, PD - pd0), nph = min(PHC, PH - ph0);        // (scalar)
+  if (lt.num) {
+    const int lvl = roi_level(rois + (size_t)r * 7, lt.finest_scale, lt.num);
+    D = pick4(lvl, lt.D); H = pick4(lvl, lt.H); W = pick4(lvl, lt.W);
+    scale = pick4(lvl, lt.scale); scale_d = pick4(lvl, lt.scale_d);
+    bottom = pick4(lvl, lt.grad);
+  }
+  const RoiGeom g = roi_geom(rois + (size_t)r * 7, scale, scale_d, NS, PD, PH, PWT);
+  {
+    const int e = lane;
+    AxisTap t;
+    IdxEntry te;
+    te.lo = -1; te.hi = -1; te.l = 0.f; te.h = 0.f;
+    if (e < NXS) {
+      if (axis_tap(sample_coord(g.sw, e / NS, g.bw, e % NS, NS), W, t)) { te.lo = t.lo; te.hi = t.hi; te.l = t.l; te.h = t.h; }
+      tabx[e] = te;
+    } else if (e < NXS + NYS) {
+      const int k = e - NXS;
+      if (k / NS < nph && axis_tap(sample_coord(g.sh, ph0 + k / NS, g.bh, k % NS, NS), H, t)) { te.lo = t.lo; te.hi = t.hi; te.l = t.l; te.h = t.h; }
+      taby[k] = te;
+    } else if (e < NXS + NYS + NZS) {
+      const int k = e - NXS - NYS;
+      if (k / NS < npd && axis_tap(sample_coord(g.sd, pd0 + k / NS, g.bd, k % NS, NS), D, t)) { te.lo = t.lo; te.hi = t.hi; te.l = t.l; te.h = t.h; }
+      tabz[k] = te;
+    }
+  }
+  static_assert(NXS + NYS + NZS <= MR3D_WAVE, "one sample per lane");
+  // ---- the chunk's top gradients: tile[bin][channel] <- 64 channel rows of nph * PWT consecutive bins, then one register per bin
+  const int B = PD * PH * PWT;
+  const int nb = nph * PWT;
+  float (*tile)[MR3D_WAVE + 1] = reinterpret_cast<float (*)[MR3D_WAVE + 1]>(buf);
+  const float inv_count = 1.f / (float)(NS * NS * NS);
+  float gq[PDC][PHC * PWT];
+#pragma unroll
+  for (int a = 0; a < PDC; ++a) {
+    const int pd = pd0 + a;
+    __syncthreads();                                                   // tables written / the previous depth's tile read out
+    if (a < npd && lane < nb) {
+      const float *src = top + ((size_t)r * C + c0) * B + (bug_compat ? pd * PD * PWT : pd * PH * PWT) + ph0 * PWT;
+#pragma unroll 8
+      for (int ch = 0; ch < MR3D_WAVE; ++ch) tile[lane][ch] = src[(size_t)ch * B + lane];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < PHC * PWT; ++b) gq[a][b] = (a < npd && b < nb) ? tile[b][lane] * inv_count : 0.f;
+  }
+  auto sf = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+  int x0 = 0x7fffffff, x1 = -1, y0 = 0x7fffffff, y1 = -1, z0 = 0x7fffffff, z1 = -1;
+#pragma unroll
+  for (int e = 0; e < NXS; ++e) {
+    const int lo = __builtin_amdgcn_readfirstlane(tabx[e].lo), hi = __builtin_amdgcn_readfirstlane(tabx[e].hi);
+    if (lo >= 0) { x0 = min(x0, lo); x1 = max(x1, hi); }
+  }
+#pragma unroll
+  for (int e = 0; e < NYS; ++e) {
+    const int lo = __builtin_amdgcn_readfirstlane(taby[e].lo), hi = __builtin_amdgcn_readfirstlane(taby[e].hi);
+    if (lo >= 0) { y0 = min(y0, lo); y1 = max(y1, hi); }
+  }
+#pragma unroll
+  for (int e = 0; e < NZS; ++e) {
+    const int lo = __builtin_amdgcn_readfirstlane(tabz[e].lo), hi = __builtin_amdgcn_readfirstlane(tabz[e].hi);
+    if (lo >= 0) { z0 = min(z0, lo); z1 = max(z1, hi); }
+  }
+  const int nx = x1 - x0 + 1, ny = y1 - y0 + 1;
+  if (nx <= 0 || ny <= 0 || z1 < z0) return;                           // nothing of this chunk lands in the map (uniform)
+  constexpr int YT = 64, PHP = 8;
+  static_assert(PHC <= PHP, "row weights");
+  __shared__ __attribute__((aligned(16))) float wyt[YT][PHP];
+  auto row_weight = [&](int y, int a) {
+    float w = 0.f;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      const IdxEntry t = taby[a * NS + i];
+      if (t.lo == y) w += t.h;
+      if (t.hi == y) w += t.l;
+    }
+    return w;
+  };
+  for (int idx = lane; idx < min(ny, YT) * PHP; idx += MR3D_WAVE) {
+    const int row = idx / PHP, a = idx - row * PHP;
+    wyt[row][a] = a < PHC ? row_weight(y0 + row, a) : 0.f;
+  }
+  __syncthreads();                                                     // (also: every lane has read its G values out of the tile)
+
+  // dense x weights Wx[x - x0][pw] of a 64-voxel piece of the footprint in LDS (lane = voxel; a clamped sample has lo == hi: both
+  // taps count): a voxel's gradient is then PWT uniform-weight FMAs on T1 -- an LDS row accumulated tap by tap was a chain of 56
+  // dependent read-modify-writes per voxel row (203 us on the mask extractor)
+  constexpr int PWP = (PWT + 3) & ~3;
+  __shared__ __attribute__((aligned(16))) float wxt[kWvSlots][PWP];
+  float *gbase = bottom + (size_t)g.b * D * H * W * C + c0 + lane;
+  for (int xs = 0; xs < nx; xs += kWvSlots) {                          // (one piece unless the footprint is wider than 64 voxels)
+    const int sx = min(kWvSlots, nx - xs);
+    __syncthreads();
+    if (lane < sx) {
+      const int x = x0 + xs + lane;
+#pragma unroll
+      for (int pw = 0; pw < PWP; ++pw) {
+        float w = 0.f;
+        if (pw < PWT) {
+#pragma unroll
+          for (int i = 0; i < NS; ++i) {
+            const IdxEntry t = tabx[pw * NS + i];
+            if (t.lo == x) w += t.h;
+            if (t.hi == x) w += t.l;
+          }
+        }
+        wxt[lane][pw] = w;
+      }
+    }
+    __syncthreads();
+    for (int z = z0; z <= z1; ++z) {
+      float wz[PDC];
+      bool zany = false;
+#pragma unroll
+      for (int a = 0; a < PDC; ++a) {
+        float w = 0.f;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+          const IdxEntry t = tabz[a * NS + i];
+          if (t.lo == z) w += t.h;
+          if (t.hi == z) w += t.l;
+        }
+        wz[a] = sf(w);
+        zany = zany || wz[a] != 0.f;
+      }
+      if (!zany) continue;
+      for (int y = y0; y <= y1; ++y) {
+        float wy[PHC];
+        if (y - y0 < YT) {
+          const float4 q0 = *reinterpret_cast<const float4 *>(&wyt[y - y0][0]), q1 = *reinterpret_cast<const float4 *>(&wyt[y - y0][4]);
+          const float q[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+          for (int a = 0; a < PHC; ++a) wy[a] = sf(q[a]);
+        } else {
+#pragma unroll
+          for (int a = 0; a < PHC; ++a) wy[a] = sf(row_weight(y, a));
+        }
+        bool any = false;
+#pragma unroll
+        for (int a = 0; a < PHC; ++a) any = any || wy[a] != 0.f;
+        if (!any) continue;
+        float t1[PWP];
+#pragma unroll
+        for (int pw = 0; pw < PWP; ++pw) t1[pw] = 0.f;
+#pragma unroll
+        for (int d = 0; d < PDC; ++d) {
+          if (wz[d] == 0.f) continue;
+#pragma unroll
+          for (int a = 0; a < PHC; ++a) {
+            if (wy[a] == 0.f) continue;
+            const float w = wz[d] * wy[a];
+#pragma unroll
+            for (int pw = 0; pw < PWT; ++pw) t1[pw] += w * gq[d][a * PWT + pw];
+          }
+        }
+        float *grow = gbase + (((size_t)z * H + y) * W + x0 + xs) * C;
+        for (int i = 0; i < sx; ++i) {
+          float val = 0.f;
+#pragma unroll
+          for (int q4 = 0; q4 < PWP / 4; ++q4) {
+            const float4 w4 = *reinterpret_cast<const float4 *>(&wxt[i][q4 * 4]);          // (uniform address: broadcast)
+            val += w4.x * t1[q4 * 4] + w4.y * t1[q4 * 4 + 1] + w4.z * t1[q4 * 4 + 2] + w4.w * t1[q4 * 4 + 3];
+          }
+          if (val != 0.f) atomicAdd(grow + (size_t)i * C, val);
+        }
+      }
+    }
+  }
+}
+
+template <int PDC, int PHC, int PWT, int NS>
+int launch_bwd_wave(const float *top, float *bottom, const float *rois, int num_rois, float scale, float scale_d, int C, int D, int H, int W,
+                    int PD, int PH, int bug, const LevelTable &lt, hipStream_t stream) {
+  const dim3 grid(num_rois, C / MR3D_WAVE, ((PD + PDC - 1) / PDC) * ((PH + PHC - 1) / PHC));
+  roi_align3d_bwd_wave<PDC, PHC, PWT, NS><<<grid, MR3D_WAVE, 0, stream>>>(top, bottom, rois, scale, scale_d, C, D, H, W, PD, PH, bug, lt);
+  return mr3d_launch_status();
+}
+
+int try_bwd_wave(const float *top, float *bottom, const float *rois, int num_rois, float scale, float scale_d, int ns, int C, int D, int H,
+                 int W, int PD, int PH, int PW, int bug, const LevelTable &lt, hipStream_t stream) {
+  if (C % MR3D_WAVE != 0 || ns != 2) return MR3D_ERR_UNSUPPORTED;
+  if (bug && (PD - 1) * PD * PW + PH * PW > PD * PH * PW) return MR3D_ERR_UNSUPPORTED;      // the bug's offsets stay inside the roi's block
+  // Mask extractor (10,14,14) x 128 rois on the SURVEY 8(d) inputs, launch alone: voxel-owner kernel 158 us; this kernel with
+  // (pooled depths, pooled rows) per wave = (1,4) 123, (2,4) 89, (3,4) 98 (269 registers), (5,2) 113 -- fewer chunks mean fewer
+  // atomic passes over a voxel plane that several pooled depths reach, until the registers halve the waves per SIMD.
+  // The (3,7,7) extractor keeps the voxel-owner kernel (73 us against 107 us for (3,7) per wave: its rois include the footprints of
+  // thousands of voxels that a single wave walks alone).
+  if (PW == 14 && PH == 14) return launch_bwd_wave<2, 4, 14, 2>(top, bottom, rois, num_rois, scale, scale_d, C, D, H, W, PD, PH, bug, lt, stream);
+  return MR3D_ERR_UNSUPPORTED;
+}
+
 // the voxel-owner backward for a pooled shape: MR3D_ERR_UNSUPPORTED = not applicable (the caller takes the plan + sub-box path)
 int try_bwd_vox(const float *top, float *bottom, const float *rois, int num_rois, float scale, float scale_d, int ns, int C, int D,
                 int H, int W, int PD, int PH, int PW, int bug, const LevelTable &lt, hipStream_t stream) {
@@ -1668,6 +1881,9 @@ extern "C" int mr3d_roi_align3d_backward(const float *top_grad, const float *roi
   const int bug = (flags & MR3D_ROIALIGN_BUG_COMPAT) ? 1 : 0;
   const int B = pooled_depth * pooled_height * pooled_width;
   if (use_cl(layout, sample_num, pooled_depth, pooled_height, pooled_width)) {
+    const int stw = try_bwd_wave(top_grad, bottom_grad, rois, num_rois, spatial_scale, spatial_scale_depth, sample_num, channels, depth,
+                                 height, width, pooled_depth, pooled_height, pooled_width, bug, LevelTable{}, stream);
+    if (stw != MR3D_ERR_UNSUPPORTED) return stw;
     const int stv = try_bwd_vox(top_grad, bottom_grad, rois, num_rois, spatial_scale, spatial_scale_depth, sample_num, channels, depth,
                                 height, width, pooled_depth, pooled_height, pooled_width, bug, LevelTable{}, stream);
     if (stv != MR3D_ERR_UNSUPPORTED) return stv;
@@ -1809,6 +2025,9 @@ extern "C" int mr3d_roi_align3d_backward_ml(const mr3d_roi_level *levels_host, i
   const int bug = (flags & MR3D_ROIALIGN_BUG_COMPAT) ? 1 : 0;
   const int B = pooled_depth * pooled_height * pooled_width;
   {
+    const int stw = try_bwd_wave(top_grad, nullptr, rois, num_rois, 0.f, 0.f, sample_num, channels, 1, 1, 1, pooled_depth, pooled_height,
+                                 pooled_width, bug, lt, stream);
+    if (stw != MR3D_ERR_UNSUPPORTED) return stw;
     const int stv = try_bwd_vox(top_grad, nullptr, rois, num_rois, 0.f, 0.f, sample_num, channels, 1, 1, 1, pooled_depth, pooled_height,
                                 pooled_width, bug, lt, stream);
     if (stv != MR3D_ERR_UNSUPPORTED) return stv;
