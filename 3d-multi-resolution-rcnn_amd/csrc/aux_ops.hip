@@ -36,7 +36,7 @@ __device__ __forceinline__ void st4(bf16_t *p, float4 v) {
 // (ow, channel quad) items with 32-bit indices (the element-per-thread form with 64-bit div / mod chains per element took
 // 137 us for the stem's 335 MB map).
 template <typename T>
-__global__ __launch_bounds__(kT) void maxpool_fwd_kernel(const T *__restrict__ x, T *__restrict__ y,
+__global__ __launch_bounds__(2 * kT) void maxpool_fwd_kernel(const T *__restrict__ x, T *__restrict__ y,
                                                         uint32_t *__restrict__ idx, int N, int D, int H, int W, int C,
                                                         int Do, int Ho, int Wo) {
   const int C4 = C / 4;
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(kT) void maxpool_fwd_kernel(const T *__restrict__ x
   const int od = row % Do;
   const int n = row / Do;
   const size_t orow = ((size_t)(n * Do + od) * Ho + oh) * (size_t)Wo * C4;
-  for (int e = threadIdx.x; e < Wo * C4; e += kT) {
+  for (int e = threadIdx.x; e < Wo * C4; e += (int)blockDim.x) {          // (512 threads when a row has more than 256 items)
     const int ow = e / C4, c4 = e - ow * C4;
     // All 27 taps are requested before the first comparison (clamped addresses; a tap outside the map is discarded afterwards):
     // with the loads inside the bounds tests a thread went through nine dependent round trips per output (3 TB/s on a kernel that
@@ -198,11 +198,30 @@ __global__ __launch_bounds__(kT) void upsample_adjoint_add_kernel(const T *__res
     const int uh = (int)(r % Hc); r /= Hc;
     const int ud = (int)(r % Dc);
     const int n = (int)(r / Dc);
+    float4 g = ld4(gc + (size_t)t * 4);
+    if (Df == 2 * Dc && Hf == 2 * Hc && Wf == 2 * Wc) {
+      // exact doubling (every level of the pyramid): the eight children are requested together -- inside the run-time-bounded loops
+      // below each load waits for the previous one (140 us for the P2 -> P3 step: 1.5 TB/s on a kernel that only moves bytes)
+      const T *base = gf + ((((size_t)n * Df + 2 * ud) * Hf + 2 * uh) * Wf + 2 * uw) * C + c4 * 4;
+      const size_t sw = C, sh = (size_t)Wf * C, sd = (size_t)Hf * Wf * C;
+      const float4 v0 = ld4(base), v1 = ld4(base + sw), v2 = ld4(base + sh), v3 = ld4(base + sh + sw);
+      const float4 v4 = ld4(base + sd), v5 = ld4(base + sd + sw), v6 = ld4(base + sd + sh), v7 = ld4(base + sd + sh + sw);
+      // (same order of additions as the loops: d, then h, then w)
+      g.x += v0.x; g.y += v0.y; g.z += v0.z; g.w += v0.w;
+      g.x += v1.x; g.y += v1.y; g.z += v1.z; g.w += v1.w;
+      g.x += v2.x; g.y += v2.y; g.z += v2.z; g.w += v2.w;
+      g.x += v3.x; g.y += v3.y; g.z += v3.z; g.w += v3.w;
+      g.x += v4.x; g.y += v4.y; g.z += v4.z; g.w += v4.w;
+      g.x += v5.x; g.y += v5.y; g.z += v5.z; g.w += v5.w;
+      g.x += v6.x; g.y += v6.y; g.z += v6.z; g.w += v6.w;
+      g.x += v7.x; g.y += v7.y; g.z += v7.z; g.w += v7.w;
+      st4(gc + (size_t)t * 4, g);
+      continue;
+    }
     int d0, d1, h0, h1, w0, w1;
     child_range(ud, Dc, Df, d0, d1);
     child_range(uh, Hc, Hf, h0, h1);
     child_range(uw, Wc, Wf, w0, w1);
-    float4 g = ld4(gc + (size_t)t * 4);
     for (int d = d0; d < d1; ++d)
       for (int h = h0; h < h1; ++h)
         for (int w = w0; w < w1; ++w) {
@@ -403,7 +422,7 @@ extern "C" int mr3d_maxpool3d_forward(const float *x, float *y, uint32_t *argmax
                                       mr3d_stream_t s) {
   if (!x || !y || !argmax || c % 4) return MR3D_ERR_INVALID_ARG;
   const int Do = (d - 1) / 2 + 1, Ho = (h - 1) / 2 + 1, Wo = (w - 1) / 2 + 1;
-  maxpool_fwd_kernel<<<(unsigned)((n * Do * Ho + 7) / 8 * 8), kT, 0, mr3d_stream(s)>>>(x, y, argmax, n, d, h, w, c, Do, Ho, Wo);
+  maxpool_fwd_kernel<<<(unsigned)((n * Do * Ho + 7) / 8 * 8), Wo * (c / 4) > kT ? 2 * kT : kT, 0, mr3d_stream(s)>>>(x, y, argmax, n, d, h, w, c, Do, Ho, Wo);
   return mr3d_launch_status();
 }
 
@@ -535,8 +554,8 @@ extern "C" int mr3d_maxpool3d_forward_bf16(const void *x, void *y, uint32_t *arg
                                            mr3d_stream_t s) {
   if (!x || !y || !argmax || c % 4) return MR3D_ERR_INVALID_ARG;
   const int Do = (d - 1) / 2 + 1, Ho = (h - 1) / 2 + 1, Wo = (w - 1) / 2 + 1;
-  maxpool_fwd_kernel<<<(unsigned)((n * Do * Ho + 7) / 8 * 8), kT, 0, mr3d_stream(s)>>>((const bf16_t *)x, (bf16_t *)y, argmax, n, d, h, w, c,
-                                                                                        Do, Ho, Wo);
+  maxpool_fwd_kernel<<<(unsigned)((n * Do * Ho + 7) / 8 * 8), Wo * (c / 4) > kT ? 2 * kT : kT, 0, mr3d_stream(s)>>>((const bf16_t *)x, (bf16_t *)y, argmax, n, d,
+                                                                                                                          h, w, c, Do, Ho, Wo);
   return mr3d_launch_status();
 }
 
