@@ -529,6 +529,20 @@ __global__ __launch_bounds__(kRankThreads) void nms3d_rank_sort_kernel(const flo
 // one wave per (suppressor block r, column block c >= r): lane = column box j, loop over the 64 boxes of block r (LDS).
 // SKIP: threshold >= 0 -- an iteration in which no lane's pair intersects leaves every bit clear (0 / x > thr is false), so
 // the division is skipped wave-uniformly; sets of small boxes spend most iterations there.
+// v_max_f32 / v_min_f32 as the hardware executes them (IEEE maxNum / minNum: a quiet NaN operand yields the other one, like CUDA's
+// fmaxf / fminf in devIoU3d).  Through fmaxf() the compiler first canonicalises every operand it cannot prove quiet -- six extra
+// `v_max x, x` per pair for the box read from LDS, 15 % of the loop.
+__device__ __forceinline__ float hw_max(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float hw_min(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 template <bool SKIP>
 __global__ __launch_bounds__(MR3D_WAVE) void nms3d_mask_t2_kernel(const float4 *__restrict__ boxes_all, SegTable seg, float thr,
                                                                  uint64_t *__restrict__ mask_all) {
@@ -552,16 +566,19 @@ __global__ __launch_bounds__(MR3D_WAVE) void nms3d_mask_t2_kernel(const float4 *
     const float4 b0 = boxes[2 * j], b1 = boxes[2 * j + 1];          // b = the later box (column), a = the earlier (row): devIoU3d(a, b)
     const int rsz = min(n - r * 64, 64);
     const int stop = (r == c) ? lane : rsz;                           // diagonal block: earlier boxes only
+    float4 a0 = rbx[0], a1 = rbx[1];
     for (int k = 0; k < rsz; ++k) {
-      const float4 a0 = rbx[2 * k], a1 = rbx[2 * k + 1];
-      float left = fmaxf(a0.x, b0.x), right = fminf(a0.z, b0.z);
-      float top = fmaxf(a0.y, b0.y), bottom = fminf(a0.w, b0.w);
-      float front = fmaxf(a1.x, b1.x), back = fminf(a1.y, b1.y);
+      const float4 n0 = rbx[2 * min(k + 1, rsz - 1)], n1 = rbx[2 * min(k + 1, rsz - 1) + 1];      // the next box travels under this pair's arithmetic
+      float left = hw_max(a0.x, b0.x), right = hw_min(a0.z, b0.z);
+      float top = hw_max(a0.y, b0.y), bottom = hw_min(a0.w, b0.w);
+      float front = hw_max(a1.x, b1.x), back = hw_min(a1.y, b1.y);
       float width = fmaxf(right - left + 1, 0.f), height = fmaxf(bottom - top + 1, 0.f);
       float depth = fmaxf(back - front + 1, 0.f);
       float interS = width * height * depth;
+      const float sa = a1.z;
+      a0 = n0; a1 = n1;
       if (SKIP && __ballot(interS > 0.f) == 0ull) continue;
-      float iou = interS / (a1.z + b1.z - interS);
+      float iou = interS / (sa + b1.z - interS);
       if (k < stop && iou > thr) t |= 1ull << k;
     }
   }
