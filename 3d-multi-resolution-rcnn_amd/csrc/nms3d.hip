@@ -701,6 +701,11 @@ void launch_sweep(const uint64_t *mask, const int *order, const SegTable &seg, i
   }
 }
 
+// (Round 4, measured and rejected: the three phases as ONE persistent launch -- one 16-wave workgroup per CU walking the phases' work
+// items, two grid barriers on a device counter where the kernel boundaries are.  Correct, but 82 us against 62 us for the ten
+// sets and 45 us against 22 us for a single 192-box set: a grid barrier costs more than a kernel boundary here -- every
+// workgroup's release / acquire fence writes back and invalidates its XCD's L2, and the barrier waits for the launch ramp of all
+// 256 workgroups twice.)
 // n <= 2048 per set: T2 words + chain sweep
 void launch_chain(const float4 *boxes, const int *order, const SegTable &seg, int num_segments, int max_cb, float thr, uint64_t *mask,
                   int64_t *keep, int32_t *num_keep, hipStream_t stream) {
