@@ -290,6 +290,8 @@ int plan_run_impl(const mr3d_op *ops, int num_ops, int *failed_index, mr3d_strea
       } else if (o.kind == MR3D_OP_MAXPOOL_FWD) skip = skip_mask & 8;
       else if (o.kind == MR3D_OP_FINISH_GRADS) skip = skip_mask & 16;
       else if (o.kind == MR3D_OP_STEM_WGRAD) skip = skip_mask & 32;
+      else if (o.kind == MR3D_OP_STEM_FWD) skip = skip_mask & 256;
+      else if (o.kind == MR3D_OP_ZERO_STUFF2 || o.kind == MR3D_OP_UPSAMPLE_ADJ || o.kind == MR3D_OP_MAXPOOL_BWD) skip = skip_mask & 512;
       else if (o.kind == MR3D_OP_CONV_FWD) skip = (skip_mask & 128) && i[6] == 3 && i[4] >= 64 && (long long)i[0] * i[1] * i[2] * i[3] < 32768;
       if (skip) continue;
     }
