@@ -24,6 +24,8 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 using bf16_t = uint16_t;
 typedef __attribute__((address_space(3))) s16x4 *lds_s16x4_ptr;
 
@@ -217,26 +219,23 @@ __global__ __launch_bounds__(512, 1) void stem_fwd_bf16_kernel(StemBfArgs p, int
 struct WgGeo {
   static constexpr int TD = 4, TH = 4, TW = 32, NT = 512;
   static constexpr int HD = TD + 6, HH = 2 * (TH - 1) + 7;                    // 10 x 13 rows
-  static constexpr int HALF = 38;                                             // columns per parity plane (36 used; 38 and the plane pad below
-                                                                              //   spread a fragment dword's 32 lanes over the banks: see PLANE)
-  // A row holds FOUR images: even columns, even columns shifted by one, odd columns, odd columns shifted by one.  A fragment
-  // starts at plane index ow + (kw >> 1): with the shifted copy every start is an EVEN element = 4-byte aligned.  (2-byte
-  // aligned 16-byte LDS reads work on gfx950 but were measured ~10x slower than dword-aligned ones: 1.68 ms for this kernel.)
-  static constexpr int ROW = 4 * HALF;
-  // A fragment is four dword reads (4-byte aligned starts), 32 lanes per LDS pass: 16 GEMM rows (8 kw x 2 channels, or 2 (kd, kh)
-  // rows) x 2 k-groups.  With HALF = 40 and planes of 10400 dwords the rows r and r + 8 -- the same tap of channels c and c + 1 -- sat
-  // on the SAME bank and the (kw, q) pattern {0,8,20,28,1,9,21,29} + {0,4} collided with itself: 4-way on average, 71 % of this
-  // kernel's LDS-active cycles were conflict cycles.  HALF = 38 with a 2-element plane pad (searched over HALF, plane and row pads
-  // with the kernel's own address map) leaves 2-way: 1.03 -> 0.8 ms.
-  static constexpr int PLANE = HD * HH * ROW + 2;
+  // The slab holds the even and the odd input columns as two separate images of [channel][depth][row][40] bf16 (36 used: column
+  // 2*ow + kw of the slab = image kw & 1, index ow + (kw >> 1)).  A lane serves ONE (channel, kd, kh) group per row tile: it reads
+  // the aligned window of 12 (even image) / 10 (odd image) elements that holds the fragments of ALL the group's kw taps -- 24 + 20
+  // bytes for 7 fragments instead of 7 x 16 -- and shifts the odd starts out with v_alignbit.  Strides in dwords: a row is 20, the
+  // pads make (group g + 1) - (group g) == 20 (mod 32) across the kh, kd and channel wraps, so the 16-byte reads of any 8
+  // consecutive lanes cover the 32 banks once.
+  static constexpr int ROWD = 20, DSTR = HH * ROWD + 8, PLN = HD * DSTR + 28;
+  static_assert((DSTR - 6 * ROWD) % 32 == ROWD && (PLN - 6 * DSTR - 6 * ROWD) % 32 == ROWD, "regular bank stride over the group wraps");
+  static constexpr int IMG_BYTES = 3 * PLN * 4;
+  static_assert(IMG_BYTES % 16 == 0 && (DSTR % 4) == 0 && (PLN % 4) == 0, "16-byte aligned windows");
   static constexpr int DYROW = 24;                                            // bf16 per dy row: 16 + 8 of padding (48 B)
   static constexpr int M = TD * TH * TW, KS = TD * TH;
-  static constexpr int SLAB_BYTES = (3 * PLANE * 2 + 15) / 16 * 16, DY_BYTES = M * DYROW * 2;
+  static constexpr int SLAB_BYTES = 2 * IMG_BYTES, DY_BYTES = M * DYROW * 2;
   static constexpr int LDS_BYTES = SLAB_BYTES + DY_BYTES + 64;
-  static constexpr int SCATTER_BYTES = M * 8 * 4;                            // POOLED: fp32 [position][8] the windows add into, one channel half at a time
+  static constexpr int SCATTER_BYTES = M * 16 * 4;                           // POOLED: fp32 [position][16] the windows add into
   static constexpr int WINDOWS = 3 * 3 * 17;                                  // pooled windows that reach a 4 x 4 x 32 tile
-  static constexpr int ROWS = 49 * 24, MT = (ROWS + 15) / 16;                 // 1176 GEMM rows -> 74 tiles (+ 1 of ones)
-  static constexpr int MTW = 10;                                              // row tiles per wave (8 waves x 10 >= 75)
+  static constexpr int GROUPS = 3 * 49;                                       // 147 (channel, kd, kh) groups -> 10 row tiles x 7 kw
   static constexpr int PAIRS = 36;                                            // columns -1 .. 70; 13 rows x 36 pairs = 468 threads per plane
   static_assert(HH * PAIRS <= NT, "one (channel, depth) plane per staging step");
 };
@@ -248,12 +247,19 @@ struct StemBfWgArgs {
   const uint32_t *pool_idx; const bf16_t *pooled;
   int Dp, Hp, Wp;
   int queue_slot;                      // g_stem_bf16_queues slot of this launch
+  int dbg;
 };
 
 // tile queues of the weight-gradient kernel, as in csrc/stem.hip: per slot 8 queue heads + 1 finished-workgroup count,
 // all 0 between launches
 __device__ unsigned g_stem_bf16_queues[64 * 16];
 
+template <int V> struct IntC { static constexpr int value = V; };
+
+// Work split of a k-step over the 8 waves: a unit = (row tile of 16 groups, column parity) = 4 (even kw) or 3 (odd kw) MFMAs on one
+// window.  Waves 0-3: two even units (wave 0 also the tile of ones: sum_p dy); waves 4-5: three odd units; waves 6-7: one even +
+// two odd -- 8..10 MFMAs per wave, 17-18 per SIMD (waves w and w + 4).
+//
 // POOLED: the max-pool backward (3x3x3 / stride 2 / pad 1) and the stem's ReLU mask are folded into the dy staging: the
 // windows that reach the tile add relu'(pooled) * g at their arg-max into an fp32 tile in LDS, which is rounded to the bf16 dy
 // rows once (the un-pooled bf16 gradient -- 168 MB on the 512 volume -- is neither written nor read).
@@ -261,7 +267,6 @@ template <bool POOLED>
 __global__ __launch_bounds__(512, 1) void stem_wgrad_bf16_kernel(StemBfWgArgs p, int tiles_d, int tiles_h, int tiles_w, int ntiles) {
   using G = WgGeo;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  bf16_t *slab = reinterpret_cast<bf16_t *>(lds);
   unsigned char *dyt = lds + G::SLAB_BYTES;
   float *scat = reinterpret_cast<float *>(lds + G::LDS_BYTES);       // POOLED only
   const int tid = threadIdx.x, lane = tid & 63;
@@ -270,34 +275,25 @@ __global__ __launch_bounds__(512, 1) void stem_wgrad_bf16_kernel(StemBfWgArgs p,
   const size_t vox = (size_t)p.D * p.H * p.W;
   const bool even_w = (p.W & 1) == 0;
 
-  // per-lane slab offset (bytes) of GEMM row R = 16*m + r for every row tile of this wave, k = 8q (+ j) folded in
-  int aoff[G::MTW];
-  bool ones[G::MTW], live[G::MTW];
-#pragma unroll
-  for (int i = 0; i < G::MTW; ++i) {
-    const int m = wave + 8 * i;                          // wave-uniform tile index
-    const int R = 16 * m + r;
-    const int kdkh = R / 24, rem = R - kdkh * 24, c = rem >> 3, kw = rem & 7;
-    const int kd = kdkh / 7, kh = kdkh - kd * 7;
-    ones[i] = (m == G::MT);                              // the extra tile: a fragment of ones -> sum_p dy
-    live[i] = (m < G::MT) && R < G::ROWS && kw < 7;
-    // input column 2*ow + kw (relative to the slab origin): parity plane kw & 1, index ow + (kw >> 1)
-    // (a dead kw = 7 lane reads its kw = 6 neighbour's fragment -- the same dwords: a broadcast, not a conflict -- and drops it)
-    const bool in_rows = (m < G::MT) && R < G::ROWS;
-    const int cc = in_rows ? c : 0, kk = in_rows ? min(kw, 6) : 0, dd = in_rows ? kd : 0, hh_ = in_rows ? kh : 0;
-    const int sft = kk >> 1;                             // odd start -> the copy shifted by one, one element earlier
-    aoff[i] = (cc * G::PLANE + (dd * G::HH + hh_) * G::ROW + (kk & 1) * 2 * G::HALF + (sft & 1) * G::HALF + (sft & ~1) + 8 * q) * 2;
-  }
+  // units of this wave (wave-uniform row tiles) and the lane's window offsets (bytes; k = 8q folded in)
+  int egt[2] = {0, 0}, ogt[3] = {0, 0, 0};
+  if (wave < 4) { egt[0] = 2 * wave; egt[1] = 2 * wave + 1; }
+  else if (wave < 6) { ogt[0] = 3 * (wave - 4); ogt[1] = ogt[0] + 1; ogt[2] = ogt[0] + 2; }
+  else { egt[0] = 8 + (wave - 6); ogt[0] = 6 + 2 * (wave - 6); ogt[1] = ogt[0] + 1; }
+  auto window_off = [&](int gt) {                        // a lane past the last group reads the last group's window and drops the result
+    const int g = min(16 * gt + r, G::GROUPS - 1);
+    const int c = g / 49, kdkh = g - c * 49, kd = kdkh / 7, kh = kdkh - kd * 7;
+    return (c * G::PLN + kd * G::DSTR + kh * G::ROWD + 4 * q) * 4;
+  };
+  const int eoff[2] = {window_off(egt[0]), window_off(egt[1])};
+  const int ooff[3] = {window_off(ogt[0]) + G::IMG_BYTES, window_off(ogt[1]) + G::IMG_BYTES, window_off(ogt[2]) + G::IMG_BYTES};
   // transposing read of dy [position][16]: group q reads positions 8q..8q+7; inside the group lane 4a+b gives row a, columns 4b..4b+3
   const int i16 = lane & 15, ra = i16 >> 2, cb = i16 & 3;
   const int b_lane = (8 * q + ra) * (G::DYROW * 2) + cb * 8;
 
-  f32x4_t acc[G::MTW];
+  f32x4_t acc[10];
 #pragma unroll
-  for (int i = 0; i < G::MTW; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  bf16x8 one8, zero8;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { one8[e] = (__bf16)1.0f; zero8[e] = (__bf16)0.0f; }
+  for (int i = 0; i < 10; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   // next tile's operands in registers: x as aligned float2 pairs, dy as two 16-byte halves of one position row.
   // Staging map as in the forward kernel: iteration u = one (channel, depth) plane, thread = (row hh, column pair pr).
@@ -315,16 +311,29 @@ __global__ __launch_bounds__(512, 1) void stem_wgrad_bf16_kernel(StemBfWgArgs p,
     const bool row_ok = s_act && tile_ok && (unsigned)ih < (unsigned)p.H;
     const bool pair_ok = even_w && iw >= 0 && iw + 1 < p.W;
     const long long off = (long long)ih * p.W + iw;
+    if (even_w) {
+      // even W: iw is even, a pair is inside the row or outside it as a whole.  Buffer loads: a lane outside its row gets an offset
+      // past the end of the image and the hardware returns zeros -- no bounds test around a load, the 30 of them are in flight together
+      // (a load inside a per-lane bounds test is a branch per load and the wave walks them one after the other)
+      const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x + (size_t)n * 3 * vox), 0,
+                                                                          (unsigned)(3 * vox * 4), 0x00020000);
+      const unsigned voff = (row_ok && pair_ok) ? (unsigned)off * 4u : 0x80000000u;
 #pragma unroll
-    for (int u = 0; u < NPL; ++u) {
-      const int c = u / G::HD, hd = u % G::HD;
-      const int id = id0 + hd;
-      st[u] = make_float2(0.f, 0.f);
-      if (row_ok && (unsigned)id < (unsigned)p.D) {
-        const float *src = p.x + ((size_t)n * 3 + c) * vox + (size_t)id * p.H * p.W + off;
-        if (pair_ok) {
-          st[u] = *reinterpret_cast<const float2 *>(src);
-        } else {
+      for (int u = 0; u < NPL; ++u) {
+        const int c = u / G::HD, hd = u % G::HD;
+        const int id = id0 + hd;                         // wave-uniform
+        st[u] = make_float2(0.f, 0.f);
+        if ((unsigned)id < (unsigned)p.D)
+          st[u] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(xr, (int)voff, (int)(((unsigned)c * (unsigned)vox + (unsigned)id * (unsigned)(p.H * p.W)) * 4u), 0));
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < NPL; ++u) {
+        const int c = u / G::HD, hd = u % G::HD;
+        const int id = id0 + hd;
+        st[u] = make_float2(0.f, 0.f);
+        if (row_ok && (unsigned)id < (unsigned)p.D) {
+          const float *src = p.x + ((size_t)n * 3 + c) * vox + (size_t)id * p.H * p.W + off;
           if ((unsigned)iw < (unsigned)p.W) st[u].x = src[0];
           if ((unsigned)(iw + 1) < (unsigned)p.W) st[u].y = src[1];
         }
@@ -362,18 +371,14 @@ __global__ __launch_bounds__(512, 1) void stem_wgrad_bf16_kernel(StemBfWgArgs p,
     }
   };
   auto commit = [&]() {
-    // slab: column s = iw - iw0; even s -> even image index s/2, odd s -> odd image index (s-1)/2; the pair (2*pr - 1, 2*pr)
-    // lands at odd index pr - 1 and even index pr (and one element earlier in the shifted copies)
+    // slab column s = iw - iw0: the pair (2*pr - 1, 2*pr) lands at odd-image index pr - 1 and even-image index pr
     if (s_act) {
-      bf16_t *dst = slab + s_hh * G::ROW;
+      bf16_t *dst = reinterpret_cast<bf16_t *>(lds) + s_hh * (2 * G::ROWD);
 #pragma unroll
       for (int u = 0; u < NPL; ++u) {
-        bf16_t *d = dst + (u / G::HD) * G::PLANE + (u % G::HD) * G::HH * G::ROW;
-        const bf16_t vo = f2bf(st[u].x), ve = f2bf(st[u].y);          // odd-plane index pr - 1, even-plane index pr
-        if (s_pr >= 1) d[2 * G::HALF + s_pr - 1] = vo;
-        if (s_pr >= 2) d[3 * G::HALF + s_pr - 2] = vo;                // shifted copy: X1[i] = X0[i + 1]
-        d[s_pr] = ve;
-        if (s_pr >= 1) d[G::HALF + s_pr - 1] = ve;
+        bf16_t *d = dst + ((u / G::HD) * G::PLN + (u % G::HD) * G::DSTR) * 2;
+        d[s_pr] = f2bf(st[u].y);
+        if (s_pr >= 1) d[G::IMG_BYTES / 2 + s_pr - 1] = f2bf(st[u].x);
       }
     }
     if constexpr (!POOLED) {
@@ -381,37 +386,109 @@ __global__ __launch_bounds__(512, 1) void stem_wgrad_bf16_kernel(StemBfWgArgs p,
       *reinterpret_cast<uint4 *>(dyt + tid * (G::DYROW * 2) + 16) = sdy[1];
     }
   };
-  // POOLED: the windows of channel quads 2*half, 2*half + 1 add their gradient at their arg-max (143 KB of slab + dy rows leave
-  // room for 8 of the 16 channels in fp32: two rounds per tile)
-  auto scatter = [&](int half) {
+  // POOLED: every window adds its gradient at its arg-max position of the tile
+  auto scatter = [&]() {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int it = tid + j * G::NT, q4 = it & 3, pp = it >> 2;
-      if ((q4 >> 1) != half) continue;
       const int pw = pp % 17, ph = (pp / 17) % 3, pd = pp / 51;
       const uint32_t gq[2] = {sdy[j].y, sdy[j].z};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const uint32_t gb = (r & 1) ? (gq[r >> 1] & 0xffff0000u) : (gq[r >> 1] << 16);
-        const int tap = (sdy[j].x >> (8 * r)) & 255;
+      for (int rr = 0; rr < 4; ++rr) {
+        const uint32_t gb = (rr & 1) ? (gq[rr >> 1] & 0xffff0000u) : (gq[rr >> 1] << 16);
+        const int tap = (sdy[j].x >> (8 * rr)) & 255;
         const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
         // window (pd, ph, pw) of the tile's window block covers tile positions 2 p - 1 + k
         const int td = 2 * pd - 1 + kd, th = 2 * ph - 1 + kh, tw = 2 * pw - 1 + kw;
-        if (((sdy[j].w >> r) & 1u) && (gb & 0x7fffffffu) != 0u && (unsigned)td < (unsigned)G::TD && (unsigned)th < (unsigned)G::TH &&
+        if (((sdy[j].w >> rr) & 1u) && (gb & 0x7fffffffu) != 0u && (unsigned)td < (unsigned)G::TD && (unsigned)th < (unsigned)G::TH &&
             (unsigned)tw < (unsigned)G::TW)
-          atomicAdd(scat + ((td * G::TH + th) * G::TW + tw) * 8 + (q4 & 1) * 4 + r, __uint_as_float(gb));
+          atomicAdd(scat + ((td * G::TH + th) * G::TW + tw) * 16 + q4 * 4 + rr, __uint_as_float(gb));
       }
     }
   };
-  // after the barrier behind scatter(half): a thread rounds its position's 8 sums into its bf16 dy row and clears them
-  auto round_rows = [&](int half) {
-    float4 *src = reinterpret_cast<float4 *>(scat + tid * 8);
-    const float4 a = src[0], b = src[1];
-    src[0] = src[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-    *reinterpret_cast<uint4 *>(dyt + tid * (G::DYROW * 2) + half * 16) =
-        make_uint4((uint32_t)f2bf(a.x) | ((uint32_t)f2bf(a.y) << 16), (uint32_t)f2bf(a.z) | ((uint32_t)f2bf(a.w) << 16),
-                   (uint32_t)f2bf(b.x) | ((uint32_t)f2bf(b.y) << 16), (uint32_t)f2bf(b.z) | ((uint32_t)f2bf(b.w) << 16));
+  // after the barrier behind scatter(): a thread rounds its position's 16 sums into its bf16 dy row and clears them
+  auto round_rows = [&]() {
+    float4 *src = reinterpret_cast<float4 *>(scat + tid * 16);
+    auto pk = [](const float4 &a, const float4 &b) {
+      return make_uint4((uint32_t)f2bf(a.x) | ((uint32_t)f2bf(a.y) << 16), (uint32_t)f2bf(a.z) | ((uint32_t)f2bf(a.w) << 16),
+                        (uint32_t)f2bf(b.x) | ((uint32_t)f2bf(b.y) << 16), (uint32_t)f2bf(b.z) | ((uint32_t)f2bf(b.w) << 16));
+    };
+    const float4 a = src[0], b = src[1], c = src[2], d = src[3];
+    src[0] = src[1] = src[2] = src[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<uint4 *>(dyt + tid * (G::DYROW * 2)) = pk(a, b);
+    *reinterpret_cast<uint4 *>(dyt + tid * (G::DYROW * 2) + 16) = pk(c, d);
   };
+
+  // ---- the 16 k-steps of a tile for a wave with NE even and NO odd units (+ the tile of ones)
+  auto mma_phase = [&](auto ne_, auto no_, auto ones_) {
+    constexpr int NE = decltype(ne_)::value, NO = decltype(no_)::value;
+    constexpr bool ONES = decltype(ones_)::value != 0;
+    struct Ops { u32x4 ea[NE ? NE : 1]; u32x2 eb[NE ? NE : 1]; u32x4 oa[NO ? NO : 1]; uint32_t ob[NO ? NO : 1]; bf16x8 b; };
+    auto load_step = [&](int ks, Ops &o) {
+      const int th = ks % G::TH, td = ks / G::TH;
+      unsigned char *yb = dyt + ks * 32 * (G::DYROW * 2) + b_lane;
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(yb));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(yb + 4 * (G::DYROW * 2)));
+      o.b = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      const int rowoff = (td * G::DSTR + 2 * th * G::ROWD) * 4;
+#pragma unroll
+      for (int u = 0; u < NE; ++u) {
+        o.ea[u] = *reinterpret_cast<const u32x4 *>(lds + eoff[u] + rowoff);
+        o.eb[u] = *reinterpret_cast<const u32x2 *>(lds + eoff[u] + rowoff + 16);
+      }
+#pragma unroll
+      for (int u = 0; u < NO; ++u) {
+        o.oa[u] = *reinterpret_cast<const u32x4 *>(lds + ooff[u] + rowoff);
+        o.ob[u] = *reinterpret_cast<const uint32_t *>(lds + ooff[u] + rowoff + 16);
+      }
+    };
+    auto mfma = [&](f32x4_t &c, uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, const bf16x8 &b) {
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, u32x4{a0, a1, a2, a3}), b, c, 0, 0, 0);
+    };
+    auto mma_step = [&](const Ops &o) {
+#pragma unroll
+      for (int u = 0; u < NE; ++u) {
+        const uint32_t d0 = o.ea[u][0], d1 = o.ea[u][1], d2 = o.ea[u][2], d3 = o.ea[u][3], d4 = o.eb[u][0], d5 = o.eb[u][1];
+        const uint32_t s0 = __builtin_amdgcn_alignbit(d1, d0, 16), s1 = __builtin_amdgcn_alignbit(d2, d1, 16),
+                       s2 = __builtin_amdgcn_alignbit(d3, d2, 16), s3 = __builtin_amdgcn_alignbit(d4, d3, 16),
+                       s4 = __builtin_amdgcn_alignbit(d5, d4, 16);
+        mfma(acc[4 * u + 0], d0, d1, d2, d3, o.b);          // kw 0: elements 0..7
+        mfma(acc[4 * u + 1], s0, s1, s2, s3, o.b);          // kw 2: 1..8
+        mfma(acc[4 * u + 2], d1, d2, d3, d4, o.b);          // kw 4: 2..9
+        mfma(acc[4 * u + 3], s1, s2, s3, s4, o.b);          // kw 6: 3..10
+      }
+#pragma unroll
+      for (int u = 0; u < NO; ++u) {
+        const uint32_t d0 = o.oa[u][0], d1 = o.oa[u][1], d2 = o.oa[u][2], d3 = o.oa[u][3], d4 = o.ob[u];
+        const uint32_t s0 = __builtin_amdgcn_alignbit(d1, d0, 16), s1 = __builtin_amdgcn_alignbit(d2, d1, 16),
+                       s2 = __builtin_amdgcn_alignbit(d3, d2, 16), s3 = __builtin_amdgcn_alignbit(d4, d3, 16);
+        mfma(acc[4 * NE + 3 * u + 0], d0, d1, d2, d3, o.b);   // kw 1
+        mfma(acc[4 * NE + 3 * u + 1], s0, s1, s2, s3, o.b);   // kw 3
+        mfma(acc[4 * NE + 3 * u + 2], d1, d2, d3, d4, o.b);   // kw 5
+      }
+      if constexpr (ONES) mfma(acc[4 * NE + 3 * NO], 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, o.b);
+    };
+    // the windows of k-step ks + 1 are requested before the MFMAs of k-step ks
+    Ops o0, o1;
+    load_step(0, o0);
+#pragma unroll 1
+    for (int ks = 0; ks < G::KS; ks += 2) {
+      load_step(ks + 1, o1);
+      mma_step(o0);
+      if (ks + 2 < G::KS) load_step(ks + 2, o0);
+      mma_step(o1);
+    }
+  };
+  // ---- write-out of one accumulator: column (cout) = lane & 15, group = 16*gt + 4*(lane>>4) + reg
+  auto write_acc = [&](const f32x4_t &a, int gt, int kw) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int g = 16 * gt + 4 * q + e;
+      const int c = g / 49, kdkh = g - c * 49;
+      if (g < G::GROUPS) atomicAdd(p.dw + ((size_t)(kdkh * 7 + kw) * 4 + c) * 16 + r, a[e]);
+    }
+  };
+
   // Tiles are pulled from eight queues (one contiguous range of the depth-fastest order per XCD, the workgroup's own XCD first):
   // with a fixed run per workgroup the launch ended with its latest workgroup, and in the training step the other layers'
   // last weight gradients and their finishing run beside this kernel (see stem_wgrad_kernel in csrc/stem.hip).
@@ -432,7 +509,7 @@ __global__ __launch_bounds__(512, 1) void stem_wgrad_bf16_kernel(StemBfWgArgs p,
     return -1;
   };
   if constexpr (POOLED) {
-    for (int e = tid; e < G::M * 2; e += G::NT) reinterpret_cast<float4 *>(scat)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = tid; e < G::M * 4; e += G::NT) reinterpret_cast<float4 *>(scat)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   unsigned ticket = 0;
   if (tid == 0) s_tile = take(atomicAdd(queue + home, 1u));
@@ -442,48 +519,22 @@ __global__ __launch_bounds__(512, 1) void stem_wgrad_bf16_kernel(StemBfWgArgs p,
   if (tid == 0) ticket = atomicAdd(queue + home, 1u);
   while (tile >= 0) {
     __syncthreads();
-    commit();
-    if constexpr (POOLED) scatter(0);
+    if (!(p.dbg & 2)) commit();
+    if constexpr (POOLED) { if (!(p.dbg & 8)) scatter(); }
     if (tid == 0) s_tile = take(ticket);                 // issued a tile ago
     __syncthreads();
     if constexpr (POOLED) {
-      round_rows(0);
-      __syncthreads();
-      scatter(1);
-      __syncthreads();
-      round_rows(1);
+      round_rows();
       __syncthreads();
     }
     const int next = __builtin_amdgcn_readfirstlane(s_tile);
     if (tid == 0 && next >= 0) ticket = atomicAdd(queue + home, 1u);
-    fetch(next >= 0 ? next : ntiles);                    // in flight during the MFMA phase
-    // the ten row-tile fragments and the dy fragment of a k-step are requested together, before its first MFMA
-    // (read-then-multiply per tile left every 16-cycle MFMA waiting for an LDS round trip; double-buffering them across
-    // k-steps as well needs 80 more registers and spills); tiles past the end of a wave's list multiply a valid but unused
-    // fragment instead of branching
-    auto load_step = [&](int ks, bf16x8 (&a)[G::MTW], bf16x8 &bf) {
-      const int th = ks % G::TH, td = ks / G::TH;
-      unsigned char *yb = dyt + ks * 32 * (G::DYROW * 2) + b_lane;
-      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(yb));
-      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(yb + 4 * (G::DYROW * 2)));
-      bf = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-      const int rowoff = ((td * G::HH + 2 * th) * G::ROW) * 2;
-#pragma unroll
-      for (int i = 0; i < G::MTW; ++i) {
-        a[i] = lds_frag_unaligned(lds + aoff[i] + rowoff);
-        if (!live[i]) a[i] = ones[i] ? one8 : zero8;
-      }
-    };
-    auto mma_step = [&](const bf16x8 (&a)[G::MTW], const bf16x8 &bf) {
-#pragma unroll
-      for (int i = 0; i < G::MTW; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bf, acc[i], 0, 0, 0);
-    };
-    bf16x8 aA[G::MTW], bA;
-    for (int ks = 0; ks < G::KS; ++ks) {
-      load_step(ks, aA, bA);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_step(aA, bA);
-    }
+    if (!(p.dbg & 4)) fetch(next >= 0 ? next : ntiles);                    // in flight during the MFMA phase
+    if (p.dbg & 1) {} else
+    if (wave == 0) mma_phase(IntC<2>{}, IntC<0>{}, IntC<1>{});
+    else if (wave < 4) mma_phase(IntC<2>{}, IntC<0>{}, IntC<0>{});
+    else if (wave < 6) mma_phase(IntC<0>{}, IntC<3>{}, IntC<0>{});
+    else mma_phase(IntC<1>{}, IntC<2>{}, IntC<0>{});
     tile = next;
   }
   if (tid == 0) {                                        // the last workgroup to run dry re-arms the queues
@@ -493,21 +544,24 @@ __global__ __launch_bounds__(512, 1) void stem_wgrad_bf16_kernel(StemBfWgArgs p,
       for (int x = 0; x < 9; ++x) atomicExch(queue + x, 0u);
     }
   }
-  // ---- write-out: column (cout) = lane & 15, GEMM row = 16*m + 4*(lane>>4) + reg
+  if (wave < 4) {
 #pragma unroll
-  for (int i = 0; i < G::MTW; ++i) {
-    const int m = wave + 8 * i;
-    if (m > G::MT) continue;
-    if (m == G::MT) {
-      if (p.dbias && q == 0) atomicAdd(p.dbias + r, acc[i][0]);
-      continue;
-    }
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int R = 16 * m + 4 * q + e;
-      const int kdkh = R / 24, rem = R - kdkh * 24, c = rem >> 3, kw = rem & 7;
-      if (R < G::ROWS && kw < 7) atomicAdd(p.dw + ((size_t)(kdkh * 7 + kw) * 4 + c) * 16 + r, acc[i][e]);
-    }
+      for (int k = 0; k < 4; ++k) write_acc(acc[4 * u + k], egt[u], 2 * k);
+    if (wave == 0 && p.dbias && q == 0) atomicAdd(p.dbias + r, acc[8][0]);
+  } else if (wave < 6) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) write_acc(acc[3 * u + k], ogt[u], 2 * k + 1);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) write_acc(acc[k], egt[0], 2 * k);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) write_acc(acc[4 + 3 * u + k], ogt[u], 2 * k + 1);
   }
 }
 
@@ -583,6 +637,7 @@ static int stem_wgrad_bf16_impl(const float *x_ncdhw, const void *dy_bf16, const
   if (grid >= 8) grid &= ~7;
   static std::atomic<unsigned> next_slot{0};                 // ring of queue slots: see stem_wgrad_impl in csrc/stem.hip
   a.queue_slot = (int)(next_slot.fetch_add(1) & 63u);
+  a.dbg = g_mr3d_tuning[0];
   if (pool_idx)
     stem_wgrad_bf16_kernel<true><<<(unsigned)grid, 512, G::LDS_BYTES + G::SCATTER_BYTES, mr3d_stream(stream_)>>>(a, td, th, tw, (int)ntiles);
   else
