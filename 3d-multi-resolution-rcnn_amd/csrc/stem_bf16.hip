@@ -116,101 +116,133 @@ __global__ __launch_bounds__(512, 1) void stem_fwd_bf16_kernel(StemBfArgs p, int
   for (int i = tid; i < G::W_BYTES / 16; i += G::NT)
     reinterpret_cast<uint4 *>(wl)[i] = reinterpret_cast<const uint4 *>(p.w16)[i];
 
-  // staging map: iteration u = one (channel, depth) plane of the slab (compile-time), thread = (row hh, column pair pr) of it:
-  // the per-thread part of every address is ONE register, the plane part is wave-uniform
+  // Staging map: iteration u = one (channel, depth) plane of the slab (compile-time), thread = (row hh, column pair pr) of it:
+  // the per-thread part of every address is ONE register, the plane part is wave-uniform.
+  // A workgroup's tiles are depth-adjacent inside a (n, h, w) column and the slab's depth planes form a ring (input depth id lives
+  // in slot (id + 10) % 10): the first tile of a column (or of the run) stages its 10 planes, every later one only the 4 new ones.
   constexpr int NPL = 3 * G::HD;
   const int s_hh = tid / G::PAIRS, s_pr = tid - s_hh * G::PAIRS;
   const bool s_act = s_hh < G::HH;
   float2 st[NPL];
-  auto fetch = [&](int tile) {
-    const BfTile bt = bf_tile_of(tile < ntiles ? tile : 0, tiles_d, tiles_h, tiles_w);
+  // plane u of 30: 10 per channel at a start, 4 inside a column (ONE code path: see stem_wgrad_bf16_kernel)
+  auto plane_of = [&](int u, bool start, int id_first, int &c, int &id) {
+    c = start ? u / G::HD : u / G::TD;
+    id = id_first + (start ? u % G::HD : u % G::TD);
+    return start || u < 3 * G::TD;
+  };
+  auto fetch = [&](int tile, bool start) {
+    const BfTile bt = bf_tile_of(tile, tiles_d, tiles_h, tiles_w);
     const int tw_i = bt.tw, th_i = bt.th, td_i = bt.td, n = bt.n;
-    const int id0 = td_i * G::TD - 3, ih = 2 * th_i * G::TH - 3 + s_hh, iw = 2 * tw_i * G::TW - 3 + 2 * s_pr - 1;   // iw is even
-    const bool row_ok = s_act && tile < ntiles && (unsigned)ih < (unsigned)p.H;
-    const bool pair_ok = even_w && iw >= 0 && iw + 1 < p.W;
+    const int id_first = td_i * G::TD + (start ? -3 : 3);
+    const int ih = 2 * th_i * G::TH - 3 + s_hh, iw = 2 * tw_i * G::TW - 3 + 2 * s_pr - 1;   // iw is even
+    const bool row_ok = s_act && (unsigned)ih < (unsigned)p.H;
     const long long off = (long long)ih * p.W + iw;
+    if (even_w) {
+      // even W: iw is even, a pair is inside the row or outside it as a whole.  Buffer loads: a lane outside its row gets an offset
+      // past the end of the image and the hardware returns zeros -- no bounds test around a load, all of them are in flight together
+      // (a load inside a per-lane bounds test is a branch per load and the wave walks them one after the other)
+      const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x + (size_t)n * 3 * vox), 0,
+                                                                          (unsigned)(3 * vox * 4), 0x00020000);
+      const unsigned voff = (row_ok && iw >= 0 && iw + 1 < p.W) ? (unsigned)off * 4u : 0x80000000u;
 #pragma unroll
-    for (int u = 0; u < NPL; ++u) {
-      const int c = u / G::HD, hd = u % G::HD;
-      const int id = id0 + hd;                                        // wave-uniform
-      st[u] = make_float2(0.f, 0.f);
-      if (row_ok && (unsigned)id < (unsigned)p.D) {
-        const float *src = p.x + ((size_t)n * 3 + c) * vox + (size_t)id * p.H * p.W + off;
-        if (pair_ok) {
-          st[u] = *reinterpret_cast<const float2 *>(src);
-        } else {
+      for (int u = 0; u < NPL; ++u) {
+        int c, id;                                                       // wave-uniform
+        const bool used = plane_of(u, start, id_first, c, id);
+        st[u] = make_float2(0.f, 0.f);
+        if (used && (unsigned)id < (unsigned)p.D)
+          st[u] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(
+                                                 xr, (int)voff, (int)(((unsigned)c * (unsigned)vox + (unsigned)id * (unsigned)(p.H * p.W)) * 4u), 0));
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < NPL; ++u) {
+        int c, id;
+        const bool used = plane_of(u, start, id_first, c, id);
+        st[u] = make_float2(0.f, 0.f);
+        if (used && row_ok && (unsigned)id < (unsigned)p.D) {
+          const float *src = p.x + ((size_t)n * 3 + c) * vox + (size_t)id * p.H * p.W + off;
           if ((unsigned)iw < (unsigned)p.W) st[u].x = src[0];
           if ((unsigned)(iw + 1) < (unsigned)p.W) st[u].y = src[1];
         }
       }
     }
   };
-  auto commit = [&]() {
+  auto commit = [&](int td_i, bool start) {
     if (!s_act) return;
     bf16_t *dst = slab + s_hh * G::HW;                                // slab columns 2*pr - 1, 2*pr
+    const int s0 = (td_i * G::TD + (start ? -3 : 3) + 10) % 10;       // wave-uniform ring slot of the first plane
 #pragma unroll
     for (int u = 0; u < NPL; ++u) {
-      if (s_pr >= 1) dst[u * G::HH * G::HW + 2 * s_pr - 1] = f2bf(st[u].x);
-      dst[u * G::HH * G::HW + 2 * s_pr] = f2bf(st[u].y);
+      int c, id;
+      if (!plane_of(u, start, 0, c, id)) continue;
+      int slot = s0 + id;
+      slot -= slot >= 10 ? 10 : 0;
+      bf16_t *d = dst + (c * G::HD + slot) * (G::HH * G::HW);
+      if (s_pr >= 1) d[2 * s_pr - 1] = f2bf(st[u].x);
+      d[2 * s_pr] = f2bf(st[u].y);
     }
   };
 
-  // this wave's four (td, th) rows of 16 outputs; lane (r, q): output column r, channel slot q (slot 3: zeros)
-  int abase[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int mt = wave * 4 + i, td = mt >> 3, th = mt & 7;
-    abase[i] = ((((q < 3 ? q : 0) * G::HD + td) * G::HH + 2 * th) * G::HW + 2 * r) * 2;
-  }
+  // this wave's four consecutive (th) rows of 16 outputs at depth td; lane (r, q): output column r, channel slot q.  Slot 3 reads
+  // channel 0's columns: its weights are zero (stem_pack_bf16_kernel)
+  const int w_td = wave >> 1, w_th0 = (wave & 1) * 4;
+  const int abase = (((q < 3 ? q : 0) * G::HD * G::HH + 2 * w_th0) * G::HW + 2 * r) * 2;
   const unsigned char *wlane = wl + (q * 16 + r) * 16;
-  bf16x8 zero;
+  float sh4[4];
 #pragma unroll
-  for (int e = 0; e < 8; ++e) zero[e] = (__bf16)0.0f;
-  const float sh = p.shift ? p.shift[r] : 0.f;
+  for (int e = 0; e < 4; ++e) sh4[e] = p.shift ? p.shift[4 * q + e] : 0.f;
 
   int t_begin, t_end;
   bf_tile_run((int)blockIdx.x, (int)gridDim.x, ntiles, t_begin, t_end);
-  fetch(t_begin < t_end ? t_begin : ntiles);
+  auto starts = [&](int tile) { return tile == t_begin || tile % tiles_d == 0; };      // depth is the fastest tile index
+  if (t_begin < t_end) fetch(t_begin, true);
   for (int tile = t_begin; tile < t_end; ++tile) {
+    const BfTile bt = bf_tile_of(tile, tiles_d, tiles_h, tiles_w);
     __syncthreads();                       // the previous tile's fragments have been read
-    commit();
+    commit(bt.td, starts(tile));
     __syncthreads();
-    fetch(tile + 1 < t_end ? tile + 1 : ntiles);      // in flight during the MFMA phase
+    if (tile + 1 < t_end) fetch(tile + 1, starts(tile + 1));      // in flight during the MFMA phase
     f32x4_t acc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // The wave's four accumulators are four consecutive output rows: input row j of the 13 they reach feeds row i with tap
+    // kh = j - 2 i.  One fragment read per (kd, input row) serves up to 4 MFMAs (28 per kd from 13 reads instead of 28), the seven
+    // kh weight fragments of a kd wait in registers.  The weights are the A operand: the accumulator then holds 4 consecutive
+    // output channels of one position per lane -- 8-byte stores, 512 contiguous bytes per store instruction.
+    const int ring0 = (bt.td * G::TD + 7) % 10;                       // slot of input depth 4 td - 3
 #pragma unroll 1
     for (int kd = 0; kd < 7; ++kd) {
+      bf16x8 bw[7];
 #pragma unroll
-      for (int kh = 0; kh < 7; ++kh) {
-        const bf16x8 bw = *reinterpret_cast<const bf16x8 *>(wlane + (kd * 7 + kh) * 1024);
-        const int off = ((kd * G::HH + kh) * G::HW) * 2;
+      for (int kh = 0; kh < 7; ++kh) bw[kh] = *reinterpret_cast<const bf16x8 *>(wlane + (kd * 7 + kh) * 1024);
+      int slot = ring0 + w_td + kd;                                   // wave-uniform
+      slot -= slot >= 10 ? 10 : 0;
+      const unsigned char *arow = slab_b + abase + slot * (G::HH * G::HW * 2);
+#pragma unroll
+      for (int j = 0; j < 13; ++j) {
+        const bf16x8 a = lds_frag_unaligned(arow + j * (G::HW * 2));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          bf16x8 a = lds_frag_unaligned(slab_b + abase[i] + off);
-          if (q == 3) a = zero;
-          acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bw, acc[i], 0, 0, 0);
+          const int kh = j - 2 * i;
+          if (kh >= 0 && kh < 7) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[kh], a, acc[i], 0, 0, 0);
         }
       }
     }
-    // ---- epilogue: C/D layout of 16x16: column (cout) = lane & 15, row (output column) = 4 * (lane >> 4) + reg
-    const BfTile bt = bf_tile_of(tile < ntiles ? tile : 0, tiles_d, tiles_h, tiles_w);
-    const int tw_i = bt.tw, th_i = bt.th, td_i = bt.td, n = bt.n;
-    const int d0 = td_i * G::TD, h0 = th_i * G::TH, w0 = tw_i * G::TW;
+    // ---- epilogue: C/D layout of 16x16: column (output column) = lane & 15, row (cout) = 4 * (lane >> 4) + reg
+    const int d0 = bt.td * G::TD, h0 = bt.th * G::TH, w0 = bt.tw * G::TW;
+    const int od = d0 + w_td, ow = w0 + r;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int mt = wave * 4 + i, td = mt >> 3, th = mt & 7;
-      const int od = d0 + td, oh = h0 + th;
-      if (od >= p.D || oh >= p.Ho) continue;
+      const int oh = h0 + w_th0 + i;
+      if (od >= p.D || oh >= p.Ho || ow >= p.Wo) continue;
+      float v[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int ow = w0 + 4 * q + e;
-        if (ow < p.Wo) {
-          float v = acc[i][e] + sh;
-          if (p.relu) v = fmaxf(v, 0.f);
-          p.y[((((size_t)n * p.D + od) * p.Ho + oh) * p.Wo + ow) * 16 + r] = f2bf(v);
-        }
+        v[e] = acc[i][e] + sh4[e];
+        if (p.relu) v[e] = fmaxf(v[e], 0.f);
       }
+      *reinterpret_cast<uint2 *>(p.y + ((((size_t)bt.n * p.D + od) * p.Ho + oh) * p.Wo + ow) * 16 + 4 * q) =
+          make_uint2((uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16));
     }
   }
 }
@@ -219,18 +251,19 @@ __global__ __launch_bounds__(512, 1) void stem_fwd_bf16_kernel(StemBfArgs p, int
 struct WgGeo {
   static constexpr int TD = 4, TH = 4, TW = 32, NT = 512;
   static constexpr int HD = TD + 6, HH = 2 * (TH - 1) + 7;                    // 10 x 13 rows
-  // The slab holds the even and the odd input columns as two separate images of [channel][depth][row][40] bf16 (36 used: column
-  // 2*ow + kw of the slab = image kw & 1, index ow + (kw >> 1)).  A lane serves ONE (channel, kd, kh) group per row tile: it reads
-  // the aligned window of 12 (even image) / 10 (odd image) elements that holds the fragments of ALL the group's kw taps -- 24 + 20
-  // bytes for 7 fragments instead of 7 x 16 -- and shifts the odd starts out with v_alignbit.  Strides in dwords: a row is 20, the
-  // pads make (group g + 1) - (group g) == 20 (mod 32) across the kh, kd and channel wraps, so the 16-byte reads of any 8
-  // consecutive lanes cover the 32 banks once.
-  static constexpr int ROWD = 20, DSTR = HH * ROWD + 8, PLN = HD * DSTR + 28;
-  static_assert((DSTR - 6 * ROWD) % 32 == ROWD && (PLN - 6 * DSTR - 6 * ROWD) % 32 == ROWD, "regular bank stride over the group wraps");
+  // The slab holds the even and the odd input columns as two separate images of [channel][depth slot][row][48] bf16 (36 used:
+  // column 2*ow + kw of the slab = image kw & 1, index ow + (kw >> 1)).  A lane serves ONE (channel, kd, kh) group per row tile: it
+  // reads the aligned window of 12 elements that holds the fragments of ALL the group's kw taps of one column parity -- 24 bytes
+  // for 4 (even kw) or 3 (odd kw) fragments instead of 16 bytes each -- and shifts the odd starts out with v_perm / v_alignbit.
+  // Strides in dwords, searched with the LDS's own lane groups (ds_read_b128: 4 groups of 16 lanes over 64 banks, MI355X guide):
+  // rows of 24 put the 16-byte reads of a group's lanes r and r' on different banks (2 r + q (mod 16) chunks), the pads keep most
+  // of that across the kh / kd / channel wraps and the depth ring: 5.0 LDS cycles per ds_read_b128 (4 is the floor; rows of 20
+  // dwords: 8.0), 4.3 per tail ds_read_b64 (2-way by construction: 8 elements between k-groups).
+  static constexpr int ROWD = 24, DSTR = HH * ROWD + 48, PLN = HD * DSTR + 8;
   static constexpr int IMG_BYTES = 3 * PLN * 4;
   static_assert(IMG_BYTES % 16 == 0 && (DSTR % 4) == 0 && (PLN % 4) == 0, "16-byte aligned windows");
   static constexpr int DYROW = 24;                                            // bf16 per dy row: 16 + 8 of padding (48 B)
-  static constexpr int M = TD * TH * TW, KS = TD * TH;
+  static constexpr int M = TD * TH * TW;
   static constexpr int SLAB_BYTES = 2 * IMG_BYTES, DY_BYTES = M * DYROW * 2;
   static constexpr int LDS_BYTES = SLAB_BYTES + DY_BYTES + 64;
   static constexpr int SCATTER_BYTES = M * 16 * 4;                           // POOLED: fp32 [position][16] the windows add into
@@ -247,7 +280,6 @@ struct StemBfWgArgs {
   const uint32_t *pool_idx; const bf16_t *pooled;
   int Dp, Hp, Wp;
   int queue_slot;                      // g_stem_bf16_queues slot of this launch
-  int dbg;
 };
 
 // tile queues of the weight-gradient kernel, as in csrc/stem.hip: per slot 8 queue heads + 1 finished-workgroup count,
@@ -264,7 +296,8 @@ template <int V> struct IntC { static constexpr int value = V; };
 // windows that reach the tile add relu'(pooled) * g at their arg-max into an fp32 tile in LDS, which is rounded to the bf16 dy
 // rows once (the un-pooled bf16 gradient -- 168 MB on the 512 volume -- is neither written nor read).
 template <bool POOLED>
-__global__ __launch_bounds__(512, 1) void stem_wgrad_bf16_kernel(StemBfWgArgs p, int tiles_d, int tiles_h, int tiles_w, int ntiles) {
+__global__ __launch_bounds__(512, 1) void stem_wgrad_bf16_kernel(StemBfWgArgs p, int tiles_d, int tiles_h, int tiles_w, int run_len,
+                                                                   int runs_per_col, int nunits) {
   using G = WgGeo;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char *dyt = lds + G::SLAB_BYTES;
@@ -275,18 +308,22 @@ __global__ __launch_bounds__(512, 1) void stem_wgrad_bf16_kernel(StemBfWgArgs p,
   const size_t vox = (size_t)p.D * p.H * p.W;
   const bool even_w = (p.W & 1) == 0;
 
-  // units of this wave (wave-uniform row tiles) and the lane's window offsets (bytes; k = 8q folded in)
+  // units of this wave (wave-uniform row tiles) and the lane's window offsets (bytes; k = 8q folded in, the depth slot is added
+  // per k-step: the slab is a ring of 10 depth planes, see below)
   int egt[2] = {0, 0}, ogt[3] = {0, 0, 0};
   if (wave < 4) { egt[0] = 2 * wave; egt[1] = 2 * wave + 1; }
   else if (wave < 6) { ogt[0] = 3 * (wave - 4); ogt[1] = ogt[0] + 1; ogt[2] = ogt[0] + 2; }
   else { egt[0] = 8 + (wave - 6); ogt[0] = 6 + 2 * (wave - 6); ogt[1] = ogt[0] + 1; }
-  auto window_off = [&](int gt) {                        // a lane past the last group reads the last group's window and drops the result
+  auto window_off = [&](int gt, int &kd) {               // a lane past the last group reads the last group's window and drops the result
     const int g = min(16 * gt + r, G::GROUPS - 1);
-    const int c = g / 49, kdkh = g - c * 49, kd = kdkh / 7, kh = kdkh - kd * 7;
-    return (c * G::PLN + kd * G::DSTR + kh * G::ROWD + 4 * q) * 4;
+    const int c = g / 49, kdkh = g - c * 49;
+    kd = kdkh / 7;
+    return (c * G::PLN + (kdkh - kd * 7) * G::ROWD + 4 * q) * 4;
   };
-  const int eoff[2] = {window_off(egt[0]), window_off(egt[1])};
-  const int ooff[3] = {window_off(ogt[0]) + G::IMG_BYTES, window_off(ogt[1]) + G::IMG_BYTES, window_off(ogt[2]) + G::IMG_BYTES};
+  int ekd[2], okd[3];
+  const int eoff[2] = {window_off(egt[0], ekd[0]), window_off(egt[1], ekd[1])};
+  const int ooff[3] = {window_off(ogt[0], okd[0]) + G::IMG_BYTES, window_off(ogt[1], okd[1]) + G::IMG_BYTES,
+                       window_off(ogt[2], okd[2]) + G::IMG_BYTES};
   // transposing read of dy [position][16]: group q reads positions 8q..8q+7; inside the group lane 4a+b gives row a, columns 4b..4b+3
   const int i16 = lane & 15, ra = i16 >> 2, cb = i16 & 3;
   const int b_lane = (8 * q + ra) * (G::DYROW * 2) + cb * 8;
@@ -295,56 +332,78 @@ __global__ __launch_bounds__(512, 1) void stem_wgrad_bf16_kernel(StemBfWgArgs p,
 #pragma unroll
   for (int i = 0; i < 10; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  // next tile's operands in registers: x as aligned float2 pairs, dy as two 16-byte halves of one position row.
-  // Staging map as in the forward kernel: iteration u = one (channel, depth) plane, thread = (row hh, column pair pr).
-  constexpr int NPL = 3 * G::HD;
+  // A workgroup walks RUNS of depth-adjacent tiles of one (n, h, w) column.  The slab's depth planes form a ring (input depth id
+  // lives in slot (id + 10) % 10): the first tile of a run stages its 10 planes, every later tile only the 4 new ones -- 12 instead
+  // of 30 (channel, depth) planes fetched, converted and written per tile.
+  // The next tile's operands wait in registers: x as aligned float2 pairs, dy as two 16-byte halves of one position row.  Staging
+  // map: iteration u = one (channel, depth) plane, thread = (row hh, column pair pr).
+  struct Pos { int n, th, tw, t, t_end; };               // wave-uniform
+  auto unit_pos = [&](int unit) {
+    Pos o;
+    int col = unit / runs_per_col;
+    const int ri = unit - col * runs_per_col;
+    o.tw = col % tiles_w; col /= tiles_w;
+    o.th = col % tiles_h;
+    o.n = col / tiles_h;
+    o.t = ri * run_len;
+    o.t_end = min(o.t + run_len, tiles_d);
+    return o;
+  };
   const int s_hh = tid / G::PAIRS, s_pr = tid - s_hh * G::PAIRS;
   const bool s_act = s_hh < G::HH;
-  float2 st[NPL];
+  float2 st[3 * G::HD];
   uint4 sdy[2];
-  auto fetch = [&](int tile) {
-    const BfTile bt = bf_tile_of(tile < ntiles ? tile : 0, tiles_d, tiles_h, tiles_w);
-    const int tw_i = bt.tw, th_i = bt.th, td_i = bt.td, n = bt.n;
-    const int d0 = td_i * G::TD, h0 = th_i * G::TH, w0 = tw_i * G::TW;
-    const int id0 = d0 - 3, ih = 2 * h0 - 3 + s_hh, iw = 2 * w0 - 3 + 2 * s_pr - 1;
-    const bool tile_ok = tile < ntiles;
-    const bool row_ok = s_act && tile_ok && (unsigned)ih < (unsigned)p.H;
-    const bool pair_ok = even_w && iw >= 0 && iw + 1 < p.W;
+  // planes per channel: 10 at the start of a run (start), 4 inside it.  ONE code path for both (plane u of 30 is skipped by a
+  // wave-uniform test inside a run): two instantiations met in register copies of the loaded values behind the fetch, and a copy
+  // waits for the load -- the fetch then no longer ran beside the MFMA phase
+  auto plane_of = [&](int u, bool start, int id_first, int &c, int &id) {
+    c = start ? u / G::HD : u / G::TD;
+    id = id_first + (start ? u % G::HD : u % G::TD);
+    return start || u < 3 * G::TD;
+  };
+  auto fetch_x = [&](bool start, const Pos &o, int id_first) {
+    const int h0 = o.th * G::TH, w0 = o.tw * G::TW;
+    const int ih = 2 * h0 - 3 + s_hh, iw = 2 * w0 - 3 + 2 * s_pr - 1;
+    const bool row_ok = s_act && (unsigned)ih < (unsigned)p.H;
     const long long off = (long long)ih * p.W + iw;
     if (even_w) {
       // even W: iw is even, a pair is inside the row or outside it as a whole.  Buffer loads: a lane outside its row gets an offset
-      // past the end of the image and the hardware returns zeros -- no bounds test around a load, the 30 of them are in flight together
+      // past the end of the image and the hardware returns zeros -- no bounds test around a load, all of them are in flight together
       // (a load inside a per-lane bounds test is a branch per load and the wave walks them one after the other)
-      const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x + (size_t)n * 3 * vox), 0,
+      const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.x + (size_t)o.n * 3 * vox), 0,
                                                                           (unsigned)(3 * vox * 4), 0x00020000);
-      const unsigned voff = (row_ok && pair_ok) ? (unsigned)off * 4u : 0x80000000u;
+      const unsigned voff = (row_ok && iw >= 0 && iw + 1 < p.W) ? (unsigned)off * 4u : 0x80000000u;
 #pragma unroll
-      for (int u = 0; u < NPL; ++u) {
-        const int c = u / G::HD, hd = u % G::HD;
-        const int id = id0 + hd;                         // wave-uniform
+      for (int u = 0; u < 3 * G::HD; ++u) {
+        int c, id;                                       // wave-uniform
+        const bool used = plane_of(u, start, id_first, c, id);
         st[u] = make_float2(0.f, 0.f);
-        if ((unsigned)id < (unsigned)p.D)
-          st[u] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(xr, (int)voff, (int)(((unsigned)c * (unsigned)vox + (unsigned)id * (unsigned)(p.H * p.W)) * 4u), 0));
+        if (used && (unsigned)id < (unsigned)p.D)
+          st[u] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(
+                                                 xr, (int)voff, (int)(((unsigned)c * (unsigned)vox + (unsigned)id * (unsigned)(p.H * p.W)) * 4u), 0));
       }
     } else {
 #pragma unroll
-      for (int u = 0; u < NPL; ++u) {
-        const int c = u / G::HD, hd = u % G::HD;
-        const int id = id0 + hd;
+      for (int u = 0; u < 3 * G::HD; ++u) {
+        int c, id;
+        const bool used = plane_of(u, start, id_first, c, id);
         st[u] = make_float2(0.f, 0.f);
-        if (row_ok && (unsigned)id < (unsigned)p.D) {
-          const float *src = p.x + ((size_t)n * 3 + c) * vox + (size_t)id * p.H * p.W + off;
+        if (used && row_ok && (unsigned)id < (unsigned)p.D) {
+          const float *src = p.x + ((size_t)o.n * 3 + c) * vox + (size_t)id * p.H * p.W + off;
           if ((unsigned)iw < (unsigned)p.W) st[u].x = src[0];
           if ((unsigned)(iw + 1) < (unsigned)p.W) st[u].y = src[1];
         }
       }
     }
+  };
+  auto fetch = [&](const Pos &o, bool start) {
+    const int d0 = o.t * G::TD, h0 = o.th * G::TH, w0 = o.tw * G::TW, n = o.n;
     if constexpr (!POOLED) {
       const int m = tid;                                 // 512 positions, one per thread
       const int tw = m & 31, th = (m >> 5) % G::TH, td = m / (32 * G::TH);
       const int od = d0 + td, oh = h0 + th, ow = w0 + tw;
       sdy[0] = sdy[1] = make_uint4(0u, 0u, 0u, 0u);
-      if (tile_ok && od < p.D && oh < p.Ho && ow < p.Wo) {
+      if (od < p.D && oh < p.Ho && ow < p.Wo) {
         const uint4 *src = reinterpret_cast<const uint4 *>(p.dy + ((((size_t)n * p.D + od) * p.Ho + oh) * p.Wo + ow) * 16);
         sdy[0] = src[0]; sdy[1] = src[1];
       }
@@ -356,31 +415,42 @@ __global__ __launch_bounds__(512, 1) void stem_wgrad_bf16_kernel(StemBfWgArgs p,
         const int pw = pp % 17, ph = (pp / 17) % 3, pd = pp / 51;
         const int od = (d0 >> 1) + pd, oh = (h0 >> 1) + ph, ow = (w0 >> 1) + pw;
         sdy[j] = make_uint4(0u, 0u, 0u, 0u);
-        if (tile_ok && it < G::WINDOWS * 4 && od < p.Dp && oh < p.Hp && ow < p.Wp) {
-          const size_t o = ((((size_t)n * p.Dp + od) * p.Hp + oh) * p.Wp + ow) * 4 + q4;
-          const uint2 g = *reinterpret_cast<const uint2 *>(p.dy + o * 4);
+        if (it < G::WINDOWS * 4 && od < p.Dp && oh < p.Hp && ow < p.Wp) {
+          const size_t o4 = ((((size_t)n * p.Dp + od) * p.Hp + oh) * p.Wp + ow) * 4 + q4;
+          const uint2 g = *reinterpret_cast<const uint2 *>(p.dy + o4 * 4);
           uint32_t pos = 0xfu;                           // bit r: pooled value of channel r is > 0
           if (p.pooled) {
-            const uint2 a = *reinterpret_cast<const uint2 *>(p.pooled + o * 4);
+            const uint2 a = *reinterpret_cast<const uint2 *>(p.pooled + o4 * 4);
             auto gt0 = [](uint32_t h) { return (h & 0x7fffu) != 0u && (h & 0x8000u) == 0u && (h & 0x7fffu) <= 0x7f80u; };
             pos = (gt0(a.x & 0xffffu) ? 1u : 0u) | (gt0(a.x >> 16) ? 2u : 0u) | (gt0(a.y & 0xffffu) ? 4u : 0u) | (gt0(a.y >> 16) ? 8u : 0u);
           }
-          sdy[j] = make_uint4(p.pool_idx[o], g.x, g.y, pos);
+          sdy[j] = make_uint4(p.pool_idx[o4], g.x, g.y, pos);
         }
       }
     }
+    // the x loads come last: the registers of the dy operands are cleared while nothing is in flight (clearing a register that a
+    // load of the previous round MAY still own costs an s_waitcnt vmcnt(0) -- behind the x loads it waited for all of them)
+    fetch_x(start, o, start ? d0 - 3 : d0 + 3);
   };
-  auto commit = [&]() {
+  auto commit_x = [&](bool start, int id_first) {
     // slab column s = iw - iw0: the pair (2*pr - 1, 2*pr) lands at odd-image index pr - 1 and even-image index pr
     if (s_act) {
       bf16_t *dst = reinterpret_cast<bf16_t *>(lds) + s_hh * (2 * G::ROWD);
+      const int s0 = (id_first + 10) % 10;               // wave-uniform ring slot of the first plane
 #pragma unroll
-      for (int u = 0; u < NPL; ++u) {
-        bf16_t *d = dst + ((u / G::HD) * G::PLN + (u % G::HD) * G::DSTR) * 2;
+      for (int u = 0; u < 3 * G::HD; ++u) {
+        int c, id;
+        if (!plane_of(u, start, 0, c, id)) continue;     // wave-uniform
+        int slot = s0 + id;
+        slot -= slot >= 10 ? 10 : 0;
+        bf16_t *d = dst + (c * G::PLN + slot * G::DSTR) * 2;
         d[s_pr] = f2bf(st[u].y);
         if (s_pr >= 1) d[G::IMG_BYTES / 2 + s_pr - 1] = f2bf(st[u].x);
       }
     }
+  };
+  auto commit = [&](const Pos &o, bool start) {
+    commit_x(start, start ? o.t * G::TD - 3 : o.t * G::TD + 3);
     if constexpr (!POOLED) {
       *reinterpret_cast<uint4 *>(dyt + tid * (G::DYROW * 2)) = sdy[0];
       *reinterpret_cast<uint4 *>(dyt + tid * (G::DYROW * 2) + 16) = sdy[1];
@@ -419,64 +489,102 @@ __global__ __launch_bounds__(512, 1) void stem_wgrad_bf16_kernel(StemBfWgArgs p,
     *reinterpret_cast<uint4 *>(dyt + tid * (G::DYROW * 2) + 16) = pk(c, d);
   };
 
-  // ---- the 16 k-steps of a tile for a wave with NE even and NO odd units (+ the tile of ones)
-  auto mma_phase = [&](auto ne_, auto no_, auto ones_) {
+  // ---- the 16 k-steps of a tile for a wave with NE even and NO odd units (+ the tile of ones); ring0 = slot of the tile's first
+  // input depth plane
+  auto mma_phase = [&](auto ne_, auto no_, auto ones_, int ring0) {
     constexpr int NE = decltype(ne_)::value, NO = decltype(no_)::value;
     constexpr bool ONES = decltype(ones_)::value != 0;
-    struct Ops { u32x4 ea[NE ? NE : 1]; u32x2 eb[NE ? NE : 1]; u32x4 oa[NO ? NO : 1]; uint32_t ob[NO ? NO : 1]; bf16x8 b; };
-    auto load_step = [&](int ks, Ops &o) {
-      const int th = ks % G::TH, td = ks / G::TH;
-      unsigned char *yb = dyt + ks * 32 * (G::DYROW * 2) + b_lane;
+    struct Ops { u32x4 ea[NE ? NE : 1]; u32x2 eb[NE ? NE : 1]; u32x4 oa[NO ? NO : 1]; u32x2 ob[NO ? NO : 1]; bf16x8 b; };
+    // window addresses of the units for one td (4 k-steps: th = 0..3 is a constant offset of the LDS read)
+    struct Base { uint32_t e[NE ? NE : 1], o[NO ? NO : 1], y; };
+    auto bases = [&](int td, Base &b) {
+      auto slot_off = [&](int kd) {                      // bytes of ring slot (ring0 + td + kd) % 10
+        int sl = ring0 + td + kd;
+        sl -= sl >= 10 ? 10 : 0;
+        return sl * (G::DSTR * 4);
+      };
+#pragma unroll
+      for (int u = 0; u < NE; ++u) b.e[u] = (uint32_t)(eoff[u] + slot_off(ekd[u]));
+#pragma unroll
+      for (int u = 0; u < NO; ++u) b.o[u] = (uint32_t)(ooff[u] + slot_off(okd[u]));
+      b.y = (uint32_t)(G::SLAB_BYTES + td * G::TH * 32 * (G::DYROW * 2) + b_lane);
+    };
+    auto load_step = [&](auto th_, const Base &b, Ops &o) {
+      constexpr int TH = decltype(th_)::value;
+      const unsigned char *yb = lds + b.y + TH * 32 * (G::DYROW * 2);
       const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(yb));
       const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(yb + 4 * (G::DYROW * 2)));
       o.b = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-      const int rowoff = (td * G::DSTR + 2 * th * G::ROWD) * 4;
+      constexpr int rowoff = 2 * TH * G::ROWD * 4;
 #pragma unroll
       for (int u = 0; u < NE; ++u) {
-        o.ea[u] = *reinterpret_cast<const u32x4 *>(lds + eoff[u] + rowoff);
-        o.eb[u] = *reinterpret_cast<const u32x2 *>(lds + eoff[u] + rowoff + 16);
+        const unsigned char *w = lds + b.e[u] + rowoff;
+        o.ea[u] = *reinterpret_cast<const u32x4 *>(w);
+        o.eb[u] = *reinterpret_cast<const u32x2 *>(w + 16);
       }
 #pragma unroll
       for (int u = 0; u < NO; ++u) {
-        o.oa[u] = *reinterpret_cast<const u32x4 *>(lds + ooff[u] + rowoff);
-        o.ob[u] = *reinterpret_cast<const uint32_t *>(lds + ooff[u] + rowoff + 16);
+        const unsigned char *w = lds + b.o[u] + rowoff;
+        o.oa[u] = *reinterpret_cast<const u32x4 *>(w);
+        o.ob[u] = *reinterpret_cast<const u32x2 *>(w + 16);          // (the second dword is not used: an aligned register pair for v_pk_mov)
       }
     };
-    auto mfma = [&](f32x4_t &c, uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, const bf16x8 &b) {
-      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, u32x4{a0, a1, a2, a3}), b, c, 0, 0, 0);
+    // Operand assembly.  An MFMA holds the SIMD's vector issue for 8 of its 16 cycles: two plain vector instructions per MFMA are
+    // free, every further one costs its 4 cycles.  The tuple of a fragment that starts one dword into the window is two v_pk_mov_b32
+    // of aligned register pairs ((a.hi, b.lo)), not four v_mov; the element-shifted tuples are v_perm (alignbit) of neighbouring dwords.
+    auto mfma = [&](f32x4_t &c, const u32x4 &a, const bf16x8 &b) {
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), b, c, 0, 0, 0);
+    };
+    auto hi_lo = [](const u32x2 &a, const u32x2 &b) {      // (a[1], b[0])
+      return (u32x2)__builtin_shufflevector(a, b, 1, 2);   // v_pk_mov_b32 op_sel:[1,0]
+    };
+    auto lo2 = [](const u32x4 &v) { return (u32x2)__builtin_shufflevector(v, v, 0, 1); };
+    auto hi2 = [](const u32x4 &v) { return (u32x2)__builtin_shufflevector(v, v, 2, 3); };
+    auto cat = [](const u32x2 &a, const u32x2 &b) { return (u32x4)__builtin_shufflevector(a, b, 0, 1, 2, 3); };
+    auto shifted = [&](const u32x4 &w, uint32_t d4) {      // elements 1..8 of the window whose dwords are w[0..3], d4
+      return u32x4{__builtin_amdgcn_alignbit(w[1], w[0], 16), __builtin_amdgcn_alignbit(w[2], w[1], 16),
+                   __builtin_amdgcn_alignbit(w[3], w[2], 16), __builtin_amdgcn_alignbit(d4, w[3], 16)};
     };
     auto mma_step = [&](const Ops &o) {
 #pragma unroll
       for (int u = 0; u < NE; ++u) {
-        const uint32_t d0 = o.ea[u][0], d1 = o.ea[u][1], d2 = o.ea[u][2], d3 = o.ea[u][3], d4 = o.eb[u][0], d5 = o.eb[u][1];
-        const uint32_t s0 = __builtin_amdgcn_alignbit(d1, d0, 16), s1 = __builtin_amdgcn_alignbit(d2, d1, 16),
-                       s2 = __builtin_amdgcn_alignbit(d3, d2, 16), s3 = __builtin_amdgcn_alignbit(d4, d3, 16),
-                       s4 = __builtin_amdgcn_alignbit(d5, d4, 16);
-        mfma(acc[4 * u + 0], d0, d1, d2, d3, o.b);          // kw 0: elements 0..7
-        mfma(acc[4 * u + 1], s0, s1, s2, s3, o.b);          // kw 2: 1..8
-        mfma(acc[4 * u + 2], d1, d2, d3, d4, o.b);          // kw 4: 2..9
-        mfma(acc[4 * u + 3], s1, s2, s3, s4, o.b);          // kw 6: 3..10
+        const u32x4 &w = o.ea[u];                           // dwords 0..3; o.eb[u] = dwords 4, 5
+        const u32x4 t1 = shifted(w, o.eb[u][0]);            // kw 2: elements 1..8
+        const u32x4 w1 = cat(hi_lo(lo2(w), hi2(w)), hi_lo(hi2(w), o.eb[u]));      // kw 4: elements 2..9 = dwords 1..4
+        u32x4 t2 = cat(hi_lo(lo2(t1), hi2(t1)), hi2(t1));   // kw 6: elements 3..10
+        t2[2] = t1[3];
+        t2[3] = __builtin_amdgcn_alignbit(o.eb[u][1], o.eb[u][0], 16);
+        mfma(acc[4 * u + 0], w, o.b);
+        mfma(acc[4 * u + 1], t1, o.b);
+        mfma(acc[4 * u + 2], w1, o.b);
+        mfma(acc[4 * u + 3], t2, o.b);
       }
 #pragma unroll
       for (int u = 0; u < NO; ++u) {
-        const uint32_t d0 = o.oa[u][0], d1 = o.oa[u][1], d2 = o.oa[u][2], d3 = o.oa[u][3], d4 = o.ob[u];
-        const uint32_t s0 = __builtin_amdgcn_alignbit(d1, d0, 16), s1 = __builtin_amdgcn_alignbit(d2, d1, 16),
-                       s2 = __builtin_amdgcn_alignbit(d3, d2, 16), s3 = __builtin_amdgcn_alignbit(d4, d3, 16);
-        mfma(acc[4 * NE + 3 * u + 0], d0, d1, d2, d3, o.b);   // kw 1
-        mfma(acc[4 * NE + 3 * u + 1], s0, s1, s2, s3, o.b);   // kw 3
-        mfma(acc[4 * NE + 3 * u + 2], d1, d2, d3, d4, o.b);   // kw 5
+        const u32x4 &w = o.oa[u];
+        mfma(acc[4 * NE + 3 * u + 0], w, o.b);                                     // kw 1
+        mfma(acc[4 * NE + 3 * u + 1], shifted(w, o.ob[u][0]), o.b);               // kw 3
+        mfma(acc[4 * NE + 3 * u + 2], cat(hi_lo(lo2(w), hi2(w)), hi_lo(hi2(w), o.ob[u])), o.b);   // kw 5
       }
-      if constexpr (ONES) mfma(acc[4 * NE + 3 * NO], 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u, o.b);
+      if constexpr (ONES) mfma(acc[4 * NE + 3 * NO], u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}, o.b);
     };
     // the windows of k-step ks + 1 are requested before the MFMAs of k-step ks
     Ops o0, o1;
-    load_step(0, o0);
+    Base cur, nxt;
+    bases(0, cur);
+    load_step(IntC<0>{}, cur, o0);
 #pragma unroll 1
-    for (int ks = 0; ks < G::KS; ks += 2) {
-      load_step(ks + 1, o1);
+    for (int td = 0; td < G::TD; ++td) {
+      bases(td + 1, nxt);
+      load_step(IntC<1>{}, cur, o1);
       mma_step(o0);
-      if (ks + 2 < G::KS) load_step(ks + 2, o0);
+      load_step(IntC<2>{}, cur, o0);
       mma_step(o1);
+      load_step(IntC<3>{}, cur, o1);
+      mma_step(o0);
+      if (td + 1 < G::TD) load_step(IntC<0>{}, nxt, o0);
+      mma_step(o1);
+      cur = nxt;
     }
   };
   // ---- write-out of one accumulator: column (cout) = lane & 15, group = 16*gt + 4*(lane>>4) + reg
@@ -489,13 +597,13 @@ __global__ __launch_bounds__(512, 1) void stem_wgrad_bf16_kernel(StemBfWgArgs p,
     }
   };
 
-  // Tiles are pulled from eight queues (one contiguous range of the depth-fastest order per XCD, the workgroup's own XCD first):
-  // with a fixed run per workgroup the launch ended with its latest workgroup, and in the training step the other layers'
-  // last weight gradients and their finishing run beside this kernel (see stem_wgrad_kernel in csrc/stem.hip).
-  __shared__ int s_tile;
+  // Runs are pulled from eight queues (one contiguous range of the run order per XCD, the workgroup's own XCD first): with a fixed
+  // share per workgroup the launch ended with its latest workgroup, and in the training step the other layers' last weight
+  // gradients and their finishing run beside this kernel (see stem_wgrad_kernel in csrc/stem.hip).
+  __shared__ int s_unit;
   unsigned *queue = g_stem_bf16_queues + 16 * p.queue_slot;
-  const int per_xcd = (ntiles + 7) >> 3, home = blockIdx.x & 7;
-  auto range = [&](int x, int &lo) { lo = x * per_xcd; return max(min(lo + per_xcd, ntiles) - lo, 0); };
+  const int per_xcd = (nunits + 7) >> 3, home = blockIdx.x & 7;
+  auto range = [&](int x, int &lo) { lo = x * per_xcd; return max(min(lo + per_xcd, nunits) - lo, 0); };
   auto take = [&](unsigned ticket) {                     // thread 0
     int lo, cnt = range(home, lo);
     if (ticket < (unsigned)cnt) return lo + (int)ticket;
@@ -512,30 +620,46 @@ __global__ __launch_bounds__(512, 1) void stem_wgrad_bf16_kernel(StemBfWgArgs p,
     for (int e = tid; e < G::M * 4; e += G::NT) reinterpret_cast<float4 *>(scat)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   unsigned ticket = 0;
-  if (tid == 0) s_tile = take(atomicAdd(queue + home, 1u));
+  if (tid == 0) s_unit = take(atomicAdd(queue + home, 1u));
   __syncthreads();
-  int tile = __builtin_amdgcn_readfirstlane(s_tile);      // wave-uniform: the tile arithmetic below stays on the scalar unit
-  fetch(tile >= 0 ? tile : ntiles);
-  if (tid == 0) ticket = atomicAdd(queue + home, 1u);
-  while (tile >= 0) {
+  const int first = __builtin_amdgcn_readfirstlane(s_unit);   // wave-uniform: the tile arithmetic below stays on the scalar unit
+  if (tid == 0 && first >= 0) ticket = atomicAdd(queue + home, 1u);
+  // Pipeline: [fetch tile k + 1 into registers | multiply tile k] -> barrier -> [commit tile k + 1 to LDS] -> barrier
+  bool have_cur = false, have_nxt = first >= 0, nxt_start = true;
+  Pos cur = unit_pos(0), nxt = unit_pos(first >= 0 ? first : 0);
+  while (true) {
+    if (have_nxt) fetch(nxt, nxt_start);                 // in flight during the MFMA phase
+    if (have_cur) {
+      const int ring0 = (cur.t * G::TD + 7) % 10;        // slot of input depth 4t - 3
+      if (wave == 0) mma_phase(IntC<2>{}, IntC<0>{}, IntC<1>{}, ring0);
+      else if (wave < 4) mma_phase(IntC<2>{}, IntC<0>{}, IntC<0>{}, ring0);
+      else if (wave < 6) mma_phase(IntC<0>{}, IntC<3>{}, IntC<0>{}, ring0);
+      else mma_phase(IntC<1>{}, IntC<2>{}, IntC<0>{}, ring0);
+    }
+    if (!have_nxt) break;
     __syncthreads();
-    if (!(p.dbg & 2)) commit();
-    if constexpr (POOLED) { if (!(p.dbg & 8)) scatter(); }
-    if (tid == 0) s_tile = take(ticket);                 // issued a tile ago
+    commit(nxt, nxt_start);
+    if constexpr (POOLED) scatter();
+    const bool last = nxt.t + 1 >= nxt.t_end;            // the tile after `nxt` starts a new run
+    if (tid == 0 && last) s_unit = take(ticket);         // issued a run ago
     __syncthreads();
     if constexpr (POOLED) {
       round_rows();
       __syncthreads();
     }
-    const int next = __builtin_amdgcn_readfirstlane(s_tile);
-    if (tid == 0 && next >= 0) ticket = atomicAdd(queue + home, 1u);
-    if (!(p.dbg & 4)) fetch(next >= 0 ? next : ntiles);                    // in flight during the MFMA phase
-    if (p.dbg & 1) {} else
-    if (wave == 0) mma_phase(IntC<2>{}, IntC<0>{}, IntC<1>{});
-    else if (wave < 4) mma_phase(IntC<2>{}, IntC<0>{}, IntC<0>{});
-    else if (wave < 6) mma_phase(IntC<0>{}, IntC<3>{}, IntC<0>{});
-    else mma_phase(IntC<1>{}, IntC<2>{}, IntC<0>{});
-    tile = next;
+    cur = nxt; have_cur = true;
+    if (last) {
+      const int nu = __builtin_amdgcn_readfirstlane(s_unit);
+      have_nxt = nu >= 0;
+      nxt_start = true;
+      if (have_nxt) {
+        nxt = unit_pos(nu);
+        if (tid == 0) ticket = atomicAdd(queue + home, 1u);
+      }
+    } else {
+      nxt.t += 1;
+      nxt_start = false;
+    }
   }
   if (tid == 0) {                                        // the last workgroup to run dry re-arms the queues
     const unsigned done = atomicAdd(queue + 8, 1u);
@@ -598,6 +722,8 @@ extern "C" int mr3d_stem_conv_forward_bf16(const float *x_ncdhw, const void *w16
   const int td = (d + G::TD - 1) / G::TD, th = (a.Ho + G::TH - 1) / G::TH, tw = (a.Wo + G::TW - 1) / G::TW;
   const long long ntiles = (long long)n * td * th * tw;
   if (ntiles > 0x7fffffffLL) return MR3D_ERR_UNSUPPORTED;
+  // buffer-load offsets of the slab fetch: one image below 2^31 bytes
+  if ((unsigned long long)d * h * w * 12ull > 0x7fffffffull) return MR3D_ERR_UNSUPPORTED;
   int grid = ntiles < cus ? (int)ntiles : cus;               // one persistent 8-wave workgroup per CU (100 KB of LDS)
   if (grid >= 8) grid &= ~7;                                 // XCD-contiguous tile runs (bf_tile_run)
   stem_fwd_bf16_kernel<<<(unsigned)grid, G::NT, G::LDS_BYTES, mr3d_stream(stream_)>>>(a, td, th, tw, (int)ntiles);
@@ -631,17 +757,26 @@ static int stem_wgrad_bf16_impl(const float *x_ncdhw, const void *dy_bf16, const
     attr = true;
   }
   const int td = (d + G::TD - 1) / G::TD, th = (a.Ho + G::TH - 1) / G::TH, tw = (a.Wo + G::TW - 1) / G::TW;
-  const long long ntiles = (long long)n * td * th * tw;
-  if (ntiles > 0x7fffffffLL) return MR3D_ERR_UNSUPPORTED;
-  int grid = ntiles < cus ? (int)ntiles : cus;               // one persistent workgroup per CU (140 / 156 KB of LDS)
+  const long long ncols = (long long)n * th * tw;
+  if (ncols * td > 0x7fffffffLL) return MR3D_ERR_UNSUPPORTED;
+  // buffer-load offsets of the slab fetch: one image below 2^31 bytes
+  if ((unsigned long long)d * h * w * 12ull > 0x7fffffffull) return MR3D_ERR_UNSUPPORTED;
+  // runs of depth-adjacent tiles: whole columns when there are at least 4 per workgroup, else the columns are cut so that there
+  // are (the first tile of a run stages 10 depth planes, the others 4)
+  int rpc = (int)((4ll * cus + ncols - 1) / ncols);
+  if (rpc < 1) rpc = 1;
+  if (rpc > (td + 1) / 2) rpc = (td + 1) / 2;
+  const int run_len = (td + rpc - 1) / rpc;
+  rpc = (td + run_len - 1) / run_len;
+  const long long nunits = ncols * rpc;
+  int grid = nunits < cus ? (int)nunits : cus;               // one persistent workgroup per CU (88 / 120 KB of LDS)
   if (grid >= 8) grid &= ~7;
   static std::atomic<unsigned> next_slot{0};                 // ring of queue slots: see stem_wgrad_impl in csrc/stem.hip
   a.queue_slot = (int)(next_slot.fetch_add(1) & 63u);
-  a.dbg = g_mr3d_tuning[0];
   if (pool_idx)
-    stem_wgrad_bf16_kernel<true><<<(unsigned)grid, 512, G::LDS_BYTES + G::SCATTER_BYTES, mr3d_stream(stream_)>>>(a, td, th, tw, (int)ntiles);
+    stem_wgrad_bf16_kernel<true><<<(unsigned)grid, 512, G::LDS_BYTES + G::SCATTER_BYTES, mr3d_stream(stream_)>>>(a, td, th, tw, run_len, rpc, (int)nunits);
   else
-    stem_wgrad_bf16_kernel<false><<<(unsigned)grid, 512, G::LDS_BYTES, mr3d_stream(stream_)>>>(a, td, th, tw, (int)ntiles);
+    stem_wgrad_bf16_kernel<false><<<(unsigned)grid, 512, G::LDS_BYTES, mr3d_stream(stream_)>>>(a, td, th, tw, run_len, rpc, (int)nunits);
   return mr3d_launch_status();
 }
 
