@@ -50,7 +50,8 @@ enum {
   MR3D_TUNE_PLAN_SKIP = 1,        /* sensitivity runs ONLY (results are wrong): bit mask of plan records mr3d_plan_run leaves out --
                                      1: CONV_WGRAD 3x3x3 16->16, 2: CONV_WGRAD 3x3x3 64->64, 4: every CONV_WGRAD, 8: MAXPOOL_FWD,
                                      16: FINISH_GRADS, 32: STEM_WGRAD, 64: CONV_WGRAD 1x1x1, 128: CONV_FWD 3x3x3 with cin >= 64 on
-                                     maps below 32768 positions (layer3 / layer4 convs and data gradients) */
+                                     maps below 32768 positions (layer3 / layer4 convs and data gradients), 256: STEM_FWD,
+                                     512: ZERO_STUFF2 / UPSAMPLE_ADJ / MAXPOOL_BWD */
   MR3D_TUNE_RESERVED_2 = 2, MR3D_TUNE_RESERVED_3 = 3,
   MR3D_TUNE_NUM_KEYS = 16
 };
@@ -603,7 +604,9 @@ int mr3d_stem_conv_wgrad_bf16dy(const float *x_ncdhw, const void *dy_bf16, float
 /* The stem on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16; csrc/stem_bf16.hip): the fp32 volume is converted to bf16 while
  * it is staged, accumulation fp32.  w16 = mr3d_stem_pack_weights_bf16(w_packed): [49 (kd,kh)][4 c][16 cout][8 kw] bf16 (50 KB)
  * from the generic fp32 packing [343][4][16].  Plan records: STEM_FWD with i[25] = bf16 and i[5] = 1 (p[1] = w16), STEM_WGRAD with
- * i[25] = bf16 and i[6] = 1; dw_packed / dbias fp32, PRE-ZEROED, same layout as the fp32 stem's. */
+ * i[25] = bf16 and i[6] = 1; dw_packed / dbias fp32, PRE-ZEROED, same layout as the fp32 stem's.
+ * Size limit: one image of the volume (3 x d x h x w fp32) below 2^31 bytes -- the slab fetch addresses it with 32-bit buffer
+ * offsets; MR3D_ERR_UNSUPPORTED beyond (178 M voxels; the second pathway's 120 x 768 x 768 volume has 71 M). */
 int mr3d_stem_pack_weights_bf16(const float *w_packed, void *w16, mr3d_stream_t stream);
 int mr3d_stem_conv_forward_bf16(const float *x_ncdhw, const void *w16, const float *shift, void *y_bf16, int n, int d, int h, int w,
                                 int relu, mr3d_stream_t stream);

@@ -147,6 +147,10 @@ def test_stem_size_guard():
     assert L.mr3d_stem_conv_forward(p, p, p, p, 1, 1024, 512, 512, 1, None) == 4         # 2^28 voxels
     assert L.mr3d_stem_conv_wgrad_ws(p, p, p, p, 1, 1024, 512, 512, None, ctypes.c_longlong(0), None) == 4
     assert L.mr3d_stem_conv_forward(p, p, p, p, 9, 1000, 512, 512, 1, None) == 4         # volume fits, output 9 * 1000 * 256 * 256 * 64 B >= 2^31
+    # the bf16 stem kernels fetch their slabs with 32-bit buffer offsets: one image (3 channels, fp32) below 2^31 bytes
+    assert L.mr3d_stem_conv_forward_bf16(p, p, p, p, 1, 684, 512, 512, 1, None) == 4     # 684 * 2^18 * 12 B > 2^31
+    assert L.mr3d_stem_conv_wgrad_bf16(p, p, p, p, 1, 684, 512, 512, None) == 4
+    assert L.mr3d_stem_conv_wgrad_bf16_pooled(p, p, p, p, p, p, 1, 684, 512, 512, None) == 4
 
 
 def test_up_even_flag_is_refused_where_no_kernel_implements_it():

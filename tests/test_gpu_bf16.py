@@ -236,6 +236,50 @@ def test_stem_bf16_forward_and_wgrad(dev, dhw):
     _close(db.cpu(), dy.double().sum(dim=(0, 2, 3, 4)), 'stem dbias', 1e-4, 1e-4)
 
 
+@pytest.mark.parametrize('n,dhw', [(1, (44, 128, 132)), (2, (21, 96, 72))])
+def test_stem_bf16_depth_ring_over_many_tiles(dev, n, dhw):
+    """More tiles than workgroups: the persistent bf16 stem kernels walk depth-adjacent tiles and keep the slab's depth planes in
+    a ring (a tile inside a column stages only its 4 new planes), columns change inside a workgroup's run, the last depth tile
+    is ragged.  Checked against the fp32 stem kernels on the same bf16-rounded operands (they accumulate the same products in
+    fp32: the outputs agree to the bf16 rounding of y, the weight gradients to fp32 summation order)."""
+    from mr3d_amd import _hip
+    g = torch.Generator().manual_seed(sum(dhw) + n)
+    x = _bf(torch.randn((n, 3) + dhw, generator=g)).to(dev)
+    w = _bf(torch.randn((16, 3, 7, 7, 7), generator=g) / np.sqrt(3 * 343))
+    shift = torch.randn(16, generator=g).to(dev)
+    wp = torch.zeros(343, 4, 16)
+    wp[:, :3, :] = w.reshape(16, 3, 343).permute(2, 1, 0)
+    wp = wp.to(dev)
+    ref = _hip.stem_conv_forward(x, wp, shift, relu=True)                      # fp32 [N, D, Ho, Wo, 16]
+    y = _hip.stem_conv_forward_bf16(x, wp, shift=shift, relu=True)
+    assert tuple(y.shape) == tuple(ref.shape)
+    _close(y.float().cpu(), ref.cpu().double(), 'stem fwd (ring)', BF16_EPS, 3e-3)
+    dy = torch.randn(ref.shape, generator=g).bfloat16().to(dev)
+    dw_ref, db_ref = torch.zeros(343, 4, 16, device=dev), torch.zeros(16, device=dev)
+    _hip.stem_conv_wgrad(x, dy.float(), dw_ref, db_ref)
+    dw, db = torch.zeros(343, 4, 16, device=dev), torch.zeros(16, device=dev)
+    _hip.stem_conv_wgrad_bf16(x, dy, dw, dbias=db)
+    _close(dw.cpu(), dw_ref.cpu().double(), 'stem wgrad (ring)', 2e-5, 2e-5)
+    _close(db.cpu(), db_ref.cpu().double(), 'stem dbias (ring)', 2e-5, 2e-5)
+    # the pooled-gradient form on the same volume: gradient of the max-pooled map scattered inside the kernel
+    d, ho, wo = y.shape[1:4]
+    pooled = torch.empty((n, (d - 1) // 2 + 1, (ho - 1) // 2 + 1, (wo - 1) // 2 + 1, 16), device=dev, dtype=torch.bfloat16)
+    am = torch.empty(pooled.shape[:4] + (4,), dtype=torch.int32, device=dev)
+    op = _hip.make_op(_hip.OP_MAXPOOL_FWD, [y, pooled, am], [n, d, ho, wo, 16]); op.i[25] = _hip.DTYPE_BF16
+    _hip.Plan([op]).run(dev)
+    gp = torch.randn(pooled.shape, generator=g).bfloat16().to(dev)
+    gs = torch.empty_like(y)
+    op = _hip.make_op(_hip.OP_MAXPOOL_BWD, [gp, am, pooled, gs], [n, d, ho, wo, 16]); op.i[25] = _hip.DTYPE_BF16
+    _hip.Plan([op]).run(dev)
+    dw2, db2 = torch.zeros(343, 4, 16, device=dev), torch.zeros(16, device=dev)
+    _hip.stem_conv_wgrad_bf16(x, gs, dw2, dbias=db2)
+    dw3, db3 = torch.zeros(343, 4, 16, device=dev), torch.zeros(16, device=dev)
+    _hip.stem_conv_wgrad_bf16_pooled(x, gp, am, pooled, dw3, dbias=db3)
+    # (the window sums may round differently where two windows share an arg-max: fp32 order)
+    _close(dw3.cpu(), dw2.cpu().double(), 'pooled stem wgrad (ring)', 2e-3, 2e-3)
+    _close(db3.cpu(), db2.cpu().double(), 'pooled stem dbias (ring)', 2e-3, 2e-3)
+
+
 @pytest.mark.parametrize('dhw', [(6, 20, 24), (5, 34, 70)])
 def test_stem_fp32_arithmetic_with_bf16_output(dev, dhw):
     """STEM_FWD record with bf16 storage and fp32 arithmetic (mr3d_stem_conv_forward_bf16out: 2-byte buffer stores) = the fp32
