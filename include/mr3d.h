@@ -52,7 +52,9 @@ enum {
                                      16: FINISH_GRADS, 32: STEM_WGRAD, 64: CONV_WGRAD 1x1x1, 128: CONV_FWD 3x3x3 with cin >= 64 on
                                      maps below 32768 positions (layer3 / layer4 convs and data gradients), 256: STEM_FWD,
                                      512: ZERO_STUFF2 / UPSAMPLE_ADJ / MAXPOOL_BWD */
-  MR3D_TUNE_RESERVED_2 = 2, MR3D_TUNE_RESERVED_3 = 3,
+  MR3D_TUNE_FORK_SYSTEM_FENCE = 2, /* 1 (set BEFORE the first mr3d_plan_run of the process): the plan executor's fork / join events keep
+                                     their system-scope fence (the round-3 behaviour; default 0 = hipEventDisableSystemFence) */
+  MR3D_TUNE_RESERVED_3 = 3,
   MR3D_TUNE_NUM_KEYS = 16
 };
 void mr3d_tuning_set(int key, int value);
