@@ -29,6 +29,7 @@ struct GemmArgs {
   int relu, atomic;
   int ksteps_total;         // ceil(K / kBK)
   float *part;              // split launches with a workspace: split z stores its products to part[z][M][N] (plain stores)
+  int fast_a, fast_b;       // the operand is read with whole float4 buffer loads (see gload_fast)
 };
 
 // stage one 16 x 128 operand block into registers.  KMAJ: stored [rows][K] (k contiguous); else stored [K][rows]
@@ -71,6 +72,30 @@ __device__ __forceinline__ void gload(const float *__restrict__ p, long long ld,
   }
 }
 
+// The same block through a buffer descriptor, for operands whose float4 groups are inside the matrix or outside it as a whole
+// (contiguous extent and leading dimension multiples of 4, below 2^31 bytes): a group outside gets an offset past the end of the
+// buffer and the hardware returns zeros.  No bounds test around a load -- in gload every load sits in its own divergent branch
+// and the wave walks them -- so a step's three or four loads leave back to back.
+template <bool KMAJ, int TR>
+__device__ __forceinline__ void gload_fast(__amdgpu_buffer_rsrc_t rs, long long ld, int row0, int rows, int k0, int K, int tid,
+                                           float4 (&r)[kBK * TR / 4 / kGemmThreads]) {
+#pragma unroll
+  for (int u = 0; u < kBK * TR / 4 / kGemmThreads; ++u) {
+    const int f = tid + u * kGemmThreads;
+    unsigned off;
+    if constexpr (KMAJ) {
+      const int m = f / (kBK / 4), kq = f % (kBK / 4);
+      const int row = row0 + m, k = k0 + 4 * kq;
+      off = (row < rows && k < K) ? (unsigned)((long long)row * ld + k) * 4u : 0x80000000u;
+    } else {
+      const int kr = f / (TR / 4), q = f % (TR / 4);
+      const int k = k0 + kr, col = row0 + 4 * q;
+      off = (k < K && col < rows) ? (unsigned)((long long)k * ld + col) * 4u : 0x80000000u;
+    }
+    r[u] = buffer_load4(rs, off, 0u);
+  }
+}
+
 template <bool KMAJ, int TR>
 __device__ __forceinline__ void lstore(float *__restrict__ t, int tid, const float4 (&r)[kBK * TR / 4 / kGemmThreads]) {
 #pragma unroll
@@ -110,20 +135,25 @@ __global__ __launch_bounds__(kGemmThreads, 2) void linear_gemm_kernel(GemmArgs p
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  float4 ra[kBK * BM / 4 / kGemmThreads], rb[kBK * kBN / 4 / kGemmThreads];
-  if (s_begin < s_end) {
-    gload<AK, BM>(p.a, p.lda, m0, p.M, s_begin * kBK, p.K, tid, ra);
-    gload<BK, kBN>(p.b, p.ldb, n0, p.N, s_begin * kBK, p.K, tid, rb);
-  }
-  for (int s = s_begin; s < s_end; ++s) {
+  // Operand blocks of the next TWO k-steps wait in registers: one step of 16-32 MFMAs per wave (1-2 thousand cycles per SIMD with
+  // the partner workgroup's) is shorter than a trip to L2 / HBM, and with one step of lookahead every step ended in that wait.
+  float4 ra[2][kBK * BM / 4 / kGemmThreads], rb[2][kBK * kBN / 4 / kGemmThreads];
+  const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.a), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.b), 0, 0x7fffffff, 0x00020000);
+  auto load_step = [&](int s, float4 (&qa)[kBK * BM / 4 / kGemmThreads], float4 (&qb)[kBK * kBN / 4 / kGemmThreads]) {
+    if (p.fast_a) gload_fast<AK, BM>(rsa, p.lda, m0, p.M, s * kBK, p.K, tid, qa);
+    else gload<AK, BM>(p.a, p.lda, m0, p.M, s * kBK, p.K, tid, qa);
+    if (p.fast_b) gload_fast<BK, kBN>(rsb, p.ldb, n0, p.N, s * kBK, p.K, tid, qb);
+    else gload<BK, kBN>(p.b, p.ldb, n0, p.N, s * kBK, p.K, tid, qb);
+  };
+  if (s_begin < s_end) load_step(s_begin, ra[0], rb[0]);
+  if (s_begin + 1 < s_end) load_step(s_begin + 1, ra[1], rb[1]);
+  auto step = [&](int s, float4 (&qa)[kBK * BM / 4 / kGemmThreads], float4 (&qb)[kBK * kBN / 4 / kGemmThreads]) {
     const int buf = (s - s_begin) & 1;
-    lstore<AK, BM>(lds[buf][0], tid, ra);
-    lstore<BK, kBN>(lds[buf][1], tid, rb);
+    lstore<AK, BM>(lds[buf][0], tid, qa);
+    lstore<BK, kBN>(lds[buf][1], tid, qb);
     __syncthreads();
-    if (s + 1 < s_end) {
-      gload<AK, BM>(p.a, p.lda, m0, p.M, (s + 1) * kBK, p.K, tid, ra);
-      gload<BK, kBN>(p.b, p.ldb, n0, p.N, (s + 1) * kBK, p.K, tid, rb);
-    }
+    if (s + 2 < s_end) load_step(s + 2, qa, qb);
     const float *ta = lds[buf][0] + h * kLdsRow + wm * 64 + l31;
     const float *tb = lds[buf][1] + h * kLdsRow + wn * (32 * NBW) + l31;
     // all fragments of the step are requested before its first MFMA (one LDS latency per step, not one per k pair)
@@ -142,6 +172,10 @@ __global__ __launch_bounds__(kGemmThreads, 2) void linear_gemm_kernel(GemmArgs p
 #pragma unroll
         for (int j = 0; j < NBW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
     // the buffer written two steps from now is this one: the barrier of the NEXT step orders its reads before that
+  };
+  for (int s = s_begin; s < s_end; s += 2) {
+    step(s, ra[0], rb[0]);
+    if (s + 1 < s_end) step(s + 1, ra[1], rb[1]);
   }
 
   // C/D layout of 32x32: column = lane & 31, rows (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
@@ -214,6 +248,13 @@ int launch_gemm(GemmArgs p, float *workspace, long long workspace_bytes, hipStre
   const int bm = narrow ? 64 : kBM;
   const int tm = (p.M + bm - 1) / bm, tn = (p.N + kBN - 1) / kBN;
   p.ksteps_total = (p.K + kBK - 1) / kBK;
+  // whole float4 groups inside or outside the operand, 32-bit byte offsets (gload_fast)
+  auto fast = [](bool kmaj, long long ld, int rows, int K) {
+    const long long extent = kmaj ? (long long)rows * ld : (long long)K * ld;
+    return (ld & 3) == 0 && ((kmaj ? K : rows) & 3) == 0 && extent * 4 < 0x7fffffffLL;
+  };
+  p.fast_a = fast(AK, p.lda, p.M, p.K) && (reinterpret_cast<uintptr_t>(p.a) & 15) == 0;
+  p.fast_b = fast(BK, p.ldb, p.N, p.K) && (reinterpret_cast<uintptr_t>(p.b) & 15) == 0;
   const int split = split_of(p.M, p.N, p.K);
   p.atomic = split > 1;
   p.part = (split > 1 && workspace && workspace_bytes >= (long long)split * p.M * p.N * 4) ? workspace : nullptr;
