@@ -276,6 +276,136 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_bf16_kernel(BfArgs p, int 
   }
 }
 
+// ------------------------------------------------------------------------------------------------ 3x3x3 / stride 1, 16 -> 16 channels
+// conv2 of the layer1 bottlenecks and its data gradient (resnet3d.py:126-139 at 16 planes): six launches per step on the largest
+// map.  In the generic kernel above they are its worst case -- K = 16 per tap is ONE MFMA per tap and 32-row tile, half of the
+// 32-wide N tile is padding, and the epilogue transposes 32 columns through LDS for 16 -- 47-71 us per launch with the matrix pipe
+// busy 13 % (profiles/r04/bench_bf16_sq_counters.md).  Here, on v_mfma_f32_16x16x32_bf16:
+//   * A = weights [16 cout][32 k], k = 2 taps x 16 channels: the 14 A fragments of a lane are read once from the generic packed
+//     layout ([tap][Cin/8][CoutPad][8]: a lane's 8 channels of one tap and cout are 16 contiguous bytes) and stay in registers;
+//   * B = the halo [position][16 ch] in LDS (32 B per position): a lane's fragment -- 8 channels of one position under one tap --
+//     is ONE ds_read_b128, conflict-free as it lies (16 consecutive positions x two 16-byte halves fill the 64 banks);
+//   * the accumulator holds 4 consecutive output channels of one position per lane: shift / ReLU / ReLU-mask and an 8-byte store
+//     straight from registers, 512 contiguous bytes per store instruction, no LDS pass.
+// A wave owns one depth of the 4 x 8 x 16 tile: 8 rows of 16 positions x 14 k-steps = 112 MFMAs on 112 LDS reads.
+struct C16 {
+  static constexpr int TD = 4, TH = 8, TW = 16, HD = TD + 2, HH = TH + 2, HW = TW + 2, HP = HD * HH * HW;
+  static constexpr int ROWB = 32, LDS_BYTES = HP * ROWB, NT = 256, STEPS = 14;
+  static constexpr int PIECES = HP * 2, NIT = (PIECES + NT - 1) / NT;
+};
+typedef __attribute__((ext_vector_type(4))) float f32x4_c16;
+
+__global__ __launch_bounds__(C16::NT, 3) void conv3d_bf16_c16_kernel(BfArgs p, int tiles_d, int tiles_h, int tiles_w) {
+  using C = C16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  int b = blockIdx.x;
+  const int tw_i = b % tiles_w; b /= tiles_w;
+  const int th_i = b % tiles_h; b /= tiles_h;
+  const int td_i = b % tiles_d; b /= tiles_d;
+  const int n = b;
+  const int od0 = td_i * C::TD, oh0 = th_i * C::TH, ow0 = tw_i * C::TW;
+
+  // halo -> LDS through registers; a piece = 16 bytes (8 channels) of one position.  Buffer loads: a position outside the map
+  // gets an offset past the end of the buffer and reads as zeros (the launcher bounds x below 2^31 bytes)
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(p.x), 0, 0x7fffffff, 0x00020000);
+  uint4 stage[C::NIT];
+#pragma unroll
+  for (int j = 0; j < C::NIT; ++j) {
+    const int it = tid + j * C::NT;
+    const int pos = it >> 1, half = it & 1;
+    const int hw = pos % C::HW, hh = (pos / C::HW) % C::HH, hd = pos / (C::HW * C::HH);
+    const int id = od0 - 1 + hd, ih = oh0 - 1 + hh, iw = ow0 - 1 + hw;
+    const bool ok = it < C::PIECES && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+    const unsigned off = ok ? (unsigned)((((n * p.D + id) * p.H + ih) * p.W + iw) * 32 + half * 16) : 0x80000000u;
+    stage[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)off, 0, 0));
+  }
+  // this lane's weight fragments: k-step s covers taps 2s and 2s + 1; lanes q = 0, 1 hold tap 2s (channels 0-7, 8-15), q = 2, 3
+  // tap 2s + 1 (the 28th tap does not exist: zeros)
+  bf16x8 wr[C::STEPS];
+  int toff[C::STEPS];                                  // LDS byte offset of the lane's tap in a k-step
+#pragma unroll
+  for (int s = 0; s < C::STEPS; ++s) {
+    const int tap = 2 * s + (q >> 1);
+    const int tc = tap < 27 ? tap : 26;
+    const bf16x8 w = reinterpret_cast<const bf16x8 *>(p.w)[(size_t)(tc * 2 + (q & 1)) * p.CoutPad + r];
+    bf16x8 z;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.0f;
+    wr[s] = tap < 27 ? w : z;
+    const int kw = tc % 3, kh = (tc / 3) % 3, kd = tc / 9;
+    toff[s] = ((kd * C::HH + kh) * C::HW + kw) * C::ROWB;
+  }
+#pragma unroll
+  for (int j = 0; j < C::NIT; ++j) {
+    const int it = tid + j * C::NT;
+    if (it < C::PIECES) *reinterpret_cast<uint4 *>(lds + it * 16) = stage[j];
+  }
+  __syncthreads();
+
+  f32x4_c16 acc[C::TH];
+#pragma unroll
+  for (int i = 0; i < C::TH; ++i) acc[i] = f32x4_c16{0.f, 0.f, 0.f, 0.f};
+  // lane (r, q): position column r of every row of depth `wave`, channel half q & 1
+  const unsigned char *bbase = lds + ((wave * C::HH) * C::HW + r) * C::ROWB + (q & 1) * 16;
+#pragma unroll
+  for (int s = 0; s < C::STEPS; ++s) {
+    const unsigned char *bs = bbase + toff[s];
+#pragma unroll
+    for (int i = 0; i < C::TH; ++i) {
+      const bf16x8 f = *reinterpret_cast<const bf16x8 *>(bs + i * (C::HW * C::ROWB));
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[s], f, acc[i], 0, 0, 0);
+    }
+  }
+  // ---- epilogue: C/D layout of 16x16: column (position) = lane & 15, row (cout) = 4 * (lane >> 4) + reg
+  const int od = od0 + wave, ow = ow0 + r;
+  if (od >= p.Do || ow >= p.Wo) return;
+  float sh[4] = {0.f, 0.f, 0.f, 0.f};
+  if (p.shift) {
+    const float4 s4 = *reinterpret_cast<const float4 *>(p.shift + 4 * q);
+    sh[0] = s4.x; sh[1] = s4.y; sh[2] = s4.z; sh[3] = s4.w;
+  }
+#pragma unroll
+  for (int i = 0; i < C::TH; ++i) {
+    const int oh = oh0 + i;
+    if (oh >= p.Ho) continue;
+    const size_t idx = ((((size_t)n * p.Do + od) * p.Ho + oh) * p.Wo + ow) * 16 + 4 * q;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] = acc[i][e] + sh[e];
+      if (p.relu) v[e] = fmaxf(v[e], 0.f);
+    }
+    if (p.mask) {
+      const uint2 m = *reinterpret_cast<const uint2 *>(p.mask + idx);
+      if (!(__uint_as_float(m.x << 16) > 0.f)) v[0] = 0.f;
+      if (!(__uint_as_float(m.x & 0xffff0000u) > 0.f)) v[1] = 0.f;
+      if (!(__uint_as_float(m.y << 16) > 0.f)) v[2] = 0.f;
+      if (!(__uint_as_float(m.y & 0xffff0000u) > 0.f)) v[3] = 0.f;
+    }
+    *reinterpret_cast<uint2 *>(p.y + idx) = make_uint2((uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16),
+                                                      (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16));
+  }
+}
+
+// the shapes the 16-channel kernel takes: dense output, no residual / upsample inputs, the whole input below 2^31 bytes
+bool c16_ok(const BfArgs &a) {
+  return a.Cin == 16 && a.Cout == 16 && a.pd == 1 && a.ph == 1 && a.pw == 1 && !a.add1 && !a.add2 && !a.up && !a.x_live &&
+         a.ysd == 1 && a.ysh == 1 && a.ysw == 1 && a.yD == a.Do && a.yH == a.Ho && a.yW == a.Wo &&
+         (long long)a.N * a.D * a.H * a.W * 32 < 0x7fffffffLL && !g_mr3d_tuning[MR3D_TUNE_RESERVED_3];
+}
+
+int launch_c16(const BfArgs &a, hipStream_t stream) {
+  using C = C16;
+  const int tiles_d = (a.Do + C::TD - 1) / C::TD, tiles_h = (a.Ho + C::TH - 1) / C::TH, tiles_w = (a.Wo + C::TW - 1) / C::TW;
+  const long long tiles = (long long)a.N * tiles_d * tiles_h * tiles_w;
+  if (tiles > 0x7fffffffLL) return MR3D_ERR_UNSUPPORTED;
+  conv3d_bf16_c16_kernel<<<(unsigned)tiles, C::NT, C::LDS_BYTES, stream>>>(a, tiles_d, tiles_h, tiles_w);
+  return mr3d_launch_status();
+}
+
 template <class C, bool LIVE = false>
 int launch_bf(const BfArgs &a, hipStream_t stream) {
   const int tiles_d = (a.Do + C::TD - 1) / C::TD, tiles_h = (a.Ho + C::TH - 1) / C::TH, tiles_w = (a.Wo + C::TW - 1) / C::TW;
@@ -362,6 +492,7 @@ extern "C" int mr3d_conv3d_forward_bf16(const mr3d_conv3d_desc *d, mr3d_stream_t
     return dispatch_cc<1, 1>(a, stream);
   }
   if (k == 1 && s == 2) return dispatch_cc<1, 2>(a, stream);
+  if (k == 3 && s == 1 && c16_ok(a)) return launch_c16(a, stream);
   if (k == 3 && s == 1) return dispatch_cc<3, 1>(a, stream);
   if (k == 3 && s == 2) return dispatch_cc<3, 2>(a, stream);
   return MR3D_ERR_UNSUPPORTED;

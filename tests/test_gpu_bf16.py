@@ -52,6 +52,7 @@ CASES = [
     (64, 128, 1, 2, 0, (6, 10, 12)),
     (256, 512, 1, 2, 0, (5, 8, 7)),
     (16, 16, 3, 1, 1, (6, 10, 12)),
+    (16, 16, 3, 1, 1, (9, 21, 37)),           # several 4x8x16 tiles of the 16-channel kernel, ragged in every axis
     (32, 32, 3, 1, 1, (5, 9, 9)),
     (64, 64, 3, 1, 1, (8, 16, 17)),
     (64, 64, 3, 1, 1, (12, 40, 40)),          # enough tiles for the 4x8x8 instance
