@@ -394,7 +394,7 @@ __global__ __launch_bounds__(C16::NT, 3) void conv3d_bf16_c16_kernel(BfArgs p, i
 bool c16_ok(const BfArgs &a) {
   return a.Cin == 16 && a.Cout == 16 && a.pd == 1 && a.ph == 1 && a.pw == 1 && !a.add1 && !a.add2 && !a.up && !a.x_live &&
          a.ysd == 1 && a.ysh == 1 && a.ysw == 1 && a.yD == a.Do && a.yH == a.Ho && a.yW == a.Wo &&
-         (long long)a.N * a.D * a.H * a.W * 32 < 0x7fffffffLL && !g_mr3d_tuning[MR3D_TUNE_RESERVED_3];
+         (long long)a.N * a.D * a.H * a.W * 32 < 0x7fffffffLL;
 }
 
 int launch_c16(const BfArgs &a, hipStream_t stream) {

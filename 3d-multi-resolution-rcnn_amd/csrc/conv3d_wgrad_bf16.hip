@@ -358,11 +358,9 @@ extern "C" int mr3d_conv3d_wgrad_bf16(const mr3d_conv3d_wgrad_desc *d, mr3d_stre
   if (k == 1 && s == 1 && sparse) return launch_wg<WgCfg<1, 1, 2, 8>, true>(a, stream);
   if (k == 3 && s == 1) return launch_wg<WgCfg<3, 1, 2, 8>>(a, stream);
   if (k == 3 && s == 2) return launch_wg<WgCfg<3, 2, 1, 4>>(a, stream);
-  if (k == 1 && s == 1) {
-    // large maps: 512 positions per tile iteration (twice the bytes in flight per workgroup and barrier pair)
-    if ((long long)a.N * a.Do * a.Ho * a.Wo >= 262144) return launch_wg<WgCfg<1, 1, 4, 8>>(a, stream);      // 64 -> 64 at 40x128x128: 41 -> 37 us
-    return launch_wg<WgCfg<1, 1, 2, 8>>(a, stream);
-  }
+  // (512-position tiles for the 1x1x1 records of the large maps: 41 -> 37 us for 64 -> 64 at 40x128x128 alone, but the bf16 backbone
+  // step 4.61 -> 4.66 ms -- twice the LDS per workgroup leaves less room beside the main chain's kernels)
+  if (k == 1 && s == 1) return launch_wg<WgCfg<1, 1, 2, 8>>(a, stream);
   if (k == 1 && s == 2) return launch_wg<WgCfg<1, 2, 2, 8>>(a, stream);
   return MR3D_ERR_UNSUPPORTED;
 }

@@ -109,7 +109,7 @@ WG_CASES = [
     (64, 16, 1, 1, 0, (6, 10, 20)),
     (16, 64, 1, 1, 0, (9, 17, 33)),
     (256, 64, 1, 1, 0, (5, 16, 15)),
-    (16, 64, 1, 1, 0, (9, 125, 126)),         # 2 x 141,750 positions: the 4 x 8 x 16 tile of the large maps, ragged
+    (16, 64, 1, 1, 0, (9, 125, 126)),         # 2 x 141,750 positions: many tiles per persistent workgroup, ragged
     (64, 128, 1, 2, 0, (6, 10, 12)),
     (16, 16, 3, 1, 1, (6, 10, 12)),
     (32, 32, 3, 1, 1, (5, 9, 19)),
