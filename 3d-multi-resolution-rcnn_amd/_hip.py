@@ -537,6 +537,28 @@ def conv3d_wgrad_bf16(x, dy, dw_packed, k, stride, pad, dbias=None, sparse_dy=Fa
     return dw_packed
 
 
+def conv3d_dgrad_s2k3_bf16(dy, wb16, dx_shape, add1=None, add2=None, mask=None, out=None):
+    """bf16 form of conv3d_dgrad_s2k3 (mr3d_conv3d_dgrad_s2k3_bf16).  dy: [N,Do,Ho,Wo,Cout_fwd] bf16; wb16: pack_conv_weight_bf16 of
+    the flipped / transposed taps (Cin = Cout_fwd, Cout = Cin_fwd); returns dx [N,D,H,W,Cin_fwd] bf16."""
+    assert dy.is_cuda and dy.is_contiguous() and dy.dtype == torch.bfloat16 and dy.dim() == 5 and wb16.dtype == torch.bfloat16
+    dx = out if out is not None else torch.empty(tuple(dx_shape), dtype=torch.bfloat16, device=dy.device)
+    assert tuple(dx.shape) == tuple(dx_shape) and dx.is_contiguous() and dx.dtype == torch.bfloat16
+    for t in (add1, add2, mask):
+        assert t is None or (tuple(t.shape) == tuple(dx.shape) and t.is_contiguous() and t.dtype == torch.bfloat16)
+    d = Conv3dDesc()
+    d.x, d.w, d.y = dy.data_ptr(), wb16.data_ptr(), dx.data_ptr()
+    d.add1, d.add2, d.mask = _opt(add1), _opt(add2), _opt(mask)
+    d.n, d.d, d.h, d.w_in, d.cin, d.cout = dy.size(0), dy.size(1), dy.size(2), dy.size(3), dy.size(4), dx.size(4)
+    d.kd = d.kh = d.kw = 3
+    d.sd = d.sh = d.sw = 2
+    d.pd = d.ph = d.pw = 1
+    d.y_d, d.y_h, d.y_w = dx.size(1), dx.size(2), dx.size(3)
+    with torch.cuda.device(dy.device):
+        st = lib().mr3d_conv3d_dgrad_s2k3_bf16(ctypes.byref(d), stream_ptr(dy.device))
+    check(st, 'mr3d_conv3d_dgrad_s2k3_bf16')
+    return dx
+
+
 def conv3d_dgrad_s2k3(dy, wb_packed, dx_shape, add1=None, add2=None, mask=None, out=None):
     """Data gradient of a kernel-3/stride-2/pad-1 conv without zero-stuffing (mr3d_conv3d_dgrad_s2k3).
     dy: [N,Do,Ho,Wo,Cout_fwd]; wb_packed: [27,Cout_fwd,Cin_fwd] flipped/transposed taps; returns dx [N,D,H,W,Cin_fwd]."""

@@ -45,9 +45,13 @@ __device__ __forceinline__ int nearest_src(int dst, int in, int out) {
   return s < in - 1 ? s : in - 1;
 }
 
-template <int K_, int S_, int TD_, int TH_, int TW_, int CC_, int NT_>
+// PAR_: the parity-decomposed data gradient of a kernel-3 / stride-2 / pad-1 convolution (mr3d_conv3d_dgrad_s2k3_bf16): K_ = 2 is
+// then the per-axis MAXIMUM of taps an output class meets; blockIdx.z is the class, its 1..8 taps are walked, and the outputs go to
+// positions 2 o + (class bit) of dx.
+template <int K_, int S_, int TD_, int TH_, int TW_, int CC_, int NT_, bool PAR_ = false>
 struct BfCfg {
   static constexpr int K = K_, S = S_, TD = TD_, TH = TH_, TW = TW_, CC = CC_, NT = NT_;
+  static constexpr bool PAR = PAR_;
   static constexpr bool PW1 = (K_ == 1);
   static constexpr int LS = PW1 ? 1 : S_;          // LDS step per output position
   static constexpr int GS = PW1 ? S_ : 1;          // global step per halo position (a strided 1x1x1 reads every S-th voxel)
@@ -87,6 +91,22 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_bf16_kernel(BfArgs p, int 
   const int od0 = td_i * C::TD, oh0 = th_i * C::TH, ow0 = tw_i * C::TW;
   const int id0 = od0 * C::S - p.pd, ih0 = oh0 * C::S - p.ph, iw0 = ow0 * C::S - p.pw;
   const int n0 = blockIdx.y * C::NB;
+  // PAR: parity class of the outputs this workgroup produces (the 8-tap class first); class-local tap t -> halo offset
+  // (kd, kh, kw) in {0, 1}^3 and tap {1} / {0, 2} of the flipped 3x3x3 kernel per axis
+  const int cls = C::PAR ? 7 - (int)blockIdx.z : 0;
+  const int ad = (cls >> 2) & 1, ah = (cls >> 1) & 1, aw = cls & 1;
+  const int tap_shift = ad + ah + aw;                       // PAR: the class walks 1 << tap_shift taps
+  auto tap_of = [&](int t, int &kd, int &kh, int &kw) {     // -> index into the weight array
+    if constexpr (C::PAR) {
+      kw = aw ? (t & 1) : 0;
+      kh = ah ? ((t >> aw) & 1) : 0;
+      kd = ad ? ((t >> (aw + ah)) & 1) : 0;
+      return ((ad ? 2 * kd : 1) * 3 + (ah ? 2 * kh : 1)) * 3 + (aw ? 2 * kw : 1);
+    } else {
+      kw = t % C::K; kh = (t / C::K) % C::K; kd = t / (C::K * C::K);
+      return t;
+    }
+  };
   bool dead = false;                                 // (workgroup-uniform: every wave tests the same halo rows)
   if constexpr (LIVE) {
     static_assert(C::HD * C::HH <= 64, "one lane per halo row");
@@ -153,14 +173,17 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_bf16_kernel(BfArgs p, int 
   };
   // weight fragments of one tap (all k-steps of the chunk, all N tiles)
   auto load_b = [&](bf16x8 (&dst)[C::KK][C::NT], int c0, int tap) {
-    const bf16x8 *wt = wlane + ((size_t)tap * cin8 + (c0 >> 3)) * p.CoutPad;
+    int kd_, kh_, kw_;
+    const int wtap = tap_of(tap, kd_, kh_, kw_);
+    const bf16x8 *wt = wlane + ((size_t)wtap * cin8 + (c0 >> 3)) * p.CoutPad;
 #pragma unroll
     for (int kk = 0; kk < C::KK; ++kk)
 #pragma unroll
       for (int nt = 0; nt < C::NT; ++nt) dst[kk][nt] = wt[(size_t)kk * 2 * p.CoutPad + nt * 32];
   };
   auto mma_tap = [&](const bf16x8 (&bw)[C::KK][C::NT], int tap) {
-    const int kw = tap % C::K, kh = (tap / C::K) % C::K, kd = tap / (C::K * C::K);
+    int kd, kh, kw;
+    (void)tap_of(tap, kd, kh, kw);
     const int tapoff = ((kd * C::HH + kh) * C::HWP + kw) * C::ROWB;
 #pragma unroll
     for (int kk = 0; kk < C::KK; ++kk) {
@@ -181,17 +204,27 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_bf16_kernel(BfArgs p, int 
   constexpr int RD = C::MTW == 1 ? 4 : 2;
   bf16x8 bq[RD][C::KK][C::NT];
   const int nchunks = p.Cin / C::CC;
-  const int total = dead ? 0 : nchunks * C::TAPS;          // flattened (chunk, tap) walk; the B registers rotate across it
+  const int ntaps = C::PAR ? (1 << tap_shift) : C::TAPS;
+  const int total = dead ? 0 : nchunks * ntaps;            // flattened (chunk, tap) walk; the B registers rotate across it
+  auto split = [&](int cur, int &chunk, int &tap) {
+    if constexpr (C::PAR) { chunk = cur >> tap_shift; tap = cur & (ntaps - 1); }
+    else { chunk = cur / C::TAPS; tap = cur - chunk * C::TAPS; }
+  };
   if (!dead) fetch(0);
 #pragma unroll
   for (int u = 0; u < RD - 1; ++u)
-    if (u < total) load_b(bq[u], (u / C::TAPS) * C::CC, u % C::TAPS);
+    if (u < total) {
+      int c_, t_;
+      split(u, c_, t_);
+      load_b(bq[u], c_ * C::CC, t_);
+    }
   for (int it = 0; it < total; it += RD) {
 #pragma unroll
     for (int u = 0; u < RD; ++u) {
       const int cur = it + u;
       if (cur >= total) break;
-      const int chunk = cur / C::TAPS, tap = cur - chunk * C::TAPS;
+      int chunk, tap;
+      split(cur, chunk, tap);
       if (tap == 0) {
         __syncthreads();                        // every wave is done reading the previous chunk's halo
         commit();
@@ -200,7 +233,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_bf16_kernel(BfArgs p, int 
       }
       const int nxt = cur + RD - 1;
       if (nxt < total) {
-        const int nchunk = nxt / C::TAPS, ntap = nxt - nchunk * C::TAPS;
+        int nchunk, ntap;
+        split(nxt, nchunk, ntap);
         load_b(bq[(u + RD - 1) % RD], nchunk * C::CC, ntap);
       }
       mma_tap(bq[u], tap);
@@ -230,10 +264,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_bf16_kernel(BfArgs p, int 
       const int tw = m % C::TW, th = (m / C::TW) % C::TH, td = m / (C::TW * C::TH);
       const int od = od0 + td, oh = oh0 + th, ow = ow0 + tw;
       if (co >= p.Cout || od >= p.Do || oh >= p.Ho || ow >= p.Wo) continue;
+      if (C::PAR && (2 * od + ad >= p.yD || 2 * oh + ah >= p.yH || 2 * ow + aw >= p.yW)) continue;
       const float4 v0 = *reinterpret_cast<const float4 *>(eps + m * EROW + grp * 8);
       const float4 v1 = *reinterpret_cast<const float4 *>(eps + m * EROW + grp * 8 + 4);
       float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-      const size_t idx = ((((size_t)n * p.yD + od * p.ysd) * p.yH + oh * p.ysh) * p.yW + ow * p.ysw) * p.Cout + co;
+      const size_t idx = C::PAR ? ((((size_t)n * p.yD + 2 * od + ad) * p.yH + 2 * oh + ah) * p.yW + 2 * ow + aw) * p.Cout + co
+                                : ((((size_t)n * p.yD + od * p.ysd) * p.yH + oh * p.ysh) * p.yW + ow * p.ysw) * p.Cout + co;
       if (p.shift) {
         const float4 s0 = *reinterpret_cast<const float4 *>(p.shift + co), s1 = *reinterpret_cast<const float4 *>(p.shift + co + 4);
         v[0] += s0.x; v[1] += s0.y; v[2] += s0.z; v[3] += s0.w; v[4] += s1.x; v[5] += s1.y; v[6] += s1.z; v[7] += s1.w;
@@ -418,7 +454,7 @@ int launch_bf(const BfArgs &a, hipStream_t stream) {
     }
     attr_done = true;
   }
-  dim3 grid((unsigned)(a.N * tiles_d * tiles_h * tiles_w), (unsigned)(a.CoutPad / C::NB));
+  dim3 grid((unsigned)(a.N * tiles_d * tiles_h * tiles_w), (unsigned)(a.CoutPad / C::NB), C::PAR ? 8u : 1u);
   conv3d_bf16_kernel<C, LIVE><<<grid, kThreads, C::LDS_BYTES, stream>>>(a, tiles_d, tiles_h, tiles_w);
   return mr3d_launch_status();
 }
@@ -456,6 +492,36 @@ int dispatch_cc(const BfArgs &a, hipStream_t stream) {
 }
 
 }  // namespace
+
+// Data gradient of a kernel-3 / stride-2 / pad-1 convolution from the coarse dy, bf16 (the fp32 form: mr3d_conv3d_dgrad_s2k3 in
+// csrc/conv3d_fwd.hip): the 8 output parity classes of dx are computed with the 1..8 taps each of them meets -- the zero-stuffed
+// form multiplied 8x the positions, 7/8 of them zeros.
+extern "C" int mr3d_conv3d_dgrad_s2k3_bf16(const mr3d_conv3d_desc *d, mr3d_stream_t stream_) {
+  if (!d || !d->x || !d->w || !d->y) return MR3D_ERR_INVALID_ARG;
+  if (d->y_d <= 0 || d->y_h <= 0 || d->y_w <= 0 || d->shift || d->up || d->relu) return MR3D_ERR_INVALID_ARG;
+  if (d->d != (d->y_d - 1) / 2 + 1 || d->h != (d->y_h - 1) / 2 + 1 || d->w_in != (d->y_w - 1) / 2 + 1) return MR3D_ERR_INVALID_ARG;
+  if (d->n <= 0 || d->cin % 16 != 0 || d->cout % 8 != 0) return MR3D_ERR_UNSUPPORTED;
+  BfArgs a;
+  a.x = (const bf16_t *)d->x; a.w = (const bf16_t *)d->w; a.y = (bf16_t *)d->y; a.shift = nullptr;
+  a.add1 = (const bf16_t *)d->add1; a.add2 = (const bf16_t *)d->add2; a.up = nullptr; a.mask = (const bf16_t *)d->mask;
+  a.N = d->n; a.D = d->d; a.H = d->h; a.W = d->w_in; a.Cin = d->cin; a.Cout = d->cout;
+  a.CoutPad = (d->cout + 31) / 32 * 32;
+  a.pd = a.ph = a.pw = 0;
+  a.Do = d->d; a.Ho = d->h; a.Wo = d->w_in;          // class grid = dy's grid
+  a.Du = a.Hu = a.Wu = 0; a.relu = 0;
+  a.x_live = nullptr;
+  a.ysd = a.ysh = a.ysw = 2; a.yD = d->y_d; a.yH = d->y_h; a.yW = d->y_w;
+  hipStream_t stream = mr3d_stream(stream_);
+  const bool wide = a.CoutPad % 64 == 0;
+  const long long wg488 = (long long)a.N * ((a.Do + 3) / 4) * ((a.Ho + 7) / 8) * ((a.Wo + 7) / 8) * (a.CoutPad / (wide ? 64 : 32)) * 8;
+  const bool big = wg488 >= 512;
+  if (a.Cin % 32 == 0) {
+    if (wide) return big ? launch_bf<BfCfg<2, 1, 4, 8, 8, 32, 2, true>>(a, stream) : launch_bf<BfCfg<2, 1, 2, 8, 8, 32, 2, true>>(a, stream);
+    return big ? launch_bf<BfCfg<2, 1, 4, 8, 8, 32, 1, true>>(a, stream) : launch_bf<BfCfg<2, 1, 2, 8, 8, 32, 1, true>>(a, stream);
+  }
+  if (wide) return big ? launch_bf<BfCfg<2, 1, 4, 8, 8, 16, 2, true>>(a, stream) : launch_bf<BfCfg<2, 1, 2, 8, 8, 16, 2, true>>(a, stream);
+  return big ? launch_bf<BfCfg<2, 1, 4, 8, 8, 16, 1, true>>(a, stream) : launch_bf<BfCfg<2, 1, 2, 8, 8, 16, 1, true>>(a, stream);
+}
 
 extern "C" int mr3d_conv3d_forward_bf16(const mr3d_conv3d_desc *d, mr3d_stream_t stream_) {
   if (!d || !d->x || !d->w || !d->y) return MR3D_ERR_INVALID_ARG;

@@ -34,7 +34,7 @@ int run_one(const mr3d_op &o, mr3d_stream_t s, bool shared_ws = true, const unsi
       memcpy(&d.n, i, sizeof(int) * 25);
       d.workspace = nullptr; d.workspace_bytes = 0;
       d.x_live = nullptr;
-      return mr3d_conv3d_dgrad_s2k3(&d, s);
+      return bf16 ? mr3d_conv3d_dgrad_s2k3_bf16(&d, s) : mr3d_conv3d_dgrad_s2k3(&d, s);
     }
     case MR3D_OP_CONV_WGRAD: {
       mr3d_conv3d_wgrad_desc d;

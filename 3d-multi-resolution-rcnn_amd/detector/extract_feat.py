@@ -631,17 +631,12 @@ class ExtractFeat3D(nn.Module):
             g_a1 = self._new(st['a1'].shape)
             if b['stride'] == 1:
                 bwd.append(self._conv_dgrad(g_a2, b['conv2'], g_a1, mask=st['a1']))
-            elif self.bf16:
-                # strided 3x3x3, bf16: zero-stuff the coarse gradient onto a1's grid, then the stride-1 data-gradient kernel
-                stuffed = self._new(st['a1'].shape[:4] + (b['conv2'].cout,))
-                bwd.append(self._op(_hip.OP_ZERO_STUFF2, [g_a2, stuffed], [N, *g_a2.shape[1:4], *stuffed.shape[1:4], b['conv2'].cout]))
-                bwd.append(self._conv_dgrad(stuffed, b['conv2'], g_a1, mask=st['a1']))
             else:
-                # strided 3x3x3: parity-decomposed data gradient straight from the coarse g_a2 (no zero-stuffing)
+                # strided 3x3x3: parity-decomposed data gradient straight from the coarse g_a2 (no zero-stuffing; the bf16 plan
+                # zero-stuffed until round 4: 8x the positions through the stride-1 kernel, 7/8 of them zeros)
                 sp = b['conv2']
                 ints = self._conv_ints(g_a2.shape, sp.cout, sp.cin_pad, 3, (2, 2, 2), 1, ydims=g_a1.shape[1:4])
-                bwd.append(_hip.make_op(_hip.OP_CONV_DGRAD_S2,
-                                        [g_a2, self._w(sp, 'wb'), g_a1, None, None, None, None, st['a1']], ints))
+                bwd.append(self._op(_hip.OP_CONV_DGRAD_S2, [g_a2, self._w(sp, 'wb'), g_a1, None, None, None, None, st['a1']], ints))
             emit_wgrad(self._conv_wgrad(x, g_a1, b['conv1']), b['stage'])          # (behind conv1's data gradient instead: 9.99 -> 10.25 ms)
             first_of_stage = b['block'] == 0
             lat_part = gC_lat[b['stage'] - 1] if (first_of_stage and b['stage'] > 0) else None

@@ -251,6 +251,9 @@ int mr3d_conv3d_forward_variant(const mr3d_conv3d_desc *desc, mr3d_conv3d_varian
  * flipped/transposed 27-tap weights of mr3d_prepare_weights (wb), y = dx [n,y_d,y_h,y_w,cout] with y_d/y_h/y_w
  * REQUIRED and d == (y_d-1)/2+1 etc.; add1/add2/mask as in mr3d_conv3d_forward; shift/up/relu must be unset. */
 int mr3d_conv3d_dgrad_s2k3(const mr3d_conv3d_desc *desc, mr3d_stream_t stream);
+/* the same on bf16 maps (x = dy, y = dx, add1 / add2 / mask bf16; w = the bf16 packing of mr3d_prepare_weights_bf16's `wb`);
+ * plan record CONV_DGRAD_S2 with i[25] = MR3D_DTYPE_BF16 */
+int mr3d_conv3d_dgrad_s2k3_bf16(const mr3d_conv3d_desc *desc, mr3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * conv3d weight gradient -- the wgrad half of autograd's backward of the torch.nn.Conv3d calls above

@@ -120,6 +120,30 @@ WG_CASES = [
 ]
 
 
+@pytest.mark.parametrize('cin,cout,dhw', [(32, 32, (8, 16, 14)), (64, 64, (7, 11, 9)), (128, 128, (5, 16, 16)), (32, 32, (9, 33, 20)),
+                                          (64, 64, (20, 64, 64))])
+def test_conv3d_dgrad_s2k3_bf16_parity_decomposed(dev, cin, cout, dhw):
+    """mr3d_conv3d_dgrad_s2k3_bf16: the data gradient of the strided conv2 (resnet3d.py:139) from the coarse dy, 8 parity classes
+    with 1..8 taps each, against float64 on the same bf16-rounded operands; plain, and with the residual add + ReLU mask fused;
+    odd and even extents, both tile sizes, 32- and 64-wide Cout tiles"""
+    from mr3d_amd import _hip
+    g = torch.Generator().manual_seed(cin + dhw[0])
+    n = 1 if dhw[1] >= 64 else 2
+    w = _bf(torch.randn((cout, cin, 3, 3, 3), generator=g) / np.sqrt(cin * 27))     # forward conv: cin -> cout, stride 2
+    do = tuple((v - 1) // 2 + 1 for v in dhw)
+    dy = _bf(torch.randn((n, cout) + do, generator=g))
+    a1 = _bf(torch.randn((n, cin) + dhw, generator=g))
+    add = _bf(torch.randn((n, cin) + dhw, generator=g))
+    ref = torch.nn.grad.conv3d_input((n, cin) + dhw, w.double(), dy.double(), stride=2, padding=1)
+    wb16 = _hip.pack_conv_weight_bf16(w.flip(2, 3, 4).transpose(0, 1).contiguous()).to(dev)
+    dyd = _cl(dy).to(dev).bfloat16()
+    dx = _hip.conv3d_dgrad_s2k3_bf16(dyd, wb16, (n,) + dhw + (cin,))
+    _close(dx.float().permute(0, 4, 1, 2, 3).cpu(), ref, 'dgrad s2k3', BF16_EPS, 3e-3)
+    dx = _hip.conv3d_dgrad_s2k3_bf16(dyd, wb16, (n,) + dhw + (cin,), add1=_cl(add).to(dev).bfloat16(), mask=_cl(a1).to(dev).bfloat16())
+    exp = torch.where(a1 > 0, ref + add.double(), torch.zeros_like(ref))
+    _close(dx.float().permute(0, 4, 1, 2, 3).cpu(), exp, 'dgrad s2k3 + add + mask', BF16_EPS, 3e-3)
+
+
 @pytest.mark.parametrize('cin,cout,k,stride,pad,dhw', WG_CASES)
 def test_conv3d_bf16_wgrad(dev, cin, cout, k, stride, pad, dhw):
     """transposing LDS reads (ds_read_b64_tr_b16) feed positions as the GEMM K axis: weight gradient + sum dy vs float64"""
