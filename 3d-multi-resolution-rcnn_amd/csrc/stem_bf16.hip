@@ -7,9 +7,10 @@
 // MFMA work is useful, still ~4x the fp32 kernel's rate).  The weights are the A operand (pre-packed [kd*7+kh][c4][cout][kw8] bf16,
 // 50 KB, staged in LDS once per workgroup), the input the B operand: a lane's fragment -- 8 consecutive kw taps of one channel
 // for one output position -- is 8 CONSECUTIVE input columns starting at 2*ow - 3, 16 bytes of the planar bf16 slab
-// [c][depth slot][h][w] at a 4-byte-aligned address.  A wave owns four consecutive output rows: input row j feeds row i with
-// tap kh = j - 2i, so ONE fragment read per (kd, input row) serves up to four MFMAs (13 reads for 28 MFMAs) against the seven
-// kh weight fragments of the kd, which wait in registers.  The accumulator holds 4 consecutive output channels of one position
+// [c][depth slot][h][w] at a 4-byte-aligned address.  A wave owns two output depths x four consecutive output rows of the
+// 8 x 8 x 16 tile: the fragment of input plane pl and row j feeds depth t with tap kd = pl - t and row i with tap kh = j - 2i, so
+// ONE fragment read serves up to eight MFMAs (104 reads for 392 MFMAs) against the seven kh weight fragments of two kd taps,
+// which wait in registers.  The accumulator holds 4 consecutive output channels of one position
 // per lane: 8-byte stores, 512 contiguous bytes per store instruction.
 //
 // Weight gradient.  GEMM M = (channel, kd, kh, kw) rows, N = 16 output channels, K = positions, 32 consecutive ow per step.
@@ -24,7 +25,7 @@
 //
 // Both kernels walk depth-adjacent tiles and keep the slab's depth planes in a ring: a tile stages only its 4 new planes (12 of
 // the 30 (channel, depth) planes), fetched with buffer loads (zeros past the borders from the hardware: no branch per load)
-// that stay in flight during the MFMA phase of the tile before.  512x512x80: forward 0.59 -> 0.38 ms, weight gradient (with the
+// that stay in flight during the MFMA phase of the tile before.  512x512x80: forward 0.59 -> 0.34 ms, weight gradient (with the
 // max-pool backward folded in) 0.81 -> 0.41 ms.
 #include <atomic>
 #include "mr3d_common.h"
@@ -70,8 +71,8 @@ __global__ __launch_bounds__(256) void stem_pack_bf16_kernel(const float *__rest
 // once; the input slab of the NEXT tile is fetched into registers (all loads in flight at once) while the current tile is
 // multiplied, then converted to bf16 and written to LDS -- the global latency never sits between two MFMA phases.
 struct FwdGeo {
-  static constexpr int TD = 4, TH = 8, TW = 16, NT = 512;
-  static constexpr int HD = TD + 6, HH = 2 * (TH - 1) + 7, HW = 40;          // 38 columns used (+1 read by the zero kw slot)
+  static constexpr int TD = 8, TH = 8, TW = 16, NT = 512;
+  static constexpr int HD = TD + 6, HH = 2 * (TH - 1) + 7, HW = 40;          // 14 ring slots x 21 rows x 38 columns used (+1 read by the zero kw slot)
   static constexpr int PLANE = HD * HH * HW;                                  // bf16 elements per channel
   static constexpr int W_BYTES = 49 * 4 * 16 * 8 * 2;
   static constexpr int LDS_BYTES = W_BYTES + 3 * PLANE * 2 + 64;
@@ -130,21 +131,24 @@ __global__ __launch_bounds__(512, 1) void stem_fwd_bf16_kernel(StemBfArgs p, int
   // Staging map: iteration u = one (channel, depth) plane of the slab (compile-time), thread = (row hh, column pair pr) of it:
   // the per-thread part of every address is ONE register, the plane part is wave-uniform.
   // A workgroup's tiles are depth-adjacent inside a (n, h, w) column and the slab's depth planes form a ring (input depth id lives
-  // in slot (id + 10) % 10): the first tile of a column (or of the run) stages its 10 planes, every later one only the 4 new ones.
-  constexpr int NPL = 3 * G::HD;
+  // in slot (id + 14) % 14): a tile (8 output depths, 14 input planes) stages only its 8 new planes; the first tile of a column (or
+  // of the workgroup's run) takes one more staging round in front for the other 6.
+  constexpr int RCNT = G::TD, SCNT = G::HD - G::TD;                   // planes per channel of a regular / a start round: 8 / 6
+  constexpr int NPL = 3 * RCNT;
   const int s_hh = tid / G::PAIRS, s_pr = tid - s_hh * G::PAIRS;
   const bool s_act = s_hh < G::HH;
   float2 st[NPL];
-  // plane u of 30: 10 per channel at a start, 4 inside a column (ONE code path: see stem_wgrad_bf16_kernel)
-  auto plane_of = [&](int u, bool start, int id_first, int &c, int &id) {
-    c = start ? u / G::HD : u / G::TD;
-    id = id_first + (start ? u % G::HD : u % G::TD);
-    return start || u < 3 * G::TD;
+  // plane u of 24 in a round: ONE code path for both round kinds (see stem_wgrad_bf16_kernel)
+  auto plane_of = [&](int u, bool start, int &c, int &j) {
+    c = start ? u / SCNT : u / RCNT;
+    j = start ? u % SCNT : u % RCNT;
+    return start ? u < 3 * SCNT : true;
   };
+  auto first_id = [&](int td_i, bool start) { return td_i * G::TD + (start ? -3 : 3); };
   auto fetch = [&](int tile, bool start) {
     const BfTile bt = bf_tile_of(tile, tiles_d, tiles_h, tiles_w);
-    const int tw_i = bt.tw, th_i = bt.th, td_i = bt.td, n = bt.n;
-    const int id_first = td_i * G::TD + (start ? -3 : 3);
+    const int tw_i = bt.tw, th_i = bt.th, n = bt.n;
+    const int id_first = first_id(bt.td, start);
     const int ih = 2 * th_i * G::TH - 3 + s_hh, iw = 2 * tw_i * G::TW - 3 + 2 * s_pr - 1;   // iw is even
     const bool row_ok = s_act && (unsigned)ih < (unsigned)p.H;
     const long long off = (long long)ih * p.W + iw;
@@ -157,8 +161,9 @@ __global__ __launch_bounds__(512, 1) void stem_fwd_bf16_kernel(StemBfArgs p, int
       const unsigned voff = (row_ok && iw >= 0 && iw + 1 < p.W) ? (unsigned)off * 4u : 0x80000000u;
 #pragma unroll
       for (int u = 0; u < NPL; ++u) {
-        int c, id;                                                       // wave-uniform
-        const bool used = plane_of(u, start, id_first, c, id);
+        int c, j;                                                        // wave-uniform
+        const bool used = plane_of(u, start, c, j);
+        const int id = id_first + j;
         st[u] = make_float2(0.f, 0.f);
         if (used && (unsigned)id < (unsigned)p.D)
           st[u] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(
@@ -167,8 +172,9 @@ __global__ __launch_bounds__(512, 1) void stem_fwd_bf16_kernel(StemBfArgs p, int
     } else {
 #pragma unroll
       for (int u = 0; u < NPL; ++u) {
-        int c, id;
-        const bool used = plane_of(u, start, id_first, c, id);
+        int c, j;
+        const bool used = plane_of(u, start, c, j);
+        const int id = id_first + j;
         st[u] = make_float2(0.f, 0.f);
         if (used && row_ok && (unsigned)id < (unsigned)p.D) {
           const float *src = p.x + ((size_t)n * 3 + c) * vox + (size_t)id * p.H * p.W + off;
@@ -181,53 +187,50 @@ __global__ __launch_bounds__(512, 1) void stem_fwd_bf16_kernel(StemBfArgs p, int
   auto commit = [&](int td_i, bool start) {
     if (!s_act) return;
     bf16_t *dst = slab + s_hh * G::HW;                                // slab columns 2*pr - 1, 2*pr
-    const int s0 = (td_i * G::TD + (start ? -3 : 3) + 10) % 10;       // wave-uniform ring slot of the first plane
+    const int s0 = (first_id(td_i, start) + G::HD) % G::HD;           // wave-uniform ring slot of the round's first plane
 #pragma unroll
     for (int u = 0; u < NPL; ++u) {
-      int c, id;
-      if (!plane_of(u, start, 0, c, id)) continue;
-      int slot = s0 + id;
-      slot -= slot >= 10 ? 10 : 0;
+      int c, j;
+      if (!plane_of(u, start, c, j)) continue;
+      int slot = s0 + j;
+      slot -= slot >= G::HD ? G::HD : 0;
       bf16_t *d = dst + (c * G::HD + slot) * (G::HH * G::HW);
       if (s_pr >= 1) d[2 * s_pr - 1] = f2bf(st[u].x);
       d[2 * s_pr] = f2bf(st[u].y);
     }
   };
 
-  // this wave's four consecutive (th) rows of 16 outputs at depth td; lane (r, q): output column r, channel slot q.  Slot 3 reads
-  // channel 0's columns: its weights are zero (stem_pack_bf16_kernel)
-  const int w_td = wave >> 1, w_th0 = (wave & 1) * 4;
+  // this wave's outputs: two depths (2 * (wave >> 1), + 1) x four consecutive rows ((wave & 1) * 4 ..) of 16 columns; lane (r, q):
+  // output column r, channel slot q.  Slot 3 reads channel 0's columns: its weights are zero (stem_pack_bf16_kernel)
+  const int w_td0 = (wave >> 1) * 2, w_th0 = (wave & 1) * 4;
   const int abase = (((q < 3 ? q : 0) * G::HD * G::HH + 2 * w_th0) * G::HW + 2 * r) * 2;
   const unsigned char *wlane = wl + (q * 16 + r) * 16;
   float sh4[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) sh4[e] = p.shift ? p.shift[4 * q + e] : 0.f;
 
-  int t_begin, t_end;
-  bf_tile_run((int)blockIdx.x, (int)gridDim.x, ntiles, t_begin, t_end);
-  auto starts = [&](int tile) { return tile == t_begin || tile % tiles_d == 0; };      // depth is the fastest tile index
-  if (t_begin < t_end) fetch(t_begin, true);
-  for (int tile = t_begin; tile < t_end; ++tile) {
+  // Multiply one tile.  The weights are the A operand: the accumulator holds 4 consecutive output channels of one position per
+  // lane (8-byte stores, 512 contiguous bytes per store instruction).  A wave's eight accumulators are 2 output depths x 4 output
+  // rows: the fragment of input plane pl and input row j feeds depth t with tap kd = pl - t and row i with tap kh = j - 2i -- ONE
+  // fragment read per (plane, row) serves up to 8 MFMAs (104 reads for 392 MFMAs; a 4-deep tile with one depth per wave read 91
+  // for 196 and its MFMA phase ran at the LDS array's pace), against the seven kh weight fragments of two kd taps in registers.
+  f32x4_t acc[2][4];
+  auto mma = [&](int tile) {
     const BfTile bt = bf_tile_of(tile, tiles_d, tiles_h, tiles_w);
-    __syncthreads();                       // the previous tile's fragments have been read
-    commit(bt.td, starts(tile));
-    __syncthreads();
-    if (tile + 1 < t_end) fetch(tile + 1, starts(tile + 1));      // in flight during the MFMA phase
-    f32x4_t acc[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    // The wave's four accumulators are four consecutive output rows: input row j of the 13 they reach feeds row i with tap
-    // kh = j - 2 i.  One fragment read per (kd, input row) serves up to 4 MFMAs (28 per kd from 13 reads instead of 28), the seven
-    // kh weight fragments of a kd wait in registers.  The weights are the A operand: the accumulator then holds 4 consecutive
-    // output channels of one position per lane -- 8-byte stores, 512 contiguous bytes per store instruction.
-    const int ring0 = (bt.td * G::TD + 7) % 10;                       // slot of input depth 4 td - 3
-#pragma unroll 1
-    for (int kd = 0; kd < 7; ++kd) {
-      bf16x8 bw[7];
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int kh = 0; kh < 7; ++kh) bw[kh] = *reinterpret_cast<const bf16x8 *>(wlane + (kd * 7 + kh) * 1024);
-      int slot = ring0 + w_td + kd;                                   // wave-uniform
-      slot -= slot >= 10 ? 10 : 0;
+      for (int i = 0; i < 4; ++i) acc[t][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int ring0 = (bt.td * G::TD - 3 + G::HD) % G::HD;            // slot of input depth 8 td - 3
+    bf16x8 bw[2][7];                                                  // kh fragments of kd = pl (bw[pl & 1]) and kd = pl - 1
+#pragma unroll
+    for (int pl = 0; pl < 8; ++pl) {
+      if (pl < 7) {
+#pragma unroll
+        for (int kh = 0; kh < 7; ++kh) bw[pl & 1][kh] = *reinterpret_cast<const bf16x8 *>(wlane + (pl * 7 + kh) * 1024);
+      }
+      int slot = ring0 + w_td0 + pl;                                  // wave-uniform
+      slot -= slot >= G::HD ? G::HD : 0;
       const unsigned char *arow = slab_b + abase + slot * (G::HH * G::HW * 2);
 #pragma unroll
       for (int j = 0; j < 13; ++j) {
@@ -235,25 +238,72 @@ __global__ __launch_bounds__(512, 1) void stem_fwd_bf16_kernel(StemBfArgs p, int
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int kh = j - 2 * i;
-          if (kh >= 0 && kh < 7) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[kh], a, acc[i], 0, 0, 0);
+          if (kh >= 0 && kh < 7) {
+            if (pl < 7) acc[0][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[pl & 1][kh], a, acc[0][i], 0, 0, 0);
+            if (pl >= 1) acc[1][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[(pl - 1) & 1][kh], a, acc[1][i], 0, 0, 0);
+          }
         }
       }
     }
-    // ---- epilogue: C/D layout of 16x16: column (output column) = lane & 15, row (cout) = 4 * (lane >> 4) + reg
+  };
+  // ---- epilogue: C/D layout of 16x16: column (output column) = lane & 15, row (cout) = 4 * (lane >> 4) + reg.  Called BEHIND the
+  // commit of the next round, so that the stores drain under the next MFMA phase and not in front of a barrier.
+  auto epilogue = [&](int tile) {
+    const BfTile bt = bf_tile_of(tile, tiles_d, tiles_h, tiles_w);
     const int d0 = bt.td * G::TD, h0 = bt.th * G::TH, w0 = bt.tw * G::TW;
-    const int od = d0 + w_td, ow = w0 + r;
+    // stores through a buffer descriptor: the output row (n, od, oh) is a SCALAR byte offset, the lane's (column, channel quad) a
+    // constant one (a column past the row's end gets an offset past the end of the buffer: the store is dropped) -- no 64-bit
+    // index arithmetic per store
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, 0x7fffffff, 0x00020000);
+    const int ow = w0 + r;
+    const unsigned voff = ow < p.Wo ? (unsigned)(ow * 16 + 4 * q) * 2u : 0x80000000u;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int oh = h0 + w_th0 + i;
-      if (od >= p.D || oh >= p.Ho || ow >= p.Wo) continue;
-      float v[4];
+    for (int t = 0; t < 2; ++t) {
+      const int od = d0 + w_td0 + t;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        v[e] = acc[i][e] + sh4[e];
-        if (p.relu) v[e] = fmaxf(v[e], 0.f);
+      for (int i = 0; i < 4; ++i) {
+        const int oh = h0 + w_th0 + i;
+        if (od >= p.D || oh >= p.Ho) continue;                 // (wave-uniform)
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = acc[t][i][e] + sh4[e];
+          if (p.relu) v[e] = fmaxf(v[e], 0.f);
+        }
+        typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_st;
+        const u32x2_st o = {(uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16)};
+        __builtin_amdgcn_raw_buffer_store_b64(o, yr, (int)voff, (int)((((bt.n * p.D + od) * p.Ho + oh) * p.Wo) * 32), 0);
       }
-      *reinterpret_cast<uint2 *>(p.y + ((((size_t)bt.n * p.D + od) * p.Ho + oh) * p.Wo + ow) * 16 + 4 * q) =
-          make_uint2((uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16), (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16));
+    }
+  };
+
+  int t_begin, t_end;
+  bf_tile_run((int)blockIdx.x, (int)gridDim.x, ntiles, t_begin, t_end);
+  auto starts = [&](int tile) { return tile == t_begin || tile % tiles_d == 0; };      // depth is the fastest tile index
+  // pipeline: [fetch round k + 1 into registers | multiply the tile round k completed] -> barrier -> [commit round k + 1] -> barrier
+  bool have_cur = false, have_nxt = t_begin < t_end;
+  int cur = t_begin, nxt = t_begin;
+  bool nxt_start = true;                                              // the next round is the 6-plane round in front of a column's first tile
+  while (true) {
+    if (have_nxt) fetch(nxt, nxt_start);                              // in flight during the MFMA phase
+    if (have_cur) mma(cur);
+    if (!have_nxt) {
+      if (have_cur) epilogue(cur);
+      break;
+    }
+    __syncthreads();                                                  // the previous tile's fragments have been read
+    commit(bf_tile_of(nxt, tiles_d, tiles_h, tiles_w).td, nxt_start);
+    __syncthreads();
+    if (have_cur) epilogue(cur);
+    if (nxt_start) {
+      have_cur = false;
+      nxt_start = false;                                              // same tile: its 8 new planes
+    } else {
+      have_cur = true;
+      cur = nxt;
+      nxt = nxt + 1;
+      have_nxt = nxt < t_end;
+      nxt_start = have_nxt && starts(nxt);
     }
   }
 }
@@ -715,8 +765,9 @@ extern "C" int mr3d_stem_conv_forward_bf16(const float *x_ncdhw, const void *w16
   a.x = x_ncdhw; a.w16 = (const bf16_t *)w16; a.shift = shift; a.y = (bf16_t *)y_bf16;
   a.N = n; a.D = d; a.H = h; a.W = w; a.Ho = (h - 1) / 2 + 1; a.Wo = (w - 1) / 2 + 1; a.relu = relu;
   using G = FwdGeo;
-  // buffer-load offsets of the slab fetch: one image (3 channels, fp32) below 2^31 bytes
+  // buffer-load offsets of the slab fetch: one image (3 channels, fp32) below 2^31 bytes; buffer-store offsets: the output too
   if ((unsigned long long)d * h * w * 12ull > 0x7fffffffull) return MR3D_ERR_UNSUPPORTED;
+  if ((unsigned long long)n * d * a.Ho * a.Wo * 32ull > 0x7fffffffull) return MR3D_ERR_UNSUPPORTED;
   static bool attr = false;
   static int cus = 0;
   if (!attr) {

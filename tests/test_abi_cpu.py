@@ -149,6 +149,7 @@ def test_stem_size_guard():
     assert L.mr3d_stem_conv_forward(p, p, p, p, 9, 1000, 512, 512, 1, None) == 4         # volume fits, output 9 * 1000 * 256 * 256 * 64 B >= 2^31
     # the bf16 stem kernels fetch their slabs with 32-bit buffer offsets: one image (3 channels, fp32) below 2^31 bytes
     assert L.mr3d_stem_conv_forward_bf16(p, p, p, p, 1, 684, 512, 512, 1, None) == 4     # 684 * 2^18 * 12 B > 2^31
+    assert L.mr3d_stem_conv_forward_bf16(p, p, p, p, 40, 100, 512, 512, 1, None) == 4    # images fit, the bf16 output (40 x 100 x 2^16 x 32 B) does not
     assert L.mr3d_stem_conv_wgrad_bf16(p, p, p, p, 1, 684, 512, 512, None) == 4
     assert L.mr3d_stem_conv_wgrad_bf16_pooled(p, p, p, p, p, p, 1, 684, 512, 512, None) == 4
 
