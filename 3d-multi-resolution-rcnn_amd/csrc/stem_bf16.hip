@@ -247,7 +247,8 @@ __global__ __launch_bounds__(512, 1) void stem_fwd_bf16_kernel(StemBfArgs p, int
     }
   };
   // ---- epilogue: C/D layout of 16x16: column (output column) = lane & 15, row (cout) = 4 * (lane >> 4) + reg.  Called BEHIND the
-  // commit of the next round, so that the stores drain under the next MFMA phase and not in front of a barrier.
+  // commit of the next round, so that the stores drain under the next MFMA phase and not in front of a barrier.  (Streaming
+  // stores -- cache policy slc -- make this launch 40 us shorter alone and the max-pool behind it as much longer: 4.471 / 4.476 ms.)
   auto epilogue = [&](int tile) {
     const BfTile bt = bf_tile_of(tile, tiles_d, tiles_h, tiles_w);
     const int d0 = bt.td * G::TD, h0 = bt.th * G::TH, w0 = bt.tw * G::TW;
