@@ -1,3 +1,4 @@
+"""RoI extractor forward time by roi size class (development aid: which kernel a class of rois lands in shows as its time)."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -19,14 +20,8 @@ def timed(fn, iters=30):
     for _ in range(iters): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) * 1e3 / iters
-L = _hip.lib()
 for tag, n, osz, od in (('bbox', 512, 7, 3), ('mask', 128, 14, 10)):
     ext = SingleRoIExtractor(dict(type='RoIAlign3D', out_size=osz, out_size_depth=od, sample_num=2), 64, [4, 8, 16, 32], [2, 4, 8, 16])
     for cls, (lo, hi, zlo, zhi) in (('tiny 8-16px', (8, 16, 4, 8)), ('small 8-32px', (8, 32, 4, 16)), ('flat 64-128 x 2-4', (64, 128, 2, 4)), ('big 48-128px', (48, 128, 24, 40)), ('mixed', (4, 128, 2, 40))):
         r = rois(n, lo, hi, zlo, zhi)
-        out = []
-        for knob in (9, 1, 0):
-            L.mr3d_tuning_set(0, knob)
-            out.append(timed(lambda: ext(feats, r)))
-        L.mr3d_tuning_set(0, 0)
-        print(f'{tag:5s} {cls:20s} old {out[0]:7.1f} us   wave(knob 1) {out[1]:7.1f}   wave {out[2]:7.1f} us', flush=True)
+        print(f'{tag:5s} {cls:20s} {timed(lambda: ext(feats, r)):7.1f} us', flush=True)
