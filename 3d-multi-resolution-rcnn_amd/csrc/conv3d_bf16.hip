@@ -48,10 +48,14 @@ __device__ __forceinline__ int nearest_src(int dst, int in, int out) {
 // PAR_: the parity-decomposed data gradient of a kernel-3 / stride-2 / pad-1 convolution (mr3d_conv3d_dgrad_s2k3_bf16): K_ = 2 is
 // then the per-axis MAXIMUM of taps an output class meets; blockIdx.z is the class, its 1..8 taps are walked, and the outputs go to
 // positions 2 o + (class bit) of dx.
-template <int K_, int S_, int TD_, int TH_, int TW_, int CC_, int NT_, bool PAR_ = false>
+// PARF_: the FORWARD kernel-3 / stride-2 / pad-1 convolution from the 8 parity classes of its INPUT (x[2j + a] per axis): class a = 0
+// meets tap 1 at j = o, class a = 1 taps 0 and 2 at j = o - 1, o -- every class is a dense 1..8-tap convolution on a halo of
+// (T + 1)^3 positions read with step 2, walked one class after the other into the same accumulators.  (The direct form staged
+// (2T + 1)^3 positions of 16 channels at a time: 2 x 8 x 8 outputs were all that fitted.)
+template <int K_, int S_, int TD_, int TH_, int TW_, int CC_, int NT_, bool PAR_ = false, bool PARF_ = false>
 struct BfCfg {
   static constexpr int K = K_, S = S_, TD = TD_, TH = TH_, TW = TW_, CC = CC_, NT = NT_;
-  static constexpr bool PAR = PAR_;
+  static constexpr bool PAR = PAR_, PARF = PARF_;
   static constexpr bool PW1 = (K_ == 1);
   static constexpr int LS = PW1 ? 1 : S_;          // LDS step per output position
   static constexpr int GS = PW1 ? S_ : 1;          // global step per halo position (a strided 1x1x1 reads every S-th voxel)
@@ -96,8 +100,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_bf16_kernel(BfArgs p, int 
   const int cls = C::PAR ? 7 - (int)blockIdx.z : 0;
   const int ad = (cls >> 2) & 1, ah = (cls >> 1) & 1, aw = cls & 1;
   const int tap_shift = ad + ah + aw;                       // PAR: the class walks 1 << tap_shift taps
-  auto tap_of = [&](int t, int &kd, int &kh, int &kw) {     // -> index into the weight array
-    if constexpr (C::PAR) {
+  auto tap_of = [&](int c_, int t, int &kd, int &kh, int &kw) {     // (class, class-local tap) -> index into the weight array
+    if constexpr (C::PAR || C::PARF) {
+      const int ad = (c_ >> 2) & 1, ah = (c_ >> 1) & 1, aw = c_ & 1;
       kw = aw ? (t & 1) : 0;
       kh = ah ? ((t >> aw) & 1) : 0;
       kd = ad ? ((t >> (aw + ah)) & 1) : 0;
@@ -145,14 +150,17 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_bf16_kernel(BfArgs p, int 
 
   // ---- halo staging through registers (the next chunk is fetched before the MFMA loop of the current one)
   uint4 stage[C::NIT];
-  auto fetch = [&](int c0) {
+  auto fetch = [&](int c_, int c0) {
+    // PARF: the halo of input parity class c_ -- positions 2 (o0 + h) - a per axis
+    const int gs = C::PARF ? 2 : C::GS;
+    const int fd0 = C::PARF ? 2 * od0 - ((c_ >> 2) & 1) : id0, fh0 = C::PARF ? 2 * oh0 - ((c_ >> 1) & 1) : ih0, fw0 = C::PARF ? 2 * ow0 - (c_ & 1) : iw0;
 #pragma unroll
     for (int j = 0; j < C::NIT; ++j) {
       const int it = tid + j * kThreads;
       constexpr int Q = C::CC / 8;
       const int pos = it / Q, q = it - pos * Q;
       const int hw = pos % C::HW, hh = (pos / C::HW) % C::HH, hd = pos / (C::HW * C::HH);
-      const int id = id0 + hd * C::GS, ih = ih0 + hh * C::GS, iw = iw0 + hw * C::GS;
+      const int id = fd0 + hd * gs, ih = fh0 + hh * gs, iw = fw0 + hw * gs;
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
       if (it < C::PIECES && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
         v = *reinterpret_cast<const uint4 *>(p.x + ((((size_t)n * p.D + id) * p.H + ih) * p.W + iw) * p.Cin + c0 + q * 8);
@@ -172,18 +180,18 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_bf16_kernel(BfArgs p, int 
     }
   };
   // weight fragments of one tap (all k-steps of the chunk, all N tiles)
-  auto load_b = [&](bf16x8 (&dst)[C::KK][C::NT], int c0, int tap) {
+  auto load_b = [&](bf16x8 (&dst)[C::KK][C::NT], int c_, int c0, int tap) {
     int kd_, kh_, kw_;
-    const int wtap = tap_of(tap, kd_, kh_, kw_);
+    const int wtap = tap_of(c_, tap, kd_, kh_, kw_);
     const bf16x8 *wt = wlane + ((size_t)wtap * cin8 + (c0 >> 3)) * p.CoutPad;
 #pragma unroll
     for (int kk = 0; kk < C::KK; ++kk)
 #pragma unroll
       for (int nt = 0; nt < C::NT; ++nt) dst[kk][nt] = wt[(size_t)kk * 2 * p.CoutPad + nt * 32];
   };
-  auto mma_tap = [&](const bf16x8 (&bw)[C::KK][C::NT], int tap) {
+  auto mma_tap = [&](const bf16x8 (&bw)[C::KK][C::NT], int c_, int tap) {
     int kd, kh, kw;
-    (void)tap_of(tap, kd, kh, kw);
+    (void)tap_of(c_, tap, kd, kh, kw);
     const int tapoff = ((kd * C::HH + kh) * C::HWP + kw) * C::ROWB;
 #pragma unroll
     for (int kk = 0; kk < C::KK; ++kk) {
@@ -205,39 +213,57 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_bf16_kernel(BfArgs p, int 
   bf16x8 bq[RD][C::KK][C::NT];
   const int nchunks = p.Cin / C::CC;
   const int ntaps = C::PAR ? (1 << tap_shift) : C::TAPS;
-  const int total = dead ? 0 : nchunks * ntaps;            // flattened (chunk, tap) walk; the B registers rotate across it
-  auto split = [&](int cur, int &chunk, int &tap) {
-    if constexpr (C::PAR) { chunk = cur >> tap_shift; tap = cur & (ntaps - 1); }
-    else { chunk = cur / C::TAPS; tap = cur - chunk * C::TAPS; }
+  const int total = dead ? 0 : (C::PARF ? nchunks * 27 : nchunks * ntaps);      // flattened (class,) (chunk, tap) walk; the B registers rotate across it
+  auto split = [&](int cur, int &c_, int &chunk, int &tap) {          // (wave-uniform)
+    if constexpr (C::PARF) {
+      int base = 0;
+      c_ = 0; chunk = 0; tap = 0;
+      for (int k = 7; k >= 0; --k) {                                    // the 8-tap class first
+        const int sh = __builtin_popcount((unsigned)k), span = nchunks << sh;
+        if (cur < base + span) { c_ = k; chunk = (cur - base) >> sh; tap = (cur - base) & ((1 << sh) - 1); break; }
+        base += span;
+      }
+    } else if constexpr (C::PAR) { c_ = cls; chunk = cur >> tap_shift; tap = cur & (ntaps - 1); }
+    else { c_ = 0; chunk = cur / C::TAPS; tap = cur - chunk * C::TAPS; }
   };
-  if (!dead) fetch(0);
+  auto taps_of = [&](int c_) { return (C::PAR || C::PARF) ? (1 << __builtin_popcount((unsigned)c_)) : C::TAPS; };
+  if (!dead) {
+    int c_, ch_, t_;
+    split(0, c_, ch_, t_);
+    fetch(c_, 0);
+  }
 #pragma unroll
   for (int u = 0; u < RD - 1; ++u)
     if (u < total) {
-      int c_, t_;
-      split(u, c_, t_);
-      load_b(bq[u], c_ * C::CC, t_);
+      int k_, c_, t_;
+      split(u, k_, c_, t_);
+      load_b(bq[u], k_, c_ * C::CC, t_);
     }
   for (int it = 0; it < total; it += RD) {
 #pragma unroll
     for (int u = 0; u < RD; ++u) {
       const int cur = it + u;
       if (cur >= total) break;
-      int chunk, tap;
-      split(cur, chunk, tap);
+      int kcls, chunk, tap;
+      split(cur, kcls, chunk, tap);
       if (tap == 0) {
         __syncthreads();                        // every wave is done reading the previous chunk's halo
         commit();
         __syncthreads();
-        if (chunk + 1 < nchunks) fetch((chunk + 1) * C::CC);
+        const int nstage = cur + taps_of(kcls);  // first step of the next (class, chunk) halo
+        if (nstage < total) {
+          int k2, c2, t2;
+          split(nstage, k2, c2, t2);
+          fetch(k2, c2 * C::CC);
+        }
       }
       const int nxt = cur + RD - 1;
       if (nxt < total) {
-        int nchunk, ntap;
-        split(nxt, nchunk, ntap);
-        load_b(bq[(u + RD - 1) % RD], nchunk * C::CC, ntap);
+        int k3, nchunk, ntap;
+        split(nxt, k3, nchunk, ntap);
+        load_b(bq[(u + RD - 1) % RD], k3, nchunk * C::CC, ntap);
       }
-      mma_tap(bq[u], tap);
+      mma_tap(bq[u], kcls, tap);
     }
   }
 
@@ -560,6 +586,20 @@ extern "C" int mr3d_conv3d_forward_bf16(const mr3d_conv3d_desc *d, mr3d_stream_t
   if (k == 1 && s == 2) return dispatch_cc<1, 2>(a, stream);
   if (k == 3 && s == 1 && c16_ok(a)) return launch_c16(a, stream);
   if (k == 3 && s == 1) return dispatch_cc<3, 1>(a, stream);
+  if (k == 3 && s == 2 && a.pd == 1 && a.ph == 1 && a.pw == 1 && (long long)a.N * a.Do * a.Ho * a.Wo >= 8192) {
+    // from the 8 parity classes of the input (BfCfg PARF): 32-channel chunks and 4 x 8 x 8 tiles fit now.  512 volume: layer2.0 conv2
+    // 67 -> 31 us, layer3.0 40 -> 34; on layer4.0's 1280 outputs the 32 (class, chunk) stagings of a workgroup are a longer chain than
+    // the direct form's 8 (62 against 37 us): small maps keep it
+    const bool wide = a.CoutPad % 64 == 0;
+    const long long wg488 = (long long)a.N * ((a.Do + 3) / 4) * ((a.Ho + 7) / 8) * ((a.Wo + 7) / 8) * (a.CoutPad / (wide ? 64 : 32));
+    const bool big = wg488 >= 512;
+    if (a.Cin % 32 == 0) {
+      if (wide) return big ? launch_bf<BfCfg<2, 1, 4, 8, 8, 32, 2, false, true>>(a, stream) : launch_bf<BfCfg<2, 1, 2, 8, 8, 32, 2, false, true>>(a, stream);
+      return big ? launch_bf<BfCfg<2, 1, 4, 8, 8, 32, 1, false, true>>(a, stream) : launch_bf<BfCfg<2, 1, 2, 8, 8, 32, 1, false, true>>(a, stream);
+    }
+    if (wide) return big ? launch_bf<BfCfg<2, 1, 4, 8, 8, 16, 2, false, true>>(a, stream) : launch_bf<BfCfg<2, 1, 2, 8, 8, 16, 2, false, true>>(a, stream);
+    return big ? launch_bf<BfCfg<2, 1, 4, 8, 8, 16, 1, false, true>>(a, stream) : launch_bf<BfCfg<2, 1, 2, 8, 8, 16, 1, false, true>>(a, stream);
+  }
   if (k == 3 && s == 2) return dispatch_cc<3, 2>(a, stream);
   return MR3D_ERR_UNSUPPORTED;
 }

@@ -59,6 +59,8 @@ CASES = [
     (128, 128, 3, 1, 1, (3, 6, 8)),
     (32, 32, 3, 2, 1, (8, 16, 14)),
     (64, 64, 3, 2, 1, (7, 11, 9)),
+    (32, 32, 3, 2, 1, (16, 40, 66)),          # >= 8192 outputs: the forward from the 8 parity classes of the input (PARF), even extents
+    (64, 64, 3, 2, 1, (17, 41, 47)),          # ... odd extents, 64-wide Cout tile
     (64, 8, 1, 1, 0, (4, 8, 8)),              # Cout % 8 only (RPN regression head 64 -> 6 padded to 8)
 ]
 
