@@ -452,6 +452,115 @@ __global__ __launch_bounds__(C16::NT, 3) void conv3d_bf16_c16_kernel(BfArgs p, i
   }
 }
 
+// ------------------------------------------------------------------------------------------------ 3x3x3 / stride 1, 32 -> 32 channels
+// conv2 of the layer2 bottlenecks and its data gradient (eight launches per step): the same construction as the 16-channel kernel
+// with one tap per k-step (k = 32 channels).  The two 16-wide output-channel tiles belong to different waves, so a wave's 27 weight
+// fragments still fit its registers (108); a wave owns one depth of the 2 x 8 x 16 tile and one channel tile: 216 MFMAs on 216
+// ds_read_b128.  Halo rows of 80 bytes (64 + 16: three of a read's sixteen 16-byte slots collide, against every fourth with 64).
+struct C32 {
+  static constexpr int TD = 2, TH = 8, TW = 16, HD = TD + 2, HH = TH + 2, HW = TW + 2, HP = HD * HH * HW;
+  static constexpr int ROWB = 80, LDS_BYTES = HP * ROWB, NT = 256, STEPS = 27;
+  static constexpr int PIECES = HP * 4, NIT = (PIECES + NT - 1) / NT;
+};
+
+__global__ __launch_bounds__(C32::NT, 2) void conv3d_bf16_c32_kernel(BfArgs p, int tiles_d, int tiles_h, int tiles_w) {
+  using C = C32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int ct = wave & 1, td = wave >> 1;             // output-channel tile, depth inside the tile
+  int b = blockIdx.x;
+  const int tw_i = b % tiles_w; b /= tiles_w;
+  const int th_i = b % tiles_h; b /= tiles_h;
+  const int td_i = b % tiles_d; b /= tiles_d;
+  const int n = b;
+  const int od0 = td_i * C::TD, oh0 = th_i * C::TH, ow0 = tw_i * C::TW;
+
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(p.x), 0, 0x7fffffff, 0x00020000);
+  uint4 stage[C::NIT];
+#pragma unroll
+  for (int j = 0; j < C::NIT; ++j) {
+    const int it = tid + j * C::NT;
+    const int pos = it >> 2, pc = it & 3;
+    const int hw = pos % C::HW, hh = (pos / C::HW) % C::HH, hd = pos / (C::HW * C::HH);
+    const int id = od0 - 1 + hd, ih = oh0 - 1 + hh, iw = ow0 - 1 + hw;
+    const bool ok = it < C::PIECES && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+    const unsigned off = ok ? (unsigned)((((n * p.D + id) * p.H + ih) * p.W + iw) * 64 + pc * 16) : 0x80000000u;
+    stage[j] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)off, 0, 0));
+  }
+  // this lane's weight fragments: tap s, channels 8q .. 8q+7, output channel 16 ct + r
+  bf16x8 wr[C::STEPS];
+#pragma unroll
+  for (int s = 0; s < C::STEPS; ++s) wr[s] = reinterpret_cast<const bf16x8 *>(p.w)[(size_t)(s * 4 + q) * p.CoutPad + 16 * ct + r];
+#pragma unroll
+  for (int j = 0; j < C::NIT; ++j) {
+    const int it = tid + j * C::NT;
+    if (it < C::PIECES) *reinterpret_cast<uint4 *>(lds + (it >> 2) * C::ROWB + (it & 3) * 16) = stage[j];
+  }
+  __syncthreads();
+
+  f32x4_c16 acc[C::TH];
+#pragma unroll
+  for (int i = 0; i < C::TH; ++i) acc[i] = f32x4_c16{0.f, 0.f, 0.f, 0.f};
+  const unsigned char *bbase = lds + ((td * C::HH) * C::HW + r) * C::ROWB + q * 16;
+#pragma unroll
+  for (int s = 0; s < C::STEPS; ++s) {
+    const int kw = s % 3, kh = (s / 3) % 3, kd = s / 9;
+    const unsigned char *bs = bbase + ((kd * C::HH + kh) * C::HW + kw) * C::ROWB;
+#pragma unroll
+    for (int i = 0; i < C::TH; ++i) {
+      const bf16x8 f = *reinterpret_cast<const bf16x8 *>(bs + i * (C::HW * C::ROWB));
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[s], f, acc[i], 0, 0, 0);
+    }
+  }
+  // ---- epilogue: column (position) = lane & 15, row (cout inside the wave's tile) = 4 * (lane >> 4) + reg
+  const int od = od0 + td, ow = ow0 + r;
+  if (od >= p.Do || ow >= p.Wo) return;
+  const int co = 16 * ct + 4 * q;
+  float sh[4] = {0.f, 0.f, 0.f, 0.f};
+  if (p.shift) {
+    const float4 s4 = *reinterpret_cast<const float4 *>(p.shift + co);
+    sh[0] = s4.x; sh[1] = s4.y; sh[2] = s4.z; sh[3] = s4.w;
+  }
+#pragma unroll
+  for (int i = 0; i < C::TH; ++i) {
+    const int oh = oh0 + i;
+    if (oh >= p.Ho) continue;
+    const size_t idx = ((((size_t)n * p.Do + od) * p.Ho + oh) * p.Wo + ow) * 32 + co;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] = acc[i][e] + sh[e];
+      if (p.relu) v[e] = fmaxf(v[e], 0.f);
+    }
+    if (p.mask) {
+      const uint2 m = *reinterpret_cast<const uint2 *>(p.mask + idx);
+      if (!(__uint_as_float(m.x << 16) > 0.f)) v[0] = 0.f;
+      if (!(__uint_as_float(m.x & 0xffff0000u) > 0.f)) v[1] = 0.f;
+      if (!(__uint_as_float(m.y << 16) > 0.f)) v[2] = 0.f;
+      if (!(__uint_as_float(m.y & 0xffff0000u) > 0.f)) v[3] = 0.f;
+    }
+    *reinterpret_cast<uint2 *>(p.y + idx) = make_uint2((uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16),
+                                                      (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16));
+  }
+}
+
+bool c32_ok(const BfArgs &a) {
+  return a.Cin == 32 && a.Cout == 32 && a.pd == 1 && a.ph == 1 && a.pw == 1 && !a.add1 && !a.add2 && !a.up && !a.x_live &&
+         a.ysd == 1 && a.ysh == 1 && a.ysw == 1 && a.yD == a.Do && a.yH == a.Ho && a.yW == a.Wo &&
+         (long long)a.N * a.D * a.H * a.W * 64 < 0x7fffffffLL;
+}
+
+int launch_c32(const BfArgs &a, hipStream_t stream) {
+  using C = C32;
+  const int tiles_d = (a.Do + C::TD - 1) / C::TD, tiles_h = (a.Ho + C::TH - 1) / C::TH, tiles_w = (a.Wo + C::TW - 1) / C::TW;
+  const long long tiles = (long long)a.N * tiles_d * tiles_h * tiles_w;
+  if (tiles > 0x7fffffffLL) return MR3D_ERR_UNSUPPORTED;
+  conv3d_bf16_c32_kernel<<<(unsigned)tiles, C::NT, C::LDS_BYTES, stream>>>(a, tiles_d, tiles_h, tiles_w);
+  return mr3d_launch_status();
+}
+
 // the shapes the 16-channel kernel takes: dense output, no residual / upsample inputs, the whole input below 2^31 bytes
 bool c16_ok(const BfArgs &a) {
   return a.Cin == 16 && a.Cout == 16 && a.pd == 1 && a.ph == 1 && a.pw == 1 && !a.add1 && !a.add2 && !a.up && !a.x_live &&
@@ -585,6 +694,7 @@ extern "C" int mr3d_conv3d_forward_bf16(const mr3d_conv3d_desc *d, mr3d_stream_t
   }
   if (k == 1 && s == 2) return dispatch_cc<1, 2>(a, stream);
   if (k == 3 && s == 1 && c16_ok(a)) return launch_c16(a, stream);
+  if (k == 3 && s == 1 && c32_ok(a)) return launch_c32(a, stream);
   if (k == 3 && s == 1) return dispatch_cc<3, 1>(a, stream);
   if (k == 3 && s == 2 && a.pd == 1 && a.ph == 1 && a.pw == 1 && (long long)a.N * a.Do * a.Ho * a.Wo >= 8192) {
     // from the 8 parity classes of the input (BfCfg PARF): 32-channel chunks and 4 x 8 x 8 tiles fit now.  512 volume: layer2.0 conv2

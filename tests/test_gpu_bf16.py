@@ -54,6 +54,7 @@ CASES = [
     (16, 16, 3, 1, 1, (6, 10, 12)),
     (16, 16, 3, 1, 1, (9, 21, 37)),           # several 4x8x16 tiles of the 16-channel kernel, ragged in every axis
     (32, 32, 3, 1, 1, (5, 9, 9)),
+    (32, 32, 3, 1, 1, (7, 21, 37)),           # several 2x8x16 tiles of the 32-channel kernel, ragged in every axis
     (64, 64, 3, 1, 1, (8, 16, 17)),
     (64, 64, 3, 1, 1, (12, 40, 40)),          # enough tiles for the 4x8x8 instance
     (128, 128, 3, 1, 1, (3, 6, 8)),
