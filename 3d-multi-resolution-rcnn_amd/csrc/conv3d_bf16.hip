@@ -561,6 +561,170 @@ int launch_c32(const BfArgs &a, hipStream_t stream) {
   return mr3d_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------ 3x3x3 / stride 1, 64 -> 64 channels
+// conv2 of layer3's bottlenecks, the P2..P5 output convolutions of the FPN, and their data gradients.  The same construction once
+// more with 8 waves: wave (ct, kh) owns the 16-wide output-channel tile ct and the input-channel half kh -- its 27 weight
+// fragments (one per tap: 32 channels = one k-step) fit its registers, its 8 accumulators are the 2 x 4 rows of 16 positions of the
+// 2 x 4 x 16 tile; the two halves of a channel tile meet in LDS before the epilogue.
+// 512 volume, per launch: P2 map 181-202 -> 118-124 us, P3 41 -> 22, layer3 / P4 / P5 18 -> 12; bf16 backbone step 4.42 -> 4.26 ms.
+struct C64 {
+  static constexpr int TD = 2, TH = 4, TW = 16, HD = TD + 2, HH = TH + 2, HW = TW + 2, HP = HD * HH * HW;
+  static constexpr int ROWB = 128, HALO_BYTES = HP * ROWB, NT = 512, STEPS = 27;
+  static constexpr int RED_BYTES = 4 * 64 * 32 * 4;                          // 4 waves x 64 lanes x 8 accumulators x 4 floats
+  static constexpr int LDS_BYTES = 2 * HALO_BYTES + RED_BYTES;
+  static constexpr int NLOADS = HALO_BYTES / 1024;                           // 1 KB (8 positions) per wave-wide direct load
+  static_assert(HALO_BYTES % 1024 == 0, "whole wave loads");
+};
+
+// Persistent workgroups (one per CU: the 27 weight fragments of a lane take 108 registers).  The halo of the NEXT tile travels
+// global -> LDS directly (buffer_load_dwordx4 ... lds, no staging registers) into the second of two buffers while the current
+// tile is multiplied.  Rows are 128 bytes, unpadded (a direct load writes 1 KB contiguously); the 16-byte piece c of halo position
+// p sits in slot c ^ (p & 7) of its row instead -- the swizzle is applied on the GLOBAL side of the load (a lane fetches the piece
+// that belongs in its slot), and it makes the sixteen slots of a ds_read_b128 lane group distinct.
+__global__ __launch_bounds__(C64::NT, 1) void conv3d_bf16_c64_kernel(BfArgs p, int tiles_d, int tiles_h, int tiles_w, int ntiles) {
+  using C = C64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int ct = wave & 3, kh = wave >> 2;             // output-channel tile, input-channel half
+
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(p.x), 0, 0x7fffffff, 0x00020000);
+  auto origin = [&](int tile, int &n, int &od0, int &oh0, int &ow0) {
+    int b = tile;
+    ow0 = (b % tiles_w) * C::TW; b /= tiles_w;
+    oh0 = (b % tiles_h) * C::TH; b /= tiles_h;
+    od0 = (b % tiles_d) * C::TD;
+    n = b / tiles_d;
+  };
+  auto fetch = [&](int tile, int buf) {
+    int n, od0, oh0, ow0;
+    origin(tile, n, od0, oh0, ow0);
+#pragma unroll
+    for (int k = 0; k < (C::NLOADS + 7) / 8; ++k) {
+      const int ld = wave + 8 * k;                     // wave-uniform
+      if (ld < C::NLOADS) {
+        const int pos = ld * 8 + (lane >> 3), slot = lane & 7;
+        const int hw = pos % C::HW, hh = (pos / C::HW) % C::HH, hd = pos / (C::HW * C::HH);
+        const int id = od0 - 1 + hd, ih = oh0 - 1 + hh, iw = ow0 - 1 + hw;
+        const bool ok = (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        const unsigned off = ok ? (unsigned)((((n * p.D + id) * p.H + ih) * p.W + iw) * 128 + ((slot ^ (pos & 7)) << 4)) : 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void *)(lds + buf * C::HALO_BYTES + ld * 1024), 16,
+                                                 (int)off, 0, 0, 0);
+      }
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < ntiles) fetch(tile, 0);
+  // this lane's weight fragments: tap s, channels 32 kh + 8q .. + 7, output channel 16 ct + r
+  bf16x8 wr[C::STEPS];
+#pragma unroll
+  for (int s = 0; s < C::STEPS; ++s) wr[s] = reinterpret_cast<const bf16x8 *>(p.w)[(size_t)(s * 8 + 4 * kh + q) * p.CoutPad + 16 * ct + r];
+  const int co = 16 * ct + 4 * q;
+  float sh[4] = {0.f, 0.f, 0.f, 0.f};
+  if (p.shift) {
+    const float4 s4 = *reinterpret_cast<const float4 *>(p.shift + co);
+    sh[0] = s4.x; sh[1] = s4.y; sh[2] = s4.z; sh[3] = s4.w;
+  }
+  // fragment address of halo position r + c (c: a constant of the tap and the accumulator): row (r + c) * 128, slot pc ^ ((r + c) & 7)
+  // = base[c & 7] + c * 128 with eight per-lane bases
+  const int pc = 4 * kh + q;
+  unsigned base[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) base[m] = (unsigned)(r * C::ROWB + ((pc ^ ((r + m) & 7)) << 4));
+  f32x4_c16 *red = reinterpret_cast<f32x4_c16 *>(lds + 2 * C::HALO_BYTES) + ct * 64 + lane;      // [accumulator][channel tile][lane]
+  __builtin_amdgcn_s_waitcnt(0x0070);                  // vmcnt(0): this wave's part of the first halo is in LDS
+  __syncthreads();
+
+  int buf = 0;
+  for (; tile < ntiles; tile += (int)gridDim.x, buf ^= 1) {
+    const int next = tile + (int)gridDim.x;
+    if (next < ntiles) fetch(next, buf ^ 1);           // in flight during the MFMAs
+    const unsigned char *hb = lds + buf * C::HALO_BYTES;
+    f32x4_c16 acc[C::TD * C::TH];
+#pragma unroll
+    for (int i = 0; i < C::TD * C::TH; ++i) acc[i] = f32x4_c16{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < C::STEPS; ++s) {
+      const int kw = s % 3, khh = (s / 3) % 3, kd = s / 9;
+#pragma unroll
+      for (int i = 0; i < C::TD * C::TH; ++i) {
+        const int td = i / C::TH, th = i % C::TH;
+        const int c = ((td + kd) * C::HH + th + khh) * C::HW + kw;
+        const bf16x8 f = *reinterpret_cast<const bf16x8 *>(hb + base[c & 7] + c * C::ROWB);
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[s], f, acc[i], 0, 0, 0);
+      }
+    }
+    __syncthreads();                                   // this halo has been read (and the previous tile's sums)
+    // the input-channel halves meet: kh = 1 hands its sums over through LDS
+    if (kh == 1) {
+#pragma unroll
+      for (int i = 0; i < C::TD * C::TH; ++i) red[i * 256] = acc[i];
+    }
+    __builtin_amdgcn_s_waitcnt(0x0070);                // vmcnt(0): this wave's part of the next halo has landed
+    __syncthreads();
+    if (kh == 1) continue;
+    // ---- epilogue: column (position) = lane & 15, row (cout inside the wave's tile) = 4 * (lane >> 4) + reg
+    int n, od0, oh0, ow0;
+    origin(tile, n, od0, oh0, ow0);
+    const int ow = ow0 + r;
+    if (ow >= p.Wo) continue;
+#pragma unroll
+    for (int i = 0; i < C::TD * C::TH; ++i) {
+      const int od = od0 + i / C::TH, oh = oh0 + i % C::TH;
+      if (od >= p.Do || oh >= p.Ho) continue;
+      const size_t idx = ((((size_t)n * p.Do + od) * p.Ho + oh) * p.Wo + ow) * 64 + co;
+      const f32x4_c16 o2 = red[i * 256];
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = (acc[i][e] + o2[e]) + sh[e];
+        if (p.relu) v[e] = fmaxf(v[e], 0.f);
+      }
+      if (p.mask) {
+        const uint2 m = *reinterpret_cast<const uint2 *>(p.mask + idx);
+        if (!(__uint_as_float(m.x << 16) > 0.f)) v[0] = 0.f;
+        if (!(__uint_as_float(m.x & 0xffff0000u) > 0.f)) v[1] = 0.f;
+        if (!(__uint_as_float(m.y << 16) > 0.f)) v[2] = 0.f;
+        if (!(__uint_as_float(m.y & 0xffff0000u) > 0.f)) v[3] = 0.f;
+      }
+      *reinterpret_cast<uint2 *>(p.y + idx) = make_uint2((uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16),
+                                                        (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16));
+    }
+  }
+}
+
+bool c64_ok(const BfArgs &a) {
+  return a.Cin == 64 && a.Cout == 64 && a.pd == 1 && a.ph == 1 && a.pw == 1 && !a.add1 && !a.add2 && !a.up && !a.x_live &&
+         a.ysd == 1 && a.ysh == 1 && a.ysw == 1 && a.yD == a.Do && a.yH == a.Ho && a.yW == a.Wo &&
+         (long long)a.N * a.D * a.H * a.W * 128 < 0x7fffffffLL;
+}
+
+int launch_c64(const BfArgs &a, hipStream_t stream) {
+  using C = C64;
+  const int tiles_d = (a.Do + C::TD - 1) / C::TD, tiles_h = (a.Ho + C::TH - 1) / C::TH, tiles_w = (a.Wo + C::TW - 1) / C::TW;
+  const long long tiles = (long long)a.N * tiles_d * tiles_h * tiles_w;
+  if (tiles > 0x7fffffffLL) return MR3D_ERR_UNSUPPORTED;
+  static bool attr_done = false;
+  static int cus = 0;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3d_bf16_c64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            C::LDS_BYTES) != hipSuccess) {
+      (void)hipGetLastError();
+      return MR3D_ERR_LAUNCH;
+    }
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+    attr_done = true;
+  }
+  const int grid = tiles < cus ? (int)tiles : cus;
+  conv3d_bf16_c64_kernel<<<(unsigned)grid, C::NT, C::LDS_BYTES, stream>>>(a, tiles_d, tiles_h, tiles_w, (int)tiles);
+  return mr3d_launch_status();
+}
+
 // the shapes the 16-channel kernel takes: dense output, no residual / upsample inputs, the whole input below 2^31 bytes
 bool c16_ok(const BfArgs &a) {
   return a.Cin == 16 && a.Cout == 16 && a.pd == 1 && a.ph == 1 && a.pw == 1 && !a.add1 && !a.add2 && !a.up && !a.x_live &&
@@ -695,6 +859,7 @@ extern "C" int mr3d_conv3d_forward_bf16(const mr3d_conv3d_desc *d, mr3d_stream_t
   if (k == 1 && s == 2) return dispatch_cc<1, 2>(a, stream);
   if (k == 3 && s == 1 && c16_ok(a)) return launch_c16(a, stream);
   if (k == 3 && s == 1 && c32_ok(a)) return launch_c32(a, stream);
+  if (k == 3 && s == 1 && c64_ok(a)) return launch_c64(a, stream);
   if (k == 3 && s == 1) return dispatch_cc<3, 1>(a, stream);
   if (k == 3 && s == 2 && a.pd == 1 && a.ph == 1 && a.pw == 1 && (long long)a.N * a.Do * a.Ho * a.Wo >= 8192) {
     // from the 8 parity classes of the input (BfCfg PARF): 32-channel chunks and 4 x 8 x 8 tiles fit now.  512 volume: layer2.0 conv2

@@ -56,7 +56,8 @@ CASES = [
     (32, 32, 3, 1, 1, (5, 9, 9)),
     (32, 32, 3, 1, 1, (7, 21, 37)),           # several 2x8x16 tiles of the 32-channel kernel, ragged in every axis
     (64, 64, 3, 1, 1, (8, 16, 17)),
-    (64, 64, 3, 1, 1, (12, 40, 40)),          # enough tiles for the 4x8x8 instance
+    (64, 64, 3, 1, 1, (12, 40, 40)),          # more tiles than persistent workgroups: the 64-channel kernel's second halo buffer
+    (64, 64, 3, 1, 1, (9, 37, 70)),           # ... ragged in every axis
     (128, 128, 3, 1, 1, (3, 6, 8)),
     (32, 32, 3, 2, 1, (8, 16, 14)),
     (64, 64, 3, 2, 1, (7, 11, 9)),
@@ -565,4 +566,11 @@ def test_conv3d_bf16_liveness_bitmap_writes_dead_tiles_from_the_epilogue(dev):
         for kw in (dict(), dict(add1=add, relu=True)):
             y0 = _hip.conv3d_forward_bf16(x, w16, 64, (3,) * 3, (1,) * 3, (1,) * 3, **kw)
             y1 = _hip.conv3d_forward_bf16(x, w16, 64, (3,) * 3, (1,) * 3, (1,) * 3, x_live=live, **kw)
-            assert torch.equal(y0, y1)
+            if kw:
+                assert torch.equal(y0, y1)                       # same kernel with and without the bitmap
+            else:
+                # without an epilogue input the plain call takes the 64-channel kernel (another summation order): equal to the bf16
+                # rounding of y; where the bitmap kernel wrote a dead tile from its epilogue (zeros) the plain result is zero too
+                err = (y0.float() - y1.float()).abs().max().item()
+                assert err <= BF16_EPS * max(y1.float().abs().max().item(), 1e-30), err
+                assert bool(((y1 == 0) <= (y0 == 0)).all()) or x is dense
