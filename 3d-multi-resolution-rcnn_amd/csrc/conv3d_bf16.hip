@@ -33,6 +33,7 @@ struct BfArgs {
   int relu;
   int ysd, ysh, ysw, yD, yH, yW;
   const unsigned char *x_live = nullptr;      // mr3d_voxel_liveness bitmap of x, or null
+  int co_base = 0;                            // conv3d_bf16_c64_kernel: first output channel of this launch
 };
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float((uint32_t)v << 16); }
@@ -567,10 +568,14 @@ int launch_c32(const BfArgs &a, hipStream_t stream) {
 // fragments (one per tap: 32 channels = one k-step) fit its registers, its 8 accumulators are the 2 x 4 rows of 16 positions of the
 // 2 x 4 x 16 tile; the two halves of a channel tile meet in LDS before the epilogue.
 // 512 volume, per launch: P2 map 181-202 -> 118-124 us, P3 41 -> 22, layer3 / P4 / P5 18 -> 12; bf16 backbone step 4.42 -> 4.26 ms.
+// NCT = 16-wide output-channel tiles of a launch: 4 (Cout = 64), or 2 for the last 32 of a 96-wide layer (the DeformConv3d neck's
+// offset convolutions, 81 channels padded to 96: one launch of each kind, 469 -> ~190 us on the P2 map)
+template <int NCT_>
 struct C64 {
+  static constexpr int NCT = NCT_;
   static constexpr int TD = 2, TH = 4, TW = 16, HD = TD + 2, HH = TH + 2, HW = TW + 2, HP = HD * HH * HW;
-  static constexpr int ROWB = 128, HALO_BYTES = HP * ROWB, NT = 512, STEPS = 27;
-  static constexpr int RED_BYTES = 4 * 64 * 32 * 4;                          // 4 waves x 64 lanes x 8 accumulators x 4 floats
+  static constexpr int ROWB = 128, HALO_BYTES = HP * ROWB, NT = NCT_ * 2 * 64, STEPS = 27;
+  static constexpr int RED_BYTES = NCT_ * 64 * 32 * 4;                       // NCT waves x 64 lanes x 8 accumulators x 4 floats
   static constexpr int LDS_BYTES = 2 * HALO_BYTES + RED_BYTES;
   static constexpr int NLOADS = HALO_BYTES / 1024;                           // 1 KB (8 positions) per wave-wide direct load
   static_assert(HALO_BYTES % 1024 == 0, "whole wave loads");
@@ -581,13 +586,14 @@ struct C64 {
 // tile is multiplied.  Rows are 128 bytes, unpadded (a direct load writes 1 KB contiguously); the 16-byte piece c of halo position
 // p sits in slot c ^ (p & 7) of its row instead -- the swizzle is applied on the GLOBAL side of the load (a lane fetches the piece
 // that belongs in its slot), and it makes the sixteen slots of a ds_read_b128 lane group distinct.
-__global__ __launch_bounds__(C64::NT, 1) void conv3d_bf16_c64_kernel(BfArgs p, int tiles_d, int tiles_h, int tiles_w, int ntiles) {
-  using C = C64;
+template <int NCT>
+__global__ __launch_bounds__(C64<NCT>::NT, 1) void conv3d_bf16_c64_kernel(BfArgs p, int tiles_d, int tiles_h, int tiles_w, int ntiles) {
+  using C = C64<NCT>;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
-  const int ct = wave & 3, kh = wave >> 2;             // output-channel tile, input-channel half
+  const int ct = wave % NCT, kh = wave / NCT;           // output-channel tile, input-channel half
 
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(p.x), 0, 0x7fffffff, 0x00020000);
   auto origin = [&](int tile, int &n, int &od0, int &oh0, int &ow0) {
@@ -601,8 +607,8 @@ __global__ __launch_bounds__(C64::NT, 1) void conv3d_bf16_c64_kernel(BfArgs p, i
     int n, od0, oh0, ow0;
     origin(tile, n, od0, oh0, ow0);
 #pragma unroll
-    for (int k = 0; k < (C::NLOADS + 7) / 8; ++k) {
-      const int ld = wave + 8 * k;                     // wave-uniform
+    for (int k = 0; k < (C::NLOADS + 2 * NCT - 1) / (2 * NCT); ++k) {
+      const int ld = wave + 2 * NCT * k;               // wave-uniform
       if (ld < C::NLOADS) {
         const int pos = ld * 8 + (lane >> 3), slot = lane & 7;
         const int hw = pos % C::HW, hh = (pos / C::HW) % C::HH, hd = pos / (C::HW * C::HH);
@@ -619,8 +625,8 @@ __global__ __launch_bounds__(C64::NT, 1) void conv3d_bf16_c64_kernel(BfArgs p, i
   // this lane's weight fragments: tap s, channels 32 kh + 8q .. + 7, output channel 16 ct + r
   bf16x8 wr[C::STEPS];
 #pragma unroll
-  for (int s = 0; s < C::STEPS; ++s) wr[s] = reinterpret_cast<const bf16x8 *>(p.w)[(size_t)(s * 8 + 4 * kh + q) * p.CoutPad + 16 * ct + r];
-  const int co = 16 * ct + 4 * q;
+  for (int s = 0; s < C::STEPS; ++s) wr[s] = reinterpret_cast<const bf16x8 *>(p.w)[(size_t)(s * 8 + 4 * kh + q) * p.CoutPad + p.co_base + 16 * ct + r];
+  const int co = p.co_base + 16 * ct + 4 * q;
   float sh[4] = {0.f, 0.f, 0.f, 0.f};
   if (p.shift) {
     const float4 s4 = *reinterpret_cast<const float4 *>(p.shift + co);
@@ -659,7 +665,7 @@ __global__ __launch_bounds__(C64::NT, 1) void conv3d_bf16_c64_kernel(BfArgs p, i
     // the input-channel halves meet: kh = 1 hands its sums over through LDS
     if (kh == 1) {
 #pragma unroll
-      for (int i = 0; i < C::TD * C::TH; ++i) red[i * 256] = acc[i];
+      for (int i = 0; i < C::TD * C::TH; ++i) red[i * (NCT * 64)] = acc[i];
     }
     __builtin_amdgcn_s_waitcnt(0x0070);                // vmcnt(0): this wave's part of the next halo has landed
     __syncthreads();
@@ -673,8 +679,8 @@ __global__ __launch_bounds__(C64::NT, 1) void conv3d_bf16_c64_kernel(BfArgs p, i
     for (int i = 0; i < C::TD * C::TH; ++i) {
       const int od = od0 + i / C::TH, oh = oh0 + i % C::TH;
       if (od >= p.Do || oh >= p.Ho) continue;
-      const size_t idx = ((((size_t)n * p.Do + od) * p.Ho + oh) * p.Wo + ow) * 64 + co;
-      const f32x4_c16 o2 = red[i * 256];
+      const size_t idx = ((((size_t)n * p.Do + od) * p.Ho + oh) * p.Wo + ow) * p.Cout + co;
+      const f32x4_c16 o2 = red[i * (NCT * 64)];
       float v[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -695,20 +701,21 @@ __global__ __launch_bounds__(C64::NT, 1) void conv3d_bf16_c64_kernel(BfArgs p, i
 }
 
 bool c64_ok(const BfArgs &a) {
-  return a.Cin == 64 && a.Cout == 64 && a.pd == 1 && a.ph == 1 && a.pw == 1 && !a.add1 && !a.add2 && !a.up && !a.x_live &&
+  return a.Cin == 64 && (a.Cout == 64 || a.Cout == 96) && a.pd == 1 && a.ph == 1 && a.pw == 1 && !a.add1 && !a.add2 && !a.up && !a.x_live &&
          a.ysd == 1 && a.ysh == 1 && a.ysw == 1 && a.yD == a.Do && a.yH == a.Ho && a.yW == a.Wo &&
          (long long)a.N * a.D * a.H * a.W * 128 < 0x7fffffffLL;
 }
 
-int launch_c64(const BfArgs &a, hipStream_t stream) {
-  using C = C64;
+template <int NCT>
+int launch_c64_part(BfArgs a, int co_base, hipStream_t stream) {
+  using C = C64<NCT>;
   const int tiles_d = (a.Do + C::TD - 1) / C::TD, tiles_h = (a.Ho + C::TH - 1) / C::TH, tiles_w = (a.Wo + C::TW - 1) / C::TW;
   const long long tiles = (long long)a.N * tiles_d * tiles_h * tiles_w;
   if (tiles > 0x7fffffffLL) return MR3D_ERR_UNSUPPORTED;
   static bool attr_done = false;
   static int cus = 0;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3d_bf16_c64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3d_bf16_c64_kernel<NCT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             C::LDS_BYTES) != hipSuccess) {
       (void)hipGetLastError();
       return MR3D_ERR_LAUNCH;
@@ -720,9 +727,16 @@ int launch_c64(const BfArgs &a, hipStream_t stream) {
       cus = prop.multiProcessorCount;
     attr_done = true;
   }
+  a.co_base = co_base;
   const int grid = tiles < cus ? (int)tiles : cus;
-  conv3d_bf16_c64_kernel<<<(unsigned)grid, C::NT, C::LDS_BYTES, stream>>>(a, tiles_d, tiles_h, tiles_w, (int)tiles);
+  conv3d_bf16_c64_kernel<NCT><<<(unsigned)grid, C::NT, C::LDS_BYTES, stream>>>(a, tiles_d, tiles_h, tiles_w, (int)tiles);
   return mr3d_launch_status();
+}
+
+int launch_c64(const BfArgs &a, hipStream_t stream) {
+  const int st = launch_c64_part<4>(a, 0, stream);
+  if (st != MR3D_OK || a.Cout == 64) return st;
+  return launch_c64_part<2>(a, 64, stream);            // channels 64 .. 95 of a 96-wide layer
 }
 
 // the shapes the 16-channel kernel takes: dense output, no residual / upsample inputs, the whole input below 2^31 bytes

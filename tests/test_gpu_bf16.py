@@ -58,6 +58,7 @@ CASES = [
     (64, 64, 3, 1, 1, (8, 16, 17)),
     (64, 64, 3, 1, 1, (12, 40, 40)),          # more tiles than persistent workgroups: the 64-channel kernel's second halo buffer
     (64, 64, 3, 1, 1, (9, 37, 70)),           # ... ragged in every axis
+    (64, 96, 3, 1, 1, (6, 20, 33)),           # the DCN neck's offset conv (81 -> 96 channels): a 64-wide and a 32-wide launch of the 64-channel kernel
     (128, 128, 3, 1, 1, (3, 6, 8)),
     (32, 32, 3, 2, 1, (8, 16, 14)),
     (64, 64, 3, 2, 1, (7, 11, 9)),
