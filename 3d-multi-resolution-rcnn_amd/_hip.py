@@ -594,6 +594,11 @@ WGRAD_WORKSPACE_BYTES = 64 << 20        # MR3D_WGRAD_WORKSPACE_BYTES
 _wgrad_ws = {}
 
 
+def device_cus(device):
+    """compute units of the device (256 on MI355X): the persistent weight-gradient kernels launch two workgroups per CU"""
+    return int(torch.cuda.get_device_properties(torch.device(device)).multi_processor_count)
+
+
 def wgrad_workspace(device):
     """The partial-sum workspace lent to the weight-gradient kernels of PLAN records (one per device): all of them
     run in order on the plan executor's single side stream, so they can share it.  Direct calls on other streams must
@@ -910,7 +915,12 @@ def op_kernel_key(op):
         return f'conv3d_dgrad_s2k3<cc16,nb{nb}>', 2.0 * n * d * h * w * cin * cout * 27
     if op.kind in (OP_STEM_FWD, OP_STEM_WGRAD):
         n, d, h, w = i[0], i[1], i[2], i[3]
-        flops = 2.0 * n * d * ((h - 1) // 2 + 1) * ((w - 1) // 2 + 1) * 16 * 3 * 343
+        ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        flops = 2.0 * n * d * ho * wo * 16 * 3 * 343
+        if op.kind == OP_STEM_WGRAD and i[7] == 1 and i[25] != DTYPE_BF16 and w % 2 == 0 and not lib().mr3d_tuning_get(3):
+            # the gather over the pooled elements (stem_wgrad_gather.hip): one multiply-add row of 1029 per POOLED element -- the
+            # zeros of the max-pool adjoint (>= 7/8 of dy) are not multiplied; vector-ALU / LDS work, no MFMA
+            return 'stem_wgrad_gather', 2.0 * n * ((d - 1) // 2 + 1) * ((ho - 1) // 2 + 1) * ((wo - 1) // 2 + 1) * 16 * 3 * 343
         return ('stem_fwd' if op.kind == OP_STEM_FWD else 'stem_wgrad'), flops
     names = {OP_MAXPOOL_FWD: 'maxpool_fwd', OP_MAXPOOL_BWD: 'maxpool_bwd', OP_ZERO_STUFF2: 'zero_stuff', OP_UPSAMPLE_ADJ:
              'upsample_adjoint_add', OP_SUBSAMPLE_FWD: 'subsample2_fwd', OP_SUBSAMPLE_BWD: 'subsample2_bwd', OP_VOLUME_PACK:

@@ -85,3 +85,8 @@ int mr3d_pointwise_wgrad_try(const Conv3dWgradArgs &a, hipStream_t stream);
 int mr3d_pointwise_bf16_try(const void *x, const void *w, void *y, const float *shift, const void *add1, const void *add2,
                             const void *up, const void *mask, long long rows, int cin, int cout, int cout_pad, int D, int H, int W,
                             int Du, int Hu, int Wu, int relu, hipStream_t stream);
+
+// the stem's weight gradient from the pooled gradient as a gather on the vector ALUs (stem_wgrad_gather.hip)
+bool mr3d_stem_wgrad_gather_ok(int d, int h, int w);
+int mr3d_stem_wgrad_gather(const float *x, const void *g, const uint32_t *idx, const void *pooled, int bf16, float *dw, float *dbias,
+                           int n, int d, int h, int w, float *workspace, long long workspace_bytes, hipStream_t stream);

@@ -586,6 +586,9 @@ extern "C" int mr3d_stem_conv_wgrad_pooled(const float *x_ncdhw, const float *g_
                                            float *dw_packed, float *dbias, int n, int d, int h, int w, float *workspace,
                                            long long workspace_bytes, mr3d_stream_t stream_) {
   if (!argmax) return MR3D_ERR_INVALID_ARG;
+  if (x_ncdhw && g_pooled && dw_packed && n > 0 && d > 0 && h > 0 && w > 0 && mr3d_stem_wgrad_gather_ok(d, h, w))
+    return mr3d_stem_wgrad_gather(x_ncdhw, g_pooled, argmax, pooled, 0, dw_packed, dbias, n, d, h, w, workspace, workspace_bytes,
+                                  mr3d_stream(stream_));
   return stem_wgrad_impl(x_ncdhw, g_pooled, 0, dw_packed, dbias, n, d, h, w, workspace, workspace_bytes, stream_, argmax, pooled);
 }
 

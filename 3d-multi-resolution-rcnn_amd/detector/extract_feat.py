@@ -697,8 +697,15 @@ class ExtractFeat3D(nn.Module):
         # (mr3d_stem_conv_wgrad_pooled / _bf16_pooled) -- no un-pooled gradient buffer (335 MB fp32 on the 512 volume), one
         # launch less on the main chain
         bwd.append(_hip.make_op(_hip.OP_SYNC, [], [_hip.SYNC_WAIT, 0]))
-        bwd.append(self._op(_hip.OP_STEM_WGRAD, [P.x_in, g, self._s(stem, 'dwraw'), self._s(stem, 'dbias'), None, P.pool_idx,
-                                                 P.pool_out], [N, D, H, W, 0, 0, 1 if P.stem_bf16 else 0, 1]))
+        # its own partial-sum workspace (one block of [343][3][16] per workgroup, 34 MB): the shared one belongs to the side queue,
+        # whose last weight gradients still run beside this kernel; without one the 512 workgroups add 16,464 values each with
+        # same-address atomics (0.3 ms of the gather kernel's 1.1)
+        ws_bytes = 0 if self.bf16 else 2 * _hip.device_cus(self.device) * 343 * 3 * 16 * 4
+        if ws_bytes and getattr(self, '_stem_ws', None) is None:
+            self._stem_ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=self.device)
+        bwd.append(self._op(_hip.OP_STEM_WGRAD, [P.x_in, g, self._s(stem, 'dwraw'), self._s(stem, 'dbias'),
+                                                 self._stem_ws if ws_bytes else None, P.pool_idx, P.pool_out],
+                            [N, D, H, W, *_hip.split64(ws_bytes), 1 if P.stem_bf16 else 0, 1]))
         bwd.append(_hip.make_op(_hip.OP_SYNC, [], [_hip.SYNC_JOIN]))
         bwd.append(_hip.make_op(_hip.OP_FINISH_GRADS, [self._table, self._arena, self._scratch, self._grad_arena], [1, stem.cout]))
         P.fwd_ops, P.bwd_ops = fwd, bwd

@@ -650,6 +650,10 @@ def main():
                        ('winograd F(4,3) along W x F(2,3) along H' if v.winograd == 8 else
                         (f'winograd F({v.winograd},3) along W' if v.winograd else 'direct')) +
                        f' tile {v.tile_d}x{v.tile_h}x{v.tile_w} cout {v.cout_tile}')
+            elif op.kind == _hip.OP_STEM_FWD and op.i[25] == 0:
+                # stem.hip: F(2,3) along depth (10 MFMA groups per depth pair instead of 14), kw padded 7 -> 8: the counters agree
+                # (profiles/r04/insts_per_kernel.md: 6.881e7 MFMAs x 2048 FLOP = 140.9 of 172.6 GFLOP)
+                factor, tag = 10.0 / 14.0 * 8.0 / 7.0, 'winograd F(2,3) along D, kw 7->8'
             issued_flops += fl * factor
             variants[tag] = variants.get(tag, 0) + 1
         issue_factor = issued_flops / groups[dom]['flops'] if groups[dom]['flops'] else 1.0

@@ -54,7 +54,8 @@ enum {
                                      512: ZERO_STUFF2 / UPSAMPLE_ADJ / MAXPOOL_BWD */
   MR3D_TUNE_FORK_SYSTEM_FENCE = 2, /* 1 (set BEFORE the first mr3d_plan_run of the process): the plan executor's fork / join events keep
                                      their system-scope fence (the round-3 behaviour; default 0 = hipEventDisableSystemFence) */
-  MR3D_TUNE_RESERVED_3 = 3,
+  MR3D_TUNE_STEM_WGRAD_DENSE = 3, /* 1: mr3d_stem_conv_wgrad_pooled runs the dense MFMA kernel (the pooled gradient scattered into its dy
+                                     tiles: the round-3/4 form) instead of the gather over the pooled elements (stem_wgrad_gather.hip) */
   MR3D_TUNE_NUM_KEYS = 16
 };
 void mr3d_tuning_set(int key, int value);

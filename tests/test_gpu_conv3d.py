@@ -250,7 +250,7 @@ def test_stem_kernels_forward_and_wgrad(dev, n, dhw):
 
 
 @pytest.mark.parametrize('n,dhw,relu', [(1, (8, 32, 32), True), (2, (10, 40, 36), True), (1, (5, 70, 130), False), (1, (9, 17, 23), True),
-                                        (1, (16, 64, 64), True)])
+                                        (1, (16, 64, 64), True), (1, (7, 38, 90), True), (2, (3, 6, 10), False)])
 def test_stem_wgrad_from_the_pooled_gradient(dev, n, dhw, relu):
     """mr3d_stem_conv_wgrad_pooled: conv -> (ReLU) -> MaxPool3d(3, 2, 1) differentiated by torch in fp64 (resnet3d.py:467-471)
     against the kernel that scatters the pooled gradient to its arg-max positions inside its dy staging; the pooled
@@ -276,13 +276,18 @@ def test_stem_wgrad_from_the_pooled_gradient(dev, n, dhw, relu):
     F.max_pool3d(yk, 3, 2, 1).backward(gp.permute(0, 4, 1, 2, 3).double())
     dy = yk.grad * (yk.detach() > 0) if relu else yk.grad
     F.conv3d(x.double(), w.double(), shift.double(), (1, 2, 2), 3).backward(dy)
-    for ws in (None, _hip.wgrad_workspace(dev)):
-        dw = torch.zeros((343, 4, 16), device=dev); db = torch.zeros(16, device=dev)
-        _hip.stem_conv_wgrad_pooled(x.to(dev), gp.to(dev), am, pooled if relu else None, dw, db, workspace=ws)
+    # both forms: the gather over the pooled elements (default; even W) and the dense MFMA kernel (MR3D_TUNE_STEM_WGRAD_DENSE)
+    for dense, ws in ((0, None), (0, _hip.wgrad_workspace(dev)), (1, None), (1, _hip.wgrad_workspace(dev))):
+        _hip.lib().mr3d_tuning_set(3, dense)
+        try:
+            dw = torch.zeros((343, 4, 16), device=dev); db = torch.zeros(16, device=dev)
+            _hip.stem_conv_wgrad_pooled(x.to(dev), gp.to(dev), am, pooled if relu else None, dw, db, workspace=ws)
+        finally:
+            _hip.lib().mr3d_tuning_set(3, 0)
         refp = _hip.pack_conv_weight(torch.cat([w.grad, torch.zeros(16, 1, 7, 7, 7)], 1))
         errw = (dw.cpu() - refp).abs().max().item() / refp.abs().max().item()
         errb = (db.cpu() - shift.grad).abs().max().item() / shift.grad.abs().max().item()
-        assert errw <= 2e-5 and errb <= 1e-4, f'stem wgrad (pooled) rel err {errw:.3e}, dbias {errb:.3e}'
+        assert errw <= 2e-5 and errb <= 1e-4, f'stem wgrad (pooled, dense={dense}) rel err {errw:.3e}, dbias {errb:.3e}'
     # and against the two-launch form it replaces
     gs = torch.empty_like(y)
     _hip.Plan([_hip.make_op(_hip.OP_MAXPOOL_BWD, [gp.to(dev), am, pooled if relu else None, gs], [nn, d, ho, wo, 16])]).run(dev)

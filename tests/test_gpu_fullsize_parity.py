@@ -227,6 +227,63 @@ def test_full_size_backward_kernels_windows():
     assert dws[:, 3, :].abs().max().item() == 0.0                      # the padding channel stays zero
 
 
+def test_full_size_stem_wgrad_from_pooled_gradient_windows():
+    """mr3d_stem_conv_wgrad_pooled at 1x3x80x512x512 in both of its forms (the gather over the pooled elements,
+    stem_wgrad_gather.hip, and the dense MFMA kernel with the scatter in its dy staging): the pooled gradient is non-zero in
+    five windows of the 40x128x128 pooled map; the fp64 reference routes every element of a window to the arg-max the
+    device's own max-pool recorded and sums conv3d_weight over the crops (resnet3d.py:397-409,471)"""
+    import mr3d_amd  # noqa: F401
+    from mr3d_amd import _hip
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(11)
+    xs = torch.randn(1, 3, 80, 512, 512, generator=g)
+    y = torch.randn(1, 80, 256, 256, 16, generator=g).relu_().to(dev)          # stands for the stem's activation
+    pooled = torch.empty((1, 40, 128, 128, 16), device=dev)
+    am = torch.empty((1, 40, 128, 128, 4), dtype=torch.int32, device=dev)
+    _hip.Plan([_hip.make_op(_hip.OP_MAXPOOL_FWD, [y, pooled, am], [1, 80, 256, 256, 16])]).run(dev)
+    del y
+    taps = am.cpu().numpy().view(np.uint8).reshape(40, 128, 128, 16)               # tap id (kd*9 + kh*3 + kw) per channel
+    pooled_c = pooled.cpu()
+    gp = torch.zeros(1, 40, 128, 128, 16)
+    exp_dw = torch.zeros(16, 3, 7, 7, 7, dtype=torch.float64)
+    exp_db = torch.zeros(16, dtype=torch.float64)
+    for win in _windows((40, 128, 128), (4, 6, 10)):
+        (d0, d1), (h0, h1), (w0, w1) = win
+        if gp[:, d0:d1, h0:h1, w0:w1].abs().sum() > 0:
+            continue
+        blk = torch.randn(d1 - d0, h1 - h0, w1 - w0, 16, generator=g)
+        gp[0, d0:d1, h0:h1, w0:w1] = blk
+        # the stem-output window the pooled window reaches: 2p - 1 .. 2p + 1 per axis, clipped
+        swin = tuple((max(2 * a - 1, 0), min(2 * (b - 1) + 2, n)) for (a, b), n in zip(win, (80, 256, 256)))
+        dyw = torch.zeros(1, 16, *(b - a for a, b in swin), dtype=torch.float64)
+        live = (pooled_c[0, d0:d1, h0:h1, w0:w1] > 0).numpy()
+        t = taps[d0:d1, h0:h1, w0:w1].astype(np.int64)
+        pd, ph, pw, c = np.nonzero(live)
+        tt = t[pd, ph, pw, c]
+        zd = 2 * (pd + d0) - 1 + tt // 9 - swin[0][0]
+        zh = 2 * (ph + h0) - 1 + (tt // 3) % 3 - swin[1][0]
+        zw = 2 * (pw + w0) - 1 + tt % 3 - swin[2][0]
+        dyw.index_put_((torch.zeros(len(c), dtype=torch.long), torch.from_numpy(c), torch.from_numpy(zd), torch.from_numpy(zh),
+                        torch.from_numpy(zw)), blk.double()[pd, ph, pw, c], accumulate=True)
+        crop, _ = _crop_conv(xs, torch.zeros(16, 3, 7, 7, 7), None, (1, 2, 2), (3, 3, 3), swin)
+        exp_dw += torch.nn.grad.conv3d_weight(crop, (16, 3, 7, 7, 7), dyw, (1, 2, 2), 0)
+        exp_db += dyw.sum(dim=(0, 2, 3, 4))
+    xd, gd = xs.to(dev), gp.to(dev)
+    for dense in (0, 1):
+        _hip.lib().mr3d_tuning_set(3, dense)          # MR3D_TUNE_STEM_WGRAD_DENSE
+        try:
+            for ws in (None, _hip.wgrad_workspace(dev)):
+                dws = torch.zeros(343, 4, 16, device=dev)
+                dbs = torch.zeros(16, device=dev)
+                _hip.stem_conv_wgrad_pooled(xd, gd, am, pooled, dws, dbs, workspace=ws)
+                got = dws[:, :3, :].permute(2, 1, 0).reshape(16, 3, 7, 7, 7).cpu().double()
+                _assert_close(got, exp_dw, f'stem wgrad from the pooled gradient (dense={dense}, workspace={ws is not None})')
+                _assert_close(dbs.cpu().double(), exp_db, f'stem dbias from the pooled gradient (dense={dense})')
+                assert dws[:, 3, :].abs().max().item() == 0.0
+        finally:
+            _hip.lib().mr3d_tuning_set(3, 0)
+
+
 def _dgrad_s2_window(dy, w, win, dx_dims):
     """fp64 data gradient of a kernel-3 / stride-2 / pad-1 conv restricted to the dx window `win`: the coarse gradient rows that
     reach the window are cropped and run through conv_transpose3d (dx[i] = sum_o dy[o] w[i - 2 o + 1])"""

@@ -11,6 +11,26 @@ import mr3d_amd  # noqa: E402,F401
 from mr3d_amd import _hip  # noqa: E402
 
 
+_flush = None
+
+
+def timed_cold(fn, reps=6):
+    """as timed(), but a 1 GB buffer is rewritten in front of every call: the operands come from HBM as they do inside a
+    training step, not from the 256 MB Infinity Cache a back-to-back loop leaves them in"""
+    global _flush
+    if _flush is None:
+        _flush = torch.empty(256 << 20, dtype=torch.float32, device='cuda')
+    tot = 0.0
+    for i in range(reps + 1):
+        _flush.add_(1.0)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record()
+        torch.cuda.synchronize()
+        if i:
+            tot += a.elapsed_time(b)
+    return tot / reps * 1e3
+
+
 def timed(fn, reps=10):
     for _ in range(3):
         fn()
@@ -62,11 +82,24 @@ def main():
     t_pool = timed(lambda: bwd.run(dev))
     t_dense = timed(lambda: dense(dw, db))
     dw1 = torch.zeros_like(dw); dense(dw1, None)
+    _hip.lib().mr3d_tuning_set(3, 1)          # MR3D_TUNE_STEM_WGRAD_DENSE: the MFMA kernel with the scatter in its dy staging
     t_fused = timed(lambda: fused(dw, db))
     dw2 = torch.zeros_like(dw); fused(dw2, None)
     err = (dw1 - dw2).abs().max().item() / dw1.abs().max().item()
+    _hip.lib().mr3d_tuning_set(3, 0)          # the gather over the pooled elements (stem_wgrad_gather.hip)
+    ws = _hip.wgrad_workspace(dev)
+    t_gather = timed(lambda: fused(dw, db))
+    dw3 = torch.zeros_like(dw); db3 = torch.zeros_like(db); fused(dw3, db3)
+    err3 = (dw1 - dw3).abs().max().item() / dw1.abs().max().item()
     print(f'{a.dtype} density {a.density}: maxpool_bwd {t_pool:.0f} us + stem_wgrad {t_dense:.0f} us = {t_pool + t_dense:.0f} us; '
-          f'pooled-gradient kernel {t_fused:.0f} us; rel diff {err:.1e}')
+          f'pooled-gradient MFMA kernel {t_fused:.0f} us; rel diff {err:.1e}; gather kernel {t_gather:.0f} us; rel diff {err3:.1e}')
+    if not bf:
+        t_ws = timed(lambda: _hip.stem_conv_wgrad_pooled(x, gp, am, pooled, dw, db, workspace=ws))
+        t_cold = timed_cold(lambda: _hip.stem_conv_wgrad_pooled(x, gp, am, pooled, dw, db, workspace=ws))
+        _hip.lib().mr3d_tuning_set(3, 1)
+        t_cold_mfma = timed_cold(lambda: _hip.stem_conv_wgrad_pooled(x, gp, am, pooled, dw, db, workspace=ws))
+        _hip.lib().mr3d_tuning_set(3, 0)
+        print(f'gather kernel with the partial-sum workspace {t_ws:.0f} us; operands from HBM: gather {t_cold:.0f} us, MFMA kernel {t_cold_mfma:.0f} us')
 
 
 if __name__ == '__main__':
