@@ -10,7 +10,8 @@ import subprocess
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_PKG, 'libmr3d_hip.so')
+# MR3D_LIB: A/B measurements of two builds of the library on one GPU box (tools/ab.sh); the default is the in-tree build
+_SO = os.environ.get('MR3D_LIB') or os.path.join(_PKG, 'libmr3d_hip.so')
 _CSRC = os.path.join(_PKG, 'csrc')
 _lib = None
 

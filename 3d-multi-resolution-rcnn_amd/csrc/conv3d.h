@@ -58,6 +58,7 @@ struct Conv3dWgradArgs {
 int mr3d_reduce_partials(const float *part, int nparts, int G, int R, int NBc, int chunks, int ntiles, int cstep, int nstep,
                          int Cin, int Cout, float *dw, hipStream_t stream);
 
+using f32x2 = __attribute__((ext_vector_type(2))) float;      // a register pair: v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 operands
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 

@@ -52,8 +52,6 @@ struct GatherArgs {
   int queue_slot;
 };
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
 __device__ __forceinline__ f32x2 buffer_load2(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
   return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff_bytes, (int)soff_bytes, 0));
 }

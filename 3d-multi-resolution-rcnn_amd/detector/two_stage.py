@@ -18,7 +18,7 @@ from ..core.bbox import build_assigner, build_sampler, bbox2roi3D
 from ..core.mask import mask_target_single
 from .extract_feat import ExtractFeat3D
 from .heads import RPNHead3D, SharedFCBBoxHead3D, FCNMaskHead3D
-from .roi_extractor import SingleRoIExtractor
+from .roi_extractor import SingleRoIExtractor, deferred_backward, pyramid_gradient
 
 # configs/3d-multi-resolution-rcnn.py:87-127
 DEFAULT_TRAIN_CFG = dict(
@@ -190,7 +190,8 @@ class TwoStageDetector3D(nn.Module):
         backbone forward the device is still running), and only the mask branch and the backbone backward follow it.
         Same gradients: every loss enters the sum with coefficient 1, and a sum's gradient is the sum of the gradients.
         Returns the loss dict with detached values; parameter gradients are accumulated as by backward()."""
-        return self.forward_train(*args, _eager_backward=True, **kwargs)
+        with deferred_backward() as self._deferred_items:
+            return self.forward_train(*args, _eager_backward=True, **kwargs)
 
     def forward_train(self, imgs, img_meta, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_masks=None, proposals=None,
                       draws=None, _eager_backward=False):
@@ -208,6 +209,9 @@ class TwoStageDetector3D(nn.Module):
             # which is ~300 small launches with an idle device between them.  Each branch differentiates down to its own
             # detached copy of the pyramid; the two gradients are added in front of the backbone backward.
             x_graph = x
+            # the roi extractors' backward passes are recorded, not run: they are scattered into the RPN branch's gradient buffers
+            # at the end (roi_extractor.deferred_backward / pyramid_gradient) -- no per-extractor zero-filled level buffers, no adds
+            deferred = self._deferred_items
             x = tuple(t.detach().requires_grad_(True) for t in x_graph)
             x_rpn = tuple(t.detach().requires_grad_(True) for t in x_graph)
             self._mark('backbone+fpn fwd')
@@ -317,7 +321,7 @@ class TwoStageDetector3D(nn.Module):
             if self.with_mask:
                 torch.autograd.backward(losses['loss_mask'].sum())
             main.wait_stream(side)
-            torch.autograd.backward(x_graph, [b.grad if a.grad is None else a.grad + b.grad for a, b in zip(x, x_rpn)])
+            torch.autograd.backward(x_graph, pyramid_gradient(x, x_rpn, deferred))
             losses = {k: ([t.detach() for t in v] if isinstance(v, (list, tuple)) else v.detach()) for k, v in losses.items()}
             self._mark('mask branch + backbone backward')
         self.iteration += 1

@@ -16,7 +16,7 @@ from ..core.bbox import build_assigner, build_sampler, delta2bbox3D, bbox2roi3D
 from ..core.post_processing import multiclass_nms_3d
 from ..core.mask import mask_target_single
 from .heads import RPNHead3D, SharedFCBBoxHead3D, FCNMaskHead3D, rpn_get_bboxes_pair
-from .roi_extractor import SingleRoIExtractor
+from .roi_extractor import SingleRoIExtractor, deferred_backward, pyramid_gradient
 from .two_stage import TwoStageDetector3D, bbox2result3D, PosCountReadback, MASK_BATCH_BUCKETS
 
 
@@ -69,7 +69,8 @@ class TwoStageDetector3D2Scales(TwoStageDetector3D):
         """forward_train + backward of the summed losses with both RPN branches (heads, targets, losses, backward) on a second
         stream beside the roi-head chain, and the bbox / refinement heads differentiated in front of the mask heads' host
         waits -- see TwoStageDetector3D.forward_backward.  Returns the loss dict with detached values."""
-        return self.forward_train(*args, _eager_backward=True, **kwargs)
+        with deferred_backward() as self._deferred_items:
+            return self.forward_train(*args, _eager_backward=True, **kwargs)
 
     def forward_train(self, imgs, img_meta, imgs_2, img_meta_2, gt_bboxes, gt_bboxes_2, gt_labels, gt_labels_2,
                       gt_bboxes_ignore=None, gt_masks=None, gt_masks_2=None, proposals=None, draws=None, _eager_backward=False):
@@ -178,8 +179,10 @@ class TwoStageDetector3D2Scales(TwoStageDetector3D):
         if _eager_backward:
             torch.autograd.backward(losses['loss_mask'].sum() + losses['loss_mask_refinement'].sum())
             main.wait_stream(side)
-            torch.autograd.backward(graph, [b.grad if a.grad is None else a.grad + b.grad
-                                            for a, b in zip(tuple(x) + tuple(x_2), tuple(xr) + tuple(xr_2))])
+            # the four extractors on pathway 1 and the one on pathway 2 were recorded (roi_extractor.deferred_backward): their
+            # scatters go straight into the RPN branches' gradient buffers -- no zero-filled level buffers, no adds
+            items = self._deferred_items
+            torch.autograd.backward(graph, pyramid_gradient(x, xr, items) + pyramid_gradient(x_2, xr_2, items))
             losses = {k: ([t.detach() for t in v] if isinstance(v, (list, tuple)) else v.detach()) for k, v in losses.items()}
         self.iteration += 1
         return losses
