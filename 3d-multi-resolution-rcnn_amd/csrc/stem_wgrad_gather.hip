@@ -194,23 +194,23 @@ __global__ __launch_bounds__(kGatherThreads, 8) void stem_wgrad_gather_kernel(Ga
       // entry of item it + 2 are in flight (the compiler, left alone, waits for every read right behind its issue; the
       // sched_barriers pin the order, its own counted s_waitcnt lgkmcnt does the rest).
       auto rd = [&](const char *q, int i) { return *reinterpret_cast<const f32x2 *>(q + 2 * i * G::PLANE * 4); };
-      if (ci == 0) bsum += __uint_as_float(items[lane].x) + __uint_as_float(items[lane + 64].x);      // bias gradient: per-lane partial sums
-      uint2 e = items[0], en = items[1];
+      // the wave's 128 (g, offset) entries are read ONCE into two register pairs (entry lane and lane + 64 per lane) and come back
+      // per item through v_readlane: no LDS read per item for the table (2 of the 10 LDS cycles per item and input channel)
+      const uint2 ea = items[lane], eb = items[lane + 64];
+      if (ci == 0) bsum += __uint_as_float(ea.x) + __uint_as_float(eb.x);      // bias gradient: per-lane partial sums
+      auto g_of = [&](int it) { return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)(it < 64 ? ea.x : eb.x), it & 63)); };
+      auto o_of = [&](int it) { return (unsigned)__builtin_amdgcn_readlane((int)(it < 64 ? ea.y : eb.y), it & 63); };
       f32x2 v0, v1, v2, v3;
       {
-        const char *q = base + e.y;
+        const char *q = base + o_of(0);
         v0 = rd(q, 0); v1 = rd(q, 1); v2 = rd(q, 2); v3 = rd(q, 3);
       }
-      // fully unrolled: the table entry of item it + 2 is one base register plus an immediate (no vector instruction per item
-      // besides the address add and the four multiply-adds)
 #pragma unroll
       for (int it = 0; it < G::TP; ++it) {
-        const uint2 e2 = items[it + 2 < G::TP ? it + 2 : G::TP - 1];          // issued first: the next trip waits for it, not for n0..n3
-        __builtin_amdgcn_sched_barrier(0);
-        const char *qn = base + en.y;
+        const char *qn = base + o_of(it + 1 < G::TP ? it + 1 : G::TP - 1);
         const f32x2 n0 = rd(qn, 0), n1 = rd(qn, 1), n2 = rd(qn, 2), n3 = rd(qn, 3);
         __builtin_amdgcn_sched_barrier(0);
-        const float g = __uint_as_float(e.x);
+        const float g = g_of(it);
         const f32x2 gg = f32x2{g, g};
         a0 = __builtin_elementwise_fma(v0, gg, a0);
         a1 = __builtin_elementwise_fma(v1, gg, a1);
@@ -218,7 +218,6 @@ __global__ __launch_bounds__(kGatherThreads, 8) void stem_wgrad_gather_kernel(Ga
         a3 = __builtin_elementwise_fma(v3, gg, a3);
         __builtin_amdgcn_sched_barrier(0);
         v0 = n0; v1 = n1; v2 = n2; v3 = n3;
-        e = en; en = e2;
       }
       // rotate the accumulator groups: the body always works on group 0 (no dynamic register indexing)
       acc[0][0] = acc[1][0]; acc[0][1] = acc[1][1]; acc[0][2] = acc[1][2]; acc[0][3] = acc[1][3];

@@ -32,7 +32,7 @@ def key_of(name):
         return f'conv3d_{m.group(1)}<k1,s111,cc{cc},nb{nb}>'
     if 'conv3d_wino2d_kernel' in n:          # the two-dimensional Winograd form of the 64 -> 64 3x3x3 convs (conv3d_wino2d.hip)
         return 'conv3d_fwd<k3,s111,cc16,nb64>'
-    for pat, key in (('stem_fwd_kernel', 'stem_fwd'), ('stem_wgrad_kernel', 'stem_wgrad'), ('maxpool_fwd_kernel', 'maxpool_fwd'),
+    for pat, key in (('stem_fwd', 'stem_fwd'), ('stem_wgrad_gather_kernel', 'stem_wgrad_gather'), ('stem_wgrad_kernel', 'stem_wgrad'), ('maxpool_fwd_kernel', 'maxpool_fwd'),
                      ('maxpool_bwd_kernel', 'maxpool_bwd'), ('upsample_adjoint_add_kernel', 'upsample_adjoint_add')):
         if pat in n:
             return key

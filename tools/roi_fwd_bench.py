@@ -37,10 +37,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--bf16', action='store_true')
     ap.add_argument('--backward', action='store_true', help='also time forward + backward (fp32 features)')
+    ap.add_argument('--tune', default='', help='key=value pairs for mr3d_tuning_set, e.g. 4=1 (box forward without the RoI split)')
     ap.add_argument('--sizes', default='', help='xy_lo,xy_hi,z_lo,z_hi in pixels: log-uniform roi sizes instead of the SURVEY 8(d) ranges')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
     torch.manual_seed(0)
+    from mr3d_amd import _hip as _h
+    for kv in filter(None, a.tune.split(',')):
+        _h.lib().mr3d_tuning_set(*(int(v) for v in kv.split('=')))
     feats = [torch.randn(1, 64, d, h, h, device=dev).contiguous(memory_format=torch.channels_last_3d)
              for d, h in ((40, 128), (20, 64), (10, 32), (5, 16))]
     if a.bf16:
