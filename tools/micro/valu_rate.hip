@@ -2,9 +2,10 @@
 // and 8 waves per SIMD, s_memtime cycles per instruction and SIMD.  Answers: does a packed instruction do two lanes' worth of
 // work in the time of one (it is how the 157 TFLOP/s vector peak is quoted), or does it cost two issue slots?
 //   hipcc -O3 -Wno-unused-result --offload-arch=gfx950 tools/micro/valu_rate.hip -o tools/micro/valu_rate; gpurun -- tools/micro/valu_rate
-// Measured (MI355X, 4-8 waves per SIMD, wall time per instruction and SIMD at ~2.1 GHz): v_fma_f32 3.8-4.0 cycles, v_pk_fma_f32 4.4-4.7
-// (two multiply-adds per lane: 1.8x the work per cycle), v_add_f32 2.5, v_pk_add_f32 4.2-4.4 (1.15x): packing pays for
-// multiply-adds, not for the add / subtract chains of a Winograd transform.
+// Measured (MI355X, 4-8 waves per SIMD, every SIMD busy; WALL time per instruction and SIMD relative to v_fma_f32 = 1, about 1.9 ns):
+// v_pk_fma_f32 1.15-1.2 (two multiply-adds per lane: 1.7-1.8x the work per unit of time), v_add_f32 0.65, v_pk_add_f32 1.1 (1.15x the
+// work): packing pays for multiply-adds, not for the add / subtract chains of a Winograd transform (the printed cycle counts are
+// s_memtime deltas of a workgroup, the printed clock is only their ratio to the launch's wall time).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
