@@ -42,11 +42,22 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wgrad_wino2d_kernel(Conv3d
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lk = lane >> 4;
-  const int c0 = blockIdx.y * CC;
+  // Dispatch order -> (tile sequence bx, Cin tile by, (kd, Cout tile) bz).  The 12 workgroup TYPES (by, bz) of one tile sequence read
+  // the same dy tiles (and overlapping x planes); in the grid's natural order they are 128 ids apart -- three dispatch rounds --
+  // and every round re-read its tiles from HBM (855 MiB per launch on the P2 map against 190 MB of operands).  Here consecutive
+  // ids of one XCD (id % 8) are the types of ONE sequence: they are resident together, walk their tiles at the same pace, and the
+  // first to touch a tile brings it into the XCD's L2 for the other eleven.
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if ((gridDim.x & 7) == 0) {
+    const int id = bx + (int)gridDim.x * (by + (int)gridDim.y * bz), types = (int)(gridDim.y * gridDim.z);
+    const int xcd = id & 7, sq = id >> 3, type = sq % types;
+    bx = (sq / types) * 8 + xcd; by = type % (int)gridDim.y; bz = type / (int)gridDim.y;
+  }
+  const int c0 = by * CC;
   const int cotiles = p.Cout / 64;
-  const int kd = blockIdx.z / cotiles, n0 = (blockIdx.z % cotiles) * 64;
+  const int kd = bz / cotiles, n0 = (bz % cotiles) * 64;
   const int co = n0 + wave * 16 + li;                    // B operand column of this lane
-  const bool want_bias = p.dbias && kd == 0 && blockIdx.y == 0;
+  const bool want_bias = p.dbias && kd == 0 && by == 0;
 
   f32x4 acc[NF];
 #pragma unroll
@@ -138,8 +149,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wgrad_wino2d_kernel(Conv3d
   __shared__ int live[2];
   if (tid == 0) live[0] = 0;
   int tile_par = 0;
-  if ((int)blockIdx.x < ntiles) fetch(blockIdx.x, !SPARSE, true);      // sparse: only dy travels ahead; x is fetched for live tiles
-  for (int t = blockIdx.x; t < ntiles; t += gridDim.x, tile_par ^= 1) {
+  if (bx < ntiles) fetch(bx, !SPARSE, true);      // sparse: only dy travels ahead; x is fetched for live tiles
+  for (int t = bx; t < ntiles; t += gridDim.x, tile_par ^= 1) {
     __syncthreads();                                     // the previous tile's k-steps are done with dyl and V
     bool tile_live = true;                               // (workgroup-uniform)
     if constexpr (SPARSE) {
