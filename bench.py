@@ -591,8 +591,18 @@ def main():
             tf = v['flops'] / v['ms'] / 1e9 if v['ms'] > 0 else 0
             print(f'{k:40s} n={v["n"]:3d} {v["ms"]:8.3f} ms {100 * v["ms"] / tot:5.1f}%  {tf:7.2f} TFLOP/s', file=sys.stderr)
         print(f'sum of per-op times {tot:.3f} ms', file=sys.stderr)
-    marks_f = sorted(k for w_, k in groups[dom]['ops'] if w_ == 'f')
-    marks_b = sorted(k for w_, k in groups[dom]['ops'] if w_ == 'b')
+    # the next two kernels by time carry event pairs too (`roofline.next_kernels`): the dominant kernel alone says little about a step
+    # whose three largest kernels take 18 / 13 / 9 % of it
+    # (kernels whose MFMA issue factor the library reports: the forward / data-gradient convolutions and the stem kernels)
+    def priced(key):
+        kinds = {(plan.fwd if w_ == 'f' else plan.bwd).array[k].kind for w_, k in groups[key]['ops']}
+        return groups[key]['flops'] > 0 and kinds <= {_hip.OP_CONV_FWD, _hip.OP_STEM_FWD, _hip.OP_STEM_WGRAD}
+    top = sorted((k for k in groups if priced(k)), key=lambda k: -groups[k]['ms'])[:3]
+    if dom not in top:
+        top = [dom] + top[:2]
+    marked = [op for k in top for op in groups[k]['ops']]
+    marks_f = sorted(k for w_, k in marked if w_ == 'f')
+    marks_b = sorted(k for w_, k in marked if w_ == 'b')
 
     if os.environ.get('MR3D_BENCH_GRAPH') == '1':          # A/B: hipGraph replay (no per-kernel event brackets possible)
         eng.capture(plan)
@@ -632,31 +642,39 @@ def main():
         return None
 
     if rank == 0:
-        dom_ms = sum(s.elapsed_time(e) for e1, e2 in dom_events for (s, e) in list(e1.values()) + list(e2.values()))
+        def group_ms(key):
+            ops = set(groups[key]['ops'])
+            return sum(ev[k][0].elapsed_time(ev[k][1]) for e1, e2 in dom_events for w_, ev in (('f', e1), ('b', e2)) for k in ev if (w_, k) in ops)
+
+        def issue_factor_of(key):
+            """MFMA FLOPs the launches of a group really ISSUE / their algorithmic FLOPs (Winograd instances issue less; the gather form
+            of the stem weight gradient issues none: vector-ALU work)"""
+            issued, var = 0.0, {}
+            for which, k in groups[key]['ops']:
+                op = (plan.fwd if which == 'f' else plan.bwd).array[k]
+                _, fl = _hip.op_kernel_key(op)
+                factor, tag = 1.0, 'direct'
+                if op.kind == _hip.OP_CONV_FWD and op.i[25] == 0:
+                    v = _hip.op_conv_variant(op)
+                    factor = float(v.mfma_issue_factor)
+                    tag = ('streaming pointwise' if v.streaming_pointwise else
+                           ('winograd F(4,3) along W x F(2,3) along H' if v.winograd == 8 else
+                            (f'winograd F({v.winograd},3) along W' if v.winograd else 'direct')) +
+                           f' tile {v.tile_d}x{v.tile_h}x{v.tile_w} cout {v.cout_tile}')
+                elif op.kind == _hip.OP_STEM_FWD and op.i[25] == 0:
+                    # stem.hip: F(2,3) along depth (10 MFMA groups per depth pair instead of 14), kw padded 7 -> 8: the counters agree
+                    # (profiles/r04/insts_per_kernel.md: 6.881e7 MFMAs x 2048 FLOP = 140.9 of 172.6 GFLOP)
+                    factor, tag = 10.0 / 14.0 * 8.0 / 7.0, 'winograd F(2,3) along D, kw 7->8'
+                elif key == 'stem_wgrad_gather':
+                    factor, tag = 0.0, 'gather over the pooled elements on the vector ALUs (no MFMA)'
+                issued += fl * factor
+                var[tag] = var.get(tag, 0) + 1
+            return (issued / groups[key]['flops'] if groups[key]['flops'] else 1.0), var
+
+        dom_ms = group_ms(dom)
         launches = a.steps * groups[dom]['n']
         alg = groups[dom]['flops'] * a.steps / (dom_ms * 1e-3) if dom_ms > 0 else 0.0
-        # MFMA FLOPs the dominant launches really ISSUE: a Winograd instance issues 1/2 (F(4,3)) or 2/3 (F(2,3)) of the
-        # convolution's algorithmic FLOPs.  The factor comes from the library's own dispatch (mr3d_conv3d_forward_variant),
-        # launch by launch, not from a table here.
-        issued_flops, variants = 0.0, {}
-        for which, k in groups[dom]['ops']:
-            op = (plan.fwd if which == 'f' else plan.bwd).array[k]
-            _, fl = _hip.op_kernel_key(op)
-            factor, tag = 1.0, 'direct'
-            if op.kind == _hip.OP_CONV_FWD and op.i[25] == 0:
-                v = _hip.op_conv_variant(op)
-                factor = float(v.mfma_issue_factor)
-                tag = ('streaming pointwise' if v.streaming_pointwise else
-                       ('winograd F(4,3) along W x F(2,3) along H' if v.winograd == 8 else
-                        (f'winograd F({v.winograd},3) along W' if v.winograd else 'direct')) +
-                       f' tile {v.tile_d}x{v.tile_h}x{v.tile_w} cout {v.cout_tile}')
-            elif op.kind == _hip.OP_STEM_FWD and op.i[25] == 0:
-                # stem.hip: F(2,3) along depth (10 MFMA groups per depth pair instead of 14), kw padded 7 -> 8: the counters agree
-                # (profiles/r04/insts_per_kernel.md: 6.881e7 MFMAs x 2048 FLOP = 140.9 of 172.6 GFLOP)
-                factor, tag = 10.0 / 14.0 * 8.0 / 7.0, 'winograd F(2,3) along D, kw 7->8'
-            issued_flops += fl * factor
-            variants[tag] = variants.get(tag, 0) + 1
-        issue_factor = issued_flops / groups[dom]['flops'] if groups[dom]['flops'] else 1.0
+        issue_factor, variants = issue_factor_of(dom)
         ach = alg * issue_factor
         ms_per_step = el * 1e3 / a.steps
         # the engine's arithmetic decides the peak: every kernel of a bf16 run (stem included) multiplies on the bf16 matrix cores
@@ -682,8 +700,19 @@ def main():
                          'timing': 'HIP events recorded by mr3d_plan_run_marked on the stream the kernel is launched on, around every '
                                    'launch of this kernel inside the timed steps; the plan is not split (other kernels overlap '
                                    'it exactly as in production)',
-                         'whole_step_frac': FLOP_FWD_BWD_512 * scale / (ms_per_step * 1e-3) / peak},
+                         'whole_step_frac': FLOP_FWD_BWD_512 * scale / (ms_per_step * 1e-3) / peak,
+                         'next_kernels': []},
         }
+        for key in top:
+            if key == dom:
+                continue
+            kms, n_ = group_ms(key), a.steps * groups[key]['n']
+            kalg = groups[key]['flops'] * a.steps / (kms * 1e-3) if kms > 0 else 0.0
+            kf, kvar = issue_factor_of(key)
+            res['roofline']['next_kernels'].append({
+                'kernel': key, 'avg_launch_ms': kms / n_ if n_ else None, 'launches_per_step': groups[key]['n'],
+                'algorithmic_achieved': kalg / 1e12, 'algorithmic_frac': kalg / peak, 'mfma_issue_factor': kf,
+                'achieved': kalg * kf / 1e12, 'frac': kalg * kf / peak, 'variants': kvar, 'traffic': committed_traffic(key)})
         if world == 1 and not a.no_aux and a.dtype == 'f32':
             try:
                 res['aux'] = {k: (round(v, 4) if ('frac' in k or 'per_s' in k) else round(v, 1)) for k, v in ops_microbench(dev).items()}
