@@ -236,9 +236,13 @@ __global__ __launch_bounds__(kGatherThreads, 8) void stem_wgrad_gather_kernel(Ga
     }
   }
 
-  // lane (kdl, kh, j), register i: kd = 2i + kdl, taps kw = 2j - 1 (.x, none for j = 0) and 2j (.y)
+  // lane (kdl, kh, j), register i: kd = 2i + kdl, taps kw = 2j - 1 (.x, none for j = 0) and 2j (.y).  The block leaves through LDS as
+  // [tap][ci][16 channels] (the slab is free now): a wave's own values are 64 bytes apart in that layout, and stored straight from
+  // the registers the 16 waves' 4-byte pieces of a line reached HBM as separate partial writes (217 MiB written per launch for
+  // 34 MB of partial sums).
+  float *stage = lds;                                  // 343 * 3 * 16 floats = 65,856 bytes <= slab + table
+  static_assert(343 * 3 * 16 * 4 <= kGatherLds, "the partial block fits the workgroup's LDS");
   if (lane < 56) {
-    float *part = p.part ? p.part + (size_t)blockIdx.x * (343 * 3 * 16) : nullptr;
 #pragma unroll
     for (int ci = 0; ci < 3; ++ci)
 #pragma unroll
@@ -246,14 +250,24 @@ __global__ __launch_bounds__(kGatherThreads, 8) void stem_wgrad_gather_kernel(Ga
         const int kd = 2 * i + kdl;
         if (kd > 6) continue;
         const int t = (kd * 7 + kh) * 7 + 2 * j;
-        if (part) {
-          if (j > 0) part[((size_t)(t - 1) * 3 + ci) * 16 + wave] = acc[ci][i].x;
-          part[((size_t)t * 3 + ci) * 16 + wave] = acc[ci][i].y;
-        } else {
-          if (j > 0) atomicAdd(p.dw + ((size_t)(t - 1) * 4 + ci) * 16 + wave, acc[ci][i].x);
-          atomicAdd(p.dw + ((size_t)t * 4 + ci) * 16 + wave, acc[ci][i].y);
-        }
+        if (j > 0) stage[((t - 1) * 3 + ci) * 16 + wave] = acc[ci][i].x;
+        stage[(t * 3 + ci) * 16 + wave] = acc[ci][i].y;
       }
+  }
+  __syncthreads();
+  {
+    constexpr int PER4 = 343 * 3 * 4;                  // float4 of the block: element e = (tap * 3 + ci) * 4 + channel quad
+    float4 *part4 = p.part ? reinterpret_cast<float4 *>(p.part + (size_t)blockIdx.x * (343 * 3 * 16)) : nullptr;
+    for (int e = tid; e < PER4; e += kGatherThreads) {
+      const float4 v = reinterpret_cast<const float4 *>(stage)[e];
+      if (part4) {
+        part4[e] = v;
+      } else {
+        const int tc = e >> 2;
+        float *d = p.dw + ((size_t)(tc / 3) * 4 + tc % 3) * 16 + (e & 3) * 4;
+        atomicAdd(d, v.x); atomicAdd(d + 1, v.y); atomicAdd(d + 2, v.z); atomicAdd(d + 3, v.w);
+      }
+    }
   }
   if (p.dbias) {
 #pragma unroll
