@@ -332,7 +332,16 @@ int mr3d_stem_wgrad_gather(const float *x, const void *g, const uint32_t *idx, c
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
       cus = prop.multiProcessorCount;
   }
-  int grid = tiles < 2 * cus ? tiles : 2 * cus;
+  // Two 1024-thread workgroups per CU take every wave slot of the chip, and the workgroups are persistent: whatever is queued beside
+  // this kernel -- the gradient finishing of layer1 / layer2 (side queue), a collective -- starts with its last tile.  That is the
+  // cheaper order at N = 1 (48 free slots: the kernel 6 % longer, the 75 us of finishing behind it 50 us shorter, step 9.09 ->
+  // 9.04 ms; with the finishing of layer3.. moved to the middle of the backward pass the rest is too short to matter), and the
+  // gradient exchange does not depend on it: its large bucket is final in mid-backward (extract_feat.MARK_GRADS_EARLY).
+  // MR3D_TUNE_STEM_GATHER_SPARE leaves n slots free.
+  const int spare = g_mr3d_tuning[MR3D_TUNE_STEM_GATHER_SPARE] > 0 ? g_mr3d_tuning[MR3D_TUNE_STEM_GATHER_SPARE] : 0;
+  int slots = 2 * cus - spare;
+  if (slots < cus) slots = cus;
+  int grid = tiles < slots ? tiles : slots;
   if (grid >= 8) grid &= ~7;
   static std::atomic<unsigned> next_slot{0};
   a.queue_slot = (int)(next_slot.fetch_add(1) & 63u);

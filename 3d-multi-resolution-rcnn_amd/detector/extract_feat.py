@@ -59,6 +59,9 @@ class _ConvSpec:
 class ExtractFeat3D(nn.Module):
     STAGE_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
     MARK_GRADS_BUT_STEM = 1          # SYNC slot of the backward plan (see dist_utils.allreduce_overlapped)
+    MARK_GRADS_EARLY = 3             # SYNC slot: the gradients of layer3, layer4 and the neck are final (dist_utils.allreduce_overlapped)
+    EARLY_STAGE = 2                  # layer3: the first stage whose parameters belong to the early bucket
+    early_bucket = os.environ.get('MR3D_EARLY_BUCKET', '1') != '0'          # (0: ONE finishing at the end of the backward plan, rounds 1-4)
     MARK_COARSE_DGRADS = 2           # SYNC slot: the P3..P5 output-conv data gradients (side stream) are done
     MARK_LATERAL_DGRAD = 4           # SYNC slots 4 / 5: the P2 / P3 lateral data gradients (side stream, fp32 plans) are done
 
@@ -342,6 +345,16 @@ class ExtractFeat3D(nn.Module):
         """length of the leading arena range that holds the stem's parameters (conv1 weight + its BN scale / shift): the only
         gradients that are not final when the backward plan's MARK_GRADS_BUT_STEM point is reached"""
         return self.rel_offsets[self.specs[1].name + '.weight']
+
+    def _early_index(self):
+        """table index of the first layer of the early bucket (layer3.0.conv1): specs [index:] = layer3, layer4, the neck"""
+        return next(b for b in self.blocks if b['stage'] == self.EARLY_STAGE)['conv1'].index
+
+    @property
+    def early_elems(self):
+        """arena offset of the early bucket: the gradients of [early_elems:] (layer3, layer4, the neck -- and, in a DetectorArena,
+        every head behind the engine) are final at the backward plan's MARK_GRADS_EARLY point, in the middle of the backward pass"""
+        return self.rel_offsets[self.specs[self._early_index()].name + '.weight']
 
     @property
     def flat_params(self):
@@ -684,13 +697,25 @@ class ExtractFeat3D(nn.Module):
             if b['block'] == 0 and deferred:          # the stage's data-gradient chain is complete: its weight gradients, one run
                 bwd.extend(deferred)
                 deferred = []
+            if b['block'] == 0 and b['stage'] == self.EARLY_STAGE and self.early_bucket:
+                # Early bucket of the gradient exchange: every weight gradient of layer3, layer4 and the neck has been issued; their
+                # finishing (dW = s dW', BN gamma / beta) runs on the side queue NOW, underneath the backward pass of layer2 / layer1,
+                # and slot MARK_GRADS_EARLY tells the communication stream that the arena from `early_elems` on -- 99 % of the
+                # message once the heads sit behind the engine -- may be exchanged (dist_utils.allreduce_overlapped).  Until round 5
+                # ONE finishing ran beside the stem weight gradient; the gather form of that kernel occupies the chip's wave slots
+                # and the finishing of all 60 layers ended with it, i.e. with the backward pass: nothing left to overlap.
+                k0 = self._early_index()
+                bwd.append(_hip.make_op(_hip.OP_FINISH_GRADS, [self._table.data_ptr() + k0 * dsz, self._arena, self._scratch, self._grad_arena],
+                                        [nL - k0, max(sp.cout for sp in self.specs[k0:])], side=True))
+                bwd.append(_hip.make_op(_hip.OP_SYNC, [], [_hip.SYNC_MARK, self.MARK_GRADS_EARLY]))
         # Gradient finishing (dW = s dW', BN gamma / beta from the raw sums, ~0.11 ms) of every layer but the stem: queued on
         # the side stream behind the last conv weight gradient -- a side record waits for the main chain only up to the point
         # where it is issued, so it is issued HERE, in front of the max-pool backward and the stem weight gradient, and runs
         # underneath them.  The stem weight gradient (1.8 ms) needs the last data gradient and closes the main chain; only its
         # own 16 channels are finished after the join.
+        k0 = self._early_index() if self.early_bucket else nL          # (layer1 / layer2 only: the later stages were finished in the early bucket)
         bwd.append(_hip.make_op(_hip.OP_FINISH_GRADS, [self._table.data_ptr() + dsz, self._arena, self._scratch, self._grad_arena],
-                                [nL - 1, self.max_cout], side=True))
+                                [k0 - 1, max(sp.cout for sp in self.specs[1:k0])], side=True))
         # slot 1: "every parameter gradient but the stem's is final" -- the point the overlapped gradient exchange waits for
         bwd.append(_hip.make_op(_hip.OP_SYNC, [], [_hip.SYNC_MARK, self.MARK_GRADS_BUT_STEM]))
         # the max-pool backward and the stem's ReLU mask happen inside the weight gradient's dy staging

@@ -31,13 +31,16 @@ def allreduce_flat_grads(flat, world_size=None, group=None):
 _COMM_STREAMS = {}
 
 
-def allreduce_overlapped(flat, stem_elems, world_size=None, group=None, mark_slot=1, force_single_rank=False):
-    """In-place mean of the flat gradient arena as TWO collectives so that the exchange starts before the backward pass has
-    finished.  The arena begins with the stem's parameters (`stem_elems` floats); everything behind them -- the rest of the
-    backbone, the neck, every head: 99.9 % of the message -- is final as soon as the backward plan's gradient finishing of
-    those layers has run on the plan's side stream, which happens UNDERNEATH the stem's weight-gradient kernel (1.8 ms, the
-    last kernel of the backward).  So: a communication stream waits for that point (mr3d_plan_stream_wait_mark) and carries
-    the all-reduce of flat[stem_elems:]; the caller's stream then reduces the 66 KB stem range and waits for the first.
+def allreduce_overlapped(flat, stem_elems, world_size=None, group=None, mark_slot=1, force_single_rank=False, early_elems=None,
+                         early_slot=3):
+    """In-place mean of the flat gradient arena as TWO collectives so that the exchange runs underneath the backward pass.
+    early_elems given (round 5, the default of DetectorArena / bench.py): the arena from `early_elems` on -- layer3, layer4, the neck
+    and every head: 99 % of the message -- is final when the backward plan reaches its MARK_GRADS_EARLY point (slot `early_slot`: the
+    finishing of those layers on the plan's side queue, in the MIDDLE of the backward pass); a communication stream waits for that point
+    and carries the all-reduce of flat[early_elems:] while layer2, layer1 and the stem weight gradient still run; the caller's stream
+    reduces the small front range flat[:early_elems] after the backward pass and then waits for the first collective.
+    early_elems None (rounds 3-4): the split is at `stem_elems` and the first collective waits for slot `mark_slot` ("every gradient
+    but the stem's"), which ran beside the stem weight gradient -- the gather form of that kernel leaves no room beside it.
     Semantics are those of allreduce_flat_grads / the reference (SUM, then divide, before the gradient clip:
     mmdet/core/utils/dist_utils.py:22-28,51-57).  CPU tensors (gloo tests): the same two collectives, one after the other.
     Call it after loss.backward() has returned (everything is enqueued by then)."""
@@ -45,7 +48,8 @@ def allreduce_overlapped(flat, stem_elems, world_size=None, group=None, mark_slo
         world_size = dist.get_world_size(group)
     if world_size == 1 and not force_single_rank:      # force_single_rank: launch the collectives anyway (1-GPU check of the
         return flat                                     # launch structure under a profiler)
-    head, tail = flat[:stem_elems], flat[stem_elems:]
+    split, slot = (stem_elems, mark_slot) if early_elems is None else (early_elems, early_slot)
+    head, tail = flat[:split], flat[split:]
     if flat.is_cuda:
         from . import _hip
         dev = flat.device
@@ -55,7 +59,7 @@ def allreduce_overlapped(flat, stem_elems, world_size=None, group=None, mark_slo
         # the communication stream starts behind the plan's mark -- IF this step's backward pass recorded it.  It did not when
         # the side stream is off, when the plan is replayed from a hipGraph, or when no plan ran: the collective then waits for
         # everything the caller's stream holds (no overlap, same result).
-        if not _hip.plan_stream_wait_mark_checked(mark_slot, comm):
+        if not _hip.plan_stream_wait_mark_checked(slot, comm):
             comm.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(comm):
             work = dist.all_reduce(tail, op=dist.ReduceOp.SUM, group=group, async_op=True)
@@ -189,12 +193,13 @@ class DetectorArena:
                 bool(getattr(self.engine, 'grads_touched', True)) if self.engine is not None else True)
 
     def allreduce(self, world_size=None, group=None, overlap=True):
-        """the one gradient exchange of a step.  overlap (default): two collectives, the first one started underneath the
-        tail of the backward pass (allreduce_overlapped); False: ONE in-place all-reduce after the backward pass, as the
-        reference issues it"""
+        """the one gradient exchange of a step.  overlap (default): two collectives, the first one -- layer3, layer4, the neck and
+        every head -- started in the middle of the backward pass (allreduce_overlapped); False: ONE in-place all-reduce after the
+        backward pass, as the reference issues it"""
         if overlap and self.engine is not None:
             return allreduce_overlapped(self.flat_grads, self.engine.stem_elems, world_size, group,
-                                        mark_slot=self.engine.MARK_GRADS_BUT_STEM)
+                                        mark_slot=self.engine.MARK_GRADS_BUT_STEM, early_elems=self.engine.early_elems,
+                                        early_slot=self.engine.MARK_GRADS_EARLY)
         return allreduce_flat_grads(self.flat_grads, world_size, group)
 
 

@@ -56,6 +56,7 @@ def parse():
     ap.add_argument('--backbone-only-allreduce', action='store_true',
                     help='N > 1, --config backbone: exchange only the 13.7 MB backbone+FPN gradients instead of the whole '
                          "detector's arena")
+    ap.add_argument('--tune', default='', help='measurement knobs, key=value[,key=value...] for mr3d_tuning_set (include/mr3d.h); all 0 by default')
     return ap.parse_args()
 
 
@@ -521,6 +522,8 @@ def main():
 
     import mr3d_amd
     from mr3d_amd import _hip
+    for kv in filter(None, a.tune.split(',')):
+        _hip.lib().mr3d_tuning_set(*(int(v) for v in kv.split('=')))
     from mr3d_amd.detector import ExtractFeat3D
     from mr3d_amd.dist_utils import allreduce_flat_grads, allreduce_overlapped, broadcast_params
 
@@ -563,7 +566,8 @@ def main():
             if a.serial_allreduce:
                 allreduce_flat_grads(reduce_buf, world) if world > 1 else dist.all_reduce(reduce_buf)
             else:
-                allreduce_overlapped(reduce_buf, eng.stem_elems, world, force_single_rank=force_dist)
+                allreduce_overlapped(reduce_buf, eng.stem_elems, world, force_single_rank=force_dist, early_elems=eng.early_elems,
+                                     early_slot=eng.MARK_GRADS_EARLY)
         return ev, evb
 
     # ---- warmup; the last warmup step is bracketed op by op to find the dominant kernel

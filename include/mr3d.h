@@ -56,6 +56,10 @@ enum {
                                      their system-scope fence (the round-3 behaviour; default 0 = hipEventDisableSystemFence) */
   MR3D_TUNE_STEM_WGRAD_DENSE = 3, /* 1: mr3d_stem_conv_wgrad_pooled runs the dense MFMA kernel (the pooled gradient scattered into its dy
                                      tiles: the round-3/4 form) instead of the gather over the pooled elements (stem_wgrad_gather.hip) */
+  MR3D_TUNE_STEM_GATHER_SPARE = 4, /* workgroup slots the gather form of the stem weight gradient leaves free (two 1024-thread workgroups per CU
+                                     would occupy every wave slot of the chip: whatever is queued beside it -- gradient finishing, the
+                                     collective of the overlapped exchange -- waits for its end).  0 = the library's default (none: see
+                                     stem_wgrad_gather.hip), n > 0 = n slots */
   MR3D_TUNE_NUM_KEYS = 16
 };
 void mr3d_tuning_set(int key, int value);

@@ -178,7 +178,7 @@ def _overlap_worker(rank, world, port, q):
         import mr3d_amd  # noqa: F401
         from mr3d_amd.dist_utils import DetectorArena, broadcast_params, allreduce_flat_grads, allreduce_overlapped, clip_grad_norm_flat
         dets, arenas, opts = [], [], []
-        for _ in range(2):                               # [serial exchange, two-collective exchange], identical starts
+        for _ in range(3):                               # [serial exchange, split at the stem, split at the early bucket], identical starts
             torch.manual_seed(3)
             d = _StubDetector()
             a = DetectorArena(d, engine_attr=None)
@@ -190,16 +190,19 @@ def _overlap_worker(rank, world, port, q):
         for it in range(3):
             x = torch.randn(5, 6, generator=gen)
             args = (x, (torch.rand(5, 1, generator=gen) > 0.5).float(), torch.randn(5, 6, generator=gen))
-            for k in range(2):
+            for k in range(3):
                 arenas[k].zero_grad()
                 dets[k].total_loss(dets[k].forward_train(*args)).backward()
                 if k == 0:
                     allreduce_flat_grads(arenas[k].flat_grads, world)
-                else:
+                elif k == 1:
                     allreduce_overlapped(arenas[k].flat_grads, split, world)
+                else:                                    # round 5: [early_elems:] first (mid-backward on the GPU), the front range last
+                    allreduce_overlapped(arenas[k].flat_grads, split, world, early_elems=61)
                 clip_grad_norm_flat([arenas[k].flat_grads], 35.0)
                 opts[k].step()
-        same_paths = torch.equal(arenas[0].flat_params, arenas[1].flat_params) and torch.equal(arenas[0].flat_grads, arenas[1].flat_grads)
+        same_paths = all(torch.equal(arenas[0].flat_params, arenas[k].flat_params) and torch.equal(arenas[0].flat_grads, arenas[k].flat_grads)
+                         for k in (1, 2))
         ws = [torch.empty_like(arenas[1].flat_params) for _ in range(world)]
         dist.all_gather(ws, arenas[1].flat_params)
         q.put((rank, same_paths, all(torch.equal(ws[0], w) for w in ws)))
