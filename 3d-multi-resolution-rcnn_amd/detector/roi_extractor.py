@@ -46,6 +46,13 @@ def flush_deferred(items, sinks_by_key):
         _hip.roi_align3d_backward_ml(top, rois, list(sinks_by_key[key][:n]), out_d, out_h, out_w, scales, scales_d, sample_num, finest, bug)
 
 
+def assert_all_flushed(items, pyramids):
+    """every recorded backward pass belongs to one of the pyramids whose gradients are about to be handed to the backbone"""
+    keys = {p[0].data_ptr() for p in pyramids}
+    stray = [it for it in items if it[0] not in keys]
+    assert not stray, f'{len(stray)} deferred RoIAlign3D backward passes refer to feature maps outside this step\'s pyramids'
+
+
 def pyramid_gradient(x, x_rpn, items):
     """Cotangents of one pyramid for the backbone backward: per level the RPN branch's gradient (x_rpn[l].grad) plus whatever
     autograd accumulated on the roi heads' copies (x[l].grad: extractors that did not defer, e.g. a bf16 pyramid), with the

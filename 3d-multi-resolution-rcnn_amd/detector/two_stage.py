@@ -18,7 +18,7 @@ from ..core.bbox import build_assigner, build_sampler, bbox2roi3D
 from ..core.mask import mask_target_single
 from .extract_feat import ExtractFeat3D
 from .heads import RPNHead3D, SharedFCBBoxHead3D, FCNMaskHead3D
-from .roi_extractor import SingleRoIExtractor, deferred_backward, pyramid_gradient
+from .roi_extractor import SingleRoIExtractor, assert_all_flushed, deferred_backward, pyramid_gradient
 
 # configs/3d-multi-resolution-rcnn.py:87-127
 DEFAULT_TRAIN_CFG = dict(
@@ -321,6 +321,7 @@ class TwoStageDetector3D(nn.Module):
             if self.with_mask:
                 torch.autograd.backward(losses['loss_mask'].sum())
             main.wait_stream(side)
+            assert_all_flushed(deferred, (x,))
             torch.autograd.backward(x_graph, pyramid_gradient(x, x_rpn, deferred))
             losses = {k: ([t.detach() for t in v] if isinstance(v, (list, tuple)) else v.detach()) for k, v in losses.items()}
             self._mark('mask branch + backbone backward')

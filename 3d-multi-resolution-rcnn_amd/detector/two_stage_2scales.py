@@ -16,7 +16,7 @@ from ..core.bbox import build_assigner, build_sampler, delta2bbox3D, bbox2roi3D
 from ..core.post_processing import multiclass_nms_3d
 from ..core.mask import mask_target_single
 from .heads import RPNHead3D, SharedFCBBoxHead3D, FCNMaskHead3D, rpn_get_bboxes_pair
-from .roi_extractor import SingleRoIExtractor, deferred_backward, pyramid_gradient
+from .roi_extractor import SingleRoIExtractor, assert_all_flushed, deferred_backward, pyramid_gradient
 from .two_stage import TwoStageDetector3D, bbox2result3D, PosCountReadback, MASK_BATCH_BUCKETS
 
 
@@ -182,6 +182,7 @@ class TwoStageDetector3D2Scales(TwoStageDetector3D):
             # the four extractors on pathway 1 and the one on pathway 2 were recorded (roi_extractor.deferred_backward): their
             # scatters go straight into the RPN branches' gradient buffers -- no zero-filled level buffers, no adds
             items = self._deferred_items
+            assert_all_flushed(items, (x, x_2))
             torch.autograd.backward(graph, pyramid_gradient(x, xr, items) + pyramid_gradient(x_2, xr_2, items))
             losses = {k: ([t.detach() for t in v] if isinstance(v, (list, tuple)) else v.detach()) for k, v in losses.items()}
         self.iteration += 1
