@@ -705,6 +705,10 @@ def main():
                                    'launch of this kernel inside the timed steps; the plan is not split (other kernels overlap '
                                    'it exactly as in production)',
                          'whole_step_frac': FLOP_FWD_BWD_512 * scale / (ms_per_step * 1e-3) / peak,
+                         'whole_step_flops_note': 'algorithmic 2*MAC of the dense convolutions of one forward+backward pass (1124.4 GFLOP on the '
+                                                  '512x512x80 volume); the Winograd kernels issue 1/3 - 2/3 of theirs on the matrix cores and the '
+                                                  'gather form of the stem weight gradient multiplies only the <= 1/8 of dy that the max-pool '
+                                                  'adjoint leaves non-zero (21.6 of 172.6 GFLOP, same result)',
                          'next_kernels': []},
         }
         for key in top:
