@@ -250,7 +250,8 @@ def test_stem_kernels_forward_and_wgrad(dev, n, dhw):
 
 
 @pytest.mark.parametrize('n,dhw,relu', [(1, (8, 32, 32), True), (2, (10, 40, 36), True), (1, (5, 70, 130), False), (1, (9, 17, 23), True),
-                                        (1, (16, 64, 64), True), (1, (7, 38, 90), True), (2, (3, 6, 10), False)])
+                                        (1, (16, 64, 64), True), (1, (7, 38, 90), True), (2, (3, 6, 10), False), (1, (1, 2, 2), True), (1, (2, 4, 6), False),
+                                        (3, (4, 8, 10), True), (1, (33, 34, 66), True)])
 def test_stem_wgrad_from_the_pooled_gradient(dev, n, dhw, relu):
     """mr3d_stem_conv_wgrad_pooled: conv -> (ReLU) -> MaxPool3d(3, 2, 1) differentiated by torch in fp64 (resnet3d.py:467-471)
     against the kernel that scatters the pooled gradient to its arg-max positions inside its dy staging; the pooled
