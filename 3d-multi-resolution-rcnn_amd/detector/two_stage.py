@@ -323,6 +323,7 @@ class TwoStageDetector3D(nn.Module):
             main.wait_stream(side)
             assert_all_flushed(deferred, (x,))
             torch.autograd.backward(x_graph, pyramid_gradient(x, x_rpn, deferred))
+            deferred.clear()                     # the recorded top gradients are not kept alive until the next step
             losses = {k: ([t.detach() for t in v] if isinstance(v, (list, tuple)) else v.detach()) for k, v in losses.items()}
             self._mark('mask branch + backbone backward')
         self.iteration += 1

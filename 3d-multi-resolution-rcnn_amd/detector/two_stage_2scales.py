@@ -184,6 +184,7 @@ class TwoStageDetector3D2Scales(TwoStageDetector3D):
             items = self._deferred_items
             assert_all_flushed(items, (x, x_2))
             torch.autograd.backward(graph, pyramid_gradient(x, xr, items) + pyramid_gradient(x_2, xr_2, items))
+            items.clear()                     # the recorded top gradients are not kept alive until the next step
             losses = {k: ([t.detach() for t in v] if isinstance(v, (list, tuple)) else v.detach()) for k, v in losses.items()}
         self.iteration += 1
         return losses
