@@ -49,8 +49,11 @@ def main():
     ap.add_argument('--density', type=float, default=1.0, help='fraction of pooled positions with a non-zero gradient')
     ap.add_argument('--shape', type=int, nargs=3, default=(80, 512, 512))
     ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32', help='storage type of the activations / gradients')
+    ap.add_argument('--tune', default='', help='key=value[,...] for mr3d_tuning_set')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
+    for kv in filter(None, a.tune.split(',')):
+        _hip.lib().mr3d_tuning_set(*(int(v) for v in kv.split('=')))
     d, h, w = a.shape
     g = torch.Generator(device=dev).manual_seed(0)
     x = torch.randn((1, 3, d, h, w), device=dev, generator=g)
