@@ -48,6 +48,10 @@ __device__ __forceinline__ float4 buffer_load4(__amdgpu_buffer_rsrc_t r, unsigne
   const buf_f32x4 v = __builtin_bit_cast(buf_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff_bytes, (int)soff_bytes, 0));
   return make_float4(v.x, v.y, v.z, v.w);
 }
+typedef float buf_f32x3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ buf_f32x3 buffer_load3(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
+  return __builtin_bit_cast(buf_f32x3, __builtin_amdgcn_raw_buffer_load_b96(r, (int)voff_bytes, (int)soff_bytes, 0));
+}
 __device__ __forceinline__ float buffer_load1(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff_bytes, (int)soff_bytes, 0));
 }

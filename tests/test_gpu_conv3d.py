@@ -93,8 +93,17 @@ def test_conv3d_forward_fused_epilogue(dev):
     _check(y3, ref3, 'fused upsample odd')
 
 
-def test_conv3d_forward_winograd_2d_large_map(dev):
-    """3x3x3 64 -> 64 on a map with >= 256 tiles of 2x8x8 takes the F(4,3) x F(2,3) kernel (csrc/conv3d_wino2d.hip): odd
+@pytest.fixture(params=[1, 2], ids=['tile2x8x8', 'wide4x8x8'])
+def wino2d_form(request):
+    """MR3D_TUNE_WINO2D_FORM: both kernels of csrc/conv3d_wino2d.hip on every case (left alone the library picks per map)"""
+    from mr3d_amd import _hip
+    _hip.lib().mr3d_tuning_set(5, request.param)
+    yield request.param
+    _hip.lib().mr3d_tuning_set(5, 0)
+
+
+def test_conv3d_forward_winograd_2d_large_map(dev, wino2d_form):
+    """3x3x3 64 -> 64 on a map with >= 256 tiles of 2x8x8 takes the F(4,3) x F(2,3) kernels (csrc/conv3d_wino2d.hip): odd
     extents (partial tiles on every axis), the whole fused epilogue, and the data-gradient use (ReLU mask) against an fp64 conv"""
     from mr3d_amd import _hip
     g = torch.Generator().manual_seed(5)

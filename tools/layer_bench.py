@@ -45,8 +45,13 @@ def timeit(fn, iters=5):
 
 def main():
     only = sys.argv[1] if len(sys.argv) > 1 else 'fwd'
+    for kv in filter(None, os.environ.get('MR3D_LB_TUNE', '').split(',')):       # key=value[,...] for mr3d_tuning_set
+        _hip.lib().mr3d_tuning_set(*(int(v) for v in kv.split('=')))
+    keep = os.environ.get('MR3D_LB_ONLY', '')                                     # substring of the layer names to run
     tot_t = tot_f = 0
     for name, ci, co, k, st, pad, dhw in LAYERS:
+        if keep and keep not in name:
+            continue
         x = torch.randn((1,) + dhw + (ci,), device=dev)
         w = torch.randn((k ** 3, ci, co), device=dev) * 0.05
         oshape = _hip.conv3d_out_shape(x.shape, co, (k,) * 3, st, (pad,) * 3)
