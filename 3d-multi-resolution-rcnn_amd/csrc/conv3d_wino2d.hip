@@ -528,63 +528,76 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wino2d_rows_kernel(Conv3dF
 // (the same 96 accumulator registers): every A fragment feeds two MFMAs and every U fragment feeds two -- half the L2 stream and half
 // the LDS reads per MFMA.  Eight waves = 4 fh rows x 2 Cout halves share the V of 32 GEMM rows (a 4 x 8 x 8 output tile: 6 halo planes
 // for 4 output planes instead of 4 for 2).  The fh rows are summed in the epilogue (Y = Ah^T (M Aw): each wave applies Aw to its own
-// row, the four rows meet in LDS).  One workgroup per CU, so the phases of a chunk are software-pipelined INSIDE the workgroup: V is
-// double-buffered (Cin chunks of 8), the halo of chunk c + 1 travels global -> registers -> LDS and its V is formed between the MFMA
-// steps of chunk c; two barriers per chunk.
+// row, the four rows meet in LDS).  One workgroup per CU, so the phases are software-pipelined INSIDE the workgroup, across chunks
+// and across tiles: V and the halo are double-buffered (Cin chunks of 8), the halo of chunk c + 2 travels global -> LDS while the V
+// of chunk c + 1 is formed between the MFMA steps of chunk c; a workgroup walks a sequence of tiles, and what lies behind a tile's last chunk is the next
+// tile's first.  Two barriers per chunk, both between MFMA steps whose operands are already in registers.
 // U layout for this form: [kd][ci][fh][co][6] (a lane's six fw products of its fh row in 24 bytes: two 12-byte loads per Cout tile).
 constexpr int kThreadsW = 512;
 #ifndef MR3D_WIDE_ABL
 #define MR3D_WIDE_ABL 0
 #endif
-constexpr int WABL = MR3D_WIDE_ABL;                    // timing-only ablations (tools/diag/wide_ablate.sh); 0 in the library
+constexpr int WABL = MR3D_WIDE_ABL;                    // timing-only ablations (tools/diag/wide_ablate_build.sh); 0 in the library
 constexpr int WTD = 4, WHD = WTD + 2;                  // output planes of a tile, halo planes
 constexpr int WC = 8;                                  // Cin chunk
-// halo [plane][row][12 positions][10 floats]: with these pitches the 64 lanes of a V-phase read (8 patches x 8 channels: patch row pair
-// -> 240 floats = 48 banks, patch column quad -> 40 floats = 8 banks, channel -> 1) hit 64 different banks
-constexpr int WROW = 10, WHWP = 12;
-constexpr int WHPLANE = HH * WHWP * WROW;              // 1200 floats
-constexpr int WHALO = WHD * WHPLANE;                   // 7200 floats
+// halo: 30 row pairs (6 planes x 10 rows) of 2 x 10 positions x 8 channels, one 264-float slot each, two buffers.  A slot is what ONE
+// `buffer_load_dwordx4 ... lds` writes (global -> LDS without a register stop: lane l's 16 bytes land at M0 + 16 l; lanes 0..39 carry the
+// 40 pieces of the row pair, the others -- and every piece outside the volume -- an offset beyond the descriptor's range, which writes
+// zeros: tools/micro/lds_dma_probe.hip).  264 = 8 mod 64 puts the 64 lanes of a V-unit read (8 patches x 8 channels: patch row pair
+// -> one slot = 8 banks, patch column quad -> 32 floats, channel -> 1) on 64 different banks.
+constexpr int WRP = 264;
+constexpr int WHBUF = 30 * WRP;                        // 7920 floats per halo buffer
 // V [(plane, patch)][fh][fw pair][ci][2] + 4: a lane's A fragments of two adjacent products are ONE ds_read_b64, and 196 = 4 mod 64
 // puts the 32 lanes of a read pass (16 rows x 2 k) on 64 different banks
 constexpr int WVP = 4 * 3 * WC * 2 + 4;                // 196
 constexpr int WV = WHD * 8 * WVP;                      // 9408 floats
-// epilogue exchange Z [fh][row 0..31][x 0..3][co 0..63], row pitch 260 floats (4 rows further = 16 banks further)
+// epilogue exchange of ONE row tile, Z [fh][row 0..15][x 0..3][co 0..63], row pitch 260 floats (4 rows further = 16 banks further): it
+// overlays V1 and halo buffer 0, which are free behind a tile's last chunk, while V0 already holds the next tile's first chunk and
+// halo buffer 1 receives its second
 constexpr int WZP = 4 * 64 + 4;
-constexpr int WZ = 4 * 32 * WZP;                       // 33,280 floats
-constexpr int WLDS_FLOATS = (2 * WV + WHALO) > WZ ? (2 * WV + WHALO) : WZ;
-constexpr int WLDS_BYTES = WLDS_FLOATS * 4;            // 133,120
+constexpr int WZ = 4 * 16 * WZP;                       // 16,640 floats
+static_assert(WZ <= WV + WHBUF, "one half of the epilogue exchange fits V1 | halo 0");
+constexpr int WLDS_BYTES = (2 * WV + 2 * WHBUF) * 4;   // 138,624
 
 template <bool LIVE>
 __global__ __launch_bounds__(kThreadsW, 2) void conv3d_wino2d_wide_kernel(Conv3dFwdArgs p, const float *__restrict__ U, int tiles_d,
-                                                                         int tiles_h, int tiles_w, int dbg) {
+                                                                         int tiles_h, int tiles_w) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *halo = lds + 2 * WV;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fh = wave & 3, ch = wave >> 2;               // this wave's row of products and its half of the 64-wide Cout tile
-  int b = blockIdx.x;
-  const int tw_i = b % tiles_w; b /= tiles_w;
-  const int th_i = b % tiles_h; b /= tiles_h;
-  const int td_i = b % tiles_d; b /= tiles_d;
-  const int n = b;
-  const int od0 = td_i * WTD, oh0 = th_i * TH, ow0 = tw_i * TW;
-  const int id0 = od0 - p.pd, ih0 = oh0 - p.ph, iw0 = ow0 - p.pw;
-  const float *xtile = p.x + ((((long long)n * p.D + id0) * p.H + ih0) * p.W + iw0) * p.Cin;
+  // ---- the tiles of this workgroup.  Workgroup b runs on XCD b & 7 (dispatch order): an XCD takes one contiguous eighth of the
+  // tiles and its workgroups walk it side by side, so that tiles with common halo planes meet in one L2.
+  const int T = p.N * tiles_d * tiles_h * tiles_w;
+  int t_cur, t_step, t_end;
+  if ((gridDim.x & 7) == 0) {
+    const int xcd = blockIdx.x & 7, per = (T + 7) >> 3;
+    t_cur = xcd * per + (int)(blockIdx.x >> 3); t_step = (int)(gridDim.x >> 3); t_end = min(T, (xcd + 1) * per);
+  } else {
+    t_cur = blockIdx.x; t_step = gridDim.x; t_end = T;
+  }
+  if (t_cur >= t_end) return;
+  struct Tile { int n, od0, oh0, ow0; };
+  auto tile_at = [&](int t) {
+    Tile r;
+    r.ow0 = (t % tiles_w) * TW; t /= tiles_w;
+    r.oh0 = (t % tiles_h) * TH; t /= tiles_h;
+    r.od0 = (t % tiles_d) * WTD; r.n = t / tiles_d;
+    return r;
+  };
   const int li = lane & 15, lk = lane >> 4;
   const int cobase = blockIdx.y * 64;
   // A operand: GEMM row li of row tile rt = (output plane 2 rt + (li >> 3), patch li & 7); k index lk of the k-step
   const int vlane = li * WVP + fh * (3 * WC * 2) + lk * 2;                                 // floats, inside a V buffer
   const unsigned ul_off = (unsigned)((lk * 4 * p.Cout + cobase + ch * 32 + li) * 6 * 4);   // bytes: (ci = lk, fh = 0, this lane's co)
-  const __amdgpu_buffer_rsrc_t ursrc = buffer_of(U), xrsrc = buffer_of(xtile);
+  const __amdgpu_buffer_rsrc_t ursrc = buffer_of(U);
 
-  unsigned long long stamp[13];
-  auto mark = [&](int k) { if (dbg & 32) stamp[k] = wall_clock64(); };
-  mark(0);
   f32x4 acc[24];                                         // [fw][rt][ct]
 #pragma unroll
   for (int f = 0; f < 24; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  float bq[3][12], aq[2][12];                            // U fragments [ct][fw] (three steps in flight), A fragments [rt][fw]
+  float bq[4][12], aq[2][6];                             // U fragments [ct][fw] (four steps in flight), A fragments [rt][fw] (half a step ahead)
   auto load_b = [&](float (&dst)[12], int c0, int kd, int kk) {
     const unsigned src = (unsigned)((((kd * p.Cin + c0 + kk * 4) * 4 + fh) * p.Cout) * 6 * 4);       // scalar byte offset
 #pragma unroll
@@ -595,61 +608,60 @@ __global__ __launch_bounds__(kThreadsW, 2) void conv3d_wino2d_wide_kernel(Conv3d
         dst[ct * 6 + hf * 3] = v.x; dst[ct * 6 + hf * 3 + 1] = v.y; dst[ct * 6 + hf * 3 + 2] = v.z;
       }
   };
-  auto load_a = [&](float (&dst)[12], const float *vbuf, int kd, int kk) {
+  auto load_a = [&](float (&dst)[6], const float *vbuf, int rt, int kd, int kk) {
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-      for (int fp = 0; fp < 3; ++fp) {
-        const float2 v = *reinterpret_cast<const float2 *>(vbuf + vlane + (2 * rt + kd) * 8 * WVP + fp * (WC * 2) + kk * 8);
-        dst[rt * 6 + fp * 2] = v.x; dst[rt * 6 + fp * 2 + 1] = v.y;
-      }
+    for (int fp = 0; fp < 3; ++fp) {
+      const float2 v = *reinterpret_cast<const float2 *>(vbuf + vlane + (2 * rt + kd) * 8 * WVP + fp * (WC * 2) + kk * 8);
+      dst[fp * 2] = v.x; dst[fp * 2 + 1] = v.y;
+    }
   };
-  // halo staging: 600 positions x 2 channel quads = 1200 pieces of 16 bytes, three rounds of 512 threads; a piece's source offset,
-  // LDS slot and validity are formed once
-  unsigned h_rel[3], h_dst[3], h_ok = 0;
-  const int s_plane = p.H * p.W * p.Cin, s_rowp = p.W * p.Cin;
+  // halo staging, global -> LDS: wave w requests the row pairs w, w + 8, w + 16, w + 24 (< 30) of a chunk, one instruction each.  A
+  // piece's byte offset in x is formed once per tile; outside the volume (and in lanes 40..63) it lies beyond the descriptor's range.
+  // The requests are inline assembly: the compiler's wait-count pass makes every later LDS read wait for an LDS-writing load it knows
+  // of, and these take an HBM round trip.  It does not count them, so its own vmcnt waits (for the U fragments) are at worst four
+  // entries stricter than needed; the wait for the halo itself is counted by hand (below).
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 xdesc = {(unsigned)(uintptr_t)p.x, (unsigned)((uintptr_t)p.x >> 32) & 0xffffu, 0x7fffffffu, 0x00020000u};
+  const unsigned lds_base = (unsigned)(uintptr_t)lds;    // LDS byte address of the dynamic array (the low half of its flat address)
+  auto halo_offsets = [&](const Tile &t, unsigned (&rel)[4]) {
+    const int id0 = t.od0 - p.pd, ih0 = t.oh0 - p.ph, iw0 = t.ow0 - p.pw;
+    const int origin = ((t.n * p.D + id0) * p.H + ih0) * p.W + iw0;                        // position index of the halo's corner (may be negative)
+    int lv = lane;                                       // (an opaque copy: the decomposition below is redone per call -- three times per tile --
+    asm volatile("" : "+v"(lv));                         //  instead of being kept in registers over the chunk loop, which has none to spare)
+    const int r2 = lv >= 20 ? 1 : 0, piece = lv - 20 * r2, hw = piece >> 1, q = piece & 1;      // lanes 0..39: row of the pair, piece of the row
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int id = tid + j * kThreadsW, pos = id >> 1, q = id & 1;
-    const int hd = pos / (HH * HW), rem = pos - hd * (HH * HW), hh = rem / HW, hw = rem - hh * HW;
-    const bool in = id < WHD * HH * HW * 2;
-    const bool ok = in && (unsigned)(id0 + hd) < (unsigned)p.D && (unsigned)(ih0 + hh) < (unsigned)p.H && (unsigned)(iw0 + hw) < (unsigned)p.W;
-    // a piece outside the volume reads beyond the descriptor's range (2^31 - 1 bytes): the load returns zeros and touches no
-    // memory, so the fetch is branch-free (loads under a lane mask made the compiler drain the whole vector-memory queue, the U
-    // fragments in flight with it, at every fetch and commit)
-    h_rel[j] = ok ? (unsigned)(hd * s_plane + hh * s_rowp + hw * p.Cin + q * 4) * 4u : 0xfffffff0u;
-    h_dst[j] = (unsigned)(((hd * HH + hh) * WHWP + hw) * WROW + q * 4);
-    h_ok |= (in ? 1u : 0u) << j;
-  }
-  float4 st[3];
-  auto fetch_all = [&](int c0) {
-#pragma unroll
-    for (int j = 0; j < 3; ++j) st[j] = buffer_load4(xrsrc, h_rel[j], (unsigned)c0 * 4u);
+    for (int i = 0; i < 4; ++i) {
+      const int row = 2 * (wave + 8 * i) + r2;           // (wave + 8 i < 30: the caller skips the others)
+      const int hd = (row * 205) >> 11, hh = row - hd * HH;                                // row / 10 for row < 64
+      const bool ok = lv < 40 && (unsigned)(id0 + hd) < (unsigned)p.D && (unsigned)(ih0 + hh) < (unsigned)p.H && (unsigned)(iw0 + hw) < (unsigned)p.W;
+      rel[i] = ok ? (unsigned)((origin + (hd * p.H + hh) * p.W + hw) * p.Cin + q * 4) * 4u : 0xfffffff0u;
+    }
   };
-  auto commit_all = [&]() {
+  auto halo_request = [&](const unsigned (&rel)[4], int c0, int buf) {          // chunk c0 .. c0 + 7 of a tile into halo buffer buf
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
-      if (j < 2 || ((h_ok >> j) & 1u)) {                 // (rounds 0 and 1 are whole: 1024 of the 1200 pieces)
-        float2 *dd = reinterpret_cast<float2 *>(halo + h_dst[j]);
-        dd[0] = make_float2(st[j].x, st[j].y); dd[1] = make_float2(st[j].z, st[j].w);
+    for (int i = 0; i < 4; ++i)
+      if (i < 3 || wave < 6) {                           // (wave-uniform; row pairs 30, 31 do not exist)
+        const unsigned m0 = lds_base + (unsigned)((2 * WV + buf * WHBUF + (wave + 8 * i) * WRP) * 4);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                     : : "s"(m0), "v"(rel[i]), "s"(xdesc), "s"((unsigned)c0 * 4u) : "memory");      // (m0: nothing else in this kernel uses it)
       }
   };
   // V = Bh^T d Bw of a chunk: 6 planes x 8 patches x 8 channels = 384 windows.  A wave only ever multiplies the fh row of V it owns,
   // and that row needs two rows of a window (d0 - d2, d1 + d2, d2 - d1, d1 - d3): wave (fh, ch) forms row fh of the planes 3 ch ..
   // 3 ch + 2, one plane = one unit of 12 LDS reads, 21 vector instructions and 3 LDS writes per lane (lane = patch x channel) -- three
-  // equal units per wave and chunk, issued between its MFMA steps.  (The first version formed whole windows on six of the eight
-  // waves: the two SIMDs with two such waves were the chunk's critical path.)
+  // equal units per wave and chunk.  A unit's reads are requested in FRONT of an MFMA step, its arithmetic and writes follow the
+  // step (both waves of a SIMD run the same phase at the same time: a read waited for behind the MFMAs is latency nobody covers).
+  // (The first version formed whole windows on six of the eight waves: the two SIMDs with two such waves were the critical path.)
   const int vf_ra = fh == 0 ? 0 : (fh == 2 ? 2 : 1), vf_rb = fh == 3 ? 3 : (fh == 2 ? 1 : 2);
   const float vf_sg = fh == 1 ? 1.f : -1.f;
-  const int vf_src = (3 * ch) * WHPLANE + ((((lane >> 3) >> 1) * 2) * WHWP + ((lane >> 3) & 1) * 4) * WROW + (lane & 7);
+  // halo row r = 10 plane + hh sits in slot r >> 1 at (r & 1) * 80 floats; a patch's window starts on an even row
+  const int vf_src = (3 * ch * 5 + ((lane >> 3) >> 1)) * WRP + ((lane >> 3) & 1) * 32 + (lane & 7);
   const int vf_dst = (3 * ch * 8 + (lane >> 3)) * WVP + fh * (3 * WC * 2) + (lane & 7) * 2;
-  // a unit in two parts: its 12 LDS reads are requested in FRONT of an MFMA step, the arithmetic and the writes follow the step (both
-  // waves of a SIMD run the same phase at the same time: a read waited for behind the MFMAs is latency nobody covers)
   float vd[12];
-  auto vunit_read = [&](int k) {
-    const float *sa = halo + vf_src + k * WHPLANE + vf_ra * (WHWP * WROW), *sb = halo + vf_src + k * WHPLANE + vf_rb * (WHWP * WROW);
+  auto vunit_read = [&](const float *hbuf, int k) {
+    const float *sa = hbuf + vf_src + (k * 5 + (vf_ra >> 1)) * WRP + (vf_ra & 1) * 80, *sb = hbuf + vf_src + (k * 5 + (vf_rb >> 1)) * WRP + (vf_rb & 1) * 80;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) { vd[j] = sa[j * WROW]; vd[6 + j] = sb[j * WROW]; }
+    for (int j = 0; j < 6; ++j) { vd[j] = sa[j * 8]; vd[6 + j] = sb[j * 8]; }
   };
   auto vunit_finish = [&](float *vdst, int k) {
     float t[6];
@@ -661,158 +673,186 @@ __global__ __launch_bounds__(kThreadsW, 2) void conv3d_wino2d_wide_kernel(Conv3d
     dd[WC] = make_float2((t[4] - t[3]) + 4.f * (t[1] - t[2]), e + 2.f * o);
     dd[2 * WC] = make_float2(e - 2.f * o, 4.f * t[1] - 5.f * t[3] + t[5]);
   };
-  // one (kd, k-step) s = 0..5 of chunk c: 24 MFMAs on aq[s & 1] and bq[s % 3]; the A fragments of step s + 1 (LDS) and the U fragments
-  // of step s + 2 (L2; of the next chunk behind step 3) are requested in front of them
-  auto step = [&](int s, int c0, const float *vcur, const float *vnext, int unit = -1) {
-    const int s2 = s + 2;
-    if (unit >= 0 && !(WABL & 1)) vunit_read(unit);
+  // one (kd, k-step) s = 0..5 of a chunk (par: its parity -- chunks are taken in pairs, 12 steps, so that the four U buffers rotate
+  // with compile-time indices): 24 MFMAs on aq[s & 1] and bq[(6 par + s) % 4].  In front of them the requests: the A fragments of
+  // step s + 1 (LDS; behind step 5: step 0 of the next chunk) and the U fragments of step s + 3 (L2; behind the last chunk: chunk 0
+  // again -- the next tile's).  Three steps, not two: the older wave of a SIMD wins every MFMA issue slot, so the two waves run their
+  // steps one after the other rather than interleaved, and the one that runs alone covers two steps in 0.7 us -- less than an L2
+  // round trip under this load.
+  auto step = [&](int par, int s, int c0, const float *vcur, const float *vnext, int unit = -1) {
+    const int s12 = par * 6 + s, s3 = s + 3;
+    if (unit >= 0 && !(WABL & 1)) vunit_read(halo + (1 - par) * WHBUF, unit);      // the next chunk's halo
     if (WABL & 4) {}
-    else if (s2 < 6) load_b(bq[s2 % 3], c0, s2 / 2, s2 % 2);
-    else load_b(bq[s2 % 3], c0 + WC < p.Cin ? c0 + WC : 0, (s2 - 6) / 2, (s2 - 6) % 2);      // (behind the last chunk: chunk 0 again, unused)
-    if (s + 1 < 6) load_a(aq[(s + 1) & 1], vcur, (s + 1) / 2, (s + 1) % 2);
-    else load_a(aq[0], vnext, 0, 0);                     // step 0 of the next chunk (its V is complete: the barrier in front of step 5)
+    else if (s3 < 6) load_b(bq[(s12 + 3) % 4], c0, s3 / 2, s3 % 2);
+    else load_b(bq[(s12 + 3) % 4], c0 + WC < p.Cin ? c0 + WC : 0, (s3 - 6) / 2, (s3 - 6) % 2);
+    // A fragments half a step ahead: row tile 1's (this step) while row tile 0's MFMAs run, then row tile 0's of the next step
+    load_a(aq[1], vcur, 1, s / 2, s % 2);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int fw = 0; fw < 6; ++fw)
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
+      for (int ct = 0; ct < 2; ++ct)
+        acc[(fw * 2 + 0) * 2 + ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[0][fw], bq[s12 % 4][ct * 6 + fw], acc[(fw * 2 + 0) * 2 + ct], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 1 < 6) load_a(aq[0], vcur, 0, (s + 1) / 2, (s + 1) % 2);
+    else load_a(aq[0], vnext, 0, 0, 0);                  // step 0 of the next chunk (its V is complete: barrier 2 sits in front of step 5)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int fw = 0; fw < 6; ++fw)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+        acc[(fw * 2 + 1) * 2 + ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[1][fw], bq[s12 % 4][ct * 6 + fw], acc[(fw * 2 + 1) * 2 + ct], 0, 0, 0);
+  };
+
+  // ---- epilogue of one tile, a row tile (2 output planes) at a time: z = (M Aw) of this wave's fh row into Z, then per output
+  // Y = Ah^T z over the four rows + the fused tail, 16-byte stores.  Ends behind a barrier (the halo region is free again).
+  const int xstep = p.ysw * p.Cout * 4, rowstep = p.ysh * p.yW * p.Cout * 4, planestep = p.ysd * p.yH * p.yW * p.Cout * 4;   // bytes
+  auto epilogue = [&](const Tile &t, bool zero) {
+    float *Z = lds + WV;
+    int tv = tid;                                        // (an opaque copy: what is derived from it stays inside the epilogue instead of
+    asm volatile("" : "+v"(tv));                         //  being hoisted over the chunk loop, which has no registers to spare)
+    const int q = tv & 15, row = (tv >> 4) & 15, xp = tv >> 8;         // thread: GEMM row of the row tile x four output channels x two of the four columns
+    const int co = cobase + q * 4;
+    const float4 sh4 = p.shift ? *reinterpret_cast<const float4 *>(p.shift + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int dh = ((row >> 1) & 3) * 2, dw = (row & 1) * 4 + xp * 2;
+    const size_t ybase = ((((size_t)t.n * p.yD + (size_t)t.od0 * p.ysd) * p.yH + (size_t)t.oh0 * p.ysh) * p.yW + (size_t)t.ow0 * p.ysw) * p.Cout;
+    const char *add1b = p.add1 ? reinterpret_cast<const char *>(p.add1 + ybase) : nullptr;
+    const char *add2b = p.add2 ? reinterpret_cast<const char *>(p.add2 + ybase) : nullptr;
+    const char *maskb = p.mask ? reinterpret_cast<const char *>(p.mask + ybase) : nullptr;
+    char *yb = reinterpret_cast<char *>(p.y + ybase);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      if (!zero) {
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
-          acc[(fw * 2 + rt) * 2 + ct] =
-              __builtin_amdgcn_mfma_f32_16x16x4f32(aq[s & 1][rt * 6 + fw], bq[s % 3][ct * 6 + fw], acc[(fw * 2 + rt) * 2 + ct], 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float m0 = acc[(0 * 2 + rt) * 2 + ct][r], m1 = acc[(1 * 2 + rt) * 2 + ct][r], m2 = acc[(2 * 2 + rt) * 2 + ct][r],
+                        m3 = acc[(3 * 2 + rt) * 2 + ct][r], m4 = acc[(4 * 2 + rt) * 2 + ct][r], m5 = acc[(5 * 2 + rt) * 2 + ct][r];
+            const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+            float *zz = Z + (fh * 16 + lk * 4 + r) * WZP + ch * 32 + ct * 16 + li;
+            zz[0] = (m0 + s12) + s34; zz[64] = d12 + 2.f * d34; zz[128] = s12 + 4.f * s34; zz[192] = (d12 + 8.f * d34) + m5;
+          }
+        __syncthreads();
+      }
+      const int od = t.od0 + 2 * rt + (row >> 3);
+      auto emit = [&](unsigned rel, int oh, int ow, float4 v) {
+        if (od < p.Do && oh < p.Ho && ow < p.Wo) {
+          v.x += sh4.x; v.y += sh4.y; v.z += sh4.z; v.w += sh4.w;
+          if (add1b) { const float4 a = *reinterpret_cast<const float4 *>(add1b + rel); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+          if (add2b) { const float4 a = *reinterpret_cast<const float4 *>(add2b + rel); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+          if (p.up) {
+            auto nearest = [](int dst, int in, int out) {          // torch nearest: min(floor(dst * (in/out)), in-1)
+              const int s_ = (int)floorf((float)dst * ((float)in / (float)out));
+              return s_ < in - 1 ? s_ : in - 1;
+            };
+            const int ud = nearest(od, p.Du, p.Do), uh = nearest(oh, p.Hu, p.Ho), uw = nearest(ow, p.Wu, p.Wo);
+            const float4 a = *reinterpret_cast<const float4 *>(p.up + ((((size_t)t.n * p.Du + ud) * p.Hu + uh) * p.Wu + uw) * p.Cout + co);
+            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+          }
+          if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          if (maskb) {
+            const float4 m = *reinterpret_cast<const float4 *>(maskb + rel);
+            v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+          }
+          *reinterpret_cast<float4 *>(yb + rel) = v;
+        }
+      };
+      const unsigned rel0 = (unsigned)((2 * rt + (row >> 3)) * planestep + dh * rowstep + dw * xstep + co * 4);
+#pragma unroll
+      for (int xi = 0; xi < 2; ++xi) {
+        float4 z[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          z[g] = zero ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4 *>(Z + (g * 16 + row) * WZP + (xp * 2 + xi) * 64 + q * 4);
+        const float4 y0 = make_float4((z[0].x + z[1].x) + z[2].x, (z[0].y + z[1].y) + z[2].y, (z[0].z + z[1].z) + z[2].z, (z[0].w + z[1].w) + z[2].w);
+        const float4 y1 = make_float4((z[1].x - z[2].x) - z[3].x, (z[1].y - z[2].y) - z[3].y, (z[1].z - z[2].z) - z[3].z, (z[1].w - z[2].w) - z[3].w);
+        emit(rel0 + xi * xstep, t.oh0 + dh, t.ow0 + dw + xi, y0);
+        emit(rel0 + xi * xstep + rowstep, t.oh0 + dh + 1, t.ow0 + dw + xi, y1);
+      }
+      if (!zero) __syncthreads();
+    }
   };
-  bool dead = false;
-  if constexpr (LIVE) {                                  // lane r < 60 tests the 10 voxels of halo row (plane r / 10, row r % 10)
+
+  Tile tile = tile_at(t_cur);
+  if constexpr (LIVE) {                                  // one tile per workgroup (mr3d_conv3d_wino2d launches this instance so)
+    // lane r < 60 tests the 10 voxels of halo row (plane r / 10, row r % 10); all clear = nothing to multiply
+    const int id0 = tile.od0 - p.pd, ih0 = tile.oh0 - p.ph, iw0 = tile.ow0 - p.pw;
     const int hd = lane / HH, hh = lane - hd * HH;
     const int id = id0 + hd, ih = ih0 + hh;
     unsigned bits = 0;
     if (lane < WHD * HH && (unsigned)id < (unsigned)p.D && (unsigned)ih < (unsigned)p.H) {
       const int w_lo = max(iw0, 0), w_hi = min(iw0 + HW, p.W);
-      const long long b0 = (((long long)n * p.D + id) * p.H + ih) * p.W + w_lo;
+      const long long b0 = (((long long)tile.n * p.D + id) * p.H + ih) * p.W + w_lo;
       const unsigned *wd = reinterpret_cast<const unsigned *>(p.x_live) + (b0 >> 5);
       const int sh = (int)(b0 & 31), cnt = w_hi - w_lo;
       const unsigned long long two = (unsigned long long)wd[0] | ((unsigned long long)(sh + cnt > 32 ? wd[1] : 0u) << 32);
       bits = (unsigned)(two >> sh) & ((1u << cnt) - 1u);
     }
-    dead = __ballot(bits != 0) == 0;                     // (every wave tests the same rows: uniform over the workgroup)
+    if (__ballot(bits != 0) == 0) {                      // (every wave tests the same rows: uniform over the workgroup)
+      epilogue(tile, true);
+      return;
+    }
   }
-  const int nc = dead ? 0 : p.Cin / WC;
-  if (nc > 0) {
-    load_b(bq[0], 0, 0, 0);
-    load_b(bq[1], 0, 0, 1);
-    fetch_all(0);
-    commit_all();
-    __syncthreads();
+  const int nc = p.Cin / WC;                             // even (Cin is a multiple of 16): a tile starts on V0 and ends on V1
+  unsigned rel_c[4];                                     // halo piece offsets of this tile (the next tile's are formed where they are used)
+  halo_offsets(tile, rel_c);
+  int t_next = t_cur + t_step < t_end ? t_cur + t_step : -1;
+  Tile tnext = tile_at(t_next < 0 ? t_cur : t_next);
+  // pipeline fill: chunk 0 of the first tile
+  load_b(bq[0], 0, 0, 0);
+  load_b(bq[1], 0, 0, 1);
+  load_b(bq[2], 0, 1, 0);
+  halo_request(rel_c, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { vunit_read(k); vunit_finish(lds, k); }
-    fetch_all(nc > 1 ? WC : 0);
-    __syncthreads();
-    load_a(aq[0], lds, 0, 0);
-  }
-  // The loop body carries no branch around a memory request: what lies behind the last chunk is requested again from inside the
-  // tile (the last chunk's halo, chunk 0's U) and dropped.  Both barriers sit between MFMA steps whose operands are in registers.
-  for (int c = 0; c < nc; ++c) {
-    const float *vcur = lds + (c & 1) * WV;
-    float *vnext = lds + ((c + 1) & 1) * WV;
+  for (int k = 0; k < 3; ++k) { vunit_read(halo, k); vunit_finish(lds, k); }
+  halo_request(rel_c, WC, 1);
+  __syncthreads();
+  load_a(aq[0], lds, 0, 0, 0);
+  bool filling = true;                                   // the very first chunk: fewer requests lie between its halo and barrier 1
+  // The loop body carries no branch around a compiler-visible memory request: behind the last tile's last chunk the same tile is requested again and dropped.
+  auto chunk = [&](int par, int c) {                     // V[par] -> MFMAs; V[1 - par] <- halo[1 - par] (the next chunk); halo[par] <- the chunk after it
+    const float *vcur = lds + par * WV;
+    float *vnext = lds + (1 - par) * WV;
     const int c0 = c * WC;
-    if (c == 0) mark(1);
-    if (c == 3) mark(2);
-    step(0, c0, vcur, vnext);
-    if (!(WABL & 2)) commit_all();                                        // the halo of chunk c + 1 (the units that read the halo last are behind barrier 2)
-    if (c == 3) mark(3);
-    step(1, c0, vcur, vnext);
-    if (!(WABL & 2)) fetch_all((c + 2 < nc ? c + 2 : nc - 1) * WC);
-    if (c == 3) mark(4);
-    if (!(WABL & 16)) __syncthreads();                                     // 1: the halo of chunk c + 1 is complete
-    if (c == 3) mark(5);
-    step(2, c0, vcur, vnext, 0);
+    step(par, 0, c0, vcur, vnext);
+    step(par, 1, c0, vcur, vnext);
+    // the next chunk's halo was requested one chunk ago; the requests behind it are the U fragments of six steps (24; sched_barriers
+    // pin each step's four in front of its MFMAs) -- two steps in the first chunk
+    if (filling) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    filling = false;
+    if (!(WABL & 16)) __syncthreads();                   // 1: the next chunk's halo is complete; halo[par] (read one chunk ago) is free
+    if (!(WABL & 2)) {                                   // the chunk after the next: of this tile, or chunk 0 / 1 of the next tile
+      const bool wrap = c + 2 >= nc;
+      unsigned r[4] = {rel_c[0], rel_c[1], rel_c[2], rel_c[3]};
+      if (wrap) halo_offsets(tnext, r);
+      halo_request(r, (wrap ? c + 2 - nc : c + 2) * WC, par);
+    }
+    step(par, 2, c0, vcur, vnext, 0);
     if (!(WABL & 1)) vunit_finish(vnext, 0);
-    if (c == 3) mark(6);
-    step(3, c0, vcur, vnext, 1);
+    step(par, 3, c0, vcur, vnext, 1);
     if (!(WABL & 1)) vunit_finish(vnext, 1);
-    step(4, c0, vcur, vnext, 2);
+    step(par, 4, c0, vcur, vnext, 2);
     if (!(WABL & 1)) vunit_finish(vnext, 2);
-    if (c == 3) mark(7);
-    if (!(WABL & 16)) __syncthreads();                                     // 2: V of chunk c + 1 is complete; the halo is free
-    if (c == 3) mark(8);
-    step(5, c0, vcur, vnext);
-    if (c == 3) mark(9);
-  }
-  __syncthreads();                                       // every wave is done with V: Z overlays it
-  if (WABL & 8) { float t_ = 0.f; for (int f = 0; f < 24; ++f) t_ += acc[f][0] + acc[f][1] + acc[f][2] + acc[f][3]; if (t_ == 123.456f) p.y[0] = t_; return; }
-  mark(10);
-
-  // ---- epilogue: z = (M Aw) of this wave's fh row into Z, then per output Y = Ah^T z over the four rows + the fused tail
-  float *Z = lds;
-  if (!dead) {
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float m0 = acc[(0 * 2 + rt) * 2 + ct][r], m1 = acc[(1 * 2 + rt) * 2 + ct][r], m2 = acc[(2 * 2 + rt) * 2 + ct][r],
-                      m3 = acc[(3 * 2 + rt) * 2 + ct][r], m4 = acc[(4 * 2 + rt) * 2 + ct][r], m5 = acc[(5 * 2 + rt) * 2 + ct][r];
-          const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
-          float *zz = Z + (fh * 32 + rt * 16 + lk * 4 + r) * WZP + ch * 32 + ct * 16 + li;
-          zz[0] = (m0 + s12) + s34; zz[64] = d12 + 2.f * d34; zz[128] = s12 + 4.f * s34; zz[192] = (d12 + 8.f * d34) + m5;
-        }
-    __syncthreads();
-  }
-  mark(11);
-  const int q = tid & 15, row = tid >> 4;                 // thread: GEMM row (2 x 4 outputs) x four output channels
-  const int co = cobase + q * 4;
-  const int dz = row >> 3, dh = ((row >> 1) & 3) * 2, dw = (row & 1) * 4;
-  const int od = od0 + dz;
-  const float4 sh4 = p.shift ? *reinterpret_cast<const float4 *>(p.shift + co) : make_float4(0.f, 0.f, 0.f, 0.f);
-  const size_t ybase = ((((size_t)n * p.yD + (size_t)od0 * p.ysd) * p.yH + (size_t)oh0 * p.ysh) * p.yW + (size_t)ow0 * p.ysw) * p.Cout;
-  const char *add1b = p.add1 ? reinterpret_cast<const char *>(p.add1 + ybase) : nullptr;
-  const char *add2b = p.add2 ? reinterpret_cast<const char *>(p.add2 + ybase) : nullptr;
-  const char *maskb = p.mask ? reinterpret_cast<const char *>(p.mask + ybase) : nullptr;
-  char *yb = reinterpret_cast<char *>(p.y + ybase);
-  const int xstep = p.ysw * p.Cout * 4, rowstep = p.ysh * p.yW * p.Cout * 4, planestep = p.ysd * p.yH * p.yW * p.Cout * 4;   // bytes
-  auto emit = [&](unsigned rel, int oh, int ow, float4 v) {
-    if (od < p.Do && oh < p.Ho && ow < p.Wo) {
-      v.x += sh4.x; v.y += sh4.y; v.z += sh4.z; v.w += sh4.w;
-      if (add1b) { const float4 a = *reinterpret_cast<const float4 *>(add1b + rel); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
-      if (add2b) { const float4 a = *reinterpret_cast<const float4 *>(add2b + rel); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
-      if (p.up) {
-        auto nearest = [](int dst, int in, int out) {          // torch nearest: min(floor(dst * (in/out)), in-1)
-          const int s_ = (int)floorf((float)dst * ((float)in / (float)out));
-          return s_ < in - 1 ? s_ : in - 1;
-        };
-        const int ud = nearest(od, p.Du, p.Do), uh = nearest(oh, p.Hu, p.Ho), uw = nearest(ow, p.Wu, p.Wo);
-        const float4 a = *reinterpret_cast<const float4 *>(p.up + ((((size_t)n * p.Du + ud) * p.Hu + uh) * p.Wu + uw) * p.Cout + co);
-        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-      }
-      if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      if (maskb) {
-        const float4 m = *reinterpret_cast<const float4 *>(maskb + rel);
-        v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
-      }
-      *reinterpret_cast<float4 *>(yb + rel) = v;
-    }
+    if (!(WABL & 16)) __syncthreads();                   // 2: V of the next chunk is complete; V of this chunk (behind step 4's reads) is free
+    step(par, 5, c0, vcur, vnext);
   };
-  const unsigned rel0 = (unsigned)(dz * planestep + dh * rowstep + dw * xstep + co * 4);
-#pragma unroll
-  for (int x = 0; x < 4; ++x) {
-    float4 z[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-      z[g] = dead ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4 *>(Z + (g * 32 + row) * WZP + x * 64 + q * 4);
-    const float4 y0 = make_float4((z[0].x + z[1].x) + z[2].x, (z[0].y + z[1].y) + z[2].y, (z[0].z + z[1].z) + z[2].z, (z[0].w + z[1].w) + z[2].w);
-    const float4 y1 = make_float4((z[1].x - z[2].x) - z[3].x, (z[1].y - z[2].y) - z[3].y, (z[1].z - z[2].z) - z[3].z, (z[1].w - z[2].w) - z[3].w);
-    emit(rel0 + x * xstep, oh0 + dh, ow0 + dw + x, y0);
-    emit(rel0 + x * xstep + rowstep, oh0 + dh + 1, ow0 + dw + x, y1);
-  }
-  if (dbg & 32) {
-    mark(12);
-    __syncthreads();
-    if (lane == 0) {
-      unsigned long long *o = reinterpret_cast<unsigned long long *>(p.y) + ((size_t)blockIdx.x * 8 + wave) * 16;
-#pragma unroll
-      for (int k = 0; k < 13; ++k) o[k] = stamp[k];
+  for (;;) {
+    for (int c = 0; c < nc; c += 2) {
+      chunk(0, c);
+      chunk(1, c + 1);
     }
+    if (!(WABL & 8)) epilogue(tile, false);              // Z overlays V1 | halo 0; V0 holds the next tile's first chunk, halo 1 receives its second
+#pragma unroll
+    for (int f = 0; f < 24; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (t_next < 0) break;
+    t_cur = t_next; tile = tnext;
+    halo_offsets(tile, rel_c);
+    t_next = t_cur + t_step < t_end ? t_cur + t_step : -1;
+    tnext = tile_at(t_next < 0 ? t_cur : t_next);
   }
 }
 
@@ -968,15 +1008,19 @@ int mr3d_conv3d_wino2d(const Conv3dFwdArgs &a, hipStream_t stream) {
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
   });
   if (!attr_ok) return MR3D_ERR_LAUNCH;
-  // wide form (4 x 8 x 8 tiles, one 512-thread workgroup per CU): maps with at least two rounds of such tiles
+  // wide form (4 x 8 x 8 tiles, one persistent 512-thread workgroup per CU): maps with at least two rounds of such tiles
   const int form = g_mr3d_tuning[MR3D_TUNE_WINO2D_FORM];
   const int tiles_dw = (a.Do + WTD - 1) / WTD;
   const long long wide_tiles = (long long)a.N * tiles_dw * tiles_h * tiles_w;
-  if ((form & 15) == 2 || (form == 0 && wide_tiles >= 2LL * cus)) {
+  const bool wide_fits = (long long)a.N * a.D * a.H * a.W * a.Cin * 4 < (1LL << 31) && wide_tiles < (1LL << 30);      // 32-bit byte offsets into x
+  if (wide_fits && (form == 2 || (form == 0 && wide_tiles >= 2LL * cus))) {
     const float *Uw = U + u_layout_floats(a.Cin, a.Cout);
-    dim3 grid((unsigned)wide_tiles, (unsigned)(a.Cout / 64));
-    if (a.x_live) conv3d_wino2d_wide_kernel<true><<<grid, kThreadsW, WLDS_BYTES, stream>>>(a, Uw, tiles_dw, tiles_h, tiles_w, form >> 4);
-    else conv3d_wino2d_wide_kernel<false><<<grid, kThreadsW, WLDS_BYTES, stream>>>(a, Uw, tiles_dw, tiles_h, tiles_w, form >> 4);
+    if (a.x_live) {                                      // one tile per workgroup: an all-dead halo leaves through the epilogue at once
+      conv3d_wino2d_wide_kernel<true><<<dim3((unsigned)wide_tiles, (unsigned)(a.Cout / 64)), kThreadsW, WLDS_BYTES, stream>>>(a, Uw, tiles_dw, tiles_h, tiles_w);
+    } else {
+      const unsigned wgs = (unsigned)(wide_tiles < cus ? wide_tiles : cus);
+      conv3d_wino2d_wide_kernel<false><<<dim3(wgs, (unsigned)(a.Cout / 64)), kThreadsW, WLDS_BYTES, stream>>>(a, Uw, tiles_dw, tiles_h, tiles_w);
+    }
     return mr3d_launch_status();
   }
   const int tiles_d = (a.Do + TD - 1) / TD;
