@@ -35,6 +35,10 @@
 namespace {
 
 constexpr int kThreads = 256;
+#ifndef MR3D_ROWS_ABL
+#define MR3D_ROWS_ABL 0
+#endif
+constexpr int RABL = MR3D_ROWS_ABL;                    // timing-only ablations of conv3d_wino2d_rows_kernel (tools/diag); 0 in the library
 
 constexpr int TD = 2, TH = 8, TW = 8;                  // output tile: 16 GEMM rows (patches of 2 x 4 outputs)
 constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;   // halo
@@ -392,16 +396,17 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wino2d_rows_kernel(Conv3dF
   // of its MFMAs instead of waiting for the other wave of the SIMD to be out of phase
   auto step = [&](int s, int c0, const float (&av)[MT][NF], const float (&bw)[NF], float (&an)[MT][NF], float (&bnx)[NF]) {
     const bool more = s + 1 < 12;
-    if (more) load_b(bnx, c0, (s + 1) / 4, (s + 1) % 4);
+    if (RABL & 1) {}
+    else if (more) load_b(bnx, c0, (s + 1) / 4, (s + 1) % 4);
     else if (c0 + CC < p.Cin) load_b(bnx, c0 + CC, 0, 0);
-    if (more) read_d((s + 1) / 4, (s + 1) % 4);
+    if (more && !(RABL & 2)) read_d((s + 1) / 4, (s + 1) % 4);
     __builtin_amdgcn_sched_barrier(0);                   // the requests stay up here: the scheduler would sink them next to their uses
 #pragma unroll
     for (int fh = 0; fh < 4; ++fh)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         mma(mt, fh, av[mt], bw);
-        if (more) xform(mt, fh, an[mt]);
+        if (more && !(RABL & 4)) xform(mt, fh, an[mt]);
       }
   };
 

@@ -128,6 +128,38 @@ def test_conv3d_forward_winograd_2d_large_map(dev, wino2d_form):
     assert l2 <= 1e-5, f'L2-relative error {l2:.3e}'
 
 
+def test_conv3d_forward_winograd_2d_wide_form_walks_tiles(dev):
+    """The wide kernel's workgroups are persistent: 256 of them walk the tiles of a launch, an XCD's 32 side by side over one eighth
+    of the tile range, with the chunk pipeline running across tile borders (the next tile's halo and first V are requested inside the
+    current tile's last chunks).  Two images, ragged extents (1080 tiles of 4x8x8: 135 per XCD, 4.2 per workgroup, so ranges end
+    mid-row and some workgroups take one tile more than others), the fused tail -- against the 2x8x8-tile kernel (itself checked
+    against fp64 above) and, on a window, against an fp64 conv."""
+    from mr3d_amd import _hip
+    g = torch.Generator().manual_seed(11)
+    dhw = (21, 70, 75)
+    x = torch.randn((2, 64) + dhw, generator=g)
+    w = torch.randn((64, 64, 3, 3, 3), generator=g) / np.sqrt(64 * 27)
+    shift = torch.randn(64, generator=g)
+    add1 = torch.randn((2, 64) + dhw, generator=g)
+    xd, wp, sd, ad = _cl(x).to(dev), _hip.pack_conv_weight(w).to(dev), shift.to(dev), _cl(add1).to(dev)
+    ys = {}
+    for form in (1, 2):
+        _hip.lib().mr3d_tuning_set(5, form)
+        try:
+            ys[form] = _hip.conv3d_forward(xd, wp, (3, 3, 3), (1, 1, 1), (1, 1, 1), shift=sd, add1=ad, relu=True)
+        finally:
+            _hip.lib().mr3d_tuning_set(5, 0)
+    scale = ys[1].abs().max().item()
+    assert (ys[1] - ys[2]).abs().max().item() <= 2e-5 * scale
+    # a window that spans tile borders on every axis and the seam between the two images' tile ranges, in fp64
+    win = (slice(15, 21), slice(58, 70), slice(60, 75))
+    xin = x[:, :, 13:21, 56:70, 58:75].double()                 # the window's halo (the volume's far faces pad with zeros)
+    ref = F.conv3d(F.pad(xin, (0, 1, 0, 1, 0, 1)), w.double(), shift.double())[:, :, 1:, 1:, 1:]
+    ref = torch.relu(ref + add1[(slice(None), slice(None)) + win].double())
+    got = ys[2].permute(0, 4, 1, 2, 3)[(slice(None), slice(None)) + win].cpu().double()
+    assert (got - ref).abs().max().item() <= 3e-5 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize('c,dhw', [(16, (19, 67, 75)), (32, (13, 61, 70))])
 def test_conv3d_forward_winograd_2d_narrow_cout(dev, c, dhw):
     """3x3x3 16 -> 16 / 32 -> 32 on maps with >= 256 tiles take the row-split F(4,3) x F(2,3) kernels (conv3d_wino2d_rows_kernel):
@@ -516,7 +548,7 @@ def test_conv3d_wgrad_winograd_path_ragged_volume(dev):
     assert rel(dw, 2 * ref) <= RTOL
 
 
-def test_conv3d_forward_liveness_bitmap_writes_dead_tiles_from_the_epilogue(dev):
+def test_conv3d_forward_liveness_bitmap_writes_dead_tiles_from_the_epilogue(dev, wino2d_form):
     """mr3d_voxel_liveness + mr3d_conv3d_desc.x_live (data gradients of sparse maps in detector training): the bitmap holds exactly
     the positions with a non-zero channel, and the large-map 3x3x3 kernel given the bitmap returns what it returns without it -- on a
     map with a few non-zero boxes and single voxels (on tile corners, on the volume's faces, a lone -0.0 that does not count), with
