@@ -543,6 +543,12 @@ constexpr int kThreadsW = 512;
 #define MR3D_WIDE_ABL 0
 #endif
 constexpr int WABL = MR3D_WIDE_ABL;                    // timing-only ablations (tools/diag/wide_ablate_build.sh); 0 in the library
+#ifdef MR3D_WIDE_STAMPS                                // diagnostic builds: wall-clock stamps of workgroup phases (tools/diag/wide_stamps.py)
+__device__ unsigned long long g_wide_stamps[1024 * 8 * 16];
+#define WIDE_MARK(k) do { if (stamp_tile) stamp[k] = wall_clock64(); } while (0)
+#else
+#define WIDE_MARK(k) do { } while (0)
+#endif
 constexpr int WTD = 4, WHD = WTD + 2;                  // output planes of a tile, halo planes
 constexpr int WC = 8;                                  // Cin chunk
 // halo: 30 row pairs (6 planes x 10 rows) of 2 x 10 positions x 8 channels, one 264-float slot each, two buffers.  A slot is what ONE
@@ -583,6 +589,9 @@ __global__ __launch_bounds__(kThreadsW, 2) void conv3d_wino2d_wide_kernel(Conv3d
     t_cur = blockIdx.x; t_step = gridDim.x; t_end = T;
   }
   if (t_cur >= t_end) return;
+#ifdef MR3D_WIDE_STAMPS
+  const unsigned long long stamp0 = wall_clock64();
+#endif
   struct Tile { int n, od0, oh0, ow0; };
   auto tile_at = [&](int t) {
     Tile r;
@@ -598,6 +607,12 @@ __global__ __launch_bounds__(kThreadsW, 2) void conv3d_wino2d_wide_kernel(Conv3d
   const unsigned ul_off = (unsigned)((lk * 4 * p.Cout + cobase + ch * 32 + li) * 6 * 4);   // bytes: (ci = lk, fh = 0, this lane's co)
   const __amdgpu_buffer_rsrc_t ursrc = buffer_of(U);
 
+#ifdef MR3D_WIDE_STAMPS
+  unsigned long long stamp[16] = {};
+  bool stamp_tile = false;
+  int tiles_done = 0;
+  stamp[0] = stamp0;
+#endif
   f32x4 acc[24];                                         // [fw][rt][ct]
 #pragma unroll
   for (int f = 0; f < 24; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -691,7 +706,7 @@ __global__ __launch_bounds__(kThreadsW, 2) void conv3d_wino2d_wide_kernel(Conv3d
     else if (s3 < 6) load_b(bq[(s12 + 3) % 4], c0, s3 / 2, s3 % 2);
     else load_b(bq[(s12 + 3) % 4], c0 + WC < p.Cin ? c0 + WC : 0, (s3 - 6) / 2, (s3 - 6) % 2);
     // A fragments half a step ahead: row tile 1's (this step) while row tile 0's MFMAs run, then row tile 0's of the next step
-    load_a(aq[1], vcur, 1, s / 2, s % 2);
+    if (!(WABL & 32)) load_a(aq[1], vcur, 1, s / 2, s % 2);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int fw = 0; fw < 6; ++fw)
@@ -699,7 +714,8 @@ __global__ __launch_bounds__(kThreadsW, 2) void conv3d_wino2d_wide_kernel(Conv3d
       for (int ct = 0; ct < 2; ++ct)
         acc[(fw * 2 + 0) * 2 + ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[0][fw], bq[s12 % 4][ct * 6 + fw], acc[(fw * 2 + 0) * 2 + ct], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    if (s + 1 < 6) load_a(aq[0], vcur, 0, (s + 1) / 2, (s + 1) % 2);
+    if (WABL & 32) {}
+    else if (s + 1 < 6) load_a(aq[0], vcur, 0, (s + 1) / 2, (s + 1) % 2);
     else load_a(aq[0], vnext, 0, 0, 0);                  // step 0 of the next chunk (its V is complete: barrier 2 sits in front of step 5)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -822,14 +838,18 @@ __global__ __launch_bounds__(kThreadsW, 2) void conv3d_wino2d_wide_kernel(Conv3d
     const float *vcur = lds + par * WV;
     float *vnext = lds + (1 - par) * WV;
     const int c0 = c * WC;
+    if (c == 3) WIDE_MARK(2);
     step(par, 0, c0, vcur, vnext);
     step(par, 1, c0, vcur, vnext);
+    if (c == 3) WIDE_MARK(3);
     // the next chunk's halo was requested one chunk ago; the requests behind it are the U fragments of six steps (24; sched_barriers
     // pin each step's four in front of its MFMAs) -- two steps in the first chunk
     if (filling) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
     filling = false;
+    if (c == 3) WIDE_MARK(4);
     if (!(WABL & 16)) __syncthreads();                   // 1: the next chunk's halo is complete; halo[par] (read one chunk ago) is free
+    if (c == 3) WIDE_MARK(5);
     if (!(WABL & 2)) {                                   // the chunk after the next: of this tile, or chunk 0 / 1 of the next tile
       const bool wrap = c + 2 >= nc;
       unsigned r[4] = {rel_c[0], rel_c[1], rel_c[2], rel_c[3]};
@@ -842,15 +862,27 @@ __global__ __launch_bounds__(kThreadsW, 2) void conv3d_wino2d_wide_kernel(Conv3d
     if (!(WABL & 1)) vunit_finish(vnext, 1);
     step(par, 4, c0, vcur, vnext, 2);
     if (!(WABL & 1)) vunit_finish(vnext, 2);
+    if (c == 3) WIDE_MARK(6);
     if (!(WABL & 16)) __syncthreads();                   // 2: V of the next chunk is complete; V of this chunk (behind step 4's reads) is free
+    if (c == 3) WIDE_MARK(7);
     step(par, 5, c0, vcur, vnext);
+    if (c == 3) WIDE_MARK(8);
   };
   for (;;) {
+#ifdef MR3D_WIDE_STAMPS
+    stamp_tile = tiles_done == 2;                        // the third tile of the walk
+#endif
+    WIDE_MARK(1);
     for (int c = 0; c < nc; c += 2) {
       chunk(0, c);
       chunk(1, c + 1);
     }
+    WIDE_MARK(9);
     if (!(WABL & 8)) epilogue(tile, false);              // Z overlays V1 | halo 0; V0 holds the next tile's first chunk, halo 1 receives its second
+    WIDE_MARK(10);
+#ifdef MR3D_WIDE_STAMPS
+    ++tiles_done;
+#endif
 #pragma unroll
     for (int f = 0; f < 24; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (t_next < 0) break;
@@ -859,6 +891,13 @@ __global__ __launch_bounds__(kThreadsW, 2) void conv3d_wino2d_wide_kernel(Conv3d
     t_next = t_cur + t_step < t_end ? t_cur + t_step : -1;
     tnext = tile_at(t_next < 0 ? t_cur : t_next);
   }
+#ifdef MR3D_WIDE_STAMPS
+  stamp[11] = wall_clock64();
+  if (lane == 0 && blockIdx.x < 1024) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) g_wide_stamps[((size_t)blockIdx.x * 8 + wave) * 16 + k] = stamp[k];
+  }
+#endif
 }
 
 // ---- batched form of wino2d_weights_kernel for a plan run: one launch transforms the weights of every convolution of the
@@ -984,6 +1023,12 @@ int mr3d_conv3d_wino2d_prepare(const float *const *w, const int *cin, const int 
 }
 
 void mr3d_conv3d_wino2d_prepare_end() { g_prepared.clear(); }
+
+#ifdef MR3D_WIDE_STAMPS
+extern "C" int mr3d_debug_wide_stamps(unsigned long long *dst) {     // 1024 x 8 x 16 stamps of the last wide launch
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_wide_stamps), sizeof(unsigned long long) * 1024 * 8 * 16) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" size_t mr3d_conv3d_wino2d_workspace_bytes(int cin, int cout) {
   if (cin <= 0 || cout <= 0) return 0;

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Phase stamps of conv3d_wino2d_wide_kernel (MR3D_TUNE_WINO2D_FORM = 2 + 16 * 32: the kernel writes wall_clock64 stamps over y; diagnostic
-builds only).  usage (GPU box): python tools/diag/wide_stamps.py"""
+"""Phase stamps of conv3d_wino2d_wide_kernel on the P2 map: a diagnostic build (tools/diag/wide_ablate_build.sh stamps ->
+tools/ab/wide_stamps.so) records wall_clock64 at phase borders of every wave's third tile and of its fourth chunk.
+usage (GPU box): MR3D_LIB=tools/ab/wide_stamps.so python tools/diag/wide_stamps.py"""
+import ctypes
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -14,20 +16,18 @@ x = torch.randn((1, 40, 128, 128, 64), device=dev)
 w = torch.randn((27, 64, 64), device=dev) * 0.05
 y = torch.empty((1, 40, 128, 128, 64), device=dev)
 _hip.lib().mr3d_tuning_set(5, 2)
-for _ in range(3):
+for _ in range(4):
     _hip.conv3d_forward(x, w, (3, 3, 3), (1, 1, 1), (1, 1, 1), out=y)
-_hip.lib().mr3d_tuning_set(5, 2 + 16 * 32)
-_hip.conv3d_forward(x, w, (3, 3, 3), (1, 1, 1), (1, 1, 1), out=y)
 torch.cuda.synchronize()
-raw = y.view(-1).cpu().numpy().view(np.uint64)[:2560 * 8 * 16].reshape(2560, 8, 16)[:, :, :13].astype(np.int64)
-t0 = raw[:, :, 0].min()
-rel = (raw - t0) * 10.0 / 1000.0      # us (100 MHz)
-names = ['start', 'loop', 'c3 start', 'c3 s0+commit', 'c3 s1+fetch', 'c3 barrier1', 'c3 s2+unit', 'c3 s3,4+units', 'c3 barrier2', 'c3 s5', 'loop end', 'Z', 'end']
-d = np.diff(raw, axis=2) * 10.0 / 1000.0
-print('workgroup start (us): min %.1f median %.1f max %.1f; end: min %.1f median %.1f max %.1f' % (
-    rel[:, 0, 0].min(), np.median(rel[:, 0, 0]), rel[:, 0, 0].max(), rel[:, 0, 12].min(), np.median(rel[:, 0, 12]), rel[:, 0, 12].max()))
-print('duration of a workgroup: median %.2f us' % np.median(rel[:, 0, 12] - rel[:, 0, 0]))
-for k in range(12):
-    for wv in (0, 3, 6, 7):
-        print('%-14s -> %-14s wave %d: median %.2f us  (p10 %.2f, p90 %.2f)' % (names[k], names[k + 1], wv, np.median(d[:, wv, k]),
-              np.percentile(d[:, wv, k], 10), np.percentile(d[:, wv, k], 90)))
+buf = np.zeros(1024 * 8 * 16, dtype=np.uint64)
+fn = _hip.lib().mr3d_debug_wide_stamps
+fn.argtypes = [ctypes.c_void_p]
+assert fn(buf.ctypes.data) == 0
+raw = buf.reshape(1024, 8, 16)[:256].astype(np.int64)
+us = lambda a: a * 10.0 / 1000.0      # 100 MHz
+names = {0: 'kernel start', 1: 'tile 3 start', 2: 'chunk 3 start', 3: 'steps 0-1', 4: 'halo wait', 5: 'barrier 1', 6: 'steps 2-4 + units',
+         7: 'barrier 2', 8: 'step 5', 9: 'chunks done', 10: 'epilogue done', 11: 'kernel end'}
+print('workgroup duration (us): median %.1f  min %.1f  max %.1f' % tuple(f(us(raw[:, 0, 11] - raw[:, 0, 0])) for f in (np.median, np.min, np.max)))
+print('tile 3: chunks %.2f us, epilogue %.2f us (median over workgroups, wave 0)' % (np.median(us(raw[:, 0, 9] - raw[:, 0, 1])), np.median(us(raw[:, 0, 10] - raw[:, 0, 9]))))
+for k in range(2, 8):
+    print('%-20s' % names[k + 1], '  '.join('w%d %.2f' % (wv, np.median(us(raw[:, wv, k + 1] - raw[:, wv, k]))) for wv in range(8)))
