@@ -65,6 +65,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 // two-dimensional Winograd form of the 3x3x3 / stride-1 convolution (conv3d_wino2d.hip): F(4,3) along W x F(2,3) along H
 bool mr3d_conv3d_wino2d_ok(const Conv3dFwdArgs &a);
 int mr3d_conv3d_wino2d(const Conv3dFwdArgs &a, hipStream_t stream);
+bool mr3d_conv3d_wino2d_wide(const Conv3dFwdArgs &a);            // the launch takes the wide form (4 x 8 x 8 tiles, persistent workgroups)
 bool mr3d_conv3d_wino2d_rows_ok(const Conv3dFwdArgs &a);          // Cout 16 / 32
 int mr3d_conv3d_wino2d_rows(const Conv3dFwdArgs &a, hipStream_t stream);
 // plan pre-pass: the weight transforms of n convolutions in one launch into the caller's workspace (see conv3d_wino2d.hip)

@@ -518,7 +518,8 @@ int dispatch_tile(const Conv3dFwdArgs &a, hipStream_t stream) {
     if (wino >= 4 && wgs(2, 8, 8) >= min2d && mr3d_conv3d_wino2d_ok(a)) {
       if (g_variant_probe) {
         mr3d_conv3d_variant &v = *g_variant_probe;
-        v.streaming_pointwise = 0; v.winograd = 8; v.tile_d = 2; v.tile_h = 8; v.tile_w = 8; v.cin_chunk = 16; v.cout_tile = 64;
+        const bool wide = mr3d_conv3d_wino2d_wide(a);
+        v.streaming_pointwise = 0; v.winograd = 8; v.tile_d = wide ? 4 : 2; v.tile_h = 8; v.tile_w = 8; v.cin_chunk = wide ? 8 : 16; v.cout_tile = 64;
         v.parity_decomposed = 0; v.mfma_issue_factor = 1.f / 3.f;
         return MR3D_OK;
       }

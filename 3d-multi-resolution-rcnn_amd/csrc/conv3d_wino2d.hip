@@ -167,14 +167,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wino2d_kernel(Conv3dFwdArg
     return o;
   };
   auto fetch = [&](const Own &o, int j, int c0) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if ((s_ok >> j) & 1u) {
-      const int row = o.rg + 6 * j;
-      const int hd = (row >= HH) + (row >= 2 * HH) + (row >= 3 * HH), hh = row - hd * HH;
-      const int rel = (int)__umul24(hd, s_plane) + (int)__umul24(hh, s_rowp) + (int)__umul24(o.hw, p.Cin) + o.q * 4;   // full-rate multiplies
-      v = buffer_load4(xrsrc, (unsigned)rel * 4u, (unsigned)c0 * 4u);
-    }
-    return v;
+    // a piece outside the volume reads beyond the descriptor's range: zeros, no memory touched, and no branch around the load (a load
+    // under a lane mask makes the compiler drain the vector-memory queue -- the next chunk's U fragments -- at the join)
+    const int row = o.rg + 6 * j;
+    const int hd = (row >= HH) + (row >= 2 * HH) + (row >= 3 * HH), hh = row - hd * HH;
+    const int rel = (int)__umul24(hd, s_plane) + (int)__umul24(hh, s_rowp) + (int)__umul24(o.hw, p.Cin) + o.q * 4;   // full-rate multiplies
+    return buffer_load4(xrsrc, ((s_ok >> j) & 1u) ? (unsigned)rel * 4u : 0xfffffff0u, (unsigned)c0 * 4u);
   };
   auto commit = [&](const Own &o, int j, const float4 &v) {
     const int row = o.rg + 6 * j;                        // (hd * HHP + hh) = row + hd: one spare row per plane
@@ -448,9 +446,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv3d_wino2d_rows_kernel(Conv3dF
         for (int jj = 0; jj < 4; ++jj) {
           const int row = rg + 6 * (j0 + jj);
           const int hd = (int)(__umul24(row, 205) >> 11), hh = row - hd * HH;          // row / 10 for row < 1029
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if ((s_ok >> (j0 + jj)) & 1u) v = buffer_load4(xrsrc, (__umul24(hd, s_plane) + __umul24(hh, s_rowp) + col) * 4u, (unsigned)c0 * 4u);
-          stage[jj] = v;
+          // (outside the volume: an offset beyond the descriptor's range reads zeros -- no branch around the load)
+          stage[jj] = buffer_load4(xrsrc, ((s_ok >> (j0 + jj)) & 1u) ? (__umul24(hd, s_plane) + __umul24(hh, s_rowp) + col) * 4u : 0xfffffff0u, (unsigned)c0 * 4u);
         }
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
@@ -1040,13 +1037,26 @@ bool mr3d_conv3d_wino2d_ok(const Conv3dFwdArgs &a) {
          a.Wo == a.W + 2 * a.pw - 2 && u_available(a) && (long long)a.H * a.W * a.Cin < (1LL << 24);      // 24-bit offset products in the halo staging
 }
 
+// Which of the two 64-wide kernels a launch takes: the wide form (4 x 8 x 8 tiles, one persistent 512-thread workgroup per CU) on
+// maps with at least two rounds of such tiles whose x fits 32-bit byte offsets; MR3D_TUNE_WINO2D_FORM forces either.
+static int g_wino2d_cus = 0;
+bool mr3d_conv3d_wino2d_wide(const Conv3dFwdArgs &a) {
+  if (g_wino2d_cus == 0) {
+    int dev = 0, n = 0;
+    g_wino2d_cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+  }
+  const int form = g_mr3d_tuning[MR3D_TUNE_WINO2D_FORM];
+  const long long tiles = (long long)a.N * ((a.Do + WTD - 1) / WTD) * ((a.Ho + TH - 1) / TH) * ((a.Wo + TW - 1) / TW);
+  const bool fits = (long long)a.N * a.D * a.H * a.W * a.Cin * 4 < (1LL << 31) && tiles < (1LL << 30);
+  return fits && (form == 2 || (form == 0 && tiles >= 2LL * g_wino2d_cus));
+}
+
 int mr3d_conv3d_wino2d(const Conv3dFwdArgs &a, hipStream_t stream) {
   const float *U = u_for(a, stream);
   if (!U) return MR3D_ERR_LAUNCH;
   const int tiles_h = (a.Ho + TH - 1) / TH, tiles_w = (a.Wo + TW - 1) / TW;
   static std::once_flag attr_once;                       // LDS above 64 KiB needs the opt-in attribute (one CU has 160 KiB)
   static bool attr_ok = false;
-  static int cus = 256;
   std::call_once(attr_once, [] {
     auto lds_of = [](const void *f, int bytes) { return hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess; };
     attr_ok = lds_of(reinterpret_cast<const void *>(conv3d_wino2d_kernel<false>), LDS_BYTES) &&
@@ -1054,21 +1064,16 @@ int mr3d_conv3d_wino2d(const Conv3dFwdArgs &a, hipStream_t stream) {
               lds_of(reinterpret_cast<const void *>(conv3d_wino2d_wide_kernel<false>), WLDS_BYTES) &&
               lds_of(reinterpret_cast<const void *>(conv3d_wino2d_wide_kernel<true>), WLDS_BYTES);
     if (!attr_ok) (void)hipGetLastError();
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
   });
   if (!attr_ok) return MR3D_ERR_LAUNCH;
-  // wide form (4 x 8 x 8 tiles, one persistent 512-thread workgroup per CU): maps with at least two rounds of such tiles
-  const int form = g_mr3d_tuning[MR3D_TUNE_WINO2D_FORM];
-  const int tiles_dw = (a.Do + WTD - 1) / WTD;
-  const long long wide_tiles = (long long)a.N * tiles_dw * tiles_h * tiles_w;
-  const bool wide_fits = (long long)a.N * a.D * a.H * a.W * a.Cin * 4 < (1LL << 31) && wide_tiles < (1LL << 30);      // 32-bit byte offsets into x
-  if (wide_fits && (form == 2 || (form == 0 && wide_tiles >= 2LL * cus))) {
+  if (mr3d_conv3d_wino2d_wide(a)) {
+    const int tiles_dw = (a.Do + WTD - 1) / WTD;
+    const long long wide_tiles = (long long)a.N * tiles_dw * tiles_h * tiles_w;
     const float *Uw = U + u_layout_floats(a.Cin, a.Cout);
     if (a.x_live) {                                      // one tile per workgroup: an all-dead halo leaves through the epilogue at once
       conv3d_wino2d_wide_kernel<true><<<dim3((unsigned)wide_tiles, (unsigned)(a.Cout / 64)), kThreadsW, WLDS_BYTES, stream>>>(a, Uw, tiles_dw, tiles_h, tiles_w);
     } else {
-      const unsigned wgs = (unsigned)(wide_tiles < cus ? wide_tiles : cus);
+      const unsigned wgs = (unsigned)(wide_tiles < g_wino2d_cus ? wide_tiles : g_wino2d_cus);
       conv3d_wino2d_wide_kernel<false><<<dim3(wgs, (unsigned)(a.Cout / 64)), kThreadsW, WLDS_BYTES, stream>>>(a, Uw, tiles_dw, tiles_h, tiles_w);
     }
     return mr3d_launch_status();

@@ -30,7 +30,7 @@ def key_of(name):
         cc = 64 if ci % 64 == 0 else (32 if ci % 32 == 0 else 16)
         nb = 64 if co % 64 == 0 else (32 if co % 32 == 0 else 16)
         return f'conv3d_{m.group(1)}<k1,s111,cc{cc},nb{nb}>'
-    if 'conv3d_wino2d_kernel' in n:          # the two-dimensional Winograd form of the 64 -> 64 3x3x3 convs (conv3d_wino2d.hip)
+    if 'conv3d_wino2d_kernel' in n or 'conv3d_wino2d_wide_kernel' in n:     # the two-dimensional Winograd forms of the 64 -> 64 3x3x3 convs (conv3d_wino2d.hip)
         return 'conv3d_fwd<k3,s111,cc16,nb64>'
     for pat, key in (('stem_fwd', 'stem_fwd'), ('stem_wgrad_gather_kernel', 'stem_wgrad_gather'), ('stem_wgrad_kernel', 'stem_wgrad'), ('maxpool_fwd_kernel', 'maxpool_fwd'),
                      ('maxpool_bwd_kernel', 'maxpool_bwd'), ('upsample_adjoint_add_kernel', 'upsample_adjoint_add')):
