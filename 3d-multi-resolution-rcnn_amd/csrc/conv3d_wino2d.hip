@@ -1048,6 +1048,10 @@ bool mr3d_conv3d_wino2d_wide(const Conv3dFwdArgs &a) {
   const int form = g_mr3d_tuning[MR3D_TUNE_WINO2D_FORM];
   const long long tiles = (long long)a.N * ((a.Do + WTD - 1) / WTD) * ((a.Ho + TH - 1) / TH) * ((a.Wo + TW - 1) / TW);
   const bool fits = (long long)a.N * a.D * a.H * a.W * a.Cin * 4 < (1LL << 31) && tiles < (1LL << 30);
+  // with a liveness bitmap (sparse data gradients in detector training) most tiles leave through the epilogue at once: that is a
+  // dispatch-rate question, and the 2 x 8 x 8 kernel's 256-thread workgroups (two or three per CU) retire dead tiles faster than one
+  // 512-thread workgroup per CU -- the wide form takes such launches only when forced
+  if (a.x_live && form != 2) return false;
   return fits && (form == 2 || (form == 0 && tiles >= 2LL * g_wino2d_cus));
 }
 
