@@ -245,7 +245,8 @@ size_t mr3d_conv3d_wino2d_workspace_bytes(int cin, int cout);
 typedef struct {
   int streaming_pointwise;      /* 1: the HBM-bound 1x1x1 streaming kernel (csrc/pointwise.hip) */
   int winograd;                 /* 0 direct, 2 = F(2,3) along W, 4 = F(4,3) along W, 8 = F(4,3) along W x F(2,3) along H */
-  int tile_d, tile_h, tile_w;   /* output positions per workgroup */
+  int tile_d, tile_h, tile_w;   /* output positions per workgroup tile (winograd 8, Cout 64: 4 x 8 x 8 = the wide kernel with persistent
+                                   workgroups, 2 x 8 x 8 = one workgroup per tile; csrc/conv3d_wino2d.hip) */
   int cin_chunk, cout_tile;
   int parity_decomposed;
   float mfma_issue_factor;      /* MFMA FLOPs issued / algorithmic FLOPs: 1, 2/3, 1/2 or 1/3 */

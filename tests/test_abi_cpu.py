@@ -154,6 +154,27 @@ def test_stem_size_guard():
     assert L.mr3d_stem_conv_wgrad_bf16_pooled(p, p, p, p, p, p, 1, 684, 512, 512, None) == 4
 
 
+def test_winograd_2d_variant_reports_the_kernel_form_per_map():
+    """csrc/conv3d_wino2d.hip holds two 64-wide kernels; mr3d_conv3d_forward_variant says which one a launch takes (nothing is
+    launched): the wide form (4x8x8 tiles, Cin chunks of 8) on maps with at least two rounds of such tiles -- the P2 map --, the 2x8x8
+    kernel on the P3 map, and either one when MR3D_TUNE_WINO2D_FORM forces it."""
+    import ctypes
+    from mr3d_amd import _hip
+    L = _hip.lib()
+    v = _hip.Conv3dVariant()
+    p2, p3 = _conv_desc(3, 1, 128, 128, 64, 64, d=40), _conv_desc(3, 1, 64, 64, 64, 64, d=20)
+    tile = lambda c: (L.mr3d_conv3d_forward_variant(ctypes.byref(c), ctypes.byref(v)), v.winograd, v.tile_d, v.cin_chunk)[1:]
+    try:
+        assert tile(p2) == (8, 4, 8) and tile(p3) == (8, 2, 16)
+        L.mr3d_tuning_set(5, 1)
+        assert tile(p2) == (8, 2, 16)
+        L.mr3d_tuning_set(5, 2)
+        assert tile(p3) == (8, 4, 8)
+    finally:
+        L.mr3d_tuning_set(5, 0)
+    assert abs(v.mfma_issue_factor - 1.0 / 3.0) < 1e-6
+
+
 def test_up_even_flag_is_refused_where_no_kernel_implements_it():
     """MR3D_CONV_UP_EVEN (the even-position add of a stride-2 adjoint) exists in the generic fp32 kernel and the streaming
     pointwise kernels.  The two-dimensional Winograd instances must not be chosen for it, and the bf16 entry point refuses it."""
