@@ -532,23 +532,36 @@ class ExtractFeat3D(nn.Module):
                 stage_outs.append(x)
         P.C = stage_outs
         P.lat = [None] * 4
+        P.outs = [None] * 4
+        p6 = None
+        # The P3..P5 output convolutions and P6 (small maps: tens to hundreds of workgroups each) run on the side stream, and each is
+        # queued RIGHT BEHIND the lateral convolution that produces its input: they run beside the finer laterals (the P2 one streams
+        # 0.3 GB and leaves the matrix cores idle) and are done when the P2 output convolution starts.  Queued behind ALL laterals
+        # (rounds 3-4: 11.05 -> 11.01 ms, beside the P2 convolution) they now wait for it: its wide form (conv3d_wino2d.hip) keeps one
+        # 512-thread workgroup per CU, and nothing else fits beside that.  Nothing reads them before the plan's final join.
+        interleave = not self.neck_dcn and os.environ.get('MR3D_FPN_INTERLEAVE', '1') != '0'
         for i in (3, 2, 1, 0):
             P.lat[i] = self._new(self._out_shape(P.C[i].shape, self.lateral[i]))
             fwd.append(self._conv_fwd(P.C[i], self.lateral[i], P.lat[i], up=P.lat[i + 1] if i < 3 else None))
-        P.outs = []
-        if self.neck_dcn:
-            P.outs = list(P.lat)                    # the deformable neck (detector/dcn_neck.py) takes over from here
-        else:
-            # The P3..P5 output convolutions and P6 (small maps: tens of workgroups each) are queued on the side stream IN FRONT of
-            # the P2 one, which fills the chip for 0.6 ms on the main stream; nothing reads them before the plan's final join
-            # (headline step, 300 steps each: 11.05 -> 11.01 ms).
-            P.outs = [self._new(self._out_shape(P.lat[i].shape, self.fpnconv[i])) for i in range(4)]
-            for i in (3, 2, 1):
+            if interleave and i > 0:
+                P.outs[i] = self._new(self._out_shape(P.lat[i].shape, self.fpnconv[i]))
                 fwd.append(self._side(self._conv_fwd(P.lat[i], self.fpnconv[i], P.outs[i])))
                 if i == 3:
                     _, d5, h5, w5, _ = P.outs[3].shape
                     p6 = self._new((N, (d5 - 1) // 2 + 1, (h5 - 1) // 2 + 1, (w5 - 1) // 2 + 1, self.fpn_out))
                     fwd.append(self._side(self._op(_hip.OP_SUBSAMPLE_FWD, [P.outs[3], p6], [N, d5, h5, w5, self.fpn_out])))
+        if self.neck_dcn:
+            P.outs = list(P.lat)                    # the deformable neck (detector/dcn_neck.py) takes over from here
+        else:
+            if not interleave:
+                for i in (3, 2, 1):
+                    P.outs[i] = self._new(self._out_shape(P.lat[i].shape, self.fpnconv[i]))
+                    fwd.append(self._side(self._conv_fwd(P.lat[i], self.fpnconv[i], P.outs[i])))
+                    if i == 3:
+                        _, d5, h5, w5, _ = P.outs[3].shape
+                        p6 = self._new((N, (d5 - 1) // 2 + 1, (h5 - 1) // 2 + 1, (w5 - 1) // 2 + 1, self.fpn_out))
+                        fwd.append(self._side(self._op(_hip.OP_SUBSAMPLE_FWD, [P.outs[3], p6], [N, d5, h5, w5, self.fpn_out])))
+            P.outs[0] = self._new(self._out_shape(P.lat[0].shape, self.fpnconv[0]))
             fwd.append(self._conv_fwd(P.lat[0], self.fpnconv[0], P.outs[0]))
             P.outs.append(p6)
 
