@@ -148,8 +148,18 @@ struct SideStream {
     // the weight-gradient overlap gone (kernel durations unchanged).
     // (Round 3, headline step: high 11.10 ms, normal 11.23, low 11.24 -- the weight gradients finishing early matters more
     // than the main chain's kernels keeping every CU.)
-    if (hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, hi) != hipSuccess) return false;
-    if (hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, hi) != hipSuccess) return false;
+    // Round 5 again (8.9 ms step): high 8.97, middle 8.89, low 8.99 on a bare process -- with the side queues in the high class the
+    // dispatcher serves a long weight gradient's workgroups first and 20 us convolutions of the main chain take 100-300 us beside it
+    // -- but with an RCCL communicator alive the middle class folds onto the caller's queue (10.30 against 9.02 ms), so high stays.
+    // Measured and not kept to get both: GPU_MAX_HW_QUEUES = 8 / 16 (13.4-14.2 ms with the communicator alive); the main chain on a
+    // third high-class queue of the executor's own (backbone step 8.90 against 8.85 ms, the two-stage step 18-22 against 12.4 ms: one
+    // more stream of the class and the runtime folds queues elsewhere); the caller running the whole step on a high-priority torch
+    // stream (-0.04 ms, -0.07 with the communicator: a caller's choice).
+    // MR3D_TUNE_SIDE_PRIORITY (set BEFORE the first plan run of the process): 0 = high (the default), 1 = the middle of the range, 2 = low
+    const int want = g_mr3d_tuning[MR3D_TUNE_SIDE_PRIORITY];
+    const int prio = want == 2 ? lo : (want == 1 ? (lo + hi) / 2 : hi);
+    if (hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, prio) != hipSuccess) return false;
+    if (hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, prio) != hipSuccess) return false;
     // Fork / join events order kernels of ONE device across its queues: the kernels' own agent-scope release / acquire (every
     // dispatch packet carries them -- consecutive kernels of one queue on different XCDs depend on the same) is all the visibility
     // a consumer on another queue needs.  Without hipEventDisableSystemFence the event's packet also writes the caches back to

@@ -62,6 +62,8 @@ enum {
                                      stem_wgrad_gather.hip), n > 0 = n slots */
   MR3D_TUNE_WINO2D_FORM = 5,      /* 64-wide F(4,3) x F(2,3) convolution (conv3d_wino2d.hip): 0 = the library's choice per map, 1 = always the
                                      2 x 8 x 8-tile kernel of round 2, 2 = always the wide kernel (4 x 8 x 8 tiles, 512 threads) */
+  MR3D_TUNE_SIDE_PRIORITY = 6,    /* priority class of the plan executor's side queues, read at the first plan run of the process: 0 = high
+                                     (default: a hardware queue of their own whatever other libraries hold), 1 = middle, 2 = low */
   MR3D_TUNE_NUM_KEYS = 16
 };
 void mr3d_tuning_set(int key, int value);
