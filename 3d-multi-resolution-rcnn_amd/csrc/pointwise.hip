@@ -34,10 +34,14 @@ __device__ __forceinline__ int pw_nearest_src(int dst, int in, int out) {
 // C2_ > 0: the PAIR form -- a second pointwise product CO -> C2 on the activated output tile while it still sits in the wave's
 // LDS slab (a bottleneck block's conv3 + identity + ReLU followed by the next block's conv1 + ReLU, and the mirror image in the
 // backward pass): the 4x-wide block output is written once and not read back by another launch.
-template <int CI_, int CO_, bool EXTRA_ = false, int C2_ = 0>
+// BLK_: the launch covers a WIDER layer in column blocks of CO_ output channels (blockIdx.y = block): weights, shift, y and the
+// residual / mask streams have a row pitch of p.Cout; whole tiles, no upsample add, no scatter (the 64 -> 256 convolutions of
+// layer3 on the 768 x 768 x 120 pathway of the shipped model: 34,560 positions took the generic halo-tile kernel, 60-160 us each).
+template <int CI_, int CO_, bool EXTRA_ = false, int C2_ = 0, bool BLK_ = false>
 struct PwCfg {
   static constexpr int CI = CI_, CO = CO_, C2 = C2_;
-  static constexpr bool EXTRA = EXTRA_, PAIR = C2_ > 0;
+  static constexpr bool EXTRA = EXTRA_, PAIR = C2_ > 0, BLK = BLK_;
+  static_assert(!(BLK_ && C2_ > 0), "column blocks: no pair form");
   static constexpr int KK2 = CO_ / 4, MT2 = 2, OS2 = C2_ + 4;            // stage 2: 16x16x4, both 16-row tiles of the 32-row tile
   static constexpr int NOUT2 = C2_ > 0 ? 32 * C2_ / 4 / 64 : 1;
   static_assert(C2_ == 0 || (C2_ == 16 && EXTRA_ && CO_ % 4 == 0), "pair: 16-wide second product on 32-row tiles");
@@ -80,12 +84,20 @@ __global__ __launch_bounds__(64 * C::WPW) void pointwise_fwd_kernel(Conv3dFwdArg
 #pragma unroll
     for (int kk = 0; kk < C::KK; ++kk)
 #pragma unroll
-      for (int nt = 0; nt < C::NT; ++nt) breg[kk][nt] = p.w[(size_t)(kk * C::KSTEP + lk) * C::CO + nt * C::TM + li];
+      for (int nt = 0; nt < C::NT; ++nt)
+        breg[kk][nt] = C::BLK ? p.w[(size_t)(kk * C::KSTEP + lk) * p.Cout + blockIdx.y * C::CO + nt * C::TM + li]
+                              : p.w[(size_t)(kk * C::KSTEP + lk) * C::CO + nt * C::TM + li];
   } else {
+    static_assert(!C::BLK, "column blocks: weights in registers only");
     for (int e = tid; e < C::CI * C::CO / 4; e += 64 * C::WPW)
       *reinterpret_cast<float4 *>(lds + e * 4) = *reinterpret_cast<const float4 *>(p.w + (size_t)e * 4);
     __syncthreads();
   }
+  // float4 index of element f = (row, channel quad) of the tile that starts at row0, in y / add1 / add2 / mask
+  auto oidx = [&](long long row0, int f) -> size_t {
+    if constexpr (C::BLK) return (size_t)(row0 + f / (C::CO / 4)) * (size_t)(p.Cout / 4) + blockIdx.y * (C::CO / 4) + f % (C::CO / 4);
+    else return (size_t)row0 * (C::CO / 4) + f;
+  };
 
   float breg2[C::PAIR ? C::KK2 : 1];
   if constexpr (C::PAIR) {
@@ -133,11 +145,15 @@ __global__ __launch_bounds__(64 * C::WPW) void pointwise_fwd_kernel(Conv3dFwdArg
         }
         if (p.add1) {
 #pragma unroll
-          for (int q = 0; q < C::NOUT; ++q) e1[q] = (reinterpret_cast<const float4 *>(p.add1) + t4e)[q * 64 + lane];
+          for (int q = 0; q < C::NOUT; ++q)
+            e1[q] = C::BLK ? reinterpret_cast<const float4 *>(p.add1)[oidx(tile * C::ROWS, q * 64 + lane)]
+                           : (reinterpret_cast<const float4 *>(p.add1) + t4e)[q * 64 + lane];
         }
         if (p.mask) {
 #pragma unroll
-          for (int q = 0; q < C::NOUT; ++q) em[q] = (reinterpret_cast<const float4 *>(p.mask) + t4e)[q * 64 + lane];
+          for (int q = 0; q < C::NOUT; ++q)
+            em[q] = C::BLK ? reinterpret_cast<const float4 *>(p.mask)[oidx(tile * C::ROWS, q * 64 + lane)]
+                           : (reinterpret_cast<const float4 *>(p.mask) + t4e)[q * 64 + lane];
         }
       }
     }
@@ -188,7 +204,7 @@ __global__ __launch_bounds__(64 * C::WPW) void pointwise_fwd_kernel(Conv3dFwdArg
       //     fully coalesced 1-KiB wave accesses instead of 4-B-per-lane column accesses.
 #pragma unroll
       for (int nt = 0; nt < C::NT; ++nt) {
-        const float sh = p.shift ? p.shift[nt * C::TM + li] : 0.f;
+        const float sh = p.shift ? p.shift[(C::BLK ? blockIdx.y * C::CO : 0) + nt * C::TM + li] : 0.f;
 #pragma unroll
         for (int mt = 0; mt < C::MT; ++mt)
 #pragma unroll
@@ -209,7 +225,9 @@ __global__ __launch_bounds__(64 * C::WPW) void pointwise_fwd_kernel(Conv3dFwdArg
 #pragma unroll
         for (int q = 0; q < C::NOUT; ++q) {
           float4 a;
-          if constexpr (C::EXTRA) a = e1[q]; else a = a4[q * 64 + lane];
+          if constexpr (C::EXTRA) a = e1[q];
+          else if constexpr (C::BLK) a = reinterpret_cast<const float4 *>(p.add1)[oidx(row0, q * 64 + lane)];
+          else a = a4[q * 64 + lane];
           v[q].x += a.x; v[q].y += a.y; v[q].z += a.z; v[q].w += a.w;
         }
       }
@@ -217,7 +235,7 @@ __global__ __launch_bounds__(64 * C::WPW) void pointwise_fwd_kernel(Conv3dFwdArg
         const float4 *a4 = reinterpret_cast<const float4 *>(p.add2) + t4;
 #pragma unroll
         for (int q = 0; q < C::NOUT; ++q) {
-          const float4 a = a4[q * 64 + lane];
+          const float4 a = C::BLK ? reinterpret_cast<const float4 *>(p.add2)[oidx(row0, q * 64 + lane)] : a4[q * 64 + lane];
           v[q].x += a.x; v[q].y += a.y; v[q].z += a.z; v[q].w += a.w;
         }
       }
@@ -252,7 +270,9 @@ __global__ __launch_bounds__(64 * C::WPW) void pointwise_fwd_kernel(Conv3dFwdArg
 #pragma unroll
         for (int q = 0; q < C::NOUT; ++q) {
           float4 m;
-          if constexpr (C::EXTRA) m = em[q]; else m = m4[q * 64 + lane];
+          if constexpr (C::EXTRA) m = em[q];
+          else if constexpr (C::BLK) m = reinterpret_cast<const float4 *>(p.mask)[oidx(row0, q * 64 + lane)];
+          else m = m4[q * 64 + lane];
           v[q].x = m.x > 0.f ? v[q].x : 0.f; v[q].y = m.y > 0.f ? v[q].y : 0.f;
           v[q].z = m.z > 0.f ? v[q].z : 0.f; v[q].w = m.w > 0.f ? v[q].w : 0.f;
         }
@@ -271,6 +291,9 @@ __global__ __launch_bounds__(64 * C::WPW) void pointwise_fwd_kernel(Conv3dFwdArg
           const size_t orow = (((size_t)n * p.yD + od * p.ysd) * p.yH + oh * p.ysh) * p.yW + ow * p.ysw;
           *reinterpret_cast<float4 *>(p.y + orow * C::CO + (f % (C::CO / 4)) * 4) = v[q];
         }
+      } else if constexpr (C::BLK) {
+#pragma unroll
+        for (int q = 0; q < C::NOUT; ++q) reinterpret_cast<float4 *>(p.y)[oidx(row0, q * 64 + lane)] = v[q];
       } else {
         float4 *y4 = reinterpret_cast<float4 *>(p.y) + t4;
 #pragma unroll
@@ -519,6 +542,26 @@ int launch_pw_fwd_impl(const Conv3dFwdArgs &a, hipStream_t stream) {
   return mr3d_launch_status();
 }
 
+// column-blocked launch: a.Cout / CO blocks of the CI -> CO instance (whole tiles, no upsample add, no scatter: the caller checks)
+template <int CI, int CO>
+int launch_pw_fwd_blk(const Conv3dFwdArgs &a, hipStream_t stream) {
+  const long long rows = (long long)a.N * a.Do * a.Ho * a.Wo;
+  const int blocks = a.Cout / CO;
+  auto go = [&](auto cfg) {
+    using C = decltype(cfg);
+    if (set_lds_attr<C>(pointwise_fwd_kernel<C>) != MR3D_OK) return (int)MR3D_ERR_LAUNCH;
+    const long long ntiles = rows / C::ROWS;
+    constexpr int lds_wgs = (160 * 1024) / C::LDS_BYTES < 1 ? 1 : (160 * 1024) / C::LDS_BYTES;
+    const int wg_per_cu = lds_wgs < 8 ? lds_wgs : 8;
+    long long gx = ((long long)num_cus() * wg_per_cu + blocks - 1) / blocks;
+    if (gx > ntiles) gx = ntiles;
+    pointwise_fwd_kernel<C><<<dim3((unsigned)gx, (unsigned)blocks), 64, C::LDS_BYTES, stream>>>(a, rows);
+    return mr3d_launch_status();
+  };
+  if (a.add1 || a.add2 || a.mask) return go(PwCfg<CI, CO, true, 0, true>{});
+  return go(PwCfg<CI, CO, false, 0, true>{});
+}
+
 template <int CI, int CO, int C2>
 int launch_pw_pair(const Conv3dFwdArgs &a, hipStream_t stream) {
   using C = PwCfg<CI, CO, true, C2>;
@@ -569,6 +612,10 @@ int mr3d_pointwise_fwd_try(const Conv3dFwdArgs &a, hipStream_t stream, bool prob
   const long long rows = (long long)a.N * a.Do * a.Ho * a.Wo;
   if (rows < 32768 || rows > 0x7fffffffLL) return MR3D_ERR_UNSUPPORTED;             // small maps: not HBM-bound
   const int key = a.Cin * 1000 + a.Cout;
+  // 64 -> 256 as four column blocks of the 64 -> 64 instance (whole 64-row tiles; the blocks re-read x from L2);
+  // 128 -> 256 (layer4.0 conv1's data gradient on that pathway) as eight blocks of the 128 -> 32 instance, whose weights fit registers
+  const bool blk_ok = (key == 64256 || key == 128256) && !a.up && !scatter && rows % 64 == 0;
+  if (blk_ok) return probe_only ? MR3D_OK : (key == 64256 ? launch_pw_fwd_blk<64, 64>(a, stream) : launch_pw_fwd_blk<128, 32>(a, stream));
   if (probe_only) {          // would a streaming instance take this shape? (mr3d_conv3d_forward_variant)
     switch (key) {
       case 16016: case 16064: case 64016: case 64032: case 32064: case 64064: case 32128: case 128032: case 64128: case 128064:

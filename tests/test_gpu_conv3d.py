@@ -376,6 +376,45 @@ def test_pointwise_streaming_forward_epilogues_and_wgrad(dev, cin, cout):
     assert (db.cpu() - sb).abs().max().item() <= 1e-4 * dy.abs().sum((0, 2, 3, 4)).max().item()
 
 
+@pytest.mark.parametrize('cin', [64, 128])
+def test_pointwise_streaming_column_blocks_to_256(dev, cin):
+    """64 -> 256 and 128 -> 256 on 15 x 48 x 48 (layer3's conv3 and layer4.0 conv1's data gradient on the 768 x 768 x 120 pathway of
+    the shipped model: 34,560 positions, whole 64-row tiles) run as column blocks of the streaming 64 -> 64 / 128 -> 32 instances
+    (csrc/pointwise.hip, PwCfg<..., BLK>): the plain call, shift + residual + ReLU, two adds + mask, against an fp64 conv; a ragged
+    position count and an upsample add keep the generic kernel (same results)."""
+    import ctypes
+    from mr3d_amd import _hip
+    g = torch.Generator().manual_seed(256 + cin)
+    k1, s1, p0 = (1, 1, 1), (1, 1, 1), (0, 0, 0)
+    w = torch.randn((256, cin, 1, 1, 1), generator=g) / np.sqrt(cin)
+    wp = _hip.pack_conv_weight(w).to(dev)
+    shift = torch.randn(256, generator=g)
+    for dhw, blocked in (((15, 48, 48), True), ((15, 48, 47), False)):
+        x = torch.randn((1, cin) + dhw, generator=g)
+        add1, add2, mask = (torch.randn((1, 256) + dhw, generator=g) for _ in range(3))
+        conv = F.conv3d(x.double(), w.double(), shift.double())
+        xc = _cl(x).to(dev)
+        d = _hip.Conv3dDesc()
+        d.n, d.d, d.h, d.w_in, d.cin, d.cout = 1, dhw[0], dhw[1], dhw[2], cin, 256
+        d.kd = d.kh = d.kw = d.sd = d.sh = d.sw = 1
+        d.ys_d = d.ys_h = d.ys_w = 1
+        d.y_d, d.y_h, d.y_w = dhw
+        v = _hip.Conv3dVariant()
+        assert _hip.lib().mr3d_conv3d_forward_variant(ctypes.byref(d), ctypes.byref(v)) == 0 and bool(v.streaming_pointwise) == blocked
+        y = _hip.conv3d_forward(xc, wp, k1, s1, p0)
+        _check(y, (conv - shift.double().view(1, -1, 1, 1, 1)).float(), 'plain')
+        y = _hip.conv3d_forward(xc, wp, k1, s1, p0, shift=shift.to(dev), add1=_cl(add1).to(dev), relu=True)
+        _check(y, torch.relu(conv + add1).float(), 'shift + add1 + relu')
+        y = _hip.conv3d_forward(xc, wp, k1, s1, p0, add1=_cl(add1).to(dev), add2=_cl(add2).to(dev), mask=_cl(mask).to(dev))
+        _check(y, ((conv - shift.double().view(1, -1, 1, 1, 1) + add1 + add2) * (mask > 0)).float(), 'adds + mask')
+    up = torch.randn((1, 256, 8, 24, 24), generator=g)
+    dhw = (15, 48, 48)
+    x = torch.randn((1, cin) + dhw, generator=g)
+    conv = F.conv3d(x.double(), w.double())
+    y = _hip.conv3d_forward(_cl(x).to(dev), wp, k1, s1, p0, up=_cl(up).to(dev))
+    _check(y, (conv + F.interpolate(up.double(), size=dhw, mode='nearest')).float(), 'upsample add: generic kernel')
+
+
 @pytest.mark.parametrize('planes,dhw', [(32, (8, 16, 14)), (64, (7, 11, 9)), (128, (5, 16, 16)), (16, (9, 33, 20)),
                                         (64, (20, 64, 64))])
 def test_conv3d_dgrad_s2k3_parity_decomposed(dev, planes, dhw):

@@ -26,6 +26,7 @@ LAYERS = [
     ('l3 1x1 64->256', 64, 256, 1, (1, 1, 1), 0, (10, 32, 32)),
     ('l3 1x1 64->256 big', 64, 256, 1, (1, 1, 1), 0, (15, 48, 48)),          # the 768 x 768 x 120 pathway of the shipped model
     ('l3 1x1 256->64 big', 256, 64, 1, (1, 1, 1), 0, (15, 48, 48)),
+    ('l4 1x1 128->256 big', 128, 256, 1, (1, 1, 1), 0, (15, 48, 48)),
     ('l3 3^3 64->64 big', 64, 64, 3, (1, 1, 1), 1, (15, 48, 48)),
     ('l3 1x1 256->64', 256, 64, 1, (1, 1, 1), 0, (10, 32, 32)),
     ('l4 3^3 128->128', 128, 128, 3, (1, 1, 1), 1, (5, 16, 16)),
