@@ -13,6 +13,8 @@ backward and before gradient clipping (dist_utils.py:51-57).  Works on any torch
 """
 from collections import OrderedDict
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -349,11 +351,33 @@ class DistOptimizerStep:
         self.optimizer.step()
 
 
+_gc_state = {'steps': 0, 'frozen': False}
+
+
+def freeze_gc_after_warmup(warmup_steps=3):
+    """Call once per training step.  After `warmup_steps` calls: one full collection, then `gc.freeze()` -- every object alive at
+    that point (the detectors' plans are tens of thousands of small ctypes / list objects, the module tree, the arenas' views) moves
+    to the permanent generation and later collections only look at what the steps themselves allocate.  Without it CPython's cyclic
+    collector runs a full generation-2 pass every 10-20 steps of the dual-pathway model, and that pass takes 85 ms -- two whole steps
+    during which the GPU drains (per-step times 45, 45, ..., 130, 45, ...: `tools/two_stage_bench.py --two-scales --steps 1
+    --repeats 24`; 44.9 ms per step over 8 steps with it, 50-54 without).  MR3D_GC_FREEZE=0 leaves the collector alone.  Returns True
+    in the call that froze."""
+    import gc
+    _gc_state['steps'] += 1
+    if _gc_state['frozen'] or _gc_state['steps'] <= warmup_steps or os.environ.get('MR3D_GC_FREEZE', '1') == '0':
+        return False
+    gc.collect()
+    gc.freeze()
+    _gc_state['frozen'] = True
+    return True
+
+
 def train_step(detector, arena, optimizer, batch, world_size=1, grad_clip=35.0, group=None, overlap=True):
     """One iteration of the reference's hot loop (mmdet/apis/train.py:37-48 batch_processor + dist_utils.py:51-57):
     zero -> forward_train -> sum of the losses -> backward -> ONE all-reduce of the detector's gradient arena -> L2 clip
     (configs/...py:236) -> optimizer.step().  `batch` = (args, kwargs) of detector.forward_train.  Returns
     (total loss, loss dict) as device tensors: nothing is synchronised here."""
+    freeze_gc_after_warmup()
     arena.zero_grad()
     args, kwargs = batch
     if hasattr(detector, 'forward_backward'):     # same gradients, head backward issued ahead of the step's one host wait

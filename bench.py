@@ -275,13 +275,18 @@ def ops_microbench(dev):
     out = {}
 
     def timed(fn, iters=20):
+        # the median of three windows of `iters` calls (one window now and then comes out 1.5x long: 86 instead of 58 us for the
+        # same kernel whose rocprofv3 average is 57.9 -- another process's burst, a clock step)
         fn(); torch.cuda.synchronize()
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        for _ in range(iters):
-            fn()
-        e.record(); torch.cuda.synchronize()
-        return s.elapsed_time(e) * 1e3 / iters
+        wins = []
+        for _ in range(3):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(iters):
+                fn()
+            e.record(); torch.cuda.synchronize()
+            wins.append(s.elapsed_time(e) * 1e3 / iters)
+        return sorted(wins)[1]
 
     # NMS3D: 5 pyramid levels x 2 pathways per volume; per level N in {2000,2000,2000,1280,192}, thr 0.7
     tot = 0.0
@@ -367,7 +372,7 @@ def emit_json_line(obj):
     print(json.dumps(obj), flush=True)
 
 
-def two_stage_step_ms(vol, steps=5, two_scales=False, static_mask_batch=False, bf16=False, dcn_neck=False):
+def two_stage_step_ms(vol, steps=20, two_scales=False, static_mask_batch=False, bf16=False, dcn_neck=False):
     """BASELINE configs[2]: the whole single-pathway training step (backbone+FPN, RPN + loss + proposals/NMS3D,
     assign/sample 512, RoIAlign3D + bbox head, RoIAlign3D + mask head, all losses, backward) on one volume, timed by
     tools/two_stage_bench.py in a CHILD process (a fresh allocator / stream state, as a user would run it)."""
@@ -744,7 +749,7 @@ def main():
                 res['aux']['two_stage_iters_per_s'] = round(1e3 / ms, 2)
                 # same step with the mask head always on its full 128-row capacity (no positive-count read-back)
                 res['aux']['two_stage_step_static_mask_batch_ms'] = round(two_stage_step_ms((D, H, W), static_mask_batch=True), 2)
-                ms2 = two_stage_step_ms((D, H, W), steps=3, two_scales=True)  # the shipped model: region + its 1.5x copy
+                ms2 = two_stage_step_ms((D, H, W), steps=8, two_scales=True)  # the shipped model: region + its 1.5x copy
                 res['aux']['shipped_2scales_step_ms'] = round(ms2, 2)
                 res['aux']['shipped_2scales_iters_per_s'] = round(1e3 / ms2, 2)
                 # BASELINE configs[4] (build-defined: bf16 activation storage in backbone + FPN, DeformConv3d neck); NOT the
@@ -760,8 +765,8 @@ def main():
                                                     'gradients 8e-2 in L2 (measured 1.4e-2 .. 2.9e-2), losses 2e-2 -- tests/test_gpu_bf16.py, '
                                                     'tests/test_gpu_configs.py::test_config4_dual_pathway_dcn_neck_bf16')
                 res['aux']['bf16_two_stage_step_ms'] = round(two_stage_step_ms((D, H, W), bf16=True), 2)
-                res['aux']['bf16_shipped_2scales_step_ms'] = round(two_stage_step_ms((D, H, W), steps=3, two_scales=True, bf16=True), 2)
-                res['aux']['bf16_dcn_neck_2scales_step_ms'] = round(two_stage_step_ms((D, H, W), steps=2, two_scales=True, bf16=True, dcn_neck=True), 2)
+                res['aux']['bf16_shipped_2scales_step_ms'] = round(two_stage_step_ms((D, H, W), steps=8, two_scales=True, bf16=True), 2)
+                res['aux']['bf16_dcn_neck_2scales_step_ms'] = round(two_stage_step_ms((D, H, W), steps=6, two_scales=True, bf16=True, dcn_neck=True), 2)
             except Exception as exc:  # the headline number must still print
                 res['aux'] = {'error': repr(exc)}
         if world == 1 and not a.no_cpu_baseline and a.dtype == 'f32':

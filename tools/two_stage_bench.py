@@ -85,6 +85,9 @@ def main():
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
+    from mr3d_amd.dist_utils import freeze_gc_after_warmup      # what dist_utils.train_step does per step (MR3D_GC_FREEZE=0: off)
+    for _ in range(4):
+        freeze_gc_after_warmup()
     if a.phases and not a.two_scales:
         det._phase_events = []
         det.extract.zero_grad()
