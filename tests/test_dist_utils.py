@@ -310,3 +310,21 @@ def test_arena_sgd_equals_per_parameter_sgd_with_grads_none():
     assert torch.equal(fresh.never_used.weight, det.never_used.weight)
     assert not torch.equal(fresh.mask_head.weight, det.mask_head.weight)
     assert len(arena.untouched_ranges()) == 2
+
+
+def test_freeze_gc_after_warmup_freezes_once(monkeypatch):
+    """dist_utils.freeze_gc_after_warmup (called by train_step every step): nothing during the warm-up steps, then ONE full collection +
+    gc.freeze(); MR3D_GC_FREEZE=0 leaves the collector alone."""
+    import gc
+    from mr3d_amd import dist_utils
+    monkeypatch.setattr(dist_utils, '_gc_state', {'steps': 0, 'frozen': False})
+    monkeypatch.setenv('MR3D_GC_FREEZE', '0')
+    assert [dist_utils.freeze_gc_after_warmup(2) for _ in range(4)] == [False] * 4
+    monkeypatch.setattr(dist_utils, '_gc_state', {'steps': 0, 'frozen': False})
+    monkeypatch.setenv('MR3D_GC_FREEZE', '1')
+    before = gc.get_freeze_count()
+    try:
+        assert [dist_utils.freeze_gc_after_warmup(2) for _ in range(5)] == [False, False, True, False, False]
+        assert gc.get_freeze_count() > before
+    finally:
+        gc.unfreeze()
