@@ -173,6 +173,9 @@ def test_winograd_2d_variant_reports_the_kernel_form_per_map():
     finally:
         L.mr3d_tuning_set(5, 0)
     assert abs(v.mfma_issue_factor - 1.0 / 3.0) < 1e-6
+    # the wide kernel addresses x with 32-bit byte offsets: a 2.5 GB input keeps the 2x8x8 kernel (whose own offsets are per tile)
+    big = _conv_desc(3, 1, 128, 128, 64, 64, d=600)
+    assert tile(big) == (8, 2, 16)
 
 
 def test_up_even_flag_is_refused_where_no_kernel_implements_it():
