@@ -128,6 +128,24 @@ def test_conv3d_forward_winograd_2d_large_map(dev, wino2d_form):
     assert l2 <= 1e-5, f'L2-relative error {l2:.3e}'
 
 
+def test_conv3d_forward_winograd_2d_strided_output_grid(dev, wino2d_form):
+    """mr3d_conv3d_desc.ys_* / y_*: the result of a 64 -> 64 3x3x3 convolution scattered onto the even positions of a zeroed grid of
+    twice the extent (how a coarse-grid result lands in a fine map), from both two-dimensional Winograd kernels: the even positions
+    equal the plain call, everything else stays zero."""
+    from mr3d_amd import _hip
+    g = torch.Generator().manual_seed(17)
+    dhw = (9, 42, 50)
+    x = _cl(torch.randn((1, 64) + dhw, generator=g)).to(dev)
+    wp = _hip.pack_conv_weight(torch.randn((64, 64, 3, 3, 3), generator=g) / np.sqrt(64 * 27)).to(dev)
+    shift = torch.randn(64, generator=g).to(dev)
+    plain = _hip.conv3d_forward(x, wp, (3, 3, 3), (1, 1, 1), (1, 1, 1), shift=shift, relu=True)
+    big = torch.zeros((1, 2 * dhw[0], 2 * dhw[1], 2 * dhw[2], 64), device=dev)
+    _hip.conv3d_forward(x, wp, (3, 3, 3), (1, 1, 1), (1, 1, 1), shift=shift, relu=True, out=big, out_stride=(2, 2, 2))
+    assert torch.equal(big[:, ::2, ::2, ::2], plain)
+    big[:, ::2, ::2, ::2] = 0
+    assert not bool(big.any())
+
+
 def test_conv3d_forward_winograd_2d_wide_form_walks_tiles(dev):
     """The wide kernel's workgroups are persistent: 256 of them walk the tiles of a launch, an XCD's 32 side by side over one eighth
     of the tile range, with the chunk pipeline running across tile borders (the next tile's halo and first V are requested inside the
