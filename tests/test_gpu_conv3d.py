@@ -128,6 +128,30 @@ def test_conv3d_forward_winograd_2d_large_map(dev, wino2d_form):
     assert l2 <= 1e-5, f'L2-relative error {l2:.3e}'
 
 
+@pytest.mark.parametrize('cin,cout', [(64, 128), (128, 64), (32, 64)])
+def test_conv3d_forward_winograd_2d_other_channel_counts(dev, cin, cout, wino2d_form):
+    """the 64-wide two-dimensional Winograd kernels with two Cout tiles (blockIdx.y), with 16 Cin chunks of 8 and with 4: against an
+    fp64 conv on a ragged map, fused shift + ReLU"""
+    from mr3d_amd import _hip
+    import ctypes
+    g = torch.Generator().manual_seed(cin * 3 + cout)
+    dhw = (17, 45, 51)                                  # 378 tiles of 2x8x8: the map takes these kernels
+    d = _hip.Conv3dDesc()
+    d.n, d.d, d.h, d.w_in, d.cin, d.cout = 1, dhw[0], dhw[1], dhw[2], cin, cout
+    d.kd = d.kh = d.kw = 3
+    d.sd = d.sh = d.sw = d.pd = d.ph = d.pw = 1
+    d.workspace_bytes = -1
+    v = _hip.Conv3dVariant()
+    assert _hip.lib().mr3d_conv3d_forward_variant(ctypes.byref(d), ctypes.byref(v)) == 0
+    assert v.winograd == 8 and v.tile_d == (4 if wino2d_form == 2 else 2)
+    x = torch.randn((1, cin) + dhw, generator=g)
+    w = torch.randn((cout, cin, 3, 3, 3), generator=g) / np.sqrt(cin * 27)
+    shift = torch.randn(cout, generator=g)
+    ref = torch.relu(F.conv3d(x.double(), w.double(), shift.double(), 1, 1))
+    y = _hip.conv3d_forward(_cl(x).to(dev), _hip.pack_conv_weight(w).to(dev), (3, 3, 3), (1, 1, 1), (1, 1, 1), shift=shift.to(dev), relu=True)
+    _check(y, ref.float(), f'{cin}->{cout}')
+
+
 def test_conv3d_forward_winograd_2d_strided_output_grid(dev, wino2d_form):
     """mr3d_conv3d_desc.ys_* / y_*: the result of a 64 -> 64 3x3x3 convolution scattered onto the even positions of a zeroed grid of
     twice the extent (how a coarse-grid result lands in a fine map), from both two-dimensional Winograd kernels: the even positions
