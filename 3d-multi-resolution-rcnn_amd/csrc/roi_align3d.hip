@@ -21,6 +21,7 @@
 #include <map>
 #include <mutex>
 #include <utility>
+#include <type_traits>
 
 namespace {
 
@@ -31,19 +32,21 @@ struct RoiGeom {
   int nw, nh, nd;     // samples per bin
 };
 
+// (roi_align_kernel.cu:232-259 op by op, WITHOUT fused multiply-adds like sample_coord below: `end * scale - start` contracted into
+// one fma moves an extent by an ulp, i.e. a sample coordinate near x = 175 by 1.5e-5 and an output by up to 5e-5 of the map's scale)
 __device__ __forceinline__ RoiGeom roi_geom(const float *__restrict__ roi, float scale, float scale_d, int sample_num,
                                             int PD, int PH, int PW) {
   RoiGeom g;
   g.b = (int)roi[0];
-  g.sw = roi[1] * scale;
-  g.sh = roi[2] * scale;
-  const float ew = (roi[3] + 1) * scale;
-  const float eh = (roi[4] + 1) * scale;
-  g.sd = roi[5] * scale_d;
-  const float ed = (roi[6] + 1) * scale_d;
-  const float rw = fmaxf(ew - g.sw, 0.f);
-  const float rh = fmaxf(eh - g.sh, 0.f);
-  const float rd = fmaxf(ed - g.sd, 0.f);
+  g.sw = __fmul_rn(roi[1], scale);
+  g.sh = __fmul_rn(roi[2], scale);
+  const float ew = __fmul_rn(__fadd_rn(roi[3], 1.f), scale);
+  const float eh = __fmul_rn(__fadd_rn(roi[4], 1.f), scale);
+  g.sd = __fmul_rn(roi[5], scale_d);
+  const float ed = __fmul_rn(__fadd_rn(roi[6], 1.f), scale_d);
+  const float rw = fmaxf(__fsub_rn(ew, g.sw), 0.f);
+  const float rh = fmaxf(__fsub_rn(eh, g.sh), 0.f);
+  const float rd = fmaxf(__fsub_rn(ed, g.sd), 0.f);
   g.bd = rd / PD;
   g.bh = rh / PH;
   g.bw = rw / PW;
@@ -1404,6 +1407,501 @@ int try_fwd_wave(const float *feat, float *out, const float *rois, int num_rois,
 }
 
 // ------------------------------------------------------------------------------------------
+// channels-last FORWARD, row streaming (round 6): one 4-wave workgroup per (RoI, 64 channels, PDC pooled depths) streams the voxel
+// rows of the footprint through ONE shared LDS ring; wave w owns the pooled COLUMNS pw = w PWW .. w PWW + PWW - 1 of every bin.
+// Why another kernel.  The box kernel's workgroups walk tables -> staging -> bins -> stores in lock-step, and its bins phase is
+// bound by LDS BANDWIDTH, not latency: 147 bins x 64 taps x 256 B = 2.4 MB of ds_read_b128 per RoI, two RoIs per CU = 16 us at
+// 128 B/clk.  The wave kernel above has the right arithmetic (separable: a few LDS reads per voxel row instead of 64 per bin) but a
+// 10-13 us fixed cost per wave and one wave per (RoI, pooled depth): a RoI with a thousand footprint voxels is one serial chain.
+// A first row-streaming form with one independent wave per (RoI, 2 pooled rows) (tools/diag/roi_rows_stamps.py, stamps per unit) showed
+// what bounds this op on the chip: with every wave streaming, a CU's LDS-DMA path moves ~12 B/clk (an 8 KB batch took 3.8 us with
+// eight waves per CU), so bytes loaded twice (rows shared by neighbouring units, 1.5x; whole 4-voxel pieces, 1.6x) are paid in
+// full, and the launch ended with single waves walking 36-batch units at the latency-bound 8 KB per 1.2 us: 55 us.  Hence:
+//   * every row of the footprint is loaded ONCE per workgroup, only rows and planes some sample touches, as 16-byte LDS-DMA
+//     (`buffer_load_dwordx4 ... lds`: four voxels x 64 channels per instruction), the pieces of a batch dealt over the four
+//     waves; the ring holds NB batches, NB - 1 in flight while one is contracted (counted vmcnt per wave + ONE barrier per
+//     batch; inline asm so that the compiler's own LDS-alias wait does not drain the ring);
+//   * the split over waves is by pooled column: every wave contracts every row (its 2 PWW x-samples: 4 PWW LDS reads per row) into
+//     its PDC x PH x PWW accumulators -- balanced whatever the RoI's shape, no reduction, no row loaded twice;
+//   * tap tables never leave the registers: lane e holds sample e (x samples, then y, then z), scalars come out with v_readlane,
+//     extents with one ballot per axis (samples ascend, so the valid ones are a contiguous lane range), the y / z weight of a voxel
+//     row is two compares per lane + a DPP add + a readlane per pooled row.  No table in LDS, no 64-row cap;
+//   * results leave through an LDS tile [channel][bin] laid out like the output block, 16 bytes per lane.
+// Same samples, taps and weights as the reference (axis_tap / sample_coord); sums associated per axis as in the wave kernel.
+// Rows wider than two ring buffers (> 8 LPB voxels) are evaluated bin by bin from global memory (correct, slow, never with the
+// shipped level rule below 256-pixel RoIs).
+// ------------------------------------------------------------------------------------------
+typedef unsigned rows_desc_t __attribute__((ext_vector_type(4)));
+#ifdef MR3D_ROWS_STAMPS                                // diagnostic builds: wall-clock stamps of a workgroup's phases (tools/diag/roi_rows_stamps.py)
+__device__ unsigned long long g_rows_stamps[8192 * 16];
+__device__ int g_rows_dbg;                              // timing-only ablations: 1 = no contraction, 2 = no row loads
+#define ROWS_DBG(bit) (g_rows_dbg & (bit))
+#define ROWS_MARK(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_rows_stamps[blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
+#define ROWS_NOTE(k, v) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_rows_stamps[blockIdx.x * 16 + (k)] = (unsigned long long)(v); } while (0)
+#else
+#define ROWS_MARK(k) do { } while (0)
+#define ROWS_NOTE(k, v) do { } while (0)
+#define ROWS_DBG(bit) 0
+#endif
+
+__device__ __forceinline__ void rows_wait_vmcnt(int n) {       // at most n vector-memory operations outstanding (n uniform)
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;     // (waiting for more than asked is always safe)
+  }
+}
+
+// one LDS-DMA piece: 64 lanes x 16 bytes from (descriptor base + per-lane byte offset) to LDS bytes [m0, m0 + 1024)
+__device__ __forceinline__ void rows_dma16(unsigned m0, unsigned voff, rows_desc_t desc) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(m0), "v"(voff), "s"(desc) : "memory");      // (m0: nothing else in these kernels uses it)
+}
+
+__device__ __forceinline__ float rows_rl(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+__device__ __forceinline__ void rows_barrier() {                // raw barrier: the ring's LDS-DMA stays in flight across it
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+constexpr int kRowsWaves = 4, kRowsThreads = kRowsWaves * MR3D_WAVE;
+typedef float rows_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int rows_bperm(int v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
+__device__ __forceinline__ float rows_bperm(float v, int src_lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane << 2, __builtin_bit_cast(int, v)));
+}
+
+template <int PDC, int PH_, int PW_, int NS, int LPB, int NB, int FH>
+__global__ __launch_bounds__(kRowsThreads) void roi_align3d_fwd_rows(const float *feat, float *__restrict__ out, const float *__restrict__ rois,
+                                                                     float scale, float scale_d, int C, int D, int H, int W, int PD,
+                                                                     int num_rois, LevelTable lt) {
+  constexpr int NXS = PW_ * NS, NYS = PH_ * NS, NZS = PDC * NS;
+  static_assert(NS == 2, "two samples per bin and axis");
+  static_assert(NXS + NYS + NZS <= MR3D_WAVE, "one sample per lane");
+  static_assert(PW_ <= 16, "the pooled columns are the rows of one MFMA tile");
+  static_assert((LPB == 4 || LPB == 8) && NB >= 4 && NB <= 8 && NB % 2 == 0, "cntv has one lane per buffer; the wait switch counts to 16");
+  constexpr int MP = PDC * PH_, MT = (MP + 15) / 16;              // (pooled depth, pooled row) pairs = rows of the second product, its tiles
+  constexpr int PWP = PW_ <= 8 ? 8 : 16;                          // pooled columns of the T1 scratch
+  constexpr int KXMAX = 2 * LPB;                                  // k-steps of the first product: rows of up to 8 LPB = 64 voxels
+  constexpr int NBIN = PH_ * PW_, TS = (PDC * NBIN) | 1, CHH = MR3D_WAVE / FH;      // tile: [channel][TS] floats, CHH channels per flush pass
+  constexpr int RING = NB * LPB * 256, TILE = CHH * TS;
+  constexpr uint64_t YM = ((1ull << NYS) - 1) << NXS, ZM = ((1ull << NZS) - 1) << (NXS + NYS);
+  __shared__ __attribute__((aligned(16))) float buf[RING > TILE ? RING : TILE];      // the row ring, then the output tile
+  __shared__ __attribute__((aligned(16))) float scr_all[kRowsWaves][4 * PWP * 16];   // per wave: T1 of a 4-row group, [row][pooled column][16 channels]
+  __shared__ float wy_tab[2 * NYS * 16 * MT], wz_tab[2 * NZS * 16 * MT];             // the second product's A factors, [touched row / plane][pair]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;                          // MFMA 16x16x4: A row / B column, k; D row = 4 lk + r, column li
+  // workgroup -> (RoI, channel group, pooled-depth chunk).  Workgroups are dealt round-robin over the 8 XCDs: the chunks of RoI r
+  // sit on the workgroups b with b % 8 == r % 8, next to each other in dispatch order, so that the planes two chunks share come
+  // out of one L2 (placement is a speed matter only)
+  const int pdch = (PD + PDC - 1) / PDC, upr = (C / MR3D_WAVE) * pdch;
+  const int bid = blockIdx.x, slot8 = bid >> 3;
+  const int r = (slot8 / upr) * 8 + (bid & 7);
+  ROWS_MARK(0);
+  if (r >= num_rois) return;
+  const int u = slot8 % upr;
+  const int pd0 = (u % pdch) * PDC, c0 = (u / pdch) * MR3D_WAVE;
+  const int npd = min(PDC, PD - pd0);                               // (scalar)
+  if (lt.num) {
+    const int lvl = roi_level(rois + (size_t)r * 7, lt.finest_scale, lt.num);
+    D = pick4(lvl, lt.D); H = pick4(lvl, lt.H); W = pick4(lvl, lt.W);
+    scale = pick4(lvl, lt.scale); scale_d = pick4(lvl, lt.scale_d);
+    feat = pick4(lvl, lt.feat);
+  }
+  const RoiGeom g = roi_geom(rois + (size_t)r * 7, scale, scale_d, NS, PD, PH_, PW_);
+  // ---- lane e = sample e: x samples of every bin, then the y samples, then the chunk's z samples (every wave holds the whole table).
+  // An out-of-range sample (or one of a pooled depth beyond the map) has indices -1 (it never matches a voxel) and zero weights.
+  int tlo = -1, thi = -1;
+  float tl = 0.f, th = 0.f;
+  {
+    const bool isx = lane < NXS, isy = !isx && lane < NXS + NYS, isz = !isx && !isy && lane < NXS + NYS + NZS;
+    const int k = isx ? lane : (isy ? lane - NXS : lane - NXS - NYS);
+    const int p = (isz ? pd0 : 0) + k / NS;
+    const bool in = isx || isy || (isz && k / NS < npd);
+    AxisTap t;
+    if (in && axis_tap(sample_coord(isx ? g.sw : (isy ? g.sh : g.sd), p, isx ? g.bw : (isy ? g.bh : g.bd), k % NS, NS),
+                       isx ? W : (isy ? H : D), t)) {
+      tlo = t.lo; thi = t.hi; tl = t.l; th = t.h;
+    }
+  }
+  const uint64_t vm = __builtin_amdgcn_ballot_w64(tlo >= 0);
+  ROWS_MARK(1);
+  const uint64_t xm = vm & ((1ull << NXS) - 1), ym = vm & YM, zm = vm & ZM;
+  const bool nonempty = xm != 0 && ym != 0 && zm != 0;            // else: every sample of the chunk is dropped, the bins are 0
+
+  rows_f32x4 acc[MT][PW_];                                         // this wave's 16 channels of Out[(pd, ph)][pw]
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int pw = 0; pw < PW_; ++pw) acc[mt][pw] = (rows_f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int B = PD * NBIN;
+  const float inv_count = 1.f / (float)(NS * NS * NS);
+  float *oblock = out + ((size_t)r * C + c0) * B;                  // this RoI's [64 channels][B] block
+  const float *fb = feat + (size_t)g.b * D * H * W * C + c0;       // channel group c0 of the RoI's image
+  const unsigned nrec = (unsigned)(((size_t)D * H * W * C - c0) * 4);
+
+  if (nonempty) {
+    // samples ascend along an axis: the first / last valid lane of an axis holds its lowest / highest voxel
+    const int x0 = __builtin_amdgcn_readlane(tlo, __builtin_ctzll(xm)), x1 = __builtin_amdgcn_readlane(thi, 63 - __builtin_clzll(xm));
+    const int y0 = __builtin_amdgcn_readlane(tlo, __builtin_ctzll(ym)), y1 = __builtin_amdgcn_readlane(thi, 63 - __builtin_clzll(ym));
+    const int z0 = __builtin_amdgcn_readlane(tlo, __builtin_ctzll(zm)), z1 = __builtin_amdgcn_readlane(thi, 63 - __builtin_clzll(zm));
+    const int nx = x1 - x0 + 1, pieces = (nx + 3) >> 2;
+    // touched planes / rows as bit masks relative to z0 / y0, then as lists (lane j: the j-th touched index): a row of the flattened
+    // (plane, row) sequence is two readlanes -- the streaming loop below has no search loop and next to no scalar branch (a taken
+    // branch costs ~25 cycles here: a first version that walked the rows with a cursor spent 0.8 us per 4-row batch on control flow
+    // with every load and every multiply switched off, tools/diag/roi_rows_stamps.py ablations)
+    const int ny = y1 - y0 + 1, nz = z1 - z0 + 1;
+    if (pieces <= 2 * LPB && ny <= 64 && nz <= 64) {
+      uint64_t ybits = 0, zbits = 0;
+#pragma unroll
+      for (int e = NXS; e < NXS + NYS; ++e) {
+        const int lo = __builtin_amdgcn_readlane(tlo, e), hi = __builtin_amdgcn_readlane(thi, e);
+        if (lo >= 0) ybits |= (1ull << (lo - y0)) | (1ull << (hi - y0));
+      }
+#pragma unroll
+      for (int e = NXS + NYS; e < NXS + NYS + NZS; ++e) {
+        const int lo = __builtin_amdgcn_readlane(tlo, e), hi = __builtin_amdgcn_readlane(thi, e);
+        if (lo >= 0) zbits |= (1ull << (lo - z0)) | (1ull << (hi - z0));
+      }
+      const int nyt = __builtin_popcountll(ybits), nzt = __builtin_popcountll(zbits), nrows = nyt * nzt;
+      auto compact = [&](uint64_t bits, int nset) {                 // lane j < nset: the index of the j-th set bit
+        const bool set = (bits >> lane) & 1;
+        const int below = __builtin_popcountll(bits & ((1ull << lane) - 1));        // set bits below this lane
+        const int dst = set ? below : nset + (lane - below);       // a permutation of the lanes
+        return __builtin_amdgcn_ds_permute(dst << 2, lane);
+      };
+      const int yrel = compact(ybits, nyt), zrel = compact(zbits, nzt);             // lane j: j-th touched row / plane, relative to y0 / z0
+      const int yoffs = (y0 + yrel) * W * C * 4, zoffs = (z0 + zrel) * H * W * C * 4;   // ... as byte offsets inside the image
+
+      // ---- A operand of the first product, T1[pw][c] = sum_x Wx[pw][x] F[x][c]: lane (li, lk) holds Wx[pw = li][x0 + 4 ks + lk], the
+      // summed tap weights of bin column li's two samples on that voxel (a clamped sample has lo == hi: both taps count), zero
+      // beyond the row's last voxel.  Rows of up to 16 voxels (the common case) run a loop unrolled for their k-step count; a longer
+      // row owns a whole double-size buffer and runs all 2 LPB k-steps (the ring is zero-filled at the start: stale bytes are finite)
+      const int kx = pieces;                                         // k-steps of a row
+      float ax[KXMAX];
+      {
+        const int e0 = min(li * NS, NXS - 1), e1 = min(li * NS + 1, NXS - 1);
+        const bool on = li < PW_;
+        // (every ds_bpermute runs with all lanes active, the selects follow: a permute inside `on ? ... : ...` executes under a partial
+        // mask and an inactive SOURCE lane reads as 0 -- the first build of this kernel lost every pooled column >= PW / 2 that way)
+        const int lo0 = rows_bperm(tlo, e0), hi0 = rows_bperm(thi, e0), lo1 = rows_bperm(tlo, e1), hi1 = rows_bperm(thi, e1);
+        const float l0p = rows_bperm(tl, e0), h0p = rows_bperm(th, e0), l1p = rows_bperm(tl, e1), h1p = rows_bperm(th, e1);
+        const float l0 = on ? l0p : 0.f, h0 = on ? h0p : 0.f, l1 = on ? l1p : 0.f, h1 = on ? h1p : 0.f;
+        auto wx = [&](int ks) {
+          const int x = x0 + 4 * ks + lk;
+          return ((lo0 == x ? h0 : 0.f) + (hi0 == x ? l0 : 0.f)) + ((lo1 == x ? h1 : 0.f) + (hi1 == x ? l1 : 0.f));
+        };
+#pragma unroll
+        for (int ks = 0; ks < KXMAX; ++ks) ax[ks] = wx(ks);
+      }
+      // ---- A operand of the second product, Out[(pd, ph)][.] = sum_rows wz[pd][z_row] wy[ph][y_row] T1[row][.]: lane (li, lk) of tile mt
+      // owns pair m = 16 mt + li and multiplies it with row lk of a 4-row group.  Its two factors come from tables in LDS,
+      // WY[touched row][m] and WZ[touched plane][m] (the summed tap weights of the pair's samples on that row / plane; at most 2 NYS
+      // rows and 2 NZS planes are touched), built here: lane (li, lk) of wave w fills rows lk + 4 w, + 16, ...
+      constexpr int MTW = 16 * MT;
+      {
+        float *wyt = wy_tab, *wzt = wz_tab;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int m = 16 * mt + li, pa = m / PH_, ph = m - pa * PH_;
+          const bool on = m < MP;
+          int slo[2][NS], shi[2][NS];
+          float sl[2][NS], sh[2][NS];
+#pragma unroll
+          for (int i = 0; i < NS; ++i) {
+            const int ey = min(NXS + ph * NS + i, 63), ez = min(NXS + NYS + pa * NS + i, 63);
+            slo[0][i] = rows_bperm(tlo, ey); shi[0][i] = rows_bperm(thi, ey); sl[0][i] = rows_bperm(tl, ey); sh[0][i] = rows_bperm(th, ey);
+            slo[1][i] = rows_bperm(tlo, ez); shi[1][i] = rows_bperm(thi, ez); sl[1][i] = rows_bperm(tl, ez); sh[1][i] = rows_bperm(th, ez);
+          }
+#pragma unroll
+          for (int ax_ = 0; ax_ < 2; ++ax_) {
+            const int nt = ax_ == 0 ? nyt : nzt, first = ax_ == 0 ? y0 : z0;
+            float *tab = ax_ == 0 ? wyt : wzt;
+            for (int j0 = 4 * wave; j0 < nt; j0 += 4 * kRowsWaves) {          // (uniform trip count: the permutes run with all lanes active)
+              const int j = j0 + lk;
+              const int v = first + rows_bperm(ax_ == 0 ? yrel : zrel, min(j, 63));
+              const float w = ((slo[ax_][0] == v ? sh[ax_][0] : 0.f) + (shi[ax_][0] == v ? sl[ax_][0] : 0.f)) +
+                              ((slo[ax_][1] == v ? sh[ax_][1] : 0.f) + (shi[ax_][1] == v ? sl[ax_][1] : 0.f));
+              if (j < nt) tab[j * MTW + m] = on ? w : 0.f;
+            }
+          }
+        }
+      }
+      const uint64_t fbu = mr3d_uniform64((uint64_t)(uintptr_t)fb);                 // (float geometry is uniform, but lives in vector registers)
+      const rows_desc_t desc = {(unsigned)fbu, (unsigned)(fbu >> 32) & 0xffffu, (unsigned)__builtin_amdgcn_readfirstlane((int)nrec), 0x00020000u};
+      const unsigned lds_base = (unsigned)(uintptr_t)buf;           // LDS byte address of the ring (the low half of its flat address)
+      const unsigned vstride = (unsigned)C * 4u;                    // bytes between neighbouring voxels of a row
+      const unsigned lanepart = (unsigned)(lane >> 4) * vstride + (unsigned)(lane & 15) * 16u + (unsigned)x0 * vstride;
+      // ring geometry: NB buffers of LPB pieces; a row of more than 4 LPB voxels takes buffers of twice the size
+      const int bufp = pieces <= 4 && pieces <= LPB ? LPB : 2 * LPB, nbuf = pieces <= 4 && pieces <= LPB ? NB : NB / 2;
+      const int rpb = pieces <= 4 ? bufp / pieces : 1;              // whole rows per buffer (a long row is read KXMAX k-steps deep: alone in its buffer)
+      int cntv = 0;                                                 // lane b: the pieces THIS wave requested for buffer b
+      int rl = 0, zil = 0, yil = 0;                                 // the loader's position in the row sequence: row, (plane, row) list indices
+      int outstanding = 0;                                          // this wave's pieces in flight
+      int deal = 0;                                                 // rows are dealt over the waves: row k of a batch to wave (deal + k) % 4
+      auto issue = [&](int bsel) {                                  // the next batch of rows into buffer bsel
+        const int n = min(rpb, nrows - rl);
+        int mine = 0;
+        const int kf = (wave - deal) & (kRowsWaves - 1);            // this wave's first row of the batch
+        int zi = zil, yi = yil + kf;
+        while (yi >= nyt) { yi -= nyt; ++zi; }
+        const int q4 = kRowsWaves / nyt, r4 = kRowsWaves - q4 * nyt;
+        for (int k = kf; k < n; k += kRowsWaves) {
+          const unsigned rowoff = (unsigned)(__builtin_amdgcn_readlane(zoffs, zi) + __builtin_amdgcn_readlane(yoffs, yi));
+          const unsigned m0 = lds_base + (unsigned)((bsel * bufp + k * pieces) << 10);
+          unsigned voff = lanepart + rowoff;
+          for (int pc = 0; pc < pieces; ++pc, voff += 4 * vstride) {
+            if (!ROWS_DBG(2)) rows_dma16(m0 + (unsigned)(pc << 10), voff, desc);
+          }
+          mine += pieces;
+          yi += r4; zi += q4;
+          if (yi >= nyt) { yi -= nyt; ++zi; }
+        }
+        deal = (deal + n) & (kRowsWaves - 1);
+        rl += n;
+        yil += n;                                                   // (n <= 8 rows: a few wraps at most)
+        while (yil >= nyt) { yil -= nyt; ++zil; }
+        cntv = lane == bsel ? mine : cntv;
+        outstanding += mine;
+      };
+      // ---- contraction.  A voxel row of the ring becomes T1[pw][16 channels] (first product, K = the row's voxels) and parks in
+      // the wave's scratch; every four rows the second product adds them into the accumulators (K = the four rows)
+      float *scr = scr_all[wave];
+      for (int i = lane; i < 4 * PWP * 16; i += MR3D_WAVE) scr[i] = 0.f;         // (a row slot never written multiplies a zero weight: keep it finite)
+      if (kx > 4) {                                                  // long rows read their buffer to its end
+        for (int i = tid; i < RING / 4; i += kRowsThreads) reinterpret_cast<float4 *>(buf)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
+      }
+      const int fbase = lk * 256 + (16 * wave + li) * 4;             // this lane's B element of a k-step: voxel lk, channel 16 wave + li
+      const int swr = (4 * lk * 16 + li) * 4, srd = (lk * PWP * 16 + li) * 4;       // scratch bytes: D rows 4 lk + r of a row slot / B row lk
+      // this lane's row of the current 4-row group, as list indices (plane, row): row lk of group 0, then + 4 per group
+      int gyi = lk, gzi = 0;
+      while (gyi >= nyt) { gyi -= nyt; ++gzi; }
+      const int gq4 = 4 / nyt, gr4 = 4 - gq4 * nyt;
+      auto second = [&]() {
+        const bool live = gzi < nzt;                                 // (beyond the last row: weight 0)
+        const char *py = reinterpret_cast<const char *>(wy_tab) + ((live ? gyi : 0) * MTW + li) * 4;
+        const char *pz = reinterpret_cast<const char *>(wz_tab) + ((live ? gzi : 0) * MTW + li) * 4;
+        float aw[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const float w = *reinterpret_cast<const float *>(py + mt * 64) * *reinterpret_cast<const float *>(pz + mt * 64);
+          aw[mt] = live ? w : 0.f;
+        }
+#pragma unroll
+        for (int pw = 0; pw < PW_; ++pw) {
+          const float bv = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(scr) + srd + pw * 64);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[mt][pw] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[mt], bv, acc[mt][pw], 0, 0, 0);
+        }
+        gyi += gr4; gzi += gq4;
+        if (gyi >= nyt) { gyi -= nyt; ++gzi; }
+      };
+      int rp = 0;                                                    // rows contracted
+      auto rows_of = [&](int bsel, auto KXC) {                       // the rows of buffer bsel; KXC: compile-time k-steps
+        constexpr int KX = decltype(KXC)::value;
+        const int n = ROWS_DBG(1) ? 0 : min(rpb, nrows - rp);
+        const char *rowp = reinterpret_cast<const char *>(buf) + ((bsel * bufp) << 10) + fbase;
+        for (int k = 0; k < n; ++k) {
+          rows_f32x4 t1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < KX; ++ks)
+            t1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[ks], *reinterpret_cast<const float *>(rowp + ks * 1024), t1, 0, 0, 0);
+          rowp += pieces << 10;
+          const int gi = (rp + k) & 3;                                // the row's slot in its 4-row group
+          if (4 * lk < PWP) {                                         // D rows 4 lk .. 4 lk + 3 = pooled columns
+            char *d = reinterpret_cast<char *>(scr) + swr + gi * (PWP * 64);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) *reinterpret_cast<float *>(d + rr * 64) = t1[rr];
+          }
+          if (gi == 3) second();
+        }
+        rp += n;
+      };
+      ROWS_MARK(2);
+      // the streaming loop, once per compile-time k-step count: ONE switch in front of it (a switch per batch made the compiler
+      // shuffle all 56 accumulator registers between the cases' assignments -- 220 moves per batch)
+      auto stream = [&](auto KXC) {
+        int nissued = 0, nproc = 0, bi = 0, bp = 0;                 // batches requested / contracted; the buffers they go to
+        for (; nissued < nbuf - 1 && rl < nrows; ++nissued) {
+          issue(bi);
+          bi = bi + 1 == nbuf ? 0 : bi + 1;
+        }
+        while (nproc < nissued) {
+          outstanding -= __builtin_amdgcn_readlane(cntv, bp);
+          rows_wait_vmcnt(outstanding);                              // this wave's pieces of batch nproc have landed ...
+          rows_barrier();                                           // ... everybody's have, and everybody is done with batch nproc - 1
+#ifdef MR3D_ROWS_STAMPS
+          if (nproc == 0) ROWS_MARK(3);
+#endif
+          if (rl < nrows) {                                         // its buffer takes the next batch
+            issue(bi);
+            bi = bi + 1 == nbuf ? 0 : bi + 1;
+            ++nissued;
+          }
+          rows_of(bp, KXC);
+          bp = bp + 1 == nbuf ? 0 : bp + 1;
+          ++nproc;
+        }
+        ROWS_NOTE(8, nproc);
+      };
+      switch (kx) {
+        case 1: stream(std::integral_constant<int, 1>{}); break;
+        case 2: stream(std::integral_constant<int, 2>{}); break;
+        case 3: stream(std::integral_constant<int, 3>{}); break;
+        case 4: stream(std::integral_constant<int, 4>{}); break;
+        default: stream(std::integral_constant<int, KXMAX>{}); break;
+      }
+      if (nrows & 3) second();                                      // the last, partial group
+      ROWS_NOTE(9, pieces); ROWS_NOTE(10, rpb);
+    } else {
+      // ---- rows wider than the ring: bin by bin from global memory, straight to the output (lane = channel: strided stores)
+      const __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(fb), 0, (int)nrec, 0x00020000);
+      for (int f = wave; f < npd * NBIN; f += kRowsWaves) {
+        const int a = f / NBIN, rem = f - a * NBIN, b = rem / PW_, pw = rem - b * PW_;
+        float v = 0.f;
+        for (int iz = 0; iz < NS; ++iz) {
+          const int ez = NXS + NYS + a * NS + iz;
+          const int zlo_ = __builtin_amdgcn_readlane(tlo, ez), zhi_ = __builtin_amdgcn_readlane(thi, ez);
+          const float zl2 = rows_rl(tl, ez), zh2 = rows_rl(th, ez);
+          for (int iy = 0; iy < NS; ++iy) {
+            const int ey = NXS + b * NS + iy;
+            const int ylo_ = __builtin_amdgcn_readlane(tlo, ey), yhi_ = __builtin_amdgcn_readlane(thi, ey);
+            const float yl2 = rows_rl(tl, ey), yh2 = rows_rl(th, ey);
+            for (int ix = 0; ix < NS; ++ix) {
+              const int ex = pw * NS + ix;
+              const int xlo_ = __builtin_amdgcn_readlane(tlo, ex), xhi_ = __builtin_amdgcn_readlane(thi, ex);
+              const float xl2 = rows_rl(tl, ex), xh2 = rows_rl(th, ex);
+              if (zlo_ < 0 || ylo_ < 0 || xlo_ < 0) continue;
+              auto at = [&](int zz, int yy, int xx) { return buffer_load1(fr, (unsigned)(((zz * H + yy) * W + xx) * C + lane) * 4u, 0u); };
+              v += zh2 * (yh2 * (xh2 * at(zlo_, ylo_, xlo_) + xl2 * at(zlo_, ylo_, xhi_)) + yl2 * (xh2 * at(zlo_, yhi_, xlo_) + xl2 * at(zlo_, yhi_, xhi_))) +
+                   zl2 * (yh2 * (xh2 * at(zhi_, ylo_, xlo_) + xl2 * at(zhi_, ylo_, xhi_)) + yl2 * (xh2 * at(zhi_, yhi_, xlo_) + xl2 * at(zhi_, yhi_, xhi_)));
+            }
+          }
+        }
+        oblock[(size_t)lane * B + (pd0 + a) * NBIN + rem] = v * inv_count;
+      }
+      return;
+    }
+  }
+
+  // ---- out[r][c0 + channel][pd0 .. pd0 + npd)[:][:]: through the LDS tile [channel][TS] (a wave writes its 16 channels: accumulator
+  // rows 4 lk + r are (pd, ph) pairs, the column is the channel), then every thread copies 16 bytes at a time: the chunk's bins of
+  // one channel are ONE run of npd * NBIN floats, and when the chunk is the whole RoI the 64 runs are one block
+  ROWS_MARK(4);
+  const bool whole = pd0 == 0 && npd == PD && TS == B && FH == 1;   // the tile IS the output block
+  const int run = npd * NBIN;
+#pragma unroll
+  for (int h = 0; h < FH; ++h) {
+    rows_barrier();                                                 // the ring (or the previous pass's tile) has been read
+    if ((16 * wave) / CHH == h) {
+      float *trow = buf + ((16 * wave + li) % CHH) * TS;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int m = 16 * mt + 4 * lk + rr, pa = m / PH_, ph = m - pa * PH_;
+          if (m < MP && pa < npd) {
+#pragma unroll
+            for (int pw = 0; pw < PW_; ++pw) trow[pa * NBIN + ph * PW_ + pw] = acc[mt][pw][rr] * inv_count;
+          }
+        }
+    }
+    rows_barrier();
+    if (whole) {
+      const float4 *src = reinterpret_cast<const float4 *>(buf);
+      float4 *dst = reinterpret_cast<float4 *>(oblock);
+      for (int i = tid; i < MR3D_WAVE * TS / 4; i += kRowsThreads) dst[i] = src[i];
+    } else if (NBIN % 4 == 0) {
+      const int rv = run / 4;                                       // float4 per channel
+      int ch = tid / rv, v = tid - ch * rv;
+      const int dch = kRowsThreads / rv, dv = kRowsThreads - dch * rv;
+      for (; ch < CHH; ch += dch) {
+        const float *t = buf + ch * TS + 4 * v;
+        *reinterpret_cast<float4 *>(oblock + (size_t)(h * CHH + ch) * B + pd0 * NBIN + 4 * v) = make_float4(t[0], t[1], t[2], t[3]);
+        v += dv;
+        if (v >= rv) { v -= rv; ++ch; }
+      }
+    } else {
+      int ch = tid / run, v = tid - ch * run;
+      const int dch = kRowsThreads / run, dv = kRowsThreads - dch * run;
+      for (; ch < CHH; ch += dch) {
+        oblock[(size_t)(h * CHH + ch) * B + pd0 * NBIN + v] = buf[ch * TS + v];
+        v += dv;
+        if (v >= run) { v -= run; ++ch; }
+      }
+    }
+  }
+  ROWS_MARK(5);
+#ifdef MR3D_ROWS_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ROWS_MARK(6);
+#endif
+}
+
+#ifdef MR3D_ROWS_STAMPS
+}  // namespace
+extern "C" int mr3d_debug_rows_ablate(int bits) { return hipMemcpyToSymbol(HIP_SYMBOL(g_rows_dbg), &bits, sizeof(int)) == hipSuccess ? 0 : -1; }
+extern "C" int mr3d_debug_rows_stamps(unsigned long long *dst) {     // 8192 x 16 stamps of the last row-streaming launch
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_rows_stamps), sizeof(unsigned long long) * 8192 * 16) == hipSuccess ? 0 : -1;
+}
+namespace {
+#endif
+
+template <int PDC, int PH_, int PW_, int LPB, int NB, int FH>
+int launch_fwd_rows(const float *feat, float *out, const float *rois, int num_rois, float scale, float scale_d, int C, int D, int H, int W,
+                    int PD, const LevelTable &lt, hipStream_t stream) {
+  const int upr = (C / MR3D_WAVE) * ((PD + PDC - 1) / PDC);
+  const int grid = ((num_rois + 7) / 8) * 8 * upr;
+  roi_align3d_fwd_rows<PDC, PH_, PW_, 2, LPB, NB, FH><<<grid, kRowsThreads, 0, stream>>>(feat, out, rois, scale, scale_d, C, D, H, W, PD, num_rois, lt);
+  return mr3d_launch_status();
+}
+
+// fp32 channels-last features, C % 64 == 0, sample_num 2, the two extractor shapes of the shipped model; anything else: the kernels above
+int try_fwd_rows(const float *feat, float *out, const float *rois, int num_rois, float scale, float scale_d, int ns, int C, int D, int H,
+                 int W, int PD, int PH, int PW, const LevelTable &lt, hipStream_t stream) {
+  const int form = g_mr3d_tuning[MR3D_TUNE_ROIALIGN_FORM];
+  if (form == 1 || C % MR3D_WAVE != 0 || ns != 2) return MR3D_ERR_UNSUPPORTED;
+  // byte offsets inside one image travel as 32-bit values, and the buffer descriptor's range check covers one image
+  long long image = (long long)D * H * W * C * 4;
+  for (int i = 0; i < lt.num; ++i) image = std::max(image, (long long)lt.D[i] * lt.H[i] * lt.W[i] * C * 4);
+  if (image >= (1LL << 31) || (long long)PD * PH * PW * MR3D_WAVE * 4 >= (1LL << 31)) return MR3D_ERR_UNSUPPORTED;
+#define MR3D_ROWS(PDC, PH_, PW_, LPB, NB, FH) return launch_fwd_rows<PDC, PH_, PW_, LPB, NB, FH>(feat, out, rois, num_rois, scale, scale_d, C, D, H, W, PD, lt, stream)
+  if (PW == 7 && PH == 7 && PD <= 3) {                 // the bbox extractor
+    switch (form) {
+      case 3: MR3D_ROWS(3, 7, 7, 8, 4, 1);
+      case 4: MR3D_ROWS(1, 7, 7, 8, 4, 1);
+      case 5: MR3D_ROWS(3, 7, 7, 4, 4, 1);
+      default: MR3D_ROWS(1, 7, 7, 4, 4, 1);
+    }
+  }
+  if (PW == 14 && PH == 14) {                          // the mask extractor: one pooled depth per workgroup
+    switch (form) {
+      case 3: MR3D_ROWS(2, 14, 14, 8, 4, 4);
+      case 4: MR3D_ROWS(1, 14, 14, 8, 4, 4);
+      case 5: MR3D_ROWS(1, 14, 14, 4, 4, 2);
+      default: MR3D_ROWS(1, 14, 14, 4, 4, 4);
+    }
+  }
+#undef MR3D_ROWS
+  return MR3D_ERR_UNSUPPORTED;
+}
+
+// ------------------------------------------------------------------------------------------
 // channels-last backward, voxel-owner form (C % 64 == 0).  A workgroup owns (RoI, 64 channels, a chunk of pooled depths): the
 // chunk's top-gradient planes are staged once as G[bin][64 ch] in LDS, the per-axis weight matrices Wx[x][pw] (Wy, Wz alike:
 // the summed tap weights of bin pw on voxel x) are built once together with the range of bins that reach each voxel (the
@@ -1842,6 +2340,9 @@ extern "C" int mr3d_roi_align3d_forward(const float *features, const float *rois
   hipStream_t stream = mr3d_stream(stream_);
   const int B = pooled_depth * pooled_height * pooled_width;
   if (use_cl(layout, sample_num, pooled_depth, pooled_height, pooled_width)) {
+    const int str = try_fwd_rows(features, output, rois, num_rois, spatial_scale, spatial_scale_depth, sample_num, channels, depth, height,
+                                 width, pooled_depth, pooled_height, pooled_width, LevelTable{}, stream);
+    if (str != MR3D_ERR_UNSUPPORTED) return str;
     const int st0 = try_fwd_wave(features, output, rois, num_rois, spatial_scale, spatial_scale_depth, sample_num, channels, depth, height,
                                  width, pooled_depth, pooled_height, pooled_width, LevelTable{}, stream);
     if (st0 != MR3D_ERR_UNSUPPORTED) return st0;
@@ -1993,6 +2494,9 @@ extern "C" int mr3d_roi_align3d_forward_ml(const mr3d_roi_level *levels_host, in
   if (!rois || !output) return MR3D_ERR_INVALID_ARG;
   if (!use_cl(MR3D_LAYOUT_NDHWC, sample_num, pooled_depth, pooled_height, pooled_width)) return MR3D_ERR_UNSUPPORTED;
   {
+    const int str = try_fwd_rows(nullptr, output, rois, num_rois, 0.f, 0.f, sample_num, channels, 1, 1, 1, pooled_depth, pooled_height,
+                                 pooled_width, lt, mr3d_stream(stream_));
+    if (str != MR3D_ERR_UNSUPPORTED) return str;
     const int st0 = try_fwd_wave(nullptr, output, rois, num_rois, 0.f, 0.f, sample_num, channels, 1, 1, 1, pooled_depth, pooled_height,
                                  pooled_width, lt, mr3d_stream(stream_));
     if (st0 != MR3D_ERR_UNSUPPORTED) return st0;

@@ -213,6 +213,41 @@ def test_roi_align3d_benchmark_shapes_properties(dev):
     np.testing.assert_allclose(a[:16].cpu().numpy(), exp, rtol=RTOL, atol=ATOL)
 
 
+@pytest.mark.parametrize('P', [(3, 7, 7), (10, 14, 14)])
+@pytest.mark.parametrize('form', [0, 1, 3, 4, 5])
+def test_roi_align3d_row_streaming_forward_paths(dev, P, form):
+    """the row-streaming forward (round 6, roi_align3d_fwd_rows) against the oracle on the row shapes that take its different
+    paths: one-piece rows (<= 4 voxels), unrolled k-step counts (<= 16 voxels), long rows alone in a double-size ring buffer
+    (17 .. 32 / 64 voxels), rows wider than the ring (bin-by-bin fallback), footprints with untouched rows (bins of > 2 voxels),
+    rois hanging over every border, a degenerate roi, two images, 128 channels; every (chunk, ring) instance behind
+    MR3D_TUNE_ROIALIGN_FORM and the round-5 kernels (form 1) give the same answer"""
+    from mr3d_amd import _hip
+    rng = np.random.default_rng(100 + P[0])
+    N, C, D, H, W = 2, 128, 12, 40, 300
+    feat = _feat(rng, (N, C, D, H, W), torch.channels_last_3d, dev)
+    rois = np.array([[0, 8, 8, 19, 40, 2, 10],          # 4 voxels wide: one piece per row
+                     [1, 8, 8, 60, 150, 1, 20],         # 14 voxels wide
+                     [0, 100, 20, 200, 60, 4, 9],       # 26 voxels: long row (LPB 4) / unrolled (LPB 8)
+                     [1, 300, 10, 520, 30, 0, 6],       # 56 voxels: long row in both ring sizes
+                     [0, 100, 40, 700, 70, 3, 8],       # 151 voxels: wider than the ring
+                     [1, 40, 2, 60, 158, 0, 23],        # 39 rows, bins of 5.6 voxels: untouched rows in between
+                     [0, -30, -20, 50, 30, -6, 8],      # over the low borders
+                     [1, 1100, 120, 1250, 170, 15, 40],  # over the high borders
+                     [0, 10, 10, 10, 10, 3, 3],         # one pixel
+                     [1, 30, 30, 20, 20, 5, 2]], np.float32)   # malformed: end < start
+    exp = orc.roi_align3d_forward(feat.cpu().numpy(), rois, *P, 0.25, 0.5, 2)
+    out = torch.zeros(exp.shape, device=dev)
+    _hip.lib().mr3d_tuning_set(7, form)
+    try:
+        _hip.roi_align3d_forward(feat, torch.from_numpy(rois).to(dev), *P, 0.25, 0.5, 2, out)
+    finally:
+        _hip.lib().mr3d_tuning_set(7, 0)
+    # 1e-4 relative, the absolute floor tied to the map's scale as in the full-size test: sample coordinates reach x = 175 here, where one
+    # fp32 ulp of a coordinate (1.5e-5) is 3e-5 of a bin built from N(0, 1) voxels -- every kernel of the file, the round-5 ones
+    # included, sits within 5e-5 of the oracle on the 56- and 151-voxel rows and within 3e-7 of each other
+    np.testing.assert_allclose(out.cpu().numpy(), exp, rtol=RTOL, atol=2e-5 * np.abs(exp).max())
+
+
 def test_roi_align3d_error_conventions(dev):
     from mr3d_amd.mmdet_ops.roi_align import roi_align_cuda
     f = torch.zeros((1, 4, 4, 8, 8), device=dev)
