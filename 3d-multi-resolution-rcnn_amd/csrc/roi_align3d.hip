@@ -1418,14 +1418,18 @@ int try_fwd_wave(const float *feat, float *out, const float *rois, int num_rois,
 // eight waves per CU), so bytes loaded twice (rows shared by neighbouring units, 1.5x; whole 4-voxel pieces, 1.6x) are paid in
 // full, and the launch ended with single waves walking 36-batch units at the latency-bound 8 KB per 1.2 us: 55 us.  Hence:
 //   * every row of the footprint is loaded ONCE per workgroup, only rows and planes some sample touches, as 16-byte LDS-DMA
-//     (`buffer_load_dwordx4 ... lds`: four voxels x 64 channels per instruction), the pieces of a batch dealt over the four
-//     waves; the ring holds NB batches, NB - 1 in flight while one is contracted (counted vmcnt per wave + ONE barrier per
-//     batch; inline asm so that the compiler's own LDS-alias wait does not drain the ring);
-//   * the split over waves is by pooled column: every wave contracts every row (its 2 PWW x-samples: 4 PWW LDS reads per row) into
-//     its PDC x PH x PWW accumulators -- balanced whatever the RoI's shape, no reduction, no row loaded twice;
-//   * tap tables never leave the registers: lane e holds sample e (x samples, then y, then z), scalars come out with v_readlane,
-//     extents with one ballot per axis (samples ascend, so the valid ones are a contiguous lane range), the y / z weight of a voxel
-//     row is two compares per lane + a DPP add + a readlane per pooled row.  No table in LDS, no 64-row cap;
+//     (`buffer_load_dwordx4 ... lds`: four voxels x 64 channels per instruction).  The ring holds four batches, three in flight
+//     while one is contracted; batch i is requested by wave i % 4 alone, which therefore waits for it with a plain vmcnt(0), and
+//     ONE barrier per batch publishes it (inline asm loads, so that the compiler's own LDS-alias wait does not drain the ring);
+//   * the contraction is two small fp32 MFMA products instead of per-bin taps -- the bookkeeping of which voxel feeds which bin
+//     becomes dense weight matrices: T1[pw][c] = sum_x Wx[pw][x] F[x][c] per voxel row (v_mfma_f32_16x16x4_f32, K = the row's
+//     voxels, wave w owns channels 16 w .. 16 w + 15), then Out[(pd, ph)][pw, c] += sum_rows wz[pd][z] wy[ph][y] T1[row][pw, c]
+//     for four rows at a time (K = the rows).  No run-time-indexed accumulator, no branch per row: what bounded the scalar
+//     versions of this kernel was the instruction count of a wave (one instruction per ~4.5 cycles and ~25 cycles per taken
+//     branch: with every load and every multiply switched off a 4-row batch still cost 0.8 us of cursor and weight code);
+//   * tap tables never leave the registers: lane e holds sample e (x samples, then y, then z), extents come from one ballot per
+//     axis (samples ascend, so the valid ones are a contiguous lane range), the touched rows / planes from two bit masks compacted
+//     with one ds_permute each, the two A operands from ds_bpermute gathers (ALWAYS with all lanes active, see below);
 //   * results leave through an LDS tile [channel][bin] laid out like the output block, 16 bytes per lane.
 // Same samples, taps and weights as the reference (axis_tap / sample_coord); sums associated per axis as in the wave kernel.
 // Rows wider than two ring buffers (> 8 LPB voxels) are evaluated bin by bin from global memory (correct, slow, never with the
@@ -1443,28 +1447,6 @@ __device__ int g_rows_dbg;                              // timing-only ablations
 #define ROWS_NOTE(k, v) do { } while (0)
 #define ROWS_DBG(bit) 0
 #endif
-
-__device__ __forceinline__ void rows_wait_vmcnt(int n) {       // at most n vector-memory operations outstanding (n uniform)
-  switch (n) {
-    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
-    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-    case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
-    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
-    case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;     // (waiting for more than asked is always safe)
-  }
-}
 
 // one LDS-DMA piece: 64 lanes x 16 bytes from (descriptor base + per-lane byte offset) to LDS bytes [m0, m0 + 1024)
 __device__ __forceinline__ void rows_dma16(unsigned m0, unsigned voff, rows_desc_t desc) {
@@ -1491,7 +1473,7 @@ __global__ __launch_bounds__(kRowsThreads) void roi_align3d_fwd_rows(const float
   static_assert(NS == 2, "two samples per bin and axis");
   static_assert(NXS + NYS + NZS <= MR3D_WAVE, "one sample per lane");
   static_assert(PW_ <= 16, "the pooled columns are the rows of one MFMA tile");
-  static_assert((LPB == 4 || LPB == 8) && NB >= 4 && NB <= 8 && NB % 2 == 0, "cntv has one lane per buffer; the wait switch counts to 16");
+  static_assert((LPB == 4 || LPB == 8) && NB == 4, "at most three batches in flight: a wave waits for its batch with vmcnt(0)");
   constexpr int MP = PDC * PH_, MT = (MP + 15) / 16;              // (pooled depth, pooled row) pairs = rows of the second product, its tiles
   constexpr int PWP = PW_ <= 8 ? 8 : 16;                          // pooled columns of the T1 scratch
   constexpr int KXMAX = 2 * LPB;                                  // k-steps of the first product: rows of up to 8 LPB = 64 voxels
@@ -1649,34 +1631,25 @@ __global__ __launch_bounds__(kRowsThreads) void roi_align3d_fwd_rows(const float
       // ring geometry: NB buffers of LPB pieces; a row of more than 4 LPB voxels takes buffers of twice the size
       const int bufp = pieces <= 4 && pieces <= LPB ? LPB : 2 * LPB, nbuf = pieces <= 4 && pieces <= LPB ? NB : NB / 2;
       const int rpb = pieces <= 4 ? bufp / pieces : 1;              // whole rows per buffer (a long row is read KXMAX k-steps deep: alone in its buffer)
-      int cntv = 0;                                                 // lane b: the pieces THIS wave requested for buffer b
       int rl = 0, zil = 0, yil = 0;                                 // the loader's position in the row sequence: row, (plane, row) list indices
-      int outstanding = 0;                                          // this wave's pieces in flight
-      int deal = 0;                                                 // rows are dealt over the waves: row k of a batch to wave (deal + k) % 4
-      auto issue = [&](int bsel) {                                  // the next batch of rows into buffer bsel
+      // batch i is requested by wave i % 4 alone (the others only move the cursor): with at most three batches in flight a wave
+      // has nothing younger than the batch it must wait for, so its wait is vmcnt(0) -- no per-wave piece counts, no counted waits
+      auto issue = [&](int bsel, bool mine) {                       // the next batch of rows into buffer bsel
         const int n = min(rpb, nrows - rl);
-        int mine = 0;
-        const int kf = (wave - deal) & (kRowsWaves - 1);            // this wave's first row of the batch
-        int zi = zil, yi = yil + kf;
-        while (yi >= nyt) { yi -= nyt; ++zi; }
-        const int q4 = kRowsWaves / nyt, r4 = kRowsWaves - q4 * nyt;
-        for (int k = kf; k < n; k += kRowsWaves) {
-          const unsigned rowoff = (unsigned)(__builtin_amdgcn_readlane(zoffs, zi) + __builtin_amdgcn_readlane(yoffs, yi));
-          const unsigned m0 = lds_base + (unsigned)((bsel * bufp + k * pieces) << 10);
-          unsigned voff = lanepart + rowoff;
-          for (int pc = 0; pc < pieces; ++pc, voff += 4 * vstride) {
-            if (!ROWS_DBG(2)) rows_dma16(m0 + (unsigned)(pc << 10), voff, desc);
+        if (mine && !ROWS_DBG(2)) {
+          int zi = zil, yi = yil;
+          unsigned m0 = lds_base + (unsigned)((bsel * bufp) << 10);
+          for (int k = 0; k < n; ++k) {
+            unsigned voff = lanepart + (unsigned)(__builtin_amdgcn_readlane(zoffs, zi) + __builtin_amdgcn_readlane(yoffs, yi));
+            for (int pc = 0; pc < pieces; ++pc, voff += 4 * vstride, m0 += 1024) rows_dma16(m0, voff, desc);
+            const bool wrap = yi + 1 == nyt;
+            yi = wrap ? 0 : yi + 1;
+            zi += wrap ? 1 : 0;
           }
-          mine += pieces;
-          yi += r4; zi += q4;
-          if (yi >= nyt) { yi -= nyt; ++zi; }
         }
-        deal = (deal + n) & (kRowsWaves - 1);
         rl += n;
         yil += n;                                                   // (n <= 8 rows: a few wraps at most)
         while (yil >= nyt) { yil -= nyt; ++zil; }
-        cntv = lane == bsel ? mine : cntv;
-        outstanding += mine;
       };
       // ---- contraction.  A voxel row of the ring becomes T1[pw][16 channels] (first product, K = the row's voxels) and parks in
       // the wave's scratch; every four rows the second product adds them into the accumulators (K = the four rows)
@@ -1716,20 +1689,45 @@ __global__ __launch_bounds__(kRowsThreads) void roi_align3d_fwd_rows(const float
         constexpr int KX = decltype(KXC)::value;
         const int n = ROWS_DBG(1) ? 0 : min(rpb, nrows - rp);
         const char *rowp = reinterpret_cast<const char *>(buf) + ((bsel * bufp) << 10) + fbase;
-        for (int k = 0; k < n; ++k) {
-          rows_f32x4 t1 = {0.f, 0.f, 0.f, 0.f};
+        const int rstride = pieces << 10;
+        // R rows at a time while they stay inside one 4-row group: their B reads are issued together and their MFMA chains are
+        // independent (row by row, a wave waited for an LDS round trip, two dependent MFMAs and the result's way back per row)
+        auto rows_at = [&](int k, auto RC) {
+          constexpr int R = decltype(RC)::value;
+          float bq[R][KX];
+#pragma unroll
+          for (int q = 0; q < R; ++q)
+#pragma unroll
+            for (int ks = 0; ks < KX; ++ks) bq[q][ks] = *reinterpret_cast<const float *>(rowp + q * rstride + ks * 1024);
+          rows_f32x4 t1[R];
+#pragma unroll
+          for (int q = 0; q < R; ++q) t1[q] = (rows_f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int ks = 0; ks < KX; ++ks)
-            t1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[ks], *reinterpret_cast<const float *>(rowp + ks * 1024), t1, 0, 0, 0);
-          rowp += pieces << 10;
-          const int gi = (rp + k) & 3;                                // the row's slot in its 4-row group
+#pragma unroll
+            for (int q = 0; q < R; ++q) t1[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[ks], bq[q][ks], t1[q], 0, 0, 0);
+          rowp += R * rstride;
+          const int gi = (rp + k) & 3;                                // the first row's slot in its 4-row group
           if (4 * lk < PWP) {                                         // D rows 4 lk .. 4 lk + 3 = pooled columns
             char *d = reinterpret_cast<char *>(scr) + swr + gi * (PWP * 64);
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) *reinterpret_cast<float *>(d + rr * 64) = t1[rr];
+            for (int q = 0; q < R; ++q)
+#pragma unroll
+              for (int rr = 0; rr < 4; ++rr) *reinterpret_cast<float *>(d + q * (PWP * 64) + rr * 64) = t1[q][rr];
           }
-          if (gi == 3) second();
+          // (compiler barrier: hipcc 7.2 sank second()'s scratch READS into the lane-masked block above in one copy of this loop --
+          //  the lanes of k-groups 2 and 3 then multiplied stale registers; tests: rows of <= 4 voxels with the 8-piece ring)
+          asm volatile("" ::: "memory");
+          if (gi + R == 4) second();
+        };
+        int k = 0;
+        if constexpr (KX <= 4) {
+#ifndef MR3D_ROWS_NO_R4
+          for (; k + 4 <= n && ((rp + k) & 3) == 0; k += 4) rows_at(k, std::integral_constant<int, 4>{});
+#endif
+          for (; k + 2 <= n && ((rp + k) & 1) == 0; k += 2) rows_at(k, std::integral_constant<int, 2>{});
         }
+        for (; k < n; ++k) rows_at(k, std::integral_constant<int, 1>{});
         rp += n;
       };
       ROWS_MARK(2);
@@ -1738,18 +1736,17 @@ __global__ __launch_bounds__(kRowsThreads) void roi_align3d_fwd_rows(const float
       auto stream = [&](auto KXC) {
         int nissued = 0, nproc = 0, bi = 0, bp = 0;                 // batches requested / contracted; the buffers they go to
         for (; nissued < nbuf - 1 && rl < nrows; ++nissued) {
-          issue(bi);
+          issue(bi, (nissued & (kRowsWaves - 1)) == wave);
           bi = bi + 1 == nbuf ? 0 : bi + 1;
         }
         while (nproc < nissued) {
-          outstanding -= __builtin_amdgcn_readlane(cntv, bp);
-          rows_wait_vmcnt(outstanding);                              // this wave's pieces of batch nproc have landed ...
-          rows_barrier();                                           // ... everybody's have, and everybody is done with batch nproc - 1
+          if ((nproc & (kRowsWaves - 1)) == wave) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's batch has landed ...
+          rows_barrier();                                           // ... everybody sees it, and everybody is done with batch nproc - 1
 #ifdef MR3D_ROWS_STAMPS
           if (nproc == 0) ROWS_MARK(3);
 #endif
           if (rl < nrows) {                                         // its buffer takes the next batch
-            issue(bi);
+            issue(bi, (nissued & (kRowsWaves - 1)) == wave);
             bi = bi + 1 == nbuf ? 0 : bi + 1;
             ++nissued;
           }
@@ -1799,12 +1796,13 @@ __global__ __launch_bounds__(kRowsThreads) void roi_align3d_fwd_rows(const float
     }
   }
 
-  // ---- out[r][c0 + channel][pd0 .. pd0 + npd)[:][:]: through the LDS tile [channel][TS] (a wave writes its 16 channels: accumulator
-  // rows 4 lk + r are (pd, ph) pairs, the column is the channel), then every thread copies 16 bytes at a time: the chunk's bins of
-  // one channel are ONE run of npd * NBIN floats, and when the chunk is the whole RoI the 64 runs are one block
+  // ---- out[r][c0 + channel][pd0 .. pd0 + npd)[:][:]: through the LDS tile [channel][TS] (a wave writes its 16 channels:
+  // accumulator rows 4 lk + r are (pd, ph) pairs, the column is the channel), then every thread copies 16 bytes at a time: the
+  // chunk's bins of one channel are ONE run, and when the chunk is the whole RoI the 64 runs are one block
   ROWS_MARK(4);
   const bool whole = pd0 == 0 && npd == PD && TS == B && FH == 1;   // the tile IS the output block
-  const int run = npd * NBIN;
+  const int run = npd * NBIN, goff = pd0 * NBIN;
+  const bool vec = (run & 3) == 0 && (goff & 3) == 0 && (B & 3) == 0;
 #pragma unroll
   for (int h = 0; h < FH; ++h) {
     rows_barrier();                                                 // the ring (or the previous pass's tile) has been read
@@ -1826,13 +1824,13 @@ __global__ __launch_bounds__(kRowsThreads) void roi_align3d_fwd_rows(const float
       const float4 *src = reinterpret_cast<const float4 *>(buf);
       float4 *dst = reinterpret_cast<float4 *>(oblock);
       for (int i = tid; i < MR3D_WAVE * TS / 4; i += kRowsThreads) dst[i] = src[i];
-    } else if (NBIN % 4 == 0) {
+    } else if (vec) {
       const int rv = run / 4;                                       // float4 per channel
       int ch = tid / rv, v = tid - ch * rv;
       const int dch = kRowsThreads / rv, dv = kRowsThreads - dch * rv;
       for (; ch < CHH; ch += dch) {
         const float *t = buf + ch * TS + 4 * v;
-        *reinterpret_cast<float4 *>(oblock + (size_t)(h * CHH + ch) * B + pd0 * NBIN + 4 * v) = make_float4(t[0], t[1], t[2], t[3]);
+        *reinterpret_cast<float4 *>(oblock + (size_t)(h * CHH + ch) * B + goff + 4 * v) = make_float4(t[0], t[1], t[2], t[3]);
         v += dv;
         if (v >= rv) { v -= rv; ++ch; }
       }
@@ -1840,7 +1838,7 @@ __global__ __launch_bounds__(kRowsThreads) void roi_align3d_fwd_rows(const float
       int ch = tid / run, v = tid - ch * run;
       const int dch = kRowsThreads / run, dv = kRowsThreads - dch * run;
       for (; ch < CHH; ch += dch) {
-        oblock[(size_t)(h * CHH + ch) * B + pd0 * NBIN + v] = buf[ch * TS + v];
+        oblock[(size_t)(h * CHH + ch) * B + goff + v] = buf[ch * TS + v];
         v += dv;
         if (v >= run) { v -= run; ++ch; }
       }
@@ -1881,19 +1879,26 @@ int try_fwd_rows(const float *feat, float *out, const float *rois, int num_rois,
   for (int i = 0; i < lt.num; ++i) image = std::max(image, (long long)lt.D[i] * lt.H[i] * lt.W[i] * C * 4);
   if (image >= (1LL << 31) || (long long)PD * PH * PW * MR3D_WAVE * 4 >= (1LL << 31)) return MR3D_ERR_UNSUPPORTED;
 #define MR3D_ROWS(PDC, PH_, PW_, LPB, NB, FH) return launch_fwd_rows<PDC, PH_, PW_, LPB, NB, FH>(feat, out, rois, num_rois, scale, scale_d, C, D, H, W, PD, lt, stream)
+  // Kernel times on the SURVEY 8(d) rois (rocprofv3 --kernel-trace, tools/r6_roi_kt.sh; round-5 kernels: box 54.5, wave 64.4 us):
+  //   (3,7,7)   x 512: one pooled depth per workgroup, 4-piece buffers (26 KB of LDS, six workgroups per CU: all 1536 resident) 42.3 us;
+  //                    8-piece buffers (43 KB, three per CU) 44.9; the three depths in one workgroup (two M-tiles) 55.8
+  //   (10,14,14) x 128: one pooled depth per workgroup 49.7 / 50.3 us (4- / 8-piece buffers); two depths 56.0
+  // Sharing a large chunk between workgroups that leave early when the RoI is small (each slot estimates the chunk's rows x pieces
+  // from the RoI's extents) was measured and dropped: once every slot of the chip is taken, a workgroup's turnover costs ~24 ns
+  // whatever its lifetime (4077 early leavers of 0.9 us each stretched the launch from 48 to 95 us).
   if (PW == 7 && PH == 7 && PD <= 3) {                 // the bbox extractor
     switch (form) {
-      case 3: MR3D_ROWS(3, 7, 7, 8, 4, 1);
       case 4: MR3D_ROWS(1, 7, 7, 8, 4, 1);
       case 5: MR3D_ROWS(3, 7, 7, 4, 4, 1);
+      case 6: MR3D_ROWS(3, 7, 7, 8, 4, 1);
       default: MR3D_ROWS(1, 7, 7, 4, 4, 1);
     }
   }
-  if (PW == 14 && PH == 14) {                          // the mask extractor: one pooled depth per workgroup
+  if (PW == 14 && PH == 14) {                          // the mask extractor
     switch (form) {
-      case 3: MR3D_ROWS(2, 14, 14, 8, 4, 4);
       case 4: MR3D_ROWS(1, 14, 14, 8, 4, 4);
-      case 5: MR3D_ROWS(1, 14, 14, 4, 4, 2);
+      case 5: MR3D_ROWS(2, 14, 14, 4, 4, 4);
+      case 6: MR3D_ROWS(2, 14, 14, 8, 4, 4);
       default: MR3D_ROWS(1, 14, 14, 4, 4, 4);
     }
   }

@@ -64,9 +64,9 @@ enum {
                                      2 x 8 x 8-tile kernel of round 2, 2 = always the wide kernel (4 x 8 x 8 tiles, 512 threads) */
   MR3D_TUNE_SIDE_PRIORITY = 6,    /* priority class of the plan executor's side queues, read at the first plan run of the process: 0 = high
                                      (default: a hardware queue of their own whatever other libraries hold), 1 = middle, 2 = low */
-  MR3D_TUNE_ROIALIGN_FORM = 7,    /* channels-last fp32 RoIAlign3D kernels (roi_align3d.hip): 0 = the library's choice per pooled shape (round 6: the
-                                     row-streaming kernels), 1 = the round-5 kernels (box / wave forward, voxel-owner / wave backward), 2.. = other
-                                     (chunk, ring) instances of the row-streaming kernels, see try_fwd_rows / try_bwd_rows */
+  MR3D_TUNE_ROIALIGN_FORM = 7,    /* channels-last fp32 RoIAlign3D forward (roi_align3d.hip): 0 = the library's choice per pooled shape (round 6: the
+                                     row-streaming MFMA kernel), 1 = the round-5 kernels (box / wave), 4..6 = other (pooled-depth chunk, ring)
+                                     instances of the row-streaming kernel, see try_fwd_rows */
   MR3D_TUNE_NUM_KEYS = 16
 };
 void mr3d_tuning_set(int key, int value);

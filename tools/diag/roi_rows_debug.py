@@ -24,6 +24,7 @@ rois = np.array([[0, 8, 8, 19, 40, 2, 10],
                  [0, -20, -20, 30, 30, -6, 8],
                  [0, 10, 10, 10, 10, 3, 3]], np.float32)
 f = torch.from_numpy(feat).to(dev).contiguous(memory_format=torch.channels_last_3d)
+_hip.lib().mr3d_tuning_set(7, int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 for P in ((3, 7, 7), (10, 14, 14)):
     exp = orc.roi_align3d_forward(feat, rois, *P, 0.25, 0.5, 2)
     out = torch.zeros(exp.shape, device=dev)

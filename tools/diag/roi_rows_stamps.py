@@ -37,11 +37,18 @@ for tag, n, osz, od in (('bbox', 512, 7, 3), ('mask', 128, 14, 10)):
         ext(feats, r)
     torch.cuda.synchronize()
     buf = np.zeros(8192 * 16, dtype=np.uint64)
+    zero = np.zeros(8192 * 16, dtype=np.uint64)
     assert fn(buf.ctypes.data) == 0
     raw = buf.reshape(8192, 16).astype(np.int64)
+    ex = (raw[:, 7] > 0) & (raw[:, 6] == 0)
+    if ex.any():
+        e = raw[ex]
+        print(f'  {ex.sum()} workgroups left at the split test: lifetime median {us(np.median(e[:, 7] - e[:, 0])):.2f} max {us((e[:, 7] - e[:, 0]).max()):.2f} us; their starts: median {us(np.median(e[:, 0]) - raw[raw[:, 0] > 0][:, 0].min()):.1f} last {us(e[:, 0].max() - raw[raw[:, 0] > 0][:, 0].min()):.1f} us')
     live = raw[:, 6] > 0
     s = raw[live]
     t0 = s[:, 0].min()
+    st = np.sort(us(s[:, 0] - t0))
+    print('  starts of the staying workgroups (us) at 10/25/50/75/90/100 %:', ' '.join(f'{st[int(q * (len(st) - 1))]:.1f}' for q in (0.1, 0.25, 0.5, 0.75, 0.9, 1.0)))
     print(f'== {tag} form {form}: {live.sum()} workgroups; launch span (first start -> last end) {us(s[:, 6].max() - t0):.1f} us; '
           f'starts spread {us(s[:, 0].max() - t0):.1f} us; ends: median {us(np.median(s[:, 6]) - t0):.1f}  90% {us(np.percentile(s[:, 6], 90) - t0):.1f}')
     names = ['roi + tables', 'x taps', 'first batch', 'rest of rows', 'flush issue', 'store drain']

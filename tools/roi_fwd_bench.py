@@ -38,6 +38,7 @@ def main():
     ap.add_argument('--bf16', action='store_true')
     ap.add_argument('--backward', action='store_true', help='also time forward + backward (fp32 features)')
     ap.add_argument('--tune', default='', help='key=value pairs for mr3d_tuning_set, e.g. 4=1 (box forward without the RoI split)')
+    ap.add_argument('--nrois', type=int, default=0, help='use only the first n rois of each case')
     ap.add_argument('--sizes', default='', help='xy_lo,xy_hi,z_lo,z_hi in pixels: log-uniform roi sizes instead of the SURVEY 8(d) ranges')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
@@ -60,6 +61,9 @@ def main():
             c = rng.uniform([0, 0, 0], [512, 512, 80], (n, 3))
             a0, a1 = np.clip(c - sz / 2, 0, [511, 511, 79]), np.clip(c + sz / 2, 0, [511, 511, 79])
             r_host = np.stack([np.zeros(n), a0[:, 0], a0[:, 1], a1[:, 0], a1[:, 1], a0[:, 2], a1[:, 2]], 1).astype(np.float32)
+        if a.nrois:
+            r_host = r_host[:a.nrois]
+            n = len(r_host)
         r = torch.from_numpy(r_host).to(dev)
         us = timed(lambda: ext(feats, r))
         lb, wr, rd = bench.roialign_lb_bytes(r_host, 64, od, osz, osz)
