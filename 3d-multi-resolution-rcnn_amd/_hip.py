@@ -875,6 +875,22 @@ def op_conv_variant(op):
     return v
 
 
+def op_wgrad_issue_factor(op):
+    """MFMA FLOPs a CONV_WGRAD plan record issues / its algorithmic FLOPs (mr3d_conv3d_wgrad_issue_factor: 1 direct, 2/3 F(3,2)
+    along W, 1/3 the two-dimensional Winograd form; nothing is launched).  bf16 records: direct form (1)."""
+    assert op.kind == OP_CONV_WGRAD
+    if op.i[25] == DTYPE_BF16:
+        return 1.0
+    d = Conv3dWgradDesc()
+    d.x, d.dy, d.dw, d.dbias = op.p[0], op.p[1], op.p[2], op.p[3]
+    ctypes.memmove(ctypes.addressof(d) + Conv3dWgradDesc.n.offset, ctypes.addressof(op.i), 15 * 4)
+    d.flags = op.i[17]
+    d.workspace, d.workspace_bytes = op.p[4], (op.i[15] & 0xFFFFFFFF) | (op.i[16] << 32) if op.p[4] else 0
+    fn = lib().mr3d_conv3d_wgrad_issue_factor
+    fn.restype = ctypes.c_float
+    return float(fn(ctypes.byref(d)))
+
+
 def _narrow_nb(n, do, ho, wo, cout, nb):
     """mirror of narrow_nb() in csrc/conv3d_fwd.hip: the Cout tile the forward/dgrad dispatch really picks"""
     def wgs(nb_):
@@ -905,7 +921,21 @@ def op_kernel_key(op):
         name = 'conv3d_fwd' if op.kind == OP_CONV_FWD else 'conv3d_wgrad'
         if i[25] == DTYPE_BF16:
             return f'{name}_bf16<k{k},s{sd}{sh}{sw},cin{cin},cout{cout}>', flops
-        return f'{name}<k{k},s{sd}{sh}{sw},cc{cc},nb{nb}>', flops
+        # the Winograd instances are kernels of their own (conv3d_wino2d_wide_kernel / conv3d_wino2d_kernel / the F(4,3)-along-W
+        # rows kernels): name them, so that a group of the measurement harness is ONE kernel (round 5 mixed the wide form, 0.63 of
+        # the peak, and the 2 x 8 x 8 form, 0.23, under one key).  A data-gradient launch that arms a liveness bitmap runs the
+        # 2 x 8 x 8 form whatever the probe says (sparse_pyramid_grads; off in bench.py).
+        suffix = ''
+        if op.kind == OP_CONV_FWD and k == 3 and (sd, sh, sw) == (1, 1, 1):
+            try:
+                v = op_conv_variant(op)
+                if v.winograd == 8:
+                    suffix = ',wino2d-wide' if v.tile_d == 4 else ',wino2d'
+                elif v.winograd:
+                    suffix = f',winoW{v.winograd}'
+            except Exception:
+                pass
+        return f'{name}<k{k},s{sd}{sh}{sw},cc{cc},nb{nb}{suffix}>', flops
     if op.kind == OP_PW_PAIR:
         c0, c1, c2 = i[0], i[1], i[2]
         pos = (i[5] & 0xFFFFFFFF) | (i[6] << 32)

@@ -435,10 +435,34 @@ int dispatch_wg(const Conv3dWgradArgs &a, int nb, hipStream_t stream) {
 
 }  // namespace
 
-extern "C" int mr3d_conv3d_wgrad(const mr3d_conv3d_wgrad_desc *d, mr3d_stream_t stream_) {
-  if (!d || !d->x || !d->dy || !d->dw) return MR3D_ERR_INVALID_ARG;
-  if (d->kd != d->kh || d->kh != d->kw) return MR3D_ERR_UNSUPPORTED;
-  Conv3dWgradArgs a;
+// which form the 3x3x3 / stride-1 weight gradient takes (one decision, shared by the launch and by the measurement harness's
+// mr3d_conv3d_wgrad_issue_factor)
+namespace {
+enum WgForm { WG_DIRECT_577, WG_WINO2D, WG_WINO_W64, WG_WINO_W32, WG_WINO_W16, WG_DIRECT };
+WgForm wgrad_k3s1_form(const Conv3dWgradArgs &a, int nb, int *nb3_out) {
+  const long long vol = (long long)a.Do * a.Ho * a.Wo;
+  const long long t577 = (long long)((a.Do + 4) / 5) * ((a.Ho + 6) / 7) * ((a.Wo + 6) / 7);
+  const long long t488 = (long long)((a.Do + 3) / 4) * ((a.Ho + 7) / 8) * ((a.Wo + 7) / 8);
+  if ((double)vol / t577 > 1.15 * (double)vol / t488 && a.N * t577 >= 512) return WG_DIRECT_577;
+  // 3x3x3, Cout % 64 == 0: the 32-wide Cout tile (two workgroups per CU, twice the workgroups) wins on maps with few
+  // tiles (P3: 100 vs 79 TFLOP/s, layer4: 31 vs 25), the 64-wide one on the big maps (P2: 111 vs 106)
+  const int nb3 = a.N * t488 < 2048 ? 32 : 64;
+  *nb3_out = nb3;
+  // Winograd forms (a caller that lends a workspace wants the bit-reproducible two-stage reduction: direct form)
+  constexpr int wino_env = 4;    // 0: direct form only; 1/2/3: F(3,2) along W on 64- / +32- / +16-wide tiles; 4: + the two-dimensional form
+  const int wino = a.part ? 0 : wino_env;
+  // 4: the two-dimensional form (conv3d_wgrad_wino2d.hip) on maps with >= min2d tiles of 2x8x8: P2 64->64 1096 -> 857 us
+  // standalone, backbone step 11.68 -> 11.48 ms, configs[2] step 19.7 -> 19.3 ms
+  constexpr int min2d = 256;
+  if (wino >= 4 && nb == 64 && (long long)a.N * ((a.Do + 1) / 2) * ((a.Ho + 7) / 8) * ((a.Wo + 7) / 8) >= min2d &&
+      mr3d_conv3d_wgrad_wino2d_ok(a))
+    return WG_WINO2D;
+  if (wino && nb == 64 && nb3 == 64) return WG_WINO_W64;
+  if (wino >= 2 && nb >= 32 && nb3 == 32) return WG_WINO_W32;
+  if (wino >= 3 && nb == 16) return WG_WINO_W16;
+  return WG_DIRECT;
+}
+void wgrad_args_from_desc(const mr3d_conv3d_wgrad_desc *d, Conv3dWgradArgs &a) {
   a.x = d->x; a.dy = d->dy; a.dw = d->dw; a.dbias = d->dbias;
   a.part = d->workspace; a.part_bytes = d->workspace ? d->workspace_bytes : 0;
   a.sparse_dy = d->flags & MR3D_WGRAD_SPARSE_DY;
@@ -447,13 +471,35 @@ extern "C" int mr3d_conv3d_wgrad(const mr3d_conv3d_wgrad_desc *d, mr3d_stream_t 
   a.Do = (d->d + 2 * d->pd - d->kd) / d->sd + 1;
   a.Ho = (d->h + 2 * d->ph - d->kh) / d->sh + 1;
   a.Wo = (d->w_in + 2 * d->pw - d->kw) / d->sw + 1;
+}
+}  // namespace
+
+// MFMA FLOPs the launch of this descriptor ISSUES / its algorithmic FLOPs (2 * MAC): 1 for the direct forms, 2/3 for F(3,2) along
+// W (48 products per patch and kd where the direct form has 72), 1/3 for the two-dimensional form (24); nothing is launched
+extern "C" float mr3d_conv3d_wgrad_issue_factor(const mr3d_conv3d_wgrad_desc *d) {
+  if (!d || d->kd != d->kh || d->kh != d->kw) return 1.f;
+  Conv3dWgradArgs a;
+  wgrad_args_from_desc(d, a);
+  const int nb = a.Cout % 64 == 0 ? 64 : (a.Cout % 32 == 0 ? 32 : (a.Cout % 16 == 0 ? 16 : 0));
+  if (!nb || d->kd != 3 || d->sd != 1 || d->sh != 1 || d->sw != 1 || a.Cin % 16 != 0 || a.Do <= 0 || a.Ho <= 0 || a.Wo <= 0) return 1.f;
+  int nb3 = 64;
+  switch (wgrad_k3s1_form(a, nb, &nb3)) {
+    case WG_WINO2D: return 1.f / 3.f;
+    case WG_WINO_W64: case WG_WINO_W32: case WG_WINO_W16: return 2.f / 3.f;
+    default: return 1.f;
+  }
+}
+
+extern "C" int mr3d_conv3d_wgrad(const mr3d_conv3d_wgrad_desc *d, mr3d_stream_t stream_) {
+  if (!d || !d->x || !d->dy || !d->dw) return MR3D_ERR_INVALID_ARG;
+  if (d->kd != d->kh || d->kh != d->kw) return MR3D_ERR_UNSUPPORTED;
+  Conv3dWgradArgs a;
+  wgrad_args_from_desc(d, a);
   if (a.N <= 0 || a.Do <= 0 || a.Ho <= 0 || a.Wo <= 0) return MR3D_ERR_INVALID_ARG;
   const int nb = a.Cout % 64 == 0 ? 64 : (a.Cout % 32 == 0 ? 32 : (a.Cout % 16 == 0 ? 16 : 0));
   if (!nb) return MR3D_ERR_UNSUPPORTED;
   hipStream_t stream = mr3d_stream(stream_);
   const int k = d->kd, s = d->sd * 100 + d->sh * 10 + d->sw;
-  // 3x3x3, Cout % 64 == 0: the 32-wide Cout tile (two workgroups per CU, twice the workgroups) wins on maps with few
-  // tiles (P3: 100 vs 79 TFLOP/s, layer4: 31 vs 25), the 64-wide one on the big maps (P2: 111 vs 106)
   if (k == 1 && s == 111) {
     if (a.pd == 0 && a.ph == 0 && a.pw == 0) {
       const int st = mr3d_pointwise_wgrad_try(a, stream);
@@ -467,30 +513,21 @@ extern "C" int mr3d_conv3d_wgrad(const mr3d_conv3d_wgrad_desc *d, mr3d_stream_t 
     if (a.Cin % 16 == 0) return dispatch_wg<1, 2, 2, 2, 16>(a, nb, stream);
   } else if (k == 3 && s == 111) {
     if (a.Cin % 16 == 0) {
-      const long long vol = (long long)a.Do * a.Ho * a.Wo;
-      const long long t577 = (long long)((a.Do + 4) / 5) * ((a.Ho + 6) / 7) * ((a.Wo + 6) / 7);
-      const long long t488 = (long long)((a.Do + 3) / 4) * ((a.Ho + 7) / 8) * ((a.Wo + 7) / 8);
-      if ((double)vol / t577 > 1.15 * (double)vol / t488 && a.N * t577 >= 512) {     // 10x14x14 roi volumes (mask head)
-        switch (nb) {
-          case 16: return launch_wgrad<WgCfg<3, 3, 3, 1, 1, 1, 16, 16, false, 5, 7, 7>>(a, stream);
-          case 32: return launch_wgrad<WgCfg<3, 3, 3, 1, 1, 1, 16, 32, false, 5, 7, 7>>(a, stream);
-          case 64: return launch_wgrad<WgCfg<3, 3, 3, 1, 1, 1, 16, 64, false, 5, 7, 7>>(a, stream);
-        }
+      int nb3 = 64;
+      switch (wgrad_k3s1_form(a, nb, &nb3)) {
+        case WG_DIRECT_577:                                                            // 10x14x14 roi volumes (mask head)
+          switch (nb) {
+            case 16: return launch_wgrad<WgCfg<3, 3, 3, 1, 1, 1, 16, 16, false, 5, 7, 7>>(a, stream);
+            case 32: return launch_wgrad<WgCfg<3, 3, 3, 1, 1, 1, 16, 32, false, 5, 7, 7>>(a, stream);
+            case 64: return launch_wgrad<WgCfg<3, 3, 3, 1, 1, 1, 16, 64, false, 5, 7, 7>>(a, stream);
+          }
+          break;
+        case WG_WINO2D: return mr3d_conv3d_wgrad_wino2d(a, stream);
+        case WG_WINO_W64: return launch_wgrad<WgCfg<3, 3, 3, 1, 1, 1, 16, 64, false, 4, 8, 8, true>>(a, stream);
+        case WG_WINO_W32: return launch_wgrad<WgCfg<3, 3, 3, 1, 1, 1, 16, 32, false, 4, 8, 8, true>>(a, stream);
+        case WG_WINO_W16: return launch_wgrad<WgCfg<3, 3, 3, 1, 1, 1, 16, 16, false, 4, 8, 8, true>>(a, stream);
+        case WG_DIRECT: return dispatch_wg<3, 1, 1, 1, 16>(a, nb < nb3 ? nb : nb3, stream);
       }
-      const int nb3 = a.N * t488 < 2048 ? 32 : 64;
-      // Winograd forms (a caller that lends a workspace wants the bit-reproducible two-stage reduction: direct form)
-      constexpr int wino_env = 4;    // 0: direct form only; 1/2/3: F(3,2) along W on 64- / +32- / +16-wide tiles; 4: + the two-dimensional form
-      const int wino = a.part ? 0 : wino_env;
-      // 4: the two-dimensional form (conv3d_wgrad_wino2d.hip) on maps with >= min2d tiles of 2x8x8: P2 64->64 1096 -> 857 us
-      // standalone, backbone step 11.68 -> 11.48 ms, configs[2] step 19.7 -> 19.3 ms
-      constexpr int min2d = 256;
-      if (wino >= 4 && nb == 64 && (long long)a.N * ((a.Do + 1) / 2) * ((a.Ho + 7) / 8) * ((a.Wo + 7) / 8) >= min2d &&
-          mr3d_conv3d_wgrad_wino2d_ok(a))
-        return mr3d_conv3d_wgrad_wino2d(a, stream);
-      if (wino && nb == 64 && nb3 == 64) return launch_wgrad<WgCfg<3, 3, 3, 1, 1, 1, 16, 64, false, 4, 8, 8, true>>(a, stream);
-      if (wino >= 2 && nb >= 32 && nb3 == 32) return launch_wgrad<WgCfg<3, 3, 3, 1, 1, 1, 16, 32, false, 4, 8, 8, true>>(a, stream);
-      if (wino >= 3 && nb == 16) return launch_wgrad<WgCfg<3, 3, 3, 1, 1, 1, 16, 16, false, 4, 8, 8, true>>(a, stream);
-      return dispatch_wg<3, 1, 1, 1, 16>(a, nb < nb3 ? nb : nb3, stream);
     }
   } else if (k == 3 && s == 222) {
     if (a.Cin % 16 == 0) return dispatch_wg<3, 2, 2, 2, 16, 1>(a, nb, stream);   // 3x17x17 halo: one output plane per tile

@@ -75,6 +75,61 @@ def allreduce_overlapped(flat, stem_elems, world_size=None, group=None, mark_slo
     return flat
 
 
+XGMI_LINKS, XGMI_LINK_GBPS = 7, 153.0      # MI355X: seven point-to-point xGMI links of ~153 GB/s per GPU ("All-reduce")
+
+
+def grads_checksum(flat):
+    """64-bit content checksum of a flat fp32 buffer, exact and order-free: the sum of its bit patterns as unsigned 32-bit
+    integers plus 2^32 times the sum of (pattern * (index % 65521 + 1)) -- equal buffers give equal checksums on every rank and
+    backend, a swapped or perturbed element changes it (device-side reduction, 8 bytes read back by the caller)"""
+    bits = flat.detach().contiguous().view(torch.int32).to(torch.int64) & 0xffffffff
+    idx = (torch.arange(bits.numel(), device=bits.device, dtype=torch.int64) % 65521) + 1
+    lo = bits.sum() & 0xffffffff
+    hi = (bits * idx).sum() & 0x7fffffff
+    return (hi << 32) | lo
+
+
+def ranks_hold_identical(flat, group=None):
+    """After the exchange every rank must hold the SAME gradient bits (the reference copies the reduced bucket back into every
+    rank's .grad, mmdet/core/utils/dist_utils.py:22-28).  all-gather of grads_checksum; returns (identical, [checksum per rank])."""
+    cs = grads_checksum(flat).reshape(1)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return True, [int(cs.item())]
+    got = [torch.empty_like(cs) for _ in range(world)]
+    dist.all_gather(got, cs, group=group)
+    vals = [int(g.item()) for g in got]
+    return all(v == vals[0] for v in vals), vals
+
+
+def allreduce_bus_bandwidth(nbytes, seconds, world_size):
+    """bus bandwidth of an all-reduce = 2 (n - 1) / n * bytes / t (GB/s), and its fraction of the GPU's aggregate
+    xGMI bandwidth (7 links x 153 GB/s) and of one link (what a ring is bound by)"""
+    if seconds <= 0 or world_size < 1:
+        return {'busbw_GBps': None, 'frac_of_xgmi': None, 'frac_of_one_link': None}
+    bw = 2.0 * (world_size - 1) / world_size * nbytes / seconds / 1e9
+    return {'busbw_GBps': bw, 'frac_of_xgmi': bw / (XGMI_LINKS * XGMI_LINK_GBPS), 'frac_of_one_link': bw / XGMI_LINK_GBPS}
+
+
+def time_allreduce_standalone(flat, world_size, reps=10, group=None, sync=None):
+    """seconds per in-place mean of `flat` with nothing else on the device (max over ranks): the cost the step would pay with no
+    overlap at all.  sync: callable that drains the device (torch.cuda.synchronize on a GPU, nothing on the gloo tests)."""
+    import time
+    sync = sync or (lambda: None)
+    allreduce_flat_grads(flat, world_size, group) if world_size > 1 else dist.all_reduce(flat, group=group)
+    sync()
+    if world_size > 1:
+        dist.barrier(group=group)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        allreduce_flat_grads(flat, world_size, group) if world_size > 1 else dist.all_reduce(flat, group=group)
+    sync()
+    el = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64, device=flat.device)
+    if world_size > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX, group=group)
+    return float(el.item())
+
+
 def broadcast_params(flat, src=0, group=None):
     """identical initial weights on every rank (what MMDistributedDataParallel.__init__ does with its
     coalesced state_dict broadcast, mmdet/apis/train.py:92)"""

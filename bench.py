@@ -556,7 +556,7 @@ def main():
     plan = eng._plan_for(x.shape)
     scale = (D * H * W) / (80.0 * 512 * 512)
 
-    def step(marks_f=None, marks_b=None, split=False):
+    def step(marks_f=None, marks_b=None, split=False, exchange=True):
         """split=True: every marked record is its own mr3d_plan_run call on the main stream (per-op table of the warm-up);
         otherwise each pass is ONE call -- the production launch sequence, side stream included -- and the marked records
         carry HIP timing events on the stream they really run on (mr3d_plan_run_marked)"""
@@ -567,7 +567,7 @@ def main():
         evb = plan.bwd.run(dev, marks_b) if (split or not marks_b) else plan.bwd.run_marked(marks_b, dev)
         # the exchange: everything behind the stem's parameters starts on a communication stream as soon as its gradient
         # finishing is done, underneath the stem weight gradient; the stem's 66 KB follow (dist_utils.allreduce_overlapped)
-        if world > 1 or force_dist:
+        if (world > 1 or force_dist) and exchange:
             if a.serial_allreduce:
                 allreduce_flat_grads(reduce_buf, world) if world > 1 else dist.all_reduce(reduce_buf)
             else:
@@ -647,6 +647,39 @@ def main():
             next_events.append(step(marks_next_f, marks_next_b))
         torch.cuda.synchronize()
     census = rank_census(dev, world)
+    exch = None
+    if world > 1 or force_dist:
+        # ---- the exchange, measured on its own (SURVEY 8d "All-reduce"; reference: mmdet/core/utils/dist_utils.py:22-28,51-57) --
+        # every rank runs this block: (1) the same K' steps WITHOUT the collectives -> what the exchange adds to a step that overlaps
+        # it (`ms_exposed`); (2) the in-place mean alone, 10 repetitions on an idle device -> `ms_standalone` and the bus bandwidth
+        # 2 (n - 1) / n * bytes / t against the xGMI links; (3) one more full step, then every rank's gradient arena must carry the
+        # same bits (all-gather of a 64-bit checksum): a mismatch fails the run with exit code 3
+        from mr3d_amd.dist_utils import allreduce_bus_bandwidth, ranks_hold_identical, time_allreduce_standalone
+        k2 = max(min(a.steps, 10), 1)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(k2):
+            step(exchange=False)
+        torch.cuda.synchronize()
+        noex = torch.tensor([(time.perf_counter() - t1) / k2], device=dev, dtype=torch.float64)
+        dist.all_reduce(noex, op=dist.ReduceOp.MAX)
+        ms_noex = float(noex.item()) * 1e3
+        nbytes = reduce_buf.numel() * 4
+        sec = time_allreduce_standalone(reduce_buf, world, reps=10, sync=torch.cuda.synchronize)
+        step()
+        torch.cuda.synchronize()
+        same, sums = ranks_hold_identical(reduce_buf)
+        exch = {'bytes': nbytes, 'ms_standalone': sec * 1e3, 'ms_step_without_exchange': ms_noex,
+                'ms_exposed': el * 1e3 / a.steps - ms_noex, **allreduce_bus_bandwidth(nbytes, sec, world),
+                'mode': ('serial after backward' if a.serial_allreduce else
+                         'two collectives, the first under the backward pass (dist_utils.allreduce_overlapped)'),
+                'grads_identical_across_ranks': same, 'grad_checksums': [f'{v:016x}' for v in sums],
+                'note': ('ms_exposed = step with the exchange - the same step without it (max over ranks, ' + str(k2) + ' extra steps); '
+                         'busbw = 2 (n - 1) / n * bytes / ms_standalone; frac_of_xgmi against 7 x 153 GB/s, frac_of_one_link against 153 GB/s' +
+                         ('' if world > 1 else '; ONE rank (MR3D_BENCH_FORCE_DIST): the collective moves nothing, the fields show the line a '
+                                               'multi-GPU run prints'))}
 
     def committed_traffic(kernel_key):
         """HBM bytes per launch of `kernel_key` from the committed rocprofv3 PMC passes of this same command
@@ -689,10 +722,19 @@ def main():
                     factor, tag = 10.0 / 14.0 * 8.0 / 7.0, 'winograd F(2,3) along D, kw 7->8'
                 elif key == 'stem_wgrad_gather':
                     factor, tag = 0.0, 'gather over the pooled elements on the vector ALUs (no MFMA)'
+                elif op.kind == _hip.OP_CONV_WGRAD:
+                    factor = _hip.op_wgrad_issue_factor(op)
+                    tag = {1.0: 'direct', 2.0 / 3.0: 'winograd F(3,2) along W', 1.0 / 3.0: 'winograd F(3,2) along H x F(3,4) along W'}.get(
+                        min((1.0, 2.0 / 3.0, 1.0 / 3.0), key=lambda v: abs(v - factor)), 'direct')
                 issued += fl * factor
                 var[tag] = var.get(tag, 0) + 1
             return (issued / groups[key]['flops'] if groups[key]['flops'] else 1.0), var
 
+        issued_step = priced_step = 0.0                      # MFMA FLOPs one step issues / the algorithmic FLOPs they stand for
+        for gkey, gv in groups.items():
+            if gv['flops'] > 0:
+                issued_step += gv['flops'] * issue_factor_of(gkey)[0]
+                priced_step += gv['flops']
         dom_ms = group_ms(dom)
         launches = a.steps * groups[dom]['n']
         alg = groups[dom]['flops'] * a.steps / (dom_ms * 1e-3) if dom_ms > 0 else 0.0
@@ -723,6 +765,12 @@ def main():
                                    'launch of this kernel inside the timed steps; the plan is not split (other kernels overlap '
                                    'it exactly as in production)',
                          'whole_step_frac': FLOP_FWD_BWD_512 * scale / (ms_per_step * 1e-3) / peak,
+                         'whole_step_issued_frac': issued_step / (ms_per_step * 1e-3) / peak,
+                         'whole_step_issued_gflop': issued_step / 1e9, 'whole_step_priced_gflop': priced_step / 1e9,
+                         'whole_step_issued_note': 'sum over EVERY record of the forward and backward plans of (its algorithmic 2*MAC x the MFMA '
+                                                   'issue factor the library reports for the instance it launches: 1 direct, 2/3, 1/2, 1/3 the '
+                                                   'Winograd forms, 0 the vector-ALU gather of the stem weight gradient) / step time / peak: the '
+                                                   'share of the step in which the matrix cores issue',
                          'whole_step_flops_note': 'algorithmic 2*MAC of the dense convolutions of one forward+backward pass (1124.4 GFLOP on the '
                                                   '512x512x80 volume); the Winograd kernels issue 1/3 - 2/3 of theirs on the matrix cores and the '
                                                   'gather form of the stem weight gradient multiplies only the <= 1/8 of dy that the max-pool '
@@ -779,9 +827,14 @@ def main():
                 res['cpu_baseline'].setdefault('ops', {})['allreduce_gloo'] = cpu_baseline_allreduce(min(a.cpu_seconds, 12.0))
             except Exception as exc:
                 res['cpu_baseline'].setdefault('ops', {})['allreduce_gloo'] = {'error': repr(exc)}
+        if exch is not None:
+            res['allreduce'] = exch
         emit_json_line(res)
     if world > 1 or force_dist:
         dist.destroy_process_group()
+    if exch is not None and not exch['grads_identical_across_ranks']:
+        print('bench.py: the ranks hold different gradients after the exchange: ' + ' '.join(exch['grad_checksums']), file=sys.stderr)
+        raise SystemExit(3)
 
 
 if __name__ == '__main__':

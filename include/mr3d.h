@@ -294,6 +294,9 @@ typedef struct {
   long long workspace_bytes;
 } mr3d_conv3d_wgrad_desc;
 int mr3d_conv3d_wgrad(const mr3d_conv3d_wgrad_desc *desc, mr3d_stream_t stream);
+/* MFMA FLOPs a launch of `desc` issues / its algorithmic FLOPs (2 * MAC): 1 (direct), 2/3 (F(3,2) along W) or 1/3 (the two-dimensional
+ * Winograd form); a host-only query for the measurement harness (bench.py's whole_step_issued_frac), nothing is launched */
+float mr3d_conv3d_wgrad_issue_factor(const mr3d_conv3d_wgrad_desc *desc);
 
 /* ------------------------------------------------------------------------------------------------
  * HBM-bound helpers of the backbone / neck path (activations NDHWC fp32, channels % 4 == 0).

@@ -328,3 +328,69 @@ def test_freeze_gc_after_warmup_freezes_once(monkeypatch):
         assert gc.get_freeze_count() > before
     finally:
         gc.unfreeze()
+
+
+def _checksum_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import mr3d_amd  # noqa: F401
+        from mr3d_amd.dist_utils import (allreduce_flat_grads, allreduce_overlapped, grads_checksum, ranks_hold_identical,
+                                         time_allreduce_standalone)
+        torch.manual_seed(7 + rank)
+        flat = torch.randn(40009)
+        before, sums0 = ranks_hold_identical(flat)                 # different seeds: different gradients, different checksums
+        allreduce_overlapped(flat, 1000, world, early_elems=5000)
+        after, sums1 = ranks_hold_identical(flat)                  # the exchange leaves every rank with the same bits
+        serial = flat.clone()
+        allreduce_flat_grads(serial, world)                        # a mean of equal buffers is the buffer (x + x) / 2 == x
+        same_again, _ = ranks_hold_identical(serial)
+        bad = flat.clone()
+        if rank == 1:
+            bad[12345] = torch.nextafter(bad[12345], torch.tensor(float('inf')))     # one ulp on one rank
+        caught, _ = ranks_hold_identical(bad)
+        swapped = flat.clone()
+        if rank == 1:
+            swapped[[3, 4]] = swapped[[4, 3]]                      # same multiset of values, other order
+        caught_swap, _ = ranks_hold_identical(swapped)
+        sec = time_allreduce_standalone(flat.clone(), world, reps=2)
+        q.put((rank, before, sums0, after, sums1, same_again, caught, caught_swap, sec, int(grads_checksum(flat))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_post_exchange_checksum_world2():
+    """bench.py's N > 1 line: after the exchange every rank must hold the same gradient bits (the reference copies the reduced
+    bucket back on every rank, mmdet/core/utils/dist_utils.py:22-28); the all-gathered 64-bit checksum sees a one-ulp
+    difference and a swap of two elements"""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_checksum_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, before, sums0, after, sums1, same_again, caught, caught_swap, sec, mine in res:
+        assert before is False and len(set(sums0)) == 2
+        assert after is True and len(set(sums1)) == 1 and sums1[rank] == mine
+        assert same_again is True
+        assert caught is False and caught_swap is False
+        assert sec > 0
+    assert res[0][4] == res[1][4]                                   # both ranks gathered the same list
+
+
+def test_allreduce_bus_bandwidth_formula():
+    from mr3d_amd.dist_utils import allreduce_bus_bandwidth, grads_checksum
+    # SURVEY 8(d): 2 (n - 1) / n * bytes / t; the 103.9 MB arena in 1 ms on 8 ranks = 181.8 GB/s = 0.17 of 7 x 153 GB/s
+    r = allreduce_bus_bandwidth(103.9e6, 1e-3, 8)
+    assert abs(r['busbw_GBps'] - 2 * 7 / 8 * 103.9) < 1e-6
+    assert abs(r['frac_of_xgmi'] - r['busbw_GBps'] / (7 * 153.0)) < 1e-12 and abs(r['frac_of_one_link'] - r['busbw_GBps'] / 153.0) < 1e-12
+    assert allreduce_bus_bandwidth(1e6, 1e-3, 1)['busbw_GBps'] == 0.0          # one rank moves nothing
+    assert allreduce_bus_bandwidth(1e6, 0.0, 8)['busbw_GBps'] is None
+    a = torch.arange(1000, dtype=torch.float32)
+    assert int(grads_checksum(a)) == int(grads_checksum(a.clone())) != int(grads_checksum(a.flip(0)))

@@ -30,8 +30,14 @@ def key_of(name):
         cc = 64 if ci % 64 == 0 else (32 if ci % 32 == 0 else 16)
         nb = 64 if co % 64 == 0 else (32 if co % 32 == 0 else 16)
         return f'conv3d_{m.group(1)}<k1,s111,cc{cc},nb{nb}>'
-    if 'conv3d_wino2d_kernel' in n or 'conv3d_wino2d_wide_kernel' in n:     # the two-dimensional Winograd forms of the 64 -> 64 3x3x3 convs (conv3d_wino2d.hip)
-        return 'conv3d_fwd<k3,s111,cc16,nb64>'
+    # the two-dimensional Winograd forms of the 64 -> 64 3x3x3 convs (conv3d_wino2d.hip): one key per kernel (round 6)
+    if 'conv3d_wino2d_wide_kernel' in n:
+        return 'conv3d_fwd<k3,s111,cc16,nb64,wino2d-wide>'
+    if 'conv3d_wino2d_kernel' in n:
+        return 'conv3d_fwd<k3,s111,cc16,nb64,wino2d>'
+    m = re.search(r'conv3d_wino2d_rows_kernel<(\d+)', n)
+    if m:
+        return None      # (16-wide F(4,3)-along-W rows kernels: several layer shapes share one instance; no per-key traffic)
     for pat, key in (('stem_fwd', 'stem_fwd'), ('stem_wgrad_gather_kernel', 'stem_wgrad_gather'), ('stem_wgrad_kernel', 'stem_wgrad'), ('maxpool_fwd_kernel', 'maxpool_fwd'),
                      ('maxpool_bwd_kernel', 'maxpool_bwd'), ('upsample_adjoint_add_kernel', 'upsample_adjoint_add')):
         if pat in n:
