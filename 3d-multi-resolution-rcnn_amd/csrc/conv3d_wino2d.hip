@@ -659,8 +659,10 @@ __global__ __launch_bounds__(kThreadsW, 2) void conv3d_wino2d_wide_kernel(Conv3d
     for (int i = 0; i < 4; ++i)
       if (i < 3 || wave < 6) {                           // (wave-uniform; row pairs 30, 31 do not exist)
         const unsigned m0 = lds_base + (unsigned)((2 * WV + buf * WHBUF + (wave + 8 * i) * WRP) * 4);
+        // (m0 is written without being declared: hipcc rejects it as a clobber ("reserved register").  Nothing else in this kernel
+        //  reads or writes m0 -- no ds_*_addtid, no s_movrel, no readlane / sendmsg through it -- which is what makes that safe.)
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                     : : "s"(m0), "v"(rel[i]), "s"(xdesc), "s"((unsigned)c0 * 4u) : "memory");      // (m0: nothing else in this kernel uses it)
+                     : : "s"(m0), "v"(rel[i]), "s"(xdesc), "s"((unsigned)c0 * 4u) : "memory");
       }
   };
   // V = Bh^T d Bw of a chunk: 6 planes x 8 patches x 8 channels = 384 windows.  A wave only ever multiplies the fh row of V it owns,
@@ -738,6 +740,9 @@ __global__ __launch_bounds__(kThreadsW, 2) void conv3d_wino2d_wide_kernel(Conv3d
     const char *add2b = p.add2 ? reinterpret_cast<const char *>(p.add2 + ybase) : nullptr;
     const char *maskb = p.mask ? reinterpret_cast<const char *>(p.mask + ybase) : nullptr;
     char *yb = reinterpret_cast<char *>(p.y + ybase);
+    // Z overlays V1: step 5 of the tile's last chunk still reads its A fragments out of V1 (load_a(aq[1], vcur = V1) behind barrier 2),
+    // and nothing but the ~48 MFMAs in between kept a fast wave's first Z store behind a slow wave's read.  One barrier per tile.
+    if (!zero) __syncthreads();
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
       if (!zero) {
@@ -841,6 +846,10 @@ __global__ __launch_bounds__(kThreadsW, 2) void conv3d_wino2d_wide_kernel(Conv3d
     if (c == 3) WIDE_MARK(3);
     // the next chunk's halo was requested one chunk ago; the requests behind it are the U fragments of six steps (24; sched_barriers
     // pin each step's four in front of its MFMAs) -- two steps in the first chunk
+    // (the counts are vector-memory INSTRUCTIONS: kLoadsPerStep buffer loads per load_b -- 2 column tiles x 2 halves of 12 bytes -- times
+    //  the steps requested behind the halo; a load_b that issues another number of loads needs other constants here)
+    constexpr int kLoadsPerStep = 4;
+    static_assert(2 * kLoadsPerStep == 8 && 6 * kLoadsPerStep == 24, "hand-counted vmcnt waits below");
     if (filling) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
     filling = false;

@@ -22,6 +22,7 @@
 // Bound: LDS bandwidth, 10 LDS cycles per (item, input channel) and CU.  The matrix pipe is idle, which is what the last
 // weight gradients of the side queues need while this kernel closes the backward pass.
 #include <atomic>
+#include <mutex>
 #include "conv3d.h"
 
 namespace {
@@ -49,7 +50,8 @@ struct GatherArgs {
   float *dbias;               // [16] or null
   float *part;                // [grid][343][3][16] or null (atomics)
   int N, D, H, W, Dp, Hp, Wp;
-  int queue_slot;
+  unsigned *queue;            // 8 tile-queue heads + 1 finished-workgroup count, 0 at launch: the tail of the caller's workspace (zeroed by a
+                              // memset in the launch's own stream) or, without a workspace, one of the library's 64 rotating slots
 };
 
 __device__ __forceinline__ f32x2 buffer_load2(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
@@ -58,6 +60,7 @@ __device__ __forceinline__ f32x2 buffer_load2(__amdgpu_buffer_rsrc_t r, unsigned
 
 // per slot: 8 tile-queue heads + 1 finished-workgroup count, all 0 between launches
 __device__ unsigned g_stem_gather_queues[64 * 16];
+constexpr int kGatherMaxDevices = 16;
 
 template <bool BF16>
 __global__ __launch_bounds__(kGatherThreads, 8) void stem_wgrad_gather_kernel(GatherArgs p, int tiles_d, int tiles_h, int tiles_w) {
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(kGatherThreads, 8) void stem_wgrad_gather_kernel(Ga
 
   // tiles are pulled from eight queues: the depth-fastest tile order cut into one contiguous range per XCD (stem.hip)
   __shared__ int s_tile;
-  unsigned *queue = g_stem_gather_queues + 16 * p.queue_slot;
+  unsigned *queue = p.queue;
   const int per_xcd = (num_tiles + 7) >> 3;
   const int home = blockIdx.x & 7;
   auto range = [&](int x, int &lo) { lo = x * per_xcd; return max(min(lo + per_xcd, num_tiles) - lo, 0); };
@@ -311,27 +314,28 @@ int mr3d_stem_wgrad_gather(const float *x, const void *g, const uint32_t *idx, c
   a.N = n; a.D = d; a.H = h; a.W = w;
   const int ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1;
   a.Dp = (d - 1) / 2 + 1; a.Hp = (ho - 1) / 2 + 1; a.Wp = (wo - 1) / 2 + 1;
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(stem_wgrad_gather_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            kGatherLds) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(stem_wgrad_gather_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            kGatherLds) != hipSuccess) {
-      (void)hipGetLastError();
-      return MR3D_ERR_LAUNCH;
-    }
-    attr = true;
-  }
+  // per device, once: the > 64 KiB LDS attribute of both instances and the CU count (hipGetDeviceProperties must not run inside a
+  // stream capture: a plan's first, eager run comes before any capture)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kGatherMaxDevices) dev = 0;
+  static std::once_flag once[kGatherMaxDevices];
+  static int cus_of[kGatherMaxDevices];
+  static bool attr_ok[kGatherMaxDevices];
+  static unsigned *slots_of[kGatherMaxDevices];
+  std::call_once(once[dev], [dev]() {
+    attr_ok[dev] = hipFuncSetAttribute(reinterpret_cast<const void *>(stem_wgrad_gather_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       kGatherLds) == hipSuccess &&
+                   hipFuncSetAttribute(reinterpret_cast<const void *>(stem_wgrad_gather_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       kGatherLds) == hipSuccess;
+    hipDeviceProp_t prop;
+    cus_of[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    if (hipGetSymbolAddress(reinterpret_cast<void **>(&slots_of[dev]), HIP_SYMBOL(g_stem_gather_queues)) != hipSuccess) slots_of[dev] = nullptr;
+    (void)hipGetLastError();
+  });
+  if (!attr_ok[dev]) return MR3D_ERR_LAUNCH;
+  const int cus = cus_of[dev];
   const int td = (a.Dp + G::TPD - 1) / G::TPD, th = (a.Hp + G::TPH - 1) / G::TPH, tw = (a.Wp + G::TPW - 1) / G::TPW;
   const int tiles = n * td * th * tw;
-  static int cus = 0;        // queried once: hipGetDeviceProperties must not run inside a stream capture
-  if (!cus) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-      cus = prop.multiProcessorCount;
-  }
   // Two 1024-thread workgroups per CU take every wave slot of the chip, and the workgroups are persistent: whatever is queued beside
   // this kernel -- the gradient finishing of layer1 / layer2 (side queue), a collective -- starts with its last tile.  That is the
   // cheaper order at N = 1 (48 free slots: the kernel 6 % longer, the 75 us of finishing behind it 50 us shorter, step 9.09 ->
@@ -343,9 +347,21 @@ int mr3d_stem_wgrad_gather(const float *x, const void *g, const uint32_t *idx, c
   if (slots < cus) slots = cus;
   int grid = tiles < slots ? tiles : slots;
   if (grid >= 8) grid &= ~7;
-  static std::atomic<unsigned> next_slot{0};
-  a.queue_slot = (int)(next_slot.fetch_add(1) & 63u);
-  a.part = (workspace && workspace_bytes >= (long long)grid * 343 * 3 * 16 * 4) ? workspace : nullptr;
+  const long long part_bytes = (long long)grid * 343 * 3 * 16 * 4;
+  a.part = (workspace && workspace_bytes >= part_bytes) ? workspace : nullptr;
+  if (workspace && workspace_bytes >= part_bytes + 64) {
+    // the tile queues live behind the partial sums in the caller's workspace and are zeroed in this launch's own stream: no state
+    // shared with any other launch (a replayed hipGraph and an eager launch used to be able to draw the same rotating slot)
+    a.queue = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(workspace) + part_bytes);
+    if (hipMemsetAsync(a.queue, 0, 64, stream) != hipSuccess) {
+      (void)hipGetLastError();
+      return MR3D_ERR_LAUNCH;
+    }
+  } else {
+    static std::atomic<unsigned> next_slot{0};           // no workspace: one of 64 self-re-arming slots (launches on ONE stream never overlap)
+    if (!slots_of[dev]) return MR3D_ERR_LAUNCH;
+    a.queue = slots_of[dev] + 16 * (next_slot.fetch_add(1) & 63u);
+  }
   if (bf16) stem_wgrad_gather_kernel<true><<<(unsigned)grid, kGatherThreads, kGatherLds, stream>>>(a, td, th, tw);
   else stem_wgrad_gather_kernel<false><<<(unsigned)grid, kGatherThreads, kGatherLds, stream>>>(a, td, th, tw);
   const int st = mr3d_launch_status();

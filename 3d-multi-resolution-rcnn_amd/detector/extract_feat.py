@@ -61,7 +61,7 @@ class ExtractFeat3D(nn.Module):
     MARK_GRADS_BUT_STEM = 1          # SYNC slot of the backward plan (see dist_utils.allreduce_overlapped)
     MARK_GRADS_EARLY = 3             # SYNC slot: the gradients of layer3, layer4 and the neck are final (dist_utils.allreduce_overlapped)
     EARLY_STAGE = 2                  # layer3: the first stage whose parameters belong to the early bucket
-    early_bucket = os.environ.get('MR3D_EARLY_BUCKET', '1') != '0'          # (0: ONE finishing at the end of the backward plan, rounds 1-4)
+    TUNE_LATE_GRAD_FINISH, TUNE_FPN_AFTER_LATERALS = 8, 9      # mr3d_tuning_set keys (include/mr3d.h): the A/B switches of this class
     MARK_COARSE_DGRADS = 2           # SYNC slot: the P3..P5 output-conv data gradients (side stream) are done
     MARK_LATERAL_DGRAD = 4           # SYNC slots 4 / 5: the P2 / P3 lateral data gradients (side stream, fp32 plans) are done
 
@@ -90,6 +90,8 @@ class ExtractFeat3D(nn.Module):
         assert num_outs == 5, 'the shipped config uses 4 pyramid levels + 1 max-pooled level (configs/...py:11-15)'
         self.depth = depth
         self.device = torch.device(device)
+        # the early gradient bucket (round 5): off = ONE finishing at the end of the backward plan, rounds 1-4 (an A/B knob)
+        self.early_bucket = _hip.lib().mr3d_tuning_get(self.TUNE_LATE_GRAD_FINISH) == 0
         self.fpn_out = fpn_out_channels
         self.zero_init_residual = zero_init_residual
         self.eps = 1e-5                                    # norm.py:50 cfg_.setdefault('eps', 1e-5)
@@ -539,7 +541,7 @@ class ExtractFeat3D(nn.Module):
         # 0.3 GB and leaves the matrix cores idle) and are done when the P2 output convolution starts.  Queued behind ALL laterals
         # (rounds 3-4: 11.05 -> 11.01 ms, beside the P2 convolution) they now wait for it: its wide form (conv3d_wino2d.hip) keeps one
         # 512-thread workgroup per CU, and nothing else fits beside that.  Nothing reads them before the plan's final join.
-        interleave = not self.neck_dcn and os.environ.get('MR3D_FPN_INTERLEAVE', '1') != '0'
+        interleave = not self.neck_dcn and _hip.lib().mr3d_tuning_get(self.TUNE_FPN_AFTER_LATERALS) == 0
         for i in (3, 2, 1, 0):
             P.lat[i] = self._new(self._out_shape(P.C[i].shape, self.lateral[i]))
             fwd.append(self._conv_fwd(P.C[i], self.lateral[i], P.lat[i], up=P.lat[i + 1] if i < 3 else None))

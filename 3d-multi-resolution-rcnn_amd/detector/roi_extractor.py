@@ -25,10 +25,20 @@ from .. import mmdet_ops as ops
 _deferred = None          # a plain global: autograd runs the backward of device ops on its own worker thread
 
 
+class _DeferredItems(list):
+    """what a deferred_backward() block records + the pyramids it owns: `keys` holds the data_ptr of the first level of every pyramid
+    whose extractor backward passes may be deferred (the detector registers them once its leaf copies exist).  An extractor backward
+    on any OTHER feature map -- a second detector, a nested call -- runs normally instead of being recorded and then dropped."""
+
+    def __init__(self):
+        super().__init__()
+        self.keys = set()
+
+
 class deferred_backward:
     def __enter__(self):
         global _deferred
-        self.prev, self.items = _deferred, []
+        self.prev, self.items = _deferred, _DeferredItems()
         _deferred = self.items
         return self.items
 
@@ -90,7 +100,7 @@ class _MultiLevelRoIAlign3D(Function):
     def backward(ctx, grad_output):
         (rois,) = ctx.saved_tensors
         out_d, out_h, out_w, scales, scales_d, sample_num, finest, bug = ctx.cfg
-        if _deferred is not None and ctx.feat_dtype == torch.float32:
+        if _deferred is not None and ctx.feat_dtype == torch.float32 and ctx.key in _deferred.keys:
             _deferred.append((ctx.key, grad_output.contiguous(), rois, ctx.cfg, len(ctx.shapes)))
             return (None, None) + (None,) * len(ctx.shapes)
         grads = [torch.empty(sh, dtype=torch.float32, device=rois.device, memory_format=torch.channels_last_3d).zero_()

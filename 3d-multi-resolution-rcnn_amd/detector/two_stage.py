@@ -190,14 +190,18 @@ class TwoStageDetector3D(nn.Module):
         backbone forward the device is still running), and only the mask branch and the backbone backward follow it.
         Same gradients: every loss enters the sum with coefficient 1, and a sum's gradient is the sum of the gradients.
         Returns the loss dict with detached values; parameter gradients are accumulated as by backward()."""
-        with deferred_backward() as self._deferred_items:
-            return self.forward_train(*args, _eager_backward=True, **kwargs)
+        with deferred_backward() as items:
+            return self.forward_train(*args, _eager_backward=items, **kwargs)
 
     def forward_train(self, imgs, img_meta, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_masks=None, proposals=None,
                       draws=None, _eager_backward=False):
         """Returns the reference's loss dict (loss_rpn_cls / loss_rpn_reg lists per level, loss_cls, acc, loss_reg,
         loss_mask).  draws: optional dict(rpn=[(pos, neg) per image], rcnn=[(pos, neg) per image]) of sampler words."""
         assert imgs.shape[1] == 3                                           # two_stage_3d.py:124
+        if _eager_backward is True:      # (a direct call: the recording block belongs to forward_backward)
+            return self.forward_backward(imgs, img_meta, gt_bboxes, gt_labels, gt_bboxes_ignore=gt_bboxes_ignore, gt_masks=gt_masks,
+                                         proposals=proposals, draws=draws)
+        deferred, _eager_backward = _eager_backward, _eager_backward is not False
         draws = draws or {}
         self._mark('start')
         x = self.extract_feat(imgs)
@@ -211,8 +215,8 @@ class TwoStageDetector3D(nn.Module):
             x_graph = x
             # the roi extractors' backward passes are recorded, not run: they are scattered into the RPN branch's gradient buffers
             # at the end (roi_extractor.deferred_backward / pyramid_gradient) -- no per-extractor zero-filled level buffers, no adds
-            deferred = self._deferred_items
             x = tuple(t.detach().requires_grad_(True) for t in x_graph)
+            deferred.keys.add(x[0].data_ptr())                   # only THIS pyramid's extractor backward passes are recorded
             x_rpn = tuple(t.detach().requires_grad_(True) for t in x_graph)
             self._mark('backbone+fpn fwd')
             main = torch.cuda.current_stream()

@@ -69,12 +69,17 @@ class TwoStageDetector3D2Scales(TwoStageDetector3D):
         """forward_train + backward of the summed losses with both RPN branches (heads, targets, losses, backward) on a second
         stream beside the roi-head chain, and the bbox / refinement heads differentiated in front of the mask heads' host
         waits -- see TwoStageDetector3D.forward_backward.  Returns the loss dict with detached values."""
-        with deferred_backward() as self._deferred_items:
-            return self.forward_train(*args, _eager_backward=True, **kwargs)
+        with deferred_backward() as items:
+            return self.forward_train(*args, _eager_backward=items, **kwargs)
 
     def forward_train(self, imgs, img_meta, imgs_2, img_meta_2, gt_bboxes, gt_bboxes_2, gt_labels, gt_labels_2,
                       gt_bboxes_ignore=None, gt_masks=None, gt_masks_2=None, proposals=None, draws=None, _eager_backward=False):
         assert imgs.shape[1] == 3 and imgs_2.shape[1] == 3                     # :148
+        if _eager_backward is True:      # (a direct call: the recording block belongs to forward_backward)
+            return self.forward_backward(imgs, img_meta, imgs_2, img_meta_2, gt_bboxes, gt_bboxes_2, gt_labels, gt_labels_2,
+                                         gt_bboxes_ignore=gt_bboxes_ignore, gt_masks=gt_masks, gt_masks_2=gt_masks_2, proposals=proposals,
+                                         draws=draws)
+        deferred, _eager_backward = _eager_backward, _eager_backward is not False
         # One volume per GPU, like the reference's own dual-pathway model: its refinement stage wraps ALL pathway-2 predictions
         # in a one-element list (`pred_bboxes_2 = [torch.from_numpy(pred_bboxes_2).cuda()]`, two_stage_3d_2scales.py:263-267)
         # and then indexes it per image (:275-283), which raises for a second image; the shipped config sets imgs_per_gpu = 1
@@ -91,6 +96,7 @@ class TwoStageDetector3D2Scales(TwoStageDetector3D):
             graph = tuple(x) + tuple(x_2)
             leaf = lambda ts: tuple(t.detach().requires_grad_(True) for t in ts)
             x, x_2 = leaf(x), leaf(x_2)                                        # roi heads
+            deferred.keys.update((x[0].data_ptr(), x_2[0].data_ptr()))          # only these pyramids' extractor backward passes are recorded
             xr, xr_2 = leaf(x), leaf(x_2)                                      # RPN branches
             main = torch.cuda.current_stream()
             if getattr(self, '_rpn_stream', None) is None:
@@ -181,7 +187,7 @@ class TwoStageDetector3D2Scales(TwoStageDetector3D):
             main.wait_stream(side)
             # the four extractors on pathway 1 and the one on pathway 2 were recorded (roi_extractor.deferred_backward): their
             # scatters go straight into the RPN branches' gradient buffers -- no zero-filled level buffers, no adds
-            items = self._deferred_items
+            items = deferred
             assert_all_flushed(items, (x, x_2))
             torch.autograd.backward(graph, pyramid_gradient(x, xr, items) + pyramid_gradient(x_2, xr_2, items))
             items.clear()                     # the recorded top gradients are not kept alive until the next step

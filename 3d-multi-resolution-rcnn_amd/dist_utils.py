@@ -254,8 +254,11 @@ class DetectorArena:
         every head -- started in the middle of the backward pass (allreduce_overlapped); False: ONE in-place all-reduce after the
         backward pass, as the reference issues it"""
         if overlap and self.engine is not None:
+            # (an engine built without the early bucket never records its slot: split at the stem instead of waiting on a slot
+            #  nobody arms, which would serialise the whole exchange behind the backward pass)
+            early = self.engine.early_elems if getattr(self.engine, 'early_bucket', True) else None
             return allreduce_overlapped(self.flat_grads, self.engine.stem_elems, world_size, group,
-                                        mark_slot=self.engine.MARK_GRADS_BUT_STEM, early_elems=self.engine.early_elems,
+                                        mark_slot=self.engine.MARK_GRADS_BUT_STEM, early_elems=early,
                                         early_slot=self.engine.MARK_GRADS_EARLY)
         return allreduce_flat_grads(self.flat_grads, world_size, group)
 
@@ -410,29 +413,37 @@ _gc_state = {'steps': 0, 'frozen': False}
 
 
 def freeze_gc_after_warmup(warmup_steps=3):
-    """Call once per training step.  After `warmup_steps` calls: one full collection, then `gc.freeze()` -- every object alive at
-    that point (the detectors' plans are tens of thousands of small ctypes / list objects, the module tree, the arenas' views) moves
-    to the permanent generation and later collections only look at what the steps themselves allocate.  Without it CPython's cyclic
-    collector runs a full generation-2 pass every 10-20 steps of the dual-pathway model, and that pass takes 85 ms -- two whole steps
-    during which the GPU drains (per-step times 45, 45, ..., 130, 45, ...: `tools/two_stage_bench.py --two-scales --steps 1
-    --repeats 24`; 44.9 ms per step over 8 steps with it, 50-54 without).  MR3D_GC_FREEZE=0 leaves the collector alone.  Returns True
-    in the call that froze."""
+    """OPT-IN helper for a training loop (bench.py, tools/two_stage_bench.py and tools/train_synthetic.py call it once per step;
+    train_step does so only when asked, `freeze_gc=True`): after `warmup_steps` calls, one full collection, then `gc.freeze()` --
+    every object alive at that point moves to the permanent generation and later collections only look at what the steps themselves
+    allocate.  It is a process-wide, irreversible-until-`gc.unfreeze()` change to the HOST application's collector, which is why the
+    library never makes it on its own (round 5 did, from inside train_step).  Why a loop wants it: CPython runs a full generation-2
+    pass every 10-20 steps of the dual-pathway model and that pass takes 30-85 ms while the GPU drains (per-step times 45, 45, ...,
+    130, 45, ...; 44.9 ms per step over 8 steps with the freeze, 50-54 without).  tools/diag/gc_census.py: of the 215 k objects
+    the collector tracks once the two-stage detector, its plans and three steps exist, 170 k are PyTorch's own modules, functions
+    and descriptors -- the detectors add 44 k -- so flattening the plans into one ctypes array would not take the pass away.
+    Returns True in the call that froze; logs one line when it does."""
     import gc
     _gc_state['steps'] += 1
-    if _gc_state['frozen'] or _gc_state['steps'] <= warmup_steps or os.environ.get('MR3D_GC_FREEZE', '1') == '0':
+    if _gc_state['frozen'] or _gc_state['steps'] <= warmup_steps:
         return False
     gc.collect()
     gc.freeze()
     _gc_state['frozen'] = True
+    import sys
+    print(f'mr3d: gc.freeze() after {warmup_steps} warm-up steps ({gc.get_freeze_count()} objects made permanent; gc.unfreeze() undoes it)',
+          file=sys.stderr)
     return True
 
 
-def train_step(detector, arena, optimizer, batch, world_size=1, grad_clip=35.0, group=None, overlap=True):
+def train_step(detector, arena, optimizer, batch, world_size=1, grad_clip=35.0, group=None, overlap=True, freeze_gc=False):
     """One iteration of the reference's hot loop (mmdet/apis/train.py:37-48 batch_processor + dist_utils.py:51-57):
     zero -> forward_train -> sum of the losses -> backward -> ONE all-reduce of the detector's gradient arena -> L2 clip
     (configs/...py:236) -> optimizer.step().  `batch` = (args, kwargs) of detector.forward_train.  Returns
-    (total loss, loss dict) as device tensors: nothing is synchronised here."""
-    freeze_gc_after_warmup()
+    (total loss, loss dict) as device tensors: nothing is synchronised here.  freeze_gc=True: freeze_gc_after_warmup() per call (a
+    process-wide change to the host's cyclic collector: off unless the loop's owner asks for it)."""
+    if freeze_gc:
+        freeze_gc_after_warmup()
     arena.zero_grad()
     args, kwargs = batch
     if hasattr(detector, 'forward_backward'):     # same gradients, head backward issued ahead of the step's one host wait

@@ -413,13 +413,13 @@ def two_stage_main(a, rank, world, dev):
     meta = [dict(img_shape=(H, W, 3, D), pad_shape=(H, W, 3, D), ori_shape=(H, W, 3))]
     batch = ((img, meta, [gt], [gl]), dict(gt_masks=[masks]))
     for _ in range(a.warmup):
-        train_step(det, arena, opt, batch, world)
+        train_step(det, arena, opt, batch, world, freeze_gc=True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        train_step(det, arena, opt, batch, world)
+        train_step(det, arena, opt, batch, world, freeze_gc=True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -67,6 +67,10 @@ enum {
   MR3D_TUNE_ROIALIGN_FORM = 7,    /* channels-last fp32 RoIAlign3D forward (roi_align3d.hip): 0 = the library's choice per pooled shape (round 6: the
                                      row-streaming MFMA kernel), 1 = the round-5 kernels (box / wave), 4..6 = other (pooled-depth chunk, ring)
                                      instances of the row-streaming kernel, see try_fwd_rows */
+  MR3D_TUNE_LATE_GRAD_FINISH = 8, /* read when an ExtractFeat3D engine is built: 1 = ONE gradient finishing at the end of the backward plan (rounds
+                                     1-4) instead of the early bucket in the middle of it (the exchange then overlaps only the stem weight gradient) */
+  MR3D_TUNE_FPN_AFTER_LATERALS = 9, /* read when a plan is built: 1 = the P3..P5 output convolutions are queued behind ALL lateral convolutions
+                                     (rounds 3-4) instead of right behind their own lateral */
   MR3D_TUNE_NUM_KEYS = 16
 };
 void mr3d_tuning_set(int key, int value);
@@ -256,6 +260,8 @@ typedef struct {
   int parity_decomposed;
   float mfma_issue_factor;      /* MFMA FLOPs issued / algorithmic FLOPs: 1, 2/3, 1/2 or 1/3 */
 } mr3d_conv3d_variant;
+/* The probe sees the descriptor only: a launch whose descriptor arms a liveness bitmap (`x_live`, the sparse data gradients of the
+ * pyramid) runs the 2 x 8 x 8 kernel where the probe reports the wide 4 x 8 x 8 one -- same mfma_issue_factor, other tile. */
 int mr3d_conv3d_forward_variant(const mr3d_conv3d_desc *desc, mr3d_conv3d_variant *out);
 
 /* Data gradient of a kernel-3 / stride-2 / pad-1 convolution (resnet3d.py:139, the strided conv2 of the first

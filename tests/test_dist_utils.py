@@ -312,16 +312,14 @@ def test_arena_sgd_equals_per_parameter_sgd_with_grads_none():
     assert len(arena.untouched_ranges()) == 2
 
 
-def test_freeze_gc_after_warmup_freezes_once(monkeypatch):
-    """dist_utils.freeze_gc_after_warmup (called by train_step every step): nothing during the warm-up steps, then ONE full collection +
-    gc.freeze(); MR3D_GC_FREEZE=0 leaves the collector alone."""
+def test_freeze_gc_after_warmup_is_opt_in_and_freezes_once(monkeypatch):
+    """dist_utils.freeze_gc_after_warmup: nothing during the warm-up steps, then ONE full collection + gc.freeze(); train_step calls it
+    only with freeze_gc=True (a library call must not change the host's collector on its own)"""
     import gc
+    import inspect
     from mr3d_amd import dist_utils
+    assert inspect.signature(dist_utils.train_step).parameters['freeze_gc'].default is False
     monkeypatch.setattr(dist_utils, '_gc_state', {'steps': 0, 'frozen': False})
-    monkeypatch.setenv('MR3D_GC_FREEZE', '0')
-    assert [dist_utils.freeze_gc_after_warmup(2) for _ in range(4)] == [False] * 4
-    monkeypatch.setattr(dist_utils, '_gc_state', {'steps': 0, 'frozen': False})
-    monkeypatch.setenv('MR3D_GC_FREEZE', '1')
     before = gc.get_freeze_count()
     try:
         assert [dist_utils.freeze_gc_after_warmup(2) for _ in range(5)] == [False, False, True, False, False]

@@ -68,7 +68,7 @@ def main():
     for it in range(a.iters):
         img, meta, img_2, meta_2, gt, gl, masks = synthetic_sample(rng, D, H, W, dev)
         batch = ((img, [meta], img_2, [meta_2], [gt], [gt * 1.5], [gl], [gl]), dict(gt_masks=[masks]))
-        total, losses = train_step(det, arena, opt, batch, world, grad_clip=35.0)
+        total, losses = train_step(det, arena, opt, batch, world, grad_clip=35.0, freeze_gc=True)
         if rank == 0 and (it % 5 == 0 or it == a.iters - 1):
             print(f'iter {it:4d}  loss {total.item():8.4f}  ' +
                   '  '.join(f'{k} {float(sum(t.sum() for t in v) if isinstance(v, list) else v.sum()):.4f}'

@@ -85,7 +85,7 @@ def main():
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
-    from mr3d_amd.dist_utils import freeze_gc_after_warmup      # what dist_utils.train_step does per step (MR3D_GC_FREEZE=0: off)
+    from mr3d_amd.dist_utils import freeze_gc_after_warmup      # the opt-in collector freeze of a training loop (dist_utils.freeze_gc_after_warmup)
     for _ in range(4):
         freeze_gc_after_warmup()
     if a.phases and not a.two_scales:
