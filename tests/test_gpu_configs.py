@@ -206,3 +206,82 @@ def test_config4_dual_pathway_dcn_neck_bf16(dev):
             assert ((p_.grad - gh_ref[n]).norm() / gh_ref[n].norm()).item() < 1e-4, n
     print(f'configs[4] bf16+dcn vs fp32: backbone gradient L2 {rel:.3e}, cosine {cos:.5f}; ' +
           ', '.join(f'{k} {val(l_bf[k]):.5f}/{val(l_ref[k]):.5f}' for k in l_ref if k != 'acc'))
+
+
+def test_config4_real_size_dual_pathway_dcn_neck_bf16_properties(dev):
+    """BASELINE configs[4] at ITS sizes -- the 512x512x80 volume and its 1.5x copy (768x768x120), bf16 activation storage, DeformConv3d
+    neck -- through the shipped dual-pathway detector's training step (forward_backward), outside bench.py.  No oracle runs at this
+    size (fp32 PyTorch on the host would take minutes per step): size-independent properties instead --
+      * every loss of the reference's dict is there and finite;
+      * every parameter of the model is reached by the backward pass: a finite gradient everywhere, a non-zero one in every module of
+        both pathways (backbone stem .. layer4, FPN laterals, the DCN neck, both RPN heads, bbox / refinement / mask heads);
+      * the step is a function of its inputs: the same sampler words and the same proposals give bit-identical losses and the same
+        sample counts on a second run (kept lists, top-k selections and assignments are integer work; the float atomics of the
+        scatter kernels only enter the gradients)."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    from two_stage_bench import synthetic_gt
+    from mr3d_amd.detector import TwoStageDetector3D2Scales
+    D, H, W = 80, 512, 512
+    D2, H2, W2 = 120, 768, 768
+    torch.manual_seed(11)
+    det = TwoStageDetector3D2Scales(device=dev, dtype=torch.bfloat16, neck_dcn=True)
+    det.extract.zero_init_residual = False
+    det.extract.init_weights()
+    with torch.no_grad():
+        for b in det.extract.blocks:
+            det.extract.get_parameter(b['conv3'].bn + '.weight').fill_(RESIDUAL_SCALE)
+        for off in det.dcn_neck.conv_offset:
+            off.weight.normal_(0, 0.01)
+    rng = np.random.default_rng(4)
+    img = torch.randn(1, 3, D, H, W, device=dev)
+    img_2 = torch.randn(1, 3, D2, H2, W2, device=dev)
+    gt, masks = synthetic_gt(rng, 12, D, H, W, dev)
+    gl = torch.ones(12, dtype=torch.long, device=dev)
+    meta = [dict(img_shape=(H, W, 3, D), pad_shape=(H, W, 3, D), ori_shape=(H, W, 3))]
+    meta_2 = [dict(img_shape=(H2, W2, 3, D2), pad_shape=(H2, W2, 3, D2), ori_shape=(H2, W2, 3))]
+    w = lambda n: rng.integers(0, 2 ** 31 - 1, n)
+    draws = {k: [(w(128), w(256))] for k in ('rpn', 'rpn_2')}
+    draws.update({k: [(w(128), w(512))] for k in ('rcnn', 'rcnn_2', 'refine')})
+    args = (img, meta, img_2, meta_2, [gt], [gt * 1.5], [gl], [gl])
+
+    def val(v):
+        return float(sum(t.sum() for t in v)) if isinstance(v, (list, tuple)) else float(v)
+
+    def run(proposals=None):
+        det.extract.zero_grad()
+        for n_, c in det.named_children():
+            if n_ != 'extract':
+                c.zero_grad(set_to_none=True)
+        losses = det.forward_backward(*args, gt_masks=[masks], draws=draws, proposals=proposals)
+        torch.cuda.synchronize()
+        return {k: val(v) for k, v in losses.items()}, det.last_sample_counts.clone()
+
+    l1, c1 = run()
+    assert set(l1) == {'loss_rpn_cls', 'loss_rpn_reg', 'loss_rpn_cls_2', 'loss_rpn_reg_2', 'loss_cls', 'acc', 'loss_reg',
+                       'loss_refinement_reg', 'loss_mask', 'loss_mask_refinement'}
+    assert all(np.isfinite(v) for v in l1.values()), l1
+    assert int(c1[0][0]) > 0 and int(c1[1][0]) > 0, 'both pathways sampled positives (the mask heads ran)'
+    g = det.extract.flat_grads
+    assert torch.isfinite(g).all()
+    # every layer of the backbone + FPN engine received gradient (arena ranges by parameter name)
+    seen = {}
+    for name, p in det.extract.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+        seen[name.split('.')[0] if not name.startswith('layer') else name.split('.')[0]] = seen.get(name.split('.')[0], 0.0) + float(p.grad.abs().sum())
+    assert all(v > 0 for v in seen.values()), seen
+    modules = {}
+    for name, p in det.named_parameters():
+        if name.startswith('extract.'):
+            continue
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+        modules[name.split('.')[0]] = modules.get(name.split('.')[0], 0.0) + float(p.grad.abs().sum())
+    assert {'dcn_neck', 'rpn_head', 'rpn_head_2', 'bbox_head', 'refinement_head', 'mask_head', 'refinement_mask_head'} <= set(modules), modules.keys()
+    assert all(v > 0 for v in modules.values()), modules
+    proposals = det.last_proposals
+    l2, c2 = run(proposals)
+    assert torch.equal(c1, c2)
+    for k in l1:
+        assert l1[k] == l2[k], (k, l1[k], l2[k])
+    print('configs[4] at 512x512x80 + 768x768x120, bf16 + DCN neck:', {k: round(v, 5) for k, v in l1.items()}, 'sample counts', c1.tolist())
