@@ -543,23 +543,34 @@ __device__ __forceinline__ float hw_min(float a, float b) {
   return r;
 }
 
+// grid (ceil(pairs / 4), 1, segment), 256 threads: wave w of workgroup b takes block pair p = 4 b + w of the UPPER TRIANGLE only,
+// p = c (c + 1) / 2 + r with r <= c (round 6: the square grid of one-wave workgroups launched 1024 workgroups per set of which 496
+// left at once -- a workgroup's turnover costs ~24 ns of dispatch whatever it does, tools/diag/roi_rows_stamps.py -- and 4x the
+// workgroups for the pairs that stay).  The waves of a workgroup are independent: no barrier after the wave's own LDS staging.
+constexpr int kT2Waves = 4;
 template <bool SKIP>
-__global__ __launch_bounds__(MR3D_WAVE) void nms3d_mask_t2_kernel(const float4 *__restrict__ boxes_all, SegTable seg, float thr,
-                                                                 uint64_t *__restrict__ mask_all) {
+__global__ __launch_bounds__(kT2Waves * MR3D_WAVE) void nms3d_mask_t2_kernel(const float4 *__restrict__ boxes_all, SegTable seg, float thr,
+                                                                            uint64_t *__restrict__ mask_all) {
   const int sg = blockIdx.z;
   const int n = seg_rows(seg, sg), cb = (n + 63) / 64;
-  const int c = blockIdx.x, r = blockIdx.y;
-  if (c < r || c >= cb) return;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pair = blockIdx.x * kT2Waves + wave;
+  int c = (int)((sqrtf(8.f * (float)pair + 1.f) - 1.f) * 0.5f);      // p = c (c + 1) / 2 + r: the float estimate is off by at most one
+  while (c * (c + 1) / 2 > pair) --c;
+  while ((c + 1) * (c + 2) / 2 <= pair) ++c;
+  const int r = pair - c * (c + 1) / 2;
+  if (c >= cb) return;                                               // (wave-uniform)
   const float4 *boxes = boxes_all + seg.box_off[sg];
   uint64_t *t2 = mask_all + seg.mask_off[sg];
-  __shared__ float4 rbx[2 * MR3D_WAVE];
-  const int lane = threadIdx.x;
+  __shared__ float4 rbx_all[kT2Waves][2 * MR3D_WAVE];
+  float4 *rbx = rbx_all[wave];
+  const int lane = threadIdx.x & 63;
   const int ridx = r * 64 + lane;
   if (ridx < n) {
     rbx[2 * lane] = boxes[2 * ridx];
     rbx[2 * lane + 1] = boxes[2 * ridx + 1];
   }
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();                                    // (the wave's own LDS rows: its DS operations complete in order)
   const int j = c * 64 + lane;
   uint64_t t = 0;
   if (j < n) {
@@ -709,9 +720,10 @@ void launch_sweep(const uint64_t *mask, const int *order, const SegTable &seg, i
 // n <= 2048 per set: T2 words + chain sweep
 void launch_chain(const float4 *boxes, const int *order, const SegTable &seg, int num_segments, int max_cb, float thr, uint64_t *mask,
                   int64_t *keep, int32_t *num_keep, hipStream_t stream) {
-  const dim3 grid(max_cb, max_cb, num_segments);
-  if (thr >= 0.f) nms3d_mask_t2_kernel<true><<<grid, MR3D_WAVE, 0, stream>>>(boxes, seg, thr, mask);
-  else nms3d_mask_t2_kernel<false><<<grid, MR3D_WAVE, 0, stream>>>(boxes, seg, thr, mask);
+  const int pairs = max_cb * (max_cb + 1) / 2;
+  const dim3 grid((pairs + kT2Waves - 1) / kT2Waves, 1, num_segments);
+  if (thr >= 0.f) nms3d_mask_t2_kernel<true><<<grid, kT2Waves * MR3D_WAVE, 0, stream>>>(boxes, seg, thr, mask);
+  else nms3d_mask_t2_kernel<false><<<grid, kT2Waves * MR3D_WAVE, 0, stream>>>(boxes, seg, thr, mask);
   nms3d_sweep_chain_kernel<<<num_segments, kChainThreads, 0, stream>>>(mask, order, seg, keep, num_keep);
 }
 
