@@ -1430,7 +1430,7 @@ int try_fwd_wave(const float *feat, float *out, const float *rois, int num_rois,
 //   * tap tables never leave the registers: lane e holds sample e (x samples, then y, then z), extents come from one ballot per
 //     axis (samples ascend, so the valid ones are a contiguous lane range), the touched rows / planes from two bit masks compacted
 //     with one ds_permute each, the two A operands from ds_bpermute gathers (ALWAYS with all lanes active, see below);
-//   * results leave through an LDS tile [channel][bin] laid out like the output block, 16 bytes per lane.
+//   * results leave straight from the accumulator registers: a lane holds whole pooled rows of its channel.
 // Same samples, taps and weights as the reference (axis_tap / sample_coord); sums associated per axis as in the wave kernel.
 // Rows wider than two ring buffers (> 8 LPB voxels) are evaluated bin by bin from global memory (correct, slow, never with the
 // shipped level rule below 256-pixel RoIs).
@@ -1465,7 +1465,7 @@ __device__ __forceinline__ float rows_bperm(float v, int src_lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane << 2, __builtin_bit_cast(int, v)));
 }
 
-template <int PDC, int PH_, int PW_, int NS, int LPB, int NB, int FH>
+template <int PDC, int PH_, int PW_, int NS, int LPB, int NB>
 __global__ __launch_bounds__(kRowsThreads) void roi_align3d_fwd_rows(const float *feat, float *__restrict__ out, const float *__restrict__ rois,
                                                                      float scale, float scale_d, int C, int D, int H, int W, int PD,
                                                                      int num_rois, LevelTable lt) {
@@ -1477,10 +1477,10 @@ __global__ __launch_bounds__(kRowsThreads) void roi_align3d_fwd_rows(const float
   constexpr int MP = PDC * PH_, MT = (MP + 15) / 16;              // (pooled depth, pooled row) pairs = rows of the second product, its tiles
   constexpr int PWP = PW_ <= 8 ? 8 : 16;                          // pooled columns of the T1 scratch
   constexpr int KXMAX = 2 * LPB;                                  // k-steps of the first product: rows of up to 8 LPB = 64 voxels
-  constexpr int NBIN = PH_ * PW_, TS = (PDC * NBIN) | 1, CHH = MR3D_WAVE / FH;      // tile: [channel][TS] floats, CHH channels per flush pass
-  constexpr int RING = NB * LPB * 256, TILE = CHH * TS;
+  constexpr int NBIN = PH_ * PW_;
+  constexpr int RING = NB * LPB * 256;
   constexpr uint64_t YM = ((1ull << NYS) - 1) << NXS, ZM = ((1ull << NZS) - 1) << (NXS + NYS);
-  __shared__ __attribute__((aligned(16))) float buf[RING > TILE ? RING : TILE];      // the row ring, then the output tile
+  __shared__ __attribute__((aligned(16))) float buf[RING];                           // the row ring
   __shared__ __attribute__((aligned(16))) float scr_all[kRowsWaves][4 * PWP * 16];   // per wave: T1 of a 4-row group, [row][pooled column][16 channels]
   __shared__ float wy_tab[2 * NYS * 16 * MT], wz_tab[2 * NZS * 16 * MT];             // the second product's A factors, [touched row / plane][pair]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1796,53 +1796,31 @@ __global__ __launch_bounds__(kRowsThreads) void roi_align3d_fwd_rows(const float
     }
   }
 
-  // ---- out[r][c0 + channel][pd0 .. pd0 + npd)[:][:]: through the LDS tile [channel][TS] (a wave writes its 16 channels:
-  // accumulator rows 4 lk + r are (pd, ph) pairs, the column is the channel), then every thread copies 16 bytes at a time: the
-  // chunk's bins of one channel are ONE run, and when the chunk is the whole RoI the 64 runs are one block
+  // ---- out[r][c0 + channel][pd0 + pa][ph][0 .. PW): accumulator row 4 lk + r of tile mt is the pair (pa, ph), the column is the
+  // channel: a lane holds the PW pooled columns of its pairs -- one contiguous run of PW floats per pair in the channel's row of the
+  // output block.  Straight from the registers, 8 bytes per store where the run is 8-byte aligned (PW even): no LDS tile, no barrier
+  // (a tile [channel][bin] copied out 16 bytes per lane cost two barriers per pass and 1.5 us (3,7,7) / 3.5 us (10,14,14) per
+  // workgroup; the lines are completed in L2 by the neighbouring lanes' runs)
   ROWS_MARK(4);
-  const bool whole = pd0 == 0 && npd == PD && TS == B && FH == 1;   // the tile IS the output block
-  const int run = npd * NBIN, goff = pd0 * NBIN;
-  const bool vec = (run & 3) == 0 && (goff & 3) == 0 && (B & 3) == 0;
+  {
+    float *och = oblock + (size_t)(16 * wave + li) * B + (size_t)pd0 * NBIN;
 #pragma unroll
-  for (int h = 0; h < FH; ++h) {
-    rows_barrier();                                                 // the ring (or the previous pass's tile) has been read
-    if ((16 * wave) / CHH == h) {
-      float *trow = buf + ((16 * wave + li) % CHH) * TS;
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+      for (int rr = 0; rr < 4; ++rr) {
+        const int m = 16 * mt + 4 * lk + rr, pa = m / PH_, ph = m - pa * PH_;
+        if (m < MP && pa < npd) {
+          float *run = och + pa * NBIN + ph * PW_;
+          if constexpr (PW_ % 2 == 0) {
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const int m = 16 * mt + 4 * lk + rr, pa = m / PH_, ph = m - pa * PH_;
-          if (m < MP && pa < npd) {
+            for (int pw = 0; pw < PW_; pw += 2)
+              *reinterpret_cast<float2 *>(run + pw) = make_float2(acc[mt][pw][rr] * inv_count, acc[mt][pw + 1][rr] * inv_count);
+          } else {
 #pragma unroll
-            for (int pw = 0; pw < PW_; ++pw) trow[pa * NBIN + ph * PW_ + pw] = acc[mt][pw][rr] * inv_count;
+            for (int pw = 0; pw < PW_; ++pw) run[pw] = acc[mt][pw][rr] * inv_count;
           }
         }
-    }
-    rows_barrier();
-    if (whole) {
-      const float4 *src = reinterpret_cast<const float4 *>(buf);
-      float4 *dst = reinterpret_cast<float4 *>(oblock);
-      for (int i = tid; i < MR3D_WAVE * TS / 4; i += kRowsThreads) dst[i] = src[i];
-    } else if (vec) {
-      const int rv = run / 4;                                       // float4 per channel
-      int ch = tid / rv, v = tid - ch * rv;
-      const int dch = kRowsThreads / rv, dv = kRowsThreads - dch * rv;
-      for (; ch < CHH; ch += dch) {
-        const float *t = buf + ch * TS + 4 * v;
-        *reinterpret_cast<float4 *>(oblock + (size_t)(h * CHH + ch) * B + goff + 4 * v) = make_float4(t[0], t[1], t[2], t[3]);
-        v += dv;
-        if (v >= rv) { v -= rv; ++ch; }
       }
-    } else {
-      int ch = tid / run, v = tid - ch * run;
-      const int dch = kRowsThreads / run, dv = kRowsThreads - dch * run;
-      for (; ch < CHH; ch += dch) {
-        oblock[(size_t)(h * CHH + ch) * B + goff + v] = buf[ch * TS + v];
-        v += dv;
-        if (v >= run) { v -= run; ++ch; }
-      }
-    }
   }
   ROWS_MARK(5);
 #ifdef MR3D_ROWS_STAMPS
@@ -1860,12 +1838,12 @@ extern "C" int mr3d_debug_rows_stamps(unsigned long long *dst) {     // 8192 x 1
 namespace {
 #endif
 
-template <int PDC, int PH_, int PW_, int LPB, int NB, int FH>
+template <int PDC, int PH_, int PW_, int LPB, int NB>
 int launch_fwd_rows(const float *feat, float *out, const float *rois, int num_rois, float scale, float scale_d, int C, int D, int H, int W,
                     int PD, const LevelTable &lt, hipStream_t stream) {
   const int upr = (C / MR3D_WAVE) * ((PD + PDC - 1) / PDC);
   const int grid = ((num_rois + 7) / 8) * 8 * upr;
-  roi_align3d_fwd_rows<PDC, PH_, PW_, 2, LPB, NB, FH><<<grid, kRowsThreads, 0, stream>>>(feat, out, rois, scale, scale_d, C, D, H, W, PD, num_rois, lt);
+  roi_align3d_fwd_rows<PDC, PH_, PW_, 2, LPB, NB><<<grid, kRowsThreads, 0, stream>>>(feat, out, rois, scale, scale_d, C, D, H, W, PD, num_rois, lt);
   return mr3d_launch_status();
 }
 
@@ -1878,28 +1856,31 @@ int try_fwd_rows(const float *feat, float *out, const float *rois, int num_rois,
   long long image = (long long)D * H * W * C * 4;
   for (int i = 0; i < lt.num; ++i) image = std::max(image, (long long)lt.D[i] * lt.H[i] * lt.W[i] * C * 4);
   if (image >= (1LL << 31) || (long long)PD * PH * PW * MR3D_WAVE * 4 >= (1LL << 31)) return MR3D_ERR_UNSUPPORTED;
-#define MR3D_ROWS(PDC, PH_, PW_, LPB, NB, FH) return launch_fwd_rows<PDC, PH_, PW_, LPB, NB, FH>(feat, out, rois, num_rois, scale, scale_d, C, D, H, W, PD, lt, stream)
+#define MR3D_ROWS(PDC, PH_, PW_, LPB, NB) return launch_fwd_rows<PDC, PH_, PW_, LPB, NB>(feat, out, rois, num_rois, scale, scale_d, C, D, H, W, PD, lt, stream)
   // Kernel times on the SURVEY 8(d) rois (rocprofv3 --kernel-trace, tools/r6_roi_kt.sh; round-5 kernels: box 54.5, wave 64.4 us):
-  //   (3,7,7)   x 512: one pooled depth per workgroup, 4-piece buffers (26 KB of LDS, six workgroups per CU: all 1536 resident) 42.3 us;
-  //                    8-piece buffers (43 KB, three per CU) 44.9; the three depths in one workgroup (two M-tiles) 55.8
-  //   (10,14,14) x 128: one pooled depth per workgroup 49.7 / 50.3 us (4- / 8-piece buffers); two depths 56.0
+  //   (3,7,7)   x 512: one pooled depth per workgroup, 4-piece buffers (26 KB of LDS, six workgroups per CU: all 1536 resident) 40.7 us;
+  //                    8-piece buffers (43 KB, three per CU) 41.8; the three depths in one workgroup (two M-tiles) 57.0
+  //   (10,14,14) x 128: one pooled depth per workgroup 50.5 / 48.9 us (4- / 8-piece buffers); two depths 55.8
+  // Summing the planes of a voxel row before the products (one pooled depth per workgroup: b = sum_z wz[z] F[z][y][x], 2-3x fewer
+  // MFMAs) was measured too: 40.0 against 41.8 us with 8-piece buffers, 49.0 against 40.7 with 4-piece ones (a buffer then holds one
+  // or two y-rows: more barriers, no 4-row pipelining) -- the products are not what bounds a batch; not kept.
   // Sharing a large chunk between workgroups that leave early when the RoI is small (each slot estimates the chunk's rows x pieces
   // from the RoI's extents) was measured and dropped: once every slot of the chip is taken, a workgroup's turnover costs ~24 ns
   // whatever its lifetime (4077 early leavers of 0.9 us each stretched the launch from 48 to 95 us).
   if (PW == 7 && PH == 7 && PD <= 3) {                 // the bbox extractor
     switch (form) {
-      case 4: MR3D_ROWS(1, 7, 7, 8, 4, 1);
-      case 5: MR3D_ROWS(3, 7, 7, 4, 4, 1);
-      case 6: MR3D_ROWS(3, 7, 7, 8, 4, 1);
-      default: MR3D_ROWS(1, 7, 7, 4, 4, 1);
+      case 4: MR3D_ROWS(1, 7, 7, 8, 4);
+      case 5: MR3D_ROWS(3, 7, 7, 4, 4);
+      case 6: MR3D_ROWS(3, 7, 7, 8, 4);
+      default: MR3D_ROWS(1, 7, 7, 4, 4);
     }
   }
   if (PW == 14 && PH == 14) {                          // the mask extractor
     switch (form) {
-      case 4: MR3D_ROWS(1, 14, 14, 8, 4, 4);
-      case 5: MR3D_ROWS(2, 14, 14, 4, 4, 4);
-      case 6: MR3D_ROWS(2, 14, 14, 8, 4, 4);
-      default: MR3D_ROWS(1, 14, 14, 4, 4, 4);
+      case 4: MR3D_ROWS(1, 14, 14, 4, 4);
+      case 5: MR3D_ROWS(2, 14, 14, 4, 4);
+      case 6: MR3D_ROWS(2, 14, 14, 8, 4);
+      default: MR3D_ROWS(1, 14, 14, 8, 4);
     }
   }
 #undef MR3D_ROWS
