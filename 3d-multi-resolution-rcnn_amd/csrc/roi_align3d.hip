@@ -1864,6 +1864,11 @@ int try_fwd_rows(const float *feat, float *out, const float *rois, int num_rois,
   // Summing the planes of a voxel row before the products (one pooled depth per workgroup: b = sum_z wz[z] F[z][y][x], 2-3x fewer
   // MFMAs) was measured too: 40.0 against 41.8 us with 8-piece buffers, 49.0 against 40.7 with 4-piece ones (a buffer then holds one
   // or two y-rows: more barriers, no 4-row pipelining) -- the products are not what bounds a batch; not kept.
+  // A dynamic form was built and measured as well (round 6): a one-workgroup plan kernel wrote a unit list into a caller-lent workspace --
+  // (RoI, pooled depth, range of pooled rows), largest first, large chunks split by an estimate of their rows x pieces -- and persistent
+  // workgroups drew units from it (first unit = own index, then a ticket counter: 1536 workgroups drawing their first ticket from ONE
+  // counter staggered the launch by 15 us).  bbox: 37.9 us unsplit / 38.0-43.7 split at 256 / 128 / 64 KB against 40.7 static, plus 7.4 us
+  // for the plan kernel; mask: 54-98 us against 49.  Every split unit pays the whole skeleton again and the order buys 3 us: not kept.
   // Sharing a large chunk between workgroups that leave early when the RoI is small (each slot estimates the chunk's rows x pieces
   // from the RoI's extents) was measured and dropped: once every slot of the chip is taken, a workgroup's turnover costs ~24 ns
   // whatever its lifetime (4077 early leavers of 0.9 us each stretched the launch from 48 to 95 us).
