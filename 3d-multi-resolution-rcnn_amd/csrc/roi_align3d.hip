@@ -2252,6 +2252,214 @@ int launch_bwd_wave(const float *top, float *bottom, const float *rois, int num_
   return mr3d_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------
+// channels-last BACKWARD, one workgroup per (RoI, 64 channels, every K-th voxel PLANE of the footprint) (round 6).
+// roi_align3d_bwd_wave adds a voxel once per (pooled-depth pair, pooled-row quad) chunk that reaches it: 2.4 atomic passes over
+// the footprint on the mask extractor (90 MB of 256-byte atomics at the chip's ~1 TB/s atomic rate = the launch).  Here a voxel is
+// added ONCE per RoI: per voxel plane z
+//     U[ph][pw]  = sum_pd Wz[pd][z] G[pd][ph][pw]          (the pooled depths that reach z: a ballot over the 2 taps x NS samples)
+//     V[pw]      = sum_ph Wy[ph][y] U[ph][pw]               per voxel row y of the plane
+//     dF[z][y][x] += sum_pw Wx[pw][x] V[pw]                 one 256-byte atomic per voxel (lane = channel)
+// The top gradient is [R, C, PD, PH, PW]: the 256 threads read the (64 channels x PH x PW) block of a pooled depth as 8-byte
+// pieces of consecutive bins, accumulate U in registers over the depths of the plane and transpose it through LDS ONCE per plane
+// (U[channel][ph][PWP], channel rows of RS floats with RS / 4 odd: the 16 lanes of a ds_read_b128 pass land on 64 distinct banks);
+// the four waves then split the plane's rows, V in registers, Wy / Wx from dense LDS tables (uniform addresses: broadcast reads).
+// Same taps and weights as every other form (axis_tap's l / h, dropped samples contribute nothing, a clamped sample counts both
+// taps); the reference's top-gradient index bug (:554-555) behind `bug_compat`.
+// ------------------------------------------------------------------------------------------
+constexpr int kPlThreads = 256, kPlPdMax = 16, kPlYCap = 64, kPlXCap = 128;
+
+template <int PH_, int PW_, int NS>
+struct PlCfg {
+  static constexpr int PWP = PW_ <= 8 ? 8 : 16, PHP = PH_ <= 8 ? 8 : 16;
+  static constexpr int RS0 = PH_ * PWP;
+  static constexpr int RS = ((RS0 / 4) % 2 == 0) ? RS0 + 4 : RS0;
+  static constexpr int VEC = PW_ % 2 == 0 ? 2 : 1;
+  static constexpr int ROWI = PW_ / VEC;                       // pieces per pooled row
+  static constexpr int CHI = PH_ * ROWI;                       // pieces per channel
+  static constexpr int ITEMS = 64 * CHI;
+  static constexpr int PER = (ITEMS + kPlThreads - 1) / kPlThreads;
+  static constexpr int NXS = PW_ * NS, NYS = PH_ * NS, NZS = kPlPdMax * NS;
+  static constexpr int FLOATS = 64 * RS + kPlYCap * PHP + kPlXCap * PWP;
+  static constexpr int LDS_BYTES = FLOATS * 4 + (NXS + NYS + NZS) * 16 + 32;
+  static_assert(PW_ <= 16 && PH_ <= 16, "padded table rows");
+};
+
+__device__ __forceinline__ float pl_axis_weight(const IdxEntry *tab, int bin, int v, int ns) {
+  float w = 0.f;
+  for (int i = 0; i < ns; ++i) {
+    const IdxEntry t = tab[bin * ns + i];
+    if (t.lo == v) w += t.h;
+    if (t.hi == v) w += t.l;
+  }
+  return w;
+}
+
+template <int PH_, int PW_, int NS>
+__global__ __launch_bounds__(kPlThreads) void roi_align3d_bwd_planes(const float *__restrict__ top, float *bottom, const float *__restrict__ rois,
+                                                                    float scale, float scale_d, int C, int D, int H, int W, int PD, int K,
+                                                                    int bug_compat, LevelTable lt) {
+  using S = PlCfg<PH_, PW_, NS>;
+  constexpr int PWP = S::PWP, PHP = S::PHP, RS = S::RS, VEC = S::VEC, NXS = S::NXS, NYS = S::NYS, PER = S::PER;
+  extern __shared__ __attribute__((aligned(16))) float pl_lds[];
+  float *U = pl_lds;                                           // [64 channels][RS]
+  float *wyt = U + 64 * RS;                                    // [kPlYCap][PHP]
+  float *wxt = wyt + kPlYCap * PHP;                            // [kPlXCap][PWP]
+  IdxEntry *tabx = reinterpret_cast<IdxEntry *>(wxt + kPlXCap * PWP), *taby = tabx + NXS, *tabz = taby + NYS;
+  int *ext = reinterpret_cast<int *>(tabz + S::NZS);           // x0, x1, y0, y1, z0, z1
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = blockIdx.x, c0 = blockIdx.y * 64, k = blockIdx.z;
+  if (lt.num) {
+    const int lvl = roi_level(rois + (size_t)r * 7, lt.finest_scale, lt.num);
+    D = pick4(lvl, lt.D); H = pick4(lvl, lt.H); W = pick4(lvl, lt.W);
+    scale = pick4(lvl, lt.scale); scale_d = pick4(lvl, lt.scale_d);
+    bottom = pick4(lvl, lt.grad);
+  }
+  const RoiGeom g = roi_geom(rois + (size_t)r * 7, scale, scale_d, NS, PD, PH_, PW_);
+  if (tid < 6) ext[tid] = (tid & 1) ? -1 : 0x7fffffff;
+  __syncthreads();
+  if (tid < NXS + NYS + PD * NS) {
+    const int axis = tid < NXS ? 0 : (tid < NXS + NYS ? 1 : 2);
+    const int e = tid - (axis == 0 ? 0 : (axis == 1 ? NXS : NXS + NYS));
+    const float v = axis == 0 ? sample_coord(g.sw, e / NS, g.bw, e % NS, NS)
+                              : (axis == 1 ? sample_coord(g.sh, e / NS, g.bh, e % NS, NS) : sample_coord(g.sd, e / NS, g.bd, e % NS, NS));
+    AxisTap t;
+    IdxEntry te;
+    te.lo = -1; te.hi = -1; te.l = 0.f; te.h = 0.f;
+    if (axis_tap(v, axis == 0 ? W : (axis == 1 ? H : D), t)) {
+      te.lo = t.lo; te.hi = t.hi; te.l = t.l; te.h = t.h;
+      atomicMin(&ext[2 * axis], t.lo);
+      atomicMax(&ext[2 * axis + 1], t.hi);
+    }
+    (axis == 0 ? tabx : (axis == 1 ? taby : tabz))[e] = te;
+  }
+  __syncthreads();
+  const int x0 = ext[0], x1 = ext[1], y0 = ext[2], y1 = ext[3], z0 = ext[4], z1 = ext[5];
+  const int nx = x1 - x0 + 1, ny = y1 - y0 + 1;
+  if (nx <= 0 || ny <= 0 || z0 + k > z1) return;              // nothing lands in the map / no plane for this workgroup (uniform)
+  for (int idx = tid; idx < min(ny, kPlYCap) * PHP; idx += kPlThreads) {
+    const int row = idx / PHP, a = idx - row * PHP;
+    wyt[idx] = a < PH_ ? pl_axis_weight(taby, a, y0 + row, NS) : 0.f;
+  }
+  for (int idx = tid; idx < min(nx, kPlXCap) * PWP; idx += kPlThreads) {
+    const int col = idx / PWP, a = idx - col * PWP;
+    wxt[idx] = a < PW_ ? pl_axis_weight(tabx, a, x0 + col, NS) : 0.f;
+  }
+  // (the first plane's barrier below also covers the tables)
+  const int B = PD * PH_ * PW_;
+  const float inv_count = 1.f / (float)(NS * NS * NS);
+  const float *tbase = top + ((size_t)r * C + c0) * B;
+  const int pd_stride = bug_compat ? PD * PW_ : PH_ * PW_;
+  float *gbase = bottom + (size_t)g.b * D * H * W * C + c0 + lane;
+  auto sf = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+
+  for (int z = z0 + k; z <= z1; z += K) {
+    const float wzl = lane < PD ? pl_axis_weight(tabz, lane, z, NS) * inv_count : 0.f;
+    unsigned long long mz = __ballot(wzl != 0.f);
+    float acc[PER][VEC];
+#pragma unroll
+    for (int i = 0; i < PER; ++i)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) acc[i][v] = 0.f;
+    while (mz) {
+      const int pd = __builtin_ctzll(mz);
+      mz &= mz - 1;
+      const float w = sf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wzl), pd)));
+      const float *src = tbase + pd * pd_stride;
+      float val[PER][VEC];
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int item = tid + i * kPlThreads;
+        const int c = item / S::CHI, rem = item - c * S::CHI;
+        const bool on = (PER * kPlThreads == S::ITEMS) || item < S::ITEMS;
+        const float *p = src + (size_t)c * B + rem * VEC;
+        if (VEC == 2) {
+          const float2 q = on ? *reinterpret_cast<const float2 *>(p) : make_float2(0.f, 0.f);
+          val[i][0] = q.x; val[i][VEC - 1] = q.y;
+        } else {
+          val[i][0] = on ? *p : 0.f;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < PER; ++i)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[i][v] += w * val[i][v];
+    }
+    __syncthreads();                                           // the previous plane's rows are done with U (first plane: the tables)
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int item = tid + i * kPlThreads;
+      const int c = item / S::CHI, rem = item - c * S::CHI;
+      const int ph = rem / S::ROWI, j = rem - ph * S::ROWI;
+      if ((PER * kPlThreads == S::ITEMS) || item < S::ITEMS) {
+        float *d = U + c * RS + ph * PWP + j * VEC;
+        if (VEC == 2) *reinterpret_cast<float2 *>(d) = make_float2(acc[i][0], acc[i][VEC - 1]);
+        else d[0] = acc[i][0];
+      }
+    }
+    __syncthreads();
+    for (int y = y0 + wave; y <= y1; y += kPlThreads / 64) {
+      const int yi = y - y0;
+      float wyl = 0.f;
+      if (yi < kPlYCap) { if (lane < PHP) wyl = wyt[yi * PHP + lane]; }
+      else if (lane < PH_) wyl = pl_axis_weight(taby, lane, y, NS);
+      unsigned long long my = __ballot(wyl != 0.f);
+      if (!my) continue;
+      float V[PWP];
+#pragma unroll
+      for (int pw = 0; pw < PWP; ++pw) V[pw] = 0.f;
+      while (my) {
+        const int a = __builtin_ctzll(my);
+        my &= my - 1;
+        const float w = sf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wyl), a)));
+        const float4 *u = reinterpret_cast<const float4 *>(U + lane * RS + a * PWP);
+#pragma unroll
+        for (int q = 0; q < PWP / 4; ++q) {
+          const float4 v4 = u[q];
+          V[q * 4] += w * v4.x; V[q * 4 + 1] += w * v4.y; V[q * 4 + 2] += w * v4.z; V[q * 4 + 3] += w * v4.w;
+        }
+      }
+      float *grow = gbase + (((size_t)z * H + y) * W + x0) * C;
+#pragma unroll 2
+      for (int i = 0; i < nx; ++i) {
+        float val = 0.f;
+        if (i < kPlXCap) {
+#pragma unroll
+          for (int q = 0; q < PWP / 4; ++q) {
+            const float4 w4 = *reinterpret_cast<const float4 *>(wxt + i * PWP + q * 4);          // (uniform address: broadcast)
+            if (q * 4 < PW_) val += w4.x * V[q * 4];
+            if (q * 4 + 1 < PW_) val += w4.y * V[q * 4 + 1];
+            if (q * 4 + 2 < PW_) val += w4.z * V[q * 4 + 2];
+            if (q * 4 + 3 < PW_) val += w4.w * V[q * 4 + 3];
+          }
+        } else {
+#pragma unroll
+          for (int pw = 0; pw < PW_; ++pw) val += pl_axis_weight(tabx, pw, x0 + i, NS) * V[pw];
+        }
+        if (val != 0.f) atomicAdd(grow + (size_t)i * C, val);
+      }
+    }
+  }
+}
+
+template <int PH_, int PW_, int NS>
+int launch_bwd_planes(const float *top, float *bottom, const float *rois, int num_rois, float scale, float scale_d, int C, int D, int H, int W,
+                      int PD, int K, int bug, const LevelTable &lt, hipStream_t stream) {
+  using S = PlCfg<PH_, PW_, NS>;
+  static std::once_flag once;
+  static bool ok = false;
+  std::call_once(once, [] {
+    ok = hipFuncSetAttribute(reinterpret_cast<const void *>(roi_align3d_bwd_planes<PH_, PW_, NS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             S::LDS_BYTES) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+  });
+  if (!ok) return MR3D_ERR_LAUNCH;
+  const dim3 grid(num_rois, C / 64, K);
+  roi_align3d_bwd_planes<PH_, PW_, NS><<<grid, kPlThreads, S::LDS_BYTES, stream>>>(top, bottom, rois, scale, scale_d, C, D, H, W, PD, K, bug, lt);
+  return mr3d_launch_status();
+}
+
 int try_bwd_wave(const float *top, float *bottom, const float *rois, int num_rois, float scale, float scale_d, int ns, int C, int D, int H,
                  int W, int PD, int PH, int PW, int bug, const LevelTable &lt, hipStream_t stream) {
   if (C % MR3D_WAVE != 0 || ns != 2) return MR3D_ERR_UNSUPPORTED;
@@ -2261,6 +2469,14 @@ int try_bwd_wave(const float *top, float *bottom, const float *rois, int num_roi
   // atomic passes over a voxel plane that several pooled depths reach, until the registers halve the waves per SIMD.
   // The (3,7,7) extractor keeps the voxel-owner kernel (73 us against 107 us for (3,7) per wave: its rois include the footprints of
   // thousands of voxels that a single wave walks alone).
+  // Plane-owner kernel, K = planes in flight per RoI (SURVEY 8(d) inputs, launch alone): mask extractor (10,14,14) x 128 rois
+  // K = 1 / 2 / 4 / 8 / 12 / 16: 96.7 / 52.9 / 33.7 / 31.9 / 32.3 / 33.9 us (roi_align3d_bwd_wave<2,4,14,2>: 87.6); bbox extractor
+  // (3,7,7) x 512 rois K = 2 / 8 / 12 / 16: 50.0 / 43.0 / 45.1 / 47.7 us (voxel-owner kernel: 74.0).  MR3D_TUNE_ROIALIGN_FORM = 1
+  // keeps the round-5 kernels.
+  if (PD <= kPlPdMax && g_mr3d_tuning[MR3D_TUNE_ROIALIGN_FORM] != 1) {
+    if (PW == 14 && PH == 14) return launch_bwd_planes<14, 14, 2>(top, bottom, rois, num_rois, scale, scale_d, C, D, H, W, PD, 8, bug, lt, stream);
+    if (PW == 7 && PH == 7) return launch_bwd_planes<7, 7, 2>(top, bottom, rois, num_rois, scale, scale_d, C, D, H, W, PD, 8, bug, lt, stream);
+  }
   if (PW == 14 && PH == 14) return launch_bwd_wave<2, 4, 14, 2>(top, bottom, rois, num_rois, scale, scale_d, C, D, H, W, PD, PH, bug, lt, stream);
   return MR3D_ERR_UNSUPPORTED;
 }

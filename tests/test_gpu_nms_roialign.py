@@ -248,6 +248,40 @@ def test_roi_align3d_row_streaming_forward_paths(dev, P, form):
     np.testing.assert_allclose(out.cpu().numpy(), exp, rtol=RTOL, atol=2e-5 * np.abs(exp).max())
 
 
+@pytest.mark.parametrize('P', [(3, 7, 7), (10, 14, 14), (16, 14, 14)])
+@pytest.mark.parametrize('form', [0, 1])
+def test_roi_align3d_plane_owner_backward_paths(dev, P, form):
+    """the plane-owner backward (round 6, roi_align3d_bwd_planes) against the oracle on the footprints that take its different paths:
+    a few voxels (fewer planes than workgroups), bins of several voxels (planes no pooled depth reaches, rows no pooled row reaches),
+    footprints beyond its dense weight tables (> 64 rows, > 128 columns: weights formed on the fly), rois over every border, a
+    degenerate and a malformed roi, two images, 128 channels, the reference's top-gradient index bug on and off, the maximum
+    pooled depth of the kernel; form 1 = the round-5 kernels on the same inputs"""
+    from mr3d_amd import _hip
+    rng = np.random.default_rng(200 + P[0])
+    N, C, D, H, W = 2, 128, 24, 80, 160
+    rois = np.array([[0, 8, 8, 19, 40, 2, 10],
+                     [1, 8, 8, 60, 150, 1, 20],
+                     [0, 2, 3, 630, 310, 0, 46],         # 158 x 78 x 24 voxels: beyond both weight tables
+                     [1, 100, 20, 700, 60, 4, 9],        # 151 columns, 11 rows
+                     [0, 40, 2, 60, 300, 0, 47],         # 75 rows, bins of 5 voxels along y
+                     [1, -30, -20, 50, 30, -6, 8],
+                     [0, 600, 290, 700, 350, 40, 60],
+                     [1, 10, 10, 10, 10, 3, 3],
+                     [0, 30, 30, 20, 20, 5, 2]], np.float32)
+    top = rng.normal(size=(len(rois), C) + P).astype(np.float32)
+    for bug in (True, False):
+        if bug and (P[0] - 1) * P[0] * P[2] + P[1] * P[2] > P[0] * P[1] * P[2]:
+            continue                                     # (the bug's offsets leave the roi's block: mmdet_ops routes that case elsewhere)
+        exp = orc.roi_align3d_backward(top, rois, (N, C, D, H, W), 0.25, 0.5, 2, bug_compat=bug)
+        grad = torch.zeros((N, C, D, H, W), device=dev).contiguous(memory_format=torch.channels_last_3d)
+        _hip.lib().mr3d_tuning_set(7, form)
+        try:
+            _hip.roi_align3d_backward(torch.from_numpy(top).to(dev), torch.from_numpy(rois).to(dev), *P, 0.25, 0.5, 2, grad, bug_compat=bug)
+        finally:
+            _hip.lib().mr3d_tuning_set(7, 0)
+        np.testing.assert_allclose(grad.cpu().numpy(), exp, rtol=RTOL, atol=RTOL * np.abs(exp).max())
+
+
 def test_roi_align3d_error_conventions(dev):
     from mr3d_amd.mmdet_ops.roi_align import roi_align_cuda
     f = torch.zeros((1, 4, 4, 8, 8), device=dev)
