@@ -1869,6 +1869,13 @@ int try_fwd_rows(const float *feat, float *out, const float *rois, int num_rois,
   // workgroups drew units from it (first unit = own index, then a ticket counter: 1536 workgroups drawing their first ticket from ONE
   // counter staggered the launch by 15 us).  bbox: 37.9 us unsplit / 38.0-43.7 split at 256 / 128 / 64 KB against 40.7 static, plus 7.4 us
   // for the plan kernel; mask: 54-98 us against 49.  Every split unit pays the whole skeleton again and the order buys 3 us: not kept.
+  // A register-only form in the image of the plane-owner backward was built and measured too (round 6): one workgroup per (RoI, pooled
+  // depth), lane = channel, wave w owning four (two) pooled rows whose 4 x 14 (2 x 7) accumulators never leave its registers; per voxel
+  // row V[pw] = sum_x Wx[pw][x] F[x] with the voxels of 3 - 12 rows (48 registers) requested together through per-row buffer descriptors
+  // and Wx broadcast from LDS, then T[ph] += wz wy V; output through LDS as 8-byte pieces.  Deterministic, no barrier between set-up
+  // and output, parity green -- bbox 42.4 - 43.3 us, mask 64.3 - 71.3 us against 42.4 / 51.6 for the kernels below on the same box: ~3,000
+  // instructions per wave at one per 4.5 cycles with two or three waves per SIMD (194 registers) is the same wall from the other side.
+  // Not kept.
   // Sharing a large chunk between workgroups that leave early when the RoI is small (each slot estimates the chunk's rows x pieces
   // from the RoI's extents) was measured and dropped: once every slot of the chip is taken, a workgroup's turnover costs ~24 ns
   // whatever its lifetime (4077 early leavers of 0.9 us each stretched the launch from 48 to 95 us).
@@ -2267,7 +2274,7 @@ int launch_bwd_wave(const float *top, float *bottom, const float *rois, int num_
 // Same taps and weights as every other form (axis_tap's l / h, dropped samples contribute nothing, a clamped sample counts both
 // taps); the reference's top-gradient index bug (:554-555) behind `bug_compat`.
 // ------------------------------------------------------------------------------------------
-constexpr int kPlThreads = 256, kPlPdMax = 16, kPlYCap = 64, kPlXCap = 128;
+constexpr int kPlThreads = 256, kPlPdMax = 16, kPlYCap = 128, kPlXCap = 128;
 
 template <int PH_, int PW_, int NS>
 struct PlCfg {

@@ -253,19 +253,19 @@ def test_roi_align3d_row_streaming_forward_paths(dev, P, form):
 def test_roi_align3d_plane_owner_backward_paths(dev, P, form):
     """the plane-owner backward (round 6, roi_align3d_bwd_planes) against the oracle on the footprints that take its different paths:
     a few voxels (fewer planes than workgroups), bins of several voxels (planes no pooled depth reaches, rows no pooled row reaches),
-    footprints beyond its dense weight tables (> 64 rows, > 128 columns: weights formed on the fly), rois over every border, a
+    footprints beyond its dense weight tables (> 128 rows or columns: weights formed on the fly), rois over every border, a
     degenerate and a malformed roi, two images, 128 channels, the reference's top-gradient index bug on and off, the maximum
     pooled depth of the kernel; form 1 = the round-5 kernels on the same inputs"""
     from mr3d_amd import _hip
     rng = np.random.default_rng(200 + P[0])
-    N, C, D, H, W = 2, 128, 24, 80, 160
+    N, C, D, H, W = 2, 128, 12, 140, 160
     rois = np.array([[0, 8, 8, 19, 40, 2, 10],
                      [1, 8, 8, 60, 150, 1, 20],
-                     [0, 2, 3, 630, 310, 0, 46],         # 158 x 78 x 24 voxels: beyond both weight tables
+                     [0, 2, 3, 630, 550, 0, 22],         # 158 x 138 x 12 voxels: beyond both weight tables
                      [1, 100, 20, 700, 60, 4, 9],        # 151 columns, 11 rows
                      [0, 40, 2, 60, 300, 0, 47],         # 75 rows, bins of 5 voxels along y
                      [1, -30, -20, 50, 30, -6, 8],
-                     [0, 600, 290, 700, 350, 40, 60],
+                     [0, 600, 500, 700, 580, 18, 30],
                      [1, 10, 10, 10, 10, 3, 3],
                      [0, 30, 30, 20, 20, 5, 2]], np.float32)
     top = rng.normal(size=(len(rois), C) + P).astype(np.float32)
