@@ -1848,6 +1848,10 @@ int launch_fwd_rows(const float *feat, float *out, const float *rois, int num_ro
 }
 
 // fp32 channels-last features, C % 64 == 0, sample_num 2, the two extractor shapes of the shipped model; anything else: the kernels above
+struct LevelTable;
+int try_fwd_fold(const float *feat, float *out, const float *rois, int num_rois, float scale, float scale_d, int C, int D, int H, int W, int PD,
+                 int PH, int PW, const LevelTable &lt, hipStream_t stream);         // (defined next to the plane-owner backward)
+
 int try_fwd_rows(const float *feat, float *out, const float *rois, int num_rois, float scale, float scale_d, int ns, int C, int D, int H,
                  int W, int PD, int PH, int PW, const LevelTable &lt, hipStream_t stream) {
   const int form = g_mr3d_tuning[MR3D_TUNE_ROIALIGN_FORM];
@@ -1856,6 +1860,15 @@ int try_fwd_rows(const float *feat, float *out, const float *rois, int num_rois,
   long long image = (long long)D * H * W * C * 4;
   for (int i = 0; i < lt.num; ++i) image = std::max(image, (long long)lt.D[i] * lt.H[i] * lt.W[i] * C * 4);
   if (image >= (1LL << 31) || (long long)PD * PH * PW * MR3D_WAVE * 4 >= (1LL << 31)) return MR3D_ERR_UNSUPPORTED;
+  // The plane-folded kernel (further down, next to the backward it mirrors): bbox extractor 30.5 us against 40.8 for the row-streaming
+  // kernel (kernel times, 512 rois; 13.8 against 24.7 us at 64 rois); mask extractor 53.4 against 49.9 us (27.7 against 35.0 at 64 rois:
+  // a (RoI, pooled depth) unit of the mask extractor is ~9 voxel rows x 2 planes of work under the same set-up, four barriers and a
+  // 50 KB output tile that keeps it at two workgroups per CU).  Default: folded for (.,7,7), row streaming for (.,14,14);
+  // MR3D_TUNE_ROIALIGN_FORM = 2: row streaming for both, 8: folded for both, 4 / 5 / 6: the row-streaming instances below.
+  if ((form == 0 && PW == 7 && PH == 7) || form == 8) {
+    const int sto = try_fwd_fold(feat, out, rois, num_rois, scale, scale_d, C, D, H, W, PD, PH, PW, lt, stream);
+    if (sto != MR3D_ERR_UNSUPPORTED) return sto;
+  }
 #define MR3D_ROWS(PDC, PH_, PW_, LPB, NB) return launch_fwd_rows<PDC, PH_, PW_, LPB, NB>(feat, out, rois, num_rois, scale, scale_d, C, D, H, W, PD, lt, stream)
   // Kernel times on the SURVEY 8(d) rois (rocprofv3 --kernel-trace, tools/r6_roi_kt.sh; round-5 kernels: box 54.5, wave 64.4 us):
   //   (3,7,7)   x 512: one pooled depth per workgroup, 4-piece buffers (26 KB of LDS, six workgroups per CU: all 1536 resident) 40.7 us;
@@ -2465,6 +2478,311 @@ int launch_bwd_planes(const float *top, float *bottom, const float *rois, int nu
   const dim3 grid(num_rois, C / 64, K);
   roi_align3d_bwd_planes<PH_, PW_, NS><<<grid, kPlThreads, S::LDS_BYTES, stream>>>(top, bottom, rois, scale, scale_d, C, D, H, W, PD, K, bug, lt);
   return mr3d_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------
+// channels-last FORWARD, planes folded first (round 6): one workgroup per (RoI, 64 channels, pooled depth), lane = channel.
+// The transposed form of roi_align3d_bwd_planes: every voxel row of the footprint is multiplied ONCE.
+//   phase A (the waves split the voxel rows y):   F'[x]  = sum_z Wz[z] F[z][y][x]        z over the <= 2 NS planes of the pooled depth;
+//                                                 V[pw]  = sum_x Wx[pw][x] F'[x]         (Wx: dense LDS table, uniform address = broadcast)
+//                                                 -> LDS  Vt[y][channel][pw]
+//   phase B (wave w owns pooled rows 4w .. 4w+3): T[ph][pw] = sum over the 2 NS taps of ph  weight * Vt[tap row][pw]     (registers)
+//   output: registers -> LDS [channel][ph][PWP] -> 8-byte pieces of consecutive bins of the [R, C, PD, PH, PW] output.
+// The voxels of a row piece (<= 16 voxels x <= 4 planes) are requested together through one buffer descriptor per (plane, piece):
+// a voxel behind the row's end is out of the descriptor's range and reads 0 -- no branch, no select.  Footprints of more than
+// kFoldRows voxel rows take several passes (the accumulators stay in registers); the sum order is fixed by the RoI alone.
+// The row-streaming kernel above multiplies every voxel row of every plane (two MFMA products with padded K); the owner-wave
+// form read a row once per wave whose pooled rows reach it.
+// ------------------------------------------------------------------------------------------
+
+template <int PH_, int PW_, int NS, int ROWS>
+struct FoldCfg {
+  static constexpr int kFoldRows = ROWS;
+  using P = PlCfg<PH_, PW_, NS>;
+  static constexpr int PWP = P::PWP;
+  static constexpr int VP = ((PWP / 4) % 2 == 0) ? PWP + 4 : PWP;              // floats per (row, channel) of Vt: VP / 4 odd
+  static constexpr int UNION = (kFoldRows * 64 * VP > 64 * P::RS) ? kFoldRows * 64 * VP : 64 * P::RS;
+  static constexpr int FLOATS = UNION + kPlXCap * PWP;
+  static constexpr int LDS_BYTES = FLOATS * 4 + (P::NXS + P::NYS) * 16 + 64;
+};
+
+template <int PH_, int PW_, int NS, int ROWS>
+__global__ __launch_bounds__(kPlThreads, (PH_ > 8 ? 2 : 4)) void roi_align3d_fwd_fold(const float *feat, float *__restrict__ out,
+                                                                                     const float *__restrict__ rois, float scale, float scale_d,
+                                                                                     int C, int D, int H, int W, int PD, LevelTable lt) {
+  using S = PlCfg<PH_, PW_, NS>;
+  using Fc = FoldCfg<PH_, PW_, NS, ROWS>;
+  constexpr int kFoldRows = ROWS;
+  constexpr int PWP = S::PWP, RS = S::RS, VEC = S::VEC, NXS = S::NXS, NYS = S::NYS, PER = S::PER, VP = Fc::VP;
+  constexpr int PHW = (PH_ + 3) / 4, NZ = 2 * NS;
+  extern __shared__ __attribute__((aligned(16))) float pl_lds[];
+  float *U = pl_lds;                                           // [64 channels][RS]: the output tile ...
+  float *Vt = pl_lds;                                          // ... and before it [kFoldRows][64 channels][VP]
+  float *wxt = pl_lds + Fc::UNION;                             // [kPlXCap][PWP]
+  IdxEntry *tabx = reinterpret_cast<IdxEntry *>(wxt + kPlXCap * PWP), *taby = tabx + NXS;
+  int *ext = reinterpret_cast<int *>(taby + NYS);              // x0, x1, y0, y1, -, -, planes | plane index x4 | plane weight x4
+  int *zl = ext + 8;
+  float *wzl = reinterpret_cast<float *>(ext + 12);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = blockIdx.x, c0 = blockIdx.y * 64, pd = blockIdx.z;
+  if (lt.num) {
+    const int lvl = roi_level(rois + (size_t)r * 7, lt.finest_scale, lt.num);
+    D = pick4(lvl, lt.D); H = pick4(lvl, lt.H); W = pick4(lvl, lt.W);
+    scale = pick4(lvl, lt.scale); scale_d = pick4(lvl, lt.scale_d);
+    feat = pick4(lvl, lt.feat);
+  }
+  const RoiGeom g = roi_geom(rois + (size_t)r * 7, scale, scale_d, NS, PD, PH_, PW_);
+  if (tid < 6) ext[tid] = (tid & 1) ? -1 : 0x7fffffff;
+  if (tid == 64) {                                             // the planes of this pooled depth: <= 2 per sample, merged
+    AxisTap t[NS];
+    bool ok[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) ok[s] = axis_tap(sample_coord(g.sd, pd, g.bd, s, NS), D, t[s]);
+    const float inv_count = 1.f / (float)(NS * NS * NS);
+    int n = 0;
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        if (!ok[s]) continue;
+        const int z = e ? t[s].hi : t[s].lo;
+        bool dup = false;
+        for (int q = 0; q < n; ++q) dup = dup || zl[q] == z;
+        if (dup) continue;
+        float w = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < NS; ++s2) {
+          if (!ok[s2]) continue;
+          if (t[s2].lo == z) w += t[s2].h;
+          if (t[s2].hi == z) w += t[s2].l;
+        }
+        zl[n] = z; wzl[n] = w * inv_count;
+        ++n;
+      }
+    for (int q = n; q < NZ; ++q) { zl[q] = 0; wzl[q] = 0.f; }
+    ext[6] = n;
+  }
+  __syncthreads();
+  if (tid < NXS + NYS) {
+    const int axis = tid < NXS ? 0 : 1;
+    const int e = tid - (axis == 0 ? 0 : NXS);
+    const float v = axis == 0 ? sample_coord(g.sw, e / NS, g.bw, e % NS, NS) : sample_coord(g.sh, e / NS, g.bh, e % NS, NS);
+    AxisTap t;
+    IdxEntry te;
+    te.lo = -1; te.hi = -1; te.l = 0.f; te.h = 0.f;
+    if (axis_tap(v, axis == 0 ? W : H, t)) {
+      te.lo = t.lo; te.hi = t.hi; te.l = t.l; te.h = t.h;
+      atomicMin(&ext[2 * axis], t.lo);
+      atomicMax(&ext[2 * axis + 1], t.hi);
+    }
+    (axis == 0 ? tabx : taby)[e] = te;
+  }
+  __syncthreads();
+  const int x0 = __builtin_amdgcn_readfirstlane(ext[0]), y0 = __builtin_amdgcn_readfirstlane(ext[2]);
+  const int nzp = __builtin_amdgcn_readfirstlane(ext[6]);
+  const int nx = __builtin_amdgcn_readfirstlane(ext[1]) - x0 + 1, ny = __builtin_amdgcn_readfirstlane(ext[3]) - y0 + 1;
+  const float *fbase = feat + (size_t)g.b * D * H * W * C + c0;
+  const int ph0 = wave * PHW;
+  const int nphw = min(PHW, PH_ - ph0);
+  auto sf = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
+
+  if (nx > kPlXCap) {
+    // a footprint wider than the weight table (a RoI of > 128 voxels along x of its level): bin by bin, tap by tap
+    for (int bin = wave; bin < PH_ * PW_; bin += kPlThreads / 64) {
+      const int ph = bin / PW_, pw = bin - ph * PW_;
+      float acc = 0.f;
+      for (int k = 0; k < nzp; ++k) {
+        const int z = zl[k];
+        for (int sy = 0; sy < 2 * NS; ++sy) {
+          const IdxEntry ty = taby[ph * NS + (sy >> 1)];
+          if (ty.lo < 0) continue;
+          const float wzy = wzl[k] * ((sy & 1) ? ty.l : ty.h);
+          const float *prow = fbase + ((size_t)z * H + ((sy & 1) ? ty.hi : ty.lo)) * W * C + lane;
+          for (int sx = 0; sx < 2 * NS; ++sx) {
+            const IdxEntry tx = tabx[pw * NS + (sx >> 1)];
+            if (tx.lo < 0) continue;
+            acc += wzy * ((sx & 1) ? tx.l : tx.h) * prow[(size_t)((sx & 1) ? tx.hi : tx.lo) * C];
+          }
+        }
+      }
+      U[lane * RS + ph * PWP + pw] = acc;
+    }
+  } else {
+    const int nxt = min((nx + 15) & ~15, kPlXCap);             // (the columns behind the row's end carry weight 0; kPlXCap % 16 == 0)
+    for (int idx = tid; idx < nxt * PWP; idx += kPlThreads) {
+      const int col = idx / PWP, a = idx - col * PWP;
+      wxt[idx] = a < PW_ ? pl_axis_weight(tabx, a, x0 + col, NS) : 0.f;
+    }
+    float T[PHW][PW_];
+#pragma unroll
+    for (int j = 0; j < PHW; ++j)
+#pragma unroll
+      for (int pw = 0; pw < PW_; ++pw) T[j][pw] = 0.f;
+    const unsigned cstep = (unsigned)C * 4u, lane4 = (unsigned)lane * 4u;
+    const int zq[NZ] = {__builtin_amdgcn_readfirstlane(zl[0]), __builtin_amdgcn_readfirstlane(zl[1]), __builtin_amdgcn_readfirstlane(zl[NZ > 2 ? 2 : 0]),
+                        __builtin_amdgcn_readfirstlane(zl[NZ > 3 ? 3 : 0])};
+    const float wq[NZ] = {sf(wzl[0]), sf(wzl[1]), sf(wzl[NZ > 2 ? 2 : 0]), sf(wzl[NZ > 3 ? 3 : 0])};
+    static_assert(NZ == 4, "two samples per bin along z");
+
+    // phase A for one voxel row: V[pw] of the folded row, pieces of XB voxels
+    auto row = [&](auto xb_tag, int y, float (&V)[PW_]) {
+      constexpr int XB = decltype(xb_tag)::value;
+      const int nch = (nx + XB - 1) / XB;
+      for (int pc = 0; pc < nch; ++pc) {
+        float f[NZ][XB];
+        const int nvox = min(XB, nx - pc * XB);
+#pragma unroll
+        for (int k = 0; k < NZ; ++k) {
+          const bool on = k < nzp;
+          const float *pbase = fbase + (size_t)(((zq[k] * H + y) * W + x0 + pc * XB)) * C;
+          const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(on ? pbase : fbase), 0, on ? nvox * (int)cstep : 0, 0x00020000);
+#pragma unroll
+          for (int i = 0; i < XB; ++i) f[k][i] = buffer_load1(pr, lane4, (unsigned)i * cstep);
+        }
+        __builtin_amdgcn_sched_barrier(0);                     // every request of the piece before the first multiply-add
+        float ff[XB];
+#pragma unroll
+        for (int i = 0; i < XB; ++i) {
+          ff[i] = wq[0] * f[0][i];
+#pragma unroll
+          for (int k = 1; k < NZ; ++k) ff[i] += wq[k] * f[k][i];
+        }
+        const float *wrow = wxt + pc * XB * PWP;
+        // the weights of voxel i + 1 are requested before voxel i's multiply-adds and no further ahead (left alone the scheduler
+        // hoists every read of the piece)
+        float4 wc[PWP / 4], wn[PWP / 4];
+#pragma unroll
+        for (int q = 0; q < PWP / 4; ++q) wc[q] = *reinterpret_cast<const float4 *>(wrow + q * 4);      // (uniform address: broadcast)
+#pragma unroll
+        for (int i = 0; i < XB; ++i) {
+          if (i + 1 < XB) {
+#pragma unroll
+            for (int q = 0; q < PWP / 4; ++q) wn[q] = *reinterpret_cast<const float4 *>(wrow + (i + 1) * PWP + q * 4);
+          }
+          asm volatile("" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < PWP / 4; ++q) {
+            if (q * 4 < PW_) V[q * 4] += wc[q].x * ff[i];
+            if (q * 4 + 1 < PW_) V[q * 4 + 1] += wc[q].y * ff[i];
+            if (q * 4 + 2 < PW_) V[q * 4 + 2] += wc[q].z * ff[i];
+            if (q * 4 + 3 < PW_) V[q * 4 + 3] += wc[q].w * ff[i];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < PWP / 4; ++q) wc[q] = wn[q];
+        }
+      }
+    };
+
+    __syncthreads();                                           // the weight table
+    for (int yb = 0; yb < ny && nzp > 0; yb += kFoldRows) {
+      const int nrows = min(kFoldRows, ny - yb);
+      if (yb) __syncthreads();                                 // the previous pass's phase B is done with Vt
+      for (int yr = wave; yr < nrows; yr += kPlThreads / 64) {
+        float V[PW_];
+#pragma unroll
+        for (int pw = 0; pw < PW_; ++pw) V[pw] = 0.f;
+        if (nx <= 4) row(std::integral_constant<int, 4>{}, y0 + yb + yr, V);
+        else if (nx <= 8) row(std::integral_constant<int, 8>{}, y0 + yb + yr, V);
+        else if (nx <= 12) row(std::integral_constant<int, 12>{}, y0 + yb + yr, V);
+        else row(std::integral_constant<int, 16>{}, y0 + yb + yr, V);
+        float *d = Vt + (yr * 64 + lane) * VP;
+#pragma unroll
+        for (int q = 0; q < PWP / 4; ++q) {
+          float4 v;
+          v.x = q * 4 < PW_ ? V[q * 4 < PW_ ? q * 4 : 0] : 0.f;
+          v.y = q * 4 + 1 < PW_ ? V[q * 4 + 1 < PW_ ? q * 4 + 1 : 0] : 0.f;
+          v.z = q * 4 + 2 < PW_ ? V[q * 4 + 2 < PW_ ? q * 4 + 2 : 0] : 0.f;
+          v.w = q * 4 + 3 < PW_ ? V[q * 4 + 3 < PW_ ? q * 4 + 3 : 0] : 0.f;
+          *reinterpret_cast<float4 *>(d + q * 4) = v;
+        }
+      }
+      __syncthreads();
+      // phase B: the 2 NS taps of each of the wave's pooled rows that fall into this pass
+#pragma unroll
+      for (int j = 0; j < PHW; ++j) {
+        if (j < nphw) {
+#pragma unroll
+          for (int e = 0; e < 2 * NS; ++e) {
+            const IdxEntry ty = taby[(ph0 + j) * NS + (e >> 1)];
+            const int yy = __builtin_amdgcn_readfirstlane((e & 1) ? ty.hi : ty.lo) - y0 - yb;
+            const float w = sf((e & 1) ? ty.l : ty.h);
+            if (yy >= 0 && yy < nrows && w != 0.f) {           // (an out-of-range sample has lo = hi = -1)
+              const float4 *s = reinterpret_cast<const float4 *>(Vt + (yy * 64 + lane) * VP);
+#pragma unroll
+              for (int q = 0; q < PWP / 4; ++q) {
+                const float4 v4 = s[q];
+                if (q * 4 < PW_) T[j][q * 4 < PW_ ? q * 4 : 0] += w * v4.x;
+                if (q * 4 + 1 < PW_) T[j][q * 4 + 1 < PW_ ? q * 4 + 1 : 0] += w * v4.y;
+                if (q * 4 + 2 < PW_) T[j][q * 4 + 2 < PW_ ? q * 4 + 2 : 0] += w * v4.z;
+                if (q * 4 + 3 < PW_) T[j][q * 4 + 3 < PW_ ? q * 4 + 3 : 0] += w * v4.w;
+              }
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();                                           // every wave is done with Vt: the output tile takes its place
+#pragma unroll
+    for (int j = 0; j < PHW; ++j) {
+      if (j < nphw) {
+        float *d = U + lane * RS + (ph0 + j) * PWP;
+#pragma unroll
+        for (int q = 0; q < PWP / 4; ++q) {
+          float4 v;
+          v.x = q * 4 < PW_ ? T[j][q * 4 < PW_ ? q * 4 : 0] : 0.f;
+          v.y = q * 4 + 1 < PW_ ? T[j][q * 4 + 1 < PW_ ? q * 4 + 1 : 0] : 0.f;
+          v.z = q * 4 + 2 < PW_ ? T[j][q * 4 + 2 < PW_ ? q * 4 + 2 : 0] : 0.f;
+          v.w = q * 4 + 3 < PW_ ? T[j][q * 4 + 3 < PW_ ? q * 4 + 3 : 0] : 0.f;
+          *reinterpret_cast<float4 *>(d + q * 4) = v;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- the output tile: LDS [channel][ph][PWP] -> 8-byte pieces of consecutive bins
+  const int B = PD * PH_ * PW_;
+  float *obase = out + ((size_t)r * C + c0) * B + pd * PH_ * PW_;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int item = tid + i * kPlThreads;
+    if ((PER * kPlThreads == S::ITEMS) || item < S::ITEMS) {
+      const int c = item / S::CHI, rem = item - c * S::CHI;
+      const int ph = rem / S::ROWI, j = rem - ph * S::ROWI;
+      const float *s = U + c * RS + ph * PWP + j * VEC;
+      float *d = obase + (size_t)c * B + rem * VEC;
+      if (VEC == 2) *reinterpret_cast<float2 *>(d) = *reinterpret_cast<const float2 *>(s);
+      else d[0] = s[0];
+    }
+  }
+}
+
+template <int PH_, int PW_, int NS, int ROWS>
+int launch_fwd_fold(const float *feat, float *out, const float *rois, int num_rois, float scale, float scale_d, int C, int D, int H, int W, int PD,
+                    const LevelTable &lt, hipStream_t stream) {
+  using Fc = FoldCfg<PH_, PW_, NS, ROWS>;
+  static std::once_flag once;
+  static bool ok = false;
+  std::call_once(once, [] {
+    ok = hipFuncSetAttribute(reinterpret_cast<const void *>(roi_align3d_fwd_fold<PH_, PW_, NS, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             Fc::LDS_BYTES) == hipSuccess;
+    if (!ok) (void)hipGetLastError();
+  });
+  if (!ok) return MR3D_ERR_LAUNCH;
+  const dim3 grid(num_rois, C / 64, PD);
+  roi_align3d_fwd_fold<PH_, PW_, NS, ROWS><<<grid, kPlThreads, Fc::LDS_BYTES, stream>>>(feat, out, rois, scale, scale_d, C, D, H, W, PD, lt);
+  return mr3d_launch_status();
+}
+
+int try_fwd_fold(const float *feat, float *out, const float *rois, int num_rois, float scale, float scale_d, int C, int D, int H, int W, int PD,
+                 int PH, int PW, const LevelTable &lt, hipStream_t stream) {
+  // voxel rows per pass (SURVEY 8(d) rois, (3,7,7) x 512, kernel time): 8 / 10 / 12 / 16 rows = 34.7 / 33.3 / 32.8 / 34.4 us with two
+  // piece widths; 30.5 us with the four (12 rows)
+  if (PW == 14 && PH == 14) return launch_fwd_fold<14, 14, 2, 12>(feat, out, rois, num_rois, scale, scale_d, C, D, H, W, PD, lt, stream);
+  if (PW == 7 && PH == 7) return launch_fwd_fold<7, 7, 2, 12>(feat, out, rois, num_rois, scale, scale_d, C, D, H, W, PD, lt, stream);
+  return MR3D_ERR_UNSUPPORTED;
 }
 
 int try_bwd_wave(const float *top, float *bottom, const float *rois, int num_rois, float scale, float scale_d, int ns, int C, int D, int H,

@@ -64,9 +64,11 @@ enum {
                                      2 x 8 x 8-tile kernel of round 2, 2 = always the wide kernel (4 x 8 x 8 tiles, 512 threads) */
   MR3D_TUNE_SIDE_PRIORITY = 6,    /* priority class of the plan executor's side queues, read at the first plan run of the process: 0 = high
                                      (default: a hardware queue of their own whatever other libraries hold), 1 = middle, 2 = low */
-  MR3D_TUNE_ROIALIGN_FORM = 7,    /* channels-last fp32 RoIAlign3D forward (roi_align3d.hip): 0 = the library's choice per pooled shape (round 6: the
-                                     row-streaming MFMA kernel), 1 = the round-5 kernels (box / wave), 4..6 = other (pooled-depth chunk, ring)
-                                     instances of the row-streaming kernel, see try_fwd_rows */
+  MR3D_TUNE_ROIALIGN_FORM = 7,    /* channels-last fp32 RoIAlign3D (roi_align3d.hip): 0 = the library's choice per pooled shape (round 6: forward =
+                                     the plane-folded kernel for (.,7,7), the row-streaming MFMA kernel for (.,14,14); backward = the plane-owner
+                                     kernel), 1 = the round-5 kernels (forward box / wave, backward voxel-owner / wave), 2 = row streaming for both
+                                     forward shapes, 8 = plane-folded for both, 4..6 = other (pooled-depth chunk, ring) instances of the
+                                     row-streaming kernel, see try_fwd_rows */
   MR3D_TUNE_LATE_GRAD_FINISH = 8, /* read when an ExtractFeat3D engine is built: 1 = ONE gradient finishing at the end of the backward plan (rounds
                                      1-4) instead of the early bucket in the middle of it (the exchange then overlaps only the stem weight gradient) */
   MR3D_TUNE_FPN_AFTER_LATERALS = 9, /* read when a plan is built: 1 = the P3..P5 output convolutions are queued behind ALL lateral convolutions

@@ -214,9 +214,10 @@ def test_roi_align3d_benchmark_shapes_properties(dev):
 
 
 @pytest.mark.parametrize('P', [(3, 7, 7), (10, 14, 14)])
-@pytest.mark.parametrize("form", [0, 1, 4, 5, 6])
+@pytest.mark.parametrize("form", [0, 1, 2, 4, 5, 6, 8])
 def test_roi_align3d_row_streaming_forward_paths(dev, P, form):
-    """the row-streaming forward (round 6, roi_align3d_fwd_rows) against the oracle on the row shapes that take its different
+    """the round-6 forward kernels (row streaming roi_align3d_fwd_rows; planes folded first roi_align3d_fwd_fold: form 0 takes it for
+    (3,7,7), form 8 for both shapes, form 2 = row streaming for both) against the oracle on the row shapes that take their different
     paths: one-piece rows (<= 4 voxels), unrolled k-step counts (<= 16 voxels), long rows alone in a double-size ring buffer
     (17 .. 32 / 64 voxels), rows wider than the ring (bin-by-bin fallback), footprints with untouched rows (bins of > 2 voxels),
     rois hanging over every border, a degenerate roi, two images, 128 channels; every (chunk, ring) instance behind

@@ -6,7 +6,7 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for f in ${FORMS:-0 1 4}; do
   rm -rf $O/kt$f
-  rocprofv3 --output-format csv --kernel-trace --stats -d $O/kt$f -o kt -- python3 $REPO/tools/roi_fwd_bench.py --tune 7=$f > /dev/null 2> $O/kt$f.err
+  rocprofv3 --output-format csv --kernel-trace --stats -d $O/kt$f -o kt -- python3 $REPO/tools/roi_fwd_bench.py --tune 7=$f $ARGS > /dev/null 2> $O/kt$f.err
   KS=$(find $O/kt$f -name '*kernel_stats.csv' | head -1)
   echo "== form $f"; python3 - "$KS" <<'PY'
 import csv, sys
