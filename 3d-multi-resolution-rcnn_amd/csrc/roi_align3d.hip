@@ -1442,7 +1442,11 @@ __device__ int g_rows_dbg;                              // timing-only ablations
 #define ROWS_DBG(bit) (g_rows_dbg & (bit))
 #define ROWS_MARK(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_rows_stamps[blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
 #define ROWS_NOTE(k, v) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_rows_stamps[blockIdx.x * 16 + (k)] = (unsigned long long)(v); } while (0)
+#define FOLD_MARK(k) do { const unsigned b_ = blockIdx.x + gridDim.x * blockIdx.z; if (threadIdx.x == 0 && b_ < 8192) g_rows_stamps[b_ * 16 + (k)] = wall_clock64(); } while (0)
+#define FOLD_NOTE(k, v) do { const unsigned b_ = blockIdx.x + gridDim.x * blockIdx.z; if (threadIdx.x == 0 && b_ < 8192) g_rows_stamps[b_ * 16 + (k)] = (unsigned long long)(v); } while (0)
 #else
+#define FOLD_MARK(k) do { } while (0)
+#define FOLD_NOTE(k, v) do { } while (0)
 #define ROWS_MARK(k) do { } while (0)
 #define ROWS_NOTE(k, v) do { } while (0)
 #define ROWS_DBG(bit) 0
@@ -2526,6 +2530,7 @@ __global__ __launch_bounds__(kPlThreads, (PH_ > 8 ? 2 : 4)) void roi_align3d_fwd
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = blockIdx.x, c0 = blockIdx.y * 64, pd = blockIdx.z;
+  FOLD_MARK(0);
   if (lt.num) {
     const int lvl = roi_level(rois + (size_t)r * 7, lt.finest_scale, lt.num);
     D = pick4(lvl, lt.D); H = pick4(lvl, lt.H); W = pick4(lvl, lt.W);
@@ -2564,6 +2569,7 @@ __global__ __launch_bounds__(kPlThreads, (PH_ > 8 ? 2 : 4)) void roi_align3d_fwd
     ext[6] = n;
   }
   __syncthreads();
+  FOLD_MARK(1);
   if (tid < NXS + NYS) {
     const int axis = tid < NXS ? 0 : 1;
     const int e = tid - (axis == 0 ? 0 : NXS);
@@ -2579,6 +2585,7 @@ __global__ __launch_bounds__(kPlThreads, (PH_ > 8 ? 2 : 4)) void roi_align3d_fwd
     (axis == 0 ? tabx : taby)[e] = te;
   }
   __syncthreads();
+  FOLD_MARK(2);
   const int x0 = __builtin_amdgcn_readfirstlane(ext[0]), y0 = __builtin_amdgcn_readfirstlane(ext[2]);
   const int nzp = __builtin_amdgcn_readfirstlane(ext[6]);
   const int nx = __builtin_amdgcn_readfirstlane(ext[1]) - x0 + 1, ny = __builtin_amdgcn_readfirstlane(ext[3]) - y0 + 1;
@@ -2677,6 +2684,8 @@ __global__ __launch_bounds__(kPlThreads, (PH_ > 8 ? 2 : 4)) void roi_align3d_fwd
     };
 
     __syncthreads();                                           // the weight table
+    FOLD_MARK(3);
+    FOLD_NOTE(10, nx); FOLD_NOTE(11, ny); FOLD_NOTE(12, nzp);
     for (int yb = 0; yb < ny && nzp > 0; yb += kFoldRows) {
       const int nrows = min(kFoldRows, ny - yb);
       if (yb) __syncthreads();                                 // the previous pass's phase B is done with Vt
@@ -2699,7 +2708,9 @@ __global__ __launch_bounds__(kPlThreads, (PH_ > 8 ? 2 : 4)) void roi_align3d_fwd
           *reinterpret_cast<float4 *>(d + q * 4) = v;
         }
       }
+      FOLD_MARK(4);
       __syncthreads();
+      FOLD_MARK(5);
       // phase B: the 2 NS taps of each of the wave's pooled rows that fall into this pass
 #pragma unroll
       for (int j = 0; j < PHW; ++j) {
@@ -2724,6 +2735,7 @@ __global__ __launch_bounds__(kPlThreads, (PH_ > 8 ? 2 : 4)) void roi_align3d_fwd
         }
       }
     }
+    FOLD_MARK(6);
     __syncthreads();                                           // every wave is done with Vt: the output tile takes its place
 #pragma unroll
     for (int j = 0; j < PHW; ++j) {
@@ -2742,6 +2754,7 @@ __global__ __launch_bounds__(kPlThreads, (PH_ > 8 ? 2 : 4)) void roi_align3d_fwd
     }
   }
   __syncthreads();
+  FOLD_MARK(7);
   // ---- the output tile: LDS [channel][ph][PWP] -> 8-byte pieces of consecutive bins
   const int B = PD * PH_ * PW_;
   float *obase = out + ((size_t)r * C + c0) * B + pd * PH_ * PW_;
@@ -2757,6 +2770,11 @@ __global__ __launch_bounds__(kPlThreads, (PH_ > 8 ? 2 : 4)) void roi_align3d_fwd
       else d[0] = s[0];
     }
   }
+  FOLD_MARK(8);
+#ifdef MR3D_ROWS_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  FOLD_MARK(9);
+#endif
 }
 
 template <int PH_, int PW_, int NS, int ROWS>
