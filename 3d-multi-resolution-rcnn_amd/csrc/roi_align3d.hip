@@ -2497,6 +2497,12 @@ int launch_bwd_planes(const float *top, float *bottom, const float *rois, int nu
 // kFoldRows voxel rows take several passes (the accumulators stay in registers); the sum order is fixed by the RoI alone.
 // The row-streaming kernel above multiplies every voxel row of every plane (two MFMA products with padded K); the owner-wave
 // form read a row once per wave whose pooled rows reach it.
+// Phase stamps (tools/diag/roi_fold_stamps.py, SURVEY 8(d) rois; median / max per workgroup): roi + planes 1.7, samples 0.3, x table 0.6,
+// phase A 2.9 / 16.4, phase B 1.2 (mask 2.4), tile + stores 1.3 (mask 2.1) -- lifetime 8.5 / 21.6 us (mask 10.2 / 24.6): a wave issues one
+// instruction per ~4.5 cycles and there are two or three waves per SIMD.  Measured and not kept: two row pieces per step when the
+// pooled depth has two planes (half the memory round trips of the mask extractor: phase A 2.68 -> 2.58 us -- the step is issue-bound,
+// 64 load slots + fold + 11 instructions per voxel -- and 164 -> 239 registers); the four taps of a pooled row read together in
+// phase B (2.36 -> 2.48 us).
 // ------------------------------------------------------------------------------------------
 
 template <int PH_, int PW_, int NS, int ROWS>
