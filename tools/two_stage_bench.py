@@ -44,8 +44,12 @@ def main():
     ap.add_argument('--host-profile', action='store_true', help='cProfile of the host side of 5 steps + enqueue time per step')
     ap.add_argument('--bf16', action='store_true', help='BASELINE configs[4]: bf16 activation storage in backbone + FPN')
     ap.add_argument('--dcn-neck', action='store_true', help='BASELINE configs[4]: DeformConv3d in place of the FPN output convs')
+    ap.add_argument('--tune', default='', help='key=value pairs for mr3d_tuning_set, e.g. 7=1 (round-5 RoIAlign3D kernels)')
     a = ap.parse_args()
     D, H, W = (int(v) for v in a.vol.split(','))
+    from mr3d_amd import _hip as _h
+    for kv in filter(None, a.tune.split(',')):
+        _h.lib().mr3d_tuning_set(*(int(v) for v in kv.split('=')))
     dev = torch.device('cuda:0')
     torch.manual_seed(0)
     kw = dict(dtype=torch.bfloat16 if a.bf16 else torch.float32, neck_dcn=a.dcn_neck)
