@@ -541,6 +541,9 @@ int dispatch_tile(const Conv3dFwdArgs &a, hipStream_t stream) {
   } else {
     using T2 = FwdCfg<K, K, K, SD, SH, SW, 2, 4, 8, CC, NB>;
     if (wgs(2, 8, 8) >= 512) return launch_fwd<T1>(a, stream);
+    // (round 6: 32 input channels per chunk for the 3x3x3 convolutions of layer3 / layer4 -- 87 KB of LDS, half the chunk passes --
+    //  measured: layer3 64 -> 64 on 10x32x32 33 -> 47 us (one workgroup per CU instead of two or three), layer4 128 -> 128 on 5x16x16
+    //  30 -> 30 us: the chunk passes are not what these launches wait for; a wave's 432 / 864 dependent MFMA steps at ~80 cycles each are)
     return launch_fwd<T2>(a, stream);
   }
 }
