@@ -97,6 +97,9 @@ __device__ __forceinline__ int nearest_src(int dst, int in, int out) {
   return s < in - 1 ? s : in - 1;
 }
 
+#ifndef MR3D_FWD_ABL
+#define MR3D_FWD_ABL 0                                       // timing-only ablations of the small-tile path (tools/diag/fwd_abl.sh); 0 in the library
+#endif
 template <class C>
 __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_fwd_kernel(Conv3dFwdArgs p, int tiles_d, int tiles_h, int tiles_w) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -157,6 +160,7 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_fwd_kernel(Conv3dFw
   constexpr int NWV = C::BLDS ? (WQ + kThreads - 1) / kThreads : 1;
   float4 wstage[NWV];
   auto fetch = [&](int c0) {
+    if (MR3D_FWD_ABL & 4) return;
     if constexpr (C::BLDS) {
 #pragma unroll
       for (int j = 0; j < NWV; ++j) {
@@ -296,7 +300,7 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_fwd_kernel(Conv3dFw
 #pragma unroll
     for (int j = 0; j < NIT; ++j) {
       const int it = tid + j * kThreads;
-      if (it < C::HP * Q) {
+      if (it < C::HP * Q && !(MR3D_FWD_ABL & 2)) {
         const int pos = it / Q, q = it - pos * Q;
         float *d = lds + pos * C::ROW + q * 4;
         d[0] = stage[j].x; d[1] = stage[j].y; d[2] = stage[j].z; d[3] = stage[j].w;
@@ -306,7 +310,7 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_fwd_kernel(Conv3dFw
 #pragma unroll
       for (int j = 0; j < NWV; ++j) {
         const int e = tid + j * kThreads;
-        if (e < WQ) *reinterpret_cast<float4 *>(wl + e * 4) = wstage[j];
+        if (e < WQ && !(MR3D_FWD_ABL & 2)) *reinterpret_cast<float4 *>(wl + e * 4) = wstage[j];
       }
     }
     __syncthreads();
@@ -315,27 +319,61 @@ __global__ __launch_bounds__(kThreads, C::MINWG) void conv3d_fwd_kernel(Conv3dFw
     }
 
     if constexpr (C::BLDS) {
-      // ---- K loop with both operands in LDS
-      for (int kd = 0; kd < nkd; ++kd)
-        for (int kh = 0; kh < nkh; ++kh)
+      // ---- K loop with both operands in LDS.  The operand pairs of a tap row (kW taps x KK k-steps) are read ONE ROW AHEAD into a second
+      // register set (round 6): written as `a = lds[..]; mfma(a, b)` the compiler kept every A fragment in the same register pair, so
+      // each pair of MFMAs waited for its own LDS read -- ~80 cycles per 32-cycle MFMA with the one or two waves per SIMD these
+      // launches have (layer3 / layer4 / P4 / P5: 64-position tiles).
+      static_assert(C::MT == 1, "64-row tiles: one MFMA tile per wave");
+      float a0[RT][C::KK], b0[RT][C::KK], a1[RT][C::KK], b1[RT][C::KK];
+      auto ld = [&](float (&av)[RT][C::KK], float (&bv)[RT][C::KK], int kd, int kh) {
+        if (MR3D_FWD_ABL & 8) {
 #pragma unroll
           for (int t = 0; t < RT; ++t)
-            if (t < nrt) {
-              const int tapoff = ((kd * C::HH + kh) * C::HW + t) * C::ROW;
-              const float *wt = wl + (wtap(kd, kh, t) * C::CC + lk) * C::NB + wave_n * C::TM + li;
 #pragma unroll
-              for (int kk = 0; kk < C::KK; ++kk) {
-                const float b = wt[kk * C::KSTEP * C::NB];
+            for (int kk = 0; kk < C::KK; ++kk) { av[t][kk] = (float)(kd + t); bv[t][kk] = (float)(kh + kk); }
+          return;
+        }
 #pragma unroll
-                for (int mt = 0; mt < C::MT; ++mt) {
-                  const float a = lds[abase[mt] + tapoff + kk * C::KSTEP];
-                  if constexpr (C::k16)
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[mt], 0, 0, 0);
-                  else
-                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mt], 0, 0, 0);
-                }
-              }
+        for (int t = 0; t < RT; ++t)
+          if (t < nrt) {
+            const int tapoff = ((kd * C::HH + kh) * C::HW + t) * C::ROW;
+            const float *wt = wl + (wtap(kd, kh, t) * C::CC + lk) * C::NB + wave_n * C::TM + li;
+#pragma unroll
+            for (int kk = 0; kk < C::KK; ++kk) {
+              bv[t][kk] = wt[kk * C::KSTEP * C::NB];
+              av[t][kk] = lds[abase[0] + tapoff + kk * C::KSTEP];
             }
+          }
+      };
+      auto mm = [&](const float (&av)[RT][C::KK], const float (&bv)[RT][C::KK]) {
+        if (MR3D_FWD_ABL & 1) { acc[0][0] += av[0][0] * bv[0][0]; return; }
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+          if (t < nrt) {
+#pragma unroll
+            for (int kk = 0; kk < C::KK; ++kk) {
+              if constexpr (C::k16)
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][kk], bv[t][kk], acc[0], 0, 0, 0);
+              else
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t][kk], bv[t][kk], acc[0], 0, 0, 0);
+            }
+          }
+      };
+      int kd = 0, kh = 0;
+      auto next = [&]() { if (++kh == nkh) { kh = 0; ++kd; } };
+      ld(a0, b0, 0, 0);
+      int row = 0;
+      for (; row + 1 < nrows; row += 2) {
+        next();
+        ld(a1, b1, kd, kh);
+        __builtin_amdgcn_sched_barrier(0);                     // the next row's reads are in flight under this row's MFMAs
+        mm(a0, b0);
+        next();
+        if (row + 2 < nrows) ld(a0, b0, kd, kh);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(a1, b1);
+      }
+      if (row < nrows) mm(a0, b0);
       continue;
     }
 
