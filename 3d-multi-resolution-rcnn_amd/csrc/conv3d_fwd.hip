@@ -579,9 +579,14 @@ int dispatch_tile(const Conv3dFwdArgs &a, hipStream_t stream) {
   } else {
     using T2 = FwdCfg<K, K, K, SD, SH, SW, 2, 4, 8, CC, NB>;
     if (wgs(2, 8, 8) >= 512) return launch_fwd<T1>(a, stream);
-    // (round 6: 32 input channels per chunk for the 3x3x3 convolutions of layer3 / layer4 -- 87 KB of LDS, half the chunk passes --
-    //  measured: layer3 64 -> 64 on 10x32x32 33 -> 47 us (one workgroup per CU instead of two or three), layer4 128 -> 128 on 5x16x16
-    //  30 -> 30 us: the chunk passes are not what these launches wait for; a wave's 432 / 864 dependent MFMA steps at ~80 cycles each are)
+    // Round 6, what the 3x3x3 launches of layer3 (10x32x32, 64 -> 64: 640 workgroups) and layer4 (5x16x16, 128 -> 128: 160) wait for,
+    // by timing-only ablations (tools/diag/fwd_abl.sh; back-to-back launches through ctypes cost 13 us each with an empty kernel):
+    // 34 / 27 us as built; without the MFMAs 14 / 13; without the LDS staging writes and the global fetch 28 / 21; without the LDS
+    // operand reads 29 / 22.  A wave's 432 / 864 MFMAs are 14.4 / 11.5 us of matrix-pipe time per SIMD (2.5 / 1 waves per SIMD): these
+    // launches run at 72-82 % of the direct form's MFMA time plus the launch skeleton.  32 input channels per chunk (87 KB of LDS, half
+    // the chunk passes) was measured too: layer3 33 -> 47 us (one workgroup per CU), layer4 30 -> 30.  Fewer multiplies would need
+    // a Winograd form on 16-wide Cout tiles, whose input transform is then formed four times (9.6 vector instructions per MFMA in
+    // conv3d_wino2d_rows_kernel<1>): not built.
     return launch_fwd<T2>(a, stream);
   }
 }
