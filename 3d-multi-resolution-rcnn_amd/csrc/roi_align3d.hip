@@ -2821,7 +2821,9 @@ int try_bwd_wave(const float *top, float *bottom, const float *rois, int num_roi
   // Plane-owner kernel, K = planes in flight per RoI (SURVEY 8(d) inputs, launch alone): mask extractor (10,14,14) x 128 rois
   // K = 1 / 2 / 4 / 8 / 12 / 16: 96.7 / 52.9 / 33.7 / 31.9 / 32.3 / 33.9 us (roi_align3d_bwd_wave<2,4,14,2>: 87.6); bbox extractor
   // (3,7,7) x 512 rois K = 2 / 8 / 12 / 16: 50.0 / 43.0 / 45.1 / 47.7 us (voxel-owner kernel: 74.0).  MR3D_TUNE_ROIALIGN_FORM = 1
-  // keeps the round-5 kernels.
+  // keeps the round-5 kernels.  Splitting a RoI's pooled rows over 2 / 4 workgroups as well (each holds a slice of U and adds the voxel
+  // rows its pooled rows reach; 30 KB of LDS, three per CU) was measured on the mask extractor: (slices, K) = (1,8) 36.4, (2,8) 34.8,
+  // (2,4) 34.1, (4,4) 42.0, (4,2) 43.9 us on one box -- not kept.
   if (PD <= kPlPdMax && g_mr3d_tuning[MR3D_TUNE_ROIALIGN_FORM] != 1) {
     if (PW == 14 && PH == 14) return launch_bwd_planes<14, 14, 2>(top, bottom, rois, num_rois, scale, scale_d, C, D, H, W, PD, 8, bug, lt, stream);
     if (PW == 7 && PH == 7) return launch_bwd_planes<7, 7, 2>(top, bottom, rois, num_rois, scale, scale_d, C, D, H, W, PD, 8, bug, lt, stream);
