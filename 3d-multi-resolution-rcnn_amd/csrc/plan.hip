@@ -314,8 +314,10 @@ int plan_run_impl(const mr3d_op *ops, int num_ops, int *failed_index, mr3d_strea
     }
     const bool on_side = use_side && wants_side(ops[k]);
     bool on_second = false;
-    // (fp32 records only: the bf16 backbone step measured 5.50 ms on one side queue, 5.57 on two -- its queue has slack)
-    if (on_side && two_side_queues && ops[k].kind == MR3D_OP_CONV_WGRAD && ops[k].i[25] != MR3D_DTYPE_BF16) {
+    // (the bf16 backbone step measured 5.50 ms on one side queue and 5.57 on two in round 4 -- its queue had slack; at 4.3 ms it ends
+    //  with the side queue's last weight gradients: MR3D_TUNE_BF16_ONE_SIDE_QUEUE)
+    if (on_side && two_side_queues && ops[k].kind == MR3D_OP_CONV_WGRAD &&
+        (ops[k].i[25] != MR3D_DTYPE_BF16 || g_mr3d_tuning[MR3D_TUNE_BF16_ONE_SIDE_QUEUE] == 0)) {
       // records that accumulate into the SAME dw must stay on one queue (the first queue may reduce a lent partial-sum workspace
       // into dw without atomics, the second adds atomically: two queues on one dw would race) -- e.g. the RPN head's five
       // levels share dw1 / dw3.  A new dw takes the queues in turn.

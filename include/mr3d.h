@@ -73,6 +73,8 @@ enum {
                                      1-4) instead of the early bucket in the middle of it (the exchange then overlaps only the stem weight gradient) */
   MR3D_TUNE_FPN_AFTER_LATERALS = 9, /* read when a plan is built: 1 = the P3..P5 output convolutions are queued behind ALL lateral convolutions
                                      (rounds 3-4) instead of right behind their own lateral */
+  MR3D_TUNE_BF16_ONE_SIDE_QUEUE = 10, /* plan executor: 1 = the bf16 weight-gradient records stay on ONE side queue (rounds 4-5: the 5.5 ms bf16 step
+                                     had slack there); 0 = they alternate between the two side queues like the fp32 ones */
   MR3D_TUNE_NUM_KEYS = 16
 };
 void mr3d_tuning_set(int key, int value);
