@@ -2502,7 +2502,8 @@ int launch_bwd_planes(const float *top, float *bottom, const float *rois, int nu
 // instruction per ~4.5 cycles and there are two or three waves per SIMD.  Measured and not kept: two row pieces per step when the
 // pooled depth has two planes (half the memory round trips of the mask extractor: phase A 2.68 -> 2.58 us -- the step is issue-bound,
 // 64 load slots + fold + 11 instructions per voxel -- and 164 -> 239 registers); the four taps of a pooled row read together in
-// phase B (2.36 -> 2.48 us).
+// phase B (2.36 -> 2.48 us); the voxels of the NEXT row piece requested before the current one is multiplied (two register sets of
+// 4 planes x 8 voxels, ping-pong: phase A 2.9 -> 2.96 us median, 16.4 -> 15.4 max; launch 33.9 -> 34.5 / 51 -> 56 us).
 // ------------------------------------------------------------------------------------------
 
 template <int PH_, int PW_, int NS, int ROWS>
