@@ -249,7 +249,7 @@ def test_roi_align3d_row_streaming_forward_paths(dev, P, form):
     np.testing.assert_allclose(out.cpu().numpy(), exp, rtol=RTOL, atol=2e-5 * np.abs(exp).max())
 
 
-@pytest.mark.parametrize('P', [(3, 7, 7), (10, 14, 14), (16, 14, 14)])
+@pytest.mark.parametrize('P', [(3, 7, 7), (10, 14, 14), (16, 14, 14), (17, 14, 14)])     # (pooled depth 17: beyond the kernel, the round-5 one takes it)
 @pytest.mark.parametrize('form', [0, 1])
 def test_roi_align3d_plane_owner_backward_paths(dev, P, form):
     """the plane-owner backward (round 6, roi_align3d_bwd_planes) against the oracle on the footprints that take its different paths:
