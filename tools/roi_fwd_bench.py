@@ -39,6 +39,7 @@ def main():
     ap.add_argument('--backward', action='store_true', help='also time forward + backward (fp32 features)')
     ap.add_argument('--tune', default='', help='key=value pairs for mr3d_tuning_set, e.g. 4=1 (box forward without the RoI split)')
     ap.add_argument('--nrois', type=int, default=0, help='use only the first n rois of each case')
+    ap.add_argument('--sort', default='', help="'desc' / 'asc': hand the rois over ordered by the voxel area of their footprint at their own level")
     ap.add_argument('--sizes', default='', help='xy_lo,xy_hi,z_lo,z_hi in pixels: log-uniform roi sizes instead of the SURVEY 8(d) ranges')
     a = ap.parse_args()
     dev = torch.device('cuda:0')
@@ -64,6 +65,12 @@ def main():
         if a.nrois:
             r_host = r_host[:a.nrois]
             n = len(r_host)
+        if a.sort:
+            wv, hv, dv = r_host[:, 3] - r_host[:, 1] + 1, r_host[:, 4] - r_host[:, 2] + 1, r_host[:, 6] - r_host[:, 5] + 1
+            lvl = np.clip(np.floor(np.log2(np.sqrt(wv * hv * dv) / 56 + 1e-6)), 0, 3)
+            area = (wv / (4 * 2 ** lvl) + 2) * (hv / (4 * 2 ** lvl) + 2)
+            order = np.argsort(-area if a.sort == 'desc' else area, kind='stable')
+            r_host = np.ascontiguousarray(r_host[order])
         r = torch.from_numpy(r_host).to(dev)
         us = timed(lambda: ext(feats, r))
         lb, wr, rd = bench.roialign_lb_bytes(r_host, 64, od, osz, osz)
