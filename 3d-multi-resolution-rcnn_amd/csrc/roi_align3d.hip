@@ -2467,18 +2467,27 @@ __global__ __launch_bounds__(kPlThreads) void roi_align3d_bwd_planes(const float
   }
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: one attempt per (kernel, device), up to 16
+// devices in one process (a 17th takes the attempt on every call)
+template <class K>
+bool raise_lds_limit(K kernel, int bytes) {
+  static std::mutex mu;
+  static signed char state[16] = {};                           // 0 not tried, 1 set, -1 refused
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+  std::lock_guard<std::mutex> lock(mu);
+  if (dev >= 0 && dev < 16 && state[dev]) return state[dev] > 0;
+  const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+  if (!ok) (void)hipGetLastError();
+  if (dev >= 0 && dev < 16) state[dev] = ok ? 1 : -1;
+  return ok;
+}
+
 template <int PH_, int PW_, int NS>
 int launch_bwd_planes(const float *top, float *bottom, const float *rois, int num_rois, float scale, float scale_d, int C, int D, int H, int W,
                       int PD, int K, int bug, const LevelTable &lt, hipStream_t stream) {
   using S = PlCfg<PH_, PW_, NS>;
-  static std::once_flag once;
-  static bool ok = false;
-  std::call_once(once, [] {
-    ok = hipFuncSetAttribute(reinterpret_cast<const void *>(roi_align3d_bwd_planes<PH_, PW_, NS>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             S::LDS_BYTES) == hipSuccess;
-    if (!ok) (void)hipGetLastError();
-  });
-  if (!ok) return MR3D_ERR_LAUNCH;
+  if (!raise_lds_limit(roi_align3d_bwd_planes<PH_, PW_, NS>, S::LDS_BYTES)) return MR3D_ERR_LAUNCH;
   const dim3 grid(num_rois, C / 64, K);
   roi_align3d_bwd_planes<PH_, PW_, NS><<<grid, kPlThreads, S::LDS_BYTES, stream>>>(top, bottom, rois, scale, scale_d, C, D, H, W, PD, K, bug, lt);
   return mr3d_launch_status();
@@ -2788,14 +2797,7 @@ template <int PH_, int PW_, int NS, int ROWS>
 int launch_fwd_fold(const float *feat, float *out, const float *rois, int num_rois, float scale, float scale_d, int C, int D, int H, int W, int PD,
                     const LevelTable &lt, hipStream_t stream) {
   using Fc = FoldCfg<PH_, PW_, NS, ROWS>;
-  static std::once_flag once;
-  static bool ok = false;
-  std::call_once(once, [] {
-    ok = hipFuncSetAttribute(reinterpret_cast<const void *>(roi_align3d_fwd_fold<PH_, PW_, NS, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             Fc::LDS_BYTES) == hipSuccess;
-    if (!ok) (void)hipGetLastError();
-  });
-  if (!ok) return MR3D_ERR_LAUNCH;
+  if (!raise_lds_limit(roi_align3d_fwd_fold<PH_, PW_, NS, ROWS>, Fc::LDS_BYTES)) return MR3D_ERR_LAUNCH;
   const dim3 grid(num_rois, C / 64, PD);
   roi_align3d_fwd_fold<PH_, PW_, NS, ROWS><<<grid, kPlThreads, Fc::LDS_BYTES, stream>>>(feat, out, rois, scale, scale_d, C, D, H, W, PD, lt);
   return mr3d_launch_status();
