@@ -1869,7 +1869,7 @@ int try_fwd_rows(const float *feat, float *out, const float *rois, int num_rois,
   // a (RoI, pooled depth) unit of the mask extractor is ~9 voxel rows x 2 planes of work under the same set-up, four barriers and a
   // 50 KB output tile that keeps it at two workgroups per CU).  Default: folded for (.,7,7), row streaming for (.,14,14);
   // MR3D_TUNE_ROIALIGN_FORM = 2: row streaming for both, 8: folded for both, 4 / 5 / 6: the row-streaming instances below.
-  if ((form == 0 && PW == 7 && PH == 7) || form == 8 || form == 9) {
+  if ((form == 0 && PW == 7 && PH == 7) || form == 8) {
     const int sto = try_fwd_fold(feat, out, rois, num_rois, scale, scale_d, C, D, H, W, PD, PH, PW, lt, stream);
     if (sto != MR3D_ERR_UNSUPPORTED) return sto;
   }
@@ -2512,43 +2512,36 @@ int launch_bwd_planes(const float *top, float *bottom, const float *rois, int nu
 // pooled depth has two planes (half the memory round trips of the mask extractor: phase A 2.68 -> 2.58 us -- the step is issue-bound,
 // 64 load slots + fold + 11 instructions per voxel -- and 164 -> 239 registers); the four taps of a pooled row read together in
 // phase B (2.36 -> 2.48 us); the voxels of the NEXT row piece requested before the current one is multiplied (two register sets of
-// 4 planes x 8 voxels, ping-pong: phase A 2.9 -> 2.96 us median, 16.4 -> 15.4 max; launch 33.9 -> 34.5 / 51 -> 56 us).
+// 4 planes x 8 voxels, ping-pong: phase A 2.9 -> 2.96 us median, 16.4 -> 15.4 max; launch 33.9 -> 34.5 / 51 -> 56 us); for the
+// (.,14,14) shape three workgroups per CU instead of two (46 KB of LDS: Vt rows of 16 floats with the quads of a channel rotated
+// by channel / 4, the output tile in two halves of eight pooled rows, a 64-column weight table): 53.8 -> 51.2 us, roi_align3d_fwd_rows 49.9.
 // ------------------------------------------------------------------------------------------
 
-// SLIM (the (.,14,14) shape: 46 KB instead of 70, three workgroups per CU): Vt rows of 16 floats with the four 16-byte quads of a
-// channel rotated by (channel / 4) -- the 16 lanes of a ds_*_b128 pass still cover the 64 banks -- instead of a 20-float pitch; the
-// output tile in two halves of eight pooled rows; a 64-column weight table (wider footprints take the bin-by-bin path)
-template <int PH_, int PW_, int NS, int ROWS, bool SLIM>
+template <int PH_, int PW_, int NS, int ROWS>
 struct FoldCfg {
   static constexpr int kFoldRows = ROWS;
   using P = PlCfg<PH_, PW_, NS>;
   static constexpr int PWP = P::PWP;
-  static_assert(!SLIM || PWP == 16, "the rotation is over four quads");
-  static constexpr int VP = SLIM ? 16 : (((PWP / 4) % 2 == 0) ? PWP + 4 : PWP);   // floats per (row, channel) of Vt: VP / 4 odd, or rotated quads
-  static constexpr int NH = SLIM ? 2 : 1;                      // output tiles per workgroup
-  static constexpr int PHH = SLIM ? 8 : PH_;                   // pooled rows per output tile
-  static constexpr int RSU0 = PHH * PWP;
-  static constexpr int RSU = ((RSU0 / 4) % 2 == 0) ? RSU0 + 4 : RSU0;          // floats per channel of an output tile
-  static constexpr int XCAP = SLIM ? 64 : kPlXCap;             // columns of the dense x-weight table
-  static constexpr int UNION = (kFoldRows * 64 * VP > 64 * RSU) ? kFoldRows * 64 * VP : 64 * RSU;
-  static constexpr int FLOATS = UNION + XCAP * PWP;
+  static constexpr int VP = ((PWP / 4) % 2 == 0) ? PWP + 4 : PWP;              // floats per (row, channel) of Vt: VP / 4 odd
+  static constexpr int UNION = (kFoldRows * 64 * VP > 64 * P::RS) ? kFoldRows * 64 * VP : 64 * P::RS;
+  static constexpr int FLOATS = UNION + kPlXCap * PWP;
   static constexpr int LDS_BYTES = FLOATS * 4 + (P::NXS + P::NYS) * 16 + 64;
 };
 
-template <int PH_, int PW_, int NS, int ROWS, bool SLIM>
-__global__ __launch_bounds__(kPlThreads, (PH_ > 8 ? (SLIM ? 3 : 2) : 4)) void roi_align3d_fwd_fold(const float *feat, float *__restrict__ out,
+template <int PH_, int PW_, int NS, int ROWS>
+__global__ __launch_bounds__(kPlThreads, (PH_ > 8 ? 2 : 4)) void roi_align3d_fwd_fold(const float *feat, float *__restrict__ out,
                                                                                      const float *__restrict__ rois, float scale, float scale_d,
                                                                                      int C, int D, int H, int W, int PD, LevelTable lt) {
   using S = PlCfg<PH_, PW_, NS>;
-  using Fc = FoldCfg<PH_, PW_, NS, ROWS, SLIM>;
-  constexpr int kFoldRows = ROWS, XCAP = Fc::XCAP, RSU = Fc::RSU;
+  using Fc = FoldCfg<PH_, PW_, NS, ROWS>;
+  constexpr int kFoldRows = ROWS;
   constexpr int PWP = S::PWP, RS = S::RS, VEC = S::VEC, NXS = S::NXS, NYS = S::NYS, PER = S::PER, VP = Fc::VP;
   constexpr int PHW = (PH_ + 3) / 4, NZ = 2 * NS;
   extern __shared__ __attribute__((aligned(16))) float pl_lds[];
   float *U = pl_lds;                                           // [64 channels][RS]: the output tile ...
   float *Vt = pl_lds;                                          // ... and before it [kFoldRows][64 channels][VP]
-  float *wxt = pl_lds + Fc::UNION;                             // [XCAP][PWP]
-  IdxEntry *tabx = reinterpret_cast<IdxEntry *>(wxt + XCAP * PWP), *taby = tabx + NXS;
+  float *wxt = pl_lds + Fc::UNION;                             // [kPlXCap][PWP]
+  IdxEntry *tabx = reinterpret_cast<IdxEntry *>(wxt + kPlXCap * PWP), *taby = tabx + NXS;
   int *ext = reinterpret_cast<int *>(taby + NYS);              // x0, x1, y0, y1, -, -, planes | plane index x4 | plane weight x4
   int *zl = ext + 8;
   float *wzl = reinterpret_cast<float *>(ext + 12);
@@ -2619,18 +2612,38 @@ __global__ __launch_bounds__(kPlThreads, (PH_ > 8 ? (SLIM ? 3 : 2) : 4)) void ro
   const int nphw = min(PHW, PH_ - ph0);
   auto sf = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); };
 
-  const bool wide = nx > XCAP;                                 // a footprint wider than the weight table: bin by bin, tap by tap (below)
-  float T[PHW][PW_];
-#pragma unroll
-  for (int j = 0; j < PHW; ++j)
-#pragma unroll
-    for (int pw = 0; pw < PW_; ++pw) T[j][pw] = 0.f;
-  if (!wide) {
-    const int nxt = min((nx + 15) & ~15, XCAP);             // (the columns behind the row's end carry weight 0; kPlXCap % 16 == 0)
+  if (nx > kPlXCap) {
+    // a footprint wider than the weight table (a RoI of > 128 voxels along x of its level): bin by bin, tap by tap
+    for (int bin = wave; bin < PH_ * PW_; bin += kPlThreads / 64) {
+      const int ph = bin / PW_, pw = bin - ph * PW_;
+      float acc = 0.f;
+      for (int k = 0; k < nzp; ++k) {
+        const int z = zl[k];
+        for (int sy = 0; sy < 2 * NS; ++sy) {
+          const IdxEntry ty = taby[ph * NS + (sy >> 1)];
+          if (ty.lo < 0) continue;
+          const float wzy = wzl[k] * ((sy & 1) ? ty.l : ty.h);
+          const float *prow = fbase + ((size_t)z * H + ((sy & 1) ? ty.hi : ty.lo)) * W * C + lane;
+          for (int sx = 0; sx < 2 * NS; ++sx) {
+            const IdxEntry tx = tabx[pw * NS + (sx >> 1)];
+            if (tx.lo < 0) continue;
+            acc += wzy * ((sx & 1) ? tx.l : tx.h) * prow[(size_t)((sx & 1) ? tx.hi : tx.lo) * C];
+          }
+        }
+      }
+      U[lane * RS + ph * PWP + pw] = acc;
+    }
+  } else {
+    const int nxt = min((nx + 15) & ~15, kPlXCap);             // (the columns behind the row's end carry weight 0; kPlXCap % 16 == 0)
     for (int idx = tid; idx < nxt * PWP; idx += kPlThreads) {
       const int col = idx / PWP, a = idx - col * PWP;
       wxt[idx] = a < PW_ ? pl_axis_weight(tabx, a, x0 + col, NS) : 0.f;
     }
+    float T[PHW][PW_];
+#pragma unroll
+    for (int j = 0; j < PHW; ++j)
+#pragma unroll
+      for (int pw = 0; pw < PW_; ++pw) T[j][pw] = 0.f;
     const unsigned cstep = (unsigned)C * 4u, lane4 = (unsigned)lane * 4u;
     const int zq[NZ] = {__builtin_amdgcn_readfirstlane(zl[0]), __builtin_amdgcn_readfirstlane(zl[1]), __builtin_amdgcn_readfirstlane(zl[NZ > 2 ? 2 : 0]),
                         __builtin_amdgcn_readfirstlane(zl[NZ > 3 ? 3 : 0])};
@@ -2710,7 +2723,7 @@ __global__ __launch_bounds__(kPlThreads, (PH_ > 8 ? (SLIM ? 3 : 2) : 4)) void ro
           v.y = q * 4 + 1 < PW_ ? V[q * 4 + 1 < PW_ ? q * 4 + 1 : 0] : 0.f;
           v.z = q * 4 + 2 < PW_ ? V[q * 4 + 2 < PW_ ? q * 4 + 2 : 0] : 0.f;
           v.w = q * 4 + 3 < PW_ ? V[q * 4 + 3 < PW_ ? q * 4 + 3 : 0] : 0.f;
-          *reinterpret_cast<float4 *>(d + (SLIM ? ((q ^ (lane >> 2)) & 3) : q) * 4) = v;
+          *reinterpret_cast<float4 *>(d + q * 4) = v;
         }
       }
       FOLD_MARK(4);
@@ -2729,7 +2742,7 @@ __global__ __launch_bounds__(kPlThreads, (PH_ > 8 ? (SLIM ? 3 : 2) : 4)) void ro
               const float4 *s = reinterpret_cast<const float4 *>(Vt + (yy * 64 + lane) * VP);
 #pragma unroll
               for (int q = 0; q < PWP / 4; ++q) {
-                const float4 v4 = s[SLIM ? ((q ^ (lane >> 2)) & 3) : q];
+                const float4 v4 = s[q];
                 if (q * 4 < PW_) T[j][q * 4 < PW_ ? q * 4 : 0] += w * v4.x;
                 if (q * 4 + 1 < PW_) T[j][q * 4 + 1 < PW_ ? q * 4 + 1 : 0] += w * v4.y;
                 if (q * 4 + 2 < PW_) T[j][q * 4 + 2 < PW_ ? q * 4 + 2 : 0] += w * v4.z;
@@ -2741,70 +2754,40 @@ __global__ __launch_bounds__(kPlThreads, (PH_ > 8 ? (SLIM ? 3 : 2) : 4)) void ro
       }
     }
     FOLD_MARK(6);
+    __syncthreads();                                           // every wave is done with Vt: the output tile takes its place
+#pragma unroll
+    for (int j = 0; j < PHW; ++j) {
+      if (j < nphw) {
+        float *d = U + lane * RS + (ph0 + j) * PWP;
+#pragma unroll
+        for (int q = 0; q < PWP / 4; ++q) {
+          float4 v;
+          v.x = q * 4 < PW_ ? T[j][q * 4 < PW_ ? q * 4 : 0] : 0.f;
+          v.y = q * 4 + 1 < PW_ ? T[j][q * 4 + 1 < PW_ ? q * 4 + 1 : 0] : 0.f;
+          v.z = q * 4 + 2 < PW_ ? T[j][q * 4 + 2 < PW_ ? q * 4 + 2 : 0] : 0.f;
+          v.w = q * 4 + 3 < PW_ ? T[j][q * 4 + 3 < PW_ ? q * 4 + 3 : 0] : 0.f;
+          *reinterpret_cast<float4 *>(d + q * 4) = v;
+        }
+      }
+    }
   }
-  // ---- output: registers (or, for a footprint wider than the weight table, the bins formed tap by tap) -> an LDS tile
-  // [channel][pooled row of the tile][PWP] -> 8-byte pieces of consecutive bins; NH tiles of PHH pooled rows, one after the other
+  __syncthreads();
+  FOLD_MARK(7);
+  // ---- the output tile: LDS [channel][ph][PWP] -> 8-byte pieces of consecutive bins
   const int B = PD * PH_ * PW_;
   float *obase = out + ((size_t)r * C + c0) * B + pd * PH_ * PW_;
-  auto emit = [&](auto h_tag) {
-    constexpr int h = decltype(h_tag)::value;
-    constexpr int pa = h * Fc::PHH, np = (PH_ - pa < Fc::PHH) ? PH_ - pa : Fc::PHH;      // pooled rows [pa, pa + np) of this tile
-    constexpr int CHIh = np * S::ROWI, ITEMSh = 64 * CHIh, PERh = (ITEMSh + kPlThreads - 1) / kPlThreads;
-    __syncthreads();                                           // every wave is done with Vt / the previous tile has left
-    if (wide) {
-      for (int bin = wave; bin < np * PW_; bin += kPlThreads / 64) {
-        const int ph = pa + bin / PW_, pw = bin % PW_;
-        float acc = 0.f;
-        for (int k = 0; k < nzp; ++k) {
-          const int z = zl[k];
-          for (int sy = 0; sy < 2 * NS; ++sy) {
-            const IdxEntry ty = taby[ph * NS + (sy >> 1)];
-            if (ty.lo < 0) continue;
-            const float wzy = wzl[k] * ((sy & 1) ? ty.l : ty.h);
-            const float *prow = fbase + ((size_t)z * H + ((sy & 1) ? ty.hi : ty.lo)) * W * C + lane;
-            for (int sx = 0; sx < 2 * NS; ++sx) {
-              const IdxEntry tx = tabx[pw * NS + (sx >> 1)];
-              if (tx.lo < 0) continue;
-              acc += wzy * ((sx & 1) ? tx.l : tx.h) * prow[(size_t)((sx & 1) ? tx.hi : tx.lo) * C];
-            }
-          }
-        }
-        U[lane * RSU + (ph - pa) * PWP + pw] = acc;
-      }
-    } else {
 #pragma unroll
-      for (int j = 0; j < PHW; ++j) {
-        if (j < nphw && ph0 + j >= pa && ph0 + j < pa + np) {
-          float *d = U + lane * RSU + (ph0 + j - pa) * PWP;
-#pragma unroll
-          for (int q = 0; q < PWP / 4; ++q) {
-            float4 v;
-            v.x = q * 4 < PW_ ? T[j][q * 4 < PW_ ? q * 4 : 0] : 0.f;
-            v.y = q * 4 + 1 < PW_ ? T[j][q * 4 + 1 < PW_ ? q * 4 + 1 : 0] : 0.f;
-            v.z = q * 4 + 2 < PW_ ? T[j][q * 4 + 2 < PW_ ? q * 4 + 2 : 0] : 0.f;
-            v.w = q * 4 + 3 < PW_ ? T[j][q * 4 + 3 < PW_ ? q * 4 + 3 : 0] : 0.f;
-            *reinterpret_cast<float4 *>(d + q * 4) = v;
-          }
-        }
-      }
+  for (int i = 0; i < PER; ++i) {
+    const int item = tid + i * kPlThreads;
+    if ((PER * kPlThreads == S::ITEMS) || item < S::ITEMS) {
+      const int c = item / S::CHI, rem = item - c * S::CHI;
+      const int ph = rem / S::ROWI, j = rem - ph * S::ROWI;
+      const float *s = U + c * RS + ph * PWP + j * VEC;
+      float *d = obase + (size_t)c * B + rem * VEC;
+      if (VEC == 2) *reinterpret_cast<float2 *>(d) = *reinterpret_cast<const float2 *>(s);
+      else d[0] = s[0];
     }
-    __syncthreads();
-    if (h == 0) FOLD_MARK(7);
-#pragma unroll
-    for (int i = 0; i < PERh; ++i) {
-      const int item = tid + i * kPlThreads;
-      if ((PERh * kPlThreads == ITEMSh) || item < ITEMSh) {
-        const int c = item / CHIh, rem = item - c * CHIh;
-        const int ph = rem / S::ROWI, j = rem - ph * S::ROWI;
-        const float *sp = U + c * RSU + ph * PWP + j * VEC;
-        float *d = obase + (size_t)c * B + (pa * S::ROWI + rem) * VEC;
-        if (VEC == 2) *reinterpret_cast<float2 *>(d) = *reinterpret_cast<const float2 *>(sp);
-        else d[0] = sp[0];
-      }
-    }
-  };
-  emit(std::integral_constant<int, 0>{});
-  if constexpr (Fc::NH > 1) emit(std::integral_constant<int, 1>{});
+  }
   FOLD_MARK(8);
 #ifdef MR3D_ROWS_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2812,13 +2795,13 @@ __global__ __launch_bounds__(kPlThreads, (PH_ > 8 ? (SLIM ? 3 : 2) : 4)) void ro
 #endif
 }
 
-template <int PH_, int PW_, int NS, int ROWS, bool SLIM>
+template <int PH_, int PW_, int NS, int ROWS>
 int launch_fwd_fold(const float *feat, float *out, const float *rois, int num_rois, float scale, float scale_d, int C, int D, int H, int W, int PD,
                     const LevelTable &lt, hipStream_t stream) {
-  using Fc = FoldCfg<PH_, PW_, NS, ROWS, SLIM>;
-  if (!raise_lds_limit(roi_align3d_fwd_fold<PH_, PW_, NS, ROWS, SLIM>, Fc::LDS_BYTES)) return MR3D_ERR_LAUNCH;
+  using Fc = FoldCfg<PH_, PW_, NS, ROWS>;
+  if (!raise_lds_limit(roi_align3d_fwd_fold<PH_, PW_, NS, ROWS>, Fc::LDS_BYTES)) return MR3D_ERR_LAUNCH;
   const dim3 grid(num_rois, C / 64, PD);
-  roi_align3d_fwd_fold<PH_, PW_, NS, ROWS, SLIM><<<grid, kPlThreads, Fc::LDS_BYTES, stream>>>(feat, out, rois, scale, scale_d, C, D, H, W, PD, lt);
+  roi_align3d_fwd_fold<PH_, PW_, NS, ROWS><<<grid, kPlThreads, Fc::LDS_BYTES, stream>>>(feat, out, rois, scale, scale_d, C, D, H, W, PD, lt);
   return mr3d_launch_status();
 }
 
@@ -2826,11 +2809,8 @@ int try_fwd_fold(const float *feat, float *out, const float *rois, int num_rois,
                  int PH, int PW, const LevelTable &lt, hipStream_t stream) {
   // voxel rows per pass (SURVEY 8(d) rois, (3,7,7) x 512, kernel time): 8 / 10 / 12 / 16 rows = 34.7 / 33.3 / 32.8 / 34.4 us with two
   // piece widths; 30.5 us with the four (12 rows)
-  if (PW == 14 && PH == 14) {
-    if (g_mr3d_tuning[MR3D_TUNE_ROIALIGN_FORM] == 9) return launch_fwd_fold<14, 14, 2, 12, false>(feat, out, rois, num_rois, scale, scale_d, C, D, H, W, PD, lt, stream);
-    return launch_fwd_fold<14, 14, 2, 10, true>(feat, out, rois, num_rois, scale, scale_d, C, D, H, W, PD, lt, stream);
-  }
-  if (PW == 7 && PH == 7) return launch_fwd_fold<7, 7, 2, 12, false>(feat, out, rois, num_rois, scale, scale_d, C, D, H, W, PD, lt, stream);
+  if (PW == 14 && PH == 14) return launch_fwd_fold<14, 14, 2, 12>(feat, out, rois, num_rois, scale, scale_d, C, D, H, W, PD, lt, stream);
+  if (PW == 7 && PH == 7) return launch_fwd_fold<7, 7, 2, 12>(feat, out, rois, num_rois, scale, scale_d, C, D, H, W, PD, lt, stream);
   return MR3D_ERR_UNSUPPORTED;
 }
 

@@ -214,7 +214,7 @@ def test_roi_align3d_benchmark_shapes_properties(dev):
 
 
 @pytest.mark.parametrize('P', [(3, 7, 7), (10, 14, 14)])
-@pytest.mark.parametrize("form", [0, 1, 2, 4, 5, 6, 8, 9])
+@pytest.mark.parametrize("form", [0, 1, 2, 4, 5, 6, 8])
 def test_roi_align3d_row_streaming_forward_paths(dev, P, form):
     """the round-6 forward kernels (row streaming roi_align3d_fwd_rows; planes folded first roi_align3d_fwd_fold: form 0 takes it for
     (3,7,7), form 8 for both shapes, form 2 = row streaming for both) against the oracle on the row shapes that take their different
